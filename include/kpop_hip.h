@@ -1,0 +1,174 @@
+/*
+ * kpop_hip.h -- C ABI of libkpop_hip.so: KPop's count -> twist -> distance hot
+ * path on AMD MI355X (gfx950).
+ *
+ * The reference (PaoloRibeca/KPop) is pure OCaml and has no FFI of its own
+ * (SURVEY.md F1); these are the entry points an OCaml `ctypes`/stub binding
+ * would bind to replace the three OCaml call sites on the hot path.  Each
+ * entry point cites the reference code it replaces (file:line under the
+ * reference checkout).  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain C, no exceptions/callbacks across the boundary, no torch types;
+ *   - every function returns 0 on success or a negative kpop_status;
+ *     kpop_last_error() returns a thread-local message for the last failure;
+ *   - host entry points (kpop_*) take caller-owned host buffers and do
+ *     H2D / compute / D2H internally;
+ *   - device entry points (kpop_dev_*) take pointers that already live in HBM
+ *     plus a hipStream_t passed as void* (NULL = default stream); they only
+ *     enqueue work and never synchronise;
+ *   - call from one thread per process, from the PARENT process only (a HIP
+ *     context does not survive fork(); the reference's fork()ed workers at
+ *     lib/Twister.ml:90 are replaced wholesale, not per-worker);
+ *   - one process drives one GPU (kpop_init(device)); multi-GPU = one process
+ *     per GPU, reads sharded by the caller.
+ *
+ * k-mer encoding (declared by this repository, see kpop_amd/csrc/kmer.h; the
+ * reference keeps it in the absent BiOCamLib): A0 C1 G2 T3 either case,
+ * big-endian 2-bit packing, DNA-ds key = min(fwd, reverse complement), any
+ * other byte breaks the window.
+ */
+#ifndef KPOP_HIP_H
+#define KPOP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  KPOP_OK = 0,
+  KPOP_ERR_INVALID = -1,     /* bad argument */
+  KPOP_ERR_CAPACITY = -2,    /* caller buffer too small */
+  KPOP_ERR_UNSUPPORTED = -3, /* valid request the HIP path does not cover yet */
+  KPOP_ERR_HIP = -4,         /* HIP runtime error (no device, OOM, launch failure) */
+  KPOP_ERR_NOT_INIT = -5
+} kpop_status;
+
+/* bin/KPopCount.ml:66-82 (Content.t) */
+#define KPOP_DNA_DS 0
+#define KPOP_DNA_SS 1
+/* lib/Space.ml:140-143 (Distance.t) */
+#define KPOP_EUCLIDEAN 0
+#define KPOP_COSINE 1
+#define KPOP_MINKOWSKI 2
+/* lib/Space.ml:81-84 (Metric.t) */
+#define KPOP_METRIC_FLAT 0
+#define KPOP_METRIC_POWERS 1
+
+/* ---------------------------------------------------------------- runtime */
+int kpop_init(int device);          /* select the GPU this process drives */
+int kpop_shutdown(void);            /* release workspaces */
+int kpop_device_count(void);        /* >=0, or negative kpop_status */
+const char *kpop_last_error(void);
+const char *kpop_version(void);
+int kpop_synchronize(void *stream);
+
+/* plain device-memory helpers so a non-HIP host language can stage buffers */
+int kpop_dev_malloc(void **ptr, uint64_t bytes);
+int kpop_dev_free(void *ptr);
+int kpop_memcpy_h2d(void *dst, const void *src, uint64_t bytes);
+int kpop_memcpy_d2h(void *dst, const void *src, uint64_t bytes);
+int kpop_dev_memset(void *dst, int value, uint64_t bytes);
+
+/* ------------------------------------------------------------------ count
+ * Replaces the per-read loop of KMerCounter.compute, bin/KPopCount.ml:36-50:
+ *   KIH.iterc res read.seq (:38) + KIHF.iter dump (:46,:60) + KIHF.clear (:49).
+ * bases: concatenated, already linted sequences (read r = bases[offsets[r] ..
+ * offsets[r+1])).  per_read=1 is -L (one spectrum per read, :39-50); per_read=0
+ * is -l (one spectrum for all reads, :60).  Output: CSR of unique
+ * (hash, count), hashes ascending inside a spectrum (the reference's Hashtbl
+ * order is unspecified; consumers key by name).  out_offsets has n_reads+1
+ * entries (per_read=1) or 2 (per_read=0).  k: 1..30.  Integer, bit-exact.    */
+int kpop_count_reads(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, int k, int content,
+                     int per_read, uint64_t *out_hash, uint32_t *out_count, uint64_t *out_offsets,
+                     uint64_t out_capacity);
+
+/* ---------------------------------------------------------------- twister
+ * Device-resident twister: replaces Twister.t.twister (lib/Twister.ml:22-25)
+ * plus the inverted name->column Hashtbl (lib/Twister.ml:71-76).
+ * T_dims_major is the reference layout: n_dims rows (one Float.Array per
+ * dimension) of n_cols coefficients; col_hash[c] = hash of the k-mer naming
+ * column c (hex name parsed by the binding).  On device it is re-laid k-mer-
+ * major so one k-mer's coefficients are one contiguous row.                  */
+typedef struct kpop_twister kpop_twister;
+int kpop_twister_load(const double *T_dims_major, uint64_t n_cols, uint32_t n_dims, const uint64_t *col_hash,
+                      int k, kpop_twister **out);
+/* synthetic twister generated on device: columns = every
+   canonical (DNA-ds) / every (DNA-ss) k-mer ascending, coefficient(d,h) from
+   SplitMix64 -- bench/test tooling, same function as the oracle's.           */
+int kpop_twister_synth(uint64_t seed, int k, int content, uint32_t n_dims, kpop_twister **out);
+int kpop_twister_free(kpop_twister *tw);
+int kpop_twister_info(const kpop_twister *tw, uint64_t *n_cols, uint32_t *n_dims, int *k,
+                      uint64_t *device_bytes);
+
+/* ------------------------------------------------------------------ twist
+ * Replaces the worker closure of Twister.add_twisted_from_files,
+ * lib/Twister.ml:146-188: name->column lookup (:151), acc over found k-mers
+ * only (:158), duplicate k-mers summed (:160-163), normalise by acc when
+ * normalize && acc<>0 (:177-178), sparse mat-vec (:183).
+ * Spectra are CSR (hash, value) lines; out is n_spectra x n_dims row-major
+ * (the "transposed" product of :52,:190).                                    */
+int kpop_twist(const kpop_twister *tw, const uint64_t *hash, const double *value, const uint64_t *offsets,
+               uint32_t n_spectra, int normalize, double *out);
+
+/* Fused count -> twist (bin/KPopCount.ml:36-50 piped into lib/Twister.ml:146-188,
+ * the README.md:606 pipeline) without materialising text spectra.            */
+int kpop_count_twist(const kpop_twister *tw, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                     int content, int normalize, double *out);
+
+/* ----------------------------------------------------------------- metric
+ * Replaces Space.Distance.Metric.compute, lib/Space.ml:88-105 (called from
+ * Twister.get_metrics_vector, lib/Twister.ml:208-209).  O(n_dims) host code. */
+int kpop_metric_compute(int metric_kind, const double *inertia, uint32_t n_dims, double power_int,
+                        double threshold, double power_ext, double *out);
+
+/* --------------------------------------------------------------- distance
+ * Replaces Base.get_normalizations + Base.get_distance_rowwise,
+ * lib/Matrix.ml:42-76,191-266 (Space.Distance.compute, lib/Space.ml:182-205).
+ * out is r2 x r1 row-major: out[j*r1+i] = d(m1 row i, m2 row j) (:253).      */
+int kpop_distance_rowwise(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
+                          const double *metric, int kind, double p, int normalize, double *out);
+
+/* Replaces Matrix.summarize_rowwise + summarize_distance_matrix_row,
+ * lib/Matrix.ml:691-766,632-690: per m2 row the mean, sample sd, upper median
+ * and MAD of its r1 distances (out_stats r2 x 4), then the keep_at_most
+ * closest m1 rows, whole tie groups included (:648-649).  Neighbour outputs
+ * have a fixed stride max_neighbours per row; out_n[j] is the reference's
+ * eff_len (may exceed max_neighbours: entries beyond the stride are dropped).
+ * keep_at_most=0 means "all" (:723-726).  The r2 x r1 matrix is never formed. */
+int kpop_distance_summary(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
+                          const double *metric, int kind, double p, int normalize, uint32_t keep_at_most,
+                          uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
+                          double *out_dist, double *out_z);
+
+/* --------------------------------------------------- device-resident path
+ * Same operations on buffers already in HBM; enqueue only.                   */
+int kpop_dev_synth_reads(uint64_t seed, uint64_t n_reads, uint32_t read_len, uint64_t first_read,
+                         uint8_t *d_bases, uint64_t *d_offsets, void *stream);
+/* max_len = longest read in the batch (host knows it from the offsets) */
+int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bases, const uint64_t *d_offsets,
+                         uint32_t n_reads, uint32_t max_len, int content, int normalize, double *d_out,
+                         void *stream);
+int kpop_dev_twist(const kpop_twister *tw, const uint64_t *d_hash, const double *d_value,
+                   const uint64_t *d_offsets, uint32_t n_spectra, uint64_t max_lines, int normalize,
+                   double *d_out, void *stream);
+/* Distance workspace: row norms and the pre-normalised copies a/n_i, b/n_j of
+   both operands (the per-element divisions of lib/Matrix.ml:247-249, done once).
+   kpop_dev_distance_workspace_bytes gives the size d_work must have.          */
+uint64_t kpop_dev_distance_workspace_bytes(uint32_t r1, uint32_t r2, uint32_t n_dims);
+int kpop_dev_distance_rowwise(const double *d_m1, uint32_t r1, const double *d_m2, uint32_t r2,
+                              uint32_t n_dims, const double *d_metric, int kind, double p, int normalize,
+                              void *d_work, double *d_out, void *stream);
+int kpop_dev_distance_summary(const double *d_m1, uint32_t r1, const double *d_m2, uint32_t r2,
+                              uint32_t n_dims, const double *d_metric, int kind, double p, int normalize,
+                              uint32_t keep_at_most, uint32_t max_neighbours, void *d_work,
+                              double *d_out_stats, uint32_t *d_out_n, uint32_t *d_out_idx,
+                              double *d_out_dist, double *d_out_z, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

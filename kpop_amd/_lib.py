@@ -1,0 +1,86 @@
+"""ctypes binding of libkpop_hip.so -- the C ABI declared in include/kpop_hip.h.
+
+There is no CPU fallback: if the shared library is missing, or no GPU is
+visible when kpop_init() runs, the caller gets an exception.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkpop_hip.so")
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+f64p = C.POINTER(C.c_double)
+vp = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/kpop_hip.h one to one
+SIGNATURES = {
+    "kpop_init": (C.c_int, [C.c_int]),
+    "kpop_shutdown": (C.c_int, []),
+    "kpop_device_count": (C.c_int, []),
+    "kpop_last_error": (C.c_char_p, []),
+    "kpop_version": (C.c_char_p, []),
+    "kpop_synchronize": (C.c_int, [vp]),
+    "kpop_dev_malloc": (C.c_int, [C.POINTER(vp), C.c_uint64]),
+    "kpop_dev_free": (C.c_int, [vp]),
+    "kpop_memcpy_h2d": (C.c_int, [vp, vp, C.c_uint64]),
+    "kpop_memcpy_d2h": (C.c_int, [vp, vp, C.c_uint64]),
+    "kpop_dev_memset": (C.c_int, [vp, C.c_int, C.c_uint64]),
+    "kpop_count_reads": (C.c_int, [u8p, u64p, C.c_uint32, C.c_int, C.c_int, C.c_int, u64p, u32p, u64p,
+                                   C.c_uint64]),
+    "kpop_twister_load": (C.c_int, [f64p, C.c_uint64, C.c_uint32, u64p, C.c_int, C.POINTER(vp)]),
+    "kpop_twister_synth": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.POINTER(vp)]),
+    "kpop_twister_free": (C.c_int, [vp]),
+    "kpop_twister_info": (C.c_int, [vp, u64p, u32p, C.POINTER(C.c_int), u64p]),
+    "kpop_twist": (C.c_int, [vp, u64p, f64p, u64p, C.c_uint32, C.c_int, f64p]),
+    "kpop_count_twist": (C.c_int, [vp, u8p, u64p, C.c_uint32, C.c_int, C.c_int, f64p]),
+    "kpop_metric_compute": (C.c_int, [C.c_int, f64p, C.c_uint32, C.c_double, C.c_double, C.c_double, f64p]),
+    "kpop_distance_rowwise": (C.c_int, [f64p, C.c_uint32, f64p, C.c_uint32, C.c_uint32, f64p, C.c_int,
+                                        C.c_double, C.c_int, f64p]),
+    "kpop_distance_summary": (C.c_int, [f64p, C.c_uint32, f64p, C.c_uint32, C.c_uint32, f64p, C.c_int,
+                                        C.c_double, C.c_int, C.c_uint32, C.c_uint32, f64p, u32p, u32p, f64p,
+                                        f64p]),
+    "kpop_dev_synth_reads": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, vp, vp, vp]),
+    "kpop_dev_count_twist": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, vp]),
+    "kpop_dev_twist": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int, vp, vp]),
+    "kpop_dev_distance_workspace_bytes": (C.c_uint64, [C.c_uint32, C.c_uint32, C.c_uint32]),
+    "kpop_dev_distance_rowwise": (C.c_int, [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, C.c_int,
+                                            C.c_double, C.c_int, vp, vp, vp]),
+    "kpop_dev_distance_summary": (C.c_int, [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, C.c_int,
+                                            C.c_double, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp,
+                                            vp, vp]),
+}
+
+
+class KPopError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libkpop_hip: %s (status %d)" % (msg, code))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """dlopen libkpop_hip.so and declare every symbol of include/kpop_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C kpop_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise KPopError(rc, load().kpop_last_error().decode("utf-8", "replace"))

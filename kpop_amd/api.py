@@ -1,0 +1,243 @@
+"""Host-side mirror of the reference's hot-path interface, over the C ABI.
+
+Names follow the reference (PaoloRibeca/KPop):
+  count_reads        KMerCounter.compute            bin/KPopCount.ml:26-63
+  Twister            Twister.t + add_twisted_...    lib/Twister.ml:22-25,58-206
+  metric_compute     Space.Distance.Metric.compute  lib/Space.ml:88-105
+  distance_rowwise   Matrix.get_distance_rowwise    lib/Matrix.ml:191-266
+  distance_summary   Matrix.summarize_rowwise       lib/Matrix.ml:691-766
+
+Everything here is plumbing (numpy <-> pointers); the arithmetic runs in the
+HIP kernels of libkpop_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KPopError, check  # noqa: F401
+
+DNA_DS, DNA_SS = 0, 1
+EUCLIDEAN, COSINE, MINKOWSKI = 0, 1, 2
+METRIC_FLAT, METRIC_POWERS = 0, 1
+
+_DISTANCES = {"euclidean": EUCLIDEAN, "cosine": COSINE, "minkowski": MINKOWSKI}
+
+
+def _p(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _nz(a, dt):
+    """ctypes needs a valid pointer even for empty arrays."""
+    return a if a.size else np.zeros(1, dtype=dt)
+
+
+def init(device=0):
+    check(_lib.load().kpop_init(int(device)))
+
+
+def device_count():
+    n = _lib.load().kpop_device_count()
+    if n < 0:
+        check(n)
+    return n
+
+
+def parse_distance(name):
+    """Space.Distance.of_string, lib/Space.ml:208-225: 'euclidean' | 'cosine' | 'minkowski(p)'."""
+    if name in ("euclidean", "cosine"):
+        return _DISTANCES[name], 2.0
+    if name.startswith("minkowski(") and name.endswith(")"):
+        try:
+            p = float(name[len("minkowski("):-1])
+        except ValueError:
+            raise ValueError("Unknown_distance %r" % name)
+        if p < 0:
+            raise ValueError("Negative_power %r" % p)
+        return MINKOWSKI, p
+    raise ValueError("Unknown_distance %r" % name)
+
+
+# ------------------------------------------------------------------ count
+def count_reads(bases, offsets, k, content=DNA_DS, per_read=True, capacity=None):
+    """-> (hash u64[], count u32[], offsets u64[]) CSR of per-read spectra (-L) or one spectrum (-l)."""
+    bases = _c(bases, np.uint8)
+    offsets = _c(offsets, np.uint64)
+    n = len(offsets) - 1
+    if capacity is None:
+        capacity = int(offsets[-1] - offsets[0]) + 1 if n > 0 else 1
+    oh = np.empty(capacity, dtype=np.uint64)
+    oc = np.empty(capacity, dtype=np.uint32)
+    oo = np.zeros(n + 1 if per_read else 2, dtype=np.uint64)
+    bb = _nz(bases, np.uint8)
+    check(_lib.load().kpop_count_reads(_p(bb, C.c_uint8), _p(offsets, C.c_uint64), n, int(k), int(content),
+                                       1 if per_read else 0, _p(oh, C.c_uint64), _p(oc, C.c_uint32),
+                                       _p(oo, C.c_uint64), capacity))
+    t = int(oo[-1])
+    return oh[:t].copy(), oc[:t].copy(), oo
+
+
+# ---------------------------------------------------------------- twister
+class Twister:
+    """Device-resident twister (lib/Twister.ml:22-25 + the name->column table of :71-76)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def load(cls, T_dims_major, col_hash, k):
+        T = _c(T_dims_major, np.float64)
+        if T.ndim != 2:
+            raise ValueError("twister must be n_dims x n_cols")
+        n_dims, n_cols = T.shape
+        col_hash = _c(col_hash, np.uint64)
+        if len(col_hash) != n_cols:
+            raise ValueError("col_hash length %d <> n_cols %d" % (len(col_hash), n_cols))
+        h = C.c_void_p()
+        check(_lib.load().kpop_twister_load(_p(_nz(T, np.float64), C.c_double), n_cols, n_dims,
+                                            _p(_nz(col_hash, np.uint64), C.c_uint64), int(k), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def synth(cls, seed, k, n_dims, content=DNA_DS):
+        h = C.c_void_p()
+        check(_lib.load().kpop_twister_synth(int(seed), int(k), int(content), int(n_dims), C.byref(h)))
+        return cls(h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self):
+        n_cols, n_dims, k, nbytes = C.c_uint64(), C.c_uint32(), C.c_int(), C.c_uint64()
+        check(_lib.load().kpop_twister_info(self._h, C.byref(n_cols), C.byref(n_dims), C.byref(k),
+                                            C.byref(nbytes)))
+        return {"n_cols": n_cols.value, "n_dims": n_dims.value, "k": k.value, "device_bytes": nbytes.value}
+
+    def twist(self, hash_, value, offsets, normalize=True):
+        """Spectra (CSR of hash,value lines) -> twisted rows; lib/Twister.ml:146-188."""
+        hash_ = _c(hash_, np.uint64)
+        value = _c(value, np.float64)
+        offsets = _c(offsets, np.uint64)
+        n = len(offsets) - 1
+        out = np.zeros((n, self.info()["n_dims"]), dtype=np.float64)
+        check(_lib.load().kpop_twist(self._h, _p(_nz(hash_, np.uint64), C.c_uint64),
+                                     _p(_nz(value, np.float64), C.c_double), _p(offsets, C.c_uint64), n,
+                                     1 if normalize else 0, _p(_nz(out, np.float64), C.c_double)))
+        return out
+
+    def count_twist(self, bases, offsets, content=DNA_DS, normalize=True):
+        """Reads -> twisted rows, count and twist fused on the device."""
+        bases = _c(bases, np.uint8)
+        offsets = _c(offsets, np.uint64)
+        n = len(offsets) - 1
+        out = np.zeros((n, self.info()["n_dims"]), dtype=np.float64)
+        check(_lib.load().kpop_count_twist(self._h, _p(_nz(bases, np.uint8), C.c_uint8),
+                                           _p(offsets, C.c_uint64), n, int(content), 1 if normalize else 0,
+                                           _p(_nz(out, np.float64), C.c_double)))
+        return out
+
+    def free(self):
+        if self._h is not None and self._h.value:
+            _lib.load().kpop_twister_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# ----------------------------------------------------------------- metric
+def metric_compute(inertia, kind=METRIC_POWERS, power_int=1.0, threshold=1.0, power_ext=2.0):
+    """Default = powers(1,1,2), bin/KPopTwistDB.ml:92."""
+    inertia = _c(inertia, np.float64)
+    out = np.empty(len(inertia), dtype=np.float64)
+    check(_lib.load().kpop_metric_compute(int(kind), _p(_nz(inertia, np.float64), C.c_double), len(inertia),
+                                          power_int, threshold, power_ext, _p(_nz(out, np.float64), C.c_double)))
+    return out
+
+
+# --------------------------------------------------------------- distance
+def distance_rowwise(m1, m2, metric, kind=EUCLIDEAN, p=2.0, normalize=True):
+    """-> r2 x r1 matrix, rows = m2 (the file operand), cols = m1 (the register); lib/Matrix.ml:253,264-266."""
+    m1 = _c(m1, np.float64)
+    m2 = _c(m2, np.float64)
+    metric = _c(metric, np.float64)
+    if m1.shape[1] != m2.shape[1] or m1.shape[1] != len(metric):
+        raise ValueError("Incompatible_geometries")  # lib/Matrix.ml:193-194
+    r1, d = m1.shape
+    r2 = m2.shape[0]
+    out = np.zeros((r2, r1), dtype=np.float64)
+    check(_lib.load().kpop_distance_rowwise(_p(_nz(m1, np.float64), C.c_double), r1,
+                                            _p(_nz(m2, np.float64), C.c_double), r2, d,
+                                            _p(metric, C.c_double), int(kind), float(p), 1 if normalize else 0,
+                                            _p(_nz(out, np.float64), C.c_double)))
+    return out
+
+
+def distance_summary(m1, m2, metric, kind=EUCLIDEAN, p=2.0, normalize=True, keep_at_most=2,
+                     max_neighbours=None):
+    """-> stats (r2 x 4: mean, sd, median, MAD), n (r2), idx/dist/z (r2 x max_neighbours)."""
+    m1 = _c(m1, np.float64)
+    m2 = _c(m2, np.float64)
+    metric = _c(metric, np.float64)
+    if m1.shape[1] != m2.shape[1] or m1.shape[1] != len(metric):
+        raise ValueError("Incompatible_geometries")  # lib/Matrix.ml:698-699
+    r1, d = m1.shape
+    r2 = m2.shape[0]
+    if max_neighbours is None:
+        max_neighbours = r1 if not keep_at_most else min(r1, max(keep_at_most * 4, 8))
+    max_neighbours = max(int(max_neighbours), 1)
+    stats = np.zeros((r2, 4), dtype=np.float64)
+    n = np.zeros(r2, dtype=np.uint32)
+    idx = np.zeros((r2, max_neighbours), dtype=np.uint32)
+    dist = np.zeros((r2, max_neighbours), dtype=np.float64)
+    z = np.zeros((r2, max_neighbours), dtype=np.float64)
+    check(_lib.load().kpop_distance_summary(_p(_nz(m1, np.float64), C.c_double), r1,
+                                            _p(_nz(m2, np.float64), C.c_double), r2, d,
+                                            _p(metric, C.c_double), int(kind), float(p), 1 if normalize else 0,
+                                            int(keep_at_most or 0), max_neighbours,
+                                            _p(_nz(stats, np.float64), C.c_double), _p(_nz(n, np.uint32), C.c_uint32),
+                                            _p(_nz(idx, np.uint32), C.c_uint32), _p(_nz(dist, np.float64), C.c_double),
+                                            _p(_nz(z, np.float64), C.c_double)))
+    return stats, n, idx, dist, z
+
+
+# ------------------------------------------------- device-resident entry points
+def dev_synth_reads(seed, n_reads, read_len, d_bases, d_offsets, first_read=0, stream=0):
+    check(_lib.load().kpop_dev_synth_reads(int(seed), int(n_reads), int(read_len), int(first_read), d_bases,
+                                           d_offsets, stream))
+
+
+def dev_count_twist(tw, d_bases, d_offsets, n_reads, max_len, d_out, content=DNA_DS, normalize=True, stream=0):
+    check(_lib.load().kpop_dev_count_twist(tw.handle, d_bases, d_offsets, int(n_reads), int(max_len), int(content),
+                                           1 if normalize else 0, d_out, stream))
+
+
+def dev_twist(tw, d_hash, d_value, d_offsets, n_spectra, max_lines, d_out, normalize=True, stream=0):
+    check(_lib.load().kpop_dev_twist(tw.handle, d_hash, d_value, d_offsets, int(n_spectra), int(max_lines),
+                                     1 if normalize else 0, d_out, stream))
+
+
+def dev_distance_workspace_bytes(r1, r2, n_dims):
+    return int(_lib.load().kpop_dev_distance_workspace_bytes(int(r1), int(r2), int(n_dims)))
+
+
+def dev_distance_rowwise(d_m1, r1, d_m2, r2, n_dims, d_metric, d_work, d_out, kind=EUCLIDEAN, p=2.0,
+                         normalize=True, stream=0):
+    check(_lib.load().kpop_dev_distance_rowwise(d_m1, int(r1), d_m2, int(r2), int(n_dims), d_metric, int(kind),
+                                                float(p), 1 if normalize else 0, d_work, d_out, stream))
+
+
+def dev_distance_summary(d_m1, r1, d_m2, r2, n_dims, d_metric, d_work, d_stats, d_n, d_idx, d_dist, d_z,
+                         keep_at_most=2, max_neighbours=8, kind=EUCLIDEAN, p=2.0, normalize=True, stream=0):
+    check(_lib.load().kpop_dev_distance_summary(d_m1, int(r1), d_m2, int(r2), int(n_dims), d_metric, int(kind),
+                                                float(p), 1 if normalize else 0, int(keep_at_most or 0),
+                                                int(max_neighbours), d_work, d_stats, d_n, d_idx, d_dist, d_z, stream))

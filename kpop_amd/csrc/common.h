@@ -1,0 +1,77 @@
+// common.h -- error plumbing, launch helpers and the per-process context.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/kpop_hip.h"
+
+namespace kpop {
+
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+const char *get_error();
+
+#define KPOP_FAIL(code, ...)        \
+  do {                              \
+    ::kpop::set_error(__VA_ARGS__); \
+    return (code);                  \
+  } while (0)
+
+#define KPOP_HIP(expr)                                                                       \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      KPOP_FAIL(KPOP_ERR_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+#define KPOP_TRY(expr)     \
+  do {                     \
+    int _rc = (expr);      \
+    if (_rc != 0) return _rc; \
+  } while (0)
+
+#define KPOP_LAUNCH_CHECK() KPOP_HIP(hipGetLastError())
+
+struct Context {
+  bool initialised = false;
+  int device = -1;
+  int n_cus = 256;
+  size_t lds_per_block = 65536;
+};
+Context &ctx();
+int require_init();
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// RAII device buffer for the host-side entry points.
+struct DevBuf {
+  void *p = nullptr;
+  uint64_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  int alloc(uint64_t n) {
+    if (p) {
+      (void)hipFree(p);
+      p = nullptr;
+    }
+    bytes = n;
+    if (n == 0) n = 8;
+    KPOP_HIP(hipMalloc(&p, n));
+    return 0;
+  }
+  template <class T>
+  T *as() const {
+    return reinterpret_cast<T *>(p);
+  }
+};
+
+constexpr int kWave = 64;  // gfx950 wavefront
+
+static inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+}  // namespace kpop

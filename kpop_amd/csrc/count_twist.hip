@@ -1,0 +1,483 @@
+// count_twist.hip -- the count and twist stages, and their fusion.
+//
+//   count_wave_kernel        bin/KPopCount.ml:36-50 (-L: one spectrum per read)
+//   twist_csr_kernel         lib/Twister.ml:146-188 on CSR spectra
+//   count_twist_wave_kernel  both, fused: the README.md:606 pipeline without
+//                            the text spectra in between
+//
+// Work decomposition: ONE WAVEFRONT PER READ.  Reads are independent through
+// count and twist, a 150 bp read has 139 windows (<= 64*R with
+// R = 4 keys per lane), and the twist of one read is a gather of <= 139 twister
+// rows of n_dims f64 -- with lane d owning dimension d, every row is one
+// fully coalesced 512-byte load (n_dims = 64) and no cross-lane reduction is
+// ever needed.  The kernel is HBM-bound on that gather.
+#include <algorithm>
+#include <vector>
+
+#include "kmer.h"
+#include "read_hash.h"
+#include "scan.h"
+#include "twister.h"
+#include "wave_sort.h"
+
+namespace kpop {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kGatherUnroll = 8;
+
+// ---------------------------------------------------------------------------
+// per-wave LDS
+// ---------------------------------------------------------------------------
+template <int R, typename K>
+struct WaveLds {
+  K key[64 * R + kGatherUnroll];          // distinct keys (twister columns / hashes), ascending
+  uint32_t start[64 * R + 4];             // first index of each run; [n_unique] = n_valid
+  double x[64 * R + kGatherUnroll];       // normalised multiplicities
+  uint8_t codes[(codes_bytes<R>() + 15) & ~15];
+};
+
+// ---------------------------------------------------------------------------
+// count: one wave per read -> fixed-stride scratch rows of (hash, count)
+// ---------------------------------------------------------------------------
+template <int R, typename H>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void count_wave_kernel(
+    const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ read_ids,
+    uint32_t n, int k, int content, uint32_t stride, uint64_t *__restrict__ scr_hash,
+    uint32_t *__restrict__ scr_count, uint32_t *__restrict__ n_unique_out) {
+  __shared__ WaveLds<R, H> lds[kWavesPerBlock];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t w = blockIdx.x * kWavesPerBlock + wv;
+  if (w >= n) return;
+  const uint32_t r = read_ids ? read_ids[w] : w;
+  const uint64_t off = offsets[r];
+  const uint32_t len = (uint32_t)(offsets[r + 1] - off);
+  WaveLds<R, H> &L = lds[wv];
+
+  wave_stage_codes<R>(bases + off, len, lane, L.codes);
+  H key[R];
+  wave_hash_windows<R, H>(L.codes, k, content, lane, key);
+  wave_bitonic_sort<R, H>(key, lane);
+  uint32_t n_valid;
+  const uint32_t nu = wave_unique<R, H>(key, (H)~(H)0, lane, L.key, L.start, n_valid);
+  for (uint32_t u = lane; u < nu; u += 64) {
+    scr_hash[(uint64_t)r * stride + u] = (uint64_t)L.key[u];
+    scr_count[(uint64_t)r * stride + u] = L.start[u + 1] - L.start[u];
+  }
+  if (lane == 0) n_unique_out[r] = nu;
+}
+
+// scratch rows -> CSR, one wave per read
+__global__ __launch_bounds__(256) void compact_spectra_kernel(const uint64_t *__restrict__ scr_hash,
+                                                              const uint32_t *__restrict__ scr_count,
+                                                              const uint32_t *__restrict__ n_unique,
+                                                              const uint64_t *__restrict__ out_offsets, uint32_t n,
+                                                              uint32_t stride, uint64_t *__restrict__ out_hash,
+                                                              uint32_t *__restrict__ out_count) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const uint32_t nu = n_unique[r];
+  const uint64_t o = out_offsets[r];
+  for (uint32_t u = lane; u < nu; u += 64) {
+    out_hash[o + u] = scr_hash[(uint64_t)r * stride + u];
+    out_count[o + u] = scr_count[(uint64_t)r * stride + u];
+  }
+}
+
+struct LoadU32 {
+  const uint32_t *p;
+  __device__ uint32_t operator()(uint64_t i) const { return p[i]; }
+};
+struct StoreOffsets {
+  uint64_t *out;
+  __device__ void operator()(uint64_t i, uint64_t prefix, uint32_t) const { out[i] = prefix; }
+};
+
+// ---------------------------------------------------------------------------
+// the gather: t_d = sum_u rows[col_u][d] * x_u, u ascending (lib/Twister.ml:183)
+// lane owns dims lane, lane+64, ...; products and sums are NOT fused (the
+// reference is OCaml: one rounding per multiply and per add).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wave_gather_rows(const TwisterView &tv, const uint32_t *s_col, const double *s_x,
+                                                 uint32_t nu, int lane, double *__restrict__ out_row) {
+  for (uint32_t d0 = 0; d0 < tv.n_dims; d0 += 64) {
+    const uint32_t d = d0 + lane;
+    const bool active = d < tv.n_dims;
+    const double *base = tv.rows + d;
+    double acc = 0.0;
+    for (uint32_t u0 = 0; u0 < nu; u0 += kGatherUnroll) {
+      double v[kGatherUnroll];
+#pragma unroll
+      for (int j = 0; j < kGatherUnroll; ++j) {
+        const uint32_t col = s_col[u0 + j];  // padded with 0 past nu
+        v[j] = (active && u0 + j < nu) ? base[(uint64_t)col * tv.d_pad] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < kGatherUnroll; ++j) acc = __dadd_rn(acc, __dmul_rn(v[j], s_x[u0 + j]));  // x padded with 0
+    }
+    if (active) out_row[d] = acc;
+  }
+}
+
+// x_u = count_u / acc when normalising and acc <> 0 (lib/Twister.ml:177-178)
+template <int R>
+__device__ __forceinline__ void wave_fill_x(WaveLds<R, uint32_t> &L, uint32_t nu, double acc, int normalize, int lane) {
+  const bool norm = normalize && acc != 0.0;
+  for (uint32_t u = lane; u < nu + kGatherUnroll; u += 64) {
+    if (u < nu) {
+      double c = (double)(L.start[u + 1] - L.start[u]);
+      L.x[u] = norm ? c / acc : c;
+    } else {
+      L.x[u] = 0.0;
+      L.key[u] = 0u;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------
+// fused count -> twist: one wave per read
+// ---------------------------------------------------------------------------
+template <int R, typename H>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void count_twist_wave_kernel(
+    TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets,
+    const uint32_t *__restrict__ read_ids, uint32_t n, int content, int normalize, double *__restrict__ out) {
+  __shared__ WaveLds<R, uint32_t> lds[kWavesPerBlock];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t w = blockIdx.x * kWavesPerBlock + wv;
+  if (w >= n) return;
+  const uint32_t r = read_ids ? read_ids[w] : w;
+  const uint64_t off = offsets[r];
+  const uint32_t len = (uint32_t)(offsets[r + 1] - off);
+  WaveLds<R, uint32_t> &L = lds[wv];
+
+  wave_stage_codes<R>(bases + off, len, lane, L.codes);
+  H hkey[R];
+  wave_hash_windows<R, H>(L.codes, tv.k, content, lane, hkey);
+  // name -> column (lib/Twister.ml:151); k-mers the twister does not know are
+  // dropped here, hence also from the normaliser (:158,:167-169)
+  uint32_t key[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) key[i] = (hkey[i] != (H)~(H)0) ? lookup_col(tv, (uint64_t)hkey[i]) : kNoCol;
+  wave_bitonic_sort<R, uint32_t>(key, lane);
+  uint32_t n_valid;
+  const uint32_t nu = wave_unique<R, uint32_t>(key, kNoCol, lane, L.key, L.start, n_valid);
+  // counts are integers, so acc (:158) is exact whatever the order of the adds
+  wave_fill_x<R>(L, nu, (double)n_valid, normalize, lane);
+  wave_gather_rows(tv, L.key, L.x, nu, lane, out + (uint64_t)r * tv.n_dims);
+}
+
+// ---------------------------------------------------------------------------
+// twist of CSR spectra (hash, value): one wave per spectrum, any length.
+// Lines are taken in file order; duplicates are not merged first (the sum is
+// the same up to rounding) -- see DESIGN.md "twist_csr".  acc is a wave
+// reduction, exact for integer counts.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kWavesPerBlock) void twist_csr_kernel(
+    TwisterView tv, const uint64_t *__restrict__ hash, const double *__restrict__ value,
+    const uint64_t *__restrict__ offsets, uint32_t n, int normalize, double *__restrict__ out) {
+  __shared__ uint32_t s_col[kWavesPerBlock][64 + kGatherUnroll];
+  __shared__ double s_x[kWavesPerBlock][64 + kGatherUnroll];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t s = blockIdx.x * kWavesPerBlock + wv;
+  if (s >= n) return;
+  const uint64_t lo = offsets[s], hi = offsets[s + 1];
+  // pass 1: acc over lines whose k-mer the twister knows
+  double part = 0.0;
+  for (uint64_t i = lo + lane; i < hi; i += 64)
+    if (lookup_col(tv, hash[i]) != kNoCol) part += value[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  const double acc = part;
+  const bool norm = normalize && acc != 0.0;
+  // pass 2: 64 lines at a time through LDS, then the shared gather
+  const uint32_t n_dims = tv.n_dims;
+  for (uint32_t d0 = 0; d0 < n_dims; d0 += 64) {
+    const uint32_t d = d0 + lane;
+    const bool active = d < n_dims;
+    double t = 0.0;
+    for (uint64_t i0 = lo; i0 < hi; i0 += 64) {
+      const uint64_t i = i0 + lane;
+      uint32_t col = kNoCol;
+      double x = 0.0;
+      if (i < hi) {
+        col = lookup_col(tv, hash[i]);
+        x = norm ? value[i] / acc : value[i];
+      }
+      if (col == kNoCol) {
+        col = 0;
+        x = 0.0;
+      }
+      __builtin_amdgcn_wave_barrier();
+      s_col[wv][lane] = col;
+      s_x[wv][lane] = x;
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t cnt = (uint32_t)min((uint64_t)64, hi - i0);
+      const double *base = tv.rows + d;
+      for (uint32_t u0 = 0; u0 < cnt; u0 += kGatherUnroll) {
+        double v[kGatherUnroll];
+#pragma unroll
+        for (int j = 0; j < kGatherUnroll; ++j) {
+          const uint32_t uu = min(u0 + j, 63u);
+          const uint32_t c = s_col[wv][uu];
+          const double xx = s_x[wv][uu];
+          v[j] = (active && u0 + j < cnt && xx != 0.0) ? base[(uint64_t)c * tv.d_pad] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < kGatherUnroll; ++j) {
+          const uint32_t uu = min(u0 + j, 63u);
+          const double xx = (u0 + j < cnt) ? s_x[wv][uu] : 0.0;
+          t = __dadd_rn(t, __dmul_rn(v[j], xx));
+        }
+      }
+    }
+    if (active) out[(uint64_t)s * n_dims + d] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// synthetic reads: base i of read r from SplitMix64 stream
+// element (first_read + r) * read_len + i
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64d(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ void synth_reads_kernel(uint64_t seed, uint64_t n_reads, uint32_t read_len, uint64_t first_read,
+                                   uint8_t *__restrict__ bases, uint64_t *__restrict__ offsets) {
+  const uint64_t total = n_reads * read_len;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    uint64_t g = first_read * read_len + i;
+    uint64_t z = mix64d(seed + (g + 1) * 0x9E3779B97F4A7C15ull);
+    bases[i] = (uint8_t)("ACGT"[z >> 62]);
+  }
+  if (offsets)
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n_reads; r += stride)
+      offsets[r] = r * read_len;
+}
+
+// ---------------------------------------------------------------------------
+// dispatch helpers
+// ---------------------------------------------------------------------------
+static int pick_R(uint32_t max_windows) {
+  if (max_windows <= 64) return 1;
+  if (max_windows <= 128) return 2;
+  if (max_windows <= 256) return 4;
+  if (max_windows <= 512) return 8;
+  return 0;
+}
+
+template <typename H>
+static int launch_count_wave(int R, const uint8_t *bases, const uint64_t *offsets, const uint32_t *ids, uint32_t n, int k,
+                             int content, uint32_t stride, uint64_t *sh, uint32_t *sc, uint32_t *nu, hipStream_t st) {
+  dim3 grid(div_up(n, kWavesPerBlock)), block(64 * kWavesPerBlock);
+  switch (R) {
+    case 1: count_wave_kernel<1, H><<<grid, block, 0, st>>>(bases, offsets, ids, n, k, content, stride, sh, sc, nu); break;
+    case 2: count_wave_kernel<2, H><<<grid, block, 0, st>>>(bases, offsets, ids, n, k, content, stride, sh, sc, nu); break;
+    case 4: count_wave_kernel<4, H><<<grid, block, 0, st>>>(bases, offsets, ids, n, k, content, stride, sh, sc, nu); break;
+    case 8: count_wave_kernel<8, H><<<grid, block, 0, st>>>(bases, offsets, ids, n, k, content, stride, sh, sc, nu); break;
+    default: KPOP_FAIL(KPOP_ERR_INVALID, "launch_count_wave: R=%d", R);
+  }
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename H>
+static int launch_count_twist_wave(int R, const TwisterView &tv, const uint8_t *bases, const uint64_t *offsets,
+                                   const uint32_t *ids, uint32_t n, int content, int normalize, double *out,
+                                   hipStream_t st) {
+  dim3 grid(div_up(n, kWavesPerBlock)), block(64 * kWavesPerBlock);
+  switch (R) {
+    case 1: count_twist_wave_kernel<1, H><<<grid, block, 0, st>>>(tv, bases, offsets, ids, n, content, normalize, out); break;
+    case 2: count_twist_wave_kernel<2, H><<<grid, block, 0, st>>>(tv, bases, offsets, ids, n, content, normalize, out); break;
+    case 4: count_twist_wave_kernel<4, H><<<grid, block, 0, st>>>(tv, bases, offsets, ids, n, content, normalize, out); break;
+    case 8: count_twist_wave_kernel<8, H><<<grid, block, 0, st>>>(tv, bases, offsets, ids, n, content, normalize, out); break;
+    default: KPOP_FAIL(KPOP_ERR_INVALID, "launch_count_twist_wave: R=%d", R);
+  }
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
+
+static int check_offsets(const uint64_t *offsets, uint32_t n, uint64_t *max_len) {
+  uint64_t m = 0;
+  for (uint32_t r = 0; r < n; ++r) {
+    if (offsets[r + 1] < offsets[r]) KPOP_FAIL(KPOP_ERR_INVALID, "offsets are not non-decreasing at read %u", r);
+    m = std::max(m, offsets[r + 1] - offsets[r]);
+  }
+  *max_len = m;
+  return 0;
+}
+
+}  // namespace kpop
+
+using namespace kpop;
+
+// ---------------------------------------------------------------------------
+// C ABI: device-resident entry points
+// ---------------------------------------------------------------------------
+extern "C" int kpop_dev_synth_reads(uint64_t seed, uint64_t n_reads, uint32_t read_len, uint64_t first_read,
+                                    uint8_t *d_bases, uint64_t *d_offsets, void *stream) {
+  KPOP_TRY(require_init());
+  if (!d_bases && n_reads && read_len) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_synth_reads: null bases");
+  synth_reads_kernel<<<dim3(2048), dim3(256), 0, as_stream(stream)>>>(seed, n_reads, read_len, first_read, d_bases,
+                                                                       d_offsets);
+  KPOP_LAUNCH_CHECK();
+  return KPOP_OK;
+}
+
+extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bases, const uint64_t *d_offsets,
+                                    uint32_t n_reads, uint32_t max_len, int content, int normalize, double *d_out,
+                                    void *stream) {
+  KPOP_TRY(require_init());
+  if (!tw || !d_offsets || !d_out) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_count_twist: null argument");
+  if (content != KPOP_DNA_DS && content != KPOP_DNA_SS)
+    KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_count_twist: content %d (protein k-mers are not on the HIP path)", content);
+  if (n_reads == 0) return KPOP_OK;
+  const uint32_t max_windows = (max_len >= (uint32_t)tw->k) ? max_len - tw->k + 1 : 0;
+  const int R = pick_R(max_windows);
+  if (R == 0)
+    KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_count_twist: reads longer than %d windows need the long-sequence path",
+              64 * 8);
+  const TwisterView tv = view_of(tw);
+  if (tw->k <= 15)
+    return launch_count_twist_wave<uint32_t>(R, tv, d_bases, d_offsets, nullptr, n_reads, content, normalize, d_out,
+                                             as_stream(stream));
+  return launch_count_twist_wave<uint64_t>(R, tv, d_bases, d_offsets, nullptr, n_reads, content, normalize, d_out,
+                                           as_stream(stream));
+}
+
+extern "C" int kpop_dev_twist(const kpop_twister *tw, const uint64_t *d_hash, const double *d_value,
+                              const uint64_t *d_offsets, uint32_t n_spectra, uint64_t max_lines, int normalize,
+                              double *d_out, void *stream) {
+  KPOP_TRY(require_init());
+  (void)max_lines;
+  if (!tw || !d_offsets || !d_out) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_twist: null argument");
+  if (n_spectra == 0) return KPOP_OK;
+  twist_csr_kernel<<<dim3(div_up(n_spectra, kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, as_stream(stream)>>>(
+      view_of(tw), d_hash, d_value, d_offsets, n_spectra, normalize, d_out);
+  KPOP_LAUNCH_CHECK();
+  return KPOP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// C ABI: host-buffer entry points
+// ---------------------------------------------------------------------------
+extern "C" int kpop_count_reads(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, int k, int content,
+                                int per_read, uint64_t *out_hash, uint32_t *out_count, uint64_t *out_offsets,
+                                uint64_t out_capacity) {
+  KPOP_TRY(require_init());
+  if (!offsets || !out_offsets || (!out_hash && out_capacity) || (!out_count && out_capacity))
+    KPOP_FAIL(KPOP_ERR_INVALID, "kpop_count_reads: null argument");
+  if (k < 1 || k > kMaxK) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_count_reads: k=%d out of range 1..%d", k, kMaxK);
+  if (content != KPOP_DNA_DS && content != KPOP_DNA_SS)
+    KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_count_reads: content %d (protein k-mers are not on the HIP path)", content);
+  if (!per_read) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_count_reads: merged (-l) mode is not on the HIP path yet");
+  out_offsets[0] = 0;
+  if (n_reads == 0) return KPOP_OK;
+  uint64_t max_len = 0;
+  KPOP_TRY(check_offsets(offsets, n_reads, &max_len));
+  const uint64_t max_windows = (max_len >= (uint64_t)k) ? max_len - k + 1 : 0;
+  const int R = pick_R((uint32_t)std::min<uint64_t>(max_windows, 0xFFFFFFFFull));
+  if (R == 0)
+    KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_count_reads: reads longer than %d windows need the long-sequence path", 64 * 8);
+  const uint32_t stride = 64 * R;
+  const uint64_t base0 = offsets[0], n_bases = offsets[n_reads] - base0;
+  hipStream_t st = nullptr;
+  DevBuf d_bases, d_off, d_sh, d_sc, d_nu, d_sums, d_oo, d_oh, d_oc;
+  KPOP_TRY(d_bases.alloc(n_bases));
+  KPOP_TRY(d_off.alloc((uint64_t)(n_reads + 1) * 8));
+  KPOP_TRY(d_sh.alloc((uint64_t)n_reads * stride * 8));
+  KPOP_TRY(d_sc.alloc((uint64_t)n_reads * stride * 4));
+  KPOP_TRY(d_nu.alloc((uint64_t)n_reads * 4));
+  KPOP_TRY(d_sums.alloc((scan_blocks(n_reads) + 1) * 8));
+  KPOP_TRY(d_oo.alloc((uint64_t)(n_reads + 1) * 8));
+  std::vector<uint64_t> rel(n_reads + 1);
+  for (uint32_t r = 0; r <= n_reads; ++r) rel[r] = offsets[r] - base0;
+  if (n_bases) KPOP_HIP(hipMemcpyAsync(d_bases.p, bases + base0, n_bases, hipMemcpyHostToDevice, st));
+  KPOP_HIP(hipMemcpyAsync(d_off.p, rel.data(), (uint64_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+  if (k <= 15)
+    KPOP_TRY(launch_count_wave<uint32_t>(R, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), nullptr, n_reads, k, content,
+                                         stride, d_sh.as<uint64_t>(), d_sc.as<uint32_t>(), d_nu.as<uint32_t>(), st));
+  else
+    KPOP_TRY(launch_count_wave<uint64_t>(R, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), nullptr, n_reads, k, content,
+                                         stride, d_sh.as<uint64_t>(), d_sc.as<uint32_t>(), d_nu.as<uint32_t>(), st));
+  KPOP_TRY(exclusive_scan(LoadU32{d_nu.as<uint32_t>()}, StoreOffsets{d_oo.as<uint64_t>()}, n_reads,
+                          d_sums.as<uint64_t>(), st));
+  uint64_t total = 0;
+  KPOP_HIP(hipMemcpyAsync(&total, d_sums.as<uint64_t>() + scan_blocks(n_reads), 8, hipMemcpyDeviceToHost, st));
+  KPOP_HIP(hipStreamSynchronize(st));
+  if (total > out_capacity)
+    KPOP_FAIL(KPOP_ERR_CAPACITY, "kpop_count_reads: %llu distinct (read,k-mer) pairs, capacity %llu",
+              (unsigned long long)total, (unsigned long long)out_capacity);
+  KPOP_TRY(d_oh.alloc(total * 8));
+  KPOP_TRY(d_oc.alloc(total * 4));
+  compact_spectra_kernel<<<dim3(div_up(n_reads, 4)), dim3(256), 0, st>>>(
+      d_sh.as<uint64_t>(), d_sc.as<uint32_t>(), d_nu.as<uint32_t>(), d_oo.as<uint64_t>(), n_reads, stride,
+      d_oh.as<uint64_t>(), d_oc.as<uint32_t>());
+  KPOP_LAUNCH_CHECK();
+  KPOP_HIP(hipMemcpyAsync(out_offsets, d_oo.p, (uint64_t)n_reads * 8, hipMemcpyDeviceToHost, st));
+  if (total) {
+    KPOP_HIP(hipMemcpyAsync(out_hash, d_oh.p, total * 8, hipMemcpyDeviceToHost, st));
+    KPOP_HIP(hipMemcpyAsync(out_count, d_oc.p, total * 4, hipMemcpyDeviceToHost, st));
+  }
+  KPOP_HIP(hipStreamSynchronize(st));
+  out_offsets[n_reads] = total;
+  return KPOP_OK;
+}
+
+extern "C" int kpop_count_twist(const kpop_twister *tw, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                                int content, int normalize, double *out) {
+  KPOP_TRY(require_init());
+  if (!tw || !offsets || (!out && n_reads)) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_count_twist: null argument");
+  if (n_reads == 0) return KPOP_OK;
+  uint64_t max_len = 0;
+  KPOP_TRY(check_offsets(offsets, n_reads, &max_len));
+  const uint64_t base0 = offsets[0], n_bases = offsets[n_reads] - base0;
+  hipStream_t st = nullptr;
+  DevBuf d_bases, d_off, d_out;
+  KPOP_TRY(d_bases.alloc(n_bases));
+  KPOP_TRY(d_off.alloc((uint64_t)(n_reads + 1) * 8));
+  KPOP_TRY(d_out.alloc((uint64_t)n_reads * tw->n_dims * 8));
+  std::vector<uint64_t> rel(n_reads + 1);
+  for (uint32_t r = 0; r <= n_reads; ++r) rel[r] = offsets[r] - base0;
+  if (n_bases) KPOP_HIP(hipMemcpyAsync(d_bases.p, bases + base0, n_bases, hipMemcpyHostToDevice, st));
+  KPOP_HIP(hipMemcpyAsync(d_off.p, rel.data(), (uint64_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+  KPOP_TRY(kpop_dev_count_twist(tw, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), n_reads,
+                                (uint32_t)std::min<uint64_t>(max_len, 0xFFFFFFFFull), content, normalize,
+                                d_out.as<double>(), st));
+  KPOP_HIP(hipMemcpyAsync(out, d_out.p, (uint64_t)n_reads * tw->n_dims * 8, hipMemcpyDeviceToHost, st));
+  KPOP_HIP(hipStreamSynchronize(st));
+  return KPOP_OK;
+}
+
+extern "C" int kpop_twist(const kpop_twister *tw, const uint64_t *hash, const double *value, const uint64_t *offsets,
+                          uint32_t n_spectra, int normalize, double *out) {
+  KPOP_TRY(require_init());
+  if (!tw || !offsets || (!out && n_spectra)) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_twist: null argument");
+  if (n_spectra == 0) return KPOP_OK;
+  uint64_t max_lines = 0;
+  KPOP_TRY(check_offsets(offsets, n_spectra, &max_lines));
+  const uint64_t base0 = offsets[0], n_lines = offsets[n_spectra] - base0;
+  if (n_lines && (!hash || !value)) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_twist: null hash/value");
+  hipStream_t st = nullptr;
+  DevBuf d_h, d_v, d_off, d_out;
+  KPOP_TRY(d_h.alloc(n_lines * 8));
+  KPOP_TRY(d_v.alloc(n_lines * 8));
+  KPOP_TRY(d_off.alloc((uint64_t)(n_spectra + 1) * 8));
+  KPOP_TRY(d_out.alloc((uint64_t)n_spectra * tw->n_dims * 8));
+  std::vector<uint64_t> rel(n_spectra + 1);
+  for (uint32_t r = 0; r <= n_spectra; ++r) rel[r] = offsets[r] - base0;
+  if (n_lines) {
+    KPOP_HIP(hipMemcpyAsync(d_h.p, hash + base0, n_lines * 8, hipMemcpyHostToDevice, st));
+    KPOP_HIP(hipMemcpyAsync(d_v.p, value + base0, n_lines * 8, hipMemcpyHostToDevice, st));
+  }
+  KPOP_HIP(hipMemcpyAsync(d_off.p, rel.data(), (uint64_t)(n_spectra + 1) * 8, hipMemcpyHostToDevice, st));
+  KPOP_TRY(kpop_dev_twist(tw, d_h.as<uint64_t>(), d_v.as<double>(), d_off.as<uint64_t>(), n_spectra, max_lines,
+                          normalize, d_out.as<double>(), st));
+  KPOP_HIP(hipMemcpyAsync(out, d_out.p, (uint64_t)n_spectra * tw->n_dims * 8, hipMemcpyDeviceToHost, st));
+  KPOP_HIP(hipStreamSynchronize(st));
+  return KPOP_OK;
+}

@@ -1,0 +1,493 @@
+// distance.hip -- norms, rowwise distances and the per-row summary.
+//
+//   row_norms_kernel         Base.get_normalizations   lib/Matrix.ml:42-76
+//                            Space.compute_norm        lib/Space.ml:166-181
+//   distance_rowwise_kernel  Base.get_distance_rowwise lib/Matrix.ml:191-266
+//                            Space.Distance.compute    lib/Space.ml:182-205
+//   distance_summary_kernel  summarize_rowwise / summarize_distance_matrix_row
+//                                                      lib/Matrix.ml:691-766,632-690
+//
+// Numerics follow the reference operation for operation: every pair's sum runs
+// over the dimensions in ascending order in ONE thread, diff*diff*m is
+// evaluated left to right, nothing is fused, and a/n_i, b/n_j are the same
+// IEEE divisions the reference performs per element (lib/Matrix.ml:247-249) --
+// done once per row here instead of once per pair.
+#include <math.h>
+
+#include "common.h"
+
+namespace kpop {
+
+// ---------------------------------------------------------------------------
+// unscaled component and scale (lib/Space.ml:150-165)
+// ---------------------------------------------------------------------------
+template <int KIND>
+__device__ __forceinline__ double component(double diff, double m, double p) {
+  if (KIND == KPOP_MINKOWSKI) return __dmul_rn(pow(fabs(diff), p), m);
+  return __dmul_rn(__dmul_rn(diff, diff), m);
+}
+
+template <int KIND>
+__device__ __forceinline__ double scale_distance(double x, double p) {
+  if (KIND == KPOP_EUCLIDEAN) return sqrt(x);
+  if (KIND == KPOP_COSINE) return x / 2.0;
+  return pow(x, 1.0 / p);
+}
+
+// ---------------------------------------------------------------------------
+// norms + pre-normalised rows.  One thread per row walks the dimensions in
+// order; 64-row x 32-dim tiles go through LDS so global traffic is coalesced.
+// ---------------------------------------------------------------------------
+constexpr int kNormRows = 64, kNormDims = 32;
+
+template <int KIND>
+__global__ __launch_bounds__(256) void row_norms_kernel(const double *__restrict__ m, uint32_t rows, uint32_t n_dims,
+                                                        const double *__restrict__ metric, double p,
+                                                        double *__restrict__ norms) {
+  __shared__ double tile[kNormRows][kNormDims + 1];
+  __shared__ double s_metric[kNormDims];
+  const uint32_t row0 = blockIdx.x * kNormRows;
+  double acc = 0.0;
+  for (uint32_t c0 = 0; c0 < n_dims; c0 += kNormDims) {
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < kNormRows * kNormDims; e += 256) {
+      uint32_t i = e / kNormDims, c = e % kNormDims;
+      tile[i][c] = (row0 + i < rows && c0 + c < n_dims) ? m[(uint64_t)(row0 + i) * n_dims + c0 + c] : 0.0;
+    }
+    if (threadIdx.x < kNormDims) s_metric[threadIdx.x] = (c0 + threadIdx.x < n_dims) ? metric[c0 + threadIdx.x] : 0.0;
+    __syncthreads();
+    if (threadIdx.x < kNormRows) {
+      const uint32_t lim = min((uint32_t)kNormDims, n_dims - c0);
+      for (uint32_t c = 0; c < lim; ++c) {
+        double el = tile[threadIdx.x][c];
+        // lib/Space.ml:169-178: acc +. (el *. el *. m_i)  |  acc +. ((|el| ** p) *. m_i)
+        acc = __dadd_rn(acc, component<KIND>(el, s_metric[c], p));
+      }
+    }
+  }
+  if (threadIdx.x < kNormRows && row0 + threadIdx.x < rows) {
+    double nv = scale_distance<KIND>(acc, p);
+    norms[row0 + threadIdx.x] = (nv == 0.0) ? 1.0 : nv;  // lib/Matrix.ml:67
+  }
+}
+
+__global__ void normalise_rows_kernel(const double *__restrict__ m, uint64_t total, uint32_t n_dims,
+                                      const double *__restrict__ norms, double *__restrict__ out) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride)
+    out[e] = m[e] / norms[e / n_dims];  // adaptor_a / adaptor_b, lib/Matrix.ml:248
+}
+
+// ---------------------------------------------------------------------------
+// rowwise distances.  Block = 64 rows of m2 (j) x 64 rows of m1 (i); each of
+// the 256 threads owns a 4(j) x 4(i) micro-tile and walks the dimensions in
+// order, 32 at a time through LDS ([dim][row] so a thread's 4 rows are
+// contiguous).  a, b are the pre-normalised operands.
+// ---------------------------------------------------------------------------
+constexpr int kDT = 64, kDC = 32, kDS = kDT + 1;
+
+template <int KIND>
+__global__ __launch_bounds__(256) void distance_rowwise_kernel(const double *__restrict__ a, uint32_t r1,
+                                                               const double *__restrict__ b, uint32_t r2,
+                                                               uint32_t n_dims, const double *__restrict__ metric,
+                                                               double p, double *__restrict__ out) {
+  __shared__ double As[kDC][kDS];
+  __shared__ double Bs[kDC][kDS];
+  __shared__ double s_metric[kDC];
+  const uint32_t i0 = blockIdx.x * kDT, j0 = blockIdx.y * kDT;
+  const uint32_t ti = (threadIdx.x & 15) * 4, tj = (threadIdx.x >> 4) * 4;
+  double acc[4][4];
+#pragma unroll
+  for (int y = 0; y < 4; ++y)
+#pragma unroll
+    for (int x = 0; x < 4; ++x) acc[y][x] = 0.0;
+  for (uint32_t c0 = 0; c0 < n_dims; c0 += kDC) {
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < kDT * kDC; e += 256) {
+      const uint32_t row = e / kDC, c = e % kDC;
+      const bool cok = c0 + c < n_dims;
+      As[c][row] = (cok && i0 + row < r1) ? a[(uint64_t)(i0 + row) * n_dims + c0 + c] : 0.0;
+      Bs[c][row] = (cok && j0 + row < r2) ? b[(uint64_t)(j0 + row) * n_dims + c0 + c] : 0.0;
+    }
+    if (threadIdx.x < kDC) s_metric[threadIdx.x] = (c0 + threadIdx.x < n_dims) ? metric[c0 + threadIdx.x] : 0.0;
+    __syncthreads();
+    const uint32_t lim = min((uint32_t)kDC, n_dims - c0);
+    for (uint32_t c = 0; c < lim; ++c) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) av[x] = As[c][ti + x];
+#pragma unroll
+      for (int y = 0; y < 4; ++y) bv[y] = Bs[c][tj + y];
+      const double mc = s_metric[c];
+#pragma unroll
+      for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          // lib/Space.ml:192-200: diff = a -. b ; acc +. (diff *. diff *. m)
+          double diff = __dsub_rn(av[x], bv[y]);
+          acc[y][x] = __dadd_rn(acc[y][x], component<KIND>(diff, mc, p));
+        }
+    }
+  }
+#pragma unroll
+  for (int y = 0; y < 4; ++y) {
+    const uint32_t j = j0 + tj + y;
+    if (j >= r2) continue;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const uint32_t i = i0 + ti + x;
+      if (i < r1) out[(uint64_t)j * r1 + i] = scale_distance<KIND>(acc[y][x], p);  // data.(j).@(i), lib/Matrix.ml:253
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// summary: one block per m2 row.  LDS: dist[NP] (column order), kd[NP]/ki[NP]
+// (sorted by distance then column: the FloatIntMultimap of lib/Matrix.ml:631).
+// ---------------------------------------------------------------------------
+struct DistIdx {
+  double d;
+  uint32_t i;
+};
+
+__device__ __forceinline__ bool pair_less(double da, uint32_t ia, double db, uint32_t ib) {
+  return (da < db) || (da == db && ia < ib);
+}
+
+// block-wide bitonic sort of (kd, ki) pairs, NP a power of two
+__device__ void block_sort_pairs(double *kd, uint32_t *ki, uint32_t NP) {
+  for (uint32_t s = 2; s <= NP; s <<= 1) {
+    for (uint32_t t = s >> 1; t > 0; t >>= 1) {
+      __syncthreads();
+      for (uint32_t q = threadIdx.x; q < NP / 2; q += blockDim.x) {
+        const uint32_t i = 2 * q - (q & (t - 1)), j = i + t;
+        const bool asc = (i & s) == 0;
+        const double di = kd[i], dj = kd[j];
+        const uint32_t ii = ki[i], ij = ki[j];
+        const bool gt = pair_less(dj, ij, di, ii);
+        if (gt == asc) {
+          kd[i] = dj; kd[j] = di;
+          ki[i] = ij; ki[j] = ii;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__device__ void block_sort_keys(double *kd, uint32_t NP) {
+  for (uint32_t s = 2; s <= NP; s <<= 1) {
+    for (uint32_t t = s >> 1; t > 0; t >>= 1) {
+      __syncthreads();
+      for (uint32_t q = threadIdx.x; q < NP / 2; q += blockDim.x) {
+        const uint32_t i = 2 * q - (q & (t - 1)), j = i + t;
+        const bool asc = (i & s) == 0;
+        const double di = kd[i], dj = kd[j];
+        if ((dj < di) == asc) {
+          kd[i] = dj; kd[j] = di;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void distance_summary_kernel(
+    const double *__restrict__ a, uint32_t r1, const double *__restrict__ b, uint32_t r2, uint32_t n_dims,
+    const double *__restrict__ metric, double p, uint32_t NP, uint32_t req_len, uint32_t max_neighbours,
+    double *__restrict__ out_stats, uint32_t *__restrict__ out_n, uint32_t *__restrict__ out_idx,
+    double *__restrict__ out_dist, double *__restrict__ out_z) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double *dist = reinterpret_cast<double *>(smem);     // [NP] column order
+  double *kd = dist + NP;                               // [NP]
+  uint32_t *ki = reinterpret_cast<uint32_t *>(kd + NP);  // [NP]
+  __shared__ double s_stats[4];
+  __shared__ uint32_t s_eff;
+  const uint32_t j = blockIdx.x;
+  const double *brow = b + (uint64_t)j * n_dims;
+  const double inf = __longlong_as_double(0x7FF0000000000000ll);
+  // distances of row j to every m1 row (lib/Matrix.ml:744-749), one thread per m1 row
+  for (uint32_t i = threadIdx.x; i < NP; i += blockDim.x) {
+    double d = inf;
+    if (i < r1) {
+      const double *arow = a + (uint64_t)i * n_dims;
+      double acc = 0.0;
+      for (uint32_t c = 0; c < n_dims; ++c) {
+        double diff = __dsub_rn(arow[c], brow[c]);
+        acc = __dadd_rn(acc, component<KIND>(diff, metric[c], p));
+      }
+      d = scale_distance<KIND>(acc, p);
+    }
+    dist[i] = d;
+    kd[i] = d;
+    ki[i] = (i < r1) ? i : 0xFFFFFFFFu;
+  }
+  block_sort_pairs(kd, ki, NP);
+  // lib/Matrix.ml:640-655, literally, by one thread: the multimap is walked in
+  // ascending order one distinct distance at a time
+  if (threadIdx.x == 0) {
+    uint32_t eff_len = 0;
+    long long median_pos = r1 / 2;
+    double median = 0.0, acc = 0.0;
+    for (uint32_t s = 0; s < r1;) {
+      uint32_t e = s + 1;
+      const double dd = kd[s];
+      while (e < r1 && kd[e] == dd) ++e;
+      const long long set_len = e - s;
+      acc = __dadd_rn(acc, __dmul_rn((double)set_len, dd));
+      if (median_pos >= 0 && median_pos - set_len < 0) median = dd;
+      median_pos -= set_len;
+      if (eff_len < req_len) eff_len += (uint32_t)set_len;
+      s = e;
+    }
+    const double mean = (r1 > 0) ? acc / (double)r1 : 0.0;
+    // :657-670 squared deviations in column order
+    acc = 0.0;
+    for (uint32_t c = 0; c < r1; ++c) {
+      double dv = __dsub_rn(dist[c], mean);
+      acc = __dadd_rn(acc, __dmul_rn(dv, dv));
+    }
+    s_stats[0] = mean;
+    s_stats[1] = (r1 > 1) ? sqrt(acc / ((double)r1 - 1.0)) : 0.0;  // :679-683
+    s_stats[2] = median;
+    s_eff = min(eff_len, r1);
+  }
+  __syncthreads();
+  // neighbours: the first eff_len entries of the multimap (:685-689)
+  {
+    const double mean = s_stats[0], sd = s_stats[1];
+    const uint32_t n_out = min(s_eff, max_neighbours);
+    for (uint32_t q = threadIdx.x; q < n_out; q += blockDim.x) {
+      out_idx[(uint64_t)j * max_neighbours + q] = ki[q];
+      out_dist[(uint64_t)j * max_neighbours + q] = kd[q];
+      out_z[(uint64_t)j * max_neighbours + q] = __dsub_rn(kd[q], mean) / sd;
+    }
+  }
+  __syncthreads();
+  // MAD: |d - median| sorted, element n/2 (:659-678)
+  {
+    const double median = s_stats[2];
+    for (uint32_t i = threadIdx.x; i < NP; i += blockDim.x) kd[i] = (i < r1) ? fabs(__dsub_rn(dist[i], median)) : inf;
+  }
+  block_sort_keys(kd, NP);
+  if (threadIdx.x == 0) {
+    out_stats[(uint64_t)j * 4 + 0] = s_stats[0];
+    out_stats[(uint64_t)j * 4 + 1] = s_stats[1];
+    out_stats[(uint64_t)j * 4 + 2] = s_stats[2];
+    out_stats[(uint64_t)j * 4 + 3] = (r1 > 0) ? kd[r1 / 2] : 0.0;
+    out_n[j] = s_eff;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host-side orchestration
+// ---------------------------------------------------------------------------
+struct DistWork {
+  double *n1, *n2, *a, *b;
+};
+
+static DistWork carve(void *work, uint32_t r1, uint32_t r2, uint32_t n_dims) {
+  double *w = reinterpret_cast<double *>(work);
+  DistWork d;
+  d.n1 = w;
+  d.n2 = d.n1 + r1;
+  d.a = d.n2 + r2;
+  d.b = d.a + (uint64_t)r1 * n_dims;
+  return d;
+}
+
+template <int KIND>
+static int prepare_operands(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
+                            const double *metric, double p, int normalize, void *work, const double **a,
+                            const double **b, hipStream_t st) {
+  if (!normalize) {  // n1 = n2 = 1 (lib/Matrix.ml:201-202): x /. 1. = x
+    *a = m1;
+    *b = m2;
+    return 0;
+  }
+  DistWork w = carve(work, r1, r2, n_dims);
+  if (r1) {
+    row_norms_kernel<KIND><<<dim3(div_up(r1, kNormRows)), dim3(256), 0, st>>>(m1, r1, n_dims, metric, p, w.n1);
+    KPOP_LAUNCH_CHECK();
+    uint64_t tot = (uint64_t)r1 * n_dims;
+    normalise_rows_kernel<<<dim3(std::min<uint32_t>(div_up(tot, 256), 4096)), dim3(256), 0, st>>>(m1, tot, n_dims, w.n1, w.a);
+    KPOP_LAUNCH_CHECK();
+  }
+  if (r2) {
+    row_norms_kernel<KIND><<<dim3(div_up(r2, kNormRows)), dim3(256), 0, st>>>(m2, r2, n_dims, metric, p, w.n2);
+    KPOP_LAUNCH_CHECK();
+    uint64_t tot = (uint64_t)r2 * n_dims;
+    normalise_rows_kernel<<<dim3(std::min<uint32_t>(div_up(tot, 256), 4096)), dim3(256), 0, st>>>(m2, tot, n_dims, w.n2, w.b);
+    KPOP_LAUNCH_CHECK();
+  }
+  *a = w.a;
+  *b = w.b;
+  return 0;
+}
+
+template <int KIND>
+static int rowwise_impl(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
+                        const double *metric, double p, int normalize, void *work, double *out, hipStream_t st) {
+  const double *a, *b;
+  KPOP_TRY(prepare_operands<KIND>(m1, r1, m2, r2, n_dims, metric, p, normalize, work, &a, &b, st));
+  dim3 grid(div_up(r1, kDT), div_up(r2, kDT));
+  if (grid.y > 65535) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "distance_rowwise: more than %d rows in the second operand", 65535 * kDT);
+  distance_rowwise_kernel<KIND><<<grid, dim3(256), 0, st>>>(a, r1, b, r2, n_dims, metric, p, out);
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
+
+constexpr uint32_t kSummaryMaxR1 = 4096;
+
+template <int KIND>
+static int summary_impl(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
+                        const double *metric, double p, int normalize, uint32_t keep_at_most, uint32_t max_neighbours,
+                        void *work, double *out_stats, uint32_t *out_n, uint32_t *out_idx, double *out_dist,
+                        double *out_z, hipStream_t st) {
+  const double *a, *b;
+  KPOP_TRY(prepare_operands<KIND>(m1, r1, m2, r2, n_dims, metric, p, normalize, work, &a, &b, st));
+  uint32_t NP = 64;
+  while (NP < r1) NP <<= 1;
+  const size_t smem = (size_t)NP * (8 + 8 + 4);
+  static bool attr_set[3] = {false, false, false};
+  if (!attr_set[KIND]) {
+    KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&distance_summary_kernel<KIND>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSummaryMaxR1 * 20)));
+    attr_set[KIND] = true;
+  }
+  const uint32_t req_len = keep_at_most ? keep_at_most : r1;  // lib/Matrix.ml:723-726
+  distance_summary_kernel<KIND><<<dim3(r2), dim3(256), smem, st>>>(a, r1, b, r2, n_dims, metric, p, NP, req_len,
+                                                                   max_neighbours, out_stats, out_n, out_idx, out_dist,
+                                                                   out_z);
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
+
+static int check_kind(int kind, double p, const char *who) {
+  if (kind != KPOP_EUCLIDEAN && kind != KPOP_COSINE && kind != KPOP_MINKOWSKI)
+    KPOP_FAIL(KPOP_ERR_INVALID, "%s: unknown distance kind %d", who, kind);
+  if (kind == KPOP_MINKOWSKI && !(p >= 0.0)) KPOP_FAIL(KPOP_ERR_INVALID, "%s: negative Minkowski power", who);  // lib/Space.ml:222-223
+  return 0;
+}
+
+}  // namespace kpop
+
+using namespace kpop;
+
+extern "C" uint64_t kpop_dev_distance_workspace_bytes(uint32_t r1, uint32_t r2, uint32_t n_dims) {
+  return ((uint64_t)r1 + r2 + ((uint64_t)r1 + r2) * n_dims) * sizeof(double) + 64;
+}
+
+extern "C" int kpop_dev_distance_rowwise(const double *d_m1, uint32_t r1, const double *d_m2, uint32_t r2,
+                                         uint32_t n_dims, const double *d_metric, int kind, double p, int normalize,
+                                         void *d_work, double *d_out, void *stream) {
+  KPOP_TRY(require_init());
+  KPOP_TRY(check_kind(kind, p, "kpop_dev_distance_rowwise"));
+  if (r1 == 0 || r2 == 0) return KPOP_OK;
+  if (!d_m1 || !d_m2 || !d_metric || !d_out || (normalize && !d_work))
+    KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_distance_rowwise: null argument");
+  if (n_dims == 0) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_distance_rowwise: n_dims must be positive");
+  hipStream_t st = as_stream(stream);
+  switch (kind) {
+    case KPOP_EUCLIDEAN: return rowwise_impl<KPOP_EUCLIDEAN>(d_m1, r1, d_m2, r2, n_dims, d_metric, p, normalize, d_work, d_out, st);
+    case KPOP_COSINE: return rowwise_impl<KPOP_COSINE>(d_m1, r1, d_m2, r2, n_dims, d_metric, p, normalize, d_work, d_out, st);
+    default: return rowwise_impl<KPOP_MINKOWSKI>(d_m1, r1, d_m2, r2, n_dims, d_metric, p, normalize, d_work, d_out, st);
+  }
+}
+
+extern "C" int kpop_dev_distance_summary(const double *d_m1, uint32_t r1, const double *d_m2, uint32_t r2,
+                                         uint32_t n_dims, const double *d_metric, int kind, double p, int normalize,
+                                         uint32_t keep_at_most, uint32_t max_neighbours, void *d_work,
+                                         double *d_out_stats, uint32_t *d_out_n, uint32_t *d_out_idx,
+                                         double *d_out_dist, double *d_out_z, void *stream) {
+  KPOP_TRY(require_init());
+  KPOP_TRY(check_kind(kind, p, "kpop_dev_distance_summary"));
+  if (r2 == 0) return KPOP_OK;
+  if (!d_m2 || !d_metric || !d_out_stats || !d_out_n || (normalize && !d_work) || (r1 && !d_m1))
+    KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_distance_summary: null argument");
+  if (max_neighbours && (!d_out_idx || !d_out_dist || !d_out_z))
+    KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_distance_summary: null neighbour buffers");
+  if (n_dims == 0) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_distance_summary: n_dims must be positive");
+  if (r1 > kSummaryMaxR1)
+    KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_distance_summary: r1=%u, the HIP path covers up to %u reference rows", r1,
+              kSummaryMaxR1);
+  hipStream_t st = as_stream(stream);
+  switch (kind) {
+    case KPOP_EUCLIDEAN:
+      return summary_impl<KPOP_EUCLIDEAN>(d_m1, r1, d_m2, r2, n_dims, d_metric, p, normalize, keep_at_most, max_neighbours,
+                                          d_work, d_out_stats, d_out_n, d_out_idx, d_out_dist, d_out_z, st);
+    case KPOP_COSINE:
+      return summary_impl<KPOP_COSINE>(d_m1, r1, d_m2, r2, n_dims, d_metric, p, normalize, keep_at_most, max_neighbours,
+                                       d_work, d_out_stats, d_out_n, d_out_idx, d_out_dist, d_out_z, st);
+    default:
+      return summary_impl<KPOP_MINKOWSKI>(d_m1, r1, d_m2, r2, n_dims, d_metric, p, normalize, keep_at_most, max_neighbours,
+                                          d_work, d_out_stats, d_out_n, d_out_idx, d_out_dist, d_out_z, st);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host-buffer entry points
+// ---------------------------------------------------------------------------
+extern "C" int kpop_distance_rowwise(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
+                                     const double *metric, int kind, double p, int normalize, double *out) {
+  KPOP_TRY(require_init());
+  KPOP_TRY(check_kind(kind, p, "kpop_distance_rowwise"));
+  if (r1 == 0 || r2 == 0) return KPOP_OK;
+  if (!m1 || !m2 || !metric || !out) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_distance_rowwise: null argument");
+  if (n_dims == 0) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_distance_rowwise: n_dims must be positive");
+  hipStream_t st = nullptr;
+  DevBuf d1, d2, dm, dw, dout;
+  KPOP_TRY(d1.alloc((uint64_t)r1 * n_dims * 8));
+  KPOP_TRY(d2.alloc((uint64_t)r2 * n_dims * 8));
+  KPOP_TRY(dm.alloc((uint64_t)n_dims * 8));
+  KPOP_TRY(dw.alloc(kpop_dev_distance_workspace_bytes(r1, r2, n_dims)));
+  KPOP_TRY(dout.alloc((uint64_t)r1 * r2 * 8));
+  KPOP_HIP(hipMemcpyAsync(d1.p, m1, (uint64_t)r1 * n_dims * 8, hipMemcpyHostToDevice, st));
+  KPOP_HIP(hipMemcpyAsync(d2.p, m2, (uint64_t)r2 * n_dims * 8, hipMemcpyHostToDevice, st));
+  KPOP_HIP(hipMemcpyAsync(dm.p, metric, (uint64_t)n_dims * 8, hipMemcpyHostToDevice, st));
+  KPOP_TRY(kpop_dev_distance_rowwise(d1.as<double>(), r1, d2.as<double>(), r2, n_dims, dm.as<double>(), kind, p,
+                                     normalize, dw.p, dout.as<double>(), st));
+  KPOP_HIP(hipMemcpyAsync(out, dout.p, (uint64_t)r1 * r2 * 8, hipMemcpyDeviceToHost, st));
+  KPOP_HIP(hipStreamSynchronize(st));
+  return KPOP_OK;
+}
+
+extern "C" int kpop_distance_summary(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
+                                     const double *metric, int kind, double p, int normalize, uint32_t keep_at_most,
+                                     uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
+                                     double *out_dist, double *out_z) {
+  KPOP_TRY(require_init());
+  KPOP_TRY(check_kind(kind, p, "kpop_distance_summary"));
+  if (r2 == 0) return KPOP_OK;
+  if (!m2 || !metric || !out_stats || !out_n || (r1 && !m1))
+    KPOP_FAIL(KPOP_ERR_INVALID, "kpop_distance_summary: null argument");
+  if (n_dims == 0) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_distance_summary: n_dims must be positive");
+  hipStream_t st = nullptr;
+  DevBuf d1, d2, dm, dw, ds, dn, di, dd, dz;
+  const uint64_t nn = (uint64_t)r2 * max_neighbours;
+  KPOP_TRY(d1.alloc((uint64_t)r1 * n_dims * 8));
+  KPOP_TRY(d2.alloc((uint64_t)r2 * n_dims * 8));
+  KPOP_TRY(dm.alloc((uint64_t)n_dims * 8));
+  KPOP_TRY(dw.alloc(kpop_dev_distance_workspace_bytes(r1, r2, n_dims)));
+  KPOP_TRY(ds.alloc((uint64_t)r2 * 4 * 8));
+  KPOP_TRY(dn.alloc((uint64_t)r2 * 4));
+  KPOP_TRY(di.alloc(nn * 4));
+  KPOP_TRY(dd.alloc(nn * 8));
+  KPOP_TRY(dz.alloc(nn * 8));
+  if (r1) KPOP_HIP(hipMemcpyAsync(d1.p, m1, (uint64_t)r1 * n_dims * 8, hipMemcpyHostToDevice, st));
+  KPOP_HIP(hipMemcpyAsync(d2.p, m2, (uint64_t)r2 * n_dims * 8, hipMemcpyHostToDevice, st));
+  KPOP_HIP(hipMemcpyAsync(dm.p, metric, (uint64_t)n_dims * 8, hipMemcpyHostToDevice, st));
+  KPOP_TRY(kpop_dev_distance_summary(d1.as<double>(), r1, d2.as<double>(), r2, n_dims, dm.as<double>(), kind, p,
+                                     normalize, keep_at_most, max_neighbours, dw.p, ds.as<double>(), dn.as<uint32_t>(),
+                                     di.as<uint32_t>(), dd.as<double>(), dz.as<double>(), st));
+  KPOP_HIP(hipMemcpyAsync(out_stats, ds.p, (uint64_t)r2 * 4 * 8, hipMemcpyDeviceToHost, st));
+  KPOP_HIP(hipMemcpyAsync(out_n, dn.p, (uint64_t)r2 * 4, hipMemcpyDeviceToHost, st));
+  if (nn) {
+    KPOP_HIP(hipMemcpyAsync(out_idx, di.p, nn * 4, hipMemcpyDeviceToHost, st));
+    KPOP_HIP(hipMemcpyAsync(out_dist, dd.p, nn * 8, hipMemcpyDeviceToHost, st));
+    KPOP_HIP(hipMemcpyAsync(out_z, dz.p, nn * 8, hipMemcpyDeviceToHost, st));
+  }
+  KPOP_HIP(hipStreamSynchronize(st));
+  return KPOP_OK;
+}

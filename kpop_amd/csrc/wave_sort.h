@@ -1,0 +1,98 @@
+// wave_sort.h -- one-wavefront (64 lanes) sort + run-length collapse, in registers.
+//
+// A wave holds N = 64*R keys, R per lane; element index e = lane*R + r.
+// Bitonic network: strides below R are in-lane register swaps, strides >= R
+// are one cross-lane exchange (lane ^ (stride/R)) per register.  Invalid
+// slots carry the all-ones sentinel and sort to the end.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kpop {
+
+template <typename K>
+__device__ __forceinline__ K key_min(K a, K b) { return a < b ? a : b; }
+template <typename K>
+__device__ __forceinline__ K key_max(K a, K b) { return a < b ? b : a; }
+
+__device__ __forceinline__ uint32_t wave_shfl_xor(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
+__device__ __forceinline__ uint64_t wave_shfl_xor(uint64_t v, int m) {
+  return (uint64_t)__shfl_xor((unsigned long long)v, m, 64);
+}
+__device__ __forceinline__ uint32_t wave_shfl_up1(uint32_t v) { return (uint32_t)__shfl_up((int)v, 1, 64); }
+__device__ __forceinline__ uint64_t wave_shfl_up1(uint64_t v) {
+  return (uint64_t)__shfl_up((unsigned long long)v, 1, 64);
+}
+
+template <int R, typename K>
+__device__ __forceinline__ void wave_bitonic_sort(K (&key)[R], int lane) {
+  constexpr int N = 64 * R;
+#pragma unroll
+  for (int s = 2; s <= N; s <<= 1) {
+#pragma unroll
+    for (int t = s >> 1; t > 0; t >>= 1) {
+      if (t >= R) {
+        const int lt = t / R;
+        // e & s == (lane & (s/R)) * R for s >= R; the last merge (s == N) is ascending everywhere
+        const bool asc = (s == N) ? true : ((lane & (s / R)) == 0);
+        const bool lower = (lane & lt) == 0;
+        const bool keep_min = (lower == asc);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          K other = wave_shfl_xor(key[r], lt);
+          K mn = key_min(key[r], other), mx = key_max(key[r], other);
+          key[r] = keep_min ? mn : mx;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if ((r & t) == 0) {
+            const bool asc = (s >= N) ? true : (s < R ? ((r & s) == 0) : ((lane & (s / R)) == 0));
+            K a = key[r], b = key[r ^ t];
+            K mn = key_min(a, b), mx = key_max(a, b);
+            key[r] = asc ? mn : mx;
+            key[r ^ t] = asc ? mx : mn;
+          }
+        }
+      }
+    }
+  }
+}
+
+// After wave_bitonic_sort: collapse runs of equal keys.
+//   s_key[u]   = u-th distinct key (ascending), u < n_unique
+//   s_start[u] = index of its first occurrence; s_start[n_unique] = n_valid
+// so its multiplicity is s_start[u+1]-s_start[u].  s_key/s_start are this
+// wave's private LDS regions (64*R and 64*R+1 entries).  Returns n_unique.
+template <int R, typename K>
+__device__ __forceinline__ uint32_t wave_unique(const K (&key)[R], K sentinel, int lane, K *s_key,
+                                                uint32_t *s_start, uint32_t &n_valid) {
+  K prev = wave_shfl_up1(key[R - 1]);
+  bool head[R];
+  uint32_t below = 0, total = 0, valid = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    K p = (r == 0) ? prev : key[r - 1];
+    bool first = (r == 0) && (lane == 0);
+    head[r] = (key[r] != sentinel) && (first || key[r] != p);
+    uint64_t m = __ballot(head[r]);
+    below += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    total += (uint32_t)__popcll(m);
+    valid += (uint32_t)__popcll(__ballot(key[r] != sentinel));
+  }
+  uint32_t pos = below;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (head[r]) {
+      s_key[pos] = key[r];
+      s_start[pos] = (uint32_t)(lane * R + r);
+      ++pos;
+    }
+  }
+  if (lane == 0) s_start[total] = valid;
+  n_valid = valid;
+  __builtin_amdgcn_wave_barrier();
+  return total;
+}
+
+}  // namespace kpop

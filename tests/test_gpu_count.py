@@ -1,0 +1,84 @@
+"""GPU parity: k-mer counting (bin/KPopCount.ml:36-50) through the C ABI vs the oracle.  Bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, concat, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def spectra_equal(a, b):
+    (ha, ca, oa), (hb, cb, ob) = a, b
+    assert oa.tolist() == ob.tolist()
+    assert np.array_equal(ha, hb)
+    assert np.array_equal(ca, cb)
+
+
+def random_reads(rng, n, lo, hi, p_n=0.01):
+    seqs = []
+    for _ in range(n):
+        L = int(rng.randint(lo, hi + 1))
+        s = rng.choice(list("ACGTNacgtRY-"), size=L, p=[(1 - p_n * 4) / 4] * 4 + [p_n] + [p_n / 2] * 4 + [p_n / 3] * 3)
+        seqs.append("".join(s))
+    return seqs
+
+
+def test_count_golden_vectors(kpop, oracle):
+    g = load_golden("count_small.json")
+    seqs = [s for _, s in g["reads"]]
+    bases, offs = concat(seqs)
+    for case in g["cases"]:
+        k = case["k"]
+        content = kpop.DNA_DS if case["content"] == "DNA-ds" else kpop.DNA_SS
+        h, c, o = kpop.count_reads(bases, offs, k, content)
+        for r in range(len(seqs)):
+            got = [[oracle.to_hex(a, k), int(b)] for a, b in zip(h[int(o[r]):int(o[r + 1])], c[int(o[r]):int(o[r + 1])])]
+            assert got == case["spectra"][r], (g["reads"][r][0], k, case["content"])
+
+
+@pytest.mark.parametrize("k", [1, 4, 10, 12, 15, 16, 17, 24, 30])
+@pytest.mark.parametrize("content", [0, 1])
+def test_count_random_ragged(kpop, oracle, k, content):
+    rng = np.random.RandomState(100 + k)
+    seqs = ["", "A", "ACGT" * 3] + random_reads(rng, 300, 0, 180)
+    bases, offs = concat(seqs)
+    spectra_equal(kpop.count_reads(bases, offs, k, content), oracle.count_reads(bases, offs, k, content))
+
+
+@pytest.mark.parametrize("max_len", [60, 75, 139, 267, 523])
+def test_count_every_keys_per_lane_variant(kpop, oracle, max_len):
+    """Read lengths that select R = 1, 2, 4, 8 keys per lane, up to the last window that fits."""
+    rng = np.random.RandomState(max_len)
+    k = 12
+    seqs = random_reads(rng, 64, max(0, max_len - 40), max_len, p_n=0.004) + ["ACGT" * (max_len // 4)]
+    seqs.append("".join(rng.choice(list("ACGT"), size=max_len)))
+    bases, offs = concat(seqs)
+    spectra_equal(kpop.count_reads(bases, offs, k), oracle.count_reads(bases, offs, k))
+
+
+def test_count_headline_shape_10k_k10(kpop, oracle):
+    """BASELINE config 2: synthetic 10k x 150 bp, k=10, bit-exact k-mer check."""
+    bases, offs = oracle.synth_reads(0x4B506F70, 10000, 150)
+    spectra_equal(kpop.count_reads(bases, offs, 10), oracle.count_reads(bases, offs, 10))
+
+
+def test_count_offsets_not_starting_at_zero(kpop, oracle):
+    bases, offs = oracle.synth_reads(5, 50, 100)
+    sub = offs[10:31].copy()
+    h, c, o = kpop.count_reads(bases, sub, 12)
+    ho, co, oo = oracle.count_reads(bases, sub, 12)
+    spectra_equal((h, c, o), (ho, co, oo))
+
+
+def test_count_errors(kpop):
+    bases, offs = concat(["ACGTACGTACGT"])
+    for k in (0, 31):
+        with pytest.raises(kpop.KPopError):
+            kpop.count_reads(bases, offs, k)
+    with pytest.raises(kpop.KPopError):
+        kpop.count_reads(bases, offs, 3, content=2)  # protein: not on the HIP path
+    with pytest.raises(kpop.KPopError) as e:
+        kpop.count_reads(bases, offs, 3, capacity=2)
+    assert e.value.code == -2  # KPOP_ERR_CAPACITY
+    h, c, o = kpop.count_reads(np.zeros(0, np.uint8), np.zeros(1, np.uint64), 5)
+    assert len(h) == 0 and o.tolist() == [0]
