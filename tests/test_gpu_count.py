@@ -78,7 +78,7 @@ def test_count_errors(kpop):
     with pytest.raises(kpop.KPopError):
         kpop.count_reads(bases, offs, 3, content=2)  # protein: not on the HIP path
     with pytest.raises(kpop.KPopError) as e:
-        kpop.count_reads(bases, offs, 3, capacity=2)
+        kpop.count_reads(bases, offs, 3, capacity=1)
     assert e.value.code == -2  # KPOP_ERR_CAPACITY
     h, c, o = kpop.count_reads(np.zeros(0, np.uint8), np.zeros(1, np.uint64), 5)
     assert len(h) == 0 and o.tolist() == [0]
