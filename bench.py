@@ -121,7 +121,8 @@ def main():
     coffs = torch.empty(C + 1, dtype=torch.int64, device=dev)
     api.dev_synth_reads(CLASS_SEED, C, args.class_len, cbases.data_ptr(), coffs.data_ptr(), stream=sp)
     classes = torch.zeros(C, d, dtype=torch.float64, device=dev)
-    api.dev_count_twist(tw, cbases.data_ptr(), coffs.data_ptr(), C, args.class_len, classes.data_ptr(), stream=sp)
+    api.dev_count_twist(tw, cbases.data_ptr(), coffs.data_ptr(), C, C * args.class_len, args.class_len, classes.data_ptr(),
+                        stream=sp)
     from oracle import oracle as O  # only for the inertia of the synthetic twister and the cpu_baseline leg
     metric_host = kpop_amd.metric_compute(O.synth_inertia(d))
     metric = torch.from_numpy(metric_host).to(dev)
@@ -132,7 +133,8 @@ def main():
     def step(ev=None):
         if ev:
             ev[0].record(stream)
-        api.dev_count_twist(tw, bases.data_ptr(), offsets.data_ptr(), n_local, L, twisted.data_ptr(), stream=sp)
+        api.dev_count_twist(tw, bases.data_ptr(), offsets.data_ptr(), n_local, n_local * L, L, twisted.data_ptr(),
+                            stream=sp)
         if ev:
             ev[1].record(stream)
         api.dev_distance_rowwise(classes.data_ptr(), C, twisted.data_ptr(), n_local, d, metric.data_ptr(),

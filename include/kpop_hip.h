@@ -148,10 +148,13 @@ int kpop_distance_summary(const double *m1, uint32_t r1, const double *m2, uint3
  * Same operations on buffers already in HBM; enqueue only.                   */
 int kpop_dev_synth_reads(uint64_t seed, uint64_t n_reads, uint32_t read_len, uint64_t first_read,
                          uint8_t *d_bases, uint64_t *d_offsets, void *stream);
-/* max_len = longest read in the batch (host knows it from the offsets) */
+/* n_bases = offsets[n_reads] (size of d_bases), max_len = longest read in the batch: the host
+   knows both from the offsets it uploaded.  Reads of up to 512 windows take the one-wavefront-
+   per-read kernel; longer sequences (genomes) the streaming kernel, whose segment partials
+   live in a library-owned workspace (grown with hipMalloc on the first call that needs more). */
 int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bases, const uint64_t *d_offsets,
-                         uint32_t n_reads, uint32_t max_len, int content, int normalize, double *d_out,
-                         void *stream);
+                         uint32_t n_reads, uint64_t n_bases, uint32_t max_len, int content, int normalize,
+                         double *d_out, void *stream);
 int kpop_dev_twist(const kpop_twister *tw, const uint64_t *d_hash, const double *d_value,
                    const uint64_t *d_offsets, uint32_t n_spectra, uint64_t max_lines, int normalize,
                    double *d_out, void *stream);

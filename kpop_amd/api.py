@@ -216,9 +216,10 @@ def dev_synth_reads(seed, n_reads, read_len, d_bases, d_offsets, first_read=0, s
                                            d_offsets, stream))
 
 
-def dev_count_twist(tw, d_bases, d_offsets, n_reads, max_len, d_out, content=DNA_DS, normalize=True, stream=0):
-    check(_lib.load().kpop_dev_count_twist(tw.handle, d_bases, d_offsets, int(n_reads), int(max_len), int(content),
-                                           1 if normalize else 0, d_out, stream))
+def dev_count_twist(tw, d_bases, d_offsets, n_reads, n_bases, max_len, d_out, content=DNA_DS, normalize=True,
+                    stream=0):
+    check(_lib.load().kpop_dev_count_twist(tw.handle, d_bases, d_offsets, int(n_reads), int(n_bases), int(max_len),
+                                           int(content), 1 if normalize else 0, d_out, stream))
 
 
 def dev_twist(tw, d_hash, d_value, d_offsets, n_spectra, max_lines, d_out, normalize=True, stream=0):

@@ -33,11 +33,22 @@ const char *get_error();
 
 #define KPOP_LAUNCH_CHECK() KPOP_HIP(hipGetLastError())
 
+// grow-only device scratch owned by the library (long-sequence partial sums,
+// segment tables).  ensure() may hipMalloc on the first call with a larger
+// shape; steady-state calls only enqueue.
+struct Workspace {
+  void *p = nullptr;
+  uint64_t bytes = 0;
+  int ensure(uint64_t need, void **out);
+  void release();
+};
+
 struct Context {
   bool initialised = false;
   int device = -1;
   int n_cus = 256;
   size_t lds_per_block = 65536;
+  Workspace ws;
 };
 Context &ctx();
 int require_init();

@@ -52,6 +52,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void count_wave_kernel(
   const uint64_t off = offsets[r];
   const uint32_t len = (uint32_t)(offsets[r + 1] - off);
   WaveLds<R, H> &L = lds[wv];
+  if (len >= (uint32_t)k && len - (uint32_t)k + 1 > 64u * R) {  // long-sequence path's business
+    if (lane == 0) n_unique_out[r] = 0;
+    return;
+  }
 
   wave_stage_codes<R>(bases + off, len, lane, L.codes);
   H key[R];
@@ -150,6 +154,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void count_twist_wave_kernel(
   const uint64_t off = offsets[r];
   const uint32_t len = (uint32_t)(offsets[r + 1] - off);
   WaveLds<R, uint32_t> &L = lds[wv];
+  if (len >= (uint32_t)tv.k && len - (uint32_t)tv.k + 1 > 64u * R) return;  // count_twist_stream_kernel's business
 
   wave_stage_codes<R>(bases + off, len, lane, L.codes);
   H hkey[R];
@@ -232,6 +237,121 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void twist_csr_kernel(
       }
     }
     if (active) out[(uint64_t)s * n_dims + d] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// long sequences (assembled genomes: 30 kb .. Mb): streaming fused count->twist.
+// A sequence is cut into segments of kSegWindows windows, one 256-thread block
+// per segment.  Each wave takes 64 windows at a time: every lane hashes one
+// window and looks its column up, then the wave walks the 64 columns with
+// v_readlane (wave-uniform row address) and all lanes load that row -- lane d
+// owns dimension d exactly as in the per-read kernel.  No sort: the sum runs
+// over k-mer INSTANCES in sequence order and is divided by acc once at the end,
+//   t_d = (sum_windows T[col(w)][d]) / acc
+// which equals the reference's sum_h T[h][d]*(c_h/acc) (lib/Twister.ml:177-183)
+// up to rounding.  Segment partials are combined in segment order by a second
+// kernel, so results are bitwise reproducible.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kWaveMaxWindows = 512;  // 64 lanes x R=8: the per-read kernels' limit
+constexpr uint32_t kSegWindows = 16384;
+
+__global__ void segment_count_kernel(const uint64_t *__restrict__ offsets, uint32_t n, int k,
+                                     uint32_t *__restrict__ nseg) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const uint64_t len = offsets[r + 1] - offsets[r];
+  const uint64_t w = (len >= (uint64_t)k) ? len - k + 1 : 0;
+  nseg[r] = (w > kWaveMaxWindows) ? (uint32_t)((w + kSegWindows - 1) / kSegWindows) : 0u;
+}
+
+struct StoreU64 {
+  uint64_t *out;
+  __device__ void operator()(uint64_t i, uint64_t prefix, uint32_t) const { out[i] = prefix; }
+};
+
+template <typename H>
+__global__ __launch_bounds__(256) void count_twist_stream_kernel(
+    TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int content,
+    const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ seg_off, double *__restrict__ partial,
+    uint32_t *__restrict__ partial_cnt) {
+  __shared__ double s_part[4][64];
+  __shared__ uint32_t s_cnt[4];
+  const uint32_t r = blockIdx.x, seg = blockIdx.y;
+  if (seg >= nseg[r]) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t off = offsets[r];
+  const uint64_t len = offsets[r + 1] - off;
+  const int k = tv.k;
+  const uint64_t n_win = len - k + 1;  // nseg > 0 implies len >= k
+  const uint64_t w0 = (uint64_t)seg * kSegWindows;
+  const uint64_t w1 = min(n_win, w0 + kSegWindows);
+  const uint8_t *seq = bases + off;
+  const int shift = 2 * (k - 1);
+  const uint64_t slot = seg_off[r] + seg;
+  for (uint32_t d0 = 0; d0 < tv.n_dims; d0 += 64) {
+    const uint32_t d = d0 + lane;
+    const bool active = d < tv.n_dims;
+    const double *base = tv.rows + d;
+    double acc = 0.0;
+    uint32_t cnt = 0;
+    for (uint64_t cb = w0 + (uint64_t)wv * 64; cb < w1; cb += 4 * 64) {
+      const uint64_t win = cb + lane;
+      uint32_t col = kNoCol;
+      if (win < w1) {
+        H fwd = 0, rc = 0;
+        bool good = true;
+        for (int j = 0; j < k; ++j) {
+          const uint32_t c = base_code(seq[win + j]);
+          good = good && (c < 4u);
+          fwd = (fwd << 2) | (H)(c & 3u);
+          rc = (rc >> 2) | ((H)(3u - (c & 3u)) << shift);
+        }
+        if (good) col = lookup_col(tv, (uint64_t)((content == KPOP_DNA_DS && rc < fwd) ? rc : fwd));
+      }
+      cnt += (uint32_t)__popcll(__ballot(col != kNoCol));
+#pragma unroll
+      for (int j0 = 0; j0 < 64; j0 += kGatherUnroll) {
+        double v[kGatherUnroll];
+#pragma unroll
+        for (int u = 0; u < kGatherUnroll; ++u) {
+          const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)col, j0 + u);
+          v[u] = (cj != kNoCol && active) ? base[(uint64_t)cj * tv.d_pad] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kGatherUnroll; ++u) acc = __dadd_rn(acc, v[u]);
+      }
+    }
+    __syncthreads();
+    s_part[wv][lane] = acc;
+    if (lane == 0) s_cnt[wv] = cnt;
+    __syncthreads();
+    if (wv == 0) {
+      double t = __dadd_rn(__dadd_rn(__dadd_rn(s_part[0][lane], s_part[1][lane]), s_part[2][lane]), s_part[3][lane]);
+      if (active) partial[slot * tv.n_dims + d] = t;
+      if (d0 == 0 && lane == 0) partial_cnt[slot] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void combine_partials_kernel(const uint32_t *__restrict__ nseg,
+                                                               const uint64_t *__restrict__ seg_off,
+                                                               const double *__restrict__ partial,
+                                                               const uint32_t *__restrict__ partial_cnt,
+                                                               uint32_t n_dims, int normalize,
+                                                               double *__restrict__ out) {
+  const uint32_t r = blockIdx.x;
+  const uint32_t ns = nseg[r];
+  if (ns == 0) return;
+  const uint64_t s0 = seg_off[r];
+  uint64_t found = 0;
+  for (uint32_t s = 0; s < ns; ++s) found += partial_cnt[s0 + s];
+  const double acc = (double)found;  // lib/Twister.ml:158, exact: integer counts
+  const bool norm = normalize && acc != 0.0;
+  for (uint32_t d = threadIdx.x; d < n_dims; d += blockDim.x) {
+    double t = 0.0;
+    for (uint32_t s = 0; s < ns; ++s) t = __dadd_rn(t, partial[(s0 + s) * n_dims + d]);
+    out[(uint64_t)r * n_dims + d] = norm ? t / acc : t;
   }
 }
 
@@ -329,24 +449,52 @@ extern "C" int kpop_dev_synth_reads(uint64_t seed, uint64_t n_reads, uint32_t re
 }
 
 extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bases, const uint64_t *d_offsets,
-                                    uint32_t n_reads, uint32_t max_len, int content, int normalize, double *d_out,
-                                    void *stream) {
+                                    uint32_t n_reads, uint64_t n_bases, uint32_t max_len, int content, int normalize,
+                                    double *d_out, void *stream) {
   KPOP_TRY(require_init());
   if (!tw || !d_offsets || !d_out) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_count_twist: null argument");
   if (content != KPOP_DNA_DS && content != KPOP_DNA_SS)
     KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_count_twist: content %d (protein k-mers are not on the HIP path)", content);
   if (n_reads == 0) return KPOP_OK;
+  hipStream_t st = as_stream(stream);
   const uint32_t max_windows = (max_len >= (uint32_t)tw->k) ? max_len - tw->k + 1 : 0;
-  const int R = pick_R(max_windows);
-  if (R == 0)
-    KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_count_twist: reads longer than %d windows need the long-sequence path",
-              64 * 8);
   const TwisterView tv = view_of(tw);
+  // reads of up to 512 windows: one wavefront per read (the kernel skips longer reads)
+  const int R = pick_R(std::min(max_windows, kWaveMaxWindows));
   if (tw->k <= 15)
-    return launch_count_twist_wave<uint32_t>(R, tv, d_bases, d_offsets, nullptr, n_reads, content, normalize, d_out,
-                                             as_stream(stream));
-  return launch_count_twist_wave<uint64_t>(R, tv, d_bases, d_offsets, nullptr, n_reads, content, normalize, d_out,
-                                           as_stream(stream));
+    KPOP_TRY(launch_count_twist_wave<uint32_t>(R, tv, d_bases, d_offsets, nullptr, n_reads, content, normalize, d_out, st));
+  else
+    KPOP_TRY(launch_count_twist_wave<uint64_t>(R, tv, d_bases, d_offsets, nullptr, n_reads, content, normalize, d_out, st));
+  if (max_windows <= kWaveMaxWindows) return KPOP_OK;
+  // longer sequences: segment table, streaming kernel, ordered combine
+  const uint64_t max_slots = n_bases / kSegWindows + n_reads;  // every read adds at most W/seg + 1 segments
+  const uint64_t nb = scan_blocks(n_reads);
+  const uint64_t bytes_nseg = ((uint64_t)n_reads * 4 + 63) & ~63ull, bytes_off = ((uint64_t)(n_reads + 1) * 8 + 63) & ~63ull,
+                 bytes_sums = ((nb + 1) * 8 + 63) & ~63ull, bytes_cnt = (max_slots * 4 + 63) & ~63ull,
+                 bytes_part = max_slots * tw->n_dims * 8;
+  void *ws = nullptr;
+  KPOP_TRY(ctx().ws.ensure(bytes_nseg + bytes_off + bytes_sums + bytes_cnt + bytes_part, &ws));
+  char *wp = reinterpret_cast<char *>(ws);
+  uint32_t *nseg = reinterpret_cast<uint32_t *>(wp);
+  uint64_t *seg_off = reinterpret_cast<uint64_t *>(wp + bytes_nseg);
+  uint64_t *sums = reinterpret_cast<uint64_t *>(wp + bytes_nseg + bytes_off);
+  uint32_t *pcnt = reinterpret_cast<uint32_t *>(wp + bytes_nseg + bytes_off + bytes_sums);
+  double *part = reinterpret_cast<double *>(wp + bytes_nseg + bytes_off + bytes_sums + bytes_cnt);
+  segment_count_kernel<<<dim3(div_up(n_reads, 256)), dim3(256), 0, st>>>(d_offsets, n_reads, tw->k, nseg);
+  KPOP_LAUNCH_CHECK();
+  KPOP_TRY(exclusive_scan(LoadU32{nseg}, StoreU64{seg_off}, n_reads, sums, st));
+  const uint32_t max_seg = div_up(max_windows, kSegWindows);
+  if (max_seg > 65535) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_count_twist: sequence longer than %llu bases",
+                                 (unsigned long long)65535 * kSegWindows);
+  dim3 grid(n_reads, max_seg);
+  if (tw->k <= 15)
+    count_twist_stream_kernel<uint32_t><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt);
+  else
+    count_twist_stream_kernel<uint64_t><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt);
+  KPOP_LAUNCH_CHECK();
+  combine_partials_kernel<<<dim3(n_reads), dim3(256), 0, st>>>(nseg, seg_off, part, pcnt, tw->n_dims, normalize, d_out);
+  KPOP_LAUNCH_CHECK();
+  return KPOP_OK;
 }
 
 extern "C" int kpop_dev_twist(const kpop_twister *tw, const uint64_t *d_hash, const double *d_value,
@@ -445,9 +593,9 @@ extern "C" int kpop_count_twist(const kpop_twister *tw, const uint8_t *bases, co
   for (uint32_t r = 0; r <= n_reads; ++r) rel[r] = offsets[r] - base0;
   if (n_bases) KPOP_HIP(hipMemcpyAsync(d_bases.p, bases + base0, n_bases, hipMemcpyHostToDevice, st));
   KPOP_HIP(hipMemcpyAsync(d_off.p, rel.data(), (uint64_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
-  KPOP_TRY(kpop_dev_count_twist(tw, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), n_reads,
-                                (uint32_t)std::min<uint64_t>(max_len, 0xFFFFFFFFull), content, normalize,
-                                d_out.as<double>(), st));
+  if (max_len > 0xFFFFFFFFull) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_count_twist: sequence longer than 2^32 bases");
+  KPOP_TRY(kpop_dev_count_twist(tw, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), n_reads, n_bases, (uint32_t)max_len,
+                                content, normalize, d_out.as<double>(), st));
   KPOP_HIP(hipMemcpyAsync(out, d_out.p, (uint64_t)n_reads * tw->n_dims * 8, hipMemcpyDeviceToHost, st));
   KPOP_HIP(hipStreamSynchronize(st));
   return KPOP_OK;

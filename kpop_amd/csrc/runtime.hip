@@ -23,6 +23,28 @@ Context &ctx() {
   return c;
 }
 
+int Workspace::ensure(uint64_t need, void **out) {
+  if (need > bytes) {
+    if (p) {
+      KPOP_HIP(hipDeviceSynchronize());  // earlier launches may still use the old block
+      KPOP_HIP(hipFree(p));
+      p = nullptr;
+      bytes = 0;
+    }
+    uint64_t want = need + need / 4 + 4096;
+    KPOP_HIP(hipMalloc(&p, want));
+    bytes = want;
+  }
+  *out = p;
+  return 0;
+}
+
+void Workspace::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  bytes = 0;
+}
+
 int require_init() {
   if (!ctx().initialised)
     KPOP_FAIL(KPOP_ERR_NOT_INIT, "libkpop_hip: kpop_init(device) has not been called (or failed: no usable GPU)");
@@ -62,6 +84,7 @@ extern "C" int kpop_init(int device) {
 }
 
 extern "C" int kpop_shutdown(void) {
+  ctx().ws.release();
   ctx().initialised = false;
   return KPOP_OK;
 }

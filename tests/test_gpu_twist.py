@@ -149,3 +149,46 @@ def test_headline_shape_sample_vs_oracle(kpop, oracle):
     want = oracle.twist(T, cols, h, c.astype(np.float64), o)
     assert_close(t1[pick], want)
     assert np.array_equal(t1[pick], want)  # ascending columns on both sides: bit-exact
+
+
+@pytest.mark.parametrize("k,d", [(10, 64), (12, 9), (7, 100), (21, 16)])
+def test_count_twist_long_sequences(kpop, oracle, k, d):
+    """Genomes (config 3 shape): sequences beyond 512 windows take the streaming kernel -- several 16384-window
+    segments, Ns inside, mixed in one batch with short reads that stay on the per-read kernel."""
+    from conftest import GOLDEN
+    rng = np.random.RandomState(k + d)
+    wuhan = "".join(l.strip() for l in open(GOLDEN + "/wuhan.fasta") if not l.startswith(">"))
+    long1 = "".join(rng.choice(list("ACGT"), size=100000))
+    long1 = long1[:40000] + "N" * 37 + long1[40037:70000] + "nnnRYK" + long1[70006:]
+    seqs = [wuhan, "ACGTTGCA" * 20, long1, "", wuhan[:513 + k - 1], wuhan[100:612 + k - 1], "".join(rng.choice(list("ACGT"), size=150))]
+    bases, offs = concat(seqs)
+    h, c, o = oracle.count_reads(bases, offs, k)
+    if k <= 12:
+        cols = oracle.enumerate_kmers(k)
+    else:
+        cols = np.unique(h)[::2].copy()
+    T = oracle.synth_twister(21, d, cols)
+    tw = kpop.Twister.load(T, cols, k)
+    for normalize in (True, False):
+        want = oracle.twist(T, cols, h, c.astype(np.float64), o, normalize)
+        got = tw.count_twist(bases, offs, normalize=normalize)
+        for r in range(len(seqs)):
+            scale = max(np.max(np.abs(want[r])), 1e-300) if normalize else max(np.max(np.abs(want[r])), 1.0)
+            assert np.max(np.abs(got[r] - want[r])) <= 1e-12 * scale * (1 if normalize else 100), (r, normalize)
+    # determinism of the segment combine
+    assert np.array_equal(tw.count_twist(bases, offs), tw.count_twist(bases, offs))
+
+
+def test_count_twist_many_genomes(kpop, oracle):
+    """A batch of 200 x 30 kb genomes: sum over instances / acc vs the oracle's dedupe-normalise-multiply."""
+    k, d, n, L = 12, 64, 200, 30000
+    bases, offs = oracle.synth_reads(77, n, L)
+    tw = kpop.Twister.synth(0x5EED, k, d)
+    got = tw.count_twist(bases, offs)
+    pick = [0, 57, 199]
+    sb, so = concat([bytes(bases[int(offs[r]):int(offs[r + 1])]).decode() for r in pick])
+    h, c, o = oracle.count_reads(sb, so, k)
+    cols = np.unique(h)
+    T = oracle.synth_twister(0x5EED, d, cols)
+    want = oracle.twist(T, cols, h, c.astype(np.float64), o)
+    assert np.max(np.abs(got[pick] - want)) <= 1e-12 * np.max(np.abs(want))

@@ -50,7 +50,7 @@ def main():
     api.dev_synth_reads(0x4B506F70, n, L, bases.data_ptr(), offs.data_ptr(), stream=sp)
     tout = torch.zeros(n, a.dims, dtype=torch.float64, device=dev)
     for _ in range(a.launches):
-        api.dev_count_twist(tw, bases.data_ptr(), offs.data_ptr(), n, L, tout.data_ptr(), stream=sp)
+        api.dev_count_twist(tw, bases.data_ptr(), offs.data_ptr(), n, n * L, L, tout.data_ptr(), stream=sp)
     torch.cuda.synchronize()
     print("calibration bytes per direction: %d; fused launches: %d" % (r2 * d * 8, a.launches))
 
