@@ -421,6 +421,11 @@ static int launch_count_twist_wave(int R, const TwisterView &tv, const uint8_t *
   return 0;
 }
 
+// sort_count.hip
+int sorted_count_batch(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, int k, int content,
+                       int per_read, uint64_t *out_hash, uint32_t *out_count, uint64_t *out_offsets, uint64_t cap,
+                       uint64_t *n_written);
+
 static int check_offsets(const uint64_t *offsets, uint32_t n, uint64_t *max_len) {
   uint64_t m = 0;
   for (uint32_t r = 0; r < n; ++r) {
@@ -522,15 +527,35 @@ extern "C" int kpop_count_reads(const uint8_t *bases, const uint64_t *offsets, u
   if (k < 1 || k > kMaxK) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_count_reads: k=%d out of range 1..%d", k, kMaxK);
   if (content != KPOP_DNA_DS && content != KPOP_DNA_SS)
     KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_count_reads: content %d (protein k-mers are not on the HIP path)", content);
-  if (!per_read) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_count_reads: merged (-l) mode is not on the HIP path yet");
-  out_offsets[0] = 0;
+  if (per_read) out_offsets[0] = 0; else out_offsets[0] = out_offsets[1] = 0;
   if (n_reads == 0) return KPOP_OK;
   uint64_t max_len = 0;
   KPOP_TRY(check_offsets(offsets, n_reads, &max_len));
   const uint64_t max_windows = (max_len >= (uint64_t)k) ? max_len - k + 1 : 0;
-  const int R = pick_R((uint32_t)std::min<uint64_t>(max_windows, 0xFFFFFFFFull));
-  if (R == 0)
-    KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_count_reads: reads longer than %d windows need the long-sequence path", 64 * 8);
+  if (!per_read) {  // -l: one spectrum for everything (bin/KPopCount.ml:60)
+    uint64_t written = 0;
+    return sorted_count_batch(bases, offsets, n_reads, k, content, 0, out_hash, out_count, out_offsets, out_capacity,
+                              &written);
+  }
+  if (max_windows > kWaveMaxWindows) {
+    // genomes: sort path, in sub-batches whose (spectrum id | hash) keys fit 63 bits
+    const int id_bits_max = 63 - 2 * k;
+    const uint64_t sub = id_bits_max >= 32 ? n_reads : std::max<uint64_t>(1, 1ull << id_bits_max);
+    uint64_t pos = 0;
+    std::vector<uint64_t> loc;
+    for (uint64_t r0 = 0; r0 < n_reads; r0 += sub) {
+      const uint32_t nr = (uint32_t)std::min<uint64_t>(sub, n_reads - r0);
+      loc.assign(nr + 1, 0);
+      uint64_t written = 0;
+      KPOP_TRY(sorted_count_batch(bases, offsets + r0, nr, k, content, 1, out_hash + pos, out_count + pos, loc.data(),
+                                  out_capacity - pos, &written));
+      for (uint32_t i = 0; i <= nr; ++i) out_offsets[r0 + i] = pos + loc[i];
+      pos += written;
+    }
+    out_offsets[n_reads] = pos;
+    return KPOP_OK;
+  }
+  const int R = pick_R((uint32_t)max_windows);
   const uint32_t stride = 64 * R;
   const uint64_t base0 = offsets[0], n_bases = offsets[n_reads] - base0;
   hipStream_t st = nullptr;

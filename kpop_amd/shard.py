@@ -1,0 +1,66 @@
+"""Sharding the hot path over the GPUs of one node: one process per GPU.
+
+Every sequence is independent through count and twist (lib/Twister.ml:146-188 keeps no cross-spectrum
+state except the duplicate-label check, :195), so reads are cut into contiguous ranges, one per rank,
+with the twister, the class vectors and the metric replicated.
+
+  * distances against a reference set (README.md:641,656): no exchange at all; rank r produces rows
+    [lo_r, hi_r) of the result;
+  * all-vs-all distances: ONE all-gather of the twisted vectors (RCCL over xGMI when the tensors are on
+    GPUs, gloo on CPU), after which rank r computes its [hi_r-lo_r] x N block of rows.
+
+torch.distributed is plumbing here (rendezvous + the collective); nothing in this file computes.
+"""
+import numpy as np
+
+
+def shard_bounds(n_items, rank, world):
+    """Contiguous, balanced ranges: the first n_items % world ranks get one extra item."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("rank %d outside world %d" % (rank, world))
+    base, extra = divmod(int(n_items), world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_reads(offsets, rank, world):
+    """-> (lo, hi, local_offsets, base_lo, base_hi): the rank's reads and the slice of `bases` they occupy;
+    local_offsets start at 0."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    lo, hi = shard_bounds(len(offsets) - 1, rank, world)
+    local = offsets[lo:hi + 1] - offsets[lo]
+    return lo, hi, local, int(offsets[lo]), int(offsets[hi])
+
+
+def all_gather_rows(local_rows, n_total, group=None):
+    """All-gather row blocks of unequal height (shard_bounds order) into the full [n_total, D] matrix.
+    local_rows: torch tensor [n_local, D] on the rank's device.  One collective, padded to the largest shard."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    d = local_rows.shape[1]
+    sizes = [shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0] for r in range(world)]
+    if local_rows.shape[0] != sizes[rank]:
+        raise ValueError("rank %d holds %d rows, its shard has %d" % (rank, local_rows.shape[0], sizes[rank]))
+    pad = max(sizes) if sizes else 0
+    send = torch.zeros(pad, d, dtype=local_rows.dtype, device=local_rows.device)
+    send[:sizes[rank]] = local_rows
+    recv = torch.empty(world * pad, d, dtype=local_rows.dtype, device=local_rows.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    out = torch.empty(n_total, d, dtype=local_rows.dtype, device=local_rows.device)
+    for r in range(world):
+        lo, hi = shard_bounds(n_total, r, world)
+        out[lo:hi] = recv[r * pad:r * pad + (hi - lo)]
+    return out
+
+
+def merge_labelled_rows(labels, rows):
+    """The reference returns twisted rows sorted by label (bytewise; lib/Twister.ml:197-204) and refuses
+    duplicate labels (:195).  Host-side bookkeeping after the shards' rows are concatenated."""
+    enc = [l.encode("utf-8", "surrogateescape") if isinstance(l, str) else bytes(l) for l in labels]
+    order = sorted(range(len(enc)), key=lambda i: enc[i])
+    for a, b in zip(order, order[1:]):
+        if enc[a] == enc[b]:
+            raise ValueError("Duplicate_label %r" % labels[a])
+    return [labels[i] for i in order], np.asarray(rows)[order]

@@ -82,3 +82,49 @@ def test_count_errors(kpop):
     assert e.value.code == -2  # KPOP_ERR_CAPACITY
     h, c, o = kpop.count_reads(np.zeros(0, np.uint8), np.zeros(1, np.uint64), 5)
     assert len(h) == 0 and o.tolist() == [0]
+
+
+def test_count_merged_golden_vectors(kpop, oracle):
+    """-l: one spectrum for all reads (bin/KPopCount.ml:60), device-wide sort path."""
+    g = load_golden("count_small.json")
+    seqs = [s for _, s in g["reads"]]
+    bases, offs = concat(seqs)
+    for case in g["cases"]:
+        k = case["k"]
+        content = kpop.DNA_DS if case["content"] == "DNA-ds" else kpop.DNA_SS
+        h, c, o = kpop.count_reads(bases, offs, k, content, per_read=False)
+        assert o.tolist() == [0, len(case["merged"])]
+        assert [[oracle.to_hex(a, k), int(b)] for a, b in zip(h, c)] == case["merged"], (k, case["content"])
+
+
+@pytest.mark.parametrize("k", [5, 12, 16, 24])
+def test_count_merged_100k_reads(kpop, oracle, k):
+    bases, offs = oracle.synth_reads(0x4B506F70, 100000, 150)
+    spectra_equal(kpop.count_reads(bases, offs, k, per_read=False), oracle.count_reads(bases, offs, k, per_read=False))
+
+
+@pytest.mark.parametrize("k", [8, 12, 21, 30])
+def test_count_genomes_per_read(kpop, oracle, k):
+    """-L on sequences beyond one wavefront's 512 windows: wuhan (29,903 bp), a 100 kb sequence with Ns,
+    short reads in the same batch; k=30 forces sub-batches of 8 spectra (63-bit composite keys)."""
+    rng = np.random.RandomState(k)
+    wuhan = "".join(l.strip() for l in open(GOLDEN + "/wuhan.fasta") if not l.startswith(">"))
+    big = "".join(rng.choice(list("ACGT"), size=100000))
+    big = big[:50000] + "NNNNN" + big[50005:]
+    seqs = [wuhan, "ACGT" * 30, big, "", "ACG", wuhan[:600]] + random_reads(rng, 14, 0, 700)
+    bases, offs = concat(seqs)
+    spectra_equal(kpop.count_reads(bases, offs, k), oracle.count_reads(bases, offs, k))
+    spectra_equal(kpop.count_reads(bases, offs, k, kpop.DNA_SS), oracle.count_reads(bases, offs, k, oracle.DNA_SS))
+
+
+def test_count_wuhan_golden(kpop, pyref):
+    import hashlib
+    g = load_golden("wuhan_counts.json")
+    seq = "".join(l.strip() for l in open(GOLDEN + "/wuhan.fasta") if not l.startswith(">"))
+    bases, offs = concat([seq])
+    for case in g["cases"]:
+        k = case["k"]
+        h, c, o = kpop.count_reads(bases, offs, k)
+        assert len(h) == case["n_distinct"] and int(c.sum()) == case["total"]
+        text = pyref.spectrum_text("MN908947.3", {int(a): int(b) for a, b in zip(h, c)}, k)
+        assert hashlib.sha256(text.encode()).hexdigest() == case["spectrum_text_sha256"]

@@ -1,0 +1,91 @@
+"""CPU tests of the N>1 path: world_size-2 gloo.  The per-shard compute is the oracle standing in for the
+HIP kernels (tests only); what is under test is the sharding, the all-gather and the row bookkeeping."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from kpop_amd.shard import merge_labelled_rows, shard_bounds, shard_reads
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 100000, 100003):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
+
+
+def test_shard_reads_ragged():
+    offs = np.array([0, 5, 5, 12, 40, 41], dtype=np.uint64)
+    lo, hi, local, b0, b1 = shard_reads(offs, 1, 2)
+    assert (lo, hi) == (3, 5) and local.tolist() == [0, 28, 29] and (b0, b1) == (12, 41)
+
+
+def test_merge_labelled_rows():
+    labels, rows = merge_labelled_rows(["b", "a", "B"], np.arange(6).reshape(3, 2))
+    assert labels == ["B", "a", "b"] and rows.tolist() == [[4, 5], [2, 3], [0, 1]]  # bytewise order
+    with pytest.raises(ValueError):
+        merge_labelled_rows(["x", "x"], np.zeros((2, 1)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, ret):
+    import torch
+    import torch.distributed as dist
+
+    from kpop_amd.shard import all_gather_rows
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        k, d, L = 6, 5, 60
+        bases, offs = O.synth_reads(0x4B506F70, n, L)
+        cols = O.enumerate_kmers(k)
+        T = O.synth_twister(3, d, cols)
+        metric = O.metric_powers(O.synth_inertia(d))
+        lo, hi, local_offs, b0, b1 = shard_reads(offs, rank, world)
+        h, c, o = O.count_reads(bases[b0:b1], local_offs, k)  # stand-in for kpop_count_twist on this rank's GPU
+        mine = O.twist(T, cols, h, c.astype(np.float64), o)
+        full = all_gather_rows(torch.from_numpy(mine), n).numpy()
+        # all-vs-all: this rank's block of rows = distances of its reads (second operand) to everyone
+        block = O.distance_rowwise(full, mine, metric)
+        ret[rank] = (lo, hi, full, block)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [11, 64])
+def test_world_size_2_all_gather_and_distance_blocks(oracle, n):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, n, ret), nprocs=world, join=True)
+    k, d, L = 6, 5, 60
+    bases, offs = oracle.synth_reads(0x4B506F70, n, L)
+    cols = oracle.enumerate_kmers(k)
+    T = oracle.synth_twister(3, d, cols)
+    h, c, o = oracle.count_reads(bases, offs, k)
+    want = oracle.twist(T, cols, h, c.astype(np.float64), o)
+    dm = oracle.distance_rowwise(want, want, oracle.metric_powers(oracle.synth_inertia(d)))
+    rows = []
+    for r in range(world):
+        lo, hi, full, block = ret[r]
+        assert np.array_equal(full, want)            # every rank holds every twisted vector after the gather
+        assert np.array_equal(block, dm[lo:hi])      # and owns its contiguous block of distance rows
+        rows.append(block)
+    assert np.array_equal(np.concatenate(rows), dm)  # shards concatenate to the single-GPU result
