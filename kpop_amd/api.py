@@ -41,6 +41,11 @@ def init(device=0):
     check(_lib.load().kpop_init(int(device)))
 
 
+def tune(key, value):
+    """Performance knobs for A/B runs (kpop_tune); results do not depend on them."""
+    check(_lib.load().kpop_tune(key.encode(), int(value)))
+
+
 def device_count():
     n = _lib.load().kpop_device_count()
     if n < 0:

@@ -23,16 +23,17 @@
 namespace kpop {
 
 constexpr int kWavesPerBlock = 4;
-constexpr int kGatherUnroll = 8;
+constexpr int kGatherUnroll = 8;   // row loads in flight per wave in the streaming kernels
+constexpr int kGatherPad = 16;     // LDS padding: the deepest gather unroll
 
 // ---------------------------------------------------------------------------
 // per-wave LDS
 // ---------------------------------------------------------------------------
 template <int R, typename K>
 struct WaveLds {
-  K key[64 * R + kGatherUnroll];          // distinct keys (twister columns / hashes), ascending
+  K key[64 * R + kGatherPad];             // distinct keys (twister columns / hashes), ascending
   uint32_t start[64 * R + 4];             // first index of each run; [n_unique] = n_valid
-  double x[64 * R + kGatherUnroll];       // normalised multiplicities
+  double x[64 * R + kGatherPad];          // normalised multiplicities
   uint8_t codes[(codes_bytes<R>() + 15) & ~15];
 };
 
@@ -102,6 +103,7 @@ struct StoreOffsets {
 // lane owns dims lane, lane+64, ...; products and sums are NOT fused (the
 // reference is OCaml: one rounding per multiply and per add).
 // ---------------------------------------------------------------------------
+template <int U, bool NT>
 __device__ __forceinline__ void wave_gather_rows(const TwisterView &tv, const uint32_t *s_col, const double *s_x,
                                                  uint32_t nu, int lane, double *__restrict__ out_row) {
   for (uint32_t d0 = 0; d0 < tv.n_dims; d0 += 64) {
@@ -109,15 +111,16 @@ __device__ __forceinline__ void wave_gather_rows(const TwisterView &tv, const ui
     const bool active = d < tv.n_dims;
     const double *base = tv.rows + d;
     double acc = 0.0;
-    for (uint32_t u0 = 0; u0 < nu; u0 += kGatherUnroll) {
-      double v[kGatherUnroll];
+    for (uint32_t u0 = 0; u0 < nu; u0 += U) {
+      double v[U];
 #pragma unroll
-      for (int j = 0; j < kGatherUnroll; ++j) {
+      for (int j = 0; j < U; ++j) {
         const uint32_t col = s_col[u0 + j];  // padded with 0 past nu
-        v[j] = (active && u0 + j < nu) ? base[(uint64_t)col * tv.d_pad] : 0.0;
+        const double *p = base + (uint64_t)col * tv.d_pad;
+        v[j] = (active && u0 + j < nu) ? (NT ? __builtin_nontemporal_load(p) : *p) : 0.0;
       }
 #pragma unroll
-      for (int j = 0; j < kGatherUnroll; ++j) acc = __dadd_rn(acc, __dmul_rn(v[j], s_x[u0 + j]));  // x padded with 0
+      for (int j = 0; j < U; ++j) acc = __dadd_rn(acc, __dmul_rn(v[j], s_x[u0 + j]));  // x padded with 0
     }
     if (active) out_row[d] = acc;
   }
@@ -127,7 +130,7 @@ __device__ __forceinline__ void wave_gather_rows(const TwisterView &tv, const ui
 template <int R>
 __device__ __forceinline__ void wave_fill_x(WaveLds<R, uint32_t> &L, uint32_t nu, double acc, int normalize, int lane) {
   const bool norm = normalize && acc != 0.0;
-  for (uint32_t u = lane; u < nu + kGatherUnroll; u += 64) {
+  for (uint32_t u = lane; u < nu + kGatherPad; u += 64) {
     if (u < nu) {
       double c = (double)(L.start[u + 1] - L.start[u]);
       L.x[u] = norm ? c / acc : c;
@@ -142,7 +145,7 @@ __device__ __forceinline__ void wave_fill_x(WaveLds<R, uint32_t> &L, uint32_t nu
 // ---------------------------------------------------------------------------
 // fused count -> twist: one wave per read
 // ---------------------------------------------------------------------------
-template <int R, typename H>
+template <int R, typename H, int U, bool NT>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void count_twist_wave_kernel(
     TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets,
     const uint32_t *__restrict__ read_ids, uint32_t n, int content, int normalize, double *__restrict__ out) {
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void count_twist_wave_kernel(
   const uint32_t nu = wave_unique<R, uint32_t>(key, kNoCol, lane, L.key, L.start, n_valid);
   // counts are integers, so acc (:158) is exact whatever the order of the adds
   wave_fill_x<R>(L, nu, (double)n_valid, normalize, lane);
-  wave_gather_rows(tv, L.key, L.x, nu, lane, out + (uint64_t)r * tv.n_dims);
+  wave_gather_rows<U, NT>(tv, L.key, L.x, nu, lane, out + (uint64_t)r * tv.n_dims);
 }
 
 // ---------------------------------------------------------------------------
@@ -405,20 +408,33 @@ static int launch_count_wave(int R, const uint8_t *bases, const uint64_t *offset
   return 0;
 }
 
-template <typename H>
-static int launch_count_twist_wave(int R, const TwisterView &tv, const uint8_t *bases, const uint64_t *offsets,
-                                   const uint32_t *ids, uint32_t n, int content, int normalize, double *out,
-                                   hipStream_t st) {
+template <typename H, int U, bool NT>
+static int launch_count_twist_wave_v(int R, const TwisterView &tv, const uint8_t *bases, const uint64_t *offsets,
+                                     const uint32_t *ids, uint32_t n, int content, int normalize, double *out,
+                                     hipStream_t st) {
   dim3 grid(div_up(n, kWavesPerBlock)), block(64 * kWavesPerBlock);
   switch (R) {
-    case 1: count_twist_wave_kernel<1, H><<<grid, block, 0, st>>>(tv, bases, offsets, ids, n, content, normalize, out); break;
-    case 2: count_twist_wave_kernel<2, H><<<grid, block, 0, st>>>(tv, bases, offsets, ids, n, content, normalize, out); break;
-    case 4: count_twist_wave_kernel<4, H><<<grid, block, 0, st>>>(tv, bases, offsets, ids, n, content, normalize, out); break;
-    case 8: count_twist_wave_kernel<8, H><<<grid, block, 0, st>>>(tv, bases, offsets, ids, n, content, normalize, out); break;
+    case 1: count_twist_wave_kernel<1, H, U, NT><<<grid, block, 0, st>>>(tv, bases, offsets, ids, n, content, normalize, out); break;
+    case 2: count_twist_wave_kernel<2, H, U, NT><<<grid, block, 0, st>>>(tv, bases, offsets, ids, n, content, normalize, out); break;
+    case 4: count_twist_wave_kernel<4, H, U, NT><<<grid, block, 0, st>>>(tv, bases, offsets, ids, n, content, normalize, out); break;
+    case 8: count_twist_wave_kernel<8, H, U, NT><<<grid, block, 0, st>>>(tv, bases, offsets, ids, n, content, normalize, out); break;
     default: KPOP_FAIL(KPOP_ERR_INVALID, "launch_count_twist_wave: R=%d", R);
   }
   KPOP_LAUNCH_CHECK();
   return 0;
+}
+
+template <typename H>
+static int launch_count_twist_wave(int R, TwisterView tv, const uint8_t *bases, const uint64_t *offsets,
+                                   const uint32_t *ids, uint32_t n, int content, int normalize, double *out,
+                                   hipStream_t st) {
+  const Context &c = ctx();
+  if (c.tune_index == 1 && tv.lut) tv.rsel = nullptr;
+  if (c.tune_unroll == 16)
+    return c.tune_nt ? launch_count_twist_wave_v<H, 16, true>(R, tv, bases, offsets, ids, n, content, normalize, out, st)
+                     : launch_count_twist_wave_v<H, 16, false>(R, tv, bases, offsets, ids, n, content, normalize, out, st);
+  return c.tune_nt ? launch_count_twist_wave_v<H, 8, true>(R, tv, bases, offsets, ids, n, content, normalize, out, st)
+                   : launch_count_twist_wave_v<H, 8, false>(R, tv, bases, offsets, ids, n, content, normalize, out, st);
 }
 
 // sort_count.hip

@@ -14,6 +14,8 @@
 // done once per row here instead of once per pair.
 #include <math.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace kpop {
@@ -40,12 +42,15 @@ __device__ __forceinline__ double scale_distance(double x, double p) {
 // ---------------------------------------------------------------------------
 constexpr int kNormRows = 64, kNormDims = 32;
 
+// norms[i] = scale(sum_c m_c g(a_ic)), 0 -> 1 (lib/Matrix.ml:67); when `normalised` is non-null the
+// block then re-reads its 64 rows (still in L2) and writes a_ic / n_i (adaptor_a/_b, lib/Matrix.ml:248)
 template <int KIND>
 __global__ __launch_bounds__(256) void row_norms_kernel(const double *__restrict__ m, uint32_t rows, uint32_t n_dims,
                                                         const double *__restrict__ metric, double p,
-                                                        double *__restrict__ norms) {
+                                                        double *__restrict__ norms, double *__restrict__ normalised) {
   __shared__ double tile[kNormRows][kNormDims + 1];
   __shared__ double s_metric[kNormDims];
+  __shared__ double s_norm[kNormRows];
   const uint32_t row0 = blockIdx.x * kNormRows;
   double acc = 0.0;
   for (uint32_t c0 = 0; c0 < n_dims; c0 += kNormDims) {
@@ -65,70 +70,104 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const double *__restrict
       }
     }
   }
-  if (threadIdx.x < kNormRows && row0 + threadIdx.x < rows) {
+  if (threadIdx.x < kNormRows) {
     double nv = scale_distance<KIND>(acc, p);
-    norms[row0 + threadIdx.x] = (nv == 0.0) ? 1.0 : nv;  // lib/Matrix.ml:67
+    nv = (nv == 0.0) ? 1.0 : nv;  // lib/Matrix.ml:67
+    s_norm[threadIdx.x] = nv;
+    if (row0 + threadIdx.x < rows) norms[row0 + threadIdx.x] = nv;
+  }
+  if (!normalised) return;
+  __syncthreads();
+  const uint32_t nrows = min((uint32_t)kNormRows, rows - row0);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (uint32_t i = wv; i < nrows; i += 4) {  // one wave per row: coalesced, no integer division
+    const double *src = m + (uint64_t)(row0 + i) * n_dims;
+    double *dst = normalised + (uint64_t)(row0 + i) * n_dims;
+    const double nv = s_norm[i];
+    for (uint32_t c = lane; c < n_dims; c += 64) dst[c] = src[c] / nv;
   }
 }
 
-__global__ void normalise_rows_kernel(const double *__restrict__ m, uint64_t total, uint32_t n_dims,
-                                      const double *__restrict__ norms, double *__restrict__ out) {
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride)
-    out[e] = m[e] / norms[e / n_dims];  // adaptor_a / adaptor_b, lib/Matrix.ml:248
-}
-
 // ---------------------------------------------------------------------------
-// rowwise distances.  Block = 64 rows of m2 (j) x 64 rows of m1 (i); each of
-// the 256 threads owns a 4(j) x 4(i) micro-tile and walks the dimensions in
-// order, 32 at a time through LDS ([dim][row] so a thread's 4 rows are
-// contiguous).  a, b are the pre-normalised operands.
+// rowwise distances.  a, b are the pre-normalised operands.  A block owns a tile
+// of `w` m1-rows (columns of the result) x TJ m2-rows; each thread owns one
+// 4(j) x 4(i) micro-tile and walks the dimensions in ascending order, 16 at a
+// time through LDS ([dim][row], so a thread's 4 rows are one 32-byte read).
+// The tile shape adapts to r1: n_cg = ceil(w/4) column groups, n_rg =
+// floor(256/n_cg) row groups (<= 64), so r1 = 65 runs as 17 x 15 groups at 95 %
+// lane use instead of paying for a second, empty 64-wide tile.
 // ---------------------------------------------------------------------------
-constexpr int kDT = 64, kDC = 32, kDS = kDT + 1;
+constexpr int kDC = 16, kMaxW = 128, kMaxTJ = 256;
 
 template <int KIND>
-__global__ __launch_bounds__(256) void distance_rowwise_kernel(const double *__restrict__ a, uint32_t r1,
+__global__ __launch_bounds__(256) void distance_rowwise_kernel(const double *__restrict__ a, uint32_t w, uint32_t r1,
                                                                const double *__restrict__ b, uint32_t r2,
                                                                uint32_t n_dims, const double *__restrict__ metric,
-                                                               double p, double *__restrict__ out) {
-  __shared__ double As[kDC][kDS];
-  __shared__ double Bs[kDC][kDS];
+                                                               double p, double *__restrict__ out, uint32_t n_cg,
+                                                               uint32_t n_rg) {
+  __shared__ __attribute__((aligned(16))) double As[kDC][kMaxW + 2];
+  __shared__ __attribute__((aligned(16))) double Bs[kDC][kMaxTJ + 2];
   __shared__ double s_metric[kDC];
-  const uint32_t i0 = blockIdx.x * kDT, j0 = blockIdx.y * kDT;
-  const uint32_t ti = (threadIdx.x & 15) * 4, tj = (threadIdx.x >> 4) * 4;
+  const uint32_t TJ = 4 * n_rg;
+  const uint32_t i0 = blockIdx.x * w, j0 = blockIdx.y * TJ;
+  const uint32_t i1 = min(r1, i0 + w);
+  const uint32_t cg = threadIdx.x % n_cg, rg = threadIdx.x / n_cg;
+  const bool worker = rg < n_rg;
+  const uint32_t ti = cg * 4, tj = (worker ? rg : 0) * 4;
   double acc[4][4];
 #pragma unroll
   for (int y = 0; y < 4; ++y)
 #pragma unroll
     for (int x = 0; x < 4; ++x) acc[y][x] = 0.0;
-  for (uint32_t c0 = 0; c0 < n_dims; c0 += kDC) {
-    __syncthreads();
-    for (uint32_t e = threadIdx.x; e < kDT * kDC; e += 256) {
-      const uint32_t row = e / kDC, c = e % kDC;
-      const bool cok = c0 + c < n_dims;
-      As[c][row] = (cok && i0 + row < r1) ? a[(uint64_t)(i0 + row) * n_dims + c0 + c] : 0.0;
-      Bs[c][row] = (cok && j0 + row < r2) ? b[(uint64_t)(j0 + row) * n_dims + c0 + c] : 0.0;
+  // Staging is software-pipelined through registers: the global loads of chunk c+1 are issued before
+  // the arithmetic of chunk c and land in LDS after it, so HBM/L2 latency hides behind the f64 work.
+  constexpr int NA = kMaxW * kDC / 256, NB = kMaxTJ * kDC / 256;
+  double ra[NA], rb[NB];
+  const uint32_t sc = threadIdx.x % kDC, rbase = threadIdx.x / kDC;  // 16 rows per sweep of the block
+  auto prefetch = [&](uint32_t c0) {
+    const bool cok = c0 + sc < n_dims;
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const uint32_t row = rbase + q * 16;
+      ra[q] = (cok && row < w && i0 + row < i1) ? a[(uint64_t)(i0 + row) * n_dims + c0 + sc] : 0.0;
     }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const uint32_t row = rbase + q * 16;
+      rb[q] = (cok && row < TJ && j0 + row < r2) ? b[(uint64_t)(j0 + row) * n_dims + c0 + sc] : 0.0;
+    }
+  };
+  prefetch(0);
+  for (uint32_t c0 = 0; c0 < n_dims; c0 += kDC) {
+    __syncthreads();  // the previous chunk's readers are done
+#pragma unroll
+    for (int q = 0; q < NA; ++q) As[sc][rbase + q * 16] = ra[q];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) Bs[sc][rbase + q * 16] = rb[q];
     if (threadIdx.x < kDC) s_metric[threadIdx.x] = (c0 + threadIdx.x < n_dims) ? metric[c0 + threadIdx.x] : 0.0;
     __syncthreads();
+    if (c0 + kDC < n_dims) prefetch(c0 + kDC);
     const uint32_t lim = min((uint32_t)kDC, n_dims - c0);
-    for (uint32_t c = 0; c < lim; ++c) {
-      double av[4], bv[4];
+    if (worker) {
+      for (uint32_t cc = 0; cc < lim; ++cc) {
+        double av[4], bv[4];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) av[x] = As[c][ti + x];
+        for (int x = 0; x < 4; ++x) av[x] = As[cc][ti + x];
 #pragma unroll
-      for (int y = 0; y < 4; ++y) bv[y] = Bs[c][tj + y];
-      const double mc = s_metric[c];
+        for (int y = 0; y < 4; ++y) bv[y] = Bs[cc][tj + y];
+        const double mc = s_metric[cc];
 #pragma unroll
-      for (int y = 0; y < 4; ++y)
+        for (int y = 0; y < 4; ++y)
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          // lib/Space.ml:192-200: diff = a -. b ; acc +. (diff *. diff *. m)
-          double diff = __dsub_rn(av[x], bv[y]);
-          acc[y][x] = __dadd_rn(acc[y][x], component<KIND>(diff, mc, p));
-        }
+          for (int x = 0; x < 4; ++x) {
+            // lib/Space.ml:192-200: diff = a -. b ; acc +. (diff *. diff *. m)
+            double diff = __dsub_rn(av[x], bv[y]);
+            acc[y][x] = __dadd_rn(acc[y][x], component<KIND>(diff, mc, p));
+          }
+      }
     }
   }
+  if (!worker) return;
 #pragma unroll
   for (int y = 0; y < 4; ++y) {
     const uint32_t j = j0 + tj + y;
@@ -136,7 +175,7 @@ __global__ __launch_bounds__(256) void distance_rowwise_kernel(const double *__r
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
       const uint32_t i = i0 + ti + x;
-      if (i < r1) out[(uint64_t)j * r1 + i] = scale_distance<KIND>(acc[y][x], p);  // data.(j).@(i), lib/Matrix.ml:253
+      if (i < i1) out[(uint64_t)j * r1 + i] = scale_distance<KIND>(acc[y][x], p);  // data.(j).@(i), lib/Matrix.ml:253
     }
   }
 }
@@ -308,17 +347,11 @@ static int prepare_operands(const double *m1, uint32_t r1, const double *m2, uin
   }
   DistWork w = carve(work, r1, r2, n_dims);
   if (r1) {
-    row_norms_kernel<KIND><<<dim3(div_up(r1, kNormRows)), dim3(256), 0, st>>>(m1, r1, n_dims, metric, p, w.n1);
-    KPOP_LAUNCH_CHECK();
-    uint64_t tot = (uint64_t)r1 * n_dims;
-    normalise_rows_kernel<<<dim3(std::min<uint32_t>(div_up(tot, 256), 4096)), dim3(256), 0, st>>>(m1, tot, n_dims, w.n1, w.a);
+    row_norms_kernel<KIND><<<dim3(div_up(r1, kNormRows)), dim3(256), 0, st>>>(m1, r1, n_dims, metric, p, w.n1, w.a);
     KPOP_LAUNCH_CHECK();
   }
   if (r2) {
-    row_norms_kernel<KIND><<<dim3(div_up(r2, kNormRows)), dim3(256), 0, st>>>(m2, r2, n_dims, metric, p, w.n2);
-    KPOP_LAUNCH_CHECK();
-    uint64_t tot = (uint64_t)r2 * n_dims;
-    normalise_rows_kernel<<<dim3(std::min<uint32_t>(div_up(tot, 256), 4096)), dim3(256), 0, st>>>(m2, tot, n_dims, w.n2, w.b);
+    row_norms_kernel<KIND><<<dim3(div_up(r2, kNormRows)), dim3(256), 0, st>>>(m2, r2, n_dims, metric, p, w.n2, w.b);
     KPOP_LAUNCH_CHECK();
   }
   *a = w.a;
@@ -331,9 +364,15 @@ static int rowwise_impl(const double *m1, uint32_t r1, const double *m2, uint32_
                         const double *metric, double p, int normalize, void *work, double *out, hipStream_t st) {
   const double *a, *b;
   KPOP_TRY(prepare_operands<KIND>(m1, r1, m2, r2, n_dims, metric, p, normalize, work, &a, &b, st));
-  dim3 grid(div_up(r1, kDT), div_up(r2, kDT));
-  if (grid.y > 65535) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "distance_rowwise: more than %d rows in the second operand", 65535 * kDT);
-  distance_rowwise_kernel<KIND><<<grid, dim3(256), 0, st>>>(a, r1, b, r2, n_dims, metric, p, out);
+  // balanced column tiles of 64..127 columns (one tile below 128)
+  const uint32_t n_tiles = std::max(1u, r1 / 64);
+  const uint32_t w = div_up(r1, n_tiles);
+  const uint32_t n_cg = div_up(w, 4);
+  const uint32_t n_rg = std::min(256u / n_cg, (uint32_t)kMaxTJ / 4);
+  const uint32_t TJ = 4 * n_rg;
+  if (div_up(r2, TJ) > 65535) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "distance_rowwise: too many rows in the second operand (%u)", r2);
+  distance_rowwise_kernel<KIND><<<dim3(div_up(r1, w), div_up(r2, TJ)), dim3(256), 0, st>>>(a, w, r1, b, r2, n_dims, metric, p,
+                                                                                         out, n_cg, n_rg);
   KPOP_LAUNCH_CHECK();
   return 0;
 }

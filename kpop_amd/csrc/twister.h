@@ -24,6 +24,7 @@ struct kpop_twister {
   uint64_t n_sorted = 0;  // entries of the bisection table (k > kLutMaxK)
   double *d_rows = nullptr;
   uint32_t *d_lut = nullptr;
+  void *d_rsel = nullptr;  // RankWord[4^k/64], only when columns ascend with the hash
   uint64_t *d_sorted_hash = nullptr;
   uint32_t *d_sorted_col = nullptr;
   uint64_t device_bytes = 0;
@@ -34,8 +35,20 @@ namespace kpop {
 constexpr int kLutMaxK = 16;             // 4^16 * 4 B = 16 GiB of 288 GB
 constexpr uint32_t kNoCol = 0xFFFFFFFFu;
 
+// Rank-select form of the name -> column map, usable when the twister's columns
+// ascend with the k-mer hash (then column = rank of the hash among present
+// k-mers): one 16-byte word per 64 consecutive hashes = presence bits + the
+// number of present k-mers before the word.  4 MB at k=12 against the 67 MB
+// LUT: small enough to stay cache-resident next to the streamed twister rows.
+struct RankWord {
+  uint64_t bits;
+  uint32_t prefix;
+  uint32_t pad;
+};
+
 struct TwisterView {
   const double *rows;
+  const RankWord *rsel;
   const uint32_t *lut;
   const uint64_t *sorted_hash;
   const uint32_t *sorted_col;
@@ -47,13 +60,23 @@ struct TwisterView {
 };
 
 static inline TwisterView view_of(const kpop_twister *tw) {
-  return TwisterView{tw->d_rows, tw->d_lut,      tw->d_sorted_hash, tw->d_sorted_col, tw->n_cols,
-                     tw->n_sorted, tw->n_dims, tw->d_pad,        tw->k};
+  return TwisterView{tw->d_rows,        reinterpret_cast<const RankWord *>(tw->d_rsel),
+                     tw->d_lut,         tw->d_sorted_hash,
+                     tw->d_sorted_col,  tw->n_cols,
+                     tw->n_sorted,      tw->n_dims,
+                     tw->d_pad,         tw->k};
 }
 
 #if defined(__HIPCC__)
 // hash -> twister column, kNoCol when absent (lib/Twister.ml:151 Hashtbl.find_opt)
 __device__ __forceinline__ uint32_t lookup_col(const TwisterView &tv, uint64_t h) {
+  if (tv.rsel) {
+    const uint4 q = *reinterpret_cast<const uint4 *>(tv.rsel + (h >> 6));  // one 16-byte load
+    const uint64_t bits = ((uint64_t)q.y << 32) | q.x;
+    const uint32_t b = (uint32_t)h & 63u;
+    const uint64_t below = bits & ((1ull << b) - 1ull);
+    return ((bits >> b) & 1ull) ? q.z + (uint32_t)__popcll(below) : kNoCol;
+  }
   if (tv.lut) return tv.lut[h];
   uint64_t lo = 0, hi = tv.n_sorted;
   while (lo < hi) {

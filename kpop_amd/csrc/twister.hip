@@ -51,6 +51,77 @@ __global__ void lut_fixup_kernel(uint32_t *lut, uint64_t lut_size) {
   if (i < lut_size) lut[i] = lut[i] - 1u;  // 0 -> 0xFFFFFFFF (kNoCol), c+1 -> c
 }
 
+// one thread per 64-hash word: presence bits from the LUT, prefix = column of the
+// first present k-mer; *ok is cleared if columns do not ascend with the hash
+__global__ void rank_index_kernel(const uint32_t *__restrict__ lut, uint64_t n_words, uint64_t lut_size,
+                                  RankWord *__restrict__ rsel, int *ok) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  uint64_t bits = 0;
+  uint32_t prefix = 0, seen = 0;
+  bool good = true;
+  for (uint32_t b = 0; b < 64; ++b) {
+    const uint64_t h = w * 64 + b;
+    const uint32_t c = (h < lut_size) ? lut[h] : kNoCol;
+    if (c == kNoCol) continue;
+    if (seen == 0) prefix = c;
+    else if (c != prefix + seen) good = false;
+    bits |= 1ull << b;
+    ++seen;
+  }
+  rsel[w].bits = bits;
+  rsel[w].prefix = prefix;
+  rsel[w].pad = seen;
+  if (!good) *ok = 0;
+}
+
+// consecutive non-empty words must continue each other's numbering
+__global__ void rank_index_check_kernel(const RankWord *__restrict__ rsel, uint64_t n_words, int *ok) {
+  // single thread walk would be slow; each thread checks its word against the previous non-empty one
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words || rsel[w].pad == 0) return;
+  uint64_t p = w;
+  while (p > 0) {
+    --p;
+    if (rsel[p].pad) {
+      if (rsel[p].prefix + rsel[p].pad != rsel[w].prefix) *ok = 0;
+      return;
+    }
+  }
+  if (rsel[w].prefix != 0) *ok = 0;
+}
+
+static int build_rank_index(kpop_twister *tw, hipStream_t st) {
+  if (!tw->d_lut) return 0;
+  const uint64_t lut_size = 1ull << (2 * tw->k);
+  const uint64_t n_words = (lut_size + 63) / 64;
+  RankWord *rsel = nullptr;
+  KPOP_HIP(hipMalloc((void **)&rsel, n_words * sizeof(RankWord)));
+  DevBuf ok;
+  if (ok.alloc(4) != 0) {
+    (void)hipFree(rsel);
+    return KPOP_ERR_HIP;
+  }
+  int one = 1;
+  hipError_t e = hipMemcpyAsync(ok.p, &one, 4, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    rank_index_kernel<<<dim3(div_up(n_words, 256)), dim3(256), 0, st>>>(tw->d_lut, n_words, lut_size, rsel, ok.as<int>());
+    rank_index_check_kernel<<<dim3(div_up(n_words, 256)), dim3(256), 0, st>>>(rsel, n_words, ok.as<int>());
+    e = hipMemcpy(&one, ok.p, 4, hipMemcpyDeviceToHost);
+  }
+  if (e != hipSuccess) {
+    (void)hipFree(rsel);
+    KPOP_FAIL(KPOP_ERR_HIP, "build_rank_index: %s", hipGetErrorString(e));
+  }
+  if (one) {
+    tw->d_rsel = rsel;
+    tw->device_bytes += n_words * sizeof(RankWord);
+  } else {
+    (void)hipFree(rsel);  // columns not in hash order: the LUT stays the index
+  }
+  return 0;
+}
+
 struct CanonFlag {
   int k;
   int content;
@@ -108,6 +179,7 @@ extern "C" int kpop_twister_free(kpop_twister *tw) {
   if (!tw) return KPOP_OK;
   if (tw->d_rows) (void)hipFree(tw->d_rows);
   if (tw->d_lut) (void)hipFree(tw->d_lut);
+  if (tw->d_rsel) (void)hipFree(tw->d_rsel);
   if (tw->d_sorted_hash) (void)hipFree(tw->d_sorted_hash);
   if (tw->d_sorted_col) (void)hipFree(tw->d_sorted_col);
   delete tw;
@@ -189,6 +261,7 @@ extern "C" int kpop_twister_load(const double *T_dims_major, uint64_t n_cols, ui
     int h_bad = 0;
     KPOP_HIP(hipMemcpy(&h_bad, bad.p, 4, hipMemcpyDeviceToHost));
     if (h_bad) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_twister_load: a column hash does not fit k=%d", k);
+    KPOP_TRY(build_rank_index(tw, st));
   } else {
     std::vector<std::pair<uint64_t, uint32_t>> hc(n_cols);
     const uint64_t lim = kmer_mask(k);
@@ -251,6 +324,7 @@ extern "C" int kpop_twister_synth(uint64_t seed, int k, int content, uint32_t n_
   synth_rows_kernel<<<dim3(div_up(lut_size, 4)), dim3(256), 0, st>>>(seed, tw->d_lut, lut_size, n_dims, tw->d_pad,
                                                                       tw->d_rows);
   KPOP_LAUNCH_CHECK();
+  KPOP_TRY(build_rank_index(tw, st));
   KPOP_HIP(hipStreamSynchronize(st));
   guard.tw = nullptr;
   *out = tw;
