@@ -126,6 +126,36 @@ __device__ __forceinline__ void wave_gather_rows(const TwisterView &tv, const ui
   }
 }
 
+// n_dims <= 32: a row is at most 256 bytes, so one wave instruction fetches G = 64/P rows (P = 8, 16 or 32
+// lanes per row).  Group g sums the rows u = g, g+G, ... in ascending order; the G partial sums are then
+// combined by a fixed xor-butterfly (same value in every lane).  The order of adds differs from the
+// reference's single ascending chain by that last tree only: deterministic, equal up to rounding.
+template <int U, bool NT>
+__device__ __forceinline__ void wave_gather_rows_packed(const TwisterView &tv, const uint32_t *s_col, const double *s_x,
+                                                        uint32_t nu, int lane, double *__restrict__ out_row) {
+  const uint32_t P = (tv.n_dims <= 8) ? 8u : (tv.n_dims <= 16 ? 16u : 32u);
+  const uint32_t G = 64u / P, g = (uint32_t)lane / P, d = (uint32_t)lane % P;
+  const bool active = d < tv.n_dims;
+  const double *base = tv.rows + d;
+  double acc = 0.0;
+  for (uint32_t u0 = 0; u0 < nu; u0 += G * U) {
+    double v[U], x[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const uint32_t u = u0 + (uint32_t)j * G + g;
+      const uint32_t uu = min(u, nu);  // [nu] is zero padding
+      const uint32_t col = s_col[uu];
+      x[j] = s_x[uu];
+      const double *p = base + (uint64_t)col * tv.d_pad;
+      v[j] = (active && u < nu) ? (NT ? __builtin_nontemporal_load(p) : *p) : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) acc = __dadd_rn(acc, __dmul_rn(v[j], x[j]));
+  }
+  for (uint32_t off = P; off < 64; off <<= 1) acc = __dadd_rn(acc, __shfl_xor(acc, (int)off, 64));
+  if (active && g == 0) out_row[d] = acc;
+}
+
 // x_u = count_u / acc when normalising and acc <> 0 (lib/Twister.ml:177-178)
 template <int R>
 __device__ __forceinline__ void wave_fill_x(WaveLds<R, uint32_t> &L, uint32_t nu, double acc, int normalize, int lane) {
@@ -172,7 +202,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void count_twist_wave_kernel(
   const uint32_t nu = wave_unique<R, uint32_t>(key, kNoCol, lane, L.key, L.start, n_valid);
   // counts are integers, so acc (:158) is exact whatever the order of the adds
   wave_fill_x<R>(L, nu, (double)n_valid, normalize, lane);
-  wave_gather_rows<U, NT>(tv, L.key, L.x, nu, lane, out + (uint64_t)r * tv.n_dims);
+  if (tv.n_dims <= 32)
+    wave_gather_rows_packed<U, NT>(tv, L.key, L.x, nu, lane, out + (uint64_t)r * tv.n_dims);
+  else
+    wave_gather_rows<U, NT>(tv, L.key, L.x, nu, lane, out + (uint64_t)r * tv.n_dims);
 }
 
 // ---------------------------------------------------------------------------
