@@ -148,6 +148,12 @@ int kpop_distance_summary(const double *m1, uint32_t r1, const double *m2, uint3
                           uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
                           double *out_dist, double *out_z);
 
+/* Replaces Matrix.summarize_distance, lib/Matrix.ml:767-810 (KPopTwistDB -S): the same per-row summary
+ * over a distance matrix that already exists (r2 rows x r1 columns, row-major).                      */
+int kpop_summarize_distances(const double *dist, uint32_t r2, uint32_t r1, uint32_t keep_at_most,
+                             uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
+                             double *out_dist, double *out_z);
+
 /* --------------------------------------------------- device-resident path
  * Same operations on buffers already in HBM; enqueue only.                   */
 int kpop_dev_synth_reads(uint64_t seed, uint64_t n_reads, uint32_t read_len, uint64_t first_read,
@@ -174,6 +180,10 @@ int kpop_dev_distance_summary(const double *d_m1, uint32_t r1, const double *d_m
                               uint32_t keep_at_most, uint32_t max_neighbours, void *d_work,
                               double *d_out_stats, uint32_t *d_out_n, uint32_t *d_out_idx,
                               double *d_out_dist, double *d_out_z, void *stream);
+
+int kpop_dev_summarize_distances(const double *d_dist, uint32_t r2, uint32_t r1, uint32_t keep_at_most,
+                                 uint32_t max_neighbours, double *d_out_stats, uint32_t *d_out_n,
+                                 uint32_t *d_out_idx, double *d_out_dist, double *d_out_z, void *stream);
 
 #ifdef __cplusplus
 }

@@ -43,6 +43,10 @@ SIGNATURES = {
     "kpop_distance_summary": (C.c_int, [f64p, C.c_uint32, f64p, C.c_uint32, C.c_uint32, f64p, C.c_int,
                                         C.c_double, C.c_int, C.c_uint32, C.c_uint32, f64p, u32p, u32p, f64p,
                                         f64p]),
+    "kpop_summarize_distances": (C.c_int, [f64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, f64p, u32p, u32p, f64p,
+                                           f64p]),
+    "kpop_dev_summarize_distances": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp,
+                                               vp]),
     "kpop_dev_synth_reads": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, vp, vp, vp]),
     "kpop_dev_count_twist": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.c_int, vp, vp]),
     "kpop_dev_twist": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int, vp, vp]),

@@ -215,6 +215,25 @@ def distance_summary(m1, m2, metric, kind=EUCLIDEAN, p=2.0, normalize=True, keep
     return stats, n, idx, dist, z
 
 
+def summarize_distances(dist, keep_at_most=2, max_neighbours=None):
+    """Matrix.summarize_distance (lib/Matrix.ml:767-810) on an existing r2 x r1 distance matrix."""
+    dist = _c(dist, np.float64)
+    r2, r1 = dist.shape
+    if max_neighbours is None:
+        max_neighbours = r1 if not keep_at_most else min(r1, max(keep_at_most * 4, 8))
+    max_neighbours = max(int(max_neighbours), 1)
+    stats = np.zeros((r2, 4), dtype=np.float64)
+    n = np.zeros(r2, dtype=np.uint32)
+    idx = np.zeros((r2, max_neighbours), dtype=np.uint32)
+    dd = np.zeros((r2, max_neighbours), dtype=np.float64)
+    z = np.zeros((r2, max_neighbours), dtype=np.float64)
+    check(_lib.load().kpop_summarize_distances(_p(_nz(dist, np.float64), C.c_double), r2, r1, int(keep_at_most or 0),
+                                               max_neighbours, _p(_nz(stats, np.float64), C.c_double),
+                                               _p(_nz(n, np.uint32), C.c_uint32), _p(_nz(idx, np.uint32), C.c_uint32),
+                                               _p(_nz(dd, np.float64), C.c_double), _p(_nz(z, np.float64), C.c_double)))
+    return stats, n, idx, dd, z
+
+
 # ------------------------------------------------- device-resident entry points
 def dev_synth_reads(seed, n_reads, read_len, d_bases, d_offsets, first_read=0, stream=0):
     check(_lib.load().kpop_dev_synth_reads(int(seed), int(n_reads), int(read_len), int(first_read), d_bases,

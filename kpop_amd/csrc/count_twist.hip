@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void count_twist_stream_kernel(
 #pragma unroll
         for (int u = 0; u < kGatherUnroll; ++u) {
           const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)col, j0 + u);
-          v[u] = (cj != kNoCol && active) ? base[(uint64_t)cj * tv.d_pad] : 0.0;
+          v[u] = (cj != kNoCol && active) ? __builtin_nontemporal_load(base + (uint64_t)cj * tv.d_pad) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < kGatherUnroll; ++u) acc = __dadd_rn(acc, v[u]);

@@ -184,6 +184,8 @@ __global__ __launch_bounds__(256) void distance_rowwise_kernel(const double *__r
 // summary: one block per m2 row.  LDS: dist[NP] (column order), kd[NP]/ki[NP]
 // (sorted by distance then column: the FloatIntMultimap of lib/Matrix.ml:631).
 // ---------------------------------------------------------------------------
+constexpr uint32_t kSummaryMaxR1 = 4096;
+
 struct DistIdx {
   double d;
   uint32_t i;
@@ -231,7 +233,9 @@ __device__ void block_sort_keys(double *kd, uint32_t NP) {
   __syncthreads();
 }
 
-template <int KIND>
+// PRE = true: `a` is a ready r2 x r1 distance matrix (summarize_distance, lib/Matrix.ml:767-810) and row j is
+// only loaded; PRE = false: distances of m2 row j to every m1 row are computed here (summarize_rowwise).
+template <int KIND, bool PRE>
 __global__ __launch_bounds__(256) void distance_summary_kernel(
     const double *__restrict__ a, uint32_t r1, const double *__restrict__ b, uint32_t r2, uint32_t n_dims,
     const double *__restrict__ metric, double p, uint32_t NP, uint32_t req_len, uint32_t max_neighbours,
@@ -244,12 +248,14 @@ __global__ __launch_bounds__(256) void distance_summary_kernel(
   __shared__ double s_stats[4];
   __shared__ uint32_t s_eff;
   const uint32_t j = blockIdx.x;
-  const double *brow = b + (uint64_t)j * n_dims;
+  const double *brow = PRE ? nullptr : b + (uint64_t)j * n_dims;
   const double inf = __longlong_as_double(0x7FF0000000000000ll);
   // distances of row j to every m1 row (lib/Matrix.ml:744-749), one thread per m1 row
   for (uint32_t i = threadIdx.x; i < NP; i += blockDim.x) {
     double d = inf;
-    if (i < r1) {
+    if (PRE) {
+      if (i < r1) d = a[(uint64_t)j * r1 + i];
+    } else if (i < r1) {
       const double *arow = a + (uint64_t)i * n_dims;
       double acc = 0.0;
       for (uint32_t c = 0; c < n_dims; ++c) {
@@ -300,7 +306,11 @@ __global__ __launch_bounds__(256) void distance_summary_kernel(
     for (uint32_t q = threadIdx.x; q < n_out; q += blockDim.x) {
       out_idx[(uint64_t)j * max_neighbours + q] = ki[q];
       out_dist[(uint64_t)j * max_neighbours + q] = kd[q];
-      out_z[(uint64_t)j * max_neighbours + q] = __dsub_rn(kd[q], mean) / sd;
+      double zz = __dsub_rn(kd[q], mean) / sd;
+      // sd = 0 makes this 0/0 (lib/Matrix.ml:688 is unguarded).  The reference runs on x86-64, whose invalid
+      // operations return the sign-set quiet NaN ("-nan" through %.15g); gfx950 returns the positive one.
+      if (zz != zz) zz = __longlong_as_double((long long)0xFFF8000000000000ull);
+      out_z[(uint64_t)j * max_neighbours + q] = zz;
     }
   }
   __syncthreads();
@@ -377,7 +387,28 @@ static int rowwise_impl(const double *m1, uint32_t r1, const double *m2, uint32_
   return 0;
 }
 
-constexpr uint32_t kSummaryMaxR1 = 4096;
+
+template <int KIND, bool PRE>
+static int launch_summary(const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims,
+                          const double *metric, double p, uint32_t keep_at_most, uint32_t max_neighbours,
+                          double *out_stats, uint32_t *out_n, uint32_t *out_idx, double *out_dist, double *out_z,
+                          hipStream_t st) {
+  uint32_t NP = 64;
+  while (NP < r1) NP <<= 1;
+  const size_t smem = (size_t)NP * (8 + 8 + 4);
+  static bool attr_set = false;
+  if (!attr_set) {
+    KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&distance_summary_kernel<KIND, PRE>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSummaryMaxR1 * 20)));
+    attr_set = true;
+  }
+  const uint32_t req_len = keep_at_most ? keep_at_most : r1;  // lib/Matrix.ml:723-726,774-777
+  distance_summary_kernel<KIND, PRE><<<dim3(r2), dim3(256), smem, st>>>(a, r1, b, r2, n_dims, metric, p, NP, req_len,
+                                                                        max_neighbours, out_stats, out_n, out_idx,
+                                                                        out_dist, out_z);
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
 
 template <int KIND>
 static int summary_impl(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
@@ -386,21 +417,8 @@ static int summary_impl(const double *m1, uint32_t r1, const double *m2, uint32_
                         double *out_z, hipStream_t st) {
   const double *a, *b;
   KPOP_TRY(prepare_operands<KIND>(m1, r1, m2, r2, n_dims, metric, p, normalize, work, &a, &b, st));
-  uint32_t NP = 64;
-  while (NP < r1) NP <<= 1;
-  const size_t smem = (size_t)NP * (8 + 8 + 4);
-  static bool attr_set[3] = {false, false, false};
-  if (!attr_set[KIND]) {
-    KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&distance_summary_kernel<KIND>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSummaryMaxR1 * 20)));
-    attr_set[KIND] = true;
-  }
-  const uint32_t req_len = keep_at_most ? keep_at_most : r1;  // lib/Matrix.ml:723-726
-  distance_summary_kernel<KIND><<<dim3(r2), dim3(256), smem, st>>>(a, r1, b, r2, n_dims, metric, p, NP, req_len,
-                                                                   max_neighbours, out_stats, out_n, out_idx, out_dist,
-                                                                   out_z);
-  KPOP_LAUNCH_CHECK();
-  return 0;
+  return launch_summary<KIND, false>(a, r1, b, r2, n_dims, metric, p, keep_at_most, max_neighbours, out_stats, out_n,
+                                     out_idx, out_dist, out_z, st);
 }
 
 static int check_kind(int kind, double p, const char *who) {
@@ -465,9 +483,53 @@ extern "C" int kpop_dev_distance_summary(const double *d_m1, uint32_t r1, const 
   }
 }
 
+extern "C" int kpop_dev_summarize_distances(const double *d_dist, uint32_t r2, uint32_t r1, uint32_t keep_at_most,
+                                            uint32_t max_neighbours, double *d_out_stats, uint32_t *d_out_n,
+                                            uint32_t *d_out_idx, double *d_out_dist, double *d_out_z, void *stream) {
+  KPOP_TRY(require_init());
+  if (r2 == 0) return KPOP_OK;
+  if (!d_out_stats || !d_out_n || (r1 && !d_dist)) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_summarize_distances: null argument");
+  if (max_neighbours && (!d_out_idx || !d_out_dist || !d_out_z))
+    KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_summarize_distances: null neighbour buffers");
+  if (r1 > kSummaryMaxR1)
+    KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_summarize_distances: r1=%u, the HIP path covers up to %u columns", r1,
+              kSummaryMaxR1);
+  return launch_summary<KPOP_EUCLIDEAN, true>(d_dist, r1, nullptr, r2, 1, nullptr, 2.0, keep_at_most, max_neighbours,
+                                              d_out_stats, d_out_n, d_out_idx, d_out_dist, d_out_z, as_stream(stream));
+}
+
 // ---------------------------------------------------------------------------
 // host-buffer entry points
 // ---------------------------------------------------------------------------
+extern "C" int kpop_summarize_distances(const double *dist, uint32_t r2, uint32_t r1, uint32_t keep_at_most,
+                                        uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
+                                        double *out_dist, double *out_z) {
+  KPOP_TRY(require_init());
+  if (r2 == 0) return KPOP_OK;
+  if (!out_stats || !out_n || (r1 && !dist)) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_summarize_distances: null argument");
+  hipStream_t st = nullptr;
+  DevBuf dd, ds, dn, di, dv, dz;
+  const uint64_t nn = (uint64_t)r2 * max_neighbours;
+  KPOP_TRY(dd.alloc((uint64_t)r1 * r2 * 8));
+  KPOP_TRY(ds.alloc((uint64_t)r2 * 4 * 8));
+  KPOP_TRY(dn.alloc((uint64_t)r2 * 4));
+  KPOP_TRY(di.alloc(nn * 4));
+  KPOP_TRY(dv.alloc(nn * 8));
+  KPOP_TRY(dz.alloc(nn * 8));
+  if (r1) KPOP_HIP(hipMemcpyAsync(dd.p, dist, (uint64_t)r1 * r2 * 8, hipMemcpyHostToDevice, st));
+  KPOP_TRY(kpop_dev_summarize_distances(dd.as<double>(), r2, r1, keep_at_most, max_neighbours, ds.as<double>(),
+                                        dn.as<uint32_t>(), di.as<uint32_t>(), dv.as<double>(), dz.as<double>(), st));
+  KPOP_HIP(hipMemcpyAsync(out_stats, ds.p, (uint64_t)r2 * 4 * 8, hipMemcpyDeviceToHost, st));
+  KPOP_HIP(hipMemcpyAsync(out_n, dn.p, (uint64_t)r2 * 4, hipMemcpyDeviceToHost, st));
+  if (nn) {
+    KPOP_HIP(hipMemcpyAsync(out_idx, di.p, nn * 4, hipMemcpyDeviceToHost, st));
+    KPOP_HIP(hipMemcpyAsync(out_dist, dv.p, nn * 8, hipMemcpyDeviceToHost, st));
+    KPOP_HIP(hipMemcpyAsync(out_z, dz.p, nn * 8, hipMemcpyDeviceToHost, st));
+  }
+  KPOP_HIP(hipStreamSynchronize(st));
+  return KPOP_OK;
+}
+
 extern "C" int kpop_distance_rowwise(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
                                      const double *metric, int kind, double p, int normalize, double *out) {
   KPOP_TRY(require_init());

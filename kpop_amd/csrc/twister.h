@@ -70,6 +70,7 @@ static inline TwisterView view_of(const kpop_twister *tw) {
 #if defined(__HIPCC__)
 // hash -> twister column, kNoCol when absent (lib/Twister.ml:151 Hashtbl.find_opt)
 __device__ __forceinline__ uint32_t lookup_col(const TwisterView &tv, uint64_t h) {
+  if (h >> (2 * tv.k)) return kNoCol;  // not a k-mer of this twister's k (caller-supplied spectra)
   if (tv.rsel) {
     const uint4 q = *reinterpret_cast<const uint4 *>(tv.rsel + (h >> 6));  // one 16-byte load
     const uint64_t bits = ((uint64_t)q.y << 32) | q.x;

@@ -1,0 +1,254 @@
+// KPopCount -- drop-in for the reference's bin/KPopCount.ml on the MI355X hot path.
+//
+// Same options, same spectra text on stdout / <prefix>.KPopSpectra.txt
+// (bin/KPopCount.ml:108-212, 26-63).  The per-read hashing/counting loop
+// (:36-50) runs in libkpop_hip.so; this file is argument parsing, FASTA/FASTQ
+// reading and printf.
+//
+// Differences from the reference, on purpose:
+//   * k-mers inside a spectrum are printed in ascending hash order (the
+//     reference prints in Hashtbl order, which is unspecified; every consumer
+//     keys by name: lib/Twister.ml:151, lib/KMerDB.ml:536-562);
+//   * -M is accepted but nothing is ever spilled: the -l spectrum is always
+//     fully merged (the reference spills partial tables with repeated hashes
+//     that consumers re-sum, bin/KPopCount.ml:39-50);
+//   * a runtime failure exits with status 1 (the reference's DB tools print
+//     the exception and exit 0);
+//   * protein content is refused (not on the HIP path).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/kpop_hip.h"
+#include "kpop_text.h"
+
+using namespace kpop_host;
+
+namespace {
+
+struct Input {
+  SeqFormat fmt;
+  std::string a, b;  // b non-empty: paired-end
+};
+
+struct Params {
+  int k = 12;                     // bin/KPopCount.ml:88
+  uint64_t max_results = 16777216;  // :89
+  int content = KPOP_DNA_DS;      // :87
+  std::vector<Input> inputs;
+  bool have_l_or_L = false;
+  std::string label;
+  std::string output;
+  bool verbose = false;
+};
+
+const char *kVersion = "18-hip";
+
+void usage(FILE *f) {
+  fprintf(f,
+          "This is KPopCount (MI355X/HIP hot path) version %s\n"
+          "Usage: KPopCount -l <output_vector_label>|-L [OPTIONS]\n"
+          " -k|-K|--k-mer-size|--k-mer-length <k>   k-mer length (1..30 for DNA; default 12)\n"
+          " -M|--max-results-size <n>               accepted for compatibility (nothing is spilled)\n"
+          " -C|--content DNA-ss|DNA-single-stranded|DNA-ds|DNA-double-stranded|protein   (default DNA-ds)\n"
+          " -f|--fasta <file>                       FASTA input (repeatable)\n"
+          " -s|--single-end <file>                  FASTQ input (repeatable)\n"
+          " -p|--paired-end <file1> <file2>         paired FASTQ input (repeatable)\n"
+          " -l|--label <label>                      one spectrum for all input, with this label\n"
+          " -L|--one-spectrum-per-sequence          one spectrum per sequence, labelled by its name\n"
+          " -o|--output <prefix>                    write <prefix>.KPopSpectra.txt (default stdout)\n"
+          " -v|--verbose  -V|--version  -h|--help\n",
+          kVersion);
+}
+
+[[noreturn]] void parse_error(const std::string &msg) {
+  usage(stderr);
+  fprintf(stderr, "(KPopCount): ERROR: %s\n", msg.c_str());
+  exit(1);
+}
+
+void check(int rc) {
+  if (rc != 0) throw Error(std::string("libkpop_hip: ") + kpop_last_error());
+}
+
+struct Merged {  // running -l spectrum: ascending hashes
+  std::vector<uint64_t> hash;
+  std::vector<uint64_t> count;
+  void add(const uint64_t *h, const uint32_t *c, uint64_t n) {
+    std::vector<uint64_t> nh, nc;
+    nh.reserve(hash.size() + n);
+    nc.reserve(hash.size() + n);
+    size_t i = 0, j = 0;
+    while (i < hash.size() || j < n) {
+      if (j == n || (i < hash.size() && hash[i] < h[j])) {
+        nh.push_back(hash[i]);
+        nc.push_back(count[i]);
+        ++i;
+      } else if (i == hash.size() || h[j] < hash[i]) {
+        nh.push_back(h[j]);
+        nc.push_back(c[j]);
+        ++j;
+      } else {
+        nh.push_back(hash[i]);
+        nc.push_back(count[i] + c[j]);
+        ++i;
+        ++j;
+      }
+    }
+    hash.swap(nh);
+    count.swap(nc);
+  }
+};
+
+void process_batch(const Params &P, const ReadBatch &b, FILE *out, Merged &merged, std::vector<uint64_t> &oh,
+                   std::vector<uint32_t> &oc, std::vector<uint64_t> &oo) {
+  if (b.size() == 0) return;
+  const bool per_read = P.label.empty();
+  const uint64_t cap = b.bases.size() + 1;
+  oh.resize(cap);
+  oc.resize(cap);
+  oo.assign(per_read ? b.size() + 1 : 2, 0);
+  static const uint8_t dummy = 0;
+  check(kpop_count_reads(b.bases.empty() ? &dummy : b.bases.data(), b.offsets.data(), (uint32_t)b.size(), P.k, P.content,
+                         per_read ? 1 : 0, oh.data(), oc.data(), oo.data(), cap));
+  if (per_read) {
+    for (size_t r = 0; r < b.size(); ++r)  // bin/KPopCount.ml:44-46
+      write_spectrum(out, strip_external_quotes_and_check(b.tags[r]), oh.data() + oo[r], oc.data() + oo[r], oo[r + 1] - oo[r],
+                     P.k);
+  } else {
+    merged.add(oh.data(), oc.data(), oo[1]);
+  }
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  Params P;
+  auto need = [&](int &i, const char *opt) -> std::string {
+    if (i + 1 >= argc) parse_error(std::string("Option '") + opt + "' needs a parameter");
+    return argv[++i];
+  };
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    if (a == "-k" || a == "-K" || a == "--k-mer-size" || a == "--k-mer-length") {
+      P.k = atoi(need(i, a.c_str()).c_str());
+      if (P.k <= 0) parse_error("k-mer length must be positive");
+    } else if (a == "-M" || a == "--max-results-size") {
+      long long v = atoll(need(i, a.c_str()).c_str());
+      if (v <= 0) parse_error("maximum results size must be positive");
+      P.max_results = (uint64_t)v;
+    } else if (a == "-C" || a == "--content") {
+      const std::string c = need(i, a.c_str());
+      if (c == "DNA-ss" || c == "DNA-single-stranded") P.content = KPOP_DNA_SS;
+      else if (c == "DNA-ds" || c == "DNA-double-stranded") P.content = KPOP_DNA_DS;
+      else if (c == "protein" || c == "prot") parse_error("protein content is not supported by the HIP path");
+      else parse_error("Invalid_content(\"" + c + "\")");
+    } else if (a == "-f" || a == "--fasta") {
+      P.inputs.push_back({SeqFormat::FASTA, need(i, a.c_str()), ""});
+    } else if (a == "-s" || a == "--single-end") {
+      P.inputs.push_back({SeqFormat::FASTQ, need(i, a.c_str()), ""});
+    } else if (a == "-p" || a == "--paired-end") {
+      std::string f1 = need(i, a.c_str());
+      std::string f2 = need(i, a.c_str());
+      P.inputs.push_back({SeqFormat::FASTQ, f1, f2});
+    } else if (a == "-l" || a == "--label") {
+      P.have_l_or_L = true;
+      try {
+        P.label = strip_external_quotes_and_check(need(i, a.c_str()));
+      } catch (const Error &) {
+        parse_error("Spectrum labels must not contain quotes");  // bin/KPopCount.ml:171
+      }
+    } else if (a == "-L" || a == "--one-spectrum-per-sequence") {
+      P.have_l_or_L = true;
+    } else if (a == "-o" || a == "--output") {
+      P.output = make_filename(need(i, a.c_str()), "KPopSpectra", true);
+    } else if (a == "-v" || a == "--verbose") {
+      P.verbose = true;
+    } else if (a == "-V" || a == "--version") {
+      printf("%s\n", kVersion);
+      return 0;
+    } else if (a == "-h" || a == "--help") {
+      usage(stdout);
+      return 1;  // bin/KPopCount.ml:211
+    } else {
+      parse_error("Unknown option '" + a + "'");
+    }
+  }
+  if (!P.have_l_or_L) parse_error("One of options '-l' and '-L' is mandatory");  // :213-214
+  if (P.k > 30) parse_error("k-mer length must be <= 30 for DNA");                // :113
+  for (size_t i = 1; i < P.inputs.size(); ++i)
+    if (P.inputs[i].fmt != P.inputs[0].fmt) parse_error("You cannot process FASTA and FASTQ inputs together");  // :236
+  if (P.inputs.empty()) return 0;  // :218
+
+  try {
+    int dev = 0;
+    if (const char *e = getenv("KPOP_DEVICE")) dev = atoi(e);
+    check(kpop_init(dev));
+    FILE *out = P.output.empty() ? stdout : fopen(P.output.c_str(), "wb");
+    if (!out) throw Error("cannot write '" + P.output + "'");
+    std::vector<char> iobuf(1 << 22);
+    setvbuf(out, iobuf.data(), _IOFBF, iobuf.size());
+    if (!P.label.empty()) fprintf(out, "\t%s\n", P.label.c_str());  // :33-34
+    const uint64_t max_bases = 256ull << 20, max_reads = 4u << 20;
+    ReadBatch batch;
+    batch.clear();
+    Merged merged;
+    std::vector<uint64_t> oh, oo;
+    std::vector<uint32_t> oc;
+    uint64_t n_reads = 0;
+    for (const Input &in : P.inputs) {
+      if (in.b.empty()) {
+        SeqReader rd(in.a, in.fmt);
+        for (;;) {
+          bool more = rd.next_batch(batch, max_bases, max_reads);
+          if (batch.size() >= max_reads || batch.bases.size() >= max_bases || !more) {
+            n_reads += batch.size();
+            process_batch(P, batch, out, merged, oh, oc, oo);
+            batch.clear();
+          }
+          if (!more) break;
+        }
+      } else {  // mates alternate: segment 0, segment 1, ... (bin/KPopCount.ml:36-54)
+        SeqReader r1(in.a, in.fmt), r2(in.b, in.fmt);
+        std::string t1, s1, t2, s2;
+        for (;;) {
+          bool m1 = r1.next_record(t1, s1), m2 = r2.next_record(t2, s2);
+          if (m1 != m2) throw Error("paired-end files '" + in.a + "' and '" + in.b + "' have different numbers of reads");
+          if (!m1) break;
+          for (int m = 0; m < 2; ++m) {
+            const std::string &s = m ? s2 : s1;
+            batch.bases.insert(batch.bases.end(), s.begin(), s.end());
+            batch.offsets.push_back(batch.bases.size());
+            batch.tags.push_back(m ? t2 : t1);
+          }
+          ++n_reads;
+          if (batch.size() >= max_reads || batch.bases.size() >= max_bases) {
+            process_batch(P, batch, out, merged, oh, oc, oo);
+            batch.clear();
+          }
+        }
+        process_batch(P, batch, out, merged, oh, oc, oo);
+        batch.clear();
+      }
+    }
+    if (!P.label.empty()) {  // final dump, bin/KPopCount.ml:60
+      std::vector<uint32_t> c32(merged.count.size());
+      for (size_t i = 0; i < c32.size(); ++i) {
+        if (merged.count[i] > 0x7FFFFFFFull) throw Error("k-mer count exceeds 2^31-1");
+        c32[i] = (uint32_t)merged.count[i];
+      }
+      write_spectrum_body(out, merged.hash.data(), c32.data(), c32.size(), P.k);
+    }
+    if (P.verbose) fprintf(stderr, "(KPopCount): Added %llu reads.\n", (unsigned long long)n_reads);
+    if (out != stdout) fclose(out);
+    else fflush(out);
+  } catch (const std::exception &e) {
+    fprintf(stderr, "(KPopCount): FATAL: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -1,0 +1,502 @@
+// KPopTwistDB -- drop-in for the hot actions of the reference's bin/KPopTwistDB.ml.
+//
+// Same register machine (bin/KPopTwistDB.ml:410-417), same option names, actions
+// executed in command-line order (:361,:437).  Hot actions run in libkpop_hip.so:
+//   -k  Twister.add_twisted_from_files   lib/Twister.ml:58-206   -> kpop_twist
+//   -d  Matrix.get_distance_rowwise      lib/Matrix.ml:621-630   -> kpop_distance_rowwise
+//   -s  Matrix.summarize_rowwise         lib/Matrix.ml:691-766   -> kpop_distance_summary
+//   -S  Matrix.summarize_distance        lib/Matrix.ml:767-810   -> kpop_summarize_distances
+// This file is argument parsing, the text formats, and the label bookkeeping of
+// lib/Twister.ml:189-206.
+//
+// Not covered (outside the hot path): embeddings (-e), splits (-p), and the OCaml-Marshal
+// binaries (-i/-a/-o; '.KPopTwister' etc.).  Where the reference takes a BINARY twisted prefix (-d, -s) this
+// tool reads '<prefix>.KPopTwisted.txt'.  Runtime failures exit 1 (the reference prints and exits 0).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/kpop_hip.h"
+#include "kpop_text.h"
+
+using namespace kpop_host;
+
+namespace {
+
+const char *kVersion = "38-hip";
+
+enum class Reg { Metrics, Twister, Twisted, Embeddings, Distances, Splits };
+
+Reg reg_of_string(const std::string &s) {  // bin/KPopTwistDB.ml:30-39
+  if (s == "m") return Reg::Metrics;
+  if (s == "T") return Reg::Twister;
+  if (s == "t") return Reg::Twisted;
+  if (s == "e") return Reg::Embeddings;
+  if (s == "d") return Reg::Distances;
+  if (s == "s") return Reg::Splits;
+  throw Error("Invalid_register_type(\"" + s + "\")");
+}
+
+struct Action {
+  enum Kind {
+    Empty, TablesToRegister, AddTablesToRegister, BinaryUnsupported, SetKmersNormalize, AddKmersFiles, RegisterToTables,
+    SetPrecision, SetDistance, SetDistanceNormalize, SetMetric, DistancesFromTwisted, SetSummaryKeepAtMost,
+    SummaryFromTwisted, SummaryFromDistances, Unsupported
+  } kind;
+  Reg reg = Reg::Twisted;
+  std::string s1, s2;
+  std::vector<std::string> files;
+  bool flag = false;
+  long long num = 0;
+};
+
+struct Metric {
+  int kind = KPOP_METRIC_POWERS;
+  double pi = 1., thr = 1., pe = 2.;  // powers(1,1,2), bin/KPopTwistDB.ml:92
+};
+
+Metric metric_of_string(const std::string &s) {  // lib/Space.ml:109-131
+  Metric m;
+  if (s == "flat") {
+    m.kind = KPOP_METRIC_FLAT;
+    return m;
+  }
+  double a, b, c;
+  char tail;
+  if (sscanf(s.c_str(), "powers(%lf,%lf,%lf%c", &a, &b, &c, &tail) != 4 || tail != ')' || s.back() != ')')
+    throw Error("Unknown_metric(\"" + s + "\")");
+  if (a < 0.) throw Error("Negative_power(" + format_g(a, 15) + ")");
+  if (b < 0. || b > 1.) throw Error("Invalid_threshold(" + format_g(b, 15) + ")");
+  if (c < 0.) throw Error("Negative_power(" + format_g(c, 15) + ")");
+  m.kind = KPOP_METRIC_POWERS;
+  m.pi = a;
+  m.thr = b;
+  m.pe = c;
+  return m;
+}
+
+struct Distance {
+  int kind = KPOP_EUCLIDEAN;
+  double p = 2.;
+};
+
+Distance distance_of_string(const std::string &s) {  // lib/Space.ml:208-225
+  Distance d;
+  if (s == "euclidean") return d;
+  if (s == "cosine") {
+    d.kind = KPOP_COSINE;
+    return d;
+  }
+  double p;
+  char tail;
+  if (sscanf(s.c_str(), "minkowski(%lf%c", &p, &tail) != 2 || tail != ')' || s.back() != ')')
+    throw Error("Unknown_distance(\"" + s + "\")");
+  if (p < 0.) throw Error("Negative_power(" + format_g(p, 15) + ")");
+  d.kind = KPOP_MINKOWSKI;
+  d.p = p;
+  return d;
+}
+
+bool bool_of_string(const std::string &s) {
+  if (s == "true") return true;
+  if (s == "false") return false;
+  throw Error("expected 'true' or 'false', got '" + s + "'");
+}
+
+void usage(FILE *f) {
+  fprintf(f,
+          "This is KPopTwistDB (MI355X/HIP hot path) version %s\n"
+          "Usage: KPopTwistDB [ACTIONS]   (executed in order of specification)\n"
+          " -z|--zero|--empty T|t|d                  empty the register\n"
+          " -I|--Input T|t|d <table_prefix>          load .KPopTwister.txt+.KPopInertia.txt | .KPopTwisted.txt | .KPopDMatrix.txt\n"
+          " -A|--Add t|d <table_prefix>              add the rows of a table to the register\n"
+          " --counts-normalize true|false            normalise spectra before twisting (default true)\n"
+          " -k|--kmers|--add-kmers|--add-kmer-files <file>[,<file>...]   twist spectra, add to the twisted register\n"
+          " --distance euclidean|cosine|minkowski(p) (default euclidean)\n"
+          " --distance-normalize true|false          (default true)\n"
+          " -m|--metric flat|powers(a,b,c)           (default powers(1,1,2))\n"
+          " -d|--distances <twisted_prefix>          distances between the twisted register and <prefix>.KPopTwisted.txt\n"
+          " --precision-for-tables <n>               (default 15)\n"
+          " -O|--Output T|t|d|m <table_prefix>       write the register as table(s)\n"
+          " --summary-at-most|--summary-keep-at-most <n>|all   (default 2)\n"
+          " -s|--compute-and-summarize-distances <twisted_prefix> <summary_prefix>\n"
+          " -S|--summarize-distances <summary_prefix>\n"
+          " -T|--threads <n> (ignored)  -v|--verbose  -V|--version  -h|--help\n"
+          "Binary registers (-i, -a, -o), embeddings (-e) and splits (-p) are not provided by this tool.\n",
+          kVersion);
+}
+
+[[noreturn]] void parse_error(const std::string &msg) {
+  usage(stderr);
+  fprintf(stderr, "(KPopTwistDB): ERROR: %s\n", msg.c_str());
+  exit(1);
+}
+
+void check(int rc) {
+  if (rc != 0) throw Error(std::string("libkpop_hip: ") + kpop_last_error());
+}
+
+bool g_gpu = false;
+void need_gpu() {
+  if (g_gpu) return;
+  int dev = 0;
+  if (const char *e = getenv("KPOP_DEVICE")) dev = atoi(e);
+  check(kpop_init(dev));
+  g_gpu = true;
+}
+
+struct TwisterReg {
+  Table twister, inertia;  // dims x k-mers ; 1 x dims
+  kpop_twister *dev = nullptr;
+  size_t name_len = 0;
+  void reset() {
+    if (dev) kpop_twister_free(dev);
+    dev = nullptr;
+    twister = Table();
+    inertia = Table();
+  }
+  void upload() {
+    if (dev) return;
+    need_gpu();
+    const size_t n = twister.cols();
+    std::vector<uint64_t> col_hash(n);
+    name_len = n ? twister.col_names[0].size() : 0;
+    for (size_t c = 0; c < n; ++c) {
+      const std::string &nm = twister.col_names[c];
+      if (nm.size() != name_len || !hex_to_hash(nm, &col_hash[c]))
+        throw Error("twister column '" + nm + "' is not a fixed-width hexadecimal k-mer hash (only DNA spectra produced by KPopCount are on the HIP path)");
+    }
+    const int k = (int)std::min<size_t>(2 * name_len, 30);  // names carry ceil(k/2) hex digits; the larger k covers both
+    if (name_len > 15) throw Error("k-mer names longer than 15 hex digits");
+    check(kpop_twister_load(twister.data.data(), n, (uint32_t)twister.rows(), col_hash.data(), std::max(k, 1), &dev));
+  }
+};
+
+void load_twister_tables(TwisterReg &T, const std::string &prefix) {  // Twister.of_files, lib/Twister.ml:32-51
+  T.reset();
+  T.twister = read_table(make_filename(prefix, "KPopTwister", true));
+  T.inertia = read_table(make_filename(prefix, "KPopInertia", true));
+  if (T.inertia.row_names != std::vector<std::string>{"inertia"} || T.twister.row_names != T.inertia.col_names)
+    throw Error("Mismatched_twister_files");  // :36-49
+}
+
+std::vector<double> metric_vector(const Metric &m, const TwisterReg &T) {  // Twister.get_metrics_vector, lib/Twister.ml:208-209
+  std::vector<double> out(T.inertia.cols());
+  check(kpop_metric_compute(m.kind, T.inertia.data.data(), (uint32_t)out.size(), m.pi, m.thr, m.pe, out.data()));
+  return out;
+}
+
+// Twister.add_twisted_from_files, lib/Twister.ml:58-206
+void add_twisted_from_files(TwisterReg &T, Table &twisted, const std::vector<std::string> &files, bool normalize, bool verbose) {
+  const std::vector<std::string> &dims = T.twister.row_names;
+  if (!twisted.empty() && twisted.col_names != dims) throw Error("Incompatible_twister_and_twisted");  // :64-69
+  T.upload();
+  Spectra sp;
+  for (const std::string &f : files) {
+    read_spectra_file(f, sp);
+    if (verbose) fprintf(stderr, "(KPopTwistDB): File '%s': read %zu spectra so far\n", f.c_str(), sp.labels.size());
+  }
+  // names -> hashes; a name the twister cannot hold is simply an unknown k-mer (:167-169)
+  const size_t n_lines = sp.names.size();
+  std::vector<uint64_t> hash(n_lines);
+  const uint64_t absent = ~0ull >> 1;  // no twister column carries this hash (k <= 30)
+  for (size_t i = 0; i < n_lines; ++i)
+    if (sp.names[i].size() != T.name_len || !hex_to_hash(sp.names[i], &hash[i])) hash[i] = absent;
+  const size_t n = sp.labels.size(), d = dims.size();
+  std::vector<double> rows(n * d);
+  if (n) check(kpop_twist(T.dev, hash.data(), sp.values.data(), sp.offsets.data(), (uint32_t)n, normalize ? 1 : 0, rows.data()));
+  // StringMap of label -> row: existing rows first, new labels must be new (:78-82,:189-195), result in
+  // bytewise label order (:197-204)
+  std::map<std::string, std::pair<const double *, size_t>> res;
+  for (size_t r = 0; r < twisted.rows(); ++r) res[twisted.row_names[r]] = {twisted.data.data() + r * d, 0};
+  for (size_t r = 0; r < n; ++r) {
+    if (res.count(sp.labels[r])) throw Error("Duplicate_label(\"" + sp.labels[r] + "\")");
+    res[sp.labels[r]] = {rows.data() + r * d, 0};
+  }
+  Table out;
+  out.col_names = dims;
+  out.data.reserve(res.size() * d);
+  for (auto &kv : res) {
+    out.row_names.push_back(kv.first);
+    out.data.insert(out.data.end(), kv.second.first, kv.second.first + d);
+  }
+  twisted.col_names.swap(out.col_names);
+  twisted.row_names.swap(out.row_names);
+  twisted.data.swap(out.data);
+}
+
+void write_summary(const std::string &path, const std::vector<std::string> &row_names, const std::vector<std::string> &col_names,
+                   const std::vector<double> &stats, const std::vector<uint32_t> &n, const std::vector<uint32_t> &idx,
+                   const std::vector<double> &dist, const std::vector<double> &z, uint32_t stride, bool quote) {
+  FILE *f = (path == "/dev/stdout") ? stdout : fopen(path.c_str(), "wb");
+  if (!f) throw Error("cannot write '" + path + "'");
+  const char *q = quote ? "\"" : "";
+  for (size_t j = 0; j < row_names.size(); ++j) {  // lib/Matrix.ml:684-690
+    fprintf(f, "%s%s%s\t%.15g\t%.15g\t%.15g\t%.15g", q, row_names[j].c_str(), q, stats[j * 4], stats[j * 4 + 1], stats[j * 4 + 2],
+            stats[j * 4 + 3]);
+    if (n[j] > stride) {
+      if (f != stdout) fclose(f);
+      throw Error("summary row '" + row_names[j] + "' has " + std::to_string(n[j]) + " tied neighbours, more than fit");
+    }
+    for (uint32_t e = 0; e < n[j]; ++e)
+      fprintf(f, "\t%s%s%s\t%.15g\t%.15g", q, col_names[idx[j * stride + e]].c_str(), q, dist[j * stride + e], z[j * stride + e]);
+    fputc('\n', f);
+  }
+  if (f != stdout) fclose(f);
+  else fflush(f);
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  std::vector<Action> program;
+  bool verbose = false, quote_summary = false;
+  auto need = [&](int &i, const std::string &opt) -> std::string {
+    if (i + 1 >= argc) parse_error("Option '" + opt + "' needs a parameter");
+    return argv[++i];
+  };
+  try {
+    for (int i = 1; i < argc; ++i) {
+      const std::string a = argv[i];
+      Action act;
+      if (a == "-z" || a == "--zero" || a == "--empty") {
+        act.kind = Action::Empty;
+        act.reg = reg_of_string(need(i, a));
+        if (act.reg == Reg::Metrics || act.reg == Reg::Splits) parse_error("You cannot load content into the metric or splits registers");
+      } else if (a == "-i" || a == "--input" || a == "-a" || a == "--add" || a == "-o" || a == "--output") {
+        act.kind = Action::BinaryUnsupported;
+        act.s1 = need(i, a);
+        act.s2 = need(i, a);
+      } else if (a == "-I" || a == "--Input") {
+        act.kind = Action::TablesToRegister;
+        act.reg = reg_of_string(need(i, a));
+        if (act.reg == Reg::Metrics || act.reg == Reg::Splits) parse_error("You cannot load content into the metric or splits registers");
+        act.s1 = need(i, a);
+      } else if (a == "-A" || a == "--Add") {
+        act.kind = Action::AddTablesToRegister;
+        act.reg = reg_of_string(need(i, a));
+        if (act.reg == Reg::Twister || act.reg == Reg::Metrics || act.reg == Reg::Splits)
+          parse_error("You cannot add content to the twister, metric or splits registers");
+        act.s1 = need(i, a);
+      } else if (a == "--counts-normalize" || a == "--counts-normalization") {
+        act.kind = Action::SetKmersNormalize;
+        act.flag = bool_of_string(need(i, a));
+      } else if (a == "-k" || a == "--kmers" || a == "--add-kmers" || a == "--add-kmer-files") {
+        act.kind = Action::AddKmersFiles;
+        std::string l = need(i, a);
+        size_t st = 0;
+        for (;;) {
+          size_t p = l.find(',', st);
+          act.files.push_back(l.substr(st, p == std::string::npos ? p : p - st));
+          if (p == std::string::npos) break;
+          st = p + 1;
+        }
+      } else if (a == "--distance" || a == "--distance-function") {
+        act.kind = Action::SetDistance;
+        act.s1 = need(i, a);
+        distance_of_string(act.s1);
+      } else if (a == "--distance-normalize" || a == "--distance-normalization") {
+        act.kind = Action::SetDistanceNormalize;
+        act.flag = bool_of_string(need(i, a));
+      } else if (a == "-m" || a == "--metric" || a == "--metric-function") {
+        act.kind = Action::SetMetric;
+        act.s1 = need(i, a);
+        metric_of_string(act.s1);
+      } else if (a == "-d" || a == "--distances" || a == "--compute-distances" || a == "--compute-twisted-distances") {
+        act.kind = Action::DistancesFromTwisted;
+        act.s1 = need(i, a);
+      } else if (a == "--precision-for-tables") {
+        act.kind = Action::SetPrecision;
+        act.num = atoll(need(i, a).c_str());
+        if (act.num <= 0) parse_error("precision must be positive");
+      } else if (a == "-O" || a == "--Output") {
+        act.kind = Action::RegisterToTables;
+        act.reg = reg_of_string(need(i, a));
+        act.s1 = need(i, a);
+      } else if (a == "--summary-at-most" || a == "--summary-keep-at-most") {
+        act.kind = Action::SetSummaryKeepAtMost;
+        std::string v = need(i, a);
+        if (v == "all") act.num = 0;
+        else {
+          act.num = atoll(v.c_str());
+          if (act.num <= 0) parse_error("Invalid_keep_at_most(\"" + v + "\")");  // bin/KPopTwistDB.ml:46-56
+        }
+      } else if (a == "-s" || a == "--compute-and-summarize-distances" || a == "--compute-and-summarize-twisted-distances") {
+        act.kind = Action::SummaryFromTwisted;
+        act.s1 = need(i, a);
+        act.s2 = need(i, a);
+      } else if (a == "-S" || a == "--summarize-distances" || a == "--summarize-twisted-distances") {
+        act.kind = Action::SummaryFromDistances;
+        act.s1 = need(i, a);
+      } else if (a == "-e" || a == "--embeddings" || a == "--compute-embeddings" || a == "--twisted-to-embeddings" || a == "-p" ||
+                 a == "--splits" || a == "--compute-splits" || a == "--embeddings-to-splits") {
+        act.kind = Action::Unsupported;
+        act.s1 = a;
+      } else if (a == "--splits-algorithm" || a == "--splits-at-most" || a == "--splits-keep-at-most" || a == "--precision-for-splits") {
+        need(i, a);
+        continue;
+      } else if (a == "-T" || a == "--threads") {
+        need(i, a);
+        continue;
+      } else if (a == "--summary-quote-names") {
+        quote_summary = true;
+        continue;
+      } else if (a == "-v" || a == "--verbose") {
+        verbose = true;
+        continue;
+      } else if (a == "-x" || a == "--print-exception-backtrace" || a == "--debug-twisting") {
+        continue;
+      } else if (a == "-V" || a == "--version") {
+        printf("%s\n", kVersion);
+        return 0;
+      } else if (a == "-h" || a == "--help") {
+        usage(stdout);
+        return 0;
+      } else {
+        parse_error("Unknown option '" + a + "'");
+      }
+      program.push_back(act);
+    }
+  } catch (const Error &e) {
+    parse_error(e.what());
+  }
+  if (program.empty()) {
+    usage(stdout);
+    return 0;
+  }
+  // static checks, bin/KPopTwistDB.ml:368-408
+  {
+    bool twister_loaded = false;
+    for (const Action &a : program) {
+      if (a.kind == Action::TablesToRegister && a.reg == Reg::Twister) twister_loaded = true;
+      if (a.kind == Action::AddKmersFiles && !twister_loaded) parse_error("Option '-k' requires a twister in the twister register!");
+      if (((a.kind == Action::RegisterToTables && a.reg == Reg::Metrics) || a.kind == Action::DistancesFromTwisted ||
+           a.kind == Action::SummaryFromTwisted) && !twister_loaded)
+        parse_error("Options '-O m', '-e', '-d', and '-s' require a twister in the twister register to provide a metric!");
+    }
+  }
+
+  TwisterReg T;
+  Table twisted, distances;
+  Metric metric;
+  Distance distance;
+  bool kmers_normalize = true, distance_normalize = true;  // bin/KPopTwistDB.ml:87-98
+  long long keep_at_most = 2;
+  int precision = 15;
+  try {
+    for (const Action &a : program) {
+      switch (a.kind) {
+        case Action::Empty:
+          if (a.reg == Reg::Twister) T.reset();
+          else if (a.reg == Reg::Twisted) twisted = Table();
+          else if (a.reg == Reg::Distances) distances = Table();
+          break;
+        case Action::BinaryUnsupported:
+          throw Error("binary .KPop* registers (OCaml Marshal) are not read or written by this tool; use the table forms -I/-A/-O");
+        case Action::Unsupported:
+          throw Error("action '" + a.s1 + "' (embeddings/splits) is outside the HIP hot path");
+        case Action::TablesToRegister:
+          if (a.reg == Reg::Twister) load_twister_tables(T, a.s1);
+          else if (a.reg == Reg::Twisted) twisted = read_table(make_filename(a.s1, "KPopTwisted", true));
+          else if (a.reg == Reg::Embeddings) twisted = read_table(make_filename(a.s1, "KPopVectors", true));  // sic, bin/KPopTwistDB.ml:474-475
+          else if (a.reg == Reg::Distances) distances = read_table(make_filename(a.s1, "KPopDMatrix", true));
+          break;
+        case Action::AddTablesToRegister:
+          if (a.reg == Reg::Twisted) merge_rowwise(twisted, read_table(make_filename(a.s1, "KPopTwisted", true)));
+          else if (a.reg == Reg::Distances) merge_rowwise(distances, read_table(make_filename(a.s1, "KPopDMatrix", true)));
+          else throw Error("embeddings are outside the HIP hot path");
+          break;
+        case Action::SetKmersNormalize: kmers_normalize = a.flag; break;
+        case Action::AddKmersFiles: add_twisted_from_files(T, twisted, a.files, kmers_normalize, verbose); break;
+        case Action::SetPrecision: precision = (int)a.num; break;
+        case Action::SetDistance: distance = distance_of_string(a.s1); break;
+        case Action::SetDistanceNormalize: distance_normalize = a.flag; break;
+        case Action::SetMetric: metric = metric_of_string(a.s1); break;
+        case Action::SetSummaryKeepAtMost: keep_at_most = a.num; break;
+        case Action::RegisterToTables:
+          if (a.reg == Reg::Twister) {  // Twister.to_files, lib/Twister.ml:28-30
+            write_table(make_filename(a.s1, "KPopTwister", true), T.twister, precision);
+            write_table(make_filename(a.s1, "KPopInertia", true), T.inertia, precision);
+          } else if (a.reg == Reg::Twisted) {
+            write_table(make_filename(a.s1, "KPopTwisted", true), twisted, precision);
+          } else if (a.reg == Reg::Distances) {
+            write_table(make_filename(a.s1, "KPopDMatrix", true), distances, precision);
+          } else if (a.reg == Reg::Metrics) {  // get_metrics_matrix, lib/Twister.ml:210-217
+            Table m;
+            m.row_names = {"metrics"};
+            m.col_names = T.inertia.col_names;
+            m.data = metric_vector(metric, T);
+            write_table(make_filename(a.s1, "KPopMetrics", true), m, precision);
+          } else {
+            throw Error("embeddings/splits are outside the HIP hot path");
+          }
+          break;
+        case Action::DistancesFromTwisted: {  // bin/KPopTwistDB.ml:542-546
+          Table m2 = read_table(make_filename(a.s1, "KPopTwisted", true));
+          if (twisted.col_names != m2.col_names) throw Error("Incompatible_geometries");  // lib/Matrix.ml:193-194
+          need_gpu();
+          std::vector<double> mv = metric_vector(metric, T);
+          if (mv.size() != twisted.cols()) throw Error("Incompatible_vector_lengths");
+          Table dm;
+          dm.col_names = twisted.row_names;  // lib/Matrix.ml:264-266
+          dm.row_names = m2.row_names;
+          dm.data.assign(dm.rows() * dm.cols(), 0.);
+          check(kpop_distance_rowwise(twisted.data.data(), (uint32_t)twisted.rows(), m2.data.data(), (uint32_t)m2.rows(),
+                                      (uint32_t)twisted.cols(), mv.data(), distance.kind, distance.p, distance_normalize ? 1 : 0,
+                                      dm.data.data()));
+          distances = dm;
+          break;
+        }
+        case Action::SummaryFromTwisted:
+        case Action::SummaryFromDistances: {
+          need_gpu();
+          const bool from_tw = a.kind == Action::SummaryFromTwisted;
+          Table m2;
+          if (from_tw) {
+            m2 = read_table(make_filename(a.s1, "KPopTwisted", true));
+            if (twisted.col_names != m2.col_names) throw Error("Incompatible_geometries");  // lib/Matrix.ml:698-699
+          }
+          const std::vector<std::string> &rows = from_tw ? m2.row_names : distances.row_names;
+          const std::vector<std::string> &cols = from_tw ? twisted.row_names : distances.col_names;
+          const uint32_t r1 = (uint32_t)cols.size(), r2 = (uint32_t)rows.size();
+          uint32_t stride = keep_at_most == 0 ? r1 : (uint32_t)std::min<long long>(r1, std::max<long long>(keep_at_most * 8, 16));
+          stride = std::max(stride, 1u);
+          std::vector<double> stats((size_t)r2 * 4), dist, z;
+          std::vector<uint32_t> n(r2), idx;
+          for (;;) {  // widen the neighbour stride if some row has a larger tie group
+            idx.assign((size_t)r2 * stride, 0);
+            dist.assign((size_t)r2 * stride, 0.);
+            z.assign((size_t)r2 * stride, 0.);
+            if (from_tw) {
+              std::vector<double> mv = metric_vector(metric, T);
+              check(kpop_distance_summary(twisted.data.data(), r1, m2.data.data(), r2, (uint32_t)twisted.cols(), mv.data(),
+                                          distance.kind, distance.p, distance_normalize ? 1 : 0, (uint32_t)keep_at_most, stride,
+                                          stats.data(), n.data(), idx.data(), dist.data(), z.data()));
+            } else {
+              check(kpop_summarize_distances(distances.data.data(), r2, r1, (uint32_t)keep_at_most, stride, stats.data(), n.data(),
+                                             idx.data(), dist.data(), z.data()));
+            }
+            uint32_t mx = 0;
+            for (uint32_t v : n) mx = std::max(mx, v);
+            if (mx <= stride) break;
+            stride = mx;
+          }
+          write_summary(make_filename(from_tw ? a.s2 : a.s1, "KPopSummary", true), rows, cols, stats, n, idx, dist, z, stride,
+                        quote_summary);
+          break;
+        }
+      }
+    }
+  } catch (const std::exception &e) {
+    fprintf(stderr, "(KPopTwistDB): FATAL: Uncaught exception: %s\n", e.what());
+    T.reset();
+    return 1;
+  }
+  T.reset();
+  return 0;
+}

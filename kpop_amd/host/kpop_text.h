@@ -1,0 +1,92 @@
+// kpop_text.h -- the reference's text formats and sequence input, host side.
+//
+// Everything here is byte/text plumbing around the C ABI of include/kpop_hip.h;
+// no arithmetic of the hot path lives in this directory.  file:line citations
+// are into the reference checkout.
+#pragma once
+#include <stdint.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace kpop_host {
+
+struct Error : std::runtime_error {
+  explicit Error(const std::string &m) : std::runtime_error(m) {}
+};
+
+// ---- names ---------------------------------------------------------------
+// Matrix.Base.strip_external_quotes_and_check (BiOCamLib; call sites bin/KPopCount.ml:45,169,
+// lib/Twister.ml:110): drop one surrounding pair of double quotes, then refuse any remaining quote.
+std::string strip_external_quotes_and_check(const std::string &s);
+
+// automatic file naming: prefix + "." + type [+ ".txt"], "/dev/..." verbatim
+// (lib/Matrix.ml:309-320, lib/Twister.ml:219-221, lib/KMerDB.ml:28-30)
+std::string make_filename(const std::string &prefix, const std::string &type_name, bool table);
+
+// k-mer hash <-> hex name (bin/KPopCount.ml:46; encoding declared in csrc/kmer.h)
+std::string hash_to_hex(uint64_t h, int k);
+bool hex_to_hash(const std::string &s, uint64_t *h);
+
+// ---- sequence input (Files.ReadsIterate + Sequences.Lint.dnaize; bin/KPopCount.ml:36,242-245) ----
+struct ReadBatch {
+  std::vector<uint8_t> bases;     // linted, concatenated
+  std::vector<uint64_t> offsets;  // n+1
+  std::vector<std::string> tags;  // n
+  void clear() {
+    bases.clear();
+    offsets.assign(1, 0);
+    tags.clear();
+  }
+  size_t size() const { return tags.size(); }
+};
+
+enum class SeqFormat { FASTA, FASTQ };
+
+// Streams records of one file into batches.  dnaize ~keep_lowercase:false ~keep_dashes:false:
+// letters are upper-cased, '-' and white space are dropped; anything that is not ACGT stays in place
+// (and breaks the k-mer window in the kernels).
+class SeqReader {
+ public:
+  SeqReader(const std::string &path, SeqFormat fmt);
+  ~SeqReader();
+  // appends up to max_bases / max_reads to `out`; returns false at end of file with nothing appended
+  bool next_batch(ReadBatch &out, uint64_t max_bases, uint64_t max_reads);
+  // one record (for interleaving paired-end mates); false at EOF
+  bool next_record(std::string &tag, std::string &seq);
+
+ private:
+  struct Impl;
+  Impl *p_;
+};
+
+// ---- spectra text (Appendix A.1; writer bin/KPopCount.ml:34,45-46,60; parser lib/Twister.ml:91-145) ----
+struct Spectra {  // CSR over spectra, lines in file order
+  std::vector<std::string> labels;
+  std::vector<uint64_t> offsets{0};
+  std::vector<std::string> names;  // k-mer names, opaque to every consumer
+  std::vector<double> values;      // float_of_string (lib/Twister.ml:155)
+};
+// Parses one file (or /dev/stdin) appending to `out`.  Errors mirror the reference's exceptions:
+// Wrong_number_of_columns (:103-104), Header_expected (:106-107), Float_expected (:155-157).
+void read_spectra_file(const std::string &path, Spectra &out);
+void write_spectrum(FILE *f, const std::string &label, const uint64_t *hash, const uint32_t *count, uint64_t n, int k);
+void write_spectrum_body(FILE *f, const uint64_t *hash, const uint32_t *count, uint64_t n, int k);
+
+// ---- matrix tables (Appendix A.2; README.md:618-626,643-650; src/KPopTwist:100,108,116) ----
+struct Table {
+  std::vector<std::string> col_names, row_names;
+  std::vector<double> data;  // row-major rows x cols
+  size_t rows() const { return row_names.size(); }
+  size_t cols() const { return col_names.size(); }
+  bool empty() const { return row_names.empty() && col_names.empty(); }
+};
+Table read_table(const std::string &path);
+void write_table(const std::string &path, const Table &t, int precision);
+// Matrix.merge_rowwise (BiOCamLib; call site lib/Matrix.ml:331-334): same columns, rows appended
+void merge_rowwise(Table &into, const Table &add);
+
+std::string format_g(double x, int precision);  // "%.*g"
+
+}  // namespace kpop_host

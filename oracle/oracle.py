@@ -242,11 +242,22 @@ def distance_summary(m1, m2, metric, kind=EUCLIDEAN, p=2., normalize=True, keep_
     return stats, offs, idx[:t].copy(), dist[:t].copy(), z[:t].copy()
 
 
+def c_g15(x):
+    """C printf("%.15g") -- what OCaml's Printf produces.  Unlike Python it prints the sign of a NaN, and the
+    NaN an x86-64 host gets from 0/0 has its sign bit set: "-nan"."""
+    import math
+    import struct
+    x = float(x)
+    if math.isnan(x):
+        return "-nan" if struct.pack(">d", x)[0] & 0x80 else "nan"
+    return "%.15g" % x
+
+
 def format_summary_line(name, stats, names, idx, dist, z):
     """lib/Matrix.ml:684-690: all %.15g, names as stored."""
-    s = "%s\t%.15g\t%.15g\t%.15g\t%.15g" % (name, stats[0], stats[1], stats[2], stats[3])
+    s = "%s\t%s\t%s\t%s\t%s" % (name, c_g15(stats[0]), c_g15(stats[1]), c_g15(stats[2]), c_g15(stats[3]))
     for i, d, zz in zip(idx, dist, z):
-        s += "\t%s\t%.15g\t%.15g" % (names[int(i)], d, zz)
+        s += "\t%s\t%s\t%s" % (names[int(i)], c_g15(d), c_g15(zz))
     return s + "\n"
 
 

@@ -1,0 +1,204 @@
+"""GPU tests of the drop-in CLIs: README-style shell pipelines (README.md:91-94,606,641,656) through
+kpop_amd/bin/KPopCount and KPopTwistDB, compared byte for byte with text built from the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from test_cli import BIN, COUNT, TWISTDB, run, write_table
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(TWISTDB), reason="host CLIs not built")]
+
+READS = [
+    ("r1 first read", "ACGTACGTTGCAACGTTGCATGCANNACGTACGTAGCATCGACTAGC"),
+    ("r2", "acgtacgttgcaacgttgcatgca"),
+    ("r3-dashes", "ACGTAC-GTACGT--ACGTACGGTCAGGATC"),
+    ("r4|short", "ACG"),
+    ("r5", "TTTTTTTTTTTTTTTTTTTTTTTTTTTTTT"),
+    ("r6 multi", "ACGATCGATCGATCGATTAGCTAGCTAGCTAGCATCGATCGATGCATGCATGCATGCATGCATCGATCGATCGATCGTAGCTAGCTAGCTAGC"),
+]
+
+
+def lint(seq):
+    return seq.upper().replace("-", "")
+
+
+def write_fasta(path, reads, width=17):
+    with open(path, "w") as f:
+        for tag, seq in reads:
+            f.write(">%s\n" % tag)
+            for i in range(0, len(seq), width):
+                f.write(seq[i:i + width] + "\n")
+
+
+def write_fastq(path, reads):
+    with open(path, "w") as f:
+        for tag, seq in reads:
+            f.write("@%s\n%s\n+\n%s\n" % (tag, seq, "I" * len(seq)))
+
+
+def expected_spectra(pyref, reads, k, ds=True):
+    return "".join(pyref.spectrum_text(tag, pyref.count_read(lint(seq), k, ds), k) for tag, seq in reads)
+
+
+def test_kpopcount_per_sequence_fasta(tmp_path, pyref):
+    fa = tmp_path / "x.fa"
+    write_fasta(fa, READS)
+    for k in (3, 5, 12):
+        r = run([COUNT, "-k", str(k), "-L", "-f", str(fa)])
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == expected_spectra(pyref, READS, k)
+    r = run([COUNT, "-k", "5", "-L", "-C", "DNA-ss", "-f", str(fa), "-o", str(tmp_path / "out")])
+    assert r.returncode == 0 and r.stdout == ""
+    assert (tmp_path / "out.KPopSpectra.txt").read_text() == expected_spectra(pyref, READS, 5, ds=False)
+
+
+def test_kpopcount_label_mode_fastq_and_paired(tmp_path, pyref):
+    fq1, fq2 = tmp_path / "a_1.fastq", tmp_path / "a_2.fastq"
+    write_fastq(fq1, READS[:3])
+    write_fastq(fq2, READS[3:])
+    k = 4
+    merged = {}
+    for _, seq in READS:
+        for h, c in pyref.count_read(lint(seq), k).items():
+            merged[h] = merged.get(h, 0) + c
+    want = pyref.spectrum_text("sample A", merged, k)
+    r = run([COUNT, "-k", str(k), "-l", "sample A", "-p", str(fq1), str(fq2)])
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == want
+    r = run([COUNT, "-k", str(k), "-l", '"sample A"', "-s", str(fq1), "-s", str(fq2)])  # quotes stripped (:169)
+    assert r.stdout == want
+    # -L with mates: every mate is its own spectrum, in segment order (bin/KPopCount.ml:39-50)
+    r = run([COUNT, "-k", str(k), "-L", "-p", str(fq1), str(fq2)])
+    inter = [READS[0], READS[3], READS[1], READS[4], READS[2], READS[5]]
+    assert r.stdout == expected_spectra(pyref, inter, k)
+
+
+def make_twister(tmp_path, oracle, k, d, seed=3, keep=0.8):
+    rng = np.random.RandomState(seed)
+    cols = oracle.enumerate_kmers(k)
+    cols = cols[rng.rand(len(cols)) < keep]
+    T = oracle.synth_twister(seed, d, cols)
+    # what the tool sees is the %.15g text
+    T = np.array([[float("%.15g" % x) for x in row] for row in T])
+    dims = ["Dim%d" % (i + 1) for i in range(d)]
+    w = np.array([float("%.15g" % x) for x in oracle.synth_inertia(d)])
+    write_table(tmp_path / "Classes.KPopTwister.txt", [oracle.to_hex(h, k) for h in cols], dims, T)
+    write_table(tmp_path / "Classes.KPopInertia.txt", dims, ["inertia"], [w])
+    return cols, T, dims, w
+
+
+def twisted_text(dims, labels, rows):
+    order = sorted(range(len(labels)), key=lambda i: labels[i].encode())
+    s = '""' + "".join('\t"%s"' % c for c in dims) + "\n"
+    for i in order:
+        s += '"%s"' % labels[i] + "".join("\t%.15g" % v for v in rows[i]) + "\n"
+    return s
+
+
+def test_count_twist_distance_summary_pipeline(tmp_path, oracle, pyref):
+    """KPopCount -L | KPopTwistDB -I T .. -k /dev/stdin -O t ..; then -d / -s / -S against the class vectors."""
+    k, d = 5, 6
+    cols, T, dims, w = make_twister(tmp_path, oracle, k, d)
+    fa, cfa = tmp_path / "test.fa", tmp_path / "classes.fa"
+    rng = np.random.RandomState(9)
+    test_reads = READS + [("z%d" % i, "".join(rng.choice(list("ACGT"), size=80))) for i in range(6)]
+    class_reads = [("c%d" % i, "".join(rng.choice(list("ACGT"), size=400))) for i in range(5)]
+    write_fasta(fa, test_reads)
+    write_fasta(cfa, class_reads)
+
+    def twist_cli(fasta, prefix):
+        p1 = subprocess.Popen([COUNT, "-k", str(k), "-L", "-f", str(fasta)], stdout=subprocess.PIPE)
+        p2 = subprocess.run([TWISTDB, "-I", "T", str(tmp_path / "Classes"), "-k", "/dev/stdin", "-O", "t", str(tmp_path / prefix)],
+                            stdin=p1.stdout, capture_output=True, text=True, timeout=120)
+        p1.wait()
+        assert p1.returncode == 0 and p2.returncode == 0, p2.stderr
+
+    def twist_oracle(reads):
+        rows = []
+        for tag, seq in reads:
+            table = pyref.count_read(lint(seq), k)
+            h = np.array(sorted(table), dtype=np.uint64)
+            v = np.array([table[int(x)] for x in h], dtype=np.float64)
+            rows.append(oracle.twist(T, cols, h, v, np.array([0, len(h)], dtype=np.uint64))[0])
+        return np.array(rows)
+
+    twist_cli(fa, "Test")
+    twist_cli(cfa, "ClassVecs")
+    t_test, t_cls = twist_oracle(test_reads), twist_oracle(class_reads)
+    got = (tmp_path / "Test.KPopTwisted.txt").read_text()
+    want = twisted_text(dims, [t for t, _ in test_reads], t_test)
+    assert got.splitlines()[0] == want.splitlines()[0]
+    for g, x in zip(got.splitlines()[1:], want.splitlines()[1:]):
+        gf, xf = g.split("\t"), x.split("\t")
+        assert gf[0] == xf[0]
+        np.testing.assert_allclose([float(v) for v in gf[1:]], [float(v) for v in xf[1:]], rtol=1e-12, atol=1e-15)
+    # from here on both sides start from the SAME %.15g tables the CLI wrote
+    def load(prefix):
+        lines = (tmp_path / (prefix + ".KPopTwisted.txt")).read_text().splitlines()
+        names = [l.split("\t")[0].strip('"') for l in lines[1:]]
+        return names, np.array([[float(v) for v in l.split("\t")[1:]] for l in lines[1:]])
+    cls_names, m1 = load("ClassVecs")
+    test_names, m2 = load("Test")
+    metric = oracle.metric_powers(w, 1.0, 1.0, 2.0)
+    base = [TWISTDB, "-I", "T", str(tmp_path / "Classes"), "-I", "t", str(tmp_path / "ClassVecs")]
+    r = run(base + ["-d", str(tmp_path / "Test"), "-O", "d", str(tmp_path / "TvC")])
+    assert r.returncode == 0, r.stderr
+    dm = oracle.distance_rowwise(m1, m2, metric)
+    want = '""' + "".join('\t"%s"' % c for c in cls_names) + "\n"
+    for j, nm in enumerate(test_names):
+        want += '"%s"' % nm + "".join("\t%.15g" % v for v in dm[j]) + "\n"
+    assert (tmp_path / "TvC.KPopDMatrix.txt").read_text() == want  # rows = the -d operand (lib/Matrix.ml:264-266)
+    # -s: summary straight from the twisted vectors; -S: from the distance register
+    r = run(base + ["-s", str(tmp_path / "Test"), str(tmp_path / "S1"), "-I", "d", str(tmp_path / "TvC"), "-S", str(tmp_path / "S2"),
+                    "--summary-keep-at-most", "all", "-S", str(tmp_path / "S3")])
+    assert r.returncode == 0, r.stderr
+    st, offs, idx, dist, z = oracle.distance_summary(m1, m2, metric, keep_at_most=2)
+    want = "".join(oracle.format_summary_line(test_names[j], st[j], cls_names, idx[int(offs[j]):int(offs[j + 1])],
+                                              dist[int(offs[j]):int(offs[j + 1])], z[int(offs[j]):int(offs[j + 1])])
+                   for j in range(len(test_names)))
+    assert (tmp_path / "S1.KPopSummary.txt").read_text() == want
+    # S2 starts from the %.15g distance table
+    dm_rt = np.array([[float("%.15g" % v) for v in row] for row in dm])
+    want2 = ""
+    for j in range(len(test_names)):
+        s, i2, d2, z2 = oracle.summarize_row(dm_rt[j], 2)
+        want2 += oracle.format_summary_line(test_names[j], s, cls_names, i2, d2, z2)
+    assert (tmp_path / "S2.KPopSummary.txt").read_text() == want2
+    assert len((tmp_path / "S3.KPopSummary.txt").read_text().splitlines()[0].split("\t")) == 5 + 3 * len(cls_names)
+    # other distances and switches reach the kernels
+    r = run(base + ["--distance", "minkowski(1)", "--distance-normalize", "false", "-m", "flat", "-d", str(tmp_path / "Test"),
+                    "-O", "d", "/dev/stdout"])
+    dm1 = oracle.distance_rowwise(m1, m2, oracle.metric_flat(d), oracle.MINKOWSKI, 1.0, False)
+    got = np.array([[float(v) for v in l.split("\t")[1:]] for l in r.stdout.splitlines()[1:]])
+    np.testing.assert_allclose(got, dm1, rtol=1e-11)
+
+
+def test_duplicate_label_and_unknown_kmers(tmp_path, oracle):
+    k, d = 4, 3
+    make_twister(tmp_path, oracle, k, d, keep=1.0)
+    sp = tmp_path / "dup.KPopSpectra.txt"
+    sp.write_text("\ta\n0a\t3\nzz\t9\n0a0\t4\n\tb\n01\t1\n\ta\n02\t2\n")
+    r = run([TWISTDB, "-I", "T", str(tmp_path / "Classes"), "-k", str(sp)])
+    assert r.returncode == 1 and 'Duplicate_label("a")' in r.stderr  # lib/Twister.ml:195
+    sp.write_text("0a\t3\n")
+    r = run([TWISTDB, "-I", "T", str(tmp_path / "Classes"), "-k", str(sp)])
+    assert r.returncode == 1 and "Header_expected" in r.stderr       # :106-107
+    sp.write_text("\ta\n0a\t3\textra\n")
+    r = run([TWISTDB, "-I", "T", str(tmp_path / "Classes"), "-k", str(sp)])
+    assert r.returncode == 1 and "Wrong_number_of_columns" in r.stderr  # :103-104
+    sp.write_text("\ta\n0a\tthree\n")
+    r = run([TWISTDB, "-I", "T", str(tmp_path / "Classes"), "-k", str(sp)])
+    assert r.returncode == 1 and "Float_expected" in r.stderr        # :155-157
+    # names that are not k-mers of this twister are dropped and do not enter the normaliser (:167-169)
+    sp.write_text('\t"q"\n0a\t3\nzz\t9\n0a0\t4\n0a\t1\n')
+    r = run([TWISTDB, "-I", "T", str(tmp_path / "Classes"), "-k", str(sp), "-O", "t", "/dev/stdout"])
+    assert r.returncode == 0, r.stderr
+    row = r.stdout.splitlines()[1].split("\t")
+    assert row[0] == '"q"'
+    tw = np.array([[float(v) for v in l.split("\t")[1:]] for l in (tmp_path / "Classes.KPopTwister.txt").read_text().splitlines()[1:]])
+    names = (tmp_path / "Classes.KPopTwister.txt").read_text().splitlines()[0].split("\t")[1:]
+    c = names.index('"0a"')
+    np.testing.assert_allclose([float(v) for v in row[1:]], tw[:, c], rtol=1e-14)  # (3+1)/4 of that column

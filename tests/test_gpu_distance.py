@@ -133,3 +133,27 @@ def test_pipeline_headline_shape_sample(kpop, oracle):
     assert np.array_equal(classes, cls_o)
     assert np.array_equal(twisted[pick], tw_o)
     assert rel_err(dist[pick], di_o) <= 1e-12
+
+
+def test_readme_known_answer_through_the_gpu(kpop):
+    """README.md:649 -> README.md:660 with the HIP summary kernel (KPopTwistDB -S path, lib/Matrix.ml:767-810)."""
+    kat = load_golden("readme_kat.json")
+    row = np.array([[float(x) for x in kat["distance_row_text"]]])
+    st, n, idx, d, z = kpop.summarize_distances(row, keep_at_most=kat["keep_at_most"], max_neighbours=10)
+    want = kat["summary_line"].split("\t")
+    np.testing.assert_allclose(st[0], [float(x) for x in want[1:5]], rtol=1e-12)
+    assert n[0] == 2
+    assert [kat["distance_header"][int(i)] for i in idx[0, :2]] == ["2", "10"]
+    assert d[0, :2].tolist() == [float(want[6]), float(want[9])]
+    np.testing.assert_allclose(z[0, :2], [float(want[7]), float(want[10])], rtol=1e-11)
+
+
+def test_summarize_distances_vs_oracle(kpop, oracle):
+    rng = np.random.RandomState(5)
+    dm = np.round(rng.rand(50, 300), 2)  # ties
+    st, n, idx, d, z = kpop.summarize_distances(dm, keep_at_most=3, max_neighbours=300)
+    for j in range(dm.shape[0]):
+        so, io, do, zo = oracle.summarize_row(dm[j], 3)
+        np.testing.assert_allclose(st[j], so, rtol=1e-12)
+        assert n[j] == len(io) and idx[j, :n[j]].tolist() == io.tolist()
+        assert np.array_equal(d[j, :n[j]], do)
