@@ -369,11 +369,10 @@ static int prepare_operands(const double *m1, uint32_t r1, const double *m2, uin
   return 0;
 }
 
+// launches the rowwise kernel on prepared (normalised) operands
 template <int KIND>
-static int rowwise_impl(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
-                        const double *metric, double p, int normalize, void *work, double *out, hipStream_t st) {
-  const double *a, *b;
-  KPOP_TRY(prepare_operands<KIND>(m1, r1, m2, r2, n_dims, metric, p, normalize, work, &a, &b, st));
+static int rowwise_block(const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims, const double *metric,
+                         double p, double *out, hipStream_t st) {
   // balanced column tiles of 64..127 columns (one tile below 128)
   const uint32_t n_tiles = std::max(1u, r1 / 64);
   const uint32_t w = div_up(r1, n_tiles);
@@ -387,6 +386,40 @@ static int rowwise_impl(const double *m1, uint32_t r1, const double *m2, uint32_
   return 0;
 }
 
+template <int KIND>
+static int rowwise_impl(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
+                        const double *metric, double p, int normalize, void *work, double *out, hipStream_t st) {
+  const double *a, *b;
+  KPOP_TRY(prepare_operands<KIND>(m1, r1, m2, r2, n_dims, metric, p, normalize, work, &a, &b, st));
+  return rowwise_block<KIND>(a, r1, b, r2, n_dims, metric, p, out, st);
+}
+
+// summary_large.hip
+int launch_summary_large(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most,
+                         uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
+                         double *out_dist, double *out_z, hipStream_t st);
+
+// r1 > kSummaryMaxR1: query rows in chunks, distance rows of a chunk in the library workspace
+template <int KIND>
+static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
+                              const double *metric, double p, int normalize, uint32_t keep_at_most,
+                              uint32_t max_neighbours, void *work, double *out_stats, uint32_t *out_n,
+                              uint32_t *out_idx, double *out_dist, double *out_z, hipStream_t st) {
+  const double *a, *b;
+  KPOP_TRY(prepare_operands<KIND>(m1, r1, m2, r2, n_dims, metric, p, normalize, work, &a, &b, st));
+  const uint64_t budget = 512ull << 20;
+  const uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(r2, budget / ((uint64_t)r1 * 8)));
+  void *ws = nullptr;
+  KPOP_TRY(ctx().ws.ensure((uint64_t)chunk * r1 * 8, &ws));
+  double *rows = reinterpret_cast<double *>(ws);
+  for (uint32_t q0 = 0; q0 < r2; q0 += chunk) {
+    const uint32_t q = std::min(chunk, r2 - q0);
+    KPOP_TRY(rowwise_block<KIND>(a, r1, b + (uint64_t)q0 * n_dims, q, n_dims, metric, p, rows, st));
+    KPOP_TRY(launch_summary_large(rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist,
+                                  out_z, st));
+  }
+  return 0;
+}
 
 template <int KIND, bool PRE>
 static int launch_summary(const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims,
@@ -466,10 +499,20 @@ extern "C" int kpop_dev_distance_summary(const double *d_m1, uint32_t r1, const 
   if (max_neighbours && (!d_out_idx || !d_out_dist || !d_out_z))
     KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_distance_summary: null neighbour buffers");
   if (n_dims == 0) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_distance_summary: n_dims must be positive");
-  if (r1 > kSummaryMaxR1)
-    KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_distance_summary: r1=%u, the HIP path covers up to %u reference rows", r1,
-              kSummaryMaxR1);
   hipStream_t st = as_stream(stream);
+  if (r1 > kSummaryMaxR1) {
+    switch (kind) {
+      case KPOP_EUCLIDEAN:
+        return summary_large_impl<KPOP_EUCLIDEAN>(d_m1, r1, d_m2, r2, n_dims, d_metric, p, normalize, keep_at_most,
+                                                  max_neighbours, d_work, d_out_stats, d_out_n, d_out_idx, d_out_dist, d_out_z, st);
+      case KPOP_COSINE:
+        return summary_large_impl<KPOP_COSINE>(d_m1, r1, d_m2, r2, n_dims, d_metric, p, normalize, keep_at_most,
+                                               max_neighbours, d_work, d_out_stats, d_out_n, d_out_idx, d_out_dist, d_out_z, st);
+      default:
+        return summary_large_impl<KPOP_MINKOWSKI>(d_m1, r1, d_m2, r2, n_dims, d_metric, p, normalize, keep_at_most,
+                                                  max_neighbours, d_work, d_out_stats, d_out_n, d_out_idx, d_out_dist, d_out_z, st);
+    }
+  }
   switch (kind) {
     case KPOP_EUCLIDEAN:
       return summary_impl<KPOP_EUCLIDEAN>(d_m1, r1, d_m2, r2, n_dims, d_metric, p, normalize, keep_at_most, max_neighbours,
@@ -492,8 +535,8 @@ extern "C" int kpop_dev_summarize_distances(const double *d_dist, uint32_t r2, u
   if (max_neighbours && (!d_out_idx || !d_out_dist || !d_out_z))
     KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_summarize_distances: null neighbour buffers");
   if (r1 > kSummaryMaxR1)
-    KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_summarize_distances: r1=%u, the HIP path covers up to %u columns", r1,
-              kSummaryMaxR1);
+    return launch_summary_large(d_dist, r2, r1, 0, keep_at_most, max_neighbours, d_out_stats, d_out_n, d_out_idx, d_out_dist,
+                                d_out_z, as_stream(stream));
   return launch_summary<KPOP_EUCLIDEAN, true>(d_dist, r1, nullptr, r2, 1, nullptr, 2.0, keep_at_most, max_neighbours,
                                               d_out_stats, d_out_n, d_out_idx, d_out_dist, d_out_z, as_stream(stream));
 }

@@ -102,8 +102,6 @@ def test_distance_errors(kpop):
         kpop.distance_rowwise(np.ones((2, 3)), np.ones((2, 3)), np.ones(3), kind=7)
     with pytest.raises(kpop.KPopError):
         kpop.distance_rowwise(np.ones((2, 3)), np.ones((2, 3)), np.ones(3), kind=2, p=-1.0)
-    with pytest.raises(kpop.KPopError):
-        kpop.distance_summary(np.ones((5000, 2)), np.ones((1, 2)), np.ones(2))  # r1 above the LDS-sort limit
     out = kpop.distance_rowwise(np.ones((0, 3)), np.ones((2, 3)), np.ones(3))
     assert out.shape == (2, 0)
 
@@ -155,5 +153,44 @@ def test_summarize_distances_vs_oracle(kpop, oracle):
     for j in range(dm.shape[0]):
         so, io, do, zo = oracle.summarize_row(dm[j], 3)
         np.testing.assert_allclose(st[j], so, rtol=1e-12)
+        assert n[j] == len(io) and idx[j, :n[j]].tolist() == io.tolist()
+        assert np.array_equal(d[j, :n[j]], do)
+
+
+@pytest.mark.parametrize("r1,keep,kind", [(5000, 2, 0), (20000, 300, 0), (4097, 0, 1), (9000, 7, 2)])
+def test_distance_summary_large_reference_set(kpop, oracle, r1, keep, kind):
+    """Relatedness-engine shape (README.md:1101): r1 beyond the LDS sort -> radix-select path.  mean/sd are tree
+    sums there, so statistics are held to 1e-10; neighbours (indices, distances) must match exactly."""
+    rng = np.random.RandomState(r1)
+    d, r2 = 16, 12
+    m1 = np.round(rng.normal(size=(r1, d)), 1)
+    m2 = np.round(rng.normal(size=(r2, d)), 1)
+    m1[7] = m1[3]
+    m2[5] = m1[11]  # a zero distance
+    metric = oracle.metric_powers(oracle.synth_inertia(d))
+    p = 1.5
+    st_o, offs, idx_o, dist_o, z_o = oracle.distance_summary(m1, m2, metric, kind, p, True, keep)
+    cap = 2048
+    st, n, idx, dist, z = kpop.distance_summary(m1, m2, metric, kind, p, True, keep, max_neighbours=cap)
+    np.testing.assert_allclose(st, st_o, rtol=1e-10, atol=1e-13)
+    for j in range(r2):
+        a, b = int(offs[j]), int(offs[j + 1])
+        assert n[j] == b - a  # the reference's eff_len, even beyond what is returned
+        m = min(n[j], cap)
+        if kind != 2:
+            assert idx[j, :m].tolist() == idx_o[a:a + m].tolist()
+            assert np.array_equal(dist[j, :m], dist_o[a:a + m])
+        else:
+            np.testing.assert_allclose(dist[j, :m], dist_o[a:a + m], rtol=1e-11)
+        np.testing.assert_allclose(z[j, :m], z_o[a:a + m], rtol=1e-8, atol=1e-9)
+
+
+def test_summarize_distances_large_row_with_ties(kpop, oracle):
+    rng = np.random.RandomState(2)
+    dm = np.round(rng.rand(6, 10000), 3)  # ~10 entries per distinct value: tie groups everywhere
+    st, n, idx, d, z = kpop.summarize_distances(dm, keep_at_most=25, max_neighbours=200)
+    for j in range(dm.shape[0]):
+        so, io, do, zo = oracle.summarize_row(dm[j], 25)
+        np.testing.assert_allclose(st[j], so, rtol=1e-10)
         assert n[j] == len(io) and idx[j, :n[j]].tolist() == io.tolist()
         assert np.array_equal(d[j, :n[j]], do)
