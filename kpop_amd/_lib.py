@@ -77,6 +77,13 @@ def load():
         raise ImportError(
             "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C kpop_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    # PyTorch-ROCm wheels bundle their own HIP/HSA runtime.  Two runtimes in one process do not both see the
+    # GPU, and whichever is loaded first wins, so when torch is installed let its copy be the process's runtime
+    # (libkpop_hip.so only needs libamdhip64.so.7 by SONAME).  Stand-alone users (the C++ CLIs) get /opt/rocm's.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it

@@ -192,3 +192,25 @@ def test_count_twist_many_genomes(kpop, oracle):
     T = oracle.synth_twister(0x5EED, d, cols)
     want = oracle.twist(T, cols, h, c.astype(np.float64), o)
     assert np.max(np.abs(got[pick] - want)) <= 1e-12 * np.max(np.abs(want))
+
+
+def test_device_pipeline_all_vs_all_single_rank(kpop, oracle):
+    """The device-resident register flow (kpop_amd/pipeline.py) incl. the all-vs-all block, world size 1."""
+    import torch
+    from kpop_amd.pipeline import DevicePipeline
+    k, d, n, L = 8, 64, 300, 120
+    dev = torch.device("cuda", 0)
+    bases, offs = oracle.synth_reads(4, n, L)
+    tw = kpop.Twister.synth(9, k, d)
+    metric = kpop.metric_compute(oracle.synth_inertia(d))
+    pipe = DevicePipeline(tw, metric, dev)
+    t = pipe.count_twist(torch.from_numpy(bases).to(dev), torch.from_numpy(offs.astype(np.int64)).to(dev), L)
+    lo, hi, block = pipe.all_vs_all_rows(t, n)
+    torch.cuda.synchronize()
+    cols = oracle.enumerate_kmers(k)
+    T = oracle.synth_twister(9, d, cols)
+    h, c, o = oracle.count_reads(bases, offs, k)
+    want_t = oracle.twist(T, cols, h, c.astype(np.float64), o)
+    assert np.array_equal(t.cpu().numpy(), want_t)
+    assert (lo, hi) == (0, n)
+    assert np.array_equal(block.cpu().numpy(), oracle.distance_rowwise(want_t, want_t, metric))
