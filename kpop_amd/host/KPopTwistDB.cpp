@@ -9,9 +9,10 @@
 // This file is argument parsing, the text formats, and the label bookkeeping of
 // lib/Twister.ml:189-206.
 //
-// Not covered (outside the hot path): embeddings (-e), splits (-p), and the OCaml-Marshal
-// binaries (-i/-a/-o; '.KPopTwister' etc.).  Where the reference takes a BINARY twisted prefix (-d, -s) this
-// tool reads '<prefix>.KPopTwisted.txt'.  Runtime failures exit 1 (the reference prints and exits 0).
+// Binary registers (-i/-a/-o, and the twisted operand of -d/-s) are OCaml Marshal streams, read and written
+// by ocaml_marshal.cpp; if '<prefix>.KPopTwisted' does not exist, -d/-s fall back to '<prefix>.KPopTwisted.txt'.
+// Not covered (outside the hot path): embeddings (-e) and splits (-p).
+// Runtime failures exit 1 (the reference prints the exception and exits 0).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -23,6 +24,7 @@
 
 #include "../../include/kpop_hip.h"
 #include "kpop_text.h"
+#include "ocaml_marshal.h"
 
 using namespace kpop_host;
 
@@ -44,7 +46,7 @@ Reg reg_of_string(const std::string &s) {  // bin/KPopTwistDB.ml:30-39
 
 struct Action {
   enum Kind {
-    Empty, TablesToRegister, AddTablesToRegister, BinaryUnsupported, SetKmersNormalize, AddKmersFiles, RegisterToTables,
+    Empty, TablesToRegister, AddTablesToRegister, BinaryToRegister, AddBinaryToRegister, RegisterToBinary, SetKmersNormalize, AddKmersFiles, RegisterToTables,
     SetPrecision, SetDistance, SetDistanceNormalize, SetMetric, DistancesFromTwisted, SetSummaryKeepAtMost,
     SummaryFromTwisted, SummaryFromDistances, Unsupported
   } kind;
@@ -127,7 +129,10 @@ void usage(FILE *f) {
           " -s|--compute-and-summarize-distances <twisted_prefix> <summary_prefix>\n"
           " -S|--summarize-distances <summary_prefix>\n"
           " -T|--threads <n> (ignored)  -v|--verbose  -V|--version  -h|--help\n"
-          "Binary registers (-i, -a, -o), embeddings (-e) and splits (-p) are not provided by this tool.\n",
+          " -i|--input T|t|d <binary_prefix>         load .KPopTwister | .KPopTwisted | .KPopDMatrix (OCaml Marshal)\n"
+          " -a|--add t|d <binary_prefix>             add the rows of a binary register\n"
+          " -o|--output T|t|d <binary_prefix>        write the register in binary form\n"
+          "Embeddings (-e) and splits (-p) are not provided by this tool.\n",
           kVersion);
 }
 
@@ -183,6 +188,16 @@ void load_twister_tables(TwisterReg &T, const std::string &prefix) {  // Twister
   T.inertia = read_table(make_filename(prefix, "KPopInertia", true));
   if (T.inertia.row_names != std::vector<std::string>{"inertia"} || T.twister.row_names != T.inertia.col_names)
     throw Error("Mismatched_twister_files");  // :36-49
+}
+
+// the twisted operand of -d / -s is a binary prefix in the reference (bin/KPopTwistDB.ml:546,554)
+Table load_twisted_operand(const std::string &prefix) {
+  const std::string bin = make_filename(prefix, "KPopTwisted", false);
+  if (FILE *f = fopen(bin.c_str(), "rb")) {
+    fclose(f);
+    return read_binary_matrix(bin, "KPopTwisted");
+  }
+  return read_table(make_filename(prefix, "KPopTwisted", true));
 }
 
 std::vector<double> metric_vector(const Metric &m, const TwisterReg &T) {  // Twister.get_metrics_vector, lib/Twister.ml:208-209
@@ -268,10 +283,22 @@ int main(int argc, char **argv) {
         act.kind = Action::Empty;
         act.reg = reg_of_string(need(i, a));
         if (act.reg == Reg::Metrics || act.reg == Reg::Splits) parse_error("You cannot load content into the metric or splits registers");
-      } else if (a == "-i" || a == "--input" || a == "-a" || a == "--add" || a == "-o" || a == "--output") {
-        act.kind = Action::BinaryUnsupported;
+      } else if (a == "-i" || a == "--input") {
+        act.kind = Action::BinaryToRegister;
+        act.reg = reg_of_string(need(i, a));
+        if (act.reg == Reg::Metrics || act.reg == Reg::Splits) parse_error("You cannot load content into the metric or splits registers");
         act.s1 = need(i, a);
-        act.s2 = need(i, a);
+      } else if (a == "-a" || a == "--add") {
+        act.kind = Action::AddBinaryToRegister;
+        act.reg = reg_of_string(need(i, a));
+        if (act.reg == Reg::Twister || act.reg == Reg::Metrics || act.reg == Reg::Splits)
+          parse_error("You cannot add content to the twister, metric or splits registers");
+        act.s1 = need(i, a);
+      } else if (a == "-o" || a == "--output") {
+        act.kind = Action::RegisterToBinary;
+        act.reg = reg_of_string(need(i, a));
+        if (act.reg == Reg::Metrics) parse_error("You cannot output binary content from the metrics registers");
+        act.s1 = need(i, a);
       } else if (a == "-I" || a == "--Input") {
         act.kind = Action::TablesToRegister;
         act.reg = reg_of_string(need(i, a));
@@ -373,7 +400,7 @@ int main(int argc, char **argv) {
   {
     bool twister_loaded = false;
     for (const Action &a : program) {
-      if (a.kind == Action::TablesToRegister && a.reg == Reg::Twister) twister_loaded = true;
+      if ((a.kind == Action::TablesToRegister || a.kind == Action::BinaryToRegister) && a.reg == Reg::Twister) twister_loaded = true;
       if (a.kind == Action::AddKmersFiles && !twister_loaded) parse_error("Option '-k' requires a twister in the twister register!");
       if (((a.kind == Action::RegisterToTables && a.reg == Reg::Metrics) || a.kind == Action::DistancesFromTwisted ||
            a.kind == Action::SummaryFromTwisted) && !twister_loaded)
@@ -396,8 +423,25 @@ int main(int argc, char **argv) {
           else if (a.reg == Reg::Twisted) twisted = Table();
           else if (a.reg == Reg::Distances) distances = Table();
           break;
-        case Action::BinaryUnsupported:
-          throw Error("binary .KPop* registers (OCaml Marshal) are not read or written by this tool; use the table forms -I/-A/-O");
+        case Action::BinaryToRegister:  // bin/KPopTwistDB.ml:449-456
+          if (a.reg == Reg::Twister) {
+            T.reset();
+            read_binary_twister(make_filename(a.s1, "KPopTwister", false), &T.twister, &T.inertia);
+          } else if (a.reg == Reg::Twisted) twisted = read_binary_matrix(make_filename(a.s1, "KPopTwisted", false), "KPopTwisted");
+          else if (a.reg == Reg::Distances) distances = read_binary_matrix(make_filename(a.s1, "KPopDMatrix", false), "KPopDMatrix");
+          else throw Error("embeddings are outside the HIP hot path");
+          break;
+        case Action::AddBinaryToRegister:  // :462-467
+          if (a.reg == Reg::Twisted) merge_rowwise(twisted, read_binary_matrix(make_filename(a.s1, "KPopTwisted", false), "KPopTwisted"));
+          else if (a.reg == Reg::Distances) merge_rowwise(distances, read_binary_matrix(make_filename(a.s1, "KPopDMatrix", false), "KPopDMatrix"));
+          else throw Error("embeddings are outside the HIP hot path");
+          break;
+        case Action::RegisterToBinary:  // :509-518
+          if (a.reg == Reg::Twister) write_binary_twister(make_filename(a.s1, "KPopTwister", false), T.twister, T.inertia);
+          else if (a.reg == Reg::Twisted) write_binary_matrix(make_filename(a.s1, "KPopTwisted", false), "KPopTwisted", twisted);
+          else if (a.reg == Reg::Distances) write_binary_matrix(make_filename(a.s1, "KPopDMatrix", false), "KPopDMatrix", distances);
+          else throw Error("embeddings/splits are outside the HIP hot path");
+          break;
         case Action::Unsupported:
           throw Error("action '" + a.s1 + "' (embeddings/splits) is outside the HIP hot path");
         case Action::TablesToRegister:
@@ -437,7 +481,7 @@ int main(int argc, char **argv) {
           }
           break;
         case Action::DistancesFromTwisted: {  // bin/KPopTwistDB.ml:542-546
-          Table m2 = read_table(make_filename(a.s1, "KPopTwisted", true));
+          Table m2 = load_twisted_operand(a.s1);
           if (twisted.col_names != m2.col_names) throw Error("Incompatible_geometries");  // lib/Matrix.ml:193-194
           need_gpu();
           std::vector<double> mv = metric_vector(metric, T);
@@ -458,7 +502,7 @@ int main(int argc, char **argv) {
           const bool from_tw = a.kind == Action::SummaryFromTwisted;
           Table m2;
           if (from_tw) {
-            m2 = read_table(make_filename(a.s1, "KPopTwisted", true));
+            m2 = load_twisted_operand(a.s1);
             if (twisted.col_names != m2.col_names) throw Error("Incompatible_geometries");  // lib/Matrix.ml:698-699
           }
           const std::vector<std::string> &rows = from_tw ? m2.row_names : distances.row_names;

@@ -1,0 +1,380 @@
+// ocaml_marshal.cpp -- see ocaml_marshal.h
+#include "ocaml_marshal.h"
+
+#include <errno.h>
+#include <string.h>
+
+#include <vector>
+
+namespace kpop_host {
+
+namespace {
+
+enum : uint8_t {
+  PREFIX_SMALL_BLOCK = 0x80, PREFIX_SMALL_INT = 0x40, PREFIX_SMALL_STRING = 0x20,
+  CODE_INT8 = 0x00, CODE_INT16 = 0x01, CODE_INT32 = 0x02, CODE_INT64 = 0x03,
+  CODE_SHARED8 = 0x04, CODE_SHARED16 = 0x05, CODE_SHARED32 = 0x06, CODE_SHARED64 = 0x14,
+  CODE_DOUBLE_ARRAY32_LITTLE = 0x07, CODE_BLOCK32 = 0x08, CODE_STRING8 = 0x09, CODE_STRING32 = 0x0A,
+  CODE_DOUBLE_BIG = 0x0B, CODE_DOUBLE_LITTLE = 0x0C, CODE_DOUBLE_ARRAY8_BIG = 0x0D, CODE_DOUBLE_ARRAY8_LITTLE = 0x0E,
+  CODE_DOUBLE_ARRAY32_BIG = 0x0F, CODE_BLOCK64 = 0x13, CODE_STRING64 = 0x15, CODE_DOUBLE_ARRAY64_BIG = 0x16,
+  CODE_DOUBLE_ARRAY64_LITTLE = 0x17
+};
+constexpr uint32_t MAGIC_SMALL = 0x8495A6BE, MAGIC_BIG = 0x8495A6BF;
+
+// ---------------------------------------------------------------- writer
+struct Writer {
+  std::string buf;
+  uint64_t n_obj = 0, size32 = 0, size64 = 0;
+  void u8(uint8_t v) { buf.push_back((char)v); }
+  void be(uint64_t v, int bytes) {
+    for (int i = bytes - 1; i >= 0; --i) buf.push_back((char)((v >> (8 * i)) & 0xFF));
+  }
+  void block_header(uint64_t size, int tag) {
+    if (size == 0) {  // atom
+      u8((uint8_t)(PREFIX_SMALL_BLOCK + tag));
+      return;
+    }
+    if (tag < 16 && size < 8) u8((uint8_t)(PREFIX_SMALL_BLOCK + tag + (size << 4)));
+    else if (size < (1ull << 22)) {
+      u8(CODE_BLOCK32);
+      be((size << 10) | (uint64_t)tag, 4);
+    } else {
+      u8(CODE_BLOCK64);
+      be((size << 10) | (uint64_t)tag, 8);
+    }
+    ++n_obj;
+    size32 += 1 + size;
+    size64 += 1 + size;
+  }
+  void string(const std::string &s) {
+    const uint64_t len = s.size();
+    if (len < 0x20) u8((uint8_t)(PREFIX_SMALL_STRING + len));
+    else if (len < 0x100) {
+      u8(CODE_STRING8);
+      u8((uint8_t)len);
+    } else if (len < (1ull << 32)) {
+      u8(CODE_STRING32);
+      be(len, 4);
+    } else {
+      u8(CODE_STRING64);
+      be(len, 8);
+    }
+    buf.append(s);
+    ++n_obj;
+    size32 += 1 + (len + 4) / 4;
+    size64 += 1 + (len + 8) / 8;
+  }
+  void double_array(const double *p, uint64_t n) {
+    if (n == 0) {  // Float.Array.create 0 is the atom
+      u8(PREFIX_SMALL_BLOCK);
+      return;
+    }
+    if (n < 0x100) {
+      u8(CODE_DOUBLE_ARRAY8_LITTLE);
+      u8((uint8_t)n);
+    } else if (n < (1ull << 32)) {
+      u8(CODE_DOUBLE_ARRAY32_LITTLE);
+      be(n, 4);
+    } else {
+      u8(CODE_DOUBLE_ARRAY64_LITTLE);
+      be(n, 8);
+    }
+    buf.append(reinterpret_cast<const char *>(p), n * 8);  // x86-64: native = little endian
+    ++n_obj;
+    size32 += 1 + 2 * n;
+    size64 += 1 + n;
+  }
+  void flush(FILE *f) {
+    std::string hd;
+    auto hbe = [&](uint64_t v, int bytes) {
+      for (int i = bytes - 1; i >= 0; --i) hd.push_back((char)((v >> (8 * i)) & 0xFF));
+    };
+    const uint64_t lim = 1ull << 32;
+    if (buf.size() >= lim || size32 >= lim || size64 >= lim) {
+      hbe(MAGIC_BIG, 4);
+      hbe(0, 4);
+      hbe(buf.size(), 8);
+      hbe(n_obj, 8);
+      hbe(size64, 8);
+    } else {
+      hbe(MAGIC_SMALL, 4);
+      hbe(buf.size(), 4);
+      hbe(n_obj, 4);
+      hbe(size32, 4);
+      hbe(size64, 4);
+    }
+    if (fwrite(hd.data(), 1, hd.size(), f) != hd.size() || fwrite(buf.data(), 1, buf.size(), f) != buf.size())
+      throw Error(std::string("write failed: ") + strerror(errno));
+  }
+};
+
+void write_string_value(FILE *f, const std::string &s) {
+  Writer w;
+  w.string(s);
+  w.flush(f);
+}
+
+// ---------------------------------------------------------------- reader
+struct Node {
+  enum Kind : uint8_t { Int, Block, String, Double, DoubleArray } kind;
+  int tag = 0;
+  uint64_t a = 0, b = 0;  // Int: a=value; Block: a=first child slot, b=count; String: a=offset,b=len; Double*: a=offset,b=count
+};
+
+struct Reader {
+  std::vector<uint8_t> data;
+  size_t pos = 0;
+  std::vector<Node> nodes;
+  std::vector<uint32_t> children;  // node ids
+  std::vector<uint32_t> objects;   // object table for shared references
+  std::string bytes;
+  std::vector<double> doubles;
+
+  uint8_t u8() {
+    if (pos >= data.size()) throw Error("marshal: truncated value");
+    return data[pos++];
+  }
+  uint64_t be(int n) {
+    uint64_t v = 0;
+    for (int i = 0; i < n; ++i) v = (v << 8) | u8();
+    return v;
+  }
+  uint32_t add(const Node &n, bool object) {
+    nodes.push_back(n);
+    const uint32_t id = (uint32_t)(nodes.size() - 1);
+    if (object) objects.push_back(id);
+    return id;
+  }
+  uint32_t shared(uint64_t ofs) {
+    if (ofs == 0 || ofs > objects.size()) throw Error("marshal: bad shared reference");
+    return objects[objects.size() - ofs];
+  }
+  uint32_t read_doubles(uint64_t n, bool little) {
+    Node nd;
+    nd.kind = Node::DoubleArray;
+    nd.a = doubles.size();
+    nd.b = n;
+    if (pos + n * 8 > data.size()) throw Error("marshal: truncated float array");
+    doubles.resize(doubles.size() + n);
+    if (little) memcpy(&doubles[nd.a], &data[pos], n * 8);
+    else
+      for (uint64_t i = 0; i < n; ++i) {
+        uint64_t v = 0;
+        for (int k = 0; k < 8; ++k) v = (v << 8) | data[pos + i * 8 + k];
+        memcpy(&doubles[nd.a + i], &v, 8);
+      }
+    pos += n * 8;
+    return add(nd, true);
+  }
+  uint32_t read_string(uint64_t len) {
+    if (pos + len > data.size()) throw Error("marshal: truncated string");
+    Node nd;
+    nd.kind = Node::String;
+    nd.a = bytes.size();
+    nd.b = len;
+    bytes.append(reinterpret_cast<const char *>(&data[pos]), len);
+    pos += len;
+    return add(nd, true);
+  }
+  uint32_t read_block(uint64_t size, int tag) {
+    Node nd;
+    nd.kind = Node::Block;
+    nd.tag = tag;
+    nd.b = size;
+    if (size == 0) return add(nd, false);  // atoms are not entered in the object table
+    const uint32_t id = add(nd, true);
+    std::vector<uint32_t> kids(size);
+    for (uint64_t i = 0; i < size; ++i) kids[i] = read_value();
+    nodes[id].a = children.size();
+    children.insert(children.end(), kids.begin(), kids.end());
+    return id;
+  }
+  uint32_t read_value() {
+    const uint8_t c = u8();
+    if (c >= PREFIX_SMALL_BLOCK) return read_block((c >> 4) & 0x7, c & 0xF);
+    if (c >= PREFIX_SMALL_INT) {
+      Node nd;
+      nd.kind = Node::Int;
+      nd.a = c & 0x3F;
+      return add(nd, false);
+    }
+    if (c >= PREFIX_SMALL_STRING) return read_string(c & 0x1F);
+    Node nd;
+    nd.kind = Node::Int;
+    switch (c) {
+      case CODE_INT8: nd.a = (uint64_t)(int64_t)(int8_t)u8(); return add(nd, false);
+      case CODE_INT16: nd.a = (uint64_t)(int64_t)(int16_t)be(2); return add(nd, false);
+      case CODE_INT32: nd.a = (uint64_t)(int64_t)(int32_t)be(4); return add(nd, false);
+      case CODE_INT64: nd.a = be(8); return add(nd, false);
+      case CODE_SHARED8: return shared(u8());
+      case CODE_SHARED16: return shared(be(2));
+      case CODE_SHARED32: return shared(be(4));
+      case CODE_SHARED64: return shared(be(8));
+      case CODE_BLOCK32: {
+        const uint64_t hd = be(4);
+        return read_block(hd >> 10, (int)(hd & 0xFF));
+      }
+      case CODE_BLOCK64: {
+        const uint64_t hd = be(8);
+        return read_block(hd >> 10, (int)(hd & 0xFF));
+      }
+      case CODE_STRING8: return read_string(u8());
+      case CODE_STRING32: return read_string(be(4));
+      case CODE_STRING64: return read_string(be(8));
+      case CODE_DOUBLE_LITTLE: return read_doubles(1, true);
+      case CODE_DOUBLE_BIG: return read_doubles(1, false);
+      case CODE_DOUBLE_ARRAY8_LITTLE: return read_doubles(u8(), true);
+      case CODE_DOUBLE_ARRAY8_BIG: return read_doubles(u8(), false);
+      case CODE_DOUBLE_ARRAY32_LITTLE: return read_doubles(be(4), true);
+      case CODE_DOUBLE_ARRAY32_BIG: return read_doubles(be(4), false);
+      case CODE_DOUBLE_ARRAY64_LITTLE: return read_doubles(be(8), true);
+      case CODE_DOUBLE_ARRAY64_BIG: return read_doubles(be(8), false);
+      default: throw Error("marshal: unsupported code 0x" + std::to_string((int)c) + " (custom blocks / closures are not part of a KPop matrix)");
+    }
+  }
+  std::string str(uint32_t id) const {
+    const Node &n = nodes[id];
+    if (n.kind != Node::String) throw Error("marshal: string expected");
+    return bytes.substr(n.a, n.b);
+  }
+};
+
+// one marshalled value: false at clean EOF
+bool read_one(FILE *f, Reader &r) {
+  uint8_t hd[32];
+  size_t got = fread(hd, 1, 4, f);
+  if (got == 0) return false;
+  if (got != 4) throw Error("marshal: truncated header");
+  const uint32_t magic = ((uint32_t)hd[0] << 24) | ((uint32_t)hd[1] << 16) | ((uint32_t)hd[2] << 8) | hd[3];
+  uint64_t data_len = 0;
+  auto be = [&](const uint8_t *p, int n) {
+    uint64_t v = 0;
+    for (int i = 0; i < n; ++i) v = (v << 8) | p[i];
+    return v;
+  };
+  if (magic == MAGIC_SMALL) {
+    if (fread(hd + 4, 1, 16, f) != 16) throw Error("marshal: truncated header");
+    data_len = be(hd + 4, 4);
+  } else if (magic == MAGIC_BIG) {
+    if (fread(hd + 4, 1, 28, f) != 28) throw Error("marshal: truncated header");
+    data_len = be(hd + 8, 8);
+  } else {
+    throw Error("marshal: bad magic number (not an OCaml output_value stream, or a compressed one)");
+  }
+  r = Reader();
+  r.data.resize(data_len);
+  if (data_len && fread(r.data.data(), 1, data_len, f) != data_len) throw Error("marshal: truncated value");
+  r.read_value();
+  return true;
+}
+
+void strings_of(const Reader &r, uint32_t id, std::vector<std::string> &out) {
+  const Node &n = r.nodes[id];
+  if (n.kind != Node::Block) throw Error("marshal: string array expected");
+  out.clear();
+  for (uint64_t i = 0; i < n.b; ++i) out.push_back(r.str(r.children[n.a + i]));
+}
+
+}  // namespace
+
+void marshal_write_matrix(FILE *f, const std::string &type_name, const Table &t) {
+  write_string_value(f, type_name);       // Type.to_string m.which |> output_value
+  write_string_value(f, kArchiveVersion);  // archive_version |> output_value
+  Writer w;                                // output_value output m.matrix
+  w.block_header(3, 0);
+  w.block_header(t.col_names.size(), 0);
+  for (const std::string &s : t.col_names) w.string(s);
+  w.block_header(t.row_names.size(), 0);
+  for (const std::string &s : t.row_names) w.string(s);
+  w.block_header(t.rows(), 0);
+  for (size_t r = 0; r < t.rows(); ++r) w.double_array(t.data.data() + r * t.cols(), t.cols());
+  w.flush(f);
+}
+
+bool marshal_read_matrix(FILE *f, std::string *type_name, Table *t) {
+  Reader r;
+  if (!read_one(f, r)) return false;
+  *type_name = r.str(0);
+  if (!read_one(f, r)) throw Error("marshal: archive version missing");
+  const std::string version = r.str(0);
+  if (version != kArchiveVersion)  // lib/Matrix.ml:831-832
+    throw Error("Incompatible_archive_version(\"" + *type_name + "\", \"" + version + "\", \"" + kArchiveVersion + "\")");
+  if (!read_one(f, r)) throw Error("marshal: matrix missing");
+  const Node &root = r.nodes[0];
+  if (root.kind != Node::Block || root.b != 3) throw Error("marshal: a 3-field matrix record was expected");
+  *t = Table();
+  strings_of(r, r.children[root.a + 0], t->col_names);
+  strings_of(r, r.children[root.a + 1], t->row_names);
+  const Node &data = r.nodes[r.children[root.a + 2]];
+  if (data.kind != Node::Block || data.b != t->row_names.size()) throw Error("marshal: matrix data does not match its row names");
+  const size_t nc = t->col_names.size();
+  t->data.reserve(t->row_names.size() * nc);
+  for (uint64_t i = 0; i < data.b; ++i) {
+    const Node &row = r.nodes[r.children[data.a + i]];
+    const bool empty_atom = row.kind == Node::Block && row.b == 0;
+    if (!(row.kind == Node::DoubleArray || empty_atom) || (empty_atom ? 0 : row.b) != nc)
+      throw Error("marshal: matrix row " + std::to_string(i) + " is not a float array of the matrix width");
+    if (!empty_atom) t->data.insert(t->data.end(), r.doubles.begin() + (long)row.a, r.doubles.begin() + (long)(row.a + row.b));
+  }
+  return true;
+}
+
+static FILE *open_or_throw(const std::string &path, const char *mode) {
+  FILE *f = fopen(path.c_str(), mode);
+  if (!f) throw Error("cannot open '" + path + "': " + strerror(errno));
+  return f;
+}
+
+Table read_binary_matrix(const std::string &path, const std::string &expect_type) {
+  FILE *f = open_or_throw(path, "rb");
+  Table t;
+  std::string ty;
+  try {
+    if (!marshal_read_matrix(f, &ty, &t)) throw Error("'" + path + "' is empty");
+  } catch (...) {
+    fclose(f);
+    throw;
+  }
+  fclose(f);
+  if (ty != expect_type) throw Error("Unexpected_type(" + ty + ", " + expect_type + ")");  // lib/Matrix.ml:841-842
+  return t;
+}
+
+void write_binary_matrix(const std::string &path, const std::string &type_name, const Table &t) {
+  FILE *f = open_or_throw(path, "wb");
+  try {
+    marshal_write_matrix(f, type_name, t);
+  } catch (...) {
+    fclose(f);
+    throw;
+  }
+  fclose(f);
+}
+
+void read_binary_twister(const std::string &path, Table *twister, Table *inertia) {  // Twister.of_binary, lib/Twister.ml:232-246
+  FILE *f = open_or_throw(path, "rb");
+  std::string t1, t2;
+  try {
+    if (!marshal_read_matrix(f, &t1, twister) || !marshal_read_matrix(f, &t2, inertia)) throw Error("'" + path + "' is truncated");
+  } catch (...) {
+    fclose(f);
+    throw;
+  }
+  fclose(f);
+  if (t1 != "KPopTwister") throw Error("Unexpected_type(KPopTwister, " + t1 + ")");
+  if (t2 != "KPopInertia") throw Error("Unexpected_type(KPopInertia, " + t2 + ")");
+}
+
+void write_binary_twister(const std::string &path, const Table &twister, const Table &inertia) {  // Twister.to_binary, :222-231
+  FILE *f = open_or_throw(path, "wb");
+  try {
+    marshal_write_matrix(f, "KPopTwister", twister);
+    marshal_write_matrix(f, "KPopInertia", inertia);
+  } catch (...) {
+    fclose(f);
+    throw;
+  }
+  fclose(f);
+}
+
+}  // namespace kpop_host

@@ -1,0 +1,37 @@
+// ocaml_marshal.h -- reading and writing the OCaml Marshal (output_value) stream of the reference's binary
+// registers: '.KPopTwister', '.KPopTwisted', '.KPopDMatrix' (lib/Matrix.ml:812-845, lib/Twister.ml:222-246).
+//
+// A binary register is a sequence of independent marshalled values:
+//     "KPop<Type>" (string), "2022-04-03" (string), Matrix.Base.t (record)
+// and '.KPopTwister' holds two such triples (twister, then inertia).  Matrix.Base.t is declared in BiOCamLib
+// (not part of the reference checkout); its field order is taken as { col_names; row_names; data } with
+// data : Float.Array.t array -- the order of every record literal in the reference (lib/Matrix.ml:188-190,
+// 264-266; lib/Twister.ml:205-206).  UNPINNED: no OCaml toolchain is available here to produce a real file.
+//
+// Wire format (OCaml runtime, extern.c / intern.c; identical in 4.x and 5.x for these codes): 20-byte header
+// {magic 0x8495A6BE, data_len, num_objects, size_32, size_64} (or the 32-byte 0x8495A6BF form), then a
+// pre-order stream of small-int / small-block / small-string prefixes and CODE_* bytes; shared references
+// (CODE_SHARED8/16/32) index the objects read so far and are honoured on input.  Output never shares.
+#pragma once
+#include <stdio.h>
+
+#include <string>
+
+#include "kpop_text.h"
+
+namespace kpop_host {
+
+constexpr const char *kArchiveVersion = "2022-04-03";  // lib/Matrix.ml:812
+
+// Matrix.to_channel / of_channel (lib/Matrix.ml:814-817,828-833).  type_name is "KPopTwisted" etc.
+void marshal_write_matrix(FILE *f, const std::string &type_name, const Table &t);
+// returns false at a clean end of file; throws on anything malformed
+bool marshal_read_matrix(FILE *f, std::string *type_name, Table *t);
+
+// whole-file helpers with the reference's checks (Unexpected_type, Incompatible_archive_version)
+Table read_binary_matrix(const std::string &path, const std::string &expect_type);
+void write_binary_matrix(const std::string &path, const std::string &type_name, const Table &t);
+void read_binary_twister(const std::string &path, Table *twister, Table *inertia);
+void write_binary_twister(const std::string &path, const Table &twister, const Table &inertia);
+
+}  // namespace kpop_host

@@ -94,8 +94,8 @@ def test_argument_errors():
     assert r.returncode == 1 and "Invalid_threshold" in r.stderr
     r = run([TWISTDB, "--summary-keep-at-most", "0"])
     assert r.returncode == 1 and "Invalid_keep_at_most" in r.stderr
-    r = run([TWISTDB, "-i", "t", "whatever"])
-    assert r.returncode == 1 and "Marshal" in r.stderr
+    r = run([TWISTDB, "-i", "t", "/nonexistent/whatever"])
+    assert r.returncode == 1 and "cannot open" in r.stderr
     assert run([TWISTDB]).returncode == 0          # empty program: usage, exit 0 (:362-365)
     assert run([TWISTDB, "-V"]).stdout.strip() == "38-hip"
     r = run([COUNT, "-f", "x.fa"])
@@ -115,3 +115,87 @@ def test_count_fails_loudly_without_gpu(tmp_path):
     fa.write_text(">r1\nACGTACGT\n")
     r = run([COUNT, "-L", "-k", "3", "-f", str(fa)])
     assert r.returncode == 1 and "no HIP device" in r.stderr and r.stdout == ""
+
+
+# ---------------------------------------------------------------- binary registers (OCaml Marshal)
+def be(v, n):
+    return int(v).to_bytes(n, "big")
+
+
+def marshal_header(data, n_obj, s32, s64):
+    return be(0x8495A6BE, 4) + be(len(data), 4) + be(n_obj, 4) + be(s32, 4) + be(s64, 4)
+
+
+def hand_marshalled_twisted():
+    """{col_names=[|"Dim1";"Dim2"|]; row_names=[|"a";"b"|]; data=[|[|1.;2.|];[|3.;4.|]|]} preceded by
+    "KPopTwisted" and "2022-04-03", assembled by hand from the OCaml runtime's extern.c rules."""
+    import struct
+    v1 = bytes([0x20 + 11]) + b"KPopTwisted"
+    v2 = bytes([0x20 + 10]) + b"2022-04-03"
+    rec = bytes([0xB0])                                                   # block tag 0, 3 fields
+    rec += bytes([0xA0]) + bytes([0x24]) + b"Dim1" + bytes([0x24]) + b"Dim2"
+    rec += bytes([0xA0]) + bytes([0x21]) + b"a" + bytes([0x21]) + b"b"
+    rec += bytes([0xA0])
+    rec += bytes([0x0E, 2]) + struct.pack("<2d", 1.0, 2.0)                  # CODE_DOUBLE_ARRAY8_LITTLE
+    rec += bytes([0x0E, 2]) + struct.pack("<2d", 3.0, 4.0)
+    return (marshal_header(v1, 1, 4, 3) + v1 + marshal_header(v2, 1, 4, 3) + v2 + marshal_header(rec, 10, 33, 27) + rec)
+
+
+def test_binary_register_bytes_match_the_ocaml_format(tmp_path):
+    write_table(tmp_path / "x.KPopTwisted.txt", ["Dim1", "Dim2"], ["a", "b"], [[1, 2], [3, 4]])
+    r = run([TWISTDB, "-I", "t", str(tmp_path / "x"), "-o", "t", str(tmp_path / "x")])
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "x.KPopTwisted").read_bytes() == hand_marshalled_twisted()
+
+
+def test_binary_register_reader_honours_sharing_and_wide_codes(tmp_path):
+    """What OCaml may emit and our writer never does: shared strings (CODE_SHARED8), BLOCK32, STRING8,
+    DOUBLE_ARRAY32 and the 32-byte big header."""
+    import struct
+    v1 = bytes([0x20 + 11]) + b"KPopTwisted"
+    v2 = bytes([0x20 + 10]) + b"2022-04-03"
+    rec = bytes([0xB0])
+    rec += bytes([0x08]) + be((2 << 10) | 0, 4) + bytes([0x09, 4]) + b"Dim1" + bytes([0x24]) + b"Dim2"  # BLOCK32, STRING8
+    # objects so far: record 0, column array 1, "Dim1" 2, "Dim2" 3, row array 4 -> intern_obj_table[5 - 3] is "Dim1"
+    rec += bytes([0xA0]) + bytes([0x04, 3]) + bytes([0x21]) + b"b"
+    rec += bytes([0xA0])
+    rec += bytes([0x07]) + be(2, 4) + struct.pack("<2d", 1.5, -2.0)   # DOUBLE_ARRAY32_LITTLE
+    rec += bytes([0x0D, 2]) + struct.pack(">2d", 3.0, 4.25)            # DOUBLE_ARRAY8_BIG
+    big = be(0x8495A6BF, 4) + be(0, 4) + be(len(rec), 8) + be(9, 8) + be(25, 8)
+    (tmp_path / "y.KPopTwisted").write_bytes(marshal_header(v1, 1, 4, 3) + v1 + marshal_header(v2, 1, 4, 3) + v2 + big + rec)
+    r = run([TWISTDB, "-i", "t", str(tmp_path / "y"), "-O", "t", "/dev/stdout"])
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == '""\t"Dim1"\t"Dim2"\n"Dim1"\t1.5\t-2\n"b"\t3\t4.25\n'
+
+
+def test_binary_round_trips_and_checks(tmp_path, oracle):
+    d, k = 5, 4
+    cols = oracle.enumerate_kmers(k)
+    T = oracle.synth_twister(2, d, cols)
+    dims = ["Dim%d" % (i + 1) for i in range(d)]
+    write_table(tmp_path / "c.KPopTwister.txt", [oracle.to_hex(h, k) for h in cols], dims, T)
+    write_table(tmp_path / "c.KPopInertia.txt", dims, ["inertia"], [oracle.synth_inertia(d)])
+    r = run([TWISTDB, "-I", "T", str(tmp_path / "c"), "-o", "T", str(tmp_path / "c"), "-z", "T", "-i", "T", str(tmp_path / "c"),
+             "-O", "T", str(tmp_path / "c2")])
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "c2.KPopTwister.txt").read_text() == (tmp_path / "c.KPopTwister.txt").read_text()
+    assert (tmp_path / "c2.KPopInertia.txt").read_text() == (tmp_path / "c.KPopInertia.txt").read_text()
+    # -a merges rows; an empty register round-trips (three atoms)
+    write_table(tmp_path / "p.KPopTwisted.txt", dims, ["s1"], [np.arange(d) / 7.0])
+    write_table(tmp_path / "q.KPopTwisted.txt", dims, ["s2", "s3"], [np.ones(d), -np.ones(d)])
+    for n in "pq":
+        assert run([TWISTDB, "-I", "t", str(tmp_path / n), "-o", "t", str(tmp_path / n)]).returncode == 0
+    r = run([TWISTDB, "-i", "t", str(tmp_path / "p"), "-a", "t", str(tmp_path / "q"), "-O", "t", "/dev/stdout"])
+    assert [l.split("\t")[0] for l in r.stdout.splitlines()] == ['""', '"s1"', '"s2"', '"s3"']
+    r = run([TWISTDB, "-z", "d", "-o", "d", str(tmp_path / "e"), "-i", "d", str(tmp_path / "e"), "-O", "d", "/dev/stdout"])
+    assert r.returncode == 0 and r.stdout == '""\n'
+    # type and version checks (lib/Matrix.ml:831-832,841-842)
+    r = run([TWISTDB, "-i", "d", str(tmp_path / "p.KPopTwisted").replace(".KPopTwisted", "")])
+    assert r.returncode == 1
+    os.rename(tmp_path / "p.KPopTwisted", tmp_path / "p.KPopDMatrix")
+    r = run([TWISTDB, "-i", "d", str(tmp_path / "p")])
+    assert r.returncode == 1 and "Unexpected_type" in r.stderr
+    raw = (tmp_path / "q.KPopTwisted").read_bytes().replace(b"2022-04-03", b"2021-01-01")
+    (tmp_path / "q.KPopTwisted").write_bytes(raw)
+    r = run([TWISTDB, "-i", "t", str(tmp_path / "q")])
+    assert r.returncode == 1 and "Incompatible_archive_version" in r.stderr
