@@ -202,3 +202,43 @@ def test_duplicate_label_and_unknown_kmers(tmp_path, oracle):
     names = (tmp_path / "Classes.KPopTwister.txt").read_text().splitlines()[0].split("\t")[1:]
     c = names.index('"0a"')
     np.testing.assert_allclose([float(v) for v in row[1:]], tw[:, c], rtol=1e-14)  # (3+1)/4 of that column
+
+
+def test_readme_commands_verbatim_with_binary_registers(tmp_path, oracle, pyref):
+    """README.md:606,641,656 as written there (binary -i/-o/-d/-s forms):
+         KPopCount ... | KPopTwistDB -i T Classes -k /dev/stdin -o t Test
+         KPopTwistDB -i t Classes -i T Classes -d Test -O d Test-vs-Classes -o d Test-vs-Classes
+         KPopTwistDB -i T Classes -i t Classes -s Test Test-vs-Classes
+       and the same through the table forms must give the same summary text."""
+    k, d = 5, 6
+    make_twister(tmp_path, oracle, k, d)
+    rng = np.random.RandomState(4)
+    test_reads = [("s%d" % i, "".join(rng.choice(list("ACGT"), size=150))) for i in range(20)]
+    class_reads = [("%d" % (i + 1), "".join(rng.choice(list("ACGT"), size=1000))) for i in range(10)]
+    write_fasta(tmp_path / "test.fa", test_reads)
+    write_fasta(tmp_path / "classes.fa", class_reads)
+    cwd = str(tmp_path)
+    penv = dict(os.environ, PATH=BIN + ":" + os.environ.get("PATH", ""))
+    sh = lambda cmd: subprocess.run(cmd, shell=True, cwd=cwd, capture_output=True, text=True, timeout=120, env=penv)
+    env = ""
+    r = sh(env + "KPopTwistDB -I T Classes -o T Classes")                      # stands in for KPopTwist (R)
+    assert r.returncode == 0, r.stderr
+    r = sh(env + "KPopCount -k 5 -L -f classes.fa | KPopTwistDB -i T Classes -k /dev/stdin -o t Classes -O t Classes")
+    assert r.returncode == 0, r.stderr
+    r = sh(env + "KPopCount -k 5 -L -f test.fa | KPopTwistDB -i T Classes -k /dev/stdin -o t Test -v")
+    assert r.returncode == 0, r.stderr
+    r = sh(env + "KPopTwistDB -i t Test -O t Test")
+    assert r.returncode == 0, r.stderr
+    r = sh(env + "KPopTwistDB -i t Classes -i T Classes -d Test -O d Test-vs-Classes -o d Test-vs-Classes")
+    assert r.returncode == 0, r.stderr
+    r = sh(env + "KPopTwistDB -i T Classes -i t Classes -s Test Test-vs-Classes")
+    assert r.returncode == 0, r.stderr
+    summary = (tmp_path / "Test-vs-Classes.KPopSummary.txt").read_text()
+    assert len(summary.splitlines()) == 20 and all(len(l.split("\t")) >= 11 for l in summary.splitlines())
+    r = sh(env + "KPopTwistDB -i T Classes -i d Test-vs-Classes -S FromD")
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "FromD.KPopSummary.txt").read_text() == summary  # binary distances keep every bit
+    # binary twisted == what the oracle computes from the same %.15g twister
+    dm_lines = (tmp_path / "Test-vs-Classes.KPopDMatrix.txt").read_text().splitlines()
+    assert dm_lines[0].split("\t")[1:] == ['"%s"' % n for n in sorted((t for t, _ in class_reads), key=lambda s: s.encode())]
+    assert [l.split("\t")[0] for l in dm_lines[1:]] == ['"%s"' % n for n in sorted((t for t, _ in test_reads), key=lambda s: s.encode())]
