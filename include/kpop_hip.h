@@ -158,6 +158,13 @@ int kpop_summarize_distances(const double *dist, uint32_t r2, uint32_t r1, uint3
  * Same operations on buffers already in HBM; enqueue only.                   */
 int kpop_dev_synth_reads(uint64_t seed, uint64_t n_reads, uint32_t read_len, uint64_t first_read,
                          uint8_t *d_bases, uint64_t *d_offsets, void *stream);
+/* -L counting with everything resident (bin/KPopCount.ml:36-50), reads of up to 512 windows.  The CSR lands
+   in d_out_hash / d_out_count (the caller sizes them for the worst case, one entry per window) and
+   d_out_offsets (n_reads+1); d_scratch needs kpop_dev_count_reads_scratch_bytes().                        */
+uint64_t kpop_dev_count_reads_scratch_bytes(uint32_t n_reads, uint32_t max_len, int k);
+int kpop_dev_count_reads(const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads, uint32_t max_len,
+                         int k, int content, void *d_scratch, uint64_t *d_out_hash, uint32_t *d_out_count,
+                         uint64_t *d_out_offsets, void *stream);
 /* n_bases = offsets[n_reads] (size of d_bases), max_len = longest read in the batch: the host
    knows both from the offsets it uploaded.  Reads of up to 512 windows take the one-wavefront-
    per-read kernel; longer sequences (genomes) the streaming kernel, whose segment partials

@@ -48,6 +48,8 @@ SIGNATURES = {
     "kpop_dev_summarize_distances": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp,
                                                vp]),
     "kpop_dev_synth_reads": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, vp, vp, vp]),
+    "kpop_dev_count_reads_scratch_bytes": (C.c_uint64, [C.c_uint32, C.c_uint32, C.c_int]),
+    "kpop_dev_count_reads": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "kpop_dev_count_twist": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.c_int, vp, vp]),
     "kpop_dev_twist": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int, vp, vp]),
     "kpop_dev_distance_workspace_bytes": (C.c_uint64, [C.c_uint32, C.c_uint32, C.c_uint32]),

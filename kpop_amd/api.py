@@ -240,6 +240,16 @@ def dev_synth_reads(seed, n_reads, read_len, d_bases, d_offsets, first_read=0, s
                                            d_offsets, stream))
 
 
+def dev_count_reads_scratch_bytes(n_reads, max_len, k):
+    return int(_lib.load().kpop_dev_count_reads_scratch_bytes(int(n_reads), int(max_len), int(k)))
+
+
+def dev_count_reads(d_bases, d_offsets, n_reads, max_len, k, d_scratch, d_out_hash, d_out_count, d_out_offsets,
+                    content=DNA_DS, stream=0):
+    check(_lib.load().kpop_dev_count_reads(d_bases, d_offsets, int(n_reads), int(max_len), int(k), int(content), d_scratch,
+                                           d_out_hash, d_out_count, d_out_offsets, stream))
+
+
 def dev_count_twist(tw, d_bases, d_offsets, n_reads, n_bases, max_len, d_out, content=DNA_DS, normalize=True,
                     stream=0):
     check(_lib.load().kpop_dev_count_twist(tw.handle, d_bases, d_offsets, int(n_reads), int(n_bases), int(max_len),

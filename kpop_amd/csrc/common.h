@@ -88,5 +88,7 @@ struct DevBuf {
 constexpr int kWave = 64;  // gfx950 wavefront
 
 static inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+// HIP refuses launches with gridDim.x * blockDim.x >= 2^32; kernels given this grid stride over the rest
+static inline uint32_t capped_grid(uint64_t blocks) { return (uint32_t)(blocks < (1u << 22) ? blocks : (1u << 22)); }
 
 }  // namespace kpop

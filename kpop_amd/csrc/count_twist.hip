@@ -310,11 +310,15 @@ template <typename H>
 __global__ __launch_bounds__(256) void count_twist_stream_kernel(
     TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int content,
     const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ seg_off, double *__restrict__ partial,
-    uint32_t *__restrict__ partial_cnt) {
+    uint32_t *__restrict__ partial_cnt, uint32_t n_reads, uint32_t max_seg) {
   __shared__ double s_part[4][64];
   __shared__ uint32_t s_cnt[4];
-  const uint32_t r = blockIdx.x, seg = blockIdx.y;
-  if (seg >= nseg[r]) return;
+  // (read, segment) pairs are dealt to blocks round-robin: a ragged batch (one genome among a million reads)
+  // has far more pairs than HIP allows blocks, and almost all of them are empty
+  const uint64_t n_pairs = (uint64_t)n_reads * max_seg;
+  for (uint64_t pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+  const uint32_t r = (uint32_t)(pair / max_seg), seg = (uint32_t)(pair % max_seg);
+  if (seg >= nseg[r]) continue;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t off = offsets[r];
   const uint64_t len = offsets[r + 1] - off;
@@ -367,6 +371,8 @@ __global__ __launch_bounds__(256) void count_twist_stream_kernel(
       if (active) partial[slot * tv.n_dims + d] = t;
       if (d0 == 0 && lane == 0) partial_cnt[slot] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     }
+  }
+  __syncthreads();
   }
 }
 
@@ -538,15 +544,60 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   KPOP_LAUNCH_CHECK();
   KPOP_TRY(exclusive_scan(LoadU32{nseg}, StoreU64{seg_off}, n_reads, sums, st));
   const uint32_t max_seg = div_up(max_windows, kSegWindows);
-  if (max_seg > 65535) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_count_twist: sequence longer than %llu bases",
-                                 (unsigned long long)65535 * kSegWindows);
-  dim3 grid(n_reads, max_seg);
+  dim3 grid(capped_grid((uint64_t)n_reads * max_seg));
   if (tw->k <= 15)
-    count_twist_stream_kernel<uint32_t><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt);
+    count_twist_stream_kernel<uint32_t><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt,
+                                                                    n_reads, max_seg);
   else
-    count_twist_stream_kernel<uint64_t><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt);
+    count_twist_stream_kernel<uint64_t><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt,
+                                                                    n_reads, max_seg);
   KPOP_LAUNCH_CHECK();
   combine_partials_kernel<<<dim3(n_reads), dim3(256), 0, st>>>(nseg, seg_off, part, pcnt, tw->n_dims, normalize, d_out);
+  KPOP_LAUNCH_CHECK();
+  return KPOP_OK;
+}
+
+// device-resident -L counting for reads of up to 512 windows: scratch rows -> scan -> CSR, all enqueued
+extern "C" uint64_t kpop_dev_count_reads_scratch_bytes(uint32_t n_reads, uint32_t max_len, int k) {
+  const uint32_t max_windows = (max_len >= (uint32_t)k) ? max_len - k + 1 : 0;
+  const int R = pick_R(std::min(max_windows, kWaveMaxWindows));
+  const uint64_t stride = 64ull * (R ? R : 8);
+  return (uint64_t)n_reads * stride * 12 + (uint64_t)n_reads * 4 + (scan_blocks(n_reads) + 1) * 8 + 256;
+}
+
+extern "C" int kpop_dev_count_reads(const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads, uint32_t max_len,
+                                    int k, int content, void *d_scratch, uint64_t *d_out_hash, uint32_t *d_out_count,
+                                    uint64_t *d_out_offsets, void *stream) {
+  KPOP_TRY(require_init());
+  if (!d_offsets || !d_scratch || !d_out_hash || !d_out_count || !d_out_offsets)
+    KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_count_reads: null argument");
+  if (k < 1 || k > kMaxK) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_count_reads: k=%d out of range 1..%d", k, kMaxK);
+  if (content != KPOP_DNA_DS && content != KPOP_DNA_SS)
+    KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_count_reads: content %d (protein k-mers are not on the HIP path)", content);
+  const uint32_t max_windows = (max_len >= (uint32_t)k) ? max_len - k + 1 : 0;
+  if (max_windows > kWaveMaxWindows)
+    KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_count_reads: reads of more than %u windows go through kpop_count_reads", kWaveMaxWindows);
+  hipStream_t st = as_stream(stream);
+  if (n_reads == 0) {
+    KPOP_HIP(hipMemsetAsync(d_out_offsets, 0, 8, st));
+    return KPOP_OK;
+  }
+  const int R = pick_R(max_windows);
+  const uint32_t stride = 64 * R;
+  char *p = reinterpret_cast<char *>(d_scratch);
+  uint64_t *sh = reinterpret_cast<uint64_t *>(p);
+  uint32_t *sc = reinterpret_cast<uint32_t *>(p + (uint64_t)n_reads * stride * 8);
+  uint32_t *nu = sc + (uint64_t)n_reads * stride;
+  uint64_t *sums = reinterpret_cast<uint64_t *>((reinterpret_cast<uintptr_t>(nu + n_reads) + 63) & ~(uintptr_t)63);
+  if (k <= 15)
+    KPOP_TRY(launch_count_wave<uint32_t>(R, d_bases, d_offsets, nullptr, n_reads, k, content, stride, sh, sc, nu, st));
+  else
+    KPOP_TRY(launch_count_wave<uint64_t>(R, d_bases, d_offsets, nullptr, n_reads, k, content, stride, sh, sc, nu, st));
+  KPOP_TRY(exclusive_scan(LoadU32{nu}, StoreOffsets{d_out_offsets}, n_reads, sums, st));
+  // offsets[n_reads] = total, still on the device
+  KPOP_HIP(hipMemcpyAsync(d_out_offsets + n_reads, sums + scan_blocks(n_reads), 8, hipMemcpyDeviceToDevice, st));
+  compact_spectra_kernel<<<dim3(div_up(n_reads, 4)), dim3(256), 0, st>>>(sh, sc, nu, d_out_offsets, n_reads, stride,
+                                                                        d_out_hash, d_out_count);
   KPOP_LAUNCH_CHECK();
   return KPOP_OK;
 }

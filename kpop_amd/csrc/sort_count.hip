@@ -25,13 +25,16 @@ template <typename H>
 __global__ __launch_bounds__(256) void window_keys_kernel(const uint8_t *__restrict__ bases,
                                                           const uint64_t *__restrict__ offsets,
                                                           const uint64_t *__restrict__ woff, int k, int content,
-                                                          int per_read, uint32_t first_id, uint64_t *__restrict__ keys) {
-  const uint32_t r = blockIdx.x;
+                                                          int per_read, uint32_t first_id, uint64_t *__restrict__ keys,
+                                                          uint32_t n_reads, uint32_t max_seg) {
+  const uint64_t n_pairs = (uint64_t)n_reads * max_seg;  // (read, segment) pairs dealt round-robin, see count_twist.hip
+  for (uint64_t pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+  const uint32_t r = (uint32_t)(pair / max_seg);
   const uint64_t off = offsets[r], len = offsets[r + 1] - off;
-  if (len < (uint64_t)k) return;
+  if (len < (uint64_t)k) continue;
   const uint64_t n_win = len - k + 1;
-  const uint64_t w0 = (uint64_t)blockIdx.y * kKeySeg;
-  if (w0 >= n_win) return;
+  const uint64_t w0 = (uint64_t)(pair % max_seg) * kKeySeg;
+  if (w0 >= n_win) continue;
   const uint64_t w1 = min(n_win, w0 + kKeySeg);
   const uint8_t *seq = bases + off;
   const int shift = 2 * (k - 1);
@@ -47,6 +50,7 @@ __global__ __launch_bounds__(256) void window_keys_kernel(const uint8_t *__restr
     }
     const uint64_t h = (uint64_t)((content == KPOP_DNA_DS && rc < fwd) ? rc : fwd);
     keys[woff[r] + w] = good ? (id | h) : ~0ull;
+  }
   }
 }
 
@@ -134,8 +138,6 @@ int sorted_count_batch(const uint8_t *bases, const uint64_t *offsets, uint32_t n
   const int bits = 2 * k + id_bits + 1;
   if (bits > 64) KPOP_FAIL(KPOP_ERR_INVALID, "sorted_count_batch: %d key bits (caller must split the batch)", bits);
   const uint32_t max_seg = div_up(max_win, kKeySeg);
-  if (max_seg > 65535) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_count_reads: sequence longer than %llu bases",
-                                 (unsigned long long)65535 * kKeySeg);
   DevBuf d_bases, d_off, d_woff, d_ka, d_kb, d_scr, d_start, d_sums, d_tot;
   KPOP_TRY(d_bases.alloc(n_bases));
   KPOP_TRY(d_off.alloc((uint64_t)(n_reads + 1) * 8));
@@ -149,15 +151,15 @@ int sorted_count_batch(const uint8_t *bases, const uint64_t *offsets, uint32_t n
   KPOP_HIP(hipMemcpyAsync(d_bases.p, bases + base0, n_bases, hipMemcpyHostToDevice, st));
   KPOP_HIP(hipMemcpyAsync(d_off.p, rel.data(), (uint64_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
   KPOP_HIP(hipMemcpyAsync(d_woff.p, woff.data(), (uint64_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
-  dim3 grid(n_reads, max_seg);
+  dim3 grid(capped_grid((uint64_t)n_reads * max_seg));
   if (k <= 15)
     window_keys_kernel<uint32_t><<<grid, dim3(256), 0, st>>>(d_bases.as<uint8_t>(), d_off.as<uint64_t>(),
                                                              d_woff.as<uint64_t>(), k, content, per_read, 0u,
-                                                             d_ka.as<uint64_t>());
+                                                             d_ka.as<uint64_t>(), n_reads, max_seg);
   else
     window_keys_kernel<uint64_t><<<grid, dim3(256), 0, st>>>(d_bases.as<uint8_t>(), d_off.as<uint64_t>(),
                                                              d_woff.as<uint64_t>(), k, content, per_read, 0u,
-                                                             d_ka.as<uint64_t>());
+                                                             d_ka.as<uint64_t>(), n_reads, max_seg);
   KPOP_LAUNCH_CHECK();
   uint64_t *sorted = nullptr;
   KPOP_TRY(radix_sort_u64(d_ka.as<uint64_t>(), d_kb.as<uint64_t>(), tw, bits, d_scr.p, st, &sorted));

@@ -47,8 +47,9 @@ __global__ void lut_fill_kernel(const uint64_t *__restrict__ col_hash, uint64_t 
 }
 
 __global__ void lut_fixup_kernel(uint32_t *lut, uint64_t lut_size) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < lut_size) lut[i] = lut[i] - 1u;  // 0 -> 0xFFFFFFFF (kNoCol), c+1 -> c
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < lut_size; i += stride)
+    lut[i] = lut[i] - 1u;  // 0 -> 0xFFFFFFFF (kNoCol), c+1 -> c
 }
 
 // one thread per 64-hash word: presence bits from the LUT, prefix = column of the
@@ -153,14 +154,15 @@ __device__ __forceinline__ double synth_coeff(uint64_t seed, uint32_t d, uint64_
 __global__ __launch_bounds__(256) void synth_rows_kernel(uint64_t seed, const uint32_t *__restrict__ lut,
                                                          uint64_t lut_size, uint32_t n_dims, uint32_t d_pad,
                                                          double *__restrict__ rows) {
-  // one wave per hash value; lanes sweep the dims so stores are coalesced
+  // one wave per hash value; lanes sweep the dims so stores are coalesced.  Grid-stride: HIP caps
+  // gridDim.x * blockDim.x at 2^32 and 4^15 hashes need more waves than that.
   const int lane = threadIdx.x & 63;
-  uint64_t h = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (h >= lut_size) return;
-  uint32_t col = lut[h];
-  if (col == kNoCol) return;
-  for (uint32_t d = lane; d < d_pad; d += 64)
-    rows[(uint64_t)col * d_pad + d] = (d < n_dims) ? synth_coeff(seed, d, h) : 0.0;
+  for (uint64_t h = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); h < lut_size; h += (uint64_t)gridDim.x * 4) {
+    const uint32_t col = lut[h];
+    if (col == kNoCol) continue;
+    for (uint32_t d = lane; d < d_pad; d += 64)
+      rows[(uint64_t)col * d_pad + d] = (d < n_dims) ? synth_coeff(seed, d, h) : 0.0;
+  }
 }
 
 static int alloc_common(kpop_twister *tw) {
@@ -256,7 +258,7 @@ extern "C" int kpop_twister_load(const double *T_dims_major, uint64_t n_cols, ui
                                                                         lut_size, bad.as<int>());
       KPOP_LAUNCH_CHECK();
     }
-    lut_fixup_kernel<<<dim3(div_up(lut_size, 256)), dim3(256), 0, st>>>(tw->d_lut, lut_size);
+    lut_fixup_kernel<<<dim3(capped_grid(div_up(lut_size, 256))), dim3(256), 0, st>>>(tw->d_lut, lut_size);
     KPOP_LAUNCH_CHECK();
     int h_bad = 0;
     KPOP_HIP(hipMemcpy(&h_bad, bad.p, 4, hipMemcpyDeviceToHost));
@@ -321,7 +323,7 @@ extern "C" int kpop_twister_synth(uint64_t seed, int k, int content, uint32_t n_
   if (total != n_cols)
     KPOP_FAIL(KPOP_ERR_HIP, "kpop_twister_synth: enumerated %llu k-mers, expected %llu", (unsigned long long)total,
               (unsigned long long)n_cols);
-  synth_rows_kernel<<<dim3(div_up(lut_size, 4)), dim3(256), 0, st>>>(seed, tw->d_lut, lut_size, n_dims, tw->d_pad,
+  synth_rows_kernel<<<dim3(capped_grid(div_up(lut_size, 4))), dim3(256), 0, st>>>(seed, tw->d_lut, lut_size, n_dims, tw->d_pad,
                                                                       tw->d_rows);
   KPOP_LAUNCH_CHECK();
   KPOP_TRY(build_rank_index(tw, st));

@@ -36,6 +36,28 @@ def main():
     dev = torch.device("cuda", 0)
     stream = torch.cuda.current_stream()
     sp = stream.cuda_stream
+    # -L counting, device resident (count_wave_kernel + scan + compaction)
+    from oracle import oracle as O
+    for n, L, k in ((100000, 150, 12), (100000, 150, 21), (1000000, 150, 12), (100000, 500, 12)):
+        bases = torch.empty(n * L, dtype=torch.uint8, device=dev)
+        offs = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        api.dev_synth_reads(0x4B506F70, n, L, bases.data_ptr(), offs.data_ptr(), stream=sp)
+        w = L - k + 1
+        scratch = torch.empty(api.dev_count_reads_scratch_bytes(n, L, k), dtype=torch.uint8, device=dev)
+        oh = torch.empty(n * w, dtype=torch.int64, device=dev)
+        oc = torch.empty(n * w, dtype=torch.int32, device=dev)
+        oo = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        t = timeit(torch, stream, lambda: api.dev_count_reads(bases.data_ptr(), offs.data_ptr(), n, L, k, scratch.data_ptr(),
+                                                               oh.data_ptr(), oc.data_ptr(), oo.data_ptr(), stream=sp))
+        gb = n * (L + w * 8) / 1e9  # read L bytes, write (L-k+1)*8 bytes per read
+        if n == 100000 and L == 150:  # parity of the device-resident CSR against the oracle
+            hb, ho = O.synth_reads(0x4B506F70, n, L)
+            h, c, o = O.count_reads(hb, ho, k)
+            tot = int(oo[-1].item())
+            assert tot == len(h) and np.array_equal(oh[:tot].cpu().numpy().view(np.uint64), h)
+            assert np.array_equal(oc[:tot].cpu().numpy().view(np.uint32), c) and np.array_equal(oo.cpu().numpy().view(np.uint64), o)
+        print("count_reads -L n=%d L=%d k=%d: %.4f ms  %.1f M reads/s  algorithmic %.0f GB/s (%.3f of 8 TB/s)"
+              % (n, L, k, t, n / t / 1e3, gb / t * 1e3, gb / t * 1e3 / 8000))
     for shp in a.shapes.split(","):
         r1, r2, d = (int(x) for x in shp.split("x"))
         m1 = torch.randn(r1, d, dtype=torch.float64, device=dev)
