@@ -123,6 +123,16 @@ int kpop_twist(const kpop_twister *tw, const uint64_t *hash, const double *value
 int kpop_count_twist(const kpop_twister *tw, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
                      int content, int normalize, double *out);
 
+/* ------------------------------------------------------ twister generation
+ * Replaces the R stage of src/KPopTwist:93-116 (library `ca`): correspondence analysis of a k-mers x spectra
+ * count table.  counts is n_kmers x n_spectra row-major (what `KPopCountDB -t` exports, src/KPopTwist:38-44);
+ * normalize = divide every column by its sum first (:93-94).  n_dims = min(n_kmers, n_spectra) - 1.  Outputs:
+ * twisted (n_spectra x n_dims: the class positions, :98-100), inertia (n_dims, :105) and the twister
+ * (n_dims x n_kmers, dims-major: exactly what kpop_twister_load takes, :110-116).  Dimension signs are
+ * arbitrary, as they are in R.  The dense S'S and S*W contractions run on the f64 matrix cores.            */
+int kpop_ca(const double *counts, uint64_t n_kmers, uint32_t n_spectra, int normalize, uint32_t *n_dims_out,
+            double *twisted, double *inertia, double *twister);
+
 /* ----------------------------------------------------------------- metric
  * Replaces Space.Distance.Metric.compute, lib/Space.ml:88-105 (called from
  * Twister.get_metrics_vector, lib/Twister.ml:208-209).  O(n_dims) host code. */

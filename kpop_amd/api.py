@@ -159,6 +159,22 @@ class Twister:
             pass
 
 
+# ------------------------------------------------------ twister generation
+def ca(counts, normalize=True):
+    """Correspondence analysis of a k-mers x spectra table (the R stage of src/KPopTwist:93-116).
+    -> twisted (J x nd), inertia (nd), twister (nd x I, dims-major)."""
+    counts = _c(counts, np.float64)
+    I, J = counts.shape
+    nd = min(I, J) - 1
+    twisted = np.zeros((J, max(nd, 1)), dtype=np.float64)
+    inertia = np.zeros(max(nd, 1), dtype=np.float64)
+    twister = np.zeros((max(nd, 1), I), dtype=np.float64)
+    n_out = C.c_uint32()
+    check(_lib.load().kpop_ca(_p(counts, C.c_double), I, J, 1 if normalize else 0, C.byref(n_out),
+                              _p(twisted, C.c_double), _p(inertia, C.c_double), _p(twister, C.c_double)))
+    return twisted[:, :nd], inertia[:nd], twister[:nd]
+
+
 # ----------------------------------------------------------------- metric
 def metric_compute(inertia, kind=METRIC_POWERS, power_int=1.0, threshold=1.0, power_ext=2.0):
     """Default = powers(1,1,2), bin/KPopTwistDB.ml:92."""

@@ -1,0 +1,250 @@
+// ca.hip -- correspondence analysis: the twister generator (replaces the R stage of src/KPopTwist:93-116).
+//
+//   stuff  <- counts, each column (spectrum) divided by its sum                 src/KPopTwist:93-94
+//   ca()   :  P = N / sum(N); masses r = P 1, c = P' 1;
+//             S = D_r^-1/2 (P - r c') D_c^-1/2 = U diag(sv) V'                 library(ca)
+//   twisted = D_c^-1/2 V diag(sv)   (principal column coordinates)               :98-100
+//   inertia = sv^2 / sum(sv^2)                                                   :105
+//   twister = (D_r^-1/2 U)'         (standard row coordinates, dims x k-mers)    :110-116
+//
+// I = number of k-mers (10^3 .. 10^7), J = number of spectra/classes (10 .. ~2000): tall and skinny.  The SVD is
+// taken through the J x J Gram matrix G = S'S (MFMA f64 GEMM, split over K = I), a one-sided Jacobi
+// eigen-decomposition of G on the host (J^3, small), and U = S V diag(1/sv) as a second MFMA GEMM.
+// The Gram route squares the condition number: dimensions whose singular value is below ~1e-7 of the largest
+// lose accuracy -- they carry < 1e-14 of the inertia.
+#include <math.h>
+
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "gemm_f64.h"
+
+namespace kpop {
+
+// column sums of an I x J row-major matrix: blocks take row slabs, partial[J] per block, ordered final sum
+constexpr uint32_t kCaSlab = 2048;
+
+__global__ __launch_bounds__(256) void ca_col_partial_kernel(const double *__restrict__ N, uint64_t I, uint32_t J,
+                                                             const double *__restrict__ col_scale,
+                                                             double *__restrict__ partial) {
+  const uint64_t i0 = (uint64_t)blockIdx.x * kCaSlab, i1 = min(I, i0 + kCaSlab);
+  for (uint32_t j = threadIdx.x; j < J; j += 256) {
+    const double w = col_scale ? col_scale[j] : 1.0;
+    double s = 0.0;
+    for (uint64_t i = i0; i < i1; ++i) s += N[i * J + j] * w;
+    partial[(uint64_t)blockIdx.x * J + j] = s;
+  }
+}
+
+__global__ void ca_col_final_kernel(const double *__restrict__ partial, uint32_t n_blocks, uint32_t J,
+                                    double *__restrict__ out) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= J) return;
+  double s = 0.0;
+  for (uint32_t b = 0; b < n_blocks; ++b) s += partial[(uint64_t)b * J + j];
+  out[j] = s;
+}
+
+// r_i = sum_j N_ij w_j ; one wave per row, fixed-order lane tree
+__global__ __launch_bounds__(256) void ca_row_mass_kernel(const double *__restrict__ N, uint64_t I, uint32_t J,
+                                                          const double *__restrict__ w, double *__restrict__ r) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= I) return;
+  double s = 0.0;
+  for (uint32_t j = lane; j < J; j += 64) s += N[i * J + j] * w[j];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) r[i] = s;
+}
+
+// S_ij = (N_ij w_j - r_i c_j) / sqrt(r_i c_j); rows without mass are zero
+__global__ void ca_standardise_kernel(const double *__restrict__ N, uint64_t I, uint32_t J, const double *__restrict__ w,
+                                      const double *__restrict__ r, const double *__restrict__ c, double *__restrict__ S) {
+  const uint64_t total = I * J, stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const uint64_t i = e / J;
+    const uint32_t j = (uint32_t)(e % J);
+    const double ri = r[i], cj = c[j];
+    S[e] = (ri > 0.0 && cj > 0.0) ? (N[e] * w[j] - ri * cj) / sqrt(ri * cj) : 0.0;
+  }
+}
+
+// twister[d][i] = U_id / sqrt(r_i), written dims-major from the I x nd product
+__global__ __launch_bounds__(256) void ca_row_coords_kernel(const double *__restrict__ U, uint64_t I, uint32_t nd,
+                                                            const double *__restrict__ r, double *__restrict__ twister) {
+  __shared__ double tile[32][33];
+  const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const uint64_t i_base = (uint64_t)blockIdx.x * 32;
+  const uint32_t d_base = blockIdx.y * 32;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint64_t i = i_base + ty + 8 * q;
+    const uint32_t d = d_base + tx;
+    double v = 0.0;
+    if (i < I && d < nd) {
+      const double ri = r[i];
+      v = ri > 0.0 ? U[i * nd + d] / sqrt(ri) : 0.0;
+    }
+    tile[ty + 8 * q][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t d = d_base + ty + 8 * q;
+    const uint64_t i = i_base + tx;
+    if (d < nd && i < I) twister[(uint64_t)d * I + i] = tile[tx][ty + 8 * q];
+  }
+}
+
+// One-sided Jacobi (Hestenes) on the columns of the symmetric PSD matrix G (n x n, column-major == row-major):
+// on exit the column norms are the eigenvalues and V holds the eigenvectors.  Round-robin pairing: the n/2
+// rotations of a step touch disjoint columns and run in parallel.
+static void jacobi_eigen_psd(std::vector<double> &A, uint32_t n, std::vector<double> &V, std::vector<double> &lambda) {
+  V.assign((size_t)n * n, 0.0);
+  for (uint32_t i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+  // store by columns: col(j) = &A[j*n]; G symmetric so the input layout does not matter
+  const uint32_t m = (n + 1) & ~1u;  // players in the tournament (one bye when n is odd)
+  std::vector<uint32_t> seat(m);
+  std::iota(seat.begin(), seat.end(), 0u);
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double worst = 0.0;
+    for (uint32_t step = 0; step + 1 < m; ++step) {
+      double step_worst = 0.0;
+#pragma omp parallel for schedule(static) reduction(max : step_worst)
+      for (int64_t t = 0; t < (int64_t)(m / 2); ++t) {
+        uint32_t p = seat[(size_t)t], q = seat[m - 1 - (size_t)t];
+        if (p >= n || q >= n) continue;
+        if (p > q) std::swap(p, q);
+        double *ap = &A[(size_t)p * n], *aq = &A[(size_t)q * n];
+        double alpha = 0.0, beta = 0.0, gamma = 0.0;
+        for (uint32_t i = 0; i < n; ++i) {
+          alpha += ap[i] * ap[i];
+          beta += aq[i] * aq[i];
+          gamma += ap[i] * aq[i];
+        }
+        if (gamma == 0.0) continue;
+        const double denom = sqrt(alpha * beta);
+        const double off = denom > 0.0 ? fabs(gamma) / denom : 0.0;
+        step_worst = std::max(step_worst, off);
+        if (off < 1e-15) continue;
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+        double *vp = &V[(size_t)p * n], *vq = &V[(size_t)q * n];
+        for (uint32_t i = 0; i < n; ++i) {
+          const double x = ap[i], y = aq[i];
+          ap[i] = cs * x - sn * y;
+          aq[i] = sn * x + cs * y;
+          const double vx = vp[i], vy = vq[i];
+          vp[i] = cs * vx - sn * vy;
+          vq[i] = sn * vx + cs * vy;
+        }
+      }
+      worst = std::max(worst, step_worst);
+      // rotate seats 1..m-1 (seat 0 fixed)
+      const uint32_t last = seat[m - 1];
+      for (uint32_t s = m - 1; s > 1; --s) seat[s] = seat[s - 1];
+      seat[1] = last;
+    }
+    if (worst < 1e-15) break;
+  }
+  lambda.assign(n, 0.0);
+  for (uint32_t j = 0; j < n; ++j) {
+    double s = 0.0;
+    for (uint32_t i = 0; i < n; ++i) s += A[(size_t)j * n + i] * A[(size_t)j * n + i];
+    lambda[j] = sqrt(s);
+  }
+}
+
+}  // namespace kpop
+
+using namespace kpop;
+
+extern "C" int kpop_ca(const double *counts, uint64_t n_kmers, uint32_t n_spectra, int normalize, uint32_t *n_dims_out,
+                       double *twisted, double *inertia, double *twister) {
+  KPOP_TRY(require_init());
+  const uint64_t I = n_kmers;
+  const uint32_t J = n_spectra;
+  if (!counts || !n_dims_out || !twisted || !inertia || !twister) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_ca: null argument");
+  if (I < 2 || J < 2) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_ca: need at least 2 k-mers and 2 spectra");
+  const uint32_t nd = (uint32_t)std::min<uint64_t>(I, J) - 1;
+  *n_dims_out = nd;
+  hipStream_t st = nullptr;
+  const uint32_t n_slabs = div_up(I, kCaSlab);
+  DevBuf dN, dS, dW, dR, dC, dPart, dG, dGslabs, dWm, dU, dT;
+  KPOP_TRY(dN.alloc(I * J * 8));
+  KPOP_TRY(dS.alloc(I * J * 8));
+  KPOP_TRY(dW.alloc((uint64_t)J * 8));
+  KPOP_TRY(dR.alloc(I * 8));
+  KPOP_TRY(dC.alloc((uint64_t)J * 8));
+  KPOP_TRY(dPart.alloc((uint64_t)n_slabs * J * 8));
+  KPOP_HIP(hipMemcpyAsync(dN.p, counts, I * J * 8, hipMemcpyHostToDevice, st));
+  // column sums -> weights w_j (P_ij = N_ij w_j)
+  ca_col_partial_kernel<<<dim3(n_slabs), dim3(256), 0, st>>>(dN.as<double>(), I, J, nullptr, dPart.as<double>());
+  KPOP_LAUNCH_CHECK();
+  ca_col_final_kernel<<<dim3(div_up(J, 256)), dim3(256), 0, st>>>(dPart.as<double>(), n_slabs, J, dC.as<double>());
+  KPOP_LAUNCH_CHECK();
+  std::vector<double> colsum(J), w(J), c(J);
+  KPOP_HIP(hipMemcpyAsync(colsum.data(), dC.p, (uint64_t)J * 8, hipMemcpyDeviceToHost, st));
+  KPOP_HIP(hipStreamSynchronize(st));
+  double total = 0.0;
+  for (uint32_t j = 0; j < J; ++j) {
+    if (!(colsum[j] > 0.0)) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_ca: spectrum %u has no counts", j);
+    total += normalize ? 1.0 : colsum[j];
+  }
+  for (uint32_t j = 0; j < J; ++j) {
+    w[j] = normalize ? 1.0 / colsum[j] / total : 1.0 / total;  // col/sum(col), then /sum(N)
+    c[j] = colsum[j] * w[j];
+  }
+  KPOP_HIP(hipMemcpyAsync(dW.p, w.data(), (uint64_t)J * 8, hipMemcpyHostToDevice, st));
+  KPOP_HIP(hipMemcpyAsync(dC.p, c.data(), (uint64_t)J * 8, hipMemcpyHostToDevice, st));
+  ca_row_mass_kernel<<<dim3(div_up(I, 4)), dim3(256), 0, st>>>(dN.as<double>(), I, J, dW.as<double>(), dR.as<double>());
+  KPOP_LAUNCH_CHECK();
+  ca_standardise_kernel<<<dim3(std::min<uint32_t>(div_up(I * J, 256), 1u << 20)), dim3(256), 0, st>>>(
+      dN.as<double>(), I, J, dW.as<double>(), dR.as<double>(), dC.as<double>(), dS.as<double>());
+  KPOP_LAUNCH_CHECK();
+  // G = S'S  (J x J), K = I split over up to 64 slabs
+  const uint32_t tiles = div_up(J, kGT) * div_up(J, kGT);
+  uint32_t splits = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, 2048 / std::max(1u, tiles)), std::max<uint64_t>(1, I / 4096));
+  splits = std::min(splits, 256u);
+  KPOP_TRY(dG.alloc((uint64_t)J * J * 8));
+  KPOP_TRY(dGslabs.alloc((uint64_t)splits * J * J * 8));
+  KPOP_TRY(gemm_f64<true>(dS.as<double>(), J, dS.as<double>(), J, dG.as<double>(), J, J, I, splits, dGslabs.as<double>(), 1, st));
+  std::vector<double> G((size_t)J * J), V, lambda;
+  KPOP_HIP(hipMemcpyAsync(G.data(), dG.p, (uint64_t)J * J * 8, hipMemcpyDeviceToHost, st));
+  KPOP_HIP(hipStreamSynchronize(st));
+  jacobi_eigen_psd(G, J, V, lambda);
+  // order by decreasing eigenvalue; sv = sqrt(lambda)
+  std::vector<uint32_t> order(J);
+  std::iota(order.begin(), order.end(), 0u);
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return lambda[a] > lambda[b]; });
+  std::vector<double> sv(nd), Wm((size_t)J * nd);
+  double sum_sq = 0.0;
+  for (uint32_t d = 0; d < nd; ++d) {
+    sv[d] = sqrt(std::max(lambda[order[d]], 0.0));
+    sum_sq += sv[d] * sv[d];
+  }
+  for (uint32_t d = 0; d < nd; ++d) {
+    inertia[d] = sum_sq > 0.0 ? sv[d] * sv[d] / sum_sq : 0.0;
+    const double *v = &V[(size_t)order[d] * J];
+    for (uint32_t j = 0; j < J; ++j) {
+      twisted[(size_t)j * nd + d] = v[j] / sqrt(c[j]) * sv[d];   // D_c^-1/2 V diag(sv)
+      Wm[(size_t)j * nd + d] = sv[d] > 0.0 ? v[j] / sv[d] : 0.0;  // V diag(1/sv)
+    }
+  }
+  // U = S W (I x nd), then the twister = (D_r^-1/2 U)'
+  KPOP_TRY(dWm.alloc((uint64_t)J * nd * 8));
+  KPOP_TRY(dU.alloc(I * nd * 8));
+  KPOP_TRY(dT.alloc(I * nd * 8));
+  KPOP_HIP(hipMemcpyAsync(dWm.p, Wm.data(), (uint64_t)J * nd * 8, hipMemcpyHostToDevice, st));
+  KPOP_TRY(gemm_f64<false>(dS.as<double>(), J, dWm.as<double>(), nd, dU.as<double>(), (uint32_t)std::min<uint64_t>(I, 0xFFFFFFFFull), nd, J,
+                           1, nullptr, 0, st));
+  ca_row_coords_kernel<<<dim3(div_up(I, 32), div_up(nd, 32)), dim3(256), 0, st>>>(dU.as<double>(), I, nd, dR.as<double>(),
+                                                                                 dT.as<double>());
+  KPOP_LAUNCH_CHECK();
+  KPOP_HIP(hipMemcpyAsync(twister, dT.p, I * nd * 8, hipMemcpyDeviceToHost, st));
+  KPOP_HIP(hipStreamSynchronize(st));
+  return KPOP_OK;
+}

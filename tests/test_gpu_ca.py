@@ -1,0 +1,73 @@
+"""GPU parity of the twister generator (kpop_ca: correspondence analysis, MFMA f64 GEMMs + host Jacobi)
+against the numpy restatement of R's `ca` as KPopTwist uses it (src/KPopTwist:93-116).  Dimension signs are
+arbitrary (they are in R too), so dimensions are sign-aligned before comparing."""
+import numpy as np
+import pytest
+
+from oracle import ca_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def synthetic_table(rng, n_kmers, n_classes, depth=200):
+    base = rng.gamma(2.0, 1.0, size=n_kmers)
+    classes = [np.maximum(base * rng.lognormal(0.0, 0.6, size=n_kmers), 0) for _ in range(n_classes)]
+    return np.array([rng.poisson(c / c.sum() * depth * n_kmers) for c in classes], dtype=np.float64).T.copy()
+
+
+@pytest.mark.parametrize("I,J,normalize", [(512, 10, True), (512, 10, False), (2080, 33, True), (8256, 130, True), (300, 2, True)])
+def test_ca_vs_numpy_svd(kpop, I, J, normalize):
+    rng = np.random.RandomState(I + J)
+    N = synthetic_table(rng, I, J)
+    N[5] = 0.0  # a k-mer that occurs nowhere: no mass, zero twister column
+    tw_o, in_o, T_o = ca_ref.ca(N, normalize)
+    tw, inertia, T = kpop.ca(N, normalize)
+    nd = min(I, J) - 1
+    assert tw.shape == (J, nd) and inertia.shape == (nd,) and T.shape == (nd, I)
+    np.testing.assert_allclose(inertia, in_o, rtol=1e-9, atol=1e-14)
+    assert abs(inertia.sum() - 1.0) < 1e-12 and np.all(np.diff(inertia) <= 1e-15)
+    tw_a = ca_ref.align_signs(tw, tw_o, axis=1)
+    T_a = ca_ref.align_signs(T, T_o, axis=0)
+    scale_tw, scale_T = np.max(np.abs(tw_o)), np.max(np.abs(T_o))
+    # the Gram route loses accuracy on dimensions with tiny singular values: hold the leading 90 % tightly
+    lead = max(1, int(0.9 * nd))
+    assert np.max(np.abs(tw_a[:, :lead] - tw_o[:, :lead])) <= 1e-8 * scale_tw
+    assert np.max(np.abs(T_a[:lead] - T_o[:lead])) <= 1e-8 * scale_T
+    assert np.max(np.abs(tw_a - tw_o)) <= 1e-6 * scale_tw
+    assert np.all(T[:, 5] == 0.0)
+    # transition formula: twisting a class's own (normalised) spectrum through the twister gives its position
+    x = N / N.sum(axis=0, keepdims=True)
+    np.testing.assert_allclose(T @ x, tw.T, rtol=0, atol=1e-9 * scale_tw)
+
+
+def test_generated_twister_feeds_the_hot_path(kpop, oracle):
+    """End to end without R: class spectra -> kpop_ca -> twister -> kpop_count_twist classifies reads
+    drawn from the classes (nearest class = true class)."""
+    k, n_classes, glen = 6, 8, 4000
+    rng = np.random.RandomState(3)
+    genomes = ["".join(rng.choice(list("ACGT"), size=glen)) for _ in range(n_classes)]
+    cols = oracle.enumerate_kmers(k)
+    col_of = {int(h): i for i, h in enumerate(cols)}
+    from conftest import concat
+    gb, go = concat(genomes)
+    h, c, o = oracle.count_reads(gb, go, k)
+    N = np.zeros((len(cols), n_classes))
+    for j in range(n_classes):
+        for hh, cc in zip(h[int(o[j]):int(o[j + 1])], c[int(o[j]):int(o[j + 1])]):
+            N[col_of[int(hh)], j] = cc
+    twisted_classes, inertia, T = kpop.ca(N)
+    tw = kpop.Twister.load(T, cols, k)
+    # class vectors through the twister == CA's own class positions
+    got = tw.count_twist(gb, go)
+    np.testing.assert_allclose(got, twisted_classes, rtol=0, atol=1e-9 * np.max(np.abs(twisted_classes)))
+    reads, truth = [], []
+    for j, g in enumerate(genomes):
+        for _ in range(20):
+            s = int(rng.randint(0, glen - 600))
+            reads.append(g[s:s + 600])
+            truth.append(j)
+    rb, ro = concat(reads)
+    t = tw.count_twist(rb, ro)
+    metric = kpop.metric_compute(inertia)
+    d = kpop.distance_rowwise(twisted_classes, t, metric)
+    assert (np.argmin(d, axis=1) == np.array(truth)).mean() >= 0.95
