@@ -9,7 +9,7 @@
 //
 // I = number of k-mers (10^3 .. 10^7), J = number of spectra/classes (10 .. ~2000): tall and skinny.  The SVD is
 // taken through the J x J Gram matrix G = S'S (MFMA f64 GEMM, split over K = I), a one-sided Jacobi
-// eigen-decomposition of G on the host (J^3, small), and U = S V diag(1/sv) as a second MFMA GEMM.
+// eigen-decomposition of G (J^3, small; one launch per round-robin step), and U = S V diag(1/sv) as a second MFMA GEMM.
 // The Gram route squares the condition number: dimensions whose singular value is below ~1e-7 of the largest
 // lose accuracy -- they carry < 1e-14 of the inertia.
 #include <math.h>
@@ -98,64 +98,103 @@ __global__ __launch_bounds__(256) void ca_row_coords_kernel(const double *__rest
   }
 }
 
-// One-sided Jacobi (Hestenes) on the columns of the symmetric PSD matrix G (n x n, column-major == row-major):
-// on exit the column norms are the eigenvalues and V holds the eigenvectors.  Round-robin pairing: the n/2
-// rotations of a step touch disjoint columns and run in parallel.
-static void jacobi_eigen_psd(std::vector<double> &A, uint32_t n, std::vector<double> &V, std::vector<double> &lambda) {
-  V.assign((size_t)n * n, 0.0);
-  for (uint32_t i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
-  // store by columns: col(j) = &A[j*n]; G symmetric so the input layout does not matter
-  const uint32_t m = (n + 1) & ~1u;  // players in the tournament (one bye when n is odd)
-  std::vector<uint32_t> seat(m);
-  std::iota(seat.begin(), seat.end(), 0u);
+// One-sided Jacobi (Hestenes) on the columns of the symmetric PSD matrix G (n x n): on exit the column norms
+// are the eigenvalues and V holds the eigenvectors.  Round-robin (circle method) pairing: the n/2 rotations of a
+// step touch disjoint columns, so a step is one launch with one 256-thread block per pair; 3 ordered block
+// reductions (|a_p|^2, |a_q|^2, a_p.a_q) then the rotation of both columns of A and of V.  The largest
+// |a_p.a_q| / (|a_p||a_q|) of a sweep is kept in `worst` (non-negative doubles order like their bit patterns).
+__device__ __forceinline__ double block_sum_256(double v, double *s_w) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
+}
+
+__global__ __launch_bounds__(256) void jacobi_step_kernel(double *__restrict__ A, double *__restrict__ V, uint32_t n,
+                                                          uint32_t m, uint32_t step, unsigned long long *worst) {
+  __shared__ double s_w[4];
+  const uint32_t t = blockIdx.x;
+  uint32_t p, q;
+  if (t == 0) {
+    p = m - 1;
+    q = step;
+  } else {
+    p = (step + t) % (m - 1);
+    q = (step + (m - 1) - t) % (m - 1);
+  }
+  if (p >= n || q >= n) return;  // the bye of an odd n
+  if (p > q) {
+    const uint32_t x = p;
+    p = q;
+    q = x;
+  }
+  double *ap = A + (uint64_t)p * n, *aq = A + (uint64_t)q * n;
+  double alpha = 0.0, beta = 0.0, gamma = 0.0;
+  for (uint32_t i = threadIdx.x; i < n; i += 256) {
+    const double x = ap[i], y = aq[i];
+    alpha += x * x;
+    beta += y * y;
+    gamma += x * y;
+  }
+  alpha = block_sum_256(alpha, s_w);
+  beta = block_sum_256(beta, s_w);
+  gamma = block_sum_256(gamma, s_w);
+  if (gamma == 0.0) return;
+  const double denom = sqrt(alpha * beta);
+  const double off = denom > 0.0 ? fabs(gamma) / denom : 0.0;
+  if (threadIdx.x == 0) atomicMax(worst, (unsigned long long)__double_as_longlong(off));
+  if (off < 1e-15) return;
+  const double zeta = (beta - alpha) / (2.0 * gamma);
+  const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+  double *vp = V + (uint64_t)p * n, *vq = V + (uint64_t)q * n;
+  for (uint32_t i = threadIdx.x; i < n; i += 256) {
+    const double x = ap[i], y = aq[i];
+    ap[i] = cs * x - sn * y;
+    aq[i] = sn * x + cs * y;
+    const double vx = vp[i], vy = vq[i];
+    vp[i] = cs * vx - sn * vy;
+    vq[i] = sn * vx + cs * vy;
+  }
+}
+
+__global__ void jacobi_identity_kernel(double *__restrict__ V, uint32_t n) {
+  const uint64_t total = (uint64_t)n * n, stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) V[e] = (e / n == e % n) ? 1.0 : 0.0;
+}
+
+__global__ __launch_bounds__(256) void jacobi_colnorm_kernel(const double *__restrict__ A, uint32_t n, double *__restrict__ lambda) {
+  __shared__ double s_w[4];
+  const double *a = A + (uint64_t)blockIdx.x * n;
+  double s = 0.0;
+  for (uint32_t i = threadIdx.x; i < n; i += 256) s += a[i] * a[i];
+  s = block_sum_256(s, s_w);
+  if (threadIdx.x == 0) lambda[blockIdx.x] = sqrt(s);
+}
+
+// d_G is overwritten (columns rotated); d_V receives the eigenvectors as columns (V[j*n + i] = component i of vector j)
+static int jacobi_eigen_psd_device(double *d_G, double *d_V, uint32_t n, double *d_lambda, hipStream_t st) {
+  DevBuf worst;
+  KPOP_TRY(worst.alloc(8));
+  jacobi_identity_kernel<<<dim3(std::min<uint32_t>(div_up((uint64_t)n * n, 256), 4096)), dim3(256), 0, st>>>(d_V, n);
+  KPOP_LAUNCH_CHECK();
+  const uint32_t m = (n + 1) & ~1u;
   for (int sweep = 0; sweep < 60; ++sweep) {
-    double worst = 0.0;
+    KPOP_HIP(hipMemsetAsync(worst.p, 0, 8, st));
     for (uint32_t step = 0; step + 1 < m; ++step) {
-      double step_worst = 0.0;
-#pragma omp parallel for schedule(static) reduction(max : step_worst)
-      for (int64_t t = 0; t < (int64_t)(m / 2); ++t) {
-        uint32_t p = seat[(size_t)t], q = seat[m - 1 - (size_t)t];
-        if (p >= n || q >= n) continue;
-        if (p > q) std::swap(p, q);
-        double *ap = &A[(size_t)p * n], *aq = &A[(size_t)q * n];
-        double alpha = 0.0, beta = 0.0, gamma = 0.0;
-        for (uint32_t i = 0; i < n; ++i) {
-          alpha += ap[i] * ap[i];
-          beta += aq[i] * aq[i];
-          gamma += ap[i] * aq[i];
-        }
-        if (gamma == 0.0) continue;
-        const double denom = sqrt(alpha * beta);
-        const double off = denom > 0.0 ? fabs(gamma) / denom : 0.0;
-        step_worst = std::max(step_worst, off);
-        if (off < 1e-15) continue;
-        const double zeta = (beta - alpha) / (2.0 * gamma);
-        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
-        double *vp = &V[(size_t)p * n], *vq = &V[(size_t)q * n];
-        for (uint32_t i = 0; i < n; ++i) {
-          const double x = ap[i], y = aq[i];
-          ap[i] = cs * x - sn * y;
-          aq[i] = sn * x + cs * y;
-          const double vx = vp[i], vy = vq[i];
-          vp[i] = cs * vx - sn * vy;
-          vq[i] = sn * vx + cs * vy;
-        }
-      }
-      worst = std::max(worst, step_worst);
-      // rotate seats 1..m-1 (seat 0 fixed)
-      const uint32_t last = seat[m - 1];
-      for (uint32_t s = m - 1; s > 1; --s) seat[s] = seat[s - 1];
-      seat[1] = last;
+      jacobi_step_kernel<<<dim3(m / 2), dim3(256), 0, st>>>(d_G, d_V, n, m, step, worst.as<unsigned long long>());
+      KPOP_LAUNCH_CHECK();
     }
-    if (worst < 1e-15) break;
+    double w = 0.0;
+    KPOP_HIP(hipMemcpyAsync(&w, worst.p, 8, hipMemcpyDeviceToHost, st));
+    KPOP_HIP(hipStreamSynchronize(st));
+    if (w < 1e-15) break;
   }
-  lambda.assign(n, 0.0);
-  for (uint32_t j = 0; j < n; ++j) {
-    double s = 0.0;
-    for (uint32_t i = 0; i < n; ++i) s += A[(size_t)j * n + i] * A[(size_t)j * n + i];
-    lambda[j] = sqrt(s);
-  }
+  jacobi_colnorm_kernel<<<dim3(n), dim3(256), 0, st>>>(d_G, n, d_lambda);
+  KPOP_LAUNCH_CHECK();
+  return 0;
 }
 
 }  // namespace kpop
@@ -212,10 +251,14 @@ extern "C" int kpop_ca(const double *counts, uint64_t n_kmers, uint32_t n_spectr
   KPOP_TRY(dG.alloc((uint64_t)J * J * 8));
   KPOP_TRY(dGslabs.alloc((uint64_t)splits * J * J * 8));
   KPOP_TRY(gemm_f64<true>(dS.as<double>(), J, dS.as<double>(), J, dG.as<double>(), J, J, I, splits, dGslabs.as<double>(), 1, st));
-  std::vector<double> G((size_t)J * J), V, lambda;
-  KPOP_HIP(hipMemcpyAsync(G.data(), dG.p, (uint64_t)J * J * 8, hipMemcpyDeviceToHost, st));
+  DevBuf dV, dLambda;
+  KPOP_TRY(dV.alloc((uint64_t)J * J * 8));
+  KPOP_TRY(dLambda.alloc((uint64_t)J * 8));
+  KPOP_TRY(jacobi_eigen_psd_device(dG.as<double>(), dV.as<double>(), J, dLambda.as<double>(), st));
+  std::vector<double> V((size_t)J * J), lambda(J);
+  KPOP_HIP(hipMemcpyAsync(V.data(), dV.p, (uint64_t)J * J * 8, hipMemcpyDeviceToHost, st));
+  KPOP_HIP(hipMemcpyAsync(lambda.data(), dLambda.p, (uint64_t)J * 8, hipMemcpyDeviceToHost, st));
   KPOP_HIP(hipStreamSynchronize(st));
-  jacobi_eigen_psd(G, J, V, lambda);
   // order by decreasing eigenvalue; sv = sqrt(lambda)
   std::vector<uint32_t> order(J);
   std::iota(order.begin(), order.end(), 0u);
