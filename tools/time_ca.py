@@ -24,7 +24,7 @@ def main():
         tw, inertia, T = kpop_amd.ca(N)
         t1 = time.time()
         flops = 2.0 * I * J * J * 0.5 + 2.0 * I * J * (J - 1)  # upper half of S'S + S*W
-        print("kpop_ca I=%d J=%d: %.2f s wall (incl. %.1f GB H2D, %.1f GB D2H, host Jacobi); GEMM flops %.2f T" % (I, J, t1 - t0, N.nbytes / 1e9, T.nbytes / 1e9, flops / 1e12), flush=True)
+        print("kpop_ca I=%d J=%d: %.2f s wall (incl. %.1f GB H2D, %.1f GB D2H, Jacobi on the GPU); GEMM flops %.2f T" % (I, J, t1 - t0, N.nbytes / 1e9, T.nbytes / 1e9, flops / 1e12), flush=True)
         if I * J <= 131328 * 256:
             tw_o, in_o, T_o = ca_ref.ca(N)
             print("   vs numpy: inertia max rel %.1e, twisted max abs (sign-aligned, leading half) %.1e" % (
