@@ -242,3 +242,58 @@ def test_readme_commands_verbatim_with_binary_registers(tmp_path, oracle, pyref)
     dm_lines = (tmp_path / "Test-vs-Classes.KPopDMatrix.txt").read_text().splitlines()
     assert dm_lines[0].split("\t")[1:] == ['"%s"' % n for n in sorted((t for t, _ in class_reads), key=lambda s: s.encode())]
     assert [l.split("\t")[0] for l in dm_lines[1:]] == ['"%s"' % n for n in sorted((t for t, _ in test_reads), key=lambda s: s.encode())]
+
+
+def test_training_without_r_then_classification(tmp_path, oracle, pyref):
+    """The README quick-start shape end to end with no R: class spectra table (what KPopCountDB -t exports,
+    src/KPopTwist:38-44) -> KPopTwistCA (replaces the Rscript stage, :49-119) -> KPopTwistDB -I/-o as the wrapper
+    does (:122-127) -> classify test reads with the README commands (:606,656)."""
+    from oracle import ca_ref
+    k, n_classes, glen = 5, 6, 3000
+    rng = np.random.RandomState(8)
+    genomes = ["".join(rng.choice(list("ACGT"), size=glen)) for _ in range(n_classes)]
+    kmers = sorted({h for g in genomes for h in pyref.count_read(g, k)})
+    N = np.array([[pyref.count_read(g, k).get(h, 0) for g in genomes] for h in kmers], dtype=np.float64)
+    with open(tmp_path / "TABLE.KPopCounter.txt", "w") as f:
+        f.write("\t".join("C%d" % (j + 1) for j in range(n_classes)) + "\n")
+        for row in N:
+            f.write("\t".join("%.15g" % v for v in row) + "\n")
+    (tmp_path / "NAMES.KPopCounter.txt").write_text("".join(pyref.to_hex(h, k) + "\n" for h in kmers))
+    CA = os.path.join(BIN, "KPopTwistCA")
+    r = run([CA, str(tmp_path / "TABLE.KPopCounter.txt"), str(tmp_path / "NAMES.KPopCounter.txt"), str(tmp_path / "Classes"),
+             str(tmp_path / "ClassKmers"), "", "1.", "TRUE", "0", "8", "FALSE", "TRUE"])
+    assert r.returncode == 0, r.stderr
+    # the three tables against the numpy restatement of R's ca (sign-aligned per dimension)
+    tw_o, in_o, T_o = ca_ref.ca(N)
+    def table(path):
+        lines = open(path).read().splitlines()
+        return lines[0].split("\t"), [l.split("\t")[0] for l in lines[1:]], np.array([[float(v) for v in l.split("\t")[1:]] for l in lines[1:]])
+    hdr, rows, tw = table(tmp_path / "Classes.KPopTwisted.txt")
+    assert hdr == ['"rn"'] + ['"Dim%d"' % (d + 1) for d in range(n_classes - 1)] and rows == ['"C%d"' % (j + 1) for j in range(n_classes)]
+    assert np.max(np.abs(ca_ref.align_signs(tw, tw_o, 1) - tw_o)) <= 1e-9 * np.max(np.abs(tw_o))
+    hdr, rows, inertia = table(tmp_path / "Classes.KPopInertia.txt")
+    assert rows == ['"inertia"'] and np.allclose(inertia[0], in_o, rtol=1e-9)
+    hdr, rows, T = table(tmp_path / "Classes.KPopTwister.txt")
+    assert hdr == ['""'] + ['"%s"' % pyref.to_hex(h, k) for h in kmers] and rows == ['"Dim%d"' % (d + 1) for d in range(n_classes - 1)]
+    assert np.max(np.abs(ca_ref.align_signs(T, T_o, 0) - T_o)) <= 1e-9 * np.max(np.abs(T_o))
+    hdr, rows, F = table(tmp_path / "ClassKmers.KPopTwisted.txt")
+    assert F.shape == (len(kmers), n_classes - 1)
+    # encode as the wrapper does, then classify
+    penv = dict(os.environ, PATH=BIN + ":" + os.environ.get("PATH", ""))
+    sh = lambda cmd: subprocess.run(cmd, shell=True, cwd=str(tmp_path), capture_output=True, text=True, timeout=120, env=penv)
+    assert sh("KPopTwistDB -I t Classes -o t Classes").returncode == 0
+    assert sh("KPopTwistDB -I T Classes -o T Classes").returncode == 0
+    reads, truth = [], []
+    for j, g in enumerate(genomes):
+        for i in range(5):
+            s = int(rng.randint(0, glen - 500))
+            reads.append(("t%d_%d" % (j + 1, i), g[s:s + 500]))
+            truth.append("C%d" % (j + 1))
+    write_fasta(tmp_path / "test.fa", reads)
+    r = sh("KPopCount -k 5 -L -f test.fa | KPopTwistDB -i T Classes -k /dev/stdin -o t Test")
+    assert r.returncode == 0, r.stderr
+    r = sh("KPopTwistDB -i T Classes -i t Classes -s Test Test-vs-Classes")
+    assert r.returncode == 0, r.stderr
+    got = {l.split("\t")[0]: l.split("\t")[5] for l in (tmp_path / "Test-vs-Classes.KPopSummary.txt").read_text().splitlines()}
+    correct = sum(got[name] == cls for (name, _), cls in zip(reads, truth))
+    assert correct >= 0.9 * len(reads), (correct, len(reads))
