@@ -123,8 +123,9 @@ def main():
     classes = torch.zeros(C, d, dtype=torch.float64, device=dev)
     api.dev_count_twist(tw, cbases.data_ptr(), coffs.data_ptr(), C, C * args.class_len, args.class_len, classes.data_ptr(),
                         stream=sp)
-    from oracle import oracle as O  # only for the inertia of the synthetic twister and the cpu_baseline leg
-    metric_host = kpop_amd.metric_compute(O.synth_inertia(d))
+    # inertia of the synthetic twister: w_d ~ 2^(-d/8), sum 1; metric = powers(1,1,2) of it
+    w = np.exp2(-np.arange(d, dtype=np.float64) / 8.0)
+    metric_host = kpop_amd.metric_compute(w / w.sum())
     metric = torch.from_numpy(metric_host).to(dev)
     twisted = torch.zeros(max(n_local, 1), d, dtype=torch.float64, device=dev)
     dmat = torch.zeros(max(n_local, 1), C, dtype=torch.float64, device=dev)
