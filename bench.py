@@ -203,7 +203,7 @@ def main():
                          "algorithmic_bytes_per_launch": n_local * bytes_per_read, "avg_launch_ms": ms_fused},
             "kernels_ms": {"count_twist": ms_fused, "distance_rowwise(+norms)": ms_dist},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs on rank 0 at N=1 only
             m = min(n_local, 20000)
             cb, parity = cpu_baseline(args, metric_host, twisted[:m].cpu().numpy(), dmat[:m].cpu().numpy(),
                                       classes.cpu().numpy(), None)
