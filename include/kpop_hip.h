@@ -66,8 +66,7 @@ const char *kpop_last_error(void);
 const char *kpop_version(void);
 int kpop_synchronize(void *stream);
 /* performance knobs for A/B measurements (results are identical for every setting):
-   "unroll" 8|16 row loads in flight per wave, "nt" 0|1 non-temporal row loads,
-   "index" 0 = rank-select name->column index when the twister allows it, 1 = force the LUT */
+   "unroll" 8|16 row loads in flight per wave, "nt" 0|1 non-temporal row loads */
 int kpop_tune(const char *key, int value);
 
 /* plain device-memory helpers so a non-HIP host language can stage buffers */

@@ -49,10 +49,9 @@ struct Context {
   int n_cus = 256;
   size_t lds_per_block = 65536;
   Workspace ws;
-  // tuning knobs (kpop_tune): gather depth, non-temporal row loads, index choice
+  // tuning knobs (kpop_tune): gather depth, non-temporal row loads
   int tune_unroll = 8;
   int tune_nt = 1;       // rows are streamed once: keep them out of the caches the index lives in
-  int tune_index = 0;  // 0 = rank-select when available, 1 = force the LUT
 };
 Context &ctx();
 int require_init();

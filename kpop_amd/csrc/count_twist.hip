@@ -468,7 +468,6 @@ static int launch_count_twist_wave(int R, TwisterView tv, const uint8_t *bases, 
                                    const uint32_t *ids, uint32_t n, int content, int normalize, double *out,
                                    hipStream_t st) {
   const Context &c = ctx();
-  if (c.tune_index == 1 && tv.lut) tv.rsel = nullptr;
   if (c.tune_unroll == 16)
     return c.tune_nt ? launch_count_twist_wave_v<H, 16, true>(R, tv, bases, offsets, ids, n, content, normalize, out, st)
                      : launch_count_twist_wave_v<H, 16, false>(R, tv, bases, offsets, ids, n, content, normalize, out, st);

@@ -94,7 +94,6 @@ extern "C" int kpop_tune(const char *key, int value) {
   Context &c = ctx();
   if (!strcmp(key, "unroll") && (value == 8 || value == 16)) c.tune_unroll = value;
   else if (!strcmp(key, "nt") && (value == 0 || value == 1)) c.tune_nt = value;
-  else if (!strcmp(key, "index") && (value == 0 || value == 1)) c.tune_index = value;
   else KPOP_FAIL(KPOP_ERR_INVALID, "kpop_tune: unknown knob or value %s=%d", key, value);
   return KPOP_OK;
 }

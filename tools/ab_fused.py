@@ -35,7 +35,7 @@ def main():
     offs = torch.empty(n + 1, dtype=torch.int64, device=dev)
     api.dev_synth_reads(0x4B506F70, n, L, bases.data_ptr(), offs.data_ptr(), stream=sp)
     out = torch.zeros(n, a.dims, dtype=torch.float64, device=dev)
-    variants = [dict(index=i, nt=t, unroll=u) for i, t, u in itertools.product((1, 0), (0, 1), (8, 16))]
+    variants = [dict(nt=t, unroll=u) for t, u in itertools.product((0, 1), (8, 16))]
     ref = None
     times = {str(v): [] for v in variants}
     for rnd in range(a.rounds):
