@@ -177,6 +177,7 @@ struct Reader {
     return add(nd, true);
   }
   uint32_t read_block(uint64_t size, int tag) {
+    if (size > data.size() - pos) throw Error("marshal: block larger than the value");  // every field takes >= 1 byte
     Node nd;
     nd.kind = Node::Block;
     nd.tag = tag;
@@ -260,6 +261,14 @@ bool read_one(FILE *f, Reader &r) {
     data_len = be(hd + 8, 8);
   } else {
     throw Error("marshal: bad magic number (not an OCaml output_value stream, or a compressed one)");
+  }
+  {  // a corrupt length must not turn into a giant allocation: it cannot exceed what is left of a regular file
+    const long here = ftell(f);
+    if (here >= 0 && fseek(f, 0, SEEK_END) == 0) {
+      const long end = ftell(f);
+      fseek(f, here, SEEK_SET);
+      if (end >= here && data_len > (uint64_t)(end - here)) throw Error("marshal: truncated value");
+    }
   }
   r = Reader();
   r.data.resize(data_len);

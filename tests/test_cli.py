@@ -8,7 +8,7 @@ import pytest
 
 from conftest import ROOT, load_golden
 
-BIN = os.path.join(ROOT, "kpop_amd", "bin")
+BIN = os.environ.get("KPOP_TEST_BIN", os.path.join(ROOT, "kpop_amd", "bin"))  # e.g. an ASan build of kpop_amd/host
 TWISTDB = os.path.join(BIN, "KPopTwistDB")
 COUNT = os.path.join(BIN, "KPopCount")
 
