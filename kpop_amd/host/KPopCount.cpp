@@ -193,7 +193,7 @@ int main(int argc, char **argv) {
     std::vector<char> iobuf(1 << 22);
     setvbuf(out, iobuf.data(), _IOFBF, iobuf.size());
     if (!P.label.empty()) fprintf(out, "\t%s\n", P.label.c_str());  // :33-34
-    const uint64_t max_bases = 256ull << 20, max_reads = 4u << 20;
+    const uint64_t max_bases = 256ull << 20, max_reads = 1u << 20;  // bounds the device scratch of a batch to a few GB
     ReadBatch batch;
     batch.clear();
     Merged merged;
