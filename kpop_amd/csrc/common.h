@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 
 #include "../../include/kpop_hip.h"
 
@@ -43,12 +44,29 @@ struct Workspace {
   void release();
 };
 
+// Device scratch of the host-buffer entry points.  hipMalloc/hipFree cost milliseconds per call at the sizes a
+// 100k-read batch needs, so scratch comes from grow-only chunks that are kept until kpop_shutdown(); an
+// ArenaScope at the top of an entry point gives stack discipline (everything taken inside is handed back on exit).
+struct Arena {
+  struct Chunk {
+    void *p;
+    uint64_t bytes;
+  };
+  std::vector<Chunk> chunks;
+  size_t cur = 0;
+  uint64_t off = 0;
+  int depth = 0;
+  int take(uint64_t n, void **out);
+  void release();
+};
+
 struct Context {
   bool initialised = false;
   int device = -1;
   int n_cus = 256;
   size_t lds_per_block = 65536;
   Workspace ws;
+  Arena arena;
   // tuning knobs (kpop_tune): gather depth, non-temporal row loads
   int tune_unroll = 8;
   int tune_nt = 1;       // rows are streamed once: keep them out of the caches the index lives in
@@ -58,23 +76,44 @@ int require_init();
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
-// RAII device buffer for the host-side entry points.
+struct ArenaScope {
+  size_t cur;
+  uint64_t off;
+  ArenaScope() {
+    Arena &a = ctx().arena;
+    cur = a.cur;
+    off = a.off;
+    ++a.depth;
+  }
+  ~ArenaScope() {
+    Arena &a = ctx().arena;
+    a.cur = cur;
+    a.off = off;
+    --a.depth;
+  }
+};
+
+// RAII device buffer for the host-side entry points: arena-backed inside an ArenaScope, hipMalloc'ed otherwise.
 struct DevBuf {
   void *p = nullptr;
   uint64_t bytes = 0;
+  bool owned = false;
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
   }
   int alloc(uint64_t n) {
-    if (p) {
-      (void)hipFree(p);
-      p = nullptr;
-    }
+    if (p && owned) (void)hipFree(p);
+    p = nullptr;
     bytes = n;
     if (n == 0) n = 8;
+    if (ctx().arena.depth > 0) {
+      owned = false;
+      return ctx().arena.take(n, &p);
+    }
+    owned = true;
     KPOP_HIP(hipMalloc(&p, n));
     return 0;
   }

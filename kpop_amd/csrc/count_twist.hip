@@ -621,6 +621,7 @@ extern "C" int kpop_count_reads(const uint8_t *bases, const uint64_t *offsets, u
                                 int per_read, uint64_t *out_hash, uint32_t *out_count, uint64_t *out_offsets,
                                 uint64_t out_capacity) {
   KPOP_TRY(require_init());
+  ArenaScope scratch;
   if (!offsets || !out_offsets || (!out_hash && out_capacity) || (!out_count && out_capacity))
     KPOP_FAIL(KPOP_ERR_INVALID, "kpop_count_reads: null argument");
   if (k < 1 || k > kMaxK) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_count_reads: k=%d out of range 1..%d", k, kMaxK);
@@ -703,6 +704,7 @@ extern "C" int kpop_count_reads(const uint8_t *bases, const uint64_t *offsets, u
 extern "C" int kpop_count_twist(const kpop_twister *tw, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
                                 int content, int normalize, double *out) {
   KPOP_TRY(require_init());
+  ArenaScope scratch;
   if (!tw || !offsets || (!out && n_reads)) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_count_twist: null argument");
   if (n_reads == 0) return KPOP_OK;
   uint64_t max_len = 0;
@@ -728,6 +730,7 @@ extern "C" int kpop_count_twist(const kpop_twister *tw, const uint8_t *bases, co
 extern "C" int kpop_twist(const kpop_twister *tw, const uint64_t *hash, const double *value, const uint64_t *offsets,
                           uint32_t n_spectra, int normalize, double *out) {
   KPOP_TRY(require_init());
+  ArenaScope scratch;
   if (!tw || !offsets || (!out && n_spectra)) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_twist: null argument");
   if (n_spectra == 0) return KPOP_OK;
   uint64_t max_lines = 0;

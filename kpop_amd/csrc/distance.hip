@@ -548,6 +548,7 @@ extern "C" int kpop_summarize_distances(const double *dist, uint32_t r2, uint32_
                                         uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
                                         double *out_dist, double *out_z) {
   KPOP_TRY(require_init());
+  ArenaScope scratch;
   if (r2 == 0) return KPOP_OK;
   if (!out_stats || !out_n || (r1 && !dist)) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_summarize_distances: null argument");
   hipStream_t st = nullptr;
@@ -576,6 +577,7 @@ extern "C" int kpop_summarize_distances(const double *dist, uint32_t r2, uint32_
 extern "C" int kpop_distance_rowwise(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
                                      const double *metric, int kind, double p, int normalize, double *out) {
   KPOP_TRY(require_init());
+  ArenaScope scratch;
   KPOP_TRY(check_kind(kind, p, "kpop_distance_rowwise"));
   if (r1 == 0 || r2 == 0) return KPOP_OK;
   if (!m1 || !m2 || !metric || !out) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_distance_rowwise: null argument");
@@ -602,6 +604,7 @@ extern "C" int kpop_distance_summary(const double *m1, uint32_t r1, const double
                                      uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
                                      double *out_dist, double *out_z) {
   KPOP_TRY(require_init());
+  ArenaScope scratch;
   KPOP_TRY(check_kind(kind, p, "kpop_distance_summary"));
   if (r2 == 0) return KPOP_OK;
   if (!m2 || !metric || !out_stats || !out_n || (r1 && !m1))

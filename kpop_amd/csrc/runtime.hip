@@ -4,6 +4,8 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace kpop {
@@ -37,6 +39,34 @@ int Workspace::ensure(uint64_t need, void **out) {
   }
   *out = p;
   return 0;
+}
+
+int Arena::take(uint64_t n, void **out) {
+  n = (n + 255) & ~255ull;
+  for (;;) {
+    if (cur < chunks.size()) {
+      if (off + n <= chunks[cur].bytes) {
+        *out = reinterpret_cast<char *>(chunks[cur].p) + off;
+        off += n;
+        return 0;
+      }
+      ++cur;  // the rest of this chunk stays unused until the scope unwinds
+      off = 0;
+      continue;
+    }
+    Chunk c;
+    c.bytes = std::max<uint64_t>(n, 64ull << 20);
+    c.p = nullptr;
+    KPOP_HIP(hipMalloc(&c.p, c.bytes));
+    chunks.push_back(c);
+  }
+}
+
+void Arena::release() {
+  for (Chunk &c : chunks) (void)hipFree(c.p);
+  chunks.clear();
+  cur = 0;
+  off = 0;
 }
 
 void Workspace::release() {
@@ -85,6 +115,7 @@ extern "C" int kpop_init(int device) {
 
 extern "C" int kpop_shutdown(void) {
   ctx().ws.release();
+  ctx().arena.release();
   ctx().initialised = false;
   return KPOP_OK;
 }
