@@ -201,6 +201,52 @@ int kpop_dev_summarize_distances(const double *d_dist, uint32_t r2, uint32_t r1,
                                  uint32_t max_neighbours, double *d_out_stats, uint32_t *d_out_n,
                                  uint32_t *d_out_idx, double *d_out_dist, double *d_out_z, void *stream);
 
+/* ------------------------------------------------- k-mer database (KPopCountDB)
+ * the operations of lib/KMerDB.ml that touch every count.  A database is the reference's
+ * `storage: I32BAVector.t array` (lib/KMerDB.ml:54-63): n_cols spectra ("columns"), each a vector of n_rows int32
+ * counts -- passed as one pointer per spectrum, exactly the shape an OCaml binding has in hand (Bigarray data
+ * lives outside the OCaml heap and does not move).  Statistics are {non_zero, max, sum, sum_log} per vector
+ * (Transformation.statistics_t, :73-79; `min` is always 0 there and unused).                                   */
+#define KPOP_TRANSF_BINARY 0 /* lib/KMerDB.ml:88-92 (Transformation.t) */
+#define KPOP_TRANSF_POWER 1
+#define KPOP_TRANSF_CLR 2
+#define KPOP_TRANSF_PSEUDO 3
+#define KPOP_COMBINE_MEAN 0 /* lib/KMerDB.ml:616-626 (CombinationCriterion.t) */
+#define KPOP_COMBINE_MEDIAN 1
+
+/* Replaces stats_table_of_core_db, lib/KMerDB.ml:171-271: col_stats is n_cols x 4, row_stats n_rows x 4 (either
+ * may be NULL).  A threshold below 1 is relative to the vector's own sum of count^power (:190-195).             */
+int kpop_counter_stats(const int32_t *const *columns, uint32_t n_cols, uint64_t n_rows, double threshold,
+                       double power, double *col_stats, double *row_stats);
+
+/* Replaces the worker + consumer of add_combined_selected, lib/KMerDB.ml:661-722: combines the spectra
+ * columns[sel[0..n_sel)] (visited in that order; the reference's order is its `found_cols`, :646-660) into
+ * out[n_rows] = Int32.of_float(sum or median * n_sel of count * max_norm / norm) (:693-716).  col_sum[c] is the
+ * linear statistic `sum` of column c (kpop_counter_stats with threshold 1, power 1).  *out_norm (may be NULL)
+ * receives the accumulated norm the reference prints in verbose mode (:715,725).                                */
+int kpop_counter_combine(const int32_t *const *columns, uint64_t n_rows, const uint32_t *sel, uint32_t n_sel,
+                         const double *col_sum, int criterion, int32_t *out, double *out_norm);
+
+/* Replaces the Transformation.compute loops of to_table / to_spectra, lib/KMerDB.ml:96-144,1040-1050,1140-1160,
+ * 1203-1212: out[r*n_cols + c] (kmer_major = 1, the default table) or out[c*n_rows + r] (kmer_major = 0:
+ * transposed table and spectra).  col_stats is n_cols x 4 from kpop_counter_stats with the same threshold/power. */
+int kpop_counter_transform(const int32_t *const *columns, uint32_t n_cols, uint64_t n_rows, int which,
+                           double threshold, double power, const double *col_stats, int kmer_major, double *out);
+
+/* device-resident forms: storage is [n_cols][ld] int32 with ld = kpop_dev_counter_ld(n_rows) */
+uint64_t kpop_dev_counter_ld(uint64_t n_rows);
+uint64_t kpop_dev_counter_workspace_bytes(uint32_t n_cols, uint64_t n_rows);
+int kpop_dev_counter_stats(const int32_t *d_storage, uint64_t ld, uint32_t n_cols, uint64_t n_rows,
+                           double threshold, double power, void *d_workspace, double *d_col_stats,
+                           double *d_row_stats, void *stream);
+/* d_sel / d_norm list the n_valid selected spectra whose norm is positive, in visiting order */
+int kpop_dev_counter_combine(const int32_t *d_storage, uint64_t ld, uint64_t n_rows, const uint32_t *d_sel,
+                             const double *d_norm, uint32_t n_valid, uint32_t n_sel, double max_norm,
+                             int criterion, void *d_workspace, int32_t *d_out, double *d_out_norm, void *stream);
+int kpop_dev_counter_transform(const int32_t *d_storage, uint64_t ld, uint32_t n_cols, uint64_t n_rows,
+                               int which, double threshold, double power, const double *d_col_stats,
+                               int kmer_major, double *d_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

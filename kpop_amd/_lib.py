@@ -48,6 +48,17 @@ SIGNATURES = {
                                            f64p]),
     "kpop_dev_summarize_distances": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp,
                                                vp]),
+    "kpop_counter_stats": (C.c_int, [C.POINTER(vp), C.c_uint32, C.c_uint64, C.c_double, C.c_double, f64p, f64p]),
+    "kpop_counter_combine": (C.c_int, [C.POINTER(vp), C.c_uint64, u32p, C.c_uint32, f64p, C.c_int, vp, f64p]),
+    "kpop_counter_transform": (C.c_int, [C.POINTER(vp), C.c_uint32, C.c_uint64, C.c_int, C.c_double, C.c_double, f64p,
+                                         C.c_int, f64p]),
+    "kpop_dev_counter_ld": (C.c_uint64, [C.c_uint64]),
+    "kpop_dev_counter_workspace_bytes": (C.c_uint64, [C.c_uint32, C.c_uint64]),
+    "kpop_dev_counter_stats": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_double, C.c_double, vp, vp, vp, vp]),
+    "kpop_dev_counter_combine": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, vp, C.c_uint32, C.c_uint32, C.c_double,
+                                           C.c_int, vp, vp, vp, vp]),
+    "kpop_dev_counter_transform": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.c_double, C.c_double,
+                                             vp, C.c_int, vp, vp]),
     "kpop_dev_synth_reads": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, vp, vp, vp]),
     "kpop_dev_count_reads_scratch_bytes": (C.c_uint64, [C.c_uint32, C.c_uint32, C.c_int]),
     "kpop_dev_count_reads": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, vp, vp, vp, vp]),

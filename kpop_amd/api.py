@@ -175,6 +175,63 @@ def ca(counts, normalize=True):
     return twisted[:, :nd], inertia[:nd], twister[:nd]
 
 
+# ---------------------------------------------------------- k-mer database
+TRANSF_BINARY, TRANSF_POWER, TRANSF_CLR, TRANSF_PSEUDO = 0, 1, 2, 3
+COMBINE_MEAN, COMBINE_MEDIAN = 0, 1
+_TRANSFORMS = {"binary": TRANSF_BINARY, "power": TRANSF_POWER, "pow": TRANSF_POWER, "clr": TRANSF_CLR,
+               "CLR": TRANSF_CLR, "pseudocounts": TRANSF_PSEUDO, "pseudo": TRANSF_PSEUDO}  # lib/KMerDB.ml:152-163
+
+
+def _columns(columns):
+    """list of int32 vectors (one per spectrum, the reference's storage) -> (kept arrays, void* array, n_rows)"""
+    cols = [_c(v, np.int32) for v in columns]
+    n_rows = cols[0].size if cols else 0
+    for v in cols:
+        if v.ndim != 1 or v.size != n_rows:
+            raise ValueError("every spectrum must be a vector of n_rows counts")
+    ptrs = (C.c_void_p * max(len(cols), 1))(*[v.ctypes.data for v in cols])
+    return cols, ptrs, n_rows
+
+
+def counter_stats(columns, threshold=1.0, power=1.0, rows=True):
+    """stats_table_of_core_db (lib/KMerDB.ml:171-271) -> (col_stats n_cols x 4, row_stats n_rows x 4 | None);
+    statistics are non_zero, max, sum, sum_log."""
+    cols, ptrs, n_rows = _columns(columns)
+    cs = np.zeros((len(cols), 4), dtype=np.float64)
+    rs = np.zeros((n_rows, 4), dtype=np.float64) if rows else None
+    check(_lib.load().kpop_counter_stats(ptrs, len(cols), n_rows, float(threshold), float(power),
+                                         _p(_nz(cs, np.float64), C.c_double),
+                                         _p(_nz(rs, np.float64), C.c_double) if rows else None))
+    return cs, rs
+
+
+def counter_combine(columns, sel, col_sum, criterion=COMBINE_MEAN):
+    """add_combined_selected (lib/KMerDB.ml:628-736) -> (int32 combined spectrum, norm)"""
+    cols, ptrs, n_rows = _columns(columns)
+    sel = _c(sel, np.uint32)
+    col_sum = _c(col_sum, np.float64)
+    out = np.zeros(n_rows, dtype=np.int32)
+    norm = C.c_double()
+    check(_lib.load().kpop_counter_combine(ptrs, n_rows, _p(_nz(sel, np.uint32), C.c_uint32), sel.size,
+                                           _p(_nz(col_sum, np.float64), C.c_double), int(criterion),
+                                           _nz(out, np.int32).ctypes.data if n_rows else None, C.byref(norm)))
+    return out, norm.value
+
+
+def counter_transform(columns, col_stats, which=TRANSF_POWER, threshold=1.0, power=1.0, kmer_major=True):
+    """Transformation.compute over a whole table (lib/KMerDB.ml:96-144) -> f64 [n_rows, n_cols] (kmer_major) or
+    [n_cols, n_rows]"""
+    cols, ptrs, n_rows = _columns(columns)
+    if isinstance(which, str):
+        which = _TRANSFORMS[which]
+    col_stats = _c(col_stats, np.float64)
+    out = np.zeros((n_rows, len(cols)) if kmer_major else (len(cols), n_rows), dtype=np.float64)
+    check(_lib.load().kpop_counter_transform(ptrs, len(cols), n_rows, int(which), float(threshold), float(power),
+                                             _p(_nz(col_stats, np.float64), C.c_double), 1 if kmer_major else 0,
+                                             _p(_nz(out, np.float64), C.c_double)))
+    return out
+
+
 # ----------------------------------------------------------------- metric
 def metric_compute(inertia, kind=METRIC_POWERS, power_int=1.0, threshold=1.0, power_ext=2.0):
     """Default = powers(1,1,2), bin/KPopTwistDB.ml:92."""

@@ -579,3 +579,112 @@ double kpo_pipeline(const uint8_t *bases, const uint64_t *offsets, uint32_t n_re
   free(ix);
   return t1 - t0;
 }
+
+/* ------------------------------------------------------------------ k-mer database (lib/KMerDB.ml) */
+
+void kpo_counter_vector_stats(const int32_t *v, uint64_t n, uint64_t stride, double threshold, double power,
+                              double *stats) {
+  /* lib/KMerDB.ml:182-195: the relative threshold is taken against the plain sum of v^power */
+  double sum = 0.;
+  for (uint64_t i = 0; i < n; ++i) sum += pow((double)v[i * stride], power);
+  if (threshold < 1.) threshold *= sum;
+  /* :196-215 */
+  double non_zero = 0., max = 0., s = 0., sl = 0.;
+  for (uint64_t i = 0; i < n; ++i) {
+    const int32_t c = v[i * stride];
+    const double f = (double)c;
+    if (f >= threshold) {
+      non_zero += 1.;
+      if ((double)c > max) max = (double)c;
+      s += pow(f, power);
+      sl += log(f) * power;
+    }
+  }
+  stats[0] = non_zero; stats[1] = max; stats[2] = s; stats[3] = sl;
+}
+
+void kpo_counter_stats(const int32_t *const *columns, uint32_t n_cols, uint64_t n_rows, double threshold,
+                       double power, double *col_stats, double *row_stats) {
+  for (uint32_t c = 0; c < n_cols; ++c)
+    kpo_counter_vector_stats(columns[c], n_rows, 1, threshold, power, col_stats + 4 * (uint64_t)c);
+  if (!row_stats) return;
+  int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (n_cols ? n_cols : 1));
+  for (uint64_t r = 0; r < n_rows; ++r) {
+    for (uint32_t c = 0; c < n_cols; ++c) tmp[c] = columns[c][r];
+    kpo_counter_vector_stats(tmp, n_cols, 1, threshold, power, row_stats + 4 * r);
+  }
+  free(tmp);
+}
+
+/* Stdlib.max on floats: `if a >= b then a else b` -- a NaN second argument comes back out */
+static double ocaml_max(double a, double b) { return a >= b ? a : b; }
+
+double kpo_counter_transform_one(int which, double threshold, double power, const double *cs, int32_t icounts) {
+  const double counts = (double)icounts, non_zero = cs[0], cmax = cs[1], csum = cs[2], csum_log = cs[3];
+  const double thr0 = threshold;
+  if (threshold < 1.) threshold *= csum; /* lib/KMerDB.ml:98-104 */
+  switch (which) {
+    case KPO_TRANSF_BINARY: return counts >= threshold ? 1. : 0.;
+    case KPO_TRANSF_POWER:
+      if (power == 1.) return counts >= threshold ? counts : 0.;
+      return counts >= threshold ? pow(counts, power) : 0.;
+    case KPO_TRANSF_CLR: {
+      double v = counts >= threshold ? counts : 0.;
+      v = ocaml_max(v, 0.1); /* epsilon, :95 */
+      return log(v) * power - csum_log / non_zero;
+    }
+    default: { /* pseudocounts, :130-144; a negative power raises Invalid_transformation there */
+      (void)thr0;
+      double v;
+      if (power == 0.) v = cmax * log((counts + 1.) / threshold);
+      else {
+        const double red = ocaml_max(0., threshold - 1.), c_p = pow(red, power);
+        if (power < 1.) v = (pow(counts, power) - c_p) * pow(cmax, 1. - power) / power;
+        else v = (pow(counts, power) - c_p) / (pow(threshold, power) - c_p);
+      }
+      return ocaml_max(0., floor(v) / csum);
+    }
+  }
+}
+
+static int cmp_double(const void *a, const void *b) {
+  const double x = *(const double *)a, y = *(const double *)b;
+  return (x > y) - (x < y);
+}
+
+/* Int32.of_float on x86-64: truncate to the native int, keep the low 32 bits */
+static int32_t int32_of_float(double x) {
+  if (!(x > -9.2e18 && x < 9.2e18)) return 0;
+  return (int32_t)(uint32_t)(uint64_t)(int64_t)x;
+}
+
+double kpo_counter_combine(const int32_t *const *columns, uint64_t n_rows, const uint32_t *sel, uint32_t n_sel,
+                           const double *col_sum, int criterion, int32_t *out) {
+  double max_norm = 0.; /* lib/KMerDB.ml:646-660 */
+  for (uint32_t s = 0; s < n_sel; ++s)
+    if (col_sum[sel[s]] > max_norm) max_norm = col_sum[sel[s]];
+  double *vals = (double *)malloc(sizeof(double) * (n_sel ? n_sel : 1));
+  double norm = 0.;
+  for (uint64_t i = 0; i < n_rows; ++i) {
+    uint32_t m = 0;
+    double sum = 0.;
+    for (uint32_t s = 0; s < n_sel; ++s) { /* :687-696 */
+      const double nrm = col_sum[sel[s]];
+      if (nrm > 0.) {
+        const double v = (double)columns[sel[s]][i] * max_norm / nrm;
+        vals[m++] = v;
+        sum += v;
+      }
+    }
+    double res;
+    if (criterion == 0) res = sum; /* RescaledMean -> FVF.sum, :703-704 */
+    else {                         /* RescaledMedian -> FVF.median * n, :705-706 */
+      qsort(vals, m, sizeof(double), cmp_double);
+      res = (m ? vals[m / 2] : 0.) * (double)n_sel;
+    }
+    norm += res;               /* :715 */
+    out[i] = int32_of_float(res); /* :716 */
+  }
+  free(vals);
+  return norm;
+}

@@ -115,6 +115,32 @@ double kpo_pipeline(const uint8_t *bases, const uint64_t *offsets, uint32_t n_re
                     int normalize_counts, int normalize_distance, int threads, double *twisted,
                     double *dist);
 
+/* ---- k-mer database (KPopCountDB): lib/KMerDB.ml ----
+   storage = n_cols spectra ("columns") of n_rows int32 counts each, one pointer per spectrum
+   (`storage: I32BAVector.t array`, lib/KMerDB.ml:54-63).
+   PARITY UNPINNED where it leans on the absent BiOCamLib: FreqVector.sum is taken as the running sum in
+   insertion order, FreqVector.median as the upper median sorted[n/2] (the convention of lib/Matrix.ml:660-668),
+   0 for an empty histogram. */
+#define KPO_TRANSF_BINARY 0
+#define KPO_TRANSF_POWER 1
+#define KPO_TRANSF_CLR 2
+#define KPO_TRANSF_PSEUDO 3
+/* stats_table_of_core_db.compute_one (lib/KMerDB.ml:174-215) for one vector of n counts read with `stride`:
+   stats[4] = non_zero, max, sum, sum_log */
+void kpo_counter_vector_stats(const int32_t *v, uint64_t n, uint64_t stride, double threshold, double power,
+                              double *stats);
+/* column statistics (col_stats n_cols x 4) and row statistics (row_stats n_rows x 4; may be NULL) */
+void kpo_counter_stats(const int32_t *const *columns, uint32_t n_cols, uint64_t n_rows, double threshold,
+                       double power, double *col_stats, double *row_stats);
+/* Transformation.compute (lib/KMerDB.ml:96-144) */
+double kpo_counter_transform_one(int which, double threshold, double power, const double *col_stats,
+                                 int32_t counts);
+/* add_combined_selected (lib/KMerDB.ml:628-736): columns[sel[0..n_sel)] visited in that order; col_sum[c] =
+   the linear statistic sum of column c (power 1, threshold 1); criterion 0 = mean, 1 = median.
+   out[n_rows] receives Int32.of_float of the combination; returns the accumulated norm (:715). */
+double kpo_counter_combine(const int32_t *const *columns, uint64_t n_rows, const uint32_t *sel, uint32_t n_sel,
+                           const double *col_sum, int criterion, int32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,12 @@ def _declare(L):
     L.kpo_distance_summary.argtypes = [f64p, C.c_uint32, f64p, C.c_uint32, C.c_uint32, f64p, C.c_int,
                                        C.c_double, C.c_int, C.c_uint32, f64p, u64p, u32p, f64p, f64p,
                                        C.c_uint64]
+    L.kpo_counter_stats.restype = None
+    L.kpo_counter_stats.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint64, C.c_double, C.c_double, f64p, f64p]
+    L.kpo_counter_transform_one.restype = C.c_double
+    L.kpo_counter_transform_one.argtypes = [C.c_int, C.c_double, C.c_double, f64p, C.c_int32]
+    L.kpo_counter_combine.restype = C.c_double
+    L.kpo_counter_combine.argtypes = [C.POINTER(C.c_void_p), C.c_uint64, u32p, C.c_uint32, f64p, C.c_int, C.c_void_p]
     L.kpo_pipeline.restype = C.c_double
     L.kpo_pipeline.argtypes = [u8p, u64p, C.c_uint32, C.c_int, C.c_int, f64p, C.c_uint64, C.c_uint32,
                                u64p, f64p, C.c_uint32, f64p, C.c_int, C.c_double, C.c_int, C.c_int,
@@ -240,6 +246,46 @@ def distance_summary(m1, m2, metric, kind=EUCLIDEAN, p=2., normalize=True, keep_
         raise RuntimeError("kpo_distance_summary failed")
     t = int(offs[-1])
     return stats, offs, idx[:t].copy(), dist[:t].copy(), z[:t].copy()
+
+
+# ----------------------------------------------------- k-mer database (lib/KMerDB.ml)
+def _columns(columns):
+    cols = [_c(v, np.int32) for v in columns]
+    n_rows = cols[0].size if cols else 0
+    ptrs = (C.c_void_p * max(len(cols), 1))(*[v.ctypes.data for v in cols])
+    return cols, ptrs, n_rows
+
+
+def counter_stats(columns, threshold=1., power=1.):
+    cols, ptrs, n_rows = _columns(columns)
+    cs = np.zeros((max(len(cols), 1), 4))
+    rs = np.zeros((max(n_rows, 1), 4))
+    lib().kpo_counter_stats(ptrs, len(cols), n_rows, threshold, power, _p(cs, C.c_double), _p(rs, C.c_double))
+    return cs[:len(cols)], rs[:n_rows]
+
+
+def counter_transform(columns, col_stats, which=1, threshold=1., power=1., kmer_major=True):
+    cols = [_c(v, np.int32) for v in columns]
+    n_rows = cols[0].size if cols else 0
+    col_stats = _c(col_stats, np.float64)
+    out = np.zeros((len(cols), n_rows))
+    L = lib()
+    for c, v in enumerate(cols):
+        cs = _p(col_stats[c], C.c_double)
+        for r in range(n_rows):
+            out[c, r] = L.kpo_counter_transform_one(which, threshold, power, cs, int(v[r]))
+    return np.ascontiguousarray(out.T) if kmer_major else out
+
+
+def counter_combine(columns, sel, col_sum, criterion=0):
+    cols, ptrs, n_rows = _columns(columns)
+    sel = _c(sel, np.uint32)
+    col_sum = _c(col_sum, np.float64)
+    out = np.zeros(max(n_rows, 1), dtype=np.int32)
+    z = np.zeros(1)
+    norm = lib().kpo_counter_combine(ptrs, n_rows, _p(sel if sel.size else np.zeros(1, np.uint32), C.c_uint32), sel.size,
+                                     _p(col_sum if col_sum.size else z, C.c_double), criterion, out.ctypes.data)
+    return out[:n_rows], norm
 
 
 def c_g15(x):

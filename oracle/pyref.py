@@ -186,3 +186,93 @@ def summarize_row(row, req_len):
             z = float("nan") if d == mean else math.copysign(float("inf"), d - mean)
         neigh.append((c, d, z))
     return (mean, sd, median, mad), neigh
+
+
+# ---------------------------------------------------------------- k-mer database (lib/KMerDB.ml)
+def counter_vector_stats(v, threshold=1.0, power=1.0):
+    """stats_table_of_core_db.compute_one, lib/KMerDB.ml:174-215 -> (non_zero, max, sum, sum_log)"""
+    s = 0.0
+    for c in v:
+        s += float(c) ** power
+    if threshold < 1.0:
+        threshold = threshold * s
+    non_zero, mx, sm, sl = 0, 0, 0.0, 0.0
+    for c in v:
+        f = float(c)
+        if f >= threshold:
+            non_zero += 1
+            mx = max(mx, c)
+            sm += f ** power
+            sl += (math.log(f) if f > 0 else -math.inf) * power
+    return (float(non_zero), float(mx), sm, sl)
+
+
+def _omax(a, b):
+    """Stdlib.max on floats: `if a >= b then a else b`"""
+    return a if a >= b else b
+
+
+def _div(a, b):
+    """IEEE division (Python raises on a zero divisor)"""
+    if b != 0.0:
+        return a / b
+    if a != a or a == 0.0:
+        return math.nan
+    return math.copysign(math.inf, a) * math.copysign(1.0, b)
+
+
+def _floor(x):
+    return float(math.floor(x)) if math.isfinite(x) else x
+
+
+def counter_transform_one(which, threshold, power, cs, counts):
+    """Transformation.compute, lib/KMerDB.ml:96-144; which in binary/power/clr/pseudocounts"""
+    non_zero, cmax, csum, csum_log = (float(x) for x in cs)
+    counts = float(counts)
+    if threshold < 1.0:
+        threshold = threshold * csum
+    if which == "binary":
+        return 1.0 if counts >= threshold else 0.0
+    if which == "power":
+        return (counts ** power if counts >= threshold else 0.0)
+    if which == "clr":
+        v = counts if counts >= threshold else 0.0
+        v = _omax(v, 0.1)
+        return math.log(v) * power - _div(csum_log, non_zero)
+    if power == 0.0:
+        q = _div(counts + 1.0, threshold)
+        v = cmax * (math.log(q) if q > 0 and math.isfinite(q) else (math.inf if q > 0 else -math.inf if q == 0 else math.nan))
+    else:
+        red = _omax(0.0, threshold - 1.0)
+        c_p = red ** power
+        if power < 1.0:
+            v = (counts ** power - c_p) * cmax ** (1.0 - power) / power
+        else:
+            v = _div(counts ** power - c_p, threshold ** power - c_p)
+    return _omax(0.0, _div(_floor(v), csum))
+
+
+def counter_combine(columns, sel, col_sum, criterion="mean"):
+    """add_combined_selected, lib/KMerDB.ml:628-736 -> (list of int32, norm)"""
+    max_norm = 0.0
+    for s in sel:
+        max_norm = max(max_norm, col_sum[s])
+    n_rows = len(columns[0]) if len(columns) else 0
+    out, norm = [], 0.0
+    for i in range(n_rows):
+        vals = []
+        for s in sel:
+            if col_sum[s] > 0.0:
+                vals.append(float(columns[s][i]) * max_norm / col_sum[s])
+        if criterion == "mean":
+            res = 0.0
+            for v in vals:
+                res += v
+        else:
+            vals.sort()
+            res = (vals[len(vals) // 2] if vals else 0.0) * float(len(sel))
+        norm += res
+        t = int(res)  # Int32.of_float: truncate, keep the low 32 bits
+        t &= 0xFFFFFFFF
+        out.append(t - (1 << 32) if t >= (1 << 31) else t)
+    return out, norm

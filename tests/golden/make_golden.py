@@ -230,7 +230,56 @@ def wuhan_fixture():
     dump("wuhan_counts.json", res)
 
 
+# ---------------------------------------------------------------- k-mer database
+def counter_fixture():
+    """lib/KMerDB.ml statistics, transformations and class combination on a small database with the edge cases the
+    code paths branch on: an all-zero spectrum (norm 0, skipped by :693), a k-mer absent everywhere, counts below
+    absolute and relative thresholds, an even and an odd number of combined spectra."""
+    rng = np.random.default_rng(0x4B506F70)
+    n_rows, n_cols = 37, 7
+    cols = [rng.poisson(lam, n_rows).astype(np.int32) for lam in (0.7, 3.0, 12.0, 40.0, 1.5, 0.2)]
+    cols.insert(3, np.zeros(n_rows, dtype=np.int32))      # spectrum 3: empty
+    for v in cols:
+        v[11] = 0                                          # k-mer 11 occurs nowhere
+    cols[2][5] = 2_000_000_000                             # large count: rescaled sums overflow int32 and wrap
+    names = {0: "binary", 1: "power", 2: "clr", 3: "pseudocounts"}
+    res = {"n_rows": n_rows, "n_cols": n_cols, "columns": [[int(x) for x in v] for v in cols], "stats": [],
+           "transforms": [], "combines": []}
+    for thr, pw in ((1.0, 1.0), (3.0, 1.0), (0.01, 1.0), (1.0, 0.5), (0.0, 2.0)):
+        cs, rs = O.counter_stats(cols, thr, pw)
+        for c in range(n_cols):
+            want = P.counter_vector_stats([int(x) for x in cols[c]], thr, pw)
+            if not np.array_equal(np.array(want), cs[c], equal_nan=True):
+                raise SystemExit("counter stats: restatements disagree (col %d, thr %g, pow %g)" % (c, thr, pw))
+        for r in range(n_rows):
+            want = P.counter_vector_stats([int(v[r]) for v in cols], thr, pw)
+            if not np.array_equal(np.array(want), rs[r], equal_nan=True):
+                raise SystemExit("counter stats: restatements disagree (row %d)" % r)
+        res["stats"].append({"threshold": thr, "power": pw, "col_stats": fhl(cs), "row_stats": fhl(rs)})
+        for which in range(4):
+            if which == 2 and thr == 0.0:
+                continue  # sum_log = -inf: every entry is nan/inf, nothing to pin
+            t = O.counter_transform(cols, cs, which, thr, pw, kmer_major=True)
+            for c in range(n_cols):
+                for r in range(n_rows):
+                    w = P.counter_transform_one(names[which], thr, pw, tuple(cs[c]), int(cols[c][r]))
+                    if not (w == t[r, c] or (w != w and t[r, c] != t[r, c])):
+                        raise SystemExit("counter transform: restatements disagree (%s, %d, %d)" % (names[which], r, c))
+            res["transforms"].append({"which": names[which], "threshold": thr, "power": pw, "table": fhl(t)})
+    lin, _ = O.counter_stats(cols, 1.0, 1.0)
+    col_sum = lin[:, 2].copy()
+    for sel in ([0, 1, 2], [6, 5, 4, 3, 2, 1, 0], [3], [1, 3, 4, 5], [2, 2], []):
+        for crit, cname in ((0, "mean"), (1, "median")):
+            out, norm = O.counter_combine(cols, sel, col_sum, crit)
+            wout, wnorm = P.counter_combine([[int(x) for x in v] for v in cols], sel, list(col_sum), cname)
+            if [int(x) for x in out] != wout or norm != wnorm:
+                raise SystemExit("counter combine: restatements disagree (%s, %s)" % (sel, cname))
+            res["combines"].append({"sel": sel, "criterion": cname, "out": [int(x) for x in out], "norm": fh(norm)})
+    dump("counter_small.json", res)
+
+
 if __name__ == "__main__":
+    counter_fixture()
     readme_kat()
     count_fixture()
     twist_fixture()

@@ -1,0 +1,127 @@
+"""GPU parity of the k-mer database operations (kpop_counter_*: lib/KMerDB.ml statistics, transformations and
+class combination) against the oracle, through the C ABI.
+
+Bars: counts, combined spectra and every statistic of the default linear transformation (threshold 1, power 1)
+are bit-exact.  With power != 1 the column sums are tree reductions of rounded pow() values and device pow/log
+are not glibc's: relative 1e-12 there (north_star allows 1e-5 for floating point)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, unhex
+
+pytestmark = pytest.mark.gpu
+
+NAMES = {"binary": 0, "power": 1, "clr": 2, "pseudocounts": 3}
+
+
+def same(a, b, exact, rtol=1e-12):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    if exact:
+        assert np.array_equal(a, b, equal_nan=True)
+    else:
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        fin = np.isfinite(a) & np.isfinite(b)
+        assert np.array_equal(a[~fin & ~np.isnan(a)], b[~fin & ~np.isnan(b)])
+        np.testing.assert_allclose(a[fin], b[fin], rtol=rtol, atol=0)
+
+
+def test_counter_golden(kpop):
+    g = load_golden("counter_small.json")
+    cols = [np.array(v, dtype=np.int32) for v in g["columns"]]
+    n_rows, n_cols = g["n_rows"], g["n_cols"]
+    for st in g["stats"]:
+        cs, rs = kpop.counter_stats(cols, st["threshold"], st["power"])
+        exact = st["power"] == 1.0  # non_zero, max, sum; sum_log goes through the device's log()
+        wc, wr = unhex(st["col_stats"], (n_cols, 4)), unhex(st["row_stats"], (n_rows, 4))
+        same(cs[:, :3], wc[:, :3], exact)
+        same(rs[:, :3], wr[:, :3], exact)
+        same(cs[:, 3], wc[:, 3], False, rtol=1e-12)
+        same(rs[:, 3], wr[:, 3], False, rtol=1e-12)
+    for tr in g["transforms"]:
+        # statistics from the oracle's side of the fixture so the transformation is tested on its own
+        st = next(s for s in g["stats"] if s["threshold"] == tr["threshold"] and s["power"] == tr["power"])
+        cs = unhex(st["col_stats"], (n_cols, 4))
+        want = unhex(tr["table"], (n_rows, n_cols))
+        for kmer_major in (True, False):
+            got = kpop.counter_transform(cols, cs, NAMES[tr["which"]], tr["threshold"], tr["power"], kmer_major=kmer_major)
+            exact = tr["which"] == "binary" or (tr["which"] == "power" and tr["power"] == 1.0)
+            same(got if kmer_major else got.T, want, exact)
+    lin = unhex(g["stats"][0]["col_stats"], (n_cols, 4))[:, 2]
+    for cb in g["combines"]:
+        out, norm = kpop.counter_combine(cols, cb["sel"], lin, 0 if cb["criterion"] == "mean" else 1)
+        assert out.tolist() == cb["out"], (cb["sel"], cb["criterion"])
+        assert norm == pytest.approx(float.fromhex(cb["norm"]), rel=1e-12)
+
+
+@pytest.mark.parametrize("n_rows,n_cols,lam", [(5000, 70, 3.0), (100_003, 9, 20.0), (777, 300, 1.0), (64, 1, 5.0), (1, 5, 2.0)])
+def test_counter_random_vs_oracle(kpop, oracle, n_rows, n_cols, lam):
+    rng = np.random.default_rng(n_rows * 31 + n_cols)
+    depth = rng.uniform(0.2, 3.0, size=n_cols)
+    cols = [rng.poisson(lam * d, n_rows).astype(np.int32) for d in depth]
+    if n_cols > 3:
+        cols[2][:] = 0
+    for thr, pw in ((1.0, 1.0), (2.0, 1.0), (1e-4, 1.0)):
+        cs, rs = kpop.counter_stats(cols, thr, pw)
+        ocs, ors = oracle.counter_stats(cols, thr, pw)
+        same(cs[:, :3], ocs[:, :3], True)
+        same(rs[:, :3], ors[:, :3], True)
+        same(cs[:, 3], ocs[:, 3], False, rtol=1e-11)
+        same(rs[:, 3], ors[:, 3], False, rtol=1e-11)
+    cs, _ = kpop.counter_stats(cols, 1.0, 0.5, rows=False)
+    ocs, _ = oracle.counter_stats(cols, 1.0, 0.5)
+    same(cs, ocs, False, rtol=1e-11)
+    lin, _ = kpop.counter_stats(cols, 1.0, 1.0, rows=False)
+    col_sum = lin[:, 2]
+    sels = [list(range(n_cols)), list(range(n_cols - 1, -1, -1)), list(rng.permutation(n_cols)[: max(1, n_cols // 2)])]
+    for sel in sels:
+        for crit in (0, 1):
+            out, norm = kpop.counter_combine(cols, sel, col_sum, crit)
+            want, wnorm = oracle.counter_combine(cols, sel, col_sum, crit)
+            assert np.array_equal(out, want), (sel[:5], crit)
+            assert norm == pytest.approx(wnorm, rel=1e-12)
+    if n_rows * n_cols <= 400_000:
+        for which, thr, pw in ((1, 1.0, 1.0), (0, 2.0, 1.0), (2, 1.0, 1.0), (3, 1.0, 1.0), (3, 2.0, 0.5), (3, 3.0, 0.0), (1, 0.001, 2.0)):
+            ocs, _ = oracle.counter_stats(cols, thr, pw)
+            got = kpop.counter_transform(cols, ocs, which, thr, pw, kmer_major=True)
+            want = oracle.counter_transform(cols, ocs, which, thr, pw, kmer_major=True)
+            same(got, want, which == 0 or (which == 1 and pw == 1.0), rtol=1e-11)
+
+
+def test_combine_properties_at_scale(kpop):
+    """k = 12 sized database (8.39 M canonical k-mers, 12 spectra): size-independent properties."""
+    n_rows = 8_390_656
+    rng = np.random.default_rng(12)
+    base = rng.poisson(3.0, n_rows).astype(np.int32)
+    cols = [base, base * 2, base * 3] + [rng.poisson(2.0, n_rows).astype(np.int32) for _ in range(9)]
+    cs, rs = kpop.counter_stats(cols, 1.0, 1.0)
+    assert np.array_equal(cs[:, 2], [float(v.astype(np.int64).sum()) for v in cols])
+    assert np.array_equal(cs[:, 0], [float(np.count_nonzero(v)) for v in cols])
+    tot = np.zeros(n_rows, dtype=np.int64)
+    for v in cols:
+        tot += v
+    assert np.array_equal(rs[:, 2], tot.astype(np.float64))
+    col_sum = cs[:, 2]
+    # three rescaled copies of one spectrum: each rescales to 3*base exactly (max_norm/norm = 3, 3/2, 1)
+    out, _ = kpop.counter_combine(cols, [0, 1, 2], col_sum, 0)
+    assert np.array_equal(out, base.astype(np.int64) * 9)
+    med, _ = kpop.counter_combine(cols, [0, 1, 2], col_sum, 1)
+    assert np.array_equal(med, base.astype(np.int64) * 9)
+    # the median does not depend on the visiting order; the mean of a single spectrum is the spectrum
+    a, _ = kpop.counter_combine(cols, list(range(12)), col_sum, 1)
+    b, _ = kpop.counter_combine(cols, list(range(11, -1, -1)), col_sum, 1)
+    assert np.array_equal(a, b)
+    one, norm = kpop.counter_combine(cols, [5], col_sum, 0)
+    assert np.array_equal(one, cols[5]) and norm == col_sum[5]
+
+
+def test_counter_errors(kpop):
+    cols = [np.arange(10, dtype=np.int32)]
+    with pytest.raises(Exception, match="Unknown_combination_criterion"):
+        kpop.counter_combine(cols, [0], [45.0], 7)
+    with pytest.raises(Exception, match="unknown transformation"):
+        kpop.counter_transform(cols, np.zeros((1, 4)), 9)
+    with pytest.raises(Exception, match="Invalid_transformation"):
+        kpop.counter_stats(cols, -1.0, 1.0)
+    cs, rs = kpop.counter_stats([], 1.0, 1.0)
+    assert cs.shape == (0, 4) and rs.shape == (0, 4)

@@ -189,3 +189,29 @@ def test_synth_generators(oracle):
     assert abs(w.sum() - 1) < 1e-15 and np.all(np.diff(w) < 0)  # strictly decreasing (lib/Space.ml:98-100)
     c = L.kpo_synth_twister_coeff(1, 3, 77)
     assert -1.0 <= c < 1.0
+
+
+def test_counter_golden(oracle, pyref):
+    """lib/KMerDB.ml statistics / transformations / class combination: C restatement against the committed fixture and
+    the independent Python restatement."""
+    g = load_golden("counter_small.json")
+    cols = [np.array(v, dtype=np.int32) for v in g["columns"]]
+    n_rows, n_cols = g["n_rows"], g["n_cols"]
+    names = {"binary": 0, "power": 1, "clr": 2, "pseudocounts": 3}
+    for st in g["stats"]:
+        cs, rs = oracle.counter_stats(cols, st["threshold"], st["power"])
+        assert np.array_equal(cs, unhex(st["col_stats"], (n_cols, 4)), equal_nan=True)
+        assert np.array_equal(rs, unhex(st["row_stats"], (n_rows, 4)), equal_nan=True)
+    for tr in g["transforms"][:8]:
+        st = next(s for s in g["stats"] if s["threshold"] == tr["threshold"] and s["power"] == tr["power"])
+        cs = unhex(st["col_stats"], (n_cols, 4))
+        got = oracle.counter_transform(cols, cs, names[tr["which"]], tr["threshold"], tr["power"])
+        assert np.array_equal(got, unhex(tr["table"], (n_rows, n_cols)), equal_nan=True)
+    lin = unhex(g["stats"][0]["col_stats"], (n_cols, 4))[:, 2]
+    for cb in g["combines"]:
+        out, norm = oracle.counter_combine(cols, cb["sel"], lin, 0 if cb["criterion"] == "mean" else 1)
+        assert out.tolist() == cb["out"] and norm == float.fromhex(cb["norm"])
+        pout, pnorm = pyref.counter_combine([[int(x) for x in v] for v in cols], cb["sel"], list(lin), cb["criterion"])
+        assert pout == cb["out"] and pnorm == norm
+    # wrap-around of Int32.of_float is exercised (a rescaled sum beyond 2^31)
+    assert any(x < 0 for cb in g["combines"] for x in cb["out"])
