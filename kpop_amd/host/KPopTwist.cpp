@@ -1,0 +1,155 @@
+// KPopTwist -- drop-in for the reference's KPopTwist (the bash script src/KPopTwist around bin/KPopTwist_.ml):
+// loads a '.KPopCounter' database, transforms and normalises its counts, runs the correspondence analysis and saves
+// '<prefix>.KPopTwister' (twister + inertia) and '<prefix>.KPopTwisted' (the twisted training spectra).
+//
+// Same options as bin/KPopTwist_.ml:52-135.  What the reference does by piping text tables through KPopCountDB, R
+// (data.table + ca) and three KPopTwistDB conversions (src/KPopTwist:36-131) happens in one process: the table
+// transformation in kpop_counter_stats/_transform, the analysis in kpop_ca, the binaries through ocaml_marshal.
+//
+// Differences from the reference, on purpose: dimension signs are arbitrary (as in R); -s resamples with SplitMix64,
+// not R's RNG; --keep-temporaries keeps the three '.txt' tables next to the binaries (no temporary directory is ever
+// made); k-mers whose transformed counts are all zero are dropped together with their names (the reference's two
+// exports can fall out of step there, src/KPopTwist:38-44).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/kpop_hip.h"
+#include "ca_pipeline.h"
+#include "counter_db.h"
+
+using namespace kpop_host;
+
+namespace {
+
+const char *kVersion = "27-hip";
+
+void usage(FILE *f) {
+  fprintf(f,
+          "This is KPopTwist (MI355X/HIP) version %s\n"
+          "Usage: KPopTwist -i|--input <binary_input_prefix> -o|--output <binary_output_prefix> [OPTIONS]\n"
+          " -k|--kmers|--keep|--keep-kmers|--kmers-keep <file>   keep only the k-mers listed (one per line)\n"
+          " -s|--sample|--sample-kmers|--kmers-sample <fraction>   resample k-mers (default 1)\n"
+          " --counts-threshold <x>   --counts-power <x>   --counts-transform|--counts-transformation binary|power|pseudocounts|clr\n"
+          " --counts-normalize|--counts-normalization true|false   (default true)\n"
+          " --kmers-threshold <x>    drop k-mers whose total is below x times the largest total (default 0)\n"
+          " -i|--input <prefix>      <prefix>.KPopCounter\n"
+          " -o|--output <prefix>     <prefix>.KPopTwister and <prefix>.KPopTwisted\n"
+          " -K|--output-kmers|--output-twisted-kmers <prefix>   also save the twisted k-mers\n"
+          " -T|--threads <n> (ignored)  --keep-temporaries  -v|--verbose  -V|--version  -h|--help\n",
+          kVersion);
+}
+
+[[noreturn]] void parse_error(const std::string &msg) {
+  usage(stderr);
+  fprintf(stderr, "(KPopTwist): ERROR: %s\n", msg.c_str());
+  exit(1);
+}
+
+double parse_float(const std::string &opt, const std::string &s, double lo, double hi) {
+  char *end = nullptr;
+  const double v = strtod(s.c_str(), &end);
+  if (end == s.c_str() || *end != 0 || !(v >= lo) || !(v <= hi)) parse_error("Option '" + opt + "': '" + s + "' is out of range");
+  return v;
+}
+
+void check(int rc) {
+  if (rc != 0) throw Error(std::string("libkpop_hip: ") + kpop_last_error());
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  std::string input, output, output_kmers;
+  Transform transform;
+  CaParams P;
+  bool temporaries = false;
+  auto need = [&](int &i, const std::string &opt) -> std::string {
+    if (i + 1 >= argc) parse_error("Option '" + opt + "' needs a parameter");
+    return argv[++i];
+  };
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    auto is = [&](std::initializer_list<const char *> names) {
+      for (const char *n : names)
+        if (a == n) return true;
+      return false;
+    };
+    if (is({"-k", "--kmers", "--keep", "--keep-kmers", "--kmers-keep"})) P.keep_path = need(i, a);
+    else if (is({"-s", "--sample", "--sample-kmers", "--kmers-sample"})) P.fraction = parse_float(a, need(i, a), 0., 1.);
+    else if (is({"--counts-threshold"})) transform.threshold = parse_float(a, need(i, a), 0., 1e300);
+    else if (is({"--counts-power"})) transform.power = parse_float(a, need(i, a), 0., 1e300);
+    else if (is({"--counts-transform", "--counts-transformation"})) transform.which = need(i, a);
+    else if (is({"--counts-normalize", "--counts-normalization"})) {
+      const std::string b = need(i, a);
+      if (b != "true" && b != "false") parse_error("Option '" + a + "': '" + b + "' is not a boolean");
+      P.normalize = b == "true";
+    } else if (is({"--kmers-threshold"})) P.threshold = parse_float(a, need(i, a), 0., 1e300);
+    else if (is({"-i", "--input"})) input = need(i, a);
+    else if (is({"-o", "--output"})) output = need(i, a);
+    else if (is({"-K", "--output-kmers", "--output-twisted-kmers"})) output_kmers = need(i, a);
+    else if (is({"-T", "--threads"})) {
+      if (atoi(need(i, a).c_str()) <= 0) parse_error("Option '" + a + "': the number of threads must be positive");
+    } else if (is({"--keep-temporaries"})) temporaries = true;
+    else if (is({"-v", "--verbose"})) P.verbose = true;
+    else if (is({"-V", "--version"})) {
+      printf("%s\n", kVersion);
+      return 0;
+    } else if (is({"-h", "--help"})) {
+      usage(stdout);
+      return 0;
+    } else {
+      parse_error("Unknown option '" + a + "'");
+    }
+  }
+  if (input.empty()) parse_error("Option '-i' is mandatory");   // TA.Mandatory, bin/KPopTwist_.ml:97-103
+  if (output.empty()) parse_error("Option '-o' is mandatory");  // :104-110
+  try {
+    const int which = transform.code();
+    int dev = 0;
+    if (const char *e = getenv("KPOP_DEVICE")) dev = atoi(e);
+    check(kpop_init(dev));
+    if (P.verbose) fprintf(stderr, "[1/16] Exporting table...\n");
+    CounterDB db = CounterDB::of_binary(input);
+    const size_t nr = db.n_rows(), nc = db.n_cols();
+    std::vector<const int32_t *> cols = db.columns();
+    // the export of src/KPopTwist:38-40: transformed counts, k-mers with an all-zero row left out
+    std::vector<double> col_stats(4 * std::max<size_t>(1, nc)), row_stats(4 * std::max<size_t>(1, nr));
+    check(kpop_counter_stats(cols.data(), (uint32_t)nc, nr, transform.threshold, transform.power, col_stats.data(), row_stats.data()));
+    std::vector<double> table(std::max<size_t>(1, nr * nc));
+    check(kpop_counter_transform(cols.data(), (uint32_t)nc, nr, which, transform.threshold, transform.power, col_stats.data(), 1,
+                                 table.data()));
+    std::vector<std::string> kmers;
+    std::vector<double> counts;
+    counts.reserve(nr * nc);
+    for (size_t r = 0; r < nr; ++r)
+      if (row_stats[4 * r + 2] > 0.) {
+        kmers.push_back(db.core.row_names[r]);
+        counts.insert(counts.end(), table.begin() + (long)(r * nc), table.begin() + (long)((r + 1) * nc));
+      }
+    table.clear();
+    table.shrink_to_fit();
+    P.want_kmer_coords = !output_kmers.empty();
+    const std::vector<std::string> spectra = db.core.col_names;
+    db = CounterDB();
+    const CaResult R = run_ca(kmers, spectra, std::move(counts), P);
+    if (P.verbose) fprintf(stderr, "[14/16] Encoding twisted...\n");
+    write_binary_matrix(make_filename(output, "KPopTwisted", false), "KPopTwisted", R.twisted);
+    if (!output_kmers.empty()) write_binary_matrix(make_filename(output_kmers, "KPopTwisted", false), "KPopTwisted", R.kmer_coords);
+    if (P.verbose) fprintf(stderr, "[15/16] Encoding twister...\n");
+    write_binary_twister(make_filename(output, "KPopTwister", false), R.twister, R.inertia);
+    if (temporaries) {
+      write_table(make_filename(output, "KPopTwisted", true), R.twisted, 15);
+      write_table(make_filename(output, "KPopInertia", true), R.inertia, 15);
+      write_table(make_filename(output, "KPopTwister", true), R.twister, 15);
+    }
+    if (P.verbose) fprintf(stderr, "All done.\n");
+  } catch (const std::exception &e) {
+    fprintf(stderr, "(KPopTwist): FATAL: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

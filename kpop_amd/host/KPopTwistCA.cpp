@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/kpop_hip.h"
+#include "ca_pipeline.h"
 #include "kpop_text.h"
 
 using namespace kpop_host;
@@ -33,43 +34,20 @@ void check(int rc) {
   if (rc != 0) throw Error(std::string("libkpop_hip: ") + kpop_last_error());
 }
 
-std::vector<std::string> read_lines(const std::string &path) {
-  std::vector<std::string> out;
-  FILE *f = fopen(path.c_str(), "rb");
-  if (!f) throw Error("cannot open '" + path + "'");
-  char *buf = nullptr;
-  size_t cap = 0;
-  ssize_t n;
-  while ((n = getline(&buf, &cap, f)) >= 0) {
-    while (n > 0 && (buf[n - 1] == '\n' || buf[n - 1] == '\r')) --n;
-    out.emplace_back(buf, (size_t)n);
-  }
-  free(buf);
-  fclose(f);
-  return out;
-}
-
 std::string unquote(const std::string &s) { return strip_external_quotes_and_check(s); }
 
-uint64_t mix64(uint64_t z) {
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-
-void write_named_table(const std::string &path, const char *corner, const std::vector<std::string> &cols,
-                       const std::vector<std::string> &rows, const double *data, size_t ld, bool transposed) {
-  // data(r, c) = transposed ? data[c * ld + r] : data[r * ld + c]
+// fwrite(quote=TRUE, sep="\t") of a data.table with a row-name column (src/KPopTwist:100,108,116)
+void write_r_table(const std::string &path, const char *corner, const Table &t) {
   FILE *f = fopen(path.c_str(), "wb");
   if (!f) throw Error("cannot write '" + path + "'");
   std::vector<char> iobuf(1 << 22);
   setvbuf(f, iobuf.data(), _IOFBF, iobuf.size());
   fprintf(f, "\"%s\"", corner);
-  for (const std::string &c : cols) fprintf(f, "\t\"%s\"", c.c_str());
+  for (const std::string &c : t.col_names) fprintf(f, "\t\"%s\"", c.c_str());
   fputc('\n', f);
-  for (size_t r = 0; r < rows.size(); ++r) {
-    fprintf(f, "\"%s\"", rows[r].c_str());
-    for (size_t c = 0; c < cols.size(); ++c) fprintf(f, "\t%.15g", transposed ? data[c * ld + r] : data[r * ld + c]);
+  for (size_t r = 0; r < t.rows(); ++r) {
+    fprintf(f, "\"%s\"", t.row_names[r].c_str());
+    for (size_t c = 0; c < t.cols(); ++c) fprintf(f, "\t%.15g", t.data[r * t.cols() + c]);
     fputc('\n', f);
   }
   fclose(f);
@@ -132,88 +110,26 @@ int main(int argc, char **argv) {
       fclose(f);
     }
     const size_t J = spectra.size();
-    size_t I = J ? N.size() / J : 0;
+    const size_t I = J ? N.size() / J : 0;
     if (kmers.size() != I) throw Error("'" + names_path + "' has " + std::to_string(kmers.size()) + " k-mers, the table has " + std::to_string(I) + " rows");
-    // [4/16] keep list (:76-82), [5/16] resampling (:84-86), [6/16] thresholding (:88-91)
-    std::vector<size_t> sel(I);
-    for (size_t i = 0; i < I; ++i) sel[i] = i;
-    if (!keep_path.empty()) {
-      std::unordered_map<std::string, size_t> idx;
-      for (size_t i = 0; i < I; ++i) idx[kmers[i]] = i;
-      sel.clear();
-      for (const std::string &nm : read_lines(keep_path)) {
-        auto it = idx.find(unquote(nm));
-        if (it == idx.end()) throw Error("k-mer '" + nm + "' of the keep list is not in the table");
-        sel.push_back(it->second);
-      }
-    }
-    if (fraction < 1.0) {
-      const size_t want = (size_t)((double)sel.size() * fraction);
-      std::vector<std::pair<uint64_t, size_t>> keyed;
-      for (size_t i = 0; i < sel.size(); ++i) keyed.push_back({mix64(0x4B506F70ull + i), i});
-      std::sort(keyed.begin(), keyed.end());
-      std::vector<size_t> pick;
-      for (size_t i = 0; i < want; ++i) pick.push_back(keyed[i].second);
-      std::sort(pick.begin(), pick.end());
-      std::vector<size_t> ns;
-      for (size_t i : pick) ns.push_back(sel[i]);
-      sel.swap(ns);
-    }
-    {
-      std::vector<double> rsum(sel.size(), 0.0);
-      double mx = 0.0;
-      for (size_t r = 0; r < sel.size(); ++r) {
-        for (size_t j = 0; j < J; ++j) rsum[r] += N[sel[r] * J + j];
-        mx = std::max(mx, rsum[r]);
-      }
-      std::vector<size_t> ns;
-      for (size_t r = 0; r < sel.size(); ++r)
-        if (rsum[r] >= mx * threshold) ns.push_back(sel[r]);
-      sel.swap(ns);
-    }
-    std::vector<double> M(sel.size() * J);
-    std::vector<std::string> knames(sel.size());
-    for (size_t r = 0; r < sel.size(); ++r) {
-      memcpy(&M[r * J], &N[sel[r] * J], J * sizeof(double));
-      knames[r] = kmers[sel[r]];
-    }
-    N.clear();
-    N.shrink_to_fit();
-    I = sel.size();
-    if (I < 2 || J < 2) throw Error("correspondence analysis needs at least 2 k-mers and 2 spectra");
-    if (verbose) fprintf(stderr, "[8/16] Twisting counts (%zu k-mers x %zu spectra) on the GPU...\n", I, J);
     int dev = 0;
     if (const char *e = getenv("KPOP_DEVICE")) dev = atoi(e);
     check(kpop_init(dev));
-    const size_t nd = std::min(I, J) - 1;
-    std::vector<double> twisted(J * nd), inertia(nd), twister(nd * I);
-    uint32_t nd_out = 0;
-    check(kpop_ca(M.data(), I, (uint32_t)J, normalize ? 1 : 0, &nd_out, twisted.data(), inertia.data(), twister.data()));
-    std::vector<std::string> dims(nd);
-    for (size_t d = 0; d < nd; ++d) dims[d] = "Dim" + std::to_string(d + 1);
+    CaParams P;
+    P.keep_path = keep_path;
+    P.fraction = fraction;
+    P.threshold = threshold;
+    P.normalize = normalize;
+    P.want_kmer_coords = !out_kmers.empty();
+    P.verbose = verbose;
+    const CaResult R = run_ca(kmers, spectra, std::move(N), P);
     if (verbose) fprintf(stderr, "[9/16] Writing twisted...\n");
-    write_named_table(make_filename(out, "KPopTwisted", true), "rn", dims, spectra, twisted.data(), nd, false);
-    if (!out_kmers.empty()) {  // principal row coordinates = standard ones x sv; sv_d^2 = inertia_d * sum(sv^2) is not
-      // recoverable from the normalised inertia, so recompute sv from the class positions: for column coordinates
-      // sum_j c_j G_jd^2 = sv_d^2.  With normalised columns c_j = 1/J.
-      std::vector<double> colsum(J, 0.0);
-      double total = 0.0;
-      for (size_t r = 0; r < I; ++r)
-        for (size_t j = 0; j < J; ++j) colsum[j] += M[r * J + j];
-      for (size_t j = 0; j < J; ++j) total += normalize ? 1.0 : colsum[j];
-      std::vector<double> koords(I * nd);
-      for (size_t d = 0; d < nd; ++d) {
-        double sv2 = 0.0;
-        for (size_t j = 0; j < J; ++j) sv2 += (normalize ? 1.0 : colsum[j]) / total * twisted[j * nd + d] * twisted[j * nd + d];
-        const double sv = sqrt(sv2);
-        for (size_t r = 0; r < I; ++r) koords[r * nd + d] = twister[d * I + r] * sv;
-      }
-      write_named_table(make_filename(out_kmers, "KPopTwisted", true), "rn", dims, knames, koords.data(), nd, false);
-    }
+    write_r_table(make_filename(out, "KPopTwisted", true), "rn", R.twisted);
+    if (!out_kmers.empty()) write_r_table(make_filename(out_kmers, "KPopTwisted", true), "rn", R.kmer_coords);
     if (verbose) fprintf(stderr, "[10/16] Writing inertia...\n");
-    write_named_table(make_filename(out, "KPopInertia", true), "rn", dims, {"inertia"}, inertia.data(), nd, false);
+    write_r_table(make_filename(out, "KPopInertia", true), "rn", R.inertia);
     if (verbose) fprintf(stderr, "[13/16] Writing twister...\n");
-    write_named_table(make_filename(out, "KPopTwister", true), "", knames, dims, twister.data(), I, false);
+    write_r_table(make_filename(out, "KPopTwister", true), "", R.twister);
   } catch (const std::exception &e) {
     fprintf(stderr, "(KPopTwistCA): FATAL: %s\n", e.what());
     return 1;

@@ -17,8 +17,9 @@ enum : uint8_t {
   CODE_DOUBLE_ARRAY32_LITTLE = 0x07, CODE_BLOCK32 = 0x08, CODE_STRING8 = 0x09, CODE_STRING32 = 0x0A,
   CODE_DOUBLE_BIG = 0x0B, CODE_DOUBLE_LITTLE = 0x0C, CODE_DOUBLE_ARRAY8_BIG = 0x0D, CODE_DOUBLE_ARRAY8_LITTLE = 0x0E,
   CODE_DOUBLE_ARRAY32_BIG = 0x0F, CODE_BLOCK64 = 0x13, CODE_STRING64 = 0x15, CODE_DOUBLE_ARRAY64_BIG = 0x16,
-  CODE_DOUBLE_ARRAY64_LITTLE = 0x17
+  CODE_DOUBLE_ARRAY64_LITTLE = 0x17, CODE_CUSTOM = 0x12, CODE_CUSTOM_LEN = 0x18, CODE_CUSTOM_FIXED = 0x19
 };
+constexpr int CAML_BA_INT32 = 6;  // runtime/caml/bigarray.h: enum caml_ba_kind
 constexpr uint32_t MAGIC_SMALL = 0x8495A6BE, MAGIC_BIG = 0x8495A6BF;
 
 // ---------------------------------------------------------------- writer
@@ -84,6 +85,60 @@ struct Writer {
     size32 += 1 + 2 * n;
     size64 += 1 + n;
   }
+  void integer(int64_t v) {
+    if (v >= 0 && v < 0x40) u8((uint8_t)(PREFIX_SMALL_INT + v));
+    else if (v >= -128 && v < 128) {
+      u8(CODE_INT8);
+      be((uint64_t)v, 1);
+    } else if (v >= -32768 && v < 32768) {
+      u8(CODE_INT16);
+      be((uint64_t)v, 2);
+    } else if (v >= -(1ll << 30) && v < (1ll << 30)) {
+      u8(CODE_INT32);
+      be((uint64_t)v, 4);
+    } else {
+      u8(CODE_INT64);
+      be((uint64_t)v, 8);
+    }
+  }
+  void string_array(const std::vector<std::string> &a) {
+    block_header(a.size(), 0);
+    for (const std::string &s : a) string(s);
+  }
+  // one-dimensional int32 c_layout Bigarray (caml_ba_serialize, runtime/bigarray.c)
+  void bigarray_int32(const int32_t *p, uint64_t n) {
+    u8(CODE_CUSTOM_LEN);
+    buf.append("_bigarr02");
+    buf.push_back('\0');
+    const size_t lens = buf.size();
+    buf.append(12, '\0');  // sz_32, sz_64: filled below
+    const size_t start = buf.size();
+    be(1, 4);              // num_dims
+    be(CAML_BA_INT32, 4);  // kind | layout (c_layout = 0)
+    if (n < 0xFFFF) be(n, 2);
+    else {
+      be(0xFFFF, 2);
+      be(n, 8);
+    }
+    const size_t at = buf.size();
+    buf.resize(at + n * 4);
+    char *d = &buf[at];
+    for (uint64_t i = 0; i < n; ++i) {
+      const uint32_t v = (uint32_t)p[i];
+      d[4 * i] = (char)(v >> 24);
+      d[4 * i + 1] = (char)(v >> 16);
+      d[4 * i + 2] = (char)(v >> 8);
+      d[4 * i + 3] = (char)v;
+    }
+    (void)start;
+    // heap size of struct caml_ba_array with one dimension: (4 + num_dims) words
+    const uint64_t sz32 = 5 * 4, sz64 = 5 * 8;
+    for (int i = 0; i < 4; ++i) buf[lens + i] = (char)((sz32 >> (8 * (3 - i))) & 0xFF);
+    for (int i = 0; i < 8; ++i) buf[lens + 4 + i] = (char)((sz64 >> (8 * (7 - i))) & 0xFF);
+    ++n_obj;
+    size32 += 2 + ((sz32 + 3) >> 2);
+    size64 += 2 + ((sz64 + 7) >> 3);
+  }
   void flush(FILE *f) {
     std::string hd;
     auto hbe = [&](uint64_t v, int bytes) {
@@ -116,7 +171,7 @@ void write_string_value(FILE *f, const std::string &s) {
 
 // ---------------------------------------------------------------- reader
 struct Node {
-  enum Kind : uint8_t { Int, Block, String, Double, DoubleArray } kind;
+  enum Kind : uint8_t { Int, Block, String, Double, DoubleArray, Int32Array } kind;
   int tag = 0;
   uint64_t a = 0, b = 0;  // Int: a=value; Block: a=first child slot, b=count; String: a=offset,b=len; Double*: a=offset,b=count
 };
@@ -129,6 +184,7 @@ struct Reader {
   std::vector<uint32_t> objects;   // object table for shared references
   std::string bytes;
   std::vector<double> doubles;
+  std::vector<int32_t> ints32;
 
   uint8_t u8() {
     if (pos >= data.size()) throw Error("marshal: truncated value");
@@ -190,6 +246,34 @@ struct Reader {
     children.insert(children.end(), kids.begin(), kids.end());
     return id;
   }
+  // custom block: only Bigarrays of int32 occur in KPop's archives
+  uint32_t read_custom(uint8_t code) {
+    std::string ident;
+    for (uint8_t ch; (ch = u8()) != 0;) ident.push_back((char)ch);
+    if (code == CODE_CUSTOM_LEN) pos += 12;  // sz_32, sz_64
+    if (code == CODE_CUSTOM_FIXED || (ident != "_bigarr02" && ident != "_bigarray"))
+      throw Error("marshal: unsupported custom block '" + ident + "'");
+    const uint64_t num_dims = be(4), flags = be(4);
+    if (num_dims != 1) throw Error("marshal: a one-dimensional Bigarray was expected");
+    if ((flags & 0xFF) != (uint64_t)CAML_BA_INT32) throw Error("marshal: an int32 Bigarray was expected");
+    uint64_t n;
+    if (ident == "_bigarray") n = be(4);
+    else {
+      n = be(2);
+      if (n == 0xFFFF) n = be(8);
+    }
+    if (n > (data.size() - pos) / 4) throw Error("marshal: truncated Bigarray");
+    Node nd;
+    nd.kind = Node::Int32Array;
+    nd.a = ints32.size();
+    nd.b = n;
+    ints32.resize(ints32.size() + n);
+    const uint8_t *s = &data[pos];
+    for (uint64_t i = 0; i < n; ++i)
+      ints32[nd.a + i] = (int32_t)(((uint32_t)s[4 * i] << 24) | ((uint32_t)s[4 * i + 1] << 16) | ((uint32_t)s[4 * i + 2] << 8) | s[4 * i + 3]);
+    pos += n * 4;
+    return add(nd, true);
+  }
   uint32_t read_value() {
     const uint8_t c = u8();
     if (c >= PREFIX_SMALL_BLOCK) return read_block((c >> 4) & 0x7, c & 0xF);
@@ -230,7 +314,10 @@ struct Reader {
       case CODE_DOUBLE_ARRAY32_BIG: return read_doubles(be(4), false);
       case CODE_DOUBLE_ARRAY64_LITTLE: return read_doubles(be(8), true);
       case CODE_DOUBLE_ARRAY64_BIG: return read_doubles(be(8), false);
-      default: throw Error("marshal: unsupported code 0x" + std::to_string((int)c) + " (custom blocks / closures are not part of a KPop matrix)");
+      case CODE_CUSTOM:
+      case CODE_CUSTOM_LEN:
+      case CODE_CUSTOM_FIXED: return read_custom(c);
+      default: throw Error("marshal: unsupported code " + std::to_string((int)c) + " (closures and abstract values are not part of a KPop archive)");
     }
   }
   std::string str(uint32_t id) const {
@@ -384,6 +471,100 @@ void write_binary_twister(const std::string &path, const Table &twister, const T
     throw;
   }
   fclose(f);
+}
+
+// ---- '.KPopCounter' ---------------------------------------------------------------------------------------------
+void write_binary_counter(const std::string &path, const CounterCore &db) {  // KMerDB.to_binary, lib/KMerDB.ml:395-413
+  FILE *f = open_or_throw(path, "wb");
+  try {
+    write_string_value(f, "KPopCounter");
+    write_string_value(f, kArchiveVersion);
+    Writer w;
+    const size_t n_cols = db.col_names.size(), n_rows = db.row_names.size(), n_meta = db.meta_names.size();
+    w.block_header(8, 0);
+    w.integer((int64_t)n_cols);
+    w.integer((int64_t)n_rows);
+    w.integer((int64_t)n_meta);
+    w.string_array(db.col_names);
+    w.string_array(db.row_names);
+    w.string_array(db.meta_names);
+    w.block_header(n_cols, 0);
+    for (size_t c = 0; c < n_cols; ++c) {
+      std::vector<std::string> m = c < db.meta.size() ? db.meta[c] : std::vector<std::string>();
+      m.resize(n_meta);
+      w.string_array(m);
+    }
+    w.block_header(n_cols, 0);
+    std::vector<int32_t> zeros;
+    for (size_t c = 0; c < n_cols; ++c) {
+      const std::vector<int32_t> &v = db.storage[c];
+      if (v.size() >= n_rows) w.bigarray_int32(v.data(), n_rows);
+      else {  // columns are allowed to be physically shorter than n_rows (trailing zeros)
+        zeros.assign(n_rows, 0);
+        std::copy(v.begin(), v.end(), zeros.begin());
+        w.bigarray_int32(zeros.data(), n_rows);
+      }
+    }
+    w.flush(f);
+  } catch (...) {
+    fclose(f);
+    throw;
+  }
+  fclose(f);
+}
+
+CounterCore read_binary_counter(const std::string &path) {  // KMerDB.of_binary, lib/KMerDB.ml:414-430
+  FILE *f = open_or_throw(path, "rb");
+  CounterCore db;
+  try {
+    Reader r;
+    if (!read_one(f, r)) throw Error("'" + path + "' is empty");
+    const std::string which = r.str(0);
+    if (!read_one(f, r)) throw Error("marshal: archive version missing");
+    const std::string version = r.str(0);
+    if (which != "KPopCounter" || version != kArchiveVersion)  // :421-422
+      throw Error("Incompatible_archive_version(\"" + which + "\", \"" + version + "\")");
+    if (!read_one(f, r)) throw Error("marshal: database missing");
+    const Node &root = r.nodes[0];
+    if (root.kind != Node::Block || root.b != 8) throw Error("marshal: the 8-field KPopCounter record was expected");
+    auto field = [&](int i) { return r.children[root.a + i]; };
+    auto integer = [&](int i) {
+      const Node &n = r.nodes[field(i)];
+      if (n.kind != Node::Int) throw Error("marshal: integer expected");
+      return (uint64_t)n.a;
+    };
+    const uint64_t n_cols = integer(0), n_rows = integer(1), n_meta = integer(2);
+    strings_of(r, field(3), db.col_names);
+    strings_of(r, field(4), db.row_names);
+    strings_of(r, field(5), db.meta_names);
+    // containers are truncated to their exact size on output (:402-409) but tolerate buffers that are longer
+    if (db.col_names.size() < n_cols || db.row_names.size() < n_rows || db.meta_names.size() < n_meta)
+      throw Error("marshal: KPopCounter name tables are shorter than the declared sizes");
+    db.col_names.resize(n_cols);
+    db.row_names.resize(n_rows);
+    db.meta_names.resize(n_meta);
+    const Node &meta = r.nodes[field(6)];
+    if (meta.kind != Node::Block || meta.b < n_cols) throw Error("marshal: KPopCounter metadata table is too short");
+    db.meta.resize(n_cols);
+    for (uint64_t c = 0; c < n_cols; ++c) {
+      strings_of(r, r.children[meta.a + c], db.meta[c]);
+      if (db.meta[c].size() < n_meta) throw Error("marshal: KPopCounter metadata row is too short");
+      db.meta[c].resize(n_meta);
+    }
+    const Node &st = r.nodes[field(7)];
+    if (st.kind != Node::Block || st.b < n_cols) throw Error("marshal: KPopCounter storage is too short");
+    db.storage.resize(n_cols);
+    for (uint64_t c = 0; c < n_cols; ++c) {
+      const Node &v = r.nodes[r.children[st.a + c]];
+      if (v.kind != Node::Int32Array || v.b < n_rows) throw Error("marshal: KPopCounter spectrum " + std::to_string(c) + " is not an int32 Bigarray of n_rows elements");
+      db.storage[c].assign(r.ints32.begin() + (long)v.a, r.ints32.begin() + (long)(v.a + n_rows));
+    }
+  } catch (...) {
+    fclose(f);
+    throw;
+  }
+  fclose(f);
+  return db;
 }
 
 }  // namespace kpop_host

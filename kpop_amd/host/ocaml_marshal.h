@@ -15,7 +15,10 @@
 #pragma once
 #include <stdio.h>
 
+#include <stdint.h>
+
 #include <string>
+#include <vector>
 
 #include "kpop_text.h"
 
@@ -33,5 +36,18 @@ Table read_binary_matrix(const std::string &path, const std::string &expect_type
 void write_binary_matrix(const std::string &path, const std::string &type_name, const Table &t);
 void read_binary_twister(const std::string &path, Table *twister, Table *inertia);
 void write_binary_twister(const std::string &path, const Table &twister, const Table &inertia);
+
+// ---- '.KPopCounter' (lib/KMerDB.ml:54-63,389-430): "KPopCounter", "2022-04-03", then the record
+//   { n_cols; n_rows; n_meta; idx_to_col_names; idx_to_row_names; idx_to_meta_names; meta; storage }
+// with storage : I32BAVector.t array.  BAVector is BiOCamLib's (absent); it is taken as a plain one-dimensional
+// int32 c_layout Bigarray -- UNPINNED like the matrix field order.  A Bigarray travels as a custom block
+// (identifier "_bigarr02": dimension count, kind|layout flags, dimensions, big-endian elements).
+struct CounterCore {
+  std::vector<std::string> col_names, row_names, meta_names;
+  std::vector<std::vector<std::string>> meta;  // n_cols x n_meta
+  std::vector<std::vector<int32_t>> storage;   // n_cols x n_rows
+};
+void write_binary_counter(const std::string &path, const CounterCore &db);
+CounterCore read_binary_counter(const std::string &path);
 
 }  // namespace kpop_host

@@ -20,7 +20,8 @@ def pytest_sessionstart(session):
     """Built artefacts are git-ignored: on a fresh checkout build them once (hipcc cross-compiles without a GPU)."""
     import shutil
     need = [os.path.join(ROOT, "kpop_amd", "libkpop_hip.so"), os.path.join(ROOT, "kpop_amd", "bin", "KPopTwistDB"),
-            os.path.join(ROOT, "kpop_amd", "bin", "KPopCount"), os.path.join(ROOT, "kpop_amd", "bin", "KPopTwistCA")]
+            os.path.join(ROOT, "kpop_amd", "bin", "KPopCount"), os.path.join(ROOT, "kpop_amd", "bin", "KPopTwistCA"),
+            os.path.join(ROOT, "kpop_amd", "bin", "KPopCountDB"), os.path.join(ROOT, "kpop_amd", "bin", "KPopTwist")]
     if all(os.path.exists(p) for p in need):
         return
     if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):

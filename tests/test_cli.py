@@ -199,3 +199,98 @@ def test_binary_round_trips_and_checks(tmp_path, oracle):
     (tmp_path / "q.KPopTwisted").write_bytes(raw)
     r = run([TWISTDB, "-i", "t", str(tmp_path / "q")])
     assert r.returncode == 1 and "Incompatible_archive_version" in r.stderr
+
+
+# ---------------------------------------------------------------- KPopCountDB: host-only actions and '.KPopCounter'
+COUNTDB = os.path.join(BIN, "KPopCountDB")
+TWIST = os.path.join(BIN, "KPopTwist")
+
+
+def hand_marshalled_counter():
+    """"KPopCounter", "2022-04-03", then { n_cols=2; n_rows=2; n_meta=1; [|"A";"B"|]; [|"aa";"ac"|]; [|"class"|];
+    [|[|"X"|];[|"Y"|]|]; [| int32 Bigarray [3;5]; [0;7] |] } assembled by hand from extern.c / bigarray.c:
+    BLOCK32 for the 8-field record, CUSTOM_LEN + "_bigarr02" + sizes (20, 40) + num_dims, kind INT32 (6), a 2-byte
+    dimension and big-endian elements for each spectrum."""
+    v1 = bytes([0x20 + 11]) + b"KPopCounter"
+    v2 = bytes([0x20 + 10]) + b"2022-04-03"
+    rec = bytes([0x08]) + be((8 << 10) | 0, 4) + bytes([0x42, 0x42, 0x41])
+    rec += bytes([0xA0, 0x21]) + b"A" + bytes([0x21]) + b"B"
+    rec += bytes([0xA0, 0x22]) + b"aa" + bytes([0x22]) + b"ac"
+    rec += bytes([0x90, 0x25]) + b"class"
+    rec += bytes([0xA0, 0x90, 0x21]) + b"X" + bytes([0x90, 0x21]) + b"Y"
+    rec += bytes([0xA0])
+    for col in ((3, 5), (0, 7)):
+        rec += bytes([0x18]) + b"_bigarr02\0" + be(20, 4) + be(40, 8) + be(1, 4) + be(6, 4) + be(2, 2)
+        rec += b"".join(be(v, 4) for v in col)
+    return marshal_header(v1, 1, 4, 3) + v1 + marshal_header(v2, 1, 4, 3) + v2 + marshal_header(rec, 17, 56, 55) + rec
+
+
+def test_counter_archive_bytes_and_host_actions(tmp_path):
+    (tmp_path / "s.KPopSpectra.txt").write_text("\tA\naa\t3\nac\t5\n\t\"B\"\nac\t2\nac\t0x5\n")
+    (tmp_path / "meta.txt").write_text("label\tclass\nA\tX\n\"B\"\t\"Y\"\n")
+    r = run([COUNTDB, "-k", str(tmp_path / "s"), "-m", str(tmp_path / "meta.txt"), "-o", str(tmp_path / "db"), "--summary", "-v"])
+    assert r.returncode == 0, r.stderr
+    assert "[Spectrum labels (2)]: 'A' 'B'\n[K-mer hashes (2)]: 'aa' 'ac'\n[Meta-data fields (1)]: 'class'\n" in r.stderr
+    assert (tmp_path / "db.KPopCounter").read_bytes() == hand_marshalled_counter()
+    # selection register: regexps on labels and metadata (anchored at the start only), negation, explicit labels
+    r = run([COUNTDB, "-i", str(tmp_path / "db"), "-R", "~.", "-P", "-R", "class~X", "-P", "-N", "-P", "-L", "q,A", "-P", "-C", "-P",
+             "-R", "~A\\|B,class~[^X]", "-P", "-R", "nofield~.", "-P"])
+    assert r.returncode == 0, r.stderr
+    sel = [l for l in r.stderr.splitlines() if l.startswith("Currently selected")]
+    assert sel == ["Currently selected spectra = [ 'A' 'B' ].", "Currently selected spectra = [ 'A' ].",
+                   "Currently selected spectra = [ 'B' ].", "Currently selected spectra = [ 'A' 'q' ].",
+                   "Currently selected spectra = [ ].", "Currently selected spectra = [ 'B' ].", "Currently selected spectra = [ ]."]
+    # -D and -e are host-only too
+    r = run([COUNTDB, "-i", str(tmp_path / "db"), "-L", "A", "-D", "--summary", "-e", "--summary"])
+    assert "[Spectrum labels (1)]: 'B'" in r.stderr and "[Spectrum labels (0)]:" in r.stderr
+
+
+def test_counter_archive_reader_accepts_what_ocaml_may_emit(tmp_path):
+    """Old-style Bigarray blocks (CODE_CUSTOM, "_bigarray", 4-byte dimensions), shared strings, name buffers longer than
+    the declared sizes."""
+    v1 = bytes([0x20 + 11]) + b"KPopCounter"
+    v2 = bytes([0x20 + 10]) + b"2022-04-03"
+    rec = bytes([0x08]) + be((8 << 10) | 0, 4) + bytes([0x41, 0x42, 0x41])
+    rec += bytes([0xA0, 0x21]) + b"A" + bytes([0x20])                      # one spare (empty) label slot
+    rec += bytes([0xA0, 0x22]) + b"aa" + bytes([0x22]) + b"ac"
+    rec += bytes([0x90, 0x21]) + b"m"
+    # objects so far: record 0, labels 1, "A" 2, "" 3, k-mers 4, "aa" 5, "ac" 6, fields 7, "m" 8, meta 9, its row 10
+    rec += bytes([0x90, 0x90, 0x04, 9])                                     # -> the value shares the string "A" (11 - 9)
+    rec += bytes([0x90, 0x12]) + b"_bigarray\0" + be(1, 4) + be(6, 4) + be(3, 4) + be(9, 4) + be(2**32 - 4, 4) + be(0, 4)
+    (tmp_path / "old.KPopCounter").write_bytes(marshal_header(v1, 1, 4, 3) + v1 + marshal_header(v2, 1, 4, 3) + v2 +
+                                                marshal_header(rec, 12, 0, 0) + rec)
+    r = run([COUNTDB, "-i", str(tmp_path / "old"), "--summary", "-v", "-R", "m~^A$", "-P"])
+    assert r.returncode == 0, r.stderr
+    assert "[Spectrum labels (1)]: 'A'" in r.stderr and "[K-mer hashes (2)]: 'aa' 'ac'" in r.stderr
+    assert "Currently selected spectra = [ 'A' ]." in r.stderr
+
+
+def test_countdb_errors(tmp_path):
+    def fails(args, what, code=1):
+        r = run([COUNTDB] + args)
+        assert r.returncode == code and what in r.stderr and r.stdout == "", (args, r.stderr)
+    fails(["--nonsense"], "Unknown option")
+    fails(["-R", "a~b~c"], "Wrong number of fields in list (expected 2, found 3)")
+    fails(["--combination-criterion", "mode"], "Unknown_combination_criterion")
+    fails(["--table-transpose", "maybe"], "is not a boolean")
+    fails(["--counts-threshold", "-1"], "non-negative")
+    fails(["-i", str(tmp_path / "missing")], "cannot open")
+    (tmp_path / "bad1.KPopSpectra.txt").write_text("aa\t3\n")
+    fails(["-k", str(tmp_path / "bad1")], "Header_expected")
+    (tmp_path / "bad2.KPopSpectra.txt").write_text("\tA\naa\t3\t4\n")
+    fails(["-k", str(tmp_path / "bad2")], "Wrong_number_of_columns(2, 3, 2)")
+    (tmp_path / "bad3.KPopSpectra.txt").write_text("\tA\naa\t3.5\n")
+    fails(["-k", str(tmp_path / "bad3")], "Wrong_format(2, \"3.5\")")
+    (tmp_path / "bad4.KPopSpectra.txt").write_text("\tA\"B\naa\t3\n")
+    fails(["-k", str(tmp_path / "bad4")], "Quotes_in_name")
+    (tmp_path / "x.KPopCounter").write_bytes(b"\x84\x95\xa6\xbe" + b"\0" * 3)
+    fails(["-i", str(tmp_path / "x")], "truncated")
+    (tmp_path / "meta.txt").write_text("label\tclass\nA\n")
+    fails(["-m", str(tmp_path / "meta.txt")], "Wrong_number_of_columns(2, 1, 2)")
+    fails(["-e", "-d", "class", "out"], "not supported")
+    r = run([COUNTDB])
+    assert r.returncode == 0 and "Usage: KPopCountDB" in r.stdout
+    r = run([TWIST, "-o", "x"])
+    assert r.returncode == 1 and "Option '-i' is mandatory" in r.stderr
+    r = run([TWIST, "-i", "x", "-o", "y", "--counts-transform", "sqrt"])
+    assert r.returncode == 1 and "Unknown_transformation" in r.stderr

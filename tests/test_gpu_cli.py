@@ -297,3 +297,208 @@ def test_training_without_r_then_classification(tmp_path, oracle, pyref):
     got = {l.split("\t")[0]: l.split("\t")[5] for l in (tmp_path / "Test-vs-Classes.KPopSummary.txt").read_text().splitlines()}
     correct = sum(got[name] == cls for (name, _), cls in zip(reads, truth))
     assert correct >= 0.9 * len(reads), (correct, len(reads))
+
+
+# ---------------------------------------------------------------- KPopCountDB / KPopTwist
+COUNTDB = os.path.join(BIN, "KPopCountDB")
+TWIST = os.path.join(BIN, "KPopTwist")
+
+
+def fmt(v, precision=15):
+    return "%.*g" % (precision, v)
+
+
+def class_fixture(pyref, rng, k, n_classes, per_class, glen):
+    """n_classes random genomes, per_class mutated copies each; -> {class: [(name, seq)]}, spectra per sequence"""
+    classes = {}
+    for c in range(n_classes):
+        g = rng.choice(list("ACGT"), size=glen)
+        members = []
+        for i in range(per_class):
+            s = g.copy()
+            pos = rng.choice(glen, size=glen // 50, replace=False)
+            s[pos] = rng.choice(list("ACGT"), size=pos.size)
+            members.append(("S%d-C%d" % (i, c + 1), "".join(s[: glen - 37 * i])))   # unequal lengths: unequal norms
+        classes["C%d" % (c + 1)] = members
+    return classes
+
+
+def expected_combination(oracle, pyref, members, k, criterion):
+    """add_combined_selected on the spectra of `members` as KPopCountDB sees them: rows in order of first appearance,
+    spectra visited in descending label order (lib/KMerDB.ml:650-660)."""
+    spectra = [(name, pyref.count_read(seq, k)) for name, seq in members]
+    rows = []
+    for _, sp in spectra:                     # KPopCount prints ascending hashes; new k-mers are appended as they come
+        for h in sorted(sp):
+            if h not in rows:
+                rows.append(h)
+    seen, order = set(), []
+    for h in rows:
+        if h not in seen:
+            seen.add(h)
+            order.append(h)
+    cols = [np.array([sp.get(h, 0) for h in order], dtype=np.int32) for _, sp in spectra]
+    lin, _ = oracle.counter_stats(cols, 1.0, 1.0)
+    labels = [name for name, _ in spectra]
+    sel = [labels.index(l) for l in sorted(labels, reverse=True)]
+    out, _ = oracle.counter_combine(cols, sel, lin[:, 2], criterion)
+    return order, out
+
+
+@pytest.mark.parametrize("criterion", ["mean", "median"])
+def test_readme_training_flow(tmp_path, oracle, pyref, criterion):
+    """README.md:91-92 verbatim (the quick-start training loop), then :606/:656 classification -- no OCaml, no R."""
+    from oracle import ca_ref
+    k, n_classes, per_class, glen = 5, 5, 4, 2500
+    rng = np.random.default_rng(91)
+    classes = class_fixture(pyref, rng, k, n_classes, per_class, glen)
+    with open(tmp_path / "clusters-small.fasta", "w") as f:
+        for members in zip(*classes.values()):             # interleaved, as a real file would be
+            for name, seq in members:
+                f.write(">%s\n%s\n" % (name, seq))
+    penv = dict(os.environ, PATH=BIN + ":" + os.environ.get("PATH", ""))
+    sh = lambda cmd: subprocess.run(["bash", "-c", cmd], cwd=str(tmp_path), capture_output=True, text=True, timeout=300, env=penv)
+    crit = "" if criterion == "mean" else "--combination-criterion median "
+    loop = ("K=%d; for CLASS in %s; do cat clusters-small.fasta | awk -v CLASS=$CLASS '{nr=(NR-1)%%2; ok=(nr==0?$0~(\"-\"CLASS\"$\"):nr==1&&ok); "
+            "if (ok) print}' | KPopCount -k $K -L -f /dev/stdin | KPopCountDB -k /dev/stdin %s-R \"~.\" -A $CLASS -L $CLASS -N -D "
+            "-t /dev/stdout; done") % (k, " ".join(classes), crit)
+    r = sh(loop + " | cat > combined.txt")  # a pipe, as in the README: opening /dev/stdout truncates a redirected file
+    assert r.returncode == 0, r.stderr
+    # every class representative, byte for byte
+    want_text, reps = "", {}
+    for cname, members in classes.items():
+        order, out = expected_combination(oracle, pyref, members, k, 0 if criterion == "mean" else 1)
+        reps[cname] = dict(zip(order, out))
+        want_text += "\t%s\n" % cname + "".join("%s\t%s\n" % (pyref.to_hex(h, k), fmt(float(v))) for h, v in zip(order, out))
+    got = (tmp_path / "combined.txt").read_text()
+    # the table drops k-mers whose row is all zero (lib/KMerDB.ml:1033-1036)
+    want_text = "".join(l + "\n" for l in want_text.splitlines() if not l.endswith("\t0"))
+    assert got == want_text
+    r = sh("cat combined.txt | KPopCountDB -k /dev/stdin -o Classes.%d -v" % k)
+    assert r.returncode == 0 and "Read %d spectra" % n_classes in r.stderr, r.stderr
+    r = sh("KPopTwist -i Classes.%d -o Classes.%d -v" % (k, k))
+    assert r.returncode == 0, r.stderr
+    assert sorted(p.name for p in tmp_path.iterdir() if p.name.startswith("Classes")) == [
+        "Classes.%d.KPopCounter" % k, "Classes.%d.KPopTwisted" % k, "Classes.%d.KPopTwister" % k]
+    # the twister against the numpy restatement of R's ca on the same class table
+    r = sh("KPopTwistDB -i T Classes.%d -O T /dev/stdout" % k)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    lines = lines[:1 + (n_classes - 1)]      # -O T writes the twister, then the inertia table, to the same path
+    kmers_out = [c.strip('"') for c in lines[0].split("\t")[1:]]
+    T = np.array([[float(v) for v in l.split("\t")[1:]] for l in lines[1:]])
+    row_order = []
+    for cname in classes:
+        for h, v in reps[cname].items():
+            if v != 0 and h not in row_order:
+                row_order.append(h)
+    assert kmers_out == [pyref.to_hex(h, k) for h in row_order]
+    N = np.array([[float(reps[c].get(h, 0)) for c in classes] for h in row_order])
+    tw_o, in_o, T_o = ca_ref.ca(N)
+    assert T.shape == T_o.shape
+    assert np.max(np.abs(ca_ref.align_signs(T, T_o, 0) - T_o)) <= 1e-8 * np.max(np.abs(T_o))
+    # classification of fragments of the training genomes (README.md:606,656)
+    reads, truth = [], []
+    for cname, members in classes.items():
+        for i in range(4):
+            name, seq = members[i % per_class]
+            s = int(rng.integers(0, len(seq) - 600))
+            reads.append(("q%s_%d" % (cname, i), seq[s:s + 600]))
+            truth.append(cname)
+    write_fasta(tmp_path / "test.fa", reads)
+    r = sh("KPopCount -k %d -L -f test.fa | KPopTwistDB -i T Classes.%d -k /dev/stdin -o t Test" % (k, k))
+    assert r.returncode == 0, r.stderr
+    r = sh("KPopTwistDB -i T Classes.%d -i t Classes.%d -s Test Test-vs-Classes" % (k, k))
+    assert r.returncode == 0, r.stderr
+    got = {l.split("\t")[0]: l.split("\t")[5] for l in (tmp_path / "Test-vs-Classes.KPopSummary.txt").read_text().splitlines()}
+    correct = sum(got[name] == cls for (name, _), cls in zip(reads, truth))
+    assert correct >= 0.9 * len(reads), (correct, len(reads))
+
+
+def test_countdb_tables_spectra_split_and_distances(tmp_path, oracle, pyref):
+    """-c (combine by class through metadata), -t with every layout switch, -s, -F and --distances against the oracle."""
+    k = 4
+    rng = np.random.default_rng(5)
+    seqs = [("s%d" % i, "".join(rng.choice(list("ACGT"), size=int(rng.integers(150, 400))))) for i in range(6)]
+    write_fasta(tmp_path / "x.fa", seqs)
+    (tmp_path / "meta.txt").write_text("label\tclass\tsite\n" + "".join("s%d\t%s\t%s\n" % (i, "ab"[i % 2], "north") for i in range(6)))
+    penv = dict(os.environ, PATH=BIN + ":" + os.environ.get("PATH", ""))
+    sh = lambda cmd: subprocess.run(["bash", "-c", cmd], cwd=str(tmp_path), capture_output=True, text=True, timeout=300, env=penv)
+    assert sh("KPopCount -k %d -L -f x.fa | KPopCountDB -k /dev/stdin -m meta.txt -o db" % k).returncode == 0
+    spectra = [pyref.count_read(s, k) for _, s in seqs]
+    rows = []
+    for sp in spectra:
+        rows += [h for h in sorted(sp) if h not in rows]
+    cols = [np.array([sp.get(h, 0) for h in rows], dtype=np.int32) for sp in spectra]
+    names = [pyref.to_hex(h, k) for h in rows]
+    labels = [n for n, _ in seqs]
+
+    def table_text(cols_idx, cs, which, thr, pw, precision=15, transpose=False, row_names=True, col_names=True, meta=None, rs=None,
+                   zero_rows=False):
+        vals = oracle.counter_transform(cols, cs, which, thr, pw, kmer_major=True)
+        keep = [r for r in range(len(rows)) if zero_rows or rs[r, 2] > 0]
+        out = ""
+        if not transpose:
+            if col_names:
+                out += "".join(("\t" if (i > 0 or row_names) else "") + labels[c] for i, c in enumerate(cols_idx)) + "\n"
+            for mname, mvals in (meta or []):
+                out += (mname if row_names else "") + "".join(("\t" if (i > 0 or row_names) else "") + mvals[c] for i, c in enumerate(cols_idx)) + "\n"
+            for r in keep:
+                out += (names[r] if row_names else "") + "".join(("\t" if (i > 0 or row_names) else "") + fmt(vals[r, c], precision)
+                                                                for i, c in enumerate(cols_idx)) + "\n"
+        else:
+            if col_names:
+                cells = [m for m, _ in (meta or [])] + [names[r] for r in keep]
+                out += "".join(("\t" if (i > 0 or row_names) else "") + c for i, c in enumerate(cells)) + "\n"
+            for c in cols_idx:
+                cells = [mv[c] for _, mv in (meta or [])] + [fmt(vals[r, c], precision) for r in keep]
+                out += (labels[c] if row_names else "") + "".join(("\t" if (i > 0 or row_names) else "") + x for i, x in enumerate(cells)) + "\n"
+        return out
+
+    meta = [("class", ["ab"[i % 2] for i in range(6)]), ("site", ["north"] * 6)]
+    cs, rs = oracle.counter_stats(cols, 1.0, 1.0)
+    r = sh("KPopCountDB -i db -t /dev/stdout")
+    assert r.returncode == 0 and r.stdout == table_text(range(6), cs, 1, 1.0, 1.0, rs=rs), r.stderr
+    r = sh("KPopCountDB -i db --table-output-metadata true --table-transpose true --counts-precision 4 -t /dev/stdout")
+    assert r.stdout == table_text(range(6), cs, 1, 1.0, 1.0, precision=4, transpose=True, meta=meta, rs=rs)
+    r = sh("KPopCountDB -i db --table-output-row-names false --table-output-metadata true -L s1,s4 -F -t /dev/stdout")
+    assert r.stdout == table_text([0, 2, 3, 5], cs, 1, 1.0, 1.0, row_names=False, meta=meta, rs=rs)
+    cs2, rs2 = oracle.counter_stats(cols, 2.0, 1.0)
+    r = sh("KPopCountDB -i db --counts-threshold 2 --counts-transform binary --table-output-col-names false -t /dev/stdout")
+    assert r.stdout == table_text(range(6), cs2, 0, 2.0, 1.0, col_names=False, rs=rs2)
+    r = sh("KPopCountDB -i db --counts-threshold 2 --counts-output-zero-kmers true --counts-transform pseudocounts -t out && cat out.KPopCounter.txt")
+    want = table_text(range(6), cs2, 3, 2.0, 1.0, rs=rs2, zero_rows=True)
+    assert r.stdout == want
+    cs3, rs3 = oracle.counter_stats(cols, 1.0, 0.5)
+    r = sh("KPopCountDB -i db --counts-power 0.5 --counts-transform clr --counts-precision 9 -t /dev/stdout")
+    got_rows = [l.split("\t") for l in r.stdout.splitlines()]
+    want_rows = [l.split("\t") for l in table_text(range(6), cs3, 2, 1.0, 0.5, precision=9, rs=rs3).splitlines()]
+    assert [g[0] for g in got_rows] == [w[0] for w in want_rows] and got_rows[0] == want_rows[0]
+    np.testing.assert_allclose([[float(v) for v in g[1:]] for g in got_rows[1:]], [[float(v) for v in w[1:]] for w in want_rows[1:]], rtol=1e-8)
+    # -s: spectra, only positive values
+    r = sh("KPopCountDB -i db --counts-threshold 2 -s /dev/stdout")
+    vals = oracle.counter_transform(cols, cs2, 1, 2.0, 1.0, kmer_major=True)
+    want = "".join("\t%s\n" % labels[c] + "".join("%s\t%s\n" % (names[i], fmt(vals[i, c])) for i in range(len(rows)) if rs2[i, 2] > 0 and vals[i, c] > 0)
+                   for c in range(6))
+    assert r.stdout == want
+    # -c: classes "a" (s0,s2,s4) and "b" (s1,s3,s5), originals removed, metadata inherited where unanimous
+    r = sh("KPopCountDB -i db -c class --table-output-metadata true -t /dev/stdout")
+    assert r.returncode == 0, r.stderr
+    lin = cs[:, 2]
+    comb = [oracle.counter_combine(cols, sel, lin, 0)[0] for sel in ([4, 2, 0], [5, 3, 1])]
+    want = "\ta\tb\nclass\ta\tb\nsite\tnorth\tnorth\n" + "".join("%s\t%s\t%s\n" % (names[i], fmt(float(comb[0][i])), fmt(float(comb[1][i])))
+                                                                 for i in range(len(rows)) if comb[0][i] + comb[1][i] > 0)
+    assert r.stdout == want
+    r = sh("KPopCountDB -i db -L a -A a -c class -t /dev/null")
+    assert r.returncode == 1 and "Class_label_is_also_spectrum_name" in r.stderr
+    r = sh("KPopCountDB -i db -c nothere")
+    assert r.returncode == 1 and "Classes_label_not_found" in r.stderr
+    # --distances between the two classes' members, spectra normalised by their sums, flat metric over k-mers
+    r = sh("KPopCountDB -i db --distance 'minkowski(1.5)' --distances 'class~a' 'class~b' D && KPopTwistDB -i d D -O d /dev/stdout")
+    assert r.returncode == 0, r.stderr
+    m = np.array([c / c.sum() for c in cols], dtype=np.float64)
+    want = oracle.distance_rowwise(m[[0, 2, 4]], m[[1, 3, 5]], np.ones(len(rows)), oracle.MINKOWSKI, 1.5, True)
+    lines = r.stdout.splitlines()
+    assert lines[0].split("\t") == ['""', '"s0"', '"s2"', '"s4"'] and [l.split("\t")[0] for l in lines[1:]] == ['"s1"', '"s3"', '"s5"']
+    got = np.array([[float(v) for v in l.split("\t")[1:]] for l in lines[1:]])
+    np.testing.assert_allclose(got, want, rtol=1e-12)
