@@ -239,13 +239,18 @@ uint64_t kpop_dev_counter_workspace_bytes(uint32_t n_cols, uint64_t n_rows);
 int kpop_dev_counter_stats(const int32_t *d_storage, uint64_t ld, uint32_t n_cols, uint64_t n_rows,
                            double threshold, double power, void *d_workspace, double *d_col_stats,
                            double *d_row_stats, void *stream);
-/* d_sel / d_norm list the n_valid selected spectra whose norm is positive, in visiting order */
+/* d_sel / d_norm list the n_valid selected spectra whose norm is positive, in visiting order; d_workspace needs
+   kpop_dev_counter_workspace_bytes(n_valid, n_rows) */
 int kpop_dev_counter_combine(const int32_t *d_storage, uint64_t ld, uint64_t n_rows, const uint32_t *d_sel,
                              const double *d_norm, uint32_t n_valid, uint32_t n_sel, double max_norm,
                              int criterion, void *d_workspace, int32_t *d_out, double *d_out_norm, void *stream);
 int kpop_dev_counter_transform(const int32_t *d_storage, uint64_t ld, uint32_t n_cols, uint64_t n_rows,
                                int which, double threshold, double power, const double *d_col_stats,
                                int kmer_major, double *d_out, void *stream);
+/* test hook: d_fast[i] = a[i] / b[i] by the reciprocal + FMA route the combination kernels use, d_exact[i] by
+   the hardware division; the two must be bit-identical */
+int kpop_dev_division_probe(const double *d_a, const double *d_b, uint64_t n, double *d_fast, double *d_exact,
+                            void *stream);
 
 #ifdef __cplusplus
 }

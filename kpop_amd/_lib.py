@@ -59,6 +59,7 @@ SIGNATURES = {
                                            C.c_int, vp, vp, vp, vp]),
     "kpop_dev_counter_transform": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.c_double, C.c_double,
                                              vp, C.c_int, vp, vp]),
+    "kpop_dev_division_probe": (C.c_int, [vp, vp, C.c_uint64, vp, vp, vp]),
     "kpop_dev_synth_reads": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, vp, vp, vp]),
     "kpop_dev_count_reads_scratch_bytes": (C.c_uint64, [C.c_uint32, C.c_uint32, C.c_int]),
     "kpop_dev_count_reads": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, vp, vp, vp, vp]),

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "common.h"
+#include "wave_sort.h"
 
 namespace kpop {
 
@@ -54,6 +55,26 @@ __device__ __forceinline__ double pow_nn(double x, double y) {
 }
 __device__ __forceinline__ double pow_count(double f, double power, bool power_one) { return power_one ? f : pow_nn(f, power); }
 
+// sum of log(count): accumulated as a running product with the exponent split off (one multiply per count
+// instead of one log()); the product of n factors carries a relative error of ~sqrt(n) ulp, far below what a sum of
+// n rounded logarithms carries.  A zero factor makes the product 0 and the sum -inf, as log 0 does.
+struct LogSum {
+  double mant = 1.;
+  int64_t expo = 0;
+  __device__ __forceinline__ void mul(double f) { mant *= f; }
+  // call at least once every 8 factors (each < 2^32): 2^700 * 2^256 stays finite
+  __device__ __forceinline__ void renorm() {
+    if (mant > 0x1p+700) {
+      int ex;
+      mant = frexp(mant, &ex);
+      expo += ex;
+    }
+  }
+  __device__ __forceinline__ double value() const { return log(mant) + (double)expo * 0.693147180559945309417232121458; }
+};
+
+constexpr int kStatUnroll = 8;
+
 // pass A (only for relative thresholds): plain sum of v^power per column slab
 __global__ __launch_bounds__(kStatBlock) void col_plain_sum_kernel(const int32_t *__restrict__ storage, uint64_t ld,
                                                                   uint64_t n_rows, double power, int power_one,
@@ -62,7 +83,15 @@ __global__ __launch_bounds__(kStatBlock) void col_plain_sum_kernel(const int32_t
   const int32_t *v = storage + (uint64_t)col * ld;
   const uint64_t lo = (uint64_t)slab * kRowsPerStatBlock, hi = min(n_rows, lo + kRowsPerStatBlock);
   double s = 0.;
-  for (uint64_t i = lo + threadIdx.x; i < hi; i += kStatBlock) s += pow_count((double)v[i], power, power_one);
+  uint64_t i = lo + threadIdx.x;
+  for (; i + (kStatUnroll - 1) * kStatBlock < hi; i += kStatUnroll * kStatBlock) {
+    int32_t c[kStatUnroll];
+#pragma unroll
+    for (int u = 0; u < kStatUnroll; ++u) c[u] = v[i + u * kStatBlock];
+#pragma unroll
+    for (int u = 0; u < kStatUnroll; ++u) s += pow_count((double)c[u], power, power_one);
+  }
+  for (; i < hi; i += kStatBlock) s += pow_count((double)v[i], power, power_one);
   __shared__ double sh[kStatBlock / 64];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
@@ -88,7 +117,21 @@ __global__ void col_threshold_kernel(const double *__restrict__ partial, uint32_
   thr[c] = t;
 }
 
-// pass B: thresholded statistics per column slab (lib/KMerDB.ml:196-215)
+struct StatAcc {
+  double nz = 0., mx = 0., s = 0.;
+  LogSum ls;
+  __device__ __forceinline__ void add(int32_t c, double threshold, double power, bool power_one) {
+    const double f = (double)c;
+    if (f >= threshold) {
+      nz += 1.;
+      mx = fmax(mx, f);
+      s += pow_count(f, power, power_one);
+      ls.mul(f);
+    }
+  }
+};
+
+// pass B: thresholded statistics per column slab (lib/KMerDB.ml:196-215); sum_log is scaled by `power` at the end
 __global__ __launch_bounds__(kStatBlock) void col_stats_kernel(const int32_t *__restrict__ storage, uint64_t ld, uint64_t n_rows,
                                                               double power, int power_one, const double *__restrict__ thr,
                                                               uint32_t n_slabs, ColPartial *__restrict__ partial) {
@@ -96,21 +139,22 @@ __global__ __launch_bounds__(kStatBlock) void col_stats_kernel(const int32_t *__
   const int32_t *v = storage + (uint64_t)col * ld;
   const uint64_t lo = (uint64_t)slab * kRowsPerStatBlock, hi = min(n_rows, lo + kRowsPerStatBlock);
   const double threshold = thr[col];
-  double nz = 0., mx = 0., s = 0., sl = 0.;
-  for (uint64_t i = lo + threadIdx.x; i < hi; i += kStatBlock) {
-    const double f = (double)v[i];
-    if (f >= threshold) {
-      nz += 1.;
-      mx = fmax(mx, f);
-      s += pow_count(f, power, power_one);
-      sl += log(f) * power;
-    }
+  StatAcc a;
+  uint64_t i = lo + threadIdx.x;
+  for (; i + (kStatUnroll - 1) * kStatBlock < hi; i += kStatUnroll * kStatBlock) {
+    int32_t c[kStatUnroll];
+#pragma unroll
+    for (int u = 0; u < kStatUnroll; ++u) c[u] = __builtin_nontemporal_load(v + i + u * kStatBlock);
+#pragma unroll
+    for (int u = 0; u < kStatUnroll; ++u) a.add(c[u], threshold, power, power_one);
+    a.ls.renorm();
+  }
+  for (; i < hi; i += kStatBlock) {
+    a.add(v[i], threshold, power, power_one);
+    a.ls.renorm();
   }
   __shared__ ColPartial sh[kStatBlock / 64];
-  nz = wave_sum(nz);
-  mx = wave_max(mx);
-  s = wave_sum(s);
-  sl = wave_sum(sl);
+  const double nz = wave_sum(a.nz), mx = wave_max(a.mx), s = wave_sum(a.s), sl = wave_sum(a.ls.value());
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ColPartial{nz, mx, s, sl};
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -125,7 +169,7 @@ __global__ __launch_bounds__(kStatBlock) void col_stats_kernel(const int32_t *__
   }
 }
 
-__global__ void col_stats_final_kernel(const ColPartial *__restrict__ partial, uint32_t n_slabs, uint32_t n_cols,
+__global__ void col_stats_final_kernel(const ColPartial *__restrict__ partial, uint32_t n_slabs, uint32_t n_cols, double power,
                                        double *__restrict__ col_stats) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_cols) return;
@@ -140,7 +184,7 @@ __global__ void col_stats_final_kernel(const ColPartial *__restrict__ partial, u
   col_stats[4 * (uint64_t)c + 0] = t.non_zero;
   col_stats[4 * (uint64_t)c + 1] = t.max;
   col_stats[4 * (uint64_t)c + 2] = t.sum;
-  col_stats[4 * (uint64_t)c + 3] = t.sum_log;
+  col_stats[4 * (uint64_t)c + 3] = t.non_zero > 0. ? t.sum_log * power : 0.;
 }
 
 // one thread per k-mer, spectra visited in order: the reference's own summation order (lib/KMerDB.ml:182-215, Row)
@@ -149,27 +193,29 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const int32_t *__restric
                                                         double *__restrict__ row_stats) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
+    const int32_t *v = storage + r;
     double threshold = threshold0;
     if (threshold0 < 1.) {
       double s = 0.;
-      for (uint32_t c = 0; c < n_cols; ++c) s += pow_count((double)storage[(uint64_t)c * ld + r], power, power_one);
+      for (uint32_t c = 0; c < n_cols; ++c) s += pow_count((double)v[(uint64_t)c * ld], power, power_one);
       threshold = threshold0 * s;
     }
-    double nz = 0., mx = 0., s = 0., sl = 0.;
-    for (uint32_t c = 0; c < n_cols; ++c) {
-      const double f = (double)storage[(uint64_t)c * ld + r];
-      if (f >= threshold) {
-        nz += 1.;
-        mx = fmax(mx, f);
-        s += pow_count(f, power, power_one);
-        sl += log(f) * power;
-      }
+    StatAcc a;
+    uint32_t c = 0;
+    for (; c + kStatUnroll <= n_cols; c += kStatUnroll) {
+      int32_t x[kStatUnroll];
+#pragma unroll
+      for (int u = 0; u < kStatUnroll; ++u) x[u] = v[(uint64_t)(c + u) * ld];
+#pragma unroll
+      for (int u = 0; u < kStatUnroll; ++u) a.add(x[u], threshold, power, power_one);
+      a.ls.renorm();
     }
+    for (; c < n_cols; ++c) a.add(v[(uint64_t)c * ld], threshold, power, power_one);
     double *o = row_stats + 4 * r;
-    o[0] = nz;
-    o[1] = mx;
-    o[2] = s;
-    o[3] = sl;
+    o[0] = a.nz;
+    o[1] = a.mx;
+    o[2] = a.s;
+    o[3] = a.nz > 0. ? a.ls.value() * power : 0.;
   }
 }
 
@@ -179,20 +225,64 @@ __device__ __forceinline__ int32_t int32_of_float(double x) {
   return (int32_t)(uint32_t)(uint64_t)(int64_t)x;
 }
 
+// a / b correctly rounded, given y = RN(1 / b) computed once per spectrum: two Newton corrections of the
+// quotient on FMAs (Markstein: with y the correctly rounded reciprocal and q1 within an ulp, RN(q1 + r1 y) is
+// RN(a / b)).  Five FMA-rate operations instead of the ~12-instruction v_div_scale / v_rcp / v_div_fmas / v_div_fixup
+// sequence, and bit-identical to it (tests/test_gpu_counter.py::test_division_by_reciprocal_is_exact); y == 0 marks a
+// divisor whose reciprocal is not safely rounded (all-ones mantissa) and takes the hardware division.
+__device__ __forceinline__ double div_rn(double a, double b, double y) {
+  if (y == 0.) return __ddiv_rn(a, b);
+  const double q0 = __dmul_rn(a, y);
+  const double r0 = __fma_rn(-b, q0, a);
+  const double q1 = __fma_rn(r0, y, q0);
+  const double r1 = __fma_rn(-b, q1, a);
+  return __fma_rn(r1, y, q1);
+}
+
+// RN(1 / b), or 0 where div_rn must not be used: all-ones mantissas, and magnitudes far enough out that the
+// residuals could leave the normal range
+__device__ __forceinline__ double safe_reciprocal(double b) {
+  const bool all_ones = (__double_as_longlong(b) & 0xFFFFFFFFFFFFFll) == 0xFFFFFFFFFFFFFll;
+  return (all_ones || !(b > 0x1p-500 && b < 0x1p+500)) ? 0. : __ddiv_rn(1., b);
+}
+
+__global__ void reciprocal_kernel(const double *__restrict__ norm, uint32_t m, double *__restrict__ rcp) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < m) rcp[j] = safe_reciprocal(norm[j]);
+}
+
+// exposed for the test of div_rn: out[i] = a[i] / b[i] both ways
+__global__ void division_probe_kernel(const double *__restrict__ a, const double *__restrict__ b, uint64_t n, double *__restrict__ fast,
+                                      double *__restrict__ exact) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fast[i] = div_rn(a[i], b[i], safe_reciprocal(b[i]));
+  exact[i] = __ddiv_rn(a[i], b[i]);
+}
+
+constexpr int kMeanUnroll = 8;
+
 // RescaledMean: sum over the selected spectra, in the order given, of count * max_norm / norm
-// (lib/KMerDB.ml:687-704).  sel/norm list only the spectra whose norm is positive (:693).
+// (lib/KMerDB.ml:687-704).  sel/norm/rcp list only the spectra whose norm is positive (:693).  One thread per k-mer,
+// eight spectra's loads in flight.
 __global__ __launch_bounds__(256) void combine_mean_kernel(const int32_t *__restrict__ storage, uint64_t ld, uint64_t n_rows,
                                                            const uint32_t *__restrict__ sel, const double *__restrict__ norm,
-                                                           uint32_t m, double max_norm, int32_t *__restrict__ out,
-                                                           double *__restrict__ norm_partial) {
+                                                           const double *__restrict__ rcp, uint32_t m, double max_norm,
+                                                           int32_t *__restrict__ out, double *__restrict__ norm_partial) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   double acc_norm = 0.;
   for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
     double s = 0.;
-    for (uint32_t j = 0; j < m; ++j) {
-      const double c = (double)storage[(uint64_t)sel[j] * ld + r];
-      s = __dadd_rn(s, __ddiv_rn(__dmul_rn(c, max_norm), norm[j]));
+    uint32_t j = 0;
+    for (; j + kMeanUnroll <= m; j += kMeanUnroll) {
+      int32_t c[kMeanUnroll];
+#pragma unroll
+      for (int u = 0; u < kMeanUnroll; ++u) c[u] = __builtin_nontemporal_load(storage + (uint64_t)sel[j + u] * ld + r);
+#pragma unroll
+      for (int u = 0; u < kMeanUnroll; ++u) s = __dadd_rn(s, div_rn(__dmul_rn((double)c[u], max_norm), norm[j + u], rcp[j + u]));
     }
+    for (; j < m; ++j)
+      s = __dadd_rn(s, div_rn(__dmul_rn((double)storage[(uint64_t)sel[j] * ld + r], max_norm), norm[j], rcp[j]));
     acc_norm += s;
     out[r] = int32_of_float(s);
   }
@@ -203,11 +293,135 @@ __global__ __launch_bounds__(256) void combine_mean_kernel(const int32_t *__rest
   if (threadIdx.x == 0) norm_partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-// RescaledMedian (lib/KMerDB.ml:705-706): a tile of R k-mers x m spectra is staged in LDS (lanes along k-mers, so
-// the loads are full lines), every k-mer's row is sorted by a bitonic network run by the whole block, and the upper
-// median sorted[m/2] is multiplied by the number of selected spectra.  Row stride P+1 keeps the staging writes off
-// one bank.
-__global__ __launch_bounds__(256) void combine_median_kernel(const int32_t *__restrict__ storage, uint64_t ld, uint64_t n_rows,
+// RescaledMedian (lib/KMerDB.ml:705-706), up to 64 spectra: one thread per k-mer, the whole row in registers.  Loads
+// are coalesced along k-mers exactly as in the mean; the P rescaled values are sorted by a fully unrolled bitonic
+// network of v_min_f64 / v_max_f64 pairs (P/2 * log2(P) * (log2(P)+1) / 2 compare-exchanges, no LDS, no shuffles) and
+// the upper median sorted[m/2] is picked with a select chain.  Unused slots hold +inf.
+template <int P>
+__global__ __launch_bounds__(256) void combine_median_thread_kernel(const int32_t *__restrict__ storage, uint64_t ld, uint64_t n_rows,
+                                                                    const uint32_t *__restrict__ sel, const double *__restrict__ norm,
+                                                                    const double *__restrict__ rcp, uint32_t m, uint32_t n_sel,
+                                                                    double max_norm, int32_t *__restrict__ out,
+                                                                    double *__restrict__ norm_partial) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint32_t me = m >> 1;
+  double acc_norm = 0.;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
+    int32_t c[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) c[j] = (uint32_t)j < m ? __builtin_nontemporal_load(storage + (uint64_t)sel[j] * ld + r) : 0;
+    double v[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) v[j] = (uint32_t)j < m ? div_rn(__dmul_rn((double)c[j], max_norm), norm[j], rcp[j]) : INFINITY;
+#pragma unroll
+    for (int k = 2; k <= P; k <<= 1) {
+#pragma unroll
+      for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+          const int l = i ^ j;
+          if (l > i) {
+            // v_min_f64 + v_max_f64; a compare with four 32-bit selects measured 1.5x slower
+            const double lo = fmin(v[i], v[l]), hi = fmax(v[i], v[l]);
+            const bool up = (i & k) == 0;
+            v[i] = up ? lo : hi;
+            v[l] = up ? hi : lo;
+          }
+        }
+      }
+    }
+    double med = m ? v[0] : 0.;
+#pragma unroll
+    for (int j = 1; j < P; ++j)
+      if (me == (uint32_t)j) med = v[j];
+    const double res = __dmul_rn(med, (double)n_sel);
+    acc_norm += res;
+    out[r] = int32_of_float(res);
+  }
+  __shared__ double sh[4];
+  acc_norm = wave_sum(acc_norm);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc_norm;
+  __syncthreads();
+  if (threadIdx.x == 0) norm_partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// the bit pattern of a double as an unsigned key with the same order (negative values only arise from counts that
+// wrapped around int32, but they must still sort)
+__device__ __forceinline__ uint64_t ordered_key(double x) {
+  const uint64_t b = (uint64_t)__double_as_longlong(x);
+  return b ^ ((uint64_t)((int64_t)b >> 63) | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ordered_value(uint64_t k) {
+  const uint64_t b = (k & 0x8000000000000000ull) ? (k ^ 0x8000000000000000ull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+
+// RescaledMedian, 65 .. 64*R spectra: one wavefront per k-mer.  A tile of TR k-mers x m
+// spectra of raw counts is staged in LDS with lanes along k-mers (full lines from HBM); each wave then takes a
+// k-mer, rescales its m counts into registers (R per lane; which lane holds which spectrum does not matter to a
+// sort), sorts the 64*R keys (ordered_key of the values; empty slots carry all-ones) with the in-register bitonic network
+// of wave_sort.h, and lane 0 stores sorted[m/2] * n_sel.
+template <int R>
+__global__ __launch_bounds__(256) void combine_median_wave_kernel(const int32_t *__restrict__ storage, uint64_t ld, uint64_t n_rows,
+                                                                  const uint32_t *__restrict__ sel, const double *__restrict__ norm,
+                                                                  const double *__restrict__ rcp, uint32_t m, uint32_t n_sel,
+                                                                  double max_norm, uint32_t TR, int32_t *__restrict__ out,
+                                                                  double *__restrict__ norm_partial) {
+  extern __shared__ int32_t tile32[];  // [m][TR + 1]
+  const uint32_t TRp = TR + 1, tr_shift = 31 - __clz(TR);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double b[R], y[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t col = (uint32_t)r * 64 + lane;
+    b[r] = col < m ? norm[col] : 1.;
+    y[r] = col < m ? rcp[col] : 1.;
+  }
+  const uint32_t me = m >> 1, med_lane = me / R, med_reg = me % R;
+  const uint64_t n_tiles = (n_rows + TR - 1) / TR;
+  double acc_norm = 0.;
+  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const uint64_t row0 = t * TR;
+    __syncthreads();
+#pragma unroll 4
+    for (uint32_t e = threadIdx.x; e < m * TR; e += 256) {
+      const uint32_t rr = e & (TR - 1), j = e >> tr_shift;
+      tile32[j * TRp + rr] = row0 + rr < n_rows ? __builtin_nontemporal_load(storage + (uint64_t)sel[j] * ld + row0 + rr) : 0;
+    }
+    __syncthreads();
+    for (uint32_t rr = wv; rr < TR && row0 + rr < n_rows; rr += 4) {
+      uint64_t key[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t col = (uint32_t)r * 64 + lane;
+        key[r] = ~0ull;
+        if (col < m) key[r] = ordered_key(div_rn(__dmul_rn((double)tile32[col * TRp + rr], max_norm), b[r], y[r]));
+      }
+      wave_bitonic_sort<R>(key, lane);
+      uint64_t pick = key[0];
+#pragma unroll
+      for (int r = 1; r < R; ++r)
+        if (med_reg == (uint32_t)r) pick = key[r];
+      const double med = m ? ordered_value((uint64_t)__shfl((unsigned long long)pick, (int)med_lane, 64)) : 0.;
+      const double res = __dmul_rn(med, (double)n_sel);
+      if (lane == 0) {
+        acc_norm += res;
+        out[row0 + rr] = int32_of_float(res);
+      }
+    }
+  }
+  __shared__ double sh[4];
+  acc_norm = wave_sum(acc_norm);
+  if (lane == 0) sh[wv] = acc_norm;
+  __syncthreads();
+  if (threadIdx.x == 0) norm_partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// RescaledMedian beyond 1024 spectra (up to 4096): a tile of R k-mers x m spectra is staged in LDS (lanes along
+// k-mers, so the loads are full lines), every k-mer's row is sorted by a bitonic network run by the whole block, and
+// the upper median sorted[m/2] is multiplied by the number of selected spectra.  Row stride P+1 keeps the staging
+// writes off one bank.
+__global__ __launch_bounds__(256) void combine_median_block_kernel(const int32_t *__restrict__ storage, uint64_t ld, uint64_t n_rows,
                                                              const uint32_t *__restrict__ sel, const double *__restrict__ norm,
                                                              uint32_t m, uint32_t n_sel, double max_norm, uint32_t P, uint32_t R,
                                                              int32_t *__restrict__ out, double *__restrict__ norm_partial) {
@@ -257,11 +471,18 @@ __global__ __launch_bounds__(256) void combine_median_kernel(const int32_t *__re
   if (threadIdx.x == 0) norm_partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-__global__ void sum_partials_kernel(const double *__restrict__ partial, uint32_t n, double *__restrict__ out) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    double s = 0.;
-    for (uint32_t i = 0; i < n; ++i) s += partial[i];
-    *out = s;
+// one block: strided per-thread sums, then a fixed tree (the same result on every run for a given n)
+__global__ __launch_bounds__(1024) void sum_partials_kernel(const double *__restrict__ partial, uint32_t n, double *__restrict__ out) {
+  double s = 0.;
+  for (uint32_t i = threadIdx.x; i < n; i += 1024) s += partial[i];
+  __shared__ double sh[16];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.;
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    *out = t;
   }
 }
 
@@ -303,8 +524,19 @@ __global__ __launch_bounds__(256) void transform_kernel(const int32_t *__restric
                                                         const double *__restrict__ col_stats, double *__restrict__ out) {
   const uint32_t c = blockIdx.y;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride)
-    out[(uint64_t)c * n_rows + r] = transform_one(which, threshold, power, col_stats + 4 * (uint64_t)c, storage[(uint64_t)c * ld + r]);
+  const int32_t *v = storage + (uint64_t)c * ld;
+  double *o = out + (uint64_t)c * n_rows;
+  const double cs[4] = {col_stats[4 * (uint64_t)c], col_stats[4 * (uint64_t)c + 1], col_stats[4 * (uint64_t)c + 2],
+                        col_stats[4 * (uint64_t)c + 3]};
+  uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; r + 7 * stride < n_rows; r += 8 * stride) {
+    int32_t x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = __builtin_nontemporal_load(v + r + u * stride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) __builtin_nontemporal_store(transform_one(which, threshold, power, cs, x[u]), o + r + u * stride);
+  }
+  for (; r < n_rows; r += stride) o[r] = transform_one(which, threshold, power, cs, v[r]);
 }
 
 // k-mer-major output: out[r][c] (the default table of -t).  64 x 64 tiles through LDS so that both the reads
@@ -329,7 +561,7 @@ __global__ __launch_bounds__(256) void transform_table_kernel(const int32_t *__r
 #pragma unroll 4
     for (int q = 0; q < 16; ++q) {
       const uint32_t c = threadIdx.x & 63, r = (threadIdx.x >> 6) + 4 * q;
-      if (row0 + r < n_rows && col0 + c < n_cols) out[(row0 + r) * n_cols + col0 + c] = tile[c][r];
+      if (row0 + r < n_rows && col0 + c < n_cols) __builtin_nontemporal_store(tile[c][r], out + (row0 + r) * n_cols + col0 + c);
     }
   }
 }
@@ -390,7 +622,7 @@ extern "C" int kpop_dev_counter_stats(const int32_t *d_storage, uint64_t ld, uin
     KPOP_LAUNCH_CHECK();
     col_stats_kernel<<<dim3(slabs, n_cols), dim3(kStatBlock), 0, st>>>(d_storage, ld, n_rows, power, p1, thr, slabs, partial);
     KPOP_LAUNCH_CHECK();
-    col_stats_final_kernel<<<dim3(div_up(n_cols, 256)), dim3(256), 0, st>>>(partial, slabs, n_cols, d_col_stats);
+    col_stats_final_kernel<<<dim3(div_up(n_cols, 256)), dim3(256), 0, st>>>(partial, slabs, n_cols, power, d_col_stats);
     KPOP_LAUNCH_CHECK();
   }
   if (d_row_stats && n_rows) {
@@ -411,10 +643,37 @@ extern "C" int kpop_dev_counter_combine(const int32_t *d_storage, uint64_t ld, u
   if (!d_workspace || !d_out) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_counter_combine: null argument");
   hipStream_t st = as_stream(stream);
   double *partial = reinterpret_cast<double *>(d_workspace);
+  double *rcp = partial + (1u << 16);
+  if (n_valid) {
+    reciprocal_kernel<<<dim3(div_up(n_valid, 256)), dim3(256), 0, st>>>(d_norm, n_valid, rcp);
+    KPOP_LAUNCH_CHECK();
+  }
   uint32_t grid;
   if (criterion == KPOP_COMBINE_MEAN) {
     grid = std::min<uint32_t>(div_up(n_rows, 256), 1u << 16);
-    combine_mean_kernel<<<dim3(grid), dim3(256), 0, st>>>(d_storage, ld, n_rows, d_sel, d_norm, n_valid, max_norm, d_out, partial);
+    combine_mean_kernel<<<dim3(grid), dim3(256), 0, st>>>(d_storage, ld, n_rows, d_sel, d_norm, rcp, n_valid, max_norm, d_out, partial);
+  } else if (n_valid <= 64) {
+    grid = std::min<uint32_t>(div_up(n_rows, 256), 1u << 16);
+#define KPOP_MEDIAN_THREAD(PP)                                                                                             \
+  combine_median_thread_kernel<PP><<<dim3(grid), dim3(256), 0, st>>>(d_storage, ld, n_rows, d_sel, d_norm, rcp, n_valid, n_sel, \
+                                                                      max_norm, d_out, partial)
+    if (n_valid <= 8) KPOP_MEDIAN_THREAD(8);
+    else if (n_valid <= 16) KPOP_MEDIAN_THREAD(16);
+    else if (n_valid <= 32) KPOP_MEDIAN_THREAD(32);
+    else KPOP_MEDIAN_THREAD(64);
+#undef KPOP_MEDIAN_THREAD
+  } else if (n_valid <= 1024) {
+    const uint32_t TR = n_valid <= 128 ? 64 : n_valid <= 256 ? 32 : n_valid <= 512 ? 16 : 8;
+    const size_t lds = (size_t)std::max<uint32_t>(1, n_valid) * (TR + 1) * 4;
+    grid = (uint32_t)std::min<uint64_t>((n_rows + TR - 1) / TR, 1u << 16);
+#define KPOP_MEDIAN_WAVE(RR)                                                                                                     \
+  combine_median_wave_kernel<RR><<<dim3(grid), dim3(256), lds, st>>>(d_storage, ld, n_rows, d_sel, d_norm, rcp, n_valid, n_sel, \
+                                                                      max_norm, TR, d_out, partial)
+    if (n_valid <= 128) KPOP_MEDIAN_WAVE(2);
+    else if (n_valid <= 256) KPOP_MEDIAN_WAVE(4);
+    else if (n_valid <= 512) KPOP_MEDIAN_WAVE(8);
+    else KPOP_MEDIAN_WAVE(16);
+#undef KPOP_MEDIAN_WAVE
   } else {
     uint32_t P = 2;
     while (P < n_valid) P <<= 1;
@@ -422,14 +681,23 @@ extern "C" int kpop_dev_counter_combine(const int32_t *d_storage, uint64_t ld, u
     if (P + 1 > budget) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_counter_combine: median of more than 4096 spectra");
     const uint32_t R = std::max<uint32_t>(1, std::min<uint32_t>(64, budget / (P + 1)));
     grid = (uint32_t)std::min<uint64_t>((n_rows + R - 1) / R, 1u << 16);
-    combine_median_kernel<<<dim3(grid), dim3(256), (size_t)R * (P + 1) * 8, st>>>(d_storage, ld, n_rows, d_sel, d_norm, n_valid, n_sel,
+    combine_median_block_kernel<<<dim3(grid), dim3(256), (size_t)R * (P + 1) * 8, st>>>(d_storage, ld, n_rows, d_sel, d_norm, n_valid, n_sel,
                                                                                    max_norm, P, R, d_out, partial);
   }
   KPOP_LAUNCH_CHECK();
   if (d_out_norm) {
-    sum_partials_kernel<<<dim3(1), dim3(64), 0, st>>>(partial, grid, d_out_norm);
+    sum_partials_kernel<<<dim3(1), dim3(1024), 0, st>>>(partial, grid, d_out_norm);
     KPOP_LAUNCH_CHECK();
   }
+  return KPOP_OK;
+}
+
+// test hook: a[i] / b[i] by the reciprocal route of the combination kernels and by the hardware division
+extern "C" int kpop_dev_division_probe(const double *d_a, const double *d_b, uint64_t n, double *d_fast, double *d_exact, void *stream) {
+  KPOP_TRY(require_init());
+  if (n == 0) return KPOP_OK;
+  division_probe_kernel<<<dim3(capped_grid(div_up(n, 256))), dim3(256), 0, as_stream(stream)>>>(d_a, d_b, n, d_fast, d_exact);
+  KPOP_LAUNCH_CHECK();
   return KPOP_OK;
 }
 
@@ -446,7 +714,7 @@ extern "C" int kpop_dev_counter_transform(const int32_t *d_storage, uint64_t ld,
         d_storage, ld, n_cols, n_rows, which, threshold, power, d_col_stats, d_out);
   } else {
     if (n_cols > 65535) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_counter_transform: more than 65535 spectra in one call");
-    transform_kernel<<<dim3((uint32_t)std::min<uint64_t>(div_up(n_rows, 256), 1u << 16), n_cols), dim3(256), 0, st>>>(
+    transform_kernel<<<dim3((uint32_t)std::min<uint64_t>(div_up(n_rows, 256 * 8), 1u << 16), n_cols), dim3(256), 0, st>>>(
         d_storage, ld, n_cols, n_rows, which, threshold, power, d_col_stats, d_out);
   }
   KPOP_LAUNCH_CHECK();
@@ -507,7 +775,7 @@ extern "C" int kpop_counter_combine(const int32_t *const *columns, uint64_t n_ro
   KPOP_TRY(upload_columns(cols.data(), m, n_rows, ds, &ld, st));
   KPOP_TRY(dsel.alloc((uint64_t)m * 4));
   KPOP_TRY(dnorm.alloc((uint64_t)m * 8));
-  KPOP_TRY(dw.alloc(kpop_dev_counter_workspace_bytes(1, n_rows)));
+  KPOP_TRY(dw.alloc(kpop_dev_counter_workspace_bytes(m, n_rows)));
   KPOP_TRY(dout.alloc(n_rows * 4));
   KPOP_TRY(dn.alloc(8));
   if (m) {

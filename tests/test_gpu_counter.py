@@ -125,3 +125,36 @@ def test_counter_errors(kpop):
         kpop.counter_stats(cols, -1.0, 1.0)
     cs, rs = kpop.counter_stats([], 1.0, 1.0)
     assert cs.shape == (0, 4) and rs.shape == (0, 4)
+
+
+def test_division_by_reciprocal_is_exact(kpop):
+    """div_rn (reciprocal + two FMA corrections) against the hardware IEEE division, bit for bit: the operands the
+    combination produces (count * max_norm over an integer norm) and adversarial ones (divisors next to powers of two,
+    all-ones mantissas, random mantissas over a wide exponent range)."""
+    import ctypes as C
+
+    import torch
+    from kpop_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(7)
+    n = 1 << 22
+    sets = []
+    counts = rng.integers(0, 5000, n).astype(np.float64)
+    max_norm = float(rng.integers(10**6, 10**12))
+    sets.append((counts * max_norm, rng.integers(1, 10**12, n).astype(np.float64)))
+    sets.append((rng.integers(1, 2**31, n).astype(np.float64) * float(2**40 + 12345), rng.integers(1, 2**53, n, dtype=np.int64).astype(np.float64)))
+    pw = 2.0 ** rng.integers(1, 52, n)
+    sets.append((rng.integers(1, 2**53, n, dtype=np.int64).astype(np.float64), np.maximum(pw + rng.integers(-2, 3, n), 1.0)))
+    ones = np.ldexp(2.0 - 2.0**-52, rng.integers(-20, 60, n))            # all-ones mantissa: the hardware route
+    sets.append((rng.integers(1, 2**53, n, dtype=np.int64).astype(np.float64), ones))
+    mant = rng.integers(2**52, 2**53, (2, n), dtype=np.int64).astype(np.float64)
+    sets.append((np.ldexp(mant[0], rng.integers(-200, 200, n)), np.ldexp(mant[1], rng.integers(-200, 200, n))))
+    dev = torch.device("cuda", 0)
+    for a, b in sets:
+        da, db = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+        fast, exact = torch.empty_like(da), torch.empty_like(da)
+        assert L.kpop_dev_division_probe(da.data_ptr(), db.data_ptr(), n, fast.data_ptr(), exact.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        f, e = fast.cpu().numpy(), exact.cpu().numpy()
+        assert np.array_equal(e, a / b)          # the hardware division is IEEE
+        assert np.array_equal(f, e), int(np.count_nonzero(f != e))
