@@ -157,6 +157,12 @@ int kpop_distance_summary(const double *m1, uint32_t r1, const double *m2, uint3
                           uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
                           double *out_dist, double *out_z);
 
+/* Replaces Base.get_embeddings, lib/Matrix.ml:78-128 (KPopTwistDB -e): every row times metric ** (1/2, or 1/p for
+ * Minkowski), then -- if normalize -- divided by its own norm under the same distance and metric (left as is when
+ * that norm is 0).  out is rows x n_dims.                                                                         */
+int kpop_embeddings(const double *m, uint32_t rows, uint32_t n_dims, const double *metric, int kind, double p,
+                    int normalize, double *out);
+
 /* Replaces Matrix.summarize_distance, lib/Matrix.ml:767-810 (KPopTwistDB -S): the same per-row summary
  * over a distance matrix that already exists (r2 rows x r1 columns, row-major).                      */
 int kpop_summarize_distances(const double *dist, uint32_t r2, uint32_t r1, uint32_t keep_at_most,

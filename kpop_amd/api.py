@@ -288,6 +288,16 @@ def distance_summary(m1, m2, metric, kind=EUCLIDEAN, p=2.0, normalize=True, keep
     return stats, n, idx, dist, z
 
 
+def embeddings(m, metric, kind=EUCLIDEAN, p=2.0, normalize=True):
+    """Base.get_embeddings (lib/Matrix.ml:78-128): principal coordinates from twisted rows."""
+    m = _c(m, np.float64)
+    metric = _c(metric, np.float64)
+    out = np.zeros_like(m)
+    check(_lib.load().kpop_embeddings(_p(_nz(m, np.float64), C.c_double), m.shape[0], m.shape[1], _p(metric, C.c_double), int(kind),
+                                      float(p), 1 if normalize else 0, _p(_nz(out, np.float64), C.c_double)))
+    return out
+
+
 def summarize_distances(dist, keep_at_most=2, max_neighbours=None):
     """Matrix.summarize_distance (lib/Matrix.ml:767-810) on an existing r2 x r1 distance matrix."""
     dist = _c(dist, np.float64)

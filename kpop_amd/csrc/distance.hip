@@ -15,6 +15,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "common.h"
 
@@ -454,6 +455,26 @@ static int summary_impl(const double *m1, uint32_t r1, const double *m2, uint32_
                                      out_idx, out_dist, out_z, st);
 }
 
+// out[i][c] = m[i][c] * w[c]  (Base.get_embeddings, lib/Matrix.ml:104)
+__global__ __launch_bounds__(256) void scale_columns_kernel(const double *__restrict__ m, uint64_t total, uint32_t n_dims,
+                                                            const double *__restrict__ w, double *__restrict__ out) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) out[e] = __dmul_rn(m[e], w[e % n_dims]);
+}
+
+template <int KIND>
+static int embeddings_impl(const double *d_m, uint32_t rows, uint32_t n_dims, const double *d_metric, const double *d_w, double p,
+                           int normalize, double *d_scaled, double *d_norms, double *d_out, hipStream_t st) {
+  const uint64_t total = (uint64_t)rows * n_dims;
+  scale_columns_kernel<<<dim3(capped_grid(div_up(total, 256))), dim3(256), 0, st>>>(d_m, total, n_dims, d_w, normalize ? d_scaled : d_out);
+  KPOP_LAUNCH_CHECK();
+  if (normalize) {  // v / norm(v) with the 0 -> 1 rule standing in for `if norm <> 0.` (lib/Matrix.ml:105-109)
+    row_norms_kernel<KIND><<<dim3(div_up(rows, kNormRows)), dim3(256), 0, st>>>(d_scaled, rows, n_dims, d_metric, p, d_norms, d_out);
+    KPOP_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 static int check_kind(int kind, double p, const char *who) {
   if (kind != KPOP_EUCLIDEAN && kind != KPOP_COSINE && kind != KPOP_MINKOWSKI)
     KPOP_FAIL(KPOP_ERR_INVALID, "%s: unknown distance kind %d", who, kind);
@@ -464,6 +485,45 @@ static int check_kind(int kind, double p, const char *who) {
 }  // namespace kpop
 
 using namespace kpop;
+
+// Base.get_embeddings, lib/Matrix.ml:78-128: rows scaled by metric ** (1/2 | 1/p), then divided by their norm
+extern "C" int kpop_embeddings(const double *m, uint32_t rows, uint32_t n_dims, const double *metric, int kind, double p,
+                               int normalize, double *out) {
+  KPOP_TRY(require_init());
+  ArenaScope scratch;
+  KPOP_TRY(check_kind(kind, p, "kpop_embeddings"));
+  if (rows == 0 || n_dims == 0) return KPOP_OK;
+  if (!m || !metric || !out) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_embeddings: null argument");
+  const double inv_power = kind == KPOP_MINKOWSKI ? 1. / p : 0.5;  // :84-87
+  std::vector<double> w(n_dims);
+  for (uint32_t c = 0; c < n_dims; ++c) w[c] = pow(metric[c], inv_power);  // host pow: the libm the reference's ** calls
+  hipStream_t st = nullptr;
+  const uint64_t bytes = (uint64_t)rows * n_dims * 8;
+  DevBuf dm, dmet, dw, ds, dn, dout;
+  KPOP_TRY(dm.alloc(bytes));
+  KPOP_TRY(dmet.alloc((uint64_t)n_dims * 8));
+  KPOP_TRY(dw.alloc((uint64_t)n_dims * 8));
+  KPOP_TRY(ds.alloc(normalize ? bytes : 8));
+  KPOP_TRY(dn.alloc((uint64_t)rows * 8));
+  KPOP_TRY(dout.alloc(bytes));
+  KPOP_HIP(hipMemcpyAsync(dm.p, m, bytes, hipMemcpyHostToDevice, st));
+  KPOP_HIP(hipMemcpyAsync(dmet.p, metric, (uint64_t)n_dims * 8, hipMemcpyHostToDevice, st));
+  KPOP_HIP(hipMemcpyAsync(dw.p, w.data(), (uint64_t)n_dims * 8, hipMemcpyHostToDevice, st));
+  int rc;
+  if (kind == KPOP_EUCLIDEAN)
+    rc = embeddings_impl<KPOP_EUCLIDEAN>(dm.as<double>(), rows, n_dims, dmet.as<double>(), dw.as<double>(), p, normalize, ds.as<double>(),
+                                         dn.as<double>(), dout.as<double>(), st);
+  else if (kind == KPOP_COSINE)
+    rc = embeddings_impl<KPOP_COSINE>(dm.as<double>(), rows, n_dims, dmet.as<double>(), dw.as<double>(), p, normalize, ds.as<double>(),
+                                      dn.as<double>(), dout.as<double>(), st);
+  else
+    rc = embeddings_impl<KPOP_MINKOWSKI>(dm.as<double>(), rows, n_dims, dmet.as<double>(), dw.as<double>(), p, normalize, ds.as<double>(),
+                                         dn.as<double>(), dout.as<double>(), st);
+  KPOP_TRY(rc);
+  KPOP_HIP(hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, st));
+  KPOP_HIP(hipStreamSynchronize(st));
+  return KPOP_OK;
+}
 
 extern "C" uint64_t kpop_dev_distance_workspace_bytes(uint32_t r1, uint32_t r2, uint32_t n_dims) {
   return ((uint64_t)r1 + r2 + ((uint64_t)r1 + r2) * n_dims) * sizeof(double) + 64;

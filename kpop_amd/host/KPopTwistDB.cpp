@@ -11,7 +11,8 @@
 //
 // Binary registers (-i/-a/-o, and the twisted operand of -d/-s) are OCaml Marshal streams, read and written
 // by ocaml_marshal.cpp; if '<prefix>.KPopTwisted' does not exist, -d/-s fall back to '<prefix>.KPopTwisted.txt'.
-// Not covered (outside the hot path): embeddings (-e) and splits (-p).
+//   -e  Matrix.get_embeddings            lib/Matrix.ml:78-128    -> kpop_embeddings  (register 'e', '.KPopVectors')
+// Not covered: splits (-p, register 's'): they are built on BiOCamLib's Trees.Splits, which is not in the checkout.
 // Runtime failures exit 1 (the reference prints the exception and exits 0).
 #include <stdio.h>
 #include <stdlib.h>
@@ -48,7 +49,7 @@ struct Action {
   enum Kind {
     Empty, TablesToRegister, AddTablesToRegister, BinaryToRegister, AddBinaryToRegister, RegisterToBinary, SetKmersNormalize, AddKmersFiles, RegisterToTables,
     SetPrecision, SetDistance, SetDistanceNormalize, SetMetric, DistancesFromTwisted, SetSummaryKeepAtMost,
-    SummaryFromTwisted, SummaryFromDistances, Unsupported
+    SummaryFromTwisted, SummaryFromDistances, EmbeddingsFromTwisted, Unsupported
   } kind;
   Reg reg = Reg::Twisted;
   std::string s1, s2;
@@ -132,7 +133,8 @@ void usage(FILE *f) {
           " -i|--input T|t|d <binary_prefix>         load .KPopTwister | .KPopTwisted | .KPopDMatrix (OCaml Marshal)\n"
           " -a|--add t|d <binary_prefix>             add the rows of a binary register\n"
           " -o|--output T|t|d <binary_prefix>        write the register in binary form\n"
-          "Embeddings (-e) and splits (-p) are not provided by this tool.\n",
+          " -e|--embeddings|--compute-embeddings|--twisted-to-embeddings   twisted register -> embeddings register ('e')\n"
+          "Splits (-p, register 's') are not provided by this tool.\n",
           kVersion);
 }
 
@@ -360,8 +362,9 @@ int main(int argc, char **argv) {
       } else if (a == "-S" || a == "--summarize-distances" || a == "--summarize-twisted-distances") {
         act.kind = Action::SummaryFromDistances;
         act.s1 = need(i, a);
-      } else if (a == "-e" || a == "--embeddings" || a == "--compute-embeddings" || a == "--twisted-to-embeddings" || a == "-p" ||
-                 a == "--splits" || a == "--compute-splits" || a == "--embeddings-to-splits") {
+      } else if (a == "-e" || a == "--embeddings" || a == "--compute-embeddings" || a == "--twisted-to-embeddings") {
+        act.kind = Action::EmbeddingsFromTwisted;
+      } else if (a == "-p" || a == "--splits" || a == "--compute-splits" || a == "--embeddings-to-splits") {
         act.kind = Action::Unsupported;
         act.s1 = a;
       } else if (a == "--splits-algorithm" || a == "--splits-at-most" || a == "--splits-keep-at-most" || a == "--precision-for-splits") {
@@ -403,13 +406,13 @@ int main(int argc, char **argv) {
       if ((a.kind == Action::TablesToRegister || a.kind == Action::BinaryToRegister) && a.reg == Reg::Twister) twister_loaded = true;
       if (a.kind == Action::AddKmersFiles && !twister_loaded) parse_error("Option '-k' requires a twister in the twister register!");
       if (((a.kind == Action::RegisterToTables && a.reg == Reg::Metrics) || a.kind == Action::DistancesFromTwisted ||
-           a.kind == Action::SummaryFromTwisted) && !twister_loaded)
+           a.kind == Action::SummaryFromTwisted || a.kind == Action::EmbeddingsFromTwisted) && !twister_loaded)
         parse_error("Options '-O m', '-e', '-d', and '-s' require a twister in the twister register to provide a metric!");
     }
   }
 
   TwisterReg T;
-  Table twisted, distances;
+  Table twisted, embeddings, distances;
   Metric metric;
   Distance distance;
   bool kmers_normalize = true, distance_normalize = true;  // bin/KPopTwistDB.ml:87-98
@@ -421,6 +424,7 @@ int main(int argc, char **argv) {
         case Action::Empty:
           if (a.reg == Reg::Twister) T.reset();
           else if (a.reg == Reg::Twisted) twisted = Table();
+          else if (a.reg == Reg::Embeddings) embeddings = Table();
           else if (a.reg == Reg::Distances) distances = Table();
           break;
         case Action::BinaryToRegister:  // bin/KPopTwistDB.ml:449-456
@@ -429,21 +433,34 @@ int main(int argc, char **argv) {
             read_binary_twister(make_filename(a.s1, "KPopTwister", false), &T.twister, &T.inertia);
           } else if (a.reg == Reg::Twisted) twisted = read_binary_matrix(make_filename(a.s1, "KPopTwisted", false), "KPopTwisted");
           else if (a.reg == Reg::Distances) distances = read_binary_matrix(make_filename(a.s1, "KPopDMatrix", false), "KPopDMatrix");
-          else throw Error("embeddings are outside the HIP hot path");
+          else if (a.reg == Reg::Embeddings) embeddings = read_binary_matrix(make_filename(a.s1, "KPopVectors", false), "KPopVectors");
+          else throw Error("nothing can be loaded into the metrics or splits registers");
           break;
         case Action::AddBinaryToRegister:  // :462-467
           if (a.reg == Reg::Twisted) merge_rowwise(twisted, read_binary_matrix(make_filename(a.s1, "KPopTwisted", false), "KPopTwisted"));
           else if (a.reg == Reg::Distances) merge_rowwise(distances, read_binary_matrix(make_filename(a.s1, "KPopDMatrix", false), "KPopDMatrix"));
-          else throw Error("embeddings are outside the HIP hot path");
+          else if (a.reg == Reg::Embeddings) merge_rowwise(embeddings, read_binary_matrix(make_filename(a.s1, "KPopVectors", false), "KPopVectors"));
+          else throw Error("nothing can be added to the twister, metrics or splits registers");
           break;
         case Action::RegisterToBinary:  // :509-518
           if (a.reg == Reg::Twister) write_binary_twister(make_filename(a.s1, "KPopTwister", false), T.twister, T.inertia);
           else if (a.reg == Reg::Twisted) write_binary_matrix(make_filename(a.s1, "KPopTwisted", false), "KPopTwisted", twisted);
           else if (a.reg == Reg::Distances) write_binary_matrix(make_filename(a.s1, "KPopDMatrix", false), "KPopDMatrix", distances);
-          else throw Error("embeddings/splits are outside the HIP hot path");
+          else if (a.reg == Reg::Embeddings) write_binary_matrix(make_filename(a.s1, "KPopVectors", false), "KPopVectors", embeddings);
+          else throw Error("splits are not provided by this tool");
           break;
         case Action::Unsupported:
-          throw Error("action '" + a.s1 + "' (embeddings/splits) is outside the HIP hot path");
+          throw Error("action '" + a.s1 + "' (splits) is not provided by this tool");
+        case Action::EmbeddingsFromTwisted: {  // bin/KPopTwistDB.ml:494-498
+          need_gpu();
+          std::vector<double> mv = metric_vector(metric, T);
+          if (mv.size() != twisted.cols()) throw Error("Incompatible_geometries");  // lib/Matrix.ml:81-82
+          embeddings = twisted;
+          if (!twisted.data.empty())
+            check(kpop_embeddings(twisted.data.data(), (uint32_t)twisted.rows(), (uint32_t)twisted.cols(), mv.data(), distance.kind,
+                                  distance.p, distance_normalize ? 1 : 0, embeddings.data.data()));
+          break;
+        }
         case Action::TablesToRegister:
           if (a.reg == Reg::Twister) load_twister_tables(T, a.s1);
           else if (a.reg == Reg::Twisted) twisted = read_table(make_filename(a.s1, "KPopTwisted", true));
@@ -453,7 +470,8 @@ int main(int argc, char **argv) {
         case Action::AddTablesToRegister:
           if (a.reg == Reg::Twisted) merge_rowwise(twisted, read_table(make_filename(a.s1, "KPopTwisted", true)));
           else if (a.reg == Reg::Distances) merge_rowwise(distances, read_table(make_filename(a.s1, "KPopDMatrix", true)));
-          else throw Error("embeddings are outside the HIP hot path");
+          else if (a.reg == Reg::Embeddings) merge_rowwise(embeddings, read_table(make_filename(a.s1, "KPopVectors", true)));
+          else throw Error("nothing can be added to the twister, metrics or splits registers");
           break;
         case Action::SetKmersNormalize: kmers_normalize = a.flag; break;
         case Action::AddKmersFiles: add_twisted_from_files(T, twisted, a.files, kmers_normalize, verbose); break;
@@ -476,8 +494,10 @@ int main(int argc, char **argv) {
             m.col_names = T.inertia.col_names;
             m.data = metric_vector(metric, T);
             write_table(make_filename(a.s1, "KPopMetrics", true), m, precision);
+          } else if (a.reg == Reg::Embeddings) {
+            write_table(make_filename(a.s1, "KPopVectors", true), embeddings, precision);
           } else {
-            throw Error("embeddings/splits are outside the HIP hot path");
+            throw Error("splits are not provided by this tool");
           }
           break;
         case Action::DistancesFromTwisted: {  // bin/KPopTwistDB.ml:542-546

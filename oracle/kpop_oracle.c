@@ -688,3 +688,21 @@ double kpo_counter_combine(const int32_t *const *columns, uint64_t n_rows, const
   free(vals);
   return norm;
 }
+
+/* ------------------------------------------------------------------ embeddings (lib/Matrix.ml:78-128) */
+void kpo_embeddings(const double *m, uint32_t rows, uint32_t n_dims, const double *metric, int kind, double p,
+                    int normalize, double *out) {
+  const double inv_power = kind == KPO_MINKOWSKI ? 1. / p : 0.5; /* :84-87 */
+  double *w = (double *)malloc(sizeof(double) * (n_dims ? n_dims : 1));
+  for (uint32_t c = 0; c < n_dims; ++c) w[c] = pow(metric[c], inv_power); /* :88 */
+  for (uint32_t i = 0; i < rows; ++i) {
+    double *v = out + (uint64_t)i * n_dims;
+    for (uint32_t c = 0; c < n_dims; ++c) v[c] = m[(uint64_t)i * n_dims + c] * w[c]; /* :104 */
+    if (normalize) {
+      const double norm = kpo_norm(kind, p, metric, v, n_dims); /* :106 */
+      if (norm != 0.)
+        for (uint32_t c = 0; c < n_dims; ++c) v[c] = v[c] / norm;
+    }
+  }
+  free(w);
+}

@@ -95,6 +95,10 @@ double kpo_distance(int kind, double p, const double *metric, const double *a, d
 void kpo_distance_rowwise(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
                           const double *metric, int kind, double p, int normalize, double *out);
 
+/* ---- embeddings: Base.get_embeddings, lib/Matrix.ml:78-128; out is rows x n_dims ---- */
+void kpo_embeddings(const double *m, uint32_t rows, uint32_t n_dims, const double *metric, int kind, double p,
+                    int normalize, double *out);
+
 /* ---- summary: lib/Matrix.ml:632-690 ---- */
 /* row of n distances -> stats[4] = mean, sd, median, MAD; neighbours (ties extend).
    out_idx/out_dist/out_z need room for n entries. Returns eff_len. */

@@ -96,6 +96,8 @@ def _declare(L):
     L.kpo_counter_transform_one.argtypes = [C.c_int, C.c_double, C.c_double, f64p, C.c_int32]
     L.kpo_counter_combine.restype = C.c_double
     L.kpo_counter_combine.argtypes = [C.POINTER(C.c_void_p), C.c_uint64, u32p, C.c_uint32, f64p, C.c_int, C.c_void_p]
+    L.kpo_embeddings.restype = None
+    L.kpo_embeddings.argtypes = [f64p, C.c_uint32, C.c_uint32, f64p, C.c_int, C.c_double, C.c_int, f64p]
     L.kpo_pipeline.restype = C.c_double
     L.kpo_pipeline.argtypes = [u8p, u64p, C.c_uint32, C.c_int, C.c_int, f64p, C.c_uint64, C.c_uint32,
                                u64p, f64p, C.c_uint32, f64p, C.c_int, C.c_double, C.c_int, C.c_int,
@@ -211,6 +213,15 @@ def distance_rowwise(m1, m2, metric, kind=EUCLIDEAN, p=2., normalize=True):
     out = np.empty((r2, r1), dtype=np.float64)
     lib().kpo_distance_rowwise(_p(m1, C.c_double), r1, _p(m2, C.c_double), r2, d, _p(metric, C.c_double),
                                kind, p, 1 if normalize else 0, _p(out, C.c_double))
+    return out
+
+
+def embeddings(m, metric, kind=EUCLIDEAN, p=2., normalize=True):
+    m = _c(m, np.float64)
+    metric = _c(metric, np.float64)
+    out = np.zeros_like(m)
+    lib().kpo_embeddings(_p(m, C.c_double), m.shape[0], m.shape[1], _p(metric, C.c_double), kind, p, 1 if normalize else 0,
+                         _p(out, C.c_double))
     return out
 
 

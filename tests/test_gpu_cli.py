@@ -502,3 +502,38 @@ def test_countdb_tables_spectra_split_and_distances(tmp_path, oracle, pyref):
     assert lines[0].split("\t") == ['""', '"s0"', '"s2"', '"s4"'] and [l.split("\t")[0] for l in lines[1:]] == ['"s1"', '"s3"', '"s5"']
     got = np.array([[float(v) for v in l.split("\t")[1:]] for l in lines[1:]])
     np.testing.assert_allclose(got, want, rtol=1e-12)
+
+
+def test_embeddings_register(tmp_path, oracle):
+    """KPopTwistDB -e: twisted -> embeddings ('e' register, .KPopVectors[.txt]), metric from the twister's inertia."""
+    d, k = 6, 4
+    cols = oracle.enumerate_kmers(k)
+    T = oracle.synth_twister(5, d, cols)
+    inertia = oracle.synth_inertia(d)
+    dims = ["Dim%d" % (i + 1) for i in range(d)]
+    write_table(tmp_path / "X.KPopTwister.txt", [oracle.to_hex(h, k) for h in cols], dims, T)
+    write_table(tmp_path / "X.KPopInertia.txt", dims, ["inertia"], [inertia])
+    rng = np.random.RandomState(3)
+    tw = rng.standard_normal((7, d))
+    names = ["s%d" % i for i in range(7)]
+    write_table(tmp_path / "tw.KPopTwisted.txt", dims, names, tw)
+    tw = np.array([[float("%.15g" % v) for v in row] for row in tw])
+    inertia_rt = np.array([float("%.15g" % v) for v in inertia])
+    metric = oracle.metric_powers(inertia_rt)
+    for dist, kind, p in (("euclidean", 0, 2.0), ("cosine", 1, 2.0), ("minkowski(1.5)", 2, 1.5)):
+        r = run([TWISTDB, "-I", "T", str(tmp_path / "X"), "-I", "t", str(tmp_path / "tw"), "--distance", dist, "-e", "-O", "e", "/dev/stdout",
+                 "-o", "e", str(tmp_path / "emb")])
+        assert r.returncode == 0, r.stderr
+        want = oracle.embeddings(tw, metric, kind, p, True)
+        lines = r.stdout.splitlines()
+        assert lines[0] == '""\t' + "\t".join('"%s"' % x for x in dims) and [l.split("\t")[0] for l in lines[1:]] == ['"%s"' % n for n in names]
+        got = np.array([[float(v) for v in l.split("\t")[1:]] for l in lines[1:]])
+        np.testing.assert_allclose(got, want, rtol=1e-13)
+    # binary round trip through the embeddings register, and the type check of the archive
+    r = run([TWISTDB, "-i", "e", str(tmp_path / "emb"), "-O", "e", "/dev/stdout"])
+    assert r.returncode == 0 and r.stdout.splitlines()[1].startswith('"s0"\t')
+    (tmp_path / "emb.KPopTwisted").write_bytes((tmp_path / "emb.KPopVectors").read_bytes())
+    r = run([TWISTDB, "-i", "t", str(tmp_path / "emb")])
+    assert r.returncode == 1 and "Unexpected_type" in r.stderr
+    r = run([TWISTDB, "-I", "t", str(tmp_path / "tw"), "-e"])
+    assert r.returncode == 1 and "require a twister" in r.stderr

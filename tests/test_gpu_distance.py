@@ -194,3 +194,21 @@ def test_summarize_distances_large_row_with_ties(kpop, oracle):
         np.testing.assert_allclose(st[j], so, rtol=1e-10)
         assert n[j] == len(io) and idx[j, :n[j]].tolist() == io.tolist()
         assert np.array_equal(d[j, :n[j]], do)
+
+
+@pytest.mark.parametrize("kind,p", [(0, 2.0), (1, 2.0), (2, 1.5), (2, 3.0)])
+@pytest.mark.parametrize("rows,d", [(1, 1), (65, 9), (1000, 64), (300, 257)])
+def test_embeddings_vs_oracle(kpop, oracle, kind, p, rows, d):
+    """Base.get_embeddings (lib/Matrix.ml:78-128): euclidean/cosine bit-exact, minkowski through the device pow()."""
+    rng = np.random.RandomState(rows * 7 + d + kind)
+    m = rng.standard_normal((rows, d))
+    if rows > 2:
+        m[1] = 0.0                                     # zero norm: the row is left as it is
+    metric = oracle.metric_powers(oracle.synth_inertia(d))
+    for normalize in (True, False):
+        got = kpop.embeddings(m, metric, kind, p, normalize)
+        want = oracle.embeddings(m, metric, kind, p, normalize)
+        if kind == 2 and normalize:
+            np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
+        else:
+            assert np.array_equal(got, want)
