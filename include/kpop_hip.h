@@ -103,6 +103,12 @@ int kpop_twister_load(const double *T_dims_major, uint64_t n_cols, uint32_t n_di
    canonical (DNA-ds) / every (DNA-ss) k-mer ascending, coefficient(d,h) from
    SplitMix64 -- bench/test tooling, same function as the oracle's.           */
 int kpop_twister_synth(uint64_t seed, int k, int content, uint32_t n_dims, kpop_twister **out);
+/* One rank's slice of the same twister when its k-mer rows are sharded over GPUs (k = 15 / large D):
+   only the k-mers with hash in [hash_lo, hash_hi).  acc_dim = 1 appends a dimension of ones, so an un-normalised
+   twist also carries the shard's part of the normaliser `acc` (lib/Twister.ml:158): the ranks all-reduce
+   [n x (n_dims+1)] partials and divide by the last column (kpop_amd/shard.py).                                  */
+int kpop_twister_synth_slice(uint64_t seed, int k, int content, uint32_t n_dims, uint64_t hash_lo,
+                             uint64_t hash_hi, int acc_dim, kpop_twister **out);
 int kpop_twister_free(kpop_twister *tw);
 int kpop_twister_info(const kpop_twister *tw, uint64_t *n_cols, uint32_t *n_dims, int *k,
                       uint64_t *device_bytes);

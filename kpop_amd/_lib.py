@@ -33,6 +33,8 @@ SIGNATURES = {
                                    C.c_uint64]),
     "kpop_twister_load": (C.c_int, [f64p, C.c_uint64, C.c_uint32, u64p, C.c_int, C.POINTER(vp)]),
     "kpop_twister_synth": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.POINTER(vp)]),
+    "kpop_twister_synth_slice": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int,
+                                           C.POINTER(vp)]),
     "kpop_twister_free": (C.c_int, [vp]),
     "kpop_twister_info": (C.c_int, [vp, u64p, u32p, C.POINTER(C.c_int), u64p]),
     "kpop_twist": (C.c_int, [vp, u64p, f64p, u64p, C.c_uint32, C.c_int, f64p]),

@@ -109,10 +109,26 @@ class Twister:
         return cls(h)
 
     @classmethod
-    def synth(cls, seed, k, n_dims, content=DNA_DS):
+    def synth(cls, seed, k, n_dims, content=DNA_DS, hash_range=None, acc_dim=False):
+        """Synthetic twister generated on the device; hash_range=(lo, hi) keeps only that slice of k-mer rows and
+        acc_dim appends the all-ones dimension of a k-mer-row shard (kpop_amd/shard.py)."""
         h = C.c_void_p()
-        check(_lib.load().kpop_twister_synth(int(seed), int(k), int(content), int(n_dims), C.byref(h)))
+        if hash_range is None and not acc_dim:
+            check(_lib.load().kpop_twister_synth(int(seed), int(k), int(content), int(n_dims), C.byref(h)))
+        else:
+            lo, hi = hash_range if hash_range is not None else (0, 1 << (2 * int(k)))
+            check(_lib.load().kpop_twister_synth_slice(int(seed), int(k), int(content), int(n_dims), int(lo), int(hi),
+                                                       1 if acc_dim else 0, C.byref(h)))
         return cls(h)
+
+    @classmethod
+    def load_slice(cls, T_dims_major, col_hash, k, hash_range):
+        """The k-mer-row shard of a real twister: the columns with hash in [lo, hi), plus the all-ones dimension."""
+        T = _c(T_dims_major, np.float64)
+        col_hash = _c(col_hash, np.uint64)
+        keep = (col_hash >= np.uint64(hash_range[0])) & (col_hash < np.uint64(hash_range[1]))
+        Ts = np.vstack([T[:, keep], np.ones((1, int(keep.sum())))])
+        return cls.load(Ts, col_hash[keep], k)
 
     @property
     def handle(self):

@@ -45,14 +45,15 @@ __global__ void rank_bits_kernel(const uint64_t *__restrict__ hashes, uint64_t n
   }
 }
 
-// presence bits of every canonical (DNA-ds) / every (DNA-ss) k-mer: the synthetic twister
-__global__ void rank_bits_canonical_kernel(int k, int content, uint64_t n_words, uint64_t n_hashes, RankWord *rsel) {
+// presence bits of every canonical (DNA-ds) / every (DNA-ss) k-mer with hash in [hash_lo, hash_hi): the synthetic
+// twister, or one rank's slice of it
+__global__ void rank_bits_canonical_kernel(int k, int content, uint64_t n_words, uint64_t hash_lo, uint64_t hash_hi, RankWord *rsel) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
     uint64_t bits = 0;
     for (uint32_t b = 0; b < 64; ++b) {
       const uint64_t h = w * 64 + b;
-      if (h < n_hashes && (content == KPOP_DNA_SS || h <= revcomp(h, k))) bits |= 1ull << b;
+      if (h >= hash_lo && h < hash_hi && (content == KPOP_DNA_SS || h <= revcomp(h, k))) bits |= 1ull << b;
     }
     rsel[w].bits = bits;
   }
@@ -82,8 +83,10 @@ __device__ __forceinline__ double synth_coeff(uint64_t seed, uint32_t d, uint64_
   return (double)(z >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;
 }
 
+// n_synth dimensions come from synth_coeff; dimensions n_synth .. n_dims-1 (the optional accumulator dimension of a
+// k-mer-row shard) are 1 so that the twist of a spectrum carries sum(v_h over the shard's k-mers) along
 __global__ __launch_bounds__(256) void synth_rows_kernel(uint64_t seed, const RankWord *__restrict__ rsel,
-                                                         uint64_t n_hashes, uint32_t n_dims, uint32_t d_pad,
+                                                         uint64_t n_hashes, uint32_t n_synth, uint32_t n_dims, uint32_t d_pad,
                                                          double *__restrict__ rows) {
   // one wave per hash value; lanes sweep the dims so stores are coalesced.  Grid-stride: HIP caps
   // gridDim.x * blockDim.x at 2^32 and 4^15 hashes need more waves than that.
@@ -93,7 +96,8 @@ __global__ __launch_bounds__(256) void synth_rows_kernel(uint64_t seed, const Ra
     const uint32_t b = (uint32_t)h & 63u;
     if (!((w.bits >> b) & 1ull)) continue;
     const uint32_t row = w.prefix + (uint32_t)__popcll(w.bits & ((1ull << b) - 1ull));
-    for (uint32_t d = lane; d < d_pad; d += 64) rows[(uint64_t)row * d_pad + d] = (d < n_dims) ? synth_coeff(seed, d, h) : 0.0;
+    for (uint32_t d = lane; d < d_pad; d += 64)
+      rows[(uint64_t)row * d_pad + d] = (d < n_synth) ? synth_coeff(seed, d, h) : (d < n_dims ? 1.0 : 0.0);
   }
 }
 
@@ -234,6 +238,11 @@ extern "C" int kpop_twister_load(const double *T_dims_major, uint64_t n_cols, ui
 }
 
 extern "C" int kpop_twister_synth(uint64_t seed, int k, int content, uint32_t n_dims, kpop_twister **out) {
+  return kpop_twister_synth_slice(seed, k, content, n_dims, 0, ~0ull, 0, out);
+}
+
+extern "C" int kpop_twister_synth_slice(uint64_t seed, int k, int content, uint32_t n_dims, uint64_t hash_lo, uint64_t hash_hi,
+                                        int acc_dim, kpop_twister **out) {
   KPOP_TRY(require_init());
   if (!out) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_twister_synth: null out");
   if (k < 1 || k > kRankMaxK)
@@ -241,29 +250,32 @@ extern "C" int kpop_twister_synth(uint64_t seed, int k, int content, uint32_t n_
   if (content != KPOP_DNA_DS && content != KPOP_DNA_SS) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_twister_synth: content");
   if (n_dims == 0) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_twister_synth: n_dims must be positive");
   const uint64_t n_hashes = 1ull << (2 * k);
+  hash_hi = std::min(hash_hi, n_hashes);
+  hash_lo = std::min(hash_lo, hash_hi);
+  const bool whole = hash_lo == 0 && hash_hi == n_hashes;
   uint64_t n_cols = n_hashes;
   if (content == KPOP_DNA_DS) n_cols = (k % 2 == 0) ? (n_hashes + (1ull << k)) / 2 : n_hashes / 2;
-  if (n_cols >= 0xFFFFFFFFull) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_twister_synth: too many columns");
   kpop_twister *tw = new kpop_twister();
   TwGuard guard{tw};
   tw->k = k;
-  tw->n_dims = n_dims;
-  tw->n_cols = tw->n_rows = n_cols;
-  KPOP_TRY(alloc_rows(tw));
+  tw->n_dims = n_dims + (acc_dim ? 1u : 0u);
   hipStream_t st = nullptr;
   const uint64_t n_words = (n_hashes + 63) / 64;
   KPOP_HIP(hipMalloc(&tw->d_rsel, n_words * sizeof(RankWord)));
   tw->device_bytes += n_words * sizeof(RankWord);
   rank_bits_canonical_kernel<<<dim3(std::min<uint32_t>(div_up(n_words, 256), 1u << 16)), dim3(256), 0, st>>>(
-      k, content, n_words, n_hashes, reinterpret_cast<RankWord *>(tw->d_rsel));
+      k, content, n_words, hash_lo, hash_hi, reinterpret_cast<RankWord *>(tw->d_rsel));
   KPOP_LAUNCH_CHECK();
   uint64_t total = 0;
   KPOP_TRY(finish_rank_select(tw, n_words, &total, st));
-  if (total != n_cols)
+  if (whole && total != n_cols)
     KPOP_FAIL(KPOP_ERR_HIP, "kpop_twister_synth: enumerated %llu k-mers, expected %llu", (unsigned long long)total,
               (unsigned long long)n_cols);
+  if (total >= 0xFFFFFFFFull) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_twister_synth: too many columns");
+  tw->n_cols = tw->n_rows = total;
+  KPOP_TRY(alloc_rows(tw));
   synth_rows_kernel<<<dim3(capped_grid(div_up(n_hashes, 4))), dim3(256), 0, st>>>(
-      seed, reinterpret_cast<const RankWord *>(tw->d_rsel), n_hashes, n_dims, tw->d_pad, tw->d_rows);
+      seed, reinterpret_cast<const RankWord *>(tw->d_rsel), n_hashes, n_dims, tw->n_dims, tw->d_pad, tw->d_rows);
   KPOP_LAUNCH_CHECK();
   KPOP_HIP(hipStreamSynchronize(st));
   guard.tw = nullptr;

@@ -7,19 +7,23 @@ device memory, the stream and (for all-vs-all) the RCCL all-gather; every comput
 import numpy as np
 
 from . import api
-from .shard import all_gather_rows, shard_bounds
+from .shard import all_gather_rows, reduce_partial_twists, shard_bounds
 
 
 class DevicePipeline:
     def __init__(self, twister, metric, device, kind=api.EUCLIDEAN, p=2.0, normalize_counts=True,
-                 normalize_distance=True):
+                 normalize_distance=True, row_sharded=False):
+        """row_sharded: `twister` is this rank's k-mer-row slice with the all-ones accumulator dimension
+        (Twister.synth(..., hash_range=kmer_slice_bounds(k, rank, world), acc_dim=True) or Twister.load_slice)."""
         import torch
         self.torch = torch
         self.tw = twister
         self.dev = device
         self.kind, self.p = kind, p
         self.normalize_counts, self.normalize_distance = normalize_counts, normalize_distance
-        self.n_dims = twister.info()["n_dims"]
+        self.row_sharded = row_sharded
+        self.tw_dims = twister.info()["n_dims"]
+        self.n_dims = self.tw_dims - (1 if row_sharded else 0)
         self.metric = torch.as_tensor(np.ascontiguousarray(metric, dtype=np.float64)).to(device)
         self._work = None
 
@@ -29,11 +33,22 @@ class DevicePipeline:
     def count_twist(self, bases, offsets, max_len, out=None):
         """bases: uint8 tensor, offsets: int64 tensor [n+1] (both on the device) -> twisted [n, D] f64."""
         n = offsets.numel() - 1
+        if self.row_sharded:
+            raise ValueError("a k-mer-row shard twists through count_twist_row_sharded (every rank sees every read)")
         if out is None:
             out = self.torch.zeros(max(n, 1), self.n_dims, dtype=self.torch.float64, device=self.dev)[:n]
         api.dev_count_twist(self.tw, bases.data_ptr(), offsets.data_ptr(), n, bases.numel(), int(max_len), out.data_ptr(),
                             normalize=self.normalize_counts, stream=self._stream())
         return out
+
+    def count_twist_row_sharded(self, bases, offsets, max_len, group=None):
+        """The k = 15 / large-D layout: ALL reads against this rank's k-mer rows, un-normalised, then ONE
+        all-reduce of the [n, D+1] partial sums (RCCL over xGMI) and the division by the reduced `acc` column."""
+        n = offsets.numel() - 1
+        partial = self.torch.zeros(max(n, 1), self.tw_dims, dtype=self.torch.float64, device=self.dev)[:n]
+        api.dev_count_twist(self.tw, bases.data_ptr(), offsets.data_ptr(), n, bases.numel(), int(max_len), partial.data_ptr(),
+                            normalize=False, stream=self._stream())
+        return reduce_partial_twists(partial, normalize=self.normalize_counts, group=group)
 
     def _workspace(self, r1, r2):
         need = api.dev_distance_workspace_bytes(r1, r2, self.n_dims)

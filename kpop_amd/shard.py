@@ -9,7 +9,14 @@ with the twister, the class vectors and the metric replicated.
   * all-vs-all distances: ONE all-gather of the twisted vectors (RCCL over xGMI when the tensors are on
     GPUs, gloo on CPU), after which rank r computes its [hi_r-lo_r] x N block of rows.
 
-torch.distributed is plumbing here (rendezvous + the collective); nothing in this file computes.
+  * twisters beyond one GPU's HBM (k = 15 with D >= 64 is 275 GB): the k-mer ROWS of the twister are cut into
+    contiguous hash ranges, one per rank; every rank twists ALL reads against its slice without normalising,
+    carrying its part of the normaliser in an extra all-ones dimension, and ONE all-reduce (sum) of the
+    [n_reads x (D+1)] partials followed by a division gives the twisted rows on every rank.  This is the one place
+    on the path with a genuine exchange of partial results.
+
+torch.distributed is plumbing here (rendezvous + the collective); nothing in this file computes beyond the final
+division of the reduced sums.
 """
 import numpy as np
 
@@ -53,6 +60,28 @@ def all_gather_rows(local_rows, n_total, group=None):
         lo, hi = shard_bounds(n_total, r, world)
         out[lo:hi] = recv[r * pad:r * pad + (hi - lo)]
     return out
+
+
+def kmer_slice_bounds(k, rank, world):
+    """Hash range [lo, hi) of the k-mer rows rank `rank` keeps: equal cuts of the 4^k hash space (canonical k-mers are
+    denser at low hashes, so low ranks hold somewhat more rows; the cuts stay trivially computable by every rank)."""
+    return shard_bounds(1 << (2 * int(k)), rank, world)
+
+
+def reduce_partial_twists(partial, normalize=True, group=None):
+    """partial: [n, D+1] un-normalised twist of every read against this rank's k-mer rows, last column = the rank's
+    part of `acc` (lib/Twister.ml:158).  One all-reduce (sum), then t = sum / acc where acc <> 0 (:177-178).
+    Works on torch tensors (GPU: RCCL, CPU: gloo); returns [n, D] on every rank."""
+    import torch
+    import torch.distributed as dist
+    total = partial.clone()
+    if dist.is_available() and dist.is_initialized():  # also at world size 1: the same code path as N > 1
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    out = total[:, :-1]
+    if not normalize:
+        return out.contiguous()
+    acc = total[:, -1:]
+    return torch.where(acc != 0, out / torch.where(acc != 0, acc, torch.ones_like(acc)), out).contiguous()
 
 
 def merge_labelled_rows(labels, rows):

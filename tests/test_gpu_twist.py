@@ -214,3 +214,78 @@ def test_device_pipeline_all_vs_all_single_rank(kpop, oracle):
     assert np.array_equal(t.cpu().numpy(), want_t)
     assert (lo, hi) == (0, n)
     assert np.array_equal(block.cpu().numpy(), oracle.distance_rowwise(want_t, want_t, metric))
+
+
+@pytest.mark.parametrize("k,d,world", [(6, 5, 2), (8, 33, 3), (9, 64, 8)])
+def test_kmer_row_sharded_twister(kpop, oracle, k, d, world):
+    """The k = 15 / large-D layout of SURVEY.md 8e at a size the oracle can check: each 'rank' holds the k-mer rows of
+    one hash range plus the all-ones dimension, twists every read without normalising, and the summed partials
+    divided by the summed `acc` are the twisted rows.  Slices of the device-generated twister and of an uploaded one."""
+    import torch
+
+    from kpop_amd.shard import kmer_slice_bounds, reduce_partial_twists
+    n, L = 300, 150
+    bases, offs = oracle.synth_reads(0x4B506F70, n, L)
+    bases = bases.copy()
+    bases[offs[3]:offs[4]] = ord("N")
+    cols = oracle.enumerate_kmers(k)
+    T = oracle.synth_twister(11, d, cols)
+    h, c, o = oracle.count_reads(bases, offs, k)
+    want = oracle.twist(T, cols, h, c.astype(np.float64), o)
+    full = kpop.Twister.synth(11, k, d)
+    for make in ("synth", "load"):
+        total = np.zeros((n, d + 1))
+        rows = 0
+        for r in range(world):
+            rng_ = kmer_slice_bounds(k, r, world)
+            tw = kpop.Twister.synth(11, k, d, hash_range=rng_, acc_dim=True) if make == "synth" else kpop.Twister.load_slice(T, cols, k, rng_)
+            info = tw.info()
+            assert info["n_dims"] == d + 1
+            rows += info["n_cols"]
+            total += tw.count_twist(bases, offs, normalize=False)
+            tw.free()
+        assert rows == len(cols)
+        got = reduce_partial_twists(torch.from_numpy(total)).numpy()   # world size 1: no collective, the division only
+        assert np.all(got[3] == 0.0)
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-15)
+    # the accumulator column is the number of k-mers of the read that the slice knows: they add up to all windows
+    assert np.array_equal(total[:, -1], np.array([c[o[i]:o[i + 1]].sum() for i in range(n)], dtype=np.float64))
+    np.testing.assert_allclose(full.count_twist(bases, offs), want, rtol=1e-12, atol=1e-15)
+
+
+def test_row_sharded_pipeline_with_rccl_world_size_1(kpop, oracle):
+    """count_twist_row_sharded through torch.distributed's nccl (= RCCL) backend on one rank: the collective path is the
+    one N > 1 ranks take; the result must be the plain twist."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+    from kpop_amd.pipeline import DevicePipeline
+    from kpop_amd.shard import kmer_slice_bounds
+    k, d, n, L = 8, 16, 200, 150
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        bases, offs = oracle.synth_reads(21, n, L)
+        tw = kpop.Twister.synth(9, k, d, hash_range=kmer_slice_bounds(k, 0, 1), acc_dim=True)
+        pipe = DevicePipeline(tw, kpop.metric_compute(oracle.synth_inertia(d)), dev, row_sharded=True)
+        t = pipe.count_twist_row_sharded(torch.from_numpy(bases).to(dev), torch.from_numpy(offs.astype(np.int64)).to(dev), L)
+        dist.barrier()
+        torch.cuda.synchronize()
+        cols = oracle.enumerate_kmers(k)
+        h, c, o = oracle.count_reads(bases, offs, k)
+        want = oracle.twist(oracle.synth_twister(9, d, cols), cols, h, c.astype(np.float64), o)
+        assert t.shape == (n, d)
+        np.testing.assert_allclose(t.cpu().numpy(), want, rtol=1e-12, atol=1e-15)
+        with pytest.raises(ValueError):
+            pipe.count_twist(torch.from_numpy(bases).to(dev), torch.from_numpy(offs.astype(np.int64)).to(dev), L)
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -89,3 +89,52 @@ def test_world_size_2_all_gather_and_distance_blocks(oracle, n):
         assert np.array_equal(block, dm[lo:hi])      # and owns its contiguous block of distance rows
         rows.append(block)
     assert np.array_equal(np.concatenate(rows), dm)  # shards concatenate to the single-GPU result
+
+
+def _row_shard_worker(rank, world, port, n, ret):
+    import torch
+    import torch.distributed as dist
+
+    from kpop_amd.shard import kmer_slice_bounds, reduce_partial_twists
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        k, d, L = 6, 5, 80
+        bases, offs = O.synth_reads(0x4B506F70, n, L)
+        bases = bases.copy()
+        bases[offs[1]:offs[2]] = ord("N")            # a read with no k-mer at all: acc = 0 on every rank
+        cols = O.enumerate_kmers(k)
+        T = O.synth_twister(3, d, cols)
+        lo, hi = kmer_slice_bounds(k, rank, world)
+        keep = (cols >= lo) & (cols < hi)
+        Ts = np.vstack([T[:, keep], np.ones((1, int(keep.sum())))])   # what Twister.load_slice uploads
+        h, c, o = O.count_reads(bases, offs, k)                         # every rank sees every read
+        partial = O.twist(Ts, cols[keep], h, c.astype(np.float64), o, normalize=False)  # stand-in for the rank's GPU
+        ret[rank] = (int(keep.sum()), reduce_partial_twists(torch.from_numpy(partial)).numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_kmer_row_sharded_twist(oracle):
+    """k-mer rows of the twister cut over 2 ranks, one all-reduce of the partial sums (k=15 case)."""
+    import torch.multiprocessing as mp
+    world, port, n = 2, _free_port(), 23
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_row_shard_worker, args=(world, port, n, ret), nprocs=world, join=True)
+    k, d, L = 6, 5, 80
+    bases, offs = oracle.synth_reads(0x4B506F70, n, L)
+    bases = bases.copy()
+    bases[offs[1]:offs[2]] = ord("N")
+    cols = oracle.enumerate_kmers(k)
+    T = oracle.synth_twister(3, d, cols)
+    h, c, o = oracle.count_reads(bases, offs, k)
+    want = oracle.twist(T, cols, h, c.astype(np.float64), o)
+    assert ret[0][0] + ret[1][0] == len(cols) and ret[0][0] > 0 and ret[1][0] > 0
+    for r in range(world):
+        got = ret[r][1]
+        assert got.shape == want.shape and np.all(got[1] == 0.0)
+        # sum of slice sums divided by acc vs the reference's sum of (v/acc) terms: rounding only
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-15)
