@@ -115,10 +115,10 @@ void process_batch(const Params &P, const ReadBatch &b, FILE *out, Merged &merge
   static const uint8_t dummy = 0;
   check(kpop_count_reads(b.bases.empty() ? &dummy : b.bases.data(), b.offsets.data(), (uint32_t)b.size(), P.k, P.content,
                          per_read ? 1 : 0, oh.data(), oc.data(), oo.data(), cap));
-  if (per_read) {
-    for (size_t r = 0; r < b.size(); ++r)  // bin/KPopCount.ml:44-46
-      write_spectrum(out, strip_external_quotes_and_check(b.tags[r]), oh.data() + oo[r], oc.data() + oo[r], oo[r + 1] - oo[r],
-                     P.k);
+  if (per_read) {  // bin/KPopCount.ml:44-46
+    std::vector<std::string> labels(b.size());
+    for (size_t r = 0; r < b.size(); ++r) labels[r] = strip_external_quotes_and_check(b.tags[r]);
+    write_spectra_parallel(out, labels, oh.data(), oc.data(), oo.data(), P.k);
   } else {
     merged.add(oh.data(), oc.data(), oo[1]);
   }

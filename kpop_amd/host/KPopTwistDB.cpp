@@ -161,14 +161,23 @@ struct TwisterReg {
   Table twister, inertia;  // dims x k-mers ; 1 x dims
   kpop_twister *dev = nullptr;
   size_t name_len = 0;
+  std::string lazy_path;  // a binary archive whose twister matrix has not been read yet (-d / -s / -e only need the inertia)
   void reset() {
     if (dev) kpop_twister_free(dev);
     dev = nullptr;
     twister = Table();
     inertia = Table();
+    lazy_path.clear();
+  }
+  void need_matrix() {
+    if (lazy_path.empty()) return;
+    const std::string p = lazy_path;
+    lazy_path.clear();
+    read_binary_twister(p, &twister, &inertia);
   }
   void upload() {
     if (dev) return;
+    need_matrix();
     need_gpu();
     const size_t n = twister.cols();
     std::vector<uint64_t> col_hash(n);
@@ -210,23 +219,20 @@ std::vector<double> metric_vector(const Metric &m, const TwisterReg &T) {  // Tw
 
 // Twister.add_twisted_from_files, lib/Twister.ml:58-206
 void add_twisted_from_files(TwisterReg &T, Table &twisted, const std::vector<std::string> &files, bool normalize, bool verbose) {
+  T.need_matrix();
   const std::vector<std::string> &dims = T.twister.row_names;
   if (!twisted.empty() && twisted.col_names != dims) throw Error("Incompatible_twister_and_twisted");  // :64-69
   T.upload();
-  Spectra sp;
+  // names -> hashes while parsing; a name the twister cannot hold is simply an unknown k-mer (:167-169)
+  HashedSpectra sp;
+  const uint64_t absent = ~0ull >> 1;  // no twister column carries this hash (k <= 30)
   for (const std::string &f : files) {
-    read_spectra_file(f, sp);
+    read_spectra_hashed(f, T.name_len, absent, sp);
     if (verbose) fprintf(stderr, "(KPopTwistDB): File '%s': read %zu spectra so far\n", f.c_str(), sp.labels.size());
   }
-  // names -> hashes; a name the twister cannot hold is simply an unknown k-mer (:167-169)
-  const size_t n_lines = sp.names.size();
-  std::vector<uint64_t> hash(n_lines);
-  const uint64_t absent = ~0ull >> 1;  // no twister column carries this hash (k <= 30)
-  for (size_t i = 0; i < n_lines; ++i)
-    if (sp.names[i].size() != T.name_len || !hex_to_hash(sp.names[i], &hash[i])) hash[i] = absent;
   const size_t n = sp.labels.size(), d = dims.size();
   std::vector<double> rows(n * d);
-  if (n) check(kpop_twist(T.dev, hash.data(), sp.values.data(), sp.offsets.data(), (uint32_t)n, normalize ? 1 : 0, rows.data()));
+  if (n) check(kpop_twist(T.dev, sp.hash.data(), sp.values.data(), sp.offsets.data(), (uint32_t)n, normalize ? 1 : 0, rows.data()));
   // StringMap of label -> row: existing rows first, new labels must be new (:78-82,:189-195), result in
   // bytewise label order (:197-204)
   std::map<std::string, std::pair<const double *, size_t>> res;
@@ -430,7 +436,12 @@ int main(int argc, char **argv) {
         case Action::BinaryToRegister:  // bin/KPopTwistDB.ml:449-456
           if (a.reg == Reg::Twister) {
             T.reset();
-            read_binary_twister(make_filename(a.s1, "KPopTwister", false), &T.twister, &T.inertia);
+            const std::string path = make_filename(a.s1, "KPopTwister", false);
+            if (path.compare(0, 5, "/dev/") == 0) read_binary_twister(path, &T.twister, &T.inertia);  // not seekable
+            else {
+              read_binary_twister_inertia(path, &T.inertia);
+              T.lazy_path = path;
+            }
           } else if (a.reg == Reg::Twisted) twisted = read_binary_matrix(make_filename(a.s1, "KPopTwisted", false), "KPopTwisted");
           else if (a.reg == Reg::Distances) distances = read_binary_matrix(make_filename(a.s1, "KPopDMatrix", false), "KPopDMatrix");
           else if (a.reg == Reg::Embeddings) embeddings = read_binary_matrix(make_filename(a.s1, "KPopVectors", false), "KPopVectors");
@@ -443,7 +454,10 @@ int main(int argc, char **argv) {
           else throw Error("nothing can be added to the twister, metrics or splits registers");
           break;
         case Action::RegisterToBinary:  // :509-518
-          if (a.reg == Reg::Twister) write_binary_twister(make_filename(a.s1, "KPopTwister", false), T.twister, T.inertia);
+          if (a.reg == Reg::Twister) {
+            T.need_matrix();
+            write_binary_twister(make_filename(a.s1, "KPopTwister", false), T.twister, T.inertia);
+          }
           else if (a.reg == Reg::Twisted) write_binary_matrix(make_filename(a.s1, "KPopTwisted", false), "KPopTwisted", twisted);
           else if (a.reg == Reg::Distances) write_binary_matrix(make_filename(a.s1, "KPopDMatrix", false), "KPopDMatrix", distances);
           else if (a.reg == Reg::Embeddings) write_binary_matrix(make_filename(a.s1, "KPopVectors", false), "KPopVectors", embeddings);
@@ -482,6 +496,7 @@ int main(int argc, char **argv) {
         case Action::SetSummaryKeepAtMost: keep_at_most = a.num; break;
         case Action::RegisterToTables:
           if (a.reg == Reg::Twister) {  // Twister.to_files, lib/Twister.ml:28-30
+            T.need_matrix();
             write_table(make_filename(a.s1, "KPopTwister", true), T.twister, precision);
             write_table(make_filename(a.s1, "KPopInertia", true), T.inertia, precision);
           } else if (a.reg == Reg::Twisted) {

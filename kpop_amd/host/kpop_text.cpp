@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
 
 namespace kpop_host {
 
@@ -209,6 +210,234 @@ void read_spectra_file(const std::string &path, Spectra &out) {
     }
   }
   if (open) out.offsets.push_back(out.names.size());
+}
+
+// ------------------------------------------------------------------ parallel spectra parser / writer
+namespace {
+
+// KPOP_HOST_THREADS / KPOP_HOST_CHUNK (work items per thread) override the defaults; the tests use them to force many
+// small chunks through the cut-and-merge logic
+unsigned pick_threads(unsigned asked, size_t work_items, size_t per_thread) {
+  unsigned t = asked ? asked : std::thread::hardware_concurrency();
+  if (const char *e = getenv("KPOP_HOST_THREADS")) t = (unsigned)atoi(e);
+  if (const char *e = getenv("KPOP_HOST_CHUNK")) per_thread = (size_t)std::max(1, atoi(e));
+  if (t == 0) t = 1;
+  t = std::min<unsigned>(t, 32);
+  return (unsigned)std::max<size_t>(1, std::min<size_t>(t, work_items / per_thread + 1));
+}
+
+std::vector<char> slurp(const std::string &path) {
+  FILE *f;
+  bool own = false;
+  if (path == "/dev/stdin" || path == "-") f = stdin;
+  else {
+    f = fopen(path.c_str(), "rb");
+    own = true;
+  }
+  if (!f) throw Error("cannot open '" + path + "': " + strerror(errno));
+  std::vector<char> buf;
+  size_t cap = 1 << 22, len = 0;
+  buf.resize(cap);
+  for (;;) {
+    if (len == cap) {
+      cap *= 2;
+      buf.resize(cap);
+    }
+    const size_t got = fread(buf.data() + len, 1, cap - len, f);
+    if (got == 0) break;
+    len += got;
+  }
+  if (own) fclose(f);
+  buf.resize(len);
+  return buf;
+}
+
+struct ChunkResult {
+  std::vector<uint64_t> hash;
+  std::vector<double> values;
+  std::vector<std::pair<uint64_t, std::string>> headers;  // (number of value lines of this chunk before it, label)
+  uint64_t n_lines = 0;
+  bool failed = false;
+  uint64_t error_line = 0;  // 1-based within the chunk
+  std::string error;
+  bool first_line_is_header = true;
+  std::string first_line;
+};
+
+void parse_chunk(const char *s, const char *e, size_t name_len, uint64_t absent, ChunkResult &r) {
+  r.hash.reserve((size_t)(e - s) / 9 + 16);
+  r.values.reserve((size_t)(e - s) / 9 + 16);
+  while (s < e) {
+    const char *nl = (const char *)memchr(s, '\n', (size_t)(e - s));
+    const char *le = nl ? nl : e;
+    const char *next = nl ? nl + 1 : e;
+    if (le > s && le[-1] == '\r') --le;
+    ++r.n_lines;
+    const char *tab = (const char *)memchr(s, '\t', (size_t)(le - s));
+    if (!tab || memchr(tab + 1, '\t', (size_t)(le - tab - 1))) {  // lib/Twister.ml:103-104
+      size_t n = 1;
+      for (const char *p = s; p < le; ++p) n += *p == '\t';
+      r.failed = true;
+      r.error_line = r.n_lines;
+      r.error = ", " + std::to_string(n) + ", 2)";
+      return;
+    }
+    if (r.n_lines == 1 && tab != s) {
+      r.first_line_is_header = false;
+      r.first_line.assign(s, (size_t)(le - s));
+    }
+    if (tab == s) {  // header
+      try {
+        r.headers.emplace_back(r.hash.size(), strip_external_quotes_and_check(std::string(tab + 1, (size_t)(le - tab - 1))));
+      } catch (const Error &ex) {
+        r.failed = true;
+        r.error_line = 0;
+        r.error = ex.what();
+        return;
+      }
+    } else {
+      uint64_t h = absent;
+      if ((size_t)(tab - s) == name_len && name_len <= 16) {
+        uint64_t v = 0;
+        bool ok = name_len > 0;
+        for (const char *p = s; p < tab; ++p) {
+          const char c = *p;
+          int d;
+          if (c >= '0' && c <= '9') d = c - '0';
+          else if (c >= 'a' && c <= 'f') d = c - 'a' + 10;
+          else if (c >= 'A' && c <= 'F') d = c - 'A' + 10;
+          else {
+            ok = false;
+            break;
+          }
+          v = (v << 4) | (uint64_t)d;
+        }
+        if (ok) h = v;
+      }
+      const char *vs = tab + 1;
+      const size_t vl = (size_t)(le - vs);
+      double val = 0.;
+      bool digits = vl > 0 && vl <= 15;
+      uint64_t iv = 0;
+      for (size_t i = 0; digits && i < vl; ++i) {
+        if (vs[i] < '0' || vs[i] > '9') digits = false;
+        else iv = iv * 10 + (uint64_t)(vs[i] - '0');
+      }
+      if (digits) val = (double)iv;  // what KPopCount writes ("%d"): exact
+      else if (!parse_float(std::string(vs, vl), &val)) {
+        r.failed = true;
+        r.error_line = 0;
+        r.error = "Float_expected(\"" + std::string(vs, vl) + "\")";  // :155-157
+        return;
+      }
+      r.hash.push_back(h);
+      r.values.push_back(val);
+    }
+    s = next;
+  }
+}
+
+}  // namespace
+
+void read_spectra_hashed(const std::string &path, size_t name_len, uint64_t absent, HashedSpectra &out, unsigned threads) {
+  const std::vector<char> buf = slurp(path);
+  const char *base = buf.data();
+  const size_t size = buf.size();
+  const unsigned T = pick_threads(threads, size, 4u << 20);
+  std::vector<size_t> cut(T + 1, size);
+  cut[0] = 0;
+  for (unsigned t = 1; t < T; ++t) {
+    size_t at = std::max(cut[t - 1], size / T * t);
+    const char *nl = at < size ? (const char *)memchr(base + at, '\n', size - at) : nullptr;
+    cut[t] = nl ? (size_t)(nl - base) + 1 : size;
+  }
+  std::vector<ChunkResult> res(T);
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < T; ++t)
+    pool.emplace_back([&, t] { parse_chunk(base + cut[t], base + cut[t + 1], name_len, absent, res[t]); });
+  parse_chunk(base + cut[0], base + cut[1], name_len, absent, res[0]);
+  for (std::thread &th : pool) th.join();
+  // errors in file order, with the sequential parser's precedence on line 1 (column count, then Header_expected)
+  uint64_t lines_before = 0;
+  for (unsigned t = 0; t < T; ++t) {
+    const ChunkResult &r = res[t];
+    const bool col_error_on_line_1 = r.failed && r.error_line == 1 && t == 0;
+    if (t == 0 && r.n_lines >= 1 && !r.first_line_is_header && !col_error_on_line_1)
+      throw Error("Header_expected(\"" + r.first_line + "\")");  // lib/Twister.ml:106-107
+    if (r.failed) {
+      if (r.error_line) throw Error("Wrong_number_of_columns(" + std::to_string(lines_before + r.error_line) + r.error);
+      throw Error(r.error);
+    }
+    lines_before += r.n_lines;
+  }
+  size_t total = out.hash.size();
+  for (const ChunkResult &r : res) total += r.hash.size();
+  const size_t start = out.hash.size();
+  out.hash.resize(total);
+  out.values.resize(total);
+  size_t at = start;
+  bool open = false;
+  for (const ChunkResult &r : res) {
+    for (const auto &h : r.headers) {
+      if (open) out.offsets.push_back(at + h.first);
+      out.labels.push_back(h.second);
+      open = true;
+    }
+    if (!r.hash.empty()) {
+      memcpy(&out.hash[at], r.hash.data(), r.hash.size() * 8);
+      memcpy(&out.values[at], r.values.data(), r.values.size() * 8);
+    }
+    at += r.hash.size();
+  }
+  if (open) out.offsets.push_back(at);
+}
+
+void write_spectra_parallel(FILE *f, const std::vector<std::string> &labels, const uint64_t *hash, const uint32_t *count,
+                            const uint64_t *offsets, int k, unsigned threads) {
+  const size_t n = labels.size();
+  if (n == 0) return;
+  const unsigned T = pick_threads(threads, (size_t)(offsets[n] - offsets[0]), 1u << 18);
+  const int digits = (k + 1) / 2;
+  std::vector<std::string> text(T);
+  auto work = [&](unsigned t) {
+    const size_t lo = n * t / T, hi = n * (t + 1) / T;
+    std::string &o = text[t];
+    size_t label_bytes = 0;
+    for (size_t r = lo; r < hi; ++r) label_bytes += labels[r].size() + 2;
+    o.reserve(label_bytes + (size_t)(offsets[hi] - offsets[lo]) * (size_t)(digits + 8));
+    static const char hx[] = "0123456789abcdef";
+    char buf[40];
+    for (size_t r = lo; r < hi; ++r) {
+      o.push_back('\t');
+      o.append(labels[r]);
+      o.push_back('\n');
+      for (uint64_t i = offsets[r]; i < offsets[r + 1]; ++i) {
+        uint64_t h = hash[i];
+        for (int d = digits - 1; d >= 0; --d) {
+          buf[d] = hx[h & 15];
+          h >>= 4;
+        }
+        int len = digits;
+        buf[len++] = '\t';
+        char tmp[12];
+        int tl = 0;
+        uint32_t c = count[i];
+        do {
+          tmp[tl++] = (char)('0' + c % 10);
+          c /= 10;
+        } while (c);
+        while (tl) buf[len++] = tmp[--tl];
+        buf[len++] = '\n';
+        o.append(buf, (size_t)len);
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < T; ++t) pool.emplace_back(work, t);
+  work(0);
+  for (std::thread &th : pool) th.join();
+  for (const std::string &o : text)
+    if (fwrite(o.data(), 1, o.size(), f) != o.size()) throw Error(std::string("write failed: ") + strerror(errno));
 }
 
 void write_spectrum_body(FILE *f, const uint64_t *hash, const uint32_t *count, uint64_t n, int k) {

@@ -72,6 +72,22 @@ struct Spectra {  // CSR over spectra, lines in file order
 // Wrong_number_of_columns (:103-104), Header_expected (:106-107), Float_expected (:155-157).
 void read_spectra_file(const std::string &path, Spectra &out);
 void write_spectrum(FILE *f, const std::string &label, const uint64_t *hash, const uint32_t *count, uint64_t n, int k);
+
+// The same parser for the GPU path: k-mer names are turned into hashes while parsing (a name that is not `name_len`
+// hexadecimal digits can match no twister column and becomes `absent`), no per-line strings are made, and the file
+// is cut at line boundaries and parsed by several threads.  Same errors, same line numbers.
+struct HashedSpectra {
+  std::vector<std::string> labels;
+  std::vector<uint64_t> offsets{0};
+  std::vector<uint64_t> hash;
+  std::vector<double> values;
+};
+void read_spectra_hashed(const std::string &path, size_t name_len, uint64_t absent, HashedSpectra &out, unsigned threads = 0);
+
+// "\t<label>\n" + "<hex>\t<count>\n"... for reads [0, n) of a CSR result, formatted by several threads and written in
+// order (bin/KPopCount.ml:44-46).  labels must already be checked.
+void write_spectra_parallel(FILE *f, const std::vector<std::string> &labels, const uint64_t *hash, const uint32_t *count,
+                            const uint64_t *offsets, int k, unsigned threads = 0);
 void write_spectrum_body(FILE *f, const uint64_t *hash, const uint32_t *count, uint64_t n, int k);
 
 // ---- matrix tables (Appendix A.2; README.md:618-626,643-650; src/KPopTwist:100,108,116) ----

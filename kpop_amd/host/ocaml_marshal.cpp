@@ -327,8 +327,8 @@ struct Reader {
   }
 };
 
-// one marshalled value: false at clean EOF
-bool read_one(FILE *f, Reader &r) {
+// header of one marshalled value: false at clean EOF, else the length of the data that follows
+bool read_header(FILE *f, uint64_t *data_len_out) {
   uint8_t hd[32];
   size_t got = fread(hd, 1, 4, f);
   if (got == 0) return false;
@@ -357,6 +357,14 @@ bool read_one(FILE *f, Reader &r) {
       if (end >= here && data_len > (uint64_t)(end - here)) throw Error("marshal: truncated value");
     }
   }
+  *data_len_out = data_len;
+  return true;
+}
+
+// one marshalled value: false at clean EOF
+bool read_one(FILE *f, Reader &r) {
+  uint64_t data_len = 0;
+  if (!read_header(f, &data_len)) return false;
   r = Reader();
   r.data.resize(data_len);
   if (data_len && fread(r.data.data(), 1, data_len, f) != data_len) throw Error("marshal: truncated value");
@@ -458,6 +466,31 @@ void read_binary_twister(const std::string &path, Table *twister, Table *inertia
   }
   fclose(f);
   if (t1 != "KPopTwister") throw Error("Unexpected_type(KPopTwister, " + t1 + ")");
+  if (t2 != "KPopInertia") throw Error("Unexpected_type(KPopInertia, " + t2 + ")");
+}
+
+// the inertia half only: the twister matrix is stepped over by its declared length (-d / -s need the metric, not
+// the 8-bytes-per-coefficient matrix in front of it)
+void read_binary_twister_inertia(const std::string &path, Table *inertia) {
+  FILE *f = open_or_throw(path, "rb");
+  std::string t2;
+  try {
+    Reader r;
+    if (!read_one(f, r)) throw Error("'" + path + "' is empty");
+    const std::string t1 = r.str(0);
+    if (t1 != "KPopTwister") throw Error("Unexpected_type(KPopTwister, " + t1 + ")");
+    if (!read_one(f, r)) throw Error("marshal: archive version missing");
+    const std::string version = r.str(0);
+    if (version != kArchiveVersion) throw Error("Incompatible_archive_version(\"" + t1 + "\", \"" + version + "\", \"" + kArchiveVersion + "\")");
+    uint64_t len = 0;
+    if (!read_header(f, &len)) throw Error("'" + path + "' is truncated");
+    if (fseek(f, (long)len, SEEK_CUR) != 0) throw Error("'" + path + "' cannot be searched (a pipe?)");
+    if (!marshal_read_matrix(f, &t2, inertia)) throw Error("'" + path + "' is truncated");
+  } catch (...) {
+    fclose(f);
+    throw;
+  }
+  fclose(f);
   if (t2 != "KPopInertia") throw Error("Unexpected_type(KPopInertia, " + t2 + ")");
 }
 

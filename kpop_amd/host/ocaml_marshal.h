@@ -35,6 +35,7 @@ bool marshal_read_matrix(FILE *f, std::string *type_name, Table *t);
 Table read_binary_matrix(const std::string &path, const std::string &expect_type);
 void write_binary_matrix(const std::string &path, const std::string &type_name, const Table &t);
 void read_binary_twister(const std::string &path, Table *twister, Table *inertia);
+void read_binary_twister_inertia(const std::string &path, Table *inertia);  // skips over the twister matrix
 void write_binary_twister(const std::string &path, const Table &twister, const Table &inertia);
 
 // ---- '.KPopCounter' (lib/KMerDB.ml:54-63,389-430): "KPopCounter", "2022-04-03", then the record

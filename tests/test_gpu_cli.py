@@ -537,3 +537,32 @@ def test_embeddings_register(tmp_path, oracle):
     assert r.returncode == 1 and "Unexpected_type" in r.stderr
     r = run([TWISTDB, "-I", "t", str(tmp_path / "tw"), "-e"])
     assert r.returncode == 1 and "require a twister" in r.stderr
+
+
+def test_parallel_text_paths_are_chunking_invariant(tmp_path, oracle, pyref):
+    """KPopCount's spectra writer and KPopTwistDB's spectra parser cut their work over host threads: forcing 32 tiny
+    chunks must not change a byte, and errors keep the sequential parser's line numbers."""
+    k, d = 5, 7
+    rng = np.random.RandomState(17)
+    reads = [("read %d" % i, "".join(rng.choice(list("ACGTN"), p=[.24, .24, .24, .24, .04], size=rng.randint(0, 90)))) for i in range(400)]
+    write_fasta(tmp_path / "x.fa", reads)
+    tiny = dict(os.environ, KPOP_HOST_THREADS="32", KPOP_HOST_CHUNK="64")
+    one = dict(os.environ, KPOP_HOST_THREADS="1")
+    outs = [subprocess.run([COUNT, "-k", str(k), "-L", "-f", str(tmp_path / "x.fa")], capture_output=True, text=True, env=e) for e in (tiny, one)]
+    assert outs[0].returncode == 0 and outs[0].stdout == outs[1].stdout == expected_spectra(pyref, reads, k)
+    (tmp_path / "x.KPopSpectra.txt").write_text(outs[0].stdout)
+    make_twister(tmp_path, oracle, k, d)
+    res = []
+    for name, e in (("a", tiny), ("b", one)):
+        r = subprocess.run([TWISTDB, "-I", "T", str(tmp_path / "Classes"), "-k", str(tmp_path / "x.KPopSpectra.txt"), "-O", "t", "/dev/stdout"],
+                           capture_output=True, text=True, env=e)
+        assert r.returncode == 0, r.stderr
+        res.append(r.stdout)
+    assert res[0] == res[1] and res[0].count("\n") == len(reads) + 1
+    lines = outs[0].stdout.splitlines(keepends=True)
+    for bad_at, bad, what in ((700, "aaa\t1\t2\n", "Wrong_number_of_columns(701, 3, 2)"), (1500, "aaa\tx1\n", "Float_expected(\"x1\")"),
+                              (0, "aaa\t3\n", "Header_expected(\"aaa\t3\")"), (900, "\tq\"uote\n", "Quotes_in_name")):
+        (tmp_path / "bad.txt").write_text("".join(lines[:bad_at]) + bad + "".join(lines[bad_at:]))
+        for e in (tiny, one):
+            r = subprocess.run([TWISTDB, "-I", "T", str(tmp_path / "Classes"), "-k", str(tmp_path / "bad.txt")], capture_output=True, text=True, env=e)
+            assert r.returncode == 1 and what in r.stderr, (what, r.stderr)
