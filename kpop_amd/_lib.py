@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkpop_hip.so")
+LIB_PATH = os.environ.get("KPOP_HIP_LIB", os.path.join(_HERE, "libkpop_hip.so"))  # the override is for A/B runs of two builds
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)
@@ -104,6 +104,8 @@ def load():
         pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if "KPOP_HIP_LIB" in os.environ and not hasattr(lib, name):
+            continue  # an older build under A/B comparison
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
