@@ -289,3 +289,75 @@ def test_row_sharded_pipeline_with_rccl_world_size_1(kpop, oracle):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_config5_k15_full_twister(kpop, oracle):
+    """BASELINE config 5 at its full size: every canonical 15-mer (536,870,912 rows x 16 dims, 69 GB of HBM) resident;
+    10k reads and three 30 kb genomes twisted; a sample checked against the oracle with the twister restricted to the
+    sample's own k-mers (the synthetic coefficients are a pure function of (dimension, hash)); the row-sharded layout
+    (two hash-range slices with accumulator dimensions) must give the same rows."""
+    import torch
+    from kpop_amd.shard import kmer_slice_bounds, reduce_partial_twists
+    free, total = torch.cuda.mem_get_info(0)
+    if free < 150e9:
+        pytest.skip("needs 150 GB of free HBM")
+    k, d, n, L = 15, 16, 10000, 150
+    tw = kpop.Twister.synth(0x5EED, k, d)
+    info = tw.info()
+    assert info["n_cols"] == 4 ** 15 // 2 and info["device_bytes"] > 68e9
+    bases, offs = oracle.synth_reads(0x4B506F70, n, L)
+    gb, go = oracle.synth_reads(0xABCDE, 3, 30000)
+    allb = np.concatenate([bases, gb])
+    allo = np.concatenate([offs, go[1:] + offs[-1]])
+    got = tw.count_twist(allb, allo)
+    tw.free()
+    pick = list(range(0, n, 250)) + [n, n + 1, n + 2]
+    sb = np.concatenate([allb[int(allo[r]):int(allo[r + 1])] for r in pick])
+    so = np.zeros(len(pick) + 1, dtype=np.uint64)
+    so[1:] = np.cumsum([int(allo[r + 1] - allo[r]) for r in pick])
+    h, c, o = oracle.count_reads(sb, so, k)
+    cols = np.unique(h)
+    want = oracle.twist(oracle.synth_twister(0x5EED, d, cols), cols, h, c.astype(np.float64), o)
+    # D <= 32 packs two k-mer rows per wavefront load (the order of summation differs from the oracle's), and genomes
+    # go through the streaming kernel: rounding only
+    np.testing.assert_allclose(got[pick], want, rtol=1e-12, atol=1e-15)
+    # properties over all 10k reads: coordinates of a normalised spectrum are convex combinations of coefficients in [-1,1)
+    assert np.all(np.abs(got) < 1.0) and np.all(np.isfinite(got))
+    total = np.zeros((n + 3, d + 1))
+    for r in range(2):
+        sl = kpop.Twister.synth(0x5EED, k, d, hash_range=kmer_slice_bounds(k, r, 2), acc_dim=True)
+        total += sl.count_twist(allb, allo, normalize=False)
+        sl.free()
+    sharded = reduce_partial_twists(torch.from_numpy(total)).numpy()
+    np.testing.assert_allclose(sharded, got, rtol=1e-12, atol=1e-15)
+    assert np.array_equal(total[:n, -1], np.full(n, L - k + 1.0))           # every window of an N-free read is counted once
+
+
+def test_config3_50k_genomes_full_size(kpop, oracle):
+    """BASELINE config 3 at its full size: 50,000 sequences of 30 kb (1.5 GB of bases, generated on the device), k = 12,
+    D = 64.  A sample of genomes -- first, last and a spread -- is copied back and checked against the oracle with the
+    twister restricted to the sample's k-mers; every row must be finite and inside the coefficient range."""
+    import torch
+    from kpop_amd import api
+    k, d, n, L = 12, 64, 50000, 30000
+    dev = torch.device("cuda", 0)
+    sp = torch.cuda.current_stream().cuda_stream
+    tw = kpop.Twister.synth(0x7457, k, d)
+    bases = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    offs = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    api.dev_synth_reads(0xC0FFEE, n, L, bases.data_ptr(), offs.data_ptr(), stream=sp)
+    out = torch.zeros(n, d, dtype=torch.float64, device=dev)
+    api.dev_count_twist(tw, bases.data_ptr(), offs.data_ptr(), n, n * L, L, out.data_ptr(), stream=sp)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.all(np.isfinite(got)) and np.all(np.abs(got) < 1.0)
+    pick = [0, 1, 777, 24999, 49998, 49999]
+    sb = np.concatenate([bases[r * L:(r + 1) * L].cpu().numpy() for r in pick])
+    so = np.arange(len(pick) + 1, dtype=np.uint64) * L
+    first, _ = oracle.synth_reads(0xC0FFEE, 2, L)
+    assert np.array_equal(sb[:2 * L], first)                                  # the device generator is the oracle's
+    h, c, o = oracle.count_reads(sb, so, k)
+    cols = np.unique(h)
+    want = oracle.twist(oracle.synth_twister(0x7457, d, cols), cols, h, c.astype(np.float64), o)
+    np.testing.assert_allclose(got[pick], want, rtol=1e-12, atol=1e-15)
+    assert all(int(o[i + 1] - o[i]) > 29000 for i in range(len(pick)))     # ~29,989 distinct-ish 12-mers per genome
