@@ -212,3 +212,46 @@ def test_embeddings_vs_oracle(kpop, oracle, kind, p, rows, d):
             np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
         else:
             assert np.array_equal(got, want)
+
+
+def test_config4_one_million_reads_pipeline(kpop, oracle):
+    """BASELINE config 4 (1M x 150 bp, k = 12) through the device-resident pipeline on one GPU -- the work 8 ranks would
+    split by reads with no collective: count -> twist -> distances to 65 class vectors.  A spread of reads is checked
+    bit for bit against the oracle (twister restricted to their k-mers); shards of the read range reproduce the rows."""
+    import torch
+    from kpop_amd import api
+    from kpop_amd.pipeline import DevicePipeline
+    from kpop_amd.shard import shard_bounds
+    k, d, n, L, C = 12, 64, 1_000_000, 150, 65
+    dev = torch.device("cuda", 0)
+    sp = torch.cuda.current_stream().cuda_stream
+    tw = kpop.Twister.synth(0x7457, k, d)
+    metric = kpop.metric_compute(oracle.synth_inertia(d))
+    pipe = DevicePipeline(tw, metric, dev)
+    bases = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    offs = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    api.dev_synth_reads(0x4B506F70, n, L, bases.data_ptr(), offs.data_ptr(), stream=sp)
+    cb = torch.empty(C * 500, dtype=torch.uint8, device=dev)
+    co = torch.empty(C + 1, dtype=torch.int64, device=dev)
+    api.dev_synth_reads(0xC1A55, C, 500, cb.data_ptr(), co.data_ptr(), stream=sp)
+    classes = pipe.count_twist(cb, co, 500)
+    twisted = pipe.count_twist(bases, offs, L)
+    dist = pipe.distance_rowwise(classes, twisted)
+    torch.cuda.synchronize()
+    assert dist.shape == (n, C)
+    pick = np.array([0, 1, 124_999, 125_000, 500_000, 999_999])
+    hb = np.concatenate([bases[r * L:(r + 1) * L].cpu().numpy() for r in pick])
+    ho = np.arange(len(pick) + 1, dtype=np.uint64) * L
+    chb, cho = oracle.synth_reads(0xC1A55, C, 500)
+    h, c, o = oracle.count_reads(np.concatenate([hb, chb]), np.concatenate([ho, cho[1:] + ho[-1]]), k)
+    cols = np.unique(h)
+    want = oracle.twist(oracle.synth_twister(0x7457, d, cols), cols, h, c.astype(np.float64), o)
+    assert np.array_equal(twisted[torch.from_numpy(pick).to(dev)].cpu().numpy(), want[:len(pick)])
+    assert np.array_equal(classes.cpu().numpy(), want[len(pick):])
+    wd = oracle.distance_rowwise(want[len(pick):], want[:len(pick)], metric)
+    assert np.array_equal(dist[torch.from_numpy(pick).to(dev)].cpu().numpy(), wd)
+    # rank r of 8 twists reads [lo, hi) only: the same rows, no exchange
+    for r in (0, 3, 7):
+        lo, hi = shard_bounds(n, r, 8)
+        part = pipe.count_twist(bases[lo * L:hi * L], offs[lo:hi + 1] - offs[lo], L)
+        assert torch.equal(part, twisted[lo:hi])
