@@ -440,51 +440,69 @@ void CounterDB::output_summary() const {
 
 namespace {
 
-// what to_table and to_spectra share: statistics over the whole register, the surviving rows and columns, and the
-// transformed counts of the surviving columns (spectrum-major: values[c * n_rows + r])
-struct Transformed {
+// what to_table and to_spectra share: statistics over the whole register and the surviving rows and columns.  The
+// transformed counts are then produced block by block (a band of k-mers for the k-mer-major table, a batch of
+// spectra for the transposed table and for spectra), so the host never holds more than block_values() doubles.
+size_t block_values() {  // KPOP_HOST_BLOCK: the tests force tiny blocks through the banding logic
+  if (const char *e = getenv("KPOP_HOST_BLOCK")) return (size_t)std::max(1, atoi(e));
+  return 64u << 20;
+}
+
+struct Plan {
   std::vector<uint32_t> rows, cols;
-  std::vector<double> values;
+  std::vector<const int32_t *> col_ptrs;
+  std::vector<double> cs;  // 4 statistics per surviving column
+  int which = KPOP_TRANSF_POWER;
+  double threshold = 1., power = 1.;
+  size_t n_rows = 0;
 };
 
-Transformed transform_register(CounterDB &db, const TableFilter &filter) {
-  Transformed t;
-  const int which = filter.transform.code();
+Plan plan_register(CounterDB &db, const TableFilter &filter) {
+  Plan p;
+  p.which = filter.transform.code();
+  p.threshold = filter.transform.threshold;
+  p.power = filter.transform.power;
   ensure_gpu();
   const size_t n_rows = db.n_rows(), n_cols = db.n_cols();
+  p.n_rows = n_rows;
   std::vector<const int32_t *> all = db.columns();
   std::vector<double> col_stats(4 * std::max<size_t>(1, n_cols)), row_stats(4 * std::max<size_t>(1, n_rows));
-  check(kpop_counter_stats(all.data(), (uint32_t)n_cols, n_rows, filter.transform.threshold, filter.transform.power, col_stats.data(),
-                           row_stats.data()));
+  check(kpop_counter_stats(all.data(), (uint32_t)n_cols, n_rows, p.threshold, p.power, col_stats.data(), row_stats.data()));
   for (size_t r = 0; r < n_rows; ++r)
-    if (row_stats[4 * r + 2] > 0. || filter.print_zero_rows) t.rows.push_back((uint32_t)r);
-  std::vector<const int32_t *> cols;
-  std::vector<double> cs;
+    if (row_stats[4 * r + 2] > 0. || filter.print_zero_rows) p.rows.push_back((uint32_t)r);
   for (size_t c = 0; c < n_cols; ++c)
     if (!filter.filter_columns.count(db.core.col_names[c])) {
-      t.cols.push_back((uint32_t)c);
-      cols.push_back(all[c]);
-      cs.insert(cs.end(), col_stats.begin() + 4 * (long)c, col_stats.begin() + 4 * (long)c + 4);
+      p.cols.push_back((uint32_t)c);
+      p.col_ptrs.push_back(all[c]);
+      p.cs.insert(p.cs.end(), col_stats.begin() + 4 * (long)c, col_stats.begin() + 4 * (long)c + 4);
     }
-  t.values.resize(std::max<size_t>(1, cols.size() * n_rows));
-  check(kpop_counter_transform(cols.data(), (uint32_t)cols.size(), n_rows, which, filter.transform.threshold, filter.transform.power,
-                               cs.data(), 0, t.values.data()));
-  return t;
+  return p;
+}
+
+// out[(c - c0) * (r1 - r0) + (r - r0)] for surviving columns [c0, c1) and k-mers [r0, r1)
+void eval_block(const Plan &p, size_t c0, size_t c1, size_t r0, size_t r1, std::vector<double> &out) {
+  out.resize(std::max<size_t>(1, (c1 - c0) * (r1 - r0)));
+  if (c1 == c0 || r1 == r0) return;
+  std::vector<const int32_t *> ptrs(c1 - c0);
+  for (size_t c = c0; c < c1; ++c) ptrs[c - c0] = p.col_ptrs[c] + r0;
+  check(kpop_counter_transform(ptrs.data(), (uint32_t)(c1 - c0), r1 - r0, p.which, p.threshold, p.power, p.cs.data() + 4 * c0, 0,
+                               out.data()));
 }
 
 }  // namespace
 
 void CounterDB::to_table(const TableFilter &filter, const std::string &prefix) {
-  const Transformed t = transform_register(*this, filter);
+  const Plan t = plan_register(*this, filter);
   const std::string fname = counter_filename(prefix, true);
   FILE *out = open_out(fname);
   std::vector<char> iobuf(1 << 22);
   setvbuf(out, iobuf.data(), _IOFBF, iobuf.size());
-  const size_t nr = n_rows();
+  const size_t nr = n_rows(), ncs = t.cols.size();
   std::vector<uint32_t> meta;
   if (filter.print_metadata)
     for (size_t m = 0; m < n_meta(); ++m) meta.push_back((uint32_t)m);
   const bool rn = filter.print_row_names;
+  std::vector<double> values;
   if (meta.size() + t.rows.size() > 0) {
     if (filter.transpose) {  // rows are spectra (:1058-1112)
       if (filter.print_col_names) {
@@ -499,34 +517,47 @@ void CounterDB::to_table(const TableFilter &filter, const std::string &prefix) {
         }
         fputc('\n', out);
       }
-      for (size_t i = 0; i < t.cols.size(); ++i) {
-        const uint32_t c = t.cols[i];
-        if (rn) fputs(core.col_names[c].c_str(), out);
-        bool first_done = false;
-        for (uint32_t m : meta) {
-          fprintf(out, "%s%s", (first_done || rn) ? "\t" : "", core.meta[c][m].c_str());
-          first_done = true;
+      const size_t batch = std::max<size_t>(1, block_values() / std::max<size_t>(1, nr));
+      for (size_t c0 = 0; c0 < ncs; c0 += batch) {
+        const size_t c1 = std::min(ncs, c0 + batch);
+        eval_block(t, c0, c1, 0, nr, values);
+        for (size_t i = c0; i < c1; ++i) {
+          const uint32_t c = t.cols[i];
+          if (rn) fputs(core.col_names[c].c_str(), out);
+          bool first_done = false;
+          for (uint32_t m : meta) {
+            fprintf(out, "%s%s", (first_done || rn) ? "\t" : "", core.meta[c][m].c_str());
+            first_done = true;
+          }
+          for (uint32_t r : t.rows) {
+            fprintf(out, "%s%.*g", (first_done || rn) ? "\t" : "", filter.precision, values[(i - c0) * nr + r]);
+            first_done = true;
+          }
+          fputc('\n', out);
         }
-        for (uint32_t r : t.rows) {
-          fprintf(out, "%s%.*g", (first_done || rn) ? "\t" : "", filter.precision, t.values[i * nr + r]);
-          first_done = true;
-        }
-        fputc('\n', out);
       }
     } else {  // rows are k-mers (:1113-1160)
       if (filter.print_col_names) {
-        for (size_t i = 0; i < t.cols.size(); ++i) fprintf(out, "%s%s", (i > 0 || rn) ? "\t" : "", core.col_names[t.cols[i]].c_str());
+        for (size_t i = 0; i < ncs; ++i) fprintf(out, "%s%s", (i > 0 || rn) ? "\t" : "", core.col_names[t.cols[i]].c_str());
         fputc('\n', out);
       }
       for (uint32_t m : meta) {
         if (rn) fputs(core.meta_names[m].c_str(), out);
-        for (size_t i = 0; i < t.cols.size(); ++i) fprintf(out, "%s%s", (i > 0 || rn) ? "\t" : "", core.meta[t.cols[i]][m].c_str());
+        for (size_t i = 0; i < ncs; ++i) fprintf(out, "%s%s", (i > 0 || rn) ? "\t" : "", core.meta[t.cols[i]][m].c_str());
         fputc('\n', out);
       }
-      for (uint32_t r : t.rows) {
-        if (rn) fputs(core.row_names[r].c_str(), out);
-        for (size_t i = 0; i < t.cols.size(); ++i) fprintf(out, "%s%.*g", (i > 0 || rn) ? "\t" : "", filter.precision, t.values[i * nr + r]);
-        fputc('\n', out);
+      const size_t band = std::max<size_t>(1, block_values() / std::max<size_t>(1, ncs));
+      size_t next = 0;  // position in t.rows
+      for (size_t r0 = 0; r0 < nr && next < t.rows.size(); r0 += band) {
+        const size_t r1 = std::min(nr, r0 + band);
+        if (t.rows[next] >= r1) continue;
+        eval_block(t, 0, ncs, r0, r1, values);
+        for (; next < t.rows.size() && t.rows[next] < r1; ++next) {
+          const uint32_t r = t.rows[next];
+          if (rn) fputs(core.row_names[r].c_str(), out);
+          for (size_t i = 0; i < ncs; ++i) fprintf(out, "%s%.*g", (i > 0 || rn) ? "\t" : "", filter.precision, values[i * (r1 - r0) + (r - r0)]);
+          fputc('\n', out);
+        }
       }
     }
   }
@@ -534,17 +565,23 @@ void CounterDB::to_table(const TableFilter &filter, const std::string &prefix) {
 }
 
 void CounterDB::to_spectra(const TableFilter &filter, const std::string &prefix) {
-  const Transformed t = transform_register(*this, filter);
+  const Plan t = plan_register(*this, filter);
   const std::string fname = make_filename(prefix, "KPopSpectra", true);
   FILE *out = open_out(fname);
   std::vector<char> iobuf(1 << 22);
   setvbuf(out, iobuf.data(), _IOFBF, iobuf.size());
-  const size_t nr = n_rows();
-  for (size_t i = 0; i < t.cols.size(); ++i) {
-    fprintf(out, "\t%s\n", core.col_names[t.cols[i]].c_str());
-    for (uint32_t r : t.rows) {
-      const double v = t.values[i * nr + r];
-      if (v > 0.) fprintf(out, "%s\t%.*g\n", core.row_names[r].c_str(), filter.precision, v);  // :1222-1223
+  const size_t nr = n_rows(), ncs = t.cols.size();
+  std::vector<double> values;
+  const size_t batch = std::max<size_t>(1, block_values() / std::max<size_t>(1, nr));
+  for (size_t c0 = 0; c0 < ncs; c0 += batch) {
+    const size_t c1 = std::min(ncs, c0 + batch);
+    eval_block(t, c0, c1, 0, nr, values);
+    for (size_t i = c0; i < c1; ++i) {
+      fprintf(out, "\t%s\n", core.col_names[t.cols[i]].c_str());
+      for (uint32_t r : t.rows) {
+        const double v = values[(i - c0) * nr + r];
+        if (v > 0.) fprintf(out, "%s\t%.*g\n", core.row_names[r].c_str(), filter.precision, v);  // :1222-1223
+      }
     }
   }
   if (fclose(out) != 0) throw Error("write to '" + fname + "' failed");

@@ -481,6 +481,12 @@ def test_countdb_tables_spectra_split_and_distances(tmp_path, oracle, pyref):
     want = "".join("\t%s\n" % labels[c] + "".join("%s\t%s\n" % (names[i], fmt(vals[i, c])) for i in range(len(rows)) if rs2[i, 2] > 0 and vals[i, c] > 0)
                    for c in range(6))
     assert r.stdout == want
+    # the tables and spectra are produced block by block: tiny blocks must give the same bytes
+    tiny = "KPOP_HOST_BLOCK=50 "
+    for cmd in ("KPopCountDB -i db -t /dev/stdout", "KPopCountDB -i db --table-output-metadata true --table-transpose true -t /dev/stdout",
+                "KPopCountDB -i db --counts-threshold 2 -s /dev/stdout", "KPopCountDB -i db -L s1,s4 -F --counts-transform clr -t /dev/stdout"):
+        a, b = sh(cmd), sh(tiny + cmd)
+        assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and len(a.stdout) > 1000, cmd
     # -c: classes "a" (s0,s2,s4) and "b" (s1,s3,s5), originals removed, metadata inherited where unanimous
     r = sh("KPopCountDB -i db -c class --table-output-metadata true -t /dev/stdout")
     assert r.returncode == 0, r.stderr
