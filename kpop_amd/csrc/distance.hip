@@ -100,12 +100,15 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const double *__restrict
 // ---------------------------------------------------------------------------
 constexpr int kDC = 16, kMaxW = 128, kMaxTJ = 256;
 
-template <int KIND>
+// SLAB (spectral distances, n_dims in the millions and few rows): blockIdx.z owns dimensions [z*slab, (z+1)*slab) and
+// writes its raw partial sums to slab z of `out` ([gridDim.z][r2][r1]); reduce_slabs_kernel adds the slabs in order and
+// applies the scale.  SLAB = false is the hot path: one block walks all the dimensions, the sum is the reference's.
+template <int KIND, bool SLAB = false>
 __global__ __launch_bounds__(256) void distance_rowwise_kernel(const double *__restrict__ a, uint32_t w, uint32_t r1,
                                                                const double *__restrict__ b, uint32_t r2,
                                                                uint32_t n_dims, const double *__restrict__ metric,
                                                                double p, double *__restrict__ out, uint32_t n_cg,
-                                                               uint32_t n_rg) {
+                                                               uint32_t n_rg, uint32_t slab = 0) {
   __shared__ __attribute__((aligned(16))) double As[kDC][kMaxW + 2];
   __shared__ __attribute__((aligned(16))) double Bs[kDC][kMaxTJ + 2];
   __shared__ double s_metric[kDC];
@@ -125,8 +128,10 @@ __global__ __launch_bounds__(256) void distance_rowwise_kernel(const double *__r
   constexpr int NA = kMaxW * kDC / 256, NB = kMaxTJ * kDC / 256;
   double ra[NA], rb[NB];
   const uint32_t sc = threadIdx.x % kDC, rbase = threadIdx.x / kDC;  // 16 rows per sweep of the block
+  const uint32_t d_begin = SLAB ? blockIdx.z * slab : 0u;
+  const uint32_t d_end = SLAB ? min(n_dims, d_begin + slab) : n_dims;
   auto prefetch = [&](uint32_t c0) {
-    const bool cok = c0 + sc < n_dims;
+    const bool cok = c0 + sc < d_end;
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
       const uint32_t row = rbase + q * 16;
@@ -138,17 +143,17 @@ __global__ __launch_bounds__(256) void distance_rowwise_kernel(const double *__r
       rb[q] = (cok && row < TJ && j0 + row < r2) ? b[(uint64_t)(j0 + row) * n_dims + c0 + sc] : 0.0;
     }
   };
-  prefetch(0);
-  for (uint32_t c0 = 0; c0 < n_dims; c0 += kDC) {
+  prefetch(d_begin);
+  for (uint32_t c0 = d_begin; c0 < d_end; c0 += kDC) {
     __syncthreads();  // the previous chunk's readers are done
 #pragma unroll
     for (int q = 0; q < NA; ++q) As[sc][rbase + q * 16] = ra[q];
 #pragma unroll
     for (int q = 0; q < NB; ++q) Bs[sc][rbase + q * 16] = rb[q];
-    if (threadIdx.x < kDC) s_metric[threadIdx.x] = (c0 + threadIdx.x < n_dims) ? metric[c0 + threadIdx.x] : 0.0;
+    if (threadIdx.x < kDC) s_metric[threadIdx.x] = (c0 + threadIdx.x < d_end) ? metric[c0 + threadIdx.x] : 0.0;
     __syncthreads();
-    if (c0 + kDC < n_dims) prefetch(c0 + kDC);
-    const uint32_t lim = min((uint32_t)kDC, n_dims - c0);
+    if (c0 + kDC < d_end) prefetch(c0 + kDC);
+    const uint32_t lim = min((uint32_t)kDC, d_end - c0);
     if (worker) {
       for (uint32_t cc = 0; cc < lim; ++cc) {
         double av[4], bv[4];
@@ -176,7 +181,10 @@ __global__ __launch_bounds__(256) void distance_rowwise_kernel(const double *__r
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
       const uint32_t i = i0 + ti + x;
-      if (i < i1) out[(uint64_t)j * r1 + i] = scale_distance<KIND>(acc[y][x], p);  // data.(j).@(i), lib/Matrix.ml:253
+      if (i < i1) {
+        if (SLAB) out[((uint64_t)blockIdx.z * r2 + j) * r1 + i] = acc[y][x];
+        else out[(uint64_t)j * r1 + i] = scale_distance<KIND>(acc[y][x], p);  // data.(j).@(i), lib/Matrix.ml:253
+      }
     }
   }
 }
@@ -371,6 +379,64 @@ static int prepare_operands(const double *m1, uint32_t r1, const double *m2, uin
 }
 
 // launches the rowwise kernel on prepared (normalised) operands
+// ---------------------------------------------------------------------------
+// long rows (n_dims >= kLongD): norms and distances summed slab by slab
+// ---------------------------------------------------------------------------
+constexpr uint32_t kLongD = 32768, kSlabDims = 4096;
+
+static uint32_t long_slabs(uint32_t r1, uint32_t r2, uint32_t n_dims) {
+  const uint64_t pairs = std::max<uint64_t>(1, (uint64_t)r1 * r2);
+  const uint64_t cap = std::max<uint64_t>(1, (128ull << 20) / pairs);  // partials stay below 1 GB
+  return (uint32_t)std::min<uint64_t>(std::min<uint64_t>(div_up(n_dims, kSlabDims), cap), 65535);
+}
+static uint32_t slab_dims(uint32_t n_dims, uint32_t slabs) { return (div_up(n_dims, slabs) + kDC - 1) / kDC * kDC; }
+
+// partial[row][z] = sum over the slab of m_c g(a_c)   (block tree; lib/Space.ml:169-178 term by term)
+template <int KIND>
+__global__ __launch_bounds__(256) void row_norm_partial_kernel(const double *__restrict__ m, uint32_t n_dims, uint32_t slab,
+                                                               const double *__restrict__ metric, double p,
+                                                               double *__restrict__ partial) {
+  const uint32_t row = blockIdx.y, z = blockIdx.x;
+  const uint32_t d0 = z * slab, d1 = min(n_dims, d0 + slab);
+  const double *src = m + (uint64_t)row * n_dims;
+  double acc = 0.0;
+  for (uint32_t c = d0 + threadIdx.x; c < d1; c += 256) acc = __dadd_rn(acc, component<KIND>(src[c], metric[c], p));
+  __shared__ double sh[4];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(uint64_t)row * gridDim.x + z] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+template <int KIND>
+__global__ void row_norm_final_kernel(const double *__restrict__ partial, uint32_t rows, uint32_t slabs, double p,
+                                      double *__restrict__ norms) {
+  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  double acc = 0.0;
+  for (uint32_t z = 0; z < slabs; ++z) acc += partial[(uint64_t)row * slabs + z];
+  const double nv = scale_distance<KIND>(acc, p);
+  norms[row] = (nv == 0.0) ? 1.0 : nv;  // lib/Matrix.ml:67
+}
+
+__global__ __launch_bounds__(256) void divide_rows_kernel(const double *__restrict__ m, uint32_t n_dims, const double *__restrict__ norms,
+                                                          double *__restrict__ out) {
+  const uint32_t row = blockIdx.y;
+  const double nv = norms[row];
+  const uint64_t base = (uint64_t)row * n_dims;
+  for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < n_dims; c += gridDim.x * 256) out[base + c] = m[base + c] / nv;
+}
+
+template <int KIND>
+__global__ void reduce_slabs_kernel(const double *__restrict__ partial, uint64_t pairs, uint32_t slabs, double p,
+                                    double *__restrict__ out) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= pairs) return;
+  double acc = 0.0;
+  for (uint32_t z = 0; z < slabs; ++z) acc += partial[(uint64_t)z * pairs + e];
+  out[e] = scale_distance<KIND>(acc, p);
+}
+
 template <int KIND>
 static int rowwise_block(const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims, const double *metric,
                          double p, double *out, hipStream_t st) {
@@ -390,6 +456,40 @@ static int rowwise_block(const double *a, uint32_t r1, const double *b, uint32_t
 template <int KIND>
 static int rowwise_impl(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
                         const double *metric, double p, int normalize, void *work, double *out, hipStream_t st) {
+  if (n_dims >= kLongD) {  // spectral distances: a few rows over millions of k-mers
+    const uint32_t slabs = long_slabs(r1, r2, n_dims), slab = slab_dims(n_dims, slabs);
+    DistWork w = carve(work, r1, r2, n_dims);
+    double *partial = w.b + (uint64_t)r2 * n_dims;  // [slabs][r2][r1], then [r1 + r2][slabs] for the norms
+    double *npart = partial + (uint64_t)slabs * r1 * r2;
+    const double *a = m1, *b = m2;
+    if (normalize) {
+      const double *src[2] = {m1, m2};
+      double *nrm[2] = {w.n1, w.n2}, *dst[2] = {w.a, w.b};
+      const uint32_t rows[2] = {r1, r2};
+      for (int o = 0; o < 2; ++o) {
+        if (rows[o] > 65535) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "distance_rowwise: more than 65535 rows of %u dimensions", n_dims);
+        row_norm_partial_kernel<KIND><<<dim3(slabs, rows[o]), dim3(256), 0, st>>>(src[o], n_dims, slab, metric, p, npart);
+        KPOP_LAUNCH_CHECK();
+        row_norm_final_kernel<KIND><<<dim3(div_up(rows[o], 256)), dim3(256), 0, st>>>(npart, rows[o], slabs, p, nrm[o]);
+        KPOP_LAUNCH_CHECK();
+        divide_rows_kernel<<<dim3(std::min<uint32_t>(div_up(n_dims, 256), 1024), rows[o]), dim3(256), 0, st>>>(src[o], n_dims, nrm[o], dst[o]);
+        KPOP_LAUNCH_CHECK();
+      }
+      a = w.a;
+      b = w.b;
+    }
+    const uint32_t n_tiles = std::max(1u, r1 / 64);
+    const uint32_t wt = div_up(r1, n_tiles), n_cg = div_up(wt, 4);
+    const uint32_t n_rg = std::min(256u / n_cg, (uint32_t)kMaxTJ / 4), TJ = 4 * n_rg;
+    if (div_up(r2, TJ) > 65535) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "distance_rowwise: too many rows in the second operand (%u)", r2);
+    distance_rowwise_kernel<KIND, true><<<dim3(div_up(r1, wt), div_up(r2, TJ), slabs), dim3(256), 0, st>>>(
+        a, wt, r1, b, r2, n_dims, metric, p, partial, n_cg, n_rg, slab);
+    KPOP_LAUNCH_CHECK();
+    const uint64_t pairs = (uint64_t)r1 * r2;
+    reduce_slabs_kernel<KIND><<<dim3(div_up(pairs, 256)), dim3(256), 0, st>>>(partial, pairs, slabs, p, out);
+    KPOP_LAUNCH_CHECK();
+    return 0;
+  }
   const double *a, *b;
   KPOP_TRY(prepare_operands<KIND>(m1, r1, m2, r2, n_dims, metric, p, normalize, work, &a, &b, st));
   return rowwise_block<KIND>(a, r1, b, r2, n_dims, metric, p, out, st);
@@ -526,7 +626,12 @@ extern "C" int kpop_embeddings(const double *m, uint32_t rows, uint32_t n_dims, 
 }
 
 extern "C" uint64_t kpop_dev_distance_workspace_bytes(uint32_t r1, uint32_t r2, uint32_t n_dims) {
-  return ((uint64_t)r1 + r2 + ((uint64_t)r1 + r2) * n_dims) * sizeof(double) + 64;
+  uint64_t doubles = (uint64_t)r1 + r2 + ((uint64_t)r1 + r2) * n_dims;
+  if (n_dims >= kLongD) {  // slab partials of the distances and of the norms
+    const uint64_t slabs = long_slabs(r1, r2, n_dims);
+    doubles += slabs * r1 * r2 + slabs * std::max(r1, r2);
+  }
+  return doubles * sizeof(double) + 64;
 }
 
 extern "C" int kpop_dev_distance_rowwise(const double *d_m1, uint32_t r1, const double *d_m2, uint32_t r2,

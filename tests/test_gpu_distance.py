@@ -255,3 +255,22 @@ def test_config4_one_million_reads_pipeline(kpop, oracle):
         lo, hi = shard_bounds(n, r, 8)
         part = pipe.count_twist(bases[lo * L:hi * L], offs[lo:hi + 1] - offs[lo], L)
         assert torch.equal(part, twisted[lo:hi])
+
+
+@pytest.mark.parametrize("kind,p", [(0, 2.0), (1, 2.0), (2, 1.5)])
+@pytest.mark.parametrize("r1,r2,d", [(7, 5, 40_000), (65, 65, 70_001), (1, 3, 524_800)])
+def test_distance_rowwise_long_rows(kpop, oracle, kind, p, r1, r2, d):
+    """Spectral distances (KPopCountDB --distances): a few rows over very many dimensions take the slab-summed path
+    (n_dims >= 32768); sums of slab sums differ from the reference's running sum by rounding only."""
+    rng = np.random.RandomState(r1 * 31 + r2 + d % 97)
+    m1 = rng.poisson(3.0, size=(r1, d)).astype(np.float64)
+    m2 = rng.poisson(3.0, size=(r2, d)).astype(np.float64)
+    m1 /= m1.sum(axis=1, keepdims=True)
+    m2 /= m2.sum(axis=1, keepdims=True)
+    m2[0] = m1[0]                                   # one coincident pair: distance exactly 0
+    metric = np.ones(d)
+    for normalize in (True, False):
+        got = kpop.distance_rowwise(m1, m2, metric, kind, p, normalize)
+        want = oracle.distance_rowwise(m1, m2, metric, kind, p, normalize)
+        assert got.shape == (r2, r1) and got[0, 0] == 0.0
+        np.testing.assert_allclose(got, want, rtol=1e-11, atol=0)
