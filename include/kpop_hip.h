@@ -26,7 +26,9 @@
  * k-mer encoding (declared by this repository, see kpop_amd/csrc/kmer.h; the
  * reference keeps it in the absent BiOCamLib): A0 C1 G2 T3 either case,
  * big-endian 2-bit packing, DNA-ds key = min(fwd, reverse complement), any
- * other byte breaks the window.
+ * other byte breaks the window.  Protein k-mers (KMers.ProteinHash): the 20 standard amino acids in alphabetical
+ * order of their one-letter codes are 0..19, 5 bits per residue big-endian, any other byte breaks the window;
+ * names are ceil(5k/4) hex digits.  Twisting takes hashes of either kind (they are just column keys).
  */
 #ifndef KPOP_HIP_H
 #define KPOP_HIP_H
@@ -50,6 +52,7 @@ typedef enum {
 /* bin/KPopCount.ml:66-82 (Content.t) */
 #define KPOP_DNA_DS 0
 #define KPOP_DNA_SS 1
+#define KPOP_PROTEIN 2 /* counting entry points only (kpop_count_reads, kpop_dev_count_reads), k <= 12 */
 /* lib/Space.ml:140-143 (Distance.t) */
 #define KPOP_EUCLIDEAN 0
 #define KPOP_COSINE 1

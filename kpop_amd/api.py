@@ -17,7 +17,7 @@ import numpy as np
 from . import _lib
 from ._lib import KPopError, check  # noqa: F401
 
-DNA_DS, DNA_SS = 0, 1
+DNA_DS, DNA_SS, PROTEIN = 0, 1, 2
 EUCLIDEAN, COSINE, MINKOWSKI = 0, 1, 2
 METRIC_FLAT, METRIC_POWERS = 0, 1
 

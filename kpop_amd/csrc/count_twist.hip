@@ -40,7 +40,7 @@ struct WaveLds {
 // ---------------------------------------------------------------------------
 // count: one wave per read -> fixed-stride scratch rows of (hash, count)
 // ---------------------------------------------------------------------------
-template <int R, typename H>
+template <int R, typename H, int SB = 2>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void count_wave_kernel(
     const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ read_ids,
     uint32_t n, int k, int content, uint32_t stride, uint64_t *__restrict__ scr_hash,
@@ -58,9 +58,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void count_wave_kernel(
     return;
   }
 
-  wave_stage_codes<R>(bases + off, len, lane, L.codes);
+  wave_stage_codes<R, SB>(bases + off, len, lane, L.codes);
   H key[R];
-  wave_hash_windows<R, H>(L.codes, k, content, lane, key);
+  wave_hash_windows<R, H, SB>(L.codes, k, content, lane, key);
   wave_bitonic_sort<R, H>(key, lane);
   uint32_t n_valid;
   const uint32_t nu = wave_unique<R, H>(key, (H)~(H)0, lane, L.key, L.start, n_valid);
@@ -432,18 +432,38 @@ static int pick_R(uint32_t max_windows) {
   return 0;
 }
 
-template <typename H>
-static int launch_count_wave(int R, const uint8_t *bases, const uint64_t *offsets, const uint32_t *ids, uint32_t n, int k,
-                             int content, uint32_t stride, uint64_t *sh, uint32_t *sc, uint32_t *nu, hipStream_t st) {
+template <typename H, int SB>
+static int launch_count_wave_sb(int R, const uint8_t *bases, const uint64_t *offsets, const uint32_t *ids, uint32_t n, int k,
+                                int content, uint32_t stride, uint64_t *sh, uint32_t *sc, uint32_t *nu, hipStream_t st) {
   dim3 grid(div_up(n, kWavesPerBlock)), block(64 * kWavesPerBlock);
   switch (R) {
-    case 1: count_wave_kernel<1, H><<<grid, block, 0, st>>>(bases, offsets, ids, n, k, content, stride, sh, sc, nu); break;
-    case 2: count_wave_kernel<2, H><<<grid, block, 0, st>>>(bases, offsets, ids, n, k, content, stride, sh, sc, nu); break;
-    case 4: count_wave_kernel<4, H><<<grid, block, 0, st>>>(bases, offsets, ids, n, k, content, stride, sh, sc, nu); break;
-    case 8: count_wave_kernel<8, H><<<grid, block, 0, st>>>(bases, offsets, ids, n, k, content, stride, sh, sc, nu); break;
+    case 1: count_wave_kernel<1, H, SB><<<grid, block, 0, st>>>(bases, offsets, ids, n, k, content, stride, sh, sc, nu); break;
+    case 2: count_wave_kernel<2, H, SB><<<grid, block, 0, st>>>(bases, offsets, ids, n, k, content, stride, sh, sc, nu); break;
+    case 4: count_wave_kernel<4, H, SB><<<grid, block, 0, st>>>(bases, offsets, ids, n, k, content, stride, sh, sc, nu); break;
+    case 8: count_wave_kernel<8, H, SB><<<grid, block, 0, st>>>(bases, offsets, ids, n, k, content, stride, sh, sc, nu); break;
     default: KPOP_FAIL(KPOP_ERR_INVALID, "launch_count_wave: R=%d", R);
   }
   KPOP_LAUNCH_CHECK();
+  return 0;
+}
+
+// keys are 32-bit while the hash (2 bits per base, 5 per residue) leaves the all-ones sentinel free: <= 30 bits
+static int launch_count_wave(int R, const uint8_t *bases, const uint64_t *offsets, const uint32_t *ids, uint32_t n, int k,
+                             int content, uint32_t stride, uint64_t *sh, uint32_t *sc, uint32_t *nu, hipStream_t st) {
+  const bool narrow = hash_bits(k, content) <= 30;
+  if (content == KPOP_PROTEIN)
+    return narrow ? launch_count_wave_sb<uint32_t, 5>(R, bases, offsets, ids, n, k, content, stride, sh, sc, nu, st)
+                  : launch_count_wave_sb<uint64_t, 5>(R, bases, offsets, ids, n, k, content, stride, sh, sc, nu, st);
+  return narrow ? launch_count_wave_sb<uint32_t, 2>(R, bases, offsets, ids, n, k, content, stride, sh, sc, nu, st)
+                : launch_count_wave_sb<uint64_t, 2>(R, bases, offsets, ids, n, k, content, stride, sh, sc, nu, st);
+}
+
+// k range and content of the counting entry points (bin/KPopCount.ml:113: <= 30 for DNA, <= 12 for protein)
+static int check_count_args(int k, int content, const char *who) {
+  if (content != KPOP_DNA_DS && content != KPOP_DNA_SS && content != KPOP_PROTEIN)
+    KPOP_FAIL(KPOP_ERR_INVALID, "%s: Invalid_content(%d)", who, content);
+  const int kmax = content == KPOP_PROTEIN ? kMaxKProtein : kMaxK;
+  if (k < 1 || k > kmax) KPOP_FAIL(KPOP_ERR_INVALID, "%s: k=%d out of range 1..%d", who, k, kmax);
   return 0;
 }
 
@@ -513,7 +533,7 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   KPOP_TRY(require_init());
   if (!tw || !d_offsets || !d_out) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_count_twist: null argument");
   if (content != KPOP_DNA_DS && content != KPOP_DNA_SS)
-    KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_count_twist: content %d (protein k-mers are not on the HIP path)", content);
+    KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_count_twist: content %d (the fused path is DNA only; protein spectra go through kpop_count_reads and kpop_twist)", content);
   if (n_reads == 0) return KPOP_OK;
   hipStream_t st = as_stream(stream);
   const uint32_t max_windows = (max_len >= (uint32_t)tw->k) ? max_len - tw->k + 1 : 0;
@@ -570,9 +590,7 @@ extern "C" int kpop_dev_count_reads(const uint8_t *d_bases, const uint64_t *d_of
   KPOP_TRY(require_init());
   if (!d_offsets || !d_scratch || !d_out_hash || !d_out_count || !d_out_offsets)
     KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_count_reads: null argument");
-  if (k < 1 || k > kMaxK) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_count_reads: k=%d out of range 1..%d", k, kMaxK);
-  if (content != KPOP_DNA_DS && content != KPOP_DNA_SS)
-    KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_count_reads: content %d (protein k-mers are not on the HIP path)", content);
+  KPOP_TRY(check_count_args(k, content, "kpop_dev_count_reads"));
   const uint32_t max_windows = (max_len >= (uint32_t)k) ? max_len - k + 1 : 0;
   if (max_windows > kWaveMaxWindows)
     KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_count_reads: reads of more than %u windows go through kpop_count_reads", kWaveMaxWindows);
@@ -588,10 +606,7 @@ extern "C" int kpop_dev_count_reads(const uint8_t *d_bases, const uint64_t *d_of
   uint32_t *sc = reinterpret_cast<uint32_t *>(p + (uint64_t)n_reads * stride * 8);
   uint32_t *nu = sc + (uint64_t)n_reads * stride;
   uint64_t *sums = reinterpret_cast<uint64_t *>((reinterpret_cast<uintptr_t>(nu + n_reads) + 63) & ~(uintptr_t)63);
-  if (k <= 15)
-    KPOP_TRY(launch_count_wave<uint32_t>(R, d_bases, d_offsets, nullptr, n_reads, k, content, stride, sh, sc, nu, st));
-  else
-    KPOP_TRY(launch_count_wave<uint64_t>(R, d_bases, d_offsets, nullptr, n_reads, k, content, stride, sh, sc, nu, st));
+  KPOP_TRY(launch_count_wave(R, d_bases, d_offsets, nullptr, n_reads, k, content, stride, sh, sc, nu, st));
   KPOP_TRY(exclusive_scan(LoadU32{nu}, StoreOffsets{d_out_offsets}, n_reads, sums, st));
   // offsets[n_reads] = total, still on the device
   KPOP_HIP(hipMemcpyAsync(d_out_offsets + n_reads, sums + scan_blocks(n_reads), 8, hipMemcpyDeviceToDevice, st));
@@ -624,9 +639,7 @@ extern "C" int kpop_count_reads(const uint8_t *bases, const uint64_t *offsets, u
   ArenaScope scratch;
   if (!offsets || !out_offsets || (!out_hash && out_capacity) || (!out_count && out_capacity))
     KPOP_FAIL(KPOP_ERR_INVALID, "kpop_count_reads: null argument");
-  if (k < 1 || k > kMaxK) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_count_reads: k=%d out of range 1..%d", k, kMaxK);
-  if (content != KPOP_DNA_DS && content != KPOP_DNA_SS)
-    KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_count_reads: content %d (protein k-mers are not on the HIP path)", content);
+  KPOP_TRY(check_count_args(k, content, "kpop_count_reads"));
   if (per_read) out_offsets[0] = 0; else out_offsets[0] = out_offsets[1] = 0;
   if (n_reads == 0) return KPOP_OK;
   uint64_t max_len = 0;
@@ -639,7 +652,7 @@ extern "C" int kpop_count_reads(const uint8_t *bases, const uint64_t *offsets, u
   }
   if (max_windows > kWaveMaxWindows) {
     // genomes: sort path, in sub-batches whose (spectrum id | hash) keys fit 63 bits
-    const int id_bits_max = 63 - 2 * k;
+    const int id_bits_max = 63 - hash_bits(k, content);
     const uint64_t sub = id_bits_max >= 32 ? n_reads : std::max<uint64_t>(1, 1ull << id_bits_max);
     uint64_t pos = 0;
     std::vector<uint64_t> loc;
@@ -671,12 +684,8 @@ extern "C" int kpop_count_reads(const uint8_t *bases, const uint64_t *offsets, u
   for (uint32_t r = 0; r <= n_reads; ++r) rel[r] = offsets[r] - base0;
   if (n_bases) KPOP_HIP(hipMemcpyAsync(d_bases.p, bases + base0, n_bases, hipMemcpyHostToDevice, st));
   KPOP_HIP(hipMemcpyAsync(d_off.p, rel.data(), (uint64_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
-  if (k <= 15)
-    KPOP_TRY(launch_count_wave<uint32_t>(R, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), nullptr, n_reads, k, content,
-                                         stride, d_sh.as<uint64_t>(), d_sc.as<uint32_t>(), d_nu.as<uint32_t>(), st));
-  else
-    KPOP_TRY(launch_count_wave<uint64_t>(R, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), nullptr, n_reads, k, content,
-                                         stride, d_sh.as<uint64_t>(), d_sc.as<uint32_t>(), d_nu.as<uint32_t>(), st));
+  KPOP_TRY(launch_count_wave(R, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), nullptr, n_reads, k, content, stride,
+                             d_sh.as<uint64_t>(), d_sc.as<uint32_t>(), d_nu.as<uint32_t>(), st));
   KPOP_TRY(exclusive_scan(LoadU32{d_nu.as<uint32_t>()}, StoreOffsets{d_oo.as<uint64_t>()}, n_reads,
                           d_sums.as<uint64_t>(), st));
   uint64_t total = 0;

@@ -8,6 +8,12 @@
 //   - hash:       big-endian 2-bit packing (first base most significant)
 //   - DNA-ds key: min(hash(fwd), hash(reverse complement))
 //   - name:       lowercase hex, zero padded to ceil(k/2) digits
+// Protein k-mers (KMers.ProteinHash, bin/KPopCount.ml:246-248; counting only, k <= 12):
+//   - residue code: the 20 standard amino acids in alphabetical order of their one-letter codes
+//                   (A0 C1 D2 E3 F4 G5 H6 I7 K8 L9 M10 N11 P12 Q13 R14 S15 T16 V17 W18 Y19), either case;
+//                   anything else (B J O U X Z * ...) breaks the window
+//   - hash:         big-endian 5-bit packing; no reverse complement
+//   - name:         lowercase hex, zero padded to ceil(5k/4) digits
 #pragma once
 #include <stdint.h>
 
@@ -20,7 +26,24 @@
 
 namespace kpop {
 
-constexpr int kMaxK = 30;  // bin/KPopCount.ml:113
+constexpr int kMaxK = 30;         // bin/KPopCount.ml:113
+constexpr int kMaxKProtein = 12;  // same line: "<= 12 for protein"
+constexpr int kContentProtein = 2;  // KPOP_PROTEIN of include/kpop_hip.h
+
+KPOP_HD int symbol_bits(int content) { return content == kContentProtein ? 5 : 2; }
+KPOP_HD int hash_bits(int k, int content) { return symbol_bits(content) * k; }
+KPOP_HD uint64_t bits_mask(int bits) { return (bits >= 64) ? ~0ull : ((1ull << bits) - 1ull); }
+
+// 0..19 for the standard amino acids in either case, 31 for everything else.  The 26-letter table
+//   A0 B- C1 D2 E3 F4 G5 H6 I7 J- K8 L9 | M10 N11 O- P12 Q13 R14 S15 T16 U- V17 W18 X- | Y19 Z-
+// is packed 5 bits per letter, 12 letters per word.
+KPOP_HD uint32_t protein_code(uint32_t c) {
+  const uint32_t u = c & 0xDFu;  // fold case
+  if (u < 'A' || u > 'Z') return 31u;
+  const uint32_t i = u - 'A';
+  const uint64_t w = i < 12 ? 0x4a3e731483107e0ull : (i < 24 ? 0xfca3f83dcd67d6aull : 0xffffffffffffff3ull);
+  return (uint32_t)(w >> (5u * (i % 12u))) & 31u;
+}
 
 // 0..3 for ACGT in either case, 4 for everything else.
 KPOP_HD uint32_t base_code(uint32_t c) {
@@ -45,5 +68,6 @@ KPOP_HD uint64_t revcomp(uint64_t h, int k) {
 }
 
 inline int hex_digits(int k) { return (k + 1) / 2; }
+inline int hex_digits_bits(int bits) { return (bits + 3) / 4; }
 
 }  // namespace kpop

@@ -23,16 +23,18 @@ constexpr int codes_bytes() { return 64 * R + 32; }
 // Stage the read as base codes (0..3, 4 = breaks the window) into s_codes;
 // everything past the read's end is 4, so windows running off the end are
 // rejected by the same test as windows over an N.
-template <int R>
+// SB = bits per symbol: 2 = DNA (codes 0..3, 4 breaks), 5 = protein (codes 0..19, 31 breaks)
+template <int R, int SB = 2>
 __device__ __forceinline__ void wave_stage_codes(const uint8_t *__restrict__ seq, uint32_t len, int lane,
                                                  uint8_t *s_codes) {
   constexpr int NB = codes_bytes<R>();
+  constexpr uint32_t kBreak = SB == 2 ? 4u : 31u;
 #pragma unroll
   for (int i = 0; i < (NB + 63) / 64; ++i) {
     int p = i * 64 + lane;
     if (p < NB) {
-      uint32_t c = 4u;
-      if ((uint32_t)p < len) c = base_code(seq[p]);
+      uint32_t c = kBreak;
+      if ((uint32_t)p < len) c = SB == 2 ? base_code(seq[p]) : protein_code(seq[p]);
       s_codes[p] = (uint8_t)c;
     }
   }
@@ -41,27 +43,28 @@ __device__ __forceinline__ void wave_stage_codes(const uint8_t *__restrict__ seq
 
 // H = uint32_t for k <= 16, uint64_t above.  key[r] = canonical hash of window
 // lane*R+r, or the all-ones sentinel when the window is invalid.
-template <int R, typename H>
+template <int R, typename H, int SB = 2>
 __device__ __forceinline__ void wave_hash_windows(const uint8_t *s_codes, int k, int content, int lane,
                                                   H (&key)[R]) {
-  const H mask = (H)kmer_mask(k);
-  const int shift = 2 * (k - 1);
+  const H mask = (H)bits_mask(SB * k);
+  const int shift = SB * (k - 1);
+  constexpr uint32_t kSym = (1u << SB) - 1u, kValid = SB == 2 ? 4u : 20u;
   const uint8_t *p = s_codes + lane * R;
   H fwd = 0, rc = 0;
   int run = 0;
   for (int j = 0; j < k - 1; ++j) {
     uint32_t c = p[j];
-    fwd = ((fwd << 2) | (H)(c & 3u)) & mask;
-    rc = (rc >> 2) | ((H)(3u - (c & 3u)) << shift);
-    run = (c < 4u) ? run + 1 : 0;
+    fwd = ((fwd << SB) | (H)(c & kSym)) & mask;
+    if (SB == 2) rc = (rc >> 2) | ((H)(3u - (c & 3u)) << shift);
+    run = (c < kValid) ? run + 1 : 0;
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     uint32_t c = p[k - 1 + r];
-    fwd = ((fwd << 2) | (H)(c & 3u)) & mask;
-    rc = (rc >> 2) | ((H)(3u - (c & 3u)) << shift);
-    run = (c < 4u) ? run + 1 : 0;
-    H canon = (content == KPOP_DNA_DS && rc < fwd) ? rc : fwd;
+    fwd = ((fwd << SB) | (H)(c & kSym)) & mask;
+    if (SB == 2) rc = (rc >> 2) | ((H)(3u - (c & 3u)) << shift);
+    run = (c < kValid) ? run + 1 : 0;
+    H canon = (SB == 2 && content == KPOP_DNA_DS && rc < fwd) ? rc : fwd;
     key[r] = (run >= k) ? canon : (H)~(H)0;
   }
 }

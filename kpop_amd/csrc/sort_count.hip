@@ -37,16 +37,23 @@ __global__ __launch_bounds__(256) void window_keys_kernel(const uint8_t *__restr
   if (w0 >= n_win) continue;
   const uint64_t w1 = min(n_win, w0 + kKeySeg);
   const uint8_t *seq = bases + off;
-  const int shift = 2 * (k - 1);
-  const uint64_t id = per_read ? ((uint64_t)(first_id + r) << (2 * k)) : 0ull;
+  const bool protein = content == KPOP_PROTEIN;
+  const int sb = symbol_bits(content), shift = sb * (k - 1);
+  const uint64_t id = per_read ? ((uint64_t)(first_id + r) << (sb * k)) : 0ull;
   for (uint64_t w = w0 + threadIdx.x; w < w1; w += 256) {
     H fwd = 0, rc = 0;
     bool good = true;
     for (int j = 0; j < k; ++j) {
-      const uint32_t c = base_code(seq[w + j]);
-      good = good && (c < 4u);
-      fwd = (fwd << 2) | (H)(c & 3u);
-      rc = (rc >> 2) | ((H)(3u - (c & 3u)) << shift);
+      if (protein) {
+        const uint32_t c = protein_code(seq[w + j]);
+        good = good && (c < 20u);
+        fwd = (fwd << 5) | (H)(c & 31u);
+      } else {
+        const uint32_t c = base_code(seq[w + j]);
+        good = good && (c < 4u);
+        fwd = (fwd << 2) | (H)(c & 3u);
+        rc = (rc >> 2) | ((H)(3u - (c & 3u)) << shift);
+      }
     }
     const uint64_t h = (uint64_t)((content == KPOP_DNA_DS && rc < fwd) ? rc : fwd);
     keys[woff[r] + w] = good ? (id | h) : ~0ull;
@@ -96,11 +103,11 @@ __global__ void finish_spectra_kernel(const uint64_t *__restrict__ uniq, const u
 
 // offsets[s] = first distinct key whose spectrum id is >= first_id + s (s = 0..n_spectra)
 __global__ void spectrum_bounds_kernel(const uint64_t *__restrict__ uniq, const uint64_t *__restrict__ n_unique_p,
-                                       uint32_t n_spectra, uint32_t first_id, int k, uint64_t *__restrict__ offsets) {
+                                       uint32_t n_spectra, uint32_t first_id, int hash_bits, uint64_t *__restrict__ offsets) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s > n_spectra) return;
   const uint64_t nu = *n_unique_p;
-  const uint64_t target = (uint64_t)(first_id + s) << (2 * k);
+  const uint64_t target = (uint64_t)(first_id + s) << hash_bits;
   uint64_t lo = 0, hi = nu;
   while (lo < hi) {
     const uint64_t mid = (lo + hi) >> 1;
@@ -135,7 +142,8 @@ int sorted_count_batch(const uint8_t *bases, const uint64_t *offsets, uint32_t n
   int id_bits = 0;
   while (per_read && (1ull << id_bits) < (uint64_t)n_reads) ++id_bits;
   // one more bit than the valid keys use: the all-ones sentinel of invalid windows must sort after them
-  const int bits = 2 * k + id_bits + 1;
+  const int hb = hash_bits(k, content);
+  const int bits = hb + id_bits + 1;
   if (bits > 64) KPOP_FAIL(KPOP_ERR_INVALID, "sorted_count_batch: %d key bits (caller must split the batch)", bits);
   const uint32_t max_seg = div_up(max_win, kKeySeg);
   DevBuf d_bases, d_off, d_woff, d_ka, d_kb, d_scr, d_start, d_sums, d_tot;
@@ -152,7 +160,7 @@ int sorted_count_batch(const uint8_t *bases, const uint64_t *offsets, uint32_t n
   KPOP_HIP(hipMemcpyAsync(d_off.p, rel.data(), (uint64_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
   KPOP_HIP(hipMemcpyAsync(d_woff.p, woff.data(), (uint64_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
   dim3 grid(capped_grid((uint64_t)n_reads * max_seg));
-  if (k <= 15)
+  if (hb <= 30)
     window_keys_kernel<uint32_t><<<grid, dim3(256), 0, st>>>(d_bases.as<uint8_t>(), d_off.as<uint64_t>(),
                                                              d_woff.as<uint64_t>(), k, content, per_read, 0u,
                                                              d_ka.as<uint64_t>(), n_reads, max_seg);
@@ -181,12 +189,12 @@ int sorted_count_batch(const uint8_t *bases, const uint64_t *offsets, uint32_t n
   KPOP_TRY(d_oo.alloc((uint64_t)(n_spectra + 1) * 8));
   if (nu) {
     finish_spectra_kernel<<<dim3(std::min<uint32_t>(div_up(nu, 256), 8192)), dim3(256), 0, st>>>(
-        other, d_start.as<uint64_t>(), d_nu, d_nv, kmer_mask(k), d_oh.as<uint64_t>(), d_oc.as<uint32_t>());
+        other, d_start.as<uint64_t>(), d_nu, d_nv, bits_mask(hb), d_oh.as<uint64_t>(), d_oc.as<uint32_t>());
     KPOP_LAUNCH_CHECK();
   }
   if (per_read) {
     spectrum_bounds_kernel<<<dim3(div_up((uint64_t)n_spectra + 1, 256)), dim3(256), 0, st>>>(other, d_nu, n_spectra, 0u,
-                                                                                              k, d_oo.as<uint64_t>());
+                                                                                              hb, d_oo.as<uint64_t>());
     KPOP_LAUNCH_CHECK();
     KPOP_HIP(hipMemcpyAsync(out_offsets, d_oo.p, (uint64_t)(n_spectra + 1) * 8, hipMemcpyDeviceToHost, st));
   } else {

@@ -14,7 +14,8 @@
 //     that consumers re-sum, bin/KPopCount.ml:39-50);
 //   * a runtime failure exits with status 1 (the reference's DB tools print
 //     the exception and exit 0);
-//   * protein content is refused (not on the HIP path).
+//   * protein k-mers use the residue encoding declared in csrc/kmer.h (the reference's lives in the absent BiOCamLib);
+//     Sequences.Lint.proteinize is taken as dnaize's twin: upper-case, dashes and blanks dropped.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -52,7 +53,7 @@ void usage(FILE *f) {
   fprintf(f,
           "This is KPopCount (MI355X/HIP hot path) version %s\n"
           "Usage: KPopCount -l <output_vector_label>|-L [OPTIONS]\n"
-          " -k|-K|--k-mer-size|--k-mer-length <k>   k-mer length (1..30 for DNA; default 12)\n"
+          " -k|-K|--k-mer-size|--k-mer-length <k>   k-mer length (1..30 for DNA, 1..12 for protein; default 12)\n"
           " -M|--max-results-size <n>               accepted for compatibility (nothing is spilled)\n"
           " -C|--content DNA-ss|DNA-single-stranded|DNA-ds|DNA-double-stranded|protein   (default DNA-ds)\n"
           " -f|--fasta <file>                       FASTA input (repeatable)\n"
@@ -118,7 +119,7 @@ void process_batch(const Params &P, const ReadBatch &b, FILE *out, Merged &merge
   if (per_read) {  // bin/KPopCount.ml:44-46
     std::vector<std::string> labels(b.size());
     for (size_t r = 0; r < b.size(); ++r) labels[r] = strip_external_quotes_and_check(b.tags[r]);
-    write_spectra_parallel(out, labels, oh.data(), oc.data(), oo.data(), P.k);
+    write_spectra_parallel(out, labels, oh.data(), oc.data(), oo.data(), name_digits(P.k, P.content == KPOP_PROTEIN));
   } else {
     merged.add(oh.data(), oc.data(), oo[1]);
   }
@@ -145,7 +146,7 @@ int main(int argc, char **argv) {
       const std::string c = need(i, a.c_str());
       if (c == "DNA-ss" || c == "DNA-single-stranded") P.content = KPOP_DNA_SS;
       else if (c == "DNA-ds" || c == "DNA-double-stranded") P.content = KPOP_DNA_DS;
-      else if (c == "protein" || c == "prot") parse_error("protein content is not supported by the HIP path");
+      else if (c == "protein" || c == "prot") P.content = KPOP_PROTEIN;
       else parse_error("Invalid_content(\"" + c + "\")");
     } else if (a == "-f" || a == "--fasta") {
       P.inputs.push_back({SeqFormat::FASTA, need(i, a.c_str()), ""});
@@ -179,7 +180,7 @@ int main(int argc, char **argv) {
     }
   }
   if (!P.have_l_or_L) parse_error("One of options '-l' and '-L' is mandatory");  // :213-214
-  if (P.k > 30) parse_error("k-mer length must be <= 30 for DNA");                // :113
+  if (P.content == KPOP_PROTEIN ? P.k > 12 : P.k > 30) parse_error("k-mer length must be <= 30 for DNA or <= 12 for protein");  // :113
   for (size_t i = 1; i < P.inputs.size(); ++i)
     if (P.inputs[i].fmt != P.inputs[0].fmt) parse_error("You cannot process FASTA and FASTQ inputs together");  // :236
   if (P.inputs.empty()) return 0;  // :218
@@ -241,7 +242,7 @@ int main(int argc, char **argv) {
         if (merged.count[i] > 0x7FFFFFFFull) throw Error("k-mer count exceeds 2^31-1");
         c32[i] = (uint32_t)merged.count[i];
       }
-      write_spectrum_body(out, merged.hash.data(), c32.data(), c32.size(), P.k);
+      write_spectrum_body(out, merged.hash.data(), c32.data(), c32.size(), name_digits(P.k, P.content == KPOP_PROTEIN));
     }
     if (P.verbose) fprintf(stderr, "(KPopCount): Added %llu reads.\n", (unsigned long long)n_reads);
     if (out != stdout) fclose(out);

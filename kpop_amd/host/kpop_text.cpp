@@ -393,11 +393,10 @@ void read_spectra_hashed(const std::string &path, size_t name_len, uint64_t abse
 }
 
 void write_spectra_parallel(FILE *f, const std::vector<std::string> &labels, const uint64_t *hash, const uint32_t *count,
-                            const uint64_t *offsets, int k, unsigned threads) {
+                            const uint64_t *offsets, int digits, unsigned threads) {
   const size_t n = labels.size();
   if (n == 0) return;
   const unsigned T = pick_threads(threads, (size_t)(offsets[n] - offsets[0]), 1u << 18);
-  const int digits = (k + 1) / 2;
   std::vector<std::string> text(T);
   auto work = [&](unsigned t) {
     const size_t lo = n * t / T, hi = n * (t + 1) / T;
@@ -440,9 +439,8 @@ void write_spectra_parallel(FILE *f, const std::vector<std::string> &labels, con
     if (fwrite(o.data(), 1, o.size(), f) != o.size()) throw Error(std::string("write failed: ") + strerror(errno));
 }
 
-void write_spectrum_body(FILE *f, const uint64_t *hash, const uint32_t *count, uint64_t n, int k) {
+void write_spectrum_body(FILE *f, const uint64_t *hash, const uint32_t *count, uint64_t n, int digits) {
   // "%s\t%d\n" (KIH.to_hex k) f, bin/KPopCount.ml:46,60
-  const int digits = (k + 1) / 2;
   char buf[64];
   static const char hx[] = "0123456789abcdef";
   for (uint64_t i = 0; i < n; ++i) {
@@ -457,9 +455,9 @@ void write_spectrum_body(FILE *f, const uint64_t *hash, const uint32_t *count, u
   }
 }
 
-void write_spectrum(FILE *f, const std::string &label, const uint64_t *hash, const uint32_t *count, uint64_t n, int k) {
+void write_spectrum(FILE *f, const std::string &label, const uint64_t *hash, const uint32_t *count, uint64_t n, int digits) {
   fprintf(f, "\t%s\n", label.c_str());  // bin/KPopCount.ml:34,45
-  write_spectrum_body(f, hash, count, n, k);
+  write_spectrum_body(f, hash, count, n, digits);
 }
 
 // ------------------------------------------------------------------ tables

@@ -71,7 +71,9 @@ struct Spectra {  // CSR over spectra, lines in file order
 // Parses one file (or /dev/stdin) appending to `out`.  Errors mirror the reference's exceptions:
 // Wrong_number_of_columns (:103-104), Header_expected (:106-107), Float_expected (:155-157).
 void read_spectra_file(const std::string &path, Spectra &out);
-void write_spectrum(FILE *f, const std::string &label, const uint64_t *hash, const uint32_t *count, uint64_t n, int k);
+// hex digits of a k-mer name: ceil(2k/4) for DNA, ceil(5k/4) for protein (encodings declared in csrc/kmer.h)
+inline int name_digits(int k, bool protein) { return protein ? (5 * k + 3) / 4 : (k + 1) / 2; }
+void write_spectrum(FILE *f, const std::string &label, const uint64_t *hash, const uint32_t *count, uint64_t n, int digits);
 
 // The same parser for the GPU path: k-mer names are turned into hashes while parsing (a name that is not `name_len`
 // hexadecimal digits can match no twister column and becomes `absent`), no per-line strings are made, and the file
@@ -87,8 +89,8 @@ void read_spectra_hashed(const std::string &path, size_t name_len, uint64_t abse
 // "\t<label>\n" + "<hex>\t<count>\n"... for reads [0, n) of a CSR result, formatted by several threads and written in
 // order (bin/KPopCount.ml:44-46).  labels must already be checked.
 void write_spectra_parallel(FILE *f, const std::vector<std::string> &labels, const uint64_t *hash, const uint32_t *count,
-                            const uint64_t *offsets, int k, unsigned threads = 0);
-void write_spectrum_body(FILE *f, const uint64_t *hash, const uint32_t *count, uint64_t n, int k);
+                            const uint64_t *offsets, int digits, unsigned threads = 0);
+void write_spectrum_body(FILE *f, const uint64_t *hash, const uint32_t *count, uint64_t n, int digits);
 
 // ---- matrix tables (Appendix A.2; README.md:618-626,643-650; src/KPopTwist:100,108,116) ----
 struct Table {

@@ -94,6 +94,16 @@ int kpo_base_code(uint8_t c) {
   }
 }
 
+void kpo_to_hex_protein(uint64_t hash, int k, char *out) {
+  int digits = (5 * k + 3) / 4;
+  static const char hx[] = "0123456789abcdef";
+  for (int i = digits - 1; i >= 0; --i) {
+    out[i] = hx[hash & 15];
+    hash >>= 4;
+  }
+  out[digits] = 0;
+}
+
 void kpo_to_hex(uint64_t hash, int k, char *out) {
   int digits = (k + 1) / 2; /* ceil(2k/4) */
   static const char hx[] = "0123456789abcdef";
@@ -112,7 +122,35 @@ static int cmp_u64(const void *a, const void *b) {
 /* KIH.iterc res seq (bin/KPopCount.ml:38): every k-window free of non-ACGT
    symbols contributes one increment of its (canonical) hash. Returns number
    of keys written into keys (cap must be >= len). */
+/* residue code of the protein hash declared by this repository (kpop_amd/csrc/kmer.h): the 20 standard amino acids
+   in alphabetical order of their one-letter codes, either case; -1 breaks the window */
+int kpo_protein_code(uint8_t c) {
+  static const char order[] = "ACDEFGHIKLMNPQRSTVWY";
+  if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 'a' + 'A');
+  for (int i = 0; i < 20; ++i)
+    if ((char)c == order[i]) return i;
+  return -1;
+}
+
+static uint64_t iterc_protein(const uint8_t *seq, uint64_t len, int k, uint64_t *keys) {
+  const uint64_t mask = (1ULL << (5 * k)) - 1;
+  uint64_t fwd = 0, n = 0;
+  int run = 0;
+  for (uint64_t i = 0; i < len; ++i) {
+    int c = kpo_protein_code(seq[i]);
+    if (c < 0) {
+      run = 0;
+      fwd = 0;
+      continue;
+    }
+    fwd = ((fwd << 5) | (uint64_t)c) & mask;
+    if (++run >= k) keys[n++] = fwd;
+  }
+  return n;
+}
+
 static uint64_t iterc(const uint8_t *seq, uint64_t len, int k, int content, uint64_t *keys) {
+  if (content == KPO_PROTEIN) return iterc_protein(seq, len, k, keys);
   uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
   uint64_t fwd = 0, rc = 0, n = 0;
   int run = 0;
@@ -147,7 +185,7 @@ static int64_t rle(uint64_t *keys, uint64_t n, uint64_t *out_hash, uint32_t *out
 
 int64_t kpo_count_read(const uint8_t *seq, uint64_t len, int k, int content, uint64_t *out_hash,
                        uint32_t *out_count, uint64_t cap) {
-  if (k < 1 || k > 30) return -2;
+  if (k < 1 || k > (content == KPO_PROTEIN ? 12 : 30)) return -2;
   uint64_t *keys = (uint64_t *)malloc(sizeof(uint64_t) * (len ? len : 1));
   uint64_t n = iterc(seq, len, k, content, keys);
   int64_t u = rle(keys, n, out_hash, out_count, cap);
@@ -158,7 +196,7 @@ int64_t kpo_count_read(const uint8_t *seq, uint64_t len, int k, int content, uin
 int kpo_count_reads(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, int k, int content,
                     int per_read, uint64_t *out_hash, uint32_t *out_count, uint64_t *out_offsets,
                     uint64_t out_capacity) {
-  if (k < 1 || k > 30) return -2;
+  if (k < 1 || k > (content == KPO_PROTEIN ? 12 : 30)) return -2;
   if (per_read) {
     /* -L: dump + clear after every read (bin/KPopCount.ml:39-50) */
     uint64_t pos = 0;

@@ -36,6 +36,7 @@ extern "C" {
 /* content modes: bin/KPopCount.ml:66-82 */
 #define KPO_DNA_DS 0
 #define KPO_DNA_SS 1
+#define KPO_PROTEIN 2 /* counting only; k <= 12; encoding declared in kpop_amd/csrc/kmer.h (PARITY UNPINNED) */
 
 /* distance kinds: lib/Space.ml:140-143 */
 #define KPO_EUCLIDEAN 0
@@ -62,6 +63,8 @@ void kpo_synth_twister(uint64_t seed, uint32_t n_dims, const uint64_t *col_hash,
 /* ---- count: restates KIH.iterc + KIHF (bin/KPopCount.ml:36-50) ---- */
 /* 0..3 for ACGT (either case), -1 otherwise */
 int kpo_base_code(uint8_t c);
+int kpo_protein_code(uint8_t c);
+void kpo_to_hex_protein(uint64_t hash, int k, char *out /* >= 17 bytes */);
 /* hex name of a hash for k: zero padded lowercase, ceil(k/2) digits (bin/KPopCount.ml:46) */
 void kpo_to_hex(uint64_t hash, int k, char *out /* >= 17 bytes */);
 /* one read -> unique (hash,count) ascending by hash.  Returns n_unique, or -1 if cap too small. */

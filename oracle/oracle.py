@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libkpop_oracle.so")
 
-DNA_DS, DNA_SS = 0, 1
+DNA_DS, DNA_SS, PROTEIN = 0, 1, 2
 EUCLIDEAN, COSINE, MINKOWSKI = 0, 1, 2
 
 
@@ -65,6 +65,8 @@ def _declare(L):
     L.kpo_base_code.argtypes = [C.c_uint8]
     L.kpo_to_hex.restype = None
     L.kpo_to_hex.argtypes = [C.c_uint64, C.c_int, C.c_char_p]
+    L.kpo_to_hex_protein.restype = None
+    L.kpo_to_hex_protein.argtypes = [C.c_uint64, C.c_int, C.c_char_p]
     L.kpo_count_read.restype = C.c_int64
     L.kpo_count_read.argtypes = [u8p, C.c_uint64, C.c_int, C.c_int, u64p, u32p, C.c_uint64]
     L.kpo_count_reads.restype = C.c_int
@@ -136,9 +138,9 @@ def synth_inertia(n_dims):
     return w
 
 
-def to_hex(h, k):
+def to_hex(h, k, content=DNA_DS):
     buf = C.create_string_buffer(20)
-    lib().kpo_to_hex(int(h), k, buf)
+    (lib().kpo_to_hex_protein if content == PROTEIN else lib().kpo_to_hex)(int(h), k, buf)
     return buf.value.decode()
 
 

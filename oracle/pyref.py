@@ -40,6 +40,29 @@ def to_hex(h, k):
     return "%0*x" % ((k + 1) // 2, h)
 
 
+_AA = "ACDEFGHIKLMNPQRSTVWY"  # residue codes 0..19 of the declared protein hash (kpop_amd/csrc/kmer.h)
+
+
+def count_read_protein(seq, k):
+    """KMers.ProteinHash (bin/KPopCount.ml:246-248) under the declared encoding: 5 bits per residue, big-endian; a
+    window holding anything but the 20 standard residues contributes nothing."""
+    seq = seq.upper()
+    res = {}
+    for i in range(len(seq) - k + 1):
+        w = seq[i:i + k]
+        if any(ch not in _AA for ch in w):
+            continue
+        h = 0
+        for ch in w:
+            h = h * 32 + _AA.index(ch)
+        res[h] = res.get(h, 0) + 1
+    return res
+
+
+def to_hex_protein(h, k):
+    return "%0*x" % ((5 * k + 3) // 4, h)
+
+
 def spectrum_text(label, table, k):
     """bin/KPopCount.ml:45-46: header '\\t<label>' then 'hex\\tcount' lines."""
     out = ["\t%s\n" % label]

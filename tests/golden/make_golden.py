@@ -129,6 +129,36 @@ def count_fixture():
     dump("count_small.json", {"reads": [[n, s] for n, s in reads], "cases": cases})
 
 
+def protein_fixture():
+    """KPopCount -C protein under the encoding declared in kpop_amd/csrc/kmer.h (5 bits per residue, the 20 standard
+    amino acids in alphabetical order; anything else breaks the window): both restatements, every k from 1 to 12."""
+    rng = np.random.RandomState(12)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    seqs = [("empty", ""), ("short", "MK"), ("with_x", "MKTAYIAKQRXQISFVKSHFSRQ*LEERLG"), ("lower", "mktayiakqrqisf"),
+            ("repeat", "GAGAGAGAGAGAGAGAGAGAGAGA"), ("ambiguous", "BZJOUX")]
+    for i in range(5):
+        seqs.append(("rand%d" % i, "".join(aa[x] for x in rng.randint(0, 20, size=int(rng.randint(15, 400))))))
+    bases, offs = concat([s for _, s in seqs])
+    cases = []
+    for k in range(1, 13):
+        h, c, o = O.count_reads(bases, offs, k, O.PROTEIN, per_read=True)
+        spectra, merged = [], {}
+        for r, (_, s) in enumerate(seqs):
+            got = {int(a): int(b) for a, b in zip(h[int(o[r]):int(o[r + 1])], c[int(o[r]):int(o[r + 1])])}
+            want = P.count_read_protein(s, k)
+            if got != want:
+                raise SystemExit("protein count: restatements disagree on %s k=%d" % (seqs[r][0], k))
+            for a, b in want.items():
+                merged[a] = merged.get(a, 0) + b
+                assert O.to_hex(a, k, O.PROTEIN) == P.to_hex_protein(a, k)
+            spectra.append([[P.to_hex_protein(a, k), int(got[a])] for a in sorted(got)])
+        hm, cm, om = O.count_reads(bases, offs, k, O.PROTEIN, per_read=False)
+        if {int(a): int(b) for a, b in zip(hm, cm)} != merged:
+            raise SystemExit("protein count: merged spectra disagree k=%d" % k)
+        cases.append({"k": k, "spectra": spectra, "merged": [[P.to_hex_protein(a, k), int(merged[a])] for a in sorted(merged)]})
+    dump("count_protein.json", {"reads": [[n, s] for n, s in seqs], "cases": cases})
+
+
 # ---------------------------------------------------------------- twist
 def twist_fixture():
     rng = np.random.RandomState(7)
@@ -282,6 +312,7 @@ if __name__ == "__main__":
     counter_fixture()
     readme_kat()
     count_fixture()
+    protein_fixture()
     twist_fixture()
     distance_fixture()
     wuhan_fixture()

@@ -572,3 +572,47 @@ def test_parallel_text_paths_are_chunking_invariant(tmp_path, oracle, pyref):
         for e in (tiny, one):
             r = subprocess.run([TWISTDB, "-I", "T", str(tmp_path / "Classes"), "-k", str(tmp_path / "bad.txt")], capture_output=True, text=True, env=e)
             assert r.returncode == 1 and what in r.stderr, (what, r.stderr)
+
+
+def test_protein_content_through_the_clis(tmp_path, oracle, pyref):
+    """KPopCount -C protein (bin/KPopCount.ml:246-248) then KPopTwistDB -k on the protein spectra: the twist side only
+    sees column names, so a twister whose columns are protein k-mers works unchanged."""
+    k, d = 3, 6
+    rng = np.random.RandomState(5)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    prots = [("p%d some description" % i, "".join(aa[x] for x in rng.randint(0, 20, size=rng.randint(5, 300)))) for i in range(40)]
+    prots.append(("with-gaps", "MKT-AYI AKQ\tRXQISFVKSHFSRQ*LEERLG"))
+    prots.append(("lower", "mktayiakqrqisfvkshf"))
+    with open(tmp_path / "p.fa", "w") as f:
+        for tag, s in prots:
+            f.write(">%s\n%s\n" % (tag, s))
+
+    def lint(s):
+        return "".join(ch for ch in s.upper() if ch not in "- \t")
+    want = "".join("\t%s\n" % tag + "".join("%s\t%d\n" % (pyref.to_hex_protein(h, k), c) for h, c in sorted(pyref.count_read_protein(lint(s), k).items()))
+                   for tag, s in prots)
+    r = run([COUNT, "-k", str(k), "-C", "protein", "-L", "-f", str(tmp_path / "p.fa")])
+    assert r.returncode == 0 and r.stdout == want, r.stderr
+    merged = {}
+    for _, s in prots:
+        for h, c in pyref.count_read_protein(lint(s), k).items():
+            merged[h] = merged.get(h, 0) + c
+    r = run([COUNT, "-k", str(k), "-C", "prot", "-l", "all", "-f", str(tmp_path / "p.fa")])
+    assert r.stdout == "\tall\n" + "".join("%s\t%d\n" % (pyref.to_hex_protein(h, k), c) for h, c in sorted(merged.items()))
+    r = run([COUNT, "-k", "13", "-C", "protein", "-L", "-f", str(tmp_path / "p.fa")])
+    assert r.returncode == 1 and "<= 12 for protein" in r.stderr
+    # a twister over the protein 3-mers that occur, then README.md:606 with -C protein
+    cols = np.array(sorted(merged), dtype=np.uint64)
+    T = np.array([[float("%.15g" % x) for x in row] for row in oracle.synth_twister(7, d, cols)])
+    dims = ["Dim%d" % (i + 1) for i in range(d)]
+    write_table(tmp_path / "P.KPopTwister.txt", [pyref.to_hex_protein(int(h), k) for h in cols], dims, T)
+    write_table(tmp_path / "P.KPopInertia.txt", dims, ["inertia"], [oracle.synth_inertia(d)])
+    penv = dict(os.environ, PATH=BIN + ":" + os.environ.get("PATH", ""))
+    r = subprocess.run(["bash", "-c", "KPopCount -k %d -C protein -L -f p.fa | KPopTwistDB -I T P -k /dev/stdin -O t /dev/stdout" % k],
+                       cwd=str(tmp_path), capture_output=True, text=True, env=penv)
+    assert r.returncode == 0, r.stderr
+    pb = np.frombuffer("".join(lint(s) for _, s in prots).encode(), dtype=np.uint8)
+    po = np.concatenate([[0], np.cumsum([len(lint(s)) for _, s in prots])]).astype(np.uint64)
+    h, c, o = oracle.count_reads(pb, po, k, oracle.PROTEIN)
+    rows = oracle.twist(T, cols, h, c.astype(np.float64), o)
+    assert r.stdout == twisted_text(dims, [t for t, _ in prots], rows)

@@ -76,7 +76,9 @@ def test_count_errors(kpop):
         with pytest.raises(kpop.KPopError):
             kpop.count_reads(bases, offs, k)
     with pytest.raises(kpop.KPopError):
-        kpop.count_reads(bases, offs, 3, content=2)  # protein: not on the HIP path
+        kpop.count_reads(bases, offs, 13, content=kpop.PROTEIN)  # protein: k <= 12 (bin/KPopCount.ml:113)
+    with pytest.raises(kpop.KPopError):
+        kpop.count_reads(bases, offs, 3, content=3)
     with pytest.raises(kpop.KPopError) as e:
         kpop.count_reads(bases, offs, 3, capacity=1)
     assert e.value.code == -2  # KPOP_ERR_CAPACITY
@@ -128,3 +130,28 @@ def test_count_wuhan_golden(kpop, pyref):
         assert len(h) == case["n_distinct"] and int(c.sum()) == case["total"]
         text = pyref.spectrum_text("MN908947.3", {int(a): int(b) for a, b in zip(h, c)}, k)
         assert hashlib.sha256(text.encode()).hexdigest() == case["spectrum_text_sha256"]
+
+
+def test_count_protein_golden_and_random(kpop, oracle):
+    """-C protein (KMers.ProteinHash under the declared 5-bit encoding): per-sequence and merged spectra against the
+    golden fixture, then random proteomes -- short sequences (one wavefront each), long ones (sort path), 32- and
+    64-bit keys (k <= 6 / k > 6)."""
+    g = load_golden("count_protein.json")
+    seqs = [s for _, s in g["reads"]]
+    bases, offs = concat(seqs)
+    for case in g["cases"]:
+        k = case["k"]
+        h, c, o = kpop.count_reads(bases, offs, k, kpop.PROTEIN)
+        for r in range(len(seqs)):
+            got = [[oracle.to_hex(a, k, oracle.PROTEIN), int(b)] for a, b in zip(h[int(o[r]):int(o[r + 1])], c[int(o[r]):int(o[r + 1])])]
+            assert got == case["spectra"][r], (k, g["reads"][r][0])
+        hm, cm, om = kpop.count_reads(bases, offs, k, kpop.PROTEIN, per_read=False)
+        assert [[oracle.to_hex(a, k, oracle.PROTEIN), int(b)] for a, b in zip(hm, cm)] == case["merged"], k
+    rng = np.random.RandomState(99)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWYXBZ*acdefghiklmnpqrstvwy-", dtype=np.uint8)
+    lens = [int(x) for x in rng.randint(0, 700, size=300)] + [5000, 40000]
+    prot = [bytes(aa[rng.randint(0, len(aa), size=n)]).decode() for n in lens]
+    pb, po = concat(prot)
+    for k in (2, 6, 7, 12):
+        spectra_equal(kpop.count_reads(pb, po, k, kpop.PROTEIN), oracle.count_reads(pb, po, k, oracle.PROTEIN))
+        spectra_equal(kpop.count_reads(pb, po, k, kpop.PROTEIN, per_read=False), oracle.count_reads(pb, po, k, oracle.PROTEIN, per_read=False))

@@ -215,3 +215,18 @@ def test_counter_golden(oracle, pyref):
         assert pout == cb["out"] and pnorm == norm
     # wrap-around of Int32.of_float is exercised (a rescaled sum beyond 2^31)
     assert any(x < 0 for cb in g["combines"] for x in cb["out"])
+
+
+def test_protein_count_golden(oracle, pyref):
+    g = load_golden("count_protein.json")
+    seqs = [s for _, s in g["reads"]]
+    bases = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint64)
+    for case in g["cases"]:
+        k = case["k"]
+        h, c, o = oracle.count_reads(bases, offs, k, oracle.PROTEIN)
+        for r, s in enumerate(seqs):
+            got = [[oracle.to_hex(a, k, oracle.PROTEIN), int(b)] for a, b in zip(h[int(o[r]):int(o[r + 1])], c[int(o[r]):int(o[r + 1])])]
+            assert got == case["spectra"][r]
+            assert {pyref.to_hex_protein(a, k): b for a, b in pyref.count_read_protein(s, k).items()} == dict(map(tuple, case["spectra"][r]))
+    assert len(g["cases"][11]["merged"][0][0]) == 15    # k = 12: 60 bits = 15 hex digits
