@@ -356,11 +356,50 @@ __device__ __forceinline__ double ordered_value(uint64_t k) {
   return __longlong_as_double((long long)b);
 }
 
+// The element of rank `target` (0-based, ascending) among the wave's 64*R keys, without sorting them: quickselect on
+// wave ballots.  Keys strictly between `lo` and `hi` are still candidates; the first candidate in (register, lane)
+// order is the pivot; two ballots per register count the candidates below the pivot and the keys equal to it, and one
+// of the bounds moves.  Every step is wave-uniform (no divergence, no LDS, no cross-lane data movement but one
+// readlane); ties and the zeros that dominate sparse spectra finish in a step.  Expected ~2 ln(m) steps of ~6R
+// instructions against the ~R log^2(64R) compare-exchanges plus cross-lane shuffles of a full sort.
+// All-ones keys are padding and never candidates (hi starts there); 0 is below every ordered_key.
+template <int R>
+__device__ __forceinline__ uint64_t wave_select_rank(const uint64_t (&key)[R], uint32_t target) {
+  uint64_t lo = 0ull, hi = ~0ull;
+  uint32_t below = 0;  // keys <= lo
+  for (;;) {
+    uint64_t pivot = 0ull;
+    bool found = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint64_t alive = __ballot(key[r] > lo && key[r] < hi);
+      if (!found && alive) {
+        const int src = __ffsll((long long)alive) - 1;
+        pivot = (uint64_t)__shfl((unsigned long long)key[r], src, 64);
+        found = true;
+      }
+    }
+    if (!found) return lo;  // cannot happen for target < number of valid keys
+    uint32_t n_lt = 0, n_eq = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      n_lt += (uint32_t)__popcll(__ballot(key[r] > lo && key[r] < pivot));
+      n_eq += (uint32_t)__popcll(__ballot(key[r] == pivot));
+    }
+    if (target < below + n_lt) hi = pivot;
+    else if (target < below + n_lt + n_eq) return pivot;
+    else {
+      lo = pivot;
+      below += n_lt + n_eq;
+    }
+  }
+}
+
 // RescaledMedian, 65 .. 64*R spectra: one wavefront per k-mer.  A tile of TR k-mers x m
 // spectra of raw counts is staged in LDS with lanes along k-mers (full lines from HBM); each wave then takes a
 // k-mer, rescales its m counts into registers (R per lane; which lane holds which spectrum does not matter to a
-// sort), sorts the 64*R keys (ordered_key of the values; empty slots carry all-ones) with the in-register bitonic network
-// of wave_sort.h, and lane 0 stores sorted[m/2] * n_sel.
+// sort), finds the key of rank m/2 among the 64*R keys (ordered_key of the values; empty slots carry all-ones) with
+// wave_select_rank, and lane 0 stores it times n_sel.
 template <int R>
 __global__ __launch_bounds__(256) void combine_median_wave_kernel(const int32_t *__restrict__ storage, uint64_t ld, uint64_t n_rows,
                                                                   const uint32_t *__restrict__ sel, const double *__restrict__ norm,
@@ -377,7 +416,7 @@ __global__ __launch_bounds__(256) void combine_median_wave_kernel(const int32_t 
     b[r] = col < m ? norm[col] : 1.;
     y[r] = col < m ? rcp[col] : 1.;
   }
-  const uint32_t me = m >> 1, med_lane = me / R, med_reg = me % R;
+  const uint32_t me = m >> 1;
   const uint64_t n_tiles = (n_rows + TR - 1) / TR;
   double acc_norm = 0.;
   for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
@@ -397,12 +436,7 @@ __global__ __launch_bounds__(256) void combine_median_wave_kernel(const int32_t 
         key[r] = ~0ull;
         if (col < m) key[r] = ordered_key(div_rn(__dmul_rn((double)tile32[col * TRp + rr], max_norm), b[r], y[r]));
       }
-      wave_bitonic_sort<R>(key, lane);
-      uint64_t pick = key[0];
-#pragma unroll
-      for (int r = 1; r < R; ++r)
-        if (med_reg == (uint32_t)r) pick = key[r];
-      const double med = m ? ordered_value((uint64_t)__shfl((unsigned long long)pick, (int)med_lane, 64)) : 0.;
+      const double med = m ? ordered_value(wave_select_rank<R>(key, me)) : 0.;
       const double res = __dmul_rn(med, (double)n_sel);
       if (lane == 0) {
         acc_norm += res;
