@@ -505,6 +505,43 @@ __global__ __launch_bounds__(256) void combine_median_block_kernel(const int32_t
   if (threadIdx.x == 0) norm_partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// RescaledMedian of any number of spectra (the fallback beyond 4096): one thread per k-mer resolves the key of rank
+// m/2 bit by bit, most significant first -- 64 passes over the k-mer's m counts, each a coalesced stream (lanes along
+// k-mers), rescaling on the fly; nothing is stored per k-mer but the prefix found so far and the remaining rank.
+__global__ __launch_bounds__(256) void combine_median_bits_kernel(const int32_t *__restrict__ storage, uint64_t ld, uint64_t n_rows,
+                                                                  const uint32_t *__restrict__ sel, const double *__restrict__ norm,
+                                                                  const double *__restrict__ rcp, uint32_t m, uint32_t n_sel,
+                                                                  double max_norm, int32_t *__restrict__ out,
+                                                                  double *__restrict__ norm_partial) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  double acc_norm = 0.;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
+    uint64_t prefix = 0ull, known = 0ull;  // bits decided so far and their mask
+    uint32_t rank = m >> 1;
+    for (int bit = 63; bit >= 0 && m; --bit) {
+      const uint64_t b = 1ull << bit;
+      uint32_t zeros = 0;
+      for (uint32_t j = 0; j < m; ++j) {
+        const uint64_t key = ordered_key(div_rn(__dmul_rn((double)storage[(uint64_t)sel[j] * ld + r], max_norm), norm[j], rcp[j]));
+        zeros += ((key & known) == prefix && !(key & b)) ? 1u : 0u;
+      }
+      if (rank >= zeros) {
+        rank -= zeros;
+        prefix |= b;
+      }
+      known |= b;
+    }
+    const double res = __dmul_rn(m ? ordered_value(prefix) : 0., (double)n_sel);
+    acc_norm += res;
+    out[r] = int32_of_float(res);
+  }
+  __shared__ double sh[4];
+  acc_norm = wave_sum(acc_norm);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc_norm;
+  __syncthreads();
+  if (threadIdx.x == 0) norm_partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
 // one block: strided per-thread sums, then a fixed tree (the same result on every run for a given n)
 __global__ __launch_bounds__(1024) void sum_partials_kernel(const double *__restrict__ partial, uint32_t n, double *__restrict__ out) {
   double s = 0.;
@@ -712,7 +749,17 @@ extern "C" int kpop_dev_counter_combine(const int32_t *d_storage, uint64_t ld, u
     uint32_t P = 2;
     while (P < n_valid) P <<= 1;
     const uint32_t budget = 8192 - 8;  // doubles of LDS (64 KB less the reduction scratch)
-    if (P + 1 > budget) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_counter_combine: median of more than 4096 spectra");
+    if (P + 1 > budget) {  // beyond 4096 spectra: bit-serial selection, any m
+      grid = std::min<uint32_t>(div_up(n_rows, 256), 1u << 16);
+      combine_median_bits_kernel<<<dim3(grid), dim3(256), 0, st>>>(d_storage, ld, n_rows, d_sel, d_norm, rcp, n_valid, n_sel, max_norm,
+                                                                  d_out, partial);
+      KPOP_LAUNCH_CHECK();
+      if (d_out_norm) {
+        sum_partials_kernel<<<dim3(1), dim3(1024), 0, st>>>(partial, grid, d_out_norm);
+        KPOP_LAUNCH_CHECK();
+      }
+      return KPOP_OK;
+    }
     const uint32_t R = std::max<uint32_t>(1, std::min<uint32_t>(64, budget / (P + 1)));
     grid = (uint32_t)std::min<uint64_t>((n_rows + R - 1) / R, 1u << 16);
     combine_median_block_kernel<<<dim3(grid), dim3(256), (size_t)R * (P + 1) * 8, st>>>(d_storage, ld, n_rows, d_sel, d_norm, n_valid, n_sel,

@@ -55,7 +55,7 @@ def test_counter_golden(kpop):
 
 
 @pytest.mark.parametrize("n_rows,n_cols,lam", [(5000, 70, 3.0), (100_003, 9, 20.0), (777, 300, 1.0), (64, 1, 5.0), (1, 5, 2.0),
-                                                (257, 1000, 0.3), (129, 1100, 2.0), (1500, 130, 0.05)])
+                                                (257, 1000, 0.3), (129, 1100, 2.0), (1500, 130, 0.05), (300, 4200, 0.7)])
 def test_counter_random_vs_oracle(kpop, oracle, n_rows, n_cols, lam):
     rng = np.random.default_rng(n_rows * 31 + n_cols)
     depth = rng.uniform(0.2, 3.0, size=n_cols)
