@@ -684,17 +684,22 @@ extern "C" int kpop_dev_counter_stats(const int32_t *d_storage, uint64_t ld, uin
     ColPartial *partial = reinterpret_cast<ColPartial *>(d_workspace);
     double *plain = reinterpret_cast<double *>(partial + (uint64_t)n_cols * slabs);
     double *thr = plain + (uint64_t)n_cols * slabs;
-    if (n_cols > 65535) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_counter_stats: more than 65535 spectra in one call");
-    if (threshold < 1.) {
-      col_plain_sum_kernel<<<dim3(slabs, n_cols), dim3(kStatBlock), 0, st>>>(d_storage, ld, n_rows, power, p1, slabs, plain);
+    for (uint32_t c0 = 0; c0 < n_cols; c0 += 65535) {  // spectra ride on grid.y
+      const uint32_t nc = std::min<uint32_t>(65535, n_cols - c0);
+      const int32_t *src = d_storage + (uint64_t)c0 * ld;
+      ColPartial *pp = partial + (uint64_t)c0 * slabs;
+      double *pl = plain + (uint64_t)c0 * slabs;
+      if (threshold < 1.) {
+        col_plain_sum_kernel<<<dim3(slabs, nc), dim3(kStatBlock), 0, st>>>(src, ld, n_rows, power, p1, slabs, pl);
+        KPOP_LAUNCH_CHECK();
+      }
+      col_threshold_kernel<<<dim3(div_up(nc, 256)), dim3(256), 0, st>>>(pl, slabs, nc, threshold, thr + c0);
+      KPOP_LAUNCH_CHECK();
+      col_stats_kernel<<<dim3(slabs, nc), dim3(kStatBlock), 0, st>>>(src, ld, n_rows, power, p1, thr + c0, slabs, pp);
+      KPOP_LAUNCH_CHECK();
+      col_stats_final_kernel<<<dim3(div_up(nc, 256)), dim3(256), 0, st>>>(pp, slabs, nc, power, d_col_stats + 4 * (uint64_t)c0);
       KPOP_LAUNCH_CHECK();
     }
-    col_threshold_kernel<<<dim3(div_up(n_cols, 256)), dim3(256), 0, st>>>(plain, slabs, n_cols, threshold, thr);
-    KPOP_LAUNCH_CHECK();
-    col_stats_kernel<<<dim3(slabs, n_cols), dim3(kStatBlock), 0, st>>>(d_storage, ld, n_rows, power, p1, thr, slabs, partial);
-    KPOP_LAUNCH_CHECK();
-    col_stats_final_kernel<<<dim3(div_up(n_cols, 256)), dim3(256), 0, st>>>(partial, slabs, n_cols, power, d_col_stats);
-    KPOP_LAUNCH_CHECK();
   }
   if (d_row_stats && n_rows) {
     row_stats_kernel<<<dim3(capped_grid(div_up(n_rows, 256))), dim3(256), 0, st>>>(d_storage, ld, n_cols, n_rows, threshold, power, p1,
@@ -794,9 +799,13 @@ extern "C" int kpop_dev_counter_transform(const int32_t *d_storage, uint64_t ld,
     transform_table_kernel<<<dim3((uint32_t)std::min<uint64_t>((n_rows + 63) / 64, 1u << 20), div_up(n_cols, 64)), dim3(256), 0, st>>>(
         d_storage, ld, n_cols, n_rows, which, threshold, power, d_col_stats, d_out);
   } else {
-    if (n_cols > 65535) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_counter_transform: more than 65535 spectra in one call");
-    transform_kernel<<<dim3((uint32_t)std::min<uint64_t>(div_up(n_rows, 256 * 8), 1u << 16), n_cols), dim3(256), 0, st>>>(
-        d_storage, ld, n_cols, n_rows, which, threshold, power, d_col_stats, d_out);
+    for (uint32_t c0 = 0; c0 < n_cols; c0 += 65535) {  // spectra ride on grid.y
+      const uint32_t nc = std::min<uint32_t>(65535, n_cols - c0);
+      transform_kernel<<<dim3((uint32_t)std::min<uint64_t>(div_up(n_rows, 256 * 8), 1u << 16), nc), dim3(256), 0, st>>>(
+          d_storage + (uint64_t)c0 * ld, ld, nc, n_rows, which, threshold, power, d_col_stats + 4 * (uint64_t)c0,
+          d_out + (uint64_t)c0 * n_rows);
+      KPOP_LAUNCH_CHECK();
+    }
   }
   KPOP_LAUNCH_CHECK();
   return KPOP_OK;

@@ -159,3 +159,22 @@ def test_division_by_reciprocal_is_exact(kpop):
         f, e = fast.cpu().numpy(), exact.cpu().numpy()
         assert np.array_equal(e, a / b)          # the hardware division is IEEE
         assert np.array_equal(f, e), int(np.count_nonzero(f != e))
+
+
+def test_counter_more_spectra_than_grid_y(kpop, oracle):
+    """70,000 spectra of 40 k-mers: spectra ride on grid.y (65,535 at most per launch), so statistics and the
+    spectrum-major transformation go in two launches; the mean of all of them and the bit-serial median agree with
+    the oracle."""
+    rng = np.random.default_rng(70000)
+    n_cols, n_rows = 70_000, 40
+    table = rng.poisson(2.0, size=(n_cols, n_rows)).astype(np.int32)
+    cols = list(table)
+    cs, rs = kpop.counter_stats(cols, 1.0, 1.0)
+    assert np.array_equal(cs[:, 2], table.sum(axis=1).astype(np.float64)) and np.array_equal(rs[:, 2], table.sum(axis=0).astype(np.float64))
+    got = kpop.counter_transform(cols, cs, 1, 1.0, 1.0, kmer_major=False)
+    assert np.array_equal(got, table.astype(np.float64))
+    sel = list(range(n_cols))
+    for crit in (0, 1):
+        out, norm = kpop.counter_combine(cols, sel, cs[:, 2], crit)
+        want, wnorm = oracle.counter_combine(cols, sel, cs[:, 2], crit)
+        assert np.array_equal(out, want) and norm == pytest.approx(wnorm, rel=1e-12)
