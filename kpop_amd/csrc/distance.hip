@@ -446,10 +446,13 @@ static int rowwise_block(const double *a, uint32_t r1, const double *b, uint32_t
   const uint32_t n_cg = div_up(w, 4);
   const uint32_t n_rg = std::min(256u / n_cg, (uint32_t)kMaxTJ / 4);
   const uint32_t TJ = 4 * n_rg;
-  if (div_up(r2, TJ) > 65535) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "distance_rowwise: too many rows in the second operand (%u)", r2);
-  distance_rowwise_kernel<KIND><<<dim3(div_up(r1, w), div_up(r2, TJ)), dim3(256), 0, st>>>(a, w, r1, b, r2, n_dims, metric, p,
-                                                                                         out, n_cg, n_rg);
-  KPOP_LAUNCH_CHECK();
+  const uint32_t rows_per_launch = 65535u * TJ;  // m2 rows ride on grid.y
+  for (uint32_t j0 = 0; j0 < r2; j0 += rows_per_launch) {
+    const uint32_t nr = std::min(rows_per_launch, r2 - j0);
+    distance_rowwise_kernel<KIND><<<dim3(div_up(r1, w), div_up(nr, TJ)), dim3(256), 0, st>>>(
+        a, w, r1, b + (uint64_t)j0 * n_dims, nr, n_dims, metric, p, out + (uint64_t)j0 * r1, n_cg, n_rg);
+    KPOP_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -274,3 +274,25 @@ def test_distance_rowwise_long_rows(kpop, oracle, kind, p, r1, r2, d):
         want = oracle.distance_rowwise(m1, m2, metric, kind, p, normalize)
         assert got.shape == (r2, r1) and got[0, 0] == 0.0
         np.testing.assert_allclose(got, want, rtol=1e-11, atol=0)
+
+
+def test_distance_rowwise_more_rows_than_grid_y(kpop, oracle):
+    """4.2 M second-operand rows against 200 reference rows: the rows ride on grid.y (65,535 blocks of 60), so the
+    launch is split; rows from both sides of the split are checked against the oracle."""
+    import torch
+    from kpop_amd import api
+    r1, r2, d = 200, 4_200_000, 4
+    dev = torch.device("cuda", 0)
+    sp = torch.cuda.current_stream().cuda_stream
+    rng = np.random.RandomState(3)
+    m1 = rng.standard_normal((r1, d))
+    m2 = torch.randn(r2, d, dtype=torch.float64, device=dev)
+    metric = np.array([0.4, 0.3, 0.2, 0.1])
+    t1, tm = torch.from_numpy(m1).to(dev), torch.from_numpy(metric).to(dev)
+    work = torch.empty(api.dev_distance_workspace_bytes(r1, r2, d), dtype=torch.uint8, device=dev)
+    out = torch.empty(r2, r1, dtype=torch.float64, device=dev)
+    api.dev_distance_rowwise(t1.data_ptr(), r1, m2.data_ptr(), r2, d, tm.data_ptr(), work.data_ptr(), out.data_ptr(), stream=sp)
+    torch.cuda.synchronize()
+    pick = torch.tensor([0, 1, 3_932_099, 3_932_100, 3_932_101, 4_199_999], device=dev)
+    want = oracle.distance_rowwise(m1, m2[pick].cpu().numpy(), metric)
+    assert np.array_equal(out[pick].cpu().numpy(), want)
