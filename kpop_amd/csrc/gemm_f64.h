@@ -9,7 +9,7 @@
 // loads of chunk c+1 fly under the 64 MFMAs of chunk c.  MFMA operand maps (cdna_hip_programming.md section 3):
 // lane l gives A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; it receives D[row = (l>>4) + 4*reg][col = l&15].
 //
-// Split-K: gridDim.z slabs of K, each writing its own C slab; gemm_reduce_slabs_kernel adds the slabs in slab
+// Split-K: slabs of K (the slowest tile coordinate of a one-dimensional launch), each writing its own C slab; gemm_reduce_slabs_kernel adds the slabs in slab
 // order (bitwise reproducible, no atomics).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -29,12 +29,28 @@ template <bool TRANS_A>
 __global__ __launch_bounds__(256) void gemm_f64_mfma_kernel(const double *__restrict__ A, uint64_t lda,
                                                             const double *__restrict__ B, uint64_t ldb,
                                                             double *__restrict__ C, uint64_t ldc, uint32_t M, uint32_t N,
-                                                            uint64_t K, uint64_t k_per_split, int upper_only) {
+                                                            uint64_t K, uint64_t k_per_split, int upper_only,
+                                                            uint32_t tiles_m, uint32_t tiles_n) {
   __shared__ double As[kGK][kGS];
   __shared__ double Bs[kGK][kGS];
-  const uint32_t m0 = blockIdx.x * kGT, n0 = blockIdx.y * kGT;  // M can be millions of rows: it rides on grid.x
-  if (upper_only && blockIdx.x > blockIdx.y) return;  // symmetric product: the mirror tile is filled by the reducer
-  const uint64_t k_begin = (uint64_t)blockIdx.z * k_per_split;
+  // Tile order (the launch is one-dimensional).  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.
+  //   S W (!TRANS_A): XCD-aware.  The blocks that share id % 8 get a contiguous run of tile numbers (bijective remap,
+  //       cdna_hip_programming.md T1) decoded with the N-tiles of one M-tile as neighbours, so the M-panel of S -- the
+  //       big operand -- is fetched into one L2 once and reused by all its N-tiles: -5..-9 % measured.
+  //   S'S (TRANS_A): plain order (M-tile fastest, K-slab slowest), K-slabs interleaved over the XCDs.  Giving each XCD
+  //       whole K-slabs was measured and lost 20 % at 1,636 columns (91 live tiles per slab on 32 CUs: a 2.8-round
+  //       tail per slab instead of one for the launch).
+  uint32_t wgid = blockIdx.x;
+  if (!TRANS_A) {
+    const uint32_t nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
+    wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
+  }
+  const uint32_t bz = wgid / (tiles_m * tiles_n), rem = wgid % (tiles_m * tiles_n);
+  const uint32_t bx = TRANS_A ? rem % tiles_m : rem / tiles_n;
+  const uint32_t by = TRANS_A ? rem / tiles_m : rem % tiles_n;
+  const uint32_t m0 = bx * kGT, n0 = by * kGT;
+  if (upper_only && bx > by) return;  // symmetric product: the mirror tile is filled by the reducer
+  const uint64_t k_begin = (uint64_t)bz * k_per_split;
   const uint64_t k_end = min(K, k_begin + k_per_split);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
@@ -85,7 +101,7 @@ __global__ __launch_bounds__(256) void gemm_f64_mfma_kernel(const double *__rest
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
-  double *Cs = C + (uint64_t)blockIdx.z * M * ldc;
+  double *Cs = C + (uint64_t)bz * M * ldc;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -125,10 +141,12 @@ static int gemm_f64(const double *A, uint64_t lda, const double *B, uint64_t ldb
   kps = (kps + kGK - 1) / kGK * kGK;
   if (kps == 0) kps = kGK;
   n_splits = (uint32_t)std::max<uint64_t>(1, (K + kps - 1) / kps);
-  dim3 grid(div_up(M, kGT), div_up(N, kGT), n_splits);
-  if (grid.y > 65535 || grid.z > 65535) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "gemm_f64: grid %u x %u x %u", grid.x, grid.y, grid.z);
+  const uint32_t tiles_m = div_up(M, kGT), tiles_n = div_up(N, kGT);
+  const uint64_t n_blocks = (uint64_t)tiles_m * tiles_n * n_splits;
+  if (n_blocks >= (1ull << 31)) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "gemm_f64: %u x %u x %u tiles", tiles_m, tiles_n, n_splits);
   double *dst = (n_splits > 1 || symmetric) ? slabs : C;
-  gemm_f64_mfma_kernel<TRANS_A><<<grid, dim3(256), 0, st>>>(A, lda, B, ldb, dst, N, M, N, K, kps, symmetric);
+  gemm_f64_mfma_kernel<TRANS_A><<<dim3((uint32_t)n_blocks), dim3(256), 0, st>>>(A, lda, B, ldb, dst, N, M, N, K, kps, symmetric,
+                                                                                  tiles_m, tiles_n);
   KPOP_LAUNCH_CHECK();
   if (dst != C) {
     gemm_reduce_slabs_kernel<0><<<dim3(std::min<uint32_t>(div_up((uint64_t)M * N, 256), 4096)), dim3(256), 0, st>>>(
