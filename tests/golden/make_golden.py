@@ -309,7 +309,33 @@ def counter_fixture():
     dump("counter_small.json", res)
 
 
+# ---------------------------------------------------------------- the reference's own Distance.Iterator test
+def distance_iterator_fixture():
+    """test/DistanceIterator.ml + its expected output test/DistanceIterator.txt: the one executable test the reference
+    ships.  Distance.Iterator (lib/Space.ml:231-420, used by no CLI) walks the pairs of a 12-point line in order of
+    increasing Minkowski(1) component up to 0.3.  The DATA kept here: the input points (test/DistanceIterator.ml:7),
+    the bound (:9) and the "(i, j): component" lines of the expected output -- a known answer for the component
+    arithmetic of lib/Space.ml:150-158,192-200 and for the order of the pairs."""
+    import re
+    src = os.path.join(REF, "test", "DistanceIterator.txt")
+    dst = os.path.join(OUT, "distance_iterator.json")
+    if not os.path.exists(src):
+        print("kept", os.path.basename(dst))
+        return
+    pairs = []
+    for line in open(src):
+        m = re.match(r"\((\d+), (\d+)\): (\S+)$", line.strip())
+        if m:
+            pairs.append([int(m.group(1)), int(m.group(2)), m.group(3)])
+    dump("distance_iterator.json", {
+        "source": "test/DistanceIterator.ml:5-9 (inputs) and test/DistanceIterator.txt (expected output) of PaoloRibeca/KPop",
+        "distance": "minkowski(1)", "metric_weight": 1.0, "max_distance_component": 0.3,
+        "points": [0.1, 0.1, 0.2, 0.2, 0.2, 0.7, 0.5, 0.99, 0.999, 0.05, 0.4, 0.05],
+        "pairs": pairs})
+
+
 if __name__ == "__main__":
+    distance_iterator_fixture()
     counter_fixture()
     readme_kat()
     count_fixture()

@@ -296,3 +296,15 @@ def test_distance_rowwise_more_rows_than_grid_y(kpop, oracle):
     pick = torch.tensor([0, 1, 3_932_099, 3_932_100, 3_932_101, 4_199_999], device=dev)
     want = oracle.distance_rowwise(m1, m2[pick].cpu().numpy(), metric)
     assert np.array_equal(out[pick].cpu().numpy(), want)
+
+
+def test_reference_distance_iterator_known_answer_on_the_gpu(kpop):
+    """The reference's test/DistanceIterator known answer (see tests/test_oracle_golden.py) through kpop_distance_rowwise:
+    Minkowski(1) goes through the device's pow(), so the digits are held to 1e-12 instead of %.15g text."""
+    g = load_golden("distance_iterator.json")
+    pts = np.array(g["points"], dtype=np.float64).reshape(-1, 1)
+    d = kpop.distance_rowwise(pts, pts, np.array([g["metric_weight"]]), kpop.MINKOWSKI, 1.0, normalize=False)
+    for i, j, text in g["pairs"]:
+        assert d[j, i] == pytest.approx(float(text), rel=1e-12, abs=1e-300)
+    n = len(pts)
+    assert {(min(i, j), max(i, j)) for i, j, _ in g["pairs"]} == {(i, j) for i in range(n) for j in range(i + 1, n) if d[j, i] <= 0.3 + 1e-15}

@@ -230,3 +230,21 @@ def test_protein_count_golden(oracle, pyref):
             assert got == case["spectra"][r]
             assert {pyref.to_hex_protein(a, k): b for a, b in pyref.count_read_protein(s, k).items()} == dict(map(tuple, case["spectra"][r]))
     assert g["cases"][-1]["k"] == 12 and len(g["cases"][-1]["merged"][0][0]) == 15    # 60 bits = 15 hex digits
+
+
+def test_reference_distance_iterator_known_answer(oracle, pyref):
+    """The reference's own executable test (test/DistanceIterator.ml -> test/DistanceIterator.txt): every pair of the 12
+    points whose Minkowski(1) component is <= 0.3, in order of increasing component, printed %.15g.  The oracle's
+    distance between the 1-dimensional vectors [a_i] and [a_j] must print the same digits, list the same pairs and
+    respect the same order."""
+    g = load_golden("distance_iterator.json")
+    pts = np.array(g["points"], dtype=np.float64).reshape(-1, 1)
+    d = oracle.distance_rowwise(pts, pts, np.array([g["metric_weight"]]), oracle.MINKOWSKI, 1.0, normalize=False)
+    for i, j, text in g["pairs"]:
+        assert "%.15g" % d[j, i] == text and "%.15g" % d[i, j] == text
+        assert "%.15g" % pyref.distance("minkowski", 1.0, [g["metric_weight"]], [pts[i, 0]], 1.0, [pts[j, 0]], 1.0) == text
+    n = len(pts)
+    want = {(i, j) for i in range(n) for j in range(i + 1, n) if d[j, i] <= g["max_distance_component"]}
+    assert {(min(i, j), max(i, j)) for i, j, _ in g["pairs"]} == want and len(g["pairs"]) == len(want)
+    vals = [d[j, i] for i, j, _ in g["pairs"]]
+    assert vals == sorted(vals)
