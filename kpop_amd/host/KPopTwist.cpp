@@ -20,41 +20,13 @@
 #include "../../include/kpop_hip.h"
 #include "ca_pipeline.h"
 #include "counter_db.h"
+#include "twist_args.h"
 
 using namespace kpop_host;
 
 namespace {
 
 const char *kVersion = "27-hip";
-
-void usage(FILE *f) {
-  fprintf(f,
-          "This is KPopTwist (MI355X/HIP) version %s\n"
-          "Usage: KPopTwist -i|--input <binary_input_prefix> -o|--output <binary_output_prefix> [OPTIONS]\n"
-          " -k|--kmers|--keep|--keep-kmers|--kmers-keep <file>   keep only the k-mers listed (one per line)\n"
-          " -s|--sample|--sample-kmers|--kmers-sample <fraction>   resample k-mers (default 1)\n"
-          " --counts-threshold <x>   --counts-power <x>   --counts-transform|--counts-transformation binary|power|pseudocounts|clr\n"
-          " --counts-normalize|--counts-normalization true|false   (default true)\n"
-          " --kmers-threshold <x>    drop k-mers whose total is below x times the largest total (default 0)\n"
-          " -i|--input <prefix>      <prefix>.KPopCounter\n"
-          " -o|--output <prefix>     <prefix>.KPopTwister and <prefix>.KPopTwisted\n"
-          " -K|--output-kmers|--output-twisted-kmers <prefix>   also save the twisted k-mers\n"
-          " -T|--threads <n> (ignored)  --keep-temporaries  -v|--verbose  -V|--version  -h|--help\n",
-          kVersion);
-}
-
-[[noreturn]] void parse_error(const std::string &msg) {
-  usage(stderr);
-  fprintf(stderr, "(KPopTwist): ERROR: %s\n", msg.c_str());
-  exit(1);
-}
-
-double parse_float(const std::string &opt, const std::string &s, double lo, double hi) {
-  char *end = nullptr;
-  const double v = strtod(s.c_str(), &end);
-  if (end == s.c_str() || *end != 0 || !(v >= lo) || !(v <= hi)) parse_error("Option '" + opt + "': '" + s + "' is out of range");
-  return v;
-}
 
 void check(int rc) {
   if (rc != 0) throw Error(std::string("libkpop_hip: ") + kpop_last_error());
@@ -63,50 +35,11 @@ void check(int rc) {
 }  // namespace
 
 int main(int argc, char **argv) {
-  std::string input, output, output_kmers;
-  Transform transform;
-  CaParams P;
-  bool temporaries = false;
-  auto need = [&](int &i, const std::string &opt) -> std::string {
-    if (i + 1 >= argc) parse_error("Option '" + opt + "' needs a parameter");
-    return argv[++i];
-  };
-  for (int i = 1; i < argc; ++i) {
-    const std::string a = argv[i];
-    auto is = [&](std::initializer_list<const char *> names) {
-      for (const char *n : names)
-        if (a == n) return true;
-      return false;
-    };
-    if (is({"-k", "--kmers", "--keep", "--keep-kmers", "--kmers-keep"})) P.keep_path = need(i, a);
-    else if (is({"-s", "--sample", "--sample-kmers", "--kmers-sample"})) P.fraction = parse_float(a, need(i, a), 0., 1.);
-    else if (is({"--counts-threshold"})) transform.threshold = parse_float(a, need(i, a), 0., 1e300);
-    else if (is({"--counts-power"})) transform.power = parse_float(a, need(i, a), 0., 1e300);
-    else if (is({"--counts-transform", "--counts-transformation"})) transform.which = need(i, a);
-    else if (is({"--counts-normalize", "--counts-normalization"})) {
-      const std::string b = need(i, a);
-      if (b != "true" && b != "false") parse_error("Option '" + a + "': '" + b + "' is not a boolean");
-      P.normalize = b == "true";
-    } else if (is({"--kmers-threshold"})) P.threshold = parse_float(a, need(i, a), 0., 1e300);
-    else if (is({"-i", "--input"})) input = need(i, a);
-    else if (is({"-o", "--output"})) output = need(i, a);
-    else if (is({"-K", "--output-kmers", "--output-twisted-kmers"})) output_kmers = need(i, a);
-    else if (is({"-T", "--threads"})) {
-      if (atoi(need(i, a).c_str()) <= 0) parse_error("Option '" + a + "': the number of threads must be positive");
-    } else if (is({"--keep-temporaries"})) temporaries = true;
-    else if (is({"-v", "--verbose"})) P.verbose = true;
-    else if (is({"-V", "--version"})) {
-      printf("%s\n", kVersion);
-      return 0;
-    } else if (is({"-h", "--help"})) {
-      usage(stdout);
-      return 0;
-    } else {
-      parse_error("Unknown option '" + a + "'");
-    }
-  }
-  if (input.empty()) parse_error("Option '-i' is mandatory");   // TA.Mandatory, bin/KPopTwist_.ml:97-103
-  if (output.empty()) parse_error("Option '-o' is mandatory");  // :104-110
+  TwistArgs A = parse_twist_args(argc, argv, "KPopTwist", kVersion);
+  const std::string &input = A.input, &output = A.output, &output_kmers = A.output_kmers;
+  const Transform &transform = A.transform;
+  CaParams &P = A.ca;
+  const bool temporaries = A.temporaries;
   try {
     const int which = transform.code();
     int dev = 0;

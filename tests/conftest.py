@@ -21,7 +21,8 @@ def pytest_sessionstart(session):
     import shutil
     need = [os.path.join(ROOT, "kpop_amd", "libkpop_hip.so"), os.path.join(ROOT, "kpop_amd", "bin", "KPopTwistDB"),
             os.path.join(ROOT, "kpop_amd", "bin", "KPopCount"), os.path.join(ROOT, "kpop_amd", "bin", "KPopTwistCA"),
-            os.path.join(ROOT, "kpop_amd", "bin", "KPopCountDB"), os.path.join(ROOT, "kpop_amd", "bin", "KPopTwist")]
+            os.path.join(ROOT, "kpop_amd", "bin", "KPopCountDB"), os.path.join(ROOT, "kpop_amd", "bin", "KPopTwist"),
+            os.path.join(ROOT, "kpop_amd", "bin", "KPopTwist_")]
     if all(os.path.exists(p) for p in need):
         return
     if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):

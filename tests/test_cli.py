@@ -294,3 +294,13 @@ def test_countdb_errors(tmp_path):
     assert r.returncode == 1 and "Option '-i' is mandatory" in r.stderr
     r = run([TWIST, "-i", "x", "-o", "y", "--counts-transform", "sqrt"])
     assert r.returncode == 1 and "Unknown_transformation" in r.stderr
+
+
+def test_kpoptwist_underscore_echoes_its_arguments():
+    """bin/KPopTwist_.ml:136-140: one line of \\001-separated fields for the bash wrapper src/KPopTwist:19-27."""
+    r = run([os.path.join(BIN, "KPopTwist_"), "-i", "In", "-o", "Out", "-s", "0.5", "--counts-transform", "clr", "-K", "km", "-T", "3",
+             "--kmers-threshold", "0.25", "--counts-normalize", "false", "-v"])
+    assert r.returncode == 0
+    assert r.stdout == "\001".join(["In", "", "0.5", "1", "1", "clr", "false", "0.25", "Out", "km", "3", "false", "true"]) + "\n"
+    r = run([os.path.join(BIN, "KPopTwist_"), "-i", "In"])
+    assert r.returncode == 1 and "Option '-o' is mandatory" in r.stderr and r.stdout == ""
