@@ -616,3 +616,43 @@ def test_protein_content_through_the_clis(tmp_path, oracle, pyref):
     h, c, o = oracle.count_reads(pb, po, k, oracle.PROTEIN)
     rows = oracle.twist(T, cols, h, c.astype(np.float64), o)
     assert r.stdout == twisted_text(dims, [t for t, _ in prots], rows)
+
+
+def test_reference_wrapper_steps_match_one_process_kpoptwist(tmp_path, oracle, pyref):
+    """The steps of the reference's bash wrapper (src/KPopTwist:19-131: KPopTwist_ echo, two KPopCountDB exports, the
+    R stage -- here KPopTwistCA with the same positional arguments -- and three KPopTwistDB encodings) give the twister
+    that the one-process KPopTwist writes."""
+    k = 4
+    rng = np.random.default_rng(44)
+    seqs = [("c%d" % i, "".join(rng.choice(list("ACGT"), size=int(rng.integers(800, 1500))))) for i in range(7)]
+    write_fasta(tmp_path / "x.fa", seqs)
+    penv = dict(os.environ, PATH=BIN + ":" + os.environ.get("PATH", ""))
+    sh = lambda cmd: subprocess.run(["bash", "-c", cmd], cwd=str(tmp_path), capture_output=True, text=True, timeout=300, env=penv)
+    assert sh("KPopCount -k %d -L -f x.fa | KPopCountDB -k /dev/stdin -o Classes" % k).returncode == 0
+    r = sh("KPopTwist -i Classes -o V -K Vk")
+    assert r.returncode == 0, r.stderr
+    script = r"""
+set -e
+PARAMETERS="$(KPopTwist_ -i Classes -o W -K Wk)"
+IFS=$'\x01' read -r PREFIX_IN KMERS_KEEP KMERS_SAMPLE THRESHOLD_COUNTS POWER TRANSFORM NORMALIZE THRESHOLD_KMERS PREFIX_OUT PREFIX_OUT_KMERS THREADS TEMPORARIES VERBOSE <<< "$PARAMETERS"
+mkdir T
+KPopCountDB -T "$THREADS" -i "$PREFIX_IN" --counts-threshold "$THRESHOLD_COUNTS" --counts-power "$POWER" --counts-transform "$TRANSFORM" \
+    --table-output-row-names false -t T/TABLE -R "~." -D \
+    --counts-output-zero-kmers true --counts-threshold 1. --counts-power 1. --counts-transform power \
+    --table-output-row-names true --table-output-metadata false -t /dev/stdout | tail -n +2 > T/NAMES.KPopCounter.txt
+KPopTwistCA T/TABLE.KPopCounter.txt T/NAMES.KPopCounter.txt "$PREFIX_OUT" "$PREFIX_OUT_KMERS" "$KMERS_KEEP" "$KMERS_SAMPLE" "$NORMALIZE" "$THRESHOLD_KMERS" "$THREADS" "$TEMPORARIES" "$VERBOSE"
+KPopTwistDB -T "$THREADS" -I t "$PREFIX_OUT" -o t "$PREFIX_OUT"
+KPopTwistDB -T "$THREADS" -I t "$PREFIX_OUT_KMERS" -o t "$PREFIX_OUT_KMERS"
+KPopTwistDB -T "$THREADS" -I T "$PREFIX_OUT" -o T "$PREFIX_OUT"
+"""
+    r = sh(script)
+    assert r.returncode == 0, r.stderr
+
+    def table(cmd):
+        out = sh(cmd).stdout.splitlines()
+        return out[0], [l.split("\t")[0] for l in out[1:]], np.array([[float(v) for v in l.split("\t")[1:]] for l in out[1:]])
+    for reg, a, b, n_lines in (("T", "V", "W", 7), ("t", "V", "W", None), ("t", "Vk", "Wk", None)):
+        ha, ra, da = table("KPopTwistDB -i %s %s -O %s /dev/stdout%s" % (reg, a, reg, " | head -%d" % n_lines if n_lines else ""))
+        hb, rb, db = table("KPopTwistDB -i %s %s -O %s /dev/stdout%s" % (reg, b, reg, " | head -%d" % n_lines if n_lines else ""))
+        assert ha == hb and ra == rb and da.shape == db.shape and da.size > 0
+        np.testing.assert_allclose(da, db, rtol=1e-12, atol=1e-13)   # W went through %.15g text on the way
