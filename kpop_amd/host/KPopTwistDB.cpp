@@ -353,7 +353,7 @@ int main(int argc, char **argv) {
         act.kind = Action::RegisterToTables;
         act.reg = reg_of_string(need(i, a));
         act.s1 = need(i, a);
-      } else if (a == "--summary-at-most" || a == "--summary-keep-at-most") {
+      } else if (a == "--summary-at-most" || a == "--summary-keep-at-most" || a == "--keep-at-most") {  // the last: README.md:768,1101
         act.kind = Action::SetSummaryKeepAtMost;
         std::string v = need(i, a);
         if (v == "all") act.num = 0;

@@ -413,6 +413,18 @@ def test_readme_training_flow(tmp_path, oracle, pyref, criterion):
     got = {l.split("\t")[0]: l.split("\t")[5] for l in (tmp_path / "Test-vs-Classes.KPopSummary.txt").read_text().splitlines()}
     correct = sum(got[name] == cls for (name, _), cls in zip(reads, truth))
     assert correct >= 0.9 * len(reads), (correct, len(reads))
+    # README.md:93 / :164 verbatim: the twisted register travels as an OCaml-Marshal stream through the pipe
+    r = sh("K=%d; cat test.fa | KPopCount -k $K -L -f /dev/stdin | KPopTwistDB -i T Classes.$K -k /dev/stdin -o t /dev/stdout | "
+           "KPopTwistDB -i T Classes.$K -i t Classes.$K -s /dev/stdin Test_prediction.$K -v" % k)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / ("Test_prediction.%d.KPopSummary.txt" % k)).read_bytes() == (tmp_path / "Test-vs-Classes.KPopSummary.txt").read_bytes()
+    # README.md:182: ... -o t /dev/stdout -v | KPopTwistDB -i t /dev/stdin -O t Test.$K
+    r = sh("K=%d; cat test.fa | KPopCount -k $K -L -f /dev/stdin | KPopTwistDB -i T Classes.$K -k /dev/stdin -o t /dev/stdout -v | "
+           "KPopTwistDB -i t /dev/stdin -O t Test.$K && KPopTwistDB -i t Test -O t /dev/stdout | cmp - Test.$K.KPopTwisted.txt" % k)
+    assert r.returncode == 0, r.stderr
+    # README.md:768: --keep-at-most (the README's spelling of --summary-keep-at-most)
+    r = sh("KPopTwistDB -i T Classes.%d -i t Classes.%d --keep-at-most 3 -s Test Top3 && awk -F'\t' '{print NF}' Top3.KPopSummary.txt | sort -u" % (k, k))
+    assert r.returncode == 0 and r.stdout.split() == ["14"], (r.stdout, r.stderr)   # 5 statistics + 3 x (name, distance, z)
 
 
 def test_countdb_tables_spectra_split_and_distances(tmp_path, oracle, pyref):
