@@ -197,12 +197,53 @@ bool str_string_match(const std::string &str_regexp, const std::string &s) {
   return std::regex_search(s, re, std::regex_constants::match_continuous);
 }
 
+bool CounterDB::hex_key(const char *s, size_t n, uint64_t *key) {
+  if (n == 0 || n > 15) return false;
+  uint64_t v = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const char c = s[i];
+    int d;
+    if (c >= '0' && c <= '9') d = c - '0';
+    else if (c >= 'a' && c <= 'f') d = c - 'a' + 10;
+    else return false;
+    v = (v << 4) | (uint64_t)d;
+  }
+  *key = ((uint64_t)n << 60) | v;
+  return true;
+}
+
+uint32_t CounterDB::row_of(const char *name, size_t len) {
+  uint64_t key;
+  if (hex_key(name, len, &key)) {
+    auto it = hex_row_idx_.find(key);
+    if (it != hex_row_idx_.end()) return it->second;
+    const uint32_t row = (uint32_t)core.row_names.size();
+    hex_row_idx_.emplace(key, row);
+    core.row_names.emplace_back(name, len);
+    return row;
+  }
+  std::string nm(name, len);
+  auto it = row_idx_.find(nm);
+  if (it != row_idx_.end()) return it->second;
+  const uint32_t row = (uint32_t)core.row_names.size();
+  row_idx_.emplace(nm, row);
+  core.row_names.push_back(std::move(nm));
+  return row;
+}
+
 void CounterDB::rebuild_indices() {  // invert_table, lib/KMerDB.ml:371-374 (Hashtbl.add: the last duplicate wins)
   col_idx_.clear();
   row_idx_.clear();
+  hex_row_idx_.clear();
   meta_idx_.clear();
   for (size_t i = 0; i < core.col_names.size(); ++i) col_idx_[core.col_names[i]] = (uint32_t)i;
-  for (size_t i = 0; i < core.row_names.size(); ++i) row_idx_[core.row_names[i]] = (uint32_t)i;
+  hex_row_idx_.reserve(core.row_names.size());
+  for (size_t i = 0; i < core.row_names.size(); ++i) {
+    const std::string &nm = core.row_names[i];
+    uint64_t key;
+    if (hex_key(nm.data(), nm.size(), &key)) hex_row_idx_[key] = (uint32_t)i;
+    else row_idx_[nm] = (uint32_t)i;
+  }
   for (size_t i = 0; i < core.meta_names.size(); ++i) meta_idx_[core.meta_names[i]] = (uint32_t)i;
 }
 
@@ -285,19 +326,11 @@ void CounterDB::add_files(const std::vector<std::string> &prefixes) {
       if (line_num == 1 && l0 != 0) throw Error("Header_expected(\"" + std::string(line, len) + "\")");
       if (l0 == 0) {  // header: a new (or an existing) spectrum
         col = add_empty_column_if_needed(strip_external_quotes_and_check(std::string(tab + 1, len - 1)));
+        if (core.storage[col].size() < n_rows()) core.storage[col].resize(n_rows(), 0);  // one allocation for the rows known so far
         ++n_spectra;
         continue;
       }
-      const std::string name(line, l0);
-      uint32_t row;
-      auto it = row_idx_.find(name);
-      if (it == row_idx_.end()) {
-        row = (uint32_t)core.row_names.size();
-        row_idx_.emplace(name, row);
-        core.row_names.push_back(name);
-      } else {
-        row = it->second;
-      }
+      const uint32_t row = row_of(line, l0);
       int32_t v;
       if (!int32_of_string(tab + 1, len - l0 - 1, &v))
         throw Error("Wrong_format(" + std::to_string(line_num) + ", \"" + std::string(tab + 1, len - l0 - 1) + "\")");

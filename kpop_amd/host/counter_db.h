@@ -69,6 +69,12 @@ class CounterDB {
 
  private:
   std::unordered_map<std::string, uint32_t> col_idx_, row_idx_, meta_idx_;
+  // k-mer names that are 1..15 lowercase hexadecimal digits (what KPopCount writes) are indexed by (length << 60 | value)
+  // instead of by string: one integer hash per spectrum line instead of a string allocation and a string hash.  Every
+  // other name lives in row_idx_; a name is in exactly one of the two.
+  std::unordered_map<uint64_t, uint32_t> hex_row_idx_;
+  static bool hex_key(const char *s, size_t n, uint64_t *key);
+  uint32_t row_of(const char *name, size_t len);  // the row of a k-mer name, appended if new
   void rebuild_indices();
   uint32_t add_empty_column_if_needed(const std::string &label);  // :376-391
 };

@@ -4,6 +4,8 @@
 #include <errno.h>
 #include <string.h>
 
+#include <algorithm>
+#include <memory>
 #include <vector>
 
 namespace kpop_host {
@@ -120,15 +122,18 @@ struct Writer {
       be(0xFFFF, 2);
       be(n, 8);
     }
-    const size_t at = buf.size();
-    buf.resize(at + n * 4);
-    char *d = &buf[at];
-    for (uint64_t i = 0; i < n; ++i) {
-      const uint32_t v = (uint32_t)p[i];
-      d[4 * i] = (char)(v >> 24);
-      d[4 * i + 1] = (char)(v >> 16);
-      d[4 * i + 2] = (char)(v >> 8);
-      d[4 * i + 3] = (char)v;
+    char tmp[4096];
+    for (uint64_t i = 0; i < n;) {  // appended through a small buffer: no zero-fill of the destination first
+      const uint64_t m = std::min<uint64_t>(1024, n - i);
+      for (uint64_t j = 0; j < m; ++j) {
+        const uint32_t v = (uint32_t)p[i + j];
+        tmp[4 * j] = (char)(v >> 24);
+        tmp[4 * j + 1] = (char)(v >> 16);
+        tmp[4 * j + 2] = (char)(v >> 8);
+        tmp[4 * j + 3] = (char)v;
+      }
+      buf.append(tmp, (size_t)m * 4);
+      i += m;
     }
     (void)start;
     // heap size of struct caml_ba_array with one dimension: (4 + num_dims) words
@@ -176,15 +181,26 @@ struct Node {
   uint64_t a = 0, b = 0;  // Int: a=value; Block: a=first child slot, b=count; String: a=offset,b=len; Double*: a=offset,b=count
 };
 
+// the bytes of one marshalled value; deliberately NOT value-initialised (a 4 GB archive should be touched once, by fread)
+struct Bytes {
+  std::unique_ptr<uint8_t[]> p;
+  size_t n = 0;
+  void alloc(size_t bytes) {
+    p.reset(new uint8_t[bytes ? bytes : 1]);
+    n = bytes;
+  }
+  size_t size() const { return n; }
+  uint8_t *data() { return p.get(); }
+  const uint8_t &operator[](size_t i) const { return p[i]; }
+};
+
 struct Reader {
-  std::vector<uint8_t> data;
+  Bytes data;
   size_t pos = 0;
   std::vector<Node> nodes;
   std::vector<uint32_t> children;  // node ids
   std::vector<uint32_t> objects;   // object table for shared references
   std::string bytes;
-  std::vector<double> doubles;
-  std::vector<int32_t> ints32;
 
   uint8_t u8() {
     if (pos >= data.size()) throw Error("marshal: truncated value");
@@ -208,17 +224,10 @@ struct Reader {
   uint32_t read_doubles(uint64_t n, bool little) {
     Node nd;
     nd.kind = Node::DoubleArray;
-    nd.a = doubles.size();
+    nd.a = pos;  // offset of the payload in `data`: decoded on extraction (copy_doubles), never copied in between
     nd.b = n;
-    if (pos + n * 8 > data.size()) throw Error("marshal: truncated float array");
-    doubles.resize(doubles.size() + n);
-    if (little) memcpy(&doubles[nd.a], &data[pos], n * 8);
-    else
-      for (uint64_t i = 0; i < n; ++i) {
-        uint64_t v = 0;
-        for (int k = 0; k < 8; ++k) v = (v << 8) | data[pos + i * 8 + k];
-        memcpy(&doubles[nd.a + i], &v, 8);
-      }
+    nd.tag = little ? 1 : 0;
+    if (n > (data.size() - pos) / 8) throw Error("marshal: truncated float array");
     pos += n * 8;
     return add(nd, true);
   }
@@ -265,12 +274,8 @@ struct Reader {
     if (n > (data.size() - pos) / 4) throw Error("marshal: truncated Bigarray");
     Node nd;
     nd.kind = Node::Int32Array;
-    nd.a = ints32.size();
+    nd.a = pos;  // offset of the big-endian payload in `data`
     nd.b = n;
-    ints32.resize(ints32.size() + n);
-    const uint8_t *s = &data[pos];
-    for (uint64_t i = 0; i < n; ++i)
-      ints32[nd.a + i] = (int32_t)(((uint32_t)s[4 * i] << 24) | ((uint32_t)s[4 * i + 1] << 16) | ((uint32_t)s[4 * i + 2] << 8) | s[4 * i + 3]);
     pos += n * 4;
     return add(nd, true);
   }
@@ -320,6 +325,28 @@ struct Reader {
       default: throw Error("marshal: unsupported code " + std::to_string((int)c) + " (closures and abstract values are not part of a KPop archive)");
     }
   }
+  // payload of a DoubleArray node appended to `out`
+  void copy_doubles(const Node &nd, std::vector<double> &out) const {
+    const size_t at = out.size();
+    out.resize(at + nd.b);
+    const uint8_t *s = &data[nd.a];
+    if (nd.tag) memcpy(out.data() + at, s, nd.b * 8);
+    else
+      for (uint64_t i = 0; i < nd.b; ++i) {
+        uint64_t v = 0;
+        for (int k = 0; k < 8; ++k) v = (v << 8) | s[i * 8 + k];
+        memcpy(&out[at + i], &v, 8);
+      }
+  }
+  // first `n` elements of an Int32Array node
+  std::vector<int32_t> int32s(const Node &nd, uint64_t n) const {
+    std::vector<int32_t> out;
+    out.reserve(n);
+    const uint8_t *s = &data[nd.a];
+    for (uint64_t i = 0; i < n; ++i)
+      out.push_back((int32_t)(((uint32_t)s[4 * i] << 24) | ((uint32_t)s[4 * i + 1] << 16) | ((uint32_t)s[4 * i + 2] << 8) | s[4 * i + 3]));
+    return out;
+  }
   std::string str(uint32_t id) const {
     const Node &n = nodes[id];
     if (n.kind != Node::String) throw Error("marshal: string expected");
@@ -366,7 +393,7 @@ bool read_one(FILE *f, Reader &r) {
   uint64_t data_len = 0;
   if (!read_header(f, &data_len)) return false;
   r = Reader();
-  r.data.resize(data_len);
+  r.data.alloc(data_len);
   if (data_len && fread(r.data.data(), 1, data_len, f) != data_len) throw Error("marshal: truncated value");
   r.read_value();
   return true;
@@ -418,7 +445,7 @@ bool marshal_read_matrix(FILE *f, std::string *type_name, Table *t) {
     const bool empty_atom = row.kind == Node::Block && row.b == 0;
     if (!(row.kind == Node::DoubleArray || empty_atom) || (empty_atom ? 0 : row.b) != nc)
       throw Error("marshal: matrix row " + std::to_string(i) + " is not a float array of the matrix width");
-    if (!empty_atom) t->data.insert(t->data.end(), r.doubles.begin() + (long)row.a, r.doubles.begin() + (long)(row.a + row.b));
+    if (!empty_atom) r.copy_doubles(row, t->data);
   }
   return true;
 }
@@ -514,6 +541,12 @@ void write_binary_counter(const std::string &path, const CounterCore &db) {  // 
     write_string_value(f, kArchiveVersion);
     Writer w;
     const size_t n_cols = db.col_names.size(), n_rows = db.row_names.size(), n_meta = db.meta_names.size();
+    {  // one allocation for the whole value: the spectra dominate
+      size_t names = 0;
+      for (const std::string &s : db.row_names) names += s.size() + 9;
+      for (const std::string &s : db.col_names) names += s.size() + 9;
+      w.buf.reserve(names + n_cols * (n_rows * 4 + 64 + n_meta * 16) + 4096);
+    }
     w.block_header(8, 0);
     w.integer((int64_t)n_cols);
     w.integer((int64_t)n_rows);
@@ -590,7 +623,7 @@ CounterCore read_binary_counter(const std::string &path) {  // KMerDB.of_binary,
     for (uint64_t c = 0; c < n_cols; ++c) {
       const Node &v = r.nodes[r.children[st.a + c]];
       if (v.kind != Node::Int32Array || v.b < n_rows) throw Error("marshal: KPopCounter spectrum " + std::to_string(c) + " is not an int32 Bigarray of n_rows elements");
-      db.storage[c].assign(r.ints32.begin() + (long)v.a, r.ints32.begin() + (long)(v.a + n_rows));
+      db.storage[c] = r.int32s(v, n_rows);
     }
   } catch (...) {
     fclose(f);
