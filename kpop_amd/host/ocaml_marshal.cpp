@@ -412,6 +412,12 @@ void marshal_write_matrix(FILE *f, const std::string &type_name, const Table &t)
   write_string_value(f, type_name);       // Type.to_string m.which |> output_value
   write_string_value(f, kArchiveVersion);  // archive_version |> output_value
   Writer w;                                // output_value output m.matrix
+  {
+    size_t names = 0;
+    for (const std::string &s : t.col_names) names += s.size() + 9;
+    for (const std::string &s : t.row_names) names += s.size() + 9;
+    w.buf.reserve(names + t.data.size() * 8 + t.rows() * 9 + 64);
+  }
   w.block_header(3, 0);
   w.block_header(t.col_names.size(), 0);
   for (const std::string &s : t.col_names) w.string(s);
