@@ -96,24 +96,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
+    # stdout must carry the one JSON line and nothing else, but RCCL prints a version banner on fd 1 whenever it feels
+    # like it (communicator bring-up, first collective of a kind, teardown).  So fd 1 points at stderr for the whole
+    # run, on every rank, and rank 0 writes its line to the saved descriptor at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        # RCCL prints a version banner on stdout when its communicator comes up; stdout must carry the one JSON
-        # line only, so fd 1 points at stderr until the first collective has run
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group("nccl", device_id=dev)  # RCCL; used for the barrier and the max over ranks only
-            dist.barrier()
-            torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
+        dist.init_process_group("nccl", device_id=dev)  # RCCL; used for the barrier and the max over ranks only
+        dist.barrier()
+        torch.cuda.synchronize()
 
     import kpop_amd
     from kpop_amd import api
@@ -226,10 +222,12 @@ def main():
                                       classes.cpu().numpy(), None)
             line["cpu_baseline"] = cb
             line["parity_check"] = parity
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     barrier()
     if use_dist:
         dist.destroy_process_group()
+    os.close(real_stdout)
 
 
 if __name__ == "__main__":

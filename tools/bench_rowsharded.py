@@ -37,16 +37,11 @@ def main():
     os.environ.setdefault("RANK", "0")
     os.environ.setdefault("WORLD_SIZE", "1")
     sys.stdout.flush()
-    saved = os.dup(1)
-    os.dup2(2, 1)  # RCCL's banner goes to stderr
-    try:
-        dist.init_process_group("nccl", device_id=dev)
-        dist.barrier()
-        torch.cuda.synchronize()
-    finally:
-        sys.stdout.flush()
-        os.dup2(saved, 1)
-        os.close(saved)
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)  # RCCL prints its banner on fd 1 at times of its own choosing: stdout is stderr until the JSON line
+    dist.init_process_group("nccl", device_id=dev)
+    dist.barrier()
+    torch.cuda.synchronize()
     import kpop_amd
     from kpop_amd import api
     from kpop_amd.pipeline import DevicePipeline
@@ -79,14 +74,14 @@ def main():
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     checksum = float(out.sum().item())
     if rank == 0:
-        print(json.dumps({"metric": "sequences/sec count->twist, k=%d, twister k-mer rows sharded over %d GPU(s)" % (k, world),
+        os.write(real_stdout, (json.dumps({"metric": "sequences/sec count->twist, k=%d, twister k-mer rows sharded over %d GPU(s)" % (k, world),
                           "value": n * a.steps / float(el.item()), "unit": "sequences/sec", "n_gpus": world, "steps": a.steps,
                           "warmup": a.warmup, "ms_per_step": float(el.item()) / a.steps * 1e3, "scaling": "strong", "dtype": "f64",
                           "data": "synthetic",
                           "config": {"workload": "%d reads x %d bp on every rank, k=%d, %d dims (+1 accumulator), rank 0 holds %d "
                                                  "k-mer rows = %.1f GB" % (n, L, k, d, info["n_cols"], info["device_bytes"] / 1e9),
                                      "collective": "one all-reduce(sum) of %d x %d f64 per step" % (n, d + 1)},
-                          "twister_build_s": t_build, "checksum": checksum}), flush=True)
+                          "twister_build_s": t_build, "checksum": checksum}) + "\n").encode())
     dist.barrier()
     dist.destroy_process_group()
 
