@@ -3,22 +3,35 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic reads already resident in HBM:
-fused count->twist (kpop_dev_count_twist) then rowwise distances to the class vectors
-(kpop_dev_distance_rowwise).  Workload = BASELINE.json's metric: 100k x 150 bp reads, k=12, with the
-survey's headline synthetic shape D=64 dims, C=65 classes.  For N>1 the driver launches one
-rank per GPU with torch.distributed.run; reads shard across ranks with no data-path collective (distances
-are vs a replicated class set), every rank does the same per-GPU work: weak scaling.
+A "step" is one pass of the hot path over one batch of synthetic reads already resident in HBM.
+
+N = 1 (default): the workload BASELINE.json's metric is quoted on -- 100k x 150 bp reads, k=12, with the survey's
+headline synthetic shape D=64 dims, C=65 classes: fused count->twist (kpop_dev_count_twist), then
+rowwise distances to the class vectors (kpop_dev_distance_rowwise).  The same line also carries, measured in the same
+run and never mixed into `value`: the PCIe-inclusive rate through the host-buffer entry points, the file-to-file rate
+through the drop-in binaries, the CPU baseline, and BASELINE config 4 (1M reads) on this one GPU -- the N = 1 point of
+the strong-scaling curve below.
+
+N > 1: BASELINE config 4, STRONG scaling -- 1M x 150 bp reads IN TOTAL, cut into contiguous shards, one rank per GPU;
+every rank twists its shard in chunks, the RCCL all-gather of chunk c (xGMI, own stream) travels under the twist of
+chunk c+1, and the rank's rows go through the distances to the class set.  After the timed region the gathered matrix
+is checked (an order-free checksum over all ranks) and used: every rank summarises a few of its rows against all
+1M twisted vectors (the all-vs-all summary of lib/Matrix.ml:691-766, N x N never formed), timed separately.
+`python bench.py --gpus N` starts its own ranks (a fresh `torch.distributed.run` child, before this process touches
+any GPU); under an existing launcher (WORLD_SIZE set) it is one of the ranks.
+
+`--workload headline --scaling weak` is round 1's mode: 100k reads per GPU, no collective (distances to a replicated
+class set need none).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -26,208 +39,485 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 READ_SEED, TWISTER_SEED, CLASS_SEED = 0x4B506F70, 0x5EED, 0xC1A55
+XGMI_DIRECT_ESTIMATE_MS = 0.42  # 64 MB per shard over 7 links x 153 GB/s, one shard per link
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads", type=int, default=100000, help="reads per GPU (weak) or in total (strong)")
+    ap.add_argument("--workload", choices=["auto", "headline", "config4"], default="auto",
+                    help="auto = headline at 1 GPU, config4 (1M reads, all-gather) beyond")
+    ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto",
+                    help="weak: --reads per GPU; strong: --reads in total (auto: weak for headline, strong for config4)")
+    ap.add_argument("--reads", type=int, default=0, help="0 = 100,000 (headline) or 1,000,000 (config4)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("-k", type=int, default=12)
     ap.add_argument("--dims", type=int, default=64)
     ap.add_argument("--classes", type=int, default=65)
-    ap.add_argument("--class-len", type=int, default=500)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--class-len", type=int, default=30000, help="class genomes (SURVEY.md 8d: 30 kb)")
+    ap.add_argument("--ag-chunks", type=int, default=4, help="config4: pieces the all-gather is cut into")
+    ap.add_argument("--queries", type=int, default=1024, help="config4: rows (in total) of the all-vs-all summary")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the PCIe-inclusive, file-to-file and config-4 legs of the 1-GPU line")
+    ap.add_argument("--f2f-reads", type=int, default=1000000, help="reads of the file-to-file leg")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even at world size 1 (exercises the N>1 code path)")
-    return ap.parse_args()
+    ap.add_argument("--spawn", action="store_true", help="start the ranks as a child launcher even for --gpus 1 (tests the relay)")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(args, metric, k_gpu_twisted, k_gpu_dist, classes_host, sample_offsets):
+# ---------------------------------------------------------------------------------------------------------
+# the launcher: no torch, no GPU call in this process
+# ---------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    argv = [a for a in sys.argv[1:] if a != "--spawn"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL cannot share buffers across ranks without it
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for raw in proc.stdout:
+        text = raw.decode("utf-8", "replace")
+        if text.startswith('{"metric"'):
+            line = text
+        else:
+            sys.stderr.write(text)
+    rc = proc.wait()
+    if line is not None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited 0 but printed no JSON line\n")
+        rc = 1
+    sys.exit(rc)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------------
+class Rank:
+    def __init__(self, args):
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        self.args, self.np, self.torch, self.dist = args, np, torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if args.gpus != self.world:
+            sys.exit("--gpus %d disagrees with WORLD_SIZE %d" % (args.gpus, self.world))
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
+        # KPOP_BENCH_SHARE_GPU=1: every rank on GPU 0 and the collectives through gloo + host staging -- a rig for
+        # running the N>1 code on a 1-GPU box; what it measures is not a scaling number and the line says so
+        self.shared_gpu = os.environ.get("KPOP_BENCH_SHARE_GPU") == "1"
+        dev_index = 0 if self.shared_gpu else self.local_rank
+        torch.cuda.set_device(dev_index)
+        self.dev = torch.device("cuda", dev_index)
+        self.use_dist = self.world > 1 or args.force_dist
+        # stdout must carry the one JSON line and nothing else, but RCCL prints a version banner on fd 1 whenever it
+        # feels like it.  So fd 1 points at stderr for the whole run, on every rank, and rank 0 writes its line to the
+        # saved descriptor at the very end.
+        sys.stdout.flush()
+        self.real_stdout = os.dup(1)
+        os.dup2(2, 1)
+        if self.use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            if self.shared_gpu:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=self.dev)  # RCCL
+            self.barrier()
+        import kpop_amd
+        from kpop_amd import api
+        self.kpop, self.api = kpop_amd, api
+        kpop_amd.init(dev_index)
+        self.stream = torch.cuda.current_stream()
+        self.sp = self.stream.cuda_stream
+        self.tw = kpop_amd.Twister.synth(TWISTER_SEED, args.k, args.dims)
+        k, d, C = args.k, args.dims, args.classes
+        cbases = torch.empty(C * args.class_len, dtype=torch.uint8, device=self.dev)
+        coffs = torch.empty(C + 1, dtype=torch.int64, device=self.dev)
+        api.dev_synth_reads(CLASS_SEED, C, args.class_len, cbases.data_ptr(), coffs.data_ptr(), stream=self.sp)
+        self.classes = torch.zeros(C, d, dtype=torch.float64, device=self.dev)
+        api.dev_count_twist(self.tw, cbases.data_ptr(), coffs.data_ptr(), C, C * args.class_len, args.class_len,
+                            self.classes.data_ptr(), stream=self.sp)
+        # inertia of the synthetic twister: w_d ~ 2^(-d/8), sum 1; metric = powers(1,1,2) of it
+        w = np.exp2(-np.arange(d, dtype=np.float64) / 8.0)
+        self.metric_host = kpop_amd.metric_compute(w / w.sum())
+        self.metric = torch.from_numpy(self.metric_host).to(self.dev)
+        torch.cuda.synchronize()
+
+    # -- plumbing
+    def barrier(self):
+        if self.use_dist:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if not self.use_dist:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cpu" if self.shared_gpu else self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def synth_reads(self, n, first):
+        t, L = self.torch, self.args.read_len
+        bases = t.empty(max(n * L, 1), dtype=t.uint8, device=self.dev)
+        offsets = t.empty(n + 1, dtype=t.int64, device=self.dev)
+        self.api.dev_synth_reads(READ_SEED, n, L, bases.data_ptr(), offsets.data_ptr(), first_read=first, stream=self.sp)
+        return bases, offsets
+
+    def timed(self, step, steps, warmup):
+        """warmup, then exactly `steps` steps between barrier + synchronize pairs; -> seconds, max over ranks"""
+        for _ in range(warmup):
+            step(None)
+        self.torch.cuda.synchronize()
+        self.barrier()
+        self.torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        self.torch.cuda.synchronize()
+        self.barrier()
+        self.torch.cuda.synchronize()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def bytes_per_read(self):
+        a = self.args
+        windows = max(a.read_len - a.k + 1, 0)
+        return a.read_len + windows * a.dims * 8 + a.dims * 8  # SURVEY.md 8d: read L B, gather nnz*D*8 B, write D*8 B
+
+    def roofline(self, n_reads_per_launch, avg_ms, launches_note=None):
+        a = self.args
+        alg = n_reads_per_launch * self.bytes_per_read()
+        achieved = alg / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = "count_twist_wave_kernel:n=%d,L=%d,k=%d,D=%d" % (n_reads_per_launch, a.read_len, a.k, a.dims)
+                if key in tj:
+                    traffic = tj[key].get("hbm_bytes_per_launch")
+                    traffic_src = ("not measured in this run: PMC passes of the same launch shape, %s"
+                                   % tj[key].get("source", "profiles/"))
+            except Exception:
+                pass
+        out = {"kernel": "count_twist_wave_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+               "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms}
+        if launches_note:
+            out["note"] = launches_note
+        return out
+
+    # -- the headline job: reads resident, count->twist then distances to the classes, no collective
+    def run_headline(self, n_local, first, steps, warmup, want_outputs=0):
+        t, a = self.torch, self.args
+        d, C, L = a.dims, a.classes, a.read_len
+        bases, offsets = self.synth_reads(n_local, first)
+        twisted = t.zeros(max(n_local, 1), d, dtype=t.float64, device=self.dev)
+        dmat = t.zeros(max(n_local, 1), C, dtype=t.float64, device=self.dev)
+        work = t.empty(self.api.dev_distance_workspace_bytes(C, n_local, d), dtype=t.uint8, device=self.dev)
+        events = [[t.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+
+        def step(i):
+            ev = events[i] if i is not None else None
+            if ev:
+                ev[0].record(self.stream)
+            self.api.dev_count_twist(self.tw, bases.data_ptr(), offsets.data_ptr(), n_local, n_local * L, L,
+                                     twisted.data_ptr(), stream=self.sp)
+            if ev:
+                ev[1].record(self.stream)
+            self.api.dev_distance_rowwise(self.classes.data_ptr(), C, twisted.data_ptr(), n_local, d, self.metric.data_ptr(),
+                                          work.data_ptr(), dmat.data_ptr(), stream=self.sp)
+            if ev:
+                ev[2].record(self.stream)
+
+        elapsed = self.timed(step, steps, warmup)
+        ms_fused = float(self.np.mean([e[0].elapsed_time(e[1]) for e in events]))
+        ms_dist = float(self.np.mean([e[1].elapsed_time(e[2]) for e in events]))
+        res = {"elapsed": elapsed, "ms_fused": ms_fused, "ms_dist": ms_dist}
+        if want_outputs:
+            m = min(n_local, want_outputs)
+            res["twisted"] = twisted[:m].cpu().numpy()
+            res["dmat"] = dmat[:m].cpu().numpy()
+        return res
+
+    # -- BASELINE config 4: reads in total, sharded; chunked all-gather under the twist; distances to the classes
+    def run_config4(self, n_total, steps, warmup):
+        from kpop_amd.pipeline import DevicePipeline, DeviceCompute, ShardedJob
+        from kpop_amd.shard import ChunkedGather
+        t, a, np = self.torch, self.args, self.np
+        layout = ChunkedGather(n_total, self.world, a.ag_chunks if self.world > 1 or self.use_dist else 1,
+                               staging="cpu" if self.shared_gpu else None)
+        lo, hi = layout.bounds[self.rank]
+        bases, offsets = self.synth_reads(hi - lo, lo)
+        pipe = DevicePipeline(self.tw, self.metric_host, self.dev)
+        comp = DeviceCompute(pipe, bases, offsets, a.read_len, self.classes)
+        comm = t.cuda.Stream(device=self.dev) if (self.world > 1 or self.use_dist) else None
+        job = ShardedJob(t, comp, layout, self.rank, a.dims, a.classes, self.dev, comm_stream=comm)
+        pipe._workspace(a.classes, job.n_local)  # allocated before the timed region
+        per_step_events = []
+
+        def step(i):
+            ev = {} if i is not None else None
+            job.step(ev)
+            if ev is not None:
+                per_step_events.append(ev)
+
+        elapsed = self.timed(step, steps, warmup)
+        res = {"elapsed": elapsed, "n_local": job.n_local, "chunks": layout.n_chunks, "chunk_rows": layout.chunk_rows}
+        tw_ms = [p[0].elapsed_time(p[1]) for ev in per_step_events for p in ev.get("twist", [])]
+        res["ms_twist_chunk"] = float(np.mean(tw_ms)) if tw_ms else None
+        res["ms_twist_step"] = float(np.sum(tw_ms) / max(len(per_step_events), 1)) if tw_ms else None
+        res["ms_dist"] = float(np.mean([p[0].elapsed_time(p[1]) for ev in per_step_events for p in ev.get("distance", [])]))
+        ag = [p[0].elapsed_time(p[1]) for ev in per_step_events for p in ev.get("gather", [])]
+        if ag:
+            res["ms_allgather_step_on_its_stream"] = float(np.sum(ag) / len(per_step_events))
+        if job.full is not None:
+            # the exchange alone, nothing else running: all chunks back to back on the comm stream
+            t.cuda.synchronize()
+            self.barrier()
+            reps, e0, e1 = 5, t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+            with t.cuda.stream(comm):
+                for c in range(layout.n_chunks):
+                    layout.gather_chunk(c, job.local, job.full)  # warm
+                e0.record(comm)
+                for _ in range(reps):
+                    for c in range(layout.n_chunks):
+                        layout.gather_chunk(c, job.local, job.full)
+                e1.record(comm)
+            t.cuda.synchronize()
+            alone = self.max_over_ranks(e0.elapsed_time(e1) / reps)
+            rx = layout.bytes_received_per_rank(a.dims)
+            res["allgather"] = {"ms_alone": alone, "bytes_received_per_rank": rx,
+                                "bytes_gathered_total": layout.world * layout.per_pad * a.dims * 8,
+                                "rx_GBps_per_rank": rx / (alone * 1e-3) / 1e9 if alone > 0 else None,
+                                "direct_xgmi_estimate_ms": XGMI_DIRECT_ESTIMATE_MS * (layout.per_pad * a.dims * 8) / 64e6,
+                                "ranks_in_communicator": self.dist.get_world_size() if self.use_dist else 1,
+                                "backend": "gloo+host staging (KPOP_BENCH_SHARE_GPU rig)" if self.shared_gpu else "nccl (RCCL)"}
+            # is the gathered matrix the union of the shards?  order-free checksum of the f64 bit patterns
+            mine = job.local[:job.n_local].view(t.int64).sum()
+            got = job.full.view(t.int64).sum()  # padding rows are zeros
+            tot = mine.clone().cpu() if self.shared_gpu else mine.clone()
+            if self.use_dist:
+                self.dist.all_reduce(tot)
+            res["gather_checksum_ok"] = bool(int(tot.item()) == int(got.item()))
+        # the gathered matrix in use: a few rows of every rank against all n_total twisted vectors
+        q_rank = max(1, a.queries // self.world)
+        t.cuda.synchronize()
+        self.barrier()
+        t0 = time.perf_counter()
+        qid, stats, nn, idx, dd, z = job.all_vs_all_summary(q_rank, keep_at_most=2, max_neighbours=8)
+        t.cuda.synchronize()
+        ava = self.max_over_ranks(time.perf_counter() - t0)
+        idx_h, dd_h, nn_h = idx.cpu().numpy(), dd.cpu().numpy(), nn.cpu().numpy()
+        # every read is its own nearest neighbour at distance 0 (identical reads would tie and also be listed)
+        own = all((dd_h[j, 0] == 0.0) and (int(qid[j]) in idx_h[j, :min(int(nn_h[j]), idx_h.shape[1])].tolist())
+                  for j in range(len(qid)))
+        own_all = self.max_over_ranks(0.0 if own else 1.0) == 0.0
+        res["all_vs_all"] = {"queries_total": q_rank * self.world, "against": n_total, "seconds": ava,
+                             "pairs_per_second": q_rank * self.world * n_total / ava if ava > 0 else None,
+                             "every_query_finds_itself_at_distance_0": own_all,
+                             "note": "after the timed region; kpop_dev_distance_summary on the gathered matrix, N x N never formed"}
+        return res
+
+    def finish(self, line):
+        if self.rank == 0:
+            sys.stdout.flush()
+            os.write(self.real_stdout, (json.dumps(line) + "\n").encode())
+        self.barrier()
+        if self.use_dist:
+            self.dist.destroy_process_group()
+        os.close(self.real_stdout)
+
+
+def cpu_baseline(R, n_reads_gpu, gpu_twisted, gpu_dist, classes_host):
     """The oracle (CPU restatement of the reference's algorithm, kind "port") timed on this box's host
     cores on a bounded sample of the same workload; also used to check the GPU results of that sample."""
+    import numpy as np
     from oracle import oracle as O
+    args = R.args
     threads = os.cpu_count() or 1
     k, d, L = args.k, args.dims, args.read_len
     t0 = time.time()
     cols = O.enumerate_kmers(k)
     T = O.synth_twister(TWISTER_SEED, d, cols)  # the reference's dims-major layout
     setup_s = time.time() - t0
-    # calibrate on 2000 reads, then size the sample for ~cpu_seconds of wall time
     calib = 2000
     bases, offs = O.synth_reads(READ_SEED, calib, L)
-    _, _, secs = O.pipeline(bases, offs, k, T, cols, classes_host, metric, threads=threads)
+    _, _, secs = O.pipeline(bases, offs, k, T, cols, classes_host, R.metric_host, threads=threads)
     rate = calib / max(secs, 1e-9)
-    n = int(min(args.reads, max(calib, rate * args.cpu_seconds)))
+    n = int(min(n_reads_gpu, max(calib, rate * args.cpu_seconds)))
     bases, offs = O.synth_reads(READ_SEED, n, L)
-    tw, di, secs = O.pipeline(bases, offs, k, T, cols, classes_host, metric, threads=threads)
+    tw, di, secs = O.pipeline(bases, offs, k, T, cols, classes_host, R.metric_host, threads=threads)
     out = {"value": n / secs, "unit": "sequences/sec", "cores": threads, "kind": "port",
-           "sample": "first %d of the %d synthetic reads, count->twist->distance in oracle/kpop_oracle.c "
-                     "(OpenMP over reads; twister in the reference's dims-major layout, generated in %.1f s "
-                     "outside the timed region)" % (n, args.reads, setup_s)}
-    m = min(n, k_gpu_twisted.shape[0])
+           "sample": "first %d of the %d synthetic reads, count->twist->distance in oracle/kpop_oracle.c, in memory "
+                     "(OpenMP over reads; twister in the reference's dims-major layout, generated in %.1f s outside the "
+                     "timed region).  The reference itself also writes the spectra as text (bin/KPopCount.ml:46), pipes "
+                     "them and parses them back in a serial producer (lib/Twister.ml:91-145); the port skips both, so "
+                     "the real OCaml path is slower than this figure" % (n, n_reads_gpu, setup_s)}
+    m = min(n, gpu_twisted.shape[0])
     parity = {
         "reads_checked": m,
-        "twisted_max_abs_err": float(np.max(np.abs(k_gpu_twisted[:m] - tw[:m]))),
-        "twisted_bit_exact": bool(np.array_equal(k_gpu_twisted[:m], tw[:m])),
-        "distance_max_rel_err": float(np.max(np.abs(k_gpu_dist[:m] - di[:m]) / np.maximum(di[:m], 1e-300))),
+        "twisted_max_abs_err": float(np.max(np.abs(gpu_twisted[:m] - tw[:m]))),
+        "twisted_bit_exact": bool(np.array_equal(gpu_twisted[:m], tw[:m])),
+        "distance_max_rel_err": float(np.max(np.abs(gpu_dist[:m] - di[:m]) / np.maximum(di[:m], 1e-300))),
     }
     return out, parity
 
 
+def pcie_inclusive(R, n, reps=5):
+    """The same step through the host-buffer entry points (kpop_count_twist + kpop_distance_rowwise): reads start in
+    host memory, distances end there; caller-owned buffers, already touched (what a C/OCaml caller hands over)."""
+    import ctypes as C
+    import numpy as np
+    from kpop_amd import _lib
+    a = R.args
+    lib = _lib.load()
+    L, d, Cn = a.read_len, a.dims, a.classes
+    bases_d, offs_d = R.synth_reads(n, 0)
+    R.torch.cuda.synchronize()
+    bases = bases_d.cpu().numpy()
+    offs = offs_d.cpu().numpy().astype(np.uint64)
+    classes = R.classes.cpu().numpy()
+    twisted = np.zeros((n, d))
+    dist = np.zeros((n, Cn))
+    p = lambda arr, ty: arr.ctypes.data_as(C.POINTER(ty))
+
+    def once():
+        rc = lib.kpop_count_twist(R.tw.handle, p(bases, C.c_uint8), p(offs, C.c_uint64), n, 0, 1, p(twisted, C.c_double))
+        rc = rc or lib.kpop_distance_rowwise(p(classes, C.c_double), Cn, p(twisted, C.c_double), n, d,
+                                             p(R.metric_host, C.c_double), 0, 2.0, 1, p(dist, C.c_double))
+        if rc:
+            raise RuntimeError(lib.kpop_last_error().decode())
+    once()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        once()
+        ts.append(time.perf_counter() - t0)
+    best = min(ts)
+    return {"value": n / best, "unit": "sequences/sec", "ms_per_step": best * 1e3,
+            "bytes_up": int(bases.nbytes + offs.nbytes + twisted.nbytes + classes.nbytes), "bytes_down": int(twisted.nbytes + dist.nbytes),
+            "note": "kpop_count_twist + kpop_distance_rowwise from pageable host buffers (best of %d): H2D, kernels, D2H; "
+                    "the twisted rows cross PCIe twice because the two entry points are separate calls" % reps}
+
+
+def file_to_file(R):
+    """FASTA file -> .KPopTwisted / summary through the drop-in binaries, as README.md:606,656 chain them."""
+    tool = os.path.join(ROOT, "tools", "file_to_file.py")
+    if not os.path.exists(tool):
+        return {"value": None, "note": "tools/file_to_file.py is missing"}
+    try:
+        out = subprocess.run([sys.executable, tool, "--reads", str(R.args.f2f_reads), "-k", str(R.args.k), "--json"],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        if out.returncode != 0:
+            return {"value": None, "note": "tools/file_to_file.py failed: " + out.stderr.decode("utf-8", "replace")[-400:]}
+        return json.loads(out.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:  # the leg is a report, never a reason to lose the headline line
+        return {"value": None, "note": "file-to-file leg failed: %r" % (e,)}
+
+
 def main():
     args = parse_args()
-    import torch
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
-        sys.exit("--gpus %d disagrees with WORLD_SIZE %d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or args.force_dist
-    # stdout must carry the one JSON line and nothing else, but RCCL prints a version banner on fd 1 whenever it feels
-    # like it (communicator bring-up, first collective of a kind, teardown).  So fd 1 points at stderr for the whole
-    # run, on every rank, and rank 0 writes its line to the saved descriptor at the very end.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL; used for the barrier and the max over ranks only
-        dist.barrier()
-        torch.cuda.synchronize()
-
-    import kpop_amd
-    from kpop_amd import api
-    kpop_amd.init(local_rank)
-
+    if args.gpus < 1:
+        sys.exit("--gpus must be positive")
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        self_launch(args)  # never returns
+    workload = args.workload if args.workload != "auto" else ("headline" if args.gpus == 1 else "config4")
+    scaling = args.scaling if args.scaling != "auto" else ("weak" if workload == "headline" else "strong")
+    reads = args.reads or (100000 if workload == "headline" else 1000000)
+    R = Rank(args)
     k, d, L, C = args.k, args.dims, args.read_len, args.classes
-    if args.scaling == "weak":
-        n_local, first = args.reads, rank * args.reads
-    else:
-        per = (args.reads + world - 1) // world
-        first = min(rank * per, args.reads)
-        n_local = min(per, args.reads - first)
-    n_total = args.reads * world if args.scaling == "weak" else args.reads
+    common_cfg = {"read_len": L, "k": k, "n_dims": d, "n_classes": C, "class_len": args.class_len,
+                  "twister": "%d canonical k-mers x %d dims, f64, synthetic, replicated on every GPU" % (R.tw.info()["n_cols"], d)}
+    if R.shared_gpu:
+        common_cfg["rig"] = "KPOP_BENCH_SHARE_GPU=1: all ranks on one GPU, collectives through gloo + host staging; not a scaling number"
 
-    stream = torch.cuda.current_stream()
-    sp = stream.cuda_stream
-    tw = kpop_amd.Twister.synth(TWISTER_SEED, k, d)
-    bases = torch.empty(max(n_local * L, 1), dtype=torch.uint8, device=dev)
-    offsets = torch.empty(n_local + 1, dtype=torch.int64, device=dev)
-    api.dev_synth_reads(READ_SEED, n_local, L, bases.data_ptr(), offsets.data_ptr(), first_read=first, stream=sp)
-    cbases = torch.empty(C * args.class_len, dtype=torch.uint8, device=dev)
-    coffs = torch.empty(C + 1, dtype=torch.int64, device=dev)
-    api.dev_synth_reads(CLASS_SEED, C, args.class_len, cbases.data_ptr(), coffs.data_ptr(), stream=sp)
-    classes = torch.zeros(C, d, dtype=torch.float64, device=dev)
-    api.dev_count_twist(tw, cbases.data_ptr(), coffs.data_ptr(), C, C * args.class_len, args.class_len, classes.data_ptr(),
-                        stream=sp)
-    # inertia of the synthetic twister (SURVEY.md 8d): w_d ~ 2^(-d/8), sum 1; metric = powers(1,1,2) of it
-    w = np.exp2(-np.arange(d, dtype=np.float64) / 8.0)
-    metric_host = kpop_amd.metric_compute(w / w.sum())
-    metric = torch.from_numpy(metric_host).to(dev)
-    twisted = torch.zeros(max(n_local, 1), d, dtype=torch.float64, device=dev)
-    dmat = torch.zeros(max(n_local, 1), C, dtype=torch.float64, device=dev)
-    work = torch.empty(api.dev_distance_workspace_bytes(C, n_local, d), dtype=torch.uint8, device=dev)
-
-    def step(ev=None):
-        if ev:
-            ev[0].record(stream)
-        api.dev_count_twist(tw, bases.data_ptr(), offsets.data_ptr(), n_local, n_local * L, L, twisted.data_ptr(),
-                            stream=sp)
-        if ev:
-            ev[1].record(stream)
-        api.dev_distance_rowwise(classes.data_ptr(), C, twisted.data_ptr(), n_local, d, metric.data_ptr(),
-                                 work.data_ptr(), dmat.data_ptr(), stream=sp)
-        if ev:
-            ev[2].record(stream)
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(events[i])
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    if rank == 0:
-        ms_fused = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
-        ms_dist = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
-        windows = max(L - k + 1, 0)
-        bytes_per_read = L + windows * d * 8 + d * 8  # SURVEY.md 8d: read L B, gather nnz*D*8 B, write D*8 B
-        achieved = n_local * bytes_per_read / (ms_fused * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = "count_twist_wave_kernel:n=%d,L=%d,k=%d,D=%d" % (n_local, L, k, d)
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        line = {
-            "metric": "sequences/sec end-to-end count->twist->distance, k=%d, %dk x %dbp" % (k, args.reads // 1000, L),
-            "value": n_total * args.steps / elapsed,
-            "unit": "sequences/sec",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": args.scaling,
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": "%d reads x %d bp per GPU, k=%d DNA-ds, twister %d canonical k-mers x %d dims (f64, "
-                                   "synthetic), %d class vectors, euclidean, metric powers(1,1,2)"
-                                   % (n_local, L, k, tw.info()["n_cols"], d, C),
-                       "reads_per_gpu": n_local, "read_len": L, "k": k, "n_dims": d, "n_classes": C,
-                       "sharding": "reads sharded across ranks, twister and classes replicated, no collective"},
-            "roofline": {"kernel": "count_twist_wave_kernel", "bound": "hbm", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": n_local * bytes_per_read, "avg_launch_ms": ms_fused},
-            "kernels_ms": {"count_twist": ms_fused, "distance_rowwise(+norms)": ms_dist},
-        }
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs on rank 0 at N=1 only
-            m = min(n_local, 20000)
-            cb, parity = cpu_baseline(args, metric_host, twisted[:m].cpu().numpy(), dmat[:m].cpu().numpy(),
-                                      classes.cpu().numpy(), None)
+    if workload == "headline":
+        if scaling == "weak":
+            n_local, first, n_total = reads, R.rank * reads, reads * R.world
+        else:
+            from kpop_amd.shard import shard_bounds
+            lo, hi = shard_bounds(reads, R.rank, R.world)
+            n_local, first, n_total = hi - lo, lo, reads
+        res = R.run_headline(n_local, first, args.steps, args.warmup, want_outputs=20000 if R.world == 1 else 0)
+        line = None
+        if R.rank == 0:
+            line = {
+                "metric": "sequences/sec end-to-end count->twist->distance, k=%d, %dk x %dbp" % (k, reads // 1000, L),
+                "value": n_total * args.steps / res["elapsed"],
+                "unit": "sequences/sec", "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": res["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "value_is": "device-resident: reads already in HBM when the timed region starts, results left in HBM "
+                            "(see pcie_inclusive and file_to_file for what a host caller and a shell user get)",
+                "config": dict(common_cfg, workload="%d reads x %d bp%s, k=%d DNA-ds, %d class vectors, euclidean, metric powers(1,1,2)"
+                               % (reads, L, " per GPU" if scaling == "weak" else " in total", k, C),
+                               reads_per_gpu=n_local,
+                               sharding="reads sharded across ranks, twister and classes replicated, no collective"),
+                "roofline": R.roofline(n_local, res["ms_fused"]),
+                "kernels_ms": {"count_twist": res["ms_fused"], "distance_rowwise(+norms)": res["ms_dist"]},
+            }
+        if R.world == 1 and not args.no_cpu_baseline:
+            cb, parity = cpu_baseline(R, n_local, res["twisted"], res["dmat"], R.classes.cpu().numpy())
             line["cpu_baseline"] = cb
             line["parity_check"] = parity
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(line) + "\n").encode())
-    barrier()
-    if use_dist:
-        dist.destroy_process_group()
-    os.close(real_stdout)
+        if R.world == 1 and not args.no_extras:
+            line["pcie_inclusive"] = pcie_inclusive(R, n_local)
+            c4 = R.run_config4(1000000, max(3, min(args.steps, 10)), 2)
+            line["config4_on_this_gpu"] = {
+                "value": 1000000 * max(3, min(args.steps, 10)) / c4["elapsed"], "unit": "sequences/sec",
+                "ms_per_step": c4["elapsed"] / max(3, min(args.steps, 10)) * 1e3,
+                "kernels_ms": {"count_twist": c4["ms_twist_step"], "distance_rowwise(+norms)": c4["ms_dist"]},
+                "all_vs_all": c4["all_vs_all"],
+                "note": "BASELINE config 4 (1M x %d bp in total) on one GPU: the N = 1 point of the strong-scaling curve "
+                        "`bench.py --gpus N` reports for N > 1" % L}
+            line["file_to_file"] = file_to_file(R)
+        R.finish(line)
+        return
+
+    # config 4
+    res = R.run_config4(reads, args.steps, args.warmup)
+    line = None
+    if R.rank == 0:
+        line = {
+            "metric": "sequences/sec end-to-end count->twist->all-gather->distance, k=%d, %dk x %dbp in total" % (k, reads // 1000, L),
+            "value": reads * args.steps / res["elapsed"],
+            "unit": "sequences/sec", "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "value_is": "device-resident; the all-gather of the twisted vectors is inside the timed region",
+            "config": dict(common_cfg, workload="BASELINE config 4: %d reads x %d bp in total, k=%d DNA-ds, sharded over %d GPU(s); "
+                           "twist in %d chunks with the all-gather of each chunk on its own stream; distances of the "
+                           "rank's rows to %d class vectors" % (reads, L, k, R.world, res["chunks"], C),
+                           reads_per_gpu=res["n_local"],
+                           sharding="reads in contiguous shards; twister, classes and metric replicated; ONE exchange: "
+                                    "all-gather of twisted vectors (RCCL over xGMI)",
+                           n1_reference="the 1-GPU line's config4_on_this_gpu.value is the same job on one GPU"),
+            "roofline": R.roofline(res["chunk_rows"], res["ms_twist_chunk"],
+                                   "one launch per chunk of %d reads, overlapped with the exchange of the previous chunk" % res["chunk_rows"]),
+            "kernels_ms": {"count_twist_per_step": res["ms_twist_step"], "distance_rowwise(+norms)": res["ms_dist"],
+                           "allgather_on_its_stream_per_step": res.get("ms_allgather_step_on_its_stream")},
+            "collective": res.get("allgather"),
+            "gather_checksum_ok": res.get("gather_checksum_ok"),
+            "all_vs_all": res["all_vs_all"],
+        }
+    R.finish(line)
 
 
 if __name__ == "__main__":

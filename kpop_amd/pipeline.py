@@ -76,3 +76,115 @@ class DevicePipeline:
         else:
             full, lo, hi = twisted_local, 0, n_total
         return lo, hi, self.distance_rowwise(full, twisted_local)
+
+
+class DeviceCompute:
+    """The kpop_dev_* calls a ShardedJob needs, on reads and class vectors resident in this rank's HBM."""
+
+    def __init__(self, pipeline, bases, offsets, read_len, classes):
+        self.p, self.bases, self.offsets, self.read_len, self.classes = pipeline, bases, offsets, int(read_len), classes
+        self.torch = pipeline.torch
+        self._summary = None
+
+    def count_twist(self, first, n, out):
+        """reads [first, first+n) of the shard -> out[0:n] (enqueued on the current stream)"""
+        if n:
+            api.dev_count_twist(self.p.tw, self.bases.data_ptr(), self.offsets.data_ptr() + 8 * first, n, self.bases.numel(),
+                                self.read_len, out.data_ptr(), normalize=self.p.normalize_counts, stream=self.p._stream())
+
+    def distance_to_classes(self, twisted, out):
+        if twisted.shape[0]:
+            self.p.distance_rowwise(self.classes, twisted, out)
+
+    def summary(self, m1, m2, keep_at_most, max_neighbours):
+        """Matrix.summarize_rowwise (lib/Matrix.ml:691-766) of the rows of m2 against all of m1, never forming r2 x r1"""
+        t, dev = self.torch, self.p.dev
+        r1, r2 = m1.shape[0], m2.shape[0]
+        stats = t.zeros(max(r2, 1), 4, dtype=t.float64, device=dev)[:r2]
+        n = t.zeros(max(r2, 1), dtype=t.int32, device=dev)[:r2]
+        idx = t.zeros(max(r2, 1), max_neighbours, dtype=t.int32, device=dev)[:r2]
+        dd = t.zeros(max(r2, 1), max_neighbours, dtype=t.float64, device=dev)[:r2]
+        z = t.zeros(max(r2, 1), max_neighbours, dtype=t.float64, device=dev)[:r2]
+        if r2:
+            api.dev_distance_summary(m1.data_ptr(), r1, m2.data_ptr(), r2, self.p.n_dims, self.p.metric.data_ptr(),
+                                     self.p._workspace(r1, r2).data_ptr(), stats.data_ptr(), n.data_ptr(), idx.data_ptr(),
+                                     dd.data_ptr(), z.data_ptr(), keep_at_most=keep_at_most, max_neighbours=max_neighbours,
+                                     kind=self.p.kind, p=self.p.p, normalize=self.p.normalize_distance, stream=self.p._stream())
+        return stats, n, idx, dd, z
+
+
+class ShardedJob:
+    """BASELINE config 4 on one rank: this rank's reads -> count->twist in chunks, the all-gather of chunk c (RCCL
+    over xGMI, on `comm_stream`) under the twist of chunk c+1, distances of the rank's rows to the class set, and --
+    on the gathered matrix -- the all-vs-all summary of any of its rows (lib/Matrix.ml:691-766; the N x N matrix is never
+    formed).  `compute` does the arithmetic (DeviceCompute on a GPU; the CPU tests put the oracle there),
+    so what this class owns is the order of operations, the streams and the row bookkeeping."""
+
+    def __init__(self, torch, compute, layout, rank, n_dims, n_classes, device, comm_stream=None, group=None):
+        from .shard import ChunkedGather  # noqa: F401  (layout is one)
+        self.torch, self.compute, self.layout, self.rank, self.group = torch, compute, layout, rank, group
+        self.lo, self.hi = layout.bounds[rank]
+        self.n_local = self.hi - self.lo
+        self.local = layout.local_buffer(torch, n_dims, device)
+        self.full = layout.full_buffer(torch, n_dims, device) if layout.world > 1 or self._dist_on() else None
+        self.dmat = torch.zeros(max(self.n_local, 1), n_classes, dtype=torch.float64, device=device)[:self.n_local]
+        self.comm_stream = comm_stream
+        self.is_cuda = getattr(device, "type", str(device)) == "cuda"
+
+    @staticmethod
+    def _dist_on():
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
+
+    def step(self, events=None):
+        """One pass over the shard.  events (optional): dict of lists the caller reads after synchronising:
+        'twist' [(start, end)] per chunk on the compute stream, 'gather' [(start, end)] per chunk on the comm stream."""
+        t, L = self.torch, self.layout
+        cur = t.cuda.current_stream() if self.is_cuda else None
+        for c in range(L.n_chunks):
+            a, b = L.chunk_span(c, self.n_local)
+            ev = self._mark(events, "twist", cur)
+            self.compute.count_twist(a, b - a, self.local[a:b])
+            self._mark_end(ev, cur)
+            if self.full is None:
+                continue
+            if self.is_cuda and self.comm_stream is not None:
+                self.comm_stream.wait_stream(cur)
+                with t.cuda.stream(self.comm_stream):
+                    ev = self._mark(events, "gather", self.comm_stream)
+                    L.gather_chunk(c, self.local, self.full, self.group)
+                    self._mark_end(ev, self.comm_stream)
+            else:
+                L.gather_chunk(c, self.local, self.full, self.group)
+        ev = self._mark(events, "distance", cur)
+        self.compute.distance_to_classes(self.local[:self.n_local], self.dmat)
+        self._mark_end(ev, cur)
+        if self.is_cuda and self.comm_stream is not None and self.full is not None:
+            cur.wait_stream(self.comm_stream)  # the step ends when every rank's rows have arrived
+
+    def _mark(self, events, key, stream):
+        if events is None or not self.is_cuda:
+            return None
+        pair = (self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True))
+        events.setdefault(key, []).append(pair)
+        pair[0].record(stream)
+        return pair
+
+    @staticmethod
+    def _mark_end(pair, stream):
+        if pair is not None:
+            pair[1].record(stream)
+
+    def gathered(self):
+        """[n_total, D] in read order, on this rank"""
+        if self.full is None:
+            return self.local[:self.n_local]
+        return self.layout.global_order(self.full)
+
+    def all_vs_all_summary(self, n_queries, keep_at_most=2, max_neighbours=8):
+        """The first n_queries rows of this rank's shard against EVERY twisted vector of the job.
+        -> (global read numbers of the queries, stats, n, idx (global read numbers), dist, z)"""
+        q = min(int(n_queries), self.n_local)
+        full = self.gathered()
+        stats, n, idx, dd, z = self.compute.summary(full, self.local[:q], keep_at_most, max_neighbours)
+        return np.arange(self.lo, self.lo + q), stats, n, idx, dd, z

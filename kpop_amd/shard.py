@@ -93,3 +93,70 @@ def merge_labelled_rows(labels, rows):
         if enc[a] == enc[b]:
             raise ValueError("Duplicate_label %r" % labels[a])
     return [labels[i] for i in order], np.asarray(rows)[order]
+
+
+class ChunkedGather:
+    """The all-gather of twisted vectors (BASELINE config 4) cut into chunks so that the exchange of
+    chunk c travels over xGMI while the rank still twists chunk c+1 (the caller puts the two on different streams).
+
+    Every rank holds `per_pad` rows (its shard, zero-padded to n_chunks * chunk_rows); chunk c of every rank lands in
+    full[c] = [world][chunk_rows][D], so each collective reads and writes contiguous memory.  The gathered matrix is
+    therefore chunk-major; `position_of_global()` maps a global read number to its row of full.view(-1, D) and
+    `global_order(full)` returns the [n_total, D] matrix in read order (what lib/Twister.ml:197-204 would hold).
+
+    staging="cpu" routes the collective through host tensors (gloo cannot move device tensors): test rigs only."""
+
+    def __init__(self, n_total, world, n_chunks=1, staging=None):
+        self.n_total, self.world = int(n_total), int(world)
+        self.bounds = [shard_bounds(self.n_total, r, self.world) for r in range(self.world)]
+        per = max(hi - lo for lo, hi in self.bounds) if self.bounds else 0
+        self.n_chunks = max(1, min(int(n_chunks), max(per, 1)))
+        self.chunk_rows = -(-max(per, 1) // self.n_chunks)
+        self.per_pad = self.chunk_rows * self.n_chunks
+        self.staging = staging
+
+    def chunk_span(self, c, n_local):
+        """rows [a, b) of the local shard that chunk c really holds (b - a < chunk_rows on the ragged edge)"""
+        a = min(c * self.chunk_rows, n_local)
+        return a, min(a + self.chunk_rows, n_local)
+
+    def local_buffer(self, torch, n_dims, device, dtype=None):
+        return torch.zeros(self.per_pad, n_dims, dtype=dtype or torch.float64, device=device)
+
+    def full_buffer(self, torch, n_dims, device, dtype=None):
+        return torch.zeros(self.n_chunks, self.world, self.chunk_rows, n_dims, dtype=dtype or torch.float64, device=device)
+
+    def gather_chunk(self, c, local, full, group=None):
+        """One collective: chunk c of every rank -> full[c].  Enqueued on the caller's current stream."""
+        import torch.distributed as dist
+        send = local[c * self.chunk_rows:(c + 1) * self.chunk_rows]
+        recv = full[c].view(self.world * self.chunk_rows, -1)
+        if not (dist.is_available() and dist.is_initialized()):
+            if self.world != 1:
+                raise RuntimeError("ChunkedGather over %d ranks needs an initialised process group" % self.world)
+            recv.copy_(send)
+            return
+        if self.staging == "cpu":
+            s = send.cpu()
+            r = s.new_empty(self.world * self.chunk_rows, s.shape[1])
+            dist.all_gather_into_tensor(r, s, group=group)
+            recv.copy_(r)
+        else:
+            dist.all_gather_into_tensor(recv, send, group=group)
+
+    def position_of_global(self):
+        """int64[n_total]: row of full.view(-1, D) holding global read g"""
+        pos = np.empty(self.n_total, dtype=np.int64)
+        for r, (lo, hi) in enumerate(self.bounds):
+            l = np.arange(hi - lo, dtype=np.int64)
+            pos[lo:hi] = ((l // self.chunk_rows) * self.world + r) * self.chunk_rows + l % self.chunk_rows
+        return pos
+
+    def global_order(self, full):
+        import torch
+        idx = torch.from_numpy(self.position_of_global()).to(full.device)
+        return full.view(-1, full.shape[-1]).index_select(0, idx)
+
+    def bytes_received_per_rank(self, n_dims, itemsize=8):
+        """payload a rank takes in from its peers per full gather"""
+        return (self.world - 1) * self.per_pad * n_dims * itemsize

@@ -138,3 +138,106 @@ def test_world_size_2_kmer_row_sharded_twist(oracle):
         assert got.shape == want.shape and np.all(got[1] == 0.0)
         # sum of slice sums divided by acc vs the reference's sum of (v/acc) terms: rounding only
         np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-15)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE config 4's flow (bench.py --gpus N): ShardedJob = chunked all-gather + all-vs-all summary
+# ---------------------------------------------------------------------------------------------------------
+def test_chunked_gather_layout():
+    from kpop_amd.shard import ChunkedGather
+    for n, world, chunks in ((0, 2, 3), (1, 2, 4), (11, 2, 3), (64, 3, 4), (1000, 8, 4), (7, 8, 2)):
+        lay = ChunkedGather(n, world, chunks)
+        pos = lay.position_of_global()
+        assert len(set(pos.tolist())) == n and (n == 0 or pos.max() < lay.n_chunks * world * lay.chunk_rows)
+        for r, (lo, hi) in enumerate(lay.bounds):
+            assert hi - lo <= lay.per_pad
+            spans = [lay.chunk_span(c, hi - lo) for c in range(lay.n_chunks)]
+            assert spans[0][0] == 0 and spans[-1][1] == hi - lo and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+class _OracleCompute:
+    """the oracle standing in for DeviceCompute (tests only): same three operations on CPU tensors"""
+
+    def __init__(self, O, bases, offs, k, T, cols, classes, metric):
+        self.O, self.bases, self.offs, self.k, self.T, self.cols, self.classes, self.metric = O, bases, offs, k, T, cols, classes, metric
+
+    def count_twist(self, first, n, out):
+        import torch
+        if n:
+            o = self.offs[first:first + n + 1]
+            h, c, oo = self.O.count_reads(self.bases[int(o[0]):int(o[-1])], o - o[0], self.k)
+            out.copy_(torch.from_numpy(self.O.twist(self.T, self.cols, h, c.astype(np.float64), oo)))
+
+    def distance_to_classes(self, twisted, out):
+        import torch
+        if twisted.shape[0]:
+            out.copy_(torch.from_numpy(self.O.distance_rowwise(self.classes, twisted.numpy(), self.metric)))
+
+    def summary(self, m1, m2, keep_at_most, max_neighbours):
+        st, offs, idx, dd, z = self.O.distance_summary(m1.numpy(), m2.numpy(), self.metric, keep_at_most=keep_at_most)
+        return st, offs, idx, dd, z
+
+
+def _config4_worker(rank, world, port, n, chunks, ret):
+    import torch
+    import torch.distributed as dist
+
+    from kpop_amd.pipeline import ShardedJob
+    from kpop_amd.shard import ChunkedGather
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        k, d, L, C = 6, 5, 60, 4
+        bases, offs = O.synth_reads(0x4B506F70, n, L)
+        cols = O.enumerate_kmers(k)
+        T = O.synth_twister(3, d, cols)
+        metric = O.metric_powers(O.synth_inertia(d))
+        cb, co = O.synth_reads(0xC1A55, C, 200)
+        hc, cc, oc = O.count_reads(cb, co, k)
+        classes = O.twist(T, cols, hc, cc.astype(np.float64), oc)
+        lay = ChunkedGather(n, world, chunks)
+        lo, hi, local_offs, b0, b1 = shard_reads(offs, rank, world)
+        comp = _OracleCompute(O, bases[b0:b1], local_offs, k, T, cols, classes, metric)
+        job = ShardedJob(torch, comp, lay, rank, d, C, torch.device("cpu"))
+        job.step()
+        job.step()  # a second pass overwrites in place
+        qid, st, so, idx, dd, z = job.all_vs_all_summary(3)
+        ret[rank] = (lo, hi, job.gathered().numpy(), job.dmat.numpy(), qid, st, so, idx, dd)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,chunks", [(11, 3), (64, 4), (5, 1)])
+def test_world_size_2_config4_job(oracle, n, chunks):
+    """What `bench.py --gpus 2` runs, with the oracle doing the arithmetic: shards twisted chunk by chunk, one
+    all-gather per chunk, rows back in read order, distances to the classes, all-vs-all summary on the gathered matrix."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_config4_worker, args=(world, port, n, chunks, ret), nprocs=world, join=True)
+    k, d, L, C = 6, 5, 60, 4
+    bases, offs = oracle.synth_reads(0x4B506F70, n, L)
+    cols = oracle.enumerate_kmers(k)
+    T = oracle.synth_twister(3, d, cols)
+    metric = oracle.metric_powers(oracle.synth_inertia(d))
+    h, c, o = oracle.count_reads(bases, offs, k)
+    want = oracle.twist(T, cols, h, c.astype(np.float64), o)
+    cb, co = oracle.synth_reads(0xC1A55, C, 200)
+    hc, cc, oc = oracle.count_reads(cb, co, k)
+    classes = oracle.twist(T, cols, hc, cc.astype(np.float64), oc)
+    dm = oracle.distance_rowwise(classes, want, metric)
+    st_w, so_w, idx_w, dd_w, _ = oracle.distance_summary(want, want, metric, keep_at_most=2)
+    for r in range(world):
+        lo, hi, full, dmat, qid, st, so, idx, dd = ret[r]
+        assert np.array_equal(full, want)
+        assert np.array_equal(dmat, dm[lo:hi])
+        assert qid.tolist() == list(range(lo, min(lo + 3, hi)))
+        for j, g in enumerate(qid):
+            assert np.array_equal(st[j], st_w[g])
+            a, b = int(so[j]), int(so[j + 1])
+            aw, bw = int(so_w[g]), int(so_w[g + 1])
+            assert idx[a:b].tolist() == idx_w[aw:bw].tolist() and np.array_equal(dd[a:b], dd_w[aw:bw])
+            assert dd[a] == 0.0 and g in idx[a:b].tolist()  # every read finds itself at distance 0
