@@ -112,6 +112,11 @@ int kpop_twister_synth(uint64_t seed, int k, int content, uint32_t n_dims, kpop_
    [n x (n_dims+1)] partials and divide by the last column (kpop_amd/shard.py).                                  */
 int kpop_twister_synth_slice(uint64_t seed, int k, int content, uint32_t n_dims, uint64_t hash_lo,
                              uint64_t hash_hi, int acc_dim, kpop_twister **out);
+/* The fused count -> twist entry points hash the reads with the k the twister was loaded with.  A twister read from
+   a file only shows the WIDTH of its k-mer names, ceil(k/2) hex digits (bin/KPopCount.ml:46), so a loader that
+   had to infer k loads with the even candidate and, once the producer of the reads has said which k it counts
+   with, sets it here (k <= the loaded k: the name -> row index of the larger k also holds every smaller hash). */
+int kpop_twister_set_count_k(kpop_twister *tw, int k);
 int kpop_twister_free(kpop_twister *tw);
 int kpop_twister_info(const kpop_twister *tw, uint64_t *n_cols, uint32_t *n_dims, int *k,
                       uint64_t *device_bytes);
@@ -130,6 +135,13 @@ int kpop_twist(const kpop_twister *tw, const uint64_t *hash, const double *value
  * the README.md:606 pipeline) without materialising text spectra.            */
 int kpop_count_twist(const kpop_twister *tw, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
                      int content, int normalize, double *out);
+
+/* The same pipeline with the count spelled out: the rows that kpop_count_reads(k, content, per_read = 1) followed
+ * by kpop_twist would give, bit for bit, for sequences of any length, with the spectra never leaving the device.
+ * k is the caller's (k <= the k the twister was loaded with: a twister file shows only the width of its k-mer names).
+ * This is what KPopTwistDB runs when KPopCount hands it reads instead of text spectra (kpop_amd/host/fast_seq.h). */
+int kpop_spectra_twist(const kpop_twister *tw, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                       int k, int content, int normalize, double *out);
 
 /* ------------------------------------------------------ twister generation
  * Replaces the R stage of src/KPopTwist:93-116 (library `ca`): correspondence analysis of a k-mers x spectra

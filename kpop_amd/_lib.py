@@ -35,10 +35,12 @@ SIGNATURES = {
     "kpop_twister_synth": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.POINTER(vp)]),
     "kpop_twister_synth_slice": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int,
                                            C.POINTER(vp)]),
+    "kpop_twister_set_count_k": (C.c_int, [vp, C.c_int]),
     "kpop_twister_free": (C.c_int, [vp]),
     "kpop_twister_info": (C.c_int, [vp, u64p, u32p, C.POINTER(C.c_int), u64p]),
     "kpop_twist": (C.c_int, [vp, u64p, f64p, u64p, C.c_uint32, C.c_int, f64p]),
     "kpop_count_twist": (C.c_int, [vp, u8p, u64p, C.c_uint32, C.c_int, C.c_int, f64p]),
+    "kpop_spectra_twist": (C.c_int, [vp, u8p, u64p, C.c_uint32, C.c_int, C.c_int, C.c_int, f64p]),
     "kpop_ca": (C.c_int, [f64p, C.c_uint64, C.c_uint32, C.c_int, u32p, f64p, f64p, f64p]),
     "kpop_metric_compute": (C.c_int, [C.c_int, f64p, C.c_uint32, C.c_double, C.c_double, C.c_double, f64p]),
     "kpop_distance_rowwise": (C.c_int, [f64p, C.c_uint32, f64p, C.c_uint32, C.c_uint32, f64p, C.c_int,

@@ -163,6 +163,19 @@ class Twister:
                                            _p(_nz(out, np.float64), C.c_double)))
         return out
 
+    def spectra_twist(self, bases, offsets, k, content=DNA_DS, normalize=True):
+        """Reads -> the rows count_reads(k) + twist would give, bit for bit, spectra kept on the device (any length)."""
+        bases = _c(bases, np.uint8)
+        offsets = _c(offsets, np.uint64)
+        n = len(offsets) - 1
+        out = np.zeros((n, self.info()["n_dims"]), dtype=np.float64)
+        check(_lib.load().kpop_spectra_twist(self._h, _p(_nz(bases, np.uint8), C.c_uint8), _p(offsets, C.c_uint64), n, int(k),
+                                             int(content), 1 if normalize else 0, _p(_nz(out, np.float64), C.c_double)))
+        return out
+
+    def set_count_k(self, k):
+        check(_lib.load().kpop_twister_set_count_k(self._h, int(k)))
+
     def free(self):
         if self._h is not None and self._h.value:
             _lib.load().kpop_twister_free(self._h)

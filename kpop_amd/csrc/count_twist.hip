@@ -17,6 +17,7 @@
 #include "kmer.h"
 #include "read_hash.h"
 #include "scan.h"
+#include "sort_count.h"
 #include "twister.h"
 #include "wave_sort.h"
 
@@ -187,11 +188,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void count_twist_wave_kernel(
   const uint64_t off = offsets[r];
   const uint32_t len = (uint32_t)(offsets[r + 1] - off);
   WaveLds<R, uint32_t> &L = lds[wv];
-  if (len >= (uint32_t)tv.k && len - (uint32_t)tv.k + 1 > 64u * R) return;  // count_twist_stream_kernel's business
+  if (len >= (uint32_t)tv.hk && len - (uint32_t)tv.hk + 1 > 64u * R) return;  // count_twist_stream_kernel's business
 
   wave_stage_codes<R>(bases + off, len, lane, L.codes);
   H hkey[R];
-  wave_hash_windows<R, H>(L.codes, tv.k, content, lane, hkey);
+  wave_hash_windows<R, H>(L.codes, tv.hk, content, lane, hkey);
   // name -> column (lib/Twister.ml:151); k-mers the twister does not know are
   // dropped here, hence also from the normaliser (:158,:167-169)
   uint32_t key[R];
@@ -214,8 +215,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void count_twist_wave_kernel(
 // the same up to rounding) -- see DESIGN.md "twist_csr".  acc is a wave
 // reduction, exact for integer counts.
 // ---------------------------------------------------------------------------
+template <typename V>  // double: spectra as parsed from text; uint32_t: counts straight from the counting kernels
 __global__ __launch_bounds__(64 * kWavesPerBlock) void twist_csr_kernel(
-    TwisterView tv, const uint64_t *__restrict__ hash, const double *__restrict__ value,
+    TwisterView tv, const uint64_t *__restrict__ hash, const V *__restrict__ value,
     const uint64_t *__restrict__ offsets, uint32_t n, int normalize, double *__restrict__ out) {
   __shared__ uint32_t s_col[kWavesPerBlock][64 + kGatherUnroll];
   __shared__ double s_x[kWavesPerBlock][64 + kGatherUnroll];
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void twist_csr_kernel(
   // pass 1: acc over lines whose k-mer the twister knows
   double part = 0.0;
   for (uint64_t i = lo + lane; i < hi; i += 64)
-    if (lookup_col(tv, hash[i]) != kNoCol) part += value[i];
+    if (lookup_col(tv, hash[i]) != kNoCol) part += (double)value[i];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
   const double acc = part;
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void twist_csr_kernel(
       double x = 0.0;
       if (i < hi) {
         col = lookup_col(tv, hash[i]);
-        x = norm ? value[i] / acc : value[i];
+        x = norm ? (double)value[i] / acc : (double)value[i];
       }
       if (col == kNoCol) {
         col = 0;
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256) void count_twist_stream_kernel(
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t off = offsets[r];
   const uint64_t len = offsets[r + 1] - off;
-  const int k = tv.k;
+  const int k = tv.hk;
   const uint64_t n_win = len - k + 1;  // nseg > 0 implies len >= k
   const uint64_t w0 = (uint64_t)seg * kSegWindows;
   const uint64_t w1 = min(n_win, w0 + kSegWindows);
@@ -495,10 +497,6 @@ static int launch_count_twist_wave(int R, TwisterView tv, const uint8_t *bases, 
                    : launch_count_twist_wave_v<H, 8, false>(R, tv, bases, offsets, ids, n, content, normalize, out, st);
 }
 
-// sort_count.hip
-int sorted_count_batch(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, int k, int content,
-                       int per_read, uint64_t *out_hash, uint32_t *out_count, uint64_t *out_offsets, uint64_t cap,
-                       uint64_t *n_written);
 
 static int check_offsets(const uint64_t *offsets, uint32_t n, uint64_t *max_len) {
   uint64_t m = 0;
@@ -536,11 +534,11 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
     KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_count_twist: content %d (the fused path is DNA only; protein spectra go through kpop_count_reads and kpop_twist)", content);
   if (n_reads == 0) return KPOP_OK;
   hipStream_t st = as_stream(stream);
-  const uint32_t max_windows = (max_len >= (uint32_t)tw->k) ? max_len - tw->k + 1 : 0;
   const TwisterView tv = view_of(tw);
+  const uint32_t max_windows = (max_len >= (uint32_t)tv.hk) ? max_len - tv.hk + 1 : 0;
   // reads of up to 512 windows: one wavefront per read (the kernel skips longer reads)
   const int R = pick_R(std::min(max_windows, kWaveMaxWindows));
-  if (tw->k <= 15)
+  if (tv.hk <= 15)
     KPOP_TRY(launch_count_twist_wave<uint32_t>(R, tv, d_bases, d_offsets, nullptr, n_reads, content, normalize, d_out, st));
   else
     KPOP_TRY(launch_count_twist_wave<uint64_t>(R, tv, d_bases, d_offsets, nullptr, n_reads, content, normalize, d_out, st));
@@ -559,12 +557,12 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   uint64_t *sums = reinterpret_cast<uint64_t *>(wp + bytes_nseg + bytes_off);
   uint32_t *pcnt = reinterpret_cast<uint32_t *>(wp + bytes_nseg + bytes_off + bytes_sums);
   double *part = reinterpret_cast<double *>(wp + bytes_nseg + bytes_off + bytes_sums + bytes_cnt);
-  segment_count_kernel<<<dim3(div_up(n_reads, 256)), dim3(256), 0, st>>>(d_offsets, n_reads, tw->k, nseg);
+  segment_count_kernel<<<dim3(div_up(n_reads, 256)), dim3(256), 0, st>>>(d_offsets, n_reads, tv.hk, nseg);
   KPOP_LAUNCH_CHECK();
   KPOP_TRY(exclusive_scan(LoadU32{nseg}, StoreU64{seg_off}, n_reads, sums, st));
   const uint32_t max_seg = div_up(max_windows, kSegWindows);
   dim3 grid(capped_grid((uint64_t)n_reads * max_seg));
-  if (tw->k <= 15)
+  if (tv.hk <= 15)
     count_twist_stream_kernel<uint32_t><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt,
                                                                     n_reads, max_seg);
   else
@@ -623,7 +621,7 @@ extern "C" int kpop_dev_twist(const kpop_twister *tw, const uint64_t *d_hash, co
   (void)max_lines;
   if (!tw || !d_offsets || !d_out) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_twist: null argument");
   if (n_spectra == 0) return KPOP_OK;
-  twist_csr_kernel<<<dim3(div_up(n_spectra, kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, as_stream(stream)>>>(
+  twist_csr_kernel<double><<<dim3(div_up(n_spectra, kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, as_stream(stream)>>>(
       view_of(tw), d_hash, d_value, d_offsets, n_spectra, normalize, d_out);
   KPOP_LAUNCH_CHECK();
   return KPOP_OK;
@@ -732,6 +730,93 @@ extern "C" int kpop_count_twist(const kpop_twister *tw, const uint8_t *bases, co
   KPOP_TRY(kpop_dev_count_twist(tw, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), n_reads, n_bases, (uint32_t)max_len,
                                 content, normalize, d_out.as<double>(), st));
   KPOP_HIP(hipMemcpyAsync(out, d_out.p, (uint64_t)n_reads * tw->n_dims * 8, hipMemcpyDeviceToHost, st));
+  KPOP_HIP(hipStreamSynchronize(st));
+  return KPOP_OK;
+}
+
+// Reads -> the twisted rows that kpop_count_reads(k, content, per_read = 1) followed by kpop_twist would give, bit for
+// bit, with the spectra never leaving the device: what `KPopCount -L | KPopTwistDB -k /dev/stdin` computes
+// (bin/KPopCount.ml:36-50 into lib/Twister.ml:146-188) minus the text in between.  The count uses the caller's k; the
+// twister may have been loaded with the other k of the pair that shares its name width (kpop_twister_set_count_k).
+// When every sequence fits one wavefront and n_dims > 32 the fused kernel IS that computation (same ascending chain of
+// unfused multiply-adds); otherwise the spectra are built on the device and twisted line by line by twist_csr_kernel.
+extern "C" int kpop_spectra_twist(const kpop_twister *tw, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                                  int k, int content, int normalize, double *out) {
+  KPOP_TRY(require_init());
+  ArenaScope scratch;
+  if (!tw || !offsets || (!out && n_reads)) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_spectra_twist: null argument");
+  KPOP_TRY(check_count_args(k, content, "kpop_spectra_twist"));
+  if (content == KPOP_PROTEIN) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_spectra_twist: DNA only (protein spectra go through kpop_count_reads and kpop_twist)");
+  if (k > tw->k) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_spectra_twist: k=%d above the twister's k=%d", k, tw->k);
+  if (n_reads == 0) return KPOP_OK;
+  uint64_t max_len = 0;
+  KPOP_TRY(check_offsets(offsets, n_reads, &max_len));
+  if (max_len > 0xFFFFFFFFull) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_spectra_twist: sequence longer than 2^32 bases");
+  const uint64_t max_windows = (max_len >= (uint64_t)k) ? max_len - k + 1 : 0;
+  hipStream_t st = nullptr;
+  kpop_twister view = *tw;  // same device arrays, the caller's counting k
+  view.hk = k;
+  const TwisterView tv = view_of(&view);
+  const uint64_t out_bytes = (uint64_t)n_reads * tw->n_dims * 8;
+  DevBuf d_out;
+  KPOP_TRY(d_out.alloc(out_bytes));
+  if (max_windows <= kWaveMaxWindows) {
+    const uint64_t base0 = offsets[0], n_bases = offsets[n_reads] - base0;
+    DevBuf d_bases, d_off;
+    KPOP_TRY(d_bases.alloc(n_bases));
+    KPOP_TRY(d_off.alloc((uint64_t)(n_reads + 1) * 8));
+    std::vector<uint64_t> rel(n_reads + 1);
+    for (uint32_t r = 0; r <= n_reads; ++r) rel[r] = offsets[r] - base0;
+    if (n_bases) KPOP_HIP(hipMemcpyAsync(d_bases.p, bases + base0, n_bases, hipMemcpyHostToDevice, st));
+    KPOP_HIP(hipMemcpyAsync(d_off.p, rel.data(), (uint64_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+    const int R = pick_R((uint32_t)max_windows);
+    if (tw->n_dims > 32) {
+      if (k <= 15)
+        KPOP_TRY(launch_count_twist_wave<uint32_t>(R, tv, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), nullptr, n_reads, content, normalize, d_out.as<double>(), st));
+      else
+        KPOP_TRY(launch_count_twist_wave<uint64_t>(R, tv, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), nullptr, n_reads, content, normalize, d_out.as<double>(), st));
+    } else {
+      const uint32_t stride = 64 * R;
+      DevBuf d_sh, d_sc, d_nu, d_sums, d_oo, d_oh, d_oc;
+      KPOP_TRY(d_sh.alloc((uint64_t)n_reads * stride * 8));
+      KPOP_TRY(d_sc.alloc((uint64_t)n_reads * stride * 4));
+      KPOP_TRY(d_nu.alloc((uint64_t)n_reads * 4));
+      KPOP_TRY(d_sums.alloc((scan_blocks(n_reads) + 1) * 8));
+      KPOP_TRY(d_oo.alloc((uint64_t)(n_reads + 1) * 8));
+      KPOP_TRY(launch_count_wave(R, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), nullptr, n_reads, k, content, stride,
+                                 d_sh.as<uint64_t>(), d_sc.as<uint32_t>(), d_nu.as<uint32_t>(), st));
+      KPOP_TRY(exclusive_scan(LoadU32{d_nu.as<uint32_t>()}, StoreOffsets{d_oo.as<uint64_t>()}, n_reads, d_sums.as<uint64_t>(), st));
+      uint64_t total = 0;
+      KPOP_HIP(hipMemcpyAsync(&total, d_sums.as<uint64_t>() + scan_blocks(n_reads), 8, hipMemcpyDeviceToHost, st));
+      KPOP_HIP(hipMemcpyAsync(d_oo.as<uint64_t>() + n_reads, d_sums.as<uint64_t>() + scan_blocks(n_reads), 8, hipMemcpyDeviceToDevice, st));
+      KPOP_HIP(hipStreamSynchronize(st));
+      KPOP_TRY(d_oh.alloc(total * 8));
+      KPOP_TRY(d_oc.alloc(total * 4));
+      compact_spectra_kernel<<<dim3(div_up(n_reads, 4)), dim3(256), 0, st>>>(d_sh.as<uint64_t>(), d_sc.as<uint32_t>(), d_nu.as<uint32_t>(),
+                                                                            d_oo.as<uint64_t>(), n_reads, stride, d_oh.as<uint64_t>(),
+                                                                            d_oc.as<uint32_t>());
+      KPOP_LAUNCH_CHECK();
+      twist_csr_kernel<uint32_t><<<dim3(div_up(n_reads, kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, st>>>(
+          tv, d_oh.as<uint64_t>(), d_oc.as<uint32_t>(), d_oo.as<uint64_t>(), n_reads, normalize, d_out.as<double>());
+      KPOP_LAUNCH_CHECK();
+    }
+  } else {
+    // genomes: sort path, in sub-batches whose (spectrum id | hash) keys fit 63 bits, then the line-by-line twist
+    const int id_bits_max = 63 - hash_bits(k, content);
+    const uint64_t sub = id_bits_max >= 32 ? n_reads : std::max<uint64_t>(1, 1ull << id_bits_max);
+    for (uint64_t r0 = 0; r0 < n_reads; r0 += sub) {
+      const uint32_t nr = (uint32_t)std::min<uint64_t>(sub, n_reads - r0);
+      ArenaScope batch;
+      SortedSpectra S;
+      KPOP_TRY(sorted_count_device(bases, offsets + r0, nr, k, content, 1, ~0ull, S, st));
+      twist_csr_kernel<uint32_t><<<dim3(div_up(nr, kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, st>>>(
+          tv, S.d_oh.as<uint64_t>(), S.d_oc.as<uint32_t>(), S.d_oo.as<uint64_t>(), nr, normalize,
+          d_out.as<double>() + r0 * tw->n_dims);
+      KPOP_LAUNCH_CHECK();
+      KPOP_HIP(hipStreamSynchronize(st));  // the batch's scratch goes back to the arena at the end of this scope
+    }
+  }
+  KPOP_HIP(hipMemcpyAsync(out, d_out.p, out_bytes, hipMemcpyDeviceToHost, st));
   KPOP_HIP(hipStreamSynchronize(st));
   return KPOP_OK;
 }

@@ -16,6 +16,8 @@
 #include "radix_sort.h"
 #include "scan.h"
 
+#include "sort_count.h"
+
 namespace kpop {
 
 constexpr uint32_t kKeySeg = 16384;  // windows per block
@@ -116,12 +118,11 @@ __global__ void spectrum_bounds_kernel(const uint64_t *__restrict__ uniq, const 
   offsets[s] = lo;
 }
 
-// One batch of reads through the sort path.  Host arrays in, CSR out at out_hash/out_count
-// (capacity `cap` entries), offsets relative to this batch.  per_read = 0 merges everything.
-int sorted_count_batch(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, int k, int content,
-                       int per_read, uint64_t *out_hash, uint32_t *out_count, uint64_t *out_offsets, uint64_t cap,
-                       uint64_t *n_written) {
-  hipStream_t st = nullptr;
+// One batch of reads through the sort path, host arrays in; the CSR stays on the device in S (d_oh, d_oc, and for
+// per_read d_oo with n_reads + 1 offsets relative to this batch).  per_read = 0 merges everything.  The buffers come
+// from the caller's ArenaScope.
+int sorted_count_device(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, int k, int content, int per_read,
+                        uint64_t cap, SortedSpectra &S, hipStream_t st) {
   const uint64_t base0 = offsets[0], n_bases = offsets[n_reads] - base0;
   std::vector<uint64_t> rel(n_reads + 1), woff(n_reads + 1);
   uint64_t tw = 0, max_win = 0;
@@ -136,8 +137,10 @@ int sorted_count_batch(const uint8_t *bases, const uint64_t *offsets, uint32_t n
   rel[n_reads] = n_bases;
   woff[n_reads] = tw;
   const uint32_t n_spectra = per_read ? n_reads : 1;
-  for (uint32_t s = 0; s <= n_spectra; ++s) out_offsets[s] = 0;
-  *n_written = 0;
+  S.nu = 0;
+  S.n_spectra = n_spectra;
+  KPOP_TRY(S.d_oo.alloc((uint64_t)(n_spectra + 1) * 8));
+  KPOP_HIP(hipMemsetAsync(S.d_oo.p, 0, (uint64_t)(n_spectra + 1) * 8, st));
   if (tw == 0) return 0;
   int id_bits = 0;
   while (per_read && (1ull << id_bits) < (uint64_t)n_reads) ++id_bits;
@@ -146,7 +149,8 @@ int sorted_count_batch(const uint8_t *bases, const uint64_t *offsets, uint32_t n
   const int bits = hb + id_bits + 1;
   if (bits > 64) KPOP_FAIL(KPOP_ERR_INVALID, "sorted_count_batch: %d key bits (caller must split the batch)", bits);
   const uint32_t max_seg = div_up(max_win, kKeySeg);
-  DevBuf d_bases, d_off, d_woff, d_ka, d_kb, d_scr, d_start, d_sums, d_tot;
+  DevBuf &d_bases = S.d_bases, &d_off = S.d_off, &d_woff = S.d_woff, &d_ka = S.d_ka, &d_kb = S.d_kb, &d_scr = S.d_scr,
+         &d_start = S.d_start, &d_sums = S.d_sums;
   KPOP_TRY(d_bases.alloc(n_bases));
   KPOP_TRY(d_off.alloc((uint64_t)(n_reads + 1) * 8));
   KPOP_TRY(d_woff.alloc((uint64_t)(n_reads + 1) * 8));
@@ -155,7 +159,6 @@ int sorted_count_batch(const uint8_t *bases, const uint64_t *offsets, uint32_t n
   KPOP_TRY(d_scr.alloc(radix_scratch_bytes(tw)));
   KPOP_TRY(d_start.alloc(tw * 8));
   KPOP_TRY(d_sums.alloc((scan_blocks(tw) + 1) * 8 * 2));
-  KPOP_TRY(d_tot.alloc(16));
   KPOP_HIP(hipMemcpyAsync(d_bases.p, bases + base0, n_bases, hipMemcpyHostToDevice, st));
   KPOP_HIP(hipMemcpyAsync(d_off.p, rel.data(), (uint64_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
   KPOP_HIP(hipMemcpyAsync(d_woff.p, woff.data(), (uint64_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
@@ -179,34 +182,45 @@ int sorted_count_batch(const uint8_t *bases, const uint64_t *offsets, uint32_t n
   const uint64_t *d_nu = sums1 + scan_blocks(tw), *d_nv = sums2 + scan_blocks(tw);
   uint64_t nu = 0;
   KPOP_HIP(hipMemcpyAsync(&nu, d_nu, 8, hipMemcpyDeviceToHost, st));
-  KPOP_HIP(hipStreamSynchronize(st));
+  KPOP_HIP(hipStreamSynchronize(st));  // the host rests its copy of `rel`/`woff` on this too
   if (nu > cap)
     KPOP_FAIL(KPOP_ERR_CAPACITY, "kpop_count_reads: %llu distinct (spectrum,k-mer) pairs, capacity %llu",
               (unsigned long long)nu, (unsigned long long)cap);
-  DevBuf d_oh, d_oc, d_oo;
-  KPOP_TRY(d_oh.alloc(nu * 8));
-  KPOP_TRY(d_oc.alloc(nu * 4));
-  KPOP_TRY(d_oo.alloc((uint64_t)(n_spectra + 1) * 8));
+  S.nu = nu;
+  KPOP_TRY(S.d_oh.alloc(nu * 8));
+  KPOP_TRY(S.d_oc.alloc(nu * 4));
   if (nu) {
     finish_spectra_kernel<<<dim3(std::min<uint32_t>(div_up(nu, 256), 8192)), dim3(256), 0, st>>>(
-        other, d_start.as<uint64_t>(), d_nu, d_nv, bits_mask(hb), d_oh.as<uint64_t>(), d_oc.as<uint32_t>());
+        other, d_start.as<uint64_t>(), d_nu, d_nv, bits_mask(hb), S.d_oh.as<uint64_t>(), S.d_oc.as<uint32_t>());
     KPOP_LAUNCH_CHECK();
   }
   if (per_read) {
     spectrum_bounds_kernel<<<dim3(div_up((uint64_t)n_spectra + 1, 256)), dim3(256), 0, st>>>(other, d_nu, n_spectra, 0u,
-                                                                                              hb, d_oo.as<uint64_t>());
+                                                                                              hb, S.d_oo.as<uint64_t>());
     KPOP_LAUNCH_CHECK();
-    KPOP_HIP(hipMemcpyAsync(out_offsets, d_oo.p, (uint64_t)(n_spectra + 1) * 8, hipMemcpyDeviceToHost, st));
   } else {
-    out_offsets[0] = 0;
-    out_offsets[1] = nu;
+    const uint64_t two[2] = {0, nu};
+    KPOP_HIP(hipMemcpyAsync(S.d_oo.p, two, 16, hipMemcpyHostToDevice, st));
+    KPOP_HIP(hipStreamSynchronize(st));
   }
-  if (nu) {
-    KPOP_HIP(hipMemcpyAsync(out_hash, d_oh.p, nu * 8, hipMemcpyDeviceToHost, st));
-    KPOP_HIP(hipMemcpyAsync(out_count, d_oc.p, nu * 4, hipMemcpyDeviceToHost, st));
+  return 0;
+}
+
+// the same with the CSR copied out to host arrays (capacity `cap` entries)
+int sorted_count_batch(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, int k, int content,
+                       int per_read, uint64_t *out_hash, uint32_t *out_count, uint64_t *out_offsets, uint64_t cap,
+                       uint64_t *n_written) {
+  hipStream_t st = nullptr;
+  SortedSpectra S;
+  *n_written = 0;
+  KPOP_TRY(sorted_count_device(bases, offsets, n_reads, k, content, per_read, cap, S, st));
+  KPOP_HIP(hipMemcpyAsync(out_offsets, S.d_oo.p, (uint64_t)(S.n_spectra + 1) * 8, hipMemcpyDeviceToHost, st));
+  if (S.nu) {
+    KPOP_HIP(hipMemcpyAsync(out_hash, S.d_oh.p, S.nu * 8, hipMemcpyDeviceToHost, st));
+    KPOP_HIP(hipMemcpyAsync(out_count, S.d_oc.p, S.nu * 4, hipMemcpyDeviceToHost, st));
   }
   KPOP_HIP(hipStreamSynchronize(st));
-  *n_written = nu;
+  *n_written = S.nu;
   return 0;
 }
 

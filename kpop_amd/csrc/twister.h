@@ -20,7 +20,8 @@
 #include "common.h"
 
 struct kpop_twister {
-  int k = 0;
+  int k = 0;   // k of the name -> row index
+  int hk = 0;  // k the fused count->twist kernels hash reads with (kpop_twister_set_count_k; <= k)
   uint32_t n_dims = 0;
   uint32_t d_pad = 0;
   uint64_t n_cols = 0;  // columns of the twister as loaded
@@ -50,11 +51,12 @@ struct TwisterView {
   uint32_t n_dims;
   uint32_t d_pad;
   int k;
+  int hk;
 };
 
 static inline TwisterView view_of(const kpop_twister *tw) {
   return TwisterView{tw->d_rows, reinterpret_cast<const RankWord *>(tw->d_rsel), tw->d_sorted_hash, tw->n_rows,
-                     tw->n_dims, tw->d_pad,                                     tw->k};
+                     tw->n_dims, tw->d_pad,                                     tw->k, tw->hk ? tw->hk : tw->k};
 }
 
 #if defined(__HIPCC__)

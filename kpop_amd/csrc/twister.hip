@@ -237,6 +237,13 @@ extern "C" int kpop_twister_load(const double *T_dims_major, uint64_t n_cols, ui
   return KPOP_OK;
 }
 
+extern "C" int kpop_twister_set_count_k(kpop_twister *tw, int k) {
+  if (!tw) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_twister_set_count_k: null twister");
+  if (k < 1 || k > tw->k) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_twister_set_count_k: k=%d outside 1..%d (the k the twister was loaded with)", k, tw->k);
+  tw->hk = k;
+  return KPOP_OK;
+}
+
 extern "C" int kpop_twister_synth(uint64_t seed, int k, int content, uint32_t n_dims, kpop_twister **out) {
   return kpop_twister_synth_slice(seed, k, content, n_dims, 0, ~0ull, 0, out);
 }

@@ -14,6 +14,10 @@
 //     that consumers re-sum, bin/KPopCount.ml:39-50);
 //   * a runtime failure exits with status 1 (the reference's DB tools print
 //     the exception and exit 0);
+//   * `-L` with stdout on a pipe whose reader is this repository's KPopTwistDB: the counting is deferred to that
+//     process (fast_seq.h, "the reads stream"): the linted reads cross the pipe instead of ~9 bytes of text per k-mer,
+//     and KPopTwistDB counts and twists them in one kernel.  Every other reader gets the text (KPOP_PIPE_FORMAT=text
+//     forces it);
 //   * protein k-mers use the residue encoding declared in csrc/kmer.h (the reference's lives in the absent BiOCamLib);
 //     Sequences.Lint.proteinize is taken as dnaize's twin: upper-case, dashes and blanks dropped.
 #include <stdio.h>
@@ -25,6 +29,7 @@
 #include <vector>
 
 #include "../../include/kpop_hip.h"
+#include "fast_seq.h"
 #include "kpop_text.h"
 
 using namespace kpop_host;
@@ -105,25 +110,71 @@ struct Merged {  // running -l spectrum: ascending hashes
   }
 };
 
-void process_batch(const Params &P, const ReadBatch &b, FILE *out, Merged &merged, std::vector<uint64_t> &oh,
-                   std::vector<uint32_t> &oc, std::vector<uint64_t> &oo) {
-  if (b.size() == 0) return;
-  const bool per_read = P.label.empty();
-  const uint64_t cap = b.bases.size() + 1;
-  oh.resize(cap);
-  oc.resize(cap);
-  oo.assign(per_read ? b.size() + 1 : 2, 0);
-  static const uint8_t dummy = 0;
-  check(kpop_count_reads(b.bases.empty() ? &dummy : b.bases.data(), b.offsets.data(), (uint32_t)b.size(), P.k, P.content,
-                         per_read ? 1 : 0, oh.data(), oc.data(), oo.data(), cap));
-  if (per_read) {  // bin/KPopCount.ml:44-46
-    std::vector<std::string> labels(b.size());
-    for (size_t r = 0; r < b.size(); ++r) labels[r] = strip_external_quotes_and_check(b.tags[r]);
-    write_spectra_parallel(out, labels, oh.data(), oc.data(), oo.data(), name_digits(P.k, P.content == KPOP_PROTEIN));
-  } else {
-    merged.add(oh.data(), oc.data(), oo[1]);
+struct Sink {  // where a batch of reads goes: the GPU and the text writer, or the reads stream
+  const Params &P;
+  FILE *out = nullptr;
+  bool decided = false, stream = false, gpu = false;
+  Merged merged;
+  std::vector<uint64_t> oh, oo, offsets;
+  std::vector<uint32_t> oc;
+  explicit Sink(const Params &p) : P(p) {}
+
+  void decide() {
+    decided = true;
+    const bool per_read = P.label.empty();
+    stream = per_read && P.output.empty() && P.content != KPOP_PROTEIN && stdout_reader_is_dropin_twistdb();
+    if (stream) {
+      fflush(stdout);
+      ReadStreamHeader h;
+      h.k = (uint32_t)P.k;
+      h.content = (uint32_t)P.content;
+      write_stream_header(1, h);
+      if (P.verbose) fprintf(stderr, "(KPopCount): the reader of stdout is KPopTwistDB: handing it the reads, it counts them itself\n");
+    }
   }
-}
+  void need_gpu() {
+    if (gpu) return;
+    int dev = 0;
+    if (const char *e = getenv("KPOP_DEVICE")) dev = atoi(e);
+    check(kpop_init(dev));
+    gpu = true;
+  }
+  void process(const FlatBatch &b) {
+    if (b.size() == 0) return;
+    if (!decided) decide();
+    if (stream) {
+      write_stream_block(1, b);
+      return;
+    }
+    need_gpu();
+    const bool per_read = P.label.empty();
+    const size_t n = b.size();
+    offsets.resize(n + 1);
+    offsets[0] = 0;
+    for (size_t r = 0; r < n; ++r) offsets[r + 1] = offsets[r] + b.lens[r];
+    const uint64_t cap = b.bases.size() + 1;
+    oh.resize(cap);
+    oc.resize(cap);
+    oo.assign(per_read ? n + 1 : 2, 0);
+    static const uint8_t dummy = 0;
+    check(kpop_count_reads(b.bases.empty() ? &dummy : b.bases.data(), offsets.data(), (uint32_t)n, P.k, P.content,
+                           per_read ? 1 : 0, oh.data(), oc.data(), oo.data(), cap));
+    if (per_read) {  // bin/KPopCount.ml:44-46
+      std::vector<std::string> labels(n);
+      size_t at = 0;
+      for (size_t r = 0; r < n; ++r) {
+        labels[r] = strip_external_quotes_and_check(std::string(b.tags.data() + at, b.tag_lens[r]));
+        at += b.tag_lens[r];
+      }
+      write_spectra_parallel(out, labels, oh.data(), oc.data(), oo.data(), name_digits(P.k, P.content == KPOP_PROTEIN));
+    } else {
+      merged.add(oh.data(), oc.data(), oo[1]);
+    }
+  }
+  void finish() {
+    if (stream) write_stream_end(1);
+  }
+};
 
 }  // namespace
 
@@ -186,56 +237,49 @@ int main(int argc, char **argv) {
   if (P.inputs.empty()) return 0;  // :218
 
   try {
-    int dev = 0;
-    if (const char *e = getenv("KPOP_DEVICE")) dev = atoi(e);
-    check(kpop_init(dev));
     FILE *out = P.output.empty() ? stdout : fopen(P.output.c_str(), "wb");
     if (!out) throw Error("cannot write '" + P.output + "'");
     std::vector<char> iobuf(1 << 22);
     setvbuf(out, iobuf.data(), _IOFBF, iobuf.size());
     if (!P.label.empty()) fprintf(out, "\t%s\n", P.label.c_str());  // :33-34
-    const uint64_t max_bases = 256ull << 20, max_reads = 1u << 20;  // bounds the device scratch of a batch to a few GB
-    ReadBatch batch;
-    batch.clear();
-    Merged merged;
-    std::vector<uint64_t> oh, oo;
-    std::vector<uint32_t> oc;
+    Sink sink(P);
+    sink.out = out;
+    Merged &merged = sink.merged;
+    FlatBatch batch;
     uint64_t n_reads = 0;
     for (const Input &in : P.inputs) {
       if (in.b.empty()) {
-        SeqReader rd(in.a, in.fmt);
-        for (;;) {
-          bool more = rd.next_batch(batch, max_bases, max_reads);
-          if (batch.size() >= max_reads || batch.bases.size() >= max_bases || !more) {
-            n_reads += batch.size();
-            process_batch(P, batch, out, merged, oh, oc, oo);
-            batch.clear();
-          }
-          if (!more) break;
+        FastSeqReader rd(in.a, in.fmt);
+        while (rd.next(batch)) {
+          n_reads += batch.size();
+          sink.process(batch);
         }
       } else {  // mates alternate: segment 0, segment 1, ... (bin/KPopCount.ml:36-54)
         SeqReader r1(in.a, in.fmt), r2(in.b, in.fmt);
         std::string t1, s1, t2, s2;
+        batch.clear();
         for (;;) {
           bool m1 = r1.next_record(t1, s1), m2 = r2.next_record(t2, s2);
           if (m1 != m2) throw Error("paired-end files '" + in.a + "' and '" + in.b + "' have different numbers of reads");
           if (!m1) break;
           for (int m = 0; m < 2; ++m) {
-            const std::string &s = m ? s2 : s1;
+            const std::string &s = m ? s2 : s1, &t = m ? t2 : t1;
             batch.bases.insert(batch.bases.end(), s.begin(), s.end());
-            batch.offsets.push_back(batch.bases.size());
-            batch.tags.push_back(m ? t2 : t1);
+            batch.lens.push_back((uint32_t)s.size());
+            batch.tags.insert(batch.tags.end(), t.begin(), t.end());
+            batch.tag_lens.push_back((uint32_t)t.size());
           }
           ++n_reads;
-          if (batch.size() >= max_reads || batch.bases.size() >= max_bases) {
-            process_batch(P, batch, out, merged, oh, oc, oo);
+          if (batch.size() >= (1u << 20) || batch.bases.size() >= (256ull << 20)) {
+            sink.process(batch);
             batch.clear();
           }
         }
-        process_batch(P, batch, out, merged, oh, oc, oo);
+        sink.process(batch);
         batch.clear();
       }
     }
+    sink.finish();
     if (!P.label.empty()) {  // final dump, bin/KPopCount.ml:60
       std::vector<uint32_t> c32(merged.count.size());
       for (size_t i = 0; i < c32.size(); ++i) {

@@ -18,12 +18,19 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
-#include <map>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/kpop_hip.h"
+#include "fast_seq.h"
 #include "kpop_text.h"
 #include "ocaml_marshal.h"
 
@@ -217,37 +224,192 @@ std::vector<double> metric_vector(const Metric &m, const TwisterReg &T) {  // Tw
   return out;
 }
 
+// One piece of twisted rows in arrival order (a spectra file, or a block of the reads stream)
+struct RowPiece {
+  std::vector<std::string> labels;
+  DVec rows;
+};
+
+// blocks of the reads stream, read ahead of the GPU by one thread
+struct BlockQueue {
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<FlatBatch> q;
+  bool done = false;
+  std::string error;
+  void push(FlatBatch &&b) {
+    std::unique_lock<std::mutex> l(m);
+    cv.wait(l, [&] { return q.size() < 2; });
+    q.push_back(std::move(b));
+    cv.notify_all();
+  }
+  bool pop(FlatBatch &b) {
+    std::unique_lock<std::mutex> l(m);
+    cv.wait(l, [&] { return !q.empty() || done; });
+    if (q.empty()) return false;
+    b = std::move(q.front());
+    q.pop_front();
+    cv.notify_all();
+    return true;
+  }
+  void finish(const std::string &err) {
+    std::lock_guard<std::mutex> l(m);
+    done = true;
+    error = err;
+    cv.notify_all();
+  }
+};
+
+// The reads stream (fast_seq.h): KPopCount sent the linted reads instead of their spectra; count and twist them in one
+// kernel.  Equal to parsing the text KPopCount would have written (bin/KPopCount.ml:44-46) and twisting that.
+void twist_read_stream(int fd, TwisterReg &T, bool normalize, std::vector<RowPiece> &pieces, bool verbose) {
+  ReadStreamReader rs(fd);
+  const int k = (int)rs.header.k, content = (int)rs.header.content;
+  if (k < 1 || k > 30 || (content != KPOP_DNA_DS && content != KPOP_DNA_SS)) throw Error("reads stream: unsupported k or content");
+  T.upload();
+  const size_t d = T.twister.rows();
+  // the names KPopCount would have written carry name_digits(k) hex digits; if the twister's names are of another
+  // width no k-mer of the stream can be a column of it (lib/Twister.ml:167-169): every row is the zero vector
+  const bool can_match = (size_t)name_digits(k, false) == T.name_len;
+  BlockQueue bq;
+  std::thread reader([&] {
+    std::string err;
+    try {
+      FlatBatch b;
+      while (rs.next(b)) bq.push(std::move(b));
+    } catch (const std::exception &e) {
+      err = e.what();
+    }
+    bq.finish(err);
+  });
+  try {
+    FlatBatch b;
+    std::vector<uint64_t> offsets;
+    uint64_t n_reads = 0;
+    while (bq.pop(b)) {
+      const size_t n = b.size();
+      RowPiece piece;
+      piece.labels.resize(n);
+      parallel_for(n, 65536, [&](size_t lo, size_t hi) {
+        size_t at = 0;
+        for (size_t r = 0; r < lo; ++r) at += b.tag_lens[r];
+        for (size_t r = lo; r < hi; ++r) {
+          // once by KPopCount when it prints the label (bin/KPopCount.ml:45), once by the parser (lib/Twister.ml:110)
+          piece.labels[r] = strip_external_quotes_and_check(strip_external_quotes_and_check(std::string(b.tags.data() + at, b.tag_lens[r])));
+          at += b.tag_lens[r];
+        }
+      });
+      offsets.resize(n + 1);
+      offsets[0] = 0;
+      for (size_t r = 0; r < n; ++r) offsets[r + 1] = offsets[r] + b.lens[r];
+      piece.rows.resize(n * d);
+      if (can_match && n) {
+        static const uint8_t dummy = 0;
+        check(kpop_spectra_twist(T.dev, b.bases.empty() ? &dummy : b.bases.data(), offsets.data(), (uint32_t)n, k, content,
+                                 normalize ? 1 : 0, piece.rows.data()));
+      } else {
+        std::fill(piece.rows.begin(), piece.rows.end(), 0.);
+      }
+      n_reads += n;
+      pieces.push_back(std::move(piece));
+      if (verbose) fprintf(stderr, "(KPopTwistDB): reads stream: %llu sequences counted and twisted so far\n", (unsigned long long)n_reads);
+    }
+  } catch (...) {
+    {  // let the reader run to its end so that it can be joined
+      std::lock_guard<std::mutex> l(bq.m);
+      bq.q.clear();
+      bq.cv.notify_all();
+    }
+    FlatBatch drop;
+    while (bq.pop(drop)) {
+    }
+    reader.join();
+    throw;
+  }
+  reader.join();
+  if (!bq.error.empty()) throw Error(bq.error);
+}
+
 // Twister.add_twisted_from_files, lib/Twister.ml:58-206
 void add_twisted_from_files(TwisterReg &T, Table &twisted, const std::vector<std::string> &files, bool normalize, bool verbose) {
   T.need_matrix();
   const std::vector<std::string> &dims = T.twister.row_names;
   if (!twisted.empty() && twisted.col_names != dims) throw Error("Incompatible_twister_and_twisted");  // :64-69
   T.upload();
-  // names -> hashes while parsing; a name the twister cannot hold is simply an unknown k-mer (:167-169)
-  HashedSpectra sp;
+  const size_t d = dims.size();
+  std::vector<RowPiece> pieces;
   const uint64_t absent = ~0ull >> 1;  // no twister column carries this hash (k <= 30)
   for (const std::string &f : files) {
-    read_spectra_hashed(f, T.name_len, absent, sp);
-    if (verbose) fprintf(stderr, "(KPopTwistDB): File '%s': read %zu spectra so far\n", f.c_str(), sp.labels.size());
+    const bool is_stdin = f == "/dev/stdin" || f == "-";
+    const int fd = is_stdin ? 0 : open(f.c_str(), O_RDONLY);
+    if (fd < 0) throw Error("cannot open '" + f + "': " + strerror(errno));
+    try {
+      for (;;) {  // a file is text spectra, or reads streams (one per KPopCount that wrote to the pipe) and then maybe text
+        char head[8];
+        size_t got = 0;
+        while (got < 8) {
+          const ssize_t r = read(fd, head + got, 8 - got);
+          if (r < 0 && errno == EINTR) continue;
+          if (r <= 0) break;
+          got += (size_t)r;
+        }
+        if (got == 8 && memcmp(head, kReadStreamMagic, 8) == 0) {
+          twist_read_stream(fd, T, normalize, pieces, verbose);
+          continue;
+        }
+        if (got == 0 && !pieces.empty()) break;  // end of file right after a stream
+        // names -> hashes while parsing; a name the twister cannot hold is simply an unknown k-mer (:167-169)
+        HashedSpectra sp;
+        read_spectra_hashed_fd(fd, head, got, T.name_len, absent, sp);
+        RowPiece piece;
+        const size_t n = sp.labels.size();
+        piece.rows.resize(n * d);
+        if (n) check(kpop_twist(T.dev, sp.hash.data(), sp.values.data(), sp.offsets.data(), (uint32_t)n, normalize ? 1 : 0, piece.rows.data()));
+        piece.labels.swap(sp.labels);
+        pieces.push_back(std::move(piece));
+        break;
+      }
+    } catch (...) {
+      if (!is_stdin) close(fd);
+      throw;
+    }
+    if (!is_stdin) close(fd);
+    if (verbose) {
+      size_t n = 0;
+      for (const RowPiece &p : pieces) n += p.labels.size();
+      fprintf(stderr, "(KPopTwistDB): File '%s': read %zu spectra so far\n", f.c_str(), n);
+    }
   }
-  const size_t n = sp.labels.size(), d = dims.size();
-  std::vector<double> rows(n * d);
-  if (n) check(kpop_twist(T.dev, sp.hash.data(), sp.values.data(), sp.offsets.data(), (uint32_t)n, normalize ? 1 : 0, rows.data()));
-  // StringMap of label -> row: existing rows first, new labels must be new (:78-82,:189-195), result in
-  // bytewise label order (:197-204)
-  std::map<std::string, std::pair<const double *, size_t>> res;
-  for (size_t r = 0; r < twisted.rows(); ++r) res[twisted.row_names[r]] = {twisted.data.data() + r * d, 0};
-  for (size_t r = 0; r < n; ++r) {
-    if (res.count(sp.labels[r])) throw Error("Duplicate_label(\"" + sp.labels[r] + "\")");
-    res[sp.labels[r]] = {rows.data() + r * d, 0};
+  // existing rows first, new labels must be new (:78-82,:189-195), result in bytewise label order (:197-204)
+  const size_t n_old = twisted.rows();
+  std::vector<std::string> labels;
+  std::vector<const double *> row_of;
+  {
+    size_t n_new = 0;
+    for (const RowPiece &p : pieces) n_new += p.labels.size();
+    labels.reserve(n_old + n_new);
+    row_of.reserve(n_old + n_new);
+    for (size_t r = 0; r < n_old; ++r) {
+      labels.push_back(twisted.row_names[r]);
+      row_of.push_back(twisted.data.data() + r * d);
+    }
+    for (RowPiece &p : pieces)
+      for (size_t r = 0; r < p.labels.size(); ++r) {
+        labels.push_back(std::move(p.labels[r]));
+        row_of.push_back(p.rows.data() + r * d);
+      }
   }
+  const std::vector<uint32_t> order = order_rows_by_label(labels, n_old);
   Table out;
   out.col_names = dims;
-  out.data.reserve(res.size() * d);
-  for (auto &kv : res) {
-    out.row_names.push_back(kv.first);
-    out.data.insert(out.data.end(), kv.second.first, kv.second.first + d);
-  }
+  out.row_names.resize(order.size());
+  out.data.resize(order.size() * d);
+  parallel_for(order.size(), 8192, [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) {
+      out.row_names[i] = std::move(labels[order[i]]);
+      memcpy(out.data.data() + i * d, row_of[order[i]], d * sizeof(double));
+    }
+  });
   twisted.col_names.swap(out.col_names);
   twisted.row_names.swap(out.row_names);
   twisted.data.swap(out.data);
@@ -507,7 +669,10 @@ int main(int argc, char **argv) {
             Table m;
             m.row_names = {"metrics"};
             m.col_names = T.inertia.col_names;
-            m.data = metric_vector(metric, T);
+            {
+              const std::vector<double> mv = metric_vector(metric, T);
+              m.data.assign(mv.begin(), mv.end());
+            }
             write_table(make_filename(a.s1, "KPopMetrics", true), m, precision);
           } else if (a.reg == Reg::Embeddings) {
             write_table(make_filename(a.s1, "KPopVectors", true), embeddings, precision);

@@ -5,11 +5,38 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <thread>
 
 namespace kpop_host {
+
+// ------------------------------------------------------------------ threads
+void parallel_for(size_t n, size_t min_per_thread, const std::function<void(size_t, size_t)> &fn) {
+  unsigned t = std::thread::hardware_concurrency();
+  if (const char *e = getenv("KPOP_HOST_THREADS")) t = (unsigned)atoi(e);
+  t = std::max(1u, std::min(t, 32u));
+  t = (unsigned)std::max<size_t>(1, std::min<size_t>(t, n / std::max<size_t>(1, min_per_thread) + 1));
+  if (t == 1 || n == 0) {
+    fn(0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  std::vector<std::exception_ptr> err(t);
+  auto run = [&](unsigned i) {
+    try {
+      fn(n * i / t, n * (i + 1) / t);
+    } catch (...) {
+      err[i] = std::current_exception();
+    }
+  };
+  for (unsigned i = 1; i < t; ++i) pool.emplace_back(run, i);
+  run(0);
+  for (std::thread &th : pool) th.join();
+  for (auto &e : err)
+    if (e) std::rethrow_exception(e);
+}
 
 // ------------------------------------------------------------------ names
 std::string strip_external_quotes_and_check(const std::string &s) {
@@ -339,8 +366,36 @@ void parse_chunk(const char *s, const char *e, size_t name_len, uint64_t absent,
 
 }  // namespace
 
+static void parse_spectra_buffer(const std::vector<char> &buf, size_t name_len, uint64_t absent, HashedSpectra &out, unsigned threads);
+
 void read_spectra_hashed(const std::string &path, size_t name_len, uint64_t absent, HashedSpectra &out, unsigned threads) {
-  const std::vector<char> buf = slurp(path);
+  parse_spectra_buffer(slurp(path), name_len, absent, out, threads);
+}
+
+void read_spectra_hashed_fd(int fd, const char *head, size_t head_len, size_t name_len, uint64_t absent, HashedSpectra &out,
+                            unsigned threads) {
+  std::vector<char> buf;
+  size_t cap = 1 << 22, len = head_len;
+  buf.resize(cap);
+  if (head_len) memcpy(buf.data(), head, head_len);
+  for (;;) {
+    if (len == cap) {
+      cap *= 2;
+      buf.resize(cap);
+    }
+    const ssize_t got = read(fd, buf.data() + len, cap - len);
+    if (got < 0) {
+      if (errno == EINTR) continue;
+      throw Error(std::string("read failed: ") + strerror(errno));
+    }
+    if (got == 0) break;
+    len += (size_t)got;
+  }
+  buf.resize(len);
+  parse_spectra_buffer(buf, name_len, absent, out, threads);
+}
+
+static void parse_spectra_buffer(const std::vector<char> &buf, size_t name_len, uint64_t absent, HashedSpectra &out, unsigned threads) {
   const char *base = buf.data();
   const size_t size = buf.size();
   const unsigned T = pick_threads(threads, size, 4u << 20);
@@ -514,6 +569,62 @@ void write_table(const std::string &path, const Table &t, int precision) {
   }
   if (f != stdout) fclose(f);
   else fflush(f);
+}
+
+std::vector<uint32_t> order_rows_by_label(const std::vector<std::string> &labels, size_t n_existing) {
+  const size_t n = labels.size();
+  if (n > 0xFFFFFFFFull) throw Error("more than 2^32 rows");
+  std::vector<uint32_t> idx(n);
+  for (size_t i = 0; i < n; ++i) idx[i] = (uint32_t)i;
+  auto less = [&](uint32_t a, uint32_t b) {
+    const int c = labels[a].compare(labels[b]);  // char_traits<char>::compare: bytewise, as OCaml's String.compare
+    return c < 0 || (c == 0 && a < b);
+  };
+  // sorted runs by the threads, then pairwise merges
+  unsigned T = std::thread::hardware_concurrency();
+  if (const char *e = getenv("KPOP_HOST_THREADS")) T = (unsigned)atoi(e);
+  T = std::max(1u, std::min(T, 16u));
+  while (T > 1 && n / T < 8192) T /= 2;
+  unsigned P = 1;
+  while (P * 2 <= T) P *= 2;  // a power of two of runs
+  std::vector<size_t> edge(P + 1);
+  for (unsigned i = 0; i <= P; ++i) edge[i] = n * i / P;
+  {
+    std::vector<std::thread> pool;
+    for (unsigned i = 1; i < P; ++i) pool.emplace_back([&, i] { std::sort(idx.begin() + edge[i], idx.begin() + edge[i + 1], less); });
+    std::sort(idx.begin() + edge[0], idx.begin() + edge[1], less);
+    for (std::thread &th : pool) th.join();
+  }
+  for (unsigned w = 1; w < P; w *= 2) {
+    std::vector<std::thread> pool;
+    for (unsigned i = 0; i + w < P + 1 && i < P; i += 2 * w) {
+      const size_t a = edge[i], m = edge[std::min(i + w, P)], b = edge[std::min(i + 2 * w, P)];
+      if (m >= b) continue;
+      pool.emplace_back([&, a, m, b] { std::inplace_merge(idx.begin() + a, idx.begin() + m, idx.begin() + b, less); });
+    }
+    for (std::thread &th : pool) th.join();
+  }
+  // groups of equal labels
+  std::vector<uint32_t> out;
+  out.reserve(n);
+  uint32_t first_dup = 0xFFFFFFFFu;
+  for (size_t i = 0; i < n;) {
+    size_t j = i + 1;
+    while (j < n && labels[idx[j]] == labels[idx[i]]) ++j;
+    // members ascend by arrival number; a new row (>= n_existing) that is not the first of its group is a duplicate
+    uint32_t keep = idx[i];
+    for (size_t q = i + 1; q < j; ++q) {
+      if (idx[q] >= n_existing) {
+        first_dup = std::min(first_dup, idx[q]);
+        break;
+      }
+      keep = idx[q];  // among existing rows the last one wins
+    }
+    out.push_back(keep);
+    i = j;
+  }
+  if (first_dup != 0xFFFFFFFFu) throw Error("Duplicate_label(\"" + labels[first_dup] + "\")");  // lib/Twister.ml:195
+  return out;
 }
 
 void merge_rowwise(Table &into, const Table &add) {

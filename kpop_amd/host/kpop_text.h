@@ -6,6 +6,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <functional>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -15,6 +17,28 @@ namespace kpop_host {
 struct Error : std::runtime_error {
   explicit Error(const std::string &m) : std::runtime_error(m) {}
 };
+
+// A vector of doubles whose resize() leaves the new elements uninitialised: the big matrices (a million twisted rows are
+// half a GB) are filled by whoever sized them, and a zero-fill first would touch every page one more time.
+template <class T>
+struct DefaultInitAlloc : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    using other = DefaultInitAlloc<U>;
+  };
+  DefaultInitAlloc() = default;
+  template <class U>
+  DefaultInitAlloc(const DefaultInitAlloc<U> &) {}
+  template <class U, class... A>
+  void construct(U *p, A &&...a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void *)p) U;
+    else ::new ((void *)p) U(std::forward<A>(a)...);
+  }
+};
+using DVec = std::vector<double, DefaultInitAlloc<double>>;
+
+// fn(lo, hi) over [0, n) cut into contiguous pieces, one per host thread (KPOP_HOST_THREADS overrides the count)
+void parallel_for(size_t n, size_t min_per_thread, const std::function<void(size_t, size_t)> &fn);
 
 // ---- names ---------------------------------------------------------------
 // Matrix.Base.strip_external_quotes_and_check (BiOCamLib; call sites bin/KPopCount.ml:45,169,
@@ -85,6 +109,9 @@ struct HashedSpectra {
   std::vector<double> values;
 };
 void read_spectra_hashed(const std::string &path, size_t name_len, uint64_t absent, HashedSpectra &out, unsigned threads = 0);
+// the same on an open descriptor whose first head_len bytes the caller has already taken off (to look at them)
+void read_spectra_hashed_fd(int fd, const char *head, size_t head_len, size_t name_len, uint64_t absent, HashedSpectra &out,
+                            unsigned threads = 0);
 
 // "\t<label>\n" + "<hex>\t<count>\n"... for reads [0, n) of a CSR result, formatted by several threads and written in
 // order (bin/KPopCount.ml:44-46).  labels must already be checked.
@@ -95,7 +122,7 @@ void write_spectrum_body(FILE *f, const uint64_t *hash, const uint32_t *count, u
 // ---- matrix tables (Appendix A.2; README.md:618-626,643-650; src/KPopTwist:100,108,116) ----
 struct Table {
   std::vector<std::string> col_names, row_names;
-  std::vector<double> data;  // row-major rows x cols
+  DVec data;  // row-major rows x cols
   size_t rows() const { return row_names.size(); }
   size_t cols() const { return col_names.size(); }
   bool empty() const { return row_names.empty() && col_names.empty(); }
@@ -104,6 +131,13 @@ Table read_table(const std::string &path);
 void write_table(const std::string &path, const Table &t, int precision);
 // Matrix.merge_rowwise (BiOCamLib; call site lib/Matrix.ml:331-334): same columns, rows appended
 void merge_rowwise(Table &into, const Table &add);
+
+// Row bookkeeping of Twister.add_twisted_from_files (lib/Twister.ml:78-82,189-204) without a tree of a million strings:
+// `labels` are the row names in arrival order, the first n_existing of them rows the register already held (among those a
+// repeated name keeps its last row, StringMap.add); a later label that is already present is the reference's
+// Duplicate_label, raised for the first such row in arrival order.  Returns the arrival numbers of the surviving rows in
+// bytewise label order.
+std::vector<uint32_t> order_rows_by_label(const std::vector<std::string> &labels, size_t n_existing);
 
 std::string format_g(double x, int precision);  // "%.*g"
 

@@ -2,7 +2,11 @@
 #include "ocaml_marshal.h"
 
 #include <errno.h>
+#include <fcntl.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <memory>
@@ -326,7 +330,7 @@ struct Reader {
     }
   }
   // payload of a DoubleArray node appended to `out`
-  void copy_doubles(const Node &nd, std::vector<double> &out) const {
+  void copy_doubles(const Node &nd, DVec &out) const {
     const size_t at = out.size();
     out.resize(at + nd.b);
     const uint8_t *s = &data[nd.a];
@@ -408,24 +412,130 @@ void strings_of(const Reader &r, uint32_t id, std::vector<std::string> &out) {
 
 }  // namespace
 
-void marshal_write_matrix(FILE *f, const std::string &type_name, const Table &t) {
-  write_string_value(f, type_name);       // Type.to_string m.which |> output_value
-  write_string_value(f, kArchiveVersion);  // archive_version |> output_value
-  Writer w;                                // output_value output m.matrix
-  {
-    size_t names = 0;
-    for (const std::string &s : t.col_names) names += s.size() + 9;
-    for (const std::string &s : t.row_names) names += s.size() + 9;
-    w.buf.reserve(names + t.data.size() * 8 + t.rows() * 9 + 64);
+// The three values of a matrix archive as {everything before the row data, the row data}: the names are small and go
+// through the Writer; the rows are a fixed number of bytes each (a float-array prefix and the doubles as they stand in
+// memory), so their place in the file is known without building them and they can be laid down in parallel.
+struct MatrixImage {
+  std::string head;        // type name, archive version, the value's header, and the record up to the data block's prefix
+  size_t row_prefix = 0;   // bytes in front of each row's doubles
+  char prefix[9];
+  size_t row_bytes = 0;    // row_prefix + 8 * cols (1 for the atom of an empty row)
+  uint64_t total() const { return head.size() + rows * row_bytes; }
+  uint64_t rows = 0;
+};
+
+static MatrixImage matrix_image(const std::string &type_name, const Table &t) {
+  MatrixImage im;
+  Writer names;  // col_names, row_names and the block prefixes
+  names.block_header(3, 0);
+  names.block_header(t.col_names.size(), 0);
+  for (const std::string &s : t.col_names) names.string(s);
+  names.block_header(t.row_names.size(), 0);
+  for (const std::string &s : t.row_names) names.string(s);
+  names.block_header(t.rows(), 0);
+  const uint64_t nc = t.cols(), nr = t.rows();
+  {  // what Writer::double_array would put in front of a row
+    Writer w;
+    if (nc == 0) w.u8(PREFIX_SMALL_BLOCK);
+    else if (nc < 0x100) {
+      w.u8(CODE_DOUBLE_ARRAY8_LITTLE);
+      w.u8((uint8_t)nc);
+    } else if (nc < (1ull << 32)) {
+      w.u8(CODE_DOUBLE_ARRAY32_LITTLE);
+      w.be(nc, 4);
+    } else {
+      w.u8(CODE_DOUBLE_ARRAY64_LITTLE);
+      w.be(nc, 8);
+    }
+    im.row_prefix = w.buf.size();
+    memcpy(im.prefix, w.buf.data(), w.buf.size());
   }
-  w.block_header(3, 0);
-  w.block_header(t.col_names.size(), 0);
-  for (const std::string &s : t.col_names) w.string(s);
-  w.block_header(t.row_names.size(), 0);
-  for (const std::string &s : t.row_names) w.string(s);
-  w.block_header(t.rows(), 0);
-  for (size_t r = 0; r < t.rows(); ++r) w.double_array(t.data.data() + r * t.cols(), t.cols());
-  w.flush(f);
+  im.row_bytes = im.row_prefix + 8 * nc;
+  im.rows = nr;
+  const uint64_t data_len = names.buf.size() + nr * im.row_bytes;
+  const uint64_t n_obj = names.n_obj + (nc ? nr : 0);
+  const uint64_t size32 = names.size32 + (nc ? nr * (1 + 2 * nc) : 0), size64 = names.size64 + (nc ? nr * (1 + nc) : 0);
+  Writer hd;
+  const uint64_t lim = 1ull << 32;
+  if (data_len >= lim || size32 >= lim || size64 >= lim) {
+    hd.be(MAGIC_BIG, 4);
+    hd.be(0, 4);
+    hd.be(data_len, 8);
+    hd.be(n_obj, 8);
+    hd.be(size64, 8);
+  } else {
+    hd.be(MAGIC_SMALL, 4);
+    hd.be(data_len, 4);
+    hd.be(n_obj, 4);
+    hd.be(size32, 4);
+    hd.be(size64, 4);
+  }
+  for (const std::string *sv : {&type_name, (const std::string *)nullptr}) {  // Type.to_string m.which, then archive_version
+    Writer w;
+    w.string(sv ? *sv : std::string(kArchiveVersion));
+    Writer h2;
+    h2.be(MAGIC_SMALL, 4);
+    h2.be(w.buf.size(), 4);
+    h2.be(w.n_obj, 4);
+    h2.be(w.size32, 4);
+    h2.be(w.size64, 4);
+    im.head += h2.buf;
+    im.head += w.buf;
+  }
+  im.head += hd.buf;
+  im.head += names.buf;
+  return im;
+}
+
+static void lay_rows(char *dst, const MatrixImage &im, const Table &t, size_t lo, size_t hi) {
+  const size_t nc = t.cols();
+  for (size_t r = lo; r < hi; ++r) {
+    char *p = dst + (r - lo) * im.row_bytes;
+    memcpy(p, im.prefix, im.row_prefix);
+    if (nc) memcpy(p + im.row_prefix, t.data.data() + r * nc, nc * 8);  // x86-64: native = little endian
+  }
+}
+
+void marshal_write_matrix(FILE *f, const std::string &type_name, const Table &t) {
+  const MatrixImage im = matrix_image(type_name, t);
+  if (fwrite(im.head.data(), 1, im.head.size(), f) != im.head.size()) throw Error(std::string("write failed: ") + strerror(errno));
+  const size_t chunk_rows = std::max<size_t>(1, (8u << 20) / std::max<size_t>(1, im.row_bytes));
+  std::vector<char> buf(chunk_rows * im.row_bytes);
+  for (size_t r0 = 0; r0 < t.rows(); r0 += chunk_rows) {
+    const size_t r1 = std::min(t.rows(), r0 + chunk_rows);
+    parallel_for(r1 - r0, 4096, [&](size_t lo, size_t hi) { lay_rows(buf.data() + lo * im.row_bytes, im, t, r0 + lo, r0 + hi); });
+    const size_t n = (r1 - r0) * im.row_bytes;
+    if (fwrite(buf.data(), 1, n, f) != n) throw Error(std::string("write failed: ") + strerror(errno));
+  }
+}
+
+// a regular file: sized once, mapped, and filled by the host threads (the page-cache copy of a half-GB matrix is the
+// longest step of a twisting run otherwise); false = not a file this works for, nothing written
+static bool write_matrix_mapped(const std::string &path, const std::string &type_name, const Table &t) {
+  if (path.compare(0, 5, "/dev/") == 0) return false;
+  const MatrixImage im = matrix_image(type_name, t);
+  const uint64_t total = im.total();
+  if (total < (16u << 20)) return false;  // small archives: the plain writer
+  const int fd = open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0666);
+  if (fd < 0) throw Error("cannot open '" + path + "': " + strerror(errno));
+  struct stat st;
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || ftruncate(fd, (off_t)total) != 0) {
+    close(fd);
+    return false;
+  }
+  char *m = (char *)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  if (m == MAP_FAILED) {
+    if (ftruncate(fd, 0) != 0) {
+    }
+    close(fd);
+    return false;
+  }
+  memcpy(m, im.head.data(), im.head.size());
+  char *body = m + im.head.size();
+  parallel_for(t.rows(), 4096, [&](size_t lo, size_t hi) { lay_rows(body + lo * im.row_bytes, im, t, lo, hi); });
+  munmap(m, total);
+  close(fd);
+  return true;
 }
 
 bool marshal_read_matrix(FILE *f, std::string *type_name, Table *t) {
@@ -478,6 +588,7 @@ Table read_binary_matrix(const std::string &path, const std::string &expect_type
 }
 
 void write_binary_matrix(const std::string &path, const std::string &type_name, const Table &t) {
+  if (write_matrix_mapped(path, type_name, t)) return;
   FILE *f = open_or_throw(path, "wb");
   try {
     marshal_write_matrix(f, type_name, t);

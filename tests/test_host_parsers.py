@@ -40,3 +40,43 @@ def test_threaded_parser_agrees_with_sequential_one(harness, tmp_path):
             path.write_text(data)
             r = subprocess.run([harness, str(path), "3"], capture_output=True, text=True, errors="replace", env=env)
             assert r.returncode == 0, (threads, chunk, it, r.stdout, r.stderr)
+
+
+@pytest.fixture(scope="module")
+def seq_harness(tmp_path_factory):
+    out = tmp_path_factory.mktemp("seq_diff") / "seq_diff"
+    host = os.path.join(ROOT, "kpop_amd", "host")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", "-o", str(out), os.path.join(ROOT, "tests", "host", "seq_diff.cpp"),
+                    os.path.join(host, "kpop_text.cpp"), os.path.join(host, "fast_seq.cpp")], check=True)
+    return str(out)
+
+
+def test_block_reader_agrees_with_line_reader(seq_harness, tmp_path):
+    """FastSeqReader (blocks cut at record boundaries, records linted by threads) against SeqReader (one line at a time)
+    on mutated FASTA and FASTQ, whatever the block size and the thread count; the reads stream round-trips them."""
+    rng = random.Random(5)
+
+    def seq(n):
+        return "".join(rng.choice("ACGTacgtNn-") for _ in range(n))
+    fasta = "".join(">r%d some text\n" % i + "".join(seq(rng.randrange(0, 70)) + "\n" for _ in range(rng.randrange(0, 4))) for i in range(40))
+    fastq = "".join("@q%d\n%s\n+\n%s\n" % (i, seq(rng.randrange(0, 80)), "I" * rng.randrange(0, 80)) for i in range(40))
+    path = tmp_path / "in.txt"
+    for threads, chunk, block in (("8", "50", "64"), ("3", "300", "200"), ("1", "1", "1000"), ("4", "100", "100000")):
+        env = dict(os.environ, KPOP_HOST_THREADS=threads, KPOP_HOST_CHUNK=chunk, KPOP_SEQ_BLOCK=block)
+        for fmt, base in (("fasta", fasta), ("fastq", fastq)):
+            for it in range(80):
+                s = list(base)
+                for _ in range(rng.randrange(0, 4)):
+                    s[rng.randrange(len(s))] = rng.choice([">", "\n", "@", "+", "\r", "\r\n", "", "\n\n", " ", "\t", ">x\n"])
+                data = "".join(s)
+                if it % 7 == 0:
+                    data = data.rstrip("\n")
+                if it % 11 == 0:
+                    data = "\n\n" + data
+                if it % 13 == 0:
+                    data = ""
+                if it % 17 == 0:
+                    data = "ACGT\n" + data
+                path.write_text(data)
+                r = subprocess.run([seq_harness, str(path), fmt], capture_output=True, text=True, errors="replace", env=env)
+                assert r.returncode == 0, (threads, chunk, block, fmt, it, r.stdout, r.stderr)
