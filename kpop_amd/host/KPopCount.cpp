@@ -242,6 +242,7 @@ int main(int argc, char **argv) {
     std::vector<char> iobuf(1 << 22);
     setvbuf(out, iobuf.data(), _IOFBF, iobuf.size());
     if (!P.label.empty()) fprintf(out, "\t%s\n", P.label.c_str());  // :33-34
+    stage_mark("KPopCount", "start");
     Sink sink(P);
     sink.out = out;
     Merged &merged = sink.merged;
@@ -251,8 +252,10 @@ int main(int argc, char **argv) {
       if (in.b.empty()) {
         FastSeqReader rd(in.a, in.fmt);
         while (rd.next(batch)) {
+          stage_mark("KPopCount", "block parsed");
           n_reads += batch.size();
           sink.process(batch);
+          stage_mark("KPopCount", "block handed on");
         }
       } else {  // mates alternate: segment 0, segment 1, ... (bin/KPopCount.ml:36-54)
         SeqReader r1(in.a, in.fmt), r2(in.b, in.fmt);

@@ -22,6 +22,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -156,7 +157,12 @@ void check(int rc) {
 }
 
 bool g_gpu = false;
+std::thread g_warm;  // brings the HIP runtime up while the main thread reads its first archive
+void warm_gpu() {
+  g_warm = std::thread([] { (void)kpop_device_count(); });
+}
 void need_gpu() {
+  if (g_warm.joinable()) g_warm.join();
   if (g_gpu) return;
   int dev = 0;
   if (const char *e = getenv("KPOP_DEVICE")) dev = atoi(e);
@@ -287,6 +293,7 @@ void twist_read_stream(int fd, TwisterReg &T, bool normalize, std::vector<RowPie
     std::vector<uint64_t> offsets;
     uint64_t n_reads = 0;
     while (bq.pop(b)) {
+      stage_mark("KPopTwistDB", "  stream block arrived");
       const size_t n = b.size();
       RowPiece piece;
       piece.labels.resize(n);
@@ -312,6 +319,7 @@ void twist_read_stream(int fd, TwisterReg &T, bool normalize, std::vector<RowPie
       }
       n_reads += n;
       pieces.push_back(std::move(piece));
+      stage_mark("KPopTwistDB", "  stream block counted+twisted");
       if (verbose) fprintf(stderr, "(KPopTwistDB): reads stream: %llu sequences counted and twisted so far\n", (unsigned long long)n_reads);
     }
   } catch (...) {
@@ -333,9 +341,11 @@ void twist_read_stream(int fd, TwisterReg &T, bool normalize, std::vector<RowPie
 // Twister.add_twisted_from_files, lib/Twister.ml:58-206
 void add_twisted_from_files(TwisterReg &T, Table &twisted, const std::vector<std::string> &files, bool normalize, bool verbose) {
   T.need_matrix();
+  stage_mark("KPopTwistDB", "twister archive read");
   const std::vector<std::string> &dims = T.twister.row_names;
   if (!twisted.empty() && twisted.col_names != dims) throw Error("Incompatible_twister_and_twisted");  // :64-69
   T.upload();
+  stage_mark("KPopTwistDB", "HIP bring-up + twister upload");
   const size_t d = dims.size();
   std::vector<RowPiece> pieces;
   const uint64_t absent = ~0ull >> 1;  // no twister column carries this hash (k <= 30)
@@ -380,6 +390,7 @@ void add_twisted_from_files(TwisterReg &T, Table &twisted, const std::vector<std
       fprintf(stderr, "(KPopTwistDB): File '%s': read %zu spectra so far\n", f.c_str(), n);
     }
   }
+  stage_mark("KPopTwistDB", "input consumed, rows twisted");
   // existing rows first, new labels must be new (:78-82,:189-195), result in bytewise label order (:197-204)
   const size_t n_old = twisted.rows();
   std::vector<std::string> labels;
@@ -400,6 +411,7 @@ void add_twisted_from_files(TwisterReg &T, Table &twisted, const std::vector<std
       }
   }
   const std::vector<uint32_t> order = order_rows_by_label(labels, n_old);
+  stage_mark("KPopTwistDB", "rows ordered by label");
   Table out;
   out.col_names = dims;
   out.row_names.resize(order.size());
@@ -413,24 +425,56 @@ void add_twisted_from_files(TwisterReg &T, Table &twisted, const std::vector<std
   twisted.col_names.swap(out.col_names);
   twisted.row_names.swap(out.row_names);
   twisted.data.swap(out.data);
+  stage_mark("KPopTwistDB", "register assembled");
 }
 
 void write_summary(const std::string &path, const std::vector<std::string> &row_names, const std::vector<std::string> &col_names,
                    const std::vector<double> &stats, const std::vector<uint32_t> &n, const std::vector<uint32_t> &idx,
                    const std::vector<double> &dist, const std::vector<double> &z, uint32_t stride, bool quote) {
+  for (size_t j = 0; j < row_names.size(); ++j)
+    if (n[j] > stride) throw Error("summary row '" + row_names[j] + "' has " + std::to_string(n[j]) + " tied neighbours, more than fit");
   FILE *f = (path == "/dev/stdout") ? stdout : fopen(path.c_str(), "wb");
   if (!f) throw Error("cannot write '" + path + "'");
   const char *q = quote ? "\"" : "";
-  for (size_t j = 0; j < row_names.size(); ++j) {  // lib/Matrix.ml:684-690
-    fprintf(f, "%s%s%s\t%.15g\t%.15g\t%.15g\t%.15g", q, row_names[j].c_str(), q, stats[j * 4], stats[j * 4 + 1], stats[j * 4 + 2],
-            stats[j * 4 + 3]);
-    if (n[j] > stride) {
-      if (f != stdout) fclose(f);
-      throw Error("summary row '" + row_names[j] + "' has " + std::to_string(n[j]) + " tied neighbours, more than fit");
-    }
-    for (uint32_t e = 0; e < n[j]; ++e)
-      fprintf(f, "\t%s%s%s\t%.15g\t%.15g", q, col_names[idx[j * stride + e]].c_str(), q, dist[j * stride + e], z[j * stride + e]);
-    fputc('\n', f);
+  // lib/Matrix.ml:684-690; lines formatted by the host threads, a few hundred thousand at a time, written in order
+  const size_t total = row_names.size(), slab = 1u << 18;
+  for (size_t s0 = 0; s0 < total; s0 += slab) {
+    const size_t s1 = std::min(total, s0 + slab);
+    std::vector<std::string> text(64);
+    std::vector<std::pair<size_t, size_t>> span(64, {0, 0});
+    std::atomic<unsigned> next{0};
+    parallel_for(s1 - s0, 2048, [&](size_t lo, size_t hi) {
+      const unsigned me = next++;
+      if (me >= text.size()) throw Error("write_summary: more pieces than expected");
+      span[me] = {lo, hi};
+      std::string &o = text[me];
+      o.reserve((hi - lo) * (size_t)(96 + 40 * std::min<uint32_t>(stride, 4)));
+      char num[512];
+      for (size_t j = s0 + lo; j < s0 + hi; ++j) {
+        int len = snprintf(num, sizeof(num), "\t%.15g\t%.15g\t%.15g\t%.15g", stats[j * 4], stats[j * 4 + 1], stats[j * 4 + 2], stats[j * 4 + 3]);
+        o += q;
+        o += row_names[j];
+        o += q;
+        o.append(num, (size_t)len);
+        for (uint32_t e = 0; e < n[j]; ++e) {
+          o += '\t';
+          o += q;
+          o += col_names[idx[j * stride + e]];
+          o += q;
+          len = snprintf(num, sizeof(num), "\t%.15g\t%.15g", dist[j * stride + e], z[j * stride + e]);
+          o.append(num, (size_t)len);
+        }
+        o += '\n';
+      }
+    });
+    std::vector<unsigned> order;
+    for (unsigned i = 0; i < next && i < text.size(); ++i) order.push_back(i);
+    std::sort(order.begin(), order.end(), [&](unsigned a, unsigned b) { return span[a].first < span[b].first; });
+    for (unsigned i : order)
+      if (fwrite(text[i].data(), 1, text[i].size(), f) != text[i].size()) {
+        if (f != stdout) fclose(f);
+        throw Error("cannot write '" + path + "'");
+      }
   }
   if (f != stdout) fclose(f);
   else fflush(f);
@@ -579,6 +623,13 @@ int main(int argc, char **argv) {
     }
   }
 
+  stage_mark("KPopTwistDB", "start");
+  for (const Action &a : program)
+    if (a.kind == Action::AddKmersFiles || a.kind == Action::DistancesFromTwisted || a.kind == Action::SummaryFromTwisted ||
+        a.kind == Action::SummaryFromDistances || a.kind == Action::EmbeddingsFromTwisted) {
+      warm_gpu();
+      break;
+    }
   TwisterReg T;
   Table twisted, embeddings, distances;
   Metric metric;
@@ -588,6 +639,7 @@ int main(int argc, char **argv) {
   int precision = 15;
   try {
     for (const Action &a : program) {
+      stage_mark("KPopTwistDB", "-- next action");
       switch (a.kind) {
         case Action::Empty:
           if (a.reg == Reg::Twister) T.reset();
@@ -704,11 +756,12 @@ int main(int argc, char **argv) {
           if (from_tw) {
             m2 = load_twisted_operand(a.s1);
             if (twisted.col_names != m2.col_names) throw Error("Incompatible_geometries");  // lib/Matrix.ml:698-699
+            stage_mark("KPopTwistDB", "  twisted operand read");
           }
           const std::vector<std::string> &rows = from_tw ? m2.row_names : distances.row_names;
           const std::vector<std::string> &cols = from_tw ? twisted.row_names : distances.col_names;
           const uint32_t r1 = (uint32_t)cols.size(), r2 = (uint32_t)rows.size();
-          uint32_t stride = keep_at_most == 0 ? r1 : (uint32_t)std::min<long long>(r1, std::max<long long>(keep_at_most * 8, 16));
+          uint32_t stride = keep_at_most == 0 ? r1 : (uint32_t)std::min<long long>(r1, keep_at_most + 2);  // widened below if a tie group is larger
           stride = std::max(stride, 1u);
           std::vector<double> stats((size_t)r2 * 4), dist, z;
           std::vector<uint32_t> n(r2), idx;
@@ -730,17 +783,22 @@ int main(int argc, char **argv) {
             if (mx <= stride) break;
             stride = mx;
           }
+          stage_mark("KPopTwistDB", "  summaries computed");
           write_summary(make_filename(from_tw ? a.s2 : a.s1, "KPopSummary", true), rows, cols, stats, n, idx, dist, z, stride,
                         quote_summary);
+          stage_mark("KPopTwistDB", "  summary text written");
           break;
         }
       }
     }
   } catch (const std::exception &e) {
     fprintf(stderr, "(KPopTwistDB): FATAL: Uncaught exception: %s\n", e.what());
+    if (g_warm.joinable()) g_warm.join();
     T.reset();
     return 1;
   }
+  stage_mark("KPopTwistDB", "last action done");
+  if (g_warm.joinable()) g_warm.join();
   T.reset();
   return 0;
 }

@@ -5,12 +5,26 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <thread>
 
 namespace kpop_host {
+
+// ------------------------------------------------------------------ timing
+void stage_mark(const char *tool, const char *stage) {
+  static const bool on = getenv("KPOP_TIMING") != nullptr;
+  if (!on) return;
+  static double t0 = -1., last = 0.;
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  const double now = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+  if (t0 < 0.) t0 = last = now;
+  fprintf(stderr, "[timing] %s: %-44s +%.3f s  (%.3f s)\n", tool, stage, now - last, now - t0);
+  last = now;
+}
 
 // ------------------------------------------------------------------ threads
 void parallel_for(size_t n, size_t min_per_thread, const std::function<void(size_t, size_t)> &fn) {

@@ -37,6 +37,9 @@ struct DefaultInitAlloc : std::allocator<T> {
 };
 using DVec = std::vector<double, DefaultInitAlloc<double>>;
 
+// KPOP_TIMING=1: "<tool>: <stage> +<seconds since the previous mark> (<seconds since the first>)" on stderr
+void stage_mark(const char *tool, const char *stage);
+
 // fn(lo, hi) over [0, n) cut into contiguous pieces, one per host thread (KPOP_HOST_THREADS overrides the count)
 void parallel_for(size_t n, size_t min_per_thread, const std::function<void(size_t, size_t)> &fn);
 

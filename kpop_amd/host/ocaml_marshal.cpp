@@ -9,6 +9,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <vector>
 
@@ -509,31 +510,35 @@ void marshal_write_matrix(FILE *f, const std::string &type_name, const Table &t)
   }
 }
 
-// a regular file: sized once, mapped, and filled by the host threads (the page-cache copy of a half-GB matrix is the
-// longest step of a twisting run otherwise); false = not a file this works for, nothing written
-static bool write_matrix_mapped(const std::string &path, const std::string &type_name, const Table &t) {
-  if (path.compare(0, 5, "/dev/") == 0) return false;
+// a big archive: rows laid down by the host threads into a buffer of a few MB, which one write() then hands to the
+// kernel -- on this class of machine a single stream of large writes fills the page cache faster than a mapping
+// written by many threads does (tools/probes/write_probe.cpp); false = small archive, nothing written
+static bool write_matrix_chunked(const std::string &path, const std::string &type_name, const Table &t) {
   const MatrixImage im = matrix_image(type_name, t);
-  const uint64_t total = im.total();
-  if (total < (16u << 20)) return false;  // small archives: the plain writer
-  const int fd = open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0666);
+  if (im.total() < (16u << 20)) return false;
+  const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
   if (fd < 0) throw Error("cannot open '" + path + "': " + strerror(errno));
-  struct stat st;
-  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || ftruncate(fd, (off_t)total) != 0) {
-    close(fd);
-    return false;
-  }
-  char *m = (char *)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  if (m == MAP_FAILED) {
-    if (ftruncate(fd, 0) != 0) {
+  auto put = [&](const char *p, size_t n) {
+    while (n) {
+      const ssize_t w = write(fd, p, n);
+      if (w < 0) {
+        if (errno == EINTR) continue;
+        const std::string msg = std::string("write failed: ") + strerror(errno);
+        close(fd);
+        throw Error(msg);
+      }
+      p += w;
+      n -= (size_t)w;
     }
-    close(fd);
-    return false;
+  };
+  put(im.head.data(), im.head.size());
+  const size_t chunk_rows = std::max<size_t>(1, (16u << 20) / std::max<size_t>(1, im.row_bytes));
+  std::vector<char> buf(chunk_rows * im.row_bytes);
+  for (size_t r0 = 0; r0 < t.rows(); r0 += chunk_rows) {
+    const size_t r1 = std::min(t.rows(), r0 + chunk_rows);
+    parallel_for(r1 - r0, 2048, [&](size_t lo, size_t hi) { lay_rows(buf.data() + lo * im.row_bytes, im, t, r0 + lo, r0 + hi); });
+    put(buf.data(), (r1 - r0) * im.row_bytes);
   }
-  memcpy(m, im.head.data(), im.head.size());
-  char *body = m + im.head.size();
-  parallel_for(t.rows(), 4096, [&](size_t lo, size_t hi) { lay_rows(body + lo * im.row_bytes, im, t, lo, hi); });
-  munmap(m, total);
   close(fd);
   return true;
 }
@@ -566,6 +571,188 @@ bool marshal_read_matrix(FILE *f, std::string *type_name, Table *t) {
   return true;
 }
 
+// ---------------------------------------------------------------- mapped reader
+// A big matrix archive read the way it was laid down: the file is mapped, the names are walked by a cursor that knows
+// only the codes a matrix of strings and float arrays is made of, and the rows -- every one the same prefix and the same
+// number of little-endian doubles, one after the other -- are copied out by the host threads.  Anything else in the
+// stream (shared references, big-endian rows, rows of another width, a record of another shape) makes try_* return
+// false and the general reader takes the file from the start.
+namespace {
+
+struct Cursor {
+  const uint8_t *p, *e;
+  bool ok = true;
+  uint8_t u8() {
+    if (p >= e) {
+      ok = false;
+      return 0;
+    }
+    return *p++;
+  }
+  uint64_t be(int n) {
+    uint64_t v = 0;
+    for (int i = 0; i < n; ++i) v = (v << 8) | u8();
+    return v;
+  }
+  bool header(uint64_t *data_len) {  // of one output_value
+    if ((size_t)(e - p) < 20) return ok = false;
+    const uint32_t magic = (uint32_t)be(4);
+    if (magic == MAGIC_SMALL) {
+      *data_len = be(4);
+      be(4);
+      be(4);
+      be(4);
+    } else if (magic == MAGIC_BIG) {
+      be(4);
+      *data_len = be(8);
+      be(8);
+      be(8);
+    } else {
+      return ok = false;
+    }
+    return ok && *data_len <= (uint64_t)(e - p);
+  }
+  bool string(std::string *out) {
+    const uint8_t c = u8();
+    uint64_t len;
+    if (c >= PREFIX_SMALL_STRING && c < PREFIX_SMALL_INT) len = c - PREFIX_SMALL_STRING;
+    else if (c == CODE_STRING8) len = u8();
+    else if (c == CODE_STRING32) len = be(4);
+    else if (c == CODE_STRING64) len = be(8);
+    else return ok = false;
+    if (!ok || len > (uint64_t)(e - p)) return ok = false;
+    out->assign(reinterpret_cast<const char *>(p), len);
+    p += len;
+    return true;
+  }
+  bool block(uint64_t *size) {  // tag 0
+    const uint8_t c = u8();
+    if (c >= PREFIX_SMALL_BLOCK) {
+      if ((c & 0xF) != 0) return ok = false;
+      *size = (c >> 4) & 0x7;
+    } else if (c == CODE_BLOCK32) {
+      const uint64_t h = be(4);
+      if (h & 0x3FF) return ok = false;
+      *size = h >> 10;
+    } else if (c == CODE_BLOCK64) {
+      const uint64_t h = be(8);
+      if (h & 0x3FF) return ok = false;
+      *size = h >> 10;
+    } else {
+      return ok = false;
+    }
+    return ok;
+  }
+  bool strings(std::vector<std::string> *out) {
+    uint64_t n;
+    if (!block(&n) || n > (uint64_t)(e - p)) return ok = false;
+    out->resize(n);
+    for (uint64_t i = 0; i < n; ++i)
+      if (!string(&(*out)[i])) return false;
+    return true;
+  }
+};
+
+struct Mapping {
+  const uint8_t *p = nullptr;
+  size_t n = 0;
+  int fd = -1;
+  ~Mapping() {
+    if (p) munmap(const_cast<uint8_t *>(p), n);
+    if (fd >= 0) close(fd);
+  }
+  bool open_file(const std::string &path) {
+    if (path.compare(0, 5, "/dev/") == 0) return false;
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < (off_t)(16u << 20)) {
+      close(fd);
+      return false;
+    }
+    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) {
+      close(fd);
+      return false;
+    }
+    this->fd = fd;
+    p = reinterpret_cast<const uint8_t *>(m);
+    n = (size_t)st.st_size;
+    return true;
+  }
+};
+
+// one {type name, version, matrix} triple at the cursor; rows copied unless `skip_rows`
+bool try_matrix(const Mapping &map, Cursor &c, std::string *type_name, Table *t, bool skip_rows) {
+  uint64_t len;
+  std::string version;
+  if (!c.header(&len) || !c.string(type_name)) return false;
+  if (!c.header(&len) || !c.string(&version)) return false;
+  if (version != kArchiveVersion) return false;  // the general reader words the error
+  if (!c.header(&len)) return false;
+  const uint8_t *value_end = c.p + len;
+  Cursor v{c.p, value_end};
+  uint64_t three, nr;
+  *t = Table();
+  if (!v.block(&three) || three != 3 || !v.strings(&t->col_names) || !v.strings(&t->row_names) || !v.block(&nr)) return false;
+  if (nr != t->row_names.size()) return false;
+  const uint64_t nc = t->col_names.size();
+  uint8_t prefix[9];
+  size_t np;
+  if (nc == 0) return false;  // atoms: leave the odd cases to the general reader
+  if (nc < 0x100) {
+    prefix[0] = CODE_DOUBLE_ARRAY8_LITTLE;
+    prefix[1] = (uint8_t)nc;
+    np = 2;
+  } else if (nc < (1ull << 32)) {
+    prefix[0] = CODE_DOUBLE_ARRAY32_LITTLE;
+    for (int i = 0; i < 4; ++i) prefix[1 + i] = (uint8_t)(nc >> (8 * (3 - i)));
+    np = 5;
+  } else {
+    return false;
+  }
+  const uint64_t row_bytes = np + 8 * nc;
+  if ((uint64_t)(value_end - v.p) != nr * row_bytes) return false;
+  const uint8_t *rows = v.p;
+  if (!skip_rows) {
+    t->data.resize(nr * nc);
+    std::atomic<bool> uniform{true};
+    // the names were walked through the mapping; the rows come in by pread (no page fault per 4 KB), a few MB at a
+    // time per thread, and lose their prefixes on the way into the matrix
+    const uint64_t rows_at = (uint64_t)(rows - map.p);
+    parallel_for(nr, std::max<size_t>(1, (4u << 20) / row_bytes), [&](size_t lo, size_t hi) {
+      const size_t per = std::max<size_t>(1, (4u << 20) / row_bytes);
+      std::vector<uint8_t> bounce(std::min(per, hi - lo) * row_bytes);
+      for (size_t r0 = lo; r0 < hi; r0 += per) {
+        const size_t r1 = std::min(hi, r0 + per);
+        size_t want = (r1 - r0) * row_bytes, got = 0;
+        while (got < want) {
+          const ssize_t g = pread(map.fd, bounce.data() + got, want - got, (off_t)(rows_at + r0 * row_bytes + got));
+          if (g < 0 && errno == EINTR) continue;
+          if (g <= 0) {
+            uniform = false;
+            return;
+          }
+          got += (size_t)g;
+        }
+        for (size_t r = r0; r < r1; ++r) {
+          const uint8_t *q = bounce.data() + (r - r0) * row_bytes;
+          if (memcmp(q, prefix, np) != 0) {
+            uniform = false;
+            return;
+          }
+          memcpy(t->data.data() + r * nc, q + np, nc * 8);
+        }
+      }
+    });
+    if (!uniform) return false;
+  }
+  c.p = value_end;
+  return true;
+}
+
+}  // namespace
+
 static FILE *open_or_throw(const std::string &path, const char *mode) {
   FILE *f = fopen(path.c_str(), mode);
   if (!f) throw Error("cannot open '" + path + "': " + strerror(errno));
@@ -573,6 +760,15 @@ static FILE *open_or_throw(const std::string &path, const char *mode) {
 }
 
 Table read_binary_matrix(const std::string &path, const std::string &expect_type) {
+  {
+    Mapping m;
+    if (m.open_file(path)) {
+      Cursor c{m.p, m.p + m.n};
+      Table t;
+      std::string ty;
+      if (try_matrix(m, c, &ty, &t, false) && ty == expect_type) return t;
+    }
+  }
   FILE *f = open_or_throw(path, "rb");
   Table t;
   std::string ty;
@@ -588,7 +784,7 @@ Table read_binary_matrix(const std::string &path, const std::string &expect_type
 }
 
 void write_binary_matrix(const std::string &path, const std::string &type_name, const Table &t) {
-  if (write_matrix_mapped(path, type_name, t)) return;
+  if (write_matrix_chunked(path, type_name, t)) return;
   FILE *f = open_or_throw(path, "wb");
   try {
     marshal_write_matrix(f, type_name, t);
@@ -600,6 +796,25 @@ void write_binary_matrix(const std::string &path, const std::string &type_name, 
 }
 
 void read_binary_twister(const std::string &path, Table *twister, Table *inertia) {  // Twister.of_binary, lib/Twister.ml:232-246
+  {
+    Mapping m;
+    if (m.open_file(path)) {
+      Cursor c{m.p, m.p + m.n};
+      std::string t1, t2;
+      if (try_matrix(m, c, &t1, twister, false) && t1 == "KPopTwister") {
+        // the inertia is a few hundred bytes: the general reader on the tail
+        FILE *f = open_or_throw(path, "rb");
+        bool ok = fseek(f, (long)(c.p - m.p), SEEK_SET) == 0;
+        try {
+          ok = ok && marshal_read_matrix(f, &t2, inertia) && t2 == "KPopInertia";
+        } catch (...) {
+          ok = false;
+        }
+        fclose(f);
+        if (ok) return;
+      }
+    }
+  }
   FILE *f = open_or_throw(path, "rb");
   std::string t1, t2;
   try {

@@ -304,3 +304,45 @@ def test_kpoptwist_underscore_echoes_its_arguments():
     assert r.stdout == "\001".join(["In", "", "0.5", "1", "1", "clr", "false", "0.25", "Out", "km", "3", "false", "true"]) + "\n"
     r = run([os.path.join(BIN, "KPopTwist_"), "-i", "In"])
     assert r.returncode == 1 and "Option '-o' is mandatory" in r.stderr and r.stdout == ""
+
+
+def test_large_archives_mapped_paths_equal_the_streamed_ones(tmp_path):
+    """Archives of 16 MB and more are written through a mapping (rows laid down by the host threads) and read back from one;
+    both must agree byte for byte with the general writer (a pipe) and reader (a pipe), and a twister archive too."""
+    import numpy as np
+    rng = np.random.RandomState(4)
+    rows, cols = 36000, 64
+    data = rng.randint(-40, 40, size=(rows, cols)) / 8.0
+    names = ["row %d" % i for i in range(rows)]
+    dims = ["Dim%d" % (i + 1) for i in range(cols)]
+    write_table(tmp_path / "big.KPopTwisted.txt", dims, names, data)
+    r = run([TWISTDB, "-I", "t", str(tmp_path / "big"), "-o", "t", str(tmp_path / "mapped")])
+    assert r.returncode == 0, r.stderr
+    piped = subprocess.run([TWISTDB, "-I", "t", str(tmp_path / "big"), "-o", "t", "/dev/stdout"], stdout=subprocess.PIPE)
+    assert piped.returncode == 0
+    blob = (tmp_path / "mapped.KPopTwisted").read_bytes()
+    assert len(blob) > (16 << 20) and blob == piped.stdout
+    # mapped reader vs the general one (which a pipe forces)
+    r = run([TWISTDB, "-i", "t", str(tmp_path / "mapped"), "-O", "t", str(tmp_path / "back1")])
+    assert r.returncode == 0, r.stderr
+    r2 = subprocess.run([TWISTDB, "-i", "t", "/dev/stdin", "-O", "t", str(tmp_path / "back2")], input=blob)
+    assert r2.returncode == 0
+    t1 = (tmp_path / "back1.KPopTwisted.txt").read_bytes()
+    assert t1 == (tmp_path / "back2.KPopTwisted.txt").read_bytes() == (tmp_path / "big.KPopTwisted.txt").read_bytes()
+    # a twister: few rows, each millions of bytes (32-bit float-array prefix), inertia behind it
+    n_k = 300000
+    tw = rng.randint(-9, 9, size=(9, n_k)) / 4.0
+    kd = ["Dim%d" % (i + 1) for i in range(9)]
+    write_table(tmp_path / "T.KPopTwister.txt", ["%06x" % i for i in range(n_k)], kd, tw)
+    write_table(tmp_path / "T.KPopInertia.txt", kd, ["inertia"], [np.arange(9, 0, -1) / 45.0])
+    r = run([TWISTDB, "-I", "T", str(tmp_path / "T"), "-o", "T", str(tmp_path / "Tb")])
+    assert r.returncode == 0, r.stderr
+    assert os.path.getsize(tmp_path / "Tb.KPopTwister") > (16 << 20)
+    r = run([TWISTDB, "-i", "T", str(tmp_path / "Tb"), "-O", "T", str(tmp_path / "Tc"), "-O", "m", str(tmp_path / "Tc")])
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "Tc.KPopTwister.txt").read_bytes() == (tmp_path / "T.KPopTwister.txt").read_bytes()
+    assert (tmp_path / "Tc.KPopInertia.txt").read_bytes() == (tmp_path / "T.KPopInertia.txt").read_bytes()
+    tb = (tmp_path / "Tb.KPopTwister").read_bytes()
+    r3 = subprocess.run([TWISTDB, "-i", "T", "/dev/stdin", "-O", "T", str(tmp_path / "Td")], input=tb)
+    assert r3.returncode == 0
+    assert (tmp_path / "Td.KPopTwister.txt").read_bytes() == (tmp_path / "T.KPopTwister.txt").read_bytes()
