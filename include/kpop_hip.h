@@ -69,7 +69,8 @@ const char *kpop_last_error(void);
 const char *kpop_version(void);
 int kpop_synchronize(void *stream);
 /* performance knobs for A/B measurements (results are identical for every setting):
-   "unroll" 8|16 row loads in flight per wave, "nt" 0|1 non-temporal row loads */
+   "unroll" 8|16 row loads in flight per wave; "nt" row loads 0 plain | 1 non-temporal | 2 chosen by the size of the
+   twister (default); "seg" windows per segment of the genome kernel, 0 = sized to an XCD's L2 (default) */
 int kpop_tune(const char *key, int value);
 
 /* plain device-memory helpers so a non-HIP host language can stage buffers */

@@ -69,7 +69,8 @@ struct Context {
   Arena arena;
   // tuning knobs (kpop_tune): gather depth, non-temporal row loads
   int tune_unroll = 8;
-  int tune_nt = 1;       // rows are streamed once: keep them out of the caches the index lives in
+  int tune_nt = 2;       // row loads: 0 plain, 1 non-temporal, 2 by the size of the twister (count_twist.hip)
+  int tune_seg = 0;      // windows per segment of the genome kernel, 0 = sized to the L2
 };
 Context &ctx();
 int require_init();

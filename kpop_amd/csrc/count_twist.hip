@@ -292,15 +292,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void twist_csr_kernel(
 // kernel, so results are bitwise reproducible.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kWaveMaxWindows = 512;  // 64 lanes x R=8: the per-read kernels' limit
-constexpr uint32_t kSegWindows = 16384;
+constexpr uint32_t kSegWindows = 16384;    // upper bound of a segment
+// Row-load policy, kpop_tune("nt", 2) = automatic (measured: profiles/r02_b_realistic_inputs.txt).
+// Non-temporal loads keep once-read rows from displacing the name -> row index, which is worth 0-6 % when reads are
+// uniformly random over a table many times the 256 MB Infinity Cache -- and costs 6-35 % whenever rows ARE re-read:
+// tables up to ~1 GB even under uniform access (the cache holds a useful share of them), reads drawn from a few
+// genomes, assemblies of one organism.  So: reads kernel non-temporal only above 2 GiB of rows; genome kernel never
+// (a batch of assemblies is one species more often than not, and there plain loads are 1.5x faster).
+constexpr uint64_t kStreamingRowBytes = 2ull << 30;
 
-__global__ void segment_count_kernel(const uint64_t *__restrict__ offsets, uint32_t n, int k,
+__global__ void segment_count_kernel(const uint64_t *__restrict__ offsets, uint32_t n, int k, uint32_t seg_windows,
                                      uint32_t *__restrict__ nseg) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   const uint64_t len = offsets[r + 1] - offsets[r];
   const uint64_t w = (len >= (uint64_t)k) ? len - k + 1 : 0;
-  nseg[r] = (w > kWaveMaxWindows) ? (uint32_t)((w + kSegWindows - 1) / kSegWindows) : 0u;
+  nseg[r] = (w > kWaveMaxWindows) ? (uint32_t)((w + seg_windows - 1) / seg_windows) : 0u;
 }
 
 struct StoreU64 {
@@ -308,26 +315,30 @@ struct StoreU64 {
   __device__ void operator()(uint64_t i, uint64_t prefix, uint32_t) const { out[i] = prefix; }
 };
 
-template <typename H>
+template <typename H, bool NT>
 __global__ __launch_bounds__(256) void count_twist_stream_kernel(
     TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int content,
     const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ seg_off, double *__restrict__ partial,
-    uint32_t *__restrict__ partial_cnt, uint32_t n_reads, uint32_t max_seg) {
+    uint32_t *__restrict__ partial_cnt, uint32_t n_reads, uint32_t max_seg, uint32_t seg_windows) {
   __shared__ double s_part[4][64];
   __shared__ uint32_t s_cnt[4];
-  // (read, segment) pairs are dealt to blocks round-robin: a ragged batch (one genome among a million reads)
-  // has far more pairs than HIP allows blocks, and almost all of them are empty
+  // (segment, read) pairs are dealt to blocks round-robin, READS FASTEST: the blocks in flight at any moment work on the
+  // same stretch of many sequences.  Assemblies of one organism are near-identical (BASELINE config 3), so those blocks
+  // gather the same twister rows -- a segment's rows (seg_windows x d_pad x 8 B, sized to sit in an XCD's 4 MB L2) come
+  // from HBM once per XCD and are L2 hits for every other sequence.  Unrelated sequences lose nothing by this order.
+  // A ragged batch (one genome among a million reads) has far more pairs than HIP allows blocks, and almost all of them
+  // are empty, hence the grid-stride loop.
   const uint64_t n_pairs = (uint64_t)n_reads * max_seg;
   for (uint64_t pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
-  const uint32_t r = (uint32_t)(pair / max_seg), seg = (uint32_t)(pair % max_seg);
+  const uint32_t seg = (uint32_t)(pair / n_reads), r = (uint32_t)(pair % n_reads);
   if (seg >= nseg[r]) continue;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t off = offsets[r];
   const uint64_t len = offsets[r + 1] - off;
   const int k = tv.hk;
   const uint64_t n_win = len - k + 1;  // nseg > 0 implies len >= k
-  const uint64_t w0 = (uint64_t)seg * kSegWindows;
-  const uint64_t w1 = min(n_win, w0 + kSegWindows);
+  const uint64_t w0 = (uint64_t)seg * seg_windows;
+  const uint64_t w1 = min(n_win, w0 + seg_windows);
   const uint8_t *seq = bases + off;
   const int shift = 2 * (k - 1);
   const uint64_t slot = seg_off[r] + seg;
@@ -358,7 +369,7 @@ __global__ __launch_bounds__(256) void count_twist_stream_kernel(
 #pragma unroll
         for (int u = 0; u < kGatherUnroll; ++u) {
           const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)col, j0 + u);
-          v[u] = (cj != kNoCol && active) ? __builtin_nontemporal_load(base + (uint64_t)cj * tv.d_pad) : 0.0;
+          v[u] = (cj != kNoCol && active) ? (NT ? __builtin_nontemporal_load(base + (uint64_t)cj * tv.d_pad) : base[(uint64_t)cj * tv.d_pad]) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < kGatherUnroll; ++u) acc = __dadd_rn(acc, v[u]);
@@ -490,11 +501,12 @@ static int launch_count_twist_wave(int R, TwisterView tv, const uint8_t *bases, 
                                    const uint32_t *ids, uint32_t n, int content, int normalize, double *out,
                                    hipStream_t st) {
   const Context &c = ctx();
+  const bool nt = c.tune_nt == 1 || (c.tune_nt == 2 && (uint64_t)tv.n_rows * tv.d_pad * 8 > kStreamingRowBytes);
   if (c.tune_unroll == 16)
-    return c.tune_nt ? launch_count_twist_wave_v<H, 16, true>(R, tv, bases, offsets, ids, n, content, normalize, out, st)
-                     : launch_count_twist_wave_v<H, 16, false>(R, tv, bases, offsets, ids, n, content, normalize, out, st);
-  return c.tune_nt ? launch_count_twist_wave_v<H, 8, true>(R, tv, bases, offsets, ids, n, content, normalize, out, st)
-                   : launch_count_twist_wave_v<H, 8, false>(R, tv, bases, offsets, ids, n, content, normalize, out, st);
+    return nt ? launch_count_twist_wave_v<H, 16, true>(R, tv, bases, offsets, ids, n, content, normalize, out, st)
+              : launch_count_twist_wave_v<H, 16, false>(R, tv, bases, offsets, ids, n, content, normalize, out, st);
+  return nt ? launch_count_twist_wave_v<H, 8, true>(R, tv, bases, offsets, ids, n, content, normalize, out, st)
+            : launch_count_twist_wave_v<H, 8, false>(R, tv, bases, offsets, ids, n, content, normalize, out, st);
 }
 
 
@@ -543,8 +555,12 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   else
     KPOP_TRY(launch_count_twist_wave<uint64_t>(R, tv, d_bases, d_offsets, nullptr, n_reads, content, normalize, d_out, st));
   if (max_windows <= kWaveMaxWindows) return KPOP_OK;
-  // longer sequences: segment table, streaming kernel, ordered combine
-  const uint64_t max_slots = n_bases / kSegWindows + n_reads;  // every read adds at most W/seg + 1 segments
+  // longer sequences: segment table, streaming kernel, ordered combine.  Segment = the stretch of a sequence one block
+  // sums: its rows should sit in one XCD's L2 (4 MB) next to those of the neighbouring segment, see the kernel.
+  const Context &cx = ctx();
+  uint32_t seg_windows = cx.tune_seg ? (uint32_t)cx.tune_seg : std::max<uint32_t>(1024u, std::min<uint32_t>(kSegWindows, (uint32_t)((3ull << 19) / ((uint64_t)tw->d_pad * 8)) / 64 * 64));
+  const bool nt = cx.tune_nt == 1;
+  const uint64_t max_slots = n_bases / seg_windows + n_reads;  // every read adds at most W/seg + 1 segments
   const uint64_t nb = scan_blocks(n_reads);
   const uint64_t bytes_nseg = ((uint64_t)n_reads * 4 + 63) & ~63ull, bytes_off = ((uint64_t)(n_reads + 1) * 8 + 63) & ~63ull,
                  bytes_sums = ((nb + 1) * 8 + 63) & ~63ull, bytes_cnt = (max_slots * 4 + 63) & ~63ull,
@@ -557,17 +573,18 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   uint64_t *sums = reinterpret_cast<uint64_t *>(wp + bytes_nseg + bytes_off);
   uint32_t *pcnt = reinterpret_cast<uint32_t *>(wp + bytes_nseg + bytes_off + bytes_sums);
   double *part = reinterpret_cast<double *>(wp + bytes_nseg + bytes_off + bytes_sums + bytes_cnt);
-  segment_count_kernel<<<dim3(div_up(n_reads, 256)), dim3(256), 0, st>>>(d_offsets, n_reads, tv.hk, nseg);
+  segment_count_kernel<<<dim3(div_up(n_reads, 256)), dim3(256), 0, st>>>(d_offsets, n_reads, tv.hk, seg_windows, nseg);
   KPOP_LAUNCH_CHECK();
   KPOP_TRY(exclusive_scan(LoadU32{nseg}, StoreU64{seg_off}, n_reads, sums, st));
-  const uint32_t max_seg = div_up(max_windows, kSegWindows);
+  const uint32_t max_seg = div_up(max_windows, seg_windows);
   dim3 grid(capped_grid((uint64_t)n_reads * max_seg));
-  if (tv.hk <= 15)
-    count_twist_stream_kernel<uint32_t><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt,
-                                                                    n_reads, max_seg);
-  else
-    count_twist_stream_kernel<uint64_t><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt,
-                                                                    n_reads, max_seg);
+#define KPOP_STREAM(H, NT) count_twist_stream_kernel<H, NT><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, n_reads, max_seg, seg_windows)
+  if (tv.hk <= 15) {
+    if (nt) KPOP_STREAM(uint32_t, true); else KPOP_STREAM(uint32_t, false);
+  } else {
+    if (nt) KPOP_STREAM(uint64_t, true); else KPOP_STREAM(uint64_t, false);
+  }
+#undef KPOP_STREAM
   KPOP_LAUNCH_CHECK();
   combine_partials_kernel<<<dim3(n_reads), dim3(256), 0, st>>>(nseg, seg_off, part, pcnt, tw->n_dims, normalize, d_out);
   KPOP_LAUNCH_CHECK();
