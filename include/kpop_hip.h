@@ -70,7 +70,8 @@ const char *kpop_version(void);
 int kpop_synchronize(void *stream);
 /* performance knobs for A/B measurements (results are identical for every setting):
    "unroll" 8|16 row loads in flight per wave; "nt" row loads 0 plain | 1 non-temporal | 2 chosen by the size of the
-   twister (default); "seg" windows per segment of the genome kernel, 0 = sized to an XCD's L2 (default) */
+   twister (default); "seg" windows per segment of the genome kernel, 0 = sized to an XCD's L2 (default); "hist" 1 (default) | 0: the
+   merged spectrum of kpop_count_reads(per_read = 0) by atomic histogram where the hashes fit 26 bits, or always by sort */
 int kpop_tune(const char *key, int value);
 
 /* plain device-memory helpers so a non-HIP host language can stage buffers */

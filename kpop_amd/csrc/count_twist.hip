@@ -39,54 +39,140 @@ struct WaveLds {
 };
 
 // ---------------------------------------------------------------------------
-// count: one wave per read -> fixed-stride scratch rows of (hash, count)
+// count: one wave per read -> CSR of (hash, count), in ONE launch.
+//
+// A read's place in the CSR is the number of distinct k-mers of all reads before it, which no block knows by itself.
+// Blocks take a ticket (the order in which they start running) and own the four reads of that ticket, so "before" means
+// "smaller ticket", and hand their totals on through one 8-byte word per block -- {status, value} in a single store,
+// so the word IS the message and no fence orders anything (MI355X_MICROARCH.md, hand-off granules):
+//   status 1: value = distinct k-mers of this block's reads          (published as soon as they are counted)
+//   status 2: value = distinct k-mers of this and all earlier blocks (published once the block knows its prefix)
+// A block looks back over its predecessors 64 at a time (one wave, one word per lane) until it meets a status-2 word.
+// A predecessor has a smaller ticket, hence is already running: waiting for it cannot deadlock, whatever the dispatch
+// order.  Round 1 wrote fixed-stride scratch rows, scanned the per-read counts in three launches and compacted in a
+// fifth: 12 B x 256 slots per read written and read back.
 // ---------------------------------------------------------------------------
-template <int R, typename H, int SB = 2>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void count_wave_kernel(
-    const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ read_ids,
-    uint32_t n, int k, int content, uint32_t stride, uint64_t *__restrict__ scr_hash,
-    uint32_t *__restrict__ scr_count, uint32_t *__restrict__ n_unique_out) {
-  __shared__ WaveLds<R, H> lds[kWavesPerBlock];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint32_t w = blockIdx.x * kWavesPerBlock + wv;
-  if (w >= n) return;
-  const uint32_t r = read_ids ? read_ids[w] : w;
-  const uint64_t off = offsets[r];
-  const uint32_t len = (uint32_t)(offsets[r + 1] - off);
-  WaveLds<R, H> &L = lds[wv];
-  if (len >= (uint32_t)k && len - (uint32_t)k + 1 > 64u * R) {  // long-sequence path's business
-    if (lane == 0) n_unique_out[r] = 0;
-    return;
-  }
+constexpr uint64_t kLookbackValueMask = (1ull << 62) - 1;
 
-  wave_stage_codes<R, SB>(bases + off, len, lane, L.codes);
-  H key[R];
-  wave_hash_windows<R, H, SB>(L.codes, k, content, lane, key);
-  wave_bitonic_sort<R, H>(key, lane);
-  uint32_t n_valid;
-  const uint32_t nu = wave_unique<R, H>(key, (H)~(H)0, lane, L.key, L.start, n_valid);
-  for (uint32_t u = lane; u < nu; u += 64) {
-    scr_hash[(uint64_t)r * stride + u] = (uint64_t)L.key[u];
-    scr_count[(uint64_t)r * stride + u] = L.start[u + 1] - L.start[u];
+// exclusive prefix of `total` over the blocks with a smaller ticket; every lane of the calling wave gets it
+__device__ __forceinline__ uint64_t lookback_exclusive(uint64_t *state, uint32_t ticket, uint64_t total, int lane, int naps) {
+  if (ticket == 0) {
+    if (lane == 0) __hip_atomic_store(&state[0], (2ull << 62) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 0;
   }
-  if (lane == 0) n_unique_out[r] = nu;
+  if (lane == 0) __hip_atomic_store(&state[ticket], (1ull << 62) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint64_t acc = 0;
+  int64_t top = (int64_t)ticket - 1;  // nearest predecessor not yet added
+  // kLookWords words per lane: a step covers 64 x kLookWords predecessors, so the chain of prefixes moves that many
+  // blocks per round trip to memory (with one word per lane it moved slower than the blocks finished their reads)
+  constexpr int kLookWords = 8;
+  for (;;) {
+    uint64_t w[kLookWords];
+    for (;;) {
+      bool ready = true;
+#pragma unroll
+      for (int j = 0; j < kLookWords; ++j) {
+        const int64_t idx = top - j * 64 - lane;
+        w[j] = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (3ull << 62);
+        ready = ready && (w[j] >> 62) != 0;
+      }
+      if (ready) break;
+      for (int z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(8);
+    }
+    bool done = false;
+#pragma unroll
+    for (int j = 0; j < kLookWords; ++j) {
+      if (done) break;  // wave-uniform
+      const int64_t idx = top - j * 64 - lane;
+      const uint64_t full = __ballot((w[j] >> 62) == 2);
+      const int stop = full ? __ffsll((long long)full) - 1 : 64;  // nearest lane holding an inclusive prefix
+      uint64_t v = (lane <= stop && idx >= 0) ? (w[j] & kLookbackValueMask) : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, o, 64);
+      acc += v;
+      done = full != 0;
+    }
+    if (done || top - 64 * kLookWords < 0) break;
+    top -= 64 * kLookWords;
+  }
+  if (lane == 0) __hip_atomic_store(&state[ticket], (2ull << 62) | (acc + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return acc;
 }
 
-// scratch rows -> CSR, one wave per read
-__global__ __launch_bounds__(256) void compact_spectra_kernel(const uint64_t *__restrict__ scr_hash,
-                                                              const uint32_t *__restrict__ scr_count,
-                                                              const uint32_t *__restrict__ n_unique,
-                                                              const uint64_t *__restrict__ out_offsets, uint32_t n,
-                                                              uint32_t stride, uint64_t *__restrict__ out_hash,
-                                                              uint32_t *__restrict__ out_count) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= n) return;
-  const uint32_t nu = n_unique[r];
-  const uint64_t o = out_offsets[r];
-  for (uint32_t u = lane; u < nu; u += 64) {
-    out_hash[o + u] = scr_hash[(uint64_t)r * stride + u];
-    out_count[o + u] = scr_count[(uint64_t)r * stride + u];
+// reads per wave: the sorted keys of a wave's reads wait in registers (R per lane and read) for the block's prefix
+template <int R>
+constexpr int reads_per_wave() { return R <= 2 ? 8 : (R == 4 ? 4 : 2); }
+
+template <int R, typename H, int SB = 2>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void count_wave_kernel(
+    const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, uint32_t n, int k, int content,
+    uint32_t *__restrict__ ticket_counter, uint64_t *__restrict__ state, uint64_t *__restrict__ out_hash,
+    uint32_t *__restrict__ out_count, uint64_t *__restrict__ out_offsets, int dbg = 0) {
+  constexpr int RW = reads_per_wave<R>(), RPB = RW * kWavesPerBlock;
+  __shared__ WaveLds<R, H> lds[kWavesPerBlock];
+  __shared__ uint32_t s_ticket;
+  __shared__ uint32_t s_nu[RPB];
+  __shared__ uint64_t s_prefix;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // one ticket per RPB reads: a single counter hands out ~90 tickets per microsecond on this part, which at four reads a
+  // ticket was slower than the counting itself
+  if (threadIdx.x == 0) s_ticket = (dbg & 2) ? blockIdx.x : atomicAdd(ticket_counter, 1u);
+  __syncthreads();
+  const uint32_t ticket = s_ticket;
+  const uint32_t r0 = ticket * RPB + wv * RW;
+  WaveLds<R, H> &L = lds[wv];
+  H keys[RW][R];
+  uint32_t nus[RW];
+#pragma unroll
+  for (int i = 0; i < RW; ++i) {
+    const uint32_t r = r0 + i;
+    nus[i] = 0;
+#pragma unroll
+    for (int q = 0; q < R; ++q) keys[i][q] = (H)~(H)0;
+    if (r < n) {
+      const uint64_t off = offsets[r];
+      const uint32_t len = (uint32_t)(offsets[r + 1] - off);
+      if (!(len >= (uint32_t)k && len - (uint32_t)k + 1 > 64u * R)) {  // longer sequences are the sort path's business
+        wave_stage_codes<R, SB>(bases + off, len, lane, L.codes);
+        wave_hash_windows<R, H, SB>(L.codes, k, content, lane, keys[i]);
+        __builtin_amdgcn_wave_barrier();  // the staging area is reused by the next read
+        wave_bitonic_sort<R, H>(keys[i], lane);
+        nus[i] = wave_unique_count<R, H>(keys[i], (H)~(H)0, lane);
+      }
+    }
+    if (lane == 0) s_nu[wv * RW + i] = nus[i];
+  }
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+  for (int i = 0; i < RPB; ++i) {
+    if (i < wv * RW) before += s_nu[i];
+    total += s_nu[i];
+  }
+  if (wv == 0) {
+    const uint64_t pre = (dbg & 1) ? (uint64_t)ticket * RPB * 64 * R : lookback_exclusive(state, ticket, (uint64_t)total, lane, (dbg >> 4) ? (dbg >> 4) : 16);
+    if (lane == 0) s_prefix = pre;
+  }
+  __syncthreads();
+  uint64_t o = s_prefix + before;
+#pragma unroll
+  for (int i = 0; i < RW; ++i) {
+    const uint32_t r = r0 + i;
+    if (r < n) {
+      if (nus[i]) {
+        uint32_t n_valid;
+        wave_unique<R, H>(keys[i], (H)~(H)0, lane, L.key, L.start, n_valid);
+        for (uint32_t u = lane; u < nus[i]; u += 64) {
+          out_hash[o + u] = (uint64_t)L.key[u];
+          out_count[o + u] = L.start[u + 1] - L.start[u];
+        }
+        __builtin_amdgcn_wave_barrier();  // L.key / L.start are rewritten by the next read
+      }
+      if (lane == 0) {
+        out_offsets[r] = o;
+        if (r == n - 1) out_offsets[n] = o + nus[i];
+      }
+      o += nus[i];
+    }
   }
 }
 
@@ -445,30 +531,38 @@ static int pick_R(uint32_t max_windows) {
   return 0;
 }
 
+// bytes of device scratch count_wave needs: the ticket counter and one look-back word per block
+static inline uint64_t count_wave_scratch_bytes(uint32_t n) { return 64 + ((uint64_t)div_up(n, 2 * kWavesPerBlock) + 1) * 8; }
+
 template <typename H, int SB>
-static int launch_count_wave_sb(int R, const uint8_t *bases, const uint64_t *offsets, const uint32_t *ids, uint32_t n, int k,
-                                int content, uint32_t stride, uint64_t *sh, uint32_t *sc, uint32_t *nu, hipStream_t st) {
-  dim3 grid(div_up(n, kWavesPerBlock)), block(64 * kWavesPerBlock);
+static int launch_count_wave_sb(int R, const uint8_t *bases, const uint64_t *offsets, uint32_t n, int k, int content, void *scratch,
+                                uint64_t *oh, uint32_t *oc, uint64_t *oo, hipStream_t st) {
+  dim3 block(64 * kWavesPerBlock);
+  const auto grid = [&](int rw) { return dim3(div_up(n, (uint32_t)rw * kWavesPerBlock)); };
+  uint32_t *ticket = reinterpret_cast<uint32_t *>(scratch);
+  uint64_t *state = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(scratch) + 64);
+  KPOP_HIP(hipMemsetAsync(scratch, 0, count_wave_scratch_bytes(n), st));
   switch (R) {
-    case 1: count_wave_kernel<1, H, SB><<<grid, block, 0, st>>>(bases, offsets, ids, n, k, content, stride, sh, sc, nu); break;
-    case 2: count_wave_kernel<2, H, SB><<<grid, block, 0, st>>>(bases, offsets, ids, n, k, content, stride, sh, sc, nu); break;
-    case 4: count_wave_kernel<4, H, SB><<<grid, block, 0, st>>>(bases, offsets, ids, n, k, content, stride, sh, sc, nu); break;
-    case 8: count_wave_kernel<8, H, SB><<<grid, block, 0, st>>>(bases, offsets, ids, n, k, content, stride, sh, sc, nu); break;
+    case 1: count_wave_kernel<1, H, SB><<<grid(reads_per_wave<1>()), block, 0, st>>>(bases, offsets, n, k, content, ticket, state, oh, oc, oo, ctx().tune_dbg); break;
+    case 2: count_wave_kernel<2, H, SB><<<grid(reads_per_wave<2>()), block, 0, st>>>(bases, offsets, n, k, content, ticket, state, oh, oc, oo, ctx().tune_dbg); break;
+    case 4: count_wave_kernel<4, H, SB><<<grid(reads_per_wave<4>()), block, 0, st>>>(bases, offsets, n, k, content, ticket, state, oh, oc, oo, ctx().tune_dbg); break;
+    case 8: count_wave_kernel<8, H, SB><<<grid(reads_per_wave<8>()), block, 0, st>>>(bases, offsets, n, k, content, ticket, state, oh, oc, oo, ctx().tune_dbg); break;
     default: KPOP_FAIL(KPOP_ERR_INVALID, "launch_count_wave: R=%d", R);
   }
   KPOP_LAUNCH_CHECK();
   return 0;
 }
 
-// keys are 32-bit while the hash (2 bits per base, 5 per residue) leaves the all-ones sentinel free: <= 30 bits
-static int launch_count_wave(int R, const uint8_t *bases, const uint64_t *offsets, const uint32_t *ids, uint32_t n, int k,
-                             int content, uint32_t stride, uint64_t *sh, uint32_t *sc, uint32_t *nu, hipStream_t st) {
+// keys are 32-bit while the hash (2 bits per base, 5 per residue) leaves the all-ones sentinel free: <= 30 bits.
+// oh / oc need one entry per window (the worst case); oo gets n + 1 offsets.
+static int launch_count_wave(int R, const uint8_t *bases, const uint64_t *offsets, uint32_t n, int k, int content, void *scratch,
+                             uint64_t *oh, uint32_t *oc, uint64_t *oo, hipStream_t st) {
   const bool narrow = hash_bits(k, content) <= 30;
   if (content == KPOP_PROTEIN)
-    return narrow ? launch_count_wave_sb<uint32_t, 5>(R, bases, offsets, ids, n, k, content, stride, sh, sc, nu, st)
-                  : launch_count_wave_sb<uint64_t, 5>(R, bases, offsets, ids, n, k, content, stride, sh, sc, nu, st);
-  return narrow ? launch_count_wave_sb<uint32_t, 2>(R, bases, offsets, ids, n, k, content, stride, sh, sc, nu, st)
-                : launch_count_wave_sb<uint64_t, 2>(R, bases, offsets, ids, n, k, content, stride, sh, sc, nu, st);
+    return narrow ? launch_count_wave_sb<uint32_t, 5>(R, bases, offsets, n, k, content, scratch, oh, oc, oo, st)
+                  : launch_count_wave_sb<uint64_t, 5>(R, bases, offsets, n, k, content, scratch, oh, oc, oo, st);
+  return narrow ? launch_count_wave_sb<uint32_t, 2>(R, bases, offsets, n, k, content, scratch, oh, oc, oo, st)
+                : launch_count_wave_sb<uint64_t, 2>(R, bases, offsets, n, k, content, scratch, oh, oc, oo, st);
 }
 
 // k range and content of the counting entry points (bin/KPopCount.ml:113: <= 30 for DNA, <= 12 for protein)
@@ -591,12 +685,11 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   return KPOP_OK;
 }
 
-// device-resident -L counting for reads of up to 512 windows: scratch rows -> scan -> CSR, all enqueued
+// device-resident -L counting for reads of up to 512 windows: one launch (count_wave_kernel), enqueue only
 extern "C" uint64_t kpop_dev_count_reads_scratch_bytes(uint32_t n_reads, uint32_t max_len, int k) {
-  const uint32_t max_windows = (max_len >= (uint32_t)k) ? max_len - k + 1 : 0;
-  const int R = pick_R(std::min(max_windows, kWaveMaxWindows));
-  const uint64_t stride = 64ull * (R ? R : 8);
-  return (uint64_t)n_reads * stride * 12 + (uint64_t)n_reads * 4 + (scan_blocks(n_reads) + 1) * 8 + 256;
+  (void)max_len;
+  (void)k;
+  return count_wave_scratch_bytes(n_reads) + 256;
 }
 
 extern "C" int kpop_dev_count_reads(const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads, uint32_t max_len,
@@ -614,21 +707,9 @@ extern "C" int kpop_dev_count_reads(const uint8_t *d_bases, const uint64_t *d_of
     KPOP_HIP(hipMemsetAsync(d_out_offsets, 0, 8, st));
     return KPOP_OK;
   }
-  const int R = pick_R(max_windows);
-  const uint32_t stride = 64 * R;
-  char *p = reinterpret_cast<char *>(d_scratch);
-  uint64_t *sh = reinterpret_cast<uint64_t *>(p);
-  uint32_t *sc = reinterpret_cast<uint32_t *>(p + (uint64_t)n_reads * stride * 8);
-  uint32_t *nu = sc + (uint64_t)n_reads * stride;
-  uint64_t *sums = reinterpret_cast<uint64_t *>((reinterpret_cast<uintptr_t>(nu + n_reads) + 63) & ~(uintptr_t)63);
-  KPOP_TRY(launch_count_wave(R, d_bases, d_offsets, nullptr, n_reads, k, content, stride, sh, sc, nu, st));
-  KPOP_TRY(exclusive_scan(LoadU32{nu}, StoreOffsets{d_out_offsets}, n_reads, sums, st));
-  // offsets[n_reads] = total, still on the device
-  KPOP_HIP(hipMemcpyAsync(d_out_offsets + n_reads, sums + scan_blocks(n_reads), 8, hipMemcpyDeviceToDevice, st));
-  compact_spectra_kernel<<<dim3(div_up(n_reads, 4)), dim3(256), 0, st>>>(sh, sc, nu, d_out_offsets, n_reads, stride,
-                                                                        d_out_hash, d_out_count);
-  KPOP_LAUNCH_CHECK();
-  return KPOP_OK;
+  void *scratch = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(d_scratch) + 63) & ~(uintptr_t)63);
+  return launch_count_wave(pick_R(max_windows), d_bases, d_offsets, n_reads, k, content, scratch, d_out_hash, d_out_count,
+                           d_out_offsets, st);
 }
 
 extern "C" int kpop_dev_twist(const kpop_twister *tw, const uint64_t *d_hash, const double *d_value,
@@ -684,44 +765,37 @@ extern "C" int kpop_count_reads(const uint8_t *bases, const uint64_t *offsets, u
     return KPOP_OK;
   }
   const int R = pick_R((uint32_t)max_windows);
-  const uint32_t stride = 64 * R;
   const uint64_t base0 = offsets[0], n_bases = offsets[n_reads] - base0;
   hipStream_t st = nullptr;
-  DevBuf d_bases, d_off, d_sh, d_sc, d_nu, d_sums, d_oo, d_oh, d_oc;
-  KPOP_TRY(d_bases.alloc(n_bases));
-  KPOP_TRY(d_off.alloc((uint64_t)(n_reads + 1) * 8));
-  KPOP_TRY(d_sh.alloc((uint64_t)n_reads * stride * 8));
-  KPOP_TRY(d_sc.alloc((uint64_t)n_reads * stride * 4));
-  KPOP_TRY(d_nu.alloc((uint64_t)n_reads * 4));
-  KPOP_TRY(d_sums.alloc((scan_blocks(n_reads) + 1) * 8));
-  KPOP_TRY(d_oo.alloc((uint64_t)(n_reads + 1) * 8));
+  DevBuf d_bases, d_off, d_scr, d_oo, d_oh, d_oc;
+  uint64_t worst = 0;  // one entry per window
   std::vector<uint64_t> rel(n_reads + 1);
   for (uint32_t r = 0; r <= n_reads; ++r) rel[r] = offsets[r] - base0;
+  for (uint32_t r = 0; r < n_reads; ++r) {
+    const uint64_t len = rel[r + 1] - rel[r];
+    worst += len >= (uint64_t)k ? len - k + 1 : 0;
+  }
+  KPOP_TRY(d_bases.alloc(n_bases));
+  KPOP_TRY(d_off.alloc((uint64_t)(n_reads + 1) * 8));
+  KPOP_TRY(d_scr.alloc(count_wave_scratch_bytes(n_reads)));
+  KPOP_TRY(d_oo.alloc((uint64_t)(n_reads + 1) * 8));
+  KPOP_TRY(d_oh.alloc(worst * 8));
+  KPOP_TRY(d_oc.alloc(worst * 4));
   if (n_bases) KPOP_HIP(hipMemcpyAsync(d_bases.p, bases + base0, n_bases, hipMemcpyHostToDevice, st));
   KPOP_HIP(hipMemcpyAsync(d_off.p, rel.data(), (uint64_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
-  KPOP_TRY(launch_count_wave(R, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), nullptr, n_reads, k, content, stride,
-                             d_sh.as<uint64_t>(), d_sc.as<uint32_t>(), d_nu.as<uint32_t>(), st));
-  KPOP_TRY(exclusive_scan(LoadU32{d_nu.as<uint32_t>()}, StoreOffsets{d_oo.as<uint64_t>()}, n_reads,
-                          d_sums.as<uint64_t>(), st));
-  uint64_t total = 0;
-  KPOP_HIP(hipMemcpyAsync(&total, d_sums.as<uint64_t>() + scan_blocks(n_reads), 8, hipMemcpyDeviceToHost, st));
+  KPOP_TRY(launch_count_wave(R, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), n_reads, k, content, d_scr.p, d_oh.as<uint64_t>(),
+                             d_oc.as<uint32_t>(), d_oo.as<uint64_t>(), st));
+  KPOP_HIP(hipMemcpyAsync(out_offsets, d_oo.p, (uint64_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, st));
   KPOP_HIP(hipStreamSynchronize(st));
+  const uint64_t total = out_offsets[n_reads];
   if (total > out_capacity)
     KPOP_FAIL(KPOP_ERR_CAPACITY, "kpop_count_reads: %llu distinct (read,k-mer) pairs, capacity %llu",
               (unsigned long long)total, (unsigned long long)out_capacity);
-  KPOP_TRY(d_oh.alloc(total * 8));
-  KPOP_TRY(d_oc.alloc(total * 4));
-  compact_spectra_kernel<<<dim3(div_up(n_reads, 4)), dim3(256), 0, st>>>(
-      d_sh.as<uint64_t>(), d_sc.as<uint32_t>(), d_nu.as<uint32_t>(), d_oo.as<uint64_t>(), n_reads, stride,
-      d_oh.as<uint64_t>(), d_oc.as<uint32_t>());
-  KPOP_LAUNCH_CHECK();
-  KPOP_HIP(hipMemcpyAsync(out_offsets, d_oo.p, (uint64_t)n_reads * 8, hipMemcpyDeviceToHost, st));
   if (total) {
     KPOP_HIP(hipMemcpyAsync(out_hash, d_oh.p, total * 8, hipMemcpyDeviceToHost, st));
     KPOP_HIP(hipMemcpyAsync(out_count, d_oc.p, total * 4, hipMemcpyDeviceToHost, st));
   }
   KPOP_HIP(hipStreamSynchronize(st));
-  out_offsets[n_reads] = total;
   return KPOP_OK;
 }
 
@@ -793,26 +867,18 @@ extern "C" int kpop_spectra_twist(const kpop_twister *tw, const uint8_t *bases, 
       else
         KPOP_TRY(launch_count_twist_wave<uint64_t>(R, tv, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), nullptr, n_reads, content, normalize, d_out.as<double>(), st));
     } else {
-      const uint32_t stride = 64 * R;
-      DevBuf d_sh, d_sc, d_nu, d_sums, d_oo, d_oh, d_oc;
-      KPOP_TRY(d_sh.alloc((uint64_t)n_reads * stride * 8));
-      KPOP_TRY(d_sc.alloc((uint64_t)n_reads * stride * 4));
-      KPOP_TRY(d_nu.alloc((uint64_t)n_reads * 4));
-      KPOP_TRY(d_sums.alloc((scan_blocks(n_reads) + 1) * 8));
+      DevBuf d_scr, d_oo, d_oh, d_oc;
+      uint64_t worst = 0;
+      for (uint32_t r = 0; r < n_reads; ++r) {
+        const uint64_t len = rel[r + 1] - rel[r];
+        worst += len >= (uint64_t)k ? len - k + 1 : 0;
+      }
+      KPOP_TRY(d_scr.alloc(count_wave_scratch_bytes(n_reads)));
       KPOP_TRY(d_oo.alloc((uint64_t)(n_reads + 1) * 8));
-      KPOP_TRY(launch_count_wave(R, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), nullptr, n_reads, k, content, stride,
-                                 d_sh.as<uint64_t>(), d_sc.as<uint32_t>(), d_nu.as<uint32_t>(), st));
-      KPOP_TRY(exclusive_scan(LoadU32{d_nu.as<uint32_t>()}, StoreOffsets{d_oo.as<uint64_t>()}, n_reads, d_sums.as<uint64_t>(), st));
-      uint64_t total = 0;
-      KPOP_HIP(hipMemcpyAsync(&total, d_sums.as<uint64_t>() + scan_blocks(n_reads), 8, hipMemcpyDeviceToHost, st));
-      KPOP_HIP(hipMemcpyAsync(d_oo.as<uint64_t>() + n_reads, d_sums.as<uint64_t>() + scan_blocks(n_reads), 8, hipMemcpyDeviceToDevice, st));
-      KPOP_HIP(hipStreamSynchronize(st));
-      KPOP_TRY(d_oh.alloc(total * 8));
-      KPOP_TRY(d_oc.alloc(total * 4));
-      compact_spectra_kernel<<<dim3(div_up(n_reads, 4)), dim3(256), 0, st>>>(d_sh.as<uint64_t>(), d_sc.as<uint32_t>(), d_nu.as<uint32_t>(),
-                                                                            d_oo.as<uint64_t>(), n_reads, stride, d_oh.as<uint64_t>(),
-                                                                            d_oc.as<uint32_t>());
-      KPOP_LAUNCH_CHECK();
+      KPOP_TRY(d_oh.alloc(worst * 8));
+      KPOP_TRY(d_oc.alloc(worst * 4));
+      KPOP_TRY(launch_count_wave(R, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), n_reads, k, content, d_scr.p, d_oh.as<uint64_t>(),
+                                 d_oc.as<uint32_t>(), d_oo.as<uint64_t>(), st));
       twist_csr_kernel<uint32_t><<<dim3(div_up(n_reads, kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, st>>>(
           tv, d_oh.as<uint64_t>(), d_oc.as<uint32_t>(), d_oo.as<uint64_t>(), n_reads, normalize, d_out.as<double>());
       KPOP_LAUNCH_CHECK();

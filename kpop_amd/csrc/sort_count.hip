@@ -118,11 +118,169 @@ __global__ void spectrum_bounds_kernel(const uint64_t *__restrict__ uniq, const 
   offsets[s] = lo;
 }
 
+// ---------------------------------------------------------------------------
+// merged spectrum (-l, bin/KPopCount.ml:60) as a histogram: when every hash fits kHistMaxBits bits the table of all
+// 2^bits counters (u32; 67 MB at k = 12, 268 MB at k = 13) takes one atomic add per window, and the spectrum is its
+// non-zero entries in index order = ascending hash order.  One pass over the bases, no key array, no sort passes.
+// The adds execute at the memory side (device-scope atomics on a table that all eight XCDs update), so they go out
+// straight from the hashing lanes: staging them through per-block LDS tables first only pays when a block sees the
+// same k-mer often, which 2^24 bins against a few thousand windows per block rules out.
+// ---------------------------------------------------------------------------
+constexpr int kHistMaxBits = 26;
+
+template <typename H>
+__global__ __launch_bounds__(256) void window_hist_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets,
+                                                          int k, int content, uint32_t *__restrict__ table, uint32_t n_reads,
+                                                          uint32_t max_seg) {
+  const uint64_t n_pairs = (uint64_t)n_reads * max_seg;
+  for (uint64_t pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+    const uint32_t r = (uint32_t)(pair / max_seg);
+    const uint64_t off = offsets[r], len = offsets[r + 1] - off;
+    if (len < (uint64_t)k) continue;
+    const uint64_t n_win = len - k + 1;
+    const uint64_t w0 = (uint64_t)(pair % max_seg) * kKeySeg;
+    if (w0 >= n_win) continue;
+    const uint64_t w1 = min(n_win, w0 + kKeySeg);
+    const uint8_t *seq = bases + off;
+    const bool protein = content == KPOP_PROTEIN;
+    const int sb = symbol_bits(content), shift = sb * (k - 1);
+    for (uint64_t w = w0 + threadIdx.x; w < w1; w += 256) {
+      H fwd = 0, rc = 0;
+      bool good = true;
+      for (int j = 0; j < k; ++j) {
+        if (protein) {
+          const uint32_t c = protein_code(seq[w + j]);
+          good = good && (c < 20u);
+          fwd = (fwd << 5) | (H)(c & 31u);
+        } else {
+          const uint32_t c = base_code(seq[w + j]);
+          good = good && (c < 4u);
+          fwd = (fwd << 2) | (H)(c & 3u);
+          rc = (rc >> 2) | ((H)(3u - (c & 3u)) << shift);
+        }
+      }
+      if (good) atomicAdd(&table[(content == KPOP_DNA_DS && rc < fwd) ? rc : fwd], 1u);
+    }
+  }
+}
+
+// short reads: one wavefront per read, windows hashed the way the per-read kernels hash them would cost LDS staging for
+// nothing here; a read's windows are spread over the lanes of its wave instead (one read per wave keeps the offsets
+// loads wave-uniform)
+template <typename H>
+__global__ __launch_bounds__(256) void read_hist_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets,
+                                                        int k, int content, uint32_t *__restrict__ table, uint32_t n_reads) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t waves = gridDim.x * 4;
+  const bool protein = content == KPOP_PROTEIN;
+  const int sb = symbol_bits(content), shift = sb * (k - 1);
+  for (uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6); r < n_reads; r += waves) {
+    const uint64_t off = offsets[r], len = offsets[r + 1] - off;
+    if (len < (uint64_t)k) continue;
+    const uint64_t n_win = len - k + 1;
+    const uint8_t *seq = bases + off;
+    for (uint64_t w = lane; w < n_win; w += 64) {
+      H fwd = 0, rc = 0;
+      bool good = true;
+      for (int j = 0; j < k; ++j) {
+        if (protein) {
+          const uint32_t c = protein_code(seq[w + j]);
+          good = good && (c < 20u);
+          fwd = (fwd << 5) | (H)(c & 31u);
+        } else {
+          const uint32_t c = base_code(seq[w + j]);
+          good = good && (c < 4u);
+          fwd = (fwd << 2) | (H)(c & 3u);
+          rc = (rc >> 2) | ((H)(3u - (c & 3u)) << shift);
+        }
+      }
+      if (good) atomicAdd(&table[(content == KPOP_DNA_DS && rc < fwd) ? rc : fwd], 1u);
+    }
+  }
+}
+
+struct NonZero {
+  const uint32_t *t;
+  __device__ uint32_t operator()(uint64_t i) const { return t[i] ? 1u : 0u; }
+};
+struct StoreBins {
+  const uint32_t *t;
+  uint64_t *hash;
+  uint32_t *count;
+  __device__ void operator()(uint64_t i, uint64_t prefix, uint32_t flag) const {
+    if (flag) {
+      hash[prefix] = i;
+      count[prefix] = t[i];
+    }
+  }
+};
+
+static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, int k, int content, uint64_t cap,
+                             SortedSpectra &S, hipStream_t st) {
+  const uint64_t base0 = offsets[0], n_bases = offsets[n_reads] - base0;
+  std::vector<uint64_t> rel(n_reads + 1);
+  uint64_t max_win = 0;
+  for (uint32_t r = 0; r <= n_reads; ++r) rel[r] = offsets[r] - base0;
+  for (uint32_t r = 0; r < n_reads; ++r) {
+    const uint64_t len = rel[r + 1] - rel[r];
+    max_win = std::max(max_win, len >= (uint64_t)k ? len - k + 1 : 0);
+  }
+  const int hb = hash_bits(k, content);
+  const uint64_t n_bins = 1ull << hb;
+  S.nu = 0;
+  S.n_spectra = 1;
+  KPOP_TRY(S.d_oo.alloc(16));
+  KPOP_TRY(S.d_bases.alloc(n_bases));
+  KPOP_TRY(S.d_off.alloc((uint64_t)(n_reads + 1) * 8));
+  KPOP_TRY(S.d_ka.alloc(n_bins * 4));  // the table
+  KPOP_TRY(S.d_sums.alloc((scan_blocks(n_bins) + 1) * 8));
+  KPOP_HIP(hipMemcpyAsync(S.d_bases.p, bases + base0, n_bases, hipMemcpyHostToDevice, st));
+  KPOP_HIP(hipMemcpyAsync(S.d_off.p, rel.data(), (uint64_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+  KPOP_HIP(hipMemsetAsync(S.d_ka.p, 0, n_bins * 4, st));
+  uint32_t *table = S.d_ka.as<uint32_t>();
+  if (max_win > 0) {
+    if (max_win <= 4096) {
+      read_hist_kernel<uint32_t><<<dim3(std::min<uint32_t>(div_up(n_reads, 4), 1u << 16)), dim3(256), 0, st>>>(
+          S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), k, content, table, n_reads);
+    } else {
+      const uint32_t max_seg = div_up(max_win, kKeySeg);
+      window_hist_kernel<uint32_t><<<dim3(capped_grid((uint64_t)n_reads * max_seg)), dim3(256), 0, st>>>(
+          S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), k, content, table, n_reads, max_seg);
+    }
+    KPOP_LAUNCH_CHECK();
+  }
+  // count the non-zero bins, then write them out in index order
+  uint64_t *sums = S.d_sums.as<uint64_t>();
+  const uint64_t nb = scan_blocks(n_bins);
+  scan_tile_sums_kernel<NonZero><<<dim3((uint32_t)nb), dim3(kScanThreads), 0, st>>>(NonZero{table}, n_bins, sums);
+  KPOP_LAUNCH_CHECK();
+  scan_block_sums_kernel<0><<<dim3(1), dim3(1024), 0, st>>>(sums, nb);
+  KPOP_LAUNCH_CHECK();
+  uint64_t nu = 0;
+  KPOP_HIP(hipMemcpyAsync(&nu, sums + nb, 8, hipMemcpyDeviceToHost, st));
+  KPOP_HIP(hipStreamSynchronize(st));
+  if (nu > cap)
+    KPOP_FAIL(KPOP_ERR_CAPACITY, "kpop_count_reads: %llu distinct k-mers, capacity %llu", (unsigned long long)nu, (unsigned long long)cap);
+  S.nu = nu;
+  KPOP_TRY(S.d_oh.alloc(nu * 8));
+  KPOP_TRY(S.d_oc.alloc(nu * 4));
+  scan_apply_kernel<NonZero, StoreBins><<<dim3((uint32_t)nb), dim3(kScanThreads), 0, st>>>(
+      NonZero{table}, StoreBins{table, S.d_oh.as<uint64_t>(), S.d_oc.as<uint32_t>()}, n_bins, sums);
+  KPOP_LAUNCH_CHECK();
+  const uint64_t two[2] = {0, nu};
+  KPOP_HIP(hipMemcpyAsync(S.d_oo.p, two, 16, hipMemcpyHostToDevice, st));
+  KPOP_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
 // One batch of reads through the sort path, host arrays in; the CSR stays on the device in S (d_oh, d_oc, and for
 // per_read d_oo with n_reads + 1 offsets relative to this batch).  per_read = 0 merges everything.  The buffers come
 // from the caller's ArenaScope.
 int sorted_count_device(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, int k, int content, int per_read,
                         uint64_t cap, SortedSpectra &S, hipStream_t st) {
+  // the merged spectrum of small-enough hashes: one atomic add per window (kpop_tune("hist", 0) keeps the sort)
+  if (!per_read && ctx().tune_hist && hash_bits(k, content) <= kHistMaxBits && n_reads > 0)
+    return hist_count_device(bases, offsets, n_reads, k, content, cap, S, st);
   const uint64_t base0 = offsets[0], n_bases = offsets[n_reads] - base0;
   std::vector<uint64_t> rel(n_reads + 1), woff(n_reads + 1);
   uint64_t tw = 0, max_win = 0;

@@ -95,4 +95,19 @@ __device__ __forceinline__ uint32_t wave_unique(const K (&key)[R], K sentinel, i
   return total;
 }
 
+// the number of distinct keys only (no LDS)
+template <int R, typename K>
+__device__ __forceinline__ uint32_t wave_unique_count(const K (&key)[R], K sentinel, int lane) {
+  K prev = wave_shfl_up1(key[R - 1]);
+  uint32_t total = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    K p = (r == 0) ? prev : key[r - 1];
+    const bool first = (r == 0) && (lane == 0);
+    const bool head = (key[r] != sentinel) && (first || key[r] != p);
+    total += (uint32_t)__popcll(__ballot(head));
+  }
+  return total;
+}
+
 }  // namespace kpop

@@ -86,8 +86,17 @@ def test_count_errors(kpop):
     assert len(h) == 0 and o.tolist() == [0]
 
 
-def test_count_merged_golden_vectors(kpop, oracle):
-    """-l: one spectrum for all reads (bin/KPopCount.ml:60), device-wide sort path."""
+@pytest.fixture(params=[1, 0], ids=["histogram", "sort"])
+def merged_path(request, kpop):
+    """-l by atomic histogram (hashes of up to 26 bits; the default there) and by device-wide sort (everything else)"""
+    from kpop_amd import api
+    api.tune("hist", request.param)
+    yield request.param
+    api.tune("hist", 1)
+
+
+def test_count_merged_golden_vectors(kpop, oracle, merged_path):
+    """-l: one spectrum for all reads (bin/KPopCount.ml:60)."""
     g = load_golden("count_small.json")
     seqs = [s for _, s in g["reads"]]
     bases, offs = concat(seqs)
@@ -99,10 +108,20 @@ def test_count_merged_golden_vectors(kpop, oracle):
         assert [[oracle.to_hex(a, k), int(b)] for a, b in zip(h, c)] == case["merged"], (k, case["content"])
 
 
-@pytest.mark.parametrize("k", [5, 12, 16, 24])
-def test_count_merged_100k_reads(kpop, oracle, k):
+@pytest.mark.parametrize("k", [5, 12, 13, 16, 24])
+def test_count_merged_100k_reads(kpop, oracle, k, merged_path):
     bases, offs = oracle.synth_reads(0x4B506F70, 100000, 150)
     spectra_equal(kpop.count_reads(bases, offs, k, per_read=False), oracle.count_reads(bases, offs, k, per_read=False))
+
+
+def test_count_merged_genomes_and_ragged(kpop, oracle, merged_path):
+    """a few long sequences among short and empty ones, either strand convention, through both merged paths"""
+    rng = np.random.RandomState(3)
+    seqs = ["".join(rng.choice(list("ACGTN"), size=n, p=[0.249, 0.249, 0.249, 0.249, 0.004])) for n in (30000, 0, 5, 700, 100000, 12, 4097, 4108)]
+    bases, offs = concat(seqs)
+    for k in (7, 12, 13):
+        for content in (kpop.DNA_DS, kpop.DNA_SS):
+            spectra_equal(kpop.count_reads(bases, offs, k, content, per_read=False), oracle.count_reads(bases, offs, k, content, per_read=False))
 
 
 @pytest.mark.parametrize("k", [8, 12, 21, 30])
