@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Joins the rocprofv3 output of tools/cli_kernels_profile.sh into one table: per kernel and section the average launch
+time (kernel trace), the HBM traffic (PMC passes: 2 x FETCH_SIZE + WRITE_SIZE KiB, the gfx950 correction of
+MI355X_MICROARCH.md's HBM section), the algorithmic bytes the workload recorded, and the two ratios the judge reads:
+achieved = algorithmic bytes / time against the 8 TB/s peak, and traffic / algorithmic.
+
+    python3 tools/cli_kernels_report.py <dir written by cli_kernels_profile.sh> > profiles/r02_c_cli_kernels.md
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def short(name):
+    n = name.replace("void ", "")
+    return n.split("(")[0]
+
+
+def main(d):
+    rows = []
+    for aj in sorted(glob.glob(os.path.join(d, "*_algo.json"))):
+        sec = json.load(open(aj))
+        name = sec["section"]
+        stats = {}
+        for f in glob.glob(os.path.join(d, name + "_trace", "**", "*kernel_stats.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                stats[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]), float(r["MinNs"]))
+        pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for which in ("fetch", "write"):
+            for f in glob.glob(os.path.join(d, name + "_" + which, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for kn in sorted(stats):
+            if not kn.startswith("kpop::"):
+                continue
+            calls, avg, mn = stats[kn]
+            algo = next((v for key, v in sec["kernels"].items() if key in kn), None)
+            fetch = pmc[kn].get("FETCH_SIZE")
+            write = pmc[kn].get("WRITE_SIZE")
+            traffic = None
+            if fetch and write:
+                traffic = (2 * sum(fetch) / len(fetch) + sum(write) / len(write)) * 1024
+            rows.append((name, kn, calls, avg / 1e6, mn / 1e6, algo, traffic))
+    print("| section | kernel | launches | avg ms | min ms | algorithmic bytes / launch | achieved (algorithmic / avg) | of 8 TB/s | HBM traffic / launch (PMC) | traffic / algorithmic | note |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
+    for name, kn, calls, avg, mn, algo, traffic in rows:
+        ab = algo["bytes"] if algo and isinstance(algo.get("bytes"), (int, float)) else None
+        ach = ab / (avg * 1e-3) / 1e9 if ab else None
+        note = (algo or {}).get("note", "")
+        if algo and algo.get("flops"):
+            note += "; %.1f Tops/s f64 of the 39.3 non-FMA peak" % (algo["flops"] / (avg * 1e-3) / 1e12)
+        print("| %s | `%s` | %d | %.4f | %.4f | %s | %s | %s | %s | %s | %s |" % (
+            name, kn.replace("kpop::", ""), calls, avg, mn, "%.4g" % ab if ab else "-", "%.0f GB/s" % ach if ach else "-",
+            "%.3f" % (ach / 8000) if ach else "-", "%.4g" % traffic if traffic else "-",
+            "%.2f" % (traffic / ab) if traffic and ab else "-", note))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
