@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "common.h"
+#include "wave_sort.h"
 
 namespace kpop {
 
@@ -339,6 +340,249 @@ __global__ __launch_bounds__(256) void distance_summary_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// summary against a SMALL first operand (the classifier's case, README.md:656: a few dozen class vectors): one
+// WAVEFRONT per m2 row instead of one block.  The first operand sits in LDS, transposed ([dim][row], so the lanes of a
+// wave -- one m1 row each -- read consecutive words), and a block walks over m2 rows grid-stride, four at a time.  The
+// (distance, column) pairs are sorted in registers (wave_bitonic_sort_pairs), and the walk of the multimap
+// (lib/Matrix.ml:640-655) and the squared deviations (:657-670) stay the reference's sequential chains, run by one lane
+// over at most 64 R values: same operations in the same order as distance_summary_kernel, so the same bits.
+// Needs r1 <= 64 R <= 512 and (PRE or r1 x n_dims doubles within kWaveSummaryLds).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kWaveSummaryLds = 48u << 10;
+constexpr int kSummaryWaves = 16;  // per block: they share the LDS copy of the first operand, and 2 blocks fill a CU's 32 wave slots
+
+__device__ __forceinline__ uint64_t dist_key(double x) {  // order-preserving map of an f64 to u64
+  const uint64_t b = (uint64_t)__double_as_longlong(x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_dist(uint64_t k) {
+  const uint64_t b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+
+template <int KIND, bool PRE, int R>
+__global__ __launch_bounds__(64 * kSummaryWaves) void distance_summary_wave_kernel(
+    const double *__restrict__ a, uint32_t r1, const double *__restrict__ b, uint32_t r2, uint32_t n_dims,
+    const double *__restrict__ metric, double p, uint32_t req_len, uint32_t max_neighbours,
+    double *__restrict__ out_stats, uint32_t *__restrict__ out_n, uint32_t *__restrict__ out_idx,
+    double *__restrict__ out_dist, double *__restrict__ out_z) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int N = 64 * R;
+  // per wave: dist[N] (column order), kd[N] (sorted), ki[N], brow[n_dims]; then the transposed first operand
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t per_wave = (uint32_t)N * 20 + (PRE ? 0u : n_dims * 8);
+  unsigned char *mine = smem + (size_t)wv * ((per_wave + 15) & ~15u);
+  double *dist = reinterpret_cast<double *>(mine);
+  double *kd = dist + N;
+  uint32_t *ki = reinterpret_cast<uint32_t *>(kd + N);
+  double *s_b = reinterpret_cast<double *>(ki + N);
+  const uint32_t n_waves = blockDim.x >> 6, n_threads = blockDim.x;
+  double *As = reinterpret_cast<double *>(smem + (size_t)n_waves * ((per_wave + 15) & ~15u));  // [n_dims][r1] + metric[n_dims]
+  double *s_metric = As + (size_t)n_dims * r1;
+  if (!PRE) {
+    for (uint32_t e = threadIdx.x; e < r1 * n_dims; e += n_threads) {
+      const uint32_t i = e / n_dims, c = e % n_dims;  // coalesced read of row-major m1
+      As[(size_t)c * r1 + i] = a[e];
+    }
+    for (uint32_t c = threadIdx.x; c < n_dims; c += n_threads) s_metric[c] = metric[c];
+  }
+  __syncthreads();
+  const double inf = __longlong_as_double(0x7FF0000000000000ll);
+  for (uint32_t j = blockIdx.x * n_waves + wv; j < r2; j += gridDim.x * n_waves) {
+    // distances of row j to every m1 row (lib/Matrix.ml:744-749): lane owns columns lane, lane + 64, ...
+    double dv[R];
+    if (PRE) {
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        const uint32_t i = (uint32_t)lane + 64u * q;
+        dv[q] = i < r1 ? a[(uint64_t)j * r1 + i] : inf;
+      }
+    } else {
+      for (uint32_t c = lane; c < n_dims; c += 64) s_b[c] = b[(uint64_t)j * n_dims + c];
+      __builtin_amdgcn_wave_barrier();
+      double acc[R];
+#pragma unroll
+      for (int q = 0; q < R; ++q) acc[q] = 0.0;
+      for (uint32_t c = 0; c < n_dims; ++c) {
+        const double bc = s_b[c], mc = s_metric[c];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          const uint32_t i = (uint32_t)lane + 64u * q;
+          const double av = i < r1 ? As[(size_t)c * r1 + i] : 0.0;
+          const double diff = __dsub_rn(av, bc);
+          acc[q] = __dadd_rn(acc[q], component<KIND>(diff, mc, p));
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < R; ++q) dv[q] = ((uint32_t)lane + 64u * q) < r1 ? scale_distance<KIND>(acc[q], p) : inf;
+    }
+    uint64_t key[R];
+    uint32_t val[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const uint32_t i = (uint32_t)lane + 64u * q;
+      if (i < r1) dist[i] = dv[q];
+      key[q] = i < r1 ? dist_key(dv[q]) : ~0ull;  // padding sorts last (a NaN distance would too; none arises from finite rows)
+      val[q] = i < r1 ? i : 0xFFFFFFFFu;
+    }
+    wave_bitonic_sort_pairs<R, uint64_t>(key, val, lane);
+#pragma unroll
+    for (int q = 0; q < R; ++q) {  // sorted position of (lane, q) is lane * R + q
+      kd[lane * R + q] = key_dist(key[q]);
+      ki[lane * R + q] = val[q];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // The walk of the multimap (lib/Matrix.ml:640-655) and the squared deviations (:657-670) are sequential chains of
+    // f64 additions in the reference, and stay so here -- but out of registers: the sorted values come back striped
+    // (position q * 64 + lane), each lane works out the term of its position, and the chain collects the terms with
+    // v_readlane, a few cycles each, instead of one LDS round trip per element.
+    double sv[R];     // sorted distance at position q * 64 + lane (inf beyond r1)
+    uint64_t hm[R];   // lanes of row q that start a group of equal distances
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const uint32_t pos = (uint32_t)q * 64u + lane;
+      sv[q] = pos < r1 ? kd[pos] : inf;
+      const double prev = pos > 0 && pos < r1 ? kd[pos - 1] : 0.0;
+      hm[q] = __ballot(pos < r1 && (pos == 0 || prev != sv[q]));
+    }
+    // position of the next group start after this one (r1 if none): the length of a group is that minus its start
+    double term[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      uint32_t next = r1;
+      const uint64_t above = lane == 63 ? 0ull : (hm[q] >> (lane + 1));
+      if (above) next = (uint32_t)q * 64u + lane + 1u + (uint32_t)__ffsll((long long)above) - 1u;
+      else {
+#pragma unroll
+        for (int q2 = R - 1; q2 > q; --q2)
+          if (hm[q2]) next = (uint32_t)q2 * 64u + (uint32_t)__ffsll((long long)hm[q2]) - 1u;
+      }
+      const uint32_t pos = (uint32_t)q * 64u + lane;
+      const bool head = (hm[q] >> lane) & 1ull;
+      term[q] = head ? __dmul_rn((double)(next - pos), sv[q]) : 0.0;  // set_len *. dist (:643)
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int lim = (int)min(64u, r1 > (uint32_t)q * 64u ? r1 - (uint32_t)q * 64u : 0u);
+      for (int i = 0; i < lim; ++i) {
+        const double t = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(term[q]) >> 32), i) << 32) |
+                                              (unsigned int)__builtin_amdgcn_readlane((int)__double_as_longlong(term[q]), i));
+        acc = __dadd_rn(acc, t);  // a position that starts no group adds +0.0: exact, the sum is never -0.0
+      }
+    }
+    const double mean = (r1 > 0) ? acc / (double)r1 : 0.0;
+    // upper median = the value at sorted position r1 / 2 (:645-647 picks the group that holds it)
+    double median = 0.0;
+    if (r1 > 0) {
+      const uint32_t mp = r1 / 2;
+#pragma unroll
+      for (int q = 0; q < R; ++q)
+        if ((mp >> 6) == (uint32_t)q)
+          median = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(sv[q]) >> 32), (int)(mp & 63u)) << 32) |
+                                        (unsigned int)__builtin_amdgcn_readlane((int)__double_as_longlong(sv[q]), (int)(mp & 63u)));
+    }
+    // groups are added while eff_len < req_len (:648-649): the first group boundary at or beyond req_len
+    uint32_t eff = r1;
+    if (req_len < r1) {
+#pragma unroll
+      for (int q = R - 1; q >= 0; --q) {
+        const uint32_t lo = req_len > (uint32_t)q * 64u ? req_len - (uint32_t)q * 64u : 0u;  // lanes of this row at or beyond req_len
+        const uint64_t m = lo >= 64u ? 0ull : (hm[q] >> lo) << lo;
+        if (m) eff = (uint32_t)q * 64u + (uint32_t)__ffsll((long long)m) - 1u;
+      }
+    }
+    // squared deviations in column order (:657-670); dv[q] is column lane + 64 q
+    double t2[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const double d0 = __dsub_rn(dv[q], mean);
+      t2[q] = ((uint32_t)lane + 64u * q) < r1 ? __dmul_rn(d0, d0) : 0.0;
+    }
+    acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int lim = (int)min(64u, r1 > (uint32_t)q * 64u ? r1 - (uint32_t)q * 64u : 0u);
+      for (int i = 0; i < lim; ++i) {
+        const double t = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(t2[q]) >> 32), i) << 32) |
+                                              (unsigned int)__builtin_amdgcn_readlane((int)__double_as_longlong(t2[q]), i));
+        acc = __dadd_rn(acc, t);
+      }
+    }
+    const double sd = (r1 > 1) ? sqrt(acc / ((double)r1 - 1.0)) : 0.0;  // :679-683
+    const uint32_t n_out = min(eff, max_neighbours);
+    for (uint32_t q = lane; q < n_out; q += 64) {  // :685-689
+      out_idx[(uint64_t)j * max_neighbours + q] = ki[q];
+      out_dist[(uint64_t)j * max_neighbours + q] = kd[q];
+      double zz = __dsub_rn(kd[q], mean) / sd;
+      if (zz != zz) zz = __longlong_as_double((long long)0xFFF8000000000000ull);  // see distance_summary_kernel
+      out_z[(uint64_t)j * max_neighbours + q] = zz;
+    }
+    // MAD: |d - median| sorted, element n/2 (:659-678)
+    uint64_t mk[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const uint32_t i = (uint32_t)lane + 64u * q;
+      mk[q] = i < r1 ? dist_key(fabs(__dsub_rn(dv[q], median))) : ~0ull;
+    }
+    wave_bitonic_sort<R, uint64_t>(mk, lane);
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t mpos = r1 / 2;  // sorted position lane * R + q
+    double mad = 0.0;
+#pragma unroll
+    for (int q = 0; q < R; ++q)
+      if (r1 > 0 && (uint32_t)lane * R + q == mpos) kd[0] = key_dist(mk[q]);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      mad = (r1 > 0) ? kd[0] : 0.0;
+      out_stats[(uint64_t)j * 4 + 0] = mean;
+      out_stats[(uint64_t)j * 4 + 1] = sd;
+      out_stats[(uint64_t)j * 4 + 2] = median;
+      out_stats[(uint64_t)j * 4 + 3] = mad;
+      out_n[j] = eff;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int KIND, bool PRE, int R>
+static int launch_summary_wave_r(const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims, const double *metric,
+                                 double p, uint32_t req_len, uint32_t max_neighbours, double *out_stats, uint32_t *out_n,
+                                 uint32_t *out_idx, double *out_dist, double *out_z, hipStream_t st) {
+  const uint32_t per_wave = ((uint32_t)(64 * R) * 20 + (PRE ? 0u : n_dims * 8) + 15) & ~15u;
+  const size_t shared = PRE ? 0 : ((size_t)n_dims * r1 + n_dims) * 8;
+  // as many waves per block as the LDS left beside the shared operand allows (two blocks per CU: 78 KB each)
+  const uint32_t waves = (uint32_t)std::max<size_t>(1, std::min<size_t>(kSummaryWaves, ((78u << 10) - shared) / per_wave));
+  const size_t smem = (size_t)waves * per_wave + shared;
+  static bool attr_set = false;
+  if (!attr_set) {
+    KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&distance_summary_wave_kernel<KIND, PRE, R>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    attr_set = true;
+  }
+  const uint32_t blocks = std::min<uint32_t>(div_up(r2, waves), (uint32_t)ctx().n_cus * 2);
+  distance_summary_wave_kernel<KIND, PRE, R><<<dim3(blocks), dim3(64 * waves), smem, st>>>(a, r1, b, r2, n_dims, metric, p, req_len,
+                                                                                     max_neighbours, out_stats, out_n, out_idx,
+                                                                                     out_dist, out_z);
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
+
+static inline bool summary_fits_wave(uint32_t r1, uint32_t n_dims, bool pre) {
+  return r1 >= 1 && r1 <= 512 && (pre || (uint64_t)r1 * n_dims * 8 <= kWaveSummaryLds);
+}
+
+template <int KIND, bool PRE>
+static int launch_summary_wave(const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims, const double *metric,
+                               double p, uint32_t req_len, uint32_t max_neighbours, double *out_stats, uint32_t *out_n,
+                               uint32_t *out_idx, double *out_dist, double *out_z, hipStream_t st) {
+  if (r1 <= 64) return launch_summary_wave_r<KIND, PRE, 1>(a, r1, b, r2, n_dims, metric, p, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st);
+  if (r1 <= 128) return launch_summary_wave_r<KIND, PRE, 2>(a, r1, b, r2, n_dims, metric, p, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st);
+  if (r1 <= 256) return launch_summary_wave_r<KIND, PRE, 4>(a, r1, b, r2, n_dims, metric, p, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st);
+  return launch_summary_wave_r<KIND, PRE, 8>(a, r1, b, r2, n_dims, metric, p, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st);
+}
+
+// ---------------------------------------------------------------------------
 // host-side orchestration
 // ---------------------------------------------------------------------------
 struct DistWork {
@@ -530,6 +774,9 @@ static int launch_summary(const double *a, uint32_t r1, const double *b, uint32_
                           const double *metric, double p, uint32_t keep_at_most, uint32_t max_neighbours,
                           double *out_stats, uint32_t *out_n, uint32_t *out_idx, double *out_dist, double *out_z,
                           hipStream_t st) {
+  if (summary_fits_wave(r1, n_dims, PRE) && ctx().tune_dbg != 4)
+    return launch_summary_wave<KIND, PRE>(a, r1, b, r2, n_dims, metric, p, keep_at_most ? keep_at_most : r1, max_neighbours, out_stats,
+                                          out_n, out_idx, out_dist, out_z, st);
   uint32_t NP = 64;
   while (NP < r1) NP <<= 1;
   const size_t smem = (size_t)NP * (8 + 8 + 4);

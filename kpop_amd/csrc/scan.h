@@ -30,14 +30,24 @@ __device__ __forceinline__ uint64_t block_reduce_sum_u64(uint64_t v, uint64_t *s
   return t;
 }
 
+// A thread owns kScanItems CONSECUTIVE elements (that is what makes the prefix a per-thread running sum), but the
+// functors usually read global memory at the element's index: evaluated thread by thread that is one 128-byte line per
+// lane and instruction for 8 useful bytes (measured: 22x the key bytes in HBM traffic on the head-flag scans of the
+// sort path).  So the tile's elements are evaluated in lane-consecutive order into LDS, and each thread then picks its
+// run out of LDS (padded: a run of 16 words per thread would put every lane of a wave on the same banks).
+__device__ __forceinline__ uint32_t scan_slot(uint32_t e) { return e + (e >> 4); }
+constexpr uint32_t kScanLdsWords = (uint32_t)kScanTile + ((uint32_t)kScanTile >> 4);
+
 template <class In>
 __global__ __launch_bounds__(kScanThreads) void scan_tile_sums_kernel(In in, uint64_t n, uint64_t *block_sums) {
   __shared__ uint64_t s_tmp[4];
-  const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+  const uint64_t tile0 = (uint64_t)blockIdx.x * kScanTile;
   uint64_t s = 0;
 #pragma unroll
-  for (int i = 0; i < kScanItems; ++i)
-    if (base + i < n) s += in(base + i);
+  for (int i = 0; i < kScanItems; ++i) {  // a sum needs no particular assignment of elements to threads
+    const uint64_t e = tile0 + (uint64_t)i * kScanThreads + threadIdx.x;
+    if (e < n) s += in(e);
+  }
   uint64_t t = block_reduce_sum_u64(s, s_tmp);
   if (threadIdx.x == 0) block_sums[blockIdx.x] = t;
 }
@@ -76,13 +86,22 @@ template <class In, class Out>
 __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(In in, Out out, uint64_t n,
                                                                    const uint64_t *block_sums) {
   __shared__ uint64_t s_wave[4];
+  __shared__ uint32_t s_v[kScanLdsWords];
+  __shared__ uint32_t s_pre[kScanLdsWords];  // prefix within the tile (a tile holds < 2^32 in total: 4096 u32 addends may not, see below)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+  const uint64_t tile0 = (uint64_t)blockIdx.x * kScanTile;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    const uint32_t e = (uint32_t)i * kScanThreads + threadIdx.x;
+    s_v[scan_slot(e)] = (tile0 + e < n) ? in(tile0 + e) : 0u;
+  }
+  __syncthreads();
+  const uint32_t first = threadIdx.x * kScanItems;
   uint32_t v[kScanItems];
   uint64_t s = 0;
 #pragma unroll
   for (int i = 0; i < kScanItems; ++i) {
-    v[i] = (base + i < n) ? in(base + i) : 0u;
+    v[i] = s_v[scan_slot(first + i)];
     s += v[i];
   }
   uint64_t incl = s;
@@ -93,12 +112,21 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(In in, Out out
   }
   if (lane == 63) s_wave[wave] = incl;
   __syncthreads();
-  uint64_t pre = block_sums[blockIdx.x] + incl - s;
+  uint64_t pre = incl - s;  // within the tile
   for (int w = 0; w < wave; ++w) pre += s_wave[w];
+  // prefixes inside a tile are kept as 32-bit offsets from the tile's base; the addends of every user are flags or
+  // digit counts of a tile, far below 2^32 / 4096 each
 #pragma unroll
   for (int i = 0; i < kScanItems; ++i) {
-    if (base + i < n) out(base + i, pre, v[i]);
+    s_pre[scan_slot(first + i)] = (uint32_t)pre;
     pre += v[i];
+  }
+  __syncthreads();
+  const uint64_t base = block_sums[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    const uint32_t e = (uint32_t)i * kScanThreads + threadIdx.x;
+    if (tile0 + e < n) out(tile0 + e, base + s_pre[scan_slot(e)], s_v[scan_slot(e)]);
   }
 }
 

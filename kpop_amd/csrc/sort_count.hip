@@ -336,7 +336,13 @@ int sorted_count_device(const uint8_t *bases, const uint64_t *offsets, uint32_t 
   // distinct keys -> `other`, first positions -> d_start; totals at the end of the sums arrays
   uint64_t *sums1 = d_sums.as<uint64_t>(), *sums2 = sums1 + scan_blocks(tw) + 1;
   KPOP_TRY(exclusive_scan(HeadFlag{sorted}, StoreHeads{sorted, other, d_start.as<uint64_t>()}, tw, sums1, st));
-  KPOP_TRY(exclusive_scan(ValidFlag{sorted}, Discard{}, tw, sums2, st));
+  {  // only the number of valid keys is wanted: tile sums and their scan, no apply pass
+    const uint64_t nb = scan_blocks(tw);
+    scan_tile_sums_kernel<ValidFlag><<<dim3((uint32_t)nb), dim3(kScanThreads), 0, st>>>(ValidFlag{sorted}, tw, sums2);
+    KPOP_LAUNCH_CHECK();
+    scan_block_sums_kernel<0><<<dim3(1), dim3(1024), 0, st>>>(sums2, nb);
+    KPOP_LAUNCH_CHECK();
+  }
   const uint64_t *d_nu = sums1 + scan_blocks(tw), *d_nv = sums2 + scan_blocks(tw);
   uint64_t nu = 0;
   KPOP_HIP(hipMemcpyAsync(&nu, d_nu, 8, hipMemcpyDeviceToHost, st));

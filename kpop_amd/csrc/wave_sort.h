@@ -59,6 +59,48 @@ __device__ __forceinline__ void wave_bitonic_sort(K (&key)[R], int lane) {
   }
 }
 
+// the same network on (key, value) pairs ordered by key, then value
+template <int R, typename K>
+__device__ __forceinline__ void wave_bitonic_sort_pairs(K (&key)[R], uint32_t (&val)[R], int lane) {
+  constexpr int N = 64 * R;
+  auto less = [](K ka, uint32_t va, K kb, uint32_t vb) { return ka < kb || (ka == kb && va < vb); };
+#pragma unroll
+  for (int s = 2; s <= N; s <<= 1) {
+#pragma unroll
+    for (int t = s >> 1; t > 0; t >>= 1) {
+      if (t >= R) {
+        const int lt = t / R;
+        const bool asc = (s == N) ? true : ((lane & (s / R)) == 0);
+        const bool lower = (lane & lt) == 0;
+        const bool keep_min = (lower == asc);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const K ok = wave_shfl_xor(key[r], lt);
+          const uint32_t ov = wave_shfl_xor(val[r], lt);
+          const bool mine_less = less(key[r], val[r], ok, ov);
+          const bool take_other = keep_min ? !mine_less : mine_less;
+          key[r] = take_other ? ok : key[r];
+          val[r] = take_other ? ov : val[r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if ((r & t) == 0) {
+            const bool asc = (s >= N) ? true : (s < R ? ((r & s) == 0) : ((lane & (s / R)) == 0));
+            const K a = key[r], b = key[r ^ t];
+            const uint32_t va = val[r], vb = val[r ^ t];
+            const bool swap = asc ? less(b, vb, a, va) : less(a, va, b, vb);
+            key[r] = swap ? b : a;
+            val[r] = swap ? vb : va;
+            key[r ^ t] = swap ? a : b;
+            val[r ^ t] = swap ? va : vb;
+          }
+        }
+      }
+    }
+  }
+}
+
 // After wave_bitonic_sort: collapse runs of equal keys.
 //   s_key[u]   = u-th distinct key (ascending), u < n_unique
 //   s_start[u] = index of its first occurrence; s_start[n_unique] = n_valid

@@ -310,3 +310,36 @@ def test_reference_distance_iterator_known_answer_on_the_gpu(kpop):
     for i in range(n):
         for j in range(i + 1, n):  # |0.1 - 0.4| is one ulp above the bound: a tolerance band around it, not a sharp cut
             assert (d[j, i] <= 0.3 * (1 + 1e-12)) if (i, j) in listed else (d[j, i] >= 0.3 * (1 - 1e-12))
+
+
+@pytest.mark.parametrize("r1", [1, 2, 63, 64, 65, 128, 129, 300, 512])
+def test_wave_summary_equals_block_summary(kpop, oracle, r1):
+    """the one-wavefront-per-row summary (small first operand) and the one-block-per-row summary are the same operations in
+    the same order: identical bits, ties and sd = 0 included; `-S` on a ready distance matrix likewise"""
+    from kpop_amd import api
+    rng = np.random.RandomState(r1)
+    d = 9 if r1 > 128 else 64
+    m1 = rng.randn(r1, d)
+    m2 = rng.randn(700, d)
+    if r1 >= 3:
+        m1[2] = m1[0]  # a tie group
+        m2[5] = m1[1]  # a zero distance
+    metric = kpop.metric_compute(oracle.synth_inertia(d))
+    for kind, p in ((kpop.EUCLIDEAN, 2.0), (kpop.COSINE, 2.0), (kpop.MINKOWSKI, 1.5)):
+        for keep in (2, 0, 7):
+            res = {}
+            for dbg in (0, 4):  # 4: force the block kernel
+                api.tune("dbg", dbg)
+                res[dbg] = kpop.distance_summary(m1, m2, metric, kind=kind, p=p, keep_at_most=keep, max_neighbours=min(r1, 40))
+            api.tune("dbg", 0)
+            for x, y in zip(res[0], res[4]):
+                assert np.array_equal(x, y, equal_nan=True), (r1, kind, keep)
+    dm = kpop.distance_rowwise(m1, m2, metric)
+    dm[3] = dm[3, 0]  # a row whose distances are all equal: sd = 0
+    res = {}
+    for dbg in (0, 4):
+        api.tune("dbg", dbg)
+        res[dbg] = kpop.summarize_distances(dm, keep_at_most=2, max_neighbours=min(r1, 16))
+    api.tune("dbg", 0)
+    for x, y in zip(res[0], res[4]):
+        assert np.array_equal(x, y, equal_nan=True), r1
