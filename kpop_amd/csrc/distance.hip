@@ -755,7 +755,9 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
                               uint32_t *out_idx, double *out_dist, double *out_z, hipStream_t st) {
   const double *a, *b;
   KPOP_TRY(prepare_operands<KIND>(m1, r1, m2, r2, n_dims, metric, p, normalize, work, &a, &b, st));
-  const uint64_t budget = 512ull << 20;
+  // distance rows of a chunk of queries live in the library workspace: enough of them (one 1024-thread block each) to
+  // put two blocks on every CU when the first operand is large
+  const uint64_t budget = 4096ull << 20;
   const uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(r2, budget / ((uint64_t)r1 * 8)));
   void *ws = nullptr;
   KPOP_TRY(ctx().ws.ensure((uint64_t)chunk * r1 * 8, &ws));

@@ -5,8 +5,9 @@
 // The r2 x r1 matrix is still never formed: query rows are processed in chunks whose distance
 // rows live in a library workspace, and each row is reduced by one 1024-thread block with
 //   - two ordered block reductions            mean, sample sd           (lib/Matrix.ml:651-655,657-683)
-//   - MSB-first radix SELECT on the f64 bits  upper median, MAD, and the keep_at_most-th smallest
-//                                             distance (8 histogram passes each; no sort of the row)
+//   - SELECT by narrowing the key range       upper median, MAD, and the keep_at_most-th smallest distance: one
+//                                             2048-bin pass + one pass that ranks the chosen bin's keys in LDS is the
+//                                             common case (no sort of the row; more passes only for crowded values)
 //   - ordered compaction + a small LDS sort   the closest rows, whole tie groups counted (:648-649)
 // Differences from the r1 <= 4096 kernel: mean and sd are tree sums (not the reference's
 // ascending chain), equal up to rounding (tests hold 1e-10); at most kLargeMaxNb neighbours
@@ -66,41 +67,131 @@ __device__ __forceinline__ uint64_t elem_key(const double *row, uint32_t i, doub
   return f64_key(x);
 }
 
-// rank-th smallest (0-based) of the n transformed elements; also how many are strictly smaller
-// and how many are equal.  All threads return the same values.
+// ---------------------------------------------------------------------------
+// Selection by narrowing the key range.  A pass bins the keys of [lo, hi] into kBins equal (power-of-two wide) bins and
+// finds the bin that holds the wanted rank; a row of smoothly spread distances leaves ~n / kBins keys there, so after ONE
+// such pass the bin's keys fit an LDS list (kCand) and are ranked exactly.  A bin that is still too full (many equal or
+// crowded values) becomes the new range: every pass narrows it at least 1024-fold, and a range of one key is a tie
+// group, known without looking further.  Round 1 took eight 8-bit passes per selection whatever the data.
+// Up to kSel ranks are served by the same passes (they share the row, not the bin).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kBins = 2048, kCand = 2048;
+constexpr int kSel = 2;
+
+struct Sel {          // one selection in progress / done
+  uint32_t rank;      // wanted 0-based rank
+  uint64_t lo, hi;    // current key range (inclusive)
+  uint32_t below;     // keys strictly below lo
+  uint64_t value;     // result
+  uint32_t n_less, n_equal;
+  int done;
+};
+
+__device__ __forceinline__ int range_shift(uint64_t lo, uint64_t hi) {  // smallest s with (hi - lo) >> s < kBins
+  const uint64_t span = hi - lo;
+  const int bits = span ? 64 - __clzll((long long)span) : 0;
+  return bits > 11 ? bits - 11 : 0;
+}
+
+// All threads call with the same arguments.  s_hist: kSel * kBins u32; s_cand: kSel * kCand u64; s_misc: 64 u32.
 template <int TRANSFORM>
-__device__ uint64_t block_select(const double *row, uint32_t n, double centre, uint32_t rank, uint32_t *s_hist,
-                                 uint32_t *s_pick, uint32_t *n_less, uint32_t *n_equal) {
-  uint64_t prefix = 0, mask = 0;
-  uint32_t r = rank;
-  for (int shift = 56; shift >= 0; shift -= 8) {
+__device__ void block_select_ranks(const double *row, uint32_t n, double centre, Sel *sel, int n_sel, uint32_t *s_hist,
+                                   uint64_t *s_cand, uint32_t *s_misc) {
+  for (int round = 0; round < 8; ++round) {
+    bool any = false;
+    for (int t = 0; t < n_sel; ++t) any = any || !sel[t].done;
+    if (!any) return;
     __syncthreads();
-    if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
+    for (uint32_t q = threadIdx.x; q < (uint32_t)n_sel * kBins; q += kLT) s_hist[q] = 0;
     __syncthreads();
+    int shift[kSel];
+    for (int t = 0; t < n_sel; ++t) shift[t] = range_shift(sel[t].lo, sel[t].hi);
     for (uint32_t i = threadIdx.x; i < n; i += kLT) {
       const uint64_t k = elem_key<TRANSFORM>(row, i, centre);
-      if ((k & mask) == prefix) atomicAdd(&s_hist[(uint32_t)(k >> shift) & 255u], 1u);
+      for (int t = 0; t < n_sel; ++t)
+        if (!sel[t].done && k >= sel[t].lo && k <= sel[t].hi) atomicAdd(&s_hist[t * kBins + (uint32_t)((k - sel[t].lo) >> shift[t])], 1u);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t cum = 0, b = 0;
-      for (; b < 256; ++b) {
-        if (cum + s_hist[b] > r) break;
-        cum += s_hist[b];
+    // the bin of each rank (one thread per selection walks 2048 counters)
+    if (threadIdx.x < (uint32_t)n_sel && !sel[threadIdx.x].done) {
+      const int t = threadIdx.x;
+      uint32_t cum = sel[t].below, bin = 0;
+      for (; bin < kBins; ++bin) {
+        const uint32_t c = s_hist[t * kBins + bin];
+        if (cum + c > sel[t].rank) break;
+        cum += c;
       }
-      if (b == 256) b = 255;  // only reachable with NaNs in the row
-      s_pick[0] = b;
-      s_pick[1] = r - cum;
-      s_pick[2] = s_hist[b];
+      if (bin == kBins) bin = kBins - 1;  // only reachable with NaNs in the row
+      s_misc[t * 4 + 0] = bin;
+      s_misc[t * 4 + 1] = cum;
+      s_misc[t * 4 + 2] = s_hist[t * kBins + bin];
     }
     __syncthreads();
-    prefix |= (uint64_t)s_pick[0] << shift;
-    mask |= 255ull << shift;
-    r = s_pick[1];
+    bool collect[kSel];
+    for (int t = 0; t < n_sel; ++t) {
+      collect[t] = false;
+      if (sel[t].done) continue;
+      const uint32_t bin = s_misc[t * 4 + 0], cum = s_misc[t * 4 + 1], cnt = s_misc[t * 4 + 2];
+      const uint64_t blo = sel[t].lo + ((uint64_t)bin << shift[t]);
+      const uint64_t bhi = shift[t] ? min(sel[t].hi, blo + ((1ull << shift[t]) - 1)) : blo;
+      sel[t].lo = blo;
+      sel[t].hi = bhi;
+      sel[t].below = cum;
+      if (blo == bhi) {  // a single key: a tie group
+        sel[t].value = blo;
+        sel[t].n_less = cum;
+        sel[t].n_equal = cnt;
+        sel[t].done = 1;
+      } else if (cnt <= kCand) {
+        collect[t] = true;
+      }
+    }
+    bool need = false;
+    for (int t = 0; t < n_sel; ++t) need = need || collect[t];
+    if (need) {
+      // gather the keys of the chosen bins and rank them exactly
+      __syncthreads();
+      if (threadIdx.x < (uint32_t)n_sel) s_misc[32 + threadIdx.x] = 0;
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < n; i += kLT) {
+        const uint64_t k = elem_key<TRANSFORM>(row, i, centre);
+        for (int t = 0; t < n_sel; ++t)
+          if (collect[t] && k >= sel[t].lo && k <= sel[t].hi) {
+            const uint32_t at = atomicAdd(&s_misc[32 + t], 1u);
+            if (at < kCand) s_cand[t * kCand + at] = k;
+          }
+      }
+      __syncthreads();
+      for (int t = 0; t < n_sel; ++t) {
+        if (!collect[t]) continue;
+        const uint32_t m = min(s_misc[32 + t], kCand), want = sel[t].rank - sel[t].below;
+        // the key with exactly `want` keys below it among the m candidates (ties: any member of the group whose span holds `want`)
+        __syncthreads();
+        if (threadIdx.x == 0) s_misc[40] = 0xFFFFFFFFu;
+        __syncthreads();
+        for (uint32_t c = threadIdx.x; c < m; c += kLT) {
+          const uint64_t kc = s_cand[t * kCand + c];
+          uint32_t less = 0, eq = 0;
+          for (uint32_t o = 0; o < m; ++o) {
+            const uint64_t ko = s_cand[t * kCand + o];
+            less += ko < kc;
+            eq += ko == kc;
+          }
+          if (less <= want && want < less + eq) {  // every member of the group qualifies and writes the same values
+            s_misc[40] = c;
+            s_misc[41] = less;
+            s_misc[42] = eq;
+          }
+        }
+        __syncthreads();
+        const uint32_t c = s_misc[40];
+        sel[t].value = s_cand[t * kCand + (c == 0xFFFFFFFFu ? 0 : c)];
+        sel[t].n_less = sel[t].below + s_misc[41];
+        sel[t].n_equal = s_misc[42];
+        sel[t].done = 1;
+      }
+    }
   }
-  *n_less = rank - r;
-  *n_equal = s_pick[2];
-  return prefix;
 }
 
 __global__ __launch_bounds__(kLT) void summary_large_kernel(const double *__restrict__ rows, uint32_t r1, uint32_t row0,
@@ -110,18 +201,42 @@ __global__ __launch_bounds__(kLT) void summary_large_kernel(const double *__rest
                                                             double *__restrict__ out_z) {
   __shared__ double s_w[kLT / 64];
   __shared__ uint32_t s_wu[kLT / 64];
-  __shared__ uint32_t s_hist[256];
-  __shared__ uint32_t s_pick[3];
+  __shared__ uint32_t s_hist[kSel * kBins];
+  __shared__ uint64_t s_cand[kSel * kCand];
+  __shared__ uint32_t s_misc[64];
+  __shared__ uint64_t s_mm[2 * (kLT / 64)];
   __shared__ double s_cd[kLargeMaxNb];
   __shared__ uint32_t s_ci[kLargeMaxNb];
   __shared__ uint32_t s_ti[kLargeMaxNb];  // columns of the tie group at the cut-off distance
   const double *row = rows + (uint64_t)blockIdx.x * r1;
   const uint32_t j = row0 + blockIdx.x;
   const uint32_t n = r1;
-  // mean (lib/Matrix.ml:651-655) and sample sd (:657-662,679-683)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // pass 1: sum (mean, lib/Matrix.ml:651-655) and the key range
   double part = 0.0;
-  for (uint32_t i = threadIdx.x; i < n; i += kLT) part = __dadd_rn(part, row[i]);
-  const double mean = n ? block_sum(part, s_w) / (double)n : 0.0;
+  uint64_t kmin = ~0ull, kmax = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += kLT) {
+    const double x = row[i];
+    part = __dadd_rn(part, x);
+    const uint64_t k = f64_key(x);
+    kmin = min(kmin, k);
+    kmax = max(kmax, k);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    kmin = min(kmin, (uint64_t)__shfl_xor((unsigned long long)kmin, o, 64));
+    kmax = max(kmax, (uint64_t)__shfl_xor((unsigned long long)kmax, o, 64));
+  }
+  if (lane == 0) {
+    s_mm[wv] = kmin;
+    s_mm[kLT / 64 + wv] = kmax;
+  }
+  const double mean = n ? block_sum(part, s_w) / (double)n : 0.0;  // block_sum synchronises
+  for (int w = 0; w < kLT / 64; ++w) {
+    kmin = min(kmin, s_mm[w]);
+    kmax = max(kmax, s_mm[kLT / 64 + w]);
+  }
+  // pass 2 (inside the first selection pass would save a read; kept apart for clarity of the sums): sample sd (:657-662,679-683)
   part = 0.0;
   for (uint32_t i = threadIdx.x; i < n; i += kLT) {
     const double dv = __dsub_rn(row[i], mean);
@@ -129,29 +244,41 @@ __global__ __launch_bounds__(kLT) void summary_large_kernel(const double *__rest
   }
   const double ss = block_sum(part, s_w);
   const double sd = (n > 1) ? sqrt(ss / ((double)n - 1.0)) : 0.0;
-  // upper median = element n/2 of the sorted row (:645-647); MAD = element n/2 of |d - median| (:671-678)
-  uint32_t lt, eq;
+  // upper median = element n/2 of the sorted row (:645-647), and the value that closes the neighbour list: groups are
+  // added while eff_len < req_len (:648-649), so eff_len = (#less + #equal) of the element of rank req_len - 1
   double median = 0.0, mad = 0.0;
-  if (n) {
-    median = key_f64(block_select<0>(row, n, 0.0, n / 2, s_hist, s_pick, &lt, &eq));
-    mad = key_f64(block_select<1>(row, n, median, n / 2, s_hist, s_pick, &lt, &eq));
-  }
-  // eff_len: groups are added while eff_len < req_len (:648-649)
   uint32_t eff = n;
-  if (n && req_len < n) {
-    block_select<0>(row, n, 0.0, req_len - 1, s_hist, s_pick, &lt, &eq);
-    eff = lt + eq;
+  Sel sel[kSel];
+  if (n) {
+    sel[0] = Sel{n / 2, kmin, kmax, 0, 0, 0, 0, 0};
+    const bool cut = req_len < n;
+    sel[1] = Sel{cut ? req_len - 1 : 0, kmin, kmax, 0, 0, 0, 0, cut ? 0 : 1};
+    block_select_ranks<0>(row, n, 0.0, sel, 2, s_hist, s_cand, s_misc);
+    median = key_f64(sel[0].value);
+    if (cut) eff = sel[1].n_less + sel[1].n_equal;
   }
   // the M closest, by (distance, column)
   const uint32_t M = min(min(eff, max_neighbours), kLargeMaxNb);
   if (M) {
-    const double vM = key_f64(block_select<0>(row, n, 0.0, M - 1, s_hist, s_pick, &lt, &eq));
-    const uint32_t n_lt = lt, want_eq = M - lt;
+    uint64_t vkey;
+    uint32_t n_lt;
+    if (req_len < n && M == eff) {  // the list ends with the tie group just found
+      vkey = sel[1].value;
+      n_lt = sel[1].n_less;
+    } else {  // the list is cut short (or holds everything): its last value is the element of rank M - 1
+      Sel s3[1] = {Sel{M - 1, kmin, kmax, 0, 0, 0, 0, 0}};
+      block_select_ranks<0>(row, n, 0.0, s3, 1, s_hist, s_cand, s_misc);
+      vkey = s3[0].value;
+      n_lt = s3[0].n_less;
+    }
+    const double vM = key_f64(vkey);
+    const uint32_t want_eq = M - n_lt;
     uint32_t got_lt = 0, got_eq = 0;
     for (uint32_t base = 0; base < n; base += kLT) {  // column order => ties resolved by column, as the multimap does
       const uint32_t i = base + threadIdx.x;
       const double dv = (i < n) ? row[i] : 0.0;
       const bool is_lt = (i < n) && dv < vM, is_eq = (i < n) && dv == vM;
+      if (!__syncthreads_or(is_lt || (is_eq && got_eq < want_eq))) continue;  // nothing of interest in this stretch
       uint32_t tot_lt, tot_eq;
       const uint32_t p_lt = block_scan_flag(is_lt, s_wu, &tot_lt);
       const uint32_t p_eq = block_scan_flag(is_eq, s_wu, &tot_eq);
@@ -195,6 +322,33 @@ __global__ __launch_bounds__(kLT) void summary_large_kernel(const double *__rest
       if (zz != zz) zz = __longlong_as_double((long long)0xFFF8000000000000ull);  // x86 invalid-operation NaN, see distance.hip
       out_z[(uint64_t)j * max_neighbours + q] = zz;
     }
+  }
+  // MAD = element n/2 of |d - median| (:671-678): its key range first, then the same selection
+  if (n) {
+    uint64_t amin = ~0ull, amax = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += kLT) {
+      const uint64_t k = elem_key<1>(row, i, median);
+      amin = min(amin, k);
+      amax = max(amax, k);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      amin = min(amin, (uint64_t)__shfl_xor((unsigned long long)amin, o, 64));
+      amax = max(amax, (uint64_t)__shfl_xor((unsigned long long)amax, o, 64));
+    }
+    __syncthreads();
+    if (lane == 0) {
+      s_mm[wv] = amin;
+      s_mm[kLT / 64 + wv] = amax;
+    }
+    __syncthreads();
+    for (int w = 0; w < kLT / 64; ++w) {
+      amin = min(amin, s_mm[w]);
+      amax = max(amax, s_mm[kLT / 64 + w]);
+    }
+    Sel sm[1] = {Sel{n / 2, amin, amax, 0, 0, 0, 0, 0}};
+    block_select_ranks<1>(row, n, median, sm, 1, s_hist, s_cand, s_misc);
+    mad = key_f64(sm[0].value);
   }
   if (threadIdx.x == 0) {
     out_stats[(uint64_t)j * 4 + 0] = mean;
