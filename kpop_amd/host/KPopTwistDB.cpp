@@ -19,12 +19,14 @@
 #include <string.h>
 
 #include <fcntl.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -32,6 +34,7 @@
 
 #include "../../include/kpop_hip.h"
 #include "fast_seq.h"
+#include "gpu_workers.h"
 #include "kpop_text.h"
 #include "ocaml_marshal.h"
 
@@ -156,6 +159,7 @@ void check(int rc) {
   if (rc != 0) throw Error(std::string("libkpop_hip: ") + kpop_last_error());
 }
 
+std::unique_ptr<GpuWorkers> g_workers;  // KPOP_DEVICES: one worker process per GPU for the reads stream (gpu_workers.h)
 bool g_gpu = false;
 std::thread g_warm;  // brings the HIP runtime up while the main thread reads its first archive
 void warm_gpu() {
@@ -272,11 +276,11 @@ void twist_read_stream(int fd, TwisterReg &T, bool normalize, std::vector<RowPie
   ReadStreamReader rs(fd);
   const int k = (int)rs.header.k, content = (int)rs.header.content;
   if (k < 1 || k > 30 || (content != KPOP_DNA_DS && content != KPOP_DNA_SS)) throw Error("reads stream: unsupported k or content");
-  T.upload();
-  const size_t d = T.twister.rows();
+  if (!g_workers) T.upload();
+  const size_t d = g_workers ? T.inertia.cols() : T.twister.rows();
   // the names KPopCount would have written carry name_digits(k) hex digits; if the twister's names are of another
   // width no k-mer of the stream can be a column of it (lib/Twister.ml:167-169): every row is the zero vector
-  const bool can_match = (size_t)name_digits(k, false) == T.name_len;
+  const bool can_match = g_workers || (size_t)name_digits(k, false) == T.name_len;  // (the workers decide for themselves)
   BlockQueue bq;
   std::thread reader([&] {
     std::string err;
@@ -310,7 +314,9 @@ void twist_read_stream(int fd, TwisterReg &T, bool normalize, std::vector<RowPie
       offsets[0] = 0;
       for (size_t r = 0; r < n; ++r) offsets[r + 1] = offsets[r] + b.lens[r];
       piece.rows.resize(n * d);
-      if (can_match && n) {
+      if (g_workers) {
+        g_workers->twist_block(b, k, content, normalize, d, piece.rows.data());
+      } else if (can_match && n) {
         static const uint8_t dummy = 0;
         check(kpop_spectra_twist(T.dev, b.bases.empty() ? &dummy : b.bases.data(), offsets.data(), (uint32_t)n, k, content,
                                  normalize ? 1 : 0, piece.rows.data()));
@@ -340,11 +346,13 @@ void twist_read_stream(int fd, TwisterReg &T, bool normalize, std::vector<RowPie
 
 // Twister.add_twisted_from_files, lib/Twister.ml:58-206
 void add_twisted_from_files(TwisterReg &T, Table &twisted, const std::vector<std::string> &files, bool normalize, bool verbose) {
-  T.need_matrix();
+  // with worker processes the parent needs the dimension names only (the inertia's columns, lib/Twister.ml:36-38); the
+  // matrix is read and uploaded here only if text spectra turn up, which the parent twists itself
+  if (!g_workers) T.need_matrix();
   stage_mark("KPopTwistDB", "twister archive read");
-  const std::vector<std::string> &dims = T.twister.row_names;
+  const std::vector<std::string> dims = g_workers ? T.inertia.col_names : T.twister.row_names;
   if (!twisted.empty() && twisted.col_names != dims) throw Error("Incompatible_twister_and_twisted");  // :64-69
-  T.upload();
+  if (!g_workers) T.upload();
   stage_mark("KPopTwistDB", "HIP bring-up + twister upload");
   const size_t d = dims.size();
   std::vector<RowPiece> pieces;
@@ -370,6 +378,7 @@ void add_twisted_from_files(TwisterReg &T, Table &twisted, const std::vector<std
         if (got == 0 && !pieces.empty()) break;  // end of file right after a stream
         // names -> hashes while parsing; a name the twister cannot hold is simply an unknown k-mer (:167-169)
         HashedSpectra sp;
+        T.upload();  // (a no-op unless worker processes had made it unnecessary so far)
         read_spectra_hashed_fd(fd, head, got, T.name_len, absent, sp);
         RowPiece piece;
         const size_t n = sp.labels.size();
@@ -624,6 +633,43 @@ int main(int argc, char **argv) {
   }
 
   stage_mark("KPopTwistDB", "start");
+  try {  // several GPUs: the workers are forked now, before this process has made any HIP call
+    int want = devices_requested();
+    const Action *src = nullptr, *first_k = nullptr;
+    for (const Action &a : program) {
+      if (a.kind == Action::AddKmersFiles && !first_k) first_k = &a;
+      if (!first_k && (a.kind == Action::BinaryToRegister || a.kind == Action::TablesToRegister) && a.reg == Reg::Twister) src = &a;
+    }
+    if (want != 0 && first_k && src && src->s1.compare(0, 5, "/dev/") != 0) {
+      if (want < 0) {  // "all": ask a child, so that this process stays clear of HIP
+        int fds[2];
+        if (pipe(fds) != 0) throw Error("pipe failed");
+        const pid_t pid = fork();
+        if (pid == 0) {
+          const int n = kpop_device_count();
+          if (write(fds[1], &n, sizeof n) < 0) {
+          }
+          _exit(0);
+        }
+        close(fds[1]);
+        int n = 0;
+        if (read(fds[0], &n, sizeof n) != (ssize_t)sizeof n) n = 0;
+        close(fds[0]);
+        waitpid(pid, nullptr, 0);
+        want = n;
+      }
+      if (want > 1) {
+        TwisterSource ts;
+        ts.prefix = src->s1;
+        ts.binary = src->kind == Action::BinaryToRegister;
+        g_workers.reset(new GpuWorkers(want, ts));
+        if (verbose) fprintf(stderr, "(KPopTwistDB): %d worker processes, one per GPU, for the reads stream\n", want);
+      }
+    }
+  } catch (const std::exception &e) {
+    fprintf(stderr, "(KPopTwistDB): FATAL: %s\n", e.what());
+    return 1;
+  }
   for (const Action &a : program)
     if (a.kind == Action::AddKmersFiles || a.kind == Action::DistancesFromTwisted || a.kind == Action::SummaryFromTwisted ||
         a.kind == Action::SummaryFromDistances || a.kind == Action::EmbeddingsFromTwisted) {
@@ -793,11 +839,13 @@ int main(int argc, char **argv) {
     }
   } catch (const std::exception &e) {
     fprintf(stderr, "(KPopTwistDB): FATAL: Uncaught exception: %s\n", e.what());
+    g_workers.reset();
     if (g_warm.joinable()) g_warm.join();
     T.reset();
     return 1;
   }
   stage_mark("KPopTwistDB", "last action done");
+  g_workers.reset();
   if (g_warm.joinable()) g_warm.join();
   T.reset();
   return 0;

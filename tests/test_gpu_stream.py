@@ -117,3 +117,33 @@ def test_reads_stream_errors_and_other_readers(tmp_path, oracle):
     assert r.returncode == 0, r.stderr
     rows = (tmp_path / "multi.KPopTwisted.txt").read_text().splitlines()
     assert [l.split("\t")[0] for l in rows[1:]] == ['"a"', '"b"', '"c"']
+
+
+def test_worker_processes_one_per_gpu(tmp_path, oracle):
+    """KPOP_DEVICES: the reads stream cut over worker processes (here 2 and 3 of them on the box's one GPU) gives the bytes
+    of the single-process run; a worker's failure reaches the user as an error, not as a hang"""
+    rng = np.random.RandomState(77)
+    k, d = 12, 40
+    make_twister(tmp_path, oracle, k, d, keep=0.02)
+    seqs = _reads(rng, n_short=300, genomes=(900, 7000))
+    fa = tmp_path / "in.fa"
+    write_fasta(fa, [("s%d" % i, s) for i, s in enumerate(seqs)], width=70)
+    # binary twister, as the README uses it
+    assert subprocess.run([TWISTDB, "-I", "T", str(tmp_path / "Classes"), "-o", "T", str(tmp_path / "Classes")]).returncode == 0
+    outs = {}
+    for devices in ("", "2", "3"):
+        env = dict(os.environ, KPOP_PIPE_FORMAT="reads", KPOP_SEQ_BLOCK="20000")  # several blocks
+        if devices:
+            env["KPOP_DEVICES"] = devices
+        r = subprocess.run("%s -k %d -L -f %s | %s -v -i T %s -k /dev/stdin -o t %s" % (COUNT, k, fa, TWISTDB, tmp_path / "Classes", tmp_path / ("w" + devices)),
+                           shell=True, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        assert ("worker processes" in r.stderr) == bool(devices)
+        outs[devices] = (tmp_path / ("w" + devices + ".KPopTwisted")).read_bytes()
+    assert outs[""] == outs["2"] == outs["3"] and len(outs[""]) > 1000
+    # the workers cannot load this twister: every one reports it, the parent stops with the message
+    (tmp_path / "Bad.KPopTwister").write_bytes(b"not an archive")
+    (tmp_path / "Bad.KPopInertia.txt").write_text((tmp_path / "Classes.KPopInertia.txt").read_text())
+    r = subprocess.run("%s -k %d -L -f %s | %s -I T %s -k /dev/stdin -o t %s" % (COUNT, k, fa, TWISTDB, tmp_path / "Missing", tmp_path / "x"),
+                       shell=True, capture_output=True, text=True, env=dict(os.environ, KPOP_DEVICES="2", KPOP_PIPE_FORMAT="reads"))
+    assert r.returncode != 0 and "cannot open" in r.stderr

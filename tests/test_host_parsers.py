@@ -80,3 +80,18 @@ def test_block_reader_agrees_with_line_reader(seq_harness, tmp_path):
                 path.write_text(data)
                 r = subprocess.run([seq_harness, str(path), fmt], capture_output=True, text=True, errors="replace", env=env)
                 assert r.returncode == 0, (threads, chunk, block, fmt, it, r.stdout, r.stderr)
+
+
+def test_row_ordering_matches_the_references_string_map(tmp_path):
+    """order_rows_by_label (threads sort runs of row numbers, pairwise merges, duplicate detection) against a std::map
+    restatement of lib/Twister.ml:78-82,189-204 on random labels: few letters (many duplicates, errors) and many"""
+    out = tmp_path / "rows_merge"
+    host = os.path.join(ROOT, "kpop_amd", "host")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", "-o", str(out), os.path.join(ROOT, "tests", "host", "rows_merge.cpp"),
+                    os.path.join(host, "kpop_text.cpp")], check=True)
+    for threads in ("1", "4", "16"):
+        env = dict(os.environ, KPOP_HOST_THREADS=threads)
+        for seed in range(12):
+            for rows, alphabet in ((0, 3), (1, 3), (40, 2), (3000, 6), (70000, 26)):
+                r = subprocess.run([str(out), str(seed), str(rows), str(alphabet)], capture_output=True, text=True, env=env)
+                assert r.returncode == 0, (threads, seed, rows, alphabet, r.stdout)
