@@ -71,7 +71,9 @@ int kpop_synchronize(void *stream);
 /* performance knobs for A/B measurements (results are identical for every setting):
    "unroll" 8|16 row loads in flight per wave; "nt" row loads 0 plain | 1 non-temporal | 2 chosen by the size of the
    twister (default); "seg" windows per segment of the genome kernel, 0 = sized to an XCD's L2 (default); "hist" 1 (default) | 0: the
-   merged spectrum of kpop_count_reads(per_read = 0) by atomic histogram where the hashes fit 26 bits, or always by sort */
+   merged spectrum of kpop_count_reads(per_read = 0) by atomic histogram where the hashes fit 26 bits, or always by sort;
+   "dense" 0 (default) | 1 | 2: kpop_twist by the sparse mat-vec, by the dense contraction on the f64 matrix cores, or
+   by the batch's density -- the one knob that changes results, in the last bits (kpop_dev_twist_dense)              */
 int kpop_tune(const char *key, int value);
 
 /* plain device-memory helpers so a non-HIP host language can stage buffers */
@@ -213,6 +215,14 @@ int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bases, const u
 int kpop_dev_twist(const kpop_twister *tw, const uint64_t *d_hash, const double *d_value,
                    const uint64_t *d_offsets, uint32_t n_spectra, uint64_t max_lines, int normalize,
                    double *d_out, void *stream);
+/* The same twist as a dense contraction on the f64 matrix cores (v_mfma_f64_16x16x4_f64): the spectra of a batch tile
+   are laid out as X[tile x n_kmers] and multiplied by the twister's rows.  2 n_kmers D flops per spectrum whatever it
+   holds: worth it for many dense spectra of a small k only.  Equal to kpop_dev_twist up to rounding
+   (the order of additions is the GEMM's).  d_work needs kpop_dev_twist_dense_workspace_bytes().                    */
+uint64_t kpop_dev_twist_dense_workspace_bytes(const kpop_twister *tw, uint32_t n_spectra);
+int kpop_dev_twist_dense(const kpop_twister *tw, const uint64_t *d_hash, const double *d_value,
+                         const uint64_t *d_offsets, uint32_t n_spectra, int normalize, void *d_work, double *d_out,
+                         void *stream);
 /* Distance workspace: row norms and the pre-normalised copies a/n_i, b/n_j of
    both operands (the per-element divisions of lib/Matrix.ml:247-249, done once).
    kpop_dev_distance_workspace_bytes gives the size d_work must have.          */

@@ -373,6 +373,16 @@ def dev_twist(tw, d_hash, d_value, d_offsets, n_spectra, max_lines, d_out, norma
                                      1 if normalize else 0, d_out, stream))
 
 
+def dev_twist_dense_workspace_bytes(tw, n_spectra):
+    return int(_lib.load().kpop_dev_twist_dense_workspace_bytes(tw.handle, int(n_spectra)))
+
+
+def dev_twist_dense(tw, d_hash, d_value, d_offsets, n_spectra, d_work, d_out, normalize=True, stream=0):
+    """the twist as X[n_spectra x n_kmers] * T on the f64 matrix cores (kpop_dev_twist_dense)"""
+    check(_lib.load().kpop_dev_twist_dense(tw.handle, d_hash, d_value, d_offsets, int(n_spectra), 1 if normalize else 0, d_work,
+                                           d_out, stream))
+
+
 def dev_distance_workspace_bytes(r1, r2, n_dims):
     return int(_lib.load().kpop_dev_distance_workspace_bytes(int(r1), int(r2), int(n_dims)))
 

@@ -927,8 +927,19 @@ extern "C" int kpop_twist(const kpop_twister *tw, const uint64_t *hash, const do
     KPOP_HIP(hipMemcpyAsync(d_v.p, value + base0, n_lines * 8, hipMemcpyHostToDevice, st));
   }
   KPOP_HIP(hipMemcpyAsync(d_off.p, rel.data(), (uint64_t)(n_spectra + 1) * 8, hipMemcpyHostToDevice, st));
-  KPOP_TRY(kpop_dev_twist(tw, d_h.as<uint64_t>(), d_v.as<double>(), d_off.as<uint64_t>(), n_spectra, max_lines,
-                          normalize, d_out.as<double>(), st));
+  // kpop_tune("dense", 1): always the contraction on the matrix cores; 2: when the batch is dense enough for it to win
+  // (measured crossover, DESIGN.md 5.9: >= 256 spectra holding >= 40 % of the twister's k-mers each); 0 (default): never --
+  // the sparse form is the reference's order of additions, the dense one agrees with it to rounding only
+  const int dense = ctx().tune_dense;
+  if (dense == 1 || (dense == 2 && n_spectra >= 256 && tw->n_rows > 0 && (double)n_lines >= 0.4 * (double)n_spectra * (double)tw->n_rows)) {
+    DevBuf d_work;
+    KPOP_TRY(d_work.alloc(kpop_dev_twist_dense_workspace_bytes(tw, n_spectra)));
+    KPOP_TRY(kpop_dev_twist_dense(tw, d_h.as<uint64_t>(), d_v.as<double>(), d_off.as<uint64_t>(), n_spectra, normalize, d_work.p,
+                                  d_out.as<double>(), st));
+  } else {
+    KPOP_TRY(kpop_dev_twist(tw, d_h.as<uint64_t>(), d_v.as<double>(), d_off.as<uint64_t>(), n_spectra, max_lines,
+                            normalize, d_out.as<double>(), st));
+  }
   KPOP_HIP(hipMemcpyAsync(out, d_out.p, (uint64_t)n_spectra * tw->n_dims * 8, hipMemcpyDeviceToHost, st));
   KPOP_HIP(hipStreamSynchronize(st));
   return KPOP_OK;

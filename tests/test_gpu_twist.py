@@ -361,3 +361,38 @@ def test_config3_50k_genomes_full_size(kpop, oracle):
     want = oracle.twist(oracle.synth_twister(0x7457, d, cols), cols, h, c.astype(np.float64), o)
     np.testing.assert_allclose(got[pick], want, rtol=1e-12, atol=1e-15)
     assert all(int(o[i + 1] - o[i]) > 29000 for i in range(len(pick)))     # ~29,989 distinct-ish 12-mers per genome
+
+
+@pytest.mark.parametrize("k,d,n", [(5, 64, 300), (7, 9, 129), (8, 100, 40)])
+def test_dense_twist_on_the_matrix_cores_equals_the_sparse_one(kpop, oracle, k, d, n):
+    """kpop_dev_twist_dense (spectra as a dense matrix times the twister's rows, f64 MFMA) against kpop_dev_twist: the same
+    sums in the GEMM's order, equal to rounding; unknown k-mers, duplicate lines, an empty spectrum, normalisation on and off"""
+    import torch
+    from kpop_amd import api
+    rng = np.random.RandomState(k * d)
+    cols = oracle.enumerate_kmers(k)
+    cols = cols[rng.rand(len(cols)) < 0.8]
+    tw = kpop.Twister.load(oracle.synth_twister(5, d, cols), cols, k)
+    allk = oracle.enumerate_kmers(k)
+    hs, vs, offs = [], [], [0]
+    for s in range(n):
+        m = 0 if s == 3 else int(rng.randint(1, min(len(allk), 600)))
+        pick = rng.choice(allk, size=m, replace=True)  # duplicates and k-mers the twister does not hold
+        hs.append(pick)
+        vs.append(rng.randint(1, 50, size=m).astype(np.float64))
+        offs.append(offs[-1] + m)
+    h, v, o = np.concatenate(hs).astype(np.uint64), np.concatenate(vs), np.array(offs, dtype=np.uint64)
+    dev = torch.device("cuda", 0)
+    dh, dv, do = torch.from_numpy(h.view(np.int64)).to(dev), torch.from_numpy(v).to(dev), torch.from_numpy(o.view(np.int64)).to(dev)
+    work = torch.empty(api.dev_twist_dense_workspace_bytes(tw, n), dtype=torch.uint8, device=dev)
+    for normalize in (True, False):
+        a = torch.zeros(n, d, dtype=torch.float64, device=dev)
+        b = torch.full((n, d), 7.0, dtype=torch.float64, device=dev)
+        api.dev_twist(tw, dh.data_ptr(), dv.data_ptr(), do.data_ptr(), n, 0, a.data_ptr(), normalize=normalize)
+        api.dev_twist_dense(tw, dh.data_ptr(), dv.data_ptr(), do.data_ptr(), n, work.data_ptr(), b.data_ptr(), normalize=normalize)
+        torch.cuda.synchronize()
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        assert np.all(b[3] == 0.0)
+        assert np.max(np.abs(a - b)) <= 1e-12 * max(np.max(np.abs(a)), 1.0)
+        want = oracle.twist(oracle.synth_twister(5, d, cols), cols, h, v, o, normalize=normalize)
+        assert np.max(np.abs(b - want)) <= 1e-12 * max(np.max(np.abs(want)), 1.0)
