@@ -188,6 +188,14 @@ int kpop_distance_summary(const double *m1, uint32_t r1, const double *m2, uint3
 int kpop_embeddings(const double *m, uint32_t rows, uint32_t n_dims, const double *metric, int kind, double p,
                     int normalize, double *out);
 
+/* Replaces Matrix.get_splits with SplitsAlgorithm.Gaps, lib/Matrix.ml:524-600 (KPopTwistDB -p, the default algorithm):
+ * per dimension the rows sorted by coordinate and the gaps between consecutive ones; all gaps by decreasing size, then
+ * dimension, then position; the s-th (s < *n_splits <= max_splits) is the split { perm[out_dim[s]][0 .. out_idx[s]] }
+ * with weight out_gap[s].  perm is n_dims x rows (the row order of every dimension); rows with equal coordinates stay in
+ * ascending row order.  The container the reference puts splits in (BiOCamLib Trees.Splits) is declared host-side.     */
+int kpop_splits_gaps(const double *embeddings, uint32_t rows, uint32_t n_dims, uint32_t max_splits, uint32_t *n_splits,
+                     double *out_gap, uint32_t *out_dim, uint32_t *out_idx, uint32_t *perm);
+
 /* Replaces Matrix.summarize_distance, lib/Matrix.ml:767-810 (KPopTwistDB -S): the same per-row summary
  * over a distance matrix that already exists (r2 rows x r1 columns, row-major).                      */
 int kpop_summarize_distances(const double *dist, uint32_t r2, uint32_t r1, uint32_t keep_at_most,

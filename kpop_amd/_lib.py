@@ -49,6 +49,7 @@ SIGNATURES = {
                                         C.c_double, C.c_int, C.c_uint32, C.c_uint32, f64p, u32p, u32p, f64p,
                                         f64p]),
     "kpop_embeddings": (C.c_int, [f64p, C.c_uint32, C.c_uint32, f64p, C.c_int, C.c_double, C.c_int, f64p]),
+    "kpop_splits_gaps": (C.c_int, [f64p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, f64p, u32p, u32p, u32p]),
     "kpop_summarize_distances": (C.c_int, [f64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, f64p, u32p, u32p, f64p,
                                            f64p]),
     "kpop_dev_summarize_distances": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp,

@@ -327,6 +327,21 @@ def embeddings(m, metric, kind=EUCLIDEAN, p=2.0, normalize=True):
     return out
 
 
+def splits_gaps(emb, max_splits=10000):
+    """Matrix.get_splits ... Gaps (lib/Matrix.ml:524-600) -> (gap, dim, idx) of the largest gaps and perm [n_dims, rows];
+    split s = perm[dim[s], :idx[s] + 1]"""
+    emb = _c(emb, np.float64)
+    rows, d = emb.shape
+    gap = np.zeros(max(max_splits, 1), dtype=np.float64)
+    dim = np.zeros(max(max_splits, 1), dtype=np.uint32)
+    idx = np.zeros(max(max_splits, 1), dtype=np.uint32)
+    perm = np.zeros((max(d, 1), max(rows, 1)), dtype=np.uint32)
+    n = C.c_uint32()
+    check(_lib.load().kpop_splits_gaps(_p(_nz(emb, np.float64), C.c_double), rows, d, int(max_splits), C.byref(n), _p(gap, C.c_double),
+                                       _p(dim, C.c_uint32), _p(idx, C.c_uint32), _p(perm, C.c_uint32)))
+    return gap[:n.value], dim[:n.value], idx[:n.value], perm[:d, :rows]
+
+
 def summarize_distances(dist, keep_at_most=2, max_neighbours=None):
     """Matrix.summarize_distance (lib/Matrix.ml:767-810) on an existing r2 x r1 distance matrix."""
     dist = _c(dist, np.float64)

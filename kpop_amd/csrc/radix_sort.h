@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 #include "common.h"
 #include "scan.h"
 
@@ -58,10 +60,13 @@ __global__ __launch_bounds__(256) void radix_count_kernel(const uint64_t *__rest
   counts[(uint64_t)threadIdx.x * n_tiles + blockIdx.x] = s_hist[threadIdx.x];
 }
 
-template <int kDummy = 0>
+// kVal = 1: a u32 value travels with every key (vin -> vout)
+template <int kVal = 0>
 __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
                                                             uint64_t n, int shift, uint64_t n_tiles,
-                                                            const uint64_t *__restrict__ bases) {
+                                                            const uint64_t *__restrict__ bases,
+                                                            const uint32_t *__restrict__ vin = nullptr,
+                                                            uint32_t *__restrict__ vout = nullptr) {
   __shared__ uint32_t s_cnt[4][256];
   __shared__ uint64_t s_base[4][256];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -71,12 +76,14 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t *__re
   const uint64_t base = (uint64_t)blockIdx.x * kRadixTile + (uint64_t)wv * kRadixItems * 64;
   uint64_t key[kRadixItems];
   uint32_t rank[kRadixItems];
+  uint32_t val[kVal ? kRadixItems : 1];
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
   for (int j = 0; j < kRadixItems; ++j) {
     const uint64_t i = base + (uint64_t)j * 64 + lane;
     const bool ok = i < n;
     key[j] = ok ? in[i] : ~0ull;
+    if (kVal) val[j] = ok ? vin[i] : 0u;
     const uint32_t dg = (uint32_t)(key[j] >> shift) & 255u;
     // lanes of this wave holding the same digit (out-of-range lanes form a class of their own)
     uint64_t peers = __ballot(ok);
@@ -114,6 +121,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t *__re
     if (i < n) {
       const uint32_t dg = (uint32_t)(key[j] >> shift) & 255u;
       out[s_base[wv][dg] + rank[j]] = key[j];
+      if (kVal) vout[s_base[wv][dg] + rank[j]] = val[j];
     }
   }
 }
@@ -148,6 +156,31 @@ static inline int radix_sort_u64(uint64_t *a, uint64_t *b, uint64_t n, int bits,
     dst = t;
   }
   *result = src;
+  return 0;
+}
+
+// the same with a u32 value per key (va / vb ping-pong with the keys); *vresult = the values beside *result
+static inline int radix_sort_pairs_u64(uint64_t *a, uint64_t *b, uint32_t *va, uint32_t *vb, uint64_t n, int bits, void *scratch,
+                                       hipStream_t st, uint64_t **result, uint32_t **vresult) {
+  *result = a;
+  *vresult = va;
+  if (n == 0) return 0;
+  const uint64_t n_tiles = radix_tiles(n);
+  if (n_tiles > 0x7FFFFFFFull) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "radix_sort_pairs_u64: %llu keys", (unsigned long long)n);
+  RadixScratch s = radix_carve(scratch, n);
+  uint64_t *src = a, *dst = b;
+  uint32_t *vsrc = va, *vdst = vb;
+  for (int shift = 0; shift < bits; shift += 8) {
+    radix_count_kernel<0><<<dim3((uint32_t)n_tiles), dim3(256), 0, st>>>(src, n, shift, n_tiles, s.counts);
+    KPOP_LAUNCH_CHECK();
+    KPOP_TRY(exclusive_scan(LoadCounts{s.counts}, StoreBases{s.bases}, n_tiles * 256, s.sums, st));
+    radix_scatter_kernel<1><<<dim3((uint32_t)n_tiles), dim3(256), 0, st>>>(src, dst, n, shift, n_tiles, s.bases, vsrc, vdst);
+    KPOP_LAUNCH_CHECK();
+    std::swap(src, dst);
+    std::swap(vsrc, vdst);
+  }
+  *result = src;
+  *vresult = vsrc;
   return 0;
 }
 

@@ -12,7 +12,8 @@
 // Binary registers (-i/-a/-o, and the twisted operand of -d/-s) are OCaml Marshal streams, read and written
 // by ocaml_marshal.cpp; if '<prefix>.KPopTwisted' does not exist, -d/-s fall back to '<prefix>.KPopTwisted.txt'.
 //   -e  Matrix.get_embeddings            lib/Matrix.ml:78-128    -> kpop_embeddings  (register 'e', '.KPopVectors')
-// Not covered: splits (-p, register 's'): they are built on BiOCamLib's Trees.Splits, which is not in the checkout.
+//   -p  Matrix.get_splits                lib/Matrix.ml:524-612   -> kpop_splits_gaps (gaps) / host/splits.cpp (centroids);
+//       register 's' is written as text only ('.PhyloSplits.txt', container declared in splits.h)
 // Runtime failures exit 1 (the reference prints the exception and exits 0).
 #include <stdio.h>
 #include <stdlib.h>
@@ -37,6 +38,7 @@
 #include "gpu_workers.h"
 #include "kpop_text.h"
 #include "ocaml_marshal.h"
+#include "splits.h"
 
 using namespace kpop_host;
 
@@ -60,7 +62,8 @@ struct Action {
   enum Kind {
     Empty, TablesToRegister, AddTablesToRegister, BinaryToRegister, AddBinaryToRegister, RegisterToBinary, SetKmersNormalize, AddKmersFiles, RegisterToTables,
     SetPrecision, SetDistance, SetDistanceNormalize, SetMetric, DistancesFromTwisted, SetSummaryKeepAtMost,
-    SummaryFromTwisted, SummaryFromDistances, EmbeddingsFromTwisted, Unsupported
+    SummaryFromTwisted, SummaryFromDistances, EmbeddingsFromTwisted, SetSplitsAlgorithm, SetSplitsKeepAtMost, SetPrecisionSplits,
+    SplitsFromEmbeddings, Unsupported
   } kind;
   Reg reg = Reg::Twisted;
   std::string s1, s2;
@@ -145,7 +148,8 @@ void usage(FILE *f) {
           " -a|--add t|d <binary_prefix>             add the rows of a binary register\n"
           " -o|--output T|t|d <binary_prefix>        write the register in binary form\n"
           " -e|--embeddings|--compute-embeddings|--twisted-to-embeddings   twisted register -> embeddings register ('e')\n"
-          "Splits (-p, register 's') are not provided by this tool.\n",
+          " -p|--splits|--compute-splits|--embeddings-to-splits   embeddings register -> splits register ('s'); -O s <prefix> writes '.PhyloSplits.txt'\n"
+          " --splits-algorithm gaps|centroids (default gaps)  --splits-keep-at-most <n> (default 10000)  --precision-for-splits <n> (default 10)\n",
           kVersion);
 }
 
@@ -586,11 +590,19 @@ int main(int argc, char **argv) {
       } else if (a == "-e" || a == "--embeddings" || a == "--compute-embeddings" || a == "--twisted-to-embeddings") {
         act.kind = Action::EmbeddingsFromTwisted;
       } else if (a == "-p" || a == "--splits" || a == "--compute-splits" || a == "--embeddings-to-splits") {
-        act.kind = Action::Unsupported;
-        act.s1 = a;
-      } else if (a == "--splits-algorithm" || a == "--splits-at-most" || a == "--splits-keep-at-most" || a == "--precision-for-splits") {
-        need(i, a);
-        continue;
+        act.kind = Action::SplitsFromEmbeddings;
+      } else if (a == "--splits-algorithm") {  // bin/KPopTwistDB.ml:234-239
+        act.kind = Action::SetSplitsAlgorithm;
+        act.s1 = need(i, a);
+        if (act.s1 != "gaps" && act.s1 != "centroids") parse_error("Unknown_algorithm(\"" + act.s1 + "\")");
+      } else if (a == "--splits-at-most" || a == "--splits-keep-at-most") {  // :240-246
+        act.kind = Action::SetSplitsKeepAtMost;
+        act.num = atoll(need(i, a).c_str());
+        if (act.num <= 0) parse_error("the number of splits to keep must be a positive integer");
+      } else if (a == "--precision-for-splits") {
+        act.kind = Action::SetPrecisionSplits;
+        act.num = atoll(need(i, a).c_str());
+        if (act.num <= 0) parse_error("precision must be positive");
       } else if (a == "-T" || a == "--threads") {
         need(i, a);
         continue;
@@ -681,8 +693,10 @@ int main(int argc, char **argv) {
   Metric metric;
   Distance distance;
   bool kmers_normalize = true, distance_normalize = true;  // bin/KPopTwistDB.ml:87-98
-  long long keep_at_most = 2;
-  int precision = 15;
+  long long keep_at_most = 2, splits_keep_at_most = 10000;
+  int precision = 15, precision_splits = 10;
+  std::string splits_algorithm = "gaps";
+  Splits splits;
   try {
     for (const Action &a : program) {
       stage_mark("KPopTwistDB", "-- next action");
@@ -721,10 +735,37 @@ int main(int argc, char **argv) {
           else if (a.reg == Reg::Twisted) write_binary_matrix(make_filename(a.s1, "KPopTwisted", false), "KPopTwisted", twisted);
           else if (a.reg == Reg::Distances) write_binary_matrix(make_filename(a.s1, "KPopDMatrix", false), "KPopDMatrix", distances);
           else if (a.reg == Reg::Embeddings) write_binary_matrix(make_filename(a.s1, "KPopVectors", false), "KPopVectors", embeddings);
-          else throw Error("splits are not provided by this tool");
+          else throw Error("binary splits ('.PhyloSplits' is BiOCamLib's Marshal of Trees.Splits.t, absent from the reference checkout) are not provided: use -O s");
           break;
         case Action::Unsupported:
-          throw Error("action '" + a.s1 + "' (splits) is not provided by this tool");
+          throw Error("action '" + a.s1 + "' is not provided by this tool");
+        case Action::SetSplitsAlgorithm: splits_algorithm = a.s1; break;
+        case Action::SetSplitsKeepAtMost: splits_keep_at_most = a.num; break;
+        case Action::SetPrecisionSplits: precision_splits = (int)a.num; break;
+        case Action::SplitsFromEmbeddings: {  // bin/KPopTwistDB.ml:503-506 -> Matrix.get_splits, lib/Matrix.ml:524-612
+          const size_t n = embeddings.rows(), d = embeddings.cols();
+          if (splits_algorithm == "centroids") {
+            splits = splits_centroids(embeddings.row_names, embeddings.data.data(), d, verbose);
+          } else {
+            need_gpu();
+            splits = Splits();
+            splits.names = embeddings.row_names;
+            const uint32_t want = (uint32_t)std::min<long long>(splits_keep_at_most, 0x7FFFFFFFll);
+            std::vector<double> gap(want ? want : 1);
+            std::vector<uint32_t> dim(want ? want : 1), idx(want ? want : 1), perm(std::max<size_t>(1, n * d));
+            uint32_t got = 0;
+            if (n > 1 && d > 0)
+              check(kpop_splits_gaps(embeddings.data.data(), (uint32_t)n, (uint32_t)d, want, &got, gap.data(), dim.data(), idx.data(), perm.data()));
+            for (uint32_t s = 0; s < got; ++s) {  // :594-598
+              Splits::Split sp;
+              sp.weight = gap[s];
+              sp.members.assign(perm.begin() + (size_t)dim[s] * n, perm.begin() + (size_t)dim[s] * n + idx[s] + 1);
+              std::sort(sp.members.begin(), sp.members.end());
+              splits.splits.push_back(std::move(sp));
+            }
+          }
+          break;
+        }
         case Action::EmbeddingsFromTwisted: {  // bin/KPopTwistDB.ml:494-498
           need_gpu();
           std::vector<double> mv = metric_vector(metric, T);
@@ -774,8 +815,8 @@ int main(int argc, char **argv) {
             write_table(make_filename(a.s1, "KPopMetrics", true), m, precision);
           } else if (a.reg == Reg::Embeddings) {
             write_table(make_filename(a.s1, "KPopVectors", true), embeddings, precision);
-          } else {
-            throw Error("splits are not provided by this tool");
+          } else {  // Trees.Splits.to_file ~precision:!precision_splits, bin/KPopTwistDB.ml:534-535 (format declared in splits.h)
+            write_splits(make_filename(a.s1, "PhyloSplits", true), splits, precision_splits);
           }
           break;
         case Action::DistancesFromTwisted: {  // bin/KPopTwistDB.ml:542-546

@@ -299,3 +299,130 @@ def counter_combine(columns, sel, col_sum, criterion="mean"):
         t &= 0xFFFFFFFF
         out.append(t - (1 << 32) if t >= (1 << 31) else t)
     return out, norm
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# phylogenetic splits from embeddings: Matrix.get_splits, lib/Matrix.ml:524-612
+# ---------------------------------------------------------------------------------------------------------------
+def splits_gaps(emb, max_splits):
+    """SplitsAlgorithm.Gaps (:527-600).  emb: rows of floats.  -> [(gap, sorted member rows)] in the reference's order: gaps by
+    decreasing size, then dimension, then position.  Equal coordinates keep ascending row order (OCaml's Array.sort leaves the
+    order of equal elements open; declared, see kpop_amd/csrc/splits.hip)."""
+    n = len(emb)
+    d = len(emb[0]) if n else 0
+    perms, gaps = [], []
+    for i in range(d):
+        col = sorted(((emb[r][i] + 0.0, r) for r in range(n)), key=lambda t: (t[0], t[1]))  # +0.0: -0. and 0. compare equal
+        perms.append([r for _, r in col])
+        gaps.extend((col[j + 1][0] - col[j][0], i, j) for j in range(n - 1))  # :571
+    gaps.sort(key=lambda t: (-t[0], t[1], t[2]))  # :590-601
+    return [(g, sorted(perms[i][:j + 1])) for g, i, j in gaps[:max_splits]]
+
+
+class _SplitMix:
+    """the declared stand-in for OCaml's Random (kpop_amd/host/splits.h)"""
+
+    def __init__(self, seed):
+        self.s = seed & 0xFFFFFFFFFFFFFFFF
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return z ^ (z >> 31)
+
+    def boolean(self):
+        return bool(self.next() & 1)
+
+    def integer(self, n):
+        return self.next() % n
+
+    def unit(self):
+        return (self.next() >> 11) * (1.0 / 9007199254740992.0)
+
+
+def _bipartition(emb, d, elements, rng):
+    """SplitsAlgorithm.Bipartition.make (:361-521), acceptance_probability_at_zero 0.2, difference_magnification_factor 10"""
+    inverse_acceptance, negative_scale = (1. - 0.2) / 0.2, -10.
+    one, two = set(), set()
+    c1, c2 = [0.] * d, [0.] * d
+    for i in elements:  # IntSet.iter: ascending
+        v = emb[i]
+        if rng.boolean():
+            two.add(i)
+            c2 = [a + b for a, b in zip(c2, v)]
+        else:
+            one.add(i)
+            c1 = [a + b for a, b in zip(c1, v)]
+
+    def objective_of():
+        n1, n2 = float(len(one)), float(len(two))
+        res = 0.
+        if n1 > 0. and n2 > 0.:
+            for s1, s2 in zip(c1, c2):
+                a = s1 / n1 if n1 > 1. else s1
+                b = s2 / n2 if n2 > 1. else s2
+                res = res + (max(a, b) - min(a, b))
+        return res / math.sqrt(1. + abs(n1 - n2))
+    objective = objective_of()
+    best = (objective, set(one), set(two))
+    terminator, rejected = max(len(elements), 40), 0
+    while rejected < terminator:
+        old_objective, o1, o2 = objective, c1, c2
+        selected = elements[rng.integer(len(elements))]
+        v = emb[selected]
+        from_one = selected in one
+        if from_one:
+            one.remove(selected)
+            two.add(selected)
+            c1 = [a - b for a, b in zip(o1, v)]
+            c2 = [a + b for a, b in zip(o2, v)]
+        else:
+            two.remove(selected)
+            one.add(selected)
+            c2 = [a - b for a, b in zip(o2, v)]
+            c1 = [a + b for a, b in zip(o1, v)]
+        objective = objective_of()
+        delta = objective - old_objective
+        score = 1. / (1. + inverse_acceptance * math.exp(negative_scale * delta))
+        if rng.unit() <= score:
+            rejected = 0
+            if objective > best[0]:
+                best = (objective, set(one), set(two))
+        else:
+            rejected += 1
+            if from_one:
+                two.remove(selected)
+                one.add(selected)
+            else:
+                one.remove(selected)
+                two.add(selected)
+            c1, c2, objective = o1, o2, old_objective
+    return best
+
+
+def splits_centroids(emb, seed=0x4B506F70):
+    """SplitsAlgorithm.Centroids (:601-612) -> [(weight, sorted member rows)] in the order the splits are added"""
+    d = len(emb[0]) if emb else 0
+    rng = _SplitMix(seed)
+    res = []
+
+    def refine(s):
+        if len(s) > 1:
+            objective, one, two = _bipartition(emb, d, sorted(s), rng)
+            res.append((objective, sorted(one)))
+            refine(one)
+            refine(two)
+        else:
+            res.append((0., sorted(s)))
+    refine(set(range(len(emb))))
+    return res
+
+
+def splits_text(names, splits, precision=10):
+    """'.PhyloSplits.txt' as declared in kpop_amd/host/splits.h"""
+    out = '""' + "".join('\t"%s"' % n for n in names) + "\n"
+    for w, members in splits:
+        out += "%.*g" % (precision, w) + "".join('\t"%s"' % names[m] for m in members) + "\n"
+    return out

@@ -343,3 +343,21 @@ def test_wave_summary_equals_block_summary(kpop, oracle, r1):
     api.tune("dbg", 0)
     for x, y in zip(res[0], res[4]):
         assert np.array_equal(x, y, equal_nan=True), r1
+
+
+def test_splits_gaps_golden_and_random(kpop, pyref):
+    """kpop_splits_gaps (per-dimension radix sorts + one stable sort of all gaps) against the restatement of
+    lib/Matrix.ml:527-600: same gaps bit for bit, same member sets, same order, ties included"""
+    from conftest import load_golden
+    g = load_golden("splits_small.json")
+    rng = np.random.RandomState(8)
+    cases = [([[float.fromhex(x) for x in row] for row in c["emb"]], c["keep"]) for c in g["cases"]]
+    big = np.round(rng.normal(size=(3000, 7)), 2)  # rounded: many equal coordinates and equal gaps
+    cases.append((big.tolist(), 500))
+    for emb, keep in cases:
+        gap, dim, idx, perm = kpop.splits_gaps(np.array(emb), keep)
+        want = pyref.splits_gaps(emb, keep)
+        assert len(gap) == len(want)
+        for s, (wg, wm) in enumerate(want):
+            assert gap[s].hex() == wg.hex(), s
+            assert sorted(perm[dim[s], :idx[s] + 1].tolist()) == wm, s

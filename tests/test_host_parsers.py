@@ -95,3 +95,25 @@ def test_row_ordering_matches_the_references_string_map(tmp_path):
             for rows, alphabet in ((0, 3), (1, 3), (40, 2), (3000, 6), (70000, 26)):
                 r = subprocess.run([str(out), str(seed), str(rows), str(alphabet)], capture_output=True, text=True, env=env)
                 assert r.returncode == 0, (threads, seed, rows, alphabet, r.stdout)
+
+
+def test_centroids_splits_match_the_python_restatement(tmp_path, pyref):
+    """SplitsAlgorithm.Centroids (lib/Matrix.ml:361-521,601-612): the drop-in's host implementation against oracle/pyref.py's,
+    both drawing from the declared SplitMix64 stream: same splits, same weights to the printed precision, same order"""
+    import numpy as np
+    from test_cli import write_table
+    out = tmp_path / "centroids_run"
+    host = os.path.join(ROOT, "kpop_amd", "host")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", "-ffp-contract=off", "-o", str(out), os.path.join(ROOT, "tests", "host", "centroids_run.cpp"),
+                    os.path.join(host, "splits.cpp"), os.path.join(host, "kpop_text.cpp")], check=True)
+    rng = np.random.RandomState(2)
+    for n, d in ((1, 3), (2, 2), (7, 3), (40, 5), (90, 9)):
+        centres = rng.normal(size=(4, d)) * 3
+        emb = np.array([centres[i % 4] + rng.normal(size=d) * 0.3 for i in range(n)])
+        emb = np.array([[float("%.15g" % x) for x in row] for row in emb])
+        names = ["leaf %d" % i for i in range(n)]
+        write_table(tmp_path / "e.txt", ["D%d" % i for i in range(d)], names, emb)
+        r = subprocess.run([str(out), str(tmp_path / "e.txt")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        want = pyref.splits_text(names, pyref.splits_centroids([list(map(float, row)) for row in emb]))
+        assert r.stdout == want, (n, d)

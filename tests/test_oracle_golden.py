@@ -248,3 +248,15 @@ def test_reference_distance_iterator_known_answer(oracle, pyref):
     assert {(min(i, j), max(i, j)) for i, j, _ in g["pairs"]} == want and len(g["pairs"]) == len(want)
     vals = [d[j, i] for i, j, _ in g["pairs"]]
     assert vals == sorted(vals)
+
+
+def test_splits_golden(pyref):
+    """the splits fixture is what the restatement of lib/Matrix.ml:524-612 gives today (regeneration would show a drift)"""
+    g = load_golden("splits_small.json")
+    for c in g["cases"]:
+        emb = [[float.fromhex(x) for x in row] for row in c["emb"]]
+        assert [[a.hex(), m] for a, m in pyref.splits_gaps(emb, c["keep"])] == c["gaps"]
+        assert [[a.hex(), m] for a, m in pyref.splits_centroids(emb)] == c["centroids"]
+        # structure: the largest gap first; a centroids run ends in one singleton split per leaf
+        assert all(float.fromhex(x[0]) >= float.fromhex(y[0]) for x, y in zip(c["gaps"], c["gaps"][1:]))
+        assert {m[0] for w, m in c["centroids"] if len(m) == 1 and float.fromhex(w) == 0.0} == set(range(len(emb)))
