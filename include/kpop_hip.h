@@ -213,10 +213,15 @@ uint64_t kpop_dev_count_reads_scratch_bytes(uint32_t n_reads, uint32_t max_len, 
 int kpop_dev_count_reads(const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads, uint32_t max_len,
                          int k, int content, void *d_scratch, uint64_t *d_out_hash, uint32_t *d_out_count,
                          uint64_t *d_out_offsets, void *stream);
-/* n_bases = offsets[n_reads] (size of d_bases), max_len = longest read in the batch: the host
-   knows both from the offsets it uploaded.  Reads of up to 512 windows take the one-wavefront-
+/* The library-owned workspace (segment partials here; distance rows of a chunk in kpop_dev_distance_summary
+   against a large first operand) is ONE per process: calls that use it must not run concurrently on two streams,
+   and the first call that needs more of it than any before synchronises the device to grow it.
+   kpop_dev_workspace_reserve(bytes) grows it ahead of time, after which those calls only enqueue.
+   n_bases = offsets[n_reads] (size of d_bases), max_len = longest read in the batch: the host
+   knows both from the offsets it uploaded (a read longer than max_len says comes back as a row of NaNs).  Reads of up to 512 windows take the one-wavefront-
    per-read kernel; longer sequences (genomes) the streaming kernel, whose segment partials
    live in a library-owned workspace (grown with hipMalloc on the first call that needs more). */
+int kpop_dev_workspace_reserve(uint64_t bytes);
 int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bases, const uint64_t *d_offsets,
                          uint32_t n_reads, uint64_t n_bases, uint32_t max_len, int content, int normalize,
                          double *d_out, void *stream);

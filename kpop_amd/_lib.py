@@ -69,6 +69,7 @@ SIGNATURES = {
     "kpop_dev_synth_reads": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, vp, vp, vp]),
     "kpop_dev_count_reads_scratch_bytes": (C.c_uint64, [C.c_uint32, C.c_uint32, C.c_int]),
     "kpop_dev_count_reads": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+    "kpop_dev_workspace_reserve": (C.c_int, [C.c_uint64]),
     "kpop_dev_count_twist": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.c_int, vp, vp]),
     "kpop_dev_twist": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int, vp, vp]),
     "kpop_dev_twist_dense_workspace_bytes": (C.c_uint64, [vp, C.c_uint32]),

@@ -274,7 +274,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void count_twist_wave_kernel(
   const uint64_t off = offsets[r];
   const uint32_t len = (uint32_t)(offsets[r + 1] - off);
   WaveLds<R, uint32_t> &L = lds[wv];
-  if (len >= (uint32_t)tv.hk && len - (uint32_t)tv.hk + 1 > 64u * R) return;  // count_twist_stream_kernel's business
+  if (len >= (uint32_t)tv.hk && len - (uint32_t)tv.hk + 1 > 64u * R) {
+    // count_twist_stream_kernel's business -- if the host scheduled it (bit 1 of `normalize`).  It does so from the
+    // caller's max_len; a max_len that understates the batch must not leave a row of stale memory behind: NaNs say so.
+    if (!(normalize & 2))
+      for (uint32_t d = lane; d < tv.n_dims; d += 64) out[(uint64_t)r * tv.n_dims + d] = __longlong_as_double(0x7FF8000000000000ll);
+    return;
+  }
+  normalize &= 1;
 
   wave_stage_codes<R>(bases + off, len, lane, L.codes);
   H hkey[R];
@@ -644,10 +651,11 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   const uint32_t max_windows = (max_len >= (uint32_t)tv.hk) ? max_len - tv.hk + 1 : 0;
   // reads of up to 512 windows: one wavefront per read (the kernel skips longer reads)
   const int R = pick_R(std::min(max_windows, kWaveMaxWindows));
+  const int flags = (normalize ? 1 : 0) | (max_windows > kWaveMaxWindows ? 2 : 0);  // bit 1: the streaming pass below takes the long ones
   if (tv.hk <= 15)
-    KPOP_TRY(launch_count_twist_wave<uint32_t>(R, tv, d_bases, d_offsets, nullptr, n_reads, content, normalize, d_out, st));
+    KPOP_TRY(launch_count_twist_wave<uint32_t>(R, tv, d_bases, d_offsets, nullptr, n_reads, content, flags, d_out, st));
   else
-    KPOP_TRY(launch_count_twist_wave<uint64_t>(R, tv, d_bases, d_offsets, nullptr, n_reads, content, normalize, d_out, st));
+    KPOP_TRY(launch_count_twist_wave<uint64_t>(R, tv, d_bases, d_offsets, nullptr, n_reads, content, flags, d_out, st));
   if (max_windows <= kWaveMaxWindows) return KPOP_OK;
   // longer sequences: segment table, streaming kernel, ordered combine.  Segment = the stretch of a sequence one block
   // sums: its rows should sit in one XCD's L2 (4 MB) next to those of the neighbouring segment, see the kernel.

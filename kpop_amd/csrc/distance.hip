@@ -892,8 +892,8 @@ extern "C" int kpop_dev_distance_rowwise(const double *d_m1, uint32_t r1, const 
   KPOP_TRY(require_init());
   KPOP_TRY(check_kind(kind, p, "kpop_dev_distance_rowwise"));
   if (r1 == 0 || r2 == 0) return KPOP_OK;
-  if (!d_m1 || !d_m2 || !d_metric || !d_out || (normalize && !d_work))
-    KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_distance_rowwise: null argument");
+  if (!d_m1 || !d_m2 || !d_metric || !d_out || ((normalize || n_dims >= kLongD) && !d_work))
+    KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_distance_rowwise: null argument (the workspace is needed when normalising and for rows of %u dimensions or more)", kLongD);
   if (n_dims == 0) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_distance_rowwise: n_dims must be positive");
   hipStream_t st = as_stream(stream);
   switch (kind) {

@@ -139,6 +139,12 @@ extern "C" int kpop_synchronize(void *stream) {
   return KPOP_OK;
 }
 
+extern "C" int kpop_dev_workspace_reserve(uint64_t bytes) {
+  KPOP_TRY(require_init());
+  void *p = nullptr;
+  return ctx().ws.ensure(bytes, &p);
+}
+
 extern "C" int kpop_dev_malloc(void **ptr, uint64_t bytes) {
   KPOP_TRY(require_init());
   if (!ptr) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_malloc: null ptr");

@@ -396,3 +396,29 @@ def test_dense_twist_on_the_matrix_cores_equals_the_sparse_one(kpop, oracle, k, 
         assert np.max(np.abs(a - b)) <= 1e-12 * max(np.max(np.abs(a)), 1.0)
         want = oracle.twist(oracle.synth_twister(5, d, cols), cols, h, v, o, normalize=normalize)
         assert np.max(np.abs(b - want)) <= 1e-12 * max(np.max(np.abs(want)), 1.0)
+
+
+def test_understated_max_len_yields_nan_rows_not_stale_memory(kpop, oracle):
+    """kpop_dev_count_twist trusts the caller's max_len to schedule the long-sequence pass; a read longer than it says
+    must come back as NaNs, and kpop_dev_distance_rowwise refuses a null workspace for very long rows"""
+    import torch
+    from kpop_amd import api
+    k, d = 10, 64
+    tw = kpop.Twister.synth(3, k, d)
+    seqs = ["ACGT" * 30, "ACGT" * 400, "TTGACC" * 20]
+    bases, offs = concat(seqs)
+    dev = torch.device("cuda", 0)
+    b, o = torch.from_numpy(bases).to(dev), torch.from_numpy(offs.view(np.int64)).to(dev)
+    out = torch.full((3, d), 7.0, dtype=torch.float64, device=dev)
+    api.dev_count_twist(tw, b.data_ptr(), o.data_ptr(), 3, b.numel(), 150, out.data_ptr())  # 150 < 1600
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.isnan(got[1]).all() and not np.isnan(got[0]).any() and not np.isnan(got[2]).any()
+    api.dev_count_twist(tw, b.data_ptr(), o.data_ptr(), 3, b.numel(), 1600, out.data_ptr())
+    torch.cuda.synchronize()
+    assert not np.isnan(out.cpu().numpy()).any()
+    m = torch.zeros(2, 40000, dtype=torch.float64, device=dev)
+    metric = torch.ones(40000, dtype=torch.float64, device=dev)
+    res = torch.zeros(2, 2, dtype=torch.float64, device=dev)
+    with pytest.raises(kpop.KPopError):
+        api.dev_distance_rowwise(m.data_ptr(), 2, m.data_ptr(), 2, 40000, metric.data_ptr(), None, res.data_ptr(), normalize=False)
