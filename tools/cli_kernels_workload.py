@@ -123,7 +123,7 @@ def main():
                                      idx.data_ptr(), dd.data_ptr(), zz.data_ptr(), keep_at_most=keep, max_neighbours=mx, stream=sp)
         torch.cuda.synchronize()
         if sec == "summary_65":
-            algo["distance_summary_kernel"] = {"bytes": (r1 + r2) * d * 8 + r2 * (32 + 4 + keep * 20), "flops": 4.0 * r1 * r2 * d,
+            algo["distance_summary"] = {"bytes": (r1 + r2) * d * 8 + r2 * (32 + 4 + keep * 20), "flops": 4.0 * r1 * r2 * d,
                                                "note": "both operands once + one summary row; f64 VALU-bound: 4 unfusable ops per pair and dimension"}
         else:
             algo["summary_large_kernel"] = {"bytes": r2 * r1 * 8, "note": "one pass over the r1 distances of each query row is the algorithmic minimum; the kernel makes several"}
