@@ -94,9 +94,11 @@ __device__ __forceinline__ int range_shift(uint64_t lo, uint64_t hi) {  // small
 }
 
 // All threads call with the same arguments.  s_hist: kSel * kBins u32; s_cand: kSel * kCand u64; s_misc: 64 u32.
-template <int TRANSFORM>
+// SUMSQ: the first pass over the row also adds up (row[i] - centre)^2 into *sumsq_part (this thread's share; the caller
+// reduces it) -- the sample variance rides on the first selection pass instead of a pass of its own.
+template <int TRANSFORM, bool SUMSQ = false>
 __device__ void block_select_ranks(const double *row, uint32_t n, double centre, Sel *sel, int n_sel, uint32_t *s_hist,
-                                   uint64_t *s_cand, uint32_t *s_misc) {
+                                   uint64_t *s_cand, uint32_t *s_misc, double *sumsq_part = nullptr) {
   for (int round = 0; round < 8; ++round) {
     bool any = false;
     for (int t = 0; t < n_sel; ++t) any = any || !sel[t].done;
@@ -106,11 +108,17 @@ __device__ void block_select_ranks(const double *row, uint32_t n, double centre,
     __syncthreads();
     int shift[kSel];
     for (int t = 0; t < n_sel; ++t) shift[t] = range_shift(sel[t].lo, sel[t].hi);
+    double sq = 0.0;
     for (uint32_t i = threadIdx.x; i < n; i += kLT) {
       const uint64_t k = elem_key<TRANSFORM>(row, i, centre);
+      if (SUMSQ && round == 0) {
+        const double dv = __dsub_rn(row[i], centre);
+        sq = __dadd_rn(sq, __dmul_rn(dv, dv));
+      }
       for (int t = 0; t < n_sel; ++t)
         if (!sel[t].done && k >= sel[t].lo && k <= sel[t].hi) atomicAdd(&s_hist[t * kBins + (uint32_t)((k - sel[t].lo) >> shift[t])], 1u);
     }
+    if (SUMSQ && round == 0) *sumsq_part = sq;
     __syncthreads();
     // the bin of each rank (one thread per selection walks 2048 counters)
     if (threadIdx.x < (uint32_t)n_sel && !sel[threadIdx.x].done) {
@@ -236,24 +244,20 @@ __global__ __launch_bounds__(kLT) void summary_large_kernel(const double *__rest
     kmin = min(kmin, s_mm[w]);
     kmax = max(kmax, s_mm[kLT / 64 + w]);
   }
-  // pass 2 (inside the first selection pass would save a read; kept apart for clarity of the sums): sample sd (:657-662,679-683)
-  part = 0.0;
-  for (uint32_t i = threadIdx.x; i < n; i += kLT) {
-    const double dv = __dsub_rn(row[i], mean);
-    part = __dadd_rn(part, __dmul_rn(dv, dv));
-  }
-  const double ss = block_sum(part, s_w);
-  const double sd = (n > 1) ? sqrt(ss / ((double)n - 1.0)) : 0.0;
   // upper median = element n/2 of the sorted row (:645-647), and the value that closes the neighbour list: groups are
-  // added while eff_len < req_len (:648-649), so eff_len = (#less + #equal) of the element of rank req_len - 1
-  double median = 0.0, mad = 0.0;
+  // added while eff_len < req_len (:648-649), so eff_len = (#less + #equal) of the element of rank req_len - 1.  The
+  // squared deviations of the sample sd (:657-662,679-683) are added up by the first of these passes.
+  double median = 0.0, mad = 0.0, sd = 0.0;
   uint32_t eff = n;
   Sel sel[kSel];
   if (n) {
     sel[0] = Sel{n / 2, kmin, kmax, 0, 0, 0, 0, 0};
     const bool cut = req_len < n;
     sel[1] = Sel{cut ? req_len - 1 : 0, kmin, kmax, 0, 0, 0, 0, cut ? 0 : 1};
-    block_select_ranks<0>(row, n, 0.0, sel, 2, s_hist, s_cand, s_misc);
+    double sq = 0.0;
+    block_select_ranks<0, true>(row, n, mean, sel, 2, s_hist, s_cand, s_misc, &sq);
+    const double ss = block_sum(sq, s_w);
+    sd = (n > 1) ? sqrt(ss / ((double)n - 1.0)) : 0.0;
     median = key_f64(sel[0].value);
     if (cut) eff = sel[1].n_less + sel[1].n_equal;
   }
@@ -323,30 +327,11 @@ __global__ __launch_bounds__(kLT) void summary_large_kernel(const double *__rest
       out_z[(uint64_t)j * max_neighbours + q] = zz;
     }
   }
-  // MAD = element n/2 of |d - median| (:671-678): its key range first, then the same selection
+  // MAD = element n/2 of |d - median| (:671-678).  Its keys lie between 0 and the larger of the two distances from the
+  // median to the ends of the row's range: known without a pass
   if (n) {
-    uint64_t amin = ~0ull, amax = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += kLT) {
-      const uint64_t k = elem_key<1>(row, i, median);
-      amin = min(amin, k);
-      amax = max(amax, k);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      amin = min(amin, (uint64_t)__shfl_xor((unsigned long long)amin, o, 64));
-      amax = max(amax, (uint64_t)__shfl_xor((unsigned long long)amax, o, 64));
-    }
-    __syncthreads();
-    if (lane == 0) {
-      s_mm[wv] = amin;
-      s_mm[kLT / 64 + wv] = amax;
-    }
-    __syncthreads();
-    for (int w = 0; w < kLT / 64; ++w) {
-      amin = min(amin, s_mm[w]);
-      amax = max(amax, s_mm[kLT / 64 + w]);
-    }
-    Sel sm[1] = {Sel{n / 2, amin, amax, 0, 0, 0, 0, 0}};
+    const double far = fmax(fabs(__dsub_rn(key_f64(kmax), median)), fabs(__dsub_rn(key_f64(kmin), median)));
+    Sel sm[1] = {Sel{n / 2, f64_key(0.0), f64_key(far), 0, 0, 0, 0, 0}};
     block_select_ranks<1>(row, n, median, sm, 1, s_hist, s_cand, s_misc);
     mad = key_f64(sm[0].value);
   }

@@ -168,7 +168,7 @@ extern "C" int kpop_twister_load(const double *T_dims_major, uint64_t n_cols, ui
     if (col_hash[c] > lim) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_twister_load: a column hash does not fit k=%d", k);
     hc[c] = {col_hash[c], (uint32_t)c};
   }
-  std::sort(hc.begin(), hc.end());
+  if (!std::is_sorted(hc.begin(), hc.end())) std::sort(hc.begin(), hc.end());  // KPopTwist writes its columns in ascending name order
   std::vector<uint64_t> sorted_hash;
   std::vector<uint32_t> dst_row(n_cols, kNoCol);
   sorted_hash.reserve(n_cols);
@@ -191,23 +191,41 @@ extern "C" int kpop_twister_load(const double *T_dims_major, uint64_t n_cols, ui
   if (tw->n_rows) KPOP_HIP(hipMemcpyAsync(d_hash.p, sorted_hash.data(), tw->n_rows * 8, hipMemcpyHostToDevice, st));
   if (n_cols) KPOP_HIP(hipMemcpyAsync(d_dst.p, dst_row.data(), n_cols * 4, hipMemcpyHostToDevice, st));
 
-  // --- rows: chunked H2D of the dims-major slabs + device transpose into rank order
+  // --- rows: H2D of the dims-major matrix + device transpose into rank order.  Up to 8 GB the matrix goes over in ONE
+  // copy (it is contiguous on the host; n_dims x chunks small copies with a synchronisation per chunk ran at ~6 GB/s on a
+  // 0.9 GB twister, a third of what one large pageable copy gets) and is transposed from there; beyond, in slabs.
   if (n_cols) {
-    const uint64_t budget = 256ull << 20;  // staging bytes
-    uint64_t chunk = std::max<uint64_t>(32, budget / (8ull * n_dims));
-    chunk = std::min<uint64_t>(chunk, n_cols);
-    DevBuf tmp;
-    KPOP_TRY(tmp.alloc(chunk * n_dims * 8));
-    for (uint64_t c0 = 0; c0 < n_cols; c0 += chunk) {
-      uint64_t cn = std::min<uint64_t>(chunk, n_cols - c0);
-      for (uint32_t d = 0; d < n_dims; ++d)
-        KPOP_HIP(hipMemcpyAsync(tmp.as<double>() + (uint64_t)d * cn, T_dims_major + (uint64_t)d * n_cols + c0,
-                                cn * 8, hipMemcpyHostToDevice, st));
-      dim3 grid(div_up(cn, 32), div_up(tw->d_pad, 32));
-      transpose_chunk_kernel<<<grid, dim3(256), 0, st>>>(tmp.as<double>(), cn, n_dims, tw->d_pad, d_dst.as<uint32_t>(),
-                                                         tw->d_rows, c0);
-      KPOP_LAUNCH_CHECK();
-      KPOP_HIP(hipStreamSynchronize(st));
+    const uint64_t whole = (uint64_t)n_cols * n_dims * 8;
+    void *full = nullptr;
+    if (whole <= (8ull << 30) && hipMalloc(&full, whole) == hipSuccess) {
+      hipError_t e = hipMemcpyAsync(full, T_dims_major, whole, hipMemcpyHostToDevice, st);
+      if (e == hipSuccess) {
+        dim3 grid(div_up(n_cols, 32), div_up(tw->d_pad, 32));
+        transpose_chunk_kernel<<<grid, dim3(256), 0, st>>>(reinterpret_cast<const double *>(full), n_cols, n_dims, tw->d_pad,
+                                                           d_dst.as<uint32_t>(), tw->d_rows, 0);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      (void)hipFree(full);
+      if (e != hipSuccess) KPOP_FAIL(KPOP_ERR_HIP, "kpop_twister_load: %s", hipGetErrorString(e));
+    } else {
+      (void)hipGetLastError();  // a failed hipMalloc of the staging copy is not an error: fall back to slabs
+      const uint64_t budget = 256ull << 20;  // staging bytes
+      uint64_t chunk = std::max<uint64_t>(32, budget / (8ull * n_dims));
+      chunk = std::min<uint64_t>(chunk, n_cols);
+      DevBuf tmp;
+      KPOP_TRY(tmp.alloc(chunk * n_dims * 8));
+      for (uint64_t c0 = 0; c0 < n_cols; c0 += chunk) {
+        uint64_t cn = std::min<uint64_t>(chunk, n_cols - c0);
+        for (uint32_t d = 0; d < n_dims; ++d)
+          KPOP_HIP(hipMemcpyAsync(tmp.as<double>() + (uint64_t)d * cn, T_dims_major + (uint64_t)d * n_cols + c0,
+                                  cn * 8, hipMemcpyHostToDevice, st));
+        dim3 grid(div_up(cn, 32), div_up(tw->d_pad, 32));
+        transpose_chunk_kernel<<<grid, dim3(256), 0, st>>>(tmp.as<double>(), cn, n_dims, tw->d_pad, d_dst.as<uint32_t>(),
+                                                           tw->d_rows, c0);
+        KPOP_LAUNCH_CHECK();
+        KPOP_HIP(hipStreamSynchronize(st));
+      }
     }
   }
 
