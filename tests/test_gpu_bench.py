@@ -39,3 +39,9 @@ def test_config4_two_ranks_on_one_gpu():
 def test_config4_through_rccl_world_size_1():
     j = _bench(["--workload", "config4", "--force-dist", "--reads", "30000", "--steps", "2", "--warmup", "1", "--queries", "32"])
     assert j["scaling"] == "strong" and j["collective"]["backend"].startswith("nccl") and j["gather_checksum_ok"] is True
+
+
+def test_round_one_mode_still_runs_two_ranks():
+    j = _bench(["--gpus", "2", "--workload", "headline", "--scaling", "weak", "--reads", "20000", "--steps", "2", "--warmup", "1"],
+               env={"KPOP_BENCH_SHARE_GPU": "1"})
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["reads_per_gpu"] == 20000

@@ -147,3 +147,45 @@ def test_worker_processes_one_per_gpu(tmp_path, oracle):
     r = subprocess.run("%s -k %d -L -f %s | %s -I T %s -k /dev/stdin -o t %s" % (COUNT, k, fa, TWISTDB, tmp_path / "Missing", tmp_path / "x"),
                        shell=True, capture_output=True, text=True, env=dict(os.environ, KPOP_DEVICES="2", KPOP_PIPE_FORMAT="reads"))
     assert r.returncode != 0 and "cannot open" in r.stderr
+
+
+def test_reads_stream_fastq_and_mates(tmp_path, oracle):
+    """single-end and paired-end FASTQ through the reads stream: the same bytes as through text spectra (mates alternate,
+    bin/KPopCount.ml:36-54, and share their tag: the consumer's Duplicate_label is the reference's behaviour there)"""
+    from test_gpu_cli import write_fastq
+    rng = np.random.RandomState(5)
+    k, d = 7, 33
+    make_twister(tmp_path, oracle, k, d, keep=0.5)
+    r1 = [("a%d" % i, "".join(rng.choice(list("ACGTN"), size=int(rng.randint(0, 160))))) for i in range(50)]
+    r2 = [("b%d" % i, "".join(rng.choice(list("ACGT"), size=int(rng.randint(0, 160))))) for i in range(50)]
+    f1, f2 = tmp_path / "x_1.fastq", tmp_path / "x_2.fastq"
+    write_fastq(f1, r1)
+    write_fastq(f2, r2)
+    outs = {}
+    for fmt in ("reads", "text"):
+        env = dict(os.environ, KPOP_PIPE_FORMAT=fmt, KPOP_SEQ_BLOCK="2000")
+        for name, inputs in (("se", "-s %s -s %s" % (f1, f2)), ("pe", "-p %s %s" % (f1, f2))):
+            r = subprocess.run("%s -k %d -L %s | %s -I T %s -k /dev/stdin -o t %s" % (COUNT, k, inputs, TWISTDB, tmp_path / "Classes", tmp_path / (name + fmt)),
+                               shell=True, capture_output=True, text=True, env=env)
+            assert r.returncode == 0, r.stderr
+            outs[name, fmt] = (tmp_path / (name + fmt + ".KPopTwisted")).read_bytes()
+    assert outs["se", "reads"] == outs["se", "text"] and outs["pe", "reads"] == outs["pe", "text"]
+    assert len(outs["pe", "reads"]) == len(outs["se", "reads"])  # the same 100 sequences either way
+
+
+def test_reads_stream_empty_and_degenerate_inputs(tmp_path, oracle):
+    """an empty FASTA, a FASTA of header-only and too-short records: the reads stream and the text pipeline agree (both leave
+    an empty or all-zero register behind, no error)"""
+    k, d = 6, 40
+    make_twister(tmp_path, oracle, k, d)
+    (tmp_path / "empty.fa").write_text("")
+    write_fasta(tmp_path / "short.fa", [("only-header", ""), ("tiny", "ACG"), ("allN", "NNNNNNNNNNNN")])
+    for name in ("empty", "short"):
+        outs = []
+        for fmt in ("reads", "text"):
+            rc1, rc2, e1, e2 = _pipeline(tmp_path, tmp_path / (name + ".fa"), k, name + fmt, fmt, table=True)
+            assert rc1 == 0 and rc2 == 0, (name, fmt, e1, e2)
+            outs.append((tmp_path / (name + fmt + ".KPopTwisted.txt")).read_bytes())
+        assert outs[0] == outs[1], name
+    rows = (tmp_path / "shortreads.KPopTwisted.txt").read_text().splitlines()
+    assert len(rows) == 4 and all(set(l.split("\t")[1:]) == {"0"} for l in rows[1:])
