@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "kmer.h"
+#include "lookback.h"
 #include "read_hash.h"
 #include "scan.h"
 #include "sort_count.h"
@@ -26,6 +27,7 @@ namespace kpop {
 constexpr int kWavesPerBlock = 4;
 constexpr int kGatherUnroll = 8;   // row loads in flight per wave in the streaming kernels
 constexpr int kGatherPad = 16;     // LDS padding: the deepest gather unroll
+constexpr uint32_t kFewSpectra = 32768;  // below this many spectra twist_csr_kernel keeps 32 row loads in flight per wave
 
 // ---------------------------------------------------------------------------
 // per-wave LDS
@@ -52,53 +54,6 @@ struct WaveLds {
 // order.  Round 1 wrote fixed-stride scratch rows, scanned the per-read counts in three launches and compacted in a
 // fifth: 12 B x 256 slots per read written and read back.
 // ---------------------------------------------------------------------------
-constexpr uint64_t kLookbackValueMask = (1ull << 62) - 1;
-
-// exclusive prefix of `total` over the blocks with a smaller ticket; every lane of the calling wave gets it
-__device__ __forceinline__ uint64_t lookback_exclusive(uint64_t *state, uint32_t ticket, uint64_t total, int lane, int naps) {
-  if (ticket == 0) {
-    if (lane == 0) __hip_atomic_store(&state[0], (2ull << 62) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return 0;
-  }
-  if (lane == 0) __hip_atomic_store(&state[ticket], (1ull << 62) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  uint64_t acc = 0;
-  int64_t top = (int64_t)ticket - 1;  // nearest predecessor not yet added
-  // kLookWords words per lane: a step covers 64 x kLookWords predecessors, so the chain of prefixes moves that many
-  // blocks per round trip to memory (with one word per lane it moved slower than the blocks finished their reads)
-  constexpr int kLookWords = 8;
-  for (;;) {
-    uint64_t w[kLookWords];
-    for (;;) {
-      bool ready = true;
-#pragma unroll
-      for (int j = 0; j < kLookWords; ++j) {
-        const int64_t idx = top - j * 64 - lane;
-        w[j] = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (3ull << 62);
-        ready = ready && (w[j] >> 62) != 0;
-      }
-      if (ready) break;
-      for (int z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(8);
-    }
-    bool done = false;
-#pragma unroll
-    for (int j = 0; j < kLookWords; ++j) {
-      if (done) break;  // wave-uniform
-      const int64_t idx = top - j * 64 - lane;
-      const uint64_t full = __ballot((w[j] >> 62) == 2);
-      const int stop = full ? __ffsll((long long)full) - 1 : 64;  // nearest lane holding an inclusive prefix
-      uint64_t v = (lane <= stop && idx >= 0) ? (w[j] & kLookbackValueMask) : 0;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, o, 64);
-      acc += v;
-      done = full != 0;
-    }
-    if (done || top - 64 * kLookWords < 0) break;
-    top -= 64 * kLookWords;
-  }
-  if (lane == 0) __hip_atomic_store(&state[ticket], (2ull << 62) | (acc + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return acc;
-}
-
 // reads per wave: the sorted keys of a wave's reads wait in registers (R per lane and read) for the block's prefix
 template <int R>
 constexpr int reads_per_wave() { return R <= 2 ? 8 : (R == 4 ? 4 : 2); }
@@ -308,7 +263,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void count_twist_wave_kernel(
 // the same up to rounding) -- see DESIGN.md "twist_csr".  acc is a wave
 // reduction, exact for integer counts.
 // ---------------------------------------------------------------------------
-template <typename V>  // double: spectra as parsed from text; uint32_t: counts straight from the counting kernels
+// U = row loads in flight per wave: 8 when there is a wave per SIMD slot anyway (read spectra by the hundred thousand), 32
+// when a few thousand long spectra leave two waves per SIMD and the latency of each batch of loads shows (genomes).
+template <typename V, int U = kGatherUnroll>  // V double: spectra as parsed from text; uint32_t: counts straight from the counting kernels
 __global__ __launch_bounds__(64 * kWavesPerBlock) void twist_csr_kernel(
     TwisterView tv, const uint64_t *__restrict__ hash, const V *__restrict__ value,
     const uint64_t *__restrict__ offsets, uint32_t n, int normalize, double *__restrict__ out) {
@@ -350,17 +307,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void twist_csr_kernel(
       __builtin_amdgcn_wave_barrier();
       const uint32_t cnt = (uint32_t)min((uint64_t)64, hi - i0);
       const double *base = tv.rows + d;
-      for (uint32_t u0 = 0; u0 < cnt; u0 += kGatherUnroll) {
-        double v[kGatherUnroll];
+      for (uint32_t u0 = 0; u0 < cnt; u0 += U) {
+        double v[U];
 #pragma unroll
-        for (int j = 0; j < kGatherUnroll; ++j) {
+        for (int j = 0; j < U; ++j) {
           const uint32_t uu = min(u0 + j, 63u);
           const uint32_t c = s_col[wv][uu];
           const double xx = s_x[wv][uu];
           v[j] = (active && u0 + j < cnt && xx != 0.0) ? base[(uint64_t)c * tv.d_pad] : 0.0;
         }
 #pragma unroll
-        for (int j = 0; j < kGatherUnroll; ++j) {
+        for (int j = 0; j < U; ++j) {
           const uint32_t uu = min(u0 + j, 63u);
           const double xx = (u0 + j < cnt) ? s_x[wv][uu] : 0.0;
           t = __dadd_rn(t, __dmul_rn(v[j], xx));
@@ -727,8 +684,12 @@ extern "C" int kpop_dev_twist(const kpop_twister *tw, const uint64_t *d_hash, co
   (void)max_lines;
   if (!tw || !d_offsets || !d_out) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_twist: null argument");
   if (n_spectra == 0) return KPOP_OK;
-  twist_csr_kernel<double><<<dim3(div_up(n_spectra, kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, as_stream(stream)>>>(
-      view_of(tw), d_hash, d_value, d_offsets, n_spectra, normalize, d_out);
+  if (n_spectra <= kFewSpectra)
+    twist_csr_kernel<double, 32><<<dim3(div_up(n_spectra, kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, as_stream(stream)>>>(
+        view_of(tw), d_hash, d_value, d_offsets, n_spectra, normalize, d_out);
+  else
+    twist_csr_kernel<double><<<dim3(div_up(n_spectra, kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, as_stream(stream)>>>(
+        view_of(tw), d_hash, d_value, d_offsets, n_spectra, normalize, d_out);
   KPOP_LAUNCH_CHECK();
   return KPOP_OK;
 }
@@ -900,9 +861,14 @@ extern "C" int kpop_spectra_twist(const kpop_twister *tw, const uint8_t *bases, 
       ArenaScope batch;
       SortedSpectra S;
       KPOP_TRY(sorted_count_device(bases, offsets + r0, nr, k, content, 1, ~0ull, S, st));
-      twist_csr_kernel<uint32_t><<<dim3(div_up(nr, kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, st>>>(
-          tv, S.d_oh.as<uint64_t>(), S.d_oc.as<uint32_t>(), S.d_oo.as<uint64_t>(), nr, normalize,
-          d_out.as<double>() + r0 * tw->n_dims);
+      if (nr <= kFewSpectra)
+        twist_csr_kernel<uint32_t, 32><<<dim3(div_up(nr, kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, st>>>(
+            tv, S.d_oh.as<uint64_t>(), S.d_oc.as<uint32_t>(), S.d_oo.as<uint64_t>(), nr, normalize,
+            d_out.as<double>() + r0 * tw->n_dims);
+      else
+        twist_csr_kernel<uint32_t><<<dim3(div_up(nr, kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, st>>>(
+            tv, S.d_oh.as<uint64_t>(), S.d_oc.as<uint32_t>(), S.d_oo.as<uint64_t>(), nr, normalize,
+            d_out.as<double>() + r0 * tw->n_dims);
       KPOP_LAUNCH_CHECK();
       KPOP_HIP(hipStreamSynchronize(st));  // the batch's scratch goes back to the arena at the end of this scope
     }

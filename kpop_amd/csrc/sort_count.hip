@@ -16,6 +16,7 @@
 #include "radix_sort.h"
 #include "scan.h"
 
+#include "lookback.h"
 #include "sort_count.h"
 
 namespace kpop {
@@ -273,11 +274,256 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// -L on assemblies of up to 32,768 windows (a SARS-CoV-2 genome is 29,892 12-mers): ONE 1024-thread block per sequence,
+// everything in LDS.  The windows' hashes go into a 128 KB key array, are sorted there (bitonic network; invalid windows
+// carry the all-ones sentinel and end up last), runs of equal keys become (hash, count) pairs, and the block's place in
+// the CSR comes from the same ticket + look-back hand-off count_wave_kernel uses (lookback.h) -- a block works ~50 us,
+// so the hand-off costs nothing here.  The sequence is read once and its spectrum written once: no key array in HBM, no
+// radix passes (5 passes over 8 B per window before), no scans.  Longer sequences and hashes beyond 30 bits keep the
+// device-wide sort below.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kBlockSortMax = 32768;
+#define KEY(i) ((i) + ((i) >> 5))  // LDS index of key i: one word of padding per 32
+
+// one pass of the register-blocked bitonic network (count_block_kernel): 2^GB keys per (virtual) thread
+template <int GB>
+__device__ __forceinline__ void bitonic_group_pass(uint32_t *s_key, uint32_t NP, uint32_t sz, int h, int lo) {
+  constexpr int E = 1 << GB;
+  const uint32_t n_groups = NP >> GB;
+  for (uint32_t vt = threadIdx.x; vt < n_groups; vt += 1024) {
+    const uint32_t base = ((vt >> lo) << (h + 1)) | (vt & ((1u << lo) - 1u));
+    const bool asc = (base & sz) == 0;
+    uint32_t rk[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) rk[e] = s_key[KEY(base | ((uint32_t)e << lo))];
+#pragma unroll
+    for (int j = GB - 1; j >= 0; --j) {
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (!(e & (1 << j))) {
+          const uint32_t x = rk[e], y = rk[e | (1 << j)];
+          const uint32_t mn = min(x, y), mx = max(x, y);
+          rk[e] = asc ? mn : mx;
+          rk[e | (1 << j)] = asc ? mx : mn;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) s_key[KEY(base | ((uint32_t)e << lo))] = rk[e];
+  }
+}
+
+template <int SB>
+__global__ __launch_bounds__(1024) void count_block_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets,
+                                                           uint32_t n, int k, int content, uint32_t *__restrict__ ticket_counter,
+                                                           uint64_t *__restrict__ state, uint64_t *__restrict__ out_hash,
+                                                           uint32_t *__restrict__ out_count, uint64_t *__restrict__ out_offsets) {
+  extern __shared__ uint32_t s_key[];  // NP keys
+  __shared__ uint32_t s_ticket, s_wtot[16];
+  __shared__ uint64_t s_prefix;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_ticket = atomicAdd(ticket_counter, 1u);
+  __syncthreads();
+  const uint32_t r = s_ticket;
+  if (r >= n) return;
+  const uint64_t off = offsets[r], len = offsets[r + 1] - off;
+  const uint32_t n_win = len >= (uint64_t)k ? (uint32_t)(len - k + 1) : 0u;
+  uint32_t NP = 64;
+  while (NP < n_win) NP <<= 1;
+  const uint8_t *seq = bases + off;
+  const int shift = SB * (k - 1);
+  constexpr uint32_t kSym = (1u << SB) - 1u, kValid = SB == 2 ? 4u : 20u;
+  // a thread hashes NP / 1024 CONSECUTIVE windows, rolling the hash from one to the next (k - 1 + NP / 1024 base loads
+  // instead of k per window), and drops key i of its run at s_key[i * 1024 + thread]: before the sort any place is as
+  // good as any other, and this one has the lanes of a wave on consecutive banks
+  {
+    const uint32_t per_h = NP >= 1024 ? NP / 1024 : 1, w0 = threadIdx.x * per_h;
+    const uint32_t mask = (uint32_t)bits_mask(SB * k);
+    uint32_t fwd = 0, rc = 0;
+    int run = 0;
+    if (w0 < n_win)
+      for (int j = 0; j < k - 1; ++j) {
+        const uint64_t at = (uint64_t)w0 + j;
+        const uint32_t c = at < len ? (SB == 2 ? base_code(seq[at]) : protein_code(seq[at])) : kValid;
+        fwd = ((fwd << SB) | (c & kSym)) & mask;
+        if (SB == 2) rc = (rc >> 2) | ((3u - (c & 3u)) << shift);
+        run = c < kValid ? run + 1 : 0;
+      }
+    for (uint32_t i = 0; i < per_h; ++i) {
+      const uint32_t w = w0 + i;
+      uint32_t key = 0xFFFFFFFFu;
+      if (w < n_win) {
+        const uint32_t c = SB == 2 ? base_code(seq[w + k - 1]) : protein_code(seq[w + k - 1]);
+        fwd = ((fwd << SB) | (c & kSym)) & mask;
+        if (SB == 2) rc = (rc >> 2) | ((3u - (c & 3u)) << shift);
+        run = c < kValid ? run + 1 : 0;
+        if (run >= k) key = (SB == 2 && content == KPOP_DNA_DS && rc < fwd) ? rc : fwd;
+      }
+      const uint32_t slot = NP >= 1024 ? i * 1024u + threadIdx.x : w;
+      if (slot < NP && (NP >= 1024 || w < NP)) s_key[KEY(slot)] = key;
+    }
+  }
+  // Bitonic network over LDS, REGISTER-BLOCKED: a thread takes 2^g keys (g <= 5) whose indices differ in g consecutive
+  // bits, runs the g compare-exchange levels those bits stand for in registers, and puts the keys back -- one LDS round
+  // trip and one barrier per group of levels: 30 passes over the 128 KB for 32,768 keys where a level per pass takes 120
+  // (the sort is bound by LDS bandwidth: 2,048 cycles per pass).  Indices are padded by one word per 32 (KEY(i)), so the
+  // lowest group, where a lane's keys are 32 consecutive ones, does not put every lane of a wave on one bank.
+  {
+    int m = 0;
+    while ((1u << m) < NP) ++m;
+    const int G = min(5, max(1, m - 10));
+    for (int top = 0; top < m; ++top) {            // merge phase sz = 2^(top + 1): strides 2^top .. 1
+      const uint32_t sz = 2u << top;
+      for (int L = top + 1; L > 0;) {
+        const int g = min(G, L), h = L - 1, lo = h - g + 1;  // this pass: stride bits h .. lo
+        __syncthreads();
+        switch (g) {  // the group size is a compile-time constant inside: straight-line loads, no predication
+          case 5: bitonic_group_pass<5>(s_key, NP, sz, h, lo); break;
+          case 4: bitonic_group_pass<4>(s_key, NP, sz, h, lo); break;
+          case 3: bitonic_group_pass<3>(s_key, NP, sz, h, lo); break;
+          case 2: bitonic_group_pass<2>(s_key, NP, sz, h, lo); break;
+          default: bitonic_group_pass<1>(s_key, NP, sz, h, lo); break;
+        }
+        L -= g;
+      }
+    }
+  }
+  __syncthreads();
+  // heads of runs: thread-order prefix over the block, NP / 1024 consecutive positions per thread
+  const uint32_t per = NP / 1024 ? NP / 1024 : 1;
+  const uint32_t p0 = threadIdx.x * per;
+  uint32_t mine = 0;
+  for (uint32_t i = p0; i < p0 + per && i < NP; ++i) {
+    const uint32_t key = s_key[KEY(i)];
+    mine += (key != 0xFFFFFFFFu && (i == 0 || s_key[KEY(i - 1)] != key)) ? 1u : 0u;
+  }
+  uint32_t incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) s_wtot[wv] = incl;
+  __syncthreads();
+  uint32_t before = incl - mine, total = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wv) before += s_wtot[w];
+    total += s_wtot[w];
+  }
+  if (wv == 0) {
+    const uint64_t pre = lookback_exclusive(state, r, (uint64_t)total, lane, 4);
+    if (lane == 0) s_prefix = pre;
+  }
+  __syncthreads();
+  uint64_t o = s_prefix + before;
+  {
+    // runs that start in this thread's stretch: a run ends where the next one starts, so only the last one needs a search
+    // (for the first position beyond the stretch whose key differs: the array is sorted).  A thread's pairs are consecutive
+    // in the output and go straight out: that costs ~5x the spectrum's bytes in partial-line HBM writes (PMC), and is
+    // still a third faster than staging them through an LDS tile for full-line writes (2.05 vs 2.75 ms on 2,000 genomes:
+    // the tiles serialise the emission over the waves).
+    const uint32_t end = min(p0 + per, NP);
+    uint32_t start = 0xFFFFFFFFu, cur = 0;
+    uint32_t prev = (p0 > 0 && p0 < NP) ? s_key[KEY(p0 - 1)] : 0xFFFFFFFFu;
+    for (uint32_t i = p0; i < end; ++i) {
+      const uint32_t key = s_key[KEY(i)];
+      if (key != 0xFFFFFFFFu && (i == 0 || prev != key)) {
+        if (start != 0xFFFFFFFFu) {
+          out_hash[o] = cur;
+          out_count[o] = i - start;
+          ++o;
+        }
+        start = i;
+        cur = key;
+      } else if (key == 0xFFFFFFFFu && start != 0xFFFFFFFFu) {  // the sentinels begin: the open run ends here
+        out_hash[o] = cur;
+        out_count[o] = i - start;
+        ++o;
+        start = 0xFFFFFFFFu;
+      }
+      prev = key;
+    }
+    if (start != 0xFFFFFFFFu) {
+      uint32_t lo = end, hi = NP;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_key[KEY(mid)] == cur) lo = mid + 1; else hi = mid;
+      }
+      out_hash[o] = cur;
+      out_count[o] = lo - start;
+    }
+  }
+  if (threadIdx.x == 0) {
+    out_offsets[r] = s_prefix;
+    if (r == n - 1) out_offsets[n] = s_prefix + total;
+  }
+}
+
+// host arrays in, CSR on the device (S.d_oh / d_oc / d_oo); false through *done when the batch is not for this kernel
+static int block_count_device(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, int k, int content, uint64_t cap,
+                              SortedSpectra &S, hipStream_t st, bool *done) {
+  *done = false;
+  if (hash_bits(k, content) > 30 || !ctx().tune_blocksort) return 0;
+  const uint64_t base0 = offsets[0], n_bases = offsets[n_reads] - base0;
+  std::vector<uint64_t> rel(n_reads + 1);
+  uint64_t max_win = 0, worst = 0;
+  for (uint32_t r = 0; r <= n_reads; ++r) rel[r] = offsets[r] - base0;
+  for (uint32_t r = 0; r < n_reads; ++r) {
+    const uint64_t len = rel[r + 1] - rel[r], w = len >= (uint64_t)k ? len - k + 1 : 0;
+    max_win = std::max(max_win, w);
+    worst += w;
+  }
+  if (max_win > kBlockSortMax) return 0;
+  uint32_t NP = 64;
+  while (NP < max_win) NP <<= 1;
+  S.nu = 0;
+  S.n_spectra = n_reads;
+  KPOP_TRY(S.d_bases.alloc(n_bases));
+  KPOP_TRY(S.d_off.alloc((uint64_t)(n_reads + 1) * 8));
+  KPOP_TRY(S.d_scr.alloc(64 + ((uint64_t)n_reads + 1) * 8));
+  KPOP_TRY(S.d_oo.alloc((uint64_t)(n_reads + 1) * 8));
+  KPOP_TRY(S.d_oh.alloc(std::max<uint64_t>(worst, 1) * 8));
+  KPOP_TRY(S.d_oc.alloc(std::max<uint64_t>(worst, 1) * 4));
+  KPOP_HIP(hipMemcpyAsync(S.d_bases.p, bases + base0, n_bases, hipMemcpyHostToDevice, st));
+  KPOP_HIP(hipMemcpyAsync(S.d_off.p, rel.data(), (uint64_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+  KPOP_HIP(hipMemsetAsync(S.d_scr.p, 0, 64 + ((uint64_t)n_reads + 1) * 8, st));
+  uint32_t *ticket = S.d_scr.as<uint32_t>();
+  uint64_t *state = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(S.d_scr.p) + 64);
+  const size_t smem = ((size_t)NP + (NP >> 5) + 1) * 4;
+  static bool attr_set[2] = {false, false};
+  const int which = content == KPOP_PROTEIN ? 1 : 0;
+  if (!attr_set[which]) {
+    if (which) KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&count_block_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((kBlockSortMax + kBlockSortMax / 32 + 1) * 4)));
+    else KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&count_block_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((kBlockSortMax + kBlockSortMax / 32 + 1) * 4)));
+    attr_set[which] = true;
+  }
+  if (which)
+    count_block_kernel<5><<<dim3(n_reads), dim3(1024), smem, st>>>(S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), n_reads, k, content, ticket,
+                                                                   state, S.d_oh.as<uint64_t>(), S.d_oc.as<uint32_t>(), S.d_oo.as<uint64_t>());
+  else
+    count_block_kernel<2><<<dim3(n_reads), dim3(1024), smem, st>>>(S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), n_reads, k, content, ticket,
+                                                                   state, S.d_oh.as<uint64_t>(), S.d_oc.as<uint32_t>(), S.d_oo.as<uint64_t>());
+  KPOP_LAUNCH_CHECK();
+  uint64_t total = 0;
+  KPOP_HIP(hipMemcpyAsync(&total, S.d_oo.as<uint64_t>() + n_reads, 8, hipMemcpyDeviceToHost, st));
+  KPOP_HIP(hipStreamSynchronize(st));
+  if (total > cap)
+    KPOP_FAIL(KPOP_ERR_CAPACITY, "kpop_count_reads: %llu distinct (spectrum,k-mer) pairs, capacity %llu", (unsigned long long)total, (unsigned long long)cap);
+  S.nu = total;
+  *done = true;
+  return 0;
+}
+
 // One batch of reads through the sort path, host arrays in; the CSR stays on the device in S (d_oh, d_oc, and for
 // per_read d_oo with n_reads + 1 offsets relative to this batch).  per_read = 0 merges everything.  The buffers come
 // from the caller's ArenaScope.
 int sorted_count_device(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, int k, int content, int per_read,
                         uint64_t cap, SortedSpectra &S, hipStream_t st) {
+  if (per_read && n_reads > 0) {  // sequences that fit a block's LDS: sorted there, one block each
+    bool done = false;
+    KPOP_TRY(block_count_device(bases, offsets, n_reads, k, content, cap, S, st, &done));
+    if (done) return 0;
+  }
   // the merged spectrum of small-enough hashes: one atomic add per window (kpop_tune("hist", 0) keeps the sort)
   if (!per_read && ctx().tune_hist && hash_bits(k, content) <= kHistMaxBits && n_reads > 0)
     return hist_count_device(bases, offsets, n_reads, k, content, cap, S, st);

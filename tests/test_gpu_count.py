@@ -174,3 +174,28 @@ def test_count_protein_golden_and_random(kpop, oracle):
     for k in (2, 6, 7, 12):
         spectra_equal(kpop.count_reads(pb, po, k, kpop.PROTEIN), oracle.count_reads(pb, po, k, oracle.PROTEIN))
         spectra_equal(kpop.count_reads(pb, po, k, kpop.PROTEIN, per_read=False), oracle.count_reads(pb, po, k, oracle.PROTEIN, per_read=False))
+
+
+@pytest.mark.parametrize("k", [4, 12, 15])
+def test_count_assemblies_block_sort_equals_device_sort_and_oracle(kpop, oracle, k):
+    """-L on sequences of 513..32,768 windows: one block per sequence sorting in LDS (the default there) against the
+    device-wide sort and the oracle; lengths around the powers of two, Ns, a homopolymer (one run of 30,000), protein too"""
+    from kpop_amd import api
+    rng = np.random.RandomState(k + 40)
+    wuhan = "".join(l.strip() for l in open(GOLDEN + "/wuhan.fasta") if not l.startswith(">"))
+    lens = [513 + k, 1023 + k, 1024 + k, 1025 + k, 5000, 16383 + k, 16384 + k, 32768 + k - 1, 700, 0, 3]
+    seqs = [wuhan, "A" * 30000] + ["".join(rng.choice(list("ACGTN"), size=n, p=[0.248, 0.248, 0.248, 0.248, 0.008])) for n in lens]
+    bases, offs = concat(seqs)
+    for content in (kpop.DNA_DS, kpop.DNA_SS):
+        want = oracle.count_reads(bases, offs, k, content)
+        res = {}
+        for flag in (1, 0):
+            api.tune("blocksort", flag)
+            res[flag] = kpop.count_reads(bases, offs, k, content)
+        api.tune("blocksort", 1)
+        spectra_equal(res[1], want)
+        spectra_equal(res[0], want)
+    if k <= 6:
+        prot = ["".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWYX"), size=n)) for n in (600, 3000, 20000)]
+        pb, po = concat(prot)
+        spectra_equal(kpop.count_reads(pb, po, k, kpop.PROTEIN), oracle.count_reads(pb, po, k, oracle.PROTEIN))
