@@ -160,6 +160,163 @@ __global__ __launch_bounds__(256) void jacobi_step_kernel(double *__restrict__ A
   }
 }
 
+// ---------------------------------------------------------------------------
+// Blocked one-sided Jacobi.  The plain step above rotates ONE column pair per workgroup and moves all of A and V through
+// the caches for it: n - 1 such steps per sweep (22,890 launches of 22 us at n = 1,636).  Here a workgroup takes two
+// blocks of kJB = 4 columns, forms their 8 x 8 Gram matrix in one pass, diagonalises it in registers -- one wavefront, a
+// lane per matrix element, the four disjoint rotations of a round-robin round at a time -- and applies the accumulated
+// 8 x 8 rotation to the eight columns of A and of V in a second pass: 28 column pairs orthogonalised per trip through
+// memory instead of one, and n / 4 - 1 steps per sweep.
+// ---------------------------------------------------------------------------
+constexpr int kJB = 4, kJC = 2 * kJB;  // columns per block, per workgroup
+
+__device__ __forceinline__ int jb_partner(int i, int round) {  // circle method on 8 indices, index 7 fixed
+  if (i == 7) return round;
+  if (i == round) return 7;
+  return (2 * round - i + 14) % 7;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void jacobi_block_step_kernel(double *__restrict__ A, double *__restrict__ V, uint32_t n,
+                                                                uint32_t m_blk, uint32_t step, unsigned long long *worst, int inner_sweeps) {
+  __shared__ double s_part[NT / 64][kJC * kJC];
+  __shared__ double s_R[kJC][kJC];
+  __shared__ int s_skip;
+  const uint32_t t = blockIdx.x;
+  uint32_t P, Q;
+  if (t == 0) {
+    P = m_blk - 1;
+    Q = step;
+  } else {
+    P = (step + t) % (m_blk - 1);
+    Q = (step + (m_blk - 1) - t) % (m_blk - 1);
+  }
+  if (P > Q) {
+    const uint32_t x = P;
+    P = Q;
+    Q = x;
+  }
+  uint32_t col[kJC];
+  bool ok[kJC];
+#pragma unroll
+  for (int c = 0; c < kJC; ++c) {
+    col[c] = (c < kJB ? P * kJB + c : Q * kJB + (c - kJB));
+    ok[c] = col[c] < n;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // 8 x 8 Gram matrix of the columns (upper triangle, 36 sums per thread)
+  double g[kJC * (kJC + 1) / 2];
+#pragma unroll
+  for (int e = 0; e < kJC * (kJC + 1) / 2; ++e) g[e] = 0.0;
+  for (uint32_t i = threadIdx.x; i < n; i += NT) {
+    double x[kJC];
+#pragma unroll
+    for (int c = 0; c < kJC; ++c) x[c] = ok[c] ? A[(uint64_t)col[c] * n + i] : 0.0;
+    int e = 0;
+#pragma unroll
+    for (int a = 0; a < kJC; ++a)
+#pragma unroll
+      for (int b = a; b < kJC; ++b) g[e++] += x[a] * x[b];
+  }
+  {
+    int e = 0;
+#pragma unroll
+    for (int a = 0; a < kJC; ++a)
+#pragma unroll
+      for (int b = a; b < kJC; ++b) {
+        double v = g[e++];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) {
+          s_part[wv][a * kJC + b] = v;
+          s_part[wv][b * kJC + a] = v;
+        }
+      }
+  }
+  __syncthreads();
+  if (wv == 0) {
+    const int r = lane >> 3, c = lane & 7;
+    double M = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) M += s_part[w][lane];
+    double R = r == c ? 1.0 : 0.0;
+    // how far from orthogonal the eight columns are (the sweep's convergence measure, as in the plain step)
+    const double drr = __shfl(M, 9 * r, 64), dcc = __shfl(M, 9 * c, 64);
+    double off = (r < c && drr > 0.0 && dcc > 0.0) ? fabs(M) / sqrt(drr * dcc) : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) off = fmax(off, __shfl_xor(off, o, 64));
+    if (lane == 0) {
+      atomicMax(worst, (unsigned long long)__double_as_longlong(off));
+      s_skip = off < 1e-15;
+    }
+    if (!(off < 1e-15)) {
+      for (int sweep = 0; sweep < inner_sweeps; ++sweep) {
+        for (int round = 0; round < 7; ++round) {
+          const int pr = jb_partner(r, round), pc = jb_partner(c, round);
+          // rotation of the plane (a, b), a < b, that holds index i: from M[a][a], M[b][b], M[a][b]
+          double cs[2], sn[2];
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            const int i = w ? c : r, pi = w ? pc : pr;
+            const int a = min(i, pi), b = max(i, pi);
+            const double app = __shfl(M, 9 * a, 64), aqq = __shfl(M, 9 * b, 64), apq = __shfl(M, 8 * a + b, 64);
+            double cc = 1.0, ss = 0.0;
+            if (apq != 0.0) {
+              const double zeta = (aqq - app) / (2.0 * apq);
+              const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+              cc = 1.0 / sqrt(1.0 + tt * tt);
+              ss = cc * tt;
+            }
+            cs[w] = cc;
+            sn[w] = ss;
+          }
+          // J[a][a] = J[b][b] = cs, J[a][b] = sn, J[b][a] = -sn;  M <- J' M J,  R <- R J
+          const double jr_other = (r < pr) ? -sn[0] : sn[0];  // J[pr][r]
+          const double jc_other = (c < pc) ? -sn[1] : sn[1];  // J[pc][c]
+          const double m_rpc = __shfl(M, 8 * r + pc, 64), m_prc = __shfl(M, 8 * pr + c, 64), m_prpc = __shfl(M, 8 * pr + pc, 64);
+          const double r_rpc = __shfl(R, 8 * r + pc, 64);
+          M = cs[0] * (M * cs[1] + m_rpc * jc_other) + jr_other * (m_prc * cs[1] + m_prpc * jc_other);
+          R = R * cs[1] + r_rpc * jc_other;
+        }
+        double od = (r != c) ? fabs(M) : 0.0, dg = (r == c) ? fabs(M) : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          od = fmax(od, __shfl_xor(od, o, 64));
+          dg = fmax(dg, __shfl_xor(dg, o, 64));
+        }
+        if (od <= 1e-16 * dg) break;
+      }
+    }
+    s_R[r][c] = R;
+  }
+  __syncthreads();
+  if (s_skip) return;
+  double Rl[kJC][kJC];
+#pragma unroll
+  for (int a = 0; a < kJC; ++a)
+#pragma unroll
+    for (int b = 0; b < kJC; ++b) Rl[a][b] = s_R[a][b];
+  for (uint32_t i = threadIdx.x; i < n; i += NT) {
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      double *X = which ? V : A;
+      double x[kJC], y[kJC];
+#pragma unroll
+      for (int c = 0; c < kJC; ++c) x[c] = ok[c] ? X[(uint64_t)col[c] * n + i] : 0.0;
+#pragma unroll
+      for (int c = 0; c < kJC; ++c) {
+        double acc = 0.0;
+#pragma unroll
+        for (int a = 0; a < kJC; ++a) acc += x[a] * Rl[a][c];
+        y[c] = acc;
+      }
+#pragma unroll
+      for (int c = 0; c < kJC; ++c)
+        if (ok[c]) X[(uint64_t)col[c] * n + i] = y[c];
+    }
+  }
+}
+
 __global__ void jacobi_identity_kernel(double *__restrict__ V, uint32_t n) {
   const uint64_t total = (uint64_t)n * n, stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) V[e] = (e / n == e % n) ? 1.0 : 0.0;
@@ -181,8 +338,16 @@ static int jacobi_eigen_psd_device(double *d_G, double *d_V, uint32_t n, double 
   jacobi_identity_kernel<<<dim3(std::min<uint32_t>(div_up((uint64_t)n * n, 256), 4096)), dim3(256), 0, st>>>(d_V, n);
   KPOP_LAUNCH_CHECK();
   const uint32_t m = (n + 1) & ~1u;
+  const uint32_t n_blk = div_up(n, kJB), m_blk = (n_blk + 1) & ~1u;
+  const bool blocked = n >= 4 * kJC && !(ctx().tune_dbg & 32);  // (32: the plain steps, for A/B)
   for (int sweep = 0; sweep < 60; ++sweep) {
     KPOP_HIP(hipMemsetAsync(worst.p, 0, 8, st));
+    if (blocked) {
+      for (uint32_t step = 0; step + 1 < m_blk; ++step) {
+        jacobi_block_step_kernel<256><<<dim3(m_blk / 2), dim3(256), 0, st>>>(d_G, d_V, n, m_blk, step, worst.as<unsigned long long>(), (ctx().tune_dbg & 15) ? (ctx().tune_dbg & 15) : 1);
+        KPOP_LAUNCH_CHECK();
+      }
+    } else
     for (uint32_t step = 0; step + 1 < m; ++step) {
       jacobi_step_kernel<<<dim3(m / 2), dim3(256), 0, st>>>(d_G, d_V, n, m, step, worst.as<unsigned long long>());
       KPOP_LAUNCH_CHECK();
