@@ -236,6 +236,14 @@ uint64_t kpop_dev_twist_dense_workspace_bytes(const kpop_twister *tw, uint32_t n
 int kpop_dev_twist_dense(const kpop_twister *tw, const uint64_t *d_hash, const double *d_value,
                          const uint64_t *d_offsets, uint32_t n_spectra, int normalize, void *d_work, double *d_out,
                          void *stream);
+/* kpop_ca on device-resident data: d_counts (n_kmers x n_spectra, row-major, not modified) in, d_twisted (n_spectra x
+   n_dims), d_inertia (n_dims) and d_twister (n_dims x n_kmers, dims-major) out, all device pointers; *n_dims_out is a
+   host word.  d_work needs kpop_dev_ca_workspace_bytes() (the standardised copy of the table).  The weights of the
+   columns and the order of the eigenvalues are host work between launches: the call synchronises `stream` on the way
+   and has completed when it returns.                                                                                */
+uint64_t kpop_dev_ca_workspace_bytes(uint64_t n_kmers, uint32_t n_spectra);
+int kpop_dev_ca(const double *d_counts, uint64_t n_kmers, uint32_t n_spectra, int normalize, void *d_work,
+                uint32_t *n_dims_out, double *d_twisted, double *d_inertia, double *d_twister, void *stream);
 /* Distance workspace: row norms and the pre-normalised copies a/n_i, b/n_j of
    both operands (the per-element divisions of lib/Matrix.ml:247-249, done once).
    kpop_dev_distance_workspace_bytes gives the size d_work must have.          */

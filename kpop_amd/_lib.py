@@ -72,6 +72,8 @@ SIGNATURES = {
     "kpop_dev_workspace_reserve": (C.c_int, [C.c_uint64]),
     "kpop_dev_count_twist": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.c_int, vp, vp]),
     "kpop_dev_twist": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int, vp, vp]),
+    "kpop_dev_ca_workspace_bytes": (C.c_uint64, [C.c_uint64, C.c_uint32]),
+    "kpop_dev_ca": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_int, vp, u32p, vp, vp, vp, vp]),
     "kpop_dev_twist_dense_workspace_bytes": (C.c_uint64, [vp, C.c_uint32]),
     "kpop_dev_twist_dense": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_int, vp, vp, vp]),
     "kpop_dev_distance_workspace_bytes": (C.c_uint64, [C.c_uint32, C.c_uint32, C.c_uint32]),

@@ -204,6 +204,18 @@ def ca(counts, normalize=True):
     return twisted[:, :nd], inertia[:nd], twister[:nd]
 
 
+def dev_ca_workspace_bytes(n_kmers, n_spectra):
+    return int(_lib.load().kpop_dev_ca_workspace_bytes(int(n_kmers), int(n_spectra)))
+
+
+def dev_ca(d_counts, n_kmers, n_spectra, d_work, d_twisted, d_inertia, d_twister, normalize=True, stream=None):
+    """kpop_ca on device pointers (kpop_dev_ca); returns n_dims"""
+    n_out = C.c_uint32()
+    check(_lib.load().kpop_dev_ca(d_counts, int(n_kmers), int(n_spectra), 1 if normalize else 0, d_work, C.byref(n_out),
+                                  d_twisted, d_inertia, d_twister, stream))
+    return int(n_out.value)
+
+
 # ---------------------------------------------------------- k-mer database
 TRANSF_BINARY, TRANSF_POWER, TRANSF_CLR, TRANSF_PSEUDO = 0, 1, 2, 3
 COMBINE_MEAN, COMBINE_MEDIAN = 0, 1

@@ -15,6 +15,12 @@
 #include <math.h>
 
 #include <algorithm>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <numeric>
 #include <vector>
 
@@ -60,8 +66,8 @@ __global__ __launch_bounds__(256) void ca_row_mass_kernel(const double *__restri
 }
 
 // S_ij = (N_ij w_j - r_i c_j) / sqrt(r_i c_j); rows without mass are zero
-__global__ void ca_standardise_kernel(const double *__restrict__ N, uint64_t I, uint32_t J, const double *__restrict__ w,
-                                      const double *__restrict__ r, const double *__restrict__ c, double *__restrict__ S) {
+__global__ void ca_standardise_kernel(const double *N, uint64_t I, uint32_t J, const double *__restrict__ w,
+                                      const double *__restrict__ r, const double *__restrict__ c, double *S) {  // (S may be N)
   const uint64_t total = I * J, stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
     const uint64_t i = e / J;
@@ -176,6 +182,68 @@ __device__ __forceinline__ int jb_partner(int i, int round) {  // circle method 
   return (2 * round - i + 14) % 7;
 }
 
+// One wavefront, a lane per element of the 8 x 8 Gram matrix summed from the waves' partials: the sweep's convergence
+// measure goes to *worst, the accumulated rotation to s_R (the identity, and *s_skip set, when the eight columns are
+// orthogonal already).
+template <int WAVES>
+__device__ __forceinline__ void jacobi_solve_8x8(double (*s_part)[kJC * kJC], double (*s_R)[kJC], int *s_skip, unsigned long long *worst,
+                                                 int inner_sweeps) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane >> 3, c = lane & 7;
+  double M = 0.0;
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) M += s_part[w][lane];
+  double R = r == c ? 1.0 : 0.0;
+  // how far from orthogonal the eight columns are (the sweep's convergence measure, as in the plain step)
+  const double drr = __shfl(M, 9 * r, 64), dcc = __shfl(M, 9 * c, 64);
+  double off = (r < c && drr > 0.0 && dcc > 0.0) ? fabs(M) / sqrt(drr * dcc) : 0.0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) off = fmax(off, __shfl_xor(off, o, 64));
+  if (lane == 0) {
+    atomicMax(worst, (unsigned long long)__double_as_longlong(off));
+    *s_skip = off < 1e-15;
+  }
+  if (!(off < 1e-15)) {
+    for (int sweep = 0; sweep < inner_sweeps; ++sweep) {
+      for (int round = 0; round < 7; ++round) {
+        const int pr = jb_partner(r, round), pc = jb_partner(c, round);
+        // rotation of the plane (a, b), a < b, that holds index i: from M[a][a], M[b][b], M[a][b]
+        double cs[2], sn[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const int i = w ? c : r, pi = w ? pc : pr;
+          const int a = min(i, pi), b = max(i, pi);
+          const double app = __shfl(M, 9 * a, 64), aqq = __shfl(M, 9 * b, 64), apq = __shfl(M, 8 * a + b, 64);
+          double cc = 1.0, ss = 0.0;
+          if (apq != 0.0) {
+            const double zeta = (aqq - app) / (2.0 * apq);
+            const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            cc = 1.0 / sqrt(1.0 + tt * tt);
+            ss = cc * tt;
+          }
+          cs[w] = cc;
+          sn[w] = ss;
+        }
+        // J[a][a] = J[b][b] = cs, J[a][b] = sn, J[b][a] = -sn;  M <- J' M J,  R <- R J
+        const double jr_other = (r < pr) ? -sn[0] : sn[0];  // J[pr][r]
+        const double jc_other = (c < pc) ? -sn[1] : sn[1];  // J[pc][c]
+        const double m_rpc = __shfl(M, 8 * r + pc, 64), m_prc = __shfl(M, 8 * pr + c, 64), m_prpc = __shfl(M, 8 * pr + pc, 64);
+        const double r_rpc = __shfl(R, 8 * r + pc, 64);
+        M = cs[0] * (M * cs[1] + m_rpc * jc_other) + jr_other * (m_prc * cs[1] + m_prpc * jc_other);
+        R = R * cs[1] + r_rpc * jc_other;
+      }
+      double od = (r != c) ? fabs(M) : 0.0, dg = (r == c) ? fabs(M) : 0.0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        od = fmax(od, __shfl_xor(od, o, 64));
+        dg = fmax(dg, __shfl_xor(dg, o, 64));
+      }
+      if (od <= 1e-16 * dg) break;
+    }
+  }
+  s_R[r][c] = R;
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void jacobi_block_step_kernel(double *__restrict__ A, double *__restrict__ V, uint32_t n,
                                                                 uint32_t m_blk, uint32_t step, unsigned long long *worst, int inner_sweeps) {
@@ -234,61 +302,7 @@ __global__ __launch_bounds__(NT) void jacobi_block_step_kernel(double *__restric
       }
   }
   __syncthreads();
-  if (wv == 0) {
-    const int r = lane >> 3, c = lane & 7;
-    double M = 0.0;
-#pragma unroll
-    for (int w = 0; w < NT / 64; ++w) M += s_part[w][lane];
-    double R = r == c ? 1.0 : 0.0;
-    // how far from orthogonal the eight columns are (the sweep's convergence measure, as in the plain step)
-    const double drr = __shfl(M, 9 * r, 64), dcc = __shfl(M, 9 * c, 64);
-    double off = (r < c && drr > 0.0 && dcc > 0.0) ? fabs(M) / sqrt(drr * dcc) : 0.0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) off = fmax(off, __shfl_xor(off, o, 64));
-    if (lane == 0) {
-      atomicMax(worst, (unsigned long long)__double_as_longlong(off));
-      s_skip = off < 1e-15;
-    }
-    if (!(off < 1e-15)) {
-      for (int sweep = 0; sweep < inner_sweeps; ++sweep) {
-        for (int round = 0; round < 7; ++round) {
-          const int pr = jb_partner(r, round), pc = jb_partner(c, round);
-          // rotation of the plane (a, b), a < b, that holds index i: from M[a][a], M[b][b], M[a][b]
-          double cs[2], sn[2];
-#pragma unroll
-          for (int w = 0; w < 2; ++w) {
-            const int i = w ? c : r, pi = w ? pc : pr;
-            const int a = min(i, pi), b = max(i, pi);
-            const double app = __shfl(M, 9 * a, 64), aqq = __shfl(M, 9 * b, 64), apq = __shfl(M, 8 * a + b, 64);
-            double cc = 1.0, ss = 0.0;
-            if (apq != 0.0) {
-              const double zeta = (aqq - app) / (2.0 * apq);
-              const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-              cc = 1.0 / sqrt(1.0 + tt * tt);
-              ss = cc * tt;
-            }
-            cs[w] = cc;
-            sn[w] = ss;
-          }
-          // J[a][a] = J[b][b] = cs, J[a][b] = sn, J[b][a] = -sn;  M <- J' M J,  R <- R J
-          const double jr_other = (r < pr) ? -sn[0] : sn[0];  // J[pr][r]
-          const double jc_other = (c < pc) ? -sn[1] : sn[1];  // J[pc][c]
-          const double m_rpc = __shfl(M, 8 * r + pc, 64), m_prc = __shfl(M, 8 * pr + c, 64), m_prpc = __shfl(M, 8 * pr + pc, 64);
-          const double r_rpc = __shfl(R, 8 * r + pc, 64);
-          M = cs[0] * (M * cs[1] + m_rpc * jc_other) + jr_other * (m_prc * cs[1] + m_prpc * jc_other);
-          R = R * cs[1] + r_rpc * jc_other;
-        }
-        double od = (r != c) ? fabs(M) : 0.0, dg = (r == c) ? fabs(M) : 0.0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          od = fmax(od, __shfl_xor(od, o, 64));
-          dg = fmax(dg, __shfl_xor(dg, o, 64));
-        }
-        if (od <= 1e-16 * dg) break;
-      }
-    }
-    s_R[r][c] = R;
-  }
+  if (wv == 0) jacobi_solve_8x8<NT / 64>(s_part, s_R, &s_skip, worst, inner_sweeps);
   __syncthreads();
   if (s_skip) return;
   double Rl[kJC][kJC];
@@ -317,6 +331,150 @@ __global__ __launch_bounds__(NT) void jacobi_block_step_kernel(double *__restric
   }
 }
 
+// v[0 .. N) summed over the 64 lanes, spread over them: after the stage at distance OFF the lanes with that bit clear
+// hold (the pair sums of) the lower half of the values, the others the upper half.
+template <int N, int OFF>
+__device__ __forceinline__ void jacobi_halve(double *v, int lane) {
+  constexpr int H = (N + 1) / 2;
+  const bool upper = lane & OFF;
+#pragma unroll
+  for (int j = 0; j < H; ++j) {
+    const double lo = v[j], hi = (j + H < N) ? v[j + H] : 0.0;
+    const double keep = upper ? hi : lo, send = upper ? lo : hi;
+    v[j] = keep + __shfl_xor(send, OFF, 64);
+  }
+}
+__device__ __forceinline__ void jacobi_wave_totals(double *v, int lane) {  // 36 -> 18 -> 9 -> 5 -> 3 -> 2 -> 1
+  jacobi_halve<36, 32>(v, lane);
+  jacobi_halve<18, 16>(v, lane);
+  jacobi_halve<9, 8>(v, lane);
+  jacobi_halve<5, 4>(v, lane);
+  jacobi_halve<3, 2>(v, lane);
+  jacobi_halve<2, 1>(v, lane);
+}
+static_assert(kJC * (kJC + 1) / 2 == 36, "jacobi_wave_totals is written for 36 sums");
+
+// The same step with the workgroup's rows of its eight columns held in registers (n <= 256 * ROWS): every load of the Gram
+// pass is in flight at once instead of one row of eight per round trip, the eight columns of V are requested before the
+// 8 x 8 problem is solved (their latency hides behind it), and A is rotated from registers without a second read.  The
+// looped kernel above spends 17 us of its 50 us per step in the Gram pass alone at n = 1,636: one wavefront per SIMD and
+// seven dependent trips to the L2 / MALL.
+template <int ROWS>
+__global__ __launch_bounds__(256) void jacobi_block_step_reg_kernel(double *__restrict__ A, double *__restrict__ V, uint32_t n,
+                                                                    uint32_t m_blk, uint32_t step, unsigned long long *worst, int inner_sweeps) {
+  __shared__ double s_part[4][kJC * kJC];
+  __shared__ double s_R[kJC][kJC];
+  __shared__ int s_skip;
+  const uint32_t t = blockIdx.x;
+  uint32_t P, Q;
+  if (t == 0) {
+    P = m_blk - 1;
+    Q = step;
+  } else {
+    P = (step + t) % (m_blk - 1);
+    Q = (step + (m_blk - 1) - t) % (m_blk - 1);
+  }
+  if (P > Q) {
+    const uint32_t x = P;
+    P = Q;
+    Q = x;
+  }
+  uint64_t base[kJC];
+  bool ok[kJC];
+#pragma unroll
+  for (int c = 0; c < kJC; ++c) {
+    const uint32_t col = (c < kJB ? P * kJB + c : Q * kJB + (c - kJB));
+    ok[c] = col < n;
+    base[c] = (uint64_t)(ok[c] ? col : 0u) * n;  // (loads are unconditional -- a predicated load costs its own round trip -- and masked after)
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double x[ROWS][kJC];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const uint32_t i = threadIdx.x + 256u * r;
+    const uint32_t ii = i < n ? i : 0u;
+#pragma unroll
+    for (int c = 0; c < kJC; ++c) x[r][c] = A[base[c] + ii];
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const bool in = threadIdx.x + 256u * r < n;
+#pragma unroll
+    for (int c = 0; c < kJC; ++c) x[r][c] = (in && ok[c]) ? x[r][c] : 0.0;
+  }
+  {
+    double g[kJC * (kJC + 1) / 2];
+#pragma unroll
+    for (int e = 0; e < kJC * (kJC + 1) / 2; ++e) g[e] = 0.0;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      int e = 0;
+#pragma unroll
+      for (int a = 0; a < kJC; ++a)
+#pragma unroll
+        for (int b = a; b < kJC; ++b) g[e++] += x[r][a] * x[r][b];
+    }
+    // sum over the wavefront: a halving exchange (the lane pair at distance OFF splits the values between them), 38
+    // exchanges instead of 36 x 6, none waiting on the one before; lane l ends with the total of entry `mine`
+    jacobi_wave_totals(g, lane);
+    int mine = 0, real = kJC * (kJC + 1) / 2, slots = real;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int h = (slots + 1) / 2;
+      if (lane & off) {
+        mine += h;
+        real = max(real - h, 0);
+      } else
+        real = min(real, h);
+      slots = h;
+    }
+    if (real > 0) {  // (36 entries: the uneven halvings leave 28 lanes holding padding)
+      int a = 0, rest = mine;
+      while (rest >= kJC - a) {
+        rest -= kJC - a;
+        ++a;
+      }
+      const int b = a + rest;
+      s_part[wv][a * kJC + b] = g[0];
+      s_part[wv][b * kJC + a] = g[0];
+    }
+  }
+  double y[ROWS][kJC];  // the rows of V, asked for now and used after the 8 x 8 problem
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const uint32_t i = threadIdx.x + 256u * r;
+    const uint32_t ii = i < n ? i : 0u;
+#pragma unroll
+    for (int c = 0; c < kJC; ++c) y[r][c] = V[base[c] + ii];
+  }
+  __syncthreads();
+  if (wv == 0) jacobi_solve_8x8<4>(s_part, s_R, &s_skip, worst, inner_sweeps);
+  __syncthreads();
+  if (s_skip) return;
+  double Rl[kJC][kJC];
+#pragma unroll
+  for (int a = 0; a < kJC; ++a)
+#pragma unroll
+    for (int b = 0; b < kJC; ++b) Rl[a][b] = s_R[a][b];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const bool in = threadIdx.x + 256u * r < n;
+#pragma unroll
+    for (int c = 0; c < kJC; ++c) {
+      double acc = 0.0, acv = 0.0;
+#pragma unroll
+      for (int a = 0; a < kJC; ++a) {
+        acc += x[r][a] * Rl[a][c];
+        acv += y[r][a] * Rl[a][c];
+      }
+      if (in && ok[c]) {
+        A[base[c] + threadIdx.x + 256u * r] = acc;
+        V[base[c] + threadIdx.x + 256u * r] = acv;
+      }
+    }
+  }
+}
+
 __global__ void jacobi_identity_kernel(double *__restrict__ V, uint32_t n) {
   const uint64_t total = (uint64_t)n * n, stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) V[e] = (e / n == e % n) ? 1.0 : 0.0;
@@ -332,28 +490,36 @@ __global__ __launch_bounds__(256) void jacobi_colnorm_kernel(const double *__res
 }
 
 // d_G is overwritten (columns rotated); d_V receives the eigenvectors as columns (V[j*n + i] = component i of vector j)
-static int jacobi_eigen_psd_device(double *d_G, double *d_V, uint32_t n, double *d_lambda, hipStream_t st) {
-  DevBuf worst;
-  KPOP_TRY(worst.alloc(8));
+static int jacobi_eigen_psd_device(double *d_G, double *d_V, uint32_t n, double *d_lambda, unsigned long long *d_worst, hipStream_t st) {
   jacobi_identity_kernel<<<dim3(std::min<uint32_t>(div_up((uint64_t)n * n, 256), 4096)), dim3(256), 0, st>>>(d_V, n);
   KPOP_LAUNCH_CHECK();
   const uint32_t m = (n + 1) & ~1u;
   const uint32_t n_blk = div_up(n, kJB), m_blk = (n_blk + 1) & ~1u;
   const bool blocked = n >= 4 * kJC && !(ctx().tune_dbg & 32);  // (32: the plain steps, for A/B)
   for (int sweep = 0; sweep < 60; ++sweep) {
-    KPOP_HIP(hipMemsetAsync(worst.p, 0, 8, st));
+    KPOP_HIP(hipMemsetAsync(d_worst, 0, 8, st));
     if (blocked) {
       for (uint32_t step = 0; step + 1 < m_blk; ++step) {
-        jacobi_block_step_kernel<256><<<dim3(m_blk / 2), dim3(256), 0, st>>>(d_G, d_V, n, m_blk, step, worst.as<unsigned long long>(), (ctx().tune_dbg & 15) ? (ctx().tune_dbg & 15) : 1);
+        const int inner = (ctx().tune_dbg & 15) ? (int)(ctx().tune_dbg & 15) : 1;
+        const dim3 grid(m_blk / 2), block(256);
+        unsigned long long *w = d_worst;
+        switch ((ctx().tune_dbg & 64) ? 0u : div_up(n, 256)) {  // (64: the looped kernel, for A/B)
+#define KPOP_JACOBI_ROWS(R) \
+  case R: jacobi_block_step_reg_kernel<R><<<grid, block, 0, st>>>(d_G, d_V, n, m_blk, step, w, inner); break;
+          KPOP_JACOBI_ROWS(1) KPOP_JACOBI_ROWS(2) KPOP_JACOBI_ROWS(3) KPOP_JACOBI_ROWS(4)
+          KPOP_JACOBI_ROWS(5) KPOP_JACOBI_ROWS(6) KPOP_JACOBI_ROWS(7) KPOP_JACOBI_ROWS(8)
+#undef KPOP_JACOBI_ROWS
+          default: jacobi_block_step_kernel<256><<<grid, block, 0, st>>>(d_G, d_V, n, m_blk, step, w, inner);
+        }
         KPOP_LAUNCH_CHECK();
       }
     } else
     for (uint32_t step = 0; step + 1 < m; ++step) {
-      jacobi_step_kernel<<<dim3(m / 2), dim3(256), 0, st>>>(d_G, d_V, n, m, step, worst.as<unsigned long long>());
+      jacobi_step_kernel<<<dim3(m / 2), dim3(256), 0, st>>>(d_G, d_V, n, m, step, d_worst);
       KPOP_LAUNCH_CHECK();
     }
     double w = 0.0;
-    KPOP_HIP(hipMemcpyAsync(&w, worst.p, 8, hipMemcpyDeviceToHost, st));
+    KPOP_HIP(hipMemcpyAsync(&w, d_worst, 8, hipMemcpyDeviceToHost, st));
     KPOP_HIP(hipStreamSynchronize(st));
     if (w < 1e-15) break;
   }
@@ -362,31 +528,111 @@ static int jacobi_eigen_psd_device(double *d_G, double *d_V, uint32_t n, double 
   return 0;
 }
 
-}  // namespace kpop
+// ---------------------------------------------------------------------------
+// The analysis on device-resident data.  d_N: the counts (I x J, row-major); d_S: where the standardised table goes (may
+// be d_N).  The small per-column and per-dimension work (J weights; the order of J eigenvalues) is host code between
+// launches, so the stream is synchronised a few times on the way.
+//
+// The twister (nd x I, dims-major) is produced in slabs of kCaDimSlab dimensions -- U = S W[:, slab] on the matrix cores,
+// then the scaled transpose -- so that the table never exists twice on the device and, for a host destination, the copy
+// of one slab runs under the product of the next (a second stream; the rows of a dims-major slab are one contiguous run
+// of the destination).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kCaDimSlab = 256;
 
-using namespace kpop;
-
-extern "C" int kpop_ca(const double *counts, uint64_t n_kmers, uint32_t n_spectra, int normalize, uint32_t *n_dims_out,
-                       double *twisted, double *inertia, double *twister) {
-  KPOP_TRY(require_init());
-  const uint64_t I = n_kmers;
-  const uint32_t J = n_spectra;
-  if (!counts || !n_dims_out || !twisted || !inertia || !twister) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_ca: null argument");
-  if (I < 2 || J < 2) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_ca: need at least 2 k-mers and 2 spectra");
-  const uint32_t nd = (uint32_t)std::min<uint64_t>(I, J) - 1;
-  *n_dims_out = nd;
+struct CaTimer {
+  bool on = getenv("KPOP_TIMING") != nullptr;
   hipStream_t st = nullptr;
+  std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+  void mark(const char *what) {
+    if (!on) return;
+    (void)hipStreamSynchronize(st);
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[kpop_ca] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - last).count());
+    last = t;
+  }
+};
+
+// A large pageable host buffer to the device: the runtime pins, copies and unpins what one call is given, one after the
+// other, so pieces handed over by a few threads (a stream each) put the pinning of one under the transfer of another.
+static int host_to_device_threads(void *dst, const void *src, uint64_t bytes) {
+  const uint64_t piece = 256ull << 20;
+  const char *e = getenv("KPOP_CA_COPY_THREADS");
+  const unsigned n_threads = (unsigned)std::max(1, std::min(16, e ? atoi(e) : 4));
+  if (bytes < 2 * piece || n_threads == 1) {
+    KPOP_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return KPOP_OK;
+  }
+  int device = 0;
+  KPOP_HIP(hipGetDevice(&device));
+  std::atomic<uint64_t> next{0};
+  std::atomic<int> failed{0};
+  std::vector<std::thread> threads;
+  for (unsigned t = 0; t < n_threads; ++t)
+    threads.emplace_back([&, device] {
+      hipStream_t s = nullptr;
+      if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+        failed = 1;
+        return;
+      }
+      for (;;) {
+        const uint64_t off = next.fetch_add(piece);
+        if (off >= bytes) break;
+        const uint64_t len = std::min(piece, bytes - off);
+        if (hipMemcpyAsync((char *)dst + off, (const char *)src + off, len, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {
+          failed = 1;
+          break;
+        }
+      }
+      (void)hipStreamDestroy(s);
+    });
+  for (auto &t : threads) t.join();
+  if (failed) KPOP_FAIL(KPOP_ERR_HIP, "kpop_ca: copying the table to the device failed");
+  return KPOP_OK;
+}
+
+struct CaOutput {          // where the results go: host pointers (kpop_ca) or device pointers (kpop_dev_ca)
+  bool on_device = false;
+  double *twisted = nullptr, *inertia = nullptr, *twister = nullptr;
+};
+
+static int ca_on_device(const double *d_N, double *d_S, uint64_t I, uint32_t J, int normalize, const CaOutput &out, hipStream_t st,
+                        CaTimer &tm) {
+  const uint32_t nd = (uint32_t)std::min<uint64_t>(I, J) - 1;
   const uint32_t n_slabs = div_up(I, kCaSlab);
-  DevBuf dN, dS, dW, dR, dC, dPart, dG, dGslabs, dWm, dU, dT;
-  KPOP_TRY(dN.alloc(I * J * 8));
-  KPOP_TRY(dS.alloc(I * J * 8));
+  const uint32_t tiles = div_up(J, kGT) * div_up(J, kGT);
+  uint32_t splits = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, 2048 / std::max(1u, tiles)), std::max<uint64_t>(1, I / 4096));
+  splits = std::min(splits, 256u);  // of K = I in G = S'S
+  const uint32_t n_dim_slabs = div_up(nd, kCaDimSlab);
+  const uint32_t slab_w = std::min(nd, kCaDimSlab);
+  DevBuf dW, dR, dC, dPart, dG, dGslabs, dWm, dV, dLambda, dWorst, dU[1], dT[2];
   KPOP_TRY(dW.alloc((uint64_t)J * 8));
   KPOP_TRY(dR.alloc(I * 8));
   KPOP_TRY(dC.alloc((uint64_t)J * 8));
   KPOP_TRY(dPart.alloc((uint64_t)n_slabs * J * 8));
-  KPOP_HIP(hipMemcpyAsync(dN.p, counts, I * J * 8, hipMemcpyHostToDevice, st));
+  KPOP_TRY(dG.alloc((uint64_t)J * J * 8));
+  KPOP_TRY(dGslabs.alloc((uint64_t)splits * J * J * 8));
+  KPOP_TRY(dV.alloc((uint64_t)J * J * 8));
+  KPOP_TRY(dLambda.alloc((uint64_t)J * 8));
+  KPOP_TRY(dWorst.alloc(8));
+  KPOP_TRY(dWm.alloc((uint64_t)J * nd * 8));
+  struct Events {
+    hipEvent_t ready[2] = {nullptr, nullptr};
+    ~Events() {
+      for (int b = 0; b < 2; ++b)
+        if (ready[b]) (void)hipEventDestroy(ready[b]);
+    }
+  } ss;
+  KPOP_TRY(dU[0].alloc(I * slab_w * 8));
+  if (!out.on_device) {
+    for (int b = 0; b < 2; ++b) {
+      KPOP_HIP(hipEventCreateWithFlags(&ss.ready[b], hipEventDisableTiming));
+      if ((uint32_t)b < n_dim_slabs) KPOP_TRY(dT[b].alloc(I * slab_w * 8));
+    }
+  }
   // column sums -> weights w_j (P_ij = N_ij w_j)
-  ca_col_partial_kernel<<<dim3(n_slabs), dim3(256), 0, st>>>(dN.as<double>(), I, J, nullptr, dPart.as<double>());
+  ca_col_partial_kernel<<<dim3(n_slabs), dim3(256), 0, st>>>(d_N, I, J, nullptr, dPart.as<double>());
   KPOP_LAUNCH_CHECK();
   ca_col_final_kernel<<<dim3(div_up(J, 256)), dim3(256), 0, st>>>(dPart.as<double>(), n_slabs, J, dC.as<double>());
   KPOP_LAUNCH_CHECK();
@@ -404,22 +650,17 @@ extern "C" int kpop_ca(const double *counts, uint64_t n_kmers, uint32_t n_spectr
   }
   KPOP_HIP(hipMemcpyAsync(dW.p, w.data(), (uint64_t)J * 8, hipMemcpyHostToDevice, st));
   KPOP_HIP(hipMemcpyAsync(dC.p, c.data(), (uint64_t)J * 8, hipMemcpyHostToDevice, st));
-  ca_row_mass_kernel<<<dim3(div_up(I, 4)), dim3(256), 0, st>>>(dN.as<double>(), I, J, dW.as<double>(), dR.as<double>());
+  ca_row_mass_kernel<<<dim3(div_up(I, 4)), dim3(256), 0, st>>>(d_N, I, J, dW.as<double>(), dR.as<double>());
   KPOP_LAUNCH_CHECK();
   ca_standardise_kernel<<<dim3(std::min<uint32_t>(div_up(I * J, 256), 1u << 20)), dim3(256), 0, st>>>(
-      dN.as<double>(), I, J, dW.as<double>(), dR.as<double>(), dC.as<double>(), dS.as<double>());
+      d_N, I, J, dW.as<double>(), dR.as<double>(), dC.as<double>(), d_S);
   KPOP_LAUNCH_CHECK();
-  // G = S'S  (J x J), K = I split over up to 64 slabs
-  const uint32_t tiles = div_up(J, kGT) * div_up(J, kGT);
-  uint32_t splits = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, 2048 / std::max(1u, tiles)), std::max<uint64_t>(1, I / 4096));
-  splits = std::min(splits, 256u);
-  KPOP_TRY(dG.alloc((uint64_t)J * J * 8));
-  KPOP_TRY(dGslabs.alloc((uint64_t)splits * J * J * 8));
-  KPOP_TRY(gemm_f64<true>(dS.as<double>(), J, dS.as<double>(), J, dG.as<double>(), J, J, I, splits, dGslabs.as<double>(), 1, st));
-  DevBuf dV, dLambda;
-  KPOP_TRY(dV.alloc((uint64_t)J * J * 8));
-  KPOP_TRY(dLambda.alloc((uint64_t)J * 8));
-  KPOP_TRY(jacobi_eigen_psd_device(dG.as<double>(), dV.as<double>(), J, dLambda.as<double>(), st));
+  tm.mark("masses, standardise");
+  // G = S'S  (J x J), K = I split over up to 256 slabs
+  KPOP_TRY(gemm_f64<true>(d_S, J, d_S, J, dG.as<double>(), J, J, I, splits, dGslabs.as<double>(), 1, st));
+  tm.mark("G = S'S");
+  KPOP_TRY(jacobi_eigen_psd_device(dG.as<double>(), dV.as<double>(), J, dLambda.as<double>(), dWorst.as<unsigned long long>(), st));
+  tm.mark("Jacobi");
   std::vector<double> V((size_t)J * J), lambda(J);
   KPOP_HIP(hipMemcpyAsync(V.data(), dV.p, (uint64_t)J * J * 8, hipMemcpyDeviceToHost, st));
   KPOP_HIP(hipMemcpyAsync(lambda.data(), dLambda.p, (uint64_t)J * 8, hipMemcpyDeviceToHost, st));
@@ -428,7 +669,14 @@ extern "C" int kpop_ca(const double *counts, uint64_t n_kmers, uint32_t n_spectr
   std::vector<uint32_t> order(J);
   std::iota(order.begin(), order.end(), 0u);
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return lambda[a] > lambda[b]; });
-  std::vector<double> sv(nd), Wm((size_t)J * nd);
+  std::vector<double> sv(nd), Wm((size_t)J * nd), h_twisted, h_inertia;
+  double *twisted = out.twisted, *inertia = out.inertia;
+  if (out.on_device) {
+    h_twisted.resize((size_t)J * nd);
+    h_inertia.resize(nd);
+    twisted = h_twisted.data();
+    inertia = h_inertia.data();
+  }
   double sum_sq = 0.0;
   for (uint32_t d = 0; d < nd; ++d) {
     sv[d] = sqrt(std::max(lambda[order[d]], 0.0));
@@ -442,17 +690,172 @@ extern "C" int kpop_ca(const double *counts, uint64_t n_kmers, uint32_t n_spectr
       Wm[(size_t)j * nd + d] = sv[d] > 0.0 ? v[j] / sv[d] : 0.0;  // V diag(1/sv)
     }
   }
-  // U = S W (I x nd), then the twister = (D_r^-1/2 U)'
-  KPOP_TRY(dWm.alloc((uint64_t)J * nd * 8));
-  KPOP_TRY(dU.alloc(I * nd * 8));
-  KPOP_TRY(dT.alloc(I * nd * 8));
+  if (out.on_device) {
+    KPOP_HIP(hipMemcpyAsync(out.twisted, twisted, (uint64_t)J * nd * 8, hipMemcpyHostToDevice, st));
+    KPOP_HIP(hipMemcpyAsync(out.inertia, inertia, (uint64_t)nd * 8, hipMemcpyHostToDevice, st));
+  }
   KPOP_HIP(hipMemcpyAsync(dWm.p, Wm.data(), (uint64_t)J * nd * 8, hipMemcpyHostToDevice, st));
-  KPOP_TRY(gemm_f64<false>(dS.as<double>(), J, dWm.as<double>(), nd, dU.as<double>(), (uint32_t)std::min<uint64_t>(I, 0xFFFFFFFFull), nd, J,
-                           1, nullptr, 0, st));
-  ca_row_coords_kernel<<<dim3(div_up(I, 32), div_up(nd, 32)), dim3(256), 0, st>>>(dU.as<double>(), I, nd, dR.as<double>(),
-                                                                                 dT.as<double>());
-  KPOP_LAUNCH_CHECK();
-  KPOP_HIP(hipMemcpyAsync(twister, dT.p, I * nd * 8, hipMemcpyDeviceToHost, st));
+  tm.mark("V back, order, W");
+  // U = S W (I x nd) slab by slab, then the twister = (D_r^-1/2 U)'
+  const uint32_t M = (uint32_t)std::min<uint64_t>(I, 0xFFFFFFFFull);
+  if (out.on_device) {
+    for (uint32_t s = 0; s < n_dim_slabs; ++s) {
+      const uint32_t d0 = s * kCaDimSlab, wd = std::min(kCaDimSlab, nd - d0);
+      KPOP_TRY(gemm_f64<false>(d_S, J, dWm.as<double>() + d0, nd, dU[0].as<double>(), M, wd, J, 1, nullptr, 0, st));
+      ca_row_coords_kernel<<<dim3(div_up(I, 32), div_up(wd, 32)), dim3(256), 0, st>>>(dU[0].as<double>(), I, wd, dR.as<double>(),
+                                                                                     out.twister + (uint64_t)d0 * I);
+      KPOP_LAUNCH_CHECK();
+    }
+    KPOP_HIP(hipStreamSynchronize(st));  // (the host vectors above are the source of copies in flight)
+    tm.mark("U = S W, row coordinates");
+    return KPOP_OK;
+  }
+  KPOP_HIP(hipStreamSynchronize(st));  // W is on the device; the copiers' streams are not ordered after `st`
+  // The destination is usually memory the caller has just allocated: whoever writes a page first takes its fault, and one
+  // thread copying takes them at 17 GB/s.  Two threads, a stream each, copy half of every slab: 6.9 GB in 0.35 s instead
+  // of 0.43 s (more threads: no better; 0.14 s when the pages are present already).  Touching the pages ahead of time from
+  // other threads, under the analysis, was measured first: the device sat idle until they were done -- 228-245 ms at
+  // 6.9 GB, whatever their number -- and nothing was gained.
+  struct Progress {
+    std::mutex m;
+    std::condition_variable cv;
+    uint32_t produced = 0;            // slabs whose kernels are enqueued and whose `ready` event is recorded
+    uint32_t parts_done[2] = {0, 0};  // copiers finished with the slab in buffer b
+    uint32_t copied = 0;              // slabs wholly on the host
+    int failed = 0;
+  } pg;
+  int device = 0;
+  KPOP_HIP(hipGetDevice(&device));
+  const char *e_cp = getenv("KPOP_CA_COPY_THREADS");
+  const unsigned n_copiers = (unsigned)std::max(1, std::min(16, e_cp ? atoi(e_cp) : 2));
+  auto produce = [&](uint32_t s) -> int {
+    const int b = s & 1;
+    const uint32_t d0 = s * kCaDimSlab, wd = std::min(kCaDimSlab, nd - d0);
+    KPOP_TRY(gemm_f64<false>(d_S, J, dWm.as<double>() + d0, nd, dU[0].as<double>(), M, wd, J, 1, nullptr, 0, st));
+    ca_row_coords_kernel<<<dim3(div_up(I, 32), div_up(wd, 32)), dim3(256), 0, st>>>(dU[0].as<double>(), I, wd, dR.as<double>(),
+                                                                                   dT[b].as<double>());
+    KPOP_LAUNCH_CHECK();
+    KPOP_HIP(hipEventRecord(ss.ready[b], st));
+    {
+      std::lock_guard<std::mutex> lk(pg.m);
+      pg.produced = s + 1;
+    }
+    pg.cv.notify_all();
+    return 0;
+  };
+  std::vector<std::thread> copiers;
+  for (unsigned t = 0; t < n_copiers; ++t)
+    copiers.emplace_back([&, t, device] {
+      hipStream_t cs = nullptr;
+      bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess;
+      for (uint32_t s = 0; s < n_dim_slabs; ++s) {
+        const int b = s & 1;
+        const uint32_t d0 = s * kCaDimSlab, wd = std::min(kCaDimSlab, nd - d0);
+        {
+          std::unique_lock<std::mutex> lk(pg.m);
+          pg.cv.wait(lk, [&] { return pg.produced > s || pg.failed; });
+          if (pg.failed) break;
+        }
+        const uint64_t bytes = (uint64_t)wd * I * 8, share = ((bytes / n_copiers) + 4095) & ~4095ull;
+        const uint64_t lo = std::min(bytes, share * t), hi = (t + 1 == n_copiers) ? bytes : std::min(bytes, share * (t + 1));
+        if (ok && hi > lo)
+          ok = hipStreamWaitEvent(cs, ss.ready[b], 0) == hipSuccess &&
+               hipMemcpyAsync((char *)(out.twister + (uint64_t)d0 * I) + lo, (const char *)dT[b].p + lo, hi - lo, hipMemcpyDeviceToHost, cs) == hipSuccess &&
+               hipStreamSynchronize(cs) == hipSuccess;
+        {
+          std::lock_guard<std::mutex> lk(pg.m);
+          if (!ok) pg.failed = 1;
+          if (++pg.parts_done[b] == n_copiers) {
+            pg.parts_done[b] = 0;
+            pg.copied = s + 1;
+          }
+        }
+        pg.cv.notify_all();
+        if (!ok) break;
+      }
+      if (cs) (void)hipStreamDestroy(cs);
+    });
+  int rc = produce(0);
+  if (rc == 0 && n_dim_slabs > 1) rc = produce(1);
+  for (uint32_t s = 0; rc == 0 && s + 2 < n_dim_slabs; ++s) {
+    {
+      std::unique_lock<std::mutex> lk(pg.m);
+      pg.cv.wait(lk, [&] { return pg.copied > s || pg.failed; });  // buffer s & 1 is free again
+      if (pg.failed) break;
+    }
+    rc = produce(s + 2);
+  }
+  if (rc != 0) {
+    {
+      std::lock_guard<std::mutex> lk(pg.m);
+      pg.failed = 1;
+    }
+    pg.cv.notify_all();
+  }
+  for (auto &t : copiers) t.join();
+  if (rc != 0) return rc;
+  if (pg.failed) KPOP_FAIL(KPOP_ERR_HIP, "kpop_ca: copying the twister to the host failed");
   KPOP_HIP(hipStreamSynchronize(st));
+  tm.mark("U = S W, twister to the host");
   return KPOP_OK;
+}
+
+}  // namespace kpop
+
+using namespace kpop;
+
+static int ca_check(const void *counts, uint64_t I, uint32_t J, const void *n_dims_out, const void *twisted, const void *inertia,
+                    const void *twister, const char *who) {
+  if (!counts || !n_dims_out || !twisted || !inertia || !twister) KPOP_FAIL(KPOP_ERR_INVALID, "%s: null argument", who);
+  if (I < 2 || J < 2) KPOP_FAIL(KPOP_ERR_INVALID, "%s: need at least 2 k-mers and 2 spectra", who);
+  return KPOP_OK;
+}
+
+extern "C" int kpop_ca(const double *counts, uint64_t n_kmers, uint32_t n_spectra, int normalize, uint32_t *n_dims_out,
+                       double *twisted, double *inertia, double *twister) {
+  KPOP_TRY(require_init());
+  const uint64_t I = n_kmers;
+  const uint32_t J = n_spectra;
+  KPOP_TRY(ca_check(counts, I, J, n_dims_out, twisted, inertia, twister, "kpop_ca"));
+  const uint32_t nd = (uint32_t)std::min<uint64_t>(I, J) - 1;
+  *n_dims_out = nd;
+  hipStream_t st = nullptr;
+  CaTimer tm;
+  CaOutput out;
+  out.twisted = twisted;
+  out.inertia = inertia;
+  out.twister = twister;
+  int rc;
+  {
+    DevBuf dS;  // the counts, standardised in place
+    KPOP_TRY(dS.alloc(I * J * 8));
+    tm.mark("alloc");
+    KPOP_TRY(host_to_device_threads(dS.p, counts, I * J * 8));
+    tm.mark("counts to the device");
+    rc = ca_on_device(dS.as<double>(), dS.as<double>(), I, J, normalize, out, st, tm);
+    tm.mark("release of the work buffers");
+  }
+  tm.mark("release of the table");
+  return rc;
+}
+
+extern "C" uint64_t kpop_dev_ca_workspace_bytes(uint64_t n_kmers, uint32_t n_spectra) {
+  return n_kmers * n_spectra * 8 + 256;  // the standardised table (the counts are not modified)
+}
+
+extern "C" int kpop_dev_ca(const double *d_counts, uint64_t n_kmers, uint32_t n_spectra, int normalize, void *d_work,
+                           uint32_t *n_dims_out, double *d_twisted, double *d_inertia, double *d_twister, void *stream) {
+  KPOP_TRY(require_init());
+  KPOP_TRY(ca_check(d_counts, n_kmers, n_spectra, n_dims_out, d_twisted, d_inertia, d_twister, "kpop_dev_ca"));
+  if (!d_work) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_ca: null workspace");
+  *n_dims_out = (uint32_t)std::min<uint64_t>(n_kmers, n_spectra) - 1;
+  CaTimer tm;
+  tm.st = (hipStream_t)stream;
+  CaOutput out;
+  out.on_device = true;
+  out.twisted = d_twisted;
+  out.inertia = d_inertia;
+  out.twister = d_twister;
+  double *d_S = reinterpret_cast<double *>(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+  return ca_on_device(d_counts, d_S, n_kmers, n_spectra, normalize, out, (hipStream_t)stream, tm);
 }

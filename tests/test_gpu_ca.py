@@ -71,3 +71,37 @@ def test_generated_twister_feeds_the_hot_path(kpop, oracle):
     metric = kpop.metric_compute(inertia)
     d = kpop.distance_rowwise(twisted_classes, t, metric)
     assert (np.argmin(d, axis=1) == np.array(truth)).mean() >= 0.95
+
+
+def test_ca_several_dim_slabs_and_device_entry(kpop):
+    """More dimensions than one slab of the twister pipeline holds (kCaDimSlab = 256 in ca.hip), with a ragged last
+    slab; and kpop_dev_ca on device pointers gives the bytes kpop_ca gives."""
+    import torch
+    from kpop_amd import api
+    I, J = 3000, 600
+    rng = np.random.RandomState(11)
+    N = synthetic_table(rng, I, J, depth=50)
+    tw, inertia, T = kpop.ca(N, True)
+    nd = J - 1
+    assert T.shape == (nd, I)
+    tw_o, in_o, T_o = ca_ref.ca(N, True)
+    np.testing.assert_allclose(inertia, in_o, rtol=1e-8, atol=1e-14)
+    lead = nd // 2
+    T_a = ca_ref.align_signs(T, T_o, axis=0)
+    assert np.max(np.abs(T_a[:lead] - T_o[:lead])) <= 1e-8 * np.max(np.abs(T_o))
+    x = N / N.sum(axis=0, keepdims=True)
+    np.testing.assert_allclose(T @ x, tw.T, rtol=0, atol=1e-9 * np.max(np.abs(tw)))
+    dev = torch.device("cuda", 0)
+    dN = torch.from_numpy(N).to(dev)
+    before = dN.clone()
+    work = torch.empty(api.dev_ca_workspace_bytes(I, J), dtype=torch.uint8, device=dev)
+    d_tw = torch.zeros(J, nd, dtype=torch.float64, device=dev)
+    d_in = torch.zeros(nd, dtype=torch.float64, device=dev)
+    d_T = torch.zeros(nd, I, dtype=torch.float64, device=dev)
+    got = api.dev_ca(dN.data_ptr(), I, J, work.data_ptr(), d_tw.data_ptr(), d_in.data_ptr(), d_T.data_ptr(), normalize=True,
+                     stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert got == nd and torch.equal(dN, before)
+    assert np.array_equal(d_in.cpu().numpy(), inertia)
+    assert np.array_equal(d_tw.cpu().numpy(), tw)
+    assert np.array_equal(d_T.cpu().numpy(), T)

@@ -13,12 +13,12 @@ for I, J in ((65664, 1636),):
     for j in range(J):
         N[:, j] = rng.poisson(base * rng.lognormal(0, 0.5, size=I) * 3)
     res = {}
-    for dbg in (1, 2, 3, 32):
+    for dbg in (1, 65, 2, 32):
         api.tune("dbg", dbg)
         kpop_amd.ca(N[:4096])
         t0 = time.time(); tw, inertia, T = kpop_amd.ca(N); t1 = time.time()
         res[dbg] = (t1 - t0, tw, inertia)
-        print("I=%d J=%d %s: %.3f s wall" % (I, J, ("blocked, %d inner sweeps" % dbg) if dbg != 32 else "plain  ", t1 - t0), flush=True)
+        print("I=%d J=%d %s: %.3f s wall" % (I, J, ("blocked, %d inner sweeps, %s" % (dbg & 15, "looped" if dbg & 64 else "rows in registers")) if dbg != 32 else "plain  ", t1 - t0), flush=True)
     api.tune("dbg", 0)
     a, b = res[2], res[32]
     print("   inertia max rel diff %.2e; |twisted| max abs diff over the leading half %.2e" % (
