@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void combine_mean_kernel(const int32_t *__rest
   if (threadIdx.x == 0) norm_partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-// RescaledMedian (lib/KMerDB.ml:705-706), up to 64 spectra: one thread per k-mer, the whole row in registers.  Loads
+// RescaledMedian (lib/KMerDB.ml:705-706), up to 32 spectra: one thread per k-mer, the whole row in registers.  Loads
 // are coalesced along k-mers exactly as in the mean; the P rescaled values are sorted by a fully unrolled bitonic
 // network of v_min_f64 / v_max_f64 pairs (P/2 * log2(P) * (log2(P)+1) / 2 compare-exchanges, no LDS, no shuffles) and
 // the upper median sorted[m/2] is picked with a select chain.  Unused slots hold +inf.
@@ -356,59 +356,76 @@ __device__ __forceinline__ double ordered_value(uint64_t k) {
   return __longlong_as_double((long long)b);
 }
 
-// The element of rank `target` (0-based, ascending) among the wave's 64*R keys, without sorting them: quickselect on
-// wave ballots.  Keys strictly between `lo` and `hi` are still candidates; the first candidate in (register, lane)
-// order is the pivot; two ballots per register count the candidates below the pivot and the keys equal to it, and one
-// of the bounds moves.  Every step is wave-uniform (no divergence, no LDS, no cross-lane data movement but one
-// readlane); ties and the zeros that dominate sparse spectra finish in a step.  Expected ~2 ln(m) steps of ~6R
-// instructions against the ~R log^2(64R) compare-exchanges plus cross-lane shuffles of a full sort.
-// All-ones keys are padding and never candidates (hi starts there); 0 is below every ordered_key.
+// The element of rank `target` (0-based, ascending) among the wave's 64*R values, without sorting them: quickselect on
+// wave ballots.  The values strictly between `lo` and `hi` are still candidates; the first candidate in (register, lane)
+// order is the pivot (the registers are looked at until one holds a candidate); two comparisons per register count the
+// values below the pivot and those not above it -- over all the values, so the bounds need not be applied -- and one of
+// the bounds moves.  Every step is wave-uniform (no divergence, no LDS, no cross-lane data movement but one readlane);
+// ties and the zeros that dominate sparse spectra finish in a step.  Expected ~2 ln(m) steps of ~2R comparisons against
+// the ~R log^2(64R) compare-exchanges plus cross-lane shuffles of a full sort.
+// The values are compared as the doubles they are (f64 comparisons issue at the full rate, 64-bit integer ones on
+// order-preserving keys do not): there is no NaN among them -- the norms are positive and finite -- and +inf is the
+// padding of the empty slots, never a candidate (hi starts there).
 template <int R>
-__device__ __forceinline__ uint64_t wave_select_rank(const uint64_t (&key)[R], uint32_t target) {
-  uint64_t lo = 0ull, hi = ~0ull;
-  uint32_t below = 0;  // keys <= lo
+__device__ __forceinline__ double wave_select_rank(const double (&v)[R], uint32_t target) {
+  double lo = -INFINITY, hi = INFINITY;
   for (;;) {
-    uint64_t pivot = 0ull;
+    double pivot = 0.;
     bool found = false;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const uint64_t alive = __ballot(key[r] > lo && key[r] < hi);
-      if (!found && alive) {
-        const int src = __ffsll((long long)alive) - 1;
-        pivot = (uint64_t)__shfl((unsigned long long)key[r], src, 64);
-        found = true;
+      if (!found) {
+        const uint64_t alive = __ballot(v[r] > lo && v[r] < hi);
+        if (alive) {
+          const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)alive) - 1);  // (uniform already: v_readlane, not a trip through LDS)
+          const uint64_t bits = (uint64_t)__double_as_longlong(v[r]);
+          pivot = __longlong_as_double((long long)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(bits >> 32), src) << 32) |
+                                                   (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bits, src)));
+          found = true;
+        }
       }
     }
-    if (!found) return lo;  // cannot happen for target < number of valid keys
-    uint32_t n_lt = 0, n_eq = 0;
+    if (!found) return lo;  // cannot happen for target < number of values
+    uint32_t n_lt = 0, n_le = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      n_lt += (uint32_t)__popcll(__ballot(key[r] > lo && key[r] < pivot));
-      n_eq += (uint32_t)__popcll(__ballot(key[r] == pivot));
+      n_lt += (uint32_t)__popcll(__ballot(v[r] < pivot));
+      n_le += (uint32_t)__popcll(__ballot(v[r] <= pivot));
     }
-    if (target < below + n_lt) hi = pivot;
-    else if (target < below + n_lt + n_eq) return pivot;
-    else {
-      lo = pivot;
-      below += n_lt + n_eq;
-    }
+    if (target < n_lt) hi = pivot;
+    else if (target < n_le) return pivot;
+    else lo = pivot;
   }
 }
 
-// RescaledMedian, 65 .. 64*R spectra: one wavefront per k-mer.  A tile of TR k-mers x m
-// spectra of raw counts is staged in LDS with lanes along k-mers (full lines from HBM); each wave then takes a
-// k-mer, rescales its m counts into registers (R per lane; which lane holds which spectrum does not matter to a
-// sort), finds the key of rank m/2 among the 64*R keys (ordered_key of the values; empty slots carry all-ones) with
+// RescaledMedian, 65 .. 64*R spectra: one wavefront per k-mer.  A tile of TR k-mers x m spectra of raw counts is staged in
+// LDS; each wave then takes a k-mer, rescales its m counts into registers (R per lane; which lane holds which spectrum
+// does not matter to a sort), finds the value of rank m/2 among the 64*R (empty slots carry +inf) with
 // wave_select_rank, and lane 0 stores it times n_sel.
+//
+// The staging is what the time went into (23.5 of 35.6 ms at 8.39 M k-mers x 500 spectra, measured with the selection
+// taken out): a dependent pair of loads per count (sel[j], then the count), four in flight per thread, and nothing in
+// flight at all while the waves select.  So: the spectra's offsets are put in LDS once; a thread fetches 16 bytes (four
+// k-mers of one spectrum) at a time, all its fetches of a tile at once; and the fetches of tile t + 1 are issued before
+// the selection of tile t and land in registers under it.
 template <int R>
+struct MedianTile {
+  static constexpr uint32_t TR = R <= 8 ? 128 / R : R == 16 ? 16 : 8;  // k-mers per tile (larger tiles stage faster but leave the selection fewer waves: measured)
+  static constexpr uint32_t NV = (uint32_t)R * 64 * (TR / 4) / 256;    // 16-byte fetches per thread and tile, at most
+};
+
+template <int R, bool VEC>
 __global__ __launch_bounds__(256) void combine_median_wave_kernel(const int32_t *__restrict__ storage, uint64_t ld, uint64_t n_rows,
                                                                   const uint32_t *__restrict__ sel, const double *__restrict__ norm,
                                                                   const double *__restrict__ rcp, uint32_t m, uint32_t n_sel,
-                                                                  double max_norm, uint32_t TR, int32_t *__restrict__ out,
+                                                                  double max_norm, int no_select, int32_t *__restrict__ out,
                                                                   double *__restrict__ norm_partial) {
-  extern __shared__ int32_t tile32[];  // [m][TR + 1]
-  const uint32_t TRp = TR + 1, tr_shift = 31 - __clz(TR);
+  constexpr uint32_t TR = MedianTile<R>::TR, TRp = TR + 1, NV = MedianTile<R>::NV, Q = TR / 4;
+  extern __shared__ uint64_t median_lds[];  // [m] offsets of the spectra, then the tile [m][TR + 1] of counts
+  uint64_t *s_off = median_lds;
+  int32_t *tile32 = reinterpret_cast<int32_t *>(median_lds + m);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (uint32_t j = threadIdx.x; j < m; j += 256) s_off[j] = (uint64_t)sel[j] * ld;
   double b[R], y[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -416,27 +433,56 @@ __global__ __launch_bounds__(256) void combine_median_wave_kernel(const int32_t 
     b[r] = col < m ? norm[col] : 1.;
     y[r] = col < m ? rcp[col] : 1.;
   }
-  const uint32_t me = m >> 1;
+  __syncthreads();
+  const uint32_t me = m >> 1, n_vec = m * Q;
   const uint64_t n_tiles = (n_rows + TR - 1) / TR;
+  int4 pre[NV];
+  auto fetch = [&](uint64_t t) {
+    const uint64_t row0 = t * TR;
+#pragma unroll
+    for (uint32_t q = 0; q < NV; ++q) {
+      const uint32_t e = threadIdx.x + 256u * q;
+      const uint32_t j = e / Q, r4 = (e % Q) * 4;
+      int4 v = make_int4(0, 0, 0, 0);
+      if (e < n_vec && row0 + r4 + 4 <= ld) {
+        const int32_t *p = storage + s_off[j] + row0 + r4;
+        if (VEC) {
+          typedef int v4i __attribute__((ext_vector_type(4)));
+          const v4i w = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p));
+          v = make_int4(w.x, w.y, w.z, w.w);
+        } else
+          v = make_int4(p[0], p[1], p[2], p[3]);
+      }
+      pre[q] = v;
+    }
+  };
   double acc_norm = 0.;
+  if (blockIdx.x < n_tiles) fetch(blockIdx.x);
   for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const uint64_t row0 = t * TR;
-    __syncthreads();
-#pragma unroll 4
-    for (uint32_t e = threadIdx.x; e < m * TR; e += 256) {
-      const uint32_t rr = e & (TR - 1), j = e >> tr_shift;
-      tile32[j * TRp + rr] = row0 + rr < n_rows ? __builtin_nontemporal_load(storage + (uint64_t)sel[j] * ld + row0 + rr) : 0;
+    __syncthreads();  // the tile before this one has been read
+#pragma unroll
+    for (uint32_t q = 0; q < NV; ++q) {
+      const uint32_t e = threadIdx.x + 256u * q;
+      if (e < n_vec) {
+        int32_t *d = tile32 + (e / Q) * TRp + (e % Q) * 4;
+        d[0] = pre[q].x;
+        d[1] = pre[q].y;
+        d[2] = pre[q].z;
+        d[3] = pre[q].w;
+      }
     }
     __syncthreads();
+    if (t + gridDim.x < n_tiles) fetch(t + gridDim.x);  // in flight under the selection
     for (uint32_t rr = wv; rr < TR && row0 + rr < n_rows; rr += 4) {
-      uint64_t key[R];
+      double v[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const uint32_t col = (uint32_t)r * 64 + lane;
-        key[r] = ~0ull;
-        if (col < m) key[r] = ordered_key(div_rn(__dmul_rn((double)tile32[col * TRp + rr], max_norm), b[r], y[r]));
+        v[r] = INFINITY;
+        if (col < m) v[r] = div_rn(__dmul_rn((double)tile32[col * TRp + rr], max_norm), b[r], y[r]);
       }
-      const double med = m ? ordered_value(wave_select_rank<R>(key, me)) : 0.;
+      const double med = no_select ? v[0] : m ? wave_select_rank<R>(v, me) : 0.;
       const double res = __dmul_rn(med, (double)n_sel);
       if (lane == 0) {
         acc_norm += res;
@@ -728,27 +774,46 @@ extern "C" int kpop_dev_counter_combine(const int32_t *d_storage, uint64_t ld, u
   if (criterion == KPOP_COMBINE_MEAN) {
     grid = std::min<uint32_t>(div_up(n_rows, 256), 1u << 16);
     combine_mean_kernel<<<dim3(grid), dim3(256), 0, st>>>(d_storage, ld, n_rows, d_sel, d_norm, rcp, n_valid, max_norm, d_out, partial);
-  } else if (n_valid <= 64) {
+  } else if (n_valid <= 32) {
+    // (33 .. 64 spectra go to the wave kernel: 2.69 against 2.49 ms at 8.39 M k-mers x 64 when every count is positive, but
+    // 1.08 ms when 70 % are zero, and the tables this runs on are mostly zeros)
     grid = std::min<uint32_t>(div_up(n_rows, 256), 1u << 16);
 #define KPOP_MEDIAN_THREAD(PP)                                                                                             \
   combine_median_thread_kernel<PP><<<dim3(grid), dim3(256), 0, st>>>(d_storage, ld, n_rows, d_sel, d_norm, rcp, n_valid, n_sel, \
                                                                       max_norm, d_out, partial)
     if (n_valid <= 8) KPOP_MEDIAN_THREAD(8);
     else if (n_valid <= 16) KPOP_MEDIAN_THREAD(16);
-    else if (n_valid <= 32) KPOP_MEDIAN_THREAD(32);
-    else KPOP_MEDIAN_THREAD(64);
+    else KPOP_MEDIAN_THREAD(32);
 #undef KPOP_MEDIAN_THREAD
-  } else if (n_valid <= 1024) {
-    const uint32_t TR = n_valid <= 128 ? 64 : n_valid <= 256 ? 32 : n_valid <= 512 ? 16 : 8;
-    const size_t lds = (size_t)std::max<uint32_t>(1, n_valid) * (TR + 1) * 4;
-    grid = (uint32_t)std::min<uint64_t>((n_rows + TR - 1) / TR, 1u << 16);
-#define KPOP_MEDIAN_WAVE(RR)                                                                                                     \
-  combine_median_wave_kernel<RR><<<dim3(grid), dim3(256), lds, st>>>(d_storage, ld, n_rows, d_sel, d_norm, rcp, n_valid, n_sel, \
-                                                                      max_norm, TR, d_out, partial)
-    if (n_valid <= 128) KPOP_MEDIAN_WAVE(2);
-    else if (n_valid <= 256) KPOP_MEDIAN_WAVE(4);
-    else if (n_valid <= 512) KPOP_MEDIAN_WAVE(8);
-    else KPOP_MEDIAN_WAVE(16);
+  } else if (n_valid <= 2048) {
+    const bool vec = (reinterpret_cast<uintptr_t>(d_storage) & 15) == 0 && (ld & 3) == 0;
+    const int no_select = (ctx().tune_dbg & 256) ? 1 : 0;  // (a probe: the staging alone)
+#define KPOP_MEDIAN_WAVE(RR, VV)                                                                                                    \
+  do {                                                                                                                              \
+    constexpr uint32_t TR = MedianTile<RR>::TR;                                                                                     \
+    const size_t lds = (size_t)n_valid * 8 + (size_t)n_valid * (TR + 1) * 4;                                                        \
+    static bool attr_set = false;                                                                                                   \
+    if (!attr_set) {                                                                                                                \
+      KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&combine_median_wave_kernel<RR, VV>),                             \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));                                 \
+      attr_set = true;                                                                                                              \
+    }                                                                                                                               \
+    grid = (uint32_t)std::min<uint64_t>((n_rows + TR - 1) / TR, 1u << 16);                                                          \
+    combine_median_wave_kernel<RR, VV><<<dim3(grid), dim3(256), lds, st>>>(d_storage, ld, n_rows, d_sel, d_norm, rcp, n_valid,     \
+                                                                            n_sel, max_norm, no_select, d_out, partial);           \
+  } while (0)
+#define KPOP_MEDIAN_WAVE_R(RR)       \
+  do {                               \
+    if (vec) KPOP_MEDIAN_WAVE(RR, true); \
+    else KPOP_MEDIAN_WAVE(RR, false);    \
+  } while (0)
+    if (n_valid <= 64) KPOP_MEDIAN_WAVE_R(1);
+    else if (n_valid <= 128) KPOP_MEDIAN_WAVE_R(2);
+    else if (n_valid <= 256) KPOP_MEDIAN_WAVE_R(4);
+    else if (n_valid <= 512) KPOP_MEDIAN_WAVE_R(8);
+    else if (n_valid <= 1024) KPOP_MEDIAN_WAVE_R(16);
+    else KPOP_MEDIAN_WAVE_R(32);
+#undef KPOP_MEDIAN_WAVE_R
 #undef KPOP_MEDIAN_WAVE
   } else {
     uint32_t P = 2;

@@ -178,3 +178,57 @@ def test_counter_more_spectra_than_grid_y(kpop, oracle):
         out, norm = kpop.counter_combine(cols, sel, cs[:, 2], crit)
         want, wnorm = oracle.counter_combine(cols, sel, cs[:, 2], crit)
         assert np.array_equal(out, want) and norm == pytest.approx(wnorm, rel=1e-12)
+
+
+@pytest.mark.parametrize("n_cols", [65, 128, 129, 257, 512, 513, 1025, 1637, 2048, 2049])
+def test_median_awkward_values(kpop, oracle, n_cols):
+    """The rescaled median where selection has the least to hold on to: column counts next to the widths the kernels
+    change at; rescaled values that agree to many digits without being equal (count c over norm n against c+1 over a
+    norm a hair larger); runs of exact ties; counts that wrapped around int32 (negative) and the largest positive
+    ones; spectra with nothing but zeros elsewhere."""
+    rng = np.random.default_rng(n_cols)
+    n_rows = 403
+    table = rng.poisson(6.0, size=(n_cols, n_rows)).astype(np.int64)
+    table[:, 0:40] = 7                                     # exact ties wherever the norms tie too
+    table[:, 40:80] = np.arange(n_cols)[:, None] % 3 + 1000  # near ties once rescaled
+    table[::7, 80:120] = -5                                # wrapped counts
+    table[::11, 120:160] = 2**31 - 1
+    table[:, 160:200] = 0
+    table[::2, 200:240] = 0                                # exactly half zeros: the upper median sits on the edge
+    cols = [c.astype(np.int32) for c in table]
+    col_sum = np.abs(table).sum(axis=1).astype(np.float64) + rng.integers(0, 3, n_cols)  # many norms equal or adjacent
+    col_sum[3] = col_sum[4]
+    sel = list(rng.permutation(n_cols))
+    out, norm = kpop.counter_combine(cols, sel, col_sum, 1)
+    want, wnorm = oracle.counter_combine(cols, sel, col_sum, 1)
+    assert np.array_equal(out, want), np.flatnonzero(out != want)[:10]
+    assert norm == pytest.approx(wnorm, rel=1e-12)
+
+
+def test_median_storage_not_16_byte_aligned(kpop, oracle):
+    """kpop_dev_counter_combine on storage that starts 4 bytes off a 16-byte boundary: the tile loads fall back from
+    16-byte fetches to single counts, same result."""
+    import torch
+    from kpop_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(99)
+    n_rows, n_cols = 1000, 200
+    table = rng.poisson(3.0, size=(n_cols, n_rows)).astype(np.int32)
+    ld = int(L.kpop_dev_counter_ld(n_rows))
+    dev = torch.device("cuda", 0)
+    flat = torch.zeros(n_cols * ld + 8, dtype=torch.int32, device=dev)
+    view = flat[1:1 + n_cols * ld].view(n_cols, ld)
+    view[:, :n_rows] = torch.from_numpy(table).to(dev)
+    assert view.data_ptr() % 16 == 4
+    col_sum = table.sum(axis=1).astype(np.float64)
+    sel = torch.arange(n_cols, dtype=torch.int32, device=dev)
+    norm = torch.from_numpy(col_sum).to(dev)
+    ws = torch.empty(int(L.kpop_dev_counter_workspace_bytes(n_cols, n_rows)), dtype=torch.uint8, device=dev)
+    out = torch.empty(n_rows, dtype=torch.int32, device=dev)
+    nrm = torch.empty(1, dtype=torch.float64, device=dev)
+    rc = L.kpop_dev_counter_combine(view.data_ptr(), ld, n_rows, sel.data_ptr(), norm.data_ptr(), n_cols, n_cols, float(col_sum.max()), 1,
+                                    ws.data_ptr(), out.data_ptr(), nrm.data_ptr(), None)
+    assert rc == 0, L.kpop_last_error()
+    torch.cuda.synchronize()
+    want, _ = oracle.counter_combine(list(table), list(range(n_cols)), col_sum, 1)
+    assert np.array_equal(out.cpu().numpy(), want)
