@@ -20,6 +20,7 @@
 //     forces it);
 //   * protein k-mers use the residue encoding declared in csrc/kmer.h (the reference's lives in the absent BiOCamLib);
 //     Sequences.Lint.proteinize is taken as dnaize's twin: upper-case, dashes and blanks dropped.
+#include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -124,6 +125,9 @@ struct Sink {  // where a batch of reads goes: the GPU and the text writer, or t
     const bool per_read = P.label.empty();
     stream = per_read && P.output.empty() && P.content != KPOP_PROTEIN && stdout_reader_is_dropin_twistdb();
     if (stream) {
+#ifdef F_SETPIPE_SZ
+      (void)fcntl(1, F_SETPIPE_SZ, 1 << 20);  // fewer, larger hand-overs to the reader (the default is 64 KB)
+#endif
       fflush(stdout);
       ReadStreamHeader h;
       h.k = (uint32_t)P.k;

@@ -31,6 +31,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 #include "../../include/kpop_hip.h"
@@ -277,6 +278,9 @@ struct BlockQueue {
 // The reads stream (fast_seq.h): KPopCount sent the linted reads instead of their spectra; count and twist them in one
 // kernel.  Equal to parsing the text KPopCount would have written (bin/KPopCount.ml:44-46) and twisting that.
 void twist_read_stream(int fd, TwisterReg &T, bool normalize, std::vector<RowPiece> &pieces, bool verbose) {
+#ifdef F_SETPIPE_SZ
+  (void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);  // (fails on anything but a pipe: fine)
+#endif
   ReadStreamReader rs(fd);
   const int k = (int)rs.header.k, content = (int)rs.header.content;
   if (k < 1 || k > 30 || (content != KPOP_DNA_DS && content != KPOP_DNA_SS)) throw Error("reads stream: unsupported k or content");
@@ -439,6 +443,10 @@ void add_twisted_from_files(TwisterReg &T, Table &twisted, const std::vector<std
   twisted.row_names.swap(out.row_names);
   twisted.data.swap(out.data);
   stage_mark("KPopTwistDB", "register assembled");
+  // millions of label strings and gigabytes of rows are now garbage: giving them back takes 0.2 s at 4M reads, so a
+  // thread of its own does it while the next action runs
+  auto *garbage = new std::tuple<std::vector<RowPiece>, std::vector<std::string>, Table>(std::move(pieces), std::move(labels), std::move(out));
+  std::thread([garbage] { delete garbage; }).detach();
 }
 
 void write_summary(const std::string &path, const std::vector<std::string> &row_names, const std::vector<std::string> &col_names,
@@ -449,45 +457,31 @@ void write_summary(const std::string &path, const std::vector<std::string> &row_
   FILE *f = (path == "/dev/stdout") ? stdout : fopen(path.c_str(), "wb");
   if (!f) throw Error("cannot write '" + path + "'");
   const char *q = quote ? "\"" : "";
-  // lib/Matrix.ml:684-690; lines formatted by the host threads, a few hundred thousand at a time, written in order
-  const size_t total = row_names.size(), slab = 1u << 18;
-  for (size_t s0 = 0; s0 < total; s0 += slab) {
-    const size_t s1 = std::min(total, s0 + slab);
-    std::vector<std::string> text(64);
-    std::vector<std::pair<size_t, size_t>> span(64, {0, 0});
-    std::atomic<unsigned> next{0};
-    parallel_for(s1 - s0, 2048, [&](size_t lo, size_t hi) {
-      const unsigned me = next++;
-      if (me >= text.size()) throw Error("write_summary: more pieces than expected");
-      span[me] = {lo, hi};
-      std::string &o = text[me];
-      o.reserve((hi - lo) * (size_t)(96 + 40 * std::min<uint32_t>(stride, 4)));
-      char num[512];
-      for (size_t j = s0 + lo; j < s0 + hi; ++j) {
-        int len = snprintf(num, sizeof(num), "\t%.15g\t%.15g\t%.15g\t%.15g", stats[j * 4], stats[j * 4 + 1], stats[j * 4 + 2], stats[j * 4 + 3]);
-        o += q;
-        o += row_names[j];
-        o += q;
-        o.append(num, (size_t)len);
-        for (uint32_t e = 0; e < n[j]; ++e) {
-          o += '\t';
-          o += q;
-          o += col_names[idx[j * stride + e]];
-          o += q;
-          len = snprintf(num, sizeof(num), "\t%.15g\t%.15g", dist[j * stride + e], z[j * stride + e]);
-          o.append(num, (size_t)len);
-        }
-        o += '\n';
+  // lib/Matrix.ml:684-690
+  try {
+    write_rows_parallel(f, path, row_names.size(), (size_t)(96 + 40 * std::min<uint32_t>(stride, 4)), [&](size_t j, std::string &o) {
+      o += q;
+      o += row_names[j];
+      o += q;
+      for (int c = 0; c < 4; ++c) {
+        o += '\t';
+        append_g(o, stats[j * 4 + c], 15);
       }
+      for (uint32_t e = 0; e < n[j]; ++e) {
+        o += '\t';
+        o += q;
+        o += col_names[idx[j * stride + e]];
+        o += q;
+        o += '\t';
+        append_g(o, dist[j * stride + e], 15);
+        o += '\t';
+        append_g(o, z[j * stride + e], 15);
+      }
+      o += '\n';
     });
-    std::vector<unsigned> order;
-    for (unsigned i = 0; i < next && i < text.size(); ++i) order.push_back(i);
-    std::sort(order.begin(), order.end(), [&](unsigned a, unsigned b) { return span[a].first < span[b].first; });
-    for (unsigned i : order)
-      if (fwrite(text[i].data(), 1, text[i].size(), f) != text[i].size()) {
-        if (f != stdout) fclose(f);
-        throw Error("cannot write '" + path + "'");
-      }
+  } catch (...) {
+    if (f != stdout) fclose(f);
+    throw;
   }
   if (f != stdout) fclose(f);
   else fflush(f);
@@ -888,6 +882,9 @@ int main(int argc, char **argv) {
   stage_mark("KPopTwistDB", "last action done");
   g_workers.reset();
   if (g_warm.joinable()) g_warm.join();
-  T.reset();
-  return 0;
+  // Everything is written and closed.  Returning would take the registers apart value by value and the HIP runtime with
+  // them (0.25-0.4 s with 4M rows in memory): the process ends here instead and the system takes it all back at once.
+  fflush(stdout);
+  fflush(stderr);
+  _exit(0);
 }

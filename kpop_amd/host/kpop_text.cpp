@@ -6,9 +6,15 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <sys/mman.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <charconv>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <thread>
 
 namespace kpop_host {
@@ -24,6 +30,50 @@ void stage_mark(const char *tool, const char *stage) {
   if (t0 < 0.) t0 = last = now;
   fprintf(stderr, "[timing] %s: %-44s +%.3f s  (%.3f s)\n", tool, stage, now - last, now - t0);
   last = now;
+}
+
+// ------------------------------------------------------------------ large blocks
+namespace {
+const bool g_huge_pages = [] {
+  const char *e = getenv("KPOP_HUGE_PAGES");
+  return !(e && e[0] == '0');
+}();
+std::mutex g_huge_mutex;
+std::vector<std::pair<void *, size_t>> g_huge_blocks;  // (address, mapped bytes) of the live ones: a handful at any time
+}  // namespace
+
+void *huge_block_alloc(size_t bytes) {
+  if (!g_huge_pages) return nullptr;
+  const size_t two_mb = 2u << 20, mapped = (bytes + two_mb - 1) / two_mb * two_mb + two_mb;
+  char *raw = (char *)mmap(nullptr, mapped, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (raw == (char *)MAP_FAILED) return nullptr;
+  char *p = (char *)(((uintptr_t)raw + two_mb - 1) & ~(uintptr_t)(two_mb - 1));
+  if (p > raw) munmap(raw, (size_t)(p - raw));
+  const size_t keep = (bytes + two_mb - 1) / two_mb * two_mb;
+  if (p + keep < raw + mapped) munmap(p + keep, (size_t)(raw + mapped - (p + keep)));
+#ifdef MADV_HUGEPAGE
+  (void)madvise(p, keep, MADV_HUGEPAGE);
+#endif
+  std::lock_guard<std::mutex> lk(g_huge_mutex);
+  g_huge_blocks.push_back({p, keep});
+  return p;
+}
+
+bool huge_block_free(void *p, size_t) {
+  size_t mapped = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_huge_mutex);
+    for (size_t i = 0; i < g_huge_blocks.size(); ++i)
+      if (g_huge_blocks[i].first == p) {
+        mapped = g_huge_blocks[i].second;
+        g_huge_blocks[i] = g_huge_blocks.back();
+        g_huge_blocks.pop_back();
+        break;
+      }
+  }
+  if (!mapped) return false;
+  munmap(p, mapped);
+  return true;
 }
 
 // ------------------------------------------------------------------ threads
@@ -92,9 +142,87 @@ bool hex_to_hash(const std::string &s, uint64_t *h) {
 }
 
 std::string format_g(double x, int precision) {
-  char buf[64];
-  snprintf(buf, sizeof(buf), "%.*g", precision, x);
-  return buf;
+  std::string s;
+  append_g(s, x, precision);
+  return s;
+}
+
+void append_g(std::string &out, double x, int precision) {
+  char buf[512];
+  if (precision >= 1 && precision <= 17) {
+    const std::to_chars_result r = std::to_chars(buf, buf + sizeof(buf), x, std::chars_format::general, precision);
+    if (r.ec == std::errc()) {
+      out.append(buf, (size_t)(r.ptr - buf));
+      return;
+    }
+  }
+  const int len = snprintf(buf, sizeof(buf), "%.*g", precision, x);
+  if (len > 0) out.append(buf, std::min((size_t)len, sizeof(buf) - 1));
+}
+
+void write_rows_parallel(FILE *f, const std::string &path, size_t n, size_t reserve_per_row,
+                         const std::function<void(size_t row, std::string &out)> &fmt) {
+  const size_t slab = 1u << 18;
+  struct Slab {
+    std::vector<std::string> text;
+    std::vector<unsigned> order;
+  };
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<Slab> ready;
+  bool done = false;
+  std::atomic<bool> failed{false};
+  std::thread writer([&] {
+    for (;;) {
+      Slab sl;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return done || !ready.empty(); });
+        if (ready.empty()) return;
+        sl = std::move(ready.front());
+        ready.pop_front();
+      }
+      cv.notify_all();
+      for (unsigned i : sl.order)
+        if (!failed && fwrite(sl.text[i].data(), 1, sl.text[i].size(), f) != sl.text[i].size()) failed = true;
+    }
+  });
+  std::exception_ptr error;
+  try {
+    for (size_t s0 = 0; s0 < n && !failed; s0 += slab) {
+      const size_t s1 = std::min(n, s0 + slab);
+      Slab sl;
+      sl.text.resize(64);
+      std::vector<std::pair<size_t, size_t>> span(64, {0, 0});
+      std::atomic<unsigned> next{0};
+      parallel_for(s1 - s0, 1024, [&](size_t lo, size_t hi) {
+        const unsigned me = next++;
+        if (me >= sl.text.size()) throw Error("write_rows_parallel: more pieces than expected");
+        span[me] = {lo, hi};
+        std::string &o = sl.text[me];
+        o.reserve((hi - lo) * reserve_per_row);
+        for (size_t r = s0 + lo; r < s0 + hi; ++r) fmt(r, o);
+      });
+      for (unsigned i = 0; i < next && i < sl.text.size(); ++i) sl.order.push_back(i);
+      std::sort(sl.order.begin(), sl.order.end(), [&](unsigned a, unsigned b) { return span[a].first < span[b].first; });
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return ready.size() < 2; });  // at most two slabs of text waiting
+        ready.push_back(std::move(sl));
+      }
+      cv.notify_all();
+    }
+  } catch (...) {
+    error = std::current_exception();
+  }
+  {
+    std::lock_guard<std::mutex> lk(m);
+    done = true;
+  }
+  cv.notify_all();
+  writer.join();
+  if (error) std::rethrow_exception(error);
+  if (failed) throw Error("cannot write '" + path + "'");
 }
 
 // ------------------------------------------------------------------ line reader
@@ -568,18 +696,20 @@ void write_table(const std::string &path, const Table &t, int precision) {
   buf += '\n';
   fwrite(buf.data(), 1, buf.size(), f);
   const size_t nc = t.cols();
-  char num[64];
-  for (size_t r = 0; r < t.rows(); ++r) {
-    buf.clear();
-    buf += '"';
-    buf += t.row_names[r];
-    buf += '"';
-    for (size_t c = 0; c < nc; ++c) {
-      int len = snprintf(num, sizeof(num), "\t%.*g", precision, t.data[r * nc + c]);
-      buf.append(num, (size_t)len);
-    }
-    buf += '\n';
-    fwrite(buf.data(), 1, buf.size(), f);
+  try {
+    write_rows_parallel(f, path, t.rows(), 8 + nc * 20, [&](size_t r, std::string &o) {
+      o += '"';
+      o += t.row_names[r];
+      o += '"';
+      for (size_t c = 0; c < nc; ++c) {
+        o += '\t';
+        append_g(o, t.data[r * nc + c], precision);
+      }
+      o += '\n';
+    });
+  } catch (...) {
+    if (f != stdout) fclose(f);
+    throw;
   }
   if (f != stdout) fclose(f);
   else fflush(f);

@@ -18,6 +18,9 @@ struct Error : std::runtime_error {
   explicit Error(const std::string &m) : std::runtime_error(m) {}
 };
 
+void *huge_block_alloc(size_t bytes);         // nullptr: not available, use the ordinary allocator
+bool huge_block_free(void *p, size_t bytes);  // false: p did not come from huge_block_alloc
+
 // A vector of doubles whose resize() leaves the new elements uninitialised: the big matrices (a million twisted rows are
 // half a GB) are filled by whoever sized them, and a zero-fill first would touch every page one more time.
 template <class T>
@@ -34,7 +37,22 @@ struct DefaultInitAlloc : std::allocator<T> {
     if constexpr (sizeof...(A) == 0) ::new ((void *)p) U;
     else ::new ((void *)p) U(std::forward<A>(a)...);
   }
+  // Large blocks are mapped on their own, 2 MB-aligned, and offered to transparent huge pages: whoever fills them (a copy
+  // from the device, the threads laying rows) takes one page fault per 2 MB instead of one per 4 KB, and giving them back is
+  // as much cheaper.  KPOP_HUGE_PAGES=0 turns it off.
+  T *allocate(size_t n) {
+    if (n * sizeof(T) >= kHugeBlock) {
+      if (void *p = huge_block_alloc(n * sizeof(T))) return static_cast<T *>(p);
+    }
+    return std::allocator<T>::allocate(n);
+  }
+  void deallocate(T *p, size_t n) {
+    if (n * sizeof(T) >= kHugeBlock && huge_block_free(p, n * sizeof(T))) return;
+    std::allocator<T>::deallocate(p, n);
+  }
+  static constexpr size_t kHugeBlock = 32u << 20;
 };
+
 using DVec = std::vector<double, DefaultInitAlloc<double>>;
 
 // KPOP_TIMING=1: "<tool>: <stage> +<seconds since the previous mark> (<seconds since the first>)" on stderr
@@ -143,5 +161,13 @@ void merge_rowwise(Table &into, const Table &add);
 std::vector<uint32_t> order_rows_by_label(const std::vector<std::string> &labels, size_t n_existing);
 
 std::string format_g(double x, int precision);  // "%.*g"
+// The same characters printf("%.*g") gives, appended to `out`: std::to_chars (shortest-path digit generation, about 4x
+// the speed of glibc's multi-precision printf; equal on every value tried, tests/host/format_g_check.cpp).
+void append_g(std::string &out, double x, int precision);
+
+// Rows [0, n) of a text file: formatted by the host threads a slab of rows at a time (fmt appends row r's text, newline
+// included, to `out`) and written in row order by a thread of their own while the next slab is being formatted.
+void write_rows_parallel(FILE *f, const std::string &path, size_t n, size_t reserve_per_row,
+                         const std::function<void(size_t row, std::string &out)> &fmt);
 
 }  // namespace kpop_host

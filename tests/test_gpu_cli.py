@@ -670,7 +670,7 @@ KPopTwistDB -T "$THREADS" -I T "$PREFIX_OUT" -o T "$PREFIX_OUT"
         np.testing.assert_allclose(da, db, rtol=1e-12, atol=1e-13)   # W went through %.15g text on the way
 
 
-def test_splits_through_the_cli(tmp_path, oracle, pyref):
+def test_splits_through_the_cli(tmp_path, kpop, oracle, pyref):
     """KPopTwistDB -e -p -O s (bin/KPopTwistDB.ml:494-506,534-535): embeddings from the twisted register, splits by both
     algorithms, the declared '.PhyloSplits.txt' text against the restatement run on the embeddings the tool itself wrote"""
     k, d = 5, 6

@@ -97,6 +97,19 @@ def test_row_ordering_matches_the_references_string_map(tmp_path):
                 assert r.returncode == 0, (threads, seed, rows, alphabet, r.stdout)
 
 
+def test_number_formatting_equals_printf(tmp_path):
+    """append_g (std::to_chars, what the tables and summaries are now printed with) gives printf("%.*g")'s characters:
+    random bit patterns, short decimals, halves, the edges of the exponent range, NaNs of either sign; precisions 15
+    (the default), 17, 6, 1, and 0 / 20 (which fall back to printf itself)"""
+    out = tmp_path / "format_g_check"
+    host = os.path.join(ROOT, "kpop_amd", "host")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-o", str(out), os.path.join(ROOT, "tests", "host", "format_g_check.cpp"),
+                    os.path.join(host, "kpop_text.cpp")], check=True)
+    for seed in (1, 2):
+        r = subprocess.run([str(out), str(seed), "600000"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout
+
+
 def test_centroids_splits_match_the_python_restatement(tmp_path, pyref):
     """SplitsAlgorithm.Centroids (lib/Matrix.ml:361-521,601-612): the drop-in's host implementation against oracle/pyref.py's,
     both drawing from the declared SplitMix64 stream: same splits, same weights to the printed precision, same order"""
