@@ -24,6 +24,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <string>
@@ -296,8 +297,14 @@ int main(int argc, char **argv) {
       write_spectrum_body(out, merged.hash.data(), c32.data(), c32.size(), name_digits(P.k, P.content == KPOP_PROTEIN));
     }
     if (P.verbose) fprintf(stderr, "(KPopCount): Added %llu reads.\n", (unsigned long long)n_reads);
-    if (out != stdout) fclose(out);
-    else fflush(out);
+    if (out != stdout) {
+      if (fclose(out) != 0) throw Error("cannot write '" + P.output + "'");
+    } else if (fflush(out) != 0)
+      throw Error("cannot write to the standard output");
+    stage_mark("KPopCount", "output closed");
+    // everything is written: end here rather than take the HIP runtime and the buffers apart piece by piece (0.3 s)
+    fflush(stderr);
+    _exit(0);
   } catch (const std::exception &e) {
     fprintf(stderr, "(KPopCount): FATAL: %s\n", e.what());
     return 1;

@@ -162,7 +162,10 @@ void append_g(std::string &out, double x, int precision) {
 
 void write_rows_parallel(FILE *f, const std::string &path, size_t n, size_t reserve_per_row,
                          const std::function<void(size_t row, std::string &out)> &fmt) {
-  const size_t slab = 1u << 18;
+  // about 64 MB of text per slab and not less than 64 KB of it per thread, whatever a row is (a read's spectrum, a genome's)
+  const size_t row_bytes = std::max<size_t>(1, reserve_per_row);
+  const size_t slab = std::max<size_t>(1, std::min<size_t>(1u << 18, (64u << 20) / row_bytes));
+  const size_t min_rows = std::max<size_t>(1, (64u << 10) / row_bytes);
   struct Slab {
     std::vector<std::string> text;
     std::vector<unsigned> order;
@@ -195,7 +198,7 @@ void write_rows_parallel(FILE *f, const std::string &path, size_t n, size_t rese
       sl.text.resize(64);
       std::vector<std::pair<size_t, size_t>> span(64, {0, 0});
       std::atomic<unsigned> next{0};
-      parallel_for(s1 - s0, 1024, [&](size_t lo, size_t hi) {
+      parallel_for(s1 - s0, min_rows, [&](size_t lo, size_t hi) {
         const unsigned me = next++;
         if (me >= sl.text.size()) throw Error("write_rows_parallel: more pieces than expected");
         span[me] = {lo, hi};
@@ -508,10 +511,12 @@ void parse_chunk(const char *s, const char *e, size_t name_len, uint64_t absent,
 
 }  // namespace
 
-static void parse_spectra_buffer(const std::vector<char> &buf, size_t name_len, uint64_t absent, HashedSpectra &out, unsigned threads);
+static void parse_spectra_buffer(const char *base, size_t size, size_t name_len, uint64_t absent, HashedSpectra &out, unsigned threads,
+                                 bool first_block = true, uint64_t lines_before = 0, uint64_t *n_lines = nullptr);
 
 void read_spectra_hashed(const std::string &path, size_t name_len, uint64_t absent, HashedSpectra &out, unsigned threads) {
-  parse_spectra_buffer(slurp(path), name_len, absent, out, threads);
+  const std::vector<char> buf = slurp(path);
+  parse_spectra_buffer(buf.data(), buf.size(), name_len, absent, out, threads);
 }
 
 void read_spectra_hashed_fd(int fd, const char *head, size_t head_len, size_t name_len, uint64_t absent, HashedSpectra &out,
@@ -534,12 +539,11 @@ void read_spectra_hashed_fd(int fd, const char *head, size_t head_len, size_t na
     len += (size_t)got;
   }
   buf.resize(len);
-  parse_spectra_buffer(buf, name_len, absent, out, threads);
+  parse_spectra_buffer(buf.data(), buf.size(), name_len, absent, out, threads);
 }
 
-static void parse_spectra_buffer(const std::vector<char> &buf, size_t name_len, uint64_t absent, HashedSpectra &out, unsigned threads) {
-  const char *base = buf.data();
-  const size_t size = buf.size();
+static void parse_spectra_buffer(const char *base, size_t size, size_t name_len, uint64_t absent, HashedSpectra &out, unsigned threads,
+                                 bool first_block, uint64_t lines_before_block, uint64_t *n_lines) {
   const unsigned T = pick_threads(threads, size, 4u << 20);
   std::vector<size_t> cut(T + 1, size);
   cut[0] = 0;
@@ -555,11 +559,11 @@ static void parse_spectra_buffer(const std::vector<char> &buf, size_t name_len, 
   parse_chunk(base + cut[0], base + cut[1], name_len, absent, res[0]);
   for (std::thread &th : pool) th.join();
   // errors in file order, with the sequential parser's precedence on line 1 (column count, then Header_expected)
-  uint64_t lines_before = 0;
+  uint64_t lines_before = lines_before_block;
   for (unsigned t = 0; t < T; ++t) {
     const ChunkResult &r = res[t];
     const bool col_error_on_line_1 = r.failed && r.error_line == 1 && t == 0;
-    if (t == 0 && r.n_lines >= 1 && !r.first_line_is_header && !col_error_on_line_1)
+    if (t == 0 && first_block && r.n_lines >= 1 && !r.first_line_is_header && !col_error_on_line_1)
       throw Error("Header_expected(\"" + r.first_line + "\")");  // lib/Twister.ml:106-107
     if (r.failed) {
       if (r.error_line) throw Error("Wrong_number_of_columns(" + std::to_string(lines_before + r.error_line) + r.error);
@@ -567,6 +571,7 @@ static void parse_spectra_buffer(const std::vector<char> &buf, size_t name_len, 
     }
     lines_before += r.n_lines;
   }
+  if (n_lines) *n_lines = lines_before - lines_before_block;
   size_t total = out.hash.size();
   for (const ChunkResult &r : res) total += r.hash.size();
   const size_t start = out.hash.size();
@@ -589,51 +594,92 @@ static void parse_spectra_buffer(const std::vector<char> &buf, size_t name_len, 
   if (open) out.offsets.push_back(at);
 }
 
+void parse_spectra_block(const char *data, size_t size, size_t name_len, uint64_t absent, bool first_block, uint64_t lines_before,
+                         HashedSpectra &out, uint64_t *n_lines, unsigned threads) {
+  out = HashedSpectra();
+  parse_spectra_buffer(data, size, name_len, absent, out, threads, first_block, lines_before, n_lines);
+}
+
+SpectraTextStream::SpectraTextStream(int fd, const char *head, size_t head_len, size_t block_bytes)
+    : fd_(fd), block_bytes_(std::max<size_t>(block_bytes, 2)) {
+  if (head_len) carry_.assign(head, head + head_len);
+}
+
+bool SpectraTextStream::next(TextBlock &block) {
+  block.clear();
+  block.swap(carry_);
+  size_t target = block_bytes_;
+  for (;;) {
+    while (!eof_ && block.size() < target) {
+      const size_t at = block.size();
+      block.resize(target);
+      size_t len = at;
+      while (len < target) {
+        const ssize_t got = read(fd_, block.data() + len, target - len);
+        if (got < 0) {
+          if (errno == EINTR) continue;
+          throw Error(std::string("read failed: ") + strerror(errno));
+        }
+        if (got == 0) {
+          eof_ = true;
+          break;
+        }
+        len += (size_t)got;
+      }
+      block.resize(len);
+    }
+    if (eof_) return !block.empty();
+    // the last header line that is not the block's first line: the block ends before it
+    const char *base = block.data();
+    size_t limit = block.size() - 1;  // bytes in which to look for a newline (one that has a byte after it)
+    while (limit > 0) {
+      const char *nl = (const char *)memrchr(base, '\n', limit);
+      if (!nl) break;
+      const size_t line = (size_t)(nl - base) + 1;  // where the line after it begins
+      if (base[line] == '\t') {
+        carry_.assign(base + line, base + block.size());
+        block.resize(line);
+        return true;
+      }
+      limit = (size_t)(nl - base);
+      if (block.size() - limit > (16u << 20)) break;  // (a last spectrum of more than 16 MB: take more input instead)
+    }
+    target = block.size() * 2;  // one spectrum longer than the block: keep reading
+  }
+}
+
 void write_spectra_parallel(FILE *f, const std::vector<std::string> &labels, const uint64_t *hash, const uint32_t *count,
                             const uint64_t *offsets, int digits, unsigned threads) {
+  (void)threads;  // (the host threads of parallel_for)
   const size_t n = labels.size();
   if (n == 0) return;
-  const unsigned T = pick_threads(threads, (size_t)(offsets[n] - offsets[0]), 1u << 18);
-  std::vector<std::string> text(T);
-  auto work = [&](unsigned t) {
-    const size_t lo = n * t / T, hi = n * (t + 1) / T;
-    std::string &o = text[t];
-    size_t label_bytes = 0;
-    for (size_t r = lo; r < hi; ++r) label_bytes += labels[r].size() + 2;
-    o.reserve(label_bytes + (size_t)(offsets[hi] - offsets[lo]) * (size_t)(digits + 8));
+  const size_t per_row = (size_t)((offsets[n] - offsets[0]) / n + 1) * (size_t)(digits + 8) + 24;
+  write_rows_parallel(f, "the spectra", n, per_row, [&](size_t r, std::string &o) {
     static const char hx[] = "0123456789abcdef";
     char buf[40];
-    for (size_t r = lo; r < hi; ++r) {
-      o.push_back('\t');
-      o.append(labels[r]);
-      o.push_back('\n');
-      for (uint64_t i = offsets[r]; i < offsets[r + 1]; ++i) {
-        uint64_t h = hash[i];
-        for (int d = digits - 1; d >= 0; --d) {
-          buf[d] = hx[h & 15];
-          h >>= 4;
-        }
-        int len = digits;
-        buf[len++] = '\t';
-        char tmp[12];
-        int tl = 0;
-        uint32_t c = count[i];
-        do {
-          tmp[tl++] = (char)('0' + c % 10);
-          c /= 10;
-        } while (c);
-        while (tl) buf[len++] = tmp[--tl];
-        buf[len++] = '\n';
-        o.append(buf, (size_t)len);
+    o.push_back('\t');
+    o.append(labels[r]);
+    o.push_back('\n');
+    for (uint64_t i = offsets[r]; i < offsets[r + 1]; ++i) {
+      uint64_t h = hash[i];
+      for (int d = digits - 1; d >= 0; --d) {
+        buf[d] = hx[h & 15];
+        h >>= 4;
       }
+      int len = digits;
+      buf[len++] = '\t';
+      char tmp[12];
+      int tl = 0;
+      uint32_t c = count[i];
+      do {
+        tmp[tl++] = (char)('0' + c % 10);
+        c /= 10;
+      } while (c);
+      while (tl) buf[len++] = tmp[--tl];
+      buf[len++] = '\n';
+      o.append(buf, (size_t)len);
     }
-  };
-  std::vector<std::thread> pool;
-  for (unsigned t = 1; t < T; ++t) pool.emplace_back(work, t);
-  work(0);
-  for (std::thread &th : pool) th.join();
-  for (const std::string &o : text)
-    if (fwrite(o.data(), 1, o.size(), f) != o.size()) throw Error(std::string("write failed: ") + strerror(errno));
+  });
 }
 
 void write_spectrum_body(FILE *f, const uint64_t *hash, const uint32_t *count, uint64_t n, int digits) {

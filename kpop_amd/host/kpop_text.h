@@ -134,6 +134,27 @@ void read_spectra_hashed(const std::string &path, size_t name_len, uint64_t abse
 void read_spectra_hashed_fd(int fd, const char *head, size_t head_len, size_t name_len, uint64_t absent, HashedSpectra &out,
                             unsigned threads = 0);
 
+// Text spectra from a descriptor a block at a time, so that reading, parsing and twisting overlap (a million read spectra
+// are 1.26 GB of text: read whole, then parsed, then twisted was 2.1 s of which none overlapped).  A block ends where a
+// spectrum ends -- before the last line that begins with a tab, a header (lib/Twister.ml:106-111) -- and is block_bytes
+// long or as much longer as its last spectrum needs.
+using TextBlock = std::vector<char, DefaultInitAlloc<char>>;
+class SpectraTextStream {
+ public:
+  SpectraTextStream(int fd, const char *head, size_t head_len, size_t block_bytes = 64u << 20);
+  bool next(TextBlock &block);  // false once the input is exhausted
+ private:
+  int fd_;
+  size_t block_bytes_;
+  TextBlock carry_;
+  bool eof_ = false;
+};
+// One block of that stream -> hashed spectra (`out` is overwritten).  first_block: the stream's first line must be a header
+// (Header_expected otherwise); lines_before: the lines of the blocks before this one, for the line numbers of
+// Wrong_number_of_columns; *n_lines receives this block's.  The same errors, in the same order, as the whole-file parser.
+void parse_spectra_block(const char *data, size_t size, size_t name_len, uint64_t absent, bool first_block, uint64_t lines_before,
+                         HashedSpectra &out, uint64_t *n_lines, unsigned threads = 0);
+
 // "\t<label>\n" + "<hex>\t<count>\n"... for reads [0, n) of a CSR result, formatted by several threads and written in
 // order (bin/KPopCount.ml:44-46).  labels must already be checked.
 void write_spectra_parallel(FILE *f, const std::vector<std::string> &labels, const uint64_t *hash, const uint32_t *count,

@@ -38,8 +38,9 @@ def test_threaded_parser_agrees_with_sequential_one(harness, tmp_path):
             if it % 13 == 0:
                 data = ""
             path.write_text(data)
-            r = subprocess.run([harness, str(path), "3"], capture_output=True, text=True, errors="replace", env=env)
-            assert r.returncode == 0, (threads, chunk, it, r.stdout, r.stderr)
+            block = rng.choice(["1", "17", "64", "300", "5000", "100000"])  # the block stream's block size (it grows as needed)
+            r = subprocess.run([harness, str(path), "3", block], capture_output=True, text=True, errors="replace", env=env)
+            assert r.returncode == 0, (threads, chunk, block, it, r.stdout, r.stderr)
 
 
 @pytest.fixture(scope="module")
