@@ -117,8 +117,9 @@ struct Sink {  // where a batch of reads goes: the GPU and the text writer, or t
   FILE *out = nullptr;
   bool decided = false, stream = false, gpu = false;
   Merged merged;
-  std::vector<uint64_t> oh, oo, offsets;
-  std::vector<uint32_t> oc;
+  std::vector<uint64_t> oo, offsets;
+  std::vector<uint64_t, DefaultInitAlloc<uint64_t>> oh;  // (one slot per base: sized for the worst case, filled by the library --
+  std::vector<uint32_t, DefaultInitAlloc<uint32_t>> oc;  //  no zero-fill of 12 bytes per base first)
   explicit Sink(const Params &p) : P(p) {}
 
   void decide() {

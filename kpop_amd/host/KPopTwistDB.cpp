@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -398,13 +399,21 @@ void twist_text_spectra(int fd, const char *head, size_t head_len, TwisterReg &T
                         std::vector<RowPiece> &pieces) {
   StageQueue<TextBlock> blocks;
   StageQueue<HashedSpectra> parsed;
+  const bool timing = getenv("KPOP_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+  double t_read = 0., t_parse = 0., t_twist = 0.;  // busy time of each stage (each written by its own thread, read after the joins)
   std::thread reader([&] {
     std::string err;
     try {
       SpectraTextStream ts(fd, head, head_len);
       TextBlock b;
-      while (ts.next(b))
-        if (!blocks.push(std::move(b))) break;
+      for (;;) {
+        const auto t0 = now();
+        const bool more = ts.next(b);
+        t_read += secs(t0, now());
+        if (!more || !blocks.push(std::move(b))) break;
+      }
     } catch (const std::exception &e) {
       err = e.what();
     }
@@ -418,7 +427,9 @@ void twist_text_spectra(int fd, const char *head, size_t head_len, TwisterReg &T
       uint64_t lines = 0, n = 0;
       while (blocks.pop(b)) {
         HashedSpectra sp;
+        const auto t0 = now();
         parse_spectra_block(b.data(), b.size(), T.name_len, absent, first, lines, sp, &n);
+        t_parse += secs(t0, now());
         first = false;
         lines += n;
         if (!parsed.push(std::move(sp))) break;
@@ -435,11 +446,12 @@ void twist_text_spectra(int fd, const char *head, size_t head_len, TwisterReg &T
     while (parsed.pop(sp)) {
       RowPiece piece;
       const size_t n = sp.labels.size();
+      const auto t0 = now();
       piece.rows.resize(n * d);
       if (n) check(kpop_twist(T.dev, sp.hash.data(), sp.values.data(), sp.offsets.data(), (uint32_t)n, normalize ? 1 : 0, piece.rows.data()));
+      t_twist += secs(t0, now());
       piece.labels.swap(sp.labels);
       pieces.push_back(std::move(piece));
-      stage_mark("KPopTwistDB", "  text block twisted");
     }
   } catch (...) {
     parsed.cancel();
@@ -450,6 +462,7 @@ void twist_text_spectra(int fd, const char *head, size_t head_len, TwisterReg &T
   }
   parser.join();
   reader.join();
+  if (timing) fprintf(stderr, "[timing] KPopTwistDB:   text spectra: reading %.3f s, parsing %.3f s, twisting %.3f s (busy time of the three stages)\n", t_read, t_parse, t_twist);
   if (!parsed.error.empty()) throw Error(parsed.error);
 }
 

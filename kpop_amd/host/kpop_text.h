@@ -126,8 +126,8 @@ void write_spectrum(FILE *f, const std::string &label, const uint64_t *hash, con
 struct HashedSpectra {
   std::vector<std::string> labels;
   std::vector<uint64_t> offsets{0};
-  std::vector<uint64_t> hash;
-  std::vector<double> values;
+  std::vector<uint64_t, DefaultInitAlloc<uint64_t>> hash;  // (sized, then filled by threads: no zero-fill first -- it
+  DVec values;                                             //  was half of the parsing time of a block)
 };
 void read_spectra_hashed(const std::string &path, size_t name_len, uint64_t absent, HashedSpectra &out, unsigned threads = 0);
 // the same on an open descriptor whose first head_len bytes the caller has already taken off (to look at them)
