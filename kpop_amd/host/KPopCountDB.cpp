@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <functional>
 #include <set>
@@ -269,10 +270,15 @@ int main(int argc, char **argv) {
   }
   try {
     State st;
+    stage_mark("KPopCountDB", "start");
     for (auto &action : program) {
       st.db.verbose = verbose;
       action(st);
+      stage_mark("KPopCountDB", "action done");
     }
+    fflush(stdout);
+    fflush(stderr);
+    _exit(0);  // every output is written and closed: the database need not be taken apart first
   } catch (const std::exception &e) {
     fprintf(stderr, "(KPopCountDB): FATAL: Uncaught exception: %s\n", e.what());
     return 1;

@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <string>
 #include <vector>
@@ -44,31 +45,42 @@ int main(int argc, char **argv) {
     const int which = transform.code();
     int dev = 0;
     if (const char *e = getenv("KPOP_DEVICE")) dev = atoi(e);
+    stage_mark("KPopTwist", "start");
     check(kpop_init(dev));
+    stage_mark("KPopTwist", "HIP bring-up");
     if (P.verbose) fprintf(stderr, "[1/16] Exporting table...\n");
     CounterDB db = CounterDB::of_binary(input);
+    stage_mark("KPopTwist", "database read");
     const size_t nr = db.n_rows(), nc = db.n_cols();
     std::vector<const int32_t *> cols = db.columns();
     // the export of src/KPopTwist:38-40: transformed counts, k-mers with an all-zero row left out
     std::vector<double> col_stats(4 * std::max<size_t>(1, nc)), row_stats(4 * std::max<size_t>(1, nr));
     check(kpop_counter_stats(cols.data(), (uint32_t)nc, nr, transform.threshold, transform.power, col_stats.data(), row_stats.data()));
-    std::vector<double> table(std::max<size_t>(1, nr * nc));
+    DVec table(std::max<size_t>(1, nr * nc));
     check(kpop_counter_transform(cols.data(), (uint32_t)nc, nr, which, transform.threshold, transform.power, col_stats.data(), 1,
                                  table.data()));
-    std::vector<std::string> kmers;
-    std::vector<double> counts;
-    counts.reserve(nr * nc);
+    stage_mark("KPopTwist", "statistics, transformed table");
+    // rows with counts, in order: their numbers first, then names and values moved by the host threads
+    std::vector<size_t> kept;
+    kept.reserve(nr);
     for (size_t r = 0; r < nr; ++r)
-      if (row_stats[4 * r + 2] > 0.) {
-        kmers.push_back(db.core.row_names[r]);
-        counts.insert(counts.end(), table.begin() + (long)(r * nc), table.begin() + (long)((r + 1) * nc));
+      if (row_stats[4 * r + 2] > 0.) kept.push_back(r);
+    std::vector<std::string> kmers(kept.size());
+    DVec counts(kept.size() * nc);
+    parallel_for(kept.size(), 4096, [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i) {
+        kmers[i] = std::move(db.core.row_names[kept[i]]);
+        memcpy(counts.data() + i * nc, table.data() + kept[i] * nc, nc * sizeof(double));
       }
+    });
     table.clear();
     table.shrink_to_fit();
     P.want_kmer_coords = !output_kmers.empty();
     const std::vector<std::string> spectra = db.core.col_names;
     db = CounterDB();
-    const CaResult R = run_ca(kmers, spectra, std::move(counts), P);
+    stage_mark("KPopTwist", "rows without counts dropped");
+    const CaResult R = run_ca(std::move(kmers), spectra, std::move(counts), P);
+    stage_mark("KPopTwist", "correspondence analysis");
     if (P.verbose) fprintf(stderr, "[14/16] Encoding twisted...\n");
     write_binary_matrix(make_filename(output, "KPopTwisted", false), "KPopTwisted", R.twisted);
     if (!output_kmers.empty()) write_binary_matrix(make_filename(output_kmers, "KPopTwisted", false), "KPopTwisted", R.kmer_coords);
@@ -79,7 +91,11 @@ int main(int argc, char **argv) {
       write_table(make_filename(output, "KPopInertia", true), R.inertia, 15);
       write_table(make_filename(output, "KPopTwister", true), R.twister, 15);
     }
+    stage_mark("KPopTwist", "outputs written");
     if (P.verbose) fprintf(stderr, "All done.\n");
+    fflush(stdout);
+    fflush(stderr);
+    _exit(0);  // everything is written and closed: no need to take gigabytes of tables apart first
   } catch (const std::exception &e) {
     fprintf(stderr, "(KPopTwist): FATAL: %s\n", e.what());
     return 1;

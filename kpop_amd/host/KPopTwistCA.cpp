@@ -76,7 +76,7 @@ int main(int argc, char **argv) {
     for (std::string &s : kmers) s = unquote(s);
     if (verbose) fprintf(stderr, "[3/16] Reading counts...\n");
     std::vector<std::string> spectra;
-    std::vector<double> N;
+    DVec N;
     {
       FILE *f = fopen(table_path.c_str(), "rb");
       if (!f) throw Error("cannot open '" + table_path + "'");
@@ -122,7 +122,7 @@ int main(int argc, char **argv) {
     P.normalize = normalize;
     P.want_kmer_coords = !out_kmers.empty();
     P.verbose = verbose;
-    const CaResult R = run_ca(kmers, spectra, std::move(N), P);
+    const CaResult R = run_ca(std::move(kmers), spectra, std::move(N), P);
     if (verbose) fprintf(stderr, "[9/16] Writing twisted...\n");
     write_r_table(make_filename(out, "KPopTwisted", true), "rn", R.twisted);
     if (!out_kmers.empty()) write_r_table(make_filename(out_kmers, "KPopTwisted", true), "rn", R.kmer_coords);

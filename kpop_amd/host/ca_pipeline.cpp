@@ -39,8 +39,7 @@ std::vector<std::string> read_lines(const std::string &path) {
   return out;
 }
 
-CaResult run_ca(const std::vector<std::string> &kmers, const std::vector<std::string> &spectra, std::vector<double> N,
-                const CaParams &P) {
+CaResult run_ca(std::vector<std::string> kmers, const std::vector<std::string> &spectra, DVec N, const CaParams &P) {
   const size_t J = spectra.size();
   size_t I = kmers.size();
   if (N.size() != I * J) throw Error("count table is not k-mers x spectra");
@@ -71,24 +70,40 @@ CaResult run_ca(const std::vector<std::string> &kmers, const std::vector<std::st
   }
   {
     std::vector<double> rsum(sel.size(), 0.0);
+    parallel_for(sel.size(), 4096, [&](size_t lo, size_t hi) {
+      for (size_t r = lo; r < hi; ++r) {
+        double t = 0.0;
+        for (size_t j = 0; j < J; ++j) t += N[sel[r] * J + j];
+        rsum[r] = t;
+      }
+    });
     double mx = 0.0;
-    for (size_t r = 0; r < sel.size(); ++r) {
-      for (size_t j = 0; j < J; ++j) rsum[r] += N[sel[r] * J + j];
-      mx = std::max(mx, rsum[r]);
-    }
+    for (size_t r = 0; r < sel.size(); ++r) mx = std::max(mx, rsum[r]);
     std::vector<size_t> ns;
     for (size_t r = 0; r < sel.size(); ++r)
       if (rsum[r] >= mx * P.threshold) ns.push_back(sel[r]);
     sel.swap(ns);
   }
-  std::vector<double> M(sel.size() * J);
-  std::vector<std::string> knames(sel.size());
-  for (size_t r = 0; r < sel.size(); ++r) {
-    memcpy(&M[r * J], &N[sel[r] * J], J * sizeof(double));
-    knames[r] = kmers[sel[r]];
+  stage_mark("KPopTwist", "  k-mers selected");
+  // the selected rows, in order: the table itself when every row is selected (the usual case: nothing to copy)
+  bool all_rows = sel.size() == I;
+  for (size_t r = 0; all_rows && r < I; ++r) all_rows = sel[r] == r;
+  DVec M;
+  std::vector<std::string> knames;
+  if (all_rows) {
+    M.swap(N);
+    knames.swap(kmers);
+  } else {
+    M.resize(sel.size() * J);
+    knames.resize(sel.size());
+    parallel_for(sel.size(), 4096, [&](size_t lo, size_t hi) {
+      for (size_t r = lo; r < hi; ++r) {
+        memcpy(&M[r * J], &N[sel[r] * J], J * sizeof(double));
+        knames[r] = kmers[sel[r]];
+      }
+    });
+    DVec().swap(N);
   }
-  N.clear();
-  N.shrink_to_fit();
   I = sel.size();
   if (I < 2 || J < 2) throw Error("correspondence analysis needs at least 2 k-mers and 2 spectra");
   if (P.verbose) fprintf(stderr, "[8/16] Twisting counts (%zu k-mers x %zu spectra) on the GPU...\n", I, J);
@@ -102,13 +117,16 @@ CaResult run_ca(const std::vector<std::string> &kmers, const std::vector<std::st
   R.inertia.col_names = dims;
   R.inertia.row_names = {"inertia"};
   R.inertia.data.resize(nd);
-  R.twister.col_names = knames;
+  if (P.want_kmer_coords) R.twister.col_names = knames;  // (the names are needed once more below)
+  else R.twister.col_names = std::move(knames);
   R.twister.row_names = dims;
   R.twister.data.resize(nd * I);
+  stage_mark("KPopTwist", "  table and result buffers laid out");
   uint32_t nd_out = 0;
   if (kpop_ca(M.data(), I, (uint32_t)J, P.normalize ? 1 : 0, &nd_out, R.twisted.data.data(), R.inertia.data.data(),
               R.twister.data.data()) != 0)
     throw Error(std::string("libkpop_hip: ") + kpop_last_error());
+  stage_mark("KPopTwist", "  kpop_ca");
   if (P.want_kmer_coords) {
     // principal row coordinates = standard ones x sv.  sv_d is not recoverable from the normalised inertia, so it is
     // recomputed from the class positions: for principal column coordinates sum_j c_j G_jd^2 = sv_d^2, c_j the column

@@ -26,8 +26,7 @@ struct CaResult {
 };
 
 // counts: kmers.size() x spectra.size() row-major (transformed counts, as KPopCountDB -t writes them)
-CaResult run_ca(const std::vector<std::string> &kmers, const std::vector<std::string> &spectra, std::vector<double> counts,
-                const CaParams &params);
+CaResult run_ca(std::vector<std::string> kmers, const std::vector<std::string> &spectra, DVec counts, const CaParams &P);
 
 std::vector<std::string> read_lines(const std::string &path);
 

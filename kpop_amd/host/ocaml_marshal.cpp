@@ -345,11 +345,13 @@ struct Reader {
   }
   // first `n` elements of an Int32Array node
   std::vector<int32_t> int32s(const Node &nd, uint64_t n) const {
-    std::vector<int32_t> out;
-    out.reserve(n);
+    std::vector<int32_t> out(n);
     const uint8_t *s = &data[nd.a];
-    for (uint64_t i = 0; i < n; ++i)
-      out.push_back((int32_t)(((uint32_t)s[4 * i] << 24) | ((uint32_t)s[4 * i + 1] << 16) | ((uint32_t)s[4 * i + 2] << 8) | s[4 * i + 3]));
+    for (uint64_t i = 0; i < n; ++i) {
+      uint32_t w;
+      memcpy(&w, s + 4 * i, 4);
+      out[i] = (int32_t)__builtin_bswap32(w);  // the payload is big-endian
+    }
     return out;
   }
   std::string str(uint32_t id) const {
@@ -955,8 +957,10 @@ CounterCore read_binary_counter(const std::string &path) {  // KMerDB.of_binary,
     for (uint64_t c = 0; c < n_cols; ++c) {
       const Node &v = r.nodes[r.children[st.a + c]];
       if (v.kind != Node::Int32Array || v.b < n_rows) throw Error("marshal: KPopCounter spectrum " + std::to_string(c) + " is not an int32 Bigarray of n_rows elements");
-      db.storage[c] = r.int32s(v, n_rows);
     }
+    parallel_for(n_cols, 1, [&](size_t lo, size_t hi) {  // (the spectra are converted by the host threads)
+      for (size_t c = lo; c < hi; ++c) db.storage[c] = r.int32s(r.nodes[r.children[st.a + c]], n_rows);
+    });
   } catch (...) {
     fclose(f);
     throw;
