@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/kpop_hip.h"
@@ -117,10 +118,26 @@ struct Sink {  // where a batch of reads goes: the GPU and the text writer, or t
   FILE *out = nullptr;
   bool decided = false, stream = false, gpu = false;
   Merged merged;
-  std::vector<uint64_t> oo, offsets;
-  std::vector<uint64_t, DefaultInitAlloc<uint64_t>> oh;  // (one slot per base: sized for the worst case, filled by the library --
-  std::vector<uint32_t, DefaultInitAlloc<uint32_t>> oc;  //  no zero-fill of 12 bytes per base first)
+  std::vector<uint64_t> offsets;
+  // Per-read spectra are written as text by a thread of their own while the next block is counted: two sets of result
+  // buffers, one being filled by the library, one being printed.
+  struct Counted {
+    std::vector<uint64_t> oo;
+    std::vector<uint64_t, DefaultInitAlloc<uint64_t>> oh;  // (one slot per base: sized for the worst case, filled by the library --
+    std::vector<uint32_t, DefaultInitAlloc<uint32_t>> oc;  //  no zero-fill of 12 bytes per base first)
+    std::vector<std::string> labels;
+  } sets[2];
+  int filling = 0;
+  std::thread writer;
+  std::string writer_error;
   explicit Sink(const Params &p) : P(p) {}
+  ~Sink() {
+    if (writer.joinable()) writer.join();
+  }
+  void wait_for_writer() {
+    if (writer.joinable()) writer.join();
+    if (!writer_error.empty()) throw Error(writer_error);
+  }
 
   void decide() {
     decided = true;
@@ -159,25 +176,38 @@ struct Sink {  // where a batch of reads goes: the GPU and the text writer, or t
     offsets[0] = 0;
     for (size_t r = 0; r < n; ++r) offsets[r + 1] = offsets[r] + b.lens[r];
     const uint64_t cap = b.bases.size() + 1;
-    oh.resize(cap);
-    oc.resize(cap);
-    oo.assign(per_read ? n + 1 : 2, 0);
+    Counted &c = sets[filling];
+    c.oh.resize(cap);
+    c.oc.resize(cap);
+    c.oo.assign(per_read ? n + 1 : 2, 0);
     static const uint8_t dummy = 0;
     check(kpop_count_reads(b.bases.empty() ? &dummy : b.bases.data(), offsets.data(), (uint32_t)n, P.k, P.content,
-                           per_read ? 1 : 0, oh.data(), oc.data(), oo.data(), cap));
+                           per_read ? 1 : 0, c.oh.data(), c.oc.data(), c.oo.data(), cap));
     if (per_read) {  // bin/KPopCount.ml:44-46
-      std::vector<std::string> labels(n);
+      c.labels.resize(n);
       size_t at = 0;
       for (size_t r = 0; r < n; ++r) {
-        labels[r] = strip_external_quotes_and_check(std::string(b.tags.data() + at, b.tag_lens[r]));
+        c.labels[r] = strip_external_quotes_and_check(std::string(b.tags.data() + at, b.tag_lens[r]));
         at += b.tag_lens[r];
       }
-      write_spectra_parallel(out, labels, oh.data(), oc.data(), oo.data(), name_digits(P.k, P.content == KPOP_PROTEIN));
+      wait_for_writer();  // the block before this one is on its way out; its buffers are free again after this
+      const int digits = name_digits(P.k, P.content == KPOP_PROTEIN);
+      FILE *f = out;
+      Counted *job = &c;
+      writer = std::thread([this, f, job, digits] {
+        try {
+          write_spectra_parallel(f, job->labels, job->oh.data(), job->oc.data(), job->oo.data(), digits);
+        } catch (const std::exception &e) {
+          writer_error = e.what();
+        }
+      });
+      filling ^= 1;
     } else {
-      merged.add(oh.data(), oc.data(), oo[1]);
+      merged.add(c.oh.data(), c.oc.data(), c.oo[1]);
     }
   }
   void finish() {
+    wait_for_writer();
     if (stream) write_stream_end(1);
   }
 };
