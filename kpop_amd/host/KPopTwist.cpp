@@ -16,6 +16,7 @@
 #include <unistd.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/kpop_hip.h"
@@ -65,19 +66,28 @@ int main(int argc, char **argv) {
     kept.reserve(nr);
     for (size_t r = 0; r < nr; ++r)
       if (row_stats[4 * r + 2] > 0.) kept.push_back(r);
-    std::vector<std::string> kmers(kept.size());
-    DVec counts(kept.size() * nc);
-    parallel_for(kept.size(), 4096, [&](size_t lo, size_t hi) {
-      for (size_t i = lo; i < hi; ++i) {
-        kmers[i] = std::move(db.core.row_names[kept[i]]);
-        memcpy(counts.data() + i * nc, table.data() + kept[i] * nc, nc * sizeof(double));
-      }
-    });
-    table.clear();
-    table.shrink_to_fit();
+    std::vector<std::string> kmers;
+    DVec counts;
+    if (kept.size() == nr) {  // every k-mer occurs somewhere (the usual case): the table as it stands
+      kmers.swap(db.core.row_names);
+      counts.swap(table);
+    } else {
+      kmers.resize(kept.size());
+      counts.resize(kept.size() * nc);
+      parallel_for(kept.size(), 4096, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+          kmers[i] = std::move(db.core.row_names[kept[i]]);
+          memcpy(counts.data() + i * nc, table.data() + kept[i] * nc, nc * sizeof(double));
+        }
+      });
+    }
+    DVec().swap(table);
     P.want_kmer_coords = !output_kmers.empty();
     const std::vector<std::string> spectra = db.core.col_names;
-    db = CounterDB();
+    {  // the database is not needed again: a thread of its own gives its gigabytes back
+      auto *garbage = new CounterDB(std::move(db));
+      std::thread([garbage] { delete garbage; }).detach();
+    }
     stage_mark("KPopTwist", "rows without counts dropped");
     const CaResult R = run_ca(std::move(kmers), spectra, std::move(counts), P);
     stage_mark("KPopTwist", "correspondence analysis");

@@ -7,6 +7,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
+#include <tuple>
 #include <unordered_map>
 
 #include "../../include/kpop_hip.h"
@@ -147,6 +149,10 @@ CaResult run_ca(std::vector<std::string> kmers, const std::vector<std::string> &
       for (size_t r = 0; r < I; ++r) R.kmer_coords.data[r * nd + d] = R.twister.data[d * I + r] * sv;
     }
   }
+  // the table is garbage now (gigabytes of it): a thread of its own gives it back while the results are being written
+  auto *garbage = new std::tuple<DVec, DVec, std::vector<std::string>, std::vector<std::string>>(std::move(M), std::move(N), std::move(knames),
+                                                                                              std::move(kmers));
+  std::thread([garbage] { delete garbage; }).detach();
   return R;
 }
 

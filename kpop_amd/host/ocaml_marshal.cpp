@@ -9,6 +9,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <thread>
 #include <atomic>
 #include <memory>
 #include <vector>
@@ -127,6 +128,16 @@ struct Writer {
       be(0xFFFF, 2);
       be(n, 8);
     }
+    if (!p) {  // the prefix alone: the caller lays the big-endian payload down itself
+      (void)start;
+      const uint64_t sz32 = 5 * 4, sz64 = 5 * 8;
+      for (int i = 0; i < 4; ++i) buf[lens + i] = (char)((sz32 >> (8 * (3 - i))) & 0xFF);
+      for (int i = 0; i < 8; ++i) buf[lens + 4 + i] = (char)((sz64 >> (8 * (7 - i))) & 0xFF);
+      ++n_obj;
+      size32 += 2 + ((sz32 + 3) >> 2);
+      size64 += 2 + ((sz64 + 7) >> 3);
+      return;
+    }
     char tmp[4096];
     for (uint64_t i = 0; i < n;) {  // appended through a small buffer: no zero-fill of the destination first
       const uint64_t m = std::min<uint64_t>(1024, n - i);
@@ -148,6 +159,28 @@ struct Writer {
     ++n_obj;
     size32 += 2 + ((sz32 + 3) >> 2);
     size64 += 2 + ((sz64 + 7) >> 3);
+  }
+  // the header of a value whose data are `data_len` bytes (buf and whatever the caller writes after it)
+  std::string header(uint64_t data_len) const {
+    std::string hd;
+    auto hbe = [&](uint64_t v, int bytes) {
+      for (int i = bytes - 1; i >= 0; --i) hd.push_back((char)((v >> (8 * i)) & 0xFF));
+    };
+    const uint64_t lim = 1ull << 32;
+    if (data_len >= lim || size32 >= lim || size64 >= lim) {
+      hbe(MAGIC_BIG, 4);
+      hbe(0, 4);
+      hbe(data_len, 8);
+      hbe(n_obj, 8);
+      hbe(size64, 8);
+    } else {
+      hbe(MAGIC_SMALL, 4);
+      hbe(data_len, 4);
+      hbe(n_obj, 4);
+      hbe(size32, 4);
+      hbe(size64, 4);
+    }
+    return hd;
   }
   void flush(FILE *f) {
     std::string hd;
@@ -401,7 +434,26 @@ bool read_one(FILE *f, Reader &r) {
   if (!read_header(f, &data_len)) return false;
   r = Reader();
   r.data.alloc(data_len);
-  if (data_len && fread(r.data.data(), 1, data_len, f) != data_len) throw Error("marshal: truncated value");
+  bool have = false;
+  if (data_len >= (64u << 20)) {  // a large value of a regular file: pieces fetched by the host threads (page cache -> buffer)
+    const off_t here = ftello(f);
+    const int fd = fileno(f);
+    if (here >= 0 && fd >= 0 && lseek(fd, 0, SEEK_CUR) >= 0) {
+      std::atomic<bool> ok{true};
+      parallel_for(data_len, 8u << 20, [&](size_t lo, size_t hi) {
+        while (lo < hi && ok) {
+          const ssize_t got = pread(fd, r.data.data() + lo, hi - lo, here + (off_t)lo);
+          if (got < 0 && errno == EINTR) continue;
+          if (got <= 0) ok = false;
+          else lo += (size_t)got;
+        }
+      });
+      if (!ok) throw Error("marshal: truncated value");
+      if (fseeko(f, here + (off_t)data_len, SEEK_SET) != 0) throw Error("marshal: cannot seek");
+      have = true;
+    }
+  }
+  if (!have && data_len && fread(r.data.data(), 1, data_len, f) != data_len) throw Error("marshal: truncated value");
   r.read_value();
   return true;
 }
@@ -895,17 +947,50 @@ void write_binary_counter(const std::string &path, const CounterCore &db) {  // 
       w.string_array(m);
     }
     w.block_header(n_cols, 0);
-    std::vector<int32_t> zeros;
-    for (size_t c = 0; c < n_cols; ++c) {
-      const std::vector<int32_t> &v = db.storage[c];
-      if (v.size() >= n_rows) w.bigarray_int32(v.data(), n_rows);
-      else {  // columns are allowed to be physically shorter than n_rows (trailing zeros)
-        zeros.assign(n_rows, 0);
-        std::copy(v.begin(), v.end(), zeros.begin());
-        w.bigarray_int32(zeros.data(), n_rows);
-      }
+    // The spectra are most of the archive (4 bytes x k-mers x spectra) and every one of them is the same few prefix bytes and
+    // a big-endian payload of known length: so the header can be written first, and the payloads converted by the host
+    // threads a group of spectra at a time, one group being written while the next is converted.
+    const size_t before = w.buf.size();
+    for (size_t c = 0; c < n_cols; ++c) w.bigarray_int32(nullptr, n_rows);
+    const size_t prefix_len = n_cols ? (w.buf.size() - before) / n_cols : 0;
+    const std::string prefix = w.buf.substr(before, prefix_len);
+    w.buf.resize(before);
+    const uint64_t col_bytes = prefix_len + (uint64_t)n_rows * 4;
+    const std::string hd = w.header(before + (uint64_t)n_cols * col_bytes);
+    if (fwrite(hd.data(), 1, hd.size(), f) != hd.size() || fwrite(w.buf.data(), 1, w.buf.size(), f) != w.buf.size())
+      throw Error(std::string("write failed: ") + strerror(errno));
+    const size_t group = std::max<size_t>(1, std::min<size_t>(n_cols, (96u << 20) / std::max<uint64_t>(1, col_bytes)));
+    std::vector<char, DefaultInitAlloc<char>> bufs[2];
+    std::thread writer;
+    std::atomic<bool> failed{false};
+    for (size_t c0 = 0, g = 0; c0 < n_cols; c0 += group, ++g) {
+      const size_t c1 = std::min(n_cols, c0 + group);
+      auto &buf = bufs[g & 1];
+      if (g >= 2 && writer.joinable()) writer.join();  // (the write two groups back used this buffer; at most one write is pending)
+      buf.resize((c1 - c0) * col_bytes);
+      parallel_for(c1 - c0, 1, [&](size_t lo, size_t hi) {
+        for (size_t c = c0 + lo; c < c0 + hi; ++c) {
+          char *dst = buf.data() + (c - c0) * col_bytes;
+          memcpy(dst, prefix.data(), prefix_len);
+          dst += prefix_len;
+          const std::vector<int32_t> &v = db.storage[c];
+          const size_t have = std::min<size_t>(v.size(), n_rows);  // columns may be physically shorter than n_rows (trailing zeros)
+          for (size_t i = 0; i < have; ++i) {
+            const uint32_t be = __builtin_bswap32((uint32_t)v[i]);
+            memcpy(dst + 4 * i, &be, 4);
+          }
+          if (have < n_rows) memset(dst + 4 * have, 0, (n_rows - have) * 4);
+        }
+      });
+      if (writer.joinable()) writer.join();
+      const char *data = buf.data();
+      const size_t bytes = buf.size();
+      writer = std::thread([f, data, bytes, &failed] {
+        if (fwrite(data, 1, bytes, f) != bytes) failed = true;
+      });
     }
-    w.flush(f);
+    if (writer.joinable()) writer.join();
+    if (failed) throw Error(std::string("write failed: ") + strerror(errno));
   } catch (...) {
     fclose(f);
     throw;
