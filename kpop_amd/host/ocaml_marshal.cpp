@@ -221,15 +221,16 @@ struct Node {
 
 // the bytes of one marshalled value; deliberately NOT value-initialised (a 4 GB archive should be touched once, by fread)
 struct Bytes {
-  std::unique_ptr<uint8_t[]> p;
-  size_t n = 0;
+  std::vector<uint8_t, DefaultInitAlloc<uint8_t>> v;  // (large ones come 2 MB-aligned and huge-page backed: kpop_text.h)
   void alloc(size_t bytes) {
-    p.reset(new uint8_t[bytes ? bytes : 1]);
+    std::vector<uint8_t, DefaultInitAlloc<uint8_t>>().swap(v);
+    v.resize(bytes ? bytes : 1);
     n = bytes;
   }
+  size_t n = 0;
   size_t size() const { return n; }
-  uint8_t *data() { return p.get(); }
-  const uint8_t &operator[](size_t i) const { return p[i]; }
+  uint8_t *data() { return v.data(); }
+  const uint8_t &operator[](size_t i) const { return v[i]; }
 };
 
 struct Reader {
