@@ -242,8 +242,17 @@ int kpop_dev_twist_dense(const kpop_twister *tw, const uint64_t *d_hash, const d
    columns and the order of the eigenvalues are host work between launches: the call synchronises `stream` on the way
    and has completed when it returns.                                                                                */
 uint64_t kpop_dev_ca_workspace_bytes(uint64_t n_kmers, uint32_t n_spectra);
+/* (d_work == d_counts is allowed: the table is then standardised where it stands and is lost) */
 int kpop_dev_ca(const double *d_counts, uint64_t n_kmers, uint32_t n_spectra, int normalize, void *d_work,
                 uint32_t *n_dims_out, double *d_twisted, double *d_inertia, double *d_twister, void *stream);
+/* What KPopTwist does to the table between the transformation and the analysis (src/KPopTwist:76-91: a keep list, a
+   sample, a threshold on the row sums), on a row-major k-mers x spectra table that stays on the device: sums of the
+   rows (lane-strided partial sums and a fixed tree per row) and of the columns (slabs of rows added in order), and the
+   rows d_rows[0 .. n_sel) copied, in that order, into d_out (n_sel x n_cols).                                          */
+int kpop_dev_table_row_sums(const double *d_table, uint64_t n_rows, uint32_t n_cols, double *d_out, void *stream);
+int kpop_dev_table_col_sums(const double *d_table, uint64_t n_rows, uint32_t n_cols, double *d_out, void *stream);
+int kpop_dev_table_gather_rows(const double *d_table, uint32_t n_cols, const uint64_t *d_rows, uint64_t n_sel,
+                               double *d_out, void *stream);
 /* Distance workspace: row norms and the pre-normalised copies a/n_i, b/n_j of
    both operands (the per-element divisions of lib/Matrix.ml:247-249, done once).
    kpop_dev_distance_workspace_bytes gives the size d_work must have.          */

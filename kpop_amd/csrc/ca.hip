@@ -59,7 +59,11 @@ __global__ __launch_bounds__(256) void ca_row_mass_kernel(const double *__restri
   const uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= I) return;
   double s = 0.0;
-  for (uint32_t j = lane; j < J; j += 64) s += N[i * J + j] * w[j];
+  if (w) {
+    for (uint32_t j = lane; j < J; j += 64) s += N[i * J + j] * w[j];
+  } else {  // plain row sums
+    for (uint32_t j = lane; j < J; j += 64) s += N[i * J + j];
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if (lane == 0) r[i] = s;
@@ -800,6 +804,18 @@ static int ca_on_device(const double *d_N, double *d_S, uint64_t I, uint32_t J, 
   return KPOP_OK;
 }
 
+// rows of a row-major table gathered into another (one wavefront per row)
+__global__ __launch_bounds__(256) void table_gather_rows_kernel(const double *__restrict__ table, uint32_t J, const uint64_t *__restrict__ rows,
+                                                                uint64_t n_sel, double *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t stride = (uint64_t)gridDim.x * 4;
+  for (uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n_sel; i += stride) {
+    const double *src = table + rows[i] * J;
+    double *dst = out + i * J;
+    for (uint32_t j = lane; j < J; j += 64) dst[j] = src[j];
+  }
+}
+
 }  // namespace kpop
 
 using namespace kpop;
@@ -856,6 +872,47 @@ extern "C" int kpop_dev_ca(const double *d_counts, uint64_t n_kmers, uint32_t n_
   out.twisted = d_twisted;
   out.inertia = d_inertia;
   out.twister = d_twister;
-  double *d_S = reinterpret_cast<double *>(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+  // d_work == d_counts: standardise the table where it stands (it is overwritten)
+  double *d_S = d_work == (const void *)d_counts ? const_cast<double *>(d_counts)
+                                                 : reinterpret_cast<double *>(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
   return ca_on_device(d_counts, d_S, n_kmers, n_spectra, normalize, out, (hipStream_t)stream, tm);
+}
+
+// ---------------------------------------------------------------- a k-mers x spectra table that stays on the device
+// (the pieces KPopTwist needs between kpop_dev_counter_transform and kpop_dev_ca: src/KPopTwist:76-91 selects k-mers by a
+// list, a sample and the row sums before the analysis)
+extern "C" int kpop_dev_table_row_sums(const double *d_table, uint64_t n_rows, uint32_t n_cols, double *d_out, void *stream) {
+  KPOP_TRY(require_init());
+  if (!d_table || !d_out) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_table_row_sums: null argument");
+  if (n_rows == 0) return KPOP_OK;
+  ca_row_mass_kernel<<<dim3(div_up(n_rows, 4)), dim3(256), 0, (hipStream_t)stream>>>(d_table, n_rows, n_cols, nullptr, d_out);
+  KPOP_LAUNCH_CHECK();
+  return KPOP_OK;
+}
+
+extern "C" int kpop_dev_table_col_sums(const double *d_table, uint64_t n_rows, uint32_t n_cols, double *d_out, void *stream) {
+  KPOP_TRY(require_init());
+  if (!d_table || !d_out) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_table_col_sums: null argument");
+  if (n_cols == 0) return KPOP_OK;
+  const uint32_t n_slabs = std::max<uint32_t>(1, div_up(n_rows, kCaSlab));
+  DevBuf part;
+  KPOP_TRY(part.alloc((uint64_t)n_slabs * n_cols * 8));
+  hipStream_t st = (hipStream_t)stream;
+  ca_col_partial_kernel<<<dim3(n_slabs), dim3(256), 0, st>>>(d_table, n_rows, n_cols, nullptr, part.as<double>());
+  KPOP_LAUNCH_CHECK();
+  ca_col_final_kernel<<<dim3(div_up(n_cols, 256)), dim3(256), 0, st>>>(part.as<double>(), n_slabs, n_cols, d_out);
+  KPOP_LAUNCH_CHECK();
+  KPOP_HIP(hipStreamSynchronize(st));  // (the partial sums are freed on return)
+  return KPOP_OK;
+}
+
+extern "C" int kpop_dev_table_gather_rows(const double *d_table, uint32_t n_cols, const uint64_t *d_rows, uint64_t n_sel, double *d_out,
+                                          void *stream) {
+  KPOP_TRY(require_init());
+  if (n_sel == 0) return KPOP_OK;
+  if (!d_table || !d_rows || !d_out) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_table_gather_rows: null argument");
+  table_gather_rows_kernel<<<dim3((uint32_t)std::min<uint64_t>(div_up(n_sel, 4), 1u << 20)), dim3(256), 0, (hipStream_t)stream>>>(
+      d_table, n_cols, d_rows, n_sel, d_out);
+  KPOP_LAUNCH_CHECK();
+  return KPOP_OK;
 }

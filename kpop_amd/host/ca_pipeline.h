@@ -27,6 +27,11 @@ struct CaResult {
 
 // counts: kmers.size() x spectra.size() row-major (transformed counts, as KPopCountDB -t writes them)
 CaResult run_ca(std::vector<std::string> kmers, const std::vector<std::string> &spectra, DVec counts, const CaParams &P);
+// The same on a table that is on the device already (d_table: kmers.size() x spectra.size() doubles, row-major, from
+// kpop_dev_malloc; this call takes it over and frees it): the table is selected from, standardised and analysed where it is,
+// and only the results cross to the host.  The threshold on the row sums uses the device's sums (a fixed tree per row), which
+// can differ from the host's running sums in the last bits.
+CaResult run_ca_device(std::vector<std::string> kmers, const std::vector<std::string> &spectra, void *d_table, const CaParams &P);
 
 std::vector<std::string> read_lines(const std::string &path);
 

@@ -105,3 +105,46 @@ def test_ca_several_dim_slabs_and_device_entry(kpop):
     assert np.array_equal(d_in.cpu().numpy(), inertia)
     assert np.array_equal(d_tw.cpu().numpy(), tw)
     assert np.array_equal(d_T.cpu().numpy(), T)
+
+
+def test_device_table_helpers_and_in_place_analysis(kpop):
+    """kpop_dev_table_row_sums / _col_sums / _gather_rows against numpy, and kpop_dev_ca with d_work == d_counts (the table
+    standardised where it stands) against the out-of-place call: the same bytes."""
+    import ctypes as C
+
+    import torch
+    from kpop_amd import _lib, api
+    L = _lib.load()
+    dev = torch.device("cuda", 0)
+    rng = np.random.RandomState(5)
+    I, J = 4099, 77
+    N = synthetic_table(rng, I, J, depth=30)
+    dN = torch.from_numpy(N).to(dev)
+    rs = torch.zeros(I, dtype=torch.float64, device=dev)
+    cs = torch.zeros(J, dtype=torch.float64, device=dev)
+    assert L.kpop_dev_table_row_sums(dN.data_ptr(), I, J, rs.data_ptr(), None) == 0
+    assert L.kpop_dev_table_col_sums(dN.data_ptr(), I, J, cs.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(rs.cpu().numpy(), N.sum(axis=1), rtol=1e-13)
+    np.testing.assert_allclose(cs.cpu().numpy(), N.sum(axis=0), rtol=1e-13)
+    assert np.array_equal(rs.cpu().numpy(), N.sum(axis=1))  # counts are integers: every order of summation is exact
+    rows = rng.permutation(I)[:1500].astype(np.uint64)
+    d_rows = torch.from_numpy(rows.view(np.int64)).to(dev)
+    picked = torch.zeros(len(rows), J, dtype=torch.float64, device=dev)
+    assert L.kpop_dev_table_gather_rows(dN.data_ptr(), J, d_rows.data_ptr(), len(rows), picked.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(picked.cpu().numpy(), N[rows.astype(np.int64)])
+    nd = J - 1
+    outs = []
+    for in_place in (False, True):
+        table = dN.clone()
+        work = table if in_place else torch.empty(api.dev_ca_workspace_bytes(I, J), dtype=torch.uint8, device=dev)
+        d_tw = torch.zeros(J, nd, dtype=torch.float64, device=dev)
+        d_in = torch.zeros(nd, dtype=torch.float64, device=dev)
+        d_T = torch.zeros(nd, I, dtype=torch.float64, device=dev)
+        assert api.dev_ca(table.data_ptr(), I, J, work.data_ptr(), d_tw.data_ptr(), d_in.data_ptr(), d_T.data_ptr()) == nd
+        torch.cuda.synchronize()
+        assert torch.equal(table, dN) != in_place  # in place: the counts are gone; otherwise untouched
+        outs.append((d_tw.cpu().numpy(), d_in.cpu().numpy(), d_T.cpu().numpy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)

@@ -695,3 +695,43 @@ def test_splits_through_the_cli(tmp_path, kpop, oracle, pyref):
     assert (tmp_path / "cent.PhyloSplits.txt").read_text() == want_c
     r = run([TWISTDB, "-I", "T", str(tmp_path / "Classes"), "-I", "t", str(tmp_path / "X"), "-e", "-p", "-o", "s", str(tmp_path / "bin")])
     assert r.returncode == 1 and "binary splits" in r.stderr
+
+
+def test_kpoptwist_kmer_selection_device_path_equals_host_path(tmp_path):
+    """KPopTwist keeps its table on the device (run_ca_device: row sums, keep list / sample / threshold, row gather and
+    kpop_dev_ca in place); KPopTwistCA, the R stage of the reference's wrapper, goes through the host table (run_ca,
+    kpop_ca).  Same k-mer selection options (src/KPopTwist:76-91), same twister: names equal, numbers to rounding."""
+    k = 5
+    rng = np.random.default_rng(77)
+    seqs = [("c%d" % i, "".join(rng.choice(list("ACGT"), size=int(rng.integers(1500, 2500))))) for i in range(9)]
+    write_fasta(tmp_path / "x.fa", seqs)
+    penv = dict(os.environ, PATH=BIN + ":" + os.environ.get("PATH", ""))
+    sh = lambda cmd: subprocess.run(["bash", "-c", cmd], cwd=str(tmp_path), capture_output=True, text=True, timeout=300, env=penv)
+    assert sh("KPopCount -k %d -L -f x.fa | KPopCountDB -k /dev/stdin -o Classes" % k).returncode == 0
+    # the table and the names as the wrapper exports them (src/KPopTwist:38-44)
+    r = sh("mkdir T && KPopCountDB -i Classes --table-output-row-names false -t T/TABLE -R '~.' -D --counts-output-zero-kmers true "
+           "--table-output-row-names true --table-output-metadata false -t /dev/stdout | tail -n +2 > T/NAMES.KPopCounter.txt")
+    assert r.returncode == 0, r.stderr
+    names = [l.split("\t")[0].strip('"') for l in (tmp_path / "T" / "NAMES.KPopCounter.txt").read_text().splitlines()]
+    keep = [n for i, n in enumerate(names) if i % 3 != 1]
+    (tmp_path / "keep.txt").write_text("".join(n + "\n" for n in reversed(keep)))  # in another order than the table's
+
+    def table(cmd):
+        out = sh(cmd).stdout.splitlines()
+        return out[0], [l.split("\t")[0] for l in out[1:]], np.array([[float(v) for v in l.split("\t")[1:]] for l in out[1:]])
+    for tag, opts, ca_args in (("plain", "", ("", "1", "0")), ("keep", "-k keep.txt", ("keep.txt", "1", "0")), ("sample", "-s 0.6", ("", "0.6", "0")),
+                               ("thr", "--kmers-threshold 0.3", ("", "1", "0.3")), ("all3", "-k keep.txt -s 0.7 --kmers-threshold 0.2", ("keep.txt", "0.7", "0.2"))):
+        r = sh("KPopTwist -i Classes -o D_%s %s" % (tag, opts))
+        assert r.returncode == 0, (tag, r.stderr)
+        r = sh("KPopTwistCA T/TABLE.KPopCounter.txt T/NAMES.KPopCounter.txt H_%s '' '%s' %s true %s 1 false false && "
+               "KPopTwistDB -I T H_%s -o T H_%s && KPopTwistDB -I t H_%s -o t H_%s" % (tag, ca_args[0], ca_args[1], ca_args[2], tag, tag, tag, tag))
+        assert r.returncode == 0, (tag, r.stderr)
+        for reg in ("T", "t"):
+            cut = " | head -%d" % len(seqs) if reg == "T" else ""  # (the twister's table is followed by the inertia's: 8 dimensions + header)
+            ha, ra, da = table("KPopTwistDB -i %s D_%s -O %s /dev/stdout%s" % (reg, tag, reg, cut))
+            hb, rb, db = table("KPopTwistDB -i %s H_%s -O %s /dev/stdout%s" % (reg, tag, reg, cut))
+            assert ha == hb and ra == rb and da.shape == db.shape and da.size > 0, (tag, reg)
+            np.testing.assert_allclose(da, db, rtol=1e-9, atol=1e-11, err_msg="%s %s" % (tag, reg))   # H went through %.15g text
+        if tag != "plain":
+            n_kmers = len(sh("KPopTwistDB -i T D_%s -O T /dev/stdout | head -1" % tag).stdout.split("\t")) - 1
+            assert n_kmers < len(names), tag

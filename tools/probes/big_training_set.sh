@@ -11,6 +11,6 @@ python3 -c "print('KPopCount -L: %.2f s' % ($t1 - $t0))"
 t0=$(now); KPOP_TIMING=1 KPopCountDB -k G -o DB 2>&1 | tail -4; t1=$(now)
 python3 -c "print('KPopCountDB -k -o: %.2f s' % ($t1 - $t0))"
 ls -la DB.KPopCounter | awk '{print $5, "bytes of database"}'
-t0=$(now); KPOP_TIMING=1 KPopTwist -i DB -o TW 2>&1 | grep -v "kpop_ca\]" | tail -14; t1=$(now)
+t0=$(now); KPOP_TIMING=1 KPopTwist -i DB -o TW 2>&1 | tail -24; t1=$(now)
 python3 -c "print('KPopTwist: %.2f s' % ($t1 - $t0))"
 ls -la TW.KPopTwister | awk '{print $5, "bytes of twister"}'
