@@ -532,6 +532,32 @@ static int jacobi_eigen_psd_device(double *d_G, double *d_V, uint32_t n, double 
   return 0;
 }
 
+// Class positions and the projection W from the eigenvectors, on the device: twisted[j][d] = v_d[j] / sqrt(c_j) * sv_d and
+// W[j][d] = v_d[j] / sv_d for the dimensions in decreasing order of eigenvalue (order[d] = the column of V).  Tiles of 32 x 32
+// through LDS: V is read along j (its columns are contiguous), the outputs are written along d.
+__global__ __launch_bounds__(256) void ca_positions_kernel(const double *__restrict__ V, uint32_t J, uint32_t nd, const uint32_t *__restrict__ order,
+                                                           const double *__restrict__ sv, const double *__restrict__ c,
+                                                           double *__restrict__ twisted, double *__restrict__ W) {
+  __shared__ double tile[32][33];
+  const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const uint32_t j0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t d = d0 + ty + 8 * q, j = j0 + tx;
+    tile[ty + 8 * q][tx] = (d < nd && j < J) ? V[(uint64_t)order[d] * J + j] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t j = j0 + ty + 8 * q, d = d0 + tx;
+    if (j < J && d < nd) {
+      const double v = tile[tx][ty + 8 * q], s = sv[d];
+      twisted[(uint64_t)j * nd + d] = v / sqrt(c[j]) * s;  // D_c^-1/2 V diag(sv)
+      W[(uint64_t)j * nd + d] = s > 0.0 ? v / s : 0.0;     // V diag(1/sv)
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // The analysis on device-resident data.  d_N: the counts (I x J, row-major); d_S: where the standardised table goes (may
 // be d_N).  The small per-column and per-dimension work (J weights; the order of J eigenvalues) is host code between
@@ -610,7 +636,7 @@ static int ca_on_device(const double *d_N, double *d_S, uint64_t I, uint32_t J, 
   splits = std::min(splits, 256u);  // of K = I in G = S'S
   const uint32_t n_dim_slabs = div_up(nd, kCaDimSlab);
   const uint32_t slab_w = std::min(nd, kCaDimSlab);
-  DevBuf dW, dR, dC, dPart, dG, dGslabs, dWm, dV, dLambda, dWorst, dU[1], dT[2];
+  DevBuf dW, dR, dC, dPart, dG, dGslabs, dWm, dV, dLambda, dWorst, dOrder, dSv, dTwisted, dU[1], dT[2];
   KPOP_TRY(dW.alloc((uint64_t)J * 8));
   KPOP_TRY(dR.alloc(I * 8));
   KPOP_TRY(dC.alloc((uint64_t)J * 8));
@@ -621,6 +647,9 @@ static int ca_on_device(const double *d_N, double *d_S, uint64_t I, uint32_t J, 
   KPOP_TRY(dLambda.alloc((uint64_t)J * 8));
   KPOP_TRY(dWorst.alloc(8));
   KPOP_TRY(dWm.alloc((uint64_t)J * nd * 8));
+  KPOP_TRY(dOrder.alloc((uint64_t)J * 4));
+  KPOP_TRY(dSv.alloc((uint64_t)nd * 8));
+  if (!out.on_device) KPOP_TRY(dTwisted.alloc((uint64_t)J * nd * 8));
   struct Events {
     hipEvent_t ready[2] = {nullptr, nullptr};
     ~Events() {
@@ -665,40 +694,33 @@ static int ca_on_device(const double *d_N, double *d_S, uint64_t I, uint32_t J, 
   tm.mark("G = S'S");
   KPOP_TRY(jacobi_eigen_psd_device(dG.as<double>(), dV.as<double>(), J, dLambda.as<double>(), dWorst.as<unsigned long long>(), st));
   tm.mark("Jacobi");
-  std::vector<double> V((size_t)J * J), lambda(J);
-  KPOP_HIP(hipMemcpyAsync(V.data(), dV.p, (uint64_t)J * J * 8, hipMemcpyDeviceToHost, st));
+  std::vector<double> lambda(J);
   KPOP_HIP(hipMemcpyAsync(lambda.data(), dLambda.p, (uint64_t)J * 8, hipMemcpyDeviceToHost, st));
   KPOP_HIP(hipStreamSynchronize(st));
-  // order by decreasing eigenvalue; sv = sqrt(lambda)
+  // order by decreasing eigenvalue; sv = sqrt(lambda): J numbers, host work.  The J x nd class positions and the projection
+  // are built from the eigenvectors where they are.
   std::vector<uint32_t> order(J);
   std::iota(order.begin(), order.end(), 0u);
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return lambda[a] > lambda[b]; });
-  std::vector<double> sv(nd), Wm((size_t)J * nd), h_twisted, h_inertia;
-  double *twisted = out.twisted, *inertia = out.inertia;
-  if (out.on_device) {
-    h_twisted.resize((size_t)J * nd);
-    h_inertia.resize(nd);
-    twisted = h_twisted.data();
-    inertia = h_inertia.data();
-  }
+  std::vector<double> sv(nd), h_inertia(nd);
   double sum_sq = 0.0;
   for (uint32_t d = 0; d < nd; ++d) {
     sv[d] = sqrt(std::max(lambda[order[d]], 0.0));
     sum_sq += sv[d] * sv[d];
   }
-  for (uint32_t d = 0; d < nd; ++d) {
-    inertia[d] = sum_sq > 0.0 ? sv[d] * sv[d] / sum_sq : 0.0;
-    const double *v = &V[(size_t)order[d] * J];
-    for (uint32_t j = 0; j < J; ++j) {
-      twisted[(size_t)j * nd + d] = v[j] / sqrt(c[j]) * sv[d];   // D_c^-1/2 V diag(sv)
-      Wm[(size_t)j * nd + d] = sv[d] > 0.0 ? v[j] / sv[d] : 0.0;  // V diag(1/sv)
-    }
+  for (uint32_t d = 0; d < nd; ++d) h_inertia[d] = sum_sq > 0.0 ? sv[d] * sv[d] / sum_sq : 0.0;
+  KPOP_HIP(hipMemcpyAsync(dOrder.p, order.data(), (uint64_t)J * 4, hipMemcpyHostToDevice, st));
+  KPOP_HIP(hipMemcpyAsync(dSv.p, sv.data(), (uint64_t)nd * 8, hipMemcpyHostToDevice, st));
+  double *d_twisted = out.on_device ? out.twisted : dTwisted.as<double>();
+  ca_positions_kernel<<<dim3(div_up(J, 32), div_up(nd, 32)), dim3(256), 0, st>>>(dV.as<double>(), J, nd, dOrder.as<uint32_t>(), dSv.as<double>(),
+                                                                                 dC.as<double>(), d_twisted, dWm.as<double>());
+  KPOP_LAUNCH_CHECK();
+  if (out.on_device) KPOP_HIP(hipMemcpyAsync(out.inertia, h_inertia.data(), (uint64_t)nd * 8, hipMemcpyHostToDevice, st));
+  else {
+    std::copy(h_inertia.begin(), h_inertia.end(), out.inertia);
+    KPOP_HIP(hipMemcpyAsync(out.twisted, d_twisted, (uint64_t)J * nd * 8, hipMemcpyDeviceToHost, st));
   }
-  if (out.on_device) {
-    KPOP_HIP(hipMemcpyAsync(out.twisted, twisted, (uint64_t)J * nd * 8, hipMemcpyHostToDevice, st));
-    KPOP_HIP(hipMemcpyAsync(out.inertia, inertia, (uint64_t)nd * 8, hipMemcpyHostToDevice, st));
-  }
-  KPOP_HIP(hipMemcpyAsync(dWm.p, Wm.data(), (uint64_t)J * nd * 8, hipMemcpyHostToDevice, st));
+  KPOP_HIP(hipStreamSynchronize(st));  // (order, sv and h_inertia are the sources of copies in flight)
   tm.mark("V back, order, W");
   // U = S W (I x nd) slab by slab, then the twister = (D_r^-1/2 U)'
   const uint32_t M = (uint32_t)std::min<uint64_t>(I, 0xFFFFFFFFull);
