@@ -525,6 +525,7 @@ static int jacobi_eigen_psd_device(double *d_G, double *d_V, uint32_t n, double 
     double w = 0.0;
     KPOP_HIP(hipMemcpyAsync(&w, d_worst, 8, hipMemcpyDeviceToHost, st));
     KPOP_HIP(hipStreamSynchronize(st));
+    if (getenv("KPOP_JACOBI_TRACE")) fprintf(stderr, "[jacobi] sweep %d: largest |cos| between two columns %.3e\n", sweep, w);
     if (w < 1e-15) break;
   }
   jacobi_colnorm_kernel<<<dim3(n), dim3(256), 0, st>>>(d_G, n, d_lambda);
