@@ -363,7 +363,7 @@ static_assert(kJC * (kJC + 1) / 2 == 36, "jacobi_wave_totals is written for 36 s
 // 8 x 8 problem is solved (their latency hides behind it), and A is rotated from registers without a second read.  The
 // looped kernel above spends 17 us of its 50 us per step in the Gram pass alone at n = 1,636: one wavefront per SIMD and
 // seven dependent trips to the L2 / MALL.
-template <int ROWS>
+template <int ROWS, bool WITH_V>
 __global__ __launch_bounds__(256) void jacobi_block_step_reg_kernel(double *__restrict__ A, double *__restrict__ V, uint32_t n,
                                                                     uint32_t m_blk, uint32_t step, unsigned long long *worst, int inner_sweeps) {
   __shared__ double s_part[4][kJC * kJC];
@@ -443,13 +443,15 @@ __global__ __launch_bounds__(256) void jacobi_block_step_reg_kernel(double *__re
       s_part[wv][b * kJC + a] = g[0];
     }
   }
-  double y[ROWS][kJC];  // the rows of V, asked for now and used after the 8 x 8 problem
+  double y[WITH_V ? ROWS : 1][kJC];  // the rows of V, asked for now and used after the 8 x 8 problem
+  if (WITH_V) {
 #pragma unroll
-  for (int r = 0; r < ROWS; ++r) {
-    const uint32_t i = threadIdx.x + 256u * r;
-    const uint32_t ii = i < n ? i : 0u;
+    for (int r = 0; r < ROWS; ++r) {
+      const uint32_t i = threadIdx.x + 256u * r;
+      const uint32_t ii = i < n ? i : 0u;
 #pragma unroll
-    for (int c = 0; c < kJC; ++c) y[r][c] = V[base[c] + ii];
+      for (int c = 0; c < kJC; ++c) y[WITH_V ? r : 0][c] = V[base[c] + ii];
+    }
   }
   __syncthreads();
   if (wv == 0) jacobi_solve_8x8<4>(s_part, s_R, &s_skip, worst, inner_sweeps);
@@ -469,11 +471,11 @@ __global__ __launch_bounds__(256) void jacobi_block_step_reg_kernel(double *__re
 #pragma unroll
       for (int a = 0; a < kJC; ++a) {
         acc += x[r][a] * Rl[a][c];
-        acv += y[r][a] * Rl[a][c];
+        if (WITH_V) acv += y[WITH_V ? r : 0][a] * Rl[a][c];
       }
       if (in && ok[c]) {
         A[base[c] + threadIdx.x + 256u * r] = acc;
-        V[base[c] + threadIdx.x + 256u * r] = acv;
+        if (WITH_V) V[base[c] + threadIdx.x + 256u * r] = acv;
       }
     }
   }
@@ -482,6 +484,130 @@ __global__ __launch_bounds__(256) void jacobi_block_step_reg_kernel(double *__re
 __global__ void jacobi_identity_kernel(double *__restrict__ V, uint32_t n) {
   const uint64_t total = (uint64_t)n * n, stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) V[e] = (e / n == e % n) ? 1.0 : 0.0;
+}
+
+// ---------------------------------------------------------------------------
+// Cholesky factor of the Gram matrix, in place (G = L L'; G is symmetric, so its storage is L's column-major one: column j
+// at A + j n).  Right-looking, panels of kCholW columns: the diagonal block is factored in LDS by one workgroup, the rows
+// below it are solved against it a thread each, and the trailing matrix loses the panel's outer product (the f64 MFMA GEMM,
+// then a subtraction).  G is positive SEMI-definite -- the analysis' trivial direction, or fewer k-mers than spectra: a
+// pivot not above `tol` closes its column with zeros (in exact arithmetic the whole row and column of the Schur complement
+// are zero there).  Why a Cholesky factor at all: the one-sided Jacobi iteration on L needs no accumulated V (the
+// eigenvectors of G are L's normalised columns once they are orthogonal) and starts from columns that are far closer to
+// orthogonal than G's own.
+// ---------------------------------------------------------------------------
+constexpr int kCholW = 64;
+
+__global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ A, uint32_t n, uint32_t j0, uint32_t w, double tol,
+                                                        double *__restrict__ D) {
+  __shared__ double s[kCholW][kCholW + 1];  // s[c][r]: row r of column c
+  for (uint32_t e = threadIdx.x; e < (uint32_t)kCholW * kCholW; e += 256) {
+    const uint32_t c = e / kCholW, r = e % kCholW;
+    s[c][r] = (c < w && r < w) ? A[(uint64_t)(j0 + c) * n + j0 + r] : (c == r ? 1.0 : 0.0);  // (beyond w: the identity)
+  }
+  __syncthreads();
+  for (uint32_t k = 0; k < w; ++k) {
+    const double d = s[k][k];
+    const bool dead = !(d > tol);
+    const double root = dead ? 0.0 : sqrt(d);
+    __syncthreads();  // everyone has the pivot
+    for (uint32_t r = k + threadIdx.x; r < w; r += 256) s[k][r] = (r == k) ? root : (dead ? 0.0 : s[k][r] / root);
+    __syncthreads();
+    const uint32_t t = w - k - 1;
+    for (uint32_t e = threadIdx.x; e < t * t; e += 256) {
+      const uint32_t c = k + 1 + e / t, r = k + 1 + e % t;
+      if (r >= c) s[c][r] -= s[k][r] * s[k][c];
+    }
+    __syncthreads();
+  }
+  for (uint32_t e = threadIdx.x; e < (uint32_t)kCholW * kCholW; e += 256) {
+    const uint32_t c = e / kCholW, r = e % kCholW;
+    const double v = r >= c ? s[c][r] : 0.0;
+    D[e] = v;
+    if (c < w && r < w) A[(uint64_t)(j0 + c) * n + j0 + r] = v;  // (the upper triangle of the block becomes the zeros L has there)
+  }
+}
+
+// rows below the diagonal block: x L11' = a, a thread per row, the row in registers
+__global__ __launch_bounds__(256) void chol_panel_kernel(double *__restrict__ A, uint32_t n, uint32_t j0, uint32_t w, const double *__restrict__ D) {
+  __shared__ double L[kCholW][kCholW + 1];  // L[c][r]: row r of column c of L11 (identity beyond w)
+  for (uint32_t e = threadIdx.x; e < (uint32_t)kCholW * kCholW; e += 256) L[e / kCholW][e % kCholW] = D[e];
+  __syncthreads();
+  const uint32_t i = j0 + w + blockIdx.x * 256 + threadIdx.x;
+  const uint32_t ii = i < n ? i : n - 1;
+  double x[kCholW];
+#pragma unroll
+  for (int c = 0; c < kCholW; ++c) x[c] = A[(uint64_t)(j0 + ((uint32_t)c < w ? c : 0)) * n + ii];
+#pragma unroll
+  for (int c = 0; c < kCholW; ++c) {
+    double acc = (uint32_t)c < w ? x[c] : 0.0;
+#pragma unroll
+    for (int k = 0; k < c; ++k) acc -= x[k] * L[k][c];
+    const double d = L[c][c];
+    x[c] = d > 0.0 ? acc / d : 0.0;
+  }
+  if (i < n) {
+#pragma unroll
+    for (int c = 0; c < kCholW; ++c)
+      if ((uint32_t)c < w) A[(uint64_t)(j0 + c) * n + i] = x[c];
+  }
+}
+
+// the trailing m x m block at (off, off) loses C (m x m, its own leading dimension)
+__global__ void chol_subtract_kernel(double *__restrict__ A, uint32_t n, uint32_t off, uint32_t m, const double *__restrict__ C) {
+  const uint64_t total = (uint64_t)m * m, stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const uint32_t c = (uint32_t)(e / m), i = (uint32_t)(e % m);
+    A[(uint64_t)(off + c) * n + off + i] -= C[e];
+  }
+}
+
+// what is above the diagonal of L (rows i < j of column j) is zero; the panels left the Gram matrix's entries there
+__global__ void chol_zero_upper_kernel(double *__restrict__ A, uint32_t n) {
+  const uint64_t total = (uint64_t)n * n, stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride)
+    if (e % n < e / n) A[e] = 0.0;
+}
+
+// columns orthogonal: eigenvalue = squared norm, eigenvector = the column over its norm (zero for a null direction)
+__global__ __launch_bounds__(256) void jacobi_unit_columns_kernel(const double *__restrict__ A, uint32_t n, double *__restrict__ V,
+                                                                  double *__restrict__ lambda) {
+  __shared__ double s_w[4];
+  const double *a = A + (uint64_t)blockIdx.x * n;
+  double s = 0.0;
+  for (uint32_t i = threadIdx.x; i < n; i += 256) s += a[i] * a[i];
+  s = block_sum_256(s, s_w);
+  if (threadIdx.x == 0) lambda[blockIdx.x] = s;
+  const double norm = sqrt(s);
+  for (uint32_t i = threadIdx.x; i < n; i += 256) V[(uint64_t)blockIdx.x * n + i] = norm > 0.0 ? a[i] / norm : 0.0;
+}
+
+static int cholesky_in_place(double *d_A, uint32_t n, double *d_scratch /* n x n */, hipStream_t st) {
+  // the tolerance of a pivot: the largest diagonal entry of G times a few thousand roundings
+  std::vector<double> diag(n);
+  KPOP_HIP(hipMemcpy2DAsync(diag.data(), 8, d_A, (size_t)(n + 1) * 8, 8, n, hipMemcpyDeviceToHost, st));
+  KPOP_HIP(hipStreamSynchronize(st));
+  double mx = 0.0;
+  for (double v : diag) mx = std::max(mx, v);
+  const double tol = mx * 1e-13;
+  DevBuf dD;
+  KPOP_TRY(dD.alloc((uint64_t)kCholW * kCholW * 8));
+  for (uint32_t j0 = 0; j0 < n; j0 += kCholW) {
+    const uint32_t w = std::min<uint32_t>(kCholW, n - j0), m = n - j0 - w;
+    chol_diag_kernel<<<dim3(1), dim3(256), 0, st>>>(d_A, n, j0, w, tol, dD.as<double>());
+    KPOP_LAUNCH_CHECK();
+    if (m == 0) break;
+    chol_panel_kernel<<<dim3(div_up(m, 256)), dim3(256), 0, st>>>(d_A, n, j0, w, dD.as<double>());
+    KPOP_LAUNCH_CHECK();
+    // C = P P' with P the m x w panel: its columns are w contiguous runs of memory, i.e. the w x m row-major matrix P'
+    const double *P = d_A + (uint64_t)j0 * n + j0 + w;
+    KPOP_TRY(gemm_f64<true>(P, n, P, n, d_scratch, m, m, w, 1, nullptr, 0, st));
+    chol_subtract_kernel<<<dim3(std::min<uint32_t>(div_up((uint64_t)m * m, 256), 4096)), dim3(256), 0, st>>>(d_A, n, j0 + w, m, d_scratch);
+    KPOP_LAUNCH_CHECK();
+  }
+  chol_zero_upper_kernel<<<dim3(std::min<uint32_t>(div_up((uint64_t)n * n, 256), 4096)), dim3(256), 0, st>>>(d_A, n);
+  KPOP_LAUNCH_CHECK();
+  return 0;
 }
 
 __global__ __launch_bounds__(256) void jacobi_colnorm_kernel(const double *__restrict__ A, uint32_t n, double *__restrict__ lambda) {
@@ -493,13 +619,19 @@ __global__ __launch_bounds__(256) void jacobi_colnorm_kernel(const double *__res
   if (threadIdx.x == 0) lambda[blockIdx.x] = sqrt(s);
 }
 
-// d_G is overwritten (columns rotated); d_V receives the eigenvectors as columns (V[j*n + i] = component i of vector j)
+// d_G is overwritten; d_V receives the eigenvectors as columns (V[j*n + i] = component i of vector j), d_lambda the eigenvalues
 static int jacobi_eigen_psd_device(double *d_G, double *d_V, uint32_t n, double *d_lambda, unsigned long long *d_worst, hipStream_t st) {
-  jacobi_identity_kernel<<<dim3(std::min<uint32_t>(div_up((uint64_t)n * n, 256), 4096)), dim3(256), 0, st>>>(d_V, n);
-  KPOP_LAUNCH_CHECK();
   const uint32_t m = (n + 1) & ~1u;
   const uint32_t n_blk = div_up(n, kJB), m_blk = (n_blk + 1) & ~1u;
   const bool blocked = n >= 4 * kJC && !(ctx().tune_dbg & 32);  // (32: the plain steps, for A/B)
+  // From 32 columns up to what the register kernel holds: Jacobi on the Cholesky factor of G, no V to rotate.  (2048: on G
+  // itself with V accumulated, as below that size and above it, for A/B.)
+  const bool on_factor = blocked && n <= 2048 && !(ctx().tune_dbg & (64 | 2048));
+  if (on_factor) KPOP_TRY(cholesky_in_place(d_G, n, d_V, st));
+  else {
+    jacobi_identity_kernel<<<dim3(std::min<uint32_t>(div_up((uint64_t)n * n, 256), 4096)), dim3(256), 0, st>>>(d_V, n);
+    KPOP_LAUNCH_CHECK();
+  }
   for (int sweep = 0; sweep < 60; ++sweep) {
     KPOP_HIP(hipMemsetAsync(d_worst, 0, 8, st));
     if (blocked) {
@@ -508,8 +640,11 @@ static int jacobi_eigen_psd_device(double *d_G, double *d_V, uint32_t n, double 
         const dim3 grid(m_blk / 2), block(256);
         unsigned long long *w = d_worst;
         switch ((ctx().tune_dbg & 64) ? 0u : div_up(n, 256)) {  // (64: the looped kernel, for A/B)
-#define KPOP_JACOBI_ROWS(R) \
-  case R: jacobi_block_step_reg_kernel<R><<<grid, block, 0, st>>>(d_G, d_V, n, m_blk, step, w, inner); break;
+#define KPOP_JACOBI_ROWS(R)                                                                                           \
+  case R:                                                                                                             \
+    if (on_factor) jacobi_block_step_reg_kernel<R, false><<<grid, block, 0, st>>>(d_G, d_V, n, m_blk, step, w, inner); \
+    else jacobi_block_step_reg_kernel<R, true><<<grid, block, 0, st>>>(d_G, d_V, n, m_blk, step, w, inner);           \
+    break;
           KPOP_JACOBI_ROWS(1) KPOP_JACOBI_ROWS(2) KPOP_JACOBI_ROWS(3) KPOP_JACOBI_ROWS(4)
           KPOP_JACOBI_ROWS(5) KPOP_JACOBI_ROWS(6) KPOP_JACOBI_ROWS(7) KPOP_JACOBI_ROWS(8)
 #undef KPOP_JACOBI_ROWS
@@ -528,7 +663,8 @@ static int jacobi_eigen_psd_device(double *d_G, double *d_V, uint32_t n, double 
     if (getenv("KPOP_JACOBI_TRACE")) fprintf(stderr, "[jacobi] sweep %d: largest |cos| between two columns %.3e\n", sweep, w);
     if (w < 1e-15) break;
   }
-  jacobi_colnorm_kernel<<<dim3(n), dim3(256), 0, st>>>(d_G, n, d_lambda);
+  if (on_factor) jacobi_unit_columns_kernel<<<dim3(n), dim3(256), 0, st>>>(d_G, n, d_V, d_lambda);
+  else jacobi_colnorm_kernel<<<dim3(n), dim3(256), 0, st>>>(d_G, n, d_lambda);
   KPOP_LAUNCH_CHECK();
   return 0;
 }

@@ -110,6 +110,7 @@ extern "C" int kpop_init(int device) {
   c.n_cus = prop.multiProcessorCount;
   c.lds_per_block = prop.sharedMemPerBlock;
   c.initialised = true;
+  if (const char *dbg = getenv("KPOP_TUNE_DBG")) c.tune_dbg = (uint32_t)atoi(dbg);  // (the A/B switches of kpop_tune("dbg"), for the command-line tools)
   return KPOP_OK;
 }
 
