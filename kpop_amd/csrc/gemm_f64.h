@@ -20,7 +20,7 @@
 namespace kpop {
 
 constexpr int kGT = 128;   // output tile edge
-constexpr int kGK = 16;    // K per chunk
+constexpr int kGK = 16;    // K per chunk (32 measured: slower, 41.8 / 69.0 ms against 36.6 / 59.7 at 524,800 x 1,636)
 constexpr int kGS = kGT + 17;  // LDS row stride in doubles (odd: transposed staging writes spread over banks)
 
 using f64x4 = __attribute__((ext_vector_type(4))) double;
@@ -60,28 +60,42 @@ __global__ __launch_bounds__(256) void gemm_f64_mfma_kernel(const double *__rest
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-  double ra[8], rb[8];
+  constexpr int kQ = kGK / 2;  // loads per thread, panel and chunk
+  double ra[kQ], rb[kQ];
+  // S W (!TRANS_A): the loads are unconditional, from addresses clamped into the operands, and what lies outside the tile is
+  // zeroed afterwards -- predicated loads each waited for themselves: 65.0 -> 59.7 ms.  S'S keeps its predicated loads: the
+  // same change cost it 3 ms (36.6 -> 40.0).
   auto prefetch = [&](uint64_t k0) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < kQ; ++q) {
+      const uint32_t nn = threadIdx.x & 127, kb = (threadIdx.x >> 7) + 2 * q;
       if (TRANS_A) {  // A[k][m]: lanes along m
         const uint32_t mm = threadIdx.x & 127, kk = (threadIdx.x >> 7) + 2 * q;
         ra[q] = (k0 + kk < k_end && m0 + mm < M) ? A[(k0 + kk) * lda + m0 + mm] : 0.0;
-      } else {  // A[m][k]: lanes along k (16 consecutive doubles = one 128-byte line)
-        const uint32_t kk = threadIdx.x & 15, mm = (threadIdx.x >> 4) + 16 * q;
-        ra[q] = (k0 + kk < k_end && m0 + mm < M) ? A[(uint64_t)(m0 + mm) * lda + k0 + kk] : 0.0;
+        rb[q] = (k0 + kb < k_end && n0 + nn < N) ? B[(k0 + kb) * ldb + n0 + nn] : 0.0;
+      } else {  // A[m][k]: lanes along k (kGK consecutive doubles: whole 128-byte lines)
+        const uint32_t kk = threadIdx.x & (kGK - 1), mm = threadIdx.x / kGK + (256 / kGK) * q;
+        ra[q] = A[(uint64_t)min(m0 + mm, M - 1) * lda + min(k0 + kk, k_end - 1)];
+        rb[q] = B[min(k0 + kb, k_end - 1) * ldb + min(n0 + nn, N - 1)];
       }
-      const uint32_t nn = threadIdx.x & 127, kb = (threadIdx.x >> 7) + 2 * q;
-      rb[q] = (k0 + kb < k_end && n0 + nn < N) ? B[(k0 + kb) * ldb + n0 + nn] : 0.0;
+    }
+    if (!TRANS_A) {
+#pragma unroll
+      for (int q = 0; q < kQ; ++q) {
+        const uint32_t kk = threadIdx.x & (kGK - 1), mm = threadIdx.x / kGK + (256 / kGK) * q;
+        const uint32_t nn = threadIdx.x & 127, kb = (threadIdx.x >> 7) + 2 * q;
+        ra[q] = (k0 + kk < k_end && m0 + mm < M) ? ra[q] : 0.0;
+        rb[q] = (k0 + kb < k_end && n0 + nn < N) ? rb[q] : 0.0;
+      }
     }
   };
   if (k_begin < k_end) prefetch(k_begin);
   for (uint64_t k0 = k_begin; k0 < k_end; k0 += kGK) {
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < kQ; ++q) {
       if (TRANS_A) As[(threadIdx.x >> 7) + 2 * q][threadIdx.x & 127] = ra[q];
-      else As[threadIdx.x & 15][(threadIdx.x >> 4) + 16 * q] = ra[q];
+      else As[threadIdx.x & (kGK - 1)][threadIdx.x / kGK + (256 / kGK) * q] = ra[q];
       Bs[(threadIdx.x >> 7) + 2 * q][threadIdx.x & 127] = rb[q];
     }
     __syncthreads();
