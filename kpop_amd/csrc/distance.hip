@@ -104,7 +104,7 @@ constexpr int kDC = 16, kMaxW = 128, kMaxTJ = 256;
 // SLAB (spectral distances, n_dims in the millions and few rows): blockIdx.z owns dimensions [z*slab, (z+1)*slab) and
 // writes its raw partial sums to slab z of `out` ([gridDim.z][r2][r1]); reduce_slabs_kernel adds the slabs in order and
 // applies the scale.  SLAB = false is the hot path: one block walks all the dimensions, the sum is the reference's.
-template <int KIND, bool SLAB = false>
+template <int KIND, bool SLAB = false, int TY = 4>
 __global__ __launch_bounds__(256) void distance_rowwise_kernel(const double *__restrict__ a, uint32_t w, uint32_t r1,
                                                                const double *__restrict__ b, uint32_t r2,
                                                                uint32_t n_dims, const double *__restrict__ metric,
@@ -113,15 +113,15 @@ __global__ __launch_bounds__(256) void distance_rowwise_kernel(const double *__r
   __shared__ __attribute__((aligned(16))) double As[kDC][kMaxW + 2];
   __shared__ __attribute__((aligned(16))) double Bs[kDC][kMaxTJ + 2];
   __shared__ double s_metric[kDC];
-  const uint32_t TJ = 4 * n_rg;
+  const uint32_t TJ = TY * n_rg;
   const uint32_t i0 = blockIdx.x * w, j0 = blockIdx.y * TJ;
   const uint32_t i1 = min(r1, i0 + w);
   const uint32_t cg = threadIdx.x % n_cg, rg = threadIdx.x / n_cg;
   const bool worker = rg < n_rg;
-  const uint32_t ti = cg * 4, tj = (worker ? rg : 0) * 4;
-  double acc[4][4];
+  const uint32_t ti = cg * 4, tj = (worker ? rg : 0) * TY;
+  double acc[TY][4];
 #pragma unroll
-  for (int y = 0; y < 4; ++y)
+  for (int y = 0; y < TY; ++y)
 #pragma unroll
     for (int x = 0; x < 4; ++x) acc[y][x] = 0.0;
   // Staging is software-pipelined through registers: the global loads of chunk c+1 are issued before
@@ -157,14 +157,14 @@ __global__ __launch_bounds__(256) void distance_rowwise_kernel(const double *__r
     const uint32_t lim = min((uint32_t)kDC, d_end - c0);
     if (worker) {
       for (uint32_t cc = 0; cc < lim; ++cc) {
-        double av[4], bv[4];
+        double av[4], bv[TY];
 #pragma unroll
         for (int x = 0; x < 4; ++x) av[x] = As[cc][ti + x];
 #pragma unroll
-        for (int y = 0; y < 4; ++y) bv[y] = Bs[cc][tj + y];
+        for (int y = 0; y < TY; ++y) bv[y] = Bs[cc][tj + y];
         const double mc = s_metric[cc];
 #pragma unroll
-        for (int y = 0; y < 4; ++y)
+        for (int y = 0; y < TY; ++y)
 #pragma unroll
           for (int x = 0; x < 4; ++x) {
             // lib/Space.ml:192-200: diff = a -. b ; acc +. (diff *. diff *. m)
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void distance_rowwise_kernel(const double *__r
   }
   if (!worker) return;
 #pragma unroll
-  for (int y = 0; y < 4; ++y) {
+  for (int y = 0; y < TY; ++y) {
     const uint32_t j = j0 + tj + y;
     if (j >= r2) continue;
 #pragma unroll
@@ -688,13 +688,21 @@ static int rowwise_block(const double *a, uint32_t r1, const double *b, uint32_t
   const uint32_t n_tiles = std::max(1u, r1 / 64);
   const uint32_t w = div_up(r1, n_tiles);
   const uint32_t n_cg = div_up(w, 4);
-  const uint32_t n_rg = std::min(256u / n_cg, (uint32_t)kMaxTJ / 4);
-  const uint32_t TJ = 4 * n_rg;
+  // a thread takes 4 columns x TY rows of the tile: TY = 8 reads a quarter fewer LDS words per pair than 4 x 4, and the LDS
+  // pipe is as busy as the VALU in this kernel; 4 keeps more row groups when the second operand is short
+  const bool tall = r2 >= 8192 && !(ctx().tune_dbg & 4096);
+  const uint32_t ty = tall ? 8 : 4;
+  const uint32_t n_rg = std::min(256u / n_cg, (uint32_t)kMaxTJ / ty);
+  const uint32_t TJ = ty * n_rg;
   const uint32_t rows_per_launch = 65535u * TJ;  // m2 rows ride on grid.y
   for (uint32_t j0 = 0; j0 < r2; j0 += rows_per_launch) {
     const uint32_t nr = std::min(rows_per_launch, r2 - j0);
-    distance_rowwise_kernel<KIND><<<dim3(div_up(r1, w), div_up(nr, TJ)), dim3(256), 0, st>>>(
-        a, w, r1, b + (uint64_t)j0 * n_dims, nr, n_dims, metric, p, out + (uint64_t)j0 * r1, n_cg, n_rg);
+    if (tall)
+      distance_rowwise_kernel<KIND, false, 8><<<dim3(div_up(r1, w), div_up(nr, TJ)), dim3(256), 0, st>>>(
+          a, w, r1, b + (uint64_t)j0 * n_dims, nr, n_dims, metric, p, out + (uint64_t)j0 * r1, n_cg, n_rg);
+    else
+      distance_rowwise_kernel<KIND><<<dim3(div_up(r1, w), div_up(nr, TJ)), dim3(256), 0, st>>>(
+          a, w, r1, b + (uint64_t)j0 * n_dims, nr, n_dims, metric, p, out + (uint64_t)j0 * r1, n_cg, n_rg);
     KPOP_LAUNCH_CHECK();
   }
   return 0;
