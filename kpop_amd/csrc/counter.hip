@@ -410,22 +410,27 @@ __device__ __forceinline__ double wave_select_rank(const double (&v)[R], uint32_
 // the selection of tile t and land in registers under it.
 template <int R>
 struct MedianTile {
-  static constexpr uint32_t TR = R <= 8 ? 128 / R : R == 16 ? 16 : 8;  // k-mers per tile (larger tiles stage faster but leave the selection fewer waves: measured)
-  static constexpr uint32_t NV = (uint32_t)R * 64 * (TR / 4) / 256;    // 16-byte fetches per thread and tile, at most
+  // Threads per block and k-mers per tile.  A tile row of 32 k-mers is a whole 128-byte line of its spectrum: narrower rows
+  // fetch every line once per tile that touches it (FETCH_SIZE 2.0x the counts at 16 k-mers, 4.0x at 8).  From 257 spectra
+  // on, a tile of 32 k-mers no longer fits beside three other blocks' -- and the selection wants the waves -- so the block
+  // grows to 8 waves instead of the tile shrinking; beyond 1,024 spectra even that does not fit and the rows stay short.
+  static constexpr uint32_t NT = (R == 8 || R == 16) ? 512 : 256;
+  static constexpr uint32_t TR = R <= 4 ? 128 / R : R <= 16 ? 32 : 8;
+  static constexpr uint32_t NV = (uint32_t)R * 64 * (TR / 4) / NT;  // 16-byte fetches per thread and tile, at most
 };
 
 template <int R, bool VEC>
-__global__ __launch_bounds__(256) void combine_median_wave_kernel(const int32_t *__restrict__ storage, uint64_t ld, uint64_t n_rows,
+__global__ __launch_bounds__(MedianTile<R>::NT) void combine_median_wave_kernel(const int32_t *__restrict__ storage, uint64_t ld, uint64_t n_rows,
                                                                   const uint32_t *__restrict__ sel, const double *__restrict__ norm,
                                                                   const double *__restrict__ rcp, uint32_t m, uint32_t n_sel,
                                                                   double max_norm, int no_select, int32_t *__restrict__ out,
                                                                   double *__restrict__ norm_partial) {
-  constexpr uint32_t TR = MedianTile<R>::TR, TRp = TR + 1, NV = MedianTile<R>::NV, Q = TR / 4;
+  constexpr uint32_t NT = MedianTile<R>::NT, TR = MedianTile<R>::TR, TRp = TR + 1, NV = MedianTile<R>::NV, Q = TR / 4;
   extern __shared__ uint64_t median_lds[];  // [m] offsets of the spectra, then the tile [m][TR + 1] of counts
   uint64_t *s_off = median_lds;
   int32_t *tile32 = reinterpret_cast<int32_t *>(median_lds + m);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (uint32_t j = threadIdx.x; j < m; j += 256) s_off[j] = (uint64_t)sel[j] * ld;
+  for (uint32_t j = threadIdx.x; j < m; j += NT) s_off[j] = (uint64_t)sel[j] * ld;
   double b[R], y[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(256) void combine_median_wave_kernel(const int32_t 
     const uint64_t row0 = t * TR;
 #pragma unroll
     for (uint32_t q = 0; q < NV; ++q) {
-      const uint32_t e = threadIdx.x + 256u * q;
+      const uint32_t e = threadIdx.x + NT * q;
       const uint32_t j = e / Q, r4 = (e % Q) * 4;
       int4 v = make_int4(0, 0, 0, 0);
       if (e < n_vec && row0 + r4 + 4 <= ld) {
@@ -463,7 +468,7 @@ __global__ __launch_bounds__(256) void combine_median_wave_kernel(const int32_t 
     __syncthreads();  // the tile before this one has been read
 #pragma unroll
     for (uint32_t q = 0; q < NV; ++q) {
-      const uint32_t e = threadIdx.x + 256u * q;
+      const uint32_t e = threadIdx.x + NT * q;
       if (e < n_vec) {
         int32_t *d = tile32 + (e / Q) * TRp + (e % Q) * 4;
         d[0] = pre[q].x;
@@ -474,7 +479,7 @@ __global__ __launch_bounds__(256) void combine_median_wave_kernel(const int32_t 
     }
     __syncthreads();
     if (t + gridDim.x < n_tiles) fetch(t + gridDim.x);  // in flight under the selection
-    for (uint32_t rr = wv; rr < TR && row0 + rr < n_rows; rr += 4) {
+    for (uint32_t rr = wv; rr < TR && row0 + rr < n_rows; rr += NT / 64) {
       double v[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -490,11 +495,16 @@ __global__ __launch_bounds__(256) void combine_median_wave_kernel(const int32_t 
       }
     }
   }
-  __shared__ double sh[4];
+  __shared__ double sh[NT / 64];
   acc_norm = wave_sum(acc_norm);
   if (lane == 0) sh[wv] = acc_norm;
   __syncthreads();
-  if (threadIdx.x == 0) norm_partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+  if (threadIdx.x == 0) {
+    double total = 0.;
+#pragma unroll
+    for (uint32_t w = 0; w < NT / 64; ++w) total += sh[w];
+    norm_partial[blockIdx.x] = total;
+  }
 }
 
 // RescaledMedian beyond 1024 spectra (up to 4096): a tile of R k-mers x m spectra is staged in LDS (lanes along
@@ -799,7 +809,7 @@ extern "C" int kpop_dev_counter_combine(const int32_t *d_storage, uint64_t ld, u
       attr_set = true;                                                                                                              \
     }                                                                                                                               \
     grid = (uint32_t)std::min<uint64_t>((n_rows + TR - 1) / TR, 1u << 16);                                                          \
-    combine_median_wave_kernel<RR, VV><<<dim3(grid), dim3(256), lds, st>>>(d_storage, ld, n_rows, d_sel, d_norm, rcp, n_valid,     \
+    combine_median_wave_kernel<RR, VV><<<dim3(grid), dim3(MedianTile<RR>::NT), lds, st>>>(d_storage, ld, n_rows, d_sel, d_norm, rcp, n_valid, \
                                                                             n_sel, max_norm, no_select, d_out, partial);           \
   } while (0)
 #define KPOP_MEDIAN_WAVE_R(RR)       \
