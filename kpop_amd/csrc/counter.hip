@@ -413,9 +413,10 @@ struct MedianTile {
   // Threads per block and k-mers per tile.  A tile row of 32 k-mers is a whole 128-byte line of its spectrum: narrower rows
   // fetch every line once per tile that touches it (FETCH_SIZE 2.0x the counts at 16 k-mers, 4.0x at 8).  From 257 spectra
   // on, a tile of 32 k-mers no longer fits beside three other blocks' -- and the selection wants the waves -- so the block
-  // grows to 8 waves instead of the tile shrinking; beyond 1,024 spectra even that does not fit and the rows stay short.
-  static constexpr uint32_t NT = (R == 8 || R == 16) ? 512 : 256;
-  static constexpr uint32_t TR = R <= 4 ? 128 / R : R <= 16 ? 32 : 8;
+  // grows to 8 waves instead of the tile shrinking; beyond 1,024 spectra the tile of an 8-wave block holds 16 k-mers (half
+  // lines: 2.0x) where a 4-wave block's held 8.
+  static constexpr uint32_t NT = R >= 8 ? 512 : 256;
+  static constexpr uint32_t TR = R <= 4 ? 128 / R : R <= 16 ? 32 : 16;
   static constexpr uint32_t NV = (uint32_t)R * 64 * (TR / 4) / NT;  // 16-byte fetches per thread and tile, at most
 };
 
