@@ -346,3 +346,64 @@ def test_large_archives_mapped_paths_equal_the_streamed_ones(tmp_path):
     r3 = subprocess.run([TWISTDB, "-i", "T", "/dev/stdin", "-O", "T", str(tmp_path / "Td")], input=tb)
     assert r3.returncode == 0
     assert (tmp_path / "Td.KPopTwister.txt").read_bytes() == (tmp_path / "T.KPopTwister.txt").read_bytes()
+
+
+def _decode_reads_stream(raw):
+    """the reads stream of kpop_amd/host/fast_seq.h -> (k, content, [(tag, linted bases)])"""
+    import struct
+    assert raw[:8] == b"\0KPopRd1"
+    k, content = struct.unpack_from("<II", raw, 8)
+    at, recs = 16, []
+    while True:
+        n, zero = struct.unpack_from("<II", raw, at)
+        at += 8
+        if n == 0:
+            break
+        nb, nt = struct.unpack_from("<QQ", raw, at)
+        at += 16
+        lens = struct.unpack_from("<%dI" % n, raw, at)
+        at += 4 * n
+        tag_lens = struct.unpack_from("<%dI" % n, raw, at)
+        at += 4 * n
+        tags, bases = raw[at:at + nt], raw[at + nt:at + nt + nb]
+        at += nt + nb
+        tb = bb = 0
+        for L, T in zip(lens, tag_lens):
+            recs.append((tags[tb:tb + T], bases[bb:bb + L]))
+            tb += T
+            bb += L
+    assert at == len(raw)
+    return k, content, recs
+
+
+def test_paired_end_through_the_block_reader(tmp_path):
+    """KPopCount -p mates_1 mates_2 (bin/KPopCount.ml:36-54: segment 0, segment 1, ... alternate) reads both files block by
+    block and deals their records alternately: the reads it hands on are those of the two files interleaved into one,
+    whatever the block size; files with different numbers of reads are refused.  (No GPU: with KPOP_PIPE_FORMAT=reads
+    KPopCount defers the counting and only lints.)"""
+    import random
+    rng = random.Random(4)
+    n = 3000
+    one, two, both = [], [], []
+    for i in range(n):
+        for m, dst in ((1, one), (2, two)):
+            s = "".join(rng.choice("ACGTNacgtRY-") for _ in range(rng.randrange(0, 260)))
+            rec = "@p%d/%d some text\n%s\n+\n%s\n" % (i, m, s, "I" * len(s))
+            dst.append(rec)
+            both.append(rec)
+    (tmp_path / "a_1.fq").write_text("".join(one))
+    (tmp_path / "a_2.fq").write_text("".join(two))
+    (tmp_path / "inter.fq").write_text("".join(both))
+    (tmp_path / "short_2.fq").write_text("".join(two[:-1]))
+    base = dict(os.environ, KPOP_PIPE_FORMAT="reads")
+    for block in (None, "300", "5000", "70000"):
+        env = dict(base, KPOP_SEQ_BLOCK=block) if block else base
+        sh = lambda cmd: subprocess.run(["bash", "-c", cmd], cwd=str(tmp_path), capture_output=True, env=env, timeout=120)
+        a = sh("%s -k 7 -L -p a_1.fq a_2.fq | cat" % COUNT)
+        b = sh("%s -k 7 -L -s inter.fq | cat" % COUNT)
+        assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+        ka, ca, ra = _decode_reads_stream(a.stdout)
+        kb, cb, rb = _decode_reads_stream(b.stdout)
+        assert (ka, ca) == (kb, cb) == (7, 0) and len(ra) == 2 * n and ra == rb, block
+        bad = sh("set -o pipefail; %s -k 7 -L -p a_1.fq short_2.fq | cat > /dev/null" % COUNT)
+        assert bad.returncode != 0 and b"different numbers of reads" in bad.stderr
