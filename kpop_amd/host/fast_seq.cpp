@@ -236,13 +236,18 @@ bool FastSeqReader::next(FlatBatch &out, size_t block_bytes, unsigned threads) {
     if (out.size() == 0) return next(out, block_bytes, threads);  // a block of blank lines
     return true;
   }
-  // FASTQ: four lines per record, taken in order (a '@' can also start a quality line, so records cannot be found
-  // from the middle of a block)
+  // FASTQ: four lines per record.  A '@' can also start a quality line, so record starts cannot be found from the middle
+  // of a block: one sequential pass finds the lines of every whole record (and raises what the line-by-line reader
+  // raises, in its order), then the threads lint the sequences and copy the names, as for FASTA.
+  struct Rec {
+    size_t tag_b, tag_e, seq_b, seq_e;
+  };
   for (;;) {
     I.fill(target);
     if (I.len == 0) return false;
     const char *b = I.buf.data(), *e = b + I.len, *p = b;
-    out.bases.reserve(I.len / 2);
+    std::vector<Rec> recs;
+    recs.reserve(I.len / 200 + 16);
     size_t done = 0;
     for (;;) {
       const char *q = p;
@@ -278,15 +283,63 @@ bool FastSeqReader::next(FlatBatch &out, size_t block_bytes, unsigned threads) {
       if (*line[0] != '@') throw Error("FASTQ file '" + I.path + "': expected '@' at the start of a record");
       if (lend[2] == line[2] || *line[2] != '+')
         throw Error("FASTQ file '" + I.path + "': truncated record '" + std::string(line[0] + 1, lend[0]) + "'");
-      out.tags.insert(out.tags.end(), line[0] + 1, lend[0]);
-      out.tag_lens.push_back((uint32_t)(lend[0] - (line[0] + 1)));
-      const size_t start = out.bases.size();
-      lint_line(line[1], lend[1], out.bases);
-      out.lens.push_back((uint32_t)(out.bases.size() - start));
+      recs.push_back({(size_t)(line[0] + 1 - b), (size_t)(lend[0] - b), (size_t)(line[1] - b), (size_t)(lend[1] - b)});
       p = q;
       done = (size_t)(p - b);
     }
-    if (out.size() > 0 || I.eof) {
+    if (!recs.empty() || I.eof) {
+      const size_t n = recs.size();
+      const unsigned T = n ? seq_threads(threads, done) : 1;
+      std::vector<FlatBatch> part(T);
+      std::vector<std::string> err(T);
+      auto work = [&](unsigned t) {
+        try {
+          FlatBatch &o = part[t];
+          const size_t lo = n * t / T, hi = n * (t + 1) / T;
+          if (hi > lo) o.bases.reserve(recs[hi - 1].seq_e - recs[lo].seq_b);
+          for (size_t r = lo; r < hi; ++r) {
+            const Rec &R = recs[r];
+            o.tags.insert(o.tags.end(), b + R.tag_b, b + R.tag_e);
+            o.tag_lens.push_back((uint32_t)(R.tag_e - R.tag_b));
+            const size_t start = o.bases.size();
+            lint_line(b + R.seq_b, b + R.seq_e, o.bases);
+            o.lens.push_back((uint32_t)(o.bases.size() - start));
+          }
+        } catch (const std::exception &ex) {
+          err[t] = ex.what();
+        }
+      };
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < T; ++t) pool.emplace_back(work, t);
+      work(0);
+      for (std::thread &th : pool) th.join();
+      for (unsigned t = 0; t < T; ++t)
+        if (!err[t].empty()) throw Error(err[t]);
+      if (T == 1) out = std::move(part[0]);
+      else {
+        size_t nb = 0, nr = 0, nt = 0;
+        for (const FlatBatch &q : part) {
+          nb += q.bases.size();
+          nr += q.lens.size();
+          nt += q.tags.size();
+        }
+        out.bases.resize(nb);
+        out.lens.resize(nr);
+        out.tags.resize(nt);
+        out.tag_lens.resize(nr);
+        nb = nr = nt = 0;
+        for (const FlatBatch &q : part) {
+          if (!q.bases.empty()) memcpy(out.bases.data() + nb, q.bases.data(), q.bases.size());
+          if (!q.lens.empty()) {
+            memcpy(out.lens.data() + nr, q.lens.data(), q.lens.size() * 4);
+            memcpy(out.tag_lens.data() + nr, q.tag_lens.data(), q.tag_lens.size() * 4);
+          }
+          if (!q.tags.empty()) memcpy(out.tags.data() + nt, q.tags.data(), q.tags.size());
+          nb += q.bases.size();
+          nr += q.lens.size();
+          nt += q.tags.size();
+        }
+      }
       I.consume(done);
       if (out.size() == 0) {
         if (I.len == 0 || I.eof) return false;
