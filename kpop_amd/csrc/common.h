@@ -71,6 +71,7 @@ struct Context {
   int tune_unroll = 8;
   int tune_nt = 2;       // row loads: 0 plain, 1 non-temporal, 2 by the size of the twister (count_twist.hip)
   int tune_seg = 0;      // windows per segment of the genome kernel, 0 = sized to the L2
+  int tune_ldspad = 0;   // extra dynamic LDS per block of the fused reads kernel: fewer resident blocks (an occupancy probe)
   int tune_dbg = 0;      // development probes (count_wave_kernel: 1 = no look-back, 2 = no ticket); results are WRONG when set
   int tune_dense = 0;    // kpop_twist: 0 sparse mat-vec (the reference's order), 1 dense contraction on the matrix cores, 2 by density
   int tune_blocksort = 1;  // -L on sequences of up to 32,768 windows: one block per sequence, sorted in LDS (0: device-wide sort)

@@ -544,10 +544,10 @@ static int launch_count_twist_wave_v(int R, const TwisterView &tv, const uint8_t
                                      hipStream_t st) {
   dim3 grid(div_up(n, kWavesPerBlock)), block(64 * kWavesPerBlock);
   switch (R) {
-    case 1: count_twist_wave_kernel<1, H, U, NT><<<grid, block, 0, st>>>(tv, bases, offsets, ids, n, content, normalize, out); break;
-    case 2: count_twist_wave_kernel<2, H, U, NT><<<grid, block, 0, st>>>(tv, bases, offsets, ids, n, content, normalize, out); break;
-    case 4: count_twist_wave_kernel<4, H, U, NT><<<grid, block, 0, st>>>(tv, bases, offsets, ids, n, content, normalize, out); break;
-    case 8: count_twist_wave_kernel<8, H, U, NT><<<grid, block, 0, st>>>(tv, bases, offsets, ids, n, content, normalize, out); break;
+    case 1: count_twist_wave_kernel<1, H, U, NT><<<grid, block, (size_t)ctx().tune_ldspad, st>>>(tv, bases, offsets, ids, n, content, normalize, out); break;
+    case 2: count_twist_wave_kernel<2, H, U, NT><<<grid, block, (size_t)ctx().tune_ldspad, st>>>(tv, bases, offsets, ids, n, content, normalize, out); break;
+    case 4: count_twist_wave_kernel<4, H, U, NT><<<grid, block, (size_t)ctx().tune_ldspad, st>>>(tv, bases, offsets, ids, n, content, normalize, out); break;
+    case 8: count_twist_wave_kernel<8, H, U, NT><<<grid, block, (size_t)ctx().tune_ldspad, st>>>(tv, bases, offsets, ids, n, content, normalize, out); break;
     default: KPOP_FAIL(KPOP_ERR_INVALID, "launch_count_twist_wave: R=%d", R);
   }
   KPOP_LAUNCH_CHECK();

@@ -53,14 +53,19 @@ def main():
             done_dist[b] = torch.cuda.Event()
             done_dist[b].record(s1)
 
-    for name, fn in (("sequential", sequential), ("two streams", pipelined), ("sequential", sequential), ("two streams", pipelined)):
-        fn(5)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        fn(40)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 40 * 1e3
-        print("%-12s %.4f ms per step  (%.1f M sequences/s)" % (name, ms, n / ms / 1e3))
+    # "ldspad": extra dynamic LDS per block of the fused kernel, i.e. fewer of its blocks per CU (17.6 KB each: 8 fit 160 KB),
+    # which leaves LDS and wave slots for the distance kernel's blocks (50 KB each) on the second stream
+    for pad in (0, 6144, 10240, 16384):
+        api.tune("ldspad", pad)
+        for name, fn in (("sequential", sequential), ("two streams", pipelined), ("sequential", sequential), ("two streams", pipelined)):
+            fn(5)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn(40)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 40 * 1e3
+            print("ldspad %5d  %-12s %.4f ms per step  (%.1f M sequences/s)" % (pad, name, ms, n / ms / 1e3), flush=True)
+    api.tune("ldspad", 0)
     a, b = dmat[0].clone(), dmat[1].clone()
     sequential(1)
     torch.cuda.synchronize()
