@@ -73,7 +73,8 @@ int kpop_synchronize(void *stream);
    twister (default); "seg" windows per segment of the genome kernel, 0 = sized to an XCD's L2 (default); "hist" 1 (default) | 0: the
    merged spectrum of kpop_count_reads(per_read = 0) by atomic histogram where the hashes fit 26 bits, or always by sort;
    "dense" 0 (default) | 1 | 2: kpop_twist by the sparse mat-vec, by the dense contraction on the f64 matrix cores, or
-   by the batch's density -- the one knob that changes results, in the last bits (kpop_dev_twist_dense)              */
+   by the batch's density -- the one knob that changes results, in the last bits (kpop_dev_twist_dense); "ldspad" bytes of
+   extra LDS per block of the fused reads kernel (an occupancy probe); "dbg" development switches (also KPOP_TUNE_DBG)  */
 int kpop_tune(const char *key, int value);
 
 /* plain device-memory helpers so a non-HIP host language can stage buffers */
