@@ -201,18 +201,32 @@ struct TwisterReg {
   void upload() {
     if (dev) return;
     need_matrix();
+    stage_mark("KPopTwistDB", "  twister matrix in memory");
     need_gpu();
+    stage_mark("KPopTwistDB", "  HIP runtime up");
     const size_t n = twister.cols();
     std::vector<uint64_t> col_hash(n);
     name_len = n ? twister.col_names[0].size() : 0;
-    for (size_t c = 0; c < n; ++c) {
-      const std::string &nm = twister.col_names[c];
-      if (nm.size() != name_len || !hex_to_hash(nm, &col_hash[c]))
-        throw Error("twister column '" + nm + "' is not a fixed-width hexadecimal k-mer hash (only DNA spectra produced by KPopCount are on the HIP path)");
-    }
+    std::atomic<size_t> bad{n};  // the first column whose name is not a hash (millions of names: the host threads convert them)
+    parallel_for(n, 65536, [&](size_t lo, size_t hi) {
+      for (size_t c = lo; c < hi; ++c) {
+        const std::string &nm = twister.col_names[c];
+        if (nm.size() != name_len || !hex_to_hash(nm, &col_hash[c])) {
+          size_t seen = bad.load();
+          while (c < seen && !bad.compare_exchange_weak(seen, c)) {
+          }
+          return;
+        }
+      }
+    });
+    if (bad.load() < n)
+      throw Error("twister column '" + twister.col_names[bad.load()] +
+                  "' is not a fixed-width hexadecimal k-mer hash (only DNA spectra produced by KPopCount are on the HIP path)");
     const int k = (int)std::min<size_t>(2 * name_len, 30);  // names carry ceil(k/2) hex digits; the larger k covers both
     if (name_len > 15) throw Error("k-mer names longer than 15 hex digits");
+    stage_mark("KPopTwistDB", "  column names to hashes");
     check(kpop_twister_load(twister.data.data(), n, (uint32_t)twister.rows(), col_hash.data(), std::max(k, 1), &dev));
+    stage_mark("KPopTwistDB", "  twister on the device");
   }
 };
 
