@@ -38,7 +38,15 @@ __global__ __launch_bounds__(256) void ca_col_partial_kernel(const double *__res
   for (uint32_t j = threadIdx.x; j < J; j += 256) {
     const double w = col_scale ? col_scale[j] : 1.0;
     double s = 0.0;
-    for (uint64_t i = i0; i < i1; ++i) s += N[i * J + j] * w;
+    uint64_t i = i0;
+    for (; i + 8 <= i1; i += 8) {  // eight loads in flight, added in row order (one at a time ran at 1.2 TB/s)
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = N[(i + u) * J + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u] * w;
+    }
+    for (; i < i1; ++i) s += N[i * J + j] * w;
     partial[(uint64_t)blockIdx.x * J + j] = s;
   }
 }
