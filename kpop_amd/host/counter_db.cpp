@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
+#include <fcntl.h>
 
 #include <algorithm>
 #include <map>
@@ -215,11 +217,9 @@ bool CounterDB::hex_key(const char *s, size_t n, uint64_t *key) {
 uint32_t CounterDB::row_of(const char *name, size_t len) {
   uint64_t key;
   if (hex_key(name, len, &key)) {
-    auto it = hex_row_idx_.find(key);
-    if (it != hex_row_idx_.end()) return it->second;
-    const uint32_t row = (uint32_t)core.row_names.size();
-    hex_row_idx_.emplace(key, row);
-    core.row_names.emplace_back(name, len);
+    bool added;
+    const uint32_t row = hex_row_idx_.find_or_add(key, (uint32_t)core.row_names.size(), &added);
+    if (added) core.row_names.emplace_back(name, len);
     return row;
   }
   std::string nm(name, len);
@@ -241,7 +241,7 @@ void CounterDB::rebuild_indices() {  // invert_table, lib/KMerDB.ml:371-374 (Has
   for (size_t i = 0; i < core.row_names.size(); ++i) {
     const std::string &nm = core.row_names[i];
     uint64_t key;
-    if (hex_key(nm.data(), nm.size(), &key)) hex_row_idx_[key] = (uint32_t)i;
+    if (hex_key(nm.data(), nm.size(), &key)) hex_row_idx_.set(key, (uint32_t)i);
     else row_idx_[nm] = (uint32_t)i;
   }
   for (size_t i = 0; i < core.meta_names.size(); ++i) meta_idx_[core.meta_names[i]] = (uint32_t)i;
@@ -305,16 +305,23 @@ void CounterDB::add_meta(const std::string &fname) {
   }
 }
 
-void CounterDB::add_files(const std::vector<std::string> &prefixes) {
-  for (const std::string &prefix : prefixes) {
-    const std::string fname = make_filename(prefix, "KPopSpectra", true);
-    Lines in(fname);
-    char *line;
-    size_t len;
-    uint64_t line_num = 0;
-    uint32_t col = 0;
-    uint64_t n_spectra = 0;
-    while (in.next(&line, &len)) {
+// One file of spectra (lib/KMerDB.ml:505-575), a block at a time (blocks end where a spectrum ends, kpop_text.h).  A block whose
+// every line is what KPopCount writes -- a fixed number of lowercase hexadecimal digits, a tab, a decimal count -- is parsed by
+// the host threads into (hash, count) arrays and entered from there; any other block goes line by line, as the whole file used
+// to (30 M lines of a thousand genomes: 4.2 s).  Rows are still numbered in the order in which their names first appear.
+void CounterDB::add_spectra_text(int fd, const std::string &fname) {
+  SpectraTextStream ts(fd, nullptr, 0);
+  TextBlock block;
+  uint64_t line_num = 0, n_spectra = 0;
+  uint32_t col = 0;
+  bool first_block = true;
+  size_t name_len = 0;
+  auto line_by_line = [&](const char *b, const char *e) {
+    while (b < e) {
+      const char *nl = (const char *)memchr(b, '\n', (size_t)(e - b));
+      const char *line = b;
+      const size_t len = (size_t)((nl ? nl : e) - b);
+      b = nl ? nl + 1 : e;
       ++line_num;
       const char *tab = (const char *)memchr(line, '\t', len);
       if (!tab || memchr(tab + 1, '\t', (size_t)(line + len - tab - 1))) {
@@ -338,9 +345,82 @@ void CounterDB::add_files(const std::vector<std::string> &prefixes) {
       if (s.size() <= row) s.resize(std::max<size_t>(row + 1, s.size() + s.size() / 2), 0);
       s[row] = (int32_t)((uint32_t)s[row] + (uint32_t)v);  // repeated k-mers accumulate (:561-562)
     }
-    if (verbose)
-      fprintf(stderr, "(KPopCountDB): File '%s': Read %llu spectra on %llu lines.\n", fname.c_str(), (unsigned long long)n_spectra,
-              (unsigned long long)line_num);
+  };
+  while (ts.next(block)) {
+    const char *b = block.data(), *e = b + block.size();
+    if (first_block) {  // the width of the names, from the first line that is not a header
+      for (const char *p = b; p < e;) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+        const char *le = nl ? nl : e;
+        if (le > p && *p != '\t') {
+          const char *tab = (const char *)memchr(p, '\t', (size_t)(le - p));
+          uint64_t key;
+          if (tab && hex_key(p, (size_t)(tab - p), &key)) name_len = (size_t)(tab - p);
+          break;
+        }
+        if (!nl) break;
+        p = nl + 1;
+      }
+    }
+    bool plain = false;
+    HashedSpectra sp;
+    uint64_t n_lines = 0;
+    static const bool lines_only = getenv("KPOP_COUNTDB_LINES") != nullptr;  // (tests: everything line by line)
+    if (name_len && !lines_only && !(first_block && (b == e || *b != '\t'))) {
+      try {
+        parse_spectra_block(b, block.size(), name_len, ~0ull >> 1, first_block, line_num, sp, &n_lines, 0, &plain);
+      } catch (const std::exception &) {
+        plain = false;  // the line-by-line pass raises it, with the message this tool gives
+      }
+      for (size_t i = 0; plain && i < sp.values.size(); ++i) plain = sp.values[i] <= 2147483647.0;
+    }
+    first_block = false;
+    if (!plain) {
+      line_by_line(b, e);
+      continue;
+    }
+    char name[16];
+    for (size_t s_i = 0; s_i < sp.labels.size(); ++s_i) {
+      col = add_empty_column_if_needed(sp.labels[s_i]);
+      if (core.storage[col].size() < n_rows()) core.storage[col].resize(n_rows(), 0);
+      ++n_spectra;
+      std::vector<int32_t> *s = &core.storage[col];
+      for (uint64_t i = sp.offsets[s_i]; i < sp.offsets[s_i + 1]; ++i) {
+        const uint64_t h = sp.hash[i];
+        bool added;
+        const uint32_t row = hex_row_idx_.find_or_add(((uint64_t)name_len << 60) | h, (uint32_t)core.row_names.size(), &added);
+        if (added) {
+          uint64_t v = h;
+          for (size_t d = name_len; d-- > 0;) {
+            name[d] = "0123456789abcdef"[v & 15];
+            v >>= 4;
+          }
+          core.row_names.emplace_back(name, name_len);
+        }
+        if (s->size() <= row) s->resize(std::max<size_t>(row + 1, s->size() + s->size() / 2), 0);
+        (*s)[row] = (int32_t)((uint32_t)(*s)[row] + (uint32_t)(int32_t)sp.values[i]);  // repeated k-mers accumulate (:561-562)
+      }
+    }
+    line_num += n_lines;
+  }
+  if (verbose)
+    fprintf(stderr, "(KPopCountDB): File '%s': Read %llu spectra on %llu lines.\n", fname.c_str(), (unsigned long long)n_spectra,
+            (unsigned long long)line_num);
+}
+
+void CounterDB::add_files(const std::vector<std::string> &prefixes) {
+  for (const std::string &prefix : prefixes) {
+    const std::string fname = make_filename(prefix, "KPopSpectra", true);
+    const bool is_stdin = fname == "/dev/stdin";
+    const int fd = is_stdin ? 0 : open(fname.c_str(), O_RDONLY);
+    if (fd < 0) throw Error("cannot open '" + fname + "': " + strerror(errno));
+    try {
+      add_spectra_text(fd, fname);
+    } catch (...) {
+      if (!is_stdin) close(fd);
+      throw;
+    }
+    if (!is_stdin) close(fd);
   }
   columns();
 }

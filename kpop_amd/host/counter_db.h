@@ -72,7 +72,66 @@ class CounterDB {
   // k-mer names that are 1..15 lowercase hexadecimal digits (what KPopCount writes) are indexed by (length << 60 | value)
   // instead of by string: one integer hash per spectrum line instead of a string allocation and a string hash.  Every
   // other name lives in row_idx_; a name is in exactly one of the two.
-  std::unordered_map<uint64_t, uint32_t> hex_row_idx_;
+  // (open addressing: a look-up per spectrum line, tens of millions of them for a thousand genomes)
+  struct HexIndex {
+    std::vector<uint64_t> keys;  // 0 = empty slot (a key is never 0: the length sits in its top bits)
+    std::vector<uint32_t> rows;
+    size_t used = 0;
+    void clear() {
+      keys.clear();
+      rows.clear();
+      used = 0;
+    }
+    void reserve(size_t n) {
+      size_t cap = 64;
+      while (cap < 2 * n + 2) cap <<= 1;
+      if (cap > keys.size()) rehash(cap);
+    }
+    static size_t slot_of(uint64_t k, size_t mask) { return (size_t)((k * 0x9E3779B97F4A7C15ull) >> 20) & mask; }
+    void rehash(size_t cap) {
+      std::vector<uint64_t> ok;
+      std::vector<uint32_t> orow;
+      ok.swap(keys);
+      orow.swap(rows);
+      keys.assign(cap, 0);
+      rows.assign(cap, 0);
+      const size_t mask = cap - 1;
+      for (size_t i = 0; i < ok.size(); ++i)
+        if (ok[i]) {
+          size_t s = slot_of(ok[i], mask);
+          while (keys[s]) s = (s + 1) & mask;
+          keys[s] = ok[i];
+          rows[s] = orow[i];
+        }
+    }
+    // the row of `key`, or, when it is new, `next_row` entered under it (and *added set)
+    uint32_t find_or_add(uint64_t key, uint32_t next_row, bool *added) {
+      if (2 * (used + 1) > keys.size()) rehash(keys.empty() ? 64 : keys.size() * 2);
+      const size_t mask = keys.size() - 1;
+      size_t s = slot_of(key, mask);
+      while (keys[s] && keys[s] != key) s = (s + 1) & mask;
+      if (keys[s]) {
+        *added = false;
+        return rows[s];
+      }
+      keys[s] = key;
+      rows[s] = next_row;
+      ++used;
+      *added = true;
+      return next_row;
+    }
+    void set(uint64_t key, uint32_t row) {  // Hashtbl.add: the last one entered under a name is the one found
+      bool added;
+      (void)find_or_add(key, row, &added);
+      if (!added) {
+        const size_t mask = keys.size() - 1;
+        size_t s = slot_of(key, mask);
+        while (keys[s] != key) s = (s + 1) & mask;
+        rows[s] = row;
+      }
+    }
+  } hex_row_idx_;
+  void add_spectra_text(int fd, const std::string &fname);  // one file of add_files
   static bool hex_key(const char *s, size_t n, uint64_t *key);
   uint32_t row_of(const char *name, size_t len);  // the row of a k-mer name, appended if new
   void rebuild_indices();

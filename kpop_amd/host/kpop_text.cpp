@@ -435,6 +435,7 @@ struct ChunkResult {
   std::string error;
   bool first_line_is_header = true;
   std::string first_line;
+  bool plain = true;  // every data line was name_len LOWERCASE hexadecimal digits, a tab, 1-15 decimal digits, a newline; no CR anywhere
 };
 
 struct HexTable {
@@ -458,12 +459,14 @@ void parse_chunk(const char *s, const char *e, size_t name_len, uint64_t absent,
     // below, which gives the same answer for these too.
     if (fast_names && r.n_lines > 0 && (size_t)(e - s) >= name_len + 3 && s[name_len] == '\t') {
       uint64_t v = 0;
-      unsigned bad = 0;
+      unsigned bad = 0, upper = 0;
       for (size_t i = 0; i < name_len; ++i) {
         const uint8_t d = kHex.v[(uint8_t)s[i]];
         bad |= d;
+        upper |= (unsigned)((uint8_t)(s[i] - 'A') < 6u);
         v = (v << 4) | (uint64_t)(d & 15);
       }
+      if (upper) r.plain = false;
       if (!(bad & 0x80)) {
         const char *p = s + name_len + 1;
         uint64_t iv = 0;
@@ -485,7 +488,11 @@ void parse_chunk(const char *s, const char *e, size_t name_len, uint64_t absent,
     const char *nl = (const char *)memchr(s, '\n', (size_t)(e - s));
     const char *le = nl ? nl : e;
     const char *next = nl ? nl + 1 : e;
-    if (le > s && le[-1] == '\r') --le;
+    if (le > s && le[-1] == '\r') {
+      --le;
+      r.plain = false;
+    }
+    if (!nl) r.plain = false;  // (a last line without its newline)
     ++r.n_lines;
     const char *tab = (const char *)memchr(s, '\t', (size_t)(le - s));
     if (!tab || memchr(tab + 1, '\t', (size_t)(le - tab - 1))) {  // lib/Twister.ml:103-104
@@ -510,6 +517,15 @@ void parse_chunk(const char *s, const char *e, size_t name_len, uint64_t absent,
         return;
       }
     } else {
+      // (a data line here was not the plain form, except a chunk's first line, which always comes this way: checked below)
+      bool plain_line = (size_t)(tab - s) == name_len && name_len >= 1 && name_len <= 16;
+      for (const char *q = s; plain_line && q < tab; ++q) plain_line = (*q >= '0' && *q <= '9') || (*q >= 'a' && *q <= 'f');
+      {
+        const size_t vl0 = (size_t)(le - (tab + 1));
+        plain_line = plain_line && vl0 >= 1 && vl0 <= 15;
+        for (const char *q = tab + 1; plain_line && q < le; ++q) plain_line = *q >= '0' && *q <= '9';
+      }
+      if (!plain_line) r.plain = false;
       uint64_t h = absent;
       if ((size_t)(tab - s) == name_len && name_len <= 16) {
         uint64_t v = 0;
@@ -554,7 +570,7 @@ void parse_chunk(const char *s, const char *e, size_t name_len, uint64_t absent,
 }  // namespace
 
 static void parse_spectra_buffer(const char *base, size_t size, size_t name_len, uint64_t absent, HashedSpectra &out, unsigned threads,
-                                 bool first_block = true, uint64_t lines_before = 0, uint64_t *n_lines = nullptr);
+                                 bool first_block = true, uint64_t lines_before = 0, uint64_t *n_lines = nullptr, bool *plain = nullptr);
 
 void read_spectra_hashed(const std::string &path, size_t name_len, uint64_t absent, HashedSpectra &out, unsigned threads) {
   const std::vector<char> buf = slurp(path);
@@ -585,7 +601,7 @@ void read_spectra_hashed_fd(int fd, const char *head, size_t head_len, size_t na
 }
 
 static void parse_spectra_buffer(const char *base, size_t size, size_t name_len, uint64_t absent, HashedSpectra &out, unsigned threads,
-                                 bool first_block, uint64_t lines_before_block, uint64_t *n_lines) {
+                                 bool first_block, uint64_t lines_before_block, uint64_t *n_lines, bool *plain) {
   const unsigned T = pick_threads(threads, size, 2u << 20);
   std::vector<size_t> cut(T + 1, size);
   cut[0] = 0;
@@ -614,6 +630,10 @@ static void parse_spectra_buffer(const char *base, size_t size, size_t name_len,
     lines_before += r.n_lines;
   }
   if (n_lines) *n_lines = lines_before - lines_before_block;
+  if (plain) {
+    *plain = true;
+    for (const ChunkResult &r : res) *plain = *plain && r.plain;
+  }
   size_t total = out.hash.size();
   for (const ChunkResult &r : res) total += r.hash.size();
   const size_t start = out.hash.size();
@@ -642,13 +662,14 @@ static void parse_spectra_buffer(const char *base, size_t size, size_t name_len,
 }
 
 void parse_spectra_block(const char *data, size_t size, size_t name_len, uint64_t absent, bool first_block, uint64_t lines_before,
-                         HashedSpectra &out, uint64_t *n_lines, unsigned threads) {
+                         HashedSpectra &out, uint64_t *n_lines, unsigned threads, bool *plain) {
   out = HashedSpectra();
-  parse_spectra_buffer(data, size, name_len, absent, out, threads, first_block, lines_before, n_lines);
+  parse_spectra_buffer(data, size, name_len, absent, out, threads, first_block, lines_before, n_lines, plain);
 }
 
 SpectraTextStream::SpectraTextStream(int fd, const char *head, size_t head_len, size_t block_bytes)
     : fd_(fd), block_bytes_(std::max<size_t>(block_bytes, 2)) {
+  if (const char *e = getenv("KPOP_TEXT_BLOCK")) block_bytes_ = (size_t)std::max(2, atoi(e));  // tests: many small blocks
   if (head_len) carry_.assign(head, head + head_len);
 }
 

@@ -153,7 +153,9 @@ class SpectraTextStream {
 // (Header_expected otherwise); lines_before: the lines of the blocks before this one, for the line numbers of
 // Wrong_number_of_columns; *n_lines receives this block's.  The same errors, in the same order, as the whole-file parser.
 void parse_spectra_block(const char *data, size_t size, size_t name_len, uint64_t absent, bool first_block, uint64_t lines_before,
-                         HashedSpectra &out, uint64_t *n_lines, unsigned threads = 0);
+                         HashedSpectra &out, uint64_t *n_lines, unsigned threads = 0, bool *plain = nullptr);
+// *plain: every data line of the block was name_len LOWERCASE hexadecimal digits, a tab, 1-15 decimal digits and a newline, and
+// no line carried a CR -- what KPopCount writes; KPopCountDB takes such blocks through this parser and the others line by line.
 
 // "\t<label>\n" + "<hex>\t<count>\n"... for reads [0, n) of a CSR result, formatted by several threads and written in
 // order (bin/KPopCount.ml:44-46).  labels must already be checked.

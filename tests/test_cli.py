@@ -407,3 +407,37 @@ def test_paired_end_through_the_block_reader(tmp_path):
         assert (ka, ca) == (kb, cb) == (7, 0) and len(ra) == 2 * n and ra == rb, block
         bad = sh("set -o pipefail; %s -k 7 -L -p a_1.fq short_2.fq | cat > /dev/null" % COUNT)
         assert bad.returncode != 0 and b"different numbers of reads" in bad.stderr
+
+
+def test_countdb_block_parser_equals_line_parser(tmp_path):
+    """KPopCountDB -k reads spectra a block at a time; blocks whose lines are all what KPopCount writes go through the threaded
+    parser, the others line by line.  Whatever the block size and the thread count -- one block of everything (the old
+    behaviour for small files), blocks of a spectrum or two, blocks cut so that plain and odd blocks alternate -- the database
+    written is the same file, or the same error is raised (lib/KMerDB.ml:505-575)."""
+    import random
+    rng = random.Random(21)
+    base = "".join("\tg%d\n" % i + "".join("%06x\t%d\n" % (rng.randrange(3000), rng.randrange(1, 500)) for _ in range(rng.randrange(0, 40)))
+                   for i in range(30))
+    oddities = ["\t", "\n", "\"", "x", "A", "-", "0x1F\n", "\r", "", "\t\t", "1_0", " ", "99999999999\n", "\tg3\n", "+5\n"]
+    for it in range(60):
+        s = list(base)
+        for _ in range(rng.randrange(0, 5) if it else 0):
+            s[rng.randrange(len(s))] = rng.choice(oddities)
+        data = "".join(s)
+        if it % 7 == 3:
+            data = data.rstrip("\n")
+        if it % 11 == 5:
+            data = "abcdef\t1\n" + data
+        (tmp_path / "in.KPopSpectra.txt").write_text(data)
+        results = []
+        for block, threads in (("lines", "1"), ("100000000", "1"), ("64", "4"), ("700", "3"), ("5000", "8")):
+            env = dict(os.environ, KPOP_TEXT_BLOCK=block, KPOP_HOST_THREADS=threads, KPOP_HOST_CHUNK="50")
+            if block == "lines":  # the reference: every line through the line parser
+                env = dict(os.environ, KPOP_COUNTDB_LINES="1")
+            out = tmp_path / ("db_%s" % block)
+            r = subprocess.run([COUNTDB, "-k", str(tmp_path / "in"), "-o", str(out)], capture_output=True, text=True, errors="replace", env=env)
+            db = (tmp_path / ("db_%s.KPopCounter" % block))
+            results.append((r.returncode, r.stderr.strip().splitlines()[-1:] if r.returncode else [], db.read_bytes() if r.returncode == 0 else b""))
+            if db.exists():
+                db.unlink()
+        assert all(x == results[0] for x in results[1:]), (it, [(a, b, len(c)) for a, b, c in results])
