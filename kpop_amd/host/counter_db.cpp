@@ -9,6 +9,7 @@
 #include <fcntl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <regex>
 
@@ -260,10 +261,13 @@ uint32_t CounterDB::add_empty_column_if_needed(const std::string &label) {
 
 std::vector<const int32_t *> CounterDB::columns() {
   std::vector<const int32_t *> out(n_cols());
-  for (size_t c = 0; c < n_cols(); ++c) {
-    if (core.storage[c].size() != n_rows()) core.storage[c].resize(n_rows(), 0);
-    out[c] = core.storage[c].data();
-  }
+  const size_t nr = n_rows();
+  parallel_for(n_cols(), 1, [&](size_t lo, size_t hi) {  // (a thousand spectra to pad: a reallocation and a copy each)
+    for (size_t c = lo; c < hi; ++c) {
+      if (core.storage[c].size() != nr) core.storage[c].resize(nr, 0);
+      out[c] = core.storage[c].data();
+    }
+  });
   return out;
 }
 
@@ -312,6 +316,15 @@ void CounterDB::add_meta(const std::string &fname) {
 void CounterDB::add_spectra_text(int fd, const std::string &fname) {
   SpectraTextStream ts(fd, nullptr, 0);
   TextBlock block;
+  const bool timing = getenv("KPOP_TIMING") != nullptr;
+  double t_phase[6] = {0, 0, 0, 0, 0, 0};  // read, parse, look-ups, new rows, columns, line by line
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto lap = [&](int which, std::chrono::steady_clock::time_point &t0) {
+    const auto t1 = now();
+    t_phase[which] += std::chrono::duration<double>(t1 - t0).count();
+    t0 = t1;
+  };
+  auto t0 = now();
   uint64_t line_num = 0, n_spectra = 0;
   uint32_t col = 0;
   bool first_block = true;
@@ -347,6 +360,7 @@ void CounterDB::add_spectra_text(int fd, const std::string &fname) {
     }
   };
   while (ts.next(block)) {
+    lap(0, t0);
     const char *b = block.data(), *e = b + block.size();
     if (first_block) {  // the width of the names, from the first line that is not a header
       for (const char *p = b; p < e;) {
@@ -375,34 +389,66 @@ void CounterDB::add_spectra_text(int fd, const std::string &fname) {
       for (size_t i = 0; plain && i < sp.values.size(); ++i) plain = sp.values[i] <= 2147483647.0;
     }
     first_block = false;
+    lap(1, t0);
     if (!plain) {
       line_by_line(b, e);
+      lap(5, t0);
       continue;
     }
+    // rows of the k-mers this database knows already, looked up by the host threads; the new ones entered one by one in the
+    // order of their first appearance (what numbers the rows); then every spectrum adds its counts into its own column
+    const size_t n_lines_data = sp.hash.size();
+    const uint64_t tag = (uint64_t)name_len << 60;
+    std::vector<uint32_t> row(n_lines_data);
+    parallel_for(n_lines_data, 65536, [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i) row[i] = hex_row_idx_.find(tag | sp.hash[i]);
+    });
+    lap(2, t0);
     char name[16];
-    for (size_t s_i = 0; s_i < sp.labels.size(); ++s_i) {
-      col = add_empty_column_if_needed(sp.labels[s_i]);
-      if (core.storage[col].size() < n_rows()) core.storage[col].resize(n_rows(), 0);
-      ++n_spectra;
-      std::vector<int32_t> *s = &core.storage[col];
-      for (uint64_t i = sp.offsets[s_i]; i < sp.offsets[s_i + 1]; ++i) {
-        const uint64_t h = sp.hash[i];
+    for (size_t i = 0; i < n_lines_data; ++i)
+      if (row[i] == HexIndex::kNone) {
         bool added;
-        const uint32_t row = hex_row_idx_.find_or_add(((uint64_t)name_len << 60) | h, (uint32_t)core.row_names.size(), &added);
+        row[i] = hex_row_idx_.find_or_add(tag | sp.hash[i], (uint32_t)core.row_names.size(), &added);
         if (added) {
-          uint64_t v = h;
+          uint64_t v = sp.hash[i];
           for (size_t d = name_len; d-- > 0;) {
             name[d] = "0123456789abcdef"[v & 15];
             v >>= 4;
           }
           core.row_names.emplace_back(name, name_len);
         }
-        if (s->size() <= row) s->resize(std::max<size_t>(row + 1, s->size() + s->size() / 2), 0);
-        (*s)[row] = (int32_t)((uint32_t)(*s)[row] + (uint32_t)(int32_t)sp.values[i]);  // repeated k-mers accumulate (:561-562)
       }
+    lap(3, t0);
+    std::vector<uint32_t> col_of(sp.labels.size());
+    bool distinct = true;  // (a label that comes twice in a block shares a column: then the spectra are entered in order)
+    {
+      std::vector<uint32_t> seen;
+      for (size_t s_i = 0; s_i < sp.labels.size(); ++s_i) {
+        col_of[s_i] = add_empty_column_if_needed(sp.labels[s_i]);
+        seen.push_back(col_of[s_i]);
+      }
+      std::sort(seen.begin(), seen.end());
+      distinct = std::adjacent_find(seen.begin(), seen.end()) == seen.end();
     }
+    n_spectra += sp.labels.size();
+    if (!sp.labels.empty()) col = col_of.back();
+    const size_t rows_now = n_rows();
+    auto enter = [&](size_t lo, size_t hi) {
+      for (size_t s_i = lo; s_i < hi; ++s_i) {
+        std::vector<int32_t> &s = core.storage[col_of[s_i]];
+        if (s.size() < rows_now) s.resize(rows_now, 0);
+        for (uint64_t i = sp.offsets[s_i]; i < sp.offsets[s_i + 1]; ++i)
+          s[row[i]] = (int32_t)((uint32_t)s[row[i]] + (uint32_t)(int32_t)sp.values[i]);  // repeated k-mers accumulate (:561-562)
+      }
+    };
+    if (distinct) parallel_for(sp.labels.size(), 1, enter);
+    else enter(0, sp.labels.size());
+    lap(4, t0);
     line_num += n_lines;
   }
+  if (timing)
+    fprintf(stderr, "[timing] KPopCountDB:   spectra text: reading %.3f s, parsing %.3f s, look-ups %.3f s, new rows %.3f s, columns %.3f s, line by line %.3f s\n",
+            t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_phase[4], t_phase[5]);
   if (verbose)
     fprintf(stderr, "(KPopCountDB): File '%s': Read %llu spectra on %llu lines.\n", fname.c_str(), (unsigned long long)n_spectra,
             (unsigned long long)line_num);

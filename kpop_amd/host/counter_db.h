@@ -120,6 +120,14 @@ class CounterDB {
       *added = true;
       return next_row;
     }
+    static constexpr uint32_t kNone = 0xFFFFFFFFu;
+    uint32_t find(uint64_t key) const {  // (read-only: safe from several threads while nobody adds)
+      if (keys.empty()) return kNone;
+      const size_t mask = keys.size() - 1;
+      size_t s = slot_of(key, mask);
+      while (keys[s] && keys[s] != key) s = (s + 1) & mask;
+      return keys[s] ? rows[s] : kNone;
+    }
     void set(uint64_t key, uint32_t row) {  // Hashtbl.add: the last one entered under a name is the one found
       bool added;
       (void)find_or_add(key, row, &added);
