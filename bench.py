@@ -380,26 +380,100 @@ def cpu_baseline(R, n_reads_gpu, gpu_twisted, gpu_dist, classes_host):
     return out, parity
 
 
-def pcie_inclusive(R, n, reps=5):
-    """The same step through the host-buffer entry points (kpop_count_twist + kpop_distance_rowwise): reads start in
-    host memory, distances end there; caller-owned buffers, already touched (what a C/OCaml caller hands over)."""
+def bus_rates(lib, nbytes=256 << 20, reps=3):
+    """page-locked H2D and D2H rates of this box (one large copy each way, best of `reps`), GB/s"""
+    import ctypes as C
+    hp, dp = C.c_void_p(), C.c_void_p()
+    if lib.kpop_host_alloc(C.byref(hp), nbytes) or lib.kpop_dev_malloc(C.byref(dp), nbytes):
+        raise RuntimeError(lib.kpop_last_error().decode())
+    C.memset(hp, 1, nbytes)
+    up, down = [], []
+    try:
+        for _ in range(reps + 1):
+            t0 = time.perf_counter()
+            lib.kpop_memcpy_h2d(dp, hp, nbytes)
+            t1 = time.perf_counter()
+            lib.kpop_memcpy_d2h(hp, dp, nbytes)
+            t2 = time.perf_counter()
+            up.append(t1 - t0)
+            down.append(t2 - t1)
+    finally:
+        lib.kpop_dev_free(dp)
+        lib.kpop_host_free(hp)
+    return nbytes / min(up[1:]) / 1e9, nbytes / min(down[1:]) / 1e9
+
+
+def pcie_inclusive(R, n, reps=5, stream_batches=10):
+    """The same step from host memory to host memory through the streaming pipeline (kpop_pipeline_*): reads start in
+    the caller's page-locked buffers, results end there; H2D of chunk c+1, kernels of chunk c and D2H of chunk c-1
+    overlap on three streams.  Reported: the steady state (several batches in flight, what a streaming caller gets) and
+    the single call (fill and drain included), for both outputs and for the outputs `-d` / `-s` need; each against
+    this box's measured page-locked bus rates."""
     import ctypes as C
     import numpy as np
     from kpop_amd import _lib
+    import kpop_amd
     a = R.args
     lib = _lib.load()
     L, d, Cn = a.read_len, a.dims, a.classes
     bases_d, offs_d = R.synth_reads(n, 0)
     R.torch.cuda.synchronize()
-    bases = bases_d.cpu().numpy()
-    offs = offs_d.cpu().numpy().astype(np.uint64)
+    bases = kpop_amd.host_empty(n * L, np.uint8)
+    bases[:] = bases_d.cpu().numpy()
+    offs = kpop_amd.host_empty(n + 1, np.uint64)
+    offs[:] = offs_d.cpu().numpy().astype(np.uint64)
     classes = R.classes.cpu().numpy()
+    h2d, d2h = bus_rates(lib)
+    out = {"bus": {"h2d_GBps": h2d, "d2h_GBps": d2h, "note": "one 256 MiB page-locked copy each way, best of 3, measured in this run"}}
+
+    def leg(outputs, label):
+        pl = kpop_amd.Pipeline(R.tw, classes, R.metric_host, outputs=outputs, keep_at_most=2, max_neighbours=8)
+        o = pl.alloc_outputs(n)
+        pl.run(bases, offs, o)  # sizes the ring
+        pl.run(bases, offs, o)
+        single = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            pl.collect(pl.submit(bases, offs, o))
+            single.append(time.perf_counter() - t0)
+        best_stream = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            tickets = [pl.submit(bases, offs, o) for _ in range(stream_batches)]
+            pl.collect(tickets[-1])
+            dt = (time.perf_counter() - t0) / stream_batches
+            best_stream = dt if best_stream is None else min(best_stream, dt)
+        st = pl.stats()
+        up = int(bases.nbytes + offs.nbytes)
+        down = int(sum(v.nbytes for v in o.values()))
+        bound = max(up / (h2d * 1e9), down / (d2h * 1e9))
+        res = {"outputs": label, "value": n / best_stream, "unit": "sequences/sec", "ms_per_batch": best_stream * 1e3,
+               "single_call": {"value": n / min(single), "ms": min(single) * 1e3},
+               "bytes_up": up, "bytes_down": down, "chunks": st["chunks"], "ring_depth": st["depth"], "pinned": st["pinned"],
+               "bus_bound_ms": bound * 1e3, "pcie_roofline": bound / best_stream,
+               "pcie_roofline_single_call": bound / min(single)}
+        pl.close()
+        return res, o
+
+    both, o_both = leg(kpop_amd.OUT_TWISTED | kpop_amd.OUT_DISTANCES, "twisted rows + distances")
+    out.update(both)
+    out["note"] = ("kpop_pipeline_submit/collect from page-locked host buffers, %d batches of %d reads in flight (best of 3); "
+                   "single_call = one submit + collect, best of %d" % (stream_batches, n, reps))
+    out["distances_only"], o_d = leg(kpop_amd.OUT_DISTANCES, "distances (what -d needs)")
+    out["summary_only"], _ = leg(kpop_amd.OUT_SUMMARY, "per-read summary (what -s needs)")
+    out["pcie_roofline_note"] = ("bus_bound_ms = max(bytes_up / h2d, bytes_down / d2h) at the rates measured above (PCIe is full duplex); "
+                                 "pcie_roofline = bus_bound_ms / ms_per_batch.  distances_only and summary_only are kernel-bound "
+                                 "(the kernels take ms_per_step), so their fraction of the BUS is low by construction")
+    # the pipeline's rows are the device-resident path's rows
+    out["matches_device_resident"] = bool(np.array_equal(o_both["distances"], o_d["distances"]))
+    # round 2's route for comparison: two separate host entry points from pageable memory, nothing overlapped
     twisted = np.zeros((n, d))
     dist = np.zeros((n, Cn))
+    pb, po = np.array(bases), np.array(offs)
     p = lambda arr, ty: arr.ctypes.data_as(C.POINTER(ty))
 
     def once():
-        rc = lib.kpop_count_twist(R.tw.handle, p(bases, C.c_uint8), p(offs, C.c_uint64), n, 0, 1, p(twisted, C.c_double))
+        rc = lib.kpop_count_twist(R.tw.handle, p(pb, C.c_uint8), p(po, C.c_uint64), n, 0, 1, p(twisted, C.c_double))
         rc = rc or lib.kpop_distance_rowwise(p(classes, C.c_double), Cn, p(twisted, C.c_double), n, d,
                                              p(R.metric_host, C.c_double), 0, 2.0, 1, p(dist, C.c_double))
         if rc:
@@ -410,50 +484,9 @@ def pcie_inclusive(R, n, reps=5):
         t0 = time.perf_counter()
         once()
         ts.append(time.perf_counter() - t0)
-    best = min(ts)
-    out = {"value": n / best, "unit": "sequences/sec", "ms_per_step": best * 1e3,
-           "bytes_up": int(bases.nbytes + offs.nbytes + twisted.nbytes + classes.nbytes), "bytes_down": int(twisted.nbytes + dist.nbytes),
-           "note": "kpop_count_twist + kpop_distance_rowwise from pageable host buffers (best of %d): H2D, kernels, D2H; "
-                   "the twisted rows cross PCIe twice because the two entry points are separate calls" % reps}
-    # the same through the device entry points and the library's own allocation/copy helpers (what a C or OCaml caller
-    # that wants both results does): every array crosses PCIe once
-    vp = C.c_void_p
-    bufs = {}
-
-    def dmalloc(name, nbytes):
-        h = vp()
-        if lib.kpop_dev_malloc(C.byref(h), int(nbytes)):
-            raise RuntimeError(lib.kpop_last_error().decode())
-        bufs[name] = h
-        return h
-    d_b, d_o = dmalloc("b", bases.nbytes), dmalloc("o", offs.nbytes)
-    d_t, d_d = dmalloc("t", twisted.nbytes), dmalloc("d", dist.nbytes)
-    d_c, d_m = dmalloc("c", classes.nbytes), dmalloc("m", R.metric_host.nbytes)
-    d_w = dmalloc("w", lib.kpop_dev_distance_workspace_bytes(Cn, n, d))
-    lib.kpop_memcpy_h2d(d_c, classes.ctypes.data, classes.nbytes)
-    lib.kpop_memcpy_h2d(d_m, R.metric_host.ctypes.data, R.metric_host.nbytes)
-
-    def once_dev():
-        rc = lib.kpop_memcpy_h2d(d_b, bases.ctypes.data, bases.nbytes) or lib.kpop_memcpy_h2d(d_o, offs.ctypes.data, offs.nbytes)
-        rc = rc or lib.kpop_dev_count_twist(R.tw.handle, d_b, d_o, n, n * L, L, 0, 1, d_t, None)
-        rc = rc or lib.kpop_dev_distance_rowwise(d_c, Cn, d_t, n, d, d_m, 0, 2.0, 1, d_w, d_d, None)
-        rc = rc or lib.kpop_memcpy_d2h(twisted.ctypes.data, d_t, twisted.nbytes) or lib.kpop_memcpy_d2h(dist.ctypes.data, d_d, dist.nbytes)
-        if rc:
-            raise RuntimeError(lib.kpop_last_error().decode())
-    try:
-        once_dev()
-        ts = []
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            once_dev()
-            ts.append(time.perf_counter() - t0)
-        b2 = min(ts)
-        out["device_entry_points"] = {"value": n / b2, "unit": "sequences/sec", "ms_per_step": b2 * 1e3,
-                                      "bytes_up": int(bases.nbytes + offs.nbytes), "bytes_down": int(twisted.nbytes + dist.nbytes),
-                                      "note": "kpop_memcpy_h2d + kpop_dev_count_twist + kpop_dev_distance_rowwise + kpop_memcpy_d2h of both results: each array crosses once"}
-    finally:
-        for h in bufs.values():
-            lib.kpop_dev_free(h)
+    out["separate_calls_pageable"] = {"value": n / min(ts), "unit": "sequences/sec", "ms_per_step": min(ts) * 1e3,
+                                      "note": "kpop_count_twist + kpop_distance_rowwise from pageable buffers, serial (round 2's pcie_inclusive)"}
+    out["matches_separate_calls"] = bool(np.array_equal(o_both["twisted"], twisted) and np.array_equal(o_both["distances"], dist))
     return out
 
 

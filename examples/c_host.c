@@ -77,6 +77,66 @@ int main(void) {
   uint32_t nn[3], idx[6];
   CHECK(kpop_distance_summary(ref, 2, twisted, 3, 2, metric, KPOP_EUCLIDEAN, 2.0, 1, 1, 2, stats, nn, idx, nd, nz));
   for (int r = 0; r < 3; ++r) printf("summary %d: mean %.15g closest %u at %.15g\n", r, stats[4 * r], idx[2 * r], nd[2 * r]);
+  /* the same three reads through the streaming pipeline: page-locked buffers, one call, distances and summary only
+   * (the twisted rows never cross the bus); must agree with the separate calls above to the last bit */
+  {
+    uint8_t *pb = NULL;
+    uint64_t *po = NULL;
+    double *pd = NULL, *ps = NULL, *pnd = NULL, *pnz = NULL;
+    uint32_t *pn = NULL, *pi = NULL;
+    CHECK(kpop_host_alloc((void **)&pb, sizeof bases));
+    CHECK(kpop_host_alloc((void **)&po, sizeof offsets));
+    CHECK(kpop_host_alloc((void **)&pd, sizeof dist));
+    CHECK(kpop_host_alloc((void **)&ps, sizeof stats));
+    CHECK(kpop_host_alloc((void **)&pn, sizeof nn));
+    CHECK(kpop_host_alloc((void **)&pi, sizeof idx));
+    CHECK(kpop_host_alloc((void **)&pnd, sizeof nd));
+    CHECK(kpop_host_alloc((void **)&pnz, sizeof nz));
+    memcpy(pb, bases, sizeof bases);
+    memcpy(po, offsets, sizeof offsets);
+    kpop_pipeline_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = sizeof cfg;
+    cfg.content = KPOP_DNA_DS;
+    cfg.normalize_counts = 1;
+    cfg.kind = KPOP_EUCLIDEAN;
+    cfg.p = 2.0;
+    cfg.normalize_distances = 1;
+    cfg.outputs = KPOP_OUT_DISTANCES | KPOP_OUT_SUMMARY;
+    cfg.keep_at_most = 1;
+    cfg.max_neighbours = 2;
+    cfg.chunk_reads = 2; /* two chunks for three reads: the ring is exercised */
+    kpop_pipeline *pl = NULL;
+    CHECK(kpop_pipeline_create(tw, ref, 2, metric, &cfg, &pl));
+    kpop_pipeline_outputs po_out;
+    memset(&po_out, 0, sizeof po_out);
+    po_out.distances = pd;
+    po_out.stats = ps;
+    po_out.n_neighbours = pn;
+    po_out.nb_index = pi;
+    po_out.nb_distance = pnd;
+    po_out.nb_z = pnz;
+    uint64_t ticket = 0;
+    CHECK(kpop_pipeline_submit(pl, pb, po, 3, &po_out, &ticket));
+    CHECK(kpop_pipeline_collect(pl, ticket));
+    uint32_t chunks = 0;
+    int pinned = 0;
+    CHECK(kpop_pipeline_stats(pl, &chunks, &pinned, NULL));
+    /* `fused` rows are what the pipeline twists (kpop_count_twist); its distances are checked by the caller of this program */
+    int same = 1;
+    for (int r = 0; r < 3; ++r) same = same && pn[r] == nn[r] && pi[2 * r] == idx[2 * r];
+    printf("pipeline: %u chunks, pinned %d, neighbours %s\n", chunks, pinned, same ? "identical" : "DIFFERENT");
+    for (int r = 0; r < 3; ++r) printf("pipeline distances %d: %.15g %.15g\n", r, pd[2 * r], pd[2 * r + 1]);
+    CHECK(kpop_pipeline_destroy(pl));
+    CHECK(kpop_host_free(pb));
+    CHECK(kpop_host_free(po));
+    CHECK(kpop_host_free(pd));
+    CHECK(kpop_host_free(ps));
+    CHECK(kpop_host_free(pn));
+    CHECK(kpop_host_free(pi));
+    CHECK(kpop_host_free(pnd));
+    CHECK(kpop_host_free(pnz));
+  }
   CHECK(kpop_twister_free(tw));
   free(T);
   CHECK(kpop_shutdown());

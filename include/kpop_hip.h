@@ -17,11 +17,17 @@
  *   - device entry points (kpop_dev_*) take pointers that already live in HBM
  *     plus a hipStream_t passed as void* (NULL = default stream); they only
  *     enqueue work and never synchronise;
- *   - call from one thread per process, from the PARENT process only (a HIP
- *     context does not survive fork(); the reference's fork()ed workers at
- *     lib/Twister.ml:90 are replaced wholesale, not per-worker);
- *   - one process drives one GPU (kpop_init(device)); multi-GPU = one process
- *     per GPU, reads sharded by the caller.
+ *   - call from the PARENT process only (a HIP context does not survive
+ *     fork(); the reference's fork()ed workers at lib/Twister.ml:90 are
+ *     replaced wholesale, not per-worker).  Host entry points of one device
+ *     run one at a time (the library serialises them); device entry points on
+ *     different streams may run concurrently (the library's scratch is per
+ *     stream);
+ *   - kpop_init(device) drives one GPU; kpop_init_devices(devices, n) drives
+ *     n of them from ONE process (SURVEY.md 8b "multi-GPU sharding is
+ *     internal"): handles (twisters, pipelines) belong to the device slot that
+ *     was current when they were made, and kpop_sharded_* spread a batch over
+ *     all slots.
  *
  * k-mer encoding (declared by this repository, see kpop_amd/csrc/kmer.h; the
  * reference keeps it in the absent BiOCamLib): A0 C1 G2 T3 either case,
@@ -62,7 +68,15 @@ typedef enum {
 #define KPOP_METRIC_POWERS 1
 
 /* ---------------------------------------------------------------- runtime */
-int kpop_init(int device);          /* select the GPU this process drives */
+int kpop_init(int device);          /* select the GPU this process drives (= kpop_init_devices(&device, 1)) */
+/* Several GPUs in one process: devices[i] becomes device SLOT i (the same GPU may be named twice: two independent
+   slots on it -- how the multi-device code is exercised on a one-GPU box).  Replaces `-T` / Parallel.get_nproc,
+   bin/KPopTwistDB.ml:103, and the fork()ed workers of lib/Twister.ml:90-196.  The calling thread works on slot 0
+   afterwards; kpop_use_device(slot) moves it (thread-local, like hipSetDevice).  Peer access between distinct GPUs is
+   enabled where the hardware allows it (xGMI).                                                                       */
+int kpop_init_devices(const int *devices, int n);
+int kpop_use_device(int slot);
+int kpop_device_slots(void);        /* slots initialised by the last kpop_init / kpop_init_devices */
 int kpop_shutdown(void);            /* release workspaces */
 int kpop_device_count(void);        /* >=0, or negative kpop_status */
 const char *kpop_last_error(void);
@@ -83,6 +97,14 @@ int kpop_dev_free(void *ptr);
 int kpop_memcpy_h2d(void *dst, const void *src, uint64_t bytes);
 int kpop_memcpy_d2h(void *dst, const void *src, uint64_t bytes);
 int kpop_dev_memset(void *dst, int value, uint64_t bytes);
+/* Page-locked host memory.  The streaming pipeline below copies straight from / to the caller's buffers; when they are
+   page-locked the copy engines run beside the kernels and kpop_pipeline_submit returns without waiting.  An OCaml
+   binding wraps kpop_host_alloc'ed memory as a Bigarray (Ctypes.bigarray_of_ptr) once and reuses it for every batch;
+   kpop_host_register pins memory the caller already owns (costly per call: do it once per buffer, not per batch). */
+int kpop_host_alloc(void **ptr, uint64_t bytes);
+int kpop_host_free(void *ptr);
+int kpop_host_register(void *ptr, uint64_t bytes);
+int kpop_host_unregister(void *ptr);
 
 /* ------------------------------------------------------------------ count
  * Replaces the per-read loop of KMerCounter.compute, bin/KPopCount.ml:36-50:
@@ -147,6 +169,58 @@ int kpop_count_twist(const kpop_twister *tw, const uint8_t *bases, const uint64_
  * This is what KPopTwistDB runs when KPopCount hands it reads instead of text spectra (kpop_amd/host/fast_seq.h). */
 int kpop_spectra_twist(const kpop_twister *tw, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
                        int k, int content, int normalize, double *out);
+
+/* ------------------------------------------------------- streaming pipeline
+ * Reads in host memory -> twisted rows / distances to a set of class vectors / per-read summary in host memory: the
+ * README.md:606 + :641 / :656 chain (bin/KPopCount.ml:36-50 -> lib/Twister.ml:58-206 -> lib/Matrix.ml:191-266 or
+ * :691-766) as one call, with the upload of chunk c+1, the kernels of chunk c and the download of chunk c-1 running at
+ * the same time on three streams (SURVEY.md 7 "pinned-memory double-buffered ingest ... never materialise").
+ * `outputs` selects what crosses the bus back: a caller after -d or -s never pulls the twisted rows.  Every output
+ * row depends on its own read only; results are bit-identical to kpop_dev_count_twist + kpop_dev_distance_rowwise /
+ * kpop_dev_distance_summary on the whole batch.
+ * A pipeline belongs to the device slot that was current at creation; twister, classes (n_classes x n_dims row-major)
+ * and metric are those of kpop_count_twist / kpop_distance_rowwise (first operand = classes, as `-d` has the register
+ * on the column side, lib/Matrix.ml:253).                                                                            */
+#define KPOP_OUT_TWISTED 1
+#define KPOP_OUT_DISTANCES 2
+#define KPOP_OUT_SUMMARY 4
+typedef struct kpop_pipeline kpop_pipeline;
+typedef struct {
+  uint32_t struct_size;      /* = sizeof(kpop_pipeline_config) */
+  int content;               /* KPOP_DNA_DS | KPOP_DNA_SS */
+  int normalize_counts;      /* --counts-normalize, lib/Twister.ml:177 */
+  int kind;                  /* KPOP_EUCLIDEAN | KPOP_COSINE | KPOP_MINKOWSKI */
+  double p;                  /* Minkowski power */
+  int normalize_distances;   /* --distance-normalize, lib/Matrix.ml:197-202 */
+  int outputs;               /* KPOP_OUT_* ored */
+  uint32_t keep_at_most;     /* summary: --summary-keep-at-most, 0 = all */
+  uint32_t max_neighbours;   /* summary: stride of the neighbour outputs */
+  uint32_t chunk_reads;      /* reads per chunk, 0 = chosen from the batch (an eighth of it, 8,192..65,536) */
+  uint32_t depth;            /* chunks in flight (device slots), 0 = 4 */
+  uint64_t chunk_bases;      /* bases per chunk, 0 = 256 MiB (a longer sequence gets a chunk of its own) */
+} kpop_pipeline_config;
+typedef struct {
+  double *twisted;           /* n_reads x n_dims            (KPOP_OUT_TWISTED)   */
+  double *distances;         /* n_reads x n_classes         (KPOP_OUT_DISTANCES) */
+  double *stats;             /* n_reads x 4: mean, sd, median, MAD (KPOP_OUT_SUMMARY, as kpop_distance_summary) */
+  uint32_t *n_neighbours;    /* n_reads */
+  uint32_t *nb_index;        /* n_reads x max_neighbours */
+  double *nb_distance;       /* n_reads x max_neighbours */
+  double *nb_z;              /* n_reads x max_neighbours */
+} kpop_pipeline_outputs;
+int kpop_pipeline_create(const kpop_twister *tw, const double *classes, uint32_t n_classes, const double *metric,
+                         const kpop_pipeline_config *cfg, kpop_pipeline **out);
+/* Enqueue one batch.  bases / offsets / the output buffers must stay valid and untouched until the ticket is
+   collected.  With page-locked buffers the call only enqueues (several batches may be in flight: submit the next
+   before collecting the previous and the bus never idles); with pageable ones it may wait for copies.            */
+int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                         const kpop_pipeline_outputs *out, uint64_t *ticket);
+int kpop_pipeline_collect(kpop_pipeline *pl, uint64_t ticket);  /* returns once that batch's outputs are in host memory */
+int kpop_pipeline_run(kpop_pipeline *pl, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                      const kpop_pipeline_outputs *out);        /* submit + collect */
+/* of the last submit: chunks it was cut into, whether every buffer was page-locked, slots in the ring */
+int kpop_pipeline_stats(const kpop_pipeline *pl, uint32_t *chunks, int *pinned, uint32_t *depth);
+int kpop_pipeline_destroy(kpop_pipeline *pl);
 
 /* ------------------------------------------------------ twister generation
  * Replaces the R stage of src/KPopTwist:93-116 (library `ca`): correspondence analysis of a k-mers x spectra
@@ -215,14 +289,15 @@ int kpop_dev_count_reads(const uint8_t *d_bases, const uint64_t *d_offsets, uint
                          int k, int content, void *d_scratch, uint64_t *d_out_hash, uint32_t *d_out_count,
                          uint64_t *d_out_offsets, void *stream);
 /* The library-owned workspace (segment partials here; distance rows of a chunk in kpop_dev_distance_summary
-   against a large first operand) is ONE per process: calls that use it must not run concurrently on two streams,
-   and the first call that needs more of it than any before synchronises the device to grow it.
-   kpop_dev_workspace_reserve(bytes) grows it ahead of time, after which those calls only enqueue.
+   against a large first operand) is one PER STREAM (per device slot), so calls on different streams may overlap;
+   the first call on a stream that needs more of it than any before synchronises the device to grow it.
+   kpop_dev_workspace_reserve[_stream](bytes) grows it ahead of time, after which those calls only enqueue.
    n_bases = offsets[n_reads] (size of d_bases), max_len = longest read in the batch: the host
    knows both from the offsets it uploaded (a read longer than max_len says comes back as a row of NaNs).  Reads of up to 512 windows take the one-wavefront-
    per-read kernel; longer sequences (genomes) the streaming kernel, whose segment partials
    live in a library-owned workspace (grown with hipMalloc on the first call that needs more). */
-int kpop_dev_workspace_reserve(uint64_t bytes);
+int kpop_dev_workspace_reserve(uint64_t bytes);                       /* the null stream's */
+int kpop_dev_workspace_reserve_stream(uint64_t bytes, void *stream);
 int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bases, const uint64_t *d_offsets,
                          uint32_t n_reads, uint64_t n_bases, uint32_t max_len, int content, int normalize,
                          double *d_out, void *stream);

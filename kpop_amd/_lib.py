@@ -15,9 +15,38 @@ u64p = C.POINTER(C.c_uint64)
 f64p = C.POINTER(C.c_double)
 vp = C.c_void_p
 
+
+class PipelineConfig(C.Structure):
+    """kpop_pipeline_config (include/kpop_hip.h)"""
+    _fields_ = [("struct_size", C.c_uint32), ("content", C.c_int), ("normalize_counts", C.c_int), ("kind", C.c_int),
+                ("p", C.c_double), ("normalize_distances", C.c_int), ("outputs", C.c_int), ("keep_at_most", C.c_uint32),
+                ("max_neighbours", C.c_uint32), ("chunk_reads", C.c_uint32), ("depth", C.c_uint32),
+                ("chunk_bases", C.c_uint64)]
+
+
+class PipelineOutputs(C.Structure):
+    """kpop_pipeline_outputs (include/kpop_hip.h)"""
+    _fields_ = [("twisted", vp), ("distances", vp), ("stats", vp), ("n_neighbours", vp), ("nb_index", vp),
+                ("nb_distance", vp), ("nb_z", vp)]
+
+
 # name -> (restype, argtypes); mirrors include/kpop_hip.h one to one
 SIGNATURES = {
     "kpop_init": (C.c_int, [C.c_int]),
+    "kpop_init_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
+    "kpop_use_device": (C.c_int, [C.c_int]),
+    "kpop_device_slots": (C.c_int, []),
+    "kpop_host_alloc": (C.c_int, [C.POINTER(vp), C.c_uint64]),
+    "kpop_host_free": (C.c_int, [vp]),
+    "kpop_host_register": (C.c_int, [vp, C.c_uint64]),
+    "kpop_host_unregister": (C.c_int, [vp]),
+    "kpop_pipeline_create": (C.c_int, [vp, f64p, C.c_uint32, f64p, C.POINTER(PipelineConfig), C.POINTER(vp)]),
+    "kpop_pipeline_submit": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(PipelineOutputs), u64p]),
+    "kpop_pipeline_collect": (C.c_int, [vp, C.c_uint64]),
+    "kpop_pipeline_run": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(PipelineOutputs)]),
+    "kpop_pipeline_stats": (C.c_int, [vp, u32p, C.POINTER(C.c_int), u32p]),
+    "kpop_pipeline_destroy": (C.c_int, [vp]),
+    "kpop_dev_workspace_reserve_stream": (C.c_int, [C.c_uint64, vp]),
     "kpop_shutdown": (C.c_int, []),
     "kpop_device_count": (C.c_int, []),
     "kpop_last_error": (C.c_char_p, []),

@@ -41,6 +41,21 @@ def init(device=0):
     check(_lib.load().kpop_init(int(device)))
 
 
+def init_devices(devices):
+    """Several GPUs in one process: devices[i] becomes device slot i (kpop_init_devices)."""
+    arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+    check(_lib.load().kpop_init_devices(arr, len(devices)))
+
+
+def use_device(slot):
+    """The calling thread's device slot (thread-local, like hipSetDevice)."""
+    check(_lib.load().kpop_use_device(int(slot)))
+
+
+def device_slots():
+    return int(_lib.load().kpop_device_slots())
+
+
 def tune(key, value):
     """Performance knobs for A/B runs (kpop_tune); results do not depend on them."""
     check(_lib.load().kpop_tune(key.encode(), int(value)))
@@ -184,6 +199,135 @@ class Twister:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------- streaming pipeline
+OUT_TWISTED, OUT_DISTANCES, OUT_SUMMARY = 1, 2, 4
+
+
+class _HostBlock:
+    """One kpop_host_alloc'ed block, freed when the last array over it goes."""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        check(_lib.load().kpop_host_alloc(C.byref(self.ptr), int(max(nbytes, 1))))
+        self.nbytes = int(max(nbytes, 1))
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ptr.value:
+                _lib.load().kpop_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def host_empty(shape, dtype):
+    """numpy array over page-locked host memory (kpop_host_alloc): what the streaming pipeline copies to and from at
+    the bus rate.  An OCaml binding does the same with Ctypes.bigarray_of_ptr."""
+    dt = np.dtype(dtype)
+    shape = (shape,) if np.isscalar(shape) else tuple(int(x) for x in shape)
+    n = int(np.prod(shape)) if shape else 1
+    blk = _HostBlock(n * dt.itemsize)
+    buf = (C.c_char * blk.nbytes).from_address(blk.ptr.value)
+    buf._kpop_block = blk  # the array's base is buf: the block lives as long as any view of it
+    return np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+
+
+class Pipeline:
+    """Reads in host memory -> twisted rows / distances to `classes` / per-read summary, streamed through the GPU in
+    chunks on three streams (kpop_pipeline_*): the README.md:606 + :641/:656 chain as one call."""
+
+    def __init__(self, tw, classes=None, metric=None, outputs=OUT_TWISTED | OUT_DISTANCES, content=DNA_DS,
+                 normalize_counts=True, kind=EUCLIDEAN, p=2.0, normalize_distances=True, keep_at_most=2,
+                 max_neighbours=8, chunk_reads=0, depth=0, chunk_bases=0):
+        self.tw = tw
+        self.n_dims = tw.info()["n_dims"]
+        self.outputs = int(outputs)
+        self.max_neighbours = int(max_neighbours)
+        cfg = _lib.PipelineConfig()
+        cfg.struct_size = C.sizeof(_lib.PipelineConfig)
+        cfg.content, cfg.normalize_counts = int(content), 1 if normalize_counts else 0
+        cfg.kind, cfg.p, cfg.normalize_distances = int(kind), float(p), 1 if normalize_distances else 0
+        cfg.outputs, cfg.keep_at_most, cfg.max_neighbours = self.outputs, int(keep_at_most or 0), self.max_neighbours
+        cfg.chunk_reads, cfg.depth, cfg.chunk_bases = int(chunk_reads), int(depth), int(chunk_bases)
+        self.n_classes = 0
+        cp = mp = None
+        if classes is not None:
+            classes = _c(classes, np.float64)
+            metric = _c(metric, np.float64)
+            if classes.ndim != 2 or classes.shape[1] != self.n_dims or len(metric) != self.n_dims:
+                raise ValueError("Incompatible_geometries")  # lib/Matrix.ml:193-194
+            self.n_classes = classes.shape[0]
+            cp, mp = _p(classes, C.c_double), _p(metric, C.c_double)
+        self._h = C.c_void_p()
+        check(_lib.load().kpop_pipeline_create(tw.handle, cp, self.n_classes, mp, C.byref(cfg), C.byref(self._h)))
+        self._pending = {}
+
+    def alloc_outputs(self, n_reads, pinned=True):
+        """dict of output arrays for a batch of n_reads (page-locked unless pinned=False)"""
+        mk = host_empty if pinned else (lambda shape, dt: np.empty(shape, dtype=dt))
+        n, o = max(int(n_reads), 1), {}
+        if self.outputs & OUT_TWISTED:
+            o["twisted"] = mk((n, self.n_dims), np.float64)[:n_reads]
+        if self.outputs & OUT_DISTANCES:
+            o["distances"] = mk((n, self.n_classes), np.float64)[:n_reads]
+        if self.outputs & OUT_SUMMARY:
+            mn = max(self.max_neighbours, 1)
+            o["stats"] = mk((n, 4), np.float64)[:n_reads]
+            o["n_neighbours"] = mk((n,), np.uint32)[:n_reads]
+            o["nb_index"] = mk((n, mn), np.uint32)[:n_reads, :self.max_neighbours]
+            o["nb_distance"] = mk((n, mn), np.float64)[:n_reads, :self.max_neighbours]
+            o["nb_z"] = mk((n, mn), np.float64)[:n_reads, :self.max_neighbours]
+        return o
+
+    def submit(self, bases, offsets, out):
+        """enqueue one batch; bases (uint8), offsets (uint64, n+1) and the arrays of `out` must stay alive and untouched
+        until collect(ticket).  -> ticket"""
+        if bases.dtype != np.uint8 or offsets.dtype != np.uint64 or not bases.flags.c_contiguous or not offsets.flags.c_contiguous:
+            raise ValueError("bases must be contiguous uint8 and offsets contiguous uint64")
+        n = len(offsets) - 1
+        po = _lib.PipelineOutputs()
+        for name in ("twisted", "distances", "stats", "n_neighbours", "nb_index", "nb_distance", "nb_z"):
+            a = out.get(name)
+            if a is not None:
+                if not a.flags.c_contiguous:
+                    raise ValueError("output %s is not contiguous" % name)
+                setattr(po, name, a.ctypes.data)
+        tk = C.c_uint64()
+        check(_lib.load().kpop_pipeline_submit(self._h, bases.ctypes.data, offsets.ctypes.data, n, C.byref(po), C.byref(tk)))
+        self._pending[tk.value] = (bases, offsets, out)
+        return tk.value
+
+    def collect(self, ticket):
+        check(_lib.load().kpop_pipeline_collect(self._h, int(ticket)))
+        for t in [t for t in self._pending if t <= ticket]:
+            del self._pending[t]
+
+    def run(self, bases, offsets, out=None, pinned_outputs=True):
+        """one batch, start to finish -> dict of output arrays"""
+        bases = _c(bases, np.uint8)
+        offsets = _c(offsets, np.uint64)
+        if out is None:
+            out = self.alloc_outputs(len(offsets) - 1, pinned=pinned_outputs)
+        self.collect(self.submit(bases, offsets, out))
+        return out
+
+    def stats(self):
+        ch, pin, dep = C.c_uint32(), C.c_int(), C.c_uint32()
+        check(_lib.load().kpop_pipeline_stats(self._h, C.byref(ch), C.byref(pin), C.byref(dep)))
+        return {"chunks": ch.value, "pinned": bool(pin.value), "depth": dep.value}
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            _lib.load().kpop_pipeline_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -60,12 +62,27 @@ struct Arena {
   void release();
 };
 
+// One Context per DEVICE SLOT.  kpop_init(device) fills slot 0; kpop_init_devices(devices, n) fills slots 0..n-1 (two
+// slots may name the same physical GPU -- that is how the multi-device paths are tested on a one-GPU box).  A host
+// thread works on the slot it chose with kpop_use_device(slot) (slot 0 until it says otherwise); the library's own
+// per-device worker threads choose theirs when they start.
 struct Context {
   bool initialised = false;
+  int slot = 0;
   int device = -1;
   int n_cus = 256;
   size_t lds_per_block = 65536;
-  Workspace ws;
+  // The library-owned scratch of the device entry points is PER STREAM: two streams running kpop_dev_count_twist on
+  // genomes, or kpop_dev_distance_summary against a large first operand, no longer share one block (round 2 did, and
+  // raced).  The null stream's is the one kpop_dev_workspace_reserve() grows.
+  std::mutex ws_mu;
+  std::map<hipStream_t, Workspace> ws_by_stream;
+  Workspace &ws_for(hipStream_t st) {
+    std::lock_guard<std::mutex> g(ws_mu);
+    return ws_by_stream[st];
+  }
+  // host-buffer entry points (null stream + arena) of one slot run one at a time
+  std::recursive_mutex host_mu;
   Arena arena;
   // tuning knobs (kpop_tune): gather depth, non-temporal row loads
   int tune_unroll = 8;
@@ -77,26 +94,41 @@ struct Context {
   int tune_blocksort = 1;  // -L on sequences of up to 32,768 windows: one block per sequence, sorted in LDS (0: device-wide sort)
   int tune_hist = 1;     // merged (-l) spectrum by atomic histogram when the hashes fit 26 bits (0: always sort)
 };
-Context &ctx();
+constexpr int kMaxSlots = 16;
+Context &ctx();              // the calling thread's slot
+Context &ctx_of(int slot);
+int current_slot();
+int n_slots();
+int use_slot(int slot);      // thread-local choice + hipSetDevice
 int require_init();
+// once-per-device-slot latch for hipFuncSetAttribute and the like (function attributes are per device)
+struct PerSlotOnce {
+  bool done[kMaxSlots] = {};
+  bool &operator()() { return done[current_slot()]; }
+};
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 struct ArenaScope {
+  Context &c;
   size_t cur;
   uint64_t off;
-  ArenaScope() {
-    Arena &a = ctx().arena;
+  ArenaScope() : c(ctx()) {
+    c.host_mu.lock();
+    Arena &a = c.arena;
     cur = a.cur;
     off = a.off;
     ++a.depth;
   }
   ~ArenaScope() {
-    Arena &a = ctx().arena;
+    Arena &a = c.arena;
     a.cur = cur;
     a.off = off;
     --a.depth;
+    c.host_mu.unlock();
   }
+  ArenaScope(const ArenaScope &) = delete;
+  ArenaScope &operator=(const ArenaScope &) = delete;
 };
 
 // RAII device buffer for the host-side entry points: arena-backed inside an ArenaScope, hipMalloc'ed otherwise.

@@ -625,7 +625,7 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
                  bytes_sums = ((nb + 1) * 8 + 63) & ~63ull, bytes_cnt = (max_slots * 4 + 63) & ~63ull,
                  bytes_part = max_slots * tw->n_dims * 8;
   void *ws = nullptr;
-  KPOP_TRY(ctx().ws.ensure(bytes_nseg + bytes_off + bytes_sums + bytes_cnt + bytes_part, &ws));
+  KPOP_TRY(ctx().ws_for(st).ensure(bytes_nseg + bytes_off + bytes_sums + bytes_cnt + bytes_part, &ws));
   char *wp = reinterpret_cast<char *>(ws);
   uint32_t *nseg = reinterpret_cast<uint32_t *>(wp);
   uint64_t *seg_off = reinterpret_cast<uint64_t *>(wp + bytes_nseg);

@@ -803,7 +803,8 @@ extern "C" int kpop_dev_counter_combine(const int32_t *d_storage, uint64_t ld, u
   do {                                                                                                                              \
     constexpr uint32_t TR = MedianTile<RR>::TR;                                                                                     \
     const size_t lds = (size_t)n_valid * 8 + (size_t)n_valid * (TR + 1) * 4;                                                        \
-    static bool attr_set = false;                                                                                                   \
+    static PerSlotOnce attr_once;                                                                                                   \
+    bool &attr_set = attr_once();                                                                                \
     if (!attr_set) {                                                                                                                \
       KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&combine_median_wave_kernel<RR, VV>),                             \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));                                 \

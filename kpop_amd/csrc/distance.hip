@@ -571,7 +571,8 @@ static int launch_summary_wave_r(const double *a, uint32_t r1, const double *b, 
   // as many waves per block as the LDS left beside the shared operand allows (two blocks per CU: 78 KB each)
   const uint32_t waves = (uint32_t)std::max<size_t>(1, std::min<size_t>(kSummaryWaves, ((78u << 10) - shared) / per_wave));
   const size_t smem = (size_t)waves * per_wave + shared;
-  static bool attr_set = false;
+  static PerSlotOnce attr_once;
+  bool &attr_set = attr_once();
   if (!attr_set) {
     KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&distance_summary_wave_kernel<KIND, PRE, R>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
@@ -802,7 +803,7 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
   const uint64_t budget = 4096ull << 20;
   const uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(r2, budget / ((uint64_t)r1 * 8)));
   void *ws = nullptr;
-  KPOP_TRY(ctx().ws.ensure((uint64_t)chunk * r1 * 8, &ws));
+  KPOP_TRY(ctx().ws_for(st).ensure((uint64_t)chunk * r1 * 8, &ws));
   double *rows = reinterpret_cast<double *>(ws);
   for (uint32_t q0 = 0; q0 < r2; q0 += chunk) {
     const uint32_t q = std::min(chunk, r2 - q0);
@@ -824,7 +825,8 @@ static int launch_summary(const double *a, uint32_t r1, const double *b, uint32_
   uint32_t NP = 64;
   while (NP < r1) NP <<= 1;
   const size_t smem = (size_t)NP * (8 + 8 + 4);
-  static bool attr_set = false;
+  static PerSlotOnce attr_once;
+  bool &attr_set = attr_once();
   if (!attr_set) {
     KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&distance_summary_kernel<KIND, PRE>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSummaryMaxR1 * 20)));

@@ -1,0 +1,357 @@
+// pipeline.hip -- the streaming host pipeline: reads in host memory -> twisted rows / distances / summary in host
+// memory, with the bus and the kernels busy at the same time.
+//
+// What it replaces: the README.md:606 + :641/:656 chain,
+//     KPopCount -L (bin/KPopCount.ml:36-50) | KPopTwistDB -k (lib/Twister.ml:58-206) ; KPopTwistDB -d / -s
+//     (lib/Matrix.ml:191-266, 691-766)
+// as ONE entry point for a host that holds reads in memory.  Round 2's host entry points ran H2D, kernels and D2H one
+// after the other on the null stream from pageable memory, and a caller that wanted distances paid for the twisted rows
+// crossing the bus twice (kpop_count_twist, then kpop_distance_rowwise).  Here:
+//
+//   * a batch is cut into chunks (reads are independent through count and twist);
+//   * three streams: chunk c+1 goes up (H2D) while chunk c runs count->twist->distance and chunk c-1 comes down (D2H).
+//     PCIe is full duplex, so both directions and the kernels overlap; the order inside a stream is the chunk order;
+//   * a ring of device slots (inputs, outputs, distance workspace: per slot, so nothing is shared between chunks in
+//     flight; the genome kernel's segment partials are per stream, common.h);
+//   * `outputs` picks what comes back: a caller after distances (-d) or a summary (-s) never pulls the twisted rows;
+//   * copies go straight from / to the caller's buffers.  When those are page-locked (kpop_host_alloc, or
+//     kpop_host_register of memory the caller owns) the copy engines run asynchronously and submit() returns at once;
+//     pageable buffers work too (HIP stages or pins them on the fly) with less overlap.
+//
+// Results are those of kpop_dev_count_twist + kpop_dev_distance_rowwise / kpop_dev_distance_summary on every chunk:
+// every row depends on its own read only, so the chunking does not show in the output.
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+#include "twister.h"
+
+namespace {
+
+using namespace kpop;
+
+struct DevMem {  // grow-only device block
+  void *p = nullptr;
+  uint64_t bytes = 0;
+  int ensure(uint64_t need) {
+    if (need <= bytes) return 0;
+    if (p) {
+      KPOP_HIP(hipDeviceSynchronize());
+      KPOP_HIP(hipFree(p));
+      p = nullptr;
+      bytes = 0;
+    }
+    const uint64_t want = need + need / 8 + 256;
+    KPOP_HIP(hipMalloc(&p, want));
+    bytes = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <class T>
+  T *as() const {
+    return reinterpret_cast<T *>(p);
+  }
+};
+
+struct RingSlot {
+  DevMem bases, offsets, twisted, dist, work, stats, nn, idx, ndist, z;
+  hipEvent_t h2d_done = nullptr, compute_done = nullptr, d2h_done = nullptr;
+  bool in_use = false;  // d2h_done has been recorded at least once
+};
+
+constexpr int kTicketRing = 64;
+
+}  // namespace
+
+struct kpop_pipeline {
+  int slot = 0;
+  const kpop_twister *tw = nullptr;
+  kpop_pipeline_config cfg{};
+  uint32_t n_classes = 0, n_dims = 0;
+  double *d_classes = nullptr, *d_metric = nullptr;
+  hipStream_t s_h2d = nullptr, s_compute = nullptr, s_d2h = nullptr;
+  std::vector<RingSlot> ring;
+  uint64_t next_chunk = 0;
+  uint64_t next_ticket = 1;
+  hipEvent_t ticket_done[kTicketRing] = {};
+  uint64_t ticket_id[kTicketRing] = {};
+  // statistics of the last submit (kpop_pipeline_stats)
+  uint32_t last_chunks = 0;
+  int last_pinned = 0;
+};
+
+namespace {
+
+struct SlotGuard {  // run on the pipeline's device slot, then go back to the caller's
+  int prev;
+  bool switched;
+  explicit SlotGuard(int slot) : prev(current_slot()), switched(false) {
+    if (slot != prev) switched = use_slot(slot) == 0;
+  }
+  ~SlotGuard() {
+    if (switched) (void)use_slot(prev);
+  }
+};
+
+static bool is_pinned(const void *p) {
+  if (!p) return true;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // plain malloc'ed memory: "invalid value", not an error of ours
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
+static void destroy(kpop_pipeline *pl) {
+  if (!pl) return;
+  SlotGuard g(pl->slot);
+  if (pl->s_h2d) (void)hipStreamSynchronize(pl->s_h2d);
+  if (pl->s_compute) (void)hipStreamSynchronize(pl->s_compute);
+  if (pl->s_d2h) (void)hipStreamSynchronize(pl->s_d2h);
+  for (RingSlot &s : pl->ring) {
+    DevMem *all[] = {&s.bases, &s.offsets, &s.twisted, &s.dist, &s.work, &s.stats, &s.nn, &s.idx, &s.ndist, &s.z};
+    for (DevMem *m : all) m->release();
+    if (s.h2d_done) (void)hipEventDestroy(s.h2d_done);
+    if (s.compute_done) (void)hipEventDestroy(s.compute_done);
+    if (s.d2h_done) (void)hipEventDestroy(s.d2h_done);
+  }
+  for (int i = 0; i < kTicketRing; ++i)
+    if (pl->ticket_done[i]) (void)hipEventDestroy(pl->ticket_done[i]);
+  if (pl->d_classes) (void)hipFree(pl->d_classes);
+  if (pl->d_metric) (void)hipFree(pl->d_metric);
+  if (pl->s_compute) {
+    // the per-stream workspace of the genome kernel dies with its stream
+    Context &c = ctx();
+    std::lock_guard<std::mutex> lk(c.ws_mu);
+    auto it = c.ws_by_stream.find(pl->s_compute);
+    if (it != c.ws_by_stream.end()) {
+      it->second.release();
+      c.ws_by_stream.erase(it);
+    }
+  }
+  if (pl->s_h2d) (void)hipStreamDestroy(pl->s_h2d);
+  if (pl->s_compute) (void)hipStreamDestroy(pl->s_compute);
+  if (pl->s_d2h) (void)hipStreamDestroy(pl->s_d2h);
+  delete pl;
+}
+
+// chunk boundaries: at most chunk_reads reads and (unless one read alone is longer) chunk_bases bases
+static uint32_t chunk_end(const uint64_t *offsets, uint32_t r0, uint32_t n, uint32_t chunk_reads, uint64_t chunk_bases) {
+  const uint32_t hi = (uint32_t)std::min<uint64_t>(n, (uint64_t)r0 + chunk_reads);
+  if (offsets[hi] - offsets[r0] <= chunk_bases) return hi;
+  // first r with offsets[r] - offsets[r0] > chunk_bases; keep at least one read
+  const uint64_t *e = std::upper_bound(offsets + r0, offsets + hi + 1, offsets[r0] + chunk_bases);
+  const uint32_t r1 = (uint32_t)(e - offsets) - 1;
+  return std::max(r1, r0 + 1);
+}
+
+}  // namespace
+
+extern "C" int kpop_pipeline_create(const kpop_twister *tw, const double *classes, uint32_t n_classes, const double *metric,
+                                    const kpop_pipeline_config *cfg, kpop_pipeline **out) {
+  KPOP_TRY(require_init());
+  if (!tw || !cfg || !out) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_create: null argument");
+  if (cfg->struct_size != sizeof(kpop_pipeline_config))
+    KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_create: config of %u bytes, this library's is %zu (set struct_size = sizeof)", cfg->struct_size,
+              sizeof(kpop_pipeline_config));
+  if (tw->slot != current_slot())
+    KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_create: the twister lives on device slot %d, the calling thread works on %d", tw->slot, current_slot());
+  const int outs = cfg->outputs;
+  if (!outs || (outs & ~(KPOP_OUT_TWISTED | KPOP_OUT_DISTANCES | KPOP_OUT_SUMMARY)))
+    KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_create: outputs=%d selects nothing or an unknown output", outs);
+  if (cfg->content != KPOP_DNA_DS && cfg->content != KPOP_DNA_SS)
+    KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_pipeline_create: content %d (the fused path is DNA only)", cfg->content);
+  if (cfg->kind != KPOP_EUCLIDEAN && cfg->kind != KPOP_COSINE && cfg->kind != KPOP_MINKOWSKI)
+    KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_create: unknown distance kind %d", cfg->kind);
+  if (cfg->kind == KPOP_MINKOWSKI && !(cfg->p >= 0.0)) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_create: negative Minkowski power");
+  const bool need_classes = outs & (KPOP_OUT_DISTANCES | KPOP_OUT_SUMMARY);
+  if (need_classes && (!classes || !metric || n_classes == 0))
+    KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_create: distances / summary need the class vectors and the metric");
+  kpop_pipeline *pl = new kpop_pipeline();
+  pl->slot = current_slot();
+  pl->tw = tw;
+  pl->cfg = *cfg;
+  pl->n_dims = tw->n_dims;
+  pl->n_classes = need_classes ? n_classes : 0;
+  if (pl->cfg.depth == 0) pl->cfg.depth = 4;
+  if (pl->cfg.depth < 2) pl->cfg.depth = 2;
+  if (pl->cfg.depth > 16) pl->cfg.depth = 16;
+  if (pl->cfg.chunk_bases == 0) pl->cfg.chunk_bases = 256ull << 20;
+  int rc = KPOP_OK;
+  do {
+#define PL_HIP(expr)                                                                                         \
+  {                                                                                                          \
+    hipError_t e_ = (expr);                                                                                  \
+    if (e_ != hipSuccess) {                                                                                  \
+      set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_));                        \
+      rc = KPOP_ERR_HIP;                                                                                     \
+      break;                                                                                                 \
+    }                                                                                                        \
+  }
+    PL_HIP(hipStreamCreateWithFlags(&pl->s_h2d, hipStreamNonBlocking));
+    PL_HIP(hipStreamCreateWithFlags(&pl->s_compute, hipStreamNonBlocking));
+    PL_HIP(hipStreamCreateWithFlags(&pl->s_d2h, hipStreamNonBlocking));
+    pl->ring.resize(pl->cfg.depth);
+    bool ok = true;
+    for (RingSlot &s : pl->ring) {
+      ok = ok && hipEventCreateWithFlags(&s.h2d_done, hipEventDisableTiming) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&s.compute_done, hipEventDisableTiming) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&s.d2h_done, hipEventDisableTiming) == hipSuccess;
+    }
+    for (int i = 0; i < kTicketRing; ++i) ok = ok && hipEventCreateWithFlags(&pl->ticket_done[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+      set_error("kpop_pipeline_create: hipEventCreate failed");
+      rc = KPOP_ERR_HIP;
+      break;
+    }
+    if (need_classes) {
+      const uint64_t cb = (uint64_t)n_classes * tw->n_dims * 8, mb = (uint64_t)tw->n_dims * 8;
+      PL_HIP(hipMalloc((void **)&pl->d_classes, cb));
+      PL_HIP(hipMalloc((void **)&pl->d_metric, mb));
+      PL_HIP(hipMemcpy(pl->d_classes, classes, cb, hipMemcpyHostToDevice));
+      PL_HIP(hipMemcpy(pl->d_metric, metric, mb, hipMemcpyHostToDevice));
+    }
+#undef PL_HIP
+  } while (0);
+  if (rc != KPOP_OK) {
+    destroy(pl);
+    return rc;
+  }
+  *out = pl;
+  return KPOP_OK;
+}
+
+extern "C" int kpop_pipeline_destroy(kpop_pipeline *pl) {
+  destroy(pl);
+  return KPOP_OK;
+}
+
+extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                                    const kpop_pipeline_outputs *o, uint64_t *ticket) {
+  if (!pl || !o || (n_reads && !offsets)) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_submit: null argument");
+  SlotGuard guard(pl->slot);
+  const int outs = pl->cfg.outputs;
+  const uint32_t D = pl->n_dims, C = pl->n_classes, mn = pl->cfg.max_neighbours;
+  if (n_reads) {
+    if ((outs & KPOP_OUT_TWISTED) && !o->twisted) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_submit: outputs has TWISTED but twisted is null");
+    if ((outs & KPOP_OUT_DISTANCES) && !o->distances) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_submit: outputs has DISTANCES but distances is null");
+    if ((outs & KPOP_OUT_SUMMARY) && (!o->stats || !o->n_neighbours || (mn && (!o->nb_index || !o->nb_distance || !o->nb_z))))
+      KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_submit: outputs has SUMMARY but a summary buffer is null");
+  }
+  // the ticket's event slot: its previous holder (64 submits ago) must have completed
+  const uint64_t tk = pl->next_ticket;
+  const int ti = (int)(tk % kTicketRing);
+  if (pl->ticket_id[ti]) KPOP_HIP(hipEventSynchronize(pl->ticket_done[ti]));
+  uint64_t total_max_len = 0;
+  for (uint32_t r = 0; r < n_reads; ++r) {
+    if (offsets[r + 1] < offsets[r]) KPOP_FAIL(KPOP_ERR_INVALID, "offsets are not non-decreasing at read %u", r);
+    total_max_len = std::max(total_max_len, offsets[r + 1] - offsets[r]);
+  }
+  if (total_max_len > 0xFFFFFFFFull) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_pipeline_submit: sequence longer than 2^32 bases");
+  // chunk size: eight chunks a batch keeps the fill (first H2D + first kernel) and the drain (last D2H) short against
+  // the steady state; not below 8,192 reads (two full rounds of one-wavefront-per-read blocks on 256 CUs)
+  uint32_t chunk_reads = pl->cfg.chunk_reads;
+  if (chunk_reads == 0) chunk_reads = std::min<uint32_t>(65536u, std::max<uint32_t>(8192u, (div_up(n_reads, 8) + 1023u) & ~1023u));
+  pl->last_pinned = (is_pinned(bases) && is_pinned(offsets) && is_pinned(o->twisted) && is_pinned(o->distances) && is_pinned(o->stats) &&
+                     is_pinned(o->n_neighbours) && is_pinned(o->nb_index) && is_pinned(o->nb_distance) && is_pinned(o->nb_z))
+                        ? 1
+                        : 0;
+  uint32_t n_chunks = 0;
+  for (uint32_t r0 = 0; r0 < n_reads;) {
+    const uint32_t r1 = chunk_end(offsets, r0, n_reads, chunk_reads, pl->cfg.chunk_bases);
+    const uint32_t n = r1 - r0;
+    const uint64_t b0 = offsets[r0], nb = offsets[r1] - b0;
+    uint64_t max_len = 0;
+    for (uint32_t r = r0; r < r1; ++r) max_len = std::max(max_len, offsets[r + 1] - offsets[r]);
+    RingSlot &s = pl->ring[pl->next_chunk % pl->ring.size()];
+    ++pl->next_chunk;
+    // the slot's previous chunk must have left the device before its buffers are grown (ensure synchronises then
+    // anyway) or overwritten (the stream waits below do that without stalling the host)
+    KPOP_TRY(s.bases.ensure(nb));
+    KPOP_TRY(s.offsets.ensure((uint64_t)(n + 1) * 8));
+    KPOP_TRY(s.twisted.ensure((uint64_t)n * D * 8));
+    if (outs & KPOP_OUT_DISTANCES) KPOP_TRY(s.dist.ensure((uint64_t)n * C * 8));
+    if (outs & (KPOP_OUT_DISTANCES | KPOP_OUT_SUMMARY)) KPOP_TRY(s.work.ensure(kpop_dev_distance_workspace_bytes(C, n, D)));
+    if (outs & KPOP_OUT_SUMMARY) {
+      KPOP_TRY(s.stats.ensure((uint64_t)n * 4 * 8));
+      KPOP_TRY(s.nn.ensure((uint64_t)n * 4));
+      KPOP_TRY(s.idx.ensure((uint64_t)n * mn * 4));
+      KPOP_TRY(s.ndist.ensure((uint64_t)n * mn * 8));
+      KPOP_TRY(s.z.ensure((uint64_t)n * mn * 8));
+    }
+    // up
+    if (s.in_use) KPOP_HIP(hipStreamWaitEvent(pl->s_h2d, s.d2h_done, 0));
+    if (nb) KPOP_HIP(hipMemcpyAsync(s.bases.p, bases + b0, nb, hipMemcpyHostToDevice, pl->s_h2d));
+    KPOP_HIP(hipMemcpyAsync(s.offsets.p, offsets + r0, (uint64_t)(n + 1) * 8, hipMemcpyHostToDevice, pl->s_h2d));
+    KPOP_HIP(hipEventRecord(s.h2d_done, pl->s_h2d));
+    // count -> twist -> distance: the kernels see the caller's absolute offsets, so the bases pointer is moved back by b0
+    KPOP_HIP(hipStreamWaitEvent(pl->s_compute, s.h2d_done, 0));
+    const uint8_t *d_bases = s.bases.as<uint8_t>() - b0;
+    KPOP_TRY(kpop_dev_count_twist(pl->tw, d_bases, s.offsets.as<uint64_t>(), n, nb, (uint32_t)max_len, pl->cfg.content,
+                                  pl->cfg.normalize_counts, s.twisted.as<double>(), pl->s_compute));
+    if (outs & KPOP_OUT_DISTANCES)
+      KPOP_TRY(kpop_dev_distance_rowwise(pl->d_classes, C, s.twisted.as<double>(), n, D, pl->d_metric, pl->cfg.kind, pl->cfg.p,
+                                         pl->cfg.normalize_distances, s.work.p, s.dist.as<double>(), pl->s_compute));
+    if (outs & KPOP_OUT_SUMMARY)
+      KPOP_TRY(kpop_dev_distance_summary(pl->d_classes, C, s.twisted.as<double>(), n, D, pl->d_metric, pl->cfg.kind, pl->cfg.p,
+                                         pl->cfg.normalize_distances, pl->cfg.keep_at_most, mn, s.work.p, s.stats.as<double>(),
+                                         s.nn.as<uint32_t>(), s.idx.as<uint32_t>(), s.ndist.as<double>(), s.z.as<double>(),
+                                         pl->s_compute));
+    KPOP_HIP(hipEventRecord(s.compute_done, pl->s_compute));
+    // down
+    KPOP_HIP(hipStreamWaitEvent(pl->s_d2h, s.compute_done, 0));
+    if (outs & KPOP_OUT_TWISTED)
+      KPOP_HIP(hipMemcpyAsync(o->twisted + (uint64_t)r0 * D, s.twisted.p, (uint64_t)n * D * 8, hipMemcpyDeviceToHost, pl->s_d2h));
+    if (outs & KPOP_OUT_DISTANCES)
+      KPOP_HIP(hipMemcpyAsync(o->distances + (uint64_t)r0 * C, s.dist.p, (uint64_t)n * C * 8, hipMemcpyDeviceToHost, pl->s_d2h));
+    if (outs & KPOP_OUT_SUMMARY) {
+      KPOP_HIP(hipMemcpyAsync(o->stats + (uint64_t)r0 * 4, s.stats.p, (uint64_t)n * 4 * 8, hipMemcpyDeviceToHost, pl->s_d2h));
+      KPOP_HIP(hipMemcpyAsync(o->n_neighbours + r0, s.nn.p, (uint64_t)n * 4, hipMemcpyDeviceToHost, pl->s_d2h));
+      if (mn) {
+        KPOP_HIP(hipMemcpyAsync(o->nb_index + (uint64_t)r0 * mn, s.idx.p, (uint64_t)n * mn * 4, hipMemcpyDeviceToHost, pl->s_d2h));
+        KPOP_HIP(hipMemcpyAsync(o->nb_distance + (uint64_t)r0 * mn, s.ndist.p, (uint64_t)n * mn * 8, hipMemcpyDeviceToHost, pl->s_d2h));
+        KPOP_HIP(hipMemcpyAsync(o->nb_z + (uint64_t)r0 * mn, s.z.p, (uint64_t)n * mn * 8, hipMemcpyDeviceToHost, pl->s_d2h));
+      }
+    }
+    KPOP_HIP(hipEventRecord(s.d2h_done, pl->s_d2h));
+    s.in_use = true;
+    ++n_chunks;
+    r0 = r1;
+  }
+  pl->last_chunks = n_chunks;
+  KPOP_HIP(hipEventRecord(pl->ticket_done[ti], pl->s_d2h));
+  pl->ticket_id[ti] = tk;
+  ++pl->next_ticket;
+  if (ticket) *ticket = tk;
+  return KPOP_OK;
+}
+
+extern "C" int kpop_pipeline_collect(kpop_pipeline *pl, uint64_t ticket) {
+  if (!pl) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_collect: null pipeline");
+  if (ticket == 0 || ticket >= pl->next_ticket) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_collect: ticket %llu was never issued", (unsigned long long)ticket);
+  SlotGuard guard(pl->slot);
+  const int ti = (int)(ticket % kTicketRing);
+  // an older ticket whose event slot has been handed on completed before that hand-over (submit waits for it)
+  if (pl->ticket_id[ti] == ticket) KPOP_HIP(hipEventSynchronize(pl->ticket_done[ti]));
+  return KPOP_OK;
+}
+
+extern "C" int kpop_pipeline_run(kpop_pipeline *pl, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                                 const kpop_pipeline_outputs *o) {
+  uint64_t tk = 0;
+  KPOP_TRY(kpop_pipeline_submit(pl, bases, offsets, n_reads, o, &tk));
+  return kpop_pipeline_collect(pl, tk);
+}
+
+extern "C" int kpop_pipeline_stats(const kpop_pipeline *pl, uint32_t *chunks, int *pinned, uint32_t *depth) {
+  if (!pl) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_stats: null pipeline");
+  if (chunks) *chunks = pl->last_chunks;
+  if (pinned) *pinned = pl->last_pinned;
+  if (depth) *depth = pl->cfg.depth;
+  return KPOP_OK;
+}

@@ -20,9 +20,21 @@ void set_error(const char *fmt, ...) {
 }
 const char *get_error() { return g_err; }
 
-Context &ctx() {
-  static Context c;
-  return c;
+static Context g_ctx[kMaxSlots];
+static int g_n_slots = 0;
+static thread_local int tl_slot = 0;
+
+Context &ctx() { return g_ctx[tl_slot]; }
+Context &ctx_of(int slot) { return g_ctx[slot]; }
+int current_slot() { return tl_slot; }
+int n_slots() { return g_n_slots; }
+
+int use_slot(int slot) {
+  if (slot < 0 || slot >= g_n_slots || !g_ctx[slot].initialised)
+    KPOP_FAIL(KPOP_ERR_INVALID, "kpop_use_device: slot %d is not one of the %d initialised", slot, g_n_slots);
+  KPOP_HIP(hipSetDevice(g_ctx[slot].device));
+  tl_slot = slot;
+  return 0;
 }
 
 int Workspace::ensure(uint64_t need, void **out) {
@@ -95,44 +107,86 @@ extern "C" int kpop_device_count(void) {
   return n;
 }
 
-extern "C" int kpop_init(int device) {
-  int n = 0;
-  hipError_t e = hipGetDeviceCount(&n);
-  if (e != hipSuccess || n <= 0)
+static void release_slot(Context &c) {
+  if (!c.initialised) return;
+  (void)hipSetDevice(c.device);
+  {
+    std::lock_guard<std::mutex> g(c.ws_mu);
+    for (auto &kv : c.ws_by_stream) kv.second.release();
+    c.ws_by_stream.clear();
+  }
+  c.arena.release();
+  c.initialised = false;
+}
+
+extern "C" int kpop_init_devices(const int *devices, int n) {
+  int n_dev = 0;
+  hipError_t e = hipGetDeviceCount(&n_dev);
+  if (e != hipSuccess || n_dev <= 0)
     KPOP_FAIL(KPOP_ERR_HIP, "kpop_init: no HIP device visible (%s); this library has no CPU path",
               e == hipSuccess ? "0 devices" : hipGetErrorString(e));
-  if (device < 0 || device >= n) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_init: device %d out of range 0..%d", device, n - 1);
-  KPOP_HIP(hipSetDevice(device));
-  hipDeviceProp_t prop;
-  KPOP_HIP(hipGetDeviceProperties(&prop, device));
-  Context &c = ctx();
-  c.device = device;
-  c.n_cus = prop.multiProcessorCount;
-  c.lds_per_block = prop.sharedMemPerBlock;
-  c.initialised = true;
-  if (const char *dbg = getenv("KPOP_TUNE_DBG")) c.tune_dbg = (uint32_t)atoi(dbg);  // (the A/B switches of kpop_tune("dbg"), for the command-line tools)
+  if (n < 1 || n > kMaxSlots) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_init_devices: %d devices (1..%d)", n, kMaxSlots);
+  if (!devices) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_init_devices: null device list");
+  for (int i = 0; i < n; ++i)
+    if (devices[i] < 0 || devices[i] >= n_dev)
+      KPOP_FAIL(KPOP_ERR_INVALID, "kpop_init: device %d out of range 0..%d", devices[i], n_dev - 1);
+  for (int i = n; i < g_n_slots; ++i) release_slot(g_ctx[i]);
+  for (int i = 0; i < n; ++i) {
+    Context &c = g_ctx[i];
+    if (c.initialised && c.device != devices[i]) release_slot(c);
+    KPOP_HIP(hipSetDevice(devices[i]));
+    hipDeviceProp_t prop;
+    KPOP_HIP(hipGetDeviceProperties(&prop, devices[i]));
+    c.slot = i;
+    c.device = devices[i];
+    c.n_cus = prop.multiProcessorCount;
+    c.lds_per_block = prop.sharedMemPerBlock;
+    c.initialised = true;
+    if (const char *dbg = getenv("KPOP_TUNE_DBG")) c.tune_dbg = (uint32_t)atoi(dbg);  // (the A/B switches of kpop_tune("dbg"), for the command-line tools)
+  }
+  g_n_slots = n;
+  // every pair of distinct devices may copy to each other directly (the in-library all-gather, multi.hip)
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      if (devices[i] == devices[j]) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can) {
+        (void)hipSetDevice(devices[i]);
+        hipError_t pe = hipDeviceEnablePeerAccess(devices[j], 0);
+        if (pe != hipSuccess) (void)hipGetLastError();  // already enabled, or refused: copies then go through the host
+      }
+    }
+  tl_slot = 0;
+  KPOP_HIP(hipSetDevice(devices[0]));
   return KPOP_OK;
 }
 
+extern "C" int kpop_init(int device) { return kpop_init_devices(&device, 1); }
+
+extern "C" int kpop_use_device(int slot) { return use_slot(slot); }
+extern "C" int kpop_device_slots(void) { return g_n_slots; }
+
 extern "C" int kpop_shutdown(void) {
-  ctx().ws.release();
-  ctx().arena.release();
-  ctx().initialised = false;
+  for (int i = 0; i < g_n_slots; ++i) release_slot(g_ctx[i]);
+  g_n_slots = 0;
+  tl_slot = 0;
   return KPOP_OK;
 }
 
 extern "C" int kpop_tune(const char *key, int value) {
   if (!key) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_tune: null key");
-  Context &c = ctx();
-  if (!strcmp(key, "unroll") && (value == 8 || value == 16)) c.tune_unroll = value;
-  else if (!strcmp(key, "nt") && (value == 0 || value == 1 || value == 2)) c.tune_nt = value;
-  else if (!strcmp(key, "dense") && value >= 0 && value <= 2) c.tune_dense = value;
-  else if (!strcmp(key, "dbg")) c.tune_dbg = value;
-  else if (!strcmp(key, "blocksort") && (value == 0 || value == 1)) c.tune_blocksort = value;
-  else if (!strcmp(key, "ldspad") && value >= 0 && value <= 65536) c.tune_ldspad = value;
-  else if (!strcmp(key, "hist") && (value == 0 || value == 1)) c.tune_hist = value;
-  else if (!strcmp(key, "seg") && (value == 0 || (value >= 64 && value <= 16384 && value % 64 == 0))) c.tune_seg = value;
-  else KPOP_FAIL(KPOP_ERR_INVALID, "kpop_tune: unknown knob or value %s=%d", key, value);
+  for (int i = 0; i < kMaxSlots; ++i) {  // a knob holds for every device slot
+    Context &c = g_ctx[i];
+    if (!strcmp(key, "unroll") && (value == 8 || value == 16)) c.tune_unroll = value;
+    else if (!strcmp(key, "nt") && (value == 0 || value == 1 || value == 2)) c.tune_nt = value;
+    else if (!strcmp(key, "dense") && value >= 0 && value <= 2) c.tune_dense = value;
+    else if (!strcmp(key, "dbg")) c.tune_dbg = value;
+    else if (!strcmp(key, "blocksort") && (value == 0 || value == 1)) c.tune_blocksort = value;
+    else if (!strcmp(key, "ldspad") && value >= 0 && value <= 65536) c.tune_ldspad = value;
+    else if (!strcmp(key, "hist") && (value == 0 || value == 1)) c.tune_hist = value;
+    else if (!strcmp(key, "seg") && (value == 0 || (value >= 64 && value <= 16384 && value % 64 == 0))) c.tune_seg = value;
+    else KPOP_FAIL(KPOP_ERR_INVALID, "kpop_tune: unknown knob or value %s=%d", key, value);
+  }
   return KPOP_OK;
 }
 
@@ -142,10 +196,38 @@ extern "C" int kpop_synchronize(void *stream) {
   return KPOP_OK;
 }
 
-extern "C" int kpop_dev_workspace_reserve(uint64_t bytes) {
+extern "C" int kpop_dev_workspace_reserve(uint64_t bytes) { return kpop_dev_workspace_reserve_stream(bytes, nullptr); }
+
+extern "C" int kpop_dev_workspace_reserve_stream(uint64_t bytes, void *stream) {
   KPOP_TRY(require_init());
   void *p = nullptr;
-  return ctx().ws.ensure(bytes, &p);
+  return ctx().ws_for(as_stream(stream)).ensure(bytes, &p);
+}
+
+// page-locked host memory: what the streaming pipeline (pipeline.hip) copies to and from at the bus rate, with the
+// copy engines running beside the kernels
+extern "C" int kpop_host_alloc(void **ptr, uint64_t bytes) {
+  KPOP_TRY(require_init());
+  if (!ptr) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_host_alloc: null ptr");
+  KPOP_HIP(hipHostMalloc(ptr, bytes ? bytes : 8, hipHostMallocPortable));
+  return KPOP_OK;
+}
+
+extern "C" int kpop_host_free(void *ptr) {
+  if (ptr) KPOP_HIP(hipHostFree(ptr));
+  return KPOP_OK;
+}
+
+extern "C" int kpop_host_register(void *ptr, uint64_t bytes) {
+  KPOP_TRY(require_init());
+  if (!ptr || !bytes) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_host_register: null or empty range");
+  KPOP_HIP(hipHostRegister(ptr, bytes, hipHostRegisterPortable));
+  return KPOP_OK;
+}
+
+extern "C" int kpop_host_unregister(void *ptr) {
+  if (ptr) KPOP_HIP(hipHostUnregister(ptr));
+  return KPOP_OK;
 }
 
 extern "C" int kpop_dev_malloc(void **ptr, uint64_t bytes) {

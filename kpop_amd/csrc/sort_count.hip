@@ -490,12 +490,12 @@ static int block_count_device(const uint8_t *bases, const uint64_t *offsets, uin
   uint32_t *ticket = S.d_scr.as<uint32_t>();
   uint64_t *state = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(S.d_scr.p) + 64);
   const size_t smem = ((size_t)NP + (NP >> 5) + 1) * 4;
-  static bool attr_set[2] = {false, false};
+  static PerSlotOnce attr_once[2];
   const int which = content == KPOP_PROTEIN ? 1 : 0;
-  if (!attr_set[which]) {
+  if (!attr_once[which]()) {
     if (which) KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&count_block_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((kBlockSortMax + kBlockSortMax / 32 + 1) * 4)));
     else KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&count_block_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((kBlockSortMax + kBlockSortMax / 32 + 1) * 4)));
-    attr_set[which] = true;
+    attr_once[which]() = true;
   }
   if (which)
     count_block_kernel<5><<<dim3(n_reads), dim3(1024), smem, st>>>(S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), n_reads, k, content, ticket,

@@ -30,6 +30,8 @@ struct kpop_twister {
   void *d_rsel = nullptr;
   uint64_t *d_sorted_hash = nullptr;
   uint64_t device_bytes = 0;
+  int slot = 0;        // device slot (common.h) whose memory holds the arrays
+  bool alias = false;  // a second handle on another twister's arrays (kpop_twister_replicate onto the same GPU): frees nothing
 };
 
 namespace kpop {

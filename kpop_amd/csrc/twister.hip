@@ -126,6 +126,10 @@ using namespace kpop;
 
 extern "C" int kpop_twister_free(kpop_twister *tw) {
   if (!tw) return KPOP_OK;
+  if (tw->alias) {
+    delete tw;
+    return KPOP_OK;
+  }
   if (tw->d_rows) (void)hipFree(tw->d_rows);
   if (tw->d_rsel) (void)hipFree(tw->d_rsel);
   if (tw->d_sorted_hash) (void)hipFree(tw->d_sorted_hash);
@@ -179,6 +183,7 @@ extern "C" int kpop_twister_load(const double *T_dims_major, uint64_t n_cols, ui
   }
   kpop_twister *tw = new kpop_twister();
   TwGuard guard{tw};
+  tw->slot = current_slot();
   tw->k = k;
   tw->n_dims = n_dims;
   tw->n_cols = n_cols;
@@ -282,6 +287,7 @@ extern "C" int kpop_twister_synth_slice(uint64_t seed, int k, int content, uint3
   if (content == KPOP_DNA_DS) n_cols = (k % 2 == 0) ? (n_hashes + (1ull << k)) / 2 : n_hashes / 2;
   kpop_twister *tw = new kpop_twister();
   TwGuard guard{tw};
+  tw->slot = current_slot();
   tw->k = k;
   tw->n_dims = n_dims + (acc_dim ? 1u : 0u);
   hipStream_t st = nullptr;
