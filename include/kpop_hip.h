@@ -195,7 +195,7 @@ typedef struct {
   int outputs;               /* KPOP_OUT_* ored */
   uint32_t keep_at_most;     /* summary: --summary-keep-at-most, 0 = all */
   uint32_t max_neighbours;   /* summary: stride of the neighbour outputs */
-  uint32_t chunk_reads;      /* reads per chunk, 0 = chosen from the batch (an eighth of it, 8,192..65,536) */
+  uint32_t chunk_reads;      /* reads per chunk, 0 = chosen from the batch (a quarter of it, 16,384..131,072) */
   uint32_t depth;            /* chunks in flight (device slots), 0 = 4 */
   uint64_t chunk_bases;      /* bases per chunk, 0 = 256 MiB (a longer sequence gets a chunk of its own) */
 } kpop_pipeline_config;
@@ -221,6 +221,59 @@ int kpop_pipeline_run(kpop_pipeline *pl, const uint8_t *bases, const uint64_t *o
 /* of the last submit: chunks it was cut into, whether every buffer was page-locked, slots in the ring */
 int kpop_pipeline_stats(const kpop_pipeline *pl, uint32_t *chunks, int *pinned, uint32_t *depth);
 int kpop_pipeline_destroy(kpop_pipeline *pl);
+
+/* ------------------------------------------------------------ several GPUs
+ * "multi-GPU sharding is internal".  After kpop_init_devices(devices, n) these calls spread one batch
+ * over all n device slots from inside the library -- one host thread per device, started per call -- replacing `-T`
+ * (bin/KPopTwistDB.ml:103) and the fork()ed workers of lib/Twister.ml:90-196 and lib/Matrix.ml:212-266,712-766.
+ * Every sequence is independent through count and twist: reads are cut into contiguous shards
+ * (kpop_shard_bounds), twister / classes / metric are replicated, results land in the caller's rows.                 */
+/* rows [lo, hi) of n_items that `rank` of `world` owns: balanced, the first n_items % world ranks get one more.
+   Pure host arithmetic (no GPU).                                                                                    */
+int kpop_shard_bounds(uint64_t n_items, int rank, int world, uint64_t *lo, uint64_t *hi);
+/* a twister on another device slot: copied device to device (xGMI where peers are enabled); onto a slot of the SAME
+   GPU it is a second handle on the same arrays.  Free with kpop_twister_free.                                       */
+int kpop_twister_replicate(const kpop_twister *src, int slot, kpop_twister **out);
+typedef struct kpop_sharded kpop_sharded;
+/* One streaming pipeline (above) per device slot; `tw` may live on any slot and is replicated to the others.
+   classes / metric may be NULL for a twisted-rows-only job (metric alone is enough for the all-vs-all summary).     */
+int kpop_sharded_create(const kpop_twister *tw, const double *classes, uint32_t n_classes, const double *metric,
+                        const kpop_pipeline_config *cfg, kpop_sharded **out);
+int kpop_sharded_slots(const kpop_sharded *sh);
+/* kpop_pipeline_run over all devices: host memory to host memory, rows of shard s written by device s.  Distances
+   against a reference set need no exchange between devices.  Bit-identical to one pipeline on one device.           */
+int kpop_sharded_run(kpop_sharded *sh, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                     const kpop_pipeline_outputs *out);
+/* BASELINE config 4 with the reads already resident: slot s holds n_reads[s] reads in ITS HBM (d_bases[s],
+   d_offsets[s] = n_reads[s] + 1 offsets into d_bases[s]; n_bases[s] bytes; max_len = longest read anywhere).  Every
+   device twists its shard in `chunks` pieces and -- gather != 0 -- pushes each finished piece into every peer's copy
+   of the full n_total x n_dims matrix (hipMemcpyPeerAsync on one stream per destination: the all-gather of
+   SURVEY.md 8e over point-to-point xGMI links) while it twists the next; then the distances of its rows to the
+   classes.  Returns when all devices are done and every copy of the matrix is complete.                             */
+int kpop_sharded_resident_step(kpop_sharded *sh, const uint8_t *const *d_bases, const uint64_t *const *d_offsets,
+                               const uint32_t *n_reads, const uint64_t *n_bases, uint32_t max_len, int chunks, int gather);
+/* device pointers of slot `slot` after a resident step: the full matrix (read order), the slot's first row and row
+   count in it, its distances to the classes (n_rows x n_classes)                                                    */
+int kpop_sharded_resident_buffers(const kpop_sharded *sh, int slot, double **d_full, uint64_t *first_row, uint64_t *n_rows,
+                                  double **d_distances);
+/* of the last resident step on that slot: host time until its kernels were done, and the time it then still waited
+   for its pushes to land (the exposed part of the exchange)                                                         */
+int kpop_sharded_timings(const kpop_sharded *sh, int slot, double *ms_compute, double *ms_exposed_comm);
+/* After a resident step with gather: slot s summarises the first min(queries_per_slot, n_s) rows of its shard (0 =
+   all) against ALL n_total twisted vectors (Matrix.summarize_rowwise, lib/Matrix.ml:691-766; N x N is never formed).
+   One output row per query, slots in order; out_query = the query's global read number; neighbour indices are global
+   read numbers.  capacity = rows the output arrays hold.                                                            */
+int kpop_sharded_all_vs_all_summary(kpop_sharded *sh, uint32_t queries_per_slot, uint32_t keep_at_most, uint32_t max_neighbours,
+                                    uint64_t capacity, uint64_t *n_queries_out, uint64_t *out_query, double *out_stats,
+                                    uint32_t *out_n, uint32_t *out_idx, double *out_dist, double *out_z);
+int kpop_sharded_destroy(kpop_sharded *sh);
+/* kpop_distance_rowwise / kpop_distance_summary with the rows of the second operand cut over the device slots        */
+int kpop_sharded_distance_rowwise(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
+                                  const double *metric, int kind, double p, int normalize, double *out);
+int kpop_sharded_distance_summary(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
+                                  const double *metric, int kind, double p, int normalize, uint32_t keep_at_most,
+                                  uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
+                                  double *out_dist, double *out_z);
 
 /* ------------------------------------------------------ twister generation
  * Replaces the R stage of src/KPopTwist:93-116 (library `ca`): correspondence analysis of a k-mers x spectra

@@ -47,6 +47,21 @@ SIGNATURES = {
     "kpop_pipeline_stats": (C.c_int, [vp, u32p, C.POINTER(C.c_int), u32p]),
     "kpop_pipeline_destroy": (C.c_int, [vp]),
     "kpop_dev_workspace_reserve_stream": (C.c_int, [C.c_uint64, vp]),
+    "kpop_shard_bounds": (C.c_int, [C.c_uint64, C.c_int, C.c_int, u64p, u64p]),
+    "kpop_twister_replicate": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+    "kpop_sharded_create": (C.c_int, [vp, f64p, C.c_uint32, f64p, C.POINTER(PipelineConfig), C.POINTER(vp)]),
+    "kpop_sharded_slots": (C.c_int, [vp]),
+    "kpop_sharded_run": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(PipelineOutputs)]),
+    "kpop_sharded_resident_step": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), u32p, u64p, C.c_uint32, C.c_int, C.c_int]),
+    "kpop_sharded_resident_buffers": (C.c_int, [vp, C.c_int, C.POINTER(vp), u64p, u64p, C.POINTER(vp)]),
+    "kpop_sharded_timings": (C.c_int, [vp, C.c_int, f64p, f64p]),
+    "kpop_sharded_all_vs_all_summary": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, u64p, u64p, f64p, u32p,
+                                                  u32p, f64p, f64p]),
+    "kpop_sharded_destroy": (C.c_int, [vp]),
+    "kpop_sharded_distance_rowwise": (C.c_int, [f64p, C.c_uint32, f64p, C.c_uint32, C.c_uint32, f64p, C.c_int, C.c_double,
+                                                C.c_int, f64p]),
+    "kpop_sharded_distance_summary": (C.c_int, [f64p, C.c_uint32, f64p, C.c_uint32, C.c_uint32, f64p, C.c_int, C.c_double,
+                                                C.c_int, C.c_uint32, C.c_uint32, f64p, u32p, u32p, f64p, f64p]),
     "kpop_shutdown": (C.c_int, []),
     "kpop_device_count": (C.c_int, []),
     "kpop_last_error": (C.c_char_p, []),

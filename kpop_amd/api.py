@@ -332,6 +332,142 @@ class Pipeline:
             pass
 
 
+# ------------------------------------------------------------ several GPUs
+def shard_bounds(n_items, rank, world):
+    """kpop_shard_bounds: rows [lo, hi) of n_items owned by `rank` of `world` (host arithmetic, no GPU)"""
+    lo, hi = C.c_uint64(), C.c_uint64()
+    check(_lib.load().kpop_shard_bounds(int(n_items), int(rank), int(world), C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
+
+
+class Sharded:
+    """One batch over every device slot of kpop_init_devices, from inside the library (kpop_sharded_*): one streaming
+    pipeline and one host thread per device; replaces `-T` and the fork()ed workers of lib/Twister.ml:90-196."""
+
+    def __init__(self, tw, classes=None, metric=None, outputs=OUT_TWISTED | OUT_DISTANCES, content=DNA_DS,
+                 normalize_counts=True, kind=EUCLIDEAN, p=2.0, normalize_distances=True, keep_at_most=2,
+                 max_neighbours=8, chunk_reads=0, depth=0, chunk_bases=0):
+        self.tw = tw
+        self.n_dims = tw.info()["n_dims"]
+        self.outputs, self.max_neighbours = int(outputs), int(max_neighbours)
+        cfg = _lib.PipelineConfig()
+        cfg.struct_size = C.sizeof(_lib.PipelineConfig)
+        cfg.content, cfg.normalize_counts = int(content), 1 if normalize_counts else 0
+        cfg.kind, cfg.p, cfg.normalize_distances = int(kind), float(p), 1 if normalize_distances else 0
+        cfg.outputs, cfg.keep_at_most, cfg.max_neighbours = self.outputs, int(keep_at_most or 0), self.max_neighbours
+        cfg.chunk_reads, cfg.depth, cfg.chunk_bases = int(chunk_reads), int(depth), int(chunk_bases)
+        self.n_classes = 0
+        cp = mp = None
+        if metric is not None:
+            metric = _c(metric, np.float64)
+            mp = _p(metric, C.c_double)
+        if classes is not None:
+            classes = _c(classes, np.float64)
+            if classes.ndim != 2 or classes.shape[1] != self.n_dims or metric is None or len(metric) != self.n_dims:
+                raise ValueError("Incompatible_geometries")
+            self.n_classes = classes.shape[0]
+            cp = _p(classes, C.c_double)
+        self._h = C.c_void_p()
+        check(_lib.load().kpop_sharded_create(tw.handle, cp, self.n_classes, mp, C.byref(cfg), C.byref(self._h)))
+        self.slots = int(_lib.load().kpop_sharded_slots(self._h))
+
+    alloc_outputs = Pipeline.alloc_outputs
+
+    def run(self, bases, offsets, out=None, pinned_outputs=True):
+        """host memory -> host memory over all devices; rows of shard s are written by device s"""
+        bases = _c(bases, np.uint8)
+        offsets = _c(offsets, np.uint64)
+        n = len(offsets) - 1
+        if out is None:
+            out = self.alloc_outputs(n, pinned=pinned_outputs)
+        po = _lib.PipelineOutputs()
+        for name in ("twisted", "distances", "stats", "n_neighbours", "nb_index", "nb_distance", "nb_z"):
+            a = out.get(name)
+            if a is not None:
+                setattr(po, name, a.ctypes.data)
+        check(_lib.load().kpop_sharded_run(self._h, bases.ctypes.data, offsets.ctypes.data, n, C.byref(po)))
+        return out
+
+    def resident_step(self, d_bases, d_offsets, n_reads, n_bases, max_len, chunks=4, gather=True):
+        """device-resident config-4 step; d_bases / d_offsets: one device pointer per slot (in that slot's HBM)"""
+        n = self.slots
+        pb = (C.c_void_p * n)(*[int(x) for x in d_bases])
+        po = (C.c_void_p * n)(*[int(x) for x in d_offsets])
+        nr = (C.c_uint32 * n)(*[int(x) for x in n_reads])
+        nb = (C.c_uint64 * n)(*[int(x) for x in n_bases])
+        check(_lib.load().kpop_sharded_resident_step(self._h, pb, po, nr, nb, int(max_len), int(chunks), 1 if gather else 0))
+
+    def resident_buffers(self, slot):
+        full, dist = C.c_void_p(), C.c_void_p()
+        first, rows = C.c_uint64(), C.c_uint64()
+        check(_lib.load().kpop_sharded_resident_buffers(self._h, int(slot), C.byref(full), C.byref(first), C.byref(rows), C.byref(dist)))
+        return full.value, first.value, rows.value, dist.value
+
+    def timings(self, slot):
+        a, b = C.c_double(), C.c_double()
+        check(_lib.load().kpop_sharded_timings(self._h, int(slot), C.byref(a), C.byref(b)))
+        return {"ms_compute": a.value, "ms_exposed_comm": b.value}
+
+    def all_vs_all_summary(self, queries_per_slot=0, keep_at_most=2, max_neighbours=8, capacity=None):
+        """after resident_step(gather=True) -> (query global ids, stats, n, idx, dist, z), one row per query"""
+        cap = int(capacity if capacity is not None else max(1, queries_per_slot) * self.slots)
+        mn = max(int(max_neighbours), 1)
+        q = np.zeros(cap, dtype=np.uint64)
+        stats = np.zeros((cap, 4))
+        n = np.zeros(cap, dtype=np.uint32)
+        idx = np.zeros((cap, mn), dtype=np.uint32)
+        dd = np.zeros((cap, mn))
+        z = np.zeros((cap, mn))
+        got = C.c_uint64()
+        check(_lib.load().kpop_sharded_all_vs_all_summary(self._h, int(queries_per_slot), int(keep_at_most or 0), int(max_neighbours), cap,
+                                                          C.byref(got), _p(q, C.c_uint64), _p(stats, C.c_double), _p(n, C.c_uint32),
+                                                          _p(idx, C.c_uint32), _p(dd, C.c_double), _p(z, C.c_double)))
+        g = got.value
+        return q[:g], stats[:g], n[:g], idx[:g], dd[:g], z[:g]
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            _lib.load().kpop_sharded_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sharded_distance_rowwise(m1, m2, metric, kind=EUCLIDEAN, p=2.0, normalize=True):
+    """distance_rowwise with the rows of m2 cut over the device slots"""
+    m1, m2, metric = _c(m1, np.float64), _c(m2, np.float64), _c(metric, np.float64)
+    r1, d = m1.shape
+    r2 = m2.shape[0]
+    out = np.zeros((r2, r1))
+    check(_lib.load().kpop_sharded_distance_rowwise(_p(_nz(m1, np.float64), C.c_double), r1, _p(_nz(m2, np.float64), C.c_double), r2, d,
+                                                    _p(metric, C.c_double), int(kind), float(p), 1 if normalize else 0,
+                                                    _p(_nz(out, np.float64), C.c_double)))
+    return out
+
+
+def sharded_distance_summary(m1, m2, metric, kind=EUCLIDEAN, p=2.0, normalize=True, keep_at_most=2, max_neighbours=8):
+    """distance_summary with the rows of m2 cut over the device slots"""
+    m1, m2, metric = _c(m1, np.float64), _c(m2, np.float64), _c(metric, np.float64)
+    r1, d = m1.shape
+    r2 = m2.shape[0]
+    mn = max(int(max_neighbours), 1)
+    stats = np.zeros((r2, 4))
+    n = np.zeros(r2, dtype=np.uint32)
+    idx = np.zeros((r2, mn), dtype=np.uint32)
+    dist = np.zeros((r2, mn))
+    z = np.zeros((r2, mn))
+    check(_lib.load().kpop_sharded_distance_summary(_p(_nz(m1, np.float64), C.c_double), r1, _p(_nz(m2, np.float64), C.c_double), r2, d,
+                                                    _p(metric, C.c_double), int(kind), float(p), 1 if normalize else 0, int(keep_at_most or 0),
+                                                    mn, _p(_nz(stats, np.float64), C.c_double), _p(_nz(n, np.uint32), C.c_uint32),
+                                                    _p(_nz(idx, np.uint32), C.c_uint32), _p(_nz(dist, np.float64), C.c_double),
+                                                    _p(_nz(z, np.float64), C.c_double)))
+    return stats, n, idx, dist, z
+
+
 # ------------------------------------------------------ twister generation
 def ca(counts, normalize=True):
     """Correspondence analysis of a k-mers x spectra table (the R stage of src/KPopTwist:93-116).

@@ -107,6 +107,35 @@ static bool is_pinned(const void *p) {
   return a.type == hipMemoryTypeHost;
 }
 
+// Device -> host.  ROCm 7's runtime executes a LINEAR copy from device memory to page-locked host memory as a blit
+// kernel of 16 workgroups: 36-46 GB/s beside a running kernel, on the CUs.  A RECTANGULAR copy of the same bytes goes to
+// the SDMA engines: 56 GB/s whatever the CUs are doing, and nothing taken from the kernels (tools/probes/
+// d2h_overlap_probe.cpp, profiles/r03_d_d2h_overlap.txt).  So a large copy to page-locked memory is issued as a
+// rectangle; pageable destinations keep the linear copy (the runtime pins or stages them itself).
+static int copy_down(void *dst, const void *src, uint64_t n_rows, uint64_t row_bytes, bool pinned, hipStream_t st) {
+  const uint64_t bytes = n_rows * row_bytes;
+  if (!bytes) return 0;
+  uint64_t done = 0;
+  if (pinned && bytes >= (512ull << 10)) {
+    // rows of the rectangle = g matrix rows each, g the largest divisor of n_rows that keeps a rectangle row under
+    // 512 KiB: the whole block goes in one rectangular copy with no linear tail (a tail is one more blit launch on
+    // the download stream).  A row count with no useful divisor falls back to 256 KiB rows and a tail.
+    uint64_t g = std::min<uint64_t>(n_rows, std::max<uint64_t>(1, (512ull << 10) / row_bytes));
+    while (g > 1 && n_rows % g) --g;
+    if (g * row_bytes >= (32ull << 10)) {
+      KPOP_HIP(hipMemcpy2DAsync(dst, g * row_bytes, src, g * row_bytes, g * row_bytes, n_rows / g, hipMemcpyDeviceToHost, st));
+      return 0;
+    }
+    constexpr uint64_t kRow = 256ull << 10;
+    KPOP_HIP(hipMemcpy2DAsync(dst, kRow, src, kRow, kRow, bytes / kRow, hipMemcpyDeviceToHost, st));
+    done = bytes / kRow * kRow;
+  }
+  if (done < bytes)
+    KPOP_HIP(hipMemcpyAsync(reinterpret_cast<char *>(dst) + done, reinterpret_cast<const char *>(src) + done, bytes - done,
+                            hipMemcpyDeviceToHost, st));
+  return 0;
+}
+
 static void destroy(kpop_pipeline *pl) {
   if (!pl) return;
   SlotGuard g(pl->slot);
@@ -253,14 +282,16 @@ extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, con
     total_max_len = std::max(total_max_len, offsets[r + 1] - offsets[r]);
   }
   if (total_max_len > 0xFFFFFFFFull) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_pipeline_submit: sequence longer than 2^32 bases");
-  // chunk size: eight chunks a batch keeps the fill (first H2D + first kernel) and the drain (last D2H) short against
-  // the steady state; not below 8,192 reads (two full rounds of one-wavefront-per-read blocks on 256 CUs)
+  // chunk size: four chunks a batch.  More of them shorten the fill (first H2D + first kernel) and the drain (last D2H)
+  // of a single call, but a launch of the one-wavefront-per-read kernel over fewer than ~25,000 reads no longer fills the
+  // chip for long enough to reach its streaming rate (12,500 reads: 0.38 ms, against 0.15 ms as an eighth of a 100,000-read
+  // launch; profiles/r03_c_pipeline_trace.txt)
   uint32_t chunk_reads = pl->cfg.chunk_reads;
-  if (chunk_reads == 0) chunk_reads = std::min<uint32_t>(65536u, std::max<uint32_t>(8192u, (div_up(n_reads, 8) + 1023u) & ~1023u));
-  pl->last_pinned = (is_pinned(bases) && is_pinned(offsets) && is_pinned(o->twisted) && is_pinned(o->distances) && is_pinned(o->stats) &&
-                     is_pinned(o->n_neighbours) && is_pinned(o->nb_index) && is_pinned(o->nb_distance) && is_pinned(o->nb_z))
-                        ? 1
-                        : 0;
+  if (chunk_reads == 0) chunk_reads = std::min<uint32_t>(131072u, std::max<uint32_t>(16384u, (div_up(n_reads, 4) + 1023u) & ~1023u));
+  const bool pin_tw = is_pinned(o->twisted), pin_di = is_pinned(o->distances), pin_st = is_pinned(o->stats),
+             pin_nn = is_pinned(o->n_neighbours), pin_ix = is_pinned(o->nb_index), pin_nd = is_pinned(o->nb_distance),
+             pin_nz = is_pinned(o->nb_z);
+  pl->last_pinned = (is_pinned(bases) && is_pinned(offsets) && pin_tw && pin_di && pin_st && pin_nn && pin_ix && pin_nd && pin_nz) ? 1 : 0;
   uint32_t n_chunks = 0;
   for (uint32_t r0 = 0; r0 < n_reads;) {
     const uint32_t r1 = chunk_end(offsets, r0, n_reads, chunk_reads, pl->cfg.chunk_bases);
@@ -306,16 +337,16 @@ extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, con
     // down
     KPOP_HIP(hipStreamWaitEvent(pl->s_d2h, s.compute_done, 0));
     if (outs & KPOP_OUT_TWISTED)
-      KPOP_HIP(hipMemcpyAsync(o->twisted + (uint64_t)r0 * D, s.twisted.p, (uint64_t)n * D * 8, hipMemcpyDeviceToHost, pl->s_d2h));
+      KPOP_TRY(copy_down(o->twisted + (uint64_t)r0 * D, s.twisted.p, n, (uint64_t)D * 8, pin_tw, pl->s_d2h));
     if (outs & KPOP_OUT_DISTANCES)
-      KPOP_HIP(hipMemcpyAsync(o->distances + (uint64_t)r0 * C, s.dist.p, (uint64_t)n * C * 8, hipMemcpyDeviceToHost, pl->s_d2h));
+      KPOP_TRY(copy_down(o->distances + (uint64_t)r0 * C, s.dist.p, n, (uint64_t)C * 8, pin_di, pl->s_d2h));
     if (outs & KPOP_OUT_SUMMARY) {
-      KPOP_HIP(hipMemcpyAsync(o->stats + (uint64_t)r0 * 4, s.stats.p, (uint64_t)n * 4 * 8, hipMemcpyDeviceToHost, pl->s_d2h));
-      KPOP_HIP(hipMemcpyAsync(o->n_neighbours + r0, s.nn.p, (uint64_t)n * 4, hipMemcpyDeviceToHost, pl->s_d2h));
+      KPOP_TRY(copy_down(o->stats + (uint64_t)r0 * 4, s.stats.p, n, 32, pin_st, pl->s_d2h));
+      KPOP_TRY(copy_down(o->n_neighbours + r0, s.nn.p, n, 4, pin_nn, pl->s_d2h));
       if (mn) {
-        KPOP_HIP(hipMemcpyAsync(o->nb_index + (uint64_t)r0 * mn, s.idx.p, (uint64_t)n * mn * 4, hipMemcpyDeviceToHost, pl->s_d2h));
-        KPOP_HIP(hipMemcpyAsync(o->nb_distance + (uint64_t)r0 * mn, s.ndist.p, (uint64_t)n * mn * 8, hipMemcpyDeviceToHost, pl->s_d2h));
-        KPOP_HIP(hipMemcpyAsync(o->nb_z + (uint64_t)r0 * mn, s.z.p, (uint64_t)n * mn * 8, hipMemcpyDeviceToHost, pl->s_d2h));
+        KPOP_TRY(copy_down(o->nb_index + (uint64_t)r0 * mn, s.idx.p, n, (uint64_t)mn * 4, pin_ix, pl->s_d2h));
+        KPOP_TRY(copy_down(o->nb_distance + (uint64_t)r0 * mn, s.ndist.p, n, (uint64_t)mn * 8, pin_nd, pl->s_d2h));
+        KPOP_TRY(copy_down(o->nb_z + (uint64_t)r0 * mn, s.z.p, n, (uint64_t)mn * 8, pin_nz, pl->s_d2h));
       }
     }
     KPOP_HIP(hipEventRecord(s.d2h_done, pl->s_d2h));
