@@ -57,7 +57,11 @@ def parse_args(argv=None):
     ap.add_argument("--dims", type=int, default=64)
     ap.add_argument("--classes", type=int, default=65)
     ap.add_argument("--class-len", type=int, default=30000, help="class genomes (SURVEY.md 8d: 30 kb)")
-    ap.add_argument("--ag-chunks", type=int, default=4, help="config4: pieces the all-gather is cut into")
+    ap.add_argument("--ag-chunks", type=int, default=0,
+                    help="config4: pieces the all-gather is cut into; 0 = max(4, GPUs): the exposed tail is one piece's exchange")
+    ap.add_argument("--in-process", action="store_true",
+                    help="all GPUs from ONE process through the C ABI (kpop_init_devices + kpop_sharded_*: one host thread per "
+                         "device, hipMemcpyPeerAsync all-gather) instead of one torch.distributed rank per GPU with RCCL")
     ap.add_argument("--queries", type=int, default=1024, help="config4: rows (in total) of the all-vs-all summary")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -106,6 +110,7 @@ def self_launch(args):
 # ---------------------------------------------------------------------------------------------------------
 class Rank:
     def __init__(self, args):
+        t_start = time.perf_counter()
         import numpy as np
         import torch
         import torch.distributed as dist
@@ -159,6 +164,9 @@ class Rank:
         self.metric_host = kpop_amd.metric_compute(w / w.sum())
         self.metric = torch.from_numpy(self.metric_host).to(self.dev)
         torch.cuda.synchronize()
+        # start-up of a rank (imports, RCCL rendezvous, the twister -- 4.3 GB synthesised on the device at k=12 -- and the
+        # class vectors): outside every timed region, reported so that it is seen
+        self.startup_s = time.perf_counter() - t_start
 
     # -- plumbing
     def barrier(self):
@@ -172,6 +180,15 @@ class Rank:
         t = self.torch.tensor([x], dtype=self.torch.float64, device="cpu" if self.shared_gpu else self.dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def gather_floats(self, x):
+        """one float per rank -> list on every rank"""
+        if not self.use_dist:
+            return [float(x)]
+        t = self.torch.zeros(self.world, dtype=self.torch.float64, device="cpu" if self.shared_gpu else self.dev)
+        t[self.rank] = float(x)
+        self.dist.all_reduce(t)
+        return [float(v) for v in t.cpu().tolist()]
 
     def synth_reads(self, n, first):
         t, L = self.torch, self.args.read_len
@@ -261,7 +278,8 @@ class Rank:
         from kpop_amd.pipeline import DevicePipeline, DeviceCompute, ShardedJob
         from kpop_amd.shard import ChunkedGather
         t, a, np = self.torch, self.args, self.np
-        layout = ChunkedGather(n_total, self.world, a.ag_chunks if self.world > 1 or self.use_dist else 1,
+        ag_chunks = a.ag_chunks if a.ag_chunks > 0 else max(4, self.world)
+        layout = ChunkedGather(n_total, self.world, ag_chunks if self.world > 1 or self.use_dist else 1,
                                staging="cpu" if self.shared_gpu else None)
         lo, hi = layout.bounds[self.rank]
         bases, offsets = self.synth_reads(hi - lo, lo)
@@ -287,6 +305,10 @@ class Rank:
         ag = [p[0].elapsed_time(p[1]) for ev in per_step_events for p in ev.get("gather", [])]
         if ag:
             res["ms_allgather_step_on_its_stream"] = float(np.sum(ag) / len(per_step_events))
+        ex = [p[0].elapsed_time(p[1]) for ev in per_step_events for p in ev.get("exposed", [])]
+        mine = float(np.sum(ex) / max(len(per_step_events), 1)) if ex else 0.0
+        res["ms_exposed_comm_per_rank"] = self.gather_floats(mine)
+        res["startup_s_per_rank"] = self.gather_floats(self.startup_s)
         if job.full is not None:
             # the exchange alone, nothing else running: all chunks back to back on the comm stream
             t.cuda.synchronize()
@@ -505,10 +527,126 @@ def file_to_file(R):
         return {"value": None, "note": "file-to-file leg failed: %r" % (e,)}
 
 
+def in_process(args):
+    """`--gpus N --in-process`: BASELINE config 4 (strong scaling) with every GPU driven from THIS process through the C
+    ABI -- what an OCaml host gets: kpop_init_devices, one kpop_sharded job, per step kpop_sharded_resident_step (twist in
+    chunks, hipMemcpyPeerAsync pushes of every finished chunk to all peers, distances to the classes).  No torch, no
+    RCCL.  KPOP_BENCH_SHARE_GPU=1 aliases every slot to GPU 0 (a rig for one-GPU boxes, not a scaling number)."""
+    import ctypes as C
+    import numpy as np
+    import kpop_amd
+    from kpop_amd import _lib
+    t_start = time.perf_counter()
+    lib = _lib.load()
+    shared = os.environ.get("KPOP_BENCH_SHARE_GPU") == "1"
+    N = args.gpus
+    kpop_amd.init_devices([0] * N if shared else list(range(N)))
+    k, d, L, Cn = args.k, args.dims, args.read_len, args.classes
+    reads = args.reads or 1000000
+    tw = kpop_amd.Twister.synth(TWISTER_SEED, k, d)
+    # class vectors: twist of C synthetic genomes, on slot 0
+    vp = C.c_void_p
+
+    def dmalloc(nbytes):
+        h = vp()
+        kpop_amd.check(lib.kpop_dev_malloc(C.byref(h), int(max(nbytes, 8))))
+        return h
+    cb, co, cl = dmalloc(Cn * args.class_len), dmalloc((Cn + 1) * 8), dmalloc(Cn * d * 8)
+    kpop_amd.check(lib.kpop_dev_synth_reads(CLASS_SEED, Cn, args.class_len, 0, cb, co, None))
+    kpop_amd.check(lib.kpop_dev_count_twist(tw.handle, cb, co, Cn, Cn * args.class_len, args.class_len, 0, 1, cl, None))
+    classes = np.zeros((Cn, d))
+    kpop_amd.check(lib.kpop_memcpy_d2h(classes.ctypes.data, cl, classes.nbytes))
+    for h in (cb, co, cl):
+        lib.kpop_dev_free(h)
+    w = np.exp2(-np.arange(d, dtype=np.float64) / 8.0)
+    metric = kpop_amd.metric_compute(w / w.sum())
+    sh = kpop_amd.Sharded(tw, classes, metric, outputs=kpop_amd.OUT_TWISTED | kpop_amd.OUT_DISTANCES)
+    d_bases, d_offs, n_reads, n_bases = [], [], [], []
+    for s in range(N):
+        lo, hi = kpop_amd.shard_bounds(reads, s, N)
+        kpop_amd.use_device(s)
+        pb, po = dmalloc((hi - lo) * L), dmalloc((hi - lo + 1) * 8)
+        kpop_amd.check(lib.kpop_dev_synth_reads(READ_SEED, hi - lo, L, lo, pb, po, None))
+        kpop_amd.check(lib.kpop_synchronize(None))
+        d_bases.append(pb.value)
+        d_offs.append(po.value)
+        n_reads.append(hi - lo)
+        n_bases.append((hi - lo) * L)
+    kpop_amd.use_device(0)
+    chunks = args.ag_chunks if args.ag_chunks > 0 else max(4, N)
+    gather = N > 1 or args.force_dist
+    startup_s = time.perf_counter() - t_start
+
+    def step():
+        sh.resident_step(d_bases, d_offs, n_reads, n_bases, L, chunks=chunks if gather else 1, gather=gather)
+    for _ in range(args.warmup):
+        step()
+    t0 = time.perf_counter()
+    tm = []
+    for _ in range(args.steps):
+        step()  # returns when every device is done and every copy of the matrix is complete
+        tm.append([sh.timings(s) for s in range(N)])
+    elapsed = time.perf_counter() - t0
+    exposed = [float(np.mean([t[s]["ms_exposed_comm"] for t in tm])) for s in range(N)]
+    compute = [float(np.mean([t[s]["ms_compute"] for t in tm])) for s in range(N)]
+    # is every copy of the gathered matrix the union of the shards?  order-free checksum of the f64 bit patterns
+    ok = None
+    if gather:
+        sums = []
+        for s in sorted({0, N - 1}):
+            full, first, rows, _ = sh.resident_buffers(s)
+            kpop_amd.use_device(s)
+            host = np.zeros((reads, d))
+            kpop_amd.check(lib.kpop_memcpy_d2h(host.ctypes.data, full, host.nbytes))
+            sums.append((int(host.view(np.int64).sum()), [int(host[a:b].view(np.int64).sum()) for a, b in
+                                                          (kpop_amd.shard_bounds(reads, r, N) for r in range(N))]))
+        kpop_amd.use_device(0)
+        ok = all(x == sums[0] for x in sums)
+    q = max(1, args.queries // N)
+    t0 = time.perf_counter()
+    qid, stats, nn, idx, dd, z = sh.all_vs_all_summary(queries_per_slot=q, keep_at_most=2, max_neighbours=8) if gather or N == 1 else (None,) * 6
+    ava = time.perf_counter() - t0
+    own = bool(qid is not None and all(dd[j, 0] == 0.0 and int(qid[j]) in idx[j, :min(int(nn[j]), 8)].tolist() for j in range(len(qid))))
+    windows = max(L - k + 1, 0)
+    per_read = L + windows * d * 8 + d * 8
+    chunk_rows = -(-max(n_reads) // (chunks if gather else 1))
+    line = {
+        "metric": "sequences/sec end-to-end count->twist->all-gather->distance, k=%d, %dk x %dbp in total" % (k, reads // 1000, L),
+        "value": reads * args.steps / elapsed, "unit": "sequences/sec", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "value_is": "device-resident; the all-gather of the twisted vectors is inside the timed region",
+        "launcher": "in-process: one process, kpop_init_devices + kpop_sharded_resident_step (one host thread per device, "
+                    "hipMemcpyPeerAsync pushes on one stream per destination); no torch.distributed, no RCCL",
+        "config": {"read_len": L, "k": k, "n_dims": d, "n_classes": Cn, "class_len": args.class_len,
+                   "workload": "BASELINE config 4: %d reads x %d bp in total, k=%d DNA-ds, sharded over %d GPU(s); twist in %d chunks, "
+                               "every finished chunk pushed to all peers under the next; distances of the shard's rows to %d class vectors"
+                               % (reads, L, k, N, chunks if gather else 1, Cn),
+                   "reads_per_gpu": max(n_reads),
+                   "sharding": "reads in contiguous shards (kpop_shard_bounds); twister, classes and metric replicated; ONE exchange: "
+                               "all-gather of twisted vectors by peer copies over xGMI"},
+        "roofline": {"kernel": "count_twist_wave_kernel", "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                     "traffic": None, "algorithmic_bytes_per_launch": chunk_rows * per_read,
+                     "note": "per-kernel events are taken in the torch.distributed mode and the 1-GPU line; this mode reports host wall time per device"},
+        "per_device_ms": {"compute_until_kernels_done": compute, "exposed_comm": exposed},
+        "startup_s": startup_s,
+        "gather_checksum_ok": ok,
+        "all_vs_all": {"queries_total": 0 if qid is None else int(len(qid)), "against": reads, "seconds": ava,
+                       "every_query_finds_itself_at_distance_0": own},
+    }
+    if shared:
+        line["config"]["rig"] = "KPOP_BENCH_SHARE_GPU=1: every device slot is GPU 0; not a scaling number"
+    sh.close()
+    print(json.dumps(line))
+
+
 def main():
     args = parse_args()
     if args.gpus < 1:
         sys.exit("--gpus must be positive")
+    if args.in_process:
+        in_process(args)
+        return
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
         self_launch(args)  # never returns
     workload = args.workload if args.workload != "auto" else ("headline" if args.gpus == 1 else "config4")
@@ -586,6 +724,8 @@ def main():
                                    "one launch per chunk of %d reads, overlapped with the exchange of the previous chunk" % res["chunk_rows"]),
             "kernels_ms": {"count_twist_per_step": res["ms_twist_step"], "distance_rowwise(+norms)": res["ms_dist"],
                            "allgather_on_its_stream_per_step": res.get("ms_allgather_step_on_its_stream")},
+            "exposed_comm_ms_per_rank": res.get("ms_exposed_comm_per_rank"),
+            "startup_s_per_rank": res.get("startup_s_per_rank"),
             "collective": res.get("allgather"),
             "gather_checksum_ok": res.get("gather_checksum_ok"),
             "all_vs_all": res["all_vs_all"],

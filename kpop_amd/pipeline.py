@@ -160,7 +160,11 @@ class ShardedJob:
         self.compute.distance_to_classes(self.local[:self.n_local], self.dmat)
         self._mark_end(ev, cur)
         if self.is_cuda and self.comm_stream is not None and self.full is not None:
-            cur.wait_stream(self.comm_stream)  # the step ends when every rank's rows have arrived
+            # the step ends when every rank's rows have arrived; what the compute stream still waits for here is the
+            # EXPOSED part of the exchange (the rest travelled under the twist)
+            ev = self._mark(events, "exposed", cur)
+            cur.wait_stream(self.comm_stream)
+            self._mark_end(ev, cur)
 
     def _mark(self, events, key, stream):
         if events is None or not self.is_cuda:

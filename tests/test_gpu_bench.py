@@ -45,3 +45,21 @@ def test_round_one_mode_still_runs_two_ranks():
     j = _bench(["--gpus", "2", "--workload", "headline", "--scaling", "weak", "--reads", "20000", "--steps", "2", "--warmup", "1"],
                env={"KPOP_BENCH_SHARE_GPU": "1"})
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["reads_per_gpu"] == 20000
+
+
+@pytest.mark.parametrize("n", [1, 3])
+def test_in_process_mode_through_the_c_abi(n):
+    """`--in-process`: every device slot driven from one process through kpop_sharded_* (slots aliased to GPU 0 here)"""
+    j = _bench(["--gpus", str(n), "--in-process", "--reads", "40001", "--steps", "2", "--warmup", "1", "--queries", "60", "--force-dist"],
+               env={"KPOP_BENCH_SHARE_GPU": "1"})
+    assert j["n_gpus"] == n and j["scaling"] == "strong" and j["value"] > 0
+    assert j["launcher"].startswith("in-process")
+    assert j["gather_checksum_ok"] is True
+    assert len(j["per_device_ms"]["exposed_comm"]) == n
+    assert j["all_vs_all"]["every_query_finds_itself_at_distance_0"] is True and j["all_vs_all"]["queries_total"] == 60 // n * n
+
+
+def test_config4_reports_exposed_comm_and_startup():
+    j = _bench(["--gpus", "2", "--reads", "40000", "--steps", "2", "--warmup", "1", "--queries", "16"], env={"KPOP_BENCH_SHARE_GPU": "1"})
+    assert len(j["exposed_comm_ms_per_rank"]) == 2 and len(j["startup_s_per_rank"]) == 2
+    assert "4 chunks" in j["config"]["workload"]  # --ag-chunks 0 = max(4, GPUs)
