@@ -304,7 +304,10 @@ int kpop_distance_rowwise(const double *m1, uint32_t r1, const double *m2, uint3
  * closest m1 rows, whole tie groups included (:648-649).  Neighbour outputs
  * have a fixed stride max_neighbours per row; out_n[j] is the reference's
  * eff_len (may exceed max_neighbours: entries beyond the stride are dropped).
- * keep_at_most=0 means "all" (:723-726).  The r2 x r1 matrix is never formed. */
+ * keep_at_most=0 means "all" (:723-726).  The r2 x r1 matrix is never formed.
+ * Against a first operand of more than 4,096 rows at most 2,048 neighbours come back per row; a row whose list is
+ * longer (keep_at_most = all, a tie group of thousands) makes the host entry points fail with KPOP_ERR_UNSUPPORTED
+ * rather than return a list they cannot fill (the device entry points only report out_n). */
 int kpop_distance_summary(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
                           const double *metric, int kind, double p, int normalize, uint32_t keep_at_most,
                           uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
@@ -354,6 +357,9 @@ int kpop_dev_workspace_reserve_stream(uint64_t bytes, void *stream);
 int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bases, const uint64_t *d_offsets,
                          uint32_t n_reads, uint64_t n_bases, uint32_t max_len, int content, int normalize,
                          double *d_out, void *stream);
+/* max_lines = lines of the longest spectrum of the batch, or 0 when the caller does not know: up to 512 the kernel keeps
+   the columns it finds while summing the counts (lib/Twister.ml:158) for the products (:183) instead of looking them up
+   twice.  A spectrum longer than a non-zero max_lines says comes back as a row of NaNs.                              */
 int kpop_dev_twist(const kpop_twister *tw, const uint64_t *d_hash, const double *d_value,
                    const uint64_t *d_offsets, uint32_t n_spectra, uint64_t max_lines, int normalize,
                    double *d_out, void *stream);
@@ -365,6 +371,14 @@ uint64_t kpop_dev_twist_dense_workspace_bytes(const kpop_twister *tw, uint32_t n
 int kpop_dev_twist_dense(const kpop_twister *tw, const uint64_t *d_hash, const double *d_value,
                          const uint64_t *d_offsets, uint32_t n_spectra, int normalize, void *d_work, double *d_out,
                          void *stream);
+/* The same for spectra whose lines ASCEND BY HASH (the order kpop_count_reads / kpop_dev_count_reads produce; repeated
+   and unknown k-mers allowed): the spectra are densified inside the contraction -- 64 spectra x 128 twister rows at a
+   time in LDS, v_mfma_f64_16x16x4_f64 against the twister's rows from L2 -- with no dense image in HBM.  acc
+   (lib/Twister.ml:158) is applied once to the finished sums.  A spectrum whose lines do not ascend comes back as a row of
+   NaNs.  Same workspace.                                                                                            */
+int kpop_dev_twist_dense_sorted(const kpop_twister *tw, const uint64_t *d_hash, const double *d_value,
+                                const uint64_t *d_offsets, uint32_t n_spectra, int normalize, void *d_work,
+                                double *d_out, void *stream);
 /* kpop_ca on device-resident data: d_counts (n_kmers x n_spectra, row-major, not modified) in, d_twisted (n_spectra x
    n_dims), d_inertia (n_dims) and d_twister (n_dims x n_kmers, dims-major) out, all device pointers; *n_dims_out is a
    host word.  d_work needs kpop_dev_ca_workspace_bytes() (the standardised copy of the table).  The weights of the

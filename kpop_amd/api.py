@@ -690,6 +690,12 @@ def dev_twist_dense(tw, d_hash, d_value, d_offsets, n_spectra, d_work, d_out, no
                                            d_out, stream))
 
 
+def dev_twist_dense_sorted(tw, d_hash, d_value, d_offsets, n_spectra, d_work, d_out, normalize=True, stream=0):
+    """kpop_dev_twist_dense_sorted: lines ascending by hash, densified inside the contraction (no X in HBM)"""
+    check(_lib.load().kpop_dev_twist_dense_sorted(tw.handle, d_hash, d_value, d_offsets, int(n_spectra), 1 if normalize else 0, d_work,
+                                                  d_out, stream))
+
+
 def dev_distance_workspace_bytes(r1, r2, n_dims):
     return int(_lib.load().kpop_dev_distance_workspace_bytes(int(r1), int(r2), int(n_dims)))
 

@@ -265,7 +265,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void count_twist_wave_kernel(
 // ---------------------------------------------------------------------------
 // U = row loads in flight per wave: 8 when there is a wave per SIMD slot anyway (read spectra by the hundred thousand), 32
 // when a few thousand long spectra leave two waves per SIMD and the latency of each batch of loads shows (genomes).
-template <typename V, int U = kGatherUnroll>  // V double: spectra as parsed from text; uint32_t: counts straight from the counting kernels
+// KEEP > 0: every spectrum has at most 64 * KEEP lines, so the columns and values found by pass 1 stay in registers (KEEP
+// per lane) and pass 2 neither reads the hashes nor walks the name -> row index again -- round 2 did both twice: 1.33 x
+// the algorithmic traffic on 100,000 read spectra.  Same lines in the same order, same arithmetic: identical results.
+template <typename V, int U = kGatherUnroll, int KEEP = 0>  // V double: spectra as parsed from text; uint32_t: counts straight from the counting kernels
 __global__ __launch_bounds__(64 * kWavesPerBlock) void twist_csr_kernel(
     TwisterView tv, const uint64_t *__restrict__ hash, const V *__restrict__ value,
     const uint64_t *__restrict__ offsets, uint32_t n, int normalize, double *__restrict__ out) {
@@ -275,10 +278,32 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void twist_csr_kernel(
   const uint32_t s = blockIdx.x * kWavesPerBlock + wv;
   if (s >= n) return;
   const uint64_t lo = offsets[s], hi = offsets[s + 1];
+  if (KEEP > 0 && hi - lo > 64ull * KEEP) {
+    // the caller's max_lines understated this spectrum: a row of NaNs says so (never a silently shortened sum)
+    for (uint32_t d = lane; d < tv.n_dims; d += 64) out[(uint64_t)s * tv.n_dims + d] = __longlong_as_double(0x7FF8000000000000ll);
+    return;
+  }
   // pass 1: acc over lines whose k-mer the twister knows
+  constexpr int NK = KEEP > 0 ? KEEP : 1;
+  uint32_t kcol[NK];
+  double kval[NK];
   double part = 0.0;
-  for (uint64_t i = lo + lane; i < hi; i += 64)
-    if (lookup_col(tv, hash[i]) != kNoCol) part += (double)value[i];
+  if (KEEP > 0) {
+#pragma unroll
+    for (int q = 0; q < NK; ++q) {
+      const uint64_t i = lo + (uint64_t)q * 64 + lane;
+      kcol[q] = kNoCol;
+      kval[q] = 0.0;
+      if (i < hi) {
+        kcol[q] = lookup_col(tv, hash[i]);
+        kval[q] = (double)value[i];
+        if (kcol[q] != kNoCol) part += kval[q];
+      }
+    }
+  } else {
+    for (uint64_t i = lo + lane; i < hi; i += 64)
+      if (lookup_col(tv, hash[i]) != kNoCol) part += (double)value[i];
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
   const double acc = part;
@@ -289,11 +314,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void twist_csr_kernel(
     const uint32_t d = d0 + lane;
     const bool active = d < n_dims;
     double t = 0.0;
-    for (uint64_t i0 = lo; i0 < hi; i0 += 64) {
+    int q = 0;
+    for (uint64_t i0 = lo; i0 < hi; i0 += 64, ++q) {
       const uint64_t i = i0 + lane;
       uint32_t col = kNoCol;
       double x = 0.0;
-      if (i < hi) {
+      if (KEEP > 0) {
+        // (a constant-index walk of the register arrays: q is uniform over the wave)
+#pragma unroll
+        for (int qq = 0; qq < NK; ++qq)
+          if (qq == q) {
+            col = kcol[qq];
+            x = norm ? kval[qq] / acc : kval[qq];
+          }
+      } else if (i < hi) {
         col = lookup_col(tv, hash[i]);
         x = norm ? (double)value[i] / acc : (double)value[i];
       }
@@ -326,6 +360,32 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void twist_csr_kernel(
     }
     if (active) out[(uint64_t)s * n_dims + d] = t;
   }
+}
+
+// launch by the longest spectrum of the batch: <= 512 lines keeps pass 1's columns in registers
+template <typename V>
+static int launch_twist_csr(const TwisterView &tv, const uint64_t *hash, const V *value, const uint64_t *offsets, uint32_t n,
+                            uint64_t max_lines, int normalize, double *out, hipStream_t st) {
+  const dim3 grid(div_up(n, kWavesPerBlock)), block(64 * kWavesPerBlock);
+  const bool few = n <= kFewSpectra;
+  if (max_lines == 0 || max_lines > 512) {
+    if (few) twist_csr_kernel<V, 32><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);
+    else twist_csr_kernel<V><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);
+  } else if (max_lines <= 64) {
+    if (few) twist_csr_kernel<V, 32, 1><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);
+    else twist_csr_kernel<V, kGatherUnroll, 1><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);
+  } else if (max_lines <= 128) {
+    if (few) twist_csr_kernel<V, 32, 2><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);
+    else twist_csr_kernel<V, kGatherUnroll, 2><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);
+  } else if (max_lines <= 256) {
+    if (few) twist_csr_kernel<V, 32, 4><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);
+    else twist_csr_kernel<V, kGatherUnroll, 4><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);
+  } else {
+    if (few) twist_csr_kernel<V, 32, 8><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);
+    else twist_csr_kernel<V, kGatherUnroll, 8><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);
+  }
+  KPOP_LAUNCH_CHECK();
+  return 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -681,17 +741,12 @@ extern "C" int kpop_dev_twist(const kpop_twister *tw, const uint64_t *d_hash, co
                               const uint64_t *d_offsets, uint32_t n_spectra, uint64_t max_lines, int normalize,
                               double *d_out, void *stream) {
   KPOP_TRY(require_init());
-  (void)max_lines;
   if (!tw || !d_offsets || !d_out) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_twist: null argument");
   if (n_spectra == 0) return KPOP_OK;
-  if (n_spectra <= kFewSpectra)
-    twist_csr_kernel<double, 32><<<dim3(div_up(n_spectra, kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, as_stream(stream)>>>(
-        view_of(tw), d_hash, d_value, d_offsets, n_spectra, normalize, d_out);
-  else
-    twist_csr_kernel<double><<<dim3(div_up(n_spectra, kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, as_stream(stream)>>>(
-        view_of(tw), d_hash, d_value, d_offsets, n_spectra, normalize, d_out);
-  KPOP_LAUNCH_CHECK();
-  return KPOP_OK;
+  // max_lines = the longest spectrum of the batch (0 = unknown): up to 512 lines the columns found while summing the
+  // counts stay in registers for the gather.  Callers pass 0 when they do not know; a spectrum longer than max_lines says
+  // comes back as a row of NaNs.
+  return launch_twist_csr<double>(view_of(tw), d_hash, d_value, d_offsets, n_spectra, max_lines, normalize, d_out, as_stream(stream));
 }
 
 // ---------------------------------------------------------------------------
@@ -848,9 +903,8 @@ extern "C" int kpop_spectra_twist(const kpop_twister *tw, const uint8_t *bases, 
       KPOP_TRY(d_oc.alloc(worst * 4));
       KPOP_TRY(launch_count_wave(R, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), n_reads, k, content, d_scr.p, d_oh.as<uint64_t>(),
                                  d_oc.as<uint32_t>(), d_oo.as<uint64_t>(), st));
-      twist_csr_kernel<uint32_t><<<dim3(div_up(n_reads, kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, st>>>(
-          tv, d_oh.as<uint64_t>(), d_oc.as<uint32_t>(), d_oo.as<uint64_t>(), n_reads, normalize, d_out.as<double>());
-      KPOP_LAUNCH_CHECK();
+      KPOP_TRY(launch_twist_csr<uint32_t>(tv, d_oh.as<uint64_t>(), d_oc.as<uint32_t>(), d_oo.as<uint64_t>(), n_reads, max_windows, normalize,
+                                          d_out.as<double>(), st));
     }
   } else {
     // genomes: sort path, in sub-batches whose (spectrum id | hash) keys fit 63 bits, then the line-by-line twist
@@ -861,15 +915,8 @@ extern "C" int kpop_spectra_twist(const kpop_twister *tw, const uint8_t *bases, 
       ArenaScope batch;
       SortedSpectra S;
       KPOP_TRY(sorted_count_device(bases, offsets + r0, nr, k, content, 1, ~0ull, S, st));
-      if (nr <= kFewSpectra)
-        twist_csr_kernel<uint32_t, 32><<<dim3(div_up(nr, kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, st>>>(
-            tv, S.d_oh.as<uint64_t>(), S.d_oc.as<uint32_t>(), S.d_oo.as<uint64_t>(), nr, normalize,
-            d_out.as<double>() + r0 * tw->n_dims);
-      else
-        twist_csr_kernel<uint32_t><<<dim3(div_up(nr, kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, st>>>(
-            tv, S.d_oh.as<uint64_t>(), S.d_oc.as<uint32_t>(), S.d_oo.as<uint64_t>(), nr, normalize,
-            d_out.as<double>() + r0 * tw->n_dims);
-      KPOP_LAUNCH_CHECK();
+      KPOP_TRY(launch_twist_csr<uint32_t>(tv, S.d_oh.as<uint64_t>(), S.d_oc.as<uint32_t>(), S.d_oo.as<uint64_t>(), nr, 0, normalize,
+                                          d_out.as<double>() + r0 * tw->n_dims, st));
       KPOP_HIP(hipStreamSynchronize(st));  // the batch's scratch goes back to the arena at the end of this scope
     }
   }
@@ -908,8 +955,21 @@ extern "C" int kpop_twist(const kpop_twister *tw, const uint64_t *hash, const do
   if (dense == 1 || (dense == 2 && n_spectra >= 256 && tw->n_rows > 0 && (double)n_lines >= 0.4 * (double)n_spectra * (double)tw->n_rows)) {
     DevBuf d_work;
     KPOP_TRY(d_work.alloc(kpop_dev_twist_dense_workspace_bytes(tw, n_spectra)));
-    KPOP_TRY(kpop_dev_twist_dense(tw, d_h.as<uint64_t>(), d_v.as<double>(), d_off.as<uint64_t>(), n_spectra, normalize, d_work.p,
-                                  d_out.as<double>(), st));
+    // lines ascending by hash in every spectrum (what KPopCount writes; the reference's own Hashtbl order is unspecified):
+    // the fused kernel densifies them inside the contraction; any other order goes through the dense image in HBM
+    bool ascending = true;
+    for (uint32_t r = 0; r < n_spectra && ascending; ++r)
+      for (uint64_t i = offsets[r] + 1; i < offsets[r + 1]; ++i)
+        if (hash[i] < hash[i - 1]) {
+          ascending = false;
+          break;
+        }
+    if (ascending)
+      KPOP_TRY(kpop_dev_twist_dense_sorted(tw, d_h.as<uint64_t>(), d_v.as<double>(), d_off.as<uint64_t>(), n_spectra, normalize, d_work.p,
+                                           d_out.as<double>(), st));
+    else
+      KPOP_TRY(kpop_dev_twist_dense(tw, d_h.as<uint64_t>(), d_v.as<double>(), d_off.as<uint64_t>(), n_spectra, normalize, d_work.p,
+                                    d_out.as<double>(), st));
   } else {
     KPOP_TRY(kpop_dev_twist(tw, d_h.as<uint64_t>(), d_v.as<double>(), d_off.as<uint64_t>(), n_spectra, max_lines,
                             normalize, d_out.as<double>(), st));

@@ -871,6 +871,20 @@ static int embeddings_impl(const double *d_m, uint32_t rows, uint32_t n_dims, co
   return 0;
 }
 
+// Against more than kSummaryMaxR1 rows the summary returns at most kLargeNeighbours neighbours per row
+// (summary_large.hip).  A row whose list is longer (--summary-keep-at-most all, or a tie group of thousands) cannot be
+// written out from what came back: the host entry points say so instead of handing over rows of zeros.
+constexpr uint32_t kLargeNeighbours = 2048;
+static int check_large_neighbour_lists(uint32_t r1, uint32_t r2, uint32_t max_neighbours, const uint32_t *out_n) {
+  if (r1 <= kSummaryMaxR1 || max_neighbours <= kLargeNeighbours) return KPOP_OK;
+  for (uint32_t j = 0; j < r2; ++j)
+    if (out_n[j] > kLargeNeighbours)
+      KPOP_FAIL(KPOP_ERR_UNSUPPORTED,
+                "summary: row %u lists %u neighbours; against a first operand of more than %u rows at most %u are returned per row "
+                "(keep_at_most = all, or a tie group that large, is not supported there)", j, out_n[j], kSummaryMaxR1, kLargeNeighbours);
+  return KPOP_OK;
+}
+
 static int check_kind(int kind, double p, const char *who) {
   if (kind != KPOP_EUCLIDEAN && kind != KPOP_COSINE && kind != KPOP_MINKOWSKI)
     KPOP_FAIL(KPOP_ERR_INVALID, "%s: unknown distance kind %d", who, kind);
@@ -1032,7 +1046,7 @@ extern "C" int kpop_summarize_distances(const double *dist, uint32_t r2, uint32_
     KPOP_HIP(hipMemcpyAsync(out_z, dz.p, nn * 8, hipMemcpyDeviceToHost, st));
   }
   KPOP_HIP(hipStreamSynchronize(st));
-  return KPOP_OK;
+  return check_large_neighbour_lists(r1, r2, max_neighbours, out_n);
 }
 
 extern "C" int kpop_distance_rowwise(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
@@ -1097,5 +1111,5 @@ extern "C" int kpop_distance_summary(const double *m1, uint32_t r1, const double
     KPOP_HIP(hipMemcpyAsync(out_z, dz.p, nn * 8, hipMemcpyDeviceToHost, st));
   }
   KPOP_HIP(hipStreamSynchronize(st));
-  return KPOP_OK;
+  return check_large_neighbour_lists(r1, r2, max_neighbours, out_n);
 }

@@ -19,7 +19,7 @@
 namespace kpop {
 
 constexpr int kLT = 1024;             // threads per row
-constexpr uint32_t kLargeMaxNb = 2048;  // neighbours returned per row at most
+constexpr uint32_t kLargeMaxNb = 2048;  // neighbours returned per row at most (= kLargeNeighbours, distance.hip)
 
 __device__ __forceinline__ uint64_t f64_key(double x) {  // order-preserving map to u64
   const uint64_t b = (uint64_t)__double_as_longlong(x);

@@ -185,6 +185,22 @@ def test_distance_summary_large_reference_set(kpop, oracle, r1, keep, kind):
         np.testing.assert_allclose(z[j, :m], z_o[a:a + m], rtol=1e-8, atol=1e-9)
 
 
+def test_large_reference_set_refuses_lists_it_cannot_fill(kpop, oracle):
+    """against more than 4,096 rows at most 2,048 neighbours come back per row: a caller that asks for more room than
+    that (keep_at_most = all) gets an error, not rows of zeros (KPopTwistDB then exits 1 instead of printing them)"""
+    rng = np.random.RandomState(1)
+    m1, m2 = rng.normal(size=(5000, 8)), rng.normal(size=(3, 8))
+    metric = oracle.metric_powers(oracle.synth_inertia(8))
+    with pytest.raises(kpop.KPopError) as e:
+        kpop.distance_summary(m1, m2, metric, keep_at_most=0, max_neighbours=5000)
+    assert "2048" in str(e.value)
+    dm = kpop.distance_rowwise(m1, m2, metric)
+    with pytest.raises(kpop.KPopError):
+        kpop.summarize_distances(dm, keep_at_most=0, max_neighbours=5000)
+    st, n, idx, dist, z = kpop.distance_summary(m1, m2, metric, keep_at_most=0, max_neighbours=2048)  # truncated by the caller's own stride
+    assert n.tolist() == [5000] * 3
+
+
 def test_summarize_distances_large_row_with_ties(kpop, oracle):
     rng = np.random.RandomState(2)
     dm = np.round(rng.rand(6, 10000), 3)  # ~10 entries per distinct value: tie groups everywhere

@@ -363,7 +363,7 @@ def test_config3_50k_genomes_full_size(kpop, oracle):
     assert all(int(o[i + 1] - o[i]) > 29000 for i in range(len(pick)))     # ~29,989 distinct-ish 12-mers per genome
 
 
-@pytest.mark.parametrize("k,d,n", [(5, 64, 300), (7, 9, 129), (8, 100, 40)])
+@pytest.mark.parametrize("k,d,n", [(5, 64, 300), (7, 9, 129), (8, 100, 40), (9, 256, 70), (6, 200, 65)])
 def test_dense_twist_on_the_matrix_cores_equals_the_sparse_one(kpop, oracle, k, d, n):
     """kpop_dev_twist_dense (spectra as a dense matrix times the twister's rows, f64 MFMA) against kpop_dev_twist: the same
     sums in the GEMM's order, equal to rounding; unknown k-mers, duplicate lines, an empty spectrum, normalisation on and off"""
@@ -396,6 +396,28 @@ def test_dense_twist_on_the_matrix_cores_equals_the_sparse_one(kpop, oracle, k, 
         assert np.max(np.abs(a - b)) <= 1e-12 * max(np.max(np.abs(a)), 1.0)
         want = oracle.twist(oracle.synth_twister(5, d, cols), cols, h, v, o, normalize=normalize)
         assert np.max(np.abs(b - want)) <= 1e-12 * max(np.max(np.abs(want)), 1.0)
+    # the fused form takes lines that ascend by hash (repeats and unknown k-mers stay): sort every spectrum's lines
+    order = np.concatenate([offs[i] + np.argsort(h[offs[i]:offs[i + 1]], kind="stable") for i in range(n)]) if len(h) else np.zeros(0, dtype=np.int64)
+    hs_, vs_ = h[order], v[order]
+    dh2, dv2 = torch.from_numpy(hs_.view(np.int64)).to(dev), torch.from_numpy(vs_).to(dev)
+    for normalize in (True, False):
+        c = torch.full((n, d), 7.0, dtype=torch.float64, device=dev)
+        api.dev_twist_dense_sorted(tw, dh2.data_ptr(), dv2.data_ptr(), do.data_ptr(), n, work.data_ptr(), c.data_ptr(), normalize=normalize)
+        torch.cuda.synchronize()
+        c = c.cpu().numpy()
+        want = oracle.twist(oracle.synth_twister(5, d, cols), cols, hs_, vs_, o, normalize=normalize)
+        assert np.all(c[3] == 0.0)
+        assert np.max(np.abs(c - want)) <= 1e-12 * max(np.max(np.abs(want)), 1.0), np.max(np.abs(c - want))
+    # lines that do NOT ascend: that spectrum (and only it) comes back as NaNs
+    bad = next(i for i in range(n) if offs[i + 1] - offs[i] >= 3 and len(np.unique(hs_[offs[i]:offs[i + 1]])) >= 2)
+    hb = hs_.copy()
+    seg = hb[offs[bad]:offs[bad + 1]]
+    seg[0], seg[-1] = seg[-1], seg[0]
+    c = torch.zeros(n, d, dtype=torch.float64, device=dev)
+    api.dev_twist_dense_sorted(tw, torch.from_numpy(hb.view(np.int64)).to(dev).data_ptr(), dv2.data_ptr(), do.data_ptr(), n, work.data_ptr(), c.data_ptr())
+    torch.cuda.synchronize()
+    c = c.cpu().numpy()
+    assert np.isnan(c[bad]).all() and not np.isnan(np.delete(c, bad, axis=0)).any()
 
 
 def test_understated_max_len_yields_nan_rows_not_stale_memory(kpop, oracle):

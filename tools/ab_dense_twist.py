@@ -50,22 +50,25 @@ def main():
         out2 = torch.zeros(n, d, dtype=torch.float64, device=dev)
         work = torch.empty(api.dev_twist_dense_workspace_bytes(tw, n), dtype=torch.uint8, device=dev)
         t1 = timed(lambda: api.dev_twist(tw, dh.data_ptr(), dv.data_ptr(), do.data_ptr(), n, 0, out1.data_ptr(), stream=st.cuda_stream))
-        t2 = timed(lambda: api.dev_twist_dense(tw, dh.data_ptr(), dv.data_ptr(), do.data_ptr(), n, work.data_ptr(), out2.data_ptr(), stream=st.cuda_stream))
+        t3 = timed(lambda: api.dev_twist_dense(tw, dh.data_ptr(), dv.data_ptr(), do.data_ptr(), n, work.data_ptr(), out2.data_ptr(), stream=st.cuda_stream))
+        t2 = timed(lambda: api.dev_twist_dense_sorted(tw, dh.data_ptr(), dv.data_ptr(), do.data_ptr(), n, work.data_ptr(), out2.data_ptr(), stream=st.cuda_stream))
         a, b = out1.cpu().numpy(), out2.cpu().numpy()
         rel = float(np.max(np.abs(a - b)) / max(np.max(np.abs(a)), 1e-300))
         rows = tw.info()["n_cols"]
         flops = 2.0 * n * rows * d
         nnz = len(h)
-        print("%-44s spectra %6d  lines/spectrum %7.0f of %9d columns (%.2f %%)  sparse %9.3f ms  dense %9.3f ms  (%5.2fx)  dense %5.1f TFLOP/s = %.2f of 78.6  max rel diff %.1e"
-              % (label, n, nnz / n, rows, 100.0 * nnz / n / rows, t1, t2, t1 / t2, flops / t2 / 1e9, flops / t2 / 1e9 / 78.6, rel), flush=True)
+        print("%-44s spectra %6d  lines/spectrum %7.0f of %9d columns (%.2f %%)  sparse %9.3f ms  dense(fused) %9.3f ms  (%5.2fx)  %5.1f TFLOP/s = %.2f of 78.6  | dense(image in HBM, round 2) %9.3f ms = %.2f  max rel diff %.1e"
+              % (label, n, nnz / n, rows, 100.0 * nnz / n / rows, t1, t2, t1 / t2, flops / t2 / 1e9, flops / t2 / 1e9 / 78.6, t3, flops / t3 / 1e9 / 78.6, rel), flush=True)
 
     n_g = int(os.environ.get("AB_GENOMES", "4096"))
     gb, go = O.synth_reads(0xC1A55, n_g, 30000)
-    for k in (7, 8, 9, 10):
+    for k in [int(x) for x in os.environ.get("AB_KS", "7,8,9,10").split(",")]:
         tw = kpop_amd.Twister.synth(0x5EED, k, d)
         h, c, o = kpop_amd.count_reads(gb, go, k)
         case("genomes 30 kb, k=%d" % k, tw, h, c, o)
         tw.free()
+    if os.environ.get("AB_ONLY_GENOMES"):
+        return
     # class spectra against a trained-like twister
     k = 12
     cb, co = O.synth_reads(0xC1A55, 65, 30000)
