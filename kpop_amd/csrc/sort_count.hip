@@ -200,6 +200,205 @@ __global__ __launch_bounds__(256) void read_hist_kernel(const uint8_t *__restric
   }
 }
 
+// (the padded LDS index and the register-blocked network pass of count_block_kernel, further down, are shared with the
+// chunk sort of the merged histogram)
+constexpr uint32_t kBlockSortMax = 32768;
+#define KEY(i) ((i) + ((i) >> 5))  // LDS index of key i: one word of padding per 32
+
+// one pass of the register-blocked bitonic network (count_block_kernel): 2^GB keys per (virtual) thread
+template <int GB>
+__device__ __forceinline__ void bitonic_group_pass(uint32_t *s_key, uint32_t NP, uint32_t sz, int h, int lo) {
+  constexpr int E = 1 << GB;
+  const uint32_t n_groups = NP >> GB;
+  for (uint32_t vt = threadIdx.x; vt < n_groups; vt += 1024) {
+    const uint32_t base = ((vt >> lo) << (h + 1)) | (vt & ((1u << lo) - 1u));
+    const bool asc = (base & sz) == 0;
+    uint32_t rk[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) rk[e] = s_key[KEY(base | ((uint32_t)e << lo))];
+#pragma unroll
+    for (int j = GB - 1; j >= 0; --j) {
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (!(e & (1 << j))) {
+          const uint32_t x = rk[e], y = rk[e | (1 << j)];
+          const uint32_t mn = min(x, y), mx = max(x, y);
+          rk[e] = asc ? mn : mx;
+          rk[e | (1 << j)] = asc ? mx : mn;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) s_key[KEY(base | ((uint32_t)e << lo))] = rk[e];
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// LDS-staged forms of the merged histogram (north_star: "LDS-staged per-block counts").
+//
+// (a) SMALL TABLES (hash_bits <= 14: DNA k <= 7, 64 KB of counters): every block owns a private copy of the whole table in
+//     LDS, adds its windows there (ds_add_u32) and hands each non-zero counter to the global table with ONE atomic at the
+//     end.  Without this, 150 million windows of 5,000 genomes hammer 8,192 global counters.
+// (b) ASSEMBLIES OF ONE ORGANISM (BASELINE config 3's case): a block takes the SAME stretch of kCombSeg windows of
+//     kCombReads consecutive sequences -- near-identical genomes put the same k-mers there -- and counts them in an LDS
+//     table of 8,192 (hash, count) slots (open addressing: ds_cmpst on the hash, ds_add on the count, eight probes, then
+//     straight to the global table); the flush issues ONE global atomic per distinct k-mer of the chunk: a 32-byte sector
+//     per distinct k-mer instead of one per window.  (Sorting the chunk's 32,768 hashes in LDS instead was measured:
+//     2.97 ms against 7.04 direct on 5,000 mutants of one genome; the table does the same combining without the 120
+//     levels of the network.)  A block whose first chunk shows no repetition (unrelated sequences: distinct > 3/4 of the
+//     windows) stops staging and adds its remaining windows directly, as window_hist_kernel does.
+// ---------------------------------------------------------------------------
+constexpr int kHistLdsBits = 14;
+
+template <int SB>
+__global__ __launch_bounds__(1024) void window_hist_lds_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets,
+                                                               int k, int content, int hash_bits_, uint32_t *__restrict__ table,
+                                                               uint32_t n_reads, uint32_t max_seg) {
+  extern __shared__ uint32_t s_tab[];
+  const uint32_t n_bins = 1u << hash_bits_;
+  for (uint32_t b = threadIdx.x; b < n_bins; b += 1024) s_tab[b] = 0;
+  __syncthreads();
+  const uint64_t n_pairs = (uint64_t)n_reads * max_seg;
+  const int shift = SB * (k - 1);
+  constexpr uint32_t kSym = (1u << SB) - 1u, kValid = SB == 2 ? 4u : 20u;
+  const uint32_t mask = (uint32_t)bits_mask(SB * k);
+  for (uint64_t pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+    const uint32_t r = (uint32_t)(pair / max_seg);
+    const uint64_t off = offsets[r], len = offsets[r + 1] - off;
+    if (len < (uint64_t)k) continue;
+    const uint64_t n_win = len - k + 1;
+    const uint64_t w0 = (uint64_t)(pair % max_seg) * kKeySeg;
+    if (w0 >= n_win) continue;
+    const uint64_t w1 = min(n_win, w0 + kKeySeg);
+    const uint8_t *seq = bases + off;
+    // a thread rolls the hash over a run of consecutive windows
+    const uint32_t per = (uint32_t)((w1 - w0 + 1023) / 1024);
+    const uint64_t a = w0 + (uint64_t)threadIdx.x * per, b = min(w1, a + per);
+    if (a >= b) continue;
+    uint32_t fwd = 0, rc = 0;
+    int run = 0;
+    for (int j = 0; j < k - 1; ++j) {
+      const uint32_t c = SB == 2 ? base_code(seq[a + j]) : protein_code(seq[a + j]);
+      fwd = ((fwd << SB) | (c & kSym)) & mask;
+      if (SB == 2) rc = (rc >> 2) | ((3u - (c & 3u)) << shift);
+      run = c < kValid ? run + 1 : 0;
+    }
+    for (uint64_t w = a; w < b; ++w) {
+      const uint32_t c = SB == 2 ? base_code(seq[w + k - 1]) : protein_code(seq[w + k - 1]);
+      fwd = ((fwd << SB) | (c & kSym)) & mask;
+      if (SB == 2) rc = (rc >> 2) | ((3u - (c & 3u)) << shift);
+      run = c < kValid ? run + 1 : 0;
+      if (run >= k) atomicAdd(&s_tab[(SB == 2 && content == KPOP_DNA_DS && rc < fwd) ? rc : fwd], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < n_bins; b += 1024) {
+    const uint32_t c = s_tab[b];
+    if (c) atomicAdd(&table[b], c);
+  }
+}
+
+constexpr uint32_t kCombSeg = 1024, kCombReads = 64;  // a chunk: the same 1,024 windows of 64 consecutive sequences
+constexpr uint32_t kCombSlots = 8192;                  // LDS table of (hash, count): 64 KB, two blocks a CU
+constexpr int kCombProbes = 8;
+
+template <int SB>
+__global__ __launch_bounds__(1024) void window_hist_combine_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets,
+                                                                   int k, int content, uint32_t *__restrict__ table, uint32_t n_reads,
+                                                                   uint32_t max_seg, int always_stage) {
+  __shared__ uint32_t s_hash[kCombSlots], s_cnt[kCombSlots];
+  __shared__ uint32_t s_distinct, s_valid;
+  const uint32_t n_groups = (n_reads + kCombReads - 1) / kCombReads;
+  const uint64_t n_chunks = (uint64_t)n_groups * max_seg;
+  const int shift = SB * (k - 1);
+  constexpr uint32_t kSym = (1u << SB) - 1u, kValid = SB == 2 ? 4u : 20u, kEmpty = 0xFFFFFFFFu;
+  const uint32_t mask = (uint32_t)bits_mask(SB * k);
+  constexpr uint32_t per_h = kCombSeg / 16;  // 16 threads a sequence, 64 consecutive windows a thread
+  for (uint32_t q = threadIdx.x; q < kCombSlots; q += 1024) {
+    s_hash[q] = kEmpty;
+    s_cnt[q] = 0;
+  }
+  bool direct = false;
+  for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    // chunks are dealt with the groups of sequences fastest: the blocks running together work on one stretch of all of them
+    const uint32_t seg = (uint32_t)(chunk / n_groups), grp = (uint32_t)(chunk % n_groups);
+    const uint32_t r = grp * kCombReads + threadIdx.x / 16;
+    uint64_t len = 0, off = 0;
+    if (r < n_reads) {
+      off = offsets[r];
+      len = offsets[r + 1] - off;
+    }
+    const uint64_t n_win = len >= (uint64_t)k ? len - k + 1 : 0;
+    const uint64_t w0 = (uint64_t)seg * kCombSeg + (uint64_t)(threadIdx.x % 16) * per_h;
+    const uint8_t *seq = bases + off;
+    uint32_t fwd = 0, rc = 0;
+    int run = 0;
+    if (w0 < n_win)
+      for (int j = 0; j < k - 1; ++j) {
+        const uint32_t c = SB == 2 ? base_code(seq[w0 + j]) : protein_code(seq[w0 + j]);
+        fwd = ((fwd << SB) | (c & kSym)) & mask;
+        if (SB == 2) rc = (rc >> 2) | ((3u - (c & 3u)) << shift);
+        run = c < kValid ? run + 1 : 0;
+      }
+    if (!direct) {
+      if (threadIdx.x == 0) {
+        s_distinct = 0;
+        s_valid = 0;
+      }
+      __syncthreads();  // (also: the table is empty -- initialised above, or emptied by the previous chunk's flush)
+    }
+    uint32_t n_ok = 0, n_new = 0;
+    for (uint32_t i = 0; i < per_h; ++i) {
+      const uint64_t w = w0 + i;
+      if (w >= n_win) break;
+      const uint32_t c = SB == 2 ? base_code(seq[w + k - 1]) : protein_code(seq[w + k - 1]);
+      fwd = ((fwd << SB) | (c & kSym)) & mask;
+      if (SB == 2) rc = (rc >> 2) | ((3u - (c & 3u)) << shift);
+      run = c < kValid ? run + 1 : 0;
+      if (run < k) continue;
+      const uint32_t key = (SB == 2 && content == KPOP_DNA_DS && rc < fwd) ? rc : fwd;
+      if (direct) {
+        atomicAdd(&table[key], 1u);
+        continue;
+      }
+      ++n_ok;
+      uint32_t slot = (key * 2654435761u) >> 19;  // 13 bits
+      bool placed = false;
+#pragma unroll 1
+      for (int t = 0; t < kCombProbes; ++t) {
+        const uint32_t prev = atomicCAS(&s_hash[slot], kEmpty, key);
+        if (prev == kEmpty || prev == key) {
+          atomicAdd(&s_cnt[slot], 1u);
+          n_new += prev == kEmpty;
+          placed = true;
+          break;
+        }
+        slot = (slot + 1) & (kCombSlots - 1);
+      }
+      if (!placed) {  // the neighbourhood is taken by other k-mers: this window goes straight to the global table
+        atomicAdd(&table[key], 1u);
+        ++n_new;
+      }
+    }
+    if (direct) continue;
+    if (n_ok) atomicAdd(&s_valid, n_ok);
+    if (n_new) atomicAdd(&s_distinct, n_new);
+    __syncthreads();
+    // one global atomic per distinct k-mer of the chunk, and the table is empty again
+    for (uint32_t q = threadIdx.x; q < kCombSlots; q += 1024) {
+      const uint32_t h = s_hash[q];
+      if (h != kEmpty) {
+        atomicAdd(&table[h], s_cnt[q]);
+        s_hash[q] = kEmpty;
+        s_cnt[q] = 0;
+      }
+    }
+    // unrelated sequences repeat nothing inside a chunk: staging then only costs, and the block's later chunks go direct
+    if (!always_stage && (uint64_t)s_distinct * 4 > (uint64_t)s_valid * 3) direct = true;
+    __syncthreads();
+  }
+}
+
 struct NonZero {
   const uint32_t *t;
   __device__ uint32_t operator()(uint64_t i) const { return t[i] ? 1u : 0u; }
@@ -240,9 +439,25 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
   KPOP_HIP(hipMemsetAsync(S.d_ka.p, 0, n_bins * 4, st));
   uint32_t *table = S.d_ka.as<uint32_t>();
   if (max_win > 0) {
-    if (max_win <= 4096) {
+    const int lds_mode = ctx().tune_histlds;  // 1 (default): LDS-staged where it applies; 0: round 2's direct atomics; 2: always sort chunks
+    const bool protein = content == KPOP_PROTEIN;
+    if (lds_mode && hb <= kHistLdsBits) {
+      // the whole table fits a block's LDS: private copies, one global atomic per non-zero counter and block
+      const uint32_t max_seg = div_up(max_win, kKeySeg);
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)n_reads * max_seg, (uint64_t)ctx().n_cus * 2);
+      const size_t lds = (size_t)n_bins * 4;
+      if (protein) window_hist_lds_kernel<5><<<dim3(blocks), dim3(1024), lds, st>>>(S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), k, content, hb, table, n_reads, max_seg);
+      else window_hist_lds_kernel<2><<<dim3(blocks), dim3(1024), lds, st>>>(S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), k, content, hb, table, n_reads, max_seg);
+    } else if (max_win <= 4096) {
       read_hist_kernel<uint32_t><<<dim3(std::min<uint32_t>(div_up(n_reads, 4), 1u << 16)), dim3(256), 0, st>>>(
           S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), k, content, table, n_reads);
+    } else if (lds_mode && n_reads >= 16) {
+      // assemblies: the same stretch of 64 sequences combined in an LDS table before it reaches the global one
+      const uint32_t max_seg = div_up(max_win, kCombSeg);
+      const uint64_t n_chunks = (uint64_t)div_up(n_reads, kCombReads) * max_seg;
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>(n_chunks, (uint64_t)ctx().n_cus * 4);
+      if (protein) window_hist_combine_kernel<5><<<dim3(blocks), dim3(1024), 0, st>>>(S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), k, content, table, n_reads, max_seg, lds_mode == 2);
+      else window_hist_combine_kernel<2><<<dim3(blocks), dim3(1024), 0, st>>>(S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), k, content, table, n_reads, max_seg, lds_mode == 2);
     } else {
       const uint32_t max_seg = div_up(max_win, kKeySeg);
       window_hist_kernel<uint32_t><<<dim3(capped_grid((uint64_t)n_reads * max_seg)), dim3(256), 0, st>>>(
@@ -283,36 +498,6 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
 // radix passes (5 passes over 8 B per window before), no scans.  Longer sequences and hashes beyond 30 bits keep the
 // device-wide sort below.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kBlockSortMax = 32768;
-#define KEY(i) ((i) + ((i) >> 5))  // LDS index of key i: one word of padding per 32
-
-// one pass of the register-blocked bitonic network (count_block_kernel): 2^GB keys per (virtual) thread
-template <int GB>
-__device__ __forceinline__ void bitonic_group_pass(uint32_t *s_key, uint32_t NP, uint32_t sz, int h, int lo) {
-  constexpr int E = 1 << GB;
-  const uint32_t n_groups = NP >> GB;
-  for (uint32_t vt = threadIdx.x; vt < n_groups; vt += 1024) {
-    const uint32_t base = ((vt >> lo) << (h + 1)) | (vt & ((1u << lo) - 1u));
-    const bool asc = (base & sz) == 0;
-    uint32_t rk[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) rk[e] = s_key[KEY(base | ((uint32_t)e << lo))];
-#pragma unroll
-    for (int j = GB - 1; j >= 0; --j) {
-#pragma unroll
-      for (int e = 0; e < E; ++e)
-        if (!(e & (1 << j))) {
-          const uint32_t x = rk[e], y = rk[e | (1 << j)];
-          const uint32_t mn = min(x, y), mx = max(x, y);
-          rk[e] = asc ? mn : mx;
-          rk[e | (1 << j)] = asc ? mx : mn;
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < E; ++e) s_key[KEY(base | ((uint32_t)e << lo))] = rk[e];
-  }
-}
-
 template <int SB>
 __global__ __launch_bounds__(1024) void count_block_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets,
                                                            uint32_t n, int k, int content, uint32_t *__restrict__ ticket_counter,

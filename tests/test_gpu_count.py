@@ -86,13 +86,17 @@ def test_count_errors(kpop):
     assert len(h) == 0 and o.tolist() == [0]
 
 
-@pytest.fixture(params=[1, 0], ids=["histogram", "sort"])
+@pytest.fixture(params=[(1, 1), (1, 0), (1, 2), (0, 1)], ids=["histogram-lds", "histogram-direct", "histogram-sorted-chunks", "sort"])
 def merged_path(request, kpop):
-    """-l by atomic histogram (hashes of up to 26 bits; the default there) and by device-wide sort (everything else)"""
+    """-l by atomic histogram (hashes of up to 26 bits; the default there) -- staged through LDS (private tables up to
+    k = 7, sorted chunks of assemblies; the default), with direct global atomics, with every chunk sorted -- and by
+    device-wide sort (everything else)"""
     from kpop_amd import api
-    api.tune("hist", request.param)
+    api.tune("hist", request.param[0])
+    api.tune("histlds", request.param[1])
     yield request.param
     api.tune("hist", 1)
+    api.tune("histlds", 1)
 
 
 def test_count_merged_golden_vectors(kpop, oracle, merged_path):
@@ -122,6 +126,26 @@ def test_count_merged_genomes_and_ragged(kpop, oracle, merged_path):
     for k in (7, 12, 13):
         for content in (kpop.DNA_DS, kpop.DNA_SS):
             spectra_equal(kpop.count_reads(bases, offs, k, content, per_read=False), oracle.count_reads(bases, offs, k, content, per_read=False))
+
+
+def test_count_merged_assemblies_of_one_organism(kpop, oracle, merged_path):
+    """-l over 70 mutated copies of one 9 kb sequence and 40 unrelated ones (BASELINE config 3's kind of batch): the chunks
+    of the LDS-staged histogram see the same k-mers across sequences (and, for the unrelated ones, nothing twice)"""
+    rng = np.random.RandomState(11)
+    ref = rng.choice(list("ACGT"), size=9000)
+    seqs = []
+    for i in range(70):
+        m = ref.copy()
+        hit = rng.rand(len(m)) < 0.002
+        m[hit] = rng.choice(list("ACGTN"), size=int(hit.sum()))
+        seqs.append("".join(m[: len(m) - int(rng.randint(0, 50))]))
+    seqs += ["".join(rng.choice(list("ACGT"), size=int(rng.randint(4200, 12000)))) for _ in range(40)]
+    bases, offs = concat(seqs)
+    for k in (4, 7, 8, 12):
+        spectra_equal(kpop.count_reads(bases, offs, k, per_read=False), oracle.count_reads(bases, offs, k, per_read=False))
+    pb, po = concat(["".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWYX"), size=5000)) for _ in range(40)])
+    for k in (2, 4):
+        spectra_equal(kpop.count_reads(pb, po, k, kpop.PROTEIN, per_read=False), oracle.count_reads(pb, po, k, oracle.PROTEIN, per_read=False))
 
 
 @pytest.mark.parametrize("k", [8, 12, 21, 30])
