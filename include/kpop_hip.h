@@ -246,6 +246,10 @@ int kpop_sharded_slots(const kpop_sharded *sh);
    against a reference set need no exchange between devices.  Bit-identical to one pipeline on one device.           */
 int kpop_sharded_run(kpop_sharded *sh, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
                      const kpop_pipeline_outputs *out);
+/* kpop_spectra_twist with the reads cut over the devices (any sequence length; bit for bit the rows of kpop_count_reads
+   + kpop_twist)                                                                                                      */
+int kpop_sharded_spectra_twist(kpop_sharded *sh, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, int k,
+                               int content, int normalize, double *out);
 /* BASELINE config 4 with the reads already resident: slot s holds n_reads[s] reads in ITS HBM (d_bases[s],
    d_offsets[s] = n_reads[s] + 1 offsets into d_bases[s]; n_bases[s] bytes; max_len = longest read anywhere).  Every
    device twists its shard in `chunks` pieces and -- gather != 0 -- pushes each finished piece into every peer's copy

@@ -52,6 +52,7 @@ SIGNATURES = {
     "kpop_sharded_create": (C.c_int, [vp, f64p, C.c_uint32, f64p, C.POINTER(PipelineConfig), C.POINTER(vp)]),
     "kpop_sharded_slots": (C.c_int, [vp]),
     "kpop_sharded_run": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(PipelineOutputs)]),
+    "kpop_sharded_spectra_twist": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, f64p]),
     "kpop_sharded_resident_step": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), u32p, u64p, C.c_uint32, C.c_int, C.c_int]),
     "kpop_sharded_resident_buffers": (C.c_int, [vp, C.c_int, C.POINTER(vp), u64p, u64p, C.POINTER(vp)]),
     "kpop_sharded_timings": (C.c_int, [vp, C.c_int, f64p, f64p]),

@@ -315,6 +315,19 @@ extern "C" int kpop_sharded_run(kpop_sharded *sh, const uint8_t *bases, const ui
   });
 }
 
+// kpop_spectra_twist over all devices (sequences of any length, the rows kpop_count_reads + kpop_twist would give bit for
+// bit): what KPopTwistDB runs on a block of the reads stream that the fused kernel does not cover
+extern "C" int kpop_sharded_spectra_twist(kpop_sharded *sh, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, int k,
+                                          int content, int normalize, double *out) {
+  if (!sh || (n_reads && (!offsets || !out))) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_sharded_spectra_twist: null argument");
+  return on_every_slot(sh->n, [&](int i) -> int {
+    uint64_t lo, hi;
+    bounds(n_reads, i, sh->n, &lo, &hi);
+    if (hi == lo) return 0;
+    return kpop_spectra_twist(sh->s[i].tw, bases, offsets + lo, (uint32_t)(hi - lo), k, content, normalize, out + lo * sh->n_dims);
+  });
+}
+
 // BASELINE config 4, device-resident: slot i holds its reads (d_bases[i], d_offsets[i]: n_reads[i] + 1 offsets into
 // d_bases[i]) in its own HBM.  Twist in `chunks` pieces; with gather != 0 every finished piece is pushed to all peers
 // while the next is twisted; then the distances of the slot's rows to the class vectors.  Returns when every device has

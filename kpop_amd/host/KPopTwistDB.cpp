@@ -37,7 +37,6 @@
 
 #include "../../include/kpop_hip.h"
 #include "fast_seq.h"
-#include "gpu_workers.h"
 #include "kpop_text.h"
 #include "ocaml_marshal.h"
 #include "splits.h"
@@ -165,18 +164,35 @@ void check(int rc) {
   if (rc != 0) throw Error(std::string("libkpop_hip: ") + kpop_last_error());
 }
 
-std::unique_ptr<GpuWorkers> g_workers;  // KPOP_DEVICES: one worker process per GPU for the reads stream (gpu_workers.h)
 bool g_gpu = false;
 std::thread g_warm;  // brings the HIP runtime up while the main thread reads its first archive
 void warm_gpu() {
   g_warm = std::thread([] { (void)kpop_device_count(); });
+}
+// KPOP_DEVICES = n | all: several GPUs from THIS process (kpop_init_devices; the library runs one host thread per device
+// and cuts every batch itself -- round 2 forked a worker process per GPU and moved reads through pipes and rows through
+// shared memory).  More slots than GPUs (a test rig on a one-GPU box) wrap around.
+int devices_requested(int visible) {
+  const char *e = getenv("KPOP_DEVICES");
+  if (!e || !*e) return 1;
+  if (!strcmp(e, "all")) return std::max(visible, 1);
+  const int n = atoi(e);
+  return n > 1 ? std::min(n, 16) : 1;
 }
 void need_gpu() {
   if (g_warm.joinable()) g_warm.join();
   if (g_gpu) return;
   int dev = 0;
   if (const char *e = getenv("KPOP_DEVICE")) dev = atoi(e);
-  check(kpop_init(dev));
+  const int visible = kpop_device_count();
+  const int n = devices_requested(visible);
+  if (n > 1 && visible > 0) {
+    std::vector<int> devs(n);
+    for (int i = 0; i < n; ++i) devs[i] = (dev + i) % visible;
+    check(kpop_init_devices(devs.data(), n));
+  } else {
+    check(kpop_init(dev));
+  }
   g_gpu = true;
 }
 
@@ -299,11 +315,35 @@ void twist_read_stream(int fd, TwisterReg &T, bool normalize, std::vector<RowPie
   ReadStreamReader rs(fd);
   const int k = (int)rs.header.k, content = (int)rs.header.content;
   if (k < 1 || k > 30 || (content != KPOP_DNA_DS && content != KPOP_DNA_SS)) throw Error("reads stream: unsupported k or content");
-  if (!g_workers) T.upload();
-  const size_t d = g_workers ? T.inertia.cols() : T.twister.rows();
+  T.upload();
+  const size_t d = T.twister.rows();
   // the names KPopCount would have written carry name_digits(k) hex digits; if the twister's names are of another
   // width no k-mer of the stream can be a column of it (lib/Twister.ml:167-169): every row is the zero vector
-  const bool can_match = g_workers || (size_t)name_digits(k, false) == T.name_len;  // (the workers decide for themselves)
+  const bool can_match = (size_t)name_digits(k, false) == T.name_len;
+  // Blocks whose sequences all fit one wavefront (<= 512 windows) and more than 32 dimensions: the fused count->twist
+  // kernel IS count + twist there (same ascending chain of unfused multiply-adds), and the block goes through the
+  // library's streaming pipeline -- chunks of it going up, being twisted and coming down at the same time -- on every
+  // device slot (kpop_sharded_run).  Anything else (genomes, few dimensions) takes kpop_spectra_twist, cut over the slots.
+  struct Job {
+    kpop_sharded *sh = nullptr;
+    ~Job() {
+      if (sh) kpop_sharded_destroy(sh);
+    }
+  } job;
+  const int slots = kpop_device_slots();
+  if (can_match) {
+    check(kpop_twister_set_count_k(T.dev, k));
+    kpop_pipeline_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = sizeof cfg;
+    cfg.content = content;
+    cfg.normalize_counts = normalize ? 1 : 0;
+    cfg.kind = KPOP_EUCLIDEAN;
+    cfg.p = 2.0;
+    cfg.outputs = KPOP_OUT_TWISTED;
+    check(kpop_sharded_create(T.dev, nullptr, 0, nullptr, &cfg, &job.sh));
+    if (verbose && slots > 1) fprintf(stderr, "(KPopTwistDB): %d device slots, one host thread each, for the reads stream\n", slots);
+  }
   BlockQueue bq;
   std::thread reader([&] {
     std::string err;
@@ -337,12 +377,20 @@ void twist_read_stream(int fd, TwisterReg &T, bool normalize, std::vector<RowPie
       offsets[0] = 0;
       for (size_t r = 0; r < n; ++r) offsets[r + 1] = offsets[r] + b.lens[r];
       piece.rows.resize(n * d);
-      if (g_workers) {
-        g_workers->twist_block(b, k, content, normalize, d, piece.rows.data());
-      } else if (can_match && n) {
+      if (can_match && n) {
         static const uint8_t dummy = 0;
-        check(kpop_spectra_twist(T.dev, b.bases.empty() ? &dummy : b.bases.data(), offsets.data(), (uint32_t)n, k, content,
-                                 normalize ? 1 : 0, piece.rows.data()));
+        const uint8_t *bp = b.bases.empty() ? &dummy : b.bases.data();
+        uint64_t max_len = 0;
+        for (size_t r = 0; r < n; ++r) max_len = std::max<uint64_t>(max_len, b.lens[r]);
+        const bool fused = d > 32 && max_len < (uint64_t)k + 512;
+        if (fused) {
+          kpop_pipeline_outputs po;
+          memset(&po, 0, sizeof po);
+          po.twisted = piece.rows.data();
+          check(kpop_sharded_run(job.sh, bp, offsets.data(), (uint32_t)n, &po));
+        } else {
+          check(kpop_sharded_spectra_twist(job.sh, bp, offsets.data(), (uint32_t)n, k, content, normalize ? 1 : 0, piece.rows.data()));
+        }
       } else {
         std::fill(piece.rows.begin(), piece.rows.end(), 0.);
       }
@@ -484,11 +532,11 @@ void twist_text_spectra(int fd, const char *head, size_t head_len, TwisterReg &T
 void add_twisted_from_files(TwisterReg &T, Table &twisted, const std::vector<std::string> &files, bool normalize, bool verbose) {
   // with worker processes the parent needs the dimension names only (the inertia's columns, lib/Twister.ml:36-38); the
   // matrix is read and uploaded here only if text spectra turn up, which the parent twists itself
-  if (!g_workers) T.need_matrix();
+  T.need_matrix();
   stage_mark("KPopTwistDB", "twister archive read");
-  const std::vector<std::string> dims = g_workers ? T.inertia.col_names : T.twister.row_names;
+  const std::vector<std::string> dims = T.twister.row_names;
   if (!twisted.empty() && twisted.col_names != dims) throw Error("Incompatible_twister_and_twisted");  // :64-69
-  if (!g_workers) T.upload();
+  T.upload();
   stage_mark("KPopTwistDB", "HIP bring-up + twister upload");
   const size_t d = dims.size();
   std::vector<RowPiece> pieces;
@@ -760,43 +808,6 @@ int main(int argc, char **argv) {
   }
 
   stage_mark("KPopTwistDB", "start");
-  try {  // several GPUs: the workers are forked now, before this process has made any HIP call
-    int want = devices_requested();
-    const Action *src = nullptr, *first_k = nullptr;
-    for (const Action &a : program) {
-      if (a.kind == Action::AddKmersFiles && !first_k) first_k = &a;
-      if (!first_k && (a.kind == Action::BinaryToRegister || a.kind == Action::TablesToRegister) && a.reg == Reg::Twister) src = &a;
-    }
-    if (want != 0 && first_k && src && src->s1.compare(0, 5, "/dev/") != 0) {
-      if (want < 0) {  // "all": ask a child, so that this process stays clear of HIP
-        int fds[2];
-        if (pipe(fds) != 0) throw Error("pipe failed");
-        const pid_t pid = fork();
-        if (pid == 0) {
-          const int n = kpop_device_count();
-          if (write(fds[1], &n, sizeof n) < 0) {
-          }
-          _exit(0);
-        }
-        close(fds[1]);
-        int n = 0;
-        if (read(fds[0], &n, sizeof n) != (ssize_t)sizeof n) n = 0;
-        close(fds[0]);
-        waitpid(pid, nullptr, 0);
-        want = n;
-      }
-      if (want > 1) {
-        TwisterSource ts;
-        ts.prefix = src->s1;
-        ts.binary = src->kind == Action::BinaryToRegister;
-        g_workers.reset(new GpuWorkers(want, ts));
-        if (verbose) fprintf(stderr, "(KPopTwistDB): %d worker processes, one per GPU, for the reads stream\n", want);
-      }
-    }
-  } catch (const std::exception &e) {
-    fprintf(stderr, "(KPopTwistDB): FATAL: %s\n", e.what());
-    return 1;
-  }
   for (const Action &a : program)
     if (a.kind == Action::AddKmersFiles || a.kind == Action::DistancesFromTwisted || a.kind == Action::SummaryFromTwisted ||
         a.kind == Action::SummaryFromDistances || a.kind == Action::EmbeddingsFromTwisted) {
@@ -944,7 +955,7 @@ int main(int argc, char **argv) {
           dm.col_names = twisted.row_names;  // lib/Matrix.ml:264-266
           dm.row_names = m2.row_names;
           dm.data.assign(dm.rows() * dm.cols(), 0.);
-          check(kpop_distance_rowwise(twisted.data.data(), (uint32_t)twisted.rows(), m2.data.data(), (uint32_t)m2.rows(),
+          check((kpop_device_slots() > 1 ? kpop_sharded_distance_rowwise : kpop_distance_rowwise)(twisted.data.data(), (uint32_t)twisted.rows(), m2.data.data(), (uint32_t)m2.rows(),
                                       (uint32_t)twisted.cols(), mv.data(), distance.kind, distance.p, distance_normalize ? 1 : 0,
                                       dm.data.data()));
           distances = dm;
@@ -973,7 +984,7 @@ int main(int argc, char **argv) {
             z.assign((size_t)r2 * stride, 0.);
             if (from_tw) {
               std::vector<double> mv = metric_vector(metric, T);
-              check(kpop_distance_summary(twisted.data.data(), r1, m2.data.data(), r2, (uint32_t)twisted.cols(), mv.data(),
+              check((kpop_device_slots() > 1 ? kpop_sharded_distance_summary : kpop_distance_summary)(twisted.data.data(), r1, m2.data.data(), r2, (uint32_t)twisted.cols(), mv.data(),
                                           distance.kind, distance.p, distance_normalize ? 1 : 0, (uint32_t)keep_at_most, stride,
                                           stats.data(), n.data(), idx.data(), dist.data(), z.data()));
             } else {
@@ -995,13 +1006,11 @@ int main(int argc, char **argv) {
     }
   } catch (const std::exception &e) {
     fprintf(stderr, "(KPopTwistDB): FATAL: Uncaught exception: %s\n", e.what());
-    g_workers.reset();
     if (g_warm.joinable()) g_warm.join();
     T.reset();
     return 1;
   }
   stage_mark("KPopTwistDB", "last action done");
-  g_workers.reset();
   if (g_warm.joinable()) g_warm.join();
   // Everything is written and closed.  Returning would take the registers apart value by value and the HIP runtime with
   // them (0.25-0.4 s with 4M rows in memory): the process ends here instead and the system takes it all back at once.

@@ -119,9 +119,10 @@ def test_reads_stream_errors_and_other_readers(tmp_path, oracle):
     assert [l.split("\t")[0] for l in rows[1:]] == ['"a"', '"b"', '"c"']
 
 
-def test_worker_processes_one_per_gpu(tmp_path, oracle):
-    """KPOP_DEVICES: the reads stream cut over worker processes (here 2 and 3 of them on the box's one GPU) gives the bytes
-    of the single-process run; a worker's failure reaches the user as an error, not as a hang"""
+def test_several_device_slots_in_one_process(tmp_path, oracle):
+    """KPOP_DEVICES: the reads stream cut over device slots inside the library (kpop_init_devices + kpop_sharded_*; here 2
+    and 3 slots on the box's one GPU) gives the bytes of the single-device run, for blocks the fused kernel takes and for
+    blocks with genomes in them; so do -d and -s; a twister that cannot be loaded is an error, not a hang"""
     rng = np.random.RandomState(77)
     k, d = 12, 40
     make_twister(tmp_path, oracle, k, d, keep=0.02)
@@ -138,10 +139,20 @@ def test_worker_processes_one_per_gpu(tmp_path, oracle):
         r = subprocess.run("%s -k %d -L -f %s | %s -v -i T %s -k /dev/stdin -o t %s" % (COUNT, k, fa, TWISTDB, tmp_path / "Classes", tmp_path / ("w" + devices)),
                            shell=True, capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr
-        assert ("worker processes" in r.stderr) == bool(devices)
+        assert ("device slots" in r.stderr) == bool(devices)
         outs[devices] = (tmp_path / ("w" + devices + ".KPopTwisted")).read_bytes()
     assert outs[""] == outs["2"] == outs["3"] and len(outs[""]) > 1000
-    # the workers cannot load this twister: every one reports it, the parent stops with the message
+    # -d and -s with their second operand's rows cut over the slots: the same files
+    for devices in ("", "3"):
+        env = dict(os.environ)
+        if devices:
+            env["KPOP_DEVICES"] = devices
+        r = subprocess.run([TWISTDB, "-i", "T", str(tmp_path / "Classes"), "-i", "t", str(tmp_path / "w"), "-d", str(tmp_path / "w"), "-o", "d", str(tmp_path / ("dd" + devices)),
+                            "-s", str(tmp_path / "w"), str(tmp_path / ("ss" + devices))], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+    assert (tmp_path / "dd.KPopDMatrix").read_bytes() == (tmp_path / "dd3.KPopDMatrix").read_bytes()
+    assert (tmp_path / "ss.KPopSummary.txt").read_bytes() == (tmp_path / "ss3.KPopSummary.txt").read_bytes()
+    # a twister that cannot be loaded: the process stops with the message
     (tmp_path / "Bad.KPopTwister").write_bytes(b"not an archive")
     (tmp_path / "Bad.KPopInertia.txt").write_text((tmp_path / "Classes.KPopInertia.txt").read_text())
     r = subprocess.run("%s -k %d -L -f %s | %s -I T %s -k /dev/stdin -o t %s" % (COUNT, k, fa, TWISTDB, tmp_path / "Missing", tmp_path / "x"),

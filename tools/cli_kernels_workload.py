@@ -21,22 +21,25 @@ cli_kernels_report.py joins that with the profiler's per-kernel averages.
 import argparse
 import json
 import os
-import subprocess
 import sys
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SYNTH = os.path.join(ROOT, "kpop_amd", "bin", "kpop_synth")
 SECTIONS = ["count_L", "twist_reads", "twist_genomes", "summary_65", "summary_1M", "merged_hist", "merged_sort", "genomes_L", "fused_genomes"]
 
 
-def mutants(n):
-    from tools.realistic_inputs import read_fasta, to_arrays
-    txt = subprocess.run([SYNTH, "mutants", "--from", os.path.join(ROOT, "tests", "golden", "wuhan.fasta"), "--n", str(n), "--mutate", "0.001"],
-                         stdout=subprocess.PIPE, check=True).stdout.decode()
-    return to_arrays(read_fasta(txt))
+def mutants(n, rate=0.001, seed=5):
+    """n copies of tests/golden/wuhan.fasta with point substitutions at `rate`, made in this process: the profiled
+    program must not start children (the profiler's preload has initialised the GPU before main() runs)."""
+    from tools.realistic_inputs import read_fasta
+    ref = np.frombuffer(read_fasta(open(os.path.join(ROOT, "tests", "golden", "wuhan.fasta")).read())[0].encode(), dtype=np.uint8)
+    rng = np.random.RandomState(seed)
+    out = np.tile(ref, n)
+    hit = np.flatnonzero(rng.rand(out.size) < rate)
+    out[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.randint(0, 4, size=len(hit))]
+    return out, np.arange(n + 1, dtype=np.uint64) * len(ref)
 
 
 def main():

@@ -1,5 +1,5 @@
 set -e
-ROOT=/root/repo; export PATH=$ROOT/kpop_amd/bin:$PATH
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"; export PATH=$ROOT/kpop_amd/bin:$PATH
 W=$(mktemp -d /dev/shm/bt_XXXX); trap 'rm -rf $W' EXIT; cd $W
 now() { python3 -c "import time; print('%.3f' % time.time())"; }
 kpop_synth genomes --n 20 --len 30000 --seed 5 > base.fa

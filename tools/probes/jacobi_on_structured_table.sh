@@ -1,5 +1,5 @@
 set -e
-ROOT=/root/repo; export PATH=$ROOT/kpop_amd/bin:$PATH
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"; export PATH=$ROOT/kpop_amd/bin:$PATH
 W=$(mktemp -d /dev/shm/jt_XXXX); trap 'rm -rf $W' EXIT; cd $W
 kpop_synth genomes --n 40 --len 30000 --seed 5 > base.fa
 for i in $(seq 1 25); do kpop_synth mutants --from base.fa --n 40 --mutate 0.01 --seed $i | sed "s/^>/>m${i}_/"; done > genomes.fa

@@ -1,5 +1,5 @@
 set -e
-ROOT=/root/repo; export PATH=$ROOT/kpop_amd/bin:$PATH
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"; export PATH=$ROOT/kpop_amd/bin:$PATH
 W=$(mktemp -d /dev/shm/kc_XXXX); trap 'rm -rf $W' EXIT; cd $W
 kpop_synth genomes --n 65 --len 30000 --seed 12648430 > classes.fa
 kpop_synth reads --from classes.fa --n 1000000 --len 150 --mutate 0.005 --seed 1263555440 > reads.fa
