@@ -409,6 +409,16 @@ uint64_t kpop_dev_distance_workspace_bytes(uint32_t r1, uint32_t r2, uint32_t n_
 int kpop_dev_distance_rowwise(const double *d_m1, uint32_t r1, const double *d_m2, uint32_t r2,
                               uint32_t n_dims, const double *d_metric, int kind, double p, int normalize,
                               void *d_work, double *d_out, void *stream);
+/* Base.get_normalizations, lib/Matrix.ml:42-76: the norms of the rows of one operand under the distance and metric
+   (0 -> 1, :67).  A caller that measures many batches against ONE first operand (the class vectors) computes its norms
+   once and hands them to kpop_dev_distance_rowwise_norms with every batch (d_norms1 = NULL: computed inside, = plain
+   kpop_dev_distance_rowwise; they are used where the kernel divides while staging -- fewer than 128 rows in the first
+   operand, normalize set -- and recomputed otherwise).                                                              */
+int kpop_dev_row_norms(const double *d_m, uint32_t rows, uint32_t n_dims, const double *d_metric, int kind, double p,
+                       double *d_norms, void *stream);
+int kpop_dev_distance_rowwise_norms(const double *d_m1, uint32_t r1, const double *d_norms1, const double *d_m2, uint32_t r2,
+                                    uint32_t n_dims, const double *d_metric, int kind, double p, int normalize,
+                                    void *d_work, double *d_out, void *stream);
 int kpop_dev_distance_summary(const double *d_m1, uint32_t r1, const double *d_m2, uint32_t r2,
                               uint32_t n_dims, const double *d_metric, int kind, double p, int normalize,
                               uint32_t keep_at_most, uint32_t max_neighbours, void *d_work,

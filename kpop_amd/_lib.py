@@ -128,6 +128,9 @@ SIGNATURES = {
     "kpop_dev_distance_workspace_bytes": (C.c_uint64, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "kpop_dev_distance_rowwise": (C.c_int, [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, C.c_int,
                                             C.c_double, C.c_int, vp, vp, vp]),
+    "kpop_dev_row_norms": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, C.c_int, C.c_double, vp, vp]),
+    "kpop_dev_distance_rowwise_norms": (C.c_int, [vp, C.c_uint32, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_int, C.c_double, C.c_int, vp, vp,
+                                                  vp]),
     "kpop_dev_distance_summary": (C.c_int, [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, C.c_int,
                                             C.c_double, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp,
                                             vp, vp]),

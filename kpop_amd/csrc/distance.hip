@@ -728,7 +728,8 @@ static int rowwise_block(const double *a, uint32_t r1, const double *b, uint32_t
 
 template <int KIND>
 static int rowwise_impl(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
-                        const double *metric, double p, int normalize, void *work, double *out, hipStream_t st) {
+                        const double *metric, double p, int normalize, void *work, double *out, hipStream_t st,
+                        const double *norms1 = nullptr) {
   if (n_dims >= kLongD) {  // spectral distances: a few rows over millions of k-mers
     const uint32_t slabs = long_slabs(r1, r2, n_dims), slab = slab_dims(n_dims, slabs);
     DistWork w = carve(work, r1, r2, n_dims);
@@ -774,7 +775,7 @@ static int rowwise_impl(const double *m1, uint32_t r1, const double *m2, uint32_
   }
   // norms only; the rowwise kernel divides as it stages the rows
   DistWork w = carve(work, r1, r2, n_dims);
-  if (r1) {
+  if (r1 && !norms1) {  // (a caller that keeps the first operand -- the class vectors of the streaming pipeline -- brings its norms along)
     row_norms_kernel<KIND><<<dim3(div_up(r1, kNormRows)), dim3(256), 0, st>>>(m1, r1, n_dims, metric, p, w.n1, nullptr);
     KPOP_LAUNCH_CHECK();
   }
@@ -782,7 +783,7 @@ static int rowwise_impl(const double *m1, uint32_t r1, const double *m2, uint32_
     row_norms_kernel<KIND><<<dim3(div_up(r2, kNormRows)), dim3(256), 0, st>>>(m2, r2, n_dims, metric, p, w.n2, nullptr);
     KPOP_LAUNCH_CHECK();
   }
-  return rowwise_block<KIND>(m1, r1, m2, r2, n_dims, metric, p, out, st, w.n1, w.n2);
+  return rowwise_block<KIND>(m1, r1, m2, r2, n_dims, metric, p, out, st, norms1 ? norms1 : w.n1, w.n2);
 }
 
 // summary_large.hip
@@ -944,9 +945,34 @@ extern "C" uint64_t kpop_dev_distance_workspace_bytes(uint32_t r1, uint32_t r2, 
   return doubles * sizeof(double) + 64;
 }
 
+// Base.get_normalizations, lib/Matrix.ml:42-76 (Space.compute_norm, lib/Space.ml:166-181): norms[i] = scale(sum_c m_c g(a_ic)), 0 -> 1
+extern "C" int kpop_dev_row_norms(const double *d_m, uint32_t rows, uint32_t n_dims, const double *d_metric, int kind, double p,
+                                  double *d_norms, void *stream) {
+  KPOP_TRY(require_init());
+  KPOP_TRY(check_kind(kind, p, "kpop_dev_row_norms"));
+  if (rows == 0) return KPOP_OK;
+  if (!d_m || !d_metric || !d_norms || n_dims == 0) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_row_norms: null argument");
+  if (n_dims >= kLongD) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_row_norms: rows of %u dimensions or more go through kpop_dev_distance_rowwise", kLongD);
+  hipStream_t st = as_stream(stream);
+  const dim3 grid(div_up(rows, kNormRows)), block(256);
+  switch (kind) {
+    case KPOP_EUCLIDEAN: row_norms_kernel<KPOP_EUCLIDEAN><<<grid, block, 0, st>>>(d_m, rows, n_dims, d_metric, p, d_norms, nullptr); break;
+    case KPOP_COSINE: row_norms_kernel<KPOP_COSINE><<<grid, block, 0, st>>>(d_m, rows, n_dims, d_metric, p, d_norms, nullptr); break;
+    default: row_norms_kernel<KPOP_MINKOWSKI><<<grid, block, 0, st>>>(d_m, rows, n_dims, d_metric, p, d_norms, nullptr); break;
+  }
+  KPOP_LAUNCH_CHECK();
+  return KPOP_OK;
+}
+
 extern "C" int kpop_dev_distance_rowwise(const double *d_m1, uint32_t r1, const double *d_m2, uint32_t r2,
                                          uint32_t n_dims, const double *d_metric, int kind, double p, int normalize,
                                          void *d_work, double *d_out, void *stream) {
+  return kpop_dev_distance_rowwise_norms(d_m1, r1, nullptr, d_m2, r2, n_dims, d_metric, kind, p, normalize, d_work, d_out, stream);
+}
+
+extern "C" int kpop_dev_distance_rowwise_norms(const double *d_m1, uint32_t r1, const double *d_norms1, const double *d_m2, uint32_t r2,
+                                               uint32_t n_dims, const double *d_metric, int kind, double p, int normalize,
+                                               void *d_work, double *d_out, void *stream) {
   KPOP_TRY(require_init());
   KPOP_TRY(check_kind(kind, p, "kpop_dev_distance_rowwise"));
   if (r1 == 0 || r2 == 0) return KPOP_OK;
@@ -955,9 +981,9 @@ extern "C" int kpop_dev_distance_rowwise(const double *d_m1, uint32_t r1, const 
   if (n_dims == 0) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_distance_rowwise: n_dims must be positive");
   hipStream_t st = as_stream(stream);
   switch (kind) {
-    case KPOP_EUCLIDEAN: return rowwise_impl<KPOP_EUCLIDEAN>(d_m1, r1, d_m2, r2, n_dims, d_metric, p, normalize, d_work, d_out, st);
-    case KPOP_COSINE: return rowwise_impl<KPOP_COSINE>(d_m1, r1, d_m2, r2, n_dims, d_metric, p, normalize, d_work, d_out, st);
-    default: return rowwise_impl<KPOP_MINKOWSKI>(d_m1, r1, d_m2, r2, n_dims, d_metric, p, normalize, d_work, d_out, st);
+    case KPOP_EUCLIDEAN: return rowwise_impl<KPOP_EUCLIDEAN>(d_m1, r1, d_m2, r2, n_dims, d_metric, p, normalize, d_work, d_out, st, d_norms1);
+    case KPOP_COSINE: return rowwise_impl<KPOP_COSINE>(d_m1, r1, d_m2, r2, n_dims, d_metric, p, normalize, d_work, d_out, st, d_norms1);
+    default: return rowwise_impl<KPOP_MINKOWSKI>(d_m1, r1, d_m2, r2, n_dims, d_metric, p, normalize, d_work, d_out, st, d_norms1);
   }
 }
 

@@ -72,7 +72,7 @@ struct kpop_pipeline {
   const kpop_twister *tw = nullptr;
   kpop_pipeline_config cfg{};
   uint32_t n_classes = 0, n_dims = 0;
-  double *d_classes = nullptr, *d_metric = nullptr;
+  double *d_classes = nullptr, *d_metric = nullptr, *d_class_norms = nullptr;
   hipStream_t s_h2d = nullptr, s_compute = nullptr, s_d2h = nullptr;
   std::vector<RingSlot> ring;
   uint64_t next_chunk = 0;
@@ -153,6 +153,7 @@ static void destroy(kpop_pipeline *pl) {
     if (pl->ticket_done[i]) (void)hipEventDestroy(pl->ticket_done[i]);
   if (pl->d_classes) (void)hipFree(pl->d_classes);
   if (pl->d_metric) (void)hipFree(pl->d_metric);
+  if (pl->d_class_norms) (void)hipFree(pl->d_class_norms);
   if (pl->s_compute) {
     // the per-stream workspace of the genome kernel dies with its stream
     Context &c = ctx();
@@ -244,6 +245,15 @@ extern "C" int kpop_pipeline_create(const kpop_twister *tw, const double *classe
       PL_HIP(hipMalloc((void **)&pl->d_metric, mb));
       PL_HIP(hipMemcpy(pl->d_classes, classes, cb, hipMemcpyHostToDevice));
       PL_HIP(hipMemcpy(pl->d_metric, metric, mb, hipMemcpyHostToDevice));
+      // the norms of the class vectors (lib/Matrix.ml:42-76) once, not with every chunk
+      if (pl->cfg.normalize_distances && n_classes < 128) {
+        PL_HIP(hipMalloc((void **)&pl->d_class_norms, (uint64_t)n_classes * 8));
+        if (kpop_dev_row_norms(pl->d_classes, n_classes, tw->n_dims, pl->d_metric, pl->cfg.kind, pl->cfg.p, pl->d_class_norms, nullptr) != KPOP_OK) {
+          rc = KPOP_ERR_HIP;
+          break;
+        }
+        PL_HIP(hipStreamSynchronize(nullptr));
+      }
     }
 #undef PL_HIP
   } while (0);
@@ -326,8 +336,8 @@ extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, con
     KPOP_TRY(kpop_dev_count_twist(pl->tw, d_bases, s.offsets.as<uint64_t>(), n, nb, (uint32_t)max_len, pl->cfg.content,
                                   pl->cfg.normalize_counts, s.twisted.as<double>(), pl->s_compute));
     if (outs & KPOP_OUT_DISTANCES)
-      KPOP_TRY(kpop_dev_distance_rowwise(pl->d_classes, C, s.twisted.as<double>(), n, D, pl->d_metric, pl->cfg.kind, pl->cfg.p,
-                                         pl->cfg.normalize_distances, s.work.p, s.dist.as<double>(), pl->s_compute));
+      KPOP_TRY(kpop_dev_distance_rowwise_norms(pl->d_classes, C, pl->d_class_norms, s.twisted.as<double>(), n, D, pl->d_metric, pl->cfg.kind,
+                                               pl->cfg.p, pl->cfg.normalize_distances, s.work.p, s.dist.as<double>(), pl->s_compute));
     if (outs & KPOP_OUT_SUMMARY)
       KPOP_TRY(kpop_dev_distance_summary(pl->d_classes, C, s.twisted.as<double>(), n, D, pl->d_metric, pl->cfg.kind, pl->cfg.p,
                                          pl->cfg.normalize_distances, pl->cfg.keep_at_most, mn, s.work.p, s.stats.as<double>(),

@@ -185,6 +185,39 @@ def test_distance_summary_large_reference_set(kpop, oracle, r1, keep, kind):
         np.testing.assert_allclose(z[j, :m], z_o[a:a + m], rtol=1e-8, atol=1e-9)
 
 
+@pytest.mark.parametrize("kind,p", [(0, 2.0), (1, 2.0), (2, 1.5)])
+def test_row_norms_and_distances_with_supplied_norms(kpop, oracle, kind, p):
+    """kpop_dev_row_norms = Base.get_normalizations (lib/Matrix.ml:42-76) against the oracle, and kpop_dev_distance_rowwise_norms
+    with those norms supplied = kpop_dev_distance_rowwise, bit for bit (what the streaming pipeline does with its class vectors)"""
+    import torch
+    from kpop_amd import _lib, api
+    lib = _lib.load()
+    rng = np.random.RandomState(kind + 3)
+    d, r1, r2 = 64, 65, 3000
+    m1, m2 = rng.normal(size=(r1, d)), rng.normal(size=(r2, d))
+    m1[4] = 0.0  # a zero row: norm 0 -> 1
+    metric = oracle.metric_powers(oracle.synth_inertia(d))
+    dev = torch.device("cuda", 0)
+    t1, t2, tm = torch.from_numpy(m1).to(dev), torch.from_numpy(m2).to(dev), torch.from_numpy(metric).to(dev)
+    norms = torch.zeros(r1, dtype=torch.float64, device=dev)
+    api.check(lib.kpop_dev_row_norms(t1.data_ptr(), r1, d, tm.data_ptr(), kind, p, norms.data_ptr(), None))
+    want = oracle.normalizations(m1, metric, kind, p)
+    got = norms.cpu().numpy()
+    if kind == 2:
+        np.testing.assert_allclose(got, want, rtol=1e-12)
+    else:
+        assert np.array_equal(got, want)
+    assert got[4] == 1.0
+    work = torch.empty(api.dev_distance_workspace_bytes(r1, r2, d), dtype=torch.uint8, device=dev)
+    a = torch.zeros(r2, r1, dtype=torch.float64, device=dev)
+    b = torch.zeros(r2, r1, dtype=torch.float64, device=dev)
+    api.dev_distance_rowwise(t1.data_ptr(), r1, t2.data_ptr(), r2, d, tm.data_ptr(), work.data_ptr(), a.data_ptr(), kind=kind, p=p)
+    api.check(lib.kpop_dev_distance_rowwise_norms(t1.data_ptr(), r1, norms.data_ptr(), t2.data_ptr(), r2, d, tm.data_ptr(), kind, p, 1, work.data_ptr(),
+                                                  b.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
+
+
 def test_large_reference_set_refuses_lists_it_cannot_fill(kpop, oracle):
     """against more than 4,096 rows at most 2,048 neighbours come back per row: a caller that asks for more room than
     that (keep_at_most = all) gets an error, not rows of zeros (KPopTwistDB then exits 1 instead of printing them)"""
