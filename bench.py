@@ -512,6 +512,58 @@ def pcie_inclusive(R, n, reps=5, stream_batches=10):
     return out
 
 
+def measure_traffic(R, n_reads):
+    """HBM bytes per launch of the fused kernel, measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters
+    never share a run with a trace summary) of a child process that launches the same kernel on the same shape
+    (tools/pmc_workload.py), corrected as MI355X_MICROARCH.md's HBM section prescribes (unit KiB; FETCH_SIZE reads one
+    half on gfx950 -- checked here on the child's own calibration stream of a known byte count).  None when rocprofv3 is not
+    there or a pass fails (the line then falls back to profiles/traffic.json and says so)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    a = R.args
+    if not shutil.which("rocprofv3"):
+        return None
+    got = {}
+    calib = {}
+    calib_rows = 1 << 20  # 512 MiB each way: beyond the Infinity Cache
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = tempfile.mkdtemp(prefix="kpop_pmc_", dir="/tmp")
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.join(ROOT, "tools", "pmc_workload.py"), "--reads", str(n_reads), "--read-len", str(a.read_len),
+                   "-k", str(a.k), "--dims", str(a.dims), "--launches", "3", "--calib-rows", str(calib_rows)]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            if r.returncode != 0:
+                return None
+            vals, cal = [], []
+            for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] != counter:
+                        continue
+                    if "count_twist_wave_kernel" in row["Kernel_Name"]:
+                        vals.append(float(row["Counter_Value"]))
+                    elif "row_norms_kernel" in row["Kernel_Name"]:
+                        cal.append(float(row["Counter_Value"]))
+            shutil.rmtree(out, ignore_errors=True)
+            if not vals:
+                return None
+            got[counter] = sorted(vals)[len(vals) // 2]
+            calib[counter] = max(cal) if cal else None
+    except Exception:
+        return None
+    known_kib = calib_rows * 64 * 8 / 1024.0  # the calibration kernel reads exactly this much
+    factor = known_kib / calib["FETCH_SIZE"] if calib.get("FETCH_SIZE") else 2.0
+    if not (1.8 <= factor <= 2.2):  # the documented gfx950 correction; anything else means the counter is not what we think
+        return None
+    return {"hbm_bytes_per_launch": (2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0, "FETCH_SIZE_KiB": got["FETCH_SIZE"],
+            "WRITE_SIZE_KiB": got["WRITE_SIZE"], "fetch_correction_checked": factor,
+            "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate) of a child process launching "
+                      "the same kernel on the same shape (tools/pmc_workload.py); FETCH_SIZE x 2 (gfx950), unit KiB; the correction "
+                      "checked on the child's 512 MiB calibration stream (%.3f)" % factor}
+
+
 def file_to_file(R):
     """FASTA file -> .KPopTwisted / summary through the drop-in binaries, as README.md:606,656 chain them."""
     tool = os.path.join(ROOT, "tools", "file_to_file.py")
@@ -689,6 +741,11 @@ def main():
             line["cpu_baseline"] = cb
             line["parity_check"] = parity
         if R.world == 1 and not args.no_extras:
+            live = measure_traffic(R, n_local)
+            if live:
+                line["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
+                line["roofline"]["traffic_source"] = live["source"]
+                line["roofline"]["traffic_counters"] = {"FETCH_SIZE_KiB": live["FETCH_SIZE_KiB"], "WRITE_SIZE_KiB": live["WRITE_SIZE_KiB"]}
             line["pcie_inclusive"] = pcie_inclusive(R, n_local)
             c4 = R.run_config4(1000000, max(3, min(args.steps, 10)), 2)
             line["config4_on_this_gpu"] = {

@@ -14,6 +14,8 @@ cli_kernels_report.py joins that with the profiler's per-kernel averages.
   summary_65   KPopTwistDB -s vs classes    distance_summary_kernel           r1 = 65, r2 = 100k, D = 64
   summary_1M   relatedness engine           summary_large_kernel (+ rowwise)  r1 = 1M, r2 = 256, keep 300
   merged_hist  KPopCount -l                 read_hist / window_hist + compaction   100k reads; 5,000 x 30 kb genomes
+  merged_hist_mutants  KPopCount -l, one organism   window_hist_combine_kernel (LDS (hash, count) tables)   5,000 wuhan mutants, k = 12
+  merged_hist_k7       KPopCount -l, small k        window_hist_lds_kernel (private LDS tables)             5,000 wuhan mutants, k = 7
   merged_sort  KPopCount -l, k > 13 or hist off   window_keys + radix passes    the same inputs, kpop_tune("hist", 0)
   genomes_L    KPopCount -L, genomes        window_keys + radix passes        2,000 x 30 kb genomes, per-sequence spectra
   fused_genomes KPopTwistDB on a reads stream of assemblies  count_twist_stream_kernel   5,000 wuhan mutants
@@ -27,7 +29,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SECTIONS = ["count_L", "twist_reads", "twist_genomes", "summary_65", "summary_1M", "merged_hist", "merged_sort", "genomes_L", "fused_genomes"]
+SECTIONS = ["count_L", "twist_reads", "twist_genomes", "summary_65", "summary_1M", "merged_hist", "merged_hist_mutants", "merged_hist_k7", "merged_sort", "genomes_L",
+            "fused_genomes"]
 
 
 def mutants(n, rate=0.001, seed=5):
@@ -131,6 +134,16 @@ def main():
         else:
             algo["summary_large_kernel"] = {"bytes": r2 * r1 * 8, "note": "one pass over the r1 distances of each query row is the algorithmic minimum; the kernel makes several"}
             algo["distance_rowwise_kernel"] = {"bytes": (r1 + r2) * d * 8 + r1 * r2 * 8, "flops": 4.0 * r1 * r2 * d, "note": "chunk rows written for the summary kernel"}
+    elif sec in ("merged_hist_mutants", "merged_hist_k7"):
+        kk = 12 if sec == "merged_hist_mutants" else 7
+        mb, mo = mutants(5000)
+        cap = (4 ** kk + 2 ** kk) // 2 + 1
+        for _ in range(3):
+            kpop_amd.count_reads(mb, mo, kk, per_read=False, capacity=cap)
+        lens = np.diff(mo.astype(np.int64))
+        wg = int(np.maximum(lens - kk + 1, 0).sum())
+        name = "window_hist_combine_kernel" if kk == 12 else "window_hist_lds_kernel"
+        algo[name] = {"bytes": int(lens.sum()) + wg * 8, "note": "SURVEY 8d: L B read + one 8-byte atomic read-modify-write per window (5,000 mutants of one 29.9 kb genome, k = %d)" % kk}
     elif sec in ("merged_hist", "merged_sort", "genomes_L"):
         if sec == "genomes_L":
             gb, go = O.synth_reads(0xC1A55, 2000, 30000)
@@ -152,7 +165,7 @@ def main():
             wr, wg = n * (L - k + 1), 5000 * (30000 - k + 1)
             if sec == "merged_hist":
                 algo["read_hist_kernel"] = {"bytes": n * L + wr * 8, "note": "SURVEY 8d: L B read + one 8-byte atomic read-modify-write per window"}
-                algo["window_hist_kernel"] = {"bytes": 5000 * 30000 + wg * 8, "note": "the same for genomes"}
+                algo["window_hist_combine_kernel"] = {"bytes": 5000 * 30000 + wg * 8, "note": "the same for 5,000 UNRELATED genomes: nothing repeats inside a chunk, the blocks fall back to direct atomics"}
                 algo["scan_apply_kernel"] = {"bytes": 4 ** k * 4, "note": "compaction: the table read once (plus the spectrum written)"}
             else:
                 algo["window_keys_kernel"] = {"bytes": "mixed", "note": "two input sizes in one section: see per-dispatch rows"}
