@@ -197,9 +197,10 @@ typedef struct {
   int outputs;               /* KPOP_OUT_* ored */
   uint32_t keep_at_most;     /* summary: --summary-keep-at-most, 0 = all */
   uint32_t max_neighbours;   /* summary: stride of the neighbour outputs */
-  uint32_t chunk_reads;      /* reads per chunk, 0 = chosen from the batch (a quarter of it, 16,384..131,072) */
+  uint32_t chunk_reads;      /* reads per chunk, 0 = chosen from the batch (a quarter of it, 16,384..131,072, after a short first chunk) */
   uint32_t depth;            /* chunks in flight (device slots), 0 = 4 */
   uint64_t chunk_bases;      /* bases per chunk, 0 = 256 MiB (a longer sequence gets a chunk of its own) */
+  int record_timeline;       /* 1: timing events around every chunk's upload, kernels and download (kpop_pipeline_timeline) */
 } kpop_pipeline_config;
 typedef struct {
   double *twisted;           /* n_reads x n_dims            (KPOP_OUT_TWISTED)   */
@@ -222,6 +223,10 @@ int kpop_pipeline_run(kpop_pipeline *pl, const uint8_t *bases, const uint64_t *o
                       const kpop_pipeline_outputs *out);        /* submit + collect */
 /* of the last submit: chunks it was cut into, whether every buffer was page-locked, slots in the ring */
 int kpop_pipeline_stats(const kpop_pipeline *pl, uint32_t *chunks, int *pinned, uint32_t *depth);
+/* The device-side timeline of the last submit of a pipeline created with record_timeline (call after its collect): per
+   chunk six times in milliseconds from the start of the first upload -- upload start, end; kernels start, end; download
+   start, end -- taken with events on the three streams.  ms holds max_chunks x 6 doubles; *n_chunks = chunks written. */
+int kpop_pipeline_timeline(kpop_pipeline *pl, uint32_t max_chunks, double *ms, uint32_t *n_chunks);
 int kpop_pipeline_destroy(kpop_pipeline *pl);
 
 /* ------------------------------------------------------------ several GPUs

@@ -21,7 +21,7 @@ class PipelineConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("content", C.c_int), ("normalize_counts", C.c_int), ("kind", C.c_int),
                 ("p", C.c_double), ("normalize_distances", C.c_int), ("outputs", C.c_int), ("keep_at_most", C.c_uint32),
                 ("max_neighbours", C.c_uint32), ("chunk_reads", C.c_uint32), ("depth", C.c_uint32),
-                ("chunk_bases", C.c_uint64)]
+                ("chunk_bases", C.c_uint64), ("record_timeline", C.c_int)]
 
 
 class PipelineOutputs(C.Structure):
@@ -45,6 +45,7 @@ SIGNATURES = {
     "kpop_pipeline_collect": (C.c_int, [vp, C.c_uint64]),
     "kpop_pipeline_run": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(PipelineOutputs)]),
     "kpop_pipeline_stats": (C.c_int, [vp, u32p, C.POINTER(C.c_int), u32p]),
+    "kpop_pipeline_timeline": (C.c_int, [vp, C.c_uint32, f64p, u32p]),
     "kpop_pipeline_destroy": (C.c_int, [vp]),
     "kpop_dev_workspace_reserve_stream": (C.c_int, [C.c_uint64, vp]),
     "kpop_shard_bounds": (C.c_int, [C.c_uint64, C.c_int, C.c_int, u64p, u64p]),

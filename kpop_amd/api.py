@@ -242,7 +242,7 @@ class Pipeline:
 
     def __init__(self, tw, classes=None, metric=None, outputs=OUT_TWISTED | OUT_DISTANCES, content=DNA_DS,
                  normalize_counts=True, kind=EUCLIDEAN, p=2.0, normalize_distances=True, keep_at_most=2,
-                 max_neighbours=8, chunk_reads=0, depth=0, chunk_bases=0):
+                 max_neighbours=8, chunk_reads=0, depth=0, chunk_bases=0, record_timeline=False):
         self.tw = tw
         self.n_dims = tw.info()["n_dims"]
         self.outputs = int(outputs)
@@ -253,6 +253,7 @@ class Pipeline:
         cfg.kind, cfg.p, cfg.normalize_distances = int(kind), float(p), 1 if normalize_distances else 0
         cfg.outputs, cfg.keep_at_most, cfg.max_neighbours = self.outputs, int(keep_at_most or 0), self.max_neighbours
         cfg.chunk_reads, cfg.depth, cfg.chunk_bases = int(chunk_reads), int(depth), int(chunk_bases)
+        cfg.record_timeline = 1 if record_timeline else 0
         self.n_classes = 0
         cp = mp = None
         if classes is not None:
@@ -314,6 +315,14 @@ class Pipeline:
             out = self.alloc_outputs(len(offsets) - 1, pinned=pinned_outputs)
         self.collect(self.submit(bases, offsets, out))
         return out
+
+    def timeline(self, max_chunks=256):
+        """[chunks, 6] ms from the first upload's start: upload start/end, kernels start/end, download start/end of every
+        chunk of the last submit (record_timeline pipelines, after collect)"""
+        ms = np.zeros((max_chunks, 6))
+        n = C.c_uint32()
+        check(_lib.load().kpop_pipeline_timeline(self._h, int(max_chunks), _p(ms, C.c_double), C.byref(n)))
+        return ms[:n.value]
 
     def stats(self):
         ch, pin, dep = C.c_uint32(), C.c_int(), C.c_uint32()

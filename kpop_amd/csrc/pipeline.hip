@@ -82,6 +82,9 @@ struct kpop_pipeline {
   // statistics of the last submit (kpop_pipeline_stats)
   uint32_t last_chunks = 0;
   int last_pinned = 0;
+  // record_timeline: six timing events per chunk of the last submit
+  std::vector<hipEvent_t> tl_events;
+  uint32_t tl_chunks = 0;
 };
 
 namespace {
@@ -151,6 +154,7 @@ static void destroy(kpop_pipeline *pl) {
   }
   for (int i = 0; i < kTicketRing; ++i)
     if (pl->ticket_done[i]) (void)hipEventDestroy(pl->ticket_done[i]);
+  for (hipEvent_t e : pl->tl_events) (void)hipEventDestroy(e);
   if (pl->d_classes) (void)hipFree(pl->d_classes);
   if (pl->d_metric) (void)hipFree(pl->d_metric);
   if (pl->d_class_norms) (void)hipFree(pl->d_class_norms);
@@ -297,14 +301,33 @@ extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, con
   // chip for long enough to reach its streaming rate (12,500 reads: 0.38 ms, against 0.15 ms as an eighth of a 100,000-read
   // launch; profiles/r03_c_pipeline_trace.txt)
   uint32_t chunk_reads = pl->cfg.chunk_reads;
-  if (chunk_reads == 0) chunk_reads = std::min<uint32_t>(131072u, std::max<uint32_t>(16384u, (div_up(n_reads, 4) + 1023u) & ~1023u));
+  // ... and a SHORT FIRST chunk (a quarter of the others) when the size is the library's to choose: nothing comes down
+  // before the first chunk has gone up and been twisted, and a download-bound batch ends that much later (0.50 ms of a
+  // 2.46 ms batch with four equal chunks; profiles/r03_p_pipeline_timeline.txt)
+  uint32_t first_chunk = 0;
+  if (chunk_reads == 0) {
+    chunk_reads = std::min<uint32_t>(131072u, std::max<uint32_t>(16384u, (div_up(n_reads, 4) + 1023u) & ~1023u));
+    if (n_reads > chunk_reads) first_chunk = std::max<uint32_t>(4096u, (chunk_reads / 4) & ~1023u);
+  }
   const bool pin_tw = is_pinned(o->twisted), pin_di = is_pinned(o->distances), pin_st = is_pinned(o->stats),
              pin_nn = is_pinned(o->n_neighbours), pin_ix = is_pinned(o->nb_index), pin_nd = is_pinned(o->nb_distance),
              pin_nz = is_pinned(o->nb_z);
   pl->last_pinned = (is_pinned(bases) && is_pinned(offsets) && pin_tw && pin_di && pin_st && pin_nn && pin_ix && pin_nd && pin_nz) ? 1 : 0;
   uint32_t n_chunks = 0;
+  const bool timeline = pl->cfg.record_timeline != 0;
+  auto mark = [&](uint32_t chunk, int which, hipStream_t st) -> int {  // timing event `which` (0..5) of chunk
+    if (!timeline || chunk >= 256) return 0;
+    const size_t at = (size_t)chunk * 6 + which;
+    while (pl->tl_events.size() <= at) {
+      hipEvent_t e;
+      KPOP_HIP(hipEventCreate(&e));
+      pl->tl_events.push_back(e);
+    }
+    KPOP_HIP(hipEventRecord(pl->tl_events[at], st));
+    return 0;
+  };
   for (uint32_t r0 = 0; r0 < n_reads;) {
-    const uint32_t r1 = chunk_end(offsets, r0, n_reads, chunk_reads, pl->cfg.chunk_bases);
+    const uint32_t r1 = chunk_end(offsets, r0, n_reads, (r0 == 0 && first_chunk) ? first_chunk : chunk_reads, pl->cfg.chunk_bases);
     const uint32_t n = r1 - r0;
     const uint64_t b0 = offsets[r0], nb = offsets[r1] - b0;
     uint64_t max_len = 0;
@@ -326,12 +349,20 @@ extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, con
       KPOP_TRY(s.z.ensure((uint64_t)n * mn * 8));
     }
     // up
-    if (s.in_use) KPOP_HIP(hipStreamWaitEvent(pl->s_h2d, s.d2h_done, 0));
+    // The slot's previous chunk must have come down before the slot is overwritten.  The HOST waits for that, not the
+    // upload stream: an upload parked in its SDMA queue behind a stream-side wait keeps that engine from the downloads,
+    // which the runtime then runs as blit kernels at two thirds of the rate, on the CUs (a batch of five chunks through a
+    // ring of four: 2.95 ms instead of 2.05).  This is the pipeline's back-pressure: with `depth` chunks in flight, submit
+    // waits for the oldest.
+    if (s.in_use && hipEventQuery(s.d2h_done) != hipSuccess) KPOP_HIP(hipEventSynchronize(s.d2h_done));
+    KPOP_TRY(mark(n_chunks, 0, pl->s_h2d));
     if (nb) KPOP_HIP(hipMemcpyAsync(s.bases.p, bases + b0, nb, hipMemcpyHostToDevice, pl->s_h2d));
     KPOP_HIP(hipMemcpyAsync(s.offsets.p, offsets + r0, (uint64_t)(n + 1) * 8, hipMemcpyHostToDevice, pl->s_h2d));
+    KPOP_TRY(mark(n_chunks, 1, pl->s_h2d));
     KPOP_HIP(hipEventRecord(s.h2d_done, pl->s_h2d));
     // count -> twist -> distance: the kernels see the caller's absolute offsets, so the bases pointer is moved back by b0
     KPOP_HIP(hipStreamWaitEvent(pl->s_compute, s.h2d_done, 0));
+    KPOP_TRY(mark(n_chunks, 2, pl->s_compute));
     const uint8_t *d_bases = s.bases.as<uint8_t>() - b0;
     KPOP_TRY(kpop_dev_count_twist(pl->tw, d_bases, s.offsets.as<uint64_t>(), n, nb, (uint32_t)max_len, pl->cfg.content,
                                   pl->cfg.normalize_counts, s.twisted.as<double>(), pl->s_compute));
@@ -343,9 +374,11 @@ extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, con
                                          pl->cfg.normalize_distances, pl->cfg.keep_at_most, mn, s.work.p, s.stats.as<double>(),
                                          s.nn.as<uint32_t>(), s.idx.as<uint32_t>(), s.ndist.as<double>(), s.z.as<double>(),
                                          pl->s_compute));
+    KPOP_TRY(mark(n_chunks, 3, pl->s_compute));
     KPOP_HIP(hipEventRecord(s.compute_done, pl->s_compute));
     // down
     KPOP_HIP(hipStreamWaitEvent(pl->s_d2h, s.compute_done, 0));
+    KPOP_TRY(mark(n_chunks, 4, pl->s_d2h));
     if (outs & KPOP_OUT_TWISTED)
       KPOP_TRY(copy_down(o->twisted + (uint64_t)r0 * D, s.twisted.p, n, (uint64_t)D * 8, pin_tw, pl->s_d2h));
     if (outs & KPOP_OUT_DISTANCES)
@@ -359,12 +392,14 @@ extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, con
         KPOP_TRY(copy_down(o->nb_z + (uint64_t)r0 * mn, s.z.p, n, (uint64_t)mn * 8, pin_nz, pl->s_d2h));
       }
     }
+    KPOP_TRY(mark(n_chunks, 5, pl->s_d2h));
     KPOP_HIP(hipEventRecord(s.d2h_done, pl->s_d2h));
     s.in_use = true;
     ++n_chunks;
     r0 = r1;
   }
   pl->last_chunks = n_chunks;
+  pl->tl_chunks = timeline ? std::min<uint32_t>(n_chunks, 256) : 0;
   KPOP_HIP(hipEventRecord(pl->ticket_done[ti], pl->s_d2h));
   pl->ticket_id[ti] = tk;
   ++pl->next_ticket;
@@ -387,6 +422,22 @@ extern "C" int kpop_pipeline_run(kpop_pipeline *pl, const uint8_t *bases, const 
   uint64_t tk = 0;
   KPOP_TRY(kpop_pipeline_submit(pl, bases, offsets, n_reads, o, &tk));
   return kpop_pipeline_collect(pl, tk);
+}
+
+extern "C" int kpop_pipeline_timeline(kpop_pipeline *pl, uint32_t max_chunks, double *ms, uint32_t *n_chunks) {
+  if (!pl || !n_chunks || (max_chunks && !ms)) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_timeline: null argument");
+  if (!pl->cfg.record_timeline) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_timeline: the pipeline was created without record_timeline");
+  SlotGuard guard(pl->slot);
+  const uint32_t n = std::min(pl->tl_chunks, max_chunks);
+  for (uint32_t c = 0; c < n; ++c)
+    for (int w = 0; w < 6; ++w) {
+      float t = 0.f;
+      KPOP_HIP(hipEventSynchronize(pl->tl_events[(size_t)c * 6 + w]));
+      KPOP_HIP(hipEventElapsedTime(&t, pl->tl_events[0], pl->tl_events[(size_t)c * 6 + w]));
+      ms[(size_t)c * 6 + w] = (double)t;
+    }
+  *n_chunks = n;
+  return KPOP_OK;
 }
 
 extern "C" int kpop_pipeline_stats(const kpop_pipeline *pl, uint32_t *chunks, int *pinned, uint32_t *depth) {
