@@ -88,6 +88,8 @@ int kpop_synchronize(void *stream);
    merged spectrum of kpop_count_reads(per_read = 0) by atomic histogram where the hashes fit 26 bits, or always by sort;
    "histlds" 1 (default) | 0 | 2: that histogram staged through LDS (private tables up to k = 7; sorted chunks of assemblies,
    left off by a block that finds no repetition), direct global atomics as in round 2, or chunks always sorted;
+   "summary2" 1 (default) | 0: summaries against more than 4,096 rows by brackets from a sample and two passes over the
+   distance rows, or by round 2's one block per row;
    "dense" 0 (default) | 1 | 2: kpop_twist by the sparse mat-vec, by the dense contraction on the f64 matrix cores, or
    by the batch's density -- the one knob that changes results, in the last bits (kpop_dev_twist_dense); "ldspad" bytes of
    extra LDS per block of the fused reads kernel (an occupancy probe); "dbg" development switches (also KPOP_TUNE_DBG)  */

@@ -789,7 +789,8 @@ static int rowwise_impl(const double *m1, uint32_t r1, const double *m2, uint32_
 // summary_large.hip
 int launch_summary_large(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most,
                          uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
-                         double *out_dist, double *out_z, hipStream_t st);
+                         double *out_dist, double *out_z, hipStream_t st, void *scratch);
+uint64_t summary_large_scratch_bytes(uint32_t n_rows, uint32_t r1);
 
 // r1 > kSummaryMaxR1: query rows in chunks, distance rows of a chunk in the library workspace
 template <int KIND>
@@ -804,13 +805,15 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
   const uint64_t budget = 4096ull << 20;
   const uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(r2, budget / ((uint64_t)r1 * 8)));
   void *ws = nullptr;
-  KPOP_TRY(ctx().ws_for(st).ensure((uint64_t)chunk * r1 * 8, &ws));
+  const uint64_t row_bytes = ((uint64_t)chunk * r1 * 8 + 255) & ~255ull;
+  KPOP_TRY(ctx().ws_for(st).ensure(row_bytes + summary_large_scratch_bytes(chunk, r1), &ws));
   double *rows = reinterpret_cast<double *>(ws);
+  void *scratch = reinterpret_cast<char *>(ws) + row_bytes;
   for (uint32_t q0 = 0; q0 < r2; q0 += chunk) {
     const uint32_t q = std::min(chunk, r2 - q0);
     KPOP_TRY(rowwise_block<KIND>(a, r1, b + (uint64_t)q0 * n_dims, q, n_dims, metric, p, rows, st));
     KPOP_TRY(launch_summary_large(rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist,
-                                  out_z, st));
+                                  out_z, st, scratch));
   }
   return 0;
 }
@@ -1035,9 +1038,17 @@ extern "C" int kpop_dev_summarize_distances(const double *d_dist, uint32_t r2, u
   if (!d_out_stats || !d_out_n || (r1 && !d_dist)) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_summarize_distances: null argument");
   if (max_neighbours && (!d_out_idx || !d_out_dist || !d_out_z))
     KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_summarize_distances: null neighbour buffers");
-  if (r1 > kSummaryMaxR1)
-    return launch_summary_large(d_dist, r2, r1, 0, keep_at_most, max_neighbours, d_out_stats, d_out_n, d_out_idx, d_out_dist,
-                                d_out_z, as_stream(stream));
+  if (r1 > kSummaryMaxR1) {
+    // rows in chunks of up to 512, so that the two-pass path's lists stay a few hundred megabytes
+    hipStream_t st = as_stream(stream);
+    const uint32_t chunk = std::min<uint32_t>(r2, 512);
+    void *scratch = nullptr;
+    KPOP_TRY(ctx().ws_for(st).ensure(summary_large_scratch_bytes(chunk, r1), &scratch));
+    for (uint32_t q0 = 0; q0 < r2; q0 += chunk)
+      KPOP_TRY(launch_summary_large(d_dist + (uint64_t)q0 * r1, std::min(chunk, r2 - q0), r1, q0, keep_at_most, max_neighbours, d_out_stats,
+                                    d_out_n, d_out_idx, d_out_dist, d_out_z, st, scratch));
+    return KPOP_OK;
+  }
   return launch_summary<KPOP_EUCLIDEAN, true>(d_dist, r1, nullptr, r2, 1, nullptr, 2.0, keep_at_most, max_neighbours,
                                               d_out_stats, d_out_n, d_out_idx, d_out_dist, d_out_z, as_stream(stream));
 }

@@ -60,9 +60,22 @@ __device__ uint32_t block_scan_flag(bool flag, uint32_t *s_w, uint32_t *total) {
   return pre + below;
 }
 
+// how a selection reaches its elements: a plain array, or a SAMPLE of a long row -- kSampleRun consecutive elements out of
+// every `stride` (runs of whole 128-byte lines, so the sample costs what it reads)
+constexpr uint32_t kSampleRun = 1024;
+struct PlainRow {
+  const double *p;
+  __device__ __forceinline__ double operator[](uint32_t i) const { return p[i]; }
+};
+struct SampledRow {
+  const double *p;
+  uint32_t stride;  // elements between the starts of two runs
+  __device__ __forceinline__ double operator[](uint32_t i) const { return p[(uint64_t)(i / kSampleRun) * stride + (i % kSampleRun)]; }
+};
+
 // TRANSFORM 0: key of row[i]; 1: key of |row[i] - centre|
-template <int TRANSFORM>
-__device__ __forceinline__ uint64_t elem_key(const double *row, uint32_t i, double centre) {
+template <int TRANSFORM, class Row>
+__device__ __forceinline__ uint64_t elem_key(const Row &row, uint32_t i, double centre) {
   const double x = TRANSFORM ? fabs(__dsub_rn(row[i], centre)) : row[i];
   return f64_key(x);
 }
@@ -96,8 +109,8 @@ __device__ __forceinline__ int range_shift(uint64_t lo, uint64_t hi) {  // small
 // All threads call with the same arguments.  s_hist: kSel * kBins u32; s_cand: kSel * kCand u64; s_misc: 64 u32.
 // SUMSQ: the first pass over the row also adds up (row[i] - centre)^2 into *sumsq_part (this thread's share; the caller
 // reduces it) -- the sample variance rides on the first selection pass instead of a pass of its own.
-template <int TRANSFORM, bool SUMSQ = false>
-__device__ void block_select_ranks(const double *row, uint32_t n, double centre, Sel *sel, int n_sel, uint32_t *s_hist,
+template <int TRANSFORM, bool SUMSQ = false, class Row = PlainRow>
+__device__ void block_select_ranks(const Row row, uint32_t n, double centre, Sel *sel, int n_sel, uint32_t *s_hist,
                                    uint64_t *s_cand, uint32_t *s_misc, double *sumsq_part = nullptr) {
   for (int round = 0; round < 8; ++round) {
     bool any = false;
@@ -141,7 +154,13 @@ __device__ void block_select_ranks(const double *row, uint32_t n, double centre,
       if (sel[t].done) continue;
       const uint32_t bin = s_misc[t * 4 + 0], cum = s_misc[t * 4 + 1], cnt = s_misc[t * 4 + 2];
       const uint64_t blo = sel[t].lo + ((uint64_t)bin << shift[t]);
-      const uint64_t bhi = shift[t] ? min(sel[t].hi, blo + ((1ull << shift[t]) - 1)) : blo;
+      // (u64 arithmetic spelt out: HIP's min() of an `unsigned long` and an `unsigned long long` goes through double, and
+      // rounded these keys to multiples of 1,024 -- round 2's selections went wrong on tie groups of more than kCand)
+      const uint64_t bend = blo + (((uint64_t)1 << shift[t]) - (uint64_t)1);
+      const uint64_t bhi = shift[t] ? (bend < sel[t].hi ? bend : sel[t].hi) : blo;
+#ifdef KPOP_SELECT_DEBUG
+      if (threadIdx.x == 0) printf("round %d sel %d shift %d bin %u cum %u cnt %u range %.17g .. %.17g rank %u\n", round, t, shift[t], bin, cum, cnt, key_f64(blo), key_f64(bhi), sel[t].rank);
+#endif
       sel[t].lo = blo;
       sel[t].hi = bhi;
       sel[t].below = cum;
@@ -202,11 +221,15 @@ __device__ void block_select_ranks(const double *row, uint32_t n, double centre,
   }
 }
 
+struct RowCounts;
+__device__ bool row_failed(const RowCounts *cnt, uint32_t row);
+
 __global__ __launch_bounds__(kLT) void summary_large_kernel(const double *__restrict__ rows, uint32_t r1, uint32_t row0,
                                                             uint32_t req_len, uint32_t max_neighbours,
                                                             double *__restrict__ out_stats, uint32_t *__restrict__ out_n,
                                                             uint32_t *__restrict__ out_idx, double *__restrict__ out_dist,
-                                                            double *__restrict__ out_z) {
+                                                            double *__restrict__ out_z, const RowCounts *only_failed = nullptr) {
+  if (only_failed && !row_failed(only_failed, blockIdx.x)) return;  // (round 3: the fallback of the two-pass path)
   __shared__ double s_w[kLT / 64];
   __shared__ uint32_t s_wu[kLT / 64];
   __shared__ uint32_t s_hist[kSel * kBins];
@@ -255,7 +278,7 @@ __global__ __launch_bounds__(kLT) void summary_large_kernel(const double *__rest
     const bool cut = req_len < n;
     sel[1] = Sel{cut ? req_len - 1 : 0, kmin, kmax, 0, 0, 0, 0, cut ? 0 : 1};
     double sq = 0.0;
-    block_select_ranks<0, true>(row, n, mean, sel, 2, s_hist, s_cand, s_misc, &sq);
+    block_select_ranks<0, true>(PlainRow{row}, n, mean, sel, 2, s_hist, s_cand, s_misc, &sq);
     const double ss = block_sum(sq, s_w);
     sd = (n > 1) ? sqrt(ss / ((double)n - 1.0)) : 0.0;
     median = key_f64(sel[0].value);
@@ -271,7 +294,7 @@ __global__ __launch_bounds__(kLT) void summary_large_kernel(const double *__rest
       n_lt = sel[1].n_less;
     } else {  // the list is cut short (or holds everything): its last value is the element of rank M - 1
       Sel s3[1] = {Sel{M - 1, kmin, kmax, 0, 0, 0, 0, 0}};
-      block_select_ranks<0>(row, n, 0.0, s3, 1, s_hist, s_cand, s_misc);
+      block_select_ranks<0>(PlainRow{row}, n, 0.0, s3, 1, s_hist, s_cand, s_misc);
       vkey = s3[0].value;
       n_lt = s3[0].n_less;
     }
@@ -332,7 +355,7 @@ __global__ __launch_bounds__(kLT) void summary_large_kernel(const double *__rest
   if (n) {
     const double far = fmax(fabs(__dsub_rn(key_f64(kmax), median)), fabs(__dsub_rn(key_f64(kmin), median)));
     Sel sm[1] = {Sel{n / 2, f64_key(0.0), f64_key(far), 0, 0, 0, 0, 0}};
-    block_select_ranks<1>(row, n, median, sm, 1, s_hist, s_cand, s_misc);
+    block_select_ranks<1>(PlainRow{row}, n, median, sm, 1, s_hist, s_cand, s_misc);
     mad = key_f64(sm[0].value);
   }
   if (threadIdx.x == 0) {
@@ -344,12 +367,432 @@ __global__ __launch_bounds__(kLT) void summary_large_kernel(const double *__rest
   }
 }
 
+// ===========================================================================
+// Round 3: the same summaries in TWO passes over the distance rows instead of eight to ten.
+//
+// A row of 10^6 distances does not fit anything on chip, so every selection above walks it from HBM several times, and
+// one block per row leaves most of the chip idle.  Here the order statistics are BRACKETED first, from a sample:
+//
+//   sample   (one block a row; reads 6 % of it)  65,536 elements in runs of 1,024: their mean m^, and by exact selection
+//            on the sample the keys (lo, hi) that bracket the row's median with six sigmas to spare (+-1.2 % of the ranks)
+//            and the key `cut` below which, generously, lie the keep_at_most closest;
+//   pass 1   (all CUs: the row cut into slices of 32,768)  every element once: counted below lo / at lo / at hi, appended
+//            to the row's candidate list when strictly between, appended to its neighbour list when <= cut; sum d and
+//            sum (d - m^)^2 per slice;
+//   finish 1 (one block a row)  mean and sd from the slices' sums in slice order (sum (d - mean)^2 = sum (d - m^)^2 -
+//            n (mean - m^)^2: m^ is within sd / 256 of the mean, nothing cancels); the EXACT median by selection among
+//            the ~2 % candidates at the rank the counts leave open; the exact cut value, eff_len and the sorted neighbours
+//            from the neighbour list; then the sample again, for the bracket of the MAD (|d - median|);
+//   pass 2   (all CUs)  |d - median| counted / collected the same way;
+//   finish 2 the exact MAD.
+//
+// Every result is the exact order statistic -- the sample only decides what is collected.  A row whose brackets miss
+// (the rank falls outside them: a database in an adversarial order), whose lists overflow (a tie group of tens of thousands
+// at the median or the cut) or whose keep_at_most exceeds what the lists hold is flagged and redone by the kernel above.
+// HBM traffic: the rows once written, twice read.
+// ===========================================================================
+constexpr uint32_t kSample = 65536, kSlice = 32768, kCandCap = 65536, kNbCap = 16384, kNbSort = 4096;
+
+struct RowInfo {   // written by the sample / finish kernels, read by the passes
+  double m_hat, median, mean, sd;
+  uint64_t klo, khi, kcut;   // brackets of the median (keys of d), neighbour threshold
+  uint64_t mlo, mhi;         // bracket of the MAD (keys of |d - median|)
+  uint32_t sample_n, sample_stride;
+};
+struct RowCounts {
+  uint32_t lt_lo, eq_lo, n_cand, eq_hi, n_nb;       // pass 1
+  uint32_t m_lt, m_eqlo, m_cand, m_eqhi;            // pass 2
+  uint32_t fail, pad0, pad1;
+};
+
+__device__ __forceinline__ uint32_t sample_count(uint32_t n, uint32_t *stride) {
+  if (n <= kSample) {
+    *stride = kSampleRun;
+    return n;
+  }
+  const uint32_t runs = kSample / kSampleRun;
+  *stride = n / runs;  // >= kSampleRun
+  return runs * kSampleRun;
+}
+
+// brackets of rank r of n from a sample of s: sample ranks r s / n -+ 6 sqrt(s) / 2 (six standard deviations of a sample
+// quantile's rank), clamped
+__device__ __forceinline__ void bracket_ranks(uint32_t r, uint32_t n, uint32_t s, uint32_t *a, uint32_t *b) {
+  const double c = (double)r * (double)s / (double)n, w = 3.0 * sqrt((double)s) + 2.0;
+  const double lo = c - w, hi = c + w;
+  *a = lo <= 0.0 ? 0u : (uint32_t)lo;
+  *b = hi >= (double)(s - 1) ? s - 1 : (uint32_t)hi;
+}
+
+__global__ __launch_bounds__(kLT) void summary2_sample_kernel(const double *__restrict__ rows, uint32_t r1, uint32_t req_len,
+                                                              RowInfo *__restrict__ info, RowCounts *__restrict__ cnt) {
+  __shared__ double s_w[kLT / 64];
+  __shared__ uint32_t s_hist[kSel * kBins];
+  __shared__ uint64_t s_cand[kSel * kCand];
+  __shared__ uint32_t s_misc[64];
+  __shared__ uint64_t s_mm[2 * (kLT / 64)];
+  const double *row = rows + (uint64_t)blockIdx.x * r1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t stride;
+  const uint32_t s = sample_count(r1, &stride);
+  const SampledRow sr{row, stride};
+  double part = 0.0;
+  uint64_t kmin = ~0ull, kmax = 0;
+  for (uint32_t i = threadIdx.x; i < s; i += kLT) {
+    const double x = sr[i];
+    part = __dadd_rn(part, x);
+    const uint64_t k = f64_key(x);
+    kmin = min(kmin, k);
+    kmax = max(kmax, k);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    kmin = min(kmin, (uint64_t)__shfl_xor((unsigned long long)kmin, o, 64));
+    kmax = max(kmax, (uint64_t)__shfl_xor((unsigned long long)kmax, o, 64));
+  }
+  if (lane == 0) {
+    s_mm[wv] = kmin;
+    s_mm[kLT / 64 + wv] = kmax;
+  }
+  const double m_hat = s ? block_sum(part, s_w) / (double)s : 0.0;
+  for (int w = 0; w < kLT / 64; ++w) {
+    kmin = min(kmin, s_mm[w]);
+    kmax = max(kmax, s_mm[kLT / 64 + w]);
+  }
+  uint32_t a, b;
+  bracket_ranks(r1 / 2, r1, s, &a, &b);
+  Sel sel[kSel] = {Sel{a, kmin, kmax, 0, 0, 0, 0, 0}, Sel{b, kmin, kmax, 0, 0, 0, 0, 0}};
+  block_select_ranks<0, false, SampledRow>(sr, s, 0.0, sel, 2, s_hist, s_cand, s_misc);
+  // the neighbour threshold: three times the sample rank the keep_at_most-th closest would have, and a margin; a bracket
+  // that reaches the sample's end takes everything (the whole row is the list: only small rows can afford that)
+  uint64_t kcut = ~0ull;
+  {
+    const double want = 3.0 * (double)req_len * (double)s / (double)r1 + 16.0;
+    if (want < (double)(s - 1)) {
+      Sel sc[1] = {Sel{(uint32_t)want, kmin, kmax, 0, 0, 0, 0, 0}};
+      block_select_ranks<0, false, SampledRow>(sr, s, 0.0, sc, 1, s_hist, s_cand, s_misc);
+      kcut = sc[0].value;
+    }
+  }
+  if (threadIdx.x == 0) {
+    RowInfo &I = info[blockIdx.x];
+    I.m_hat = m_hat;
+    I.klo = a == 0 ? 0ull : sel[0].value;           // rank 0 of the sample bounds nothing from below
+    I.khi = b == s - 1 ? ~0ull : sel[1].value;
+    I.kcut = kcut;
+    I.sample_n = s;
+    I.sample_stride = stride;
+    RowCounts z = {};
+    cnt[blockIdx.x] = z;
+  }
+}
+
+// append to a per-row list with one atomic per wave
+__device__ __forceinline__ uint32_t wave_append(bool want, uint32_t *counter, int lane) {
+  const uint64_t m = __ballot(want);
+  uint32_t base = 0;
+  if (m) {
+    const int leader = __ffsll((long long)m) - 1;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+  }
+  return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+// pass 1 (PASS = 1) and pass 2 (PASS = 2) over slice blockIdx.x of row blockIdx.y
+template <int PASS>
+__global__ __launch_bounds__(256) void summary2_pass_kernel(const double *__restrict__ rows, uint32_t r1, const RowInfo *__restrict__ info,
+                                                            RowCounts *__restrict__ cnt, double *__restrict__ cand, uint32_t *__restrict__ nb_idx,
+                                                            double *__restrict__ nb_d, double *__restrict__ part, uint32_t n_slices) {
+  __shared__ uint32_t s_c[4];
+  __shared__ double s_p[2][4];
+  const uint32_t j = blockIdx.y, sl = blockIdx.x;
+  const double *row = rows + (uint64_t)j * r1;
+  const RowInfo I = info[j];
+  RowCounts *C = cnt + j;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t i0 = sl * kSlice, i1 = min(r1, i0 + kSlice);
+  const uint64_t lo = PASS == 1 ? I.klo : I.mlo, hi = PASS == 1 ? I.khi : I.mhi;
+  double *my_cand = cand + (uint64_t)j * kCandCap;
+  uint32_t c_lt = 0, c_eqlo = 0, c_eqhi = 0;
+  double sum = 0.0, sq = 0.0;
+  for (uint32_t base = i0; base < i1; base += 256) {
+    const uint32_t i = base + threadIdx.x;
+    const bool ok = i < i1;
+    const double d = ok ? row[i] : 0.0;
+    const double x = PASS == 1 ? d : fabs(__dsub_rn(d, I.median));
+    const uint64_t k = f64_key(x);
+    if (ok) {
+      c_lt += k < lo;
+      c_eqlo += k == lo;
+      c_eqhi += (k == hi) && hi != lo;
+      if (PASS == 1) {
+        sum = __dadd_rn(sum, d);
+        const double dv = __dsub_rn(d, I.m_hat);
+        sq = __dadd_rn(sq, __dmul_rn(dv, dv));
+      }
+    }
+    const bool is_cand = ok && k > lo && k < hi;
+    if (__ballot(is_cand)) {
+      const uint32_t at = wave_append(is_cand, PASS == 1 ? &C->n_cand : &C->m_cand, lane);
+      if (is_cand && at < kCandCap) my_cand[at] = x;
+    }
+    if (PASS == 1) {
+      const bool is_nb = ok && k <= I.kcut;
+      if (__ballot(is_nb)) {
+        const uint32_t at = wave_append(is_nb, &C->n_nb, lane);
+        if (is_nb && at < kNbCap) {
+          nb_idx[(uint64_t)j * kNbCap + at] = i;
+          nb_d[(uint64_t)j * kNbCap + at] = d;
+        }
+      }
+    }
+  }
+  // the block's counts: one atomic each; its sums: one slot each (added up in slice order by the finish kernel)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    c_lt += __shfl_xor((int)c_lt, o, 64);
+    c_eqlo += __shfl_xor((int)c_eqlo, o, 64);
+    c_eqhi += __shfl_xor((int)c_eqhi, o, 64);
+    if (PASS == 1) {
+      sum = __dadd_rn(sum, __shfl_xor(sum, o, 64));
+      sq = __dadd_rn(sq, __shfl_xor(sq, o, 64));
+    }
+  }
+  if (threadIdx.x < 4) s_c[threadIdx.x] = 0;
+  __syncthreads();
+  if (lane == 0) {
+    if (c_lt) atomicAdd(&s_c[0], c_lt);
+    if (c_eqlo) atomicAdd(&s_c[1], c_eqlo);
+    if (c_eqhi) atomicAdd(&s_c[2], c_eqhi);
+    s_p[0][wv] = sum;
+    s_p[1][wv] = sq;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_c[0]) atomicAdd(PASS == 1 ? &C->lt_lo : &C->m_lt, s_c[0]);
+    if (s_c[1]) atomicAdd(PASS == 1 ? &C->eq_lo : &C->m_eqlo, s_c[1]);
+    if (s_c[2]) atomicAdd(PASS == 1 ? &C->eq_hi : &C->m_eqhi, s_c[2]);
+    if (PASS == 1) {
+      part[((uint64_t)j * n_slices + sl) * 2 + 0] = __dadd_rn(__dadd_rn(__dadd_rn(s_p[0][0], s_p[0][1]), s_p[0][2]), s_p[0][3]);
+      part[((uint64_t)j * n_slices + sl) * 2 + 1] = __dadd_rn(__dadd_rn(__dadd_rn(s_p[1][0], s_p[1][1]), s_p[1][2]), s_p[1][3]);
+    }
+  }
+}
+
+// the exact order statistic of rank r from what a pass left: counts below / at the bracket's ends and the values
+// strictly inside it.  false: the bracket missed or the list overflowed.
+__device__ bool pick_from_bracket(uint32_t r, uint32_t lt, uint32_t eqlo, uint32_t n_cand, uint32_t eqhi, uint64_t klo, uint64_t khi,
+                                  const double *cand, uint32_t *s_hist, uint64_t *s_cand, uint32_t *s_misc, double *out) {
+  if (r < lt) return false;
+  if (r < lt + eqlo) {
+    *out = key_f64(klo);
+    return true;
+  }
+  if (r < lt + eqlo + n_cand) {
+    if (n_cand > kCandCap) return false;
+    // the list's own range: its keys lie strictly between the bracket's
+    Sel sel[1] = {Sel{r - lt - eqlo, klo, khi, 0, 0, 0, 0, 0}};
+    block_select_ranks<0>(PlainRow{cand}, n_cand, 0.0, sel, 1, s_hist, s_cand, s_misc);
+    *out = key_f64(sel[0].value);
+    return true;
+  }
+  if (r < lt + eqlo + n_cand + eqhi) {
+    *out = key_f64(khi);
+    return true;
+  }
+  return false;
+}
+
+// finish 1 (STAGE = 1): mean, sd, median, neighbours, the MAD's bracket; finish 2 (STAGE = 2): the MAD and the row of statistics
+template <int STAGE>
+__global__ __launch_bounds__(kLT) void summary2_finish_kernel(const double *__restrict__ rows, uint32_t r1, uint32_t row0, uint32_t req_len,
+                                                              uint32_t max_neighbours, RowInfo *__restrict__ info, RowCounts *__restrict__ cnt,
+                                                              const double *__restrict__ cand, const uint32_t *__restrict__ nb_idx,
+                                                              const double *__restrict__ nb_d, const double *__restrict__ part, uint32_t n_slices,
+                                                              double *__restrict__ out_stats, uint32_t *__restrict__ out_n,
+                                                              uint32_t *__restrict__ out_idx, double *__restrict__ out_dist, double *__restrict__ out_z) {
+  __shared__ uint32_t s_hist[kSel * kBins];
+  __shared__ uint64_t s_cand[kSel * kCand];
+  __shared__ uint32_t s_misc[64];
+  __shared__ double s_cd[kNbSort];
+  __shared__ uint32_t s_ci[kNbSort];
+  __shared__ uint32_t s_take;
+  const uint32_t jl = blockIdx.x, j = row0 + jl, n = r1;
+  RowInfo &I = info[jl];
+  RowCounts &C = cnt[jl];
+  if (C.fail) return;
+  const double *my_cand = cand + (uint64_t)jl * kCandCap;
+  if (STAGE == 2) {
+    double mad = 0.0;
+    const bool ok = pick_from_bracket(n / 2, C.m_lt, C.m_eqlo, C.m_cand, C.m_eqhi, I.mlo, I.mhi, my_cand, s_hist, s_cand, s_misc, &mad);
+    if (threadIdx.x == 0) {
+      if (!ok) C.fail = 1;
+      else {
+        out_stats[(uint64_t)j * 4 + 0] = I.mean;
+        out_stats[(uint64_t)j * 4 + 1] = I.sd;
+        out_stats[(uint64_t)j * 4 + 2] = I.median;
+        out_stats[(uint64_t)j * 4 + 3] = mad;
+      }
+    }
+    return;
+  }
+  // ---- mean and sd: the slices' sums in slice order (every thread the same chain: a few dozen additions)
+  double sum = 0.0, sqh = 0.0;
+  for (uint32_t s = 0; s < n_slices; ++s) {
+    sum = __dadd_rn(sum, part[((uint64_t)jl * n_slices + s) * 2 + 0]);
+    sqh = __dadd_rn(sqh, part[((uint64_t)jl * n_slices + s) * 2 + 1]);
+  }
+  const double mean = sum / (double)n;
+  const double dm = __dsub_rn(mean, I.m_hat);
+  const double ss = fmax(0.0, __dsub_rn(sqh, __dmul_rn((double)n, __dmul_rn(dm, dm))));
+  const double sd = n > 1 ? sqrt(ss / ((double)n - 1.0)) : 0.0;
+  // ---- the median
+  double median = 0.0;
+  bool ok = pick_from_bracket(n / 2, C.lt_lo, C.eq_lo, C.n_cand, C.eq_hi, I.klo, I.khi, my_cand, s_hist, s_cand, s_misc, &median);
+  // ---- the neighbours: the list holds every element with key <= kcut, i.e. the n_nb smallest
+  const uint32_t n_nb = C.n_nb;
+  const uint32_t *my_idx = nb_idx + (uint64_t)jl * kNbCap;
+  const double *my_d = nb_d + (uint64_t)jl * kNbCap;
+  uint32_t eff = n;
+  if (n_nb > kNbCap || (n_nb < n && req_len > n_nb) || (n_nb == n && n > kNbCap)) ok = false;
+  if (ok) {
+    uint32_t M;
+    uint64_t vkey = ~0ull;
+    const uint64_t k_top = I.kcut == ~0ull ? f64_key(__longlong_as_double(0x7FEFFFFFFFFFFFFFll)) : I.kcut;
+    if (req_len < n) {  // (always, here: the two-pass path is taken for keep_at_most <= 2,048 and rows of 65,536 and more)
+      Sel sc[1] = {Sel{req_len - 1, 0ull, k_top, 0, 0, 0, 0, 0}};  // (from key 0: a caller's matrix may hold negative entries)
+      block_select_ranks<0>(PlainRow{my_d}, n_nb, 0.0, sc, 1, s_hist, s_cand, s_misc);
+      eff = sc[0].n_less + sc[0].n_equal;
+      vkey = sc[0].value;
+    }
+    M = min(min(eff, max_neighbours), kLargeMaxNb);
+    if (M && M < eff) {  // the list is cut short by the caller's stride: its last value is the element of rank M - 1
+      Sel s3[1] = {Sel{M - 1, 0ull, k_top, 0, 0, 0, 0, 0}};
+      block_select_ranks<0>(PlainRow{my_d}, n_nb, 0.0, s3, 1, s_hist, s_cand, s_misc);
+      vkey = s3[0].value;
+    }
+    if (M) {
+      // gather the elements closer than the last value, and those AT it; sort by (distance, column); the first M
+      __syncthreads();
+      if (threadIdx.x == 0) s_take = 0;
+      __syncthreads();
+      for (uint32_t q = threadIdx.x; q < n_nb; q += kLT) {
+        const uint64_t k = f64_key(my_d[q]);
+        if (k <= vkey) {
+          const uint32_t at = atomicAdd(&s_take, 1u);
+          if (at < kNbSort) {
+            s_cd[at] = my_d[q];
+            s_ci[at] = my_idx[q];
+          }
+        }
+      }
+      __syncthreads();
+      const uint32_t got = s_take;
+      if (got > kNbSort || got < M) ok = false;  // (a tie group too large to sort here)
+      else {
+        uint32_t NP = 1;
+        while (NP < got) NP <<= 1;
+        for (uint32_t q = got + threadIdx.x; q < NP; q += kLT) {
+          s_cd[q] = __longlong_as_double(0x7FF0000000000000ll);
+          s_ci[q] = 0xFFFFFFFFu;
+        }
+        for (uint32_t sz = 2; sz <= NP; sz <<= 1)
+          for (uint32_t t = sz >> 1; t > 0; t >>= 1) {
+            __syncthreads();
+            for (uint32_t q = threadIdx.x; q < NP / 2; q += kLT) {
+              const uint32_t a = 2 * q - (q & (t - 1)), b = a + t;
+              const bool asc = (a & sz) == 0;
+              const double da = s_cd[a], db = s_cd[b];
+              const uint32_t ia = s_ci[a], ib = s_ci[b];
+              const bool gt = (db < da) || (db == da && ib < ia);
+              if (gt == asc) {
+                s_cd[a] = db; s_cd[b] = da;
+                s_ci[a] = ib; s_ci[b] = ia;
+              }
+            }
+          }
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < M; q += kLT) {
+          out_idx[(uint64_t)j * max_neighbours + q] = s_ci[q];
+          out_dist[(uint64_t)j * max_neighbours + q] = s_cd[q];
+          double zz = __dsub_rn(s_cd[q], mean) / sd;
+          if (zz != zz) zz = __longlong_as_double((long long)0xFFF8000000000000ull);  // x86 invalid-operation NaN, see distance.hip
+          out_z[(uint64_t)j * max_neighbours + q] = zz;
+        }
+      }
+    }
+  }
+  // ---- the bracket of the MAD: the sample's |d - median| at the ranks around the middle
+  uint64_t mlo = 0, mhi = ~0ull;
+  if (ok) {
+    const SampledRow sr{rows + (uint64_t)jl * r1, I.sample_stride};
+    const uint32_t s = I.sample_n;
+    uint32_t a, b;
+    bracket_ranks(n / 2, n, s, &a, &b);
+    // keys of |d - median| over the sample lie in [key(0), key(max |..|)]: the selection narrows from the full non-negative range
+    Sel sel[kSel] = {Sel{a, f64_key(0.0), f64_key(__longlong_as_double(0x7FEFFFFFFFFFFFFFll)), 0, 0, 0, 0, 0},
+                     Sel{b, f64_key(0.0), f64_key(__longlong_as_double(0x7FEFFFFFFFFFFFFFll)), 0, 0, 0, 0, 0}};
+    block_select_ranks<1, false, SampledRow>(sr, s, median, sel, 2, s_hist, s_cand, s_misc);
+    mlo = a == 0 ? 0ull : sel[0].value;
+    mhi = b == s - 1 ? ~0ull : sel[1].value;
+  }
+  if (threadIdx.x == 0) {
+    if (!ok) C.fail = 1;
+    I.mean = mean;
+    I.sd = sd;
+    I.median = median;
+    I.mlo = mlo;
+    I.mhi = mhi;
+    if (ok) out_n[j] = eff;
+  }
+}
+
+__device__ bool row_failed(const RowCounts *cnt, uint32_t row) { return cnt[row].fail != 0; }
+
+uint64_t summary_large_scratch_bytes(uint32_t n_rows, uint32_t r1) {
+  const uint64_t n_slices = (r1 + kSlice - 1) / kSlice;
+  return (uint64_t)n_rows * (sizeof(RowInfo) + sizeof(RowCounts) + (uint64_t)kCandCap * 8 + (uint64_t)kNbCap * 12 + n_slices * 16) + 4096;
+}
+
+// scratch = nullptr (or tune "summary2" off): the one-block-per-row kernel alone
 int launch_summary_large(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most,
                          uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
-                         double *out_dist, double *out_z, hipStream_t st) {
+                         double *out_dist, double *out_z, hipStream_t st, void *scratch) {
   const uint32_t req_len = keep_at_most ? keep_at_most : r1;
-  summary_large_kernel<<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, req_len, max_neighbours, out_stats, out_n,
-                                                           out_idx, out_dist, out_z);
+  const bool two_pass = scratch && ctx().tune_summary2 && req_len <= kLargeMaxNb && r1 >= 2 * kSlice;
+  if (!two_pass) {
+    summary_large_kernel<<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist,
+                                                             out_z, nullptr);
+    KPOP_LAUNCH_CHECK();
+    return 0;
+  }
+  const uint32_t n_slices = (r1 + kSlice - 1) / kSlice;
+  char *p = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(scratch) + 255) & ~(uintptr_t)255);
+  RowInfo *info = reinterpret_cast<RowInfo *>(p);
+  p += ((uint64_t)n_rows * sizeof(RowInfo) + 255) & ~255ull;
+  RowCounts *cnt = reinterpret_cast<RowCounts *>(p);
+  p += ((uint64_t)n_rows * sizeof(RowCounts) + 255) & ~255ull;
+  double *cand = reinterpret_cast<double *>(p);
+  p += (uint64_t)n_rows * kCandCap * 8;
+  double *nb_d = reinterpret_cast<double *>(p);
+  p += (uint64_t)n_rows * kNbCap * 8;
+  uint32_t *nb_idx = reinterpret_cast<uint32_t *>(p);
+  p += (uint64_t)n_rows * kNbCap * 4;
+  double *part = reinterpret_cast<double *>(p);
+  summary2_sample_kernel<<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, req_len, info, cnt);
+  KPOP_LAUNCH_CHECK();
+  summary2_pass_kernel<1><<<dim3(n_slices, n_rows), dim3(256), 0, st>>>(rows, r1, info, cnt, cand, nb_idx, nb_d, part, n_slices);
+  KPOP_LAUNCH_CHECK();
+  summary2_finish_kernel<1><<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, req_len, max_neighbours, info, cnt, cand, nb_idx, nb_d, part, n_slices,
+                                                                out_stats, out_n, out_idx, out_dist, out_z);
+  KPOP_LAUNCH_CHECK();
+  summary2_pass_kernel<2><<<dim3(n_slices, n_rows), dim3(256), 0, st>>>(rows, r1, info, cnt, cand, nb_idx, nb_d, part, n_slices);
+  KPOP_LAUNCH_CHECK();
+  summary2_finish_kernel<2><<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, req_len, max_neighbours, info, cnt, cand, nb_idx, nb_d, part, n_slices,
+                                                                out_stats, out_n, out_idx, out_dist, out_z);
+  KPOP_LAUNCH_CHECK();
+  summary_large_kernel<<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, cnt);
   KPOP_LAUNCH_CHECK();
   return 0;
 }

@@ -218,6 +218,62 @@ def test_row_norms_and_distances_with_supplied_norms(kpop, oracle, kind, p):
     assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
 
 
+@pytest.mark.parametrize("case", ["random", "sorted", "ties", "constant", "clustered"])
+@pytest.mark.parametrize("keep", [2, 300])
+def test_summarize_distances_two_pass_path(kpop, oracle, case, keep):
+    """rows of 65,536 distances and more take the bracket-from-a-sample + two-pass path (summary_large.hip, round 3): exact
+    medians, MADs and neighbour lists whatever the sample saw -- a matrix in sorted order, heavy ties, constant rows and a
+    clustered one (the bracket misses: the row is redone by the one-block-per-row kernel) included; mean / sd to 1e-10"""
+    from kpop_amd import api
+    rng = np.random.RandomState(len(case) + keep)
+    r2, r1 = 5, 200003
+    if case == "random":
+        dm = np.abs(rng.normal(1.0, 0.2, size=(r2, r1)))
+    elif case == "sorted":
+        dm = np.sort(np.abs(rng.normal(1.0, 0.2, size=(r2, r1))), axis=1)
+        dm[1] = dm[1][::-1]
+    elif case == "ties":
+        dm = np.round(np.abs(rng.normal(1.0, 0.2, size=(r2, r1))), 2)  # ~100 distinct values: tie groups of thousands
+        dm[2, :5000] = 0.0
+    elif case == "constant":
+        dm = np.full((r2, r1), 0.75)
+        dm[3, 17] = 0.5
+    else:  # the first half of every row far from the second: a sample in runs still brackets; an adversary would not
+        dm = np.concatenate([rng.normal(1.0, 0.01, size=(r2, r1 // 2)), rng.normal(5.0, 0.01, size=(r2, r1 - r1 // 2))], axis=1)
+        dm[4, ::2] = 9.0  # ... and a row that alternates
+    cap = 512
+    for mode in (1, 0):
+        api.tune("summary2", mode)
+        st, n, idx, d, z = kpop.summarize_distances(dm, keep_at_most=keep, max_neighbours=cap)
+        for j in range(r2):
+            so, io, do, zo = oracle.summarize_row(dm[j], keep)
+            np.testing.assert_allclose(st[j, :2], so[:2], rtol=1e-10, atol=1e-13)
+            assert st[j, 2] == so[2] and st[j, 3] == so[3], (case, mode, j, st[j], so)  # median and MAD are order statistics: exact
+            assert n[j] == len(io)
+            m = min(n[j], cap)
+            assert idx[j, :m].tolist() == io[:m].tolist() and np.array_equal(d[j, :m], do[:m])
+    api.tune("summary2", 1)
+
+
+def test_distance_summary_two_pass_on_twisted_rows(kpop, oracle):
+    """the same path from twisted rows (distances computed on the device into the chunk's rows): 70,000 reference rows"""
+    rng = np.random.RandomState(9)
+    d, r1, r2 = 16, 70000, 6
+    m1 = np.round(rng.normal(size=(r1, d)), 2)
+    m2 = np.round(rng.normal(size=(r2, d)), 2)
+    m2[1] = m1[5]
+    metric = oracle.metric_powers(oracle.synth_inertia(d))
+    for keep in (1, 50):
+        st_o, offs, idx_o, dist_o, z_o = oracle.distance_summary(m1, m2, metric, 0, 2.0, True, keep)
+        st, n, idx, dist, z = kpop.distance_summary(m1, m2, metric, 0, 2.0, True, keep, max_neighbours=256)
+        np.testing.assert_allclose(st, st_o, rtol=1e-10, atol=1e-13)
+        for j in range(r2):
+            a, b = int(offs[j]), int(offs[j + 1])
+            assert n[j] == b - a
+            m = min(n[j], 256)
+            assert idx[j, :m].tolist() == idx_o[a:a + m].tolist() and np.array_equal(dist[j, :m], dist_o[a:a + m])
+
+
 def test_large_reference_set_refuses_lists_it_cannot_fill(kpop, oracle):
     """against more than 4,096 rows at most 2,048 neighbours come back per row: a caller that asks for more room than
     that (keep_at_most = all) gets an error, not rows of zeros (KPopTwistDB then exits 1 instead of printing them)"""
