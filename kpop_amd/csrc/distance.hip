@@ -702,6 +702,16 @@ __global__ void reduce_slabs_kernel(const double *__restrict__ partial, uint64_t
 template <int KIND>
 static int rowwise_block(const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims, const double *metric,
                          double p, double *out, hipStream_t st, const double *na = nullptr, const double *nb = nullptr) {
+  // A few rows against a very long first operand (the chunks of the large-reference summary: 256-512 query rows against
+  // 10^6): tiles of 32 columns x 256 rows, so the long operand is read from HBM ONCE per 256 rows (tiles of 64 x 32 read it
+  // eight times for 256 rows: 4.1 GB moved for 2.56) while the short one stays in L2.
+  if (r1 >= 65536 && r2 <= 4096 && !(ctx().tune_dbg & 8192)) {
+    const uint32_t w = 32, n_cg = 8, n_rg = 32, TJ = 8 * n_rg;
+    distance_rowwise_kernel<KIND, false, 8><<<dim3(div_up(r1, w), div_up(r2, TJ)), dim3(256), 0, st>>>(a, w, r1, b, r2, n_dims, metric, p, out, n_cg,
+                                                                                                       n_rg, 0, na, nb);
+    KPOP_LAUNCH_CHECK();
+    return 0;
+  }
   // balanced column tiles of 64..127 columns (one tile below 128)
   const uint32_t n_tiles = std::max(1u, r1 / 64);
   const uint32_t w = div_up(r1, n_tiles);

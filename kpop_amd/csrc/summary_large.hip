@@ -391,7 +391,9 @@ __global__ __launch_bounds__(kLT) void summary_large_kernel(const double *__rest
 // at the median or the cut) or whose keep_at_most exceeds what the lists hold is flagged and redone by the kernel above.
 // HBM traffic: the rows once written, twice read.
 // ===========================================================================
-constexpr uint32_t kSample = 65536, kSlice = 32768, kCandCap = 65536, kNbCap = 16384, kNbSort = 4096;
+constexpr uint32_t kSample = 65536, kSlice = 32768, kNbCap = 16384, kNbSort = 4096;
+// the brackets hold ~2.3 % of a row (six sigmas of a 65,536-element sample's quantile, both sides): room for 6 %, at least 65,536
+static inline uint32_t cand_cap_for(uint32_t r1) { return std::max<uint32_t>(65536u, ((r1 / 16 + 4095u) & ~4095u)); }
 
 struct RowInfo {   // written by the sample / finish kernels, read by the passes
   double m_hat, median, mean, sd;
@@ -503,9 +505,14 @@ __device__ __forceinline__ uint32_t wave_append(bool want, uint32_t *counter, in
 template <int PASS>
 __global__ __launch_bounds__(256) void summary2_pass_kernel(const double *__restrict__ rows, uint32_t r1, const RowInfo *__restrict__ info,
                                                             RowCounts *__restrict__ cnt, double *__restrict__ cand, uint32_t *__restrict__ nb_idx,
-                                                            double *__restrict__ nb_d, double *__restrict__ part, uint32_t n_slices) {
+                                                            double *__restrict__ nb_d, double *__restrict__ part, uint32_t n_slices, uint32_t kCandCap) {
   __shared__ uint32_t s_c[4];
   __shared__ double s_p[2][4];
+  // the block's candidates wait in LDS and go to the row's list in one piece: a global atomic per wave and iteration on the
+  // row's ONE counter (124 waves a row) was what the pass waited for -- 1.17 ms against the 0.45 its 2 GB take to read
+  constexpr uint32_t kStage = 4096;
+  __shared__ double s_stage[kStage];
+  __shared__ uint32_t s_n, s_base;
   const uint32_t j = blockIdx.y, sl = blockIdx.x;
   const double *row = rows + (uint64_t)j * r1;
   const RowInfo I = info[j];
@@ -516,38 +523,64 @@ __global__ __launch_bounds__(256) void summary2_pass_kernel(const double *__rest
   double *my_cand = cand + (uint64_t)j * kCandCap;
   uint32_t c_lt = 0, c_eqlo = 0, c_eqhi = 0;
   double sum = 0.0, sq = 0.0;
-  for (uint32_t base = i0; base < i1; base += 256) {
-    const uint32_t i = base + threadIdx.x;
-    const bool ok = i < i1;
-    const double d = ok ? row[i] : 0.0;
-    const double x = PASS == 1 ? d : fabs(__dsub_rn(d, I.median));
-    const uint64_t k = f64_key(x);
-    if (ok) {
-      c_lt += k < lo;
-      c_eqlo += k == lo;
-      c_eqhi += (k == hi) && hi != lo;
-      if (PASS == 1) {
-        sum = __dadd_rn(sum, d);
-        const double dv = __dsub_rn(d, I.m_hat);
-        sq = __dadd_rn(sq, __dmul_rn(dv, dv));
+  constexpr int U = 8;  // loads in flight per thread
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  auto flush = [&]() {  // all threads; s_n is stable (between barriers)
+    const uint32_t cnt_ = s_n;
+    if (threadIdx.x == 0) s_base = atomicAdd(PASS == 1 ? &C->n_cand : &C->m_cand, cnt_);
+    __syncthreads();
+    const uint32_t b0 = s_base;
+    for (uint32_t q = threadIdx.x; q < cnt_; q += 256)
+      if (b0 + q < kCandCap) my_cand[b0 + q] = s_stage[q];
+    __syncthreads();
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+  };
+  for (uint32_t base = i0; base < i1; base += 256 * U) {
+    if (s_n > kStage - 256 * U) flush();  // (block-uniform: read between barriers) room for a whole iteration of candidates
+    double dv8[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = base + u * 256 + threadIdx.x;
+      dv8[u] = i < i1 ? row[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = base + u * 256 + threadIdx.x;
+      const bool ok = i < i1;
+      const double d = dv8[u];
+      const double x = PASS == 1 ? d : fabs(__dsub_rn(d, I.median));
+      const uint64_t k = f64_key(x);
+      if (ok) {
+        c_lt += k < lo;
+        c_eqlo += k == lo;
+        c_eqhi += (k == hi) && hi != lo;
+        if (PASS == 1) {
+          sum = __dadd_rn(sum, d);
+          const double dv = __dsub_rn(d, I.m_hat);
+          sq = __dadd_rn(sq, __dmul_rn(dv, dv));
+        }
       }
-    }
-    const bool is_cand = ok && k > lo && k < hi;
-    if (__ballot(is_cand)) {
-      const uint32_t at = wave_append(is_cand, PASS == 1 ? &C->n_cand : &C->m_cand, lane);
-      if (is_cand && at < kCandCap) my_cand[at] = x;
-    }
-    if (PASS == 1) {
-      const bool is_nb = ok && k <= I.kcut;
-      if (__ballot(is_nb)) {
-        const uint32_t at = wave_append(is_nb, &C->n_nb, lane);
-        if (is_nb && at < kNbCap) {
-          nb_idx[(uint64_t)j * kNbCap + at] = i;
-          nb_d[(uint64_t)j * kNbCap + at] = d;
+      const bool is_cand = ok && k > lo && k < hi;
+      if (__ballot(is_cand)) {
+        const uint32_t at = wave_append(is_cand, &s_n, lane);
+        if (is_cand) s_stage[at] = x;
+      }
+      if (PASS == 1) {
+        const bool is_nb = ok && k <= I.kcut;
+        if (__ballot(is_nb)) {
+          const uint32_t at = wave_append(is_nb, &C->n_nb, lane);
+          if (is_nb && at < kNbCap) {
+            nb_idx[(uint64_t)j * kNbCap + at] = i;
+            nb_d[(uint64_t)j * kNbCap + at] = d;
+          }
         }
       }
     }
+    __syncthreads();  // s_n is read at the top of the next iteration
   }
+  if (s_n) flush();
   // the block's counts: one atomic each; its sums: one slot each (added up in slice order by the finish kernel)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -583,7 +616,7 @@ __global__ __launch_bounds__(256) void summary2_pass_kernel(const double *__rest
 // the exact order statistic of rank r from what a pass left: counts below / at the bracket's ends and the values
 // strictly inside it.  false: the bracket missed or the list overflowed.
 __device__ bool pick_from_bracket(uint32_t r, uint32_t lt, uint32_t eqlo, uint32_t n_cand, uint32_t eqhi, uint64_t klo, uint64_t khi,
-                                  const double *cand, uint32_t *s_hist, uint64_t *s_cand, uint32_t *s_misc, double *out) {
+                                  const double *cand, uint32_t kCandCap, uint32_t *s_hist, uint64_t *s_cand, uint32_t *s_misc, double *out) {
   if (r < lt) return false;
   if (r < lt + eqlo) {
     *out = key_f64(klo);
@@ -610,7 +643,7 @@ __global__ __launch_bounds__(kLT) void summary2_finish_kernel(const double *__re
                                                               uint32_t max_neighbours, RowInfo *__restrict__ info, RowCounts *__restrict__ cnt,
                                                               const double *__restrict__ cand, const uint32_t *__restrict__ nb_idx,
                                                               const double *__restrict__ nb_d, const double *__restrict__ part, uint32_t n_slices,
-                                                              double *__restrict__ out_stats, uint32_t *__restrict__ out_n,
+                                                              uint32_t kCandCap, double *__restrict__ out_stats, uint32_t *__restrict__ out_n,
                                                               uint32_t *__restrict__ out_idx, double *__restrict__ out_dist, double *__restrict__ out_z) {
   __shared__ uint32_t s_hist[kSel * kBins];
   __shared__ uint64_t s_cand[kSel * kCand];
@@ -625,7 +658,7 @@ __global__ __launch_bounds__(kLT) void summary2_finish_kernel(const double *__re
   const double *my_cand = cand + (uint64_t)jl * kCandCap;
   if (STAGE == 2) {
     double mad = 0.0;
-    const bool ok = pick_from_bracket(n / 2, C.m_lt, C.m_eqlo, C.m_cand, C.m_eqhi, I.mlo, I.mhi, my_cand, s_hist, s_cand, s_misc, &mad);
+    const bool ok = pick_from_bracket(n / 2, C.m_lt, C.m_eqlo, C.m_cand, C.m_eqhi, I.mlo, I.mhi, my_cand, kCandCap, s_hist, s_cand, s_misc, &mad);
     if (threadIdx.x == 0) {
       if (!ok) C.fail = 1;
       else {
@@ -649,7 +682,7 @@ __global__ __launch_bounds__(kLT) void summary2_finish_kernel(const double *__re
   const double sd = n > 1 ? sqrt(ss / ((double)n - 1.0)) : 0.0;
   // ---- the median
   double median = 0.0;
-  bool ok = pick_from_bracket(n / 2, C.lt_lo, C.eq_lo, C.n_cand, C.eq_hi, I.klo, I.khi, my_cand, s_hist, s_cand, s_misc, &median);
+  bool ok = pick_from_bracket(n / 2, C.lt_lo, C.eq_lo, C.n_cand, C.eq_hi, I.klo, I.khi, my_cand, kCandCap, s_hist, s_cand, s_misc, &median);
   // ---- the neighbours: the list holds every element with key <= kcut, i.e. the n_nb smallest
   const uint32_t n_nb = C.n_nb;
   const uint32_t *my_idx = nb_idx + (uint64_t)jl * kNbCap;
@@ -752,7 +785,7 @@ __device__ bool row_failed(const RowCounts *cnt, uint32_t row) { return cnt[row]
 
 uint64_t summary_large_scratch_bytes(uint32_t n_rows, uint32_t r1) {
   const uint64_t n_slices = (r1 + kSlice - 1) / kSlice;
-  return (uint64_t)n_rows * (sizeof(RowInfo) + sizeof(RowCounts) + (uint64_t)kCandCap * 8 + (uint64_t)kNbCap * 12 + n_slices * 16) + 4096;
+  return (uint64_t)n_rows * (sizeof(RowInfo) + sizeof(RowCounts) + (uint64_t)cand_cap_for(r1) * 8 + (uint64_t)kNbCap * 12 + n_slices * 16) + 4096;
 }
 
 // scratch = nullptr (or tune "summary2" off): the one-block-per-row kernel alone
@@ -773,8 +806,9 @@ int launch_summary_large(const double *rows, uint32_t n_rows, uint32_t r1, uint3
   p += ((uint64_t)n_rows * sizeof(RowInfo) + 255) & ~255ull;
   RowCounts *cnt = reinterpret_cast<RowCounts *>(p);
   p += ((uint64_t)n_rows * sizeof(RowCounts) + 255) & ~255ull;
+  const uint32_t cap = cand_cap_for(r1);
   double *cand = reinterpret_cast<double *>(p);
-  p += (uint64_t)n_rows * kCandCap * 8;
+  p += (uint64_t)n_rows * cap * 8;
   double *nb_d = reinterpret_cast<double *>(p);
   p += (uint64_t)n_rows * kNbCap * 8;
   uint32_t *nb_idx = reinterpret_cast<uint32_t *>(p);
@@ -782,15 +816,15 @@ int launch_summary_large(const double *rows, uint32_t n_rows, uint32_t r1, uint3
   double *part = reinterpret_cast<double *>(p);
   summary2_sample_kernel<<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, req_len, info, cnt);
   KPOP_LAUNCH_CHECK();
-  summary2_pass_kernel<1><<<dim3(n_slices, n_rows), dim3(256), 0, st>>>(rows, r1, info, cnt, cand, nb_idx, nb_d, part, n_slices);
+  summary2_pass_kernel<1><<<dim3(n_slices, n_rows), dim3(256), 0, st>>>(rows, r1, info, cnt, cand, nb_idx, nb_d, part, n_slices, cap);
   KPOP_LAUNCH_CHECK();
   summary2_finish_kernel<1><<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, req_len, max_neighbours, info, cnt, cand, nb_idx, nb_d, part, n_slices,
-                                                                out_stats, out_n, out_idx, out_dist, out_z);
+                                                                cap, out_stats, out_n, out_idx, out_dist, out_z);
   KPOP_LAUNCH_CHECK();
-  summary2_pass_kernel<2><<<dim3(n_slices, n_rows), dim3(256), 0, st>>>(rows, r1, info, cnt, cand, nb_idx, nb_d, part, n_slices);
+  summary2_pass_kernel<2><<<dim3(n_slices, n_rows), dim3(256), 0, st>>>(rows, r1, info, cnt, cand, nb_idx, nb_d, part, n_slices, cap);
   KPOP_LAUNCH_CHECK();
   summary2_finish_kernel<2><<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, req_len, max_neighbours, info, cnt, cand, nb_idx, nb_d, part, n_slices,
-                                                                out_stats, out_n, out_idx, out_dist, out_z);
+                                                                cap, out_stats, out_n, out_idx, out_dist, out_z);
   KPOP_LAUNCH_CHECK();
   summary_large_kernel<<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, cnt);
   KPOP_LAUNCH_CHECK();
