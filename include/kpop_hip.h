@@ -91,7 +91,8 @@ int kpop_synchronize(void *stream);
    "summary2" 1 (default) | 0: summaries against more than 4,096 rows by brackets from a sample and two passes over the
    distance rows, or by round 2's one block per row;
    "dense" 0 (default) | 1 | 2: kpop_twist by the sparse mat-vec, by the dense contraction on the f64 matrix cores, or
-   by the batch's density -- the one knob that changes results, in the last bits (kpop_dev_twist_dense); "ldspad" bytes of
+   by the batch's density (2 also sends kpop_count_twist's batches of assemblies at small k through the dense image of
+   their counts, kpop_dev_count_twist_dense) -- the one knob that changes results, in the last bits; "ldspad" bytes of
    extra LDS per block of the fused reads kernel (an occupancy probe); "dbg" development switches (also KPOP_TUNE_DBG)  */
 int kpop_tune(const char *key, int value);
 
@@ -392,6 +393,15 @@ int kpop_dev_twist_dense(const kpop_twister *tw, const uint64_t *d_hash, const d
 int kpop_dev_twist_dense_sorted(const kpop_twister *tw, const uint64_t *d_hash, const double *d_value,
                                 const uint64_t *d_offsets, uint32_t n_spectra, int normalize, void *d_work,
                                 double *d_out, void *stream);
+/* Sequences -> twisted rows with the counts handed to the contraction DENSE: for a twister of at most 36,864 k-mers
+   (every canonical k-mer up to k = 8) and 256 dimensions, one block per sequence counts into an LDS table with one
+   counter per twister row and writes it out as a row of u32; the contraction loads those rows (4 bytes per sequence and
+   k-mer), divides by acc as it stages them (lib/Twister.ml:177-178, element by element) and multiplies on the f64 matrix
+   cores.  What kpop_dev_count_twist gives, to rounding (the order of additions is the GEMM's), for batches of ASSEMBLIES
+   at small k, where every spectrum holds most of the columns.  Any sequence length.                                  */
+uint64_t kpop_dev_count_twist_dense_workspace_bytes(const kpop_twister *tw, uint32_t n_reads);
+int kpop_dev_count_twist_dense(const kpop_twister *tw, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads,
+                               int content, int normalize, void *d_work, double *d_out, void *stream);
 /* kpop_ca on device-resident data: d_counts (n_kmers x n_spectra, row-major, not modified) in, d_twisted (n_spectra x
    n_dims), d_inertia (n_dims) and d_twister (n_dims x n_kmers, dims-major) out, all device pointers; *n_dims_out is a
    host word.  d_work needs kpop_dev_ca_workspace_bytes() (the standardised copy of the table).  The weights of the

@@ -125,6 +125,8 @@ SIGNATURES = {
     "kpop_dev_table_gather_rows": (C.c_int, [vp, C.c_uint32, vp, C.c_uint64, vp, vp]),
     "kpop_dev_twist_dense_workspace_bytes": (C.c_uint64, [vp, C.c_uint32]),
     "kpop_dev_twist_dense": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_int, vp, vp, vp]),
+    "kpop_dev_count_twist_dense_workspace_bytes": (C.c_uint64, [vp, C.c_uint32]),
+    "kpop_dev_count_twist_dense": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_int, C.c_int, vp, vp, vp]),
     "kpop_dev_twist_dense_sorted": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_int, vp, vp, vp]),
     "kpop_dev_distance_workspace_bytes": (C.c_uint64, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "kpop_dev_distance_rowwise": (C.c_int, [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, C.c_int,

@@ -699,6 +699,16 @@ def dev_twist_dense(tw, d_hash, d_value, d_offsets, n_spectra, d_work, d_out, no
                                            d_out, stream))
 
 
+def dev_count_twist_dense_workspace_bytes(tw, n_reads):
+    return int(_lib.load().kpop_dev_count_twist_dense_workspace_bytes(tw.handle, int(n_reads)))
+
+
+def dev_count_twist_dense(tw, d_bases, d_offsets, n_reads, d_work, d_out, content=DNA_DS, normalize=True, stream=0):
+    """sequences -> twisted rows through the dense u32 image of their counts and the f64 matrix cores (small k, assemblies)"""
+    check(_lib.load().kpop_dev_count_twist_dense(tw.handle, d_bases, d_offsets, int(n_reads), int(content), 1 if normalize else 0, d_work,
+                                                 d_out, stream))
+
+
 def dev_twist_dense_sorted(tw, d_hash, d_value, d_offsets, n_spectra, d_work, d_out, normalize=True, stream=0):
     """kpop_dev_twist_dense_sorted: lines ascending by hash, densified inside the contraction (no X in HBM)"""
     check(_lib.load().kpop_dev_twist_dense_sorted(tw.handle, d_hash, d_value, d_offsets, int(n_spectra), 1 if normalize else 0, d_work,

@@ -842,6 +842,17 @@ extern "C" int kpop_count_twist(const kpop_twister *tw, const uint8_t *bases, co
   if (n_bases) KPOP_HIP(hipMemcpyAsync(d_bases.p, bases + base0, n_bases, hipMemcpyHostToDevice, st));
   KPOP_HIP(hipMemcpyAsync(d_off.p, rel.data(), (uint64_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
   if (max_len > 0xFFFFFFFFull) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_count_twist: sequence longer than 2^32 bases");
+  // kpop_tune("dense", 2): batches of assemblies at small k (every sequence holds a fifth or more of the twister's k-mers on
+  // average, the twister small enough for the dense image) go through the u32 image and the f64 matrix cores; results
+  // agree with the sparse kernels to rounding
+  const bool dense_image = ctx().tune_dense == 2 && tw->n_rows > 0 && tw->n_rows <= 36864 && tw->n_dims <= 256 && n_reads >= 64 &&
+                           (double)n_bases >= 0.2 * (double)tw->n_rows * (double)n_reads;
+  if (dense_image) {
+    DevBuf d_work;
+    KPOP_TRY(d_work.alloc(kpop_dev_count_twist_dense_workspace_bytes(tw, n_reads)));
+    KPOP_TRY(kpop_dev_count_twist_dense(tw, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), n_reads, content, normalize, d_work.p,
+                                        d_out.as<double>(), st));
+  } else
   KPOP_TRY(kpop_dev_count_twist(tw, d_bases.as<uint8_t>(), d_off.as<uint64_t>(), n_reads, n_bases, (uint32_t)max_len,
                                 content, normalize, d_out.as<double>(), st));
   KPOP_HIP(hipMemcpyAsync(out, d_out.p, (uint64_t)n_reads * tw->n_dims * 8, hipMemcpyDeviceToHost, st));

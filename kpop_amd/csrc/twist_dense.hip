@@ -11,6 +11,7 @@
 #include <algorithm>
 
 #include "gemm_f64.h"
+#include "kmer.h"
 #include "twister.h"
 
 namespace kpop {
@@ -340,6 +341,185 @@ __global__ void twist_dense_combine_kernel(const double *__restrict__ slabs, con
   }
 }
 
+// ---------------------------------------------------------------------------
+// Sequences -> twisted rows with the counts handed over DENSE (round 3): for a twister of up to 36,864 k-mers (every
+// canonical k-mer up to k = 8) a sequence's whole spectrum fits a block's LDS as one u32 counter per twister row, so
+//   count_dense_kernel       one block per sequence: hash rolled over the windows, name -> row, ds_add_u32 into the LDS
+//                            table, the table written out as one row of X (u32 [n_sequences][n_rows]) + acc = windows found;
+//   twist_dense_counts_kernel 64 sequences x all dims x one slab of rows per block, panels of 128 rows: the panel's counts are
+//                            loaded (4 B per element, coalesced, one panel ahead in registers), turned into x = c / acc
+//                            (the reference's per-element division, lib/Twister.ml:177-178) as they are put into LDS, and
+//                            multiplied by the twister's rows on the f64 matrix cores as in the kernel above.
+// No CSR, no name -> row walk per LINE, no scatter, no zeroing: the image costs 4 bytes per (sequence, k-mer) once written
+// and once read, against 16 bytes per line of a CSR spectrum (which at 97 % density is four times as much).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kDenseCountRows = 36864;  // u32 counters per block: 144 KB of LDS
+
+__global__ __launch_bounds__(1024) void count_dense_kernel(TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets,
+                                                           uint32_t n, int content, uint32_t *__restrict__ X, uint64_t ldx,
+                                                           double *__restrict__ acc, uint32_t rsel_words) {
+  extern __shared__ uint32_t s_tab[];
+  __shared__ uint32_t s_found[16];
+  const uint32_t r = blockIdx.x;
+  if (r >= n) return;
+  const uint32_t n_rows = (uint32_t)tv.n_rows;
+  for (uint32_t q = threadIdx.x; q < n_rows; q += 1024) s_tab[q] = 0;
+  // the name -> row index beside the counters when it fits (16 KB at k = 8): a window's lookup is then an LDS read, not a
+  // trip to L1 / L2 (30 windows a thread, one lookup each: they were most of this kernel)
+  RankWord *s_rsel = reinterpret_cast<RankWord *>(s_tab + ((n_rows + 3u) & ~3u));
+  if (rsel_words)
+    for (uint32_t q = threadIdx.x; q < rsel_words; q += 1024) s_rsel[q] = tv.rsel[q];
+  TwisterView tl = tv;
+  if (rsel_words) tl.rsel = s_rsel;
+  __syncthreads();
+  const uint64_t off = offsets[r], len = offsets[r + 1] - off;
+  const int k = tv.hk;
+  const uint64_t n_win = len >= (uint64_t)k ? len - k + 1 : 0;
+  const uint8_t *seq = bases + off;
+  const int shift = 2 * (k - 1);
+  const uint32_t mask = (uint32_t)bits_mask(2 * k);
+  // a thread rolls the hash over a run of consecutive windows (k - 1 + run base loads instead of k per window)
+  const uint64_t per = (n_win + 1023) / 1024;
+  const uint64_t a = (uint64_t)threadIdx.x * per, b = min(n_win, a + per);
+  uint32_t found = 0;
+  if (a < b) {
+    uint32_t fwd = 0, rc = 0;
+    int run = 0;
+    for (int j = 0; j < k - 1; ++j) {
+      const uint32_t c = base_code(seq[a + j]);
+      fwd = ((fwd << 2) | (c & 3u)) & mask;
+      rc = (rc >> 2) | ((3u - (c & 3u)) << shift);
+      run = c < 4u ? run + 1 : 0;
+    }
+    for (uint64_t w = a; w < b; ++w) {
+      const uint32_t c = base_code(seq[w + k - 1]);
+      fwd = ((fwd << 2) | (c & 3u)) & mask;
+      rc = (rc >> 2) | ((3u - (c & 3u)) << shift);
+      run = c < 4u ? run + 1 : 0;
+      if (run >= k) {
+        const uint32_t col = lookup_col(tl, (uint64_t)((content == KPOP_DNA_DS && rc < fwd) ? rc : fwd));
+        if (col != kNoCol) {
+          atomicAdd(&s_tab[col], 1u);
+          ++found;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) found += (uint32_t)__shfl_xor((int)found, o, 64);
+  if ((threadIdx.x & 63) == 0) s_found[threadIdx.x >> 6] = found;
+  __syncthreads();
+  uint32_t *xr = X + (uint64_t)r * ldx;
+  for (uint32_t q = threadIdx.x; q < n_rows; q += 1024) xr[q] = s_tab[q];
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < 16; ++w) t += s_found[w];
+    acc[r] = (double)t;  // exact: a count
+  }
+}
+
+template <int NB>
+__global__ __launch_bounds__(256, 2) void twist_dense_counts_kernel(TwisterView tv, const uint32_t *__restrict__ X, uint64_t ldx,
+                                                                    const double *__restrict__ accv, uint32_t n, int normalize,
+                                                                    uint32_t tiles_m, uint32_t panels_per_slab, uint32_t n_panels,
+                                                                    double *__restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) double A_s[];  // [kDM][kDStride]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t tile = blockIdx.x % tiles_m, z = blockIdx.x / tiles_m;
+  const uint32_t m0 = tile * kDM;
+  const uint32_t p_lo = z * panels_per_slab, p_hi = min(n_panels, p_lo + panels_per_slab);
+  // staging: thread t owns sequence m0 + t / 4 and the 32 columns (t % 4) * 32 .. + 32 of every panel
+  const uint32_t sm = threadIdx.x >> 2, sc = (threadIdx.x & 3u) * 32u;
+  const bool row_ok = m0 + sm < n;
+  const uint32_t *xrow = X + (uint64_t)(row_ok ? m0 + sm : 0) * ldx;
+  const double a_m = row_ok ? accv[m0 + sm] : 0.0;
+  const bool norm = normalize && a_m != 0.0;
+  const uint32_t n_rows = (uint32_t)tv.n_rows;
+  uint4 cur[8];
+  auto fetch = [&](uint32_t p) {
+    const uint32_t c0 = p * kDK + sc;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const uint32_t c = c0 + 4 * q;
+      // (ldx is a multiple of 4 and the rows 16-byte aligned: whole uint4 loads; columns past n_rows are zero padding)
+      cur[q] = (row_ok && c < ldx) ? *reinterpret_cast<const uint4 *>(xrow + c) : uint4{0, 0, 0, 0};
+    }
+  };
+  f64x4 acc[NB][4];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[nb][i] = f64x4{0.0, 0.0, 0.0, 0.0};
+  const uint32_t dcol = 16u * wv + (lane & 15);
+  if (p_lo < p_hi) fetch(p_lo);
+  for (uint32_t p = p_lo; p < p_hi; ++p) {
+    const uint32_t k0 = p * kDK;
+    __syncthreads();  // the previous panel's readers are done
+    {
+      double *dst = A_s + sm * kDStride + sc;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint32_t v[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const double c = (double)v[e];
+          dst[4 * q + e] = norm ? c / a_m : c;  // x_h = v_h / acc (lib/Twister.ml:177-178), element by element
+        }
+      }
+    }
+    __syncthreads();
+    if (p + 1 < p_hi) fetch(p + 1);  // the next panel's counts travel under this panel's MFMAs
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const uint32_t dc = 64u * nb + dcol;
+      const bool dok = dc < tv.d_pad;
+      double bb[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint32_t row = k0 + 4 * q + (lane >> 4);
+        bb[q] = (row < n_rows && dok) ? tv.rows[(uint64_t)row * tv.d_pad + dc] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < kDK / 4; ++q) {
+        const double b = bb[q & 7];
+        if (q + 8 < kDK / 4) {
+          const uint32_t row = k0 + 4 * (q + 8) + (lane >> 4);
+          bb[q & 7] = (row < n_rows && dok) ? tv.rows[(uint64_t)row * tv.d_pad + dc] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const double a = A_s[(16 * i + (lane & 15)) * kDStride + 4 * q + (lane >> 4)];
+          acc[nb][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[nb][i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const uint32_t ldo = NB * 64;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t m = m0 + 16 * i + (lane >> 4) + 4 * r;
+        if (m < n) slabs[((uint64_t)z * n + m) * ldo + 64 * nb + dcol] = acc[nb][i][r];
+      }
+}
+
+// out = the slabs added in slab order (the division by acc was applied to the operands)
+__global__ void twist_dense_sum_slabs_kernel(const double *__restrict__ slabs, uint32_t n_slabs, uint32_t n, uint32_t n_dims, uint32_t ldo,
+                                             double *__restrict__ out) {
+  const uint64_t total = (uint64_t)n * n_dims, stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const uint32_t m = (uint32_t)(e / n_dims), d = (uint32_t)(e % n_dims);
+    double t = 0.0;
+    for (uint32_t z = 0; z < n_slabs; ++z) t += slabs[((uint64_t)z * n + m) * ldo + d];
+    out[e] = t;
+  }
+}
+
+constexpr uint32_t kDenseCountBatch = 4096;  // sequences per image: 4,096 x 32,896 x 4 B = 539 MB at k = 8
+
 struct FusedPlan {
   uint32_t nb, tiles_m, n_panels, panels_per_slab, splits;
 };
@@ -448,6 +628,82 @@ extern "C" int kpop_dev_twist_dense(const kpop_twister *tw, const uint64_t *d_ha
     }
     // C[nb x D] = X[nb x K] * rows[K x d_pad]
     KPOP_TRY(gemm_f64<false>(X, K, tw->d_rows, tw->d_pad, d_out + (uint64_t)s0 * D, nb, D, K, splits, slabs, 0, st));
+  }
+  return KPOP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// sequences -> twisted rows through the dense image of their counts (see count_dense_kernel)
+// ---------------------------------------------------------------------------
+extern "C" uint64_t kpop_dev_count_twist_dense_workspace_bytes(const kpop_twister *tw, uint32_t n_reads) {
+  if (!tw) return 0;
+  const uint32_t n = std::min(n_reads, kDenseCountBatch);
+  const uint64_t ldx = (tw->n_rows + 3) & ~3ull;
+  uint64_t slabs = 0;
+  for (uint32_t t = n; t; t = (t > kDM) ? t / 2 : 0) {
+    const FusedPlan p = fused_plan(tw, t);
+    slabs = std::max<uint64_t>(slabs, (uint64_t)p.splits * t * p.nb * 64 * 8);
+  }
+  return (uint64_t)n * ldx * 4 + (uint64_t)n * 8 + slabs + 8192;
+}
+
+extern "C" int kpop_dev_count_twist_dense(const kpop_twister *tw, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads,
+                                          int content, int normalize, void *d_work, double *d_out, void *stream) {
+  KPOP_TRY(require_init());
+  if (!tw || !d_offsets || !d_out || !d_work) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_count_twist_dense: null argument");
+  if (content != KPOP_DNA_DS && content != KPOP_DNA_SS) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_count_twist_dense: DNA only");
+  if (tw->n_rows > kDenseCountRows || tw->n_rows == 0 || tw->n_dims > 256 || (tw->hk ? tw->hk : tw->k) > 16)
+    KPOP_FAIL(KPOP_ERR_UNSUPPORTED,
+              "kpop_dev_count_twist_dense: a twister of %llu k-mers x %u dimensions (the dense image needs at most %u k-mers -- every "
+              "canonical k-mer up to k = 8 -- and 256 dimensions); use kpop_dev_count_twist",
+              (unsigned long long)tw->n_rows, tw->n_dims, kDenseCountRows);
+  if (n_reads == 0) return KPOP_OK;
+  hipStream_t st = as_stream(stream);
+  const TwisterView tv = view_of(tw);
+  const uint64_t ldx = (tw->n_rows + 3) & ~3ull;
+  char *w = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(d_work) + 255) & ~(uintptr_t)255);
+  const uint32_t cap = std::min(n_reads, kDenseCountBatch);
+  uint32_t *X = reinterpret_cast<uint32_t *>(w);
+  double *accv = reinterpret_cast<double *>(w + (((uint64_t)cap * ldx * 4 + 255) & ~255ull));
+  double *slabs = accv + ((cap + 31) & ~31u);
+  // LDS of the counting kernel: the counters, and the rank-select index behind them when both fit 156 KB
+  const uint64_t words = tw->d_rsel ? ((1ull << (2 * tw->k)) + 63) / 64 : 0;
+  const size_t tab_bytes = (((size_t)tw->n_rows + 3) & ~(size_t)3) * 4;
+  const uint32_t rsel_words = (words && tab_bytes + words * sizeof(RankWord) <= (156u << 10)) ? (uint32_t)words : 0u;
+  const size_t lds_count = tab_bytes + (size_t)rsel_words * sizeof(RankWord), lds_mm = (size_t)kDM * kDStride * 8;
+  static PerSlotOnce once_c, once_m[4];
+  if (!once_c()) {
+    KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&count_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(156u << 10)));
+    once_c() = true;
+  }
+  for (uint32_t s0 = 0; s0 < n_reads; s0 += kDenseCountBatch) {
+    const uint32_t n = std::min(kDenseCountBatch, n_reads - s0);
+    count_dense_kernel<<<dim3(n), dim3(1024), lds_count, st>>>(tv, d_bases, d_offsets + s0, n, content, X, ldx, accv, rsel_words);
+    KPOP_LAUNCH_CHECK();
+    const FusedPlan p = fused_plan(tw, n);
+    const dim3 grid(p.tiles_m * p.splits), block(256);
+#define KPOP_DC(NB)                                                                                                                  \
+  {                                                                                                                                  \
+    if (!once_m[NB - 1]()) {                                                                                                         \
+      KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&twist_dense_counts_kernel<NB>),                                   \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mm));                                        \
+      once_m[NB - 1]() = true;                                                                                                       \
+    }                                                                                                                                \
+    twist_dense_counts_kernel<NB><<<grid, block, lds_mm, st>>>(tv, X, ldx, accv, n, normalize, p.tiles_m, p.panels_per_slab, p.n_panels, \
+                                                              slabs);                                                                \
+  }
+    switch (p.nb) {
+      case 1: KPOP_DC(1) break;
+      case 2: KPOP_DC(2) break;
+      case 3: KPOP_DC(3) break;
+      default: KPOP_DC(4) break;
+    }
+#undef KPOP_DC
+    KPOP_LAUNCH_CHECK();
+    twist_dense_sum_slabs_kernel<<<dim3(std::min<uint32_t>(div_up((uint64_t)n * tw->n_dims, 256), 4096)), dim3(256), 0, st>>>(
+        slabs, p.splits, n, tw->n_dims, p.nb * 64, d_out + (uint64_t)s0 * tw->n_dims);
+    KPOP_LAUNCH_CHECK();
   }
   return KPOP_OK;
 }

@@ -420,6 +420,49 @@ def test_dense_twist_on_the_matrix_cores_equals_the_sparse_one(kpop, oracle, k, 
     assert np.isnan(c[bad]).all() and not np.isnan(np.delete(c, bad, axis=0)).any()
 
 
+@pytest.mark.parametrize("k,d,content", [(5, 64, 0), (7, 9, 0), (8, 64, 0), (7, 130, 1), (6, 256, 0)])
+def test_count_twist_through_the_dense_image(kpop, oracle, k, d, content):
+    """kpop_dev_count_twist_dense: sequences -> one u32 counter per twister row in LDS -> the contraction on the f64 matrix
+    cores, against the oracle (count + twist) and the fused sparse kernels: genomes, short and empty sequences, Ns, a twister
+    that lacks some k-mers, normalisation on and off"""
+    import torch
+    from kpop_amd import api
+    rng = np.random.RandomState(k * 7 + d)
+    seqs = ["", "ACG", "N" * 50, "ACGT" * 3] + ["".join(rng.choice(list("ACGTN"), size=int(n), p=[.2475] * 4 + [.01])) for n in rng.randint(k, 9000, size=90)]
+    bases, offs = concat(seqs)
+    cols = oracle.enumerate_kmers(k, content)
+    if k >= 7:
+        cols = cols[rng.rand(len(cols)) < 0.9]
+    T = oracle.synth_twister(11, d, cols)
+    tw = kpop.Twister.load(T, cols, k)
+    dev = torch.device("cuda", 0)
+    db, do = torch.from_numpy(bases).to(dev), torch.from_numpy(offs.view(np.int64)).to(dev)
+    n = len(seqs)
+    work = torch.empty(api.dev_count_twist_dense_workspace_bytes(tw, n), dtype=torch.uint8, device=dev)
+    h, c, o = oracle.count_reads(bases, offs, k, content)
+    for normalize in (True, False):
+        out = torch.full((n, d), 7.0, dtype=torch.float64, device=dev)
+        api.dev_count_twist_dense(tw, db.data_ptr(), do.data_ptr(), n, work.data_ptr(), out.data_ptr(), content=content, normalize=normalize)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        want = oracle.twist(T, cols, h, c.astype(np.float64), o, normalize=normalize)
+        assert np.max(np.abs(got - want)) <= 1e-12 * max(np.max(np.abs(want)), 1.0), np.max(np.abs(got - want))
+        assert np.all(got[0] == 0.0) and np.all(got[2] == 0.0)
+    if k == 8:  # the host entry point picks the dense image for batches of assemblies under kpop_tune("dense", 2)
+        long_ = [s_ for s_ in seqs if len(s_) > 7000] * 8
+        lb, lo = concat(long_)
+        ref = tw.count_twist(lb, lo)
+        api.tune("dense", 2)
+        try:
+            got = tw.count_twist(lb, lo)
+        finally:
+            api.tune("dense", 0)
+        assert len(long_) >= 64 and np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref)) and not np.array_equal(got, ref)
+    big = kpop.Twister.synth(1, 9, 8)
+    with pytest.raises(kpop.KPopError):  # 131,072 k-mers: no dense image
+        api.dev_count_twist_dense(big, db.data_ptr(), do.data_ptr(), n, work.data_ptr(), out.data_ptr())
+
+
 def test_understated_max_len_yields_nan_rows_not_stale_memory(kpop, oracle):
     """kpop_dev_count_twist trusts the caller's max_len to schedule the long-sequence pass; a read longer than it says
     must come back as NaNs, and kpop_dev_distance_rowwise refuses a null workspace for very long rows"""

@@ -60,12 +60,31 @@ def main():
         print("%-44s spectra %6d  lines/spectrum %7.0f of %9d columns (%.2f %%)  sparse %9.3f ms  dense(fused) %9.3f ms  (%5.2fx)  %5.1f TFLOP/s = %.2f of 78.6  | dense(image in HBM, round 2) %9.3f ms = %.2f  max rel diff %.1e"
               % (label, n, nnz / n, rows, 100.0 * nnz / n / rows, t1, t2, t1 / t2, flops / t2 / 1e9, flops / t2 / 1e9 / 78.6, t3, flops / t3 / 1e9 / 78.6, rel), flush=True)
 
+    def from_sequences(label, tw, gb, go, k):
+        """the whole stage from sequences: fused sparse kernels (kpop_dev_count_twist) against the dense u32 image + f64 MFMA"""
+        n = len(go) - 1
+        db, dof = torch.from_numpy(gb).to(dev), torch.from_numpy(go.view(np.int64)).to(dev)
+        out1 = torch.zeros(n, d, dtype=torch.float64, device=dev)
+        out2 = torch.zeros(n, d, dtype=torch.float64, device=dev)
+        work = torch.empty(api.dev_count_twist_dense_workspace_bytes(tw, n), dtype=torch.uint8, device=dev)
+        L = int(np.diff(go.astype(np.int64)).max())
+        t1 = timed(lambda: api.dev_count_twist(tw, db.data_ptr(), dof.data_ptr(), n, db.numel(), L, out1.data_ptr(), stream=st.cuda_stream))
+        t2 = timed(lambda: api.dev_count_twist_dense(tw, db.data_ptr(), dof.data_ptr(), n, work.data_ptr(), out2.data_ptr(), stream=st.cuda_stream))
+        a, b = out1.cpu().numpy(), out2.cpu().numpy()
+        rel = float(np.max(np.abs(a - b)) / max(np.max(np.abs(a)), 1e-300))
+        rows = tw.info()["n_cols"]
+        flops = 2.0 * n * rows * d
+        print("%-44s sequences %5d -> twisted rows: sparse fused (count_twist_stream) %9.3f ms   dense image (count_dense + MFMA) %9.3f ms  (%5.2fx)  whole stage %5.1f TFLOP/s = %.2f of 78.6 (the contraction kernel alone: see the rocprofv3 stats below)  max rel diff %.1e"
+              % (label + ", from the sequences", n, t1, t2, t1 / t2, flops / t2 / 1e9, flops / t2 / 1e9 / 78.6, rel), flush=True)
+
     n_g = int(os.environ.get("AB_GENOMES", "4096"))
     gb, go = O.synth_reads(0xC1A55, n_g, 30000)
     for k in [int(x) for x in os.environ.get("AB_KS", "7,8,9,10").split(",")]:
         tw = kpop_amd.Twister.synth(0x5EED, k, d)
         h, c, o = kpop_amd.count_reads(gb, go, k)
         case("genomes 30 kb, k=%d" % k, tw, h, c, o)
+        if k <= 8:
+            from_sequences("genomes 30 kb, k=%d" % k, tw, gb, go, k)
         tw.free()
     if os.environ.get("AB_ONLY_GENOMES"):
         return
