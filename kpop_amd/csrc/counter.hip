@@ -774,6 +774,11 @@ extern "C" int kpop_dev_counter_combine(const int32_t *d_storage, uint64_t ld, u
     KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_counter_combine: Unknown_combination_criterion(%d)", criterion);
   if (n_rows == 0) return KPOP_OK;
   if (!d_workspace || !d_out) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_counter_combine: null argument");
+  // the median kernels stage groups of four rows: a leading dimension that is not kpop_dev_counter_ld's (a multiple of 32)
+  // would have them treat the last rows of a short group as padding
+  if (ld < n_rows || (ld & 3) != 0)
+    KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_counter_combine: ld=%llu for %llu rows (use kpop_dev_counter_ld: at least n_rows, a multiple of 4)",
+              (unsigned long long)ld, (unsigned long long)n_rows);
   hipStream_t st = as_stream(stream);
   double *partial = reinterpret_cast<double *>(d_workspace);
   double *rcp = partial + (1u << 16);
