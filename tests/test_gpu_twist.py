@@ -351,7 +351,7 @@ def test_config3_50k_genomes_full_size(kpop, oracle):
     torch.cuda.synchronize()
     got = out.cpu().numpy()
     assert np.all(np.isfinite(got)) and np.all(np.abs(got) < 1.0)
-    pick = [0, 1, 777, 24999, 49998, 49999]
+    pick = sorted(set([0, 1, 777, 24999, 49998, 49999] + list(range(3, n, 251))))  # 200+ genomes spread over the batch
     sb = np.concatenate([bases[r * L:(r + 1) * L].cpu().numpy() for r in pick])
     so = np.arange(len(pick) + 1, dtype=np.uint64) * L
     first, _ = oracle.synth_reads(0xC0FFEE, 2, L)
@@ -361,6 +361,18 @@ def test_config3_50k_genomes_full_size(kpop, oracle):
     want = oracle.twist(oracle.synth_twister(0x7457, d, cols), cols, h, c.astype(np.float64), o)
     np.testing.assert_allclose(got[pick], want, rtol=1e-12, atol=1e-15)
     assert all(int(o[i + 1] - o[i]) > 29000 for i in range(len(pick)))     # ~29,989 distinct-ish 12-mers per genome
+    # ... and EVERY row, through linearity: without normalisation the rows add up to the twist of the batch's merged
+    # spectrum (bin/KPopCount.ml:60 over all 50,000 sequences: 1.5 G windows through the LDS-staged histogram), so one
+    # number per dimension checks all 3.2 M coordinates
+    api.dev_count_twist(tw, bases.data_ptr(), offs.data_ptr(), n, n * L, L, out.data_ptr(), normalize=False, stream=sp)
+    torch.cuda.synchronize()
+    total = out.sum(dim=0).cpu().numpy()
+    hb = bases.cpu().numpy()
+    ho = offs.cpu().numpy().astype(np.uint64)
+    mh, mc, mo = kpop.count_reads(hb, ho, k, per_read=False, capacity=(4 ** k + 2 ** k) // 2 + 1)
+    assert int(mc.astype(np.int64).sum()) == n * (L - k + 1)
+    merged = tw.twist(mh, mc.astype(np.float64), mo, normalize=False)[0]
+    assert np.max(np.abs(total - merged)) <= 1e-9 * np.max(np.abs(merged)), np.max(np.abs(total - merged))
 
 
 @pytest.mark.parametrize("k,d,n", [(5, 64, 300), (7, 9, 129), (8, 100, 40), (9, 256, 70), (6, 200, 65)])
