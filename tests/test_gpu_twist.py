@@ -293,8 +293,8 @@ def test_row_sharded_pipeline_with_rccl_world_size_1(kpop, oracle):
 
 def test_config5_k15_full_twister(kpop, oracle):
     """BASELINE config 5 at its full size: every canonical 15-mer (536,870,912 rows x 16 dims, 69 GB of HBM) resident;
-    10k reads and three 30 kb genomes twisted; a sample checked against the oracle with the twister restricted to the
-    sample's own k-mers (the synthetic coefficients are a pure function of (dimension, hash)); the row-sharded layout
+    10k reads and three 30 kb genomes twisted; EVERY row checked against the oracle with the twister restricted to the
+    batch's own k-mers (the synthetic coefficients are a pure function of (dimension, hash)); the row-sharded layout
     (two hash-range slices with accumulator dimensions) must give the same rows."""
     import torch
     from kpop_amd.shard import kmer_slice_bounds, reduce_partial_twists
@@ -311,10 +311,8 @@ def test_config5_k15_full_twister(kpop, oracle):
     allo = np.concatenate([offs, go[1:] + offs[-1]])
     got = tw.count_twist(allb, allo)
     tw.free()
-    pick = list(range(0, n, 250)) + [n, n + 1, n + 2]
-    sb = np.concatenate([allb[int(allo[r]):int(allo[r + 1])] for r in pick])
-    so = np.zeros(len(pick) + 1, dtype=np.uint64)
-    so[1:] = np.cumsum([int(allo[r + 1] - allo[r]) for r in pick])
+    pick = list(range(n + 3))  # every read and every genome against the oracle
+    sb, so = allb, allo
     h, c, o = oracle.count_reads(sb, so, k)
     cols = np.unique(h)
     want = oracle.twist(oracle.synth_twister(0x5EED, d, cols), cols, h, c.astype(np.float64), o)
