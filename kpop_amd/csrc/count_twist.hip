@@ -429,7 +429,8 @@ template <typename H, bool NT>
 __global__ __launch_bounds__(256) void count_twist_stream_kernel(
     TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int content,
     const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ seg_off, double *__restrict__ partial,
-    uint32_t *__restrict__ partial_cnt, uint32_t n_reads, uint32_t max_seg, uint32_t seg_windows) {
+    uint32_t *__restrict__ partial_cnt, uint32_t n_reads, uint32_t max_seg, uint32_t seg_windows,
+    const uint8_t *__restrict__ tile_done = nullptr, uint32_t n_groups = 0) {
   __shared__ double s_part[4][64];
   __shared__ uint32_t s_cnt[4];
   // (segment, read) pairs are dealt to blocks round-robin, READS FASTEST: the blocks in flight at any moment work on the
@@ -442,6 +443,7 @@ __global__ __launch_bounds__(256) void count_twist_stream_kernel(
   for (uint64_t pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
   const uint32_t seg = (uint32_t)(pair / n_reads), r = (uint32_t)(pair % n_reads);
   if (seg >= nseg[r]) continue;
+  if (tile_done && tile_done[(uint64_t)seg * n_groups + r / 64]) continue;  // (count_twist_tile_kernel has written this segment's sums)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t off = offsets[r];
   const uint64_t len = offsets[r + 1] - off;
@@ -496,6 +498,199 @@ __global__ __launch_bounds__(256) void count_twist_stream_kernel(
     }
   }
   __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Assemblies of ONE organism (BASELINE config 3's kind of batch; kpop_tune("dense", 2)): the same stretch of 512 windows of
+// 64 consecutive sequences holds little more than 512 DISTINCT k-mers, so the 64 x 512 row gathers of the streaming kernel
+// (33 MB through L2 per chunk) are 64 times the rows that differ.  A block instead
+//   1. collects the chunk's distinct twister rows in an LDS hash set (ds_cmpst; at most 1,024 of them),
+//   2. numbers them, and counts every (sequence, distinct row) pair into an LDS matrix X[64][U] of u16,
+//   3. multiplies: partial[64 x D] = X[64 x U] * T_U[U x D] on the f64 matrix cores, the U rows of the twister gathered
+//      ONCE per chunk,
+// and writes the same per-segment partial sums the streaming kernel writes (combine_partials_kernel divides by acc).
+// A chunk with more distinct rows than the set holds (unrelated sequences, or a divergent stretch) is left to the
+// streaming kernel (tile_done stays 0), and a block that meets one stops trying.  The sums run over distinct rows in set
+// order, not in sequence order: equal to the streaming kernel's up to rounding, like the rest of the "dense" routes.
+// ---------------------------------------------------------------------------
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+constexpr uint32_t kTileG = 64, kTileS = 512, kTileU = 1024, kTileH = 2048, kTileXS = kTileU + 2;  // (X rows padded: 16 rows on 16 banks)
+
+template <typename H>
+__global__ __launch_bounds__(1024) void count_twist_tile_kernel(
+    TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int content,
+    const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ seg_off, double *__restrict__ partial,
+    uint32_t *__restrict__ partial_cnt, uint32_t n_reads, uint32_t max_seg, uint8_t *__restrict__ tile_done, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile_lds[];
+  uint32_t *ht_key = reinterpret_cast<uint32_t *>(tile_lds);                 // [kTileH] twister row, kNoCol = empty
+  uint16_t *ht_u = reinterpret_cast<uint16_t *>(ht_key + kTileH);            // [kTileH] number of the slot's row
+  uint32_t *ucol = reinterpret_cast<uint32_t *>(ht_u + kTileH);              // [kTileU] row of number u
+  uint32_t *Xw = ucol + kTileU;                                              // [kTileG][kTileXS / 2] pairs of u16 counts
+  __shared__ uint32_t s_over, s_n, s_found[kTileG], s_wbase[16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t n_groups = (n_reads + kTileG - 1) / kTileG;
+  const uint64_t n_chunks = (uint64_t)n_groups * max_seg;
+  const int k = tv.hk;
+  const int shift = 2 * (k - 1);
+  const H mask = (H)bits_mask(2 * k);
+  // thread t works on sequence t / 16 of the group and a sixteenth of the segment's windows (32), rolling the hash along
+  constexpr uint32_t kPer = kTileS / 16;
+  const uint32_t tg = threadIdx.x >> 4, tq = threadIdx.x & 15u;
+  int misses = 0;  // chunks in a row that did not fit the set: after four the block leaves its chunks to the streaming kernel
+  for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    // chunks are dealt with the groups fastest: blocks running together work on one stretch of all sequences
+    const uint32_t seg = (uint32_t)(chunk / n_groups), grp = (uint32_t)(chunk % n_groups);
+    if (misses >= 4) continue;  // (uniform over the block)
+    const uint32_t r = grp * kTileG + tg;
+    uint64_t off = 0, len = 0;
+    bool mine = false;
+    if (r < n_reads) {
+      off = offsets[r];
+      len = offsets[r + 1] - off;
+      mine = seg < nseg[r];  // (sequences of up to 512 windows have nseg = 0: the one-wavefront-per-read kernel's)
+    }
+    const uint64_t n_win = len >= (uint64_t)k ? len - k + 1 : 0;
+    const uint64_t w0 = (uint64_t)seg * kTileS + (uint64_t)tq * kPer, w1 = min(n_win, w0 + kPer);
+    const uint8_t *seq = bases + off;
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < kTileH; q += 1024) ht_key[q] = kNoCol;
+    for (uint32_t q = threadIdx.x; q < kTileG * kTileXS / 2; q += 1024) Xw[q] = 0;
+    if (threadIdx.x < kTileG) s_found[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+      s_over = 0;
+      s_n = 0;
+    }
+    __syncthreads();
+    // the thread's rows: found once (hash rolled, name -> row walked), kept in registers for the second pass
+    uint32_t cols[kPer];
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; ++i) cols[i] = kNoCol;
+    if (mine && w0 < w1) {
+      H fwd = 0, rc = 0;
+      int run = 0;
+      for (int j = 0; j < k - 1; ++j) {
+        const uint32_t c = base_code(seq[w0 + j]);
+        fwd = ((fwd << 2) | (H)(c & 3u)) & mask;
+        rc = (rc >> 2) | ((H)(3u - (c & 3u)) << shift);
+        run = c < 4u ? run + 1 : 0;
+      }
+#pragma unroll
+      for (uint32_t i = 0; i < kPer; ++i) {
+        const uint64_t w = w0 + i;
+        if (w < w1) {
+          const uint32_t c = base_code(seq[w + k - 1]);
+          fwd = ((fwd << 2) | (H)(c & 3u)) & mask;
+          rc = (rc >> 2) | ((H)(3u - (c & 3u)) << shift);
+          run = c < 4u ? run + 1 : 0;
+          if (run >= k && !(dbg & 8)) cols[i] = lookup_col(tv, (uint64_t)((content == KPOP_DNA_DS && rc < fwd) ? rc : fwd));
+        }
+      }
+    }
+    // ---- 1. the distinct rows into the set
+    uint16_t slots[kPer];
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; ++i) {
+      slots[i] = 0xFFFFu;
+      const uint32_t col = cols[i];
+      if (col == kNoCol || (dbg & 4)) continue;
+      if (*reinterpret_cast<volatile uint32_t *>(&s_over)) break;  // (a full table: no point in probing it further)
+      uint32_t slot = (col * 2654435761u) >> 21;  // 11 bits
+#pragma unroll 1
+      for (int t = 0; t < 32; ++t) {
+        const uint32_t prev = atomicCAS(&ht_key[slot], kNoCol, col);
+        if (prev == col || prev == kNoCol) {
+          slots[i] = (uint16_t)slot;
+          break;
+        }
+        slot = (slot + 1) & (kTileH - 1);
+      }
+      if (slots[i] == 0xFFFFu) s_over = 1;
+    }
+    __syncthreads();
+    {
+      // number the occupied slots (thread order over the table: 2 slots a thread, a block-wide scan)
+      const uint32_t q0 = threadIdx.x * 2;
+      const uint32_t o0 = ht_key[q0] != kNoCol, o1 = ht_key[q0 + 1] != kNoCol, occ = o0 + o1;
+      uint32_t incl = occ;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += up;
+      }
+      if (lane == 63) s_wbase[wv] = incl;
+      __syncthreads();
+      uint32_t before = incl - occ;
+      for (int w = 0; w < wv; ++w) before += s_wbase[w];
+      if (threadIdx.x == 1023) s_n = before + occ;
+      if (o0) {
+        if (before < kTileU) {
+          ht_u[q0] = (uint16_t)before;
+          ucol[before] = ht_key[q0];
+        }
+        ++before;
+      }
+      if (o1 && before < kTileU) {
+        ht_u[q0 + 1] = (uint16_t)before;
+        ucol[before] = ht_key[q0 + 1];
+      }
+      __syncthreads();
+    }
+    if (s_over || s_n > kTileU) {  // too many distinct rows for this scheme: the streaming kernel takes the chunk
+      ++misses;
+      continue;
+    }
+    misses = 0;
+    // ---- 2. X[sequence][number of the row] += 1
+    {
+      uint32_t found = 0;
+#pragma unroll
+      for (uint32_t i = 0; i < kPer; ++i)
+        if (slots[i] != 0xFFFFu && !(dbg & 2)) {
+          const uint32_t u = ht_u[slots[i]];
+          atomicAdd(&Xw[tg * (kTileXS / 2) + (u >> 1)], 1u << (16 * (u & 1u)));
+          ++found;
+        }
+      if (found) atomicAdd(&s_found[tg], found);
+    }
+    // (the columns are padded to a multiple of 32 with row 0 of the twister against zero counts: the loop below has no
+    // branches, so that the loads of eight steps ahead stay in flight under the MFMAs)
+    const uint32_t U = s_n, U32 = (U + 31) & ~31u;
+    for (uint32_t u = U + threadIdx.x; u < U32; u += 1024) ucol[u] = 0;
+    __syncthreads();
+    // ---- 3. partial[64 x D] = X[64 x U] * T_U: wave wv owns M tile wv & 3 (16 sequences) and the 16 dims of slice wv >> 2
+    const uint16_t *X16 = reinterpret_cast<const uint16_t *>(Xw);
+    const int mi = wv & 3, ni = wv >> 2;
+    for (uint32_t d0 = 0; d0 < tv.n_dims && !(dbg & 1); d0 += 64) {
+      const uint32_t dc = d0 + 16u * ni + (lane & 15);
+      const double *trow = tv.rows + min(dc, tv.d_pad - 1);  // (columns past the twister's are not written below)
+      f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+      constexpr int PF = 8;
+      double bb[PF];
+#pragma unroll
+      for (int q = 0; q < PF; ++q) bb[q] = trow[(uint64_t)ucol[4 * q + (lane >> 4)] * tv.d_pad];
+      const uint16_t *xrow = X16 + (16 * mi + (lane & 15)) * kTileXS + (lane >> 4);
+      for (uint32_t q0 = 0; q0 < U32 / 4; q0 += PF) {
+#pragma unroll
+        for (int qq = 0; qq < PF; ++qq) {
+          const uint32_t q = q0 + qq;
+          const double b = bb[qq];
+          bb[qq] = trow[(uint64_t)ucol[min(4 * (q + PF) + (lane >> 4), U32 - 1)] * tv.d_pad];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xrow[4 * q], b, acc, 0, 0, 0);
+        }
+      }
+      // lane l holds rows (l >> 4) + 4 r of the M tile, column l & 15 of the wave's 16 dims
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const uint32_t g = 16 * mi + (lane >> 4) + 4 * rr, rd = grp * kTileG + g;
+        if (rd < n_reads && dc < tv.n_dims && seg < nseg[rd]) partial[(seg_off[rd] + seg) * tv.n_dims + dc] = acc[rr];
+      }
+    }
+    if (threadIdx.x < kTileG) {
+      const uint32_t rd = grp * kTileG + threadIdx.x;
+      if (rd < n_reads && seg < nseg[rd]) partial_cnt[seg_off[rd] + seg] = s_found[threadIdx.x];
+    }
+    if (threadIdx.x == 0) tile_done[chunk] = 1;
   }
 }
 
@@ -678,26 +873,45 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   // sums: its rows should sit in one XCD's L2 (4 MB) next to those of the neighbouring segment, see the kernel.
   const Context &cx = ctx();
   uint32_t seg_windows = cx.tune_seg ? (uint32_t)cx.tune_seg : std::max<uint32_t>(1024u, std::min<uint32_t>(kSegWindows, (uint32_t)((3ull << 19) / ((uint64_t)tw->d_pad * 8)) / 64 * 64));
+  // kpop_tune("dense", 2): batches of assemblies first go through count_twist_tile_kernel (the distinct rows of a stretch of
+  // 64 sequences gathered once and multiplied on the matrix cores); what it leaves is the streaming kernel's as before
+  const bool tiles = cx.tune_dense == 2 && tv.rsel && n_reads >= kTileG && tv.hk <= 15;
+  if (tiles) seg_windows = kTileS;
   const bool nt = cx.tune_nt == 1;
   const uint64_t max_slots = n_bases / seg_windows + n_reads;  // every read adds at most W/seg + 1 segments
   const uint64_t nb = scan_blocks(n_reads);
+  const uint32_t max_seg = div_up(max_windows, seg_windows);
+  const uint32_t n_groups = div_up(n_reads, kTileG);
   const uint64_t bytes_nseg = ((uint64_t)n_reads * 4 + 63) & ~63ull, bytes_off = ((uint64_t)(n_reads + 1) * 8 + 63) & ~63ull,
                  bytes_sums = ((nb + 1) * 8 + 63) & ~63ull, bytes_cnt = (max_slots * 4 + 63) & ~63ull,
-                 bytes_part = max_slots * tw->n_dims * 8;
+                 bytes_part = (max_slots * tw->n_dims * 8 + 63) & ~63ull, bytes_done = tiles ? (((uint64_t)n_groups * max_seg + 63) & ~63ull) : 0;
   void *ws = nullptr;
-  KPOP_TRY(ctx().ws_for(st).ensure(bytes_nseg + bytes_off + bytes_sums + bytes_cnt + bytes_part, &ws));
+  KPOP_TRY(ctx().ws_for(st).ensure(bytes_nseg + bytes_off + bytes_sums + bytes_cnt + bytes_part + bytes_done, &ws));
   char *wp = reinterpret_cast<char *>(ws);
   uint32_t *nseg = reinterpret_cast<uint32_t *>(wp);
   uint64_t *seg_off = reinterpret_cast<uint64_t *>(wp + bytes_nseg);
   uint64_t *sums = reinterpret_cast<uint64_t *>(wp + bytes_nseg + bytes_off);
   uint32_t *pcnt = reinterpret_cast<uint32_t *>(wp + bytes_nseg + bytes_off + bytes_sums);
   double *part = reinterpret_cast<double *>(wp + bytes_nseg + bytes_off + bytes_sums + bytes_cnt);
+  uint8_t *tile_done = tiles ? reinterpret_cast<uint8_t *>(wp + bytes_nseg + bytes_off + bytes_sums + bytes_cnt + bytes_part) : nullptr;
   segment_count_kernel<<<dim3(div_up(n_reads, 256)), dim3(256), 0, st>>>(d_offsets, n_reads, tv.hk, seg_windows, nseg);
   KPOP_LAUNCH_CHECK();
   KPOP_TRY(exclusive_scan(LoadU32{nseg}, StoreU64{seg_off}, n_reads, sums, st));
-  const uint32_t max_seg = div_up(max_windows, seg_windows);
+  if (tiles) {
+    KPOP_HIP(hipMemsetAsync(tile_done, 0, bytes_done, st));
+    const size_t lds = (size_t)kTileH * 4 + kTileH * 2 + kTileU * 4 + (size_t)kTileG * kTileXS * 2;
+    static PerSlotOnce once;
+    if (!once()) {
+      KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&count_twist_tile_kernel<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      once() = true;
+    }
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)n_groups * max_seg, (uint64_t)cx.n_cus);
+    count_twist_tile_kernel<uint32_t><<<dim3(blocks), dim3(1024), lds, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, n_reads,
+                                                                           max_seg, tile_done, ctx().tune_dbg >> 24);
+    KPOP_LAUNCH_CHECK();
+  }
   dim3 grid(capped_grid((uint64_t)n_reads * max_seg));
-#define KPOP_STREAM(H, NT) count_twist_stream_kernel<H, NT><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, n_reads, max_seg, seg_windows)
+#define KPOP_STREAM(H, NT) count_twist_stream_kernel<H, NT><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, n_reads, max_seg, seg_windows, tile_done, n_groups)
   if (tv.hk <= 15) {
     if (nt) KPOP_STREAM(uint32_t, true); else KPOP_STREAM(uint32_t, false);
   } else {

@@ -473,6 +473,50 @@ def test_count_twist_through_the_dense_image(kpop, oracle, k, d, content):
         api.dev_count_twist_dense(big, db.data_ptr(), do.data_ptr(), n, work.data_ptr(), out.data_ptr())
 
 
+@pytest.mark.parametrize("k,d", [(12, 64), (10, 40), (13, 130)])
+def test_assemblies_of_one_organism_through_the_tile_kernel(kpop, oracle, k, d):
+    """kpop_tune("dense", 2): stretches of 64 near-identical assemblies go through count_twist_tile_kernel (distinct rows in an
+    LDS set, counts in an LDS matrix, the matrix cores), divergent stretches and unrelated sequences are left to the
+    streaming kernel, short reads to the wave kernel -- against the oracle and the default kernels, normalised or not"""
+    from kpop_amd import api
+    rng = np.random.RandomState(k + d)
+    ref = rng.choice(list("ACGT"), size=7000)
+    seqs = []
+    for i in range(150):  # mutants: substitutions, a few Ns, some with a deletion (the windows shift), ragged ends
+        m = ref.copy()
+        hit = rng.rand(len(m)) < 0.002
+        m[hit] = rng.choice(list("ACGTN"), size=int(hit.sum()), p=[.24, .24, .24, .24, .04])
+        if i % 7 == 0:
+            cut = int(rng.randint(100, 6000))
+            m = np.concatenate([m[:cut], m[cut + 5:]])
+        seqs.append("".join(m[: len(m) - int(rng.randint(0, 900))]))
+    seqs += ["".join(rng.choice(list("ACGT"), size=int(rng.randint(3000, 9000)))) for _ in range(70)]  # unrelated: the set overflows
+    seqs += ["ACGTTGCA" * 10, "", "ACG"] + ["".join(rng.choice(list("ACGT"), size=150)) for _ in range(20)]
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order[:40]] + seqs[:150] + [seqs[i] for i in order[40:] if i >= 150]  # a run of mutants in the middle
+    bases, offs = concat(seqs)
+    h, c, o = oracle.count_reads(bases, offs, k)
+    cols = np.unique(h)
+    cols = cols[rng.rand(len(cols)) < 0.95]
+    allc = oracle.enumerate_kmers(k) if k <= 10 else None
+    if allc is not None:
+        cols = allc
+    T = oracle.synth_twister(3, d, cols)
+    tw = kpop.Twister.load(T, cols, k)
+    for normalize in (True, False):
+        want = oracle.twist(T, cols, h, c.astype(np.float64), o, normalize=normalize)
+        ref_rows = tw.count_twist(bases, offs, normalize=normalize)
+        api.tune("dense", 2)
+        try:
+            got = tw.count_twist(bases, offs, normalize=normalize)
+        finally:
+            api.tune("dense", 0)
+        scale = max(np.max(np.abs(want)), 1.0)
+        assert np.max(np.abs(ref_rows - want)) <= 1e-12 * scale
+        assert np.max(np.abs(got - want)) <= 1e-12 * scale, np.max(np.abs(got - want))
+        assert not np.array_equal(got, ref_rows)  # (another order of additions: the tile kernel did run)
+
+
 def test_understated_max_len_yields_nan_rows_not_stale_memory(kpop, oracle):
     """kpop_dev_count_twist trusts the caller's max_len to schedule the long-sequence pass; a read longer than it says
     must come back as NaNs, and kpop_dev_distance_rowwise refuses a null workspace for very long rows"""
