@@ -363,9 +363,10 @@ __global__ __launch_bounds__(256) void distance_summary_kernel(
 // (distance, column) pairs are sorted in registers (wave_bitonic_sort_pairs), and the walk of the multimap
 // (lib/Matrix.ml:640-655) and the squared deviations (:657-670) stay the reference's sequential chains, run by one lane
 // over at most 64 R values: same operations in the same order as distance_summary_kernel, so the same bits.
-// Needs r1 <= 64 R <= 512 and (PRE or r1 x n_dims doubles within kWaveSummaryLds).
+// Needs r1 <= 512 and (PRE or r1 x n_dims doubles and four waves' buffers within a CU's LDS); a first operand of up to 512
+// rows that does not fit goes through distance rows in the workspace and the PRE variant (summary_impl).
 // ---------------------------------------------------------------------------
-constexpr uint32_t kWaveSummaryLds = 48u << 10;
+constexpr size_t kWaveSummaryHalf = 78u << 10, kWaveSummaryWhole = 159u << 10;
 constexpr int kSummaryWaves = 16;  // per block: they share the LDS copy of the first operand, and 2 blocks fill a CU's 32 wave slots
 
 __device__ __forceinline__ uint64_t dist_key(double x) {  // order-preserving map of an f64 to u64
@@ -377,20 +378,36 @@ __device__ __forceinline__ double key_dist(uint64_t k) {
   return __longlong_as_double((long long)b);
 }
 
-template <int KIND, bool PRE, int R>
+constexpr int kWaveTail = 8;  // columns beyond 64 R that the TAIL variant takes in by rank instead of doubling the network
+
+__device__ __forceinline__ double wave_readlane_f64(double v, int l) {  // l uniform
+  return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(v) >> 32), l) << 32) |
+                              (unsigned int)__builtin_amdgcn_readlane((int)__double_as_longlong(v), l));
+}
+__device__ __forceinline__ uint64_t wave_readlane_u64(uint64_t v, int l) {
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+
+// R: the 64-column slots sorted by the network (a power of two).  TAIL: 1..kWaveTail columns more (r1 = 64 R + T), whose
+// distances are worked out apart -- for eight rows of the wave at a time, a lane per (row, column) -- and take their places
+// among the sorted 64 R by rank.  65 classes (the bench's, and any set "a few more than 64") then cost one slot's network
+// and one slot's distances, not two with 63 of the second slot's 64 lanes idle.
+template <int KIND, bool PRE, int R, bool TAIL>
 __global__ __launch_bounds__(64 * kSummaryWaves) void distance_summary_wave_kernel(
     const double *__restrict__ a, uint32_t r1, const double *__restrict__ b, uint32_t r2, uint32_t n_dims,
     const double *__restrict__ metric, double p, uint32_t req_len, uint32_t max_neighbours,
     double *__restrict__ out_stats, uint32_t *__restrict__ out_n, uint32_t *__restrict__ out_idx,
-    double *__restrict__ out_dist, double *__restrict__ out_z) {
+    double *__restrict__ out_dist, double *__restrict__ out_z, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int N = 64 * R;
-  // per wave: dist[N] (column order), kd[N] (sorted), ki[N], brow[n_dims]; then the transposed first operand
+  constexpr int RS = R + (TAIL ? 1 : 0);                    // stripes of 64 sorted positions
+  constexpr int RP = RS <= 1 ? 1 : RS <= 2 ? 2 : RS <= 4 ? 4 : RS <= 8 ? 8 : 16;  // ... rounded up to a power of two (the MAD's merge)
+  constexpr int N = 64 * RS;
+  // per wave: chain[N] (terms of the sequential sums), kd[N] (sorted), ki[N], brow[n_dims]; then the transposed first operand
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t per_wave = (uint32_t)N * 20 + (PRE ? 0u : n_dims * 8);
   unsigned char *mine = smem + (size_t)wv * ((per_wave + 15) & ~15u);
-  double *dist = reinterpret_cast<double *>(mine);
-  double *kd = dist + N;
+  double *chain = reinterpret_cast<double *>(mine);
+  double *kd = chain + N;
   uint32_t *ki = reinterpret_cast<uint32_t *>(kd + N);
   double *s_b = reinterpret_cast<double *>(ki + N);
   const uint32_t n_waves = blockDim.x >> 6, n_threads = blockDim.x;
@@ -405,22 +422,45 @@ __global__ __launch_bounds__(64 * kSummaryWaves) void distance_summary_wave_kern
   }
   __syncthreads();
   const double inf = __longlong_as_double(0x7FF0000000000000ll);
-  for (uint32_t j = blockIdx.x * n_waves + wv; j < r2; j += gridDim.x * n_waves) {
+  const uint32_t n_tail = TAIL ? r1 - 64u * R : 0u;  // 1..kWaveTail
+  const uint32_t j_stride = gridDim.x * n_waves;
+  double tail_batch = 0.0;  // TAIL, not PRE: lane l holds the distance of row (l >> 3) of the batch to column 64 R + (l & 7)
+  uint32_t it = 0;
+  for (uint32_t j = blockIdx.x * n_waves + wv; j < r2; j += j_stride, ++it) {
     // distances of row j to every m1 row (lib/Matrix.ml:744-749): lane owns columns lane, lane + 64, ...
     double dv[R];
+    double dt = inf;  // TAIL: lane t < n_tail holds the distance to column 64 R + t
     if (PRE) {
 #pragma unroll
       for (int q = 0; q < R; ++q) {
         const uint32_t i = (uint32_t)lane + 64u * q;
         dv[q] = i < r1 ? a[(uint64_t)j * r1 + i] : inf;
       }
+      if (TAIL && (uint32_t)lane < n_tail) dt = a[(uint64_t)j * r1 + 64u * R + lane];
     } else {
+      if (TAIL) {
+        if ((it & 7u) == 0) {  // the tail columns of this and the wave's next seven rows
+          const uint32_t jr = j + (uint32_t)(lane >> 3) * j_stride, t = (uint32_t)lane & 7u;
+          const bool ok = jr < r2 && t < n_tail;
+          const double *brow = b + (uint64_t)(ok ? jr : j) * n_dims;
+          const double *acol = As + 64u * R + (ok ? t : 0u);
+          double acc = 0.0;
+#pragma unroll 8
+          for (uint32_t c = 0; c < n_dims; ++c) {
+            const double diff = __dsub_rn(acol[(size_t)c * r1], brow[c]);
+            acc = __dadd_rn(acc, component<KIND>(diff, s_metric[c], p));
+          }
+          tail_batch = ok ? scale_distance<KIND>(acc, p) : inf;
+        }
+        const double mine_t = __shfl(tail_batch, (int)((it & 7u) * 8u) + (lane & 7), 64);
+        dt = (uint32_t)lane < n_tail ? mine_t : inf;
+      }
       for (uint32_t c = lane; c < n_dims; c += 64) s_b[c] = b[(uint64_t)j * n_dims + c];
       __builtin_amdgcn_wave_barrier();
       double acc[R];
 #pragma unroll
       for (int q = 0; q < R; ++q) acc[q] = 0.0;
-      for (uint32_t c = 0; c < n_dims; ++c) {
+      for (uint32_t c = 0; c < n_dims && !(dbg & 8); ++c) {
         const double bc = s_b[c], mc = s_metric[c];
 #pragma unroll
         for (int q = 0; q < R; ++q) {
@@ -438,94 +478,107 @@ __global__ __launch_bounds__(64 * kSummaryWaves) void distance_summary_wave_kern
 #pragma unroll
     for (int q = 0; q < R; ++q) {
       const uint32_t i = (uint32_t)lane + 64u * q;
-      if (i < r1) dist[i] = dv[q];
       key[q] = i < r1 ? dist_key(dv[q]) : ~0ull;  // padding sorts last (a NaN distance would too; none arises from finite rows)
       val[q] = i < r1 ? i : 0xFFFFFFFFu;
     }
-    wave_bitonic_sort_pairs<R, uint64_t>(key, val, lane);
+    if (!(dbg & 1)) wave_bitonic_sort_pairs<R, uint64_t>(key, val, lane);
+    if (!TAIL) {
 #pragma unroll
-    for (int q = 0; q < R; ++q) {  // sorted position of (lane, q) is lane * R + q
-      kd[lane * R + q] = key_dist(key[q]);
-      ki[lane * R + q] = val[q];
+      for (int q = 0; q < R; ++q) {  // sorted position of (lane, q) is lane * R + q
+        kd[lane * R + q] = key_dist(key[q]);
+        ki[lane * R + q] = val[q];
+      }
+    } else {
+      // the tail's columns come after every sorted one (larger index): a tail element goes behind the sorted elements <= it
+      // and the tail elements before it in (distance, column) order; a sorted element moves up by the tail elements < it
+      const uint64_t tkey = (uint32_t)lane < n_tail ? dist_key(dt) : ~0ull;
+      uint32_t shift[R], my_pos = 0;
+#pragma unroll
+      for (int q = 0; q < R; ++q) shift[q] = 0;
+      for (uint32_t t = 0; t < n_tail; ++t) {
+        const uint64_t tk = wave_readlane_u64(tkey, (int)t);
+        uint32_t pos = 0;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          const bool before = key[q] <= tk;
+          pos += (uint32_t)__popcll(__ballot(before));
+          shift[q] += before ? 0u : 1u;
+        }
+        pos += (uint32_t)__popcll(__ballot((uint32_t)lane < n_tail && (tkey < tk || (tkey == tk && (uint32_t)lane < t))));
+        if ((uint32_t)lane == t) my_pos = pos;
+      }
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        kd[lane * R + q + shift[q]] = key_dist(key[q]);
+        ki[lane * R + q + shift[q]] = val[q];
+      }
+      if ((uint32_t)lane < n_tail) {
+        kd[my_pos] = dt;
+        ki[my_pos] = 64u * R + lane;
+      }
     }
     __builtin_amdgcn_wave_barrier();
     // The walk of the multimap (lib/Matrix.ml:640-655) and the squared deviations (:657-670) are sequential chains of
-    // f64 additions in the reference, and stay so here -- but out of registers: the sorted values come back striped
-    // (position q * 64 + lane), each lane works out the term of its position, and the chain collects the terms with
-    // v_readlane, a few cycles each, instead of one LDS round trip per element.
-    double sv[R];     // sorted distance at position q * 64 + lane (inf beyond r1)
-    uint64_t hm[R];   // lanes of row q that start a group of equal distances
+    // f64 additions in the reference, and stay so here: the sorted values come back striped (position q * 64 + lane), each
+    // lane works out the term of its position, the terms go to LDS and the chain reads them back, every lane the same
+    // word -- one ds_read per term (two v_readlane and their hazards per term made the chains a quarter of the kernel).
+    double sv[RS];     // sorted distance at position q * 64 + lane (inf beyond r1)
+    uint64_t hm[RS];   // lanes of stripe q that start a group of equal distances
 #pragma unroll
-    for (int q = 0; q < R; ++q) {
+    for (int q = 0; q < RS; ++q) {
       const uint32_t pos = (uint32_t)q * 64u + lane;
       sv[q] = pos < r1 ? kd[pos] : inf;
       const double prev = pos > 0 && pos < r1 ? kd[pos - 1] : 0.0;
       hm[q] = __ballot(pos < r1 && (pos == 0 || prev != sv[q]));
     }
     // position of the next group start after this one (r1 if none): the length of a group is that minus its start
-    double term[R];
 #pragma unroll
-    for (int q = 0; q < R; ++q) {
+    for (int q = 0; q < RS; ++q) {
       uint32_t next = r1;
       const uint64_t above = lane == 63 ? 0ull : (hm[q] >> (lane + 1));
       if (above) next = (uint32_t)q * 64u + lane + 1u + (uint32_t)__ffsll((long long)above) - 1u;
       else {
 #pragma unroll
-        for (int q2 = R - 1; q2 > q; --q2)
+        for (int q2 = RS - 1; q2 > q; --q2)
           if (hm[q2]) next = (uint32_t)q2 * 64u + (uint32_t)__ffsll((long long)hm[q2]) - 1u;
       }
       const uint32_t pos = (uint32_t)q * 64u + lane;
       const bool head = (hm[q] >> lane) & 1ull;
-      term[q] = head ? __dmul_rn((double)(next - pos), sv[q]) : 0.0;  // set_len *. dist (:643)
+      chain[pos] = head ? __dmul_rn((double)(next - pos), sv[q]) : 0.0;  // set_len *. dist (:643)
     }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t chain_len = (dbg & 2) ? min(r1, 1u) : r1;
     double acc = 0.0;
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-      const int lim = (int)min(64u, r1 > (uint32_t)q * 64u ? r1 - (uint32_t)q * 64u : 0u);
-      for (int i = 0; i < lim; ++i) {
-        const double t = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(term[q]) >> 32), i) << 32) |
-                                              (unsigned int)__builtin_amdgcn_readlane((int)__double_as_longlong(term[q]), i));
-        acc = __dadd_rn(acc, t);  // a position that starts no group adds +0.0: exact, the sum is never -0.0
-      }
-    }
+#pragma unroll 8
+    for (uint32_t i = 0; i < chain_len; ++i) acc = __dadd_rn(acc, chain[i]);  // a position that starts no group adds +0.0: exact, the sum is never -0.0
     const double mean = (r1 > 0) ? acc / (double)r1 : 0.0;
     // upper median = the value at sorted position r1 / 2 (:645-647 picks the group that holds it)
-    double median = 0.0;
-    if (r1 > 0) {
-      const uint32_t mp = r1 / 2;
-#pragma unroll
-      for (int q = 0; q < R; ++q)
-        if ((mp >> 6) == (uint32_t)q)
-          median = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(sv[q]) >> 32), (int)(mp & 63u)) << 32) |
-                                        (unsigned int)__builtin_amdgcn_readlane((int)__double_as_longlong(sv[q]), (int)(mp & 63u)));
-    }
+    const double median = r1 > 0 ? kd[r1 / 2] : 0.0;
     // groups are added while eff_len < req_len (:648-649): the first group boundary at or beyond req_len
     uint32_t eff = r1;
     if (req_len < r1) {
 #pragma unroll
-      for (int q = R - 1; q >= 0; --q) {
-        const uint32_t lo = req_len > (uint32_t)q * 64u ? req_len - (uint32_t)q * 64u : 0u;  // lanes of this row at or beyond req_len
+      for (int q = RS - 1; q >= 0; --q) {
+        const uint32_t lo = req_len > (uint32_t)q * 64u ? req_len - (uint32_t)q * 64u : 0u;  // lanes of this stripe at or beyond req_len
         const uint64_t m = lo >= 64u ? 0ull : (hm[q] >> lo) << lo;
         if (m) eff = (uint32_t)q * 64u + (uint32_t)__ffsll((long long)m) - 1u;
       }
     }
-    // squared deviations in column order (:657-670); dv[q] is column lane + 64 q
-    double t2[R];
+    // squared deviations in column order (:657-670); dv[q] is column lane + 64 q, dt column 64 R + lane
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int q = 0; q < R; ++q) {
       const double d0 = __dsub_rn(dv[q], mean);
-      t2[q] = ((uint32_t)lane + 64u * q) < r1 ? __dmul_rn(d0, d0) : 0.0;
+      chain[q * 64 + lane] = __dmul_rn(d0, d0);  // (columns beyond r1 are not read)
     }
+    if (TAIL && (uint32_t)lane < n_tail) {
+      const double d0 = __dsub_rn(dt, mean);
+      chain[64 * R + lane] = __dmul_rn(d0, d0);
+    }
+    __builtin_amdgcn_wave_barrier();
     acc = 0.0;
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-      const int lim = (int)min(64u, r1 > (uint32_t)q * 64u ? r1 - (uint32_t)q * 64u : 0u);
-      for (int i = 0; i < lim; ++i) {
-        const double t = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(t2[q]) >> 32), i) << 32) |
-                                              (unsigned int)__builtin_amdgcn_readlane((int)__double_as_longlong(t2[q]), i));
-        acc = __dadd_rn(acc, t);
-      }
-    }
+#pragma unroll 8
+    for (uint32_t i = 0; i < chain_len; ++i) acc = __dadd_rn(acc, chain[i]);
     const double sd = (r1 > 1) ? sqrt(acc / ((double)r1 - 1.0)) : 0.0;  // :679-683
     const uint32_t n_out = min(eff, max_neighbours);
     for (uint32_t q = lane; q < n_out; q += 64) {  // :685-689
@@ -535,23 +588,22 @@ __global__ __launch_bounds__(64 * kSummaryWaves) void distance_summary_wave_kern
       if (zz != zz) zz = __longlong_as_double((long long)0xFFF8000000000000ull);  // see distance_summary_kernel
       out_z[(uint64_t)j * max_neighbours + q] = zz;
     }
-    // MAD: |d - median| sorted, element n/2 (:659-678)
-    uint64_t mk[R];
+    // MAD: |d - median| sorted, element n/2 (:659-678).  Over the SORTED distances |d - median| falls down to the median's
+    // position and rises after it (the subtraction and fabs are monotone), padding last: a bitonic sequence, which one merge
+    // -- log2 N stages, not a sort's 28 -- puts in order.  The same values as over the columns, so the same element.
+    uint64_t mk[RP];
 #pragma unroll
-    for (int q = 0; q < R; ++q) {
-      const uint32_t i = (uint32_t)lane + 64u * q;
-      mk[q] = i < r1 ? dist_key(fabs(__dsub_rn(dv[q], median))) : ~0ull;
-    }
-    wave_bitonic_sort<R, uint64_t>(mk, lane);
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t mpos = r1 / 2;  // sorted position lane * R + q
+    for (int q = 0; q < RP; ++q) mk[q] = ~0ull;
+#pragma unroll
+    for (int q = 0; q < RS; ++q)
+      if (((uint32_t)q * 64u + lane) < r1) mk[q] = dist_key(fabs(__dsub_rn(sv[q], median)));
+    if (!(dbg & 4)) wave_bitonic_merge_striped<RP, uint64_t>(mk, lane);
+    const uint32_t mpos = r1 / 2;  // sorted position q * 64 + lane
     double mad = 0.0;
 #pragma unroll
-    for (int q = 0; q < R; ++q)
-      if (r1 > 0 && (uint32_t)lane * R + q == mpos) kd[0] = key_dist(mk[q]);
-    __builtin_amdgcn_wave_barrier();
+    for (int q = 0; q < RS; ++q)
+      if (r1 > 0 && (mpos >> 6) == (uint32_t)q) mad = wave_readlane_f64(key_dist(mk[q]), (int)(mpos & 63u));
     if (lane == 0) {
-      mad = (r1 > 0) ? kd[0] : 0.0;
       out_stats[(uint64_t)j * 4 + 0] = mean;
       out_stats[(uint64_t)j * 4 + 1] = sd;
       out_stats[(uint64_t)j * 4 + 2] = median;
@@ -562,42 +614,62 @@ __global__ __launch_bounds__(64 * kSummaryWaves) void distance_summary_wave_kern
   }
 }
 
-template <int KIND, bool PRE, int R>
+template <int KIND, bool PRE, int R, bool TAIL>
 static int launch_summary_wave_r(const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims, const double *metric,
                                  double p, uint32_t req_len, uint32_t max_neighbours, double *out_stats, uint32_t *out_n,
                                  uint32_t *out_idx, double *out_dist, double *out_z, hipStream_t st) {
-  const uint32_t per_wave = ((uint32_t)(64 * R) * 20 + (PRE ? 0u : n_dims * 8) + 15) & ~15u;
+  const uint32_t per_wave = ((uint32_t)(64 * (R + (TAIL ? 1 : 0))) * 20 + (PRE ? 0u : n_dims * 8) + 15) & ~15u;
   const size_t shared = PRE ? 0 : ((size_t)n_dims * r1 + n_dims) * 8;
-  // as many waves per block as the LDS left beside the shared operand allows (two blocks per CU: 78 KB each)
-  const uint32_t waves = (uint32_t)std::max<size_t>(1, std::min<size_t>(kSummaryWaves, ((78u << 10) - shared) / per_wave));
+  // as many waves per block as the LDS left beside the shared operand allows: two blocks per CU (78 KB each) while eight
+  // waves still fit beside it, one block with the whole LDS above that (100 classes x 64 dimensions: 51 KB of operand)
+  const bool two = shared + 8 * (size_t)per_wave <= kWaveSummaryHalf;
+  const size_t budget = two ? kWaveSummaryHalf : kWaveSummaryWhole;
+  const uint32_t waves = (uint32_t)std::max<size_t>(1, std::min<size_t>(kSummaryWaves, (budget - shared) / per_wave));
   const size_t smem = (size_t)waves * per_wave + shared;
   static PerSlotOnce attr_once;
   bool &attr_set = attr_once();
   if (!attr_set) {
-    KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&distance_summary_wave_kernel<KIND, PRE, R>),
+    KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&distance_summary_wave_kernel<KIND, PRE, R, TAIL>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     attr_set = true;
   }
-  const uint32_t blocks = std::min<uint32_t>(div_up(r2, waves), (uint32_t)ctx().n_cus * 2);
-  distance_summary_wave_kernel<KIND, PRE, R><<<dim3(blocks), dim3(64 * waves), smem, st>>>(a, r1, b, r2, n_dims, metric, p, req_len,
-                                                                                     max_neighbours, out_stats, out_n, out_idx,
-                                                                                     out_dist, out_z);
+  const uint32_t blocks = std::min<uint32_t>(div_up(r2, waves), (uint32_t)ctx().n_cus * (two ? 2 : 1));
+  distance_summary_wave_kernel<KIND, PRE, R, TAIL><<<dim3(blocks), dim3(64 * waves), smem, st>>>(
+      a, r1, b, r2, n_dims, metric, p, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, (ctx().tune_dbg >> 16) & 15);
   KPOP_LAUNCH_CHECK();
   return 0;
 }
 
+// the stripes of 64 sorted positions a row of r1 distances takes in the wave kernel (R, + 1 with a tail)
+static inline uint32_t wave_summary_stripes(uint32_t r1, bool tails) {
+  for (uint32_t r = 1; r <= 4; r <<= 1) {
+    if (r1 <= 64 * r) return r;
+    if (r1 <= 64 * r + kWaveTail && tails) return r + 1;
+  }
+  return 8;
+}
 static inline bool summary_fits_wave(uint32_t r1, uint32_t n_dims, bool pre) {
-  return r1 >= 1 && r1 <= 512 && (pre || (uint64_t)r1 * n_dims * 8 <= kWaveSummaryLds);
+  if (r1 < 1 || r1 > 512) return false;
+  if (pre) return true;
+  const size_t per_wave = ((size_t)64 * wave_summary_stripes(r1, !(ctx().tune_dbg & 32768)) * 20 + (size_t)n_dims * 8 + 15) & ~(size_t)15;
+  return ((size_t)n_dims * r1 + n_dims) * 8 + 4 * per_wave <= kWaveSummaryWhole;  // the first operand and at least four waves' buffers
 }
 
 template <int KIND, bool PRE>
 static int launch_summary_wave(const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims, const double *metric,
                                double p, uint32_t req_len, uint32_t max_neighbours, double *out_stats, uint32_t *out_n,
                                uint32_t *out_idx, double *out_dist, double *out_z, hipStream_t st) {
-  if (r1 <= 64) return launch_summary_wave_r<KIND, PRE, 1>(a, r1, b, r2, n_dims, metric, p, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st);
-  if (r1 <= 128) return launch_summary_wave_r<KIND, PRE, 2>(a, r1, b, r2, n_dims, metric, p, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st);
-  if (r1 <= 256) return launch_summary_wave_r<KIND, PRE, 4>(a, r1, b, r2, n_dims, metric, p, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st);
-  return launch_summary_wave_r<KIND, PRE, 8>(a, r1, b, r2, n_dims, metric, p, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st);
+#define KPOP_WAVE(RR, TT) \
+  return launch_summary_wave_r<KIND, PRE, RR, TT>(a, r1, b, r2, n_dims, metric, p, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st)
+  const bool tails = !(ctx().tune_dbg & 32768);  // (32768: the doubled network for a few columns beyond 64 R, for A/B)
+  if (r1 <= 64) KPOP_WAVE(1, false);
+  if (r1 <= 64 + kWaveTail && tails) KPOP_WAVE(1, true);
+  if (r1 <= 128) KPOP_WAVE(2, false);
+  if (r1 <= 128 + kWaveTail && tails) KPOP_WAVE(2, true);
+  if (r1 <= 256) KPOP_WAVE(4, false);
+  if (r1 <= 256 + kWaveTail && tails) KPOP_WAVE(4, true);
+  KPOP_WAVE(8, false);
+#undef KPOP_WAVE
 }
 
 // ---------------------------------------------------------------------------
@@ -861,6 +933,22 @@ static int summary_impl(const double *m1, uint32_t r1, const double *m2, uint32_
                         double *out_z, hipStream_t st) {
   const double *a, *b;
   KPOP_TRY(prepare_operands<KIND>(m1, r1, m2, r2, n_dims, metric, p, normalize, work, &a, &b, st));
+  if (r1 >= 1 && r1 <= 512 && !summary_fits_wave(r1, n_dims, false) && ctx().tune_dbg != 4) {
+    // up to 512 rows too long for LDS (100 x 200 dimensions, 500 x 64): the distances of a chunk of second-operand rows
+    // into the workspace (the tiled kernel), then one wavefront per row over them -- not one block per row
+    const uint32_t chunk = (uint32_t)std::min<uint64_t>(r2, std::max<uint64_t>(1024, (256ull << 20) / ((uint64_t)r1 * 8)));
+    void *ws = nullptr;
+    KPOP_TRY(ctx().ws_for(st).ensure((uint64_t)chunk * r1 * 8, &ws));
+    double *rows = reinterpret_cast<double *>(ws);
+    for (uint32_t q0 = 0; q0 < r2; q0 += chunk) {
+      const uint32_t q = std::min(chunk, r2 - q0);
+      KPOP_TRY(rowwise_block<KIND>(a, r1, b + (uint64_t)q0 * n_dims, q, n_dims, metric, p, rows, st));
+      KPOP_TRY((launch_summary<KIND, true>(rows, r1, nullptr, q, n_dims, metric, p, keep_at_most, max_neighbours, out_stats + (uint64_t)q0 * 4,
+                                           out_n + q0, out_idx + (uint64_t)q0 * max_neighbours, out_dist + (uint64_t)q0 * max_neighbours,
+                                           out_z + (uint64_t)q0 * max_neighbours, st)));
+    }
+    return 0;
+  }
   return launch_summary<KIND, false>(a, r1, b, r2, n_dims, metric, p, keep_at_most, max_neighbours, out_stats, out_n,
                                      out_idx, out_dist, out_z, st);
 }

@@ -59,6 +59,34 @@ __device__ __forceinline__ void wave_bitonic_sort(K (&key)[R], int lane) {
   }
 }
 
+// The last phase of the network alone, on keys held STRIPED (element index e = r * 64 + lane): puts a BITONIC sequence
+// (one that falls and then rises, or rises and then falls) in ascending order in log2(64 R) stages.
+template <int R, typename K>
+__device__ __forceinline__ void wave_bitonic_merge_striped(K (&key)[R], int lane) {
+  static_assert((R & (R - 1)) == 0, "a power of two");
+#pragma unroll
+  for (int t = 32 * R; t > 0; t >>= 1) {
+    if (t >= 64) {
+      const int rt = t / 64;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if ((r & rt) == 0) {
+          const K a = key[r], b = key[r ^ rt];
+          key[r] = key_min(a, b);
+          key[r ^ rt] = key_max(a, b);
+        }
+    } else {
+      const bool lower = (lane & t) == 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const K other = wave_shfl_xor(key[r], t);
+        const K mn = key_min(key[r], other), mx = key_max(key[r], other);
+        key[r] = lower ? mn : mx;
+      }
+    }
+  }
+}
+
 // the same network on (key, value) pairs ordered by key, then value
 template <int R, typename K>
 __device__ __forceinline__ void wave_bitonic_sort_pairs(K (&key)[R], uint32_t (&val)[R], int lane) {

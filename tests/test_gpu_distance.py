@@ -417,7 +417,7 @@ def test_reference_distance_iterator_known_answer_on_the_gpu(kpop):
             assert (d[j, i] <= 0.3 * (1 + 1e-12)) if (i, j) in listed else (d[j, i] >= 0.3 * (1 - 1e-12))
 
 
-@pytest.mark.parametrize("r1", [1, 2, 63, 64, 65, 128, 129, 300, 512])
+@pytest.mark.parametrize("r1", [1, 2, 63, 64, 65, 66, 72, 73, 128, 129, 136, 137, 257, 264, 265, 300, 512])
 def test_wave_summary_equals_block_summary(kpop, oracle, r1):
     """the one-wavefront-per-row summary (small first operand) and the one-block-per-row summary are the same operations in
     the same order: identical bits, ties and sd = 0 included; `-S` on a ready distance matrix likewise"""
@@ -429,6 +429,12 @@ def test_wave_summary_equals_block_summary(kpop, oracle, r1):
     if r1 >= 3:
         m1[2] = m1[0]  # a tie group
         m2[5] = m1[1]  # a zero distance
+    if r1 >= 66:  # 64 R + a few columns: the last ones are placed by rank among the sorted 64 R -- ties with those, and among themselves
+        m1[r1 - 1] = m1[0]
+        m1[r1 - 2] = m1[5]
+        m2[7] = m1[r1 - 1]
+        if r1 % 64 >= 4:
+            m1[r1 - 3] = m1[r1 - 4]
     metric = kpop.metric_compute(oracle.synth_inertia(d))
     for kind, p in ((kpop.EUCLIDEAN, 2.0), (kpop.COSINE, 2.0), (kpop.MINKOWSKI, 1.5)):
         for keep in (2, 0, 7):
@@ -448,6 +454,64 @@ def test_wave_summary_equals_block_summary(kpop, oracle, r1):
     api.tune("dbg", 0)
     for x, y in zip(res[0], res[4]):
         assert np.array_equal(x, y, equal_nan=True), r1
+
+
+@pytest.mark.parametrize("r1", [65, 70, 131])
+def test_wave_summary_many_rows_per_wavefront(kpop, oracle, r1):
+    """100,001 rows: every wavefront walks over a dozen of them, so the tail columns' distances are worked out for eight rows
+    at a time (distance_summary_wave_kernel, TAIL); against the block kernel bit for bit, and rows against the oracle"""
+    from kpop_amd import api
+    rng = np.random.RandomState(r1)
+    d, r2 = (64 if r1 < 128 else 20), 100001
+    m1 = np.round(rng.randn(r1, d), 2)
+    m2 = np.round(rng.randn(r2, d), 2)
+    m1[r1 - 1] = m1[3]
+    m2[99999] = m1[r1 - 1]
+    metric = kpop.metric_compute(oracle.synth_inertia(d))
+    res = {}
+    for dbg in (0, 4, 32768):  # 4: the block kernel; 32768: the wave kernel with the doubled network
+        api.tune("dbg", dbg)
+        res[dbg] = kpop.distance_summary(m1, m2, metric, keep_at_most=2, max_neighbours=8)
+    api.tune("dbg", 0)
+    for other in (4, 32768):
+        for x, y in zip(res[0], res[other]):
+            assert np.array_equal(x, y, equal_nan=True), (r1, other)
+    rows = np.concatenate([np.arange(0, r2, 9973), [99999, r2 - 1]])
+    st_o, offs, idx_o, dist_o, z_o = oracle.distance_summary(m1, m2[rows], metric, 0, 2.0, True, 2)
+    st, n, idx, dist, z = res[0]
+    np.testing.assert_allclose(st[rows], st_o, rtol=1e-10, atol=1e-13)
+    for q, j in enumerate(rows):
+        a, b = int(offs[q]), int(offs[q + 1])
+        m = min(n[j], 8)
+        assert n[j] == b - a and idx[j, :m].tolist() == idx_o[a:a + m].tolist() and np.array_equal(dist[j, :m], dist_o[a:a + m])
+
+
+@pytest.mark.parametrize("r1,d", [(100, 64), (128, 64), (200, 96), (500, 64), (100, 300), (512, 40)])
+def test_wave_summary_first_operands_beyond_half_a_cu_of_lds(kpop, oracle, r1, d):
+    """100-200 class vectors of 64+ dimensions: one block per CU with the whole LDS; what does not fit even so (500 x 64,
+    100 x 300) goes through distance rows in the workspace and the wave kernel over them.  The block kernel's bits."""
+    from kpop_amd import api
+    rng = np.random.RandomState(r1 + d)
+    m1 = np.round(rng.randn(r1, d), 1)
+    m2 = np.round(rng.randn(3001, d), 1)
+    m1[9] = m1[4]
+    m2[11] = m1[r1 - 1]
+    metric = kpop.metric_compute(oracle.synth_inertia(d))
+    for kind, p in ((kpop.EUCLIDEAN, 2.0), (kpop.MINKOWSKI, 1.5)):
+        res = {}
+        for dbg in (0, 4):
+            api.tune("dbg", dbg)
+            res[dbg] = kpop.distance_summary(m1, m2, metric, kind=kind, p=p, keep_at_most=3, max_neighbours=12)
+        api.tune("dbg", 0)
+        for x, y in zip(res[0], res[4]):
+            assert np.array_equal(x, y, equal_nan=True), (r1, d, kind)
+    st_o, offs, idx_o, dist_o, z_o = oracle.distance_summary(m1, m2[:40], metric, 0, 2.0, True, 3)
+    st, n, idx, dist, z = kpop.distance_summary(m1, m2, metric, keep_at_most=3, max_neighbours=12)
+    np.testing.assert_allclose(st[:40], st_o, rtol=1e-10, atol=1e-13)
+    for j in range(40):
+        a, b = int(offs[j]), int(offs[j + 1])
+        m = min(n[j], 12)
+        assert n[j] == b - a and idx[j, :m].tolist() == idx_o[a:a + m].tolist() and np.array_equal(dist[j, :m], dist_o[a:a + m])
 
 
 def test_splits_gaps_golden_and_random(kpop, pyref):
