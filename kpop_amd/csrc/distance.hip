@@ -243,17 +243,15 @@ __device__ void block_sort_pairs(double *kd, uint32_t *ki, uint32_t NP) {
   __syncthreads();
 }
 
-__device__ void block_sort_keys(double *kd, uint32_t NP) {
-  for (uint32_t s = 2; s <= NP; s <<= 1) {
-    for (uint32_t t = s >> 1; t > 0; t >>= 1) {
-      __syncthreads();
-      for (uint32_t q = threadIdx.x; q < NP / 2; q += blockDim.x) {
-        const uint32_t i = 2 * q - (q & (t - 1)), j = i + t;
-        const bool asc = (i & s) == 0;
-        const double di = kd[i], dj = kd[j];
-        if ((dj < di) == asc) {
-          kd[i] = dj; kd[j] = di;
-        }
+// the last phase of the network: a bitonic sequence into ascending order
+__device__ void block_merge_keys(double *kd, uint32_t NP) {
+  for (uint32_t t = NP >> 1; t > 0; t >>= 1) {
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < NP / 2; q += blockDim.x) {
+      const uint32_t i = 2 * q - (q & (t - 1)), j = i + t;
+      const double di = kd[i], dj = kd[j];
+      if (dj < di) {
+        kd[i] = dj; kd[j] = di;
       }
     }
   }
@@ -341,12 +339,13 @@ __global__ __launch_bounds__(256) void distance_summary_kernel(
     }
   }
   __syncthreads();
-  // MAD: |d - median| sorted, element n/2 (:659-678)
+  // MAD: |d - median| sorted, element n/2 (:659-678).  kd is sorted: |kd[i] - median| falls to the median's position and
+  // rises after it, padding last -- a bitonic sequence, which the network's last phase alone puts in order
   {
     const double median = s_stats[2];
-    for (uint32_t i = threadIdx.x; i < NP; i += blockDim.x) kd[i] = (i < r1) ? fabs(__dsub_rn(dist[i], median)) : inf;
+    for (uint32_t i = threadIdx.x; i < NP; i += blockDim.x) kd[i] = (i < r1) ? fabs(__dsub_rn(kd[i], median)) : inf;
   }
-  block_sort_keys(kd, NP);
+  block_merge_keys(kd, NP);
   if (threadIdx.x == 0) {
     out_stats[(uint64_t)j * 4 + 0] = s_stats[0];
     out_stats[(uint64_t)j * 4 + 1] = s_stats[1];
