@@ -18,25 +18,10 @@
 #include <vector>
 
 #include "common.h"
+#include "space_ops.h"
 #include "wave_sort.h"
 
 namespace kpop {
-
-// ---------------------------------------------------------------------------
-// unscaled component and scale (lib/Space.ml:150-165)
-// ---------------------------------------------------------------------------
-template <int KIND>
-__device__ __forceinline__ double component(double diff, double m, double p) {
-  if (KIND == KPOP_MINKOWSKI) return __dmul_rn(pow(fabs(diff), p), m);
-  return __dmul_rn(__dmul_rn(diff, diff), m);
-}
-
-template <int KIND>
-__device__ __forceinline__ double scale_distance(double x, double p) {
-  if (KIND == KPOP_EUCLIDEAN) return sqrt(x);
-  if (KIND == KPOP_COSINE) return x / 2.0;
-  return pow(x, 1.0 / p);
-}
 
 // ---------------------------------------------------------------------------
 // norms + pre-normalised rows.  One thread per row walks the dimensions in
@@ -110,7 +95,8 @@ __global__ __launch_bounds__(256) void distance_rowwise_kernel(const double *__r
                                                                uint32_t n_dims, const double *__restrict__ metric,
                                                                double p, double *__restrict__ out, uint32_t n_cg,
                                                                uint32_t n_rg, uint32_t slab = 0, const double *__restrict__ na = nullptr,
-                                                               const double *__restrict__ nb = nullptr) {
+                                                               const double *__restrict__ nb = nullptr, const uint32_t *__restrict__ gate = nullptr) {
+  if (gate && *gate == 0) return;  // (a fallback that is launched whatever happens and runs only when something failed: summary_large_impl)
   __shared__ __attribute__((aligned(16))) double As[kDC][kMaxW + 2];
   __shared__ __attribute__((aligned(16))) double Bs[kDC][kMaxTJ + 2];
   __shared__ double s_metric[kDC];
@@ -772,14 +758,15 @@ __global__ void reduce_slabs_kernel(const double *__restrict__ partial, uint64_t
 
 template <int KIND>
 static int rowwise_block(const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims, const double *metric,
-                         double p, double *out, hipStream_t st, const double *na = nullptr, const double *nb = nullptr) {
+                         double p, double *out, hipStream_t st, const double *na = nullptr, const double *nb = nullptr,
+                         const uint32_t *gate = nullptr) {
   // A few rows against a very long first operand (the chunks of the large-reference summary: 256-512 query rows against
   // 10^6): tiles of 32 columns x 256 rows, so the long operand is read from HBM ONCE per 256 rows (tiles of 64 x 32 read it
   // eight times for 256 rows: 4.1 GB moved for 2.56) while the short one stays in L2.
   if (r1 >= 65536 && r2 <= 4096 && !(ctx().tune_dbg & 8192)) {
     const uint32_t w = 32, n_cg = 8, n_rg = 32, TJ = 8 * n_rg;
     distance_rowwise_kernel<KIND, false, 8><<<dim3(div_up(r1, w), div_up(r2, TJ)), dim3(256), 0, st>>>(a, w, r1, b, r2, n_dims, metric, p, out, n_cg,
-                                                                                                       n_rg, 0, na, nb);
+                                                                                                       n_rg, 0, na, nb, gate);
     KPOP_LAUNCH_CHECK();
     return 0;
   }
@@ -798,10 +785,10 @@ static int rowwise_block(const double *a, uint32_t r1, const double *b, uint32_t
     const uint32_t nr = std::min(rows_per_launch, r2 - j0);
     if (tall)
       distance_rowwise_kernel<KIND, false, 8><<<dim3(div_up(r1, w), div_up(nr, TJ)), dim3(256), 0, st>>>(
-          a, w, r1, b + (uint64_t)j0 * n_dims, nr, n_dims, metric, p, out + (uint64_t)j0 * r1, n_cg, n_rg, 0, na, nb ? nb + j0 : nullptr);
+          a, w, r1, b + (uint64_t)j0 * n_dims, nr, n_dims, metric, p, out + (uint64_t)j0 * r1, n_cg, n_rg, 0, na, nb ? nb + j0 : nullptr, gate);
     else
       distance_rowwise_kernel<KIND><<<dim3(div_up(r1, w), div_up(nr, TJ)), dim3(256), 0, st>>>(
-          a, w, r1, b + (uint64_t)j0 * n_dims, nr, n_dims, metric, p, out + (uint64_t)j0 * r1, n_cg, n_rg, 0, na, nb ? nb + j0 : nullptr);
+          a, w, r1, b + (uint64_t)j0 * n_dims, nr, n_dims, metric, p, out + (uint64_t)j0 * r1, n_cg, n_rg, 0, na, nb ? nb + j0 : nullptr, gate);
     KPOP_LAUNCH_CHECK();
   }
   return 0;
@@ -872,6 +859,17 @@ int launch_summary_large(const double *rows, uint32_t n_rows, uint32_t r1, uint3
                          uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
                          double *out_dist, double *out_z, hipStream_t st, void *scratch);
 uint64_t summary_large_scratch_bytes(uint32_t n_rows, uint32_t r1);
+bool summary_fused_applies(uint32_t r1, uint32_t keep_at_most);
+uint32_t summary_fused_sample_rows(uint32_t r1);
+uint64_t summary_fused_scratch_bytes(uint32_t n_rows, uint32_t r1);
+int launch_sample_gather(const double *a, uint32_t r1, uint32_t n_dims, uint32_t s, double *out, hipStream_t st);
+int launch_summary_fused(int kind, const double *a, uint32_t r1, const double *b, uint32_t n_rows, uint32_t n_dims, const double *metric, double p,
+                         const double *srow, uint32_t s, uint32_t row0, uint32_t keep_at_most, uint32_t max_neighbours, double *out_stats,
+                         uint32_t *out_n, uint32_t *out_idx, double *out_dist, double *out_z, double *seg, void *scratch, hipStream_t st,
+                         const uint32_t **gate);
+int launch_summary_failed_rows(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most, uint32_t max_neighbours,
+                               double *out_stats, uint32_t *out_n, uint32_t *out_idx, double *out_dist, double *out_z, void *scratch,
+                               hipStream_t st);
 
 // r1 > kSummaryMaxR1: query rows in chunks, distance rows of a chunk in the library workspace
 template <int KIND>
@@ -881,9 +879,40 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
                               uint32_t *out_idx, double *out_dist, double *out_z, hipStream_t st) {
   const double *a, *b;
   KPOP_TRY(prepare_operands<KIND>(m1, r1, m2, r2, n_dims, metric, p, normalize, work, &a, &b, st));
+  const uint64_t budget = 4096ull << 20;
+  if (summary_fused_applies(r1, keep_at_most)) {
+    // 131,072 reference rows and more: no distance rows at all (summary_large.hip, "second step").  The workspace holds, per
+    // chunk of query rows, the candidates' segments (the same room distance rows would take, mostly untouched), the sample of
+    // the first operand and the distances to it, and the lists.
+    const uint32_t s = summary_fused_sample_rows(r1);
+    const uint64_t fixed = (((uint64_t)s * n_dims * 8 + 255) & ~255ull) + (1u << 20);
+    uint32_t chunk = r2;
+    while (chunk > 1 && fixed + (uint64_t)chunk * ((uint64_t)r1 + s) * 8 + summary_fused_scratch_bytes(chunk, r1) > budget) chunk = chunk > 256 ? (chunk - 1) / 256 * 256 : chunk / 2;
+    const uint64_t bytes_seg = ((uint64_t)chunk * r1 * 8 + 255) & ~255ull, bytes_as = ((uint64_t)s * n_dims * 8 + 255) & ~255ull,
+                   bytes_srow = ((uint64_t)chunk * s * 8 + 255) & ~255ull;
+    void *ws = nullptr;
+    KPOP_TRY(ctx().ws_for(st).ensure(bytes_seg + bytes_as + bytes_srow + summary_fused_scratch_bytes(chunk, r1), &ws));
+    char *wp = reinterpret_cast<char *>(ws);
+    double *seg = reinterpret_cast<double *>(wp), *a_s = reinterpret_cast<double *>(wp + bytes_seg),
+           *srow = reinterpret_cast<double *>(wp + bytes_seg + bytes_as);
+    void *scratch = wp + bytes_seg + bytes_as + bytes_srow;
+    KPOP_TRY(launch_sample_gather(a, r1, n_dims, s, a_s, st));
+    for (uint32_t q0 = 0; q0 < r2; q0 += chunk) {
+      const uint32_t q = std::min(chunk, r2 - q0);
+      const double *bq = b + (uint64_t)q0 * n_dims;
+      KPOP_TRY(rowwise_block<KIND>(a_s, s, bq, q, n_dims, metric, p, srow, st));
+      const uint32_t *gate = nullptr;
+      KPOP_TRY(launch_summary_fused(KIND, a, r1, bq, q, n_dims, metric, p, srow, s, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx,
+                                    out_dist, out_z, seg, scratch, st, &gate));
+      // the rows it flagged (a bracket that missed, a list that overflowed): their distance rows into the segments' room and the
+      // one-block-per-row kernel over them -- both launched whatever happened, both return at once when nothing was flagged
+      KPOP_TRY(rowwise_block<KIND>(a, r1, bq, q, n_dims, metric, p, seg, st, nullptr, nullptr, gate));
+      KPOP_TRY(launch_summary_failed_rows(seg, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, scratch, st));
+    }
+    return 0;
+  }
   // distance rows of a chunk of queries live in the library workspace: enough of them (one 1024-thread block each) to
   // put two blocks on every CU when the first operand is large
-  const uint64_t budget = 4096ull << 20;
   const uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(r2, budget / ((uint64_t)r1 * 8)));
   void *ws = nullptr;
   const uint64_t row_bytes = ((uint64_t)chunk * r1 * 8 + 255) & ~255ull;

@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "space_ops.h"
 
 namespace kpop {
 
@@ -90,6 +91,7 @@ __device__ __forceinline__ uint64_t elem_key(const Row &row, uint32_t i, double 
 // ---------------------------------------------------------------------------
 constexpr uint32_t kBins = 2048, kCand = 2048;
 constexpr int kSel = 2;
+static_assert(kBins == 2 * kLT, "block_select_ranks: a thread owns two bins");
 
 struct Sel {          // one selection in progress / done
   uint32_t rank;      // wanted 0-based rank
@@ -122,30 +124,61 @@ __device__ void block_select_ranks(const Row row, uint32_t n, double centre, Sel
     int shift[kSel];
     for (int t = 0; t < n_sel; ++t) shift[t] = range_shift(sel[t].lo, sel[t].hi);
     double sq = 0.0;
-    for (uint32_t i = threadIdx.x; i < n; i += kLT) {
-      const uint64_t k = elem_key<TRANSFORM>(row, i, centre);
-      if (SUMSQ && round == 0) {
-        const double dv = __dsub_rn(row[i], centre);
-        sq = __dadd_rn(sq, __dmul_rn(dv, dv));
+    for (uint32_t i0 = threadIdx.x; i0 < n; i0 += kLT * 4) {  // four loads in flight a thread
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = i0 + u * kLT < n ? row[i0 + u * kLT] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i0 + u * kLT >= n) continue;
+        const uint64_t k = f64_key(TRANSFORM ? fabs(__dsub_rn(v[u], centre)) : v[u]);
+        if (SUMSQ && round == 0) {
+          const double dv = __dsub_rn(v[u], centre);
+          sq = __dadd_rn(sq, __dmul_rn(dv, dv));
+        }
+        for (int t = 0; t < n_sel; ++t)
+          if (!sel[t].done && k >= sel[t].lo && k <= sel[t].hi) atomicAdd(&s_hist[t * kBins + (uint32_t)((k - sel[t].lo) >> shift[t])], 1u);
       }
-      for (int t = 0; t < n_sel; ++t)
-        if (!sel[t].done && k >= sel[t].lo && k <= sel[t].hi) atomicAdd(&s_hist[t * kBins + (uint32_t)((k - sel[t].lo) >> shift[t])], 1u);
     }
     if (SUMSQ && round == 0) *sumsq_part = sq;
     __syncthreads();
-    // the bin of each rank (one thread per selection walks 2048 counters)
-    if (threadIdx.x < (uint32_t)n_sel && !sel[threadIdx.x].done) {
-      const int t = threadIdx.x;
-      uint32_t cum = sel[t].below, bin = 0;
-      for (; bin < kBins; ++bin) {
-        const uint32_t c = s_hist[t * kBins + bin];
-        if (cum + c > sel[t].rank) break;
-        cum += c;
+    // the bin of each rank: every thread owns two neighbouring bins, a scan over the block gives the keys below them (one
+    // thread walking the 2,048 counters -- a chain of dependent LDS reads, ~0.1 ms -- was most of a selection's time)
+    for (int t = 0; t < n_sel; ++t) {
+      if (sel[t].done) continue;  // (uniform)
+      const uint32_t c0 = s_hist[t * kBins + 2 * threadIdx.x], c1 = s_hist[t * kBins + 2 * threadIdx.x + 1];
+      uint32_t incl = c0 + c1;
+      const int lane_ = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane_ >= o) incl += up;
       }
-      if (bin == kBins) bin = kBins - 1;  // only reachable with NaNs in the row
-      s_misc[t * 4 + 0] = bin;
-      s_misc[t * 4 + 1] = cum;
-      s_misc[t * 4 + 2] = s_hist[t * kBins + bin];
+      if (lane_ == 63) s_misc[16 + wv_] = incl;
+      if (threadIdx.x == 0) s_misc[t * 4 + 0] = 0xFFFFFFFFu;
+      __syncthreads();
+      uint32_t before = sel[t].below, total = sel[t].below;
+      for (int w = 0; w < kLT / 64; ++w) {
+        if (w < wv_) before += s_misc[16 + w];
+        total += s_misc[16 + w];
+      }
+      before += incl - (c0 + c1);  // keys below this thread's first bin
+      const uint32_t rank = sel[t].rank;
+      if (before <= rank && rank < before + c0) {
+        s_misc[t * 4 + 0] = 2 * threadIdx.x;
+        s_misc[t * 4 + 1] = before;
+        s_misc[t * 4 + 2] = c0;
+      } else if (before + c0 <= rank && rank < before + c0 + c1) {
+        s_misc[t * 4 + 0] = 2 * threadIdx.x + 1;
+        s_misc[t * 4 + 1] = before + c0;
+        s_misc[t * 4 + 2] = c1;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0 && s_misc[t * 4 + 0] == 0xFFFFFFFFu) {  // the rank lies beyond the keys in range: only reachable with NaNs in the row
+        s_misc[t * 4 + 0] = kBins - 1;
+        s_misc[t * 4 + 1] = total;
+        s_misc[t * 4 + 2] = s_hist[t * kBins + kBins - 1];
+      }
     }
     __syncthreads();
     bool collect[kSel];
@@ -180,13 +213,20 @@ __device__ void block_select_ranks(const Row row, uint32_t n, double centre, Sel
       __syncthreads();
       if (threadIdx.x < (uint32_t)n_sel) s_misc[32 + threadIdx.x] = 0;
       __syncthreads();
-      for (uint32_t i = threadIdx.x; i < n; i += kLT) {
-        const uint64_t k = elem_key<TRANSFORM>(row, i, centre);
-        for (int t = 0; t < n_sel; ++t)
-          if (collect[t] && k >= sel[t].lo && k <= sel[t].hi) {
-            const uint32_t at = atomicAdd(&s_misc[32 + t], 1u);
-            if (at < kCand) s_cand[t * kCand + at] = k;
-          }
+      for (uint32_t i0 = threadIdx.x; i0 < n; i0 += kLT * 4) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = i0 + u * kLT < n ? row[i0 + u * kLT] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (i0 + u * kLT >= n) continue;
+          const uint64_t k = f64_key(TRANSFORM ? fabs(__dsub_rn(v[u], centre)) : v[u]);
+          for (int t = 0; t < n_sel; ++t)
+            if (collect[t] && k >= sel[t].lo && k <= sel[t].hi) {
+              const uint32_t at = atomicAdd(&s_misc[32 + t], 1u);
+              if (at < kCand) s_cand[t * kCand + at] = k;
+            }
+        }
       }
       __syncthreads();
       for (int t = 0; t < n_sel; ++t) {
@@ -637,6 +677,88 @@ __device__ bool pick_from_bracket(uint32_t r, uint32_t lt, uint32_t eqlo, uint32
   return false;
 }
 
+// the neighbours of a row from its list of every element with key <= kcut (the n_nb smallest): eff_len (lib/Matrix.ml:648-649),
+// the first min(eff_len, max_neighbours, 2,048) by (distance, column) and their z-scores written out.  false: the list
+// overflowed, is shorter than what is asked for, or ends in a tie group too large to sort here.
+__device__ bool neighbours_from_list(uint32_t n, uint32_t req_len, uint32_t max_neighbours, uint32_t n_nb, const uint32_t *my_idx,
+                                     const double *my_d, uint64_t kcut, double mean, double sd, uint32_t j, uint32_t *__restrict__ out_idx,
+                                     double *__restrict__ out_dist, double *__restrict__ out_z, uint32_t *s_hist, uint64_t *s_cand,
+                                     uint32_t *s_misc, double *s_cd, uint32_t *s_ci, uint32_t *s_take, uint32_t *eff_out) {
+  // ---- the neighbours: the list holds every element with key <= kcut, i.e. the n_nb smallest
+  uint32_t eff = n;
+  bool ok = true;
+  if (n_nb > kNbCap || (n_nb < n && req_len > n_nb) || (n_nb == n && n > kNbCap)) ok = false;
+  if (ok) {
+    uint32_t M;
+    uint64_t vkey = ~0ull;
+    const uint64_t k_top = kcut == ~0ull ? f64_key(__longlong_as_double(0x7FEFFFFFFFFFFFFFll)) : kcut;
+    if (req_len < n) {  // (always, here: the two-pass path is taken for keep_at_most <= 2,048 and rows of 65,536 and more)
+      Sel sc[1] = {Sel{req_len - 1, 0ull, k_top, 0, 0, 0, 0, 0}};  // (from key 0: a caller's matrix may hold negative entries)
+      block_select_ranks<0>(PlainRow{my_d}, n_nb, 0.0, sc, 1, s_hist, s_cand, s_misc);
+      eff = sc[0].n_less + sc[0].n_equal;
+      vkey = sc[0].value;
+    }
+    M = min(min(eff, max_neighbours), kLargeMaxNb);
+    if (M && M < eff) {  // the list is cut short by the caller's stride: its last value is the element of rank M - 1
+      Sel s3[1] = {Sel{M - 1, 0ull, k_top, 0, 0, 0, 0, 0}};
+      block_select_ranks<0>(PlainRow{my_d}, n_nb, 0.0, s3, 1, s_hist, s_cand, s_misc);
+      vkey = s3[0].value;
+    }
+    if (M) {
+      // gather the elements closer than the last value, and those AT it; sort by (distance, column); the first M
+      __syncthreads();
+      if (threadIdx.x == 0) (*s_take) = 0;
+      __syncthreads();
+      for (uint32_t q = threadIdx.x; q < n_nb; q += kLT) {
+        const uint64_t k = f64_key(my_d[q]);
+        if (k <= vkey) {
+          const uint32_t at = atomicAdd(&(*s_take), 1u);
+          if (at < kNbSort) {
+            s_cd[at] = my_d[q];
+            s_ci[at] = my_idx[q];
+          }
+        }
+      }
+      __syncthreads();
+      const uint32_t got = (*s_take);
+      if (got > kNbSort || got < M) ok = false;  // (a tie group too large to sort here)
+      else {
+        uint32_t NP = 1;
+        while (NP < got) NP <<= 1;
+        for (uint32_t q = got + threadIdx.x; q < NP; q += kLT) {
+          s_cd[q] = __longlong_as_double(0x7FF0000000000000ll);
+          s_ci[q] = 0xFFFFFFFFu;
+        }
+        for (uint32_t sz = 2; sz <= NP; sz <<= 1)
+          for (uint32_t t = sz >> 1; t > 0; t >>= 1) {
+            __syncthreads();
+            for (uint32_t q = threadIdx.x; q < NP / 2; q += kLT) {
+              const uint32_t a = 2 * q - (q & (t - 1)), b = a + t;
+              const bool asc = (a & sz) == 0;
+              const double da = s_cd[a], db = s_cd[b];
+              const uint32_t ia = s_ci[a], ib = s_ci[b];
+              const bool gt = (db < da) || (db == da && ib < ia);
+              if (gt == asc) {
+                s_cd[a] = db; s_cd[b] = da;
+                s_ci[a] = ib; s_ci[b] = ia;
+              }
+            }
+          }
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < M; q += kLT) {
+          out_idx[(uint64_t)j * max_neighbours + q] = s_ci[q];
+          out_dist[(uint64_t)j * max_neighbours + q] = s_cd[q];
+          double zz = __dsub_rn(s_cd[q], mean) / sd;
+          if (zz != zz) zz = __longlong_as_double((long long)0xFFF8000000000000ull);  // x86 invalid-operation NaN, see distance.hip
+          out_z[(uint64_t)j * max_neighbours + q] = zz;
+        }
+      }
+    }
+  }
+  *eff_out = eff;
+  return ok;
+}
+
 // finish 1 (STAGE = 1): mean, sd, median, neighbours, the MAD's bracket; finish 2 (STAGE = 2): the MAD and the row of statistics
 template <int STAGE>
 __global__ __launch_bounds__(kLT) void summary2_finish_kernel(const double *__restrict__ rows, uint32_t r1, uint32_t row0, uint32_t req_len,
@@ -684,78 +806,10 @@ __global__ __launch_bounds__(kLT) void summary2_finish_kernel(const double *__re
   double median = 0.0;
   bool ok = pick_from_bracket(n / 2, C.lt_lo, C.eq_lo, C.n_cand, C.eq_hi, I.klo, I.khi, my_cand, kCandCap, s_hist, s_cand, s_misc, &median);
   // ---- the neighbours: the list holds every element with key <= kcut, i.e. the n_nb smallest
-  const uint32_t n_nb = C.n_nb;
-  const uint32_t *my_idx = nb_idx + (uint64_t)jl * kNbCap;
-  const double *my_d = nb_d + (uint64_t)jl * kNbCap;
   uint32_t eff = n;
-  if (n_nb > kNbCap || (n_nb < n && req_len > n_nb) || (n_nb == n && n > kNbCap)) ok = false;
-  if (ok) {
-    uint32_t M;
-    uint64_t vkey = ~0ull;
-    const uint64_t k_top = I.kcut == ~0ull ? f64_key(__longlong_as_double(0x7FEFFFFFFFFFFFFFll)) : I.kcut;
-    if (req_len < n) {  // (always, here: the two-pass path is taken for keep_at_most <= 2,048 and rows of 65,536 and more)
-      Sel sc[1] = {Sel{req_len - 1, 0ull, k_top, 0, 0, 0, 0, 0}};  // (from key 0: a caller's matrix may hold negative entries)
-      block_select_ranks<0>(PlainRow{my_d}, n_nb, 0.0, sc, 1, s_hist, s_cand, s_misc);
-      eff = sc[0].n_less + sc[0].n_equal;
-      vkey = sc[0].value;
-    }
-    M = min(min(eff, max_neighbours), kLargeMaxNb);
-    if (M && M < eff) {  // the list is cut short by the caller's stride: its last value is the element of rank M - 1
-      Sel s3[1] = {Sel{M - 1, 0ull, k_top, 0, 0, 0, 0, 0}};
-      block_select_ranks<0>(PlainRow{my_d}, n_nb, 0.0, s3, 1, s_hist, s_cand, s_misc);
-      vkey = s3[0].value;
-    }
-    if (M) {
-      // gather the elements closer than the last value, and those AT it; sort by (distance, column); the first M
-      __syncthreads();
-      if (threadIdx.x == 0) s_take = 0;
-      __syncthreads();
-      for (uint32_t q = threadIdx.x; q < n_nb; q += kLT) {
-        const uint64_t k = f64_key(my_d[q]);
-        if (k <= vkey) {
-          const uint32_t at = atomicAdd(&s_take, 1u);
-          if (at < kNbSort) {
-            s_cd[at] = my_d[q];
-            s_ci[at] = my_idx[q];
-          }
-        }
-      }
-      __syncthreads();
-      const uint32_t got = s_take;
-      if (got > kNbSort || got < M) ok = false;  // (a tie group too large to sort here)
-      else {
-        uint32_t NP = 1;
-        while (NP < got) NP <<= 1;
-        for (uint32_t q = got + threadIdx.x; q < NP; q += kLT) {
-          s_cd[q] = __longlong_as_double(0x7FF0000000000000ll);
-          s_ci[q] = 0xFFFFFFFFu;
-        }
-        for (uint32_t sz = 2; sz <= NP; sz <<= 1)
-          for (uint32_t t = sz >> 1; t > 0; t >>= 1) {
-            __syncthreads();
-            for (uint32_t q = threadIdx.x; q < NP / 2; q += kLT) {
-              const uint32_t a = 2 * q - (q & (t - 1)), b = a + t;
-              const bool asc = (a & sz) == 0;
-              const double da = s_cd[a], db = s_cd[b];
-              const uint32_t ia = s_ci[a], ib = s_ci[b];
-              const bool gt = (db < da) || (db == da && ib < ia);
-              if (gt == asc) {
-                s_cd[a] = db; s_cd[b] = da;
-                s_ci[a] = ib; s_ci[b] = ia;
-              }
-            }
-          }
-        __syncthreads();
-        for (uint32_t q = threadIdx.x; q < M; q += kLT) {
-          out_idx[(uint64_t)j * max_neighbours + q] = s_ci[q];
-          out_dist[(uint64_t)j * max_neighbours + q] = s_cd[q];
-          double zz = __dsub_rn(s_cd[q], mean) / sd;
-          if (zz != zz) zz = __longlong_as_double((long long)0xFFF8000000000000ull);  // x86 invalid-operation NaN, see distance.hip
-          out_z[(uint64_t)j * max_neighbours + q] = zz;
-        }
-      }
-    }
-  }
+  if (ok)
+    ok = neighbours_from_list(n, req_len, max_neighbours, C.n_nb, nb_idx + (uint64_t)jl * kNbCap, nb_d + (uint64_t)jl * kNbCap, I.kcut, mean, sd, j,
+                              out_idx, out_dist, out_z, s_hist, s_cand, s_misc, s_cd, s_ci, &s_take, &eff);
   // ---- the bracket of the MAD: the sample's |d - median| at the ranks around the middle
   uint64_t mlo = 0, mhi = ~0ull;
   if (ok) {
@@ -827,6 +881,567 @@ int launch_summary_large(const double *rows, uint32_t n_rows, uint32_t r1, uint3
                                                                 cap, out_stats, out_n, out_idx, out_dist, out_z);
   KPOP_LAUNCH_CHECK();
   summary_large_kernel<<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, cnt);
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// ===========================================================================
+// Round 3, second step: the summary of q query rows against r1 >= 131,072 reference rows WITHOUT the q x r1 distances in HBM.
+//
+// The two-pass path above still has the tiled distance kernel write every row (2 GB for 256 x 10^6) and reads it twice.
+// Here the brackets come first, from the distances to a SAMPLE of the reference rows (65,536 rows at even spacing, gathered
+// and run through the tiled kernel: 6 % of the work), and then ONE kernel computes every distance -- the same sequential chain
+// per pair as distance_rowwise_kernel, so the same bits -- and decides on the spot what to keep of it:
+//   - counted: below / at the ends of the median's bracket, strictly inside it; strictly inside the INNER region of the MAD;
+//   - added up: d and (d - m^)^2 (per thread and row across the tiles, then in a fixed order);
+//   - kept (8 bytes, in the row's segment of the stripe): the candidates of the median (strictly inside its bracket) and of
+//     the MAD -- the two BANDS either side of the median where |d - median| can reach the MAD's bracket whatever the median
+//     turns out to be inside its own bracket; about 13 % of a row;
+//   - kept with its column: d <= cut, the neighbours' list.
+// A block owns 256 query rows x a STRIPE of 2,048 reference rows (64 tiles of 32), so a (row, stripe) segment has one
+// writer and no global counter: its count is written once, at the end.  The finish kernel (one block a row) compacts the
+// segments, finds the exact median among its candidates at the rank the counts leave open, then the exact MAD: with the
+// median known, every element of the inner region has |d - median| <= X_in = max(U_in - median, median - L_in) and every
+// element beyond the bands >= X_out = min(median - L_lo, U_hi - median); the candidate a' of rank n/2 - n_inner among the
+// bands' |d - median| IS the MAD if X_in <= a' <= X_out (checked: a certificate, not an assumption).  Anything that does not
+// hold -- a bracket that missed, a list that overflowed, the certificate -- flags the row, and flagged rows are redone from
+// distance rows computed then (the tiled kernel and summary_large_kernel, both launched always and gated on the flags).
+// ===========================================================================
+constexpr uint32_t kStripe = 2048, kFW = 32, kFQ = 256, kFDC = 16, kMaxStripes = 8192;
+
+struct FusedThr {  // one query row's thresholds, as distances (64 bytes)
+  double lo, hi;            // the median's bracket (-inf / +inf: none)
+  double Llo, Lin, Uin, Uhi;  // lower band [Llo, Lin], inner region (Lin, Uin), upper band [Uin, Uhi]
+  double cut, mhat;
+};
+struct StripeRec {
+  uint32_t lt_eqlo, eqhi_nmed, inner, c_cnt;  // (16 bits each where paired: a stripe has 2,048 elements)
+};
+
+static inline uint32_t fused_cand_cap(uint32_t r1) { return (r1 / 4 + 4095u) & ~4095u; }  // compacted candidates: room for a quarter of a row
+
+// out[i] = a[floor(i r1 / s)]: the sample of the reference rows, at even spacing (a database sorted by class is sampled
+// class by class in proportion)
+__global__ __launch_bounds__(256) void sample_gather_kernel(const double *__restrict__ a, uint32_t r1, uint32_t n_dims, uint32_t s,
+                                                            double *__restrict__ out) {
+  const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= s) return;
+  const uint64_t src = ((uint64_t)i * r1) / s;
+  for (uint32_t c = lane; c < n_dims; c += 64) out[(uint64_t)i * n_dims + c] = a[src * n_dims + c];
+}
+
+// one block per query row over its s sample distances: m^, the brackets, the bands
+__global__ __launch_bounds__(kLT) void fused_sample_kernel(const double *__restrict__ srow, uint32_t s, uint32_t r1, uint32_t req_len,
+                                                           RowInfo *__restrict__ info, RowCounts *__restrict__ cnt, FusedThr *__restrict__ thr) {
+  __shared__ double s_w[kLT / 64];
+  __shared__ uint32_t s_hist[kSel * kBins];
+  __shared__ uint64_t s_cand[kSel * kCand];
+  __shared__ uint32_t s_misc[64];
+  __shared__ uint64_t s_mm[2 * (kLT / 64)];
+  const double *row = srow + (uint64_t)blockIdx.x * s;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const PlainRow sr{row};
+  double part = 0.0;
+  uint64_t kmin = ~0ull, kmax = 0;
+  for (uint32_t i = threadIdx.x; i < s; i += kLT) {
+    const double x = row[i];
+    part = __dadd_rn(part, x);
+    const uint64_t k = f64_key(x);
+    kmin = kmin < k ? kmin : k;
+    kmax = kmax > k ? kmax : k;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint64_t omin = (uint64_t)__shfl_xor((unsigned long long)kmin, o, 64), omax = (uint64_t)__shfl_xor((unsigned long long)kmax, o, 64);
+    kmin = kmin < omin ? kmin : omin;
+    kmax = kmax > omax ? kmax : omax;
+  }
+  if (lane == 0) {
+    s_mm[wv] = kmin;
+    s_mm[kLT / 64 + wv] = kmax;
+  }
+  const double m_hat = s ? block_sum(part, s_w) / (double)s : 0.0;
+  for (int w = 0; w < kLT / 64; ++w) {
+    kmin = kmin < s_mm[w] ? kmin : s_mm[w];
+    kmax = kmax > s_mm[kLT / 64 + w] ? kmax : s_mm[kLT / 64 + w];
+  }
+  uint32_t a, b;
+  bracket_ranks(r1 / 2, r1, s, &a, &b);
+  Sel sel[kSel] = {Sel{a, kmin, kmax, 0, 0, 0, 0, 0}, Sel{b, kmin, kmax, 0, 0, 0, 0, 0}};
+  block_select_ranks<0>(sr, s, 0.0, sel, 2, s_hist, s_cand, s_misc);
+  // the sample's own median, and -- same passes -- the neighbour threshold
+  uint64_t kcut = ~0ull;
+  const double want = 3.0 * (double)req_len * (double)s / (double)r1 + 16.0;
+  const bool cut = want < (double)(s - 1);
+  Sel sm[kSel] = {Sel{s / 2, kmin, kmax, 0, 0, 0, 0, 0}, Sel{cut ? (uint32_t)want : 0u, kmin, kmax, 0, 0, 0, 0, cut ? 0 : 1}};
+  block_select_ranks<0>(sr, s, 0.0, sm, 2, s_hist, s_cand, s_misc);
+  if (cut) kcut = sm[1].value;
+  const double ms = key_f64(sm[0].value);
+  const double far = fmax(fabs(__dsub_rn(key_f64(kmax), ms)), fabs(__dsub_rn(key_f64(kmin), ms)));
+  Sel sa[kSel] = {Sel{a, f64_key(0.0), f64_key(far), 0, 0, 0, 0, 0}, Sel{b, f64_key(0.0), f64_key(far), 0, 0, 0, 0, 0}};
+  block_select_ranks<1>(sr, s, ms, sa, 2, s_hist, s_cand, s_misc);
+  if (threadIdx.x == 0) {
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    const bool no_lo = a == 0, no_hi = b == s - 1;  // rank 0 / the last rank of the sample bound nothing
+    RowInfo &I = info[blockIdx.x];
+    I.m_hat = m_hat;
+    I.klo = no_lo ? 0ull : sel[0].value;
+    I.khi = no_hi ? ~0ull : sel[1].value;
+    I.kcut = kcut;
+    I.sample_n = s;
+    I.sample_stride = 0;
+    RowCounts z = {};
+    cnt[blockIdx.x] = z;
+    FusedThr T;
+    T.lo = no_lo ? -inf : key_f64(sel[0].value);
+    T.hi = no_hi ? inf : key_f64(sel[1].value);
+    T.cut = kcut == ~0ull ? inf : key_f64(kcut);
+    T.mhat = m_hat;
+    if (no_lo || no_hi) {  // no bracket to speak of: everything is a candidate
+      T.Llo = -inf; T.Uhi = inf; T.Lin = inf; T.Uin = -inf;
+    } else {
+      const double alo = key_f64(sa[0].value), ahi = key_f64(sa[1].value);
+      // the median lies within w of the sample's: |d - median| and |d - ms| differ by at most w, and so do their order statistics
+      const double w = fmax(T.hi - ms, ms - T.lo);
+      const double h = alo - w;  // |d - median| < h for every median in its bracket: inside (hi - h, lo + h)
+      if (h > 0.0) { T.Lin = T.hi - h; T.Uin = T.lo + h; } else { T.Lin = inf; T.Uin = -inf; }
+      T.Llo = T.lo - (ahi + w);
+      T.Uhi = T.hi + (ahi + w);
+    }
+    thr[blockIdx.x] = T;
+  }
+}
+
+// distances of 256 query rows to a stripe of 2,048 reference rows, tile by tile (32 columns x 256 rows; a thread owns 4 x 8,
+// the dimensions 16 at a time through LDS: distance_rowwise_kernel's loop), and what the summary keeps of them
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void summary_fused_pass_kernel(
+    const double *__restrict__ a, uint32_t r1, const double *__restrict__ b, uint32_t q, uint32_t n_dims,
+    const double *__restrict__ metric, double p, const FusedThr *__restrict__ thr, double *__restrict__ seg,
+    StripeRec *__restrict__ rec, double *__restrict__ part, RowCounts *__restrict__ cnt, uint32_t *__restrict__ nb_idx,
+    double *__restrict__ nb_d, uint32_t n_stripes) {
+  __shared__ __attribute__((aligned(16))) double As[kFDC][kFW + 2];
+  __shared__ __attribute__((aligned(16))) double Bs[kFDC][kFQ + 2];
+  __shared__ double s_metric[kFDC];
+  __shared__ FusedThr s_thr[kFQ];
+  __shared__ uint32_t s_ccnt[kFQ];
+  __shared__ double s_sum[kFQ], s_sq[kFQ];   // a row's running sums and counts: owned by the lane of its first column group
+  __shared__ uint32_t s_cnt[kFQ][3];         // (the registers are the distances' -- as in distance_rowwise_kernel, 250 of 256)
+  const uint32_t stripe = blockIdx.x, j0 = blockIdx.y * kFQ;
+  const uint32_t cg = threadIdx.x & 7u, rg = threadIdx.x >> 3;  // 8 column groups x 32 row groups
+  const uint32_t ti = cg * 4, tj = rg * 8;
+  const uint32_t sc = threadIdx.x & 15u, rbase = threadIdx.x >> 4;  // staging: 16 dimensions x 16 rows a sweep
+  for (uint32_t e = threadIdx.x; e < kFQ; e += 256) {
+    s_thr[e] = thr[min(j0 + e, q - 1)];
+    s_ccnt[e] = 0;
+    s_sum[e] = 0.0;
+    s_sq[e] = 0.0;
+    s_cnt[e][0] = s_cnt[e][1] = s_cnt[e][2] = 0;
+  }
+  const uint32_t ref0 = stripe * kStripe, ref1 = min(r1, ref0 + kStripe);
+  const uint32_t n_tiles = (ref1 - ref0 + kFW - 1) / kFW, n_chunks = (n_dims + kFDC - 1) / kFDC;
+  double ra[2], rb[16];
+  auto prefetch_a = [&](uint32_t tile, uint32_t c0) {  // the reference rows: from HBM
+    const uint32_t i0 = ref0 + tile * kFW;
+    const bool cok = c0 + sc < n_dims;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t row = rbase + u * 16;
+      ra[u] = (cok && i0 + row < ref1) ? a[(uint64_t)(i0 + row) * n_dims + c0 + sc] : 0.0;
+    }
+  };
+  auto prefetch_b = [&](uint32_t c0) {  // the query rows: the same 256 for every tile, from L2
+    const bool cok = c0 + sc < n_dims;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const uint32_t row = rbase + u * 16;
+      rb[u] = (cok && j0 + row < q) ? b[(uint64_t)(j0 + row) * n_dims + c0 + sc] : 0.0;
+    }
+  };
+  prefetch_a(0, 0);
+  for (uint32_t tile = 0; tile < n_tiles; ++tile) {
+    double acc[8][4];
+#pragma unroll
+    for (int y = 0; y < 8; ++y)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) acc[y][x] = 0.0;
+    prefetch_b(0);  // (after the epilogue: its sixteen registers a lane are the epilogue's until then)
+    for (uint32_t ch = 0; ch < n_chunks; ++ch) {
+      const uint32_t c0 = ch * kFDC;
+      __syncthreads();  // the previous chunk's readers are done
+#pragma unroll
+      for (int u = 0; u < 2; ++u) As[sc][rbase + u * 16] = ra[u];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) Bs[sc][rbase + u * 16] = rb[u];
+      if (threadIdx.x < kFDC) s_metric[threadIdx.x] = (c0 + threadIdx.x < n_dims) ? metric[c0 + threadIdx.x] : 0.0;
+      __syncthreads();
+      if (ch + 1 < n_chunks) {
+        prefetch_a(tile, c0 + kFDC);
+        prefetch_b(c0 + kFDC);
+      } else if (tile + 1 < n_tiles) prefetch_a(tile + 1, 0);  // (lands under this chunk's arithmetic and the epilogue)
+      const uint32_t lim = min((uint32_t)kFDC, n_dims - c0);
+      for (uint32_t cc = 0; cc < lim; ++cc) {
+        double av[4], bv[8];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) av[x] = As[cc][ti + x];
+#pragma unroll
+        for (int y = 0; y < 8; ++y) bv[y] = Bs[cc][tj + y];
+        const double mc = s_metric[cc];
+#pragma unroll
+        for (int y = 0; y < 8; ++y)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const double diff = __dsub_rn(av[x], bv[y]);  // lib/Space.ml:192-200, as distance_rowwise_kernel
+            acc[y][x] = __dadd_rn(acc[y][x], component<KIND>(diff, mc, p));
+          }
+      }
+    }
+    // ---- what the summary keeps of the tile
+    const uint32_t i0 = ref0 + tile * kFW;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+      const uint32_t rl = tj + y, j = j0 + rl;
+      const FusedThr T = s_thr[rl];
+      double sum = 0.0, sq = 0.0;
+      uint32_t pk = 0;  // lt | eqlo << 6 | eqhi << 12 | nmed << 18 | inner << 24: at most 4 each here, 32 over the row's eight lanes
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const uint32_t i = i0 + ti + x;
+        if (i >= ref1 || j >= q) continue;
+        const double d = scale_distance<KIND>(acc[y][x], p);
+        const bool medc = d > T.lo && d < T.hi;
+        const bool in = d > T.Lin && d < T.Uin;
+        pk += (d < T.lo ? 1u : 0u) + (d == T.lo ? 1u << 6 : 0u) + ((d == T.hi && T.hi != T.lo) ? 1u << 12 : 0u) + (medc ? 1u << 18 : 0u) +
+              (in ? 1u << 24 : 0u);
+        sum = __dadd_rn(sum, d);
+        const double dv = __dsub_rn(d, T.mhat);
+        sq = __dadd_rn(sq, __dmul_rn(dv, dv));
+        if (medc || (!in && d >= T.Llo && d <= T.Uhi)) {
+          const uint32_t slot = atomicAdd(&s_ccnt[rl], 1u);
+          seg[(uint64_t)j * r1 + ref0 + slot] = d;  // (at most as many as the stripe has columns)
+        }
+        if (d <= T.cut) {
+          const uint32_t at = atomicAdd(&cnt[j].n_nb, 1u);
+          if (at < kNbCap) {
+            nb_idx[(uint64_t)j * kNbCap + at] = i;
+            nb_d[(uint64_t)j * kNbCap + at] = d;
+          }
+        }
+      }
+      // the row's eight column groups sit in eight neighbouring lanes: added up in a fixed order, kept by the first
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        sum = __dadd_rn(sum, __shfl_xor(sum, o, 64));
+        sq = __dadd_rn(sq, __shfl_xor(sq, o, 64));
+        pk += (uint32_t)__shfl_xor((int)pk, o, 64);
+      }
+      if (cg == 0) {
+        s_sum[rl] = __dadd_rn(s_sum[rl], sum);
+        s_sq[rl] = __dadd_rn(s_sq[rl], sq);
+        s_cnt[rl][0] += (pk & 63u) | (((pk >> 6) & 63u) << 16);
+        s_cnt[rl][1] += ((pk >> 12) & 63u) | (((pk >> 18) & 63u) << 16);
+        s_cnt[rl][2] += pk >> 24;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const uint32_t rl = threadIdx.x, j = j0 + rl;
+    if (j < q) {
+      const uint64_t at = (uint64_t)j * n_stripes + stripe;
+      rec[at] = StripeRec{s_cnt[rl][0], s_cnt[rl][1], s_cnt[rl][2], s_ccnt[rl]};
+      part[at * 2 + 0] = s_sum[rl];
+      part[at * 2 + 1] = s_sq[rl];
+    }
+  }
+}
+
+struct BandRow {  // the candidates of the MAD among a row's compacted list: NaN for the others (its key is beyond every range)
+  const double *p;
+  double Llo, Lin, Uin, Uhi;
+  __device__ __forceinline__ double operator[](uint32_t i) const {
+    const double d = p[i];
+    const bool in = d > Lin && d < Uin;
+    return (!in && d >= Llo && d <= Uhi) ? d : __longlong_as_double(0x7FF8000000000000ll);
+  }
+};
+
+__global__ __launch_bounds__(kLT) void fused_finish_kernel(const double *__restrict__ seg, uint32_t r1, uint32_t row0, uint32_t req_len,
+                                                           uint32_t max_neighbours, const RowInfo *__restrict__ info,
+                                                           const FusedThr *__restrict__ thr, RowCounts *__restrict__ cnt,
+                                                           const StripeRec *__restrict__ rec, const double *__restrict__ part,
+                                                           uint32_t n_stripes, uint32_t *__restrict__ pre, double *__restrict__ ccand, uint32_t cap,
+                                                           const uint32_t *__restrict__ nb_idx, const double *__restrict__ nb_d,
+                                                           uint32_t *__restrict__ n_failed, double *__restrict__ out_stats,
+                                                           uint32_t *__restrict__ out_n, uint32_t *__restrict__ out_idx,
+                                                           double *__restrict__ out_dist, double *__restrict__ out_z) {
+  __shared__ uint32_t s_hist[kSel * kBins];
+  __shared__ uint64_t s_cand[kSel * kCand];
+  __shared__ uint32_t s_misc[64];
+  __shared__ double s_cd[kNbSort];
+  __shared__ uint32_t s_ci[kNbSort];
+  __shared__ uint32_t s_take;
+  __shared__ uint32_t s_wu[kLT / 64];
+  __shared__ uint32_t s_tot[8];
+  __shared__ uint64_t s_mm[2 * (kLT / 64)];
+  const uint32_t jl = blockIdx.x, j = row0 + jl, n = r1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const RowInfo I = info[jl];
+  const FusedThr T = thr[jl];
+  const StripeRec *my_rec = rec + (uint64_t)jl * n_stripes;
+  uint32_t *my_pre = pre + (uint64_t)jl * n_stripes;
+  double *my_c = ccand + (uint64_t)jl * cap;
+  if (threadIdx.x < 8) s_tot[threadIdx.x] = 0;
+  __syncthreads();
+  // ---- the stripes' counts: totals, and where each stripe's candidates go in the compacted list
+  uint32_t running = 0;
+  for (uint32_t base = 0; base < n_stripes; base += kLT) {
+    const uint32_t st = base + threadIdx.x;
+    StripeRec R = {0, 0, 0, 0};
+    if (st < n_stripes) R = my_rec[st];
+    // exclusive scan of c_cnt over the block
+    uint32_t incl = R.c_cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    __syncthreads();
+    if (lane == 63) s_wu[wv] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int w = 0; w < kLT / 64; ++w) {
+      if (w < wv) before += s_wu[w];
+      total += s_wu[w];
+    }
+    if (st < n_stripes) {
+      my_pre[st] = running + before + incl - R.c_cnt;
+      atomicAdd(&s_tot[0], R.lt_eqlo & 0xFFFFu);
+      atomicAdd(&s_tot[1], R.lt_eqlo >> 16);
+      atomicAdd(&s_tot[2], R.eqhi_nmed & 0xFFFFu);
+      atomicAdd(&s_tot[3], R.eqhi_nmed >> 16);
+      atomicAdd(&s_tot[4], R.inner);
+    }
+    running += total;
+  }
+  __syncthreads();
+  const uint32_t lt = s_tot[0], eqlo = s_tot[1], eqhi = s_tot[2], nmed = s_tot[3], n_inner = s_tot[4], n_c = running;
+  bool ok = n_c <= cap;
+  // ---- the candidates, compacted (a wave per stripe)
+  if (ok) {
+    for (uint32_t st = wv; st < n_stripes; st += kLT / 64) {
+      const uint32_t c = my_rec[st].c_cnt, at = my_pre[st];
+      const double *src = seg + (uint64_t)jl * r1 + (uint64_t)st * kStripe;
+      for (uint32_t e0 = 0; e0 < c; e0 += 64 * 8) {  // eight loads in flight a lane (a loop of one was latency-bound: 0.24 ms)
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = e0 + u * 64 + lane < c ? src[e0 + u * 64 + lane] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (e0 + u * 64 + lane < c) my_c[at + e0 + u * 64 + lane] = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- mean and sd: the stripes' sums in a fixed order -- runs of eight stripes by a thread each, then the runs' sums in
+  // order by every thread out of LDS (one chain over 512 global loads was a quarter of this kernel)
+  double sum = 0.0, sqh = 0.0;
+  {
+    double *s_ps = s_cd;  // (the neighbours' sort buffer, not yet in use: 2 x 1,024 doubles)
+    const uint32_t n_runs = (n_stripes + 7) / 8;  // <= 1,024
+    if (threadIdx.x < n_runs) {
+      double a0 = 0.0, a1 = 0.0;
+      for (uint32_t st = threadIdx.x * 8; st < min(n_stripes, threadIdx.x * 8 + 8); ++st) {
+        a0 = __dadd_rn(a0, part[((uint64_t)jl * n_stripes + st) * 2 + 0]);
+        a1 = __dadd_rn(a1, part[((uint64_t)jl * n_stripes + st) * 2 + 1]);
+      }
+      s_ps[2 * threadIdx.x] = a0;
+      s_ps[2 * threadIdx.x + 1] = a1;
+    }
+    __syncthreads();
+    for (uint32_t u = 0; u < n_runs; ++u) {
+      sum = __dadd_rn(sum, s_ps[2 * u]);
+      sqh = __dadd_rn(sqh, s_ps[2 * u + 1]);
+    }
+    __syncthreads();
+  }
+  const double mean = sum / (double)n;
+  const double dm = __dsub_rn(mean, I.m_hat);
+  const double ss = fmax(0.0, __dsub_rn(sqh, __dmul_rn((double)n, __dmul_rn(dm, dm))));
+  const double sd = n > 1 ? sqrt(ss / ((double)n - 1.0)) : 0.0;
+  // ---- the median: rank n / 2 among [lt below the bracket | eqlo at its lower end | nmed inside | eqhi at its upper end]
+  double median = 0.0;
+  const uint32_t r = n / 2;
+  if (ok) {
+    if (r < lt) ok = false;
+    else if (r < lt + eqlo) median = key_f64(I.klo);
+    else if (r < lt + eqlo + nmed) {
+      Sel sm[1] = {Sel{r - lt - eqlo, I.klo + 1, I.khi - 1, 0, 0, 0, 0, 0}};  // keys strictly inside the bracket
+      block_select_ranks<0>(PlainRow{my_c}, n_c, 0.0, sm, 1, s_hist, s_cand, s_misc);
+      median = key_f64(sm[0].value);
+    } else if (r < lt + eqlo + nmed + eqhi) median = key_f64(I.khi);
+    else ok = false;
+  }
+  // ---- the neighbours
+  uint32_t eff = n;
+  if (ok)
+    ok = neighbours_from_list(n, req_len, max_neighbours, cnt[jl].n_nb, nb_idx + (uint64_t)jl * kNbCap, nb_d + (uint64_t)jl * kNbCap, I.kcut, mean, sd,
+                              j, out_idx, out_dist, out_z, s_hist, s_cand, s_misc, s_cd, s_ci, &s_take, &eff);
+  // ---- the MAD
+  double mad = 0.0;
+  if (ok) {
+    const BandRow br{my_c, T.Llo, T.Lin, T.Uin, T.Uhi};
+    uint64_t kmin = ~0ull, kmax = 0;
+    uint32_t n_band = 0;
+    for (uint32_t i = threadIdx.x; i < n_c; i += kLT) {
+      const double d = br[i];
+      if (d == d) {
+        const uint64_t k = f64_key(fabs(__dsub_rn(d, median)));
+        kmin = kmin < k ? kmin : k;
+        kmax = kmax > k ? kmax : k;
+        ++n_band;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t omin = (uint64_t)__shfl_xor((unsigned long long)kmin, o, 64), omax = (uint64_t)__shfl_xor((unsigned long long)kmax, o, 64);
+      kmin = kmin < omin ? kmin : omin;
+      kmax = kmax > omax ? kmax : omax;
+      n_band += (uint32_t)__shfl_xor((int)n_band, o, 64);
+    }
+    __syncthreads();
+    if (lane == 0) {
+      s_mm[wv] = kmin;
+      s_mm[kLT / 64 + wv] = kmax;
+      s_wu[wv] = n_band;
+    }
+    __syncthreads();
+    n_band = 0;
+    for (int w = 0; w < kLT / 64; ++w) {
+      kmin = kmin < s_mm[w] ? kmin : s_mm[w];
+      kmax = kmax > s_mm[kLT / 64 + w] ? kmax : s_mm[kLT / 64 + w];
+      n_band += s_wu[w];
+    }
+    if (r < n_inner || r - n_inner >= n_band) ok = false;
+    else {
+      Sel sa[1] = {Sel{r - n_inner, kmin, kmax, 0, 0, 0, 0, 0}};
+      block_select_ranks<1, false, BandRow>(br, n_c, median, sa, 1, s_hist, s_cand, s_misc);
+      mad = key_f64(sa[0].value);
+      // the certificate: everything inside the inner region is at most X_in from the median, everything beyond the bands at
+      // least X_out (the same subtractions, monotone): with X_in <= mad <= X_out the ranks are what was assumed
+      const uint32_t n_outer = n - n_inner - n_band;
+      if (n_inner) {
+        const double x_in = fmax(__dsub_rn(T.Uin, median), __dsub_rn(median, T.Lin));
+        if (!(mad >= x_in)) ok = false;
+      }
+      if (n_outer) {
+        const double x_out = fmin(__dsub_rn(median, T.Llo), __dsub_rn(T.Uhi, median));
+        if (!(mad <= x_out)) ok = false;
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (!ok) {
+      cnt[jl].fail = 1;
+      atomicAdd(n_failed, 1u);
+    } else {
+      out_stats[(uint64_t)j * 4 + 0] = mean;
+      out_stats[(uint64_t)j * 4 + 1] = sd;
+      out_stats[(uint64_t)j * 4 + 2] = median;
+      out_stats[(uint64_t)j * 4 + 3] = mad;
+      out_n[j] = eff;
+    }
+  }
+}
+
+// ---- host side ------------------------------------------------------------
+bool summary_fused_applies(uint32_t r1, uint32_t keep_at_most) {
+  const uint32_t req_len = keep_at_most ? keep_at_most : r1;
+  return ctx().tune_summary2 >= 2 && req_len <= kLargeMaxNb && r1 >= 4 * kSlice && (r1 + kStripe - 1) / kStripe <= kMaxStripes;
+}
+uint32_t summary_fused_sample_rows(uint32_t r1) { return std::min<uint32_t>(kSample, r1); }
+
+struct FusedScratch {
+  RowInfo *info;
+  RowCounts *cnt;
+  FusedThr *thr;
+  StripeRec *rec;
+  double *part;
+  uint32_t *pre;
+  double *nb_d;
+  uint32_t *nb_idx;
+  double *ccand;
+  uint32_t *n_failed;
+};
+static uint64_t carve_fused(void *scratch, uint32_t n_rows, uint32_t r1, FusedScratch *F) {
+  const uint64_t n_stripes = (r1 + kStripe - 1) / kStripe;
+  char *p0 = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(scratch) + 255) & ~(uintptr_t)255), *p = p0;
+  auto take = [&](uint64_t bytes) {
+    char *at = p;
+    p += (bytes + 255) & ~255ull;
+    return at;
+  };
+  F->n_failed = reinterpret_cast<uint32_t *>(take(256));
+  F->info = reinterpret_cast<RowInfo *>(take((uint64_t)n_rows * sizeof(RowInfo)));
+  F->cnt = reinterpret_cast<RowCounts *>(take((uint64_t)n_rows * sizeof(RowCounts)));
+  F->thr = reinterpret_cast<FusedThr *>(take((uint64_t)n_rows * sizeof(FusedThr)));
+  F->rec = reinterpret_cast<StripeRec *>(take((uint64_t)n_rows * n_stripes * sizeof(StripeRec)));
+  F->part = reinterpret_cast<double *>(take((uint64_t)n_rows * n_stripes * 16));
+  F->pre = reinterpret_cast<uint32_t *>(take((uint64_t)n_rows * n_stripes * 4));
+  F->nb_d = reinterpret_cast<double *>(take((uint64_t)n_rows * kNbCap * 8));
+  F->nb_idx = reinterpret_cast<uint32_t *>(take((uint64_t)n_rows * kNbCap * 4));
+  F->ccand = reinterpret_cast<double *>(take((uint64_t)n_rows * fused_cand_cap(r1) * 8));
+  return (uint64_t)(p - p0) + 256;
+}
+uint64_t summary_fused_scratch_bytes(uint32_t n_rows, uint32_t r1) {
+  FusedScratch F;
+  return carve_fused(nullptr, n_rows, r1, &F);
+}
+
+int launch_sample_gather(const double *a, uint32_t r1, uint32_t n_dims, uint32_t s, double *out, hipStream_t st) {
+  sample_gather_kernel<<<dim3((s + 3) / 4), dim3(256), 0, st>>>(a, r1, n_dims, s, out);
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
+
+// a, b: the prepared operands (b: the chunk's n_rows query rows); srow: [n_rows][s] distances to the sample; seg: [n_rows][r1]
+// (segments now, distance rows of the fallback later).  *gate: the device word that counts the rows left to the fallback.
+int launch_summary_fused(int kind, const double *a, uint32_t r1, const double *b, uint32_t n_rows, uint32_t n_dims, const double *metric, double p,
+                         const double *srow, uint32_t s, uint32_t row0, uint32_t keep_at_most, uint32_t max_neighbours, double *out_stats,
+                         uint32_t *out_n, uint32_t *out_idx, double *out_dist, double *out_z, double *seg, void *scratch, hipStream_t st,
+                         const uint32_t **gate) {
+  const uint32_t req_len = keep_at_most ? keep_at_most : r1;
+  const uint32_t n_stripes = (r1 + kStripe - 1) / kStripe;
+  FusedScratch F;
+  carve_fused(scratch, n_rows, r1, &F);
+  KPOP_HIP(hipMemsetAsync(F.n_failed, 0, 256, st));
+  fused_sample_kernel<<<dim3(n_rows), dim3(kLT), 0, st>>>(srow, s, r1, req_len, F.info, F.cnt, F.thr);
+  KPOP_LAUNCH_CHECK();
+  const dim3 grid(n_stripes, (n_rows + kFQ - 1) / kFQ);
+#define KPOP_FUSED(K) \
+  summary_fused_pass_kernel<K><<<grid, dim3(256), 0, st>>>(a, r1, b, n_rows, n_dims, metric, p, F.thr, seg, F.rec, F.part, F.cnt, F.nb_idx, F.nb_d, n_stripes)
+  if (kind == KPOP_EUCLIDEAN) KPOP_FUSED(KPOP_EUCLIDEAN);
+  else if (kind == KPOP_COSINE) KPOP_FUSED(KPOP_COSINE);
+  else KPOP_FUSED(KPOP_MINKOWSKI);
+#undef KPOP_FUSED
+  KPOP_LAUNCH_CHECK();
+  fused_finish_kernel<<<dim3(n_rows), dim3(kLT), 0, st>>>(seg, r1, row0, req_len, max_neighbours, F.info, F.thr, F.cnt, F.rec, F.part, n_stripes, F.pre,
+                                                          F.ccand, fused_cand_cap(r1), F.nb_idx, F.nb_d, F.n_failed, out_stats, out_n, out_idx, out_dist,
+                                                          out_z);
+  KPOP_LAUNCH_CHECK();
+  *gate = F.n_failed;
+  return 0;
+}
+
+// the rows the fused path flagged, from distance rows computed meanwhile (gated the same way: nothing runs when none failed)
+int launch_summary_failed_rows(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most, uint32_t max_neighbours,
+                               double *out_stats, uint32_t *out_n, uint32_t *out_idx, double *out_dist, double *out_z, void *scratch,
+                               hipStream_t st) {
+  FusedScratch F;
+  carve_fused(scratch, n_rows, r1, &F);
+  summary_large_kernel<<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, keep_at_most ? keep_at_most : r1, max_neighbours, out_stats, out_n, out_idx,
+                                                           out_dist, out_z, F.cnt);
   KPOP_LAUNCH_CHECK();
   return 0;
 }

@@ -274,6 +274,48 @@ def test_distance_summary_two_pass_on_twisted_rows(kpop, oracle):
             assert idx[j, :m].tolist() == idx_o[a:a + m].tolist() and np.array_equal(dist[j, :m], dist_o[a:a + m])
 
 
+@pytest.mark.parametrize("case", ["random", "classes", "constant", "grid"])
+def test_distance_summary_without_distance_rows(kpop, oracle, case):
+    """kpop_tune("summary2", 2), 131,072 reference rows and more: the distances are computed and reduced in one kernel
+    (summary_fused_pass_kernel), no r2 x r1 rows in HBM.  Exact medians, MADs and neighbour lists against the oracle, and against the two-pass path
+    (kpop_tune("summary2", 1)) bit for bit; a database sorted by class, a constant one (every distance equal: the bands hold
+    everything, the rows are redone from distance rows) and a coarse grid (heavy ties) included"""
+    from kpop_amd import api
+    rng = np.random.RandomState(len(case))
+    d, r1, r2 = 12, 150001, 7
+    if case == "random":
+        m1 = rng.normal(size=(r1, d))
+    elif case == "classes":  # five classes, the database sorted by class: a stripe of 2,048 rows is all one class
+        centres = rng.normal(size=(5, d)) * 3
+        m1 = np.repeat(centres, [r1 // 5] * 4 + [r1 - 4 * (r1 // 5)], axis=0) + rng.normal(size=(r1, d)) * 0.3
+    elif case == "constant":
+        m1 = np.tile(rng.normal(size=(1, d)), (r1, 1))
+    else:
+        m1 = np.round(rng.normal(size=(r1, d)), 0)
+    m2 = rng.normal(size=(r2, d)) if case != "grid" else np.round(rng.normal(size=(r2, d)), 0)
+    m2[1] = m1[5]  # a zero distance
+    m1[77] = m1[5]  # ... twice
+    metric = oracle.metric_powers(oracle.synth_inertia(d))
+    for keep in (1, 300):
+        st_o, offs, idx_o, dist_o, z_o = oracle.distance_summary(m1, m2, metric, 0, 2.0, True, keep)
+        res = {}
+        for mode in (2, 1):
+            api.tune("summary2", mode)
+            res[mode] = kpop.distance_summary(m1, m2, metric, 0, 2.0, True, keep, max_neighbours=512)
+        api.tune("summary2", 1)
+        st, n, idx, dist, z = res[2]
+        np.testing.assert_allclose(st[:, :2], st_o[:, :2], rtol=1e-10, atol=1e-13)
+        assert np.array_equal(st[:, 2:], st_o[:, 2:]), (case, keep, st, st_o)  # median and MAD: order statistics, exact
+        assert np.array_equal(st[:, 2:], res[1][0][:, 2:])
+        for j in range(r2):
+            a, b = int(offs[j]), int(offs[j + 1])
+            assert n[j] == b - a == res[1][1][j]
+            m = min(n[j], 512)
+            assert idx[j, :m].tolist() == idx_o[a:a + m].tolist() and np.array_equal(dist[j, :m], dist_o[a:a + m]), (case, keep, j)
+            if case != "constant":  # (sd = 0 there: the reference's z is 0/0, the tree sums' sd a few ulps of nothing)
+                np.testing.assert_allclose(z[j, :m], z_o[a:a + m], rtol=1e-8, atol=1e-9)
+
+
 def test_large_reference_set_refuses_lists_it_cannot_fill(kpop, oracle):
     """against more than 4,096 rows at most 2,048 neighbours come back per row: a caller that asks for more room than
     that (keep_at_most = all) gets an error, not rows of zeros (KPopTwistDB then exits 1 instead of printing them)"""
