@@ -2,7 +2,7 @@
 on a 131,328 x 1,024 and a 65,664 x 1,636 table (small I: the transfers stay small and the solver shows)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 import kpop_amd
 from kpop_amd import api
 kpop_amd.init(0)

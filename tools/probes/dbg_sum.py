@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'.')
+import sys; sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))); sys.path.insert(0,'.')
 import numpy as np, kpop_amd
 from kpop_amd import api
 from oracle import oracle as O

@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 import torch, kpop_amd
 from kpop_amd import api
 kpop_amd.init(0)
