@@ -88,9 +88,9 @@ int kpop_synchronize(void *stream);
    merged spectrum of kpop_count_reads(per_read = 0) by atomic histogram where the hashes fit 26 bits, or always by sort;
    "histlds" 1 (default) | 0 | 2: that histogram staged through LDS (private tables up to k = 7; sorted chunks of assemblies,
    left off by a block that finds no repetition), direct global atomics as in round 2, or chunks always sorted;
-   "summary2" 1 (default) | 0 | 2: summaries against more than 4,096 rows by brackets from a sample and two passes over the
-   distance rows, by round 2's one block per row, or (131,072 rows and more) with the distances computed and reduced in one
-   kernel and no distance rows in memory -- same results, measured level with 1;
+   "summary2" 1 (default) | 3 | 0 | 2: summaries against more than 4,096 rows by brackets from a sample and ONE pass over the
+   distance rows, the same in two passes, round 2's one block per row, or (131,072 rows and more) with the distances
+   computed and reduced in one kernel and no distance rows in memory -- same results, 1, 3 and 2 level;
    "dense" 0 (default) | 1 | 2: kpop_twist by the sparse mat-vec, by the dense contraction on the f64 matrix cores, or
    by the batch's density (2 also sends kpop_count_twist's batches of assemblies at small k through the dense image of
    their counts, kpop_dev_count_twist_dense, and at k <= 15 with >= 64 sequences tries the union compaction of

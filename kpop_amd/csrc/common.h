@@ -93,7 +93,7 @@ struct Context {
   int tune_dense = 0;    // kpop_twist: 0 sparse mat-vec (the reference's order), 1 dense contraction on the matrix cores, 2 by density
   int tune_blocksort = 1;  // -L on sequences of up to 32,768 windows: one block per sequence, sorted in LDS (0: device-wide sort)
   int tune_hist = 1;     // merged (-l) spectrum by atomic histogram when the hashes fit 26 bits (0: always sort)
-  int tune_summary2 = 1; // summaries against > 4,096 rows: 1 brackets from a sample + two passes over distance rows, 0 round 2's one block per row (8-10 passes), 2 the distances computed and reduced in ONE kernel, no distance rows (131,072 rows and more; measured level with 1, left as an option: DESIGN 5.6)
+  int tune_summary2 = 1; // summaries against > 4,096 rows: 1 brackets and bands from a sample + ONE pass over distance rows, 3 the same in two passes (median, then MAD), 0 round 2's one block per row (8-10 passes), 2 the distances computed and reduced in one kernel, no distance rows (131,072 rows and more); 1, 2 and 3 are level at 256 x 1M
   int tune_histlds = 1;  // ... staged through LDS: private tables (k <= 7), sorted chunks of assemblies (0: direct atomics; 2: always sort the chunks)
 };
 constexpr int kMaxSlots = 16;

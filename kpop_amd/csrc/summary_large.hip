@@ -13,6 +13,7 @@
 // ascending chain), equal up to rounding (tests hold 1e-10); at most kLargeMaxNb neighbours
 // are returned per row (out_n still reports the reference's eff_len).
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 #include "space_ops.h"
@@ -837,55 +838,6 @@ __global__ __launch_bounds__(kLT) void summary2_finish_kernel(const double *__re
 
 __device__ bool row_failed(const RowCounts *cnt, uint32_t row) { return cnt[row].fail != 0; }
 
-uint64_t summary_large_scratch_bytes(uint32_t n_rows, uint32_t r1) {
-  const uint64_t n_slices = (r1 + kSlice - 1) / kSlice;
-  return (uint64_t)n_rows * (sizeof(RowInfo) + sizeof(RowCounts) + (uint64_t)cand_cap_for(r1) * 8 + (uint64_t)kNbCap * 12 + n_slices * 16) + 4096;
-}
-
-// scratch = nullptr (or tune "summary2" off): the one-block-per-row kernel alone
-int launch_summary_large(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most,
-                         uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
-                         double *out_dist, double *out_z, hipStream_t st, void *scratch) {
-  const uint32_t req_len = keep_at_most ? keep_at_most : r1;
-  const bool two_pass = scratch && ctx().tune_summary2 && req_len <= kLargeMaxNb && r1 >= 2 * kSlice;
-  if (!two_pass) {
-    summary_large_kernel<<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist,
-                                                             out_z, nullptr);
-    KPOP_LAUNCH_CHECK();
-    return 0;
-  }
-  const uint32_t n_slices = (r1 + kSlice - 1) / kSlice;
-  char *p = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(scratch) + 255) & ~(uintptr_t)255);
-  RowInfo *info = reinterpret_cast<RowInfo *>(p);
-  p += ((uint64_t)n_rows * sizeof(RowInfo) + 255) & ~255ull;
-  RowCounts *cnt = reinterpret_cast<RowCounts *>(p);
-  p += ((uint64_t)n_rows * sizeof(RowCounts) + 255) & ~255ull;
-  const uint32_t cap = cand_cap_for(r1);
-  double *cand = reinterpret_cast<double *>(p);
-  p += (uint64_t)n_rows * cap * 8;
-  double *nb_d = reinterpret_cast<double *>(p);
-  p += (uint64_t)n_rows * kNbCap * 8;
-  uint32_t *nb_idx = reinterpret_cast<uint32_t *>(p);
-  p += (uint64_t)n_rows * kNbCap * 4;
-  double *part = reinterpret_cast<double *>(p);
-  summary2_sample_kernel<<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, req_len, info, cnt);
-  KPOP_LAUNCH_CHECK();
-  summary2_pass_kernel<1><<<dim3(n_slices, n_rows), dim3(256), 0, st>>>(rows, r1, info, cnt, cand, nb_idx, nb_d, part, n_slices, cap);
-  KPOP_LAUNCH_CHECK();
-  summary2_finish_kernel<1><<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, req_len, max_neighbours, info, cnt, cand, nb_idx, nb_d, part, n_slices,
-                                                                cap, out_stats, out_n, out_idx, out_dist, out_z);
-  KPOP_LAUNCH_CHECK();
-  summary2_pass_kernel<2><<<dim3(n_slices, n_rows), dim3(256), 0, st>>>(rows, r1, info, cnt, cand, nb_idx, nb_d, part, n_slices, cap);
-  KPOP_LAUNCH_CHECK();
-  summary2_finish_kernel<2><<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, req_len, max_neighbours, info, cnt, cand, nb_idx, nb_d, part, n_slices,
-                                                                cap, out_stats, out_n, out_idx, out_dist, out_z);
-  KPOP_LAUNCH_CHECK();
-  summary_large_kernel<<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, cnt);
-  KPOP_LAUNCH_CHECK();
-  return 0;
-}
-
-
 // ===========================================================================
 // Round 3, second step: the summary of q query rows against r1 >= 131,072 reference rows WITHOUT the q x r1 distances in HBM.
 //
@@ -931,21 +883,28 @@ __global__ __launch_bounds__(256) void sample_gather_kernel(const double *__rest
   for (uint32_t c = lane; c < n_dims; c += 64) out[(uint64_t)i * n_dims + c] = a[src * n_dims + c];
 }
 
-// one block per query row over its s sample distances: m^, the brackets, the bands
-__global__ __launch_bounds__(kLT) void fused_sample_kernel(const double *__restrict__ srow, uint32_t s, uint32_t r1, uint32_t req_len,
+// one block per query row over s sample distances: m^, the brackets, the bands.  SAMPLED = false: `src` holds [rows][s]
+// distances to a sample of the reference rows (the one-kernel path); true: `src` holds the distance rows themselves
+// ([rows][r1]) and the sample is kSampleRun consecutive elements out of every `stride` (the one-pass path over rows)
+template <bool SAMPLED>
+__global__ __launch_bounds__(kLT) void fused_sample_kernel(const double *__restrict__ src, uint32_t s_plain, uint32_t r1, uint32_t req_len,
                                                            RowInfo *__restrict__ info, RowCounts *__restrict__ cnt, FusedThr *__restrict__ thr) {
   __shared__ double s_w[kLT / 64];
   __shared__ uint32_t s_hist[kSel * kBins];
   __shared__ uint64_t s_cand[kSel * kCand];
   __shared__ uint32_t s_misc[64];
   __shared__ uint64_t s_mm[2 * (kLT / 64)];
-  const double *row = srow + (uint64_t)blockIdx.x * s;
+  uint32_t stride = 0;
+  const uint32_t s = SAMPLED ? sample_count(r1, &stride) : s_plain;
+  using Row = typename std::conditional<SAMPLED, SampledRow, PlainRow>::type;
+  Row sr;
+  if constexpr (SAMPLED) sr = SampledRow{src + (uint64_t)blockIdx.x * r1, stride};
+  else sr = PlainRow{src + (uint64_t)blockIdx.x * s};
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const PlainRow sr{row};
   double part = 0.0;
   uint64_t kmin = ~0ull, kmax = 0;
   for (uint32_t i = threadIdx.x; i < s; i += kLT) {
-    const double x = row[i];
+    const double x = sr[i];
     part = __dadd_rn(part, x);
     const uint64_t k = f64_key(x);
     kmin = kmin < k ? kmin : k;
@@ -969,18 +928,18 @@ __global__ __launch_bounds__(kLT) void fused_sample_kernel(const double *__restr
   uint32_t a, b;
   bracket_ranks(r1 / 2, r1, s, &a, &b);
   Sel sel[kSel] = {Sel{a, kmin, kmax, 0, 0, 0, 0, 0}, Sel{b, kmin, kmax, 0, 0, 0, 0, 0}};
-  block_select_ranks<0>(sr, s, 0.0, sel, 2, s_hist, s_cand, s_misc);
+  block_select_ranks<0, false, Row>(sr, s, 0.0, sel, 2, s_hist, s_cand, s_misc);
   // the sample's own median, and -- same passes -- the neighbour threshold
   uint64_t kcut = ~0ull;
   const double want = 3.0 * (double)req_len * (double)s / (double)r1 + 16.0;
   const bool cut = want < (double)(s - 1);
   Sel sm[kSel] = {Sel{s / 2, kmin, kmax, 0, 0, 0, 0, 0}, Sel{cut ? (uint32_t)want : 0u, kmin, kmax, 0, 0, 0, 0, cut ? 0 : 1}};
-  block_select_ranks<0>(sr, s, 0.0, sm, 2, s_hist, s_cand, s_misc);
+  block_select_ranks<0, false, Row>(sr, s, 0.0, sm, 2, s_hist, s_cand, s_misc);
   if (cut) kcut = sm[1].value;
   const double ms = key_f64(sm[0].value);
   const double far = fmax(fabs(__dsub_rn(key_f64(kmax), ms)), fabs(__dsub_rn(key_f64(kmin), ms)));
   Sel sa[kSel] = {Sel{a, f64_key(0.0), f64_key(far), 0, 0, 0, 0, 0}, Sel{b, f64_key(0.0), f64_key(far), 0, 0, 0, 0, 0}};
-  block_select_ranks<1>(sr, s, ms, sa, 2, s_hist, s_cand, s_misc);
+  block_select_ranks<1, false, Row>(sr, s, ms, sa, 2, s_hist, s_cand, s_misc);
   if (threadIdx.x == 0) {
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
     const bool no_lo = a == 0, no_hi = b == s - 1;  // rank 0 / the last rank of the sample bound nothing
@@ -990,7 +949,7 @@ __global__ __launch_bounds__(kLT) void fused_sample_kernel(const double *__restr
     I.khi = no_hi ? ~0ull : sel[1].value;
     I.kcut = kcut;
     I.sample_n = s;
-    I.sample_stride = 0;
+    I.sample_stride = stride;
     RowCounts z = {};
     cnt[blockIdx.x] = z;
     FusedThr T;
@@ -1157,6 +1116,120 @@ __global__ __launch_bounds__(256, 2) void summary_fused_pass_kernel(
   }
 }
 
+// ONE pass over the distance rows (slice blockIdx.x of row blockIdx.y) -- the one-kernel path's bookkeeping on rows that
+// exist (kpop_summarize_distances on a caller's matrix; the default route for large first operands): everything counted,
+// the candidates of the median AND of the MAD's bands collected, so that no second pass for |d - median| is needed.
+// (The median's bracket is compared as keys -- a caller's matrix may hold -0.0, which differs from +0.0 as a key --, the
+// bands as doubles, here and in the finish kernel alike.)
+__global__ __launch_bounds__(256) void summary1_pass_kernel(const double *__restrict__ rows, uint32_t r1, const RowInfo *__restrict__ info,
+                                                            const FusedThr *__restrict__ thr, RowCounts *__restrict__ cnt,
+                                                            double *__restrict__ cand, uint32_t *__restrict__ nb_idx, double *__restrict__ nb_d,
+                                                            double *__restrict__ part, uint32_t n_slices, uint32_t kCandCap) {
+  __shared__ uint32_t s_c[8];
+  __shared__ double s_p[2][4];
+  constexpr uint32_t kStage = 4096;
+  __shared__ double s_stage[kStage];
+  __shared__ uint32_t s_n, s_base;
+  const uint32_t j = blockIdx.y, sl = blockIdx.x;
+  const double *row = rows + (uint64_t)j * r1;
+  const RowInfo I = info[j];
+  const FusedThr T = thr[j];
+  RowCounts *C = cnt + j;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t i0 = sl * kSlice, i1 = min(r1, i0 + kSlice);
+  double *my_cand = cand + (uint64_t)j * kCandCap;
+  uint32_t c_lt = 0, c_eqlo = 0, c_eqhi = 0, c_med = 0, c_in = 0;
+  double sum = 0.0, sq = 0.0;
+  constexpr int U = 8;  // loads in flight per thread
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  auto flush = [&]() {  // all threads; s_n is stable (between barriers)
+    const uint32_t cnt_ = s_n;
+    if (threadIdx.x == 0) s_base = atomicAdd(&C->n_cand, cnt_);
+    __syncthreads();
+    const uint32_t b0 = s_base;
+    for (uint32_t q = threadIdx.x; q < cnt_; q += 256)
+      if (b0 + q < kCandCap) my_cand[b0 + q] = s_stage[q];
+    __syncthreads();
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+  };
+  for (uint32_t base = i0; base < i1; base += 256 * U) {
+    if (s_n > kStage - 256 * U) flush();  // (block-uniform: read between barriers) room for a whole iteration of candidates
+    double dv8[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = base + u * 256 + threadIdx.x;
+      dv8[u] = i < i1 ? row[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = base + u * 256 + threadIdx.x;
+      const bool ok = i < i1;
+      const double d = dv8[u];
+      const uint64_t k = f64_key(d);
+      const bool medc = k > I.klo && k < I.khi;
+      const bool in = d > T.Lin && d < T.Uin;
+      if (ok) {
+        c_lt += k < I.klo;
+        c_eqlo += k == I.klo;
+        c_eqhi += (k == I.khi) && I.khi != I.klo;
+        c_med += medc;
+        c_in += in;
+        sum = __dadd_rn(sum, d);
+        const double dv = __dsub_rn(d, I.m_hat);
+        sq = __dadd_rn(sq, __dmul_rn(dv, dv));
+      }
+      const bool is_cand = ok && (medc || (!in && d >= T.Llo && d <= T.Uhi));
+      if (__ballot(is_cand)) {
+        const uint32_t at = wave_append(is_cand, &s_n, lane);
+        if (is_cand) s_stage[at] = d;
+      }
+      const bool is_nb = ok && k <= I.kcut;
+      if (__ballot(is_nb)) {
+        const uint32_t at = wave_append(is_nb, &C->n_nb, lane);
+        if (is_nb && at < kNbCap) {
+          nb_idx[(uint64_t)j * kNbCap + at] = i;
+          nb_d[(uint64_t)j * kNbCap + at] = d;
+        }
+      }
+    }
+    __syncthreads();  // s_n is read at the top of the next iteration
+  }
+  if (s_n) flush();
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    c_lt += __shfl_xor((int)c_lt, o, 64);
+    c_eqlo += __shfl_xor((int)c_eqlo, o, 64);
+    c_eqhi += __shfl_xor((int)c_eqhi, o, 64);
+    c_med += __shfl_xor((int)c_med, o, 64);
+    c_in += __shfl_xor((int)c_in, o, 64);
+    sum = __dadd_rn(sum, __shfl_xor(sum, o, 64));
+    sq = __dadd_rn(sq, __shfl_xor(sq, o, 64));
+  }
+  if (threadIdx.x < 8) s_c[threadIdx.x] = 0;
+  __syncthreads();
+  if (lane == 0) {
+    if (c_lt) atomicAdd(&s_c[0], c_lt);
+    if (c_eqlo) atomicAdd(&s_c[1], c_eqlo);
+    if (c_eqhi) atomicAdd(&s_c[2], c_eqhi);
+    if (c_med) atomicAdd(&s_c[3], c_med);
+    if (c_in) atomicAdd(&s_c[4], c_in);
+    s_p[0][wv] = sum;
+    s_p[1][wv] = sq;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_c[0]) atomicAdd(&C->lt_lo, s_c[0]);
+    if (s_c[1]) atomicAdd(&C->eq_lo, s_c[1]);
+    if (s_c[2]) atomicAdd(&C->eq_hi, s_c[2]);
+    if (s_c[3]) atomicAdd(&C->m_lt, s_c[3]);    // (the one-pass path keeps n_med and n_inner where the two-pass path keeps pass 2's counts)
+    if (s_c[4]) atomicAdd(&C->m_eqlo, s_c[4]);
+    part[((uint64_t)j * n_slices + sl) * 2 + 0] = __dadd_rn(__dadd_rn(__dadd_rn(s_p[0][0], s_p[0][1]), s_p[0][2]), s_p[0][3]);
+    part[((uint64_t)j * n_slices + sl) * 2 + 1] = __dadd_rn(__dadd_rn(__dadd_rn(s_p[1][0], s_p[1][1]), s_p[1][2]), s_p[1][3]);
+  }
+}
+
 struct BandRow {  // the candidates of the MAD among a row's compacted list: NaN for the others (its key is beyond every range)
   const double *p;
   double Llo, Lin, Uin, Uhi;
@@ -1167,6 +1240,9 @@ struct BandRow {  // the candidates of the MAD among a row's compacted list: NaN
   }
 };
 
+// SEG: the candidates lie in per-stripe segments of `seg` with their counts in `rec` (the one-kernel path); otherwise in the
+// row's contiguous list `ccand` with the counts in `cnt` (the one-pass path over distance rows; n_stripes = its slices)
+template <bool SEG>
 __global__ __launch_bounds__(kLT) void fused_finish_kernel(const double *__restrict__ seg, uint32_t r1, uint32_t row0, uint32_t req_len,
                                                            uint32_t max_neighbours, const RowInfo *__restrict__ info,
                                                            const FusedThr *__restrict__ thr, RowCounts *__restrict__ cnt,
@@ -1194,56 +1270,64 @@ __global__ __launch_bounds__(kLT) void fused_finish_kernel(const double *__restr
   double *my_c = ccand + (uint64_t)jl * cap;
   if (threadIdx.x < 8) s_tot[threadIdx.x] = 0;
   __syncthreads();
-  // ---- the stripes' counts: totals, and where each stripe's candidates go in the compacted list
-  uint32_t running = 0;
-  for (uint32_t base = 0; base < n_stripes; base += kLT) {
-    const uint32_t st = base + threadIdx.x;
-    StripeRec R = {0, 0, 0, 0};
-    if (st < n_stripes) R = my_rec[st];
-    // exclusive scan of c_cnt over the block
-    uint32_t incl = R.c_cnt;
+  uint32_t lt, eqlo, eqhi, nmed, n_inner, n_c;
+  bool ok;
+  if constexpr (SEG) {
+    // ---- the stripes' counts: totals, and where each stripe's candidates go in the compacted list
+    uint32_t running = 0;
+    for (uint32_t base = 0; base < n_stripes; base += kLT) {
+      const uint32_t st = base + threadIdx.x;
+      StripeRec R = {0, 0, 0, 0};
+      if (st < n_stripes) R = my_rec[st];
+      // exclusive scan of c_cnt over the block
+      uint32_t incl = R.c_cnt;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
-      if (lane >= o) incl += up;
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += up;
+      }
+      __syncthreads();
+      if (lane == 63) s_wu[wv] = incl;
+      __syncthreads();
+      uint32_t before = 0, total = 0;
+      for (int w = 0; w < kLT / 64; ++w) {
+        if (w < wv) before += s_wu[w];
+        total += s_wu[w];
+      }
+      if (st < n_stripes) {
+        my_pre[st] = running + before + incl - R.c_cnt;
+        atomicAdd(&s_tot[0], R.lt_eqlo & 0xFFFFu);
+        atomicAdd(&s_tot[1], R.lt_eqlo >> 16);
+        atomicAdd(&s_tot[2], R.eqhi_nmed & 0xFFFFu);
+        atomicAdd(&s_tot[3], R.eqhi_nmed >> 16);
+        atomicAdd(&s_tot[4], R.inner);
+      }
+      running += total;
     }
     __syncthreads();
-    if (lane == 63) s_wu[wv] = incl;
-    __syncthreads();
-    uint32_t before = 0, total = 0;
-    for (int w = 0; w < kLT / 64; ++w) {
-      if (w < wv) before += s_wu[w];
-      total += s_wu[w];
-    }
-    if (st < n_stripes) {
-      my_pre[st] = running + before + incl - R.c_cnt;
-      atomicAdd(&s_tot[0], R.lt_eqlo & 0xFFFFu);
-      atomicAdd(&s_tot[1], R.lt_eqlo >> 16);
-      atomicAdd(&s_tot[2], R.eqhi_nmed & 0xFFFFu);
-      atomicAdd(&s_tot[3], R.eqhi_nmed >> 16);
-      atomicAdd(&s_tot[4], R.inner);
-    }
-    running += total;
-  }
-  __syncthreads();
-  const uint32_t lt = s_tot[0], eqlo = s_tot[1], eqhi = s_tot[2], nmed = s_tot[3], n_inner = s_tot[4], n_c = running;
-  bool ok = n_c <= cap;
-  // ---- the candidates, compacted (a wave per stripe)
-  if (ok) {
-    for (uint32_t st = wv; st < n_stripes; st += kLT / 64) {
-      const uint32_t c = my_rec[st].c_cnt, at = my_pre[st];
-      const double *src = seg + (uint64_t)jl * r1 + (uint64_t)st * kStripe;
-      for (uint32_t e0 = 0; e0 < c; e0 += 64 * 8) {  // eight loads in flight a lane (a loop of one was latency-bound: 0.24 ms)
-        double v[8];
+    lt = s_tot[0]; eqlo = s_tot[1]; eqhi = s_tot[2]; nmed = s_tot[3]; n_inner = s_tot[4]; n_c = running;
+    ok = n_c <= cap;
+    // ---- the candidates, compacted (a wave per stripe)
+    if (ok) {
+      for (uint32_t st = wv; st < n_stripes; st += kLT / 64) {
+        const uint32_t c = my_rec[st].c_cnt, at = my_pre[st];
+        const double *src = seg + (uint64_t)jl * r1 + (uint64_t)st * kStripe;
+        for (uint32_t e0 = 0; e0 < c; e0 += 64 * 8) {  // eight loads in flight a lane (a loop of one was latency-bound: 0.24 ms)
+          double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = e0 + u * 64 + lane < c ? src[e0 + u * 64 + lane] : 0.0;
+          for (int u = 0; u < 8; ++u) v[u] = e0 + u * 64 + lane < c ? src[e0 + u * 64 + lane] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (e0 + u * 64 + lane < c) my_c[at + e0 + u * 64 + lane] = v[u];
+          for (int u = 0; u < 8; ++u)
+            if (e0 + u * 64 + lane < c) my_c[at + e0 + u * 64 + lane] = v[u];
+        }
       }
     }
+    __syncthreads();
+  } else {
+    const RowCounts C = cnt[jl];
+    lt = C.lt_lo; eqlo = C.eq_lo; eqhi = C.eq_hi; nmed = C.m_lt; n_inner = C.m_eqlo; n_c = C.n_cand;
+    ok = n_c <= cap;
   }
-  __syncthreads();
   // ---- mean and sd: the stripes' sums in a fixed order -- runs of eight stripes by a thread each, then the runs' sums in
   // order by every thread out of LDS (one chain over 512 global loads was a quarter of this kernel)
   double sum = 0.0, sqh = 0.0;
@@ -1358,7 +1442,7 @@ __global__ __launch_bounds__(kLT) void fused_finish_kernel(const double *__restr
 // ---- host side ------------------------------------------------------------
 bool summary_fused_applies(uint32_t r1, uint32_t keep_at_most) {
   const uint32_t req_len = keep_at_most ? keep_at_most : r1;
-  return ctx().tune_summary2 >= 2 && req_len <= kLargeMaxNb && r1 >= 4 * kSlice && (r1 + kStripe - 1) / kStripe <= kMaxStripes;
+  return ctx().tune_summary2 == 2 && req_len <= kLargeMaxNb && r1 >= 4 * kSlice && (r1 + kStripe - 1) / kStripe <= kMaxStripes;
 }
 uint32_t summary_fused_sample_rows(uint32_t r1) { return std::min<uint32_t>(kSample, r1); }
 
@@ -1416,7 +1500,7 @@ int launch_summary_fused(int kind, const double *a, uint32_t r1, const double *b
   FusedScratch F;
   carve_fused(scratch, n_rows, r1, &F);
   KPOP_HIP(hipMemsetAsync(F.n_failed, 0, 256, st));
-  fused_sample_kernel<<<dim3(n_rows), dim3(kLT), 0, st>>>(srow, s, r1, req_len, F.info, F.cnt, F.thr);
+  fused_sample_kernel<false><<<dim3(n_rows), dim3(kLT), 0, st>>>(srow, s, r1, req_len, F.info, F.cnt, F.thr);
   KPOP_LAUNCH_CHECK();
   const dim3 grid(n_stripes, (n_rows + kFQ - 1) / kFQ);
 #define KPOP_FUSED(K) \
@@ -1426,7 +1510,7 @@ int launch_summary_fused(int kind, const double *a, uint32_t r1, const double *b
   else KPOP_FUSED(KPOP_MINKOWSKI);
 #undef KPOP_FUSED
   KPOP_LAUNCH_CHECK();
-  fused_finish_kernel<<<dim3(n_rows), dim3(kLT), 0, st>>>(seg, r1, row0, req_len, max_neighbours, F.info, F.thr, F.cnt, F.rec, F.part, n_stripes, F.pre,
+  fused_finish_kernel<true><<<dim3(n_rows), dim3(kLT), 0, st>>>(seg, r1, row0, req_len, max_neighbours, F.info, F.thr, F.cnt, F.rec, F.part, n_stripes, F.pre,
                                                           F.ccand, fused_cand_cap(r1), F.nb_idx, F.nb_d, F.n_failed, out_stats, out_n, out_idx, out_dist,
                                                           out_z);
   KPOP_LAUNCH_CHECK();
@@ -1442,6 +1526,73 @@ int launch_summary_failed_rows(const double *rows, uint32_t n_rows, uint32_t r1,
   carve_fused(scratch, n_rows, r1, &F);
   summary_large_kernel<<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, keep_at_most ? keep_at_most : r1, max_neighbours, out_stats, out_n, out_idx,
                                                            out_dist, out_z, F.cnt);
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
+
+static inline uint32_t rows_cand_cap(uint32_t r1) { return std::max(cand_cap_for(r1), fused_cand_cap(r1)); }
+
+uint64_t summary_large_scratch_bytes(uint32_t n_rows, uint32_t r1) {
+  const uint64_t n_slices = (r1 + kSlice - 1) / kSlice;
+  return (uint64_t)n_rows * (sizeof(RowInfo) + sizeof(RowCounts) + sizeof(FusedThr) + (uint64_t)rows_cand_cap(r1) * 8 + (uint64_t)kNbCap * 12 + n_slices * 16) +
+         8192;
+}
+
+// scratch = nullptr (or tune "summary2" 0): the one-block-per-row kernel alone.  "summary2" 1 (default): ONE pass over the
+// rows (brackets and bands from a sample, certificate for the MAD); 3: two passes (the first version of round 3).
+int launch_summary_large(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most,
+                         uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
+                         double *out_dist, double *out_z, hipStream_t st, void *scratch) {
+  const uint32_t req_len = keep_at_most ? keep_at_most : r1;
+  const bool by_brackets = scratch && ctx().tune_summary2 && req_len <= kLargeMaxNb && r1 >= 2 * kSlice;
+  if (!by_brackets) {
+    summary_large_kernel<<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist,
+                                                             out_z, nullptr);
+    KPOP_LAUNCH_CHECK();
+    return 0;
+  }
+  const uint32_t n_slices = (r1 + kSlice - 1) / kSlice;
+  char *p = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(scratch) + 255) & ~(uintptr_t)255);
+  uint32_t *n_failed = reinterpret_cast<uint32_t *>(p);
+  p += 256;
+  RowInfo *info = reinterpret_cast<RowInfo *>(p);
+  p += ((uint64_t)n_rows * sizeof(RowInfo) + 255) & ~255ull;
+  RowCounts *cnt = reinterpret_cast<RowCounts *>(p);
+  p += ((uint64_t)n_rows * sizeof(RowCounts) + 255) & ~255ull;
+  FusedThr *thr = reinterpret_cast<FusedThr *>(p);
+  p += ((uint64_t)n_rows * sizeof(FusedThr) + 255) & ~255ull;
+  const uint32_t cap = rows_cand_cap(r1);
+  double *cand = reinterpret_cast<double *>(p);
+  p += (uint64_t)n_rows * cap * 8;
+  double *nb_d = reinterpret_cast<double *>(p);
+  p += (uint64_t)n_rows * kNbCap * 8;
+  uint32_t *nb_idx = reinterpret_cast<uint32_t *>(p);
+  p += (uint64_t)n_rows * kNbCap * 4;
+  double *part = reinterpret_cast<double *>(p);
+  if (ctx().tune_summary2 != 3) {
+    KPOP_HIP(hipMemsetAsync(n_failed, 0, 256, st));
+    fused_sample_kernel<true><<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, 0, r1, req_len, info, cnt, thr);
+    KPOP_LAUNCH_CHECK();
+    summary1_pass_kernel<<<dim3(n_slices, n_rows), dim3(256), 0, st>>>(rows, r1, info, thr, cnt, cand, nb_idx, nb_d, part, n_slices, cap);
+    KPOP_LAUNCH_CHECK();
+    fused_finish_kernel<false><<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, req_len, max_neighbours, info, thr, cnt, nullptr, part, n_slices, nullptr, cand,
+                                                                   cap, nb_idx, nb_d, n_failed, out_stats, out_n, out_idx, out_dist, out_z);
+    KPOP_LAUNCH_CHECK();
+  } else {
+    summary2_sample_kernel<<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, req_len, info, cnt);
+    KPOP_LAUNCH_CHECK();
+    summary2_pass_kernel<1><<<dim3(n_slices, n_rows), dim3(256), 0, st>>>(rows, r1, info, cnt, cand, nb_idx, nb_d, part, n_slices, cap);
+    KPOP_LAUNCH_CHECK();
+    summary2_finish_kernel<1><<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, req_len, max_neighbours, info, cnt, cand, nb_idx, nb_d, part, n_slices,
+                                                                  cap, out_stats, out_n, out_idx, out_dist, out_z);
+    KPOP_LAUNCH_CHECK();
+    summary2_pass_kernel<2><<<dim3(n_slices, n_rows), dim3(256), 0, st>>>(rows, r1, info, cnt, cand, nb_idx, nb_d, part, n_slices, cap);
+    KPOP_LAUNCH_CHECK();
+    summary2_finish_kernel<2><<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, req_len, max_neighbours, info, cnt, cand, nb_idx, nb_d, part, n_slices,
+                                                                  cap, out_stats, out_n, out_idx, out_dist, out_z);
+    KPOP_LAUNCH_CHECK();
+  }
+  summary_large_kernel<<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, cnt);
   KPOP_LAUNCH_CHECK();
   return 0;
 }

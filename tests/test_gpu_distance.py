@@ -221,7 +221,8 @@ def test_row_norms_and_distances_with_supplied_norms(kpop, oracle, kind, p):
 @pytest.mark.parametrize("case", ["random", "sorted", "ties", "constant", "clustered"])
 @pytest.mark.parametrize("keep", [2, 300])
 def test_summarize_distances_two_pass_path(kpop, oracle, case, keep):
-    """rows of 65,536 distances and more take the bracket-from-a-sample + two-pass path (summary_large.hip, round 3): exact
+    """rows of 65,536 distances and more take the brackets-from-a-sample paths (summary_large.hip, round 3; one pass: the
+    candidates of the median and of the MAD's bands together, a certificate for the MAD -- or two passes): exact
     medians, MADs and neighbour lists whatever the sample saw -- a matrix in sorted order, heavy ties, constant rows and a
     clustered one (the bracket misses: the row is redone by the one-block-per-row kernel) included; mean / sd to 1e-10"""
     from kpop_amd import api
@@ -242,7 +243,7 @@ def test_summarize_distances_two_pass_path(kpop, oracle, case, keep):
         dm = np.concatenate([rng.normal(1.0, 0.01, size=(r2, r1 // 2)), rng.normal(5.0, 0.01, size=(r2, r1 - r1 // 2))], axis=1)
         dm[4, ::2] = 9.0  # ... and a row that alternates
     cap = 512
-    for mode in (1, 0):
+    for mode in (1, 3, 0):  # one pass over the rows (default), two passes (the round's first version), one block per row
         api.tune("summary2", mode)
         st, n, idx, d, z = kpop.summarize_distances(dm, keep_at_most=keep, max_neighbours=cap)
         for j in range(r2):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""kpop_dev_distance_summary of 256 query rows against 1,000,000 twisted vectors (64 dimensions, keep_at_most 2): the fused
-path (kpop_tune("summary2", 2): no distance rows) against the two-pass path over distance rows (1); ms per call (HIP events,
+"""kpop_dev_distance_summary of 256 query rows against 1,000,000 twisted vectors (64 dimensions, keep_at_most 2) under
+kpop_tune("summary2", 1 | 3 | 2): one pass over distance rows (default), two passes, no distance rows; ms per call (HIP events,
 median of 5), results compared."""
 import os
 import sys
@@ -28,7 +28,7 @@ def main():
     work = torch.empty(api.dev_distance_workspace_bytes(r1, r2, d), dtype=torch.uint8, device=dev)
     cap = 8
     outs = {}
-    for mode in [int(x) for x in os.environ.get("AB_MODES", "2,1").split(",")]:
+    for mode in [int(x) for x in os.environ.get("AB_MODES", "1,3,2").split(",")]:
         api.tune("summary2", mode)
         stats = torch.zeros(r2, 4, dtype=torch.float64, device=dev)
         nn = torch.zeros(r2, dtype=torch.int32, device=dev)
@@ -54,8 +54,10 @@ def main():
         print("summary2 = %d: %8.3f ms a call (%d x %d x %d, keep_at_most %d; the normalisation of both operands included)"
               % (mode, float(np.median(ms)), r2, r1, d, keep), flush=True)
     api.tune("summary2", 1)
-    if len(outs) == 2:
-        a, b = outs[2], outs[1]
+    if 1 in outs and len(outs) > 1:
+      for other in [m for m in outs if m != 1]:
+        a, b = outs[other], outs[1]
+        print("summary2 = %d against 1:" % other, end=" ")
         print("median / MAD identical: %s; neighbours identical: %s; mean / sd max rel diff %.2e"
               % (np.array_equal(a[0][:, 2:], b[0][:, 2:]), np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]),
                  float(np.max(np.abs(a[0][:, :2] - b[0][:, :2]) / np.abs(b[0][:, :2])))))
