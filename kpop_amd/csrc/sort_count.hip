@@ -298,7 +298,8 @@ __global__ __launch_bounds__(1024) void window_hist_lds_kernel(const uint8_t *__
   }
 }
 
-constexpr uint32_t kCombSeg = 1024, kCombReads = 64;  // a chunk: the same 1,024 windows of 64 consecutive sequences
+constexpr uint32_t kCombSeg = 1024, kCombReads = 64;  // a chunk: the same 1,024 windows of 64 consecutive sequences (128: 0.65 -> 2.1 ms on 5,000 mutants -- twice the lanes of a wave on one LDS word)
+constexpr uint32_t kCombTpr = 1024 / kCombReads;          // threads a sequence
 constexpr uint32_t kCombSlots = 8192;                  // LDS table of (hash, count): 64 KB, two blocks a CU
 constexpr int kCombProbes = 8;
 
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(1024) void window_hist_combine_kernel(const uint8_t
   const int shift = SB * (k - 1);
   constexpr uint32_t kSym = (1u << SB) - 1u, kValid = SB == 2 ? 4u : 20u, kEmpty = 0xFFFFFFFFu;
   const uint32_t mask = (uint32_t)bits_mask(SB * k);
-  constexpr uint32_t per_h = kCombSeg / 16;  // 16 threads a sequence, 64 consecutive windows a thread
+  constexpr uint32_t per_h = kCombSeg / kCombTpr;  // kCombTpr threads a sequence, consecutive windows a thread
   for (uint32_t q = threadIdx.x; q < kCombSlots; q += 1024) {
     s_hash[q] = kEmpty;
     s_cnt[q] = 0;
@@ -322,14 +323,14 @@ __global__ __launch_bounds__(1024) void window_hist_combine_kernel(const uint8_t
   for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     // chunks are dealt with the groups of sequences fastest: the blocks running together work on one stretch of all of them
     const uint32_t seg = (uint32_t)(chunk / n_groups), grp = (uint32_t)(chunk % n_groups);
-    const uint32_t r = grp * kCombReads + threadIdx.x / 16;
+    const uint32_t r = grp * kCombReads + threadIdx.x / kCombTpr;
     uint64_t len = 0, off = 0;
     if (r < n_reads) {
       off = offsets[r];
       len = offsets[r + 1] - off;
     }
     const uint64_t n_win = len >= (uint64_t)k ? len - k + 1 : 0;
-    const uint64_t w0 = (uint64_t)seg * kCombSeg + (uint64_t)(threadIdx.x % 16) * per_h;
+    const uint64_t w0 = (uint64_t)seg * kCombSeg + (uint64_t)(threadIdx.x % kCombTpr) * per_h;
     const uint8_t *seq = bases + off;
     uint32_t fwd = 0, rc = 0;
     int run = 0;

@@ -12,7 +12,7 @@ cli_kernels_report.py joins that with the profiler's per-kernel averages.
   twist_reads  KPopTwistDB -k, read spectra twist_csr_kernel<double>          100k spectra of <= 139 lines, D = 64
   twist_genomes KPopTwistDB -k, genomes     twist_csr_kernel<double>          2,000 spectra of ~29.7k lines (wuhan mutants)
   summary_65   KPopTwistDB -s vs classes    distance_summary_kernel           r1 = 65, r2 = 100k, D = 64
-  summary_1M   relatedness engine           summary_large_kernel (+ rowwise)  r1 = 1M, r2 = 256, keep 300
+  summary_1M   relatedness engine           summary1_pass_kernel (+ sample, finish, rowwise)  r1 = 1M, r2 = 256, keep 300
   merged_hist  KPopCount -l                 read_hist / window_hist + compaction   100k reads; 5,000 x 30 kb genomes
   merged_hist_mutants  KPopCount -l, one organism   window_hist_combine_kernel (LDS (hash, count) tables)   5,000 wuhan mutants, k = 12
   merged_hist_k7       KPopCount -l, small k        window_hist_lds_kernel (private LDS tables)             5,000 wuhan mutants, k = 7
@@ -132,7 +132,7 @@ def main():
             algo["distance_summary"] = {"bytes": (r1 + r2) * d * 8 + r2 * (32 + 4 + keep * 20), "flops": 4.0 * r1 * r2 * d,
                                                "note": "both operands once + one summary row; f64 VALU-bound: 4 unfusable ops per pair and dimension"}
         else:
-            algo["summary_large_kernel"] = {"bytes": r2 * r1 * 8, "note": "one pass over the r1 distances of each query row is the algorithmic minimum; the kernel makes several"}
+            algo["summary1_pass_kernel"] = {"bytes": r2 * r1 * 8, "note": "one pass over the r1 distances of each query row is the algorithmic minimum: this kernel is that pass; fused_sample_kernel (a 6 % sample, several selections over it) and fused_finish_kernel (the ~13 % candidates, five passes) add theirs; summary_large_kernel is the fallback, idle here"}
             algo["distance_rowwise_kernel"] = {"bytes": (r1 + r2) * d * 8 + r1 * r2 * 8, "flops": 4.0 * r1 * r2 * d, "note": "chunk rows written for the summary kernel"}
     elif sec in ("merged_hist_mutants", "merged_hist_k7"):
         kk = 12 if sec == "merged_hist_mutants" else 7
