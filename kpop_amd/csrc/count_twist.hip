@@ -653,15 +653,59 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
         }
       if (found) atomicAdd(&s_found[tg], found);
     }
-    // (the columns are padded to a multiple of 32 with row 0 of the twister against zero counts: the loop below has no
-    // branches, so that the loads of eight steps ahead stay in flight under the MFMAs)
-    const uint32_t U = s_n, U32 = (U + 31) & ~31u;
-    for (uint32_t u = U + threadIdx.x; u < U32; u += 1024) ucol[u] = 0;
+    // (the columns are padded with row 0 of the twister against zero counts: the loops below have no branches, so that the
+    // loads of the steps ahead stay in flight under the MFMAs)
+    const uint32_t U = s_n;
+    const bool ksplit = tv.n_dims <= 64;  // (uniform)
+    const uint32_t UP = ksplit ? ((U + 63) & ~63u) : ((U + 31) & ~31u);
+    for (uint32_t u = U + threadIdx.x; u < UP; u += 1024) ucol[u] = 0;
     __syncthreads();
-    // ---- 3. partial[64 x D] = X[64 x U] * T_U: wave wv owns M tile wv & 3 (16 sequences) and the 16 dims of slice wv >> 2
     const uint16_t *X16 = reinterpret_cast<const uint16_t *>(Xw);
+    if (ksplit && !(dbg & 1)) {
+      // ---- 3a. partial[64 x D] = X[64 x U] * T_U for D <= 64: wave wv owns the 16 dims of slice wv & 3 and a QUARTER of the
+      // columns, for all 64 sequences (four accumulator tiles) -- every row of T is loaded once per block, not once per M tile
+      // (the rows' latency, not the MFMAs, was this phase: 0.86 of the kernel's 2.04 ms).  The quarters are added in order.
+      const int ni = wv & 3, kh = wv >> 2;
+      const uint32_t dc = 16u * ni + (lane & 15);
+      const double *trow = tv.rows + min(dc, tv.d_pad - 1);  // (columns past the twister's are not written below)
+      const uint32_t Uq = UP / 4, c0 = (uint32_t)kh * Uq;   // Uq a multiple of 16: a multiple of four steps
+      f64x4 acc[4];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) acc[mi] = f64x4{0.0, 0.0, 0.0, 0.0};
+      constexpr int PF = 4;  // (eight, with the columns padded to 128: no faster -- the phase is the MFMA pipe's now)
+      double bb[PF];
+#pragma unroll
+      for (int q = 0; q < PF; ++q) bb[q] = trow[(uint64_t)ucol[c0 + 4 * q + (lane >> 4)] * tv.d_pad];
+      const uint16_t *xrow = X16 + (lane & 15) * kTileXS + c0 + (lane >> 4);
+      for (uint32_t q0 = 0; q0 < Uq / 4; q0 += PF) {
+#pragma unroll
+        for (int qq = 0; qq < PF; ++qq) {
+          const uint32_t q = q0 + qq;
+          const double b = bb[qq];
+          bb[qq] = trow[(uint64_t)ucol[c0 + min(4 * (q + PF) + (lane >> 4), Uq - 1)] * tv.d_pad];
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xrow[mi * 16 * kTileXS + 4 * q], b, acc[mi], 0, 0, 0);
+        }
+      }
+      __syncthreads();  // every wave is done with X: its room takes the quarters' sums, [quarter][sequence][dim]
+      double *P = reinterpret_cast<double *>(Xw);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)  // lane l holds rows (l >> 4) + 4 r of an M tile, column l & 15 of the wave's 16 dims
+          P[((uint32_t)kh * 64 + 16 * mi + (lane >> 4) + 4 * rr) * 64 + dc] = acc[mi][rr];
+      __syncthreads();
+      for (uint32_t e = threadIdx.x; e < 64 * 64; e += 1024) {
+        const uint32_t g = e >> 6, d = e & 63u, rd = grp * kTileG + g;
+        const double v = __dadd_rn(__dadd_rn(__dadd_rn(P[e], P[4096 + e]), P[8192 + e]), P[12288 + e]);
+        if (rd < n_reads && d < tv.n_dims && seg < nseg[rd]) partial[(seg_off[rd] + seg) * tv.n_dims + d] = v;
+      }
+    }
+    // ---- 3b. the same for D > 64: wave wv owns M tile wv & 3 (16 sequences) and the 16 dims of slice wv >> 2 of every 64
     const int mi = wv & 3, ni = wv >> 2;
-    for (uint32_t d0 = 0; d0 < tv.n_dims && !(dbg & 1); d0 += 64) {
+    for (uint32_t d0 = 0; d0 < tv.n_dims && !ksplit && !(dbg & 1); d0 += 64) {
+      const uint32_t U32 = UP;
       const uint32_t dc = d0 + 16u * ni + (lane & 15);
       const double *trow = tv.rows + min(dc, tv.d_pad - 1);  // (columns past the twister's are not written below)
       f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
