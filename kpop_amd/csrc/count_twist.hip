@@ -527,7 +527,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
   uint16_t *ht_u = reinterpret_cast<uint16_t *>(ht_key + kTileH);            // [kTileH] number of the slot's row
   uint32_t *ucol = reinterpret_cast<uint32_t *>(ht_u + kTileH);              // [kTileU] row of number u
   uint32_t *Xw = ucol + kTileU;                                              // [kTileG][kTileXS / 2] pairs of u16 counts
-  __shared__ uint32_t s_over, s_n, s_found[kTileG], s_wbase[16];
+  __shared__ uint32_t s_over, s_n, s_new, s_found[kTileG], s_wbase[16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t n_groups = (n_reads + kTileG - 1) / kTileG;
   const uint64_t n_chunks = (uint64_t)n_groups * max_seg;
@@ -560,53 +560,71 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
     if (threadIdx.x == 0) {
       s_over = 0;
       s_n = 0;
+      s_new = 0;
     }
     __syncthreads();
     // the thread's rows: found once (hash rolled, name -> row walked), kept in registers for the second pass
     uint32_t cols[kPer];
+    uint16_t slots[kPer];
 #pragma unroll
-    for (uint32_t i = 0; i < kPer; ++i) cols[i] = kNoCol;
-    if (mine && w0 < w1) {
-      H fwd = 0, rc = 0;
-      int run = 0;
+    for (uint32_t i = 0; i < kPer; ++i) {
+      cols[i] = kNoCol;
+      slots[i] = 0xFFFFu;
+    }
+    const bool act = mine && w0 < w1;
+    H fwd = 0, rc = 0;
+    int run = 0;
+    if (act)
       for (int j = 0; j < k - 1; ++j) {
         const uint32_t c = base_code(seq[w0 + j]);
         fwd = ((fwd << 2) | (H)(c & 3u)) & mask;
         rc = (rc >> 2) | ((H)(3u - (c & 3u)) << shift);
         run = c < 4u ? run + 1 : 0;
       }
-#pragma unroll
-      for (uint32_t i = 0; i < kPer; ++i) {
-        const uint64_t w = w0 + i;
-        if (w < w1) {
-          const uint32_t c = base_code(seq[w + k - 1]);
-          fwd = ((fwd << 2) | (H)(c & 3u)) & mask;
-          rc = (rc >> 2) | ((H)(3u - (c & 3u)) << shift);
-          run = c < 4u ? run + 1 : 0;
-          if (run >= k && !(dbg & 8)) cols[i] = lookup_col(tv, (uint64_t)((content == KPOP_DNA_DS && rc < fwd) ? rc : fwd));
-        }
+    auto roll = [&](uint32_t i) {  // window w0 + i: its twister row
+      const uint64_t w = w0 + i;
+      if (act && w < w1) {
+        const uint32_t c = base_code(seq[w + k - 1]);
+        fwd = ((fwd << 2) | (H)(c & 3u)) & mask;
+        rc = (rc >> 2) | ((H)(3u - (c & 3u)) << shift);
+        run = c < 4u ? run + 1 : 0;
+        if (run >= k && !(dbg & 8)) cols[i] = lookup_col(tv, (uint64_t)((content == KPOP_DNA_DS && rc < fwd) ? rc : fwd));
       }
-    }
-    // ---- 1. the distinct rows into the set
-    uint16_t slots[kPer];
-#pragma unroll
-    for (uint32_t i = 0; i < kPer; ++i) {
-      slots[i] = 0xFFFFu;
+    };
+    auto insert = [&](uint32_t i) {  // ---- 1. the distinct rows into the set
       const uint32_t col = cols[i];
-      if (col == kNoCol || (dbg & 4)) continue;
-      if (*reinterpret_cast<volatile uint32_t *>(&s_over)) break;  // (a full table: no point in probing it further)
+      if (col == kNoCol || (dbg & 4)) return;
+      if (*reinterpret_cast<volatile uint32_t *>(&s_over)) return;  // (a full table: no point in probing it further)
       uint32_t slot = (col * 2654435761u) >> 21;  // 11 bits
 #pragma unroll 1
       for (int t = 0; t < 32; ++t) {
         const uint32_t prev = atomicCAS(&ht_key[slot], kNoCol, col);
         if (prev == col || prev == kNoCol) {
           slots[i] = (uint16_t)slot;
+          if (prev == kNoCol) atomicAdd(&s_new, 1u);
           break;
         }
         slot = (slot + 1) & (kTileH - 1);
       }
       if (slots[i] == 0xFFFFu) s_over = 1;
+    };
+    // A SAMPLE first -- every thread's first two windows, a sixteenth of the chunk: sequences that share little (unrelated
+    // genomes, a divergent stretch) show as many distinct rows as windows there, and the chunk is left to the streaming
+    // kernel for a sixteenth of what finding out at the end costs
+    constexpr uint32_t kProbe = 2;
+#pragma unroll
+    for (uint32_t i = 0; i < kProbe; ++i) roll(i);
+#pragma unroll
+    for (uint32_t i = 0; i < kProbe; ++i) insert(i);
+    __syncthreads();
+    if ((uint64_t)s_new * (kPer / kProbe) > kTileU + kTileU / 2) {  // (uniform: read after the barrier)
+      ++misses;
+      continue;
     }
+#pragma unroll
+    for (uint32_t i = kProbe; i < kPer; ++i) roll(i);
+#pragma unroll
+    for (uint32_t i = kProbe; i < kPer; ++i) insert(i);
     __syncthreads();
     {
       // number the occupied slots (thread order over the table: 2 slots a thread, a block-wide scan)
