@@ -95,7 +95,7 @@ int kpop_synchronize(void *stream);
    by the batch's density (2 also sends kpop_count_twist's batches of assemblies at small k through the dense image of
    their counts, kpop_dev_count_twist_dense, and at k <= 15 with >= 64 sequences tries the union compaction of
    one-organism batches first: 64 sequences x 512 windows share an LDS set of <= 1,024 twister rows and go to the matrix
-   cores, what does not fit stays with the streaming kernel; 3.0x on 0.1 % mutants, 0.90-0.94x on batches that do not
+   cores, what does not fit stays with the streaming kernel; 2.8x on 0.1 % mutants, 0.96x on batches that do not
    compact) -- the one knob that changes results, in the last bits; "ldspad" bytes of
    extra LDS per block of the fused reads kernel (an occupancy probe); "dbg" development switches (also KPOP_TUNE_DBG)  */
 int kpop_tune(const char *key, int value);
