@@ -741,13 +741,16 @@ def main():
             line["cpu_baseline"] = cb
             line["parity_check"] = parity
         if R.world == 1 and not args.no_extras:
+            # (the timed legs first, the counter passes after them: with the rocprofv3 --pmc children run BEFORE it, the
+            # pipeline leg of the same process came out at 38 M sequences/s instead of 50, four runs out of five --
+            # tools/probes/pcie_leg_repeat.py, the leg alone: 50.4-50.5, eight times out of eight)
+            line["pcie_inclusive"] = pcie_inclusive(R, n_local)
+            c4 = R.run_config4(1000000, max(3, min(args.steps, 10)), 2)
             live = measure_traffic(R, n_local)
             if live:
                 line["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
                 line["roofline"]["traffic_source"] = live["source"]
                 line["roofline"]["traffic_counters"] = {"FETCH_SIZE_KiB": live["FETCH_SIZE_KiB"], "WRITE_SIZE_KiB": live["WRITE_SIZE_KiB"]}
-            line["pcie_inclusive"] = pcie_inclusive(R, n_local)
-            c4 = R.run_config4(1000000, max(3, min(args.steps, 10)), 2)
             line["config4_on_this_gpu"] = {
                 "value": 1000000 * max(3, min(args.steps, 10)) / c4["elapsed"], "unit": "sequences/sec",
                 "ms_per_step": c4["elapsed"] / max(3, min(args.steps, 10)) * 1e3,
