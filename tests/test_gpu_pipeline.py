@@ -125,6 +125,33 @@ def test_pipeline_selected_outputs_and_tickets_in_flight(kpop, oracle):
         kpop.Pipeline(tw, classes, metric, outputs=0)
 
 
+def test_pipeline_library_chosen_chunks_with_batches_in_flight(kpop, oracle):
+    """chunk_reads = 0: the first batch is cut into chunks (a short first one), the batches submitted while it is in flight
+    go as ONE chunk each -- whatever the cut, every batch comes back with the same bits as a batch run alone"""
+    k, d, C, n = 9, 16, 5, 40000
+    bases, offs, cols, T, classes, metric = _problem(oracle, k, d, C, 31, n, max_len=70)
+    tw = kpop.Twister.load(T, cols, k)
+    want_tw, want_di, _ = _oracle_outputs(oracle, bases, offs, k, cols, T, classes, metric, 1)
+    pb = kpop.host_empty(len(bases), np.uint8)
+    pb[:] = bases
+    po = kpop.host_empty(len(offs), np.uint64)
+    po[:] = offs
+    pl = kpop.Pipeline(tw, classes, metric, outputs=kpop.OUT_TWISTED | kpop.OUT_DISTANCES)
+    alone = pl.run(pb, po)
+    assert pl.stats()["chunks"] >= 3  # 4,096 + 16,384 + ...
+    assert np.max(np.abs(alone["twisted"] - want_tw)) <= 1e-12 * max(1.0, np.max(np.abs(want_tw)))  # (D <= 32: the packed gather's tree)
+    outs = [pl.alloc_outputs(n) for _ in range(5)]
+    tickets = [pl.submit(pb, po, o) for o in outs]
+    chunks_last = pl.stats()["chunks"]
+    pl.collect(tickets[-1])
+    assert chunks_last == 1  # the fifth batch went up while the fourth was in flight
+    for o in outs:
+        assert np.array_equal(o["twisted"], alone["twisted"]) and np.array_equal(o["distances"], alone["distances"])
+    ok = want_di > 0
+    assert np.max(np.abs(alone["distances"][ok] - want_di[ok]) / want_di[ok]) <= 1e-12
+    pl.close()
+
+
 def test_pipeline_genomes_and_reads_mixed(kpop, oracle):
     """a genome among short reads: its chunk takes the streaming kernel (per-stream segment partials), the others the
     one-wavefront-per-read kernel; chunk_bases cuts chunks by size"""
