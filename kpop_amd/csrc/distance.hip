@@ -247,7 +247,7 @@ __device__ void block_merge_keys(double *kd, uint32_t NP) {
 // PRE = true: `a` is a ready r2 x r1 distance matrix (summarize_distance, lib/Matrix.ml:767-810) and row j is
 // only loaded; PRE = false: distances of m2 row j to every m1 row are computed here (summarize_rowwise).
 template <int KIND, bool PRE>
-__global__ __launch_bounds__(256) void distance_summary_kernel(
+__global__ __launch_bounds__(1024) void distance_summary_kernel(
     const double *__restrict__ a, uint32_t r1, const double *__restrict__ b, uint32_t r2, uint32_t n_dims,
     const double *__restrict__ metric, double p, uint32_t NP, uint32_t req_len, uint32_t max_neighbours,
     double *__restrict__ out_stats, uint32_t *__restrict__ out_n, uint32_t *__restrict__ out_idx,
@@ -280,34 +280,46 @@ __global__ __launch_bounds__(256) void distance_summary_kernel(
     ki[i] = (i < r1) ? i : 0xFFFFFFFFu;
   }
   block_sort_pairs(kd, ki, NP);
-  // lib/Matrix.ml:640-655, literally, by one thread: the multimap is walked in
-  // ascending order one distinct distance at a time
-  if (threadIdx.x == 0) {
-    uint32_t eff_len = 0;
-    long long median_pos = r1 / 2;
-    double median = 0.0, acc = 0.0;
-    for (uint32_t s = 0; s < r1;) {
+  // lib/Matrix.ml:640-655: the multimap is walked in ascending order one distinct distance at a time and set_len *. dist
+  // added up in that order.  The TERMS are worked out by all threads (a position that starts a group of equal distances
+  // finds its end; the others contribute +0.0, exact), the chain that adds them stays one thread's, in order -- but over
+  // terms that lie ready in LDS, eight loads ahead, instead of a walk whose every step waited for the one before
+  // (4,000 columns: ~0.2 ms a row; 100,000 rows against 1,000 / 4,000 columns: 13 -> 5.8 / 282 -> 98 ms).
+  if (threadIdx.x == 0) s_eff = r1;
+  __syncthreads();
+  for (uint32_t s = threadIdx.x; s < r1; s += blockDim.x) {
+    const double dd = kd[s];
+    const bool head = s == 0 || kd[s - 1] != dd;
+    double term = 0.0;
+    if (head) {
       uint32_t e = s + 1;
-      const double dd = kd[s];
       while (e < r1 && kd[e] == dd) ++e;
-      const long long set_len = e - s;
-      acc = __dadd_rn(acc, __dmul_rn((double)set_len, dd));
-      if (median_pos >= 0 && median_pos - set_len < 0) median = dd;
-      median_pos -= set_len;
-      if (eff_len < req_len) eff_len += (uint32_t)set_len;
-      s = e;
+      term = __dmul_rn((double)(e - s), dd);
+      if (s >= req_len) atomicMin(&s_eff, s);  // groups are added while eff_len < req_len (:648-649): the first boundary at or beyond it
     }
-    const double mean = (r1 > 0) ? acc / (double)r1 : 0.0;
+    dist[s] = term;  // (dist is put back in column order below)
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double acc = 0.0;
+#pragma unroll 8
+    for (uint32_t s = 0; s < r1; ++s) acc = __dadd_rn(acc, dist[s]);
+    s_stats[0] = (r1 > 0) ? acc / (double)r1 : 0.0;
+    s_stats[2] = (r1 > 0) ? kd[r1 / 2] : 0.0;  // the upper median: the group that holds position r1 / 2 (:645-647)
+  }
+  __syncthreads();
+  for (uint32_t s = threadIdx.x; s < r1; s += blockDim.x) dist[ki[s]] = kd[s];  // column order again
+  __syncthreads();
+  if (threadIdx.x == 0) {
     // :657-670 squared deviations in column order
-    acc = 0.0;
+    const double mean = s_stats[0];
+    double acc = 0.0;
+#pragma unroll 8
     for (uint32_t c = 0; c < r1; ++c) {
-      double dv = __dsub_rn(dist[c], mean);
+      const double dv = __dsub_rn(dist[c], mean);
       acc = __dadd_rn(acc, __dmul_rn(dv, dv));
     }
-    s_stats[0] = mean;
     s_stats[1] = (r1 > 1) ? sqrt(acc / ((double)r1 - 1.0)) : 0.0;  // :679-683
-    s_stats[2] = median;
-    s_eff = min(eff_len, r1);
   }
   __syncthreads();
   // neighbours: the first eff_len entries of the multimap (:685-689)
@@ -947,7 +959,10 @@ static int launch_summary(const double *a, uint32_t r1, const double *b, uint32_
     attr_set = true;
   }
   const uint32_t req_len = keep_at_most ? keep_at_most : r1;  // lib/Matrix.ml:723-726,774-777
-  distance_summary_kernel<KIND, PRE><<<dim3(r2), dim3(256), smem, st>>>(a, r1, b, r2, n_dims, metric, p, NP, req_len,
+  // (a row of 4,096 slots fills the LDS of a CU by itself: 1,024 threads on its sort -- 98 -> 64 ms for 100,000 rows against
+  // 4,000; below that several 256-thread blocks share a CU and more threads a block measured slower)
+  const uint32_t threads = NP >= 4096 ? 1024u : 256u;
+  distance_summary_kernel<KIND, PRE><<<dim3(r2), dim3(threads), smem, st>>>(a, r1, b, r2, n_dims, metric, p, NP, req_len,
                                                                         max_neighbours, out_stats, out_n, out_idx,
                                                                         out_dist, out_z);
   KPOP_LAUNCH_CHECK();
@@ -961,9 +976,11 @@ static int summary_impl(const double *m1, uint32_t r1, const double *m2, uint32_
                         double *out_z, hipStream_t st) {
   const double *a, *b;
   KPOP_TRY(prepare_operands<KIND>(m1, r1, m2, r2, n_dims, metric, p, normalize, work, &a, &b, st));
-  if (r1 >= 1 && r1 <= 512 && !summary_fits_wave(r1, n_dims, false) && ctx().tune_dbg != 4) {
-    // up to 512 rows too long for LDS (100 x 200 dimensions, 500 x 64): the distances of a chunk of second-operand rows
-    // into the workspace (the tiled kernel), then one wavefront per row over them -- not one block per row
+  if (r1 >= 1 && r1 <= kSummaryMaxR1 && !summary_fits_wave(r1, n_dims, false) && ctx().tune_dbg != 4) {
+    // A first operand that does not fit LDS (100 x 200 dimensions, 500 x 64, anything of 513..4,096 rows): the distances of
+    // a chunk of second-operand rows into the workspace (the tiled kernel), then the summary over them -- one wavefront per
+    // row up to 512 columns, one block per row sorting in LDS above.  Round 2's block kernel worked its distances out
+    // itself, every block reading the whole first operand: 100,000 rows against 1,000 / 4,000 took 23 / 320 ms.
     const uint32_t chunk = (uint32_t)std::min<uint64_t>(r2, std::max<uint64_t>(1024, (256ull << 20) / ((uint64_t)r1 * 8)));
     void *ws = nullptr;
     KPOP_TRY(ctx().ws_for(st).ensure((uint64_t)chunk * r1 * 8, &ws));
