@@ -27,7 +27,7 @@ namespace kpop {
 constexpr int kWavesPerBlock = 4;
 constexpr int kGatherUnroll = 8;   // row loads in flight per wave in the streaming kernels
 constexpr int kGatherPad = 16;     // LDS padding: the deepest gather unroll
-constexpr uint32_t kFewSpectra = 32768;  // below this many spectra twist_csr_kernel keeps 32 row loads in flight per wave
+constexpr uint32_t kFewSpectra = 8192;  // up to this many spectra (a wave each: one round of the chip) twist_csr_kernel keeps 32 row loads in flight per wave; with more, eight and more resident waves do better (20,000 x 139 lines: 0.194 -> 0.161 ms, 32,768 x 139: 0.311 -> 0.247 -- the threshold was 32,768)
 
 // ---------------------------------------------------------------------------
 // per-wave LDS
