@@ -126,6 +126,39 @@ def test_twist_long_spectrum(kpop, oracle):
     assert_close(tw.twist(h, c.astype(np.float64), o), oracle.twist(T, cols, h, c.astype(np.float64), o))
 
 
+@pytest.mark.parametrize("d,normalize", [(64, True), (100, False), (9, True)])
+def test_twist_few_very_long_spectra_in_segments(kpop, oracle, d, normalize):
+    """a handful of spectra of tens of thousands of lines (class spectra, genomes) are cut into segments, a wavefront each,
+    and the segments' sums added in order (twist_csr_kernel<.., SEG>): against the oracle, and against the one-wavefront-
+    per-spectrum kernel (kpop_tune("dbg", 131072)); ragged lengths, an empty spectrum, unknown k-mers, fractional values"""
+    from kpop_amd import api
+    rng = np.random.RandomState(d)
+    k = 9
+    allk = oracle.enumerate_kmers(k)
+    cols = allk[rng.rand(len(allk)) < 0.9]
+    T = oracle.synth_twister(5, d, cols)
+    tw = kpop.Twister.load(T, cols, k)
+    lens = [len(allk), 70000, 0, 16384, 33333, 5]
+    hs, vs, offs = [], [], [0]
+    for n in lens:
+        hh = np.sort(rng.choice(allk, size=min(n, len(allk)), replace=False)) if n else np.zeros(0, dtype=np.uint64)
+        hs.append(hh)
+        vs.append(np.round(rng.rand(len(hh)) * 50, 3) + 0.125)
+        offs.append(offs[-1] + len(hh))
+    h, v, o = np.concatenate(hs).astype(np.uint64), np.concatenate(vs), np.array(offs, dtype=np.uint64)
+    want = oracle.twist(T, cols, h, v, o, normalize=normalize)
+    got = tw.twist(h, v, o, normalize=normalize)
+    api.tune("dbg", 131072)
+    try:
+        plain = tw.twist(h, v, o, normalize=normalize)
+    finally:
+        api.tune("dbg", 0)
+    scale = max(1.0, np.max(np.abs(want)))
+    assert np.max(np.abs(got - want)) <= 1e-12 * scale and np.max(np.abs(plain - want)) <= 1e-12 * scale
+    assert not np.array_equal(got, plain)  # (another grouping of the additions: the segments did run)
+    assert np.array_equal(got, tw.twist(h, v, o, normalize=normalize))  # reproducible
+
+
 def test_headline_shape_sample_vs_oracle(kpop, oracle):
     """BASELINE headline shape: 100k x 150 bp, k=12, D=64, full synthetic twister (4.3 GB in HBM).
     Size-independent checks: determinism, normalised = unnormalised / n_kmers; plus a 400-read sample
