@@ -27,6 +27,7 @@ namespace kpop {
 constexpr int kWavesPerBlock = 4;
 constexpr int kGatherUnroll = 8;   // row loads in flight per wave in the streaming kernels
 constexpr int kGatherPad = 16;     // LDS padding: the deepest gather unroll
+constexpr uint64_t kCsrSegLines = 8192;  // a spectrum's sums are formed per stretch of this many lines and the stretches added in order, whichever kernel
 constexpr uint32_t kFewSpectra = 8192;  // up to this many spectra (a wave each: one round of the chip) twist_csr_kernel keeps 32 row loads in flight per wave; with more, eight and more resident waves do better (20,000 x 139 lines: 0.194 -> 0.161 ms, 32,768 x 139: 0.311 -> 0.247 -- the threshold was 32,768)
 
 // ---------------------------------------------------------------------------
@@ -313,16 +314,30 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void twist_csr_kernel(
         if (kcol[q] != kNoCol) part += kval[q];
       }
     }
-  } else if (!SEG) {
-    for (uint64_t i = lo + lane; i < hi; i += 64)
-      if (lookup_col(tv, hash[i]) != kNoCol) part += (double)value[i];
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
   double acc = part;
-  if (SEG) {  // the whole spectrum's acc: its segments' sums in segment order
-    acc = 0.0;
-    for (uint32_t g = 0; g < n_seg; ++g) acc = __dadd_rn(acc, acc_part[(uint64_t)spec * n_seg + g]);
+  // A spectrum's sums -- acc here, the twisted row below -- are formed per STRETCH of kCsrSegLines lines and the stretches
+  // added in order, in this kernel (one wave walks the stretches) as in its SEG form (a wave per stretch, added up by
+  // twist_csr_seg_combine_kernel): the same additions in the same order, so the same bits whichever launch a caller's
+  // batch gets.  Spectra of up to kCsrSegLines lines are one stretch: nothing changes for them.
+  if (KEEP == 0 && !SEG) {
+    bool first = true;
+    for (uint64_t s0 = lo; s0 < hi; s0 += kCsrSegLines) {
+      const uint64_t s1 = min(hi, s0 + kCsrSegLines);
+      double ps = 0.0;
+      for (uint64_t i = s0 + lane; i < s1; i += 64)
+        if (lookup_col(tv, hash[i]) != kNoCol) ps += (double)value[i];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ps += __shfl_xor(ps, o, 64);
+      acc = first ? ps : __dadd_rn(acc, ps);
+      first = false;
+    }
+  }
+  if (SEG) {  // the whole spectrum's acc: its stretches' sums in order
+    acc = acc_part[(uint64_t)spec * n_seg];
+    for (uint32_t g = 1; g < n_seg; ++g) acc = __dadd_rn(acc, acc_part[(uint64_t)spec * n_seg + g]);
   }
   const bool norm = normalize && acc != 0.0;
   // pass 2: 64 lines at a time through LDS, then the shared gather
@@ -330,9 +345,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void twist_csr_kernel(
   for (uint32_t d0 = 0; d0 < n_dims; d0 += 64) {
     const uint32_t d = d0 + lane;
     const bool active = d < n_dims;
-    double t = 0.0;
+    double t = 0.0, t_done = 0.0;  // t: the current stretch; t_done: the stretches before it
+    bool any_done = false;
     int q = 0;
     for (uint64_t i0 = lo; i0 < hi; i0 += 64, ++q) {
+      if (KEEP == 0 && !SEG && i0 != lo && (i0 - lo) % kCsrSegLines == 0) {  // (uniform) a stretch ends
+        t_done = any_done ? __dadd_rn(t_done, t) : t;
+        any_done = true;
+        t = 0.0;
+      }
       const uint64_t i = i0 + lane;
       uint32_t col = kNoCol;
       double x = 0.0;
@@ -383,6 +404,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void twist_csr_kernel(
         }
       }
     }
+    if (any_done) t = __dadd_rn(t_done, t);
     if (active) out[(uint64_t)s * n_dims + d] = t;
   }
 }
@@ -413,8 +435,8 @@ __global__ __launch_bounds__(256) void twist_csr_seg_combine_kernel(const double
                                                                     double *__restrict__ out) {
   const uint32_t spec = blockIdx.x;
   for (uint32_t d = threadIdx.x; d < n_dims; d += blockDim.x) {
-    double t = 0.0;
-    for (uint32_t g = 0; g < n_seg; ++g) t = __dadd_rn(t, partial[((uint64_t)spec * n_seg + g) * n_dims + d]);
+    double t = partial[(uint64_t)spec * n_seg * n_dims + d];
+    for (uint32_t g = 1; g < n_seg; ++g) t = __dadd_rn(t, partial[((uint64_t)spec * n_seg + g) * n_dims + d]);
     out[(uint64_t)spec * n_dims + d] = t;
   }
 }
@@ -427,9 +449,9 @@ static int launch_twist_csr(const TwisterView &tv, const uint64_t *hash, const V
   const bool few = n <= kFewSpectra;
   // A few very long spectra: segments, so that the whole chip works on them (see the kernel).  An empty segment adds +0.0.
   if (max_lines >= 16384 && n <= 2048 && !(ctx().tune_dbg & 131072)) {
-    const uint32_t n_seg = (uint32_t)std::min<uint64_t>(64, std::min<uint64_t>(div_up(max_lines, 4096), 8192 / n));
-    if (n_seg >= 2) {
-      const uint64_t seg_lines = (div_up(max_lines, n_seg) + 63) / 64 * 64;
+    const uint32_t n_seg = (uint32_t)div_up(max_lines, kCsrSegLines);  // (stretches of a fixed length: see the kernel)
+    if (n_seg >= 2 && (uint64_t)n * n_seg <= (1u << 22)) {
+      const uint64_t seg_lines = kCsrSegLines;
       const uint64_t bytes_acc = ((uint64_t)n * n_seg * 8 + 255) & ~255ull;
       void *ws = nullptr;
       KPOP_TRY(ctx().ws_for(st).ensure(bytes_acc + (uint64_t)n * n_seg * tv.n_dims * 8, &ws));
@@ -488,13 +510,27 @@ constexpr uint32_t kSegWindows = 16384;    // upper bound of a segment
 // (a batch of assemblies is one species more often than not, and there plain loads are 1.5x faster).
 constexpr uint64_t kStreamingRowBytes = 2ull << 30;
 
+// nseg[r] = the segments of sequence r (0: the one-wavefront-per-read kernel's), and the list of the sequences that have
+// any (wave-aggregated append: the order of the list is not the batch's, and nothing depends on it).  The streaming kernel
+// and the combine walk the LIST: one genome among 100,000 reads cost 0.66 ms of looking at pairs that had no segment.
 __global__ void segment_count_kernel(const uint64_t *__restrict__ offsets, uint32_t n, int k, uint32_t seg_windows,
-                                     uint32_t *__restrict__ nseg) {
+                                     uint32_t *__restrict__ nseg, uint32_t *__restrict__ long_ids, uint32_t *__restrict__ n_long) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n) return;
-  const uint64_t len = offsets[r + 1] - offsets[r];
-  const uint64_t w = (len >= (uint64_t)k) ? len - k + 1 : 0;
-  nseg[r] = (w > kWaveMaxWindows) ? (uint32_t)((w + seg_windows - 1) / seg_windows) : 0u;
+  uint32_t ns = 0;
+  if (r < n) {
+    const uint64_t len = offsets[r + 1] - offsets[r];
+    const uint64_t w = (len >= (uint64_t)k) ? len - k + 1 : 0;
+    ns = (w > kWaveMaxWindows) ? (uint32_t)((w + seg_windows - 1) / seg_windows) : 0u;
+    nseg[r] = ns;
+  }
+  const uint64_t m = __ballot(ns != 0);
+  if (m) {
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(n_long, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (ns) long_ids[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+  }
 }
 
 struct StoreU64 {
@@ -506,10 +542,12 @@ template <typename H, bool NT>
 __global__ __launch_bounds__(256) void count_twist_stream_kernel(
     TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int content,
     const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ seg_off, double *__restrict__ partial,
-    uint32_t *__restrict__ partial_cnt, uint32_t n_reads, uint32_t max_seg, uint32_t seg_windows,
-    const uint8_t *__restrict__ tile_done = nullptr, uint32_t n_groups = 0) {
+    uint32_t *__restrict__ partial_cnt, const uint32_t *__restrict__ long_ids, const uint32_t *__restrict__ n_long_ptr, uint32_t max_seg,
+    uint32_t seg_windows, const uint8_t *__restrict__ tile_done = nullptr, uint32_t n_groups = 0) {
   __shared__ double s_part[4][64];
   __shared__ uint32_t s_cnt[4];
+  const uint32_t n_reads = *n_long_ptr;  // the sequences that have segments (long_ids), not the batch
+  if (n_reads == 0) return;
   // (segment, read) pairs are dealt to blocks round-robin, READS FASTEST: the blocks in flight at any moment work on the
   // same stretch of many sequences.  Assemblies of one organism are near-identical (BASELINE config 3), so those blocks
   // gather the same twister rows -- a segment's rows (seg_windows x d_pad x 8 B, sized to sit in an XCD's 4 MB L2) come
@@ -518,7 +556,7 @@ __global__ __launch_bounds__(256) void count_twist_stream_kernel(
   // are empty, hence the grid-stride loop.
   const uint64_t n_pairs = (uint64_t)n_reads * max_seg;
   for (uint64_t pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
-  const uint32_t seg = (uint32_t)(pair / n_reads), r = (uint32_t)(pair % n_reads);
+  const uint32_t seg = (uint32_t)(pair / n_reads), r = long_ids[pair % n_reads];
   if (seg >= nseg[r]) continue;
   if (tile_done && tile_done[(uint64_t)seg * n_groups + r / 64]) continue;  // (count_twist_tile_kernel has written this segment's sums)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -844,8 +882,10 @@ __global__ __launch_bounds__(256) void combine_partials_kernel(const uint32_t *_
                                                                const double *__restrict__ partial,
                                                                const uint32_t *__restrict__ partial_cnt,
                                                                uint32_t n_dims, int normalize,
-                                                               double *__restrict__ out) {
-  const uint32_t r = blockIdx.x;
+                                                               double *__restrict__ out, const uint32_t *__restrict__ long_ids,
+                                                               const uint32_t *__restrict__ n_long_ptr) {
+  if (blockIdx.x >= *n_long_ptr) return;
+  const uint32_t r = long_ids[blockIdx.x];
   const uint32_t ns = nseg[r];
   if (ns == 0) return;
   const uint64_t s0 = seg_off[r];
@@ -1029,9 +1069,10 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   const uint32_t n_groups = div_up(n_reads, kTileG);
   const uint64_t bytes_nseg = ((uint64_t)n_reads * 4 + 63) & ~63ull, bytes_off = ((uint64_t)(n_reads + 1) * 8 + 63) & ~63ull,
                  bytes_sums = ((nb + 1) * 8 + 63) & ~63ull, bytes_cnt = (max_slots * 4 + 63) & ~63ull,
-                 bytes_part = (max_slots * tw->n_dims * 8 + 63) & ~63ull, bytes_done = tiles ? (((uint64_t)n_groups * max_seg + 63) & ~63ull) : 0;
+                 bytes_part = (max_slots * tw->n_dims * 8 + 63) & ~63ull, bytes_done = tiles ? (((uint64_t)n_groups * max_seg + 63) & ~63ull) : 0,
+                 bytes_long = ((uint64_t)n_reads * 4 + 64 + 63) & ~63ull;
   void *ws = nullptr;
-  KPOP_TRY(ctx().ws_for(st).ensure(bytes_nseg + bytes_off + bytes_sums + bytes_cnt + bytes_part + bytes_done, &ws));
+  KPOP_TRY(ctx().ws_for(st).ensure(bytes_nseg + bytes_off + bytes_sums + bytes_cnt + bytes_part + bytes_done + bytes_long, &ws));
   char *wp = reinterpret_cast<char *>(ws);
   uint32_t *nseg = reinterpret_cast<uint32_t *>(wp);
   uint64_t *seg_off = reinterpret_cast<uint64_t *>(wp + bytes_nseg);
@@ -1039,8 +1080,13 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   uint32_t *pcnt = reinterpret_cast<uint32_t *>(wp + bytes_nseg + bytes_off + bytes_sums);
   double *part = reinterpret_cast<double *>(wp + bytes_nseg + bytes_off + bytes_sums + bytes_cnt);
   uint8_t *tile_done = tiles ? reinterpret_cast<uint8_t *>(wp + bytes_nseg + bytes_off + bytes_sums + bytes_cnt + bytes_part) : nullptr;
-  segment_count_kernel<<<dim3(div_up(n_reads, 256)), dim3(256), 0, st>>>(d_offsets, n_reads, tv.hk, seg_windows, nseg);
+  uint32_t *n_long = reinterpret_cast<uint32_t *>(wp + bytes_nseg + bytes_off + bytes_sums + bytes_cnt + bytes_part + bytes_done);
+  uint32_t *long_ids = n_long + 16;
+  KPOP_HIP(hipMemsetAsync(n_long, 0, 64, st));
+  segment_count_kernel<<<dim3(div_up(n_reads, 256)), dim3(256), 0, st>>>(d_offsets, n_reads, tv.hk, seg_windows, nseg, long_ids, n_long);
   KPOP_LAUNCH_CHECK();
+  // (a sequence with segments has more than kWaveMaxWindows windows: at most this many of them)
+  const uint32_t max_long = (uint32_t)std::min<uint64_t>(n_reads, n_bases / kWaveMaxWindows + 1);
   KPOP_TRY(exclusive_scan(LoadU32{nseg}, StoreU64{seg_off}, n_reads, sums, st));
   if (tiles) {
     KPOP_HIP(hipMemsetAsync(tile_done, 0, bytes_done, st));
@@ -1055,8 +1101,8 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
                                                                            max_seg, tile_done, ctx().tune_dbg >> 24);
     KPOP_LAUNCH_CHECK();
   }
-  dim3 grid(capped_grid((uint64_t)n_reads * max_seg));
-#define KPOP_STREAM(H, NT) count_twist_stream_kernel<H, NT><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, n_reads, max_seg, seg_windows, tile_done, n_groups)
+  dim3 grid(capped_grid((uint64_t)max_long * max_seg));
+#define KPOP_STREAM(H, NT) count_twist_stream_kernel<H, NT><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, long_ids, n_long, max_seg, seg_windows, tile_done, n_groups)
   if (tv.hk <= 15) {
     if (nt) KPOP_STREAM(uint32_t, true); else KPOP_STREAM(uint32_t, false);
   } else {
@@ -1064,7 +1110,7 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   }
 #undef KPOP_STREAM
   KPOP_LAUNCH_CHECK();
-  combine_partials_kernel<<<dim3(n_reads), dim3(256), 0, st>>>(nseg, seg_off, part, pcnt, tw->n_dims, normalize, d_out);
+  combine_partials_kernel<<<dim3(max_long), dim3(256), 0, st>>>(nseg, seg_off, part, pcnt, tw->n_dims, normalize, d_out, long_ids, n_long);
   KPOP_LAUNCH_CHECK();
   return KPOP_OK;
 }
