@@ -89,7 +89,14 @@ struct Context {
   int tune_nt = 2;       // row loads: 0 plain, 1 non-temporal, 2 by the size of the twister (count_twist.hip)
   int tune_seg = 0;      // windows per segment of the genome kernel, 0 = sized to the L2
   int tune_ldspad = 0;   // extra dynamic LDS per block of the fused reads kernel: fewer resident blocks (an occupancy probe)
-  int tune_dbg = 0;      // development probes (count_wave_kernel: 1 = no look-back, 2 = no ticket); results are WRONG when set
+  // development probes and A/B switches (kpop_tune("dbg", bits), KPOP_TUNE_DBG); results may be WRONG when the low ones are set:
+  //   1, 2             count_wave_kernel: no look-back / no ticket          4 (the whole value)  summaries: the block kernel, not the wave kernel
+  //   & 15             ca: inner sweeps of the blocked Jacobi step           32, 64, 2048         ca: plain steps / the looped kernel / no factor route
+  //   256              counter: the median kernel's staging alone            4096, 8192, 16384    distance_rowwise: tile choices
+  //   32768            wave summary: the doubled network instead of the tail   (>> 16) & 15       wave summary ablation: sort, chains, MAD, distances
+  //   (>> 20) & 7      fused dense twist ablation                             (>> 24) & 15         count_twist_tile_kernel ablation: MFMA, X, set, lookups
+  //   1 << 28          CSR twist: one wavefront per spectrum even for a few very long spectra (same bits as the segmented launch)
+  int tune_dbg = 0;
   int tune_dense = 0;    // kpop_twist: 0 sparse mat-vec (the reference's order), 1 dense contraction on the matrix cores, 2 by density
   int tune_blocksort = 1;  // -L on sequences of up to 32,768 windows: one block per sequence, sorted in LDS (0: device-wide sort)
   int tune_hist = 1;     // merged (-l) spectrum by atomic histogram when the hashes fit 26 bits (0: always sort)

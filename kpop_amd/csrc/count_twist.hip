@@ -448,7 +448,7 @@ static int launch_twist_csr(const TwisterView &tv, const uint64_t *hash, const V
   const dim3 grid(div_up(n, kWavesPerBlock)), block(64 * kWavesPerBlock);
   const bool few = n <= kFewSpectra;
   // A few very long spectra: segments, so that the whole chip works on them (see the kernel).  An empty segment adds +0.0.
-  if (max_lines >= 16384 && n <= 2048 && !(ctx().tune_dbg & 131072)) {
+  if (max_lines >= 16384 && n <= 2048 && !(ctx().tune_dbg & (1 << 28))) {
     const uint32_t n_seg = (uint32_t)div_up(max_lines, kCsrSegLines);  // (stretches of a fixed length: see the kernel)
     if (n_seg >= 2 && (uint64_t)n * n_seg <= (1u << 22)) {
       const uint64_t seg_lines = kCsrSegLines;

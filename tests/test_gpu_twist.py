@@ -130,7 +130,7 @@ def test_twist_long_spectrum(kpop, oracle):
 def test_twist_few_very_long_spectra_in_segments(kpop, oracle, d, normalize):
     """a handful of spectra of tens of thousands of lines (class spectra, genomes) are cut into stretches of 8,192 lines, a
     wavefront each, and the stretches' sums added in order (twist_csr_kernel<.., SEG>): against the oracle, and bit for bit
-    against the one-wavefront-per-spectrum kernel, which walks the same stretches (kpop_tune("dbg", 131072)); ragged
+    against the one-wavefront-per-spectrum kernel, which walks the same stretches (kpop_tune("dbg", 1 << 28)); ragged
     lengths, an empty spectrum, unknown k-mers, fractional values"""
     from kpop_amd import api
     rng = np.random.RandomState(d)
@@ -149,7 +149,7 @@ def test_twist_few_very_long_spectra_in_segments(kpop, oracle, d, normalize):
     h, v, o = np.concatenate(hs).astype(np.uint64), np.concatenate(vs), np.array(offs, dtype=np.uint64)
     want = oracle.twist(T, cols, h, v, o, normalize=normalize)
     got = tw.twist(h, v, o, normalize=normalize)
-    api.tune("dbg", 131072)
+    api.tune("dbg", 1 << 28)
     try:
         plain = tw.twist(h, v, o, normalize=normalize)
     finally:
