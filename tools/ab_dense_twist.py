@@ -26,7 +26,7 @@ def main():
     kpop_amd.init(0)
     dev = torch.device("cuda", 0)
     st = torch.cuda.current_stream()
-    d = 64
+    d = int(os.environ.get("AB_DIMS", "64"))
 
     def timed(fn):
         fn()
