@@ -538,13 +538,15 @@ struct StoreU64 {
   __device__ void operator()(uint64_t i, uint64_t prefix, uint32_t) const { out[i] = prefix; }
 };
 
-template <typename H, bool NT>
+// NDB: blocks of 64 dimensions a lane sums per pass over the windows (1, 2 or 4): with more than 64 dimensions the windows
+// are hashed and looked up ONCE per 64 NDB dimensions, not once per 64 (every dimension's sum is the same chain either way).
+template <typename H, bool NT, int NDB = 1>
 __global__ __launch_bounds__(256) void count_twist_stream_kernel(
     TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int content,
     const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ seg_off, double *__restrict__ partial,
     uint32_t *__restrict__ partial_cnt, const uint32_t *__restrict__ long_ids, const uint32_t *__restrict__ n_long_ptr, uint32_t max_seg,
-    uint32_t seg_windows, const uint8_t *__restrict__ tile_done = nullptr, uint32_t n_groups = 0) {
-  __shared__ double s_part[4][64];
+    uint32_t seg_windows, const uint8_t *__restrict__ tile_done, uint32_t n_groups, uint32_t d_begin, uint32_t d_end) {
+  __shared__ double s_part[4][64 * NDB];
   __shared__ uint32_t s_cnt[4];
   const uint32_t n_reads = *n_long_ptr;  // the sequences that have segments (long_ids), not the batch
   if (n_reads == 0) return;
@@ -569,15 +571,19 @@ __global__ __launch_bounds__(256) void count_twist_stream_kernel(
   const uint8_t *seq = bases + off;
   const int shift = 2 * (k - 1);
   const uint64_t slot = seg_off[r] + seg;
-  for (uint32_t d0 = 0; d0 < tv.n_dims; d0 += 64) {
-    const uint32_t d = d0 + lane;
-    const bool active = d < tv.n_dims;
+  for (uint32_t d0 = d_begin; d0 < d_end; d0 += 64 * NDB) {  // (the launch's share of the dimensions: see the host side)
     // (lanes past the last dimension load a column that exists and keep a sum nobody reads; a window without a row loads
     // row 0 and adds 0.0: no branch and no exec juggling per window -- the compiler's version of the conditional load was
     // thirteen instructions and a branch a window, 151 registers, three wavefronts a SIMD; 5,000 x 30 kb on one box:
     // 6.39 -> 5.74 ms for mutants of one genome, 13.09 -> 12.66 ms for unrelated ones)
-    const double *base = tv.rows + (active ? d : tv.n_dims - 1);
-    double acc = 0.0;
+    const double *base[NDB];
+    double acc[NDB];
+#pragma unroll
+    for (int b = 0; b < NDB; ++b) {
+      const uint32_t d = d0 + 64u * b + lane;
+      base[b] = tv.rows + (d < tv.n_dims ? d : tv.n_dims - 1);
+      acc[b] = 0.0;
+    }
     uint32_t cnt = 0;
     for (uint64_t cb = w0 + (uint64_t)wv * 64; cb < w1; cb += 4 * 64) {
       const uint64_t win = cb + lane;
@@ -594,29 +600,41 @@ __global__ __launch_bounds__(256) void count_twist_stream_kernel(
         if (good) col = lookup_col(tv, (uint64_t)((content == KPOP_DNA_DS && rc < fwd) ? rc : fwd));
       }
       cnt += (uint32_t)__popcll(__ballot(col != kNoCol));
+      constexpr int GU = kGatherUnroll / (NDB > 2 ? 2 : 1);  // rows in flight (x NDB loads each)
 #pragma unroll
-      for (int j0 = 0; j0 < 64; j0 += kGatherUnroll) {
-        double v[kGatherUnroll];
+      for (int j0 = 0; j0 < 64; j0 += GU) {
+        double v[GU][NDB];
 #pragma unroll
-        for (int u = 0; u < kGatherUnroll; ++u) {
+        for (int u = 0; u < GU; ++u) {
           const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)col, j0 + u);
           const uint32_t cs = cj != kNoCol ? cj : 0u;  // (scalar)
-          const double x = NT ? __builtin_nontemporal_load(base + (uint64_t)cs * tv.d_pad) : base[(uint64_t)cs * tv.d_pad];
-          v[u] = cj != kNoCol ? x : 0.0;
+#pragma unroll
+          for (int b = 0; b < NDB; ++b) {
+            const double x = NT ? __builtin_nontemporal_load(base[b] + (uint64_t)cs * tv.d_pad) : base[b][(uint64_t)cs * tv.d_pad];
+            v[u][b] = cj != kNoCol ? x : 0.0;
+          }
         }
 #pragma unroll
-        for (int u = 0; u < kGatherUnroll; ++u) acc = __dadd_rn(acc, v[u]);
+        for (int u = 0; u < GU; ++u)
+#pragma unroll
+          for (int b = 0; b < NDB; ++b) acc[b] = __dadd_rn(acc[b], v[u][b]);
       }
     }
     __syncthreads();
-    s_part[wv][lane] = acc;
+#pragma unroll
+    for (int b = 0; b < NDB; ++b) s_part[wv][64 * b + lane] = acc[b];
     if (lane == 0) s_cnt[wv] = cnt;
     __syncthreads();
     if (wv == 0) {
-      double t = __dadd_rn(__dadd_rn(__dadd_rn(s_part[0][lane], s_part[1][lane]), s_part[2][lane]), s_part[3][lane]);
-      if (active) partial[slot * tv.n_dims + d] = t;
+#pragma unroll
+      for (int b = 0; b < NDB; ++b) {
+        const uint32_t d = d0 + 64u * b + lane;
+        const double t = __dadd_rn(__dadd_rn(__dadd_rn(s_part[0][64 * b + lane], s_part[1][64 * b + lane]), s_part[2][64 * b + lane]), s_part[3][64 * b + lane]);
+        if (d < tv.n_dims) partial[slot * tv.n_dims + d] = t;
+      }
       if (d0 == 0 && lane == 0) partial_cnt[slot] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     }
+    __syncthreads();  // (s_part is the next pass's)
   }
   __syncthreads();
   }
@@ -1102,13 +1120,34 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
     KPOP_LAUNCH_CHECK();
   }
   dim3 grid(capped_grid((uint64_t)max_long * max_seg));
-#define KPOP_STREAM(H, NT) count_twist_stream_kernel<H, NT><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, long_ids, n_long, max_seg, seg_windows, tile_done, n_groups)
+  // The dimensions go in passes of up to 256 (four blocks of 64 a lane), 128 or 64 -- one LAUNCH per pass, so that a pass never
+  // loads blocks it has no dimensions for (300 dimensions: 256 + 44; a run-time guard on the loads brought the per-window
+  // branches back: 2.4 -> 5.2 ms at 64 dimensions).  Every launch hashes the windows again: once per 256 dimensions, not per 64.
+#define KPOP_STREAM_B(H, NT, B, D0, D1) count_twist_stream_kernel<H, NT, B><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, long_ids, n_long, max_seg, seg_windows, tile_done, n_groups, D0, D1)
+#define KPOP_STREAM(H, NT)                                                        \
+  do {                                                                            \
+    for (uint32_t pos = 0; pos < tw->n_dims;) {                                    \
+      const uint32_t rem = tw->n_dims - pos;                                      \
+      if (rem > 128) {                                                            \
+        const uint32_t take = std::min(rem, 256u);                                \
+        KPOP_STREAM_B(H, NT, 4, pos, pos + take);                                 \
+        pos += take;                                                              \
+      } else if (rem > 64) {                                                      \
+        KPOP_STREAM_B(H, NT, 2, pos, pos + rem);                                  \
+        pos += rem;                                                               \
+      } else {                                                                    \
+        KPOP_STREAM_B(H, NT, 1, pos, pos + rem);                                  \
+        pos += rem;                                                               \
+      }                                                                           \
+    }                                                                             \
+  } while (0)
   if (tv.hk <= 15) {
     if (nt) KPOP_STREAM(uint32_t, true); else KPOP_STREAM(uint32_t, false);
   } else {
     if (nt) KPOP_STREAM(uint64_t, true); else KPOP_STREAM(uint64_t, false);
   }
 #undef KPOP_STREAM
+#undef KPOP_STREAM_B
   KPOP_LAUNCH_CHECK();
   combine_partials_kernel<<<dim3(max_long), dim3(256), 0, st>>>(nseg, seg_off, part, pcnt, tw->n_dims, normalize, d_out, long_ids, n_long);
   KPOP_LAUNCH_CHECK();
