@@ -902,19 +902,21 @@ __global__ __launch_bounds__(256) void combine_partials_kernel(const uint32_t *_
                                                                uint32_t n_dims, int normalize,
                                                                double *__restrict__ out, const uint32_t *__restrict__ long_ids,
                                                                const uint32_t *__restrict__ n_long_ptr) {
-  if (blockIdx.x >= *n_long_ptr) return;
-  const uint32_t r = long_ids[blockIdx.x];
-  const uint32_t ns = nseg[r];
-  if (ns == 0) return;
-  const uint64_t s0 = seg_off[r];
-  uint64_t found = 0;
-  for (uint32_t s = 0; s < ns; ++s) found += partial_cnt[s0 + s];
-  const double acc = (double)found;  // lib/Twister.ml:158, exact: integer counts
-  const bool norm = normalize && acc != 0.0;
-  for (uint32_t d = threadIdx.x; d < n_dims; d += blockDim.x) {
-    double t = 0.0;
-    for (uint32_t s = 0; s < ns; ++s) t = __dadd_rn(t, partial[(s0 + s) * n_dims + d]);
-    out[(uint64_t)r * n_dims + d] = norm ? t / acc : t;
+  const uint32_t n_long = *n_long_ptr;
+  for (uint32_t b = blockIdx.x; b < n_long; b += gridDim.x) {  // (the grid is sized from the caller's n_bases: a stride, should that understate)
+    const uint32_t r = long_ids[b];
+    const uint32_t ns = nseg[r];
+    if (ns == 0) continue;
+    const uint64_t s0 = seg_off[r];
+    uint64_t found = 0;
+    for (uint32_t s = 0; s < ns; ++s) found += partial_cnt[s0 + s];
+    const double acc = (double)found;  // lib/Twister.ml:158, exact: integer counts
+    const bool norm = normalize && acc != 0.0;
+    for (uint32_t d = threadIdx.x; d < n_dims; d += blockDim.x) {
+      double t = 0.0;
+      for (uint32_t s = 0; s < ns; ++s) t = __dadd_rn(t, partial[(s0 + s) * n_dims + d]);
+      out[(uint64_t)r * n_dims + d] = norm ? t / acc : t;
+    }
   }
 }
 
