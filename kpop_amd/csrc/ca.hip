@@ -507,7 +507,7 @@ __global__ void jacobi_identity_kernel(double *__restrict__ V, uint32_t n) {
 constexpr int kCholW = 64;
 
 __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ A, uint32_t n, uint32_t j0, uint32_t w, double tol,
-                                                        double *__restrict__ D) {
+                                                        double *__restrict__ D, uint32_t *__restrict__ n_dead) {
   __shared__ double s[kCholW][kCholW + 1];  // s[c][r]: row r of column c
   for (uint32_t e = threadIdx.x; e < (uint32_t)kCholW * kCholW; e += 256) {
     const uint32_t c = e / kCholW, r = e % kCholW;
@@ -517,6 +517,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ A, 
   for (uint32_t k = 0; k < w; ++k) {
     const double d = s[k][k];
     const bool dead = !(d > tol);
+    if (dead && threadIdx.x == 0) atomicAdd(n_dead, 1u);
     const double root = dead ? 0.0 : sqrt(d);
     __syncthreads();  // everyone has the pivot
     for (uint32_t r = k + threadIdx.x; r < w; r += 256) s[k][r] = (r == k) ? root : (dead ? 0.0 : s[k][r] / root);
@@ -602,7 +603,8 @@ __global__ __launch_bounds__(256) void jacobi_unit_columns_kernel(const double *
   for (uint32_t i = threadIdx.x; i < n; i += 256) V[(uint64_t)blockIdx.x * n + i] = norm > 0.0 ? a[i] / norm : 0.0;
 }
 
-static int cholesky_in_place(double *d_A, uint32_t n, double *d_scratch /* n x n */, hipStream_t st) {
+// *dead_out: the pivots at or below the tolerance (their columns are zeroed, not pivoted around)
+static int cholesky_in_place(double *d_A, uint32_t n, double *d_scratch /* n x n */, hipStream_t st, uint32_t *dead_out) {
   // the tolerance of a pivot: the largest diagonal entry of G times a few thousand roundings
   std::vector<double> diag(n);
   KPOP_HIP(hipMemcpy2DAsync(diag.data(), 8, d_A, (size_t)(n + 1) * 8, 8, n, hipMemcpyDeviceToHost, st));
@@ -611,10 +613,12 @@ static int cholesky_in_place(double *d_A, uint32_t n, double *d_scratch /* n x n
   for (double v : diag) mx = std::max(mx, v);
   const double tol = mx * 1e-13;
   DevBuf dD;
-  KPOP_TRY(dD.alloc((uint64_t)kCholW * kCholW * 8));
+  KPOP_TRY(dD.alloc((uint64_t)kCholW * kCholW * 8 + 64));
+  uint32_t *d_dead = reinterpret_cast<uint32_t *>(dD.as<double>() + (uint64_t)kCholW * kCholW);
+  KPOP_HIP(hipMemsetAsync(d_dead, 0, 4, st));
   for (uint32_t j0 = 0; j0 < n; j0 += kCholW) {
     const uint32_t w = std::min<uint32_t>(kCholW, n - j0), m = n - j0 - w;
-    chol_diag_kernel<<<dim3(1), dim3(256), 0, st>>>(d_A, n, j0, w, tol, dD.as<double>());
+    chol_diag_kernel<<<dim3(1), dim3(256), 0, st>>>(d_A, n, j0, w, tol, dD.as<double>(), d_dead);
     KPOP_LAUNCH_CHECK();
     if (m == 0) break;
     chol_panel_kernel<<<dim3(div_up(m, 256)), dim3(256), 0, st>>>(d_A, n, j0, w, dD.as<double>());
@@ -627,6 +631,8 @@ static int cholesky_in_place(double *d_A, uint32_t n, double *d_scratch /* n x n
   }
   chol_zero_upper_kernel<<<dim3(std::min<uint32_t>(div_up((uint64_t)n * n, 256), 4096)), dim3(256), 0, st>>>(d_A, n);
   KPOP_LAUNCH_CHECK();
+  KPOP_HIP(hipMemcpyAsync(dead_out, d_dead, 4, hipMemcpyDeviceToHost, st));
+  KPOP_HIP(hipStreamSynchronize(st));
   return 0;
 }
 
@@ -646,9 +652,25 @@ static int jacobi_eigen_psd_device(double *d_G, double *d_V, uint32_t n, double 
   const bool blocked = n >= 4 * kJC && !(ctx().tune_dbg & 32);  // (32: the plain steps, for A/B)
   // From 32 columns up to what the register kernel holds: Jacobi on the Cholesky factor of G, no V to rotate.  (2048: on G
   // itself with V accumulated, as below that size and above it, for A/B.)
-  const bool on_factor = blocked && n <= 2048 && !(ctx().tune_dbg & (64 | 2048));
-  if (on_factor) KPOP_TRY(cholesky_in_place(d_G, n, d_V, st));
-  else {
+  bool on_factor = blocked && n <= 2048 && !(ctx().tune_dbg & (64 | 2048));
+  if (on_factor) {
+    // The factorisation does not pivot: a pivot at the rounding floor is declared dead and its column zeroed.  A Gram matrix
+    // of standardised residuals has ONE such direction by construction (the trivial axis); MORE of them mean near-dependent
+    // columns (near-duplicate classes), where the couplings dropped with the dead columns would show in the eigenvectors at
+    // ~1e-7 relative, not 1e-13.  Then G is put back and the iteration runs on G itself, as it does above 2,048.
+    DevBuf keep;
+    KPOP_TRY(keep.alloc((uint64_t)n * n * 8));
+    KPOP_HIP(hipMemcpyAsync(keep.p, d_G, (uint64_t)n * n * 8, hipMemcpyDeviceToDevice, st));
+    uint32_t dead = 0;
+    KPOP_TRY(cholesky_in_place(d_G, n, d_V, st, &dead));
+    if (dead > 1 && !(ctx().tune_dbg & (1 << 29))) {  // (1 << 29: stay on the factor, for A/B)
+      if (getenv("KPOP_JACOBI_TRACE")) fprintf(stderr, "[jacobi] %u pivots at the rounding floor: the iteration runs on G, not on its factor\n", dead);
+      KPOP_HIP(hipMemcpyAsync(d_G, keep.p, (uint64_t)n * n * 8, hipMemcpyDeviceToDevice, st));
+      KPOP_HIP(hipStreamSynchronize(st));
+      on_factor = false;
+    }
+  }
+  if (!on_factor) {
     jacobi_identity_kernel<<<dim3(std::min<uint32_t>(div_up((uint64_t)n * n, 256), 4096)), dim3(256), 0, st>>>(d_V, n);
     KPOP_LAUNCH_CHECK();
   }

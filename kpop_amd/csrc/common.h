@@ -96,6 +96,7 @@ struct Context {
   //   32768            wave summary: the doubled network instead of the tail   (>> 16) & 15       wave summary ablation: sort, chains, MAD, distances
   //   (>> 20) & 7      fused dense twist ablation                             (>> 24) & 15         count_twist_tile_kernel ablation: MFMA, X, set, lookups
   //   1 << 28          CSR twist: one wavefront per spectrum even for a few very long spectra (same bits as the segmented launch)
+  //   1 << 29          ca: stay on the Cholesky factor however many pivots were at the rounding floor
   int tune_dbg = 0;
   int tune_dense = 0;    // kpop_twist: 0 sparse mat-vec (the reference's order), 1 dense contraction on the matrix cores, 2 by density
   int tune_blocksort = 1;  // -L on sequences of up to 32,768 windows: one block per sequence, sorted in LDS (0: device-wide sort)
