@@ -1421,7 +1421,9 @@ extern "C" int kpop_twist(const kpop_twister *tw, const uint64_t *hash, const do
           ascending = false;
           break;
         }
-    if (ascending)
+    // (beyond ~160 dimensions the image route's GEMM tiles are full and it overtakes the fused kernel: 4,096 genome spectra,
+    // k = 7: D = 128 0.54 against 0.82 ms, D = 200 1.51 against 0.97 -- tools/ab_dense_twist.py with AB_DIMS)
+    if (ascending && tw->n_dims <= 160)
       KPOP_TRY(kpop_dev_twist_dense_sorted(tw, d_h.as<uint64_t>(), d_v.as<double>(), d_off.as<uint64_t>(), n_spectra, normalize, d_work.p,
                                            d_out.as<double>(), st));
     else
