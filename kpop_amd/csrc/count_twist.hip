@@ -146,10 +146,48 @@ struct StoreOffsets {
 // lane owns dims lane, lane+64, ...; products and sums are NOT fused (the
 // reference is OCaml: one rounding per multiply and per add).
 // ---------------------------------------------------------------------------
+// The LAST block of dimensions when it holds at most 32 of them (n_dims = 65, 100 - 96 ...): a pass with one load
+// instruction per row would cost what a full block costs (D = 65: 1.66 ms against 1.16 at 64), so one instruction fetches
+// G = 64 / P rows (P = 8, 16 or 32 lanes a row) -- and every dimension's sum stays the ONE ascending chain of the full
+// blocks: the products are handed down the lanes row by row (a shuffle per row) and added in row order by every lane
+// group alike.  Same multiplications, same additions, same order: the same bits as a pass of its own.
+template <int U, bool NT>
+__device__ __forceinline__ void wave_gather_rows_tail(const TwisterView &tv, const uint32_t *s_col, const double *s_x, uint32_t nu,
+                                                      int lane, uint32_t d0, double *__restrict__ out_row) {
+  const uint32_t rem = tv.n_dims - d0;  // 1..32
+  const uint32_t P = rem <= 8 ? 8u : (rem <= 16 ? 16u : 32u), G = 64u / P;
+  const uint32_t g = (uint32_t)lane / P, dd = (uint32_t)lane % P;
+  const double *base = tv.rows + d0 + min(dd, rem - 1);  // (lanes past the last dimension: a column that exists)
+  double acc = 0.0;
+  constexpr int UT = 4;  // instructions in flight: G * UT rows
+  for (uint32_t u0 = 0; u0 < nu; u0 += G * UT) {
+    double pr[UT];
+#pragma unroll
+    for (int j = 0; j < UT; ++j) {
+      const uint32_t u = u0 + (uint32_t)j * G + g;
+      const uint32_t uu = min(u, nu);  // [nu] is zero padding: row 0 against x = 0
+      const double *p = base + (uint64_t)s_col[uu] * tv.d_pad;
+      const double v = NT ? __builtin_nontemporal_load(p) : *p;
+      pr[j] = u < nu ? __dmul_rn(v, s_x[uu]) : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < UT; ++j)
+      for (uint32_t gg = 0; gg < G; ++gg) {  // rows u0 + j G + gg in order
+        const double t = __shfl(pr[j], (int)(gg * P + dd), 64);
+        if (u0 + (uint32_t)j * G + gg < nu) acc = __dadd_rn(acc, t);  // (uniform)
+      }
+  }
+  if (g == 0 && dd < rem) out_row[d0 + dd] = acc;
+}
+
 template <int U, bool NT>
 __device__ __forceinline__ void wave_gather_rows(const TwisterView &tv, const uint32_t *s_col, const double *s_x,
                                                  uint32_t nu, int lane, double *__restrict__ out_row) {
   for (uint32_t d0 = 0; d0 < tv.n_dims; d0 += 64) {
+    if (d0 > 0 && tv.n_dims - d0 <= 32) {
+      wave_gather_rows_tail<U, NT>(tv, s_col, s_x, nu, lane, d0, out_row);
+      break;
+    }
     const uint32_t d = d0 + lane;
     const bool active = d < tv.n_dims;
     const double *base = tv.rows + d;

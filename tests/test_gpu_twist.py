@@ -85,10 +85,12 @@ def test_count_twist_vs_oracle(kpop, oracle, k, d):
     assert np.array_equal(got[:3], np.zeros((3, d)))  # no k-mer -> zero row
 
 
-def test_count_twist_bit_exact_when_columns_ascend(kpop, oracle):
+@pytest.mark.parametrize("d", [64, 33, 65, 72, 81, 96, 100, 130, 160])
+def test_count_twist_bit_exact_when_columns_ascend(kpop, oracle, d):
     """With columns in ascending hash order the fused kernel adds the same terms in the same order as the
-    oracle, unfused: the result is bit-identical."""
-    k, d = 8, 64
+    oracle, unfused: the result is bit-identical -- also where the last block of dimensions is short (65, 72, 81, 96, 130,
+    160: several rows per load instruction, the products handed down the lanes in row order)."""
+    k = 8
     cols = oracle.enumerate_kmers(k)
     T = oracle.synth_twister(3, d, cols)
     tw = kpop.Twister.load(T, cols, k)
