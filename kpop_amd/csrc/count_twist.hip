@@ -314,7 +314,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void count_twist_wave_kernel(
 // segment order), the segment's sum goes to `out` as a partial row [spectrum * n_seg + segment] and
 // twist_csr_seg_combine_kernel adds the partial rows in segment order.  One wave per spectrum left 200 spectra of 300,000
 // lines on a fifth of the chip (2.4 G lines/s against 15).
-template <typename V, int U = kGatherUnroll, int KEEP = 0, bool SEG = false>  // V double: spectra as parsed from text; uint32_t: counts straight from the counting kernels
+// NDB: blocks of 64 dimensions a lane sums per pass over the lines (1 to 4): with more than 64 dimensions the lines are
+// looked up and staged ONCE per 64 NDB dimensions (every dimension's sum is the same chain either way: the same bits).
+template <typename V, int U = kGatherUnroll, int KEEP = 0, bool SEG = false, int NDB = 1>  // V double: spectra as parsed from text; uint32_t: counts straight from the counting kernels
 __global__ __launch_bounds__(64 * kWavesPerBlock) void twist_csr_kernel(
     TwisterView tv, const uint64_t *__restrict__ hash, const V *__restrict__ value,
     const uint64_t *__restrict__ offsets, uint32_t n, int normalize, double *__restrict__ out, uint32_t n_seg = 1,
@@ -380,17 +382,29 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void twist_csr_kernel(
   const bool norm = normalize && acc != 0.0;
   // pass 2: 64 lines at a time through LDS, then the shared gather
   const uint32_t n_dims = tv.n_dims;
-  for (uint32_t d0 = 0; d0 < n_dims; d0 += 64) {
-    const uint32_t d = d0 + lane;
-    const bool active = d < n_dims;
-    double t = 0.0, t_done = 0.0;  // t: the current stretch; t_done: the stretches before it
+  constexpr int UE = (U >= 16 && NDB > 1) ? (U / NDB < 8 ? 8 : U / NDB) : U;  // rows in flight (x NDB loads each)
+  for (uint32_t d0 = 0; d0 < n_dims; d0 += 64 * NDB) {
+    const double *base[NDB];
+    bool active[NDB];
+    double t[NDB], t_done[NDB];  // t: the current stretch; t_done: the stretches before it
+#pragma unroll
+    for (int b = 0; b < NDB; ++b) {
+      const uint32_t d = d0 + 64u * b + lane;
+      active[b] = d < n_dims;
+      base[b] = tv.rows + (active[b] ? d : n_dims - 1);  // (lanes past the last dimension: a column that exists)
+      t[b] = 0.0;
+      t_done[b] = 0.0;
+    }
     bool any_done = false;
     int q = 0;
     for (uint64_t i0 = lo; i0 < hi; i0 += 64, ++q) {
       if (KEEP == 0 && !SEG && i0 != lo && (i0 - lo) % kCsrSegLines == 0) {  // (uniform) a stretch ends
-        t_done = any_done ? __dadd_rn(t_done, t) : t;
+#pragma unroll
+        for (int b = 0; b < NDB; ++b) {
+          t_done[b] = any_done ? __dadd_rn(t_done[b], t[b]) : t[b];
+          t[b] = 0.0;
+        }
         any_done = true;
-        t = 0.0;
       }
       const uint64_t i = i0 + lane;
       uint32_t col = kNoCol;
@@ -416,14 +430,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void twist_csr_kernel(
       s_x[wv][lane] = x;
       __builtin_amdgcn_wave_barrier();
       const uint32_t cnt = (uint32_t)min((uint64_t)64, hi - i0);
-      const double *base = tv.rows + d;
-      const double *base_c = tv.rows + (active ? d : n_dims - 1);  // (lanes past the last dimension: a column that exists)
-      (void)base;
-      (void)base_c;
-      for (uint32_t u0 = 0; u0 < cnt; u0 += U) {
-        double v[U];
+      for (uint32_t u0 = 0; u0 < cnt; u0 += UE) {
+        double v[UE][NDB];
 #pragma unroll
-        for (int j = 0; j < U; ++j) {
+        for (int j = 0; j < UE; ++j) {
           const uint32_t uu = min(u0 + j, 63u);
           const uint32_t c = s_col[wv][uu];
           const double xx = s_x[wv][uu];
@@ -431,19 +441,26 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void twist_csr_kernel(
           // brings row 0 in against x = 0, an exact zero added -- where the conditional form compiles to a branch and an exec
           // save / restore per line: 5,000 x 30 kb spectra 4.72 -> 3.19 ms.  Read spectra by the hundred thousand (U = 8)
           // are HBM-bound and 2.5 % FASTER with the conditional form's staggered issue (1.31 against 1.34 ms): it stays.
-          if constexpr (U >= 16) v[j] = base_c[(uint64_t)c * tv.d_pad];
-          else v[j] = (active && u0 + j < cnt && xx != 0.0) ? base[(uint64_t)c * tv.d_pad] : 0.0;
+#pragma unroll
+          for (int b = 0; b < NDB; ++b) {
+            if constexpr (U >= 16) v[j][b] = base[b][(uint64_t)c * tv.d_pad];
+            else v[j][b] = (active[b] && u0 + j < cnt && xx != 0.0) ? base[b][(uint64_t)c * tv.d_pad] : 0.0;
+          }
         }
 #pragma unroll
-        for (int j = 0; j < U; ++j) {
+        for (int j = 0; j < UE; ++j) {
           const uint32_t uu = min(u0 + j, 63u);
           const double xx = (u0 + j < cnt) ? s_x[wv][uu] : 0.0;
-          t = __dadd_rn(t, __dmul_rn(v[j], xx));
+#pragma unroll
+          for (int b = 0; b < NDB; ++b) t[b] = __dadd_rn(t[b], __dmul_rn(v[j][b], xx));
         }
       }
     }
-    if (any_done) t = __dadd_rn(t_done, t);
-    if (active) out[(uint64_t)s * n_dims + d] = t;
+#pragma unroll
+    for (int b = 0; b < NDB; ++b) {
+      if (any_done) t[b] = __dadd_rn(t_done[b], t[b]);
+      if (active[b]) out[(uint64_t)s * n_dims + d0 + 64u * b + lane] = t[b];
+    }
   }
 }
 
@@ -498,29 +515,36 @@ static int launch_twist_csr(const TwisterView &tv, const uint64_t *hash, const V
       const dim3 sgrid(div_up(n * n_seg, kWavesPerBlock));
       twist_csr_seg_acc_kernel<V><<<sgrid, block, 0, st>>>(tv, hash, value, offsets, n, n_seg, seg_lines, acc_part);
       KPOP_LAUNCH_CHECK();
-      twist_csr_kernel<V, 32, 0, true><<<sgrid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, partial, n_seg, seg_lines, acc_part);
+      if (tv.n_dims <= 64) twist_csr_kernel<V, 32, 0, true, 1><<<sgrid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, partial, n_seg, seg_lines, acc_part);
+      else if (tv.n_dims <= 128) twist_csr_kernel<V, 32, 0, true, 2><<<sgrid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, partial, n_seg, seg_lines, acc_part);
+      else if (tv.n_dims <= 192) twist_csr_kernel<V, 32, 0, true, 3><<<sgrid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, partial, n_seg, seg_lines, acc_part);
+      else twist_csr_kernel<V, 32, 0, true, 4><<<sgrid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, partial, n_seg, seg_lines, acc_part);
       KPOP_LAUNCH_CHECK();
       twist_csr_seg_combine_kernel<<<dim3(n), dim3(256), 0, st>>>(partial, n_seg, tv.n_dims, out);
       KPOP_LAUNCH_CHECK();
       return 0;
     }
   }
+  // (UU loads in flight, KK lines kept in registers; the blocks of 64 dimensions a lane sums per pass by the twister's width)
+#define KPOP_CSR(UU, KK)                                                                                                          \
+  do {                                                                                                                            \
+    if (tv.n_dims <= 64) twist_csr_kernel<V, UU, KK, false, 1><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);        \
+    else if (tv.n_dims <= 128) twist_csr_kernel<V, UU, KK, false, 2><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);  \
+    else if (tv.n_dims <= 192) twist_csr_kernel<V, UU, KK, false, 3><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);  \
+    else twist_csr_kernel<V, UU, KK, false, 4><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);                        \
+  } while (0)
   if (max_lines == 0 || max_lines > 512) {
-    if (few) twist_csr_kernel<V, 32><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);
-    else twist_csr_kernel<V><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);
+    if (few) KPOP_CSR(32, 0); else KPOP_CSR(kGatherUnroll, 0);
   } else if (max_lines <= 64) {
-    if (few) twist_csr_kernel<V, 32, 1><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);
-    else twist_csr_kernel<V, kGatherUnroll, 1><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);
+    if (few) KPOP_CSR(32, 1); else KPOP_CSR(kGatherUnroll, 1);
   } else if (max_lines <= 128) {
-    if (few) twist_csr_kernel<V, 32, 2><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);
-    else twist_csr_kernel<V, kGatherUnroll, 2><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);
+    if (few) KPOP_CSR(32, 2); else KPOP_CSR(kGatherUnroll, 2);
   } else if (max_lines <= 256) {
-    if (few) twist_csr_kernel<V, 32, 4><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);
-    else twist_csr_kernel<V, kGatherUnroll, 4><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);
+    if (few) KPOP_CSR(32, 4); else KPOP_CSR(kGatherUnroll, 4);
   } else {
-    if (few) twist_csr_kernel<V, 32, 8><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);
-    else twist_csr_kernel<V, kGatherUnroll, 8><<<grid, block, 0, st>>>(tv, hash, value, offsets, n, normalize, out);
+    if (few) KPOP_CSR(32, 8); else KPOP_CSR(kGatherUnroll, 8);
   }
+#undef KPOP_CSR
   KPOP_LAUNCH_CHECK();
   return 0;
 }

@@ -18,7 +18,7 @@ def main():
     kpop_amd.init(0)
     dev = torch.device("cuda", 0)
     st = torch.cuda.current_stream()
-    k, d = 12, 64
+    k, d = 12, int(os.environ.get("CSR_DIMS", "64"))
     tw = kpop_amd.Twister.synth(0x5EED, k, d)
     n_kmers = 4 ** k
     g = torch.Generator(device=dev)
