@@ -57,7 +57,7 @@ struct WaveLds {
 // ---------------------------------------------------------------------------
 // reads per wave: the sorted keys of a wave's reads wait in registers (R per lane and read) for the block's prefix
 template <int R>
-constexpr int reads_per_wave() { return R <= 2 ? 8 : (R == 4 ? 4 : 2); }
+constexpr int reads_per_wave() { return R <= 2 ? 8 : (R == 4 ? 8 : 2); }
 
 template <int R, typename H, int SB = 2>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void count_wave_kernel(
