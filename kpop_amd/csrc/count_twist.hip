@@ -62,8 +62,8 @@ constexpr int reads_per_wave() { return R <= 2 ? 8 : (R == 4 ? 8 : 2); }
 template <int R, typename H, int SB = 2>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void count_wave_kernel(
     const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, uint32_t n, int k, int content,
-    uint32_t *__restrict__ ticket_counter, uint64_t *__restrict__ state, uint64_t *__restrict__ out_hash,
-    uint32_t *__restrict__ out_count, uint64_t *__restrict__ out_offsets, int dbg = 0) {
+    uint32_t *__restrict__ ticket_counter, uint64_t *__restrict__ state, uint64_t *__restrict__ gstate, uint32_t *__restrict__ garr,
+    uint64_t *__restrict__ out_hash, uint32_t *__restrict__ out_count, uint64_t *__restrict__ out_offsets, int dbg = 0) {
   constexpr int RW = reads_per_wave<R>(), RPB = RW * kWavesPerBlock;
   __shared__ WaveLds<R, H> lds[kWavesPerBlock];
   __shared__ uint32_t s_ticket;
@@ -105,7 +105,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void count_wave_kernel(
     total += s_nu[i];
   }
   if (wv == 0) {
-    const uint64_t pre = (dbg & 1) ? (uint64_t)ticket * RPB * 64 * R : lookback_exclusive(state, ticket, (uint64_t)total, lane, (dbg >> 4) ? (dbg >> 4) : 16);
+    const int naps = (dbg >> 4) & 15 ? (dbg >> 4) & 15 : 1;
+    const uint64_t pre = (dbg & 1)     ? (uint64_t)ticket * RPB * 64 * R
+                         : (dbg & 8) ? lookback_exclusive(state, ticket, (uint64_t)total, lane, 16)  // (8: one level, round 2's)
+                                     : lookback_exclusive_grouped(state, gstate, garr, ticket, gridDim.x, (uint64_t)total, lane, naps);
     if (lane == 0) s_prefix = pre;
   }
   __syncthreads();
@@ -1018,7 +1021,12 @@ static int pick_R(uint32_t max_windows) {
 }
 
 // bytes of device scratch count_wave needs: the ticket counter and one look-back word per block
-static inline uint64_t count_wave_scratch_bytes(uint32_t n) { return 64 + ((uint64_t)div_up(n, 2 * kWavesPerBlock) + 1) * 8; }
+// ... and, for the two-level look-back, a word and an arrival counter per group of 64 blocks (lookback.h)
+static inline uint64_t count_wave_max_blocks(uint32_t n) { return (uint64_t)div_up(n, 2 * kWavesPerBlock) + 1; }
+static inline uint64_t count_wave_scratch_bytes(uint32_t n) {
+  const uint64_t blocks = count_wave_max_blocks(n), groups = blocks / kLookGroup + 2;
+  return 64 + blocks * 8 + groups * 8 + ((groups * 4 + 63) & ~63ull);
+}
 
 template <typename H, int SB>
 static int launch_count_wave_sb(int R, const uint8_t *bases, const uint64_t *offsets, uint32_t n, int k, int content, void *scratch,
@@ -1027,12 +1035,14 @@ static int launch_count_wave_sb(int R, const uint8_t *bases, const uint64_t *off
   const auto grid = [&](int rw) { return dim3(div_up(n, (uint32_t)rw * kWavesPerBlock)); };
   uint32_t *ticket = reinterpret_cast<uint32_t *>(scratch);
   uint64_t *state = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(scratch) + 64);
+  uint64_t *gstate = state + count_wave_max_blocks(n);
+  uint32_t *garr = reinterpret_cast<uint32_t *>(gstate + count_wave_max_blocks(n) / kLookGroup + 2);
   KPOP_HIP(hipMemsetAsync(scratch, 0, count_wave_scratch_bytes(n), st));
   switch (R) {
-    case 1: count_wave_kernel<1, H, SB><<<grid(reads_per_wave<1>()), block, 0, st>>>(bases, offsets, n, k, content, ticket, state, oh, oc, oo, ctx().tune_dbg); break;
-    case 2: count_wave_kernel<2, H, SB><<<grid(reads_per_wave<2>()), block, 0, st>>>(bases, offsets, n, k, content, ticket, state, oh, oc, oo, ctx().tune_dbg); break;
-    case 4: count_wave_kernel<4, H, SB><<<grid(reads_per_wave<4>()), block, 0, st>>>(bases, offsets, n, k, content, ticket, state, oh, oc, oo, ctx().tune_dbg); break;
-    case 8: count_wave_kernel<8, H, SB><<<grid(reads_per_wave<8>()), block, 0, st>>>(bases, offsets, n, k, content, ticket, state, oh, oc, oo, ctx().tune_dbg); break;
+    case 1: count_wave_kernel<1, H, SB><<<grid(reads_per_wave<1>()), block, 0, st>>>(bases, offsets, n, k, content, ticket, state, gstate, garr, oh, oc, oo, ctx().tune_dbg); break;
+    case 2: count_wave_kernel<2, H, SB><<<grid(reads_per_wave<2>()), block, 0, st>>>(bases, offsets, n, k, content, ticket, state, gstate, garr, oh, oc, oo, ctx().tune_dbg); break;
+    case 4: count_wave_kernel<4, H, SB><<<grid(reads_per_wave<4>()), block, 0, st>>>(bases, offsets, n, k, content, ticket, state, gstate, garr, oh, oc, oo, ctx().tune_dbg); break;
+    case 8: count_wave_kernel<8, H, SB><<<grid(reads_per_wave<8>()), block, 0, st>>>(bases, offsets, n, k, content, ticket, state, gstate, garr, oh, oc, oo, ctx().tune_dbg); break;
     default: KPOP_FAIL(KPOP_ERR_INVALID, "launch_count_wave: R=%d", R);
   }
   KPOP_LAUNCH_CHECK();

@@ -10,7 +10,7 @@ api.dev_synth_reads(0x4B506F70, n, L, bases.data_ptr(), offs.data_ptr(), stream=
 w = L - k + 1
 scratch = torch.empty(api.dev_count_reads_scratch_bytes(n, L, k), dtype=torch.uint8, device=dev)
 oh = torch.empty(n * 256, dtype=torch.int64, device=dev); oc = torch.empty(n * 256, dtype=torch.int32, device=dev); oo = torch.empty(n + 1, dtype=torch.int64, device=dev)
-for dbg in (0, 16, 48, 112, 240, 1, 3):
+for dbg in (0, 8, 16, 48, 1, 3):  # 0 two-level look-back, 8 one level (round 2), 16.. naps, 1 none, 3 none and no ticket
     api.tune("dbg", dbg)
     f = lambda: api.dev_count_reads(bases.data_ptr(), offs.data_ptr(), n, L, k, scratch.data_ptr(), oh.data_ptr(), oc.data_ptr(), oo.data_ptr(), stream=sp)
     f(); torch.cuda.synchronize()
