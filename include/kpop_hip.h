@@ -91,14 +91,19 @@ int kpop_synchronize(void *stream);
    "summary2" 1 (default) | 3 | 0 | 2: summaries against more than 4,096 rows by brackets from a sample and ONE pass over the
    distance rows, the same in two passes, round 2's one block per row, or (131,072 rows and more) with the distances
    computed and reduced in one kernel and no distance rows in memory -- same results, 1, 3 and 2 level;
-   "dense" 0 (default) | 1 | 2: kpop_twist by the sparse mat-vec, by the dense contraction on the f64 matrix cores, or
-   by the batch's density (2 also sends kpop_count_twist's batches of assemblies at small k through the dense image of
-   their counts, kpop_dev_count_twist_dense, and at k <= 15 with >= 64 sequences tries the union compaction of
-   one-organism batches first: 64 sequences x 512 windows share an LDS set of <= 1,024 twister rows and go to the matrix
-   cores, what does not fit stays with the streaming kernel; 2.8x on 0.1 % mutants, 0.96x on batches that do not
-   compact) -- the one knob that changes results, in the last bits; "ldspad" bytes of
+   "dense" 2 (default) | 1 | 0: the matrix-core routes of the twist.  2: chosen by the batch -- sequences of more than 512
+   windows (assemblies, k <= 15) go through count_twist_tile_kernel: the CONSENSUS rows of a stretch of 64 sequences x 512
+   windows (the rows of four seed sequences, an LDS set) are multiplied on the f64 matrix cores, the rows private to one
+   sequence are gathered per sequence (tile_residual_kernel), stretches that share little with their seeds stay with the
+   streaming kernel; kpop_count_twist's batches of assemblies at small k go through the dense image of their
+   counts (kpop_dev_count_twist_dense); kpop_twist takes the dense contraction when the spectra are dense enough.  1: kpop_twist
+   always by the dense contraction.  0: opt out -- the sparse mat-vec in the reference's order of additions everywhere.  The
+   one knob that changes results, in the last bits (<= 2e-15 relative measured; north_star allows 1e-5); "ldspad" bytes of
    extra LDS per block of the fused reads kernel (an occupancy probe); "dbg" development switches (also KPOP_TUNE_DBG)  */
 int kpop_tune(const char *key, int value);
+/* development: the phase clocks count_twist_tile_kernel adds up under kpop_tune("dbg", 16 << 24) (s_memtime ticks of thread 0 of
+   every block, nine phases; tools/probes/ab_tile_kernel.py prints them), read and cleared; synchronises the device */
+int kpop_debug_counters(uint64_t *out, int n);
 
 /* plain device-memory helpers so a non-HIP host language can stage buffers */
 int kpop_dev_malloc(void **ptr, uint64_t bytes);

@@ -61,6 +61,13 @@ def tune(key, value):
     check(_lib.load().kpop_tune(key.encode(), int(value)))
 
 
+def debug_counters(n=16):
+    """the development phase clocks of kpop_debug_counters (read and cleared)"""
+    out = (C.c_uint64 * 16)()
+    check(_lib.load().kpop_debug_counters(out, int(n)))
+    return [int(x) for x in out[:n]]
+
+
 def device_count():
     n = _lib.load().kpop_device_count()
     if n < 0:

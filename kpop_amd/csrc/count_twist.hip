@@ -610,9 +610,10 @@ __global__ __launch_bounds__(256) void count_twist_stream_kernel(
     TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int content,
     const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ seg_off, double *__restrict__ partial,
     uint32_t *__restrict__ partial_cnt, const uint32_t *__restrict__ long_ids, const uint32_t *__restrict__ n_long_ptr, uint32_t max_seg,
-    uint32_t seg_windows, const uint8_t *__restrict__ tile_done, uint32_t n_groups, uint32_t d_begin, uint32_t d_end) {
+    uint32_t seg_windows, const uint2 *__restrict__ todo, uint32_t d_begin, uint32_t d_end) {
   __shared__ double s_part[4][64 * NDB];
   __shared__ uint32_t s_cnt[4];
+  // todo: the (sequence, segment) pairs count_twist_tile_kernel left (tile_todo_kernel's list; n_long_ptr then counts those)
   const uint32_t n_reads = *n_long_ptr;  // the sequences that have segments (long_ids), not the batch
   if (n_reads == 0) return;
   // (segment, read) pairs are dealt to blocks round-robin, READS FASTEST: the blocks in flight at any moment work on the
@@ -621,11 +622,18 @@ __global__ __launch_bounds__(256) void count_twist_stream_kernel(
   // from HBM once per XCD and are L2 hits for every other sequence.  Unrelated sequences lose nothing by this order.
   // A ragged batch (one genome among a million reads) has far more pairs than HIP allows blocks, and almost all of them
   // are empty, hence the grid-stride loop.
-  const uint64_t n_pairs = (uint64_t)n_reads * max_seg;
+  const uint64_t n_pairs = todo ? (uint64_t)n_reads : (uint64_t)n_reads * max_seg;
   for (uint64_t pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
-  const uint32_t seg = (uint32_t)(pair / n_reads), r = long_ids[pair % n_reads];
-  if (seg >= nseg[r]) continue;
-  if (tile_done && tile_done[(uint64_t)seg * n_groups + r / 64]) continue;  // (count_twist_tile_kernel has written this segment's sums)
+  uint32_t seg, r;
+  if (todo) {
+    const uint2 t = todo[pair];
+    r = t.x;
+    seg = t.y;
+  } else {
+    seg = (uint32_t)(pair / n_reads);
+    r = long_ids[pair % n_reads];
+    if (seg >= nseg[r]) continue;
+  }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t off = offsets[r];
   const uint64_t len = offsets[r + 1] - off;
@@ -706,34 +714,75 @@ __global__ __launch_bounds__(256) void count_twist_stream_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// Assemblies of ONE organism (BASELINE config 3's kind of batch; kpop_tune("dense", 2)): the same stretch of 512 windows of
-// 64 consecutive sequences holds little more than 512 DISTINCT k-mers, so the 64 x 512 row gathers of the streaming kernel
-// (33 MB through L2 per chunk) are 64 times the rows that differ.  A block instead
-//   1. collects the chunk's distinct twister rows in an LDS hash set (ds_cmpst; at most 1,024 of them),
-//   2. numbers them, and counts every (sequence, distinct row) pair into an LDS matrix X[64][U] of u16,
+// Assemblies of ONE organism (BASELINE config 3's kind of batch): CONSENSUS on the matrix cores + a RESIDUAL gather.
+// The same stretch of 512 windows of 64 consecutive sequences holds little more than 512 DISTINCT k-mers, so the 64 x 512
+// row gathers of the streaming kernel (33 MB through L2 per chunk) are 64 times the rows that differ.  A block instead
+//   1. builds the chunk's CONSENSUS: the distinct twister rows of four SEED sequences (0, 16, 32, 48 of the group) in an LDS
+//      hash set -- seed 0 first, whole (at most 512 rows), the other three up to kTileSetCap rows in all,
+//   2. numbers them; every sequence looks its windows up in the set: a hit counts into an LDS matrix X[64][U] of u16, a miss
+//      (a k-mer around a substitution: private to the sequence, 12 of them per substitution) goes on the sequence's
+//      RESIDUAL list in HBM, in window order,
 //   3. multiplies: partial[64 x D] = X[64 x U] * T_U[U x D] on the f64 matrix cores, the U rows of the twister gathered
 //      ONCE per chunk,
-// and writes the same per-segment partial sums the streaming kernel writes (combine_partials_kernel divides by acc).
-// A chunk with more distinct rows than the set holds (unrelated sequences, or a divergent stretch) is left to the
-// streaming kernel (tile_done stays 0), and a block that meets one stops trying.  The sums run over distinct rows in set
-// order, not in sequence order: equal to the streaming kernel's up to rounding, like the rest of the "dense" routes.
+// and tile_residual_kernel adds every sequence's listed rows to its partial (one wavefront per (sequence, segment), the
+// gather of the streaming kernel without its hashing: those rows are the ones HBM has to deliver whatever the scheme).
+// Nothing overflows on divergence: a chunk whose sequences share little with the seeds (unrelated genomes; found from every
+// thread's first two windows, a sixteenth of the chunk) is left to the streaming kernel as a whole (slot_done stays 0), and
+// a block that meets four of those in a row skips ahead.  The sums run over the set's rows in set order, then the residual
+// rows in window order: equal to the streaming kernel's up to rounding (<= 2e-15 relative measured), like the rest of the
+// "dense" routes.  lib/Twister.ml:146-188.
 // ---------------------------------------------------------------------------
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 constexpr uint32_t kTileG = 64, kTileS = 512, kTileU = 1024, kTileH = 2048, kTileXS = kTileU + 2;  // (X rows padded: 16 rows on 16 banks)
+constexpr uint32_t kTileSetCap = 768;    // rows in the set beyond which the seeds after the first add no more
+constexpr uint32_t kTileSeedEvery = 16;  // sequences 0, 16, 32, 48 of a group are its seeds
+constexpr uint32_t kTileStageW = 136;    // dwords of a sequence's staged stretch: 3 + 512 + 14 bytes and the thirteenth dword of the last thread
+constexpr uint32_t kTileMinSeqs = 16;    // sequences with segments in a batch below which the tile kernel does not try
+
+// the sequences that have segments, in batch order (an exclusive scan's compaction), and the longest of every group of 64 of them
+struct LoadLong {
+  const uint32_t *nseg;
+  __device__ uint32_t operator()(uint64_t i) const { return nseg[i] != 0u; }
+};
+struct StoreLong {
+  uint32_t *olong;
+  __device__ void operator()(uint64_t i, uint64_t prefix, uint32_t v) const {
+    if (v) olong[prefix] = (uint32_t)i;
+  }
+};
+__global__ __launch_bounds__(256) void tile_group_max_kernel(const uint32_t *__restrict__ nseg, const uint32_t *__restrict__ olong,
+                                                             const uint64_t *__restrict__ n_long_ptr, uint32_t *__restrict__ gmax) {
+  const uint32_t n_long = (uint32_t)*n_long_ptr, g = blockIdx.x * 4 + (threadIdx.x >> 6), li = g * kTileG + (threadIdx.x & 63);
+  uint32_t m = li < n_long ? nseg[olong[li]] : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0 && (uint64_t)g * kTileG < n_long) gmax[g] = m;
+}
+
+// phase clocks of count_twist_tile_kernel (kpop_tune("dbg", 16 << 24) only: s_memtime ticks of every block's thread 0, summed
+// over blocks and chunks; read and cleared by kpop_debug_counters)
+__device__ unsigned long long g_tile_stamps[16];
 
 template <typename H>
 __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
     TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int content,
     const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ seg_off, double *__restrict__ partial,
-    uint32_t *__restrict__ partial_cnt, uint32_t n_reads, uint32_t max_seg, uint8_t *__restrict__ tile_done, int dbg) {
+    uint32_t *__restrict__ partial_cnt, const uint32_t *__restrict__ olong, const uint64_t *__restrict__ n_long_ptr,
+    const uint32_t *__restrict__ gmax, uint32_t max_seg, uint32_t *__restrict__ slot_done, uint32_t *__restrict__ res_rows, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_lds[];
-  uint32_t *ht_key = reinterpret_cast<uint32_t *>(tile_lds);                 // [kTileH] twister row, kNoCol = empty
-  uint16_t *ht_u = reinterpret_cast<uint16_t *>(ht_key + kTileH);            // [kTileH] number of the slot's row
-  uint32_t *ucol = reinterpret_cast<uint32_t *>(ht_u + kTileH);              // [kTileU] row of number u
-  uint32_t *Xw = ucol + kTileU;                                              // [kTileG][kTileXS / 2] pairs of u16 counts
-  __shared__ uint32_t s_over, s_n, s_new, s_found[kTileG], s_wbase[16];
+  uint2 *ht = reinterpret_cast<uint2 *>(tile_lds);                  // [kTileH] {twister row (kNoCol = empty), its number in the set}
+  uint32_t *ucol = reinterpret_cast<uint32_t *>(ht + kTileH);       // [kTileU] row of number u
+  uint32_t *Xw = ucol + kTileU;                                     // [kTileG][kTileXS / 2] pairs of u16 counts
+  uint32_t *stage = Xw;                                             // before X is needed: [kTileG][kTileStageW] the stretch's bases,
+  uint32_t *seedcols = Xw + kTileG * kTileStageW;                   //   and [4][kTileS] the seeds' rows
+  __shared__ uint32_t s_n, s_new, s_samp, s_add[kTileG / kTileSeedEvery], s_wbase[16];
+  __shared__ uint64_t s_slot[kTileG];  // the group's (sequence, segment) slots, ~0: the sequence has no such segment
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint32_t n_groups = (n_reads + kTileG - 1) / kTileG;
+  // groups of 64 are cut from the sequences that HAVE segments, in batch order (olong: the scan's list, the same every run): a
+  // few assemblies among a million reads make a few groups, not sixteen thousand empty ones
+  const uint32_t n_long = (uint32_t)*n_long_ptr;
+  if (n_long < kTileMinSeqs) return;  // (too few sequences to share anything: the streaming kernel's)
+  const uint32_t n_groups = (n_long + kTileG - 1) / kTileG;
   const uint64_t n_chunks = (uint64_t)n_groups * max_seg;
   const int k = tv.hk;
   const int shift = 2 * (k - 1);
@@ -741,99 +790,211 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
   // thread t works on sequence t / 16 of the group and a sixteenth of the segment's windows (32), rolling the hash along
   constexpr uint32_t kPer = kTileS / 16;
   const uint32_t tg = threadIdx.x >> 4, tq = threadIdx.x & 15u;
-  int misses = 0;  // chunks in a row that did not fit the set: after four the block leaves its chunks to the streaming kernel
+  const bool seed = (tg % kTileSeedEvery) == 0;
+  // chunks in a row that shared too little with their seeds: after four the block skips the next `backoff` of its chunks
+  // (they are the streaming kernel's), twice as many every time until a chunk is taken again
+  int misses = 0;
+  uint32_t skip = 0, backoff = 8;
+  auto missed = [&]() {
+    if (++misses >= 4) {
+      misses = 0;
+      skip = backoff;
+      backoff = min(backoff * 2u, 1u << 20);
+    }
+  };
+  unsigned long long t_last = 0, t_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const bool stamps = (dbg & 16) && threadIdx.x == 0;
+  auto stamp = [&](int phase) {
+    if (stamps) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      t_acc[phase] += now - t_last;
+      t_last = now;
+    }
+  };
+  auto set_slot = [](uint32_t col) { return (col * 2654435761u) >> 21; };  // 11 bits
+  // ORDERED linear probing: where two rows meet the smaller one keeps the slot and the other moves on, so the table -- hence the
+  // numbering of the rows, hence the order of the additions on the matrix cores -- is the same whatever order the threads
+  // arrive in (a first version, first come first served, gave sums that differed in the last bits from run to run).
+  // True: an empty slot was taken (one more row in the set).
+  auto insert = [&](uint32_t col) -> bool {
+    uint32_t slot = set_slot(col);
+#pragma unroll 1
+    for (uint32_t t = 0; t < 2 * kTileH; ++t) {
+      const uint32_t prev = atomicMin(&ht[slot].x, col);
+      if (prev == col) return false;    // (already there)
+      if (prev == kNoCol) return true;  // (an empty slot: kNoCol is the largest value)
+      if (prev > col) col = prev;       // (took prev's slot: prev is carried on)
+      slot = (slot + 1) & (kTileH - 1);
+    }
+    return false;
+  };
+  auto find = [&](uint32_t col) -> uint2 {  // the row's entry, or an empty one
+    uint32_t slot = set_slot(col);
+    uint2 e = ht[slot];
+#pragma unroll 1
+    for (uint32_t t = 0; t < kTileH && e.x != col && e.x != kNoCol; ++t) {
+      slot = (slot + 1) & (kTileH - 1);
+      e = ht[slot];
+    }
+    return e;
+  };
   for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     // chunks are dealt with the groups fastest: blocks running together work on one stretch of all sequences
     const uint32_t seg = (uint32_t)(chunk / n_groups), grp = (uint32_t)(chunk % n_groups);
-    if (misses >= 4) continue;  // (uniform over the block)
-    const uint32_t r = grp * kTileG + tg;
-    uint64_t off = 0, len = 0;
-    bool mine = false;
-    if (r < n_reads) {
-      off = offsets[r];
-      len = offsets[r + 1] - off;
-      mine = seg < nseg[r];  // (sequences of up to 512 windows have nseg = 0: the one-wavefront-per-read kernel's)
-    }
-    const uint64_t n_win = len >= (uint64_t)k ? len - k + 1 : 0;
-    const uint64_t w0 = (uint64_t)seg * kTileS + (uint64_t)tq * kPer, w1 = min(n_win, w0 + kPer);
-    const uint8_t *seq = bases + off;
-    __syncthreads();
-    for (uint32_t q = threadIdx.x; q < kTileH; q += 1024) ht_key[q] = kNoCol;
-    for (uint32_t q = threadIdx.x; q < kTileG * kTileXS / 2; q += 1024) Xw[q] = 0;
-    if (threadIdx.x < kTileG) s_found[threadIdx.x] = 0;
-    if (threadIdx.x == 0) {
-      s_over = 0;
-      s_n = 0;
-      s_new = 0;
-    }
-    __syncthreads();
-    // the thread's rows: found once (hash rolled, name -> row walked), kept in registers for the second pass
-    uint32_t cols[kPer];
-    uint16_t slots[kPer];
-#pragma unroll
-    for (uint32_t i = 0; i < kPer; ++i) {
-      cols[i] = kNoCol;
-      slots[i] = 0xFFFFu;
-    }
-    const bool act = mine && w0 < w1;
-    H fwd = 0, rc = 0;
-    int run = 0;
-    if (act)
-      for (int j = 0; j < k - 1; ++j) {
-        const uint32_t c = base_code(seq[w0 + j]);
-        fwd = ((fwd << 2) | (H)(c & 3u)) & mask;
-        rc = (rc >> 2) | ((H)(3u - (c & 3u)) << shift);
-        run = c < 4u ? run + 1 : 0;
-      }
-    auto roll = [&](uint32_t i) {  // window w0 + i: its twister row
-      const uint64_t w = w0 + i;
-      if (act && w < w1) {
-        const uint32_t c = base_code(seq[w + k - 1]);
-        fwd = ((fwd << 2) | (H)(c & 3u)) & mask;
-        rc = (rc >> 2) | ((H)(3u - (c & 3u)) << shift);
-        run = c < 4u ? run + 1 : 0;
-        if (run >= k && !(dbg & 8)) cols[i] = lookup_col(tv, (uint64_t)((content == KPOP_DNA_DS && rc < fwd) ? rc : fwd));
-      }
-    };
-    auto insert = [&](uint32_t i) {  // ---- 1. the distinct rows into the set
-      const uint32_t col = cols[i];
-      if (col == kNoCol || (dbg & 4)) return;
-      if (*reinterpret_cast<volatile uint32_t *>(&s_over)) return;  // (a full table: no point in probing it further)
-      uint32_t slot = (col * 2654435761u) >> 21;  // 11 bits
-#pragma unroll 1
-      for (int t = 0; t < 32; ++t) {
-        const uint32_t prev = atomicCAS(&ht_key[slot], kNoCol, col);
-        if (prev == col || prev == kNoCol) {
-          slots[i] = (uint16_t)slot;
-          if (prev == kNoCol) atomicAdd(&s_new, 1u);
-          break;
-        }
-        slot = (slot + 1) & (kTileH - 1);
-      }
-      if (slots[i] == 0xFFFFu) s_over = 1;
-    };
-    // A SAMPLE first -- every thread's first two windows, a sixteenth of the chunk: sequences that share little (unrelated
-    // genomes, a divergent stretch) show as many distinct rows as windows there, and the chunk is left to the streaming
-    // kernel for a sixteenth of what finding out at the end costs
-    constexpr uint32_t kProbe = 2;
-#pragma unroll
-    for (uint32_t i = 0; i < kProbe; ++i) roll(i);
-#pragma unroll
-    for (uint32_t i = 0; i < kProbe; ++i) insert(i);
-    __syncthreads();
-    if ((uint64_t)s_new * (kPer / kProbe) > kTileU + kTileU / 2) {  // (uniform: read after the barrier)
-      ++misses;
+    if (seg >= gmax[grp]) continue;  // (none of the group's sequences is this long)
+    if (skip) {  // (uniform over the block)
+      --skip;
       continue;
     }
+    const uint32_t li = grp * kTileG + tg;
+    uint32_t r = 0;
+    uint64_t off = 0, len = 0;
+    bool mine = false;
+    if (li < n_long) {
+      r = olong[li];
+      off = offsets[r];
+      len = offsets[r + 1] - off;
+      mine = seg < nseg[r];
+    }
+    const uint64_t n_win = len >= (uint64_t)k ? len - k + 1 : 0;
+    const uint64_t s_beg = (uint64_t)seg * kTileS;  // the stretch's first base (and window) in the sequence
+    const uint64_t w0 = s_beg + (uint64_t)tq * kPer, w1 = min(n_win, w0 + kPer);
+    const uint32_t nv = (mine && w1 > w0) ? (uint32_t)(w1 - w0) : 0u;  // windows of this thread that exist
+    if (stamps) t_last = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    // ---- 0. the stretch's bases into LDS: dword d of a sequence's row holds the four bytes at (stretch - a) + 4 d, a = the
+    // stretch's address modulo 4, so that the loads are aligned dwords, 64 bytes per 16 lanes (bytes past either end of the
+    // sequence are never read: the edge dwords are put together from the bytes that exist).  The byte loads this replaces
+    // were a chain of 43 dependent round trips per thread, a third of the kernel.
+    const uint8_t *ga = bases + off + s_beg;
+    const uint32_t a = (uint32_t)(reinterpret_cast<uintptr_t>(ga) & 3u);
+    {
+      const int avail = mine ? (int)min<uint64_t>(len - s_beg, (uint64_t)(kTileS + k - 1)) : 0;
 #pragma unroll
-    for (uint32_t i = kProbe; i < kPer; ++i) roll(i);
+      for (uint32_t j = 0; j < (kTileStageW + 15) / 16; ++j) {
+        const uint32_t d = tq + 16u * j;
+        if (d < kTileStageW) {
+          const int b0 = 4 * (int)d - (int)a;
+          uint32_t v = 0;
+          if (b0 >= 0 && b0 + 4 <= avail)
+            v = *reinterpret_cast<const uint32_t *>(ga + b0);
+          else
+            for (int q = 0; q < 4; ++q)
+              if (b0 + q >= 0 && b0 + q < avail) v |= (uint32_t)ga[b0 + q] << (8 * q);
+          stage[tg * kTileStageW + d] = v;
+        }
+      }
+    }
+    if (tq == 0) s_slot[tg] = mine ? seg_off[r] + seg : ~0ull;
+    for (uint32_t q = threadIdx.x; q < kTileH; q += 1024) ht[q] = make_uint2(kNoCol, 0u);
+    if (threadIdx.x == 0) {
+      s_n = 0;
+      s_new = 0;
+      s_samp = 0;
+    }
+    if (threadIdx.x < kTileG / kTileSeedEvery) s_add[threadIdx.x] = 0;
+    __syncthreads();
+    stamp(0);  // the bases staged, the set cleared
+    // ---- 1. the thread's 32 windows: hashes rolled out of LDS, then their twister rows, eight look-ups in flight at a time
+    uint32_t cols[kPer];
+    {
+      const uint32_t *sg = stage + tg * kTileStageW + tq * 8u;
+      uint32_t pw[4];  // the k - 1 bases before the first window's last base
 #pragma unroll
-    for (uint32_t i = kProbe; i < kPer; ++i) insert(i);
+      for (int i = 0; i < 4; ++i) pw[i] = __builtin_amdgcn_alignbyte(sg[i + 1], sg[i], a);
+      const uint64_t plo = (uint64_t)pw[0] | ((uint64_t)pw[1] << 32), phi = (uint64_t)pw[2] | ((uint64_t)pw[3] << 32);
+      H fwd = 0, rc = 0;
+      int run = 0;
+      for (int j = 0; j < k - 1; ++j) {
+        const uint32_t c = base_code((uint32_t)((j < 8 ? plo >> (8 * j) : phi >> (8 * (j - 8))) & 0xFFull));
+        fwd = ((fwd << 2) | (H)(c & 3u)) & mask;
+        rc = (rc >> 2) | ((H)(3u - (c & 3u)) << shift);
+        run = c < 4u ? run + 1 : 0;
+      }
+      const uint32_t sh = a + (uint32_t)(k - 1);
+      const uint32_t *sm = sg + (sh >> 2);
+      uint32_t mw[kPer / 4];  // the windows' last bases
+#pragma unroll
+      for (uint32_t i = 0; i < kPer / 4; ++i) mw[i] = __builtin_amdgcn_alignbyte(sm[i + 1], sm[i], sh & 3u);
+      uint32_t vmask = 0;
+#pragma unroll
+      for (uint32_t i = 0; i < kPer; ++i) {
+        const uint32_t c = base_code((mw[i >> 2] >> (8u * (i & 3u))) & 0xFFu);
+        fwd = ((fwd << 2) | (H)(c & 3u)) & mask;
+        rc = (rc >> 2) | ((H)(3u - (c & 3u)) << shift);
+        run = c < 4u ? run + 1 : 0;
+        cols[i] = (uint32_t)((content == KPOP_DNA_DS && rc < fwd) ? rc : fwd);  // (the hash, for now)
+        vmask |= (run >= k && i < nv) ? (1u << i) : 0u;
+      }
+#pragma unroll
+      for (uint32_t i0 = 0; i0 < kPer; i0 += 8) {
+        uint4 q[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) q[u] = *reinterpret_cast<const uint4 *>(tv.rsel + (cols[i0 + u] >> 6));  // (a hash of k bases: inside the index)
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+          const uint64_t bits = ((uint64_t)q[u].y << 32) | q[u].x;
+          const uint32_t b = cols[i0 + u] & 63u;
+          const bool there = ((vmask >> (i0 + u)) & 1u) && ((bits >> b) & 1ull);
+          cols[i0 + u] = there ? q[u].z + (uint32_t)__popcll(bits & ((1ull << b) - 1ull)) : kNoCol;
+        }
+      }
+    }
+    if (seed) {
+#pragma unroll
+      for (uint32_t i = 0; i < kPer; ++i) seedcols[(tg / kTileSeedEvery) * kTileS + tq * kPer + i] = cols[i];
+    }
+    __syncthreads();
+    stamp(1);  // everybody's rows found
+    // ---- 2. the consensus set: seed 0's rows, a thread each
+    {
+      bool took = false;
+      if (threadIdx.x < kTileS) {
+        const uint32_t col = seedcols[threadIdx.x];
+        if (col != kNoCol) took = insert(col);
+      }
+      const uint32_t n = (uint32_t)__popcll(__ballot(took));
+      if (lane == 0 && n) atomicAdd(&s_new, n);
+    }
+    __syncthreads();
+    // the other seeds are admitted in order while the set stays within kTileSetCap rows, by what each would add at most (its
+    // rows not of seed 0): a rule that does not depend on who runs when
+    uint32_t ecol[2];
+#pragma unroll
+    for (uint32_t j = 0; j < 2; ++j) {
+      const uint32_t e = threadIdx.x + 1024u * j;  // (a wavefront's 64 entries are one seed's: 512 is a multiple of 64)
+      ecol[j] = kNoCol;
+      if (e < 3u * kTileS) {
+        const uint32_t col = seedcols[kTileS + e];
+        if (col != kNoCol && find(col).x == kNoCol) ecol[j] = col;
+        const uint32_t n = (uint32_t)__popcll(__ballot(ecol[j] != kNoCol));
+        if (lane == 0 && n) atomicAdd(&s_add[1u + e / kTileS], n);
+      }
+    }
     __syncthreads();
     {
-      // number the occupied slots (thread order over the table: 2 slots a thread, a block-wide scan)
+      uint32_t total = s_new, in = 1u;  // bit q: seed q is in
+#pragma unroll
+      for (uint32_t q = 1; q < kTileG / kTileSeedEvery; ++q) {
+        total += s_add[q];
+        in |= (((in >> (q - 1)) & 1u) && total <= kTileSetCap) ? (1u << q) : 0u;
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < 2; ++j) {
+        const uint32_t e = threadIdx.x + 1024u * j;
+        if (e < 3u * kTileS && ecol[j] != kNoCol && ((in >> (1u + e / kTileS)) & 1u)) (void)insert(ecol[j]);
+      }
+    }
+    __syncthreads();
+    stamp(2);  // the set built
+    {
+      // X cleared (the bases and the seeds' rows have been used); the occupied slots numbered in table order (2 slots a
+      // thread, a block-wide scan)
+      uint4 *X4 = reinterpret_cast<uint4 *>(Xw);
+      for (uint32_t q = threadIdx.x; q < kTileG * kTileXS / 8; q += 1024) X4[q] = make_uint4(0u, 0u, 0u, 0u);
       const uint32_t q0 = threadIdx.x * 2;
-      const uint32_t o0 = ht_key[q0] != kNoCol, o1 = ht_key[q0 + 1] != kNoCol, occ = o0 + o1;
+      const uint32_t k0 = ht[q0].x, k1 = ht[q0 + 1].x;
+      const uint32_t o0 = k0 != kNoCol, o1 = k1 != kNoCol, occ = o0 + o1;
       uint32_t incl = occ;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
@@ -844,36 +1005,89 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
       __syncthreads();
       uint32_t before = incl - occ;
       for (int w = 0; w < wv; ++w) before += s_wbase[w];
-      if (threadIdx.x == 1023) s_n = before + occ;
+      if (threadIdx.x == 1023) s_n = before + occ;  // (<= kTileSetCap < kTileU)
       if (o0) {
-        if (before < kTileU) {
-          ht_u[q0] = (uint16_t)before;
-          ucol[before] = ht_key[q0];
-        }
+        ht[q0].y = before;
+        ucol[before] = k0;
         ++before;
       }
-      if (o1 && before < kTileU) {
-        ht_u[q0 + 1] = (uint16_t)before;
-        ucol[before] = ht_key[q0 + 1];
+      if (o1) {
+        ht[q0 + 1].y = before;
+        ucol[before] = k1;
       }
       __syncthreads();
     }
-    if (s_over || s_n > kTileU) {  // too many distinct rows for this scheme: the streaming kernel takes the chunk
-      ++misses;
-      continue;
-    }
-    misses = 0;
-    // ---- 2. X[sequence][number of the row] += 1
+    stamp(3);  // X cleared, the set numbered
+    // ---- 3. every window against the set: a hit becomes the row's number (bit 31 set), a miss stays the row
     {
-      uint32_t found = 0;
+      uint32_t fh = 0;  // windows with a row | hits << 16
 #pragma unroll
       for (uint32_t i = 0; i < kPer; ++i)
-        if (slots[i] != 0xFFFFu && !(dbg & 2)) {
-          const uint32_t u = ht_u[slots[i]];
-          atomicAdd(&Xw[tg * (kTileXS / 2) + (u >> 1)], 1u << (16 * (u & 1u)));
-          ++found;
+        if (cols[i] != kNoCol) {
+          const uint2 e = find(cols[i]);
+          fh += 1u;
+          if (e.x != kNoCol) {
+            cols[i] = 0x80000000u | e.y;
+            fh += 65536u;
+          }
         }
-      if (found) atomicAdd(&s_found[tg], found);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) fh += (uint32_t)__shfl_xor((int)fh, o, 64);
+      if (lane == 0 && fh) atomicAdd(&s_samp, fh);
+    }
+    __syncthreads();
+    stamp(4);  // the windows looked up in the set
+    {
+      // sequences that share little with the seeds (unrelated genomes, a divergent stretch): fewer than half the windows are
+      // of the consensus, and the chunk is left to the streaming kernel
+      const uint32_t fh = s_samp;  // (uniform: read after the barrier; at most 32,768 windows)
+      if ((fh >> 16) * 2u < (fh & 0xFFFFu)) {
+        missed();
+        continue;
+      }
+    }
+    misses = 0;
+    backoff = 8;
+    // ---- 4. X[sequence][number of the row] += 1, or the row onto the sequence's residual list
+    {
+      uint32_t found = 0, resm = 0;
+#pragma unroll
+      for (uint32_t i = 0; i < kPer; ++i) {
+        const uint32_t c = cols[i];
+        if (c != kNoCol) {
+          ++found;
+          if (c & 0x80000000u) {
+            const uint32_t u = c & 0x7FFFFFFFu;
+            if (!(dbg & 2)) atomicAdd(&Xw[tg * (kTileXS / 2) + (u >> 1)], 1u << (16 * (u & 1u)));
+          } else
+            resm |= 1u << i;
+        }
+      }
+      // the sequence's sixteen threads: where each one's residual rows go (window order), and the sequence's totals
+      const uint32_t rcnt = (uint32_t)__popc(resm);
+      uint32_t incl = rcnt;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 16);
+        if (tq >= (uint32_t)o) incl += up;
+      }
+      const uint32_t rtot = (uint32_t)__shfl((int)incl, 15, 16);
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) found += (uint32_t)__shfl_xor((int)found, o, 16);
+      if (mine) {
+        const uint64_t slot = s_slot[tg];
+        uint32_t *list = res_rows + slot * kTileS + (incl - rcnt);
+        uint32_t pos = 0;
+        if (!(dbg & 4)) {
+#pragma unroll
+          for (uint32_t i = 0; i < kPer; ++i)
+            if ((resm >> i) & 1u) list[pos++] = cols[i];
+        }
+        if (tq == 0) {
+          slot_done[slot] = 1u + rtot;
+          partial_cnt[slot] = found;
+        }
+      }
     }
     // (the columns are padded with row 0 of the twister against zero counts: the loops below have no branches, so that the
     // loads of the steps ahead stay in flight under the MFMAs)
@@ -882,6 +1096,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
     const uint32_t UP = ksplit ? ((U + 63) & ~63u) : ((U + 31) & ~31u);
     for (uint32_t u = U + threadIdx.x; u < UP; u += 1024) ucol[u] = 0;
     __syncthreads();
+    stamp(5);  // the windows counted into X or listed
     const uint16_t *X16 = reinterpret_cast<const uint16_t *>(Xw);
     if (ksplit && !(dbg & 1)) {
       // ---- 3a. partial[64 x D] = X[64 x U] * T_U for D <= 64: wave wv owns the 16 dims of slice wv & 3 and a QUARTER of the
@@ -896,8 +1111,10 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
       for (int mi = 0; mi < 4; ++mi) acc[mi] = f64x4{0.0, 0.0, 0.0, 0.0};
       constexpr int PF = 4;  // (eight, with the columns padded to 128: no faster -- the phase is the MFMA pipe's now)
       double bb[PF];
+      if (Uq) {
 #pragma unroll
-      for (int q = 0; q < PF; ++q) bb[q] = trow[(uint64_t)ucol[c0 + 4 * q + (lane >> 4)] * tv.d_pad];
+        for (int q = 0; q < PF; ++q) bb[q] = trow[(uint64_t)ucol[c0 + 4 * q + (lane >> 4)] * tv.d_pad];
+      }
       const uint16_t *xrow = X16 + (lane & 15) * kTileXS + c0 + (lane >> 4);
       for (uint32_t q0 = 0; q0 < Uq / 4; q0 += PF) {
 #pragma unroll
@@ -911,6 +1128,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
         }
       }
       __syncthreads();  // every wave is done with X: its room takes the quarters' sums, [quarter][sequence][dim]
+      stamp(6);  // the matrix cores
       double *P = reinterpret_cast<double *>(Xw);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
@@ -919,9 +1137,10 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
           P[((uint32_t)kh * 64 + 16 * mi + (lane >> 4) + 4 * rr) * 64 + dc] = acc[mi][rr];
       __syncthreads();
       for (uint32_t e = threadIdx.x; e < 64 * 64; e += 1024) {
-        const uint32_t g = e >> 6, d = e & 63u, rd = grp * kTileG + g;
+        const uint32_t g = e >> 6, d = e & 63u;
+        const uint64_t sl = s_slot[g];
         const double v = __dadd_rn(__dadd_rn(__dadd_rn(P[e], P[4096 + e]), P[8192 + e]), P[12288 + e]);
-        if (rd < n_reads && d < tv.n_dims && seg < nseg[rd]) partial[(seg_off[rd] + seg) * tv.n_dims + d] = v;
+        if (sl != ~0ull && d < tv.n_dims) partial[sl * tv.n_dims + d] = v;
       }
     }
     // ---- 3b. the same for D > 64: wave wv owns M tile wv & 3 (16 sequences) and the 16 dims of slice wv >> 2 of every 64
@@ -933,8 +1152,10 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
       f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
       constexpr int PF = 8;
       double bb[PF];
+      if (U32) {
 #pragma unroll
-      for (int q = 0; q < PF; ++q) bb[q] = trow[(uint64_t)ucol[4 * q + (lane >> 4)] * tv.d_pad];
+        for (int q = 0; q < PF; ++q) bb[q] = trow[(uint64_t)ucol[4 * q + (lane >> 4)] * tv.d_pad];
+      }
       const uint16_t *xrow = X16 + (16 * mi + (lane & 15)) * kTileXS + (lane >> 4);
       for (uint32_t q0 = 0; q0 < U32 / 4; q0 += PF) {
 #pragma unroll
@@ -948,15 +1169,79 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
       // lane l holds rows (l >> 4) + 4 r of the M tile, column l & 15 of the wave's 16 dims
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const uint32_t g = 16 * mi + (lane >> 4) + 4 * rr, rd = grp * kTileG + g;
-        if (rd < n_reads && dc < tv.n_dims && seg < nseg[rd]) partial[(seg_off[rd] + seg) * tv.n_dims + dc] = acc[rr];
+        const uint64_t sl = s_slot[16 * mi + (lane >> 4) + 4 * rr];
+        if (sl != ~0ull && dc < tv.n_dims) partial[sl * tv.n_dims + dc] = acc[rr];
       }
     }
-    if (threadIdx.x < kTileG) {
-      const uint32_t rd = grp * kTileG + threadIdx.x;
-      if (rd < n_reads && seg < nseg[rd]) partial_cnt[seg_off[rd] + seg] = s_found[threadIdx.x];
+    stamp(7);  // the sums written
+  }
+  if (stamps)
+    for (int i = 0; i < 9; ++i) atomicAdd(&g_tile_stamps[i], t_acc[i]);
+}
+
+// The residual rows of the (sequence, segment) slots count_twist_tile_kernel took: one wavefront per slot, lane = dimension,
+// eight row loads in flight, added in list (= window) order on top of the consensus sum.  These rows are private to their
+// sequence: they come from HBM whatever the scheme (512 B a row at 64 dimensions), which is what bounds this kernel.
+template <bool NT>
+__global__ __launch_bounds__(256) void tile_residual_kernel(TwisterView tv, const uint32_t *__restrict__ slot_done,
+                                                            const uint32_t *__restrict__ res_rows, double *__restrict__ partial,
+                                                            const uint64_t *__restrict__ n_slots_ptr) {
+  const uint64_t n_slots = *n_slots_ptr;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (uint64_t slot = (uint64_t)blockIdx.x * 4 + wv; slot < n_slots; slot += (uint64_t)gridDim.x * 4) {
+    const uint32_t c = slot_done[slot];
+    if (c <= 1u) continue;  // (0: the streaming kernel's; 1: no residual rows)
+    const uint32_t cnt = c - 1u;
+    const uint32_t *list = res_rows + slot * kTileS;
+    for (uint32_t d0 = 0; d0 < tv.n_dims; d0 += 64) {
+      const uint32_t d = d0 + lane;
+      const double *base = tv.rows + (d < tv.n_dims ? d : tv.n_dims - 1);
+      double acc = 0.0;
+      for (uint32_t j0 = 0; j0 < cnt; j0 += 64) {
+        const uint32_t col = (j0 + lane < cnt) ? list[j0 + lane] : kNoCol;
+        const uint32_t m = min(64u, cnt - j0);
+        constexpr int GU = kGatherUnroll;
+#pragma unroll
+        for (int j = 0; j < 64; j += GU) {
+          if ((uint32_t)j >= m) break;  // (uniform)
+          double v[GU];
+#pragma unroll
+          for (int u = 0; u < GU; ++u) {
+            const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)col, j + u);
+            const uint32_t cs = cj != kNoCol ? cj : 0u;  // (scalar)
+            const double x = NT ? __builtin_nontemporal_load(base + (uint64_t)cs * tv.d_pad) : base[(uint64_t)cs * tv.d_pad];
+            v[u] = cj != kNoCol ? x : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < GU; ++u) acc = __dadd_rn(acc, v[u]);
+        }
+      }
+      if (d < tv.n_dims) partial[slot * tv.n_dims + d] = __dadd_rn(partial[slot * tv.n_dims + d], acc);
     }
-    if (threadIdx.x == 0) tile_done[chunk] = 1;
+  }
+}
+
+// What count_twist_tile_kernel left: the (sequence, segment) pairs whose slot it did not take, for the streaming kernel (one
+// wavefront per sequence with segments; the list's order is not the batch's, and no sum depends on it).
+__global__ __launch_bounds__(256) void tile_todo_kernel(const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ seg_off,
+                                                        const uint32_t *__restrict__ olong, const uint64_t *__restrict__ n_long_ptr,
+                                                        const uint32_t *__restrict__ slot_done, uint2 *__restrict__ todo, uint32_t *__restrict__ n_todo) {
+  const uint32_t n_long = (uint32_t)*n_long_ptr;
+  const int lane = threadIdx.x & 63;
+  for (uint32_t li = blockIdx.x * 4 + (threadIdx.x >> 6); li < n_long; li += gridDim.x * 4) {
+    const uint32_t r = olong[li], ns = nseg[r];
+    const uint64_t s0 = seg_off[r];
+    for (uint32_t sb = 0; sb < ns; sb += 64) {
+      const uint32_t seg = sb + lane;
+      const bool left = seg < ns && slot_done[s0 + seg] == 0u;
+      const uint64_t m = __ballot(left);
+      if (!m) continue;
+      uint32_t base = 0;
+      const int leader = __ffsll((long long)m) - 1;
+      if (lane == leader) base = atomicAdd(n_todo, (uint32_t)__popcll(m));
+      base = (uint32_t)__shfl((int)base, leader, 64);
+      if (left) todo[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(r, seg);
+    }
   }
 }
 
@@ -1117,6 +1402,17 @@ using namespace kpop;
 // ---------------------------------------------------------------------------
 // C ABI: device-resident entry points
 // ---------------------------------------------------------------------------
+extern "C" int kpop_debug_counters(uint64_t *out, int n) {
+  KPOP_TRY(require_init());
+  if (!out || n < 0 || n > 16) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_debug_counters: out null or n not in 0..16");
+  unsigned long long h[16], z[16] = {};
+  KPOP_HIP(hipDeviceSynchronize());
+  KPOP_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tile_stamps), sizeof h));
+  KPOP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tile_stamps), z, sizeof z));
+  for (int i = 0; i < n; ++i) out[i] = h[i];
+  return KPOP_OK;
+}
+
 extern "C" int kpop_dev_synth_reads(uint64_t seed, uint64_t n_reads, uint32_t read_len, uint64_t first_read,
                                     uint8_t *d_bases, uint64_t *d_offsets, void *stream) {
   KPOP_TRY(require_init());
@@ -1150,54 +1446,83 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   // sums: its rows should sit in one XCD's L2 (4 MB) next to those of the neighbouring segment, see the kernel.
   const Context &cx = ctx();
   uint32_t seg_windows = cx.tune_seg ? (uint32_t)cx.tune_seg : std::max<uint32_t>(1024u, std::min<uint32_t>(kSegWindows, (uint32_t)((3ull << 19) / ((uint64_t)tw->d_pad * 8)) / 64 * 64));
-  // kpop_tune("dense", 2): batches of assemblies first go through count_twist_tile_kernel (the distinct rows of a stretch of
-  // 64 sequences gathered once and multiplied on the matrix cores); what it leaves is the streaming kernel's as before
-  const bool tiles = cx.tune_dense == 2 && tv.rsel && n_reads >= kTileG && tv.hk <= 15;
-  if (tiles) seg_windows = kTileS;
+  // Batches of assemblies first go through count_twist_tile_kernel (the consensus rows of a stretch of 64 sequences gathered
+  // once and multiplied on the matrix cores, the private rows listed for tile_residual_kernel); what it leaves -- stretches
+  // that share little with their seeds, found from a sample -- is the streaming kernel's as before.  kpop_tune("dense", 0)
+  // opts out (the streaming kernel alone: the reference's order of additions within a segment).
+  const bool tiles = cx.tune_dense != 0 && tv.rsel && n_reads >= kTileMinSeqs && tv.hk <= 15;
+  if (tiles && !cx.tune_seg) seg_windows = kTileS;
   const bool nt = cx.tune_nt == 1;
-  const uint64_t max_slots = n_bases / seg_windows + n_reads;  // every read adds at most W/seg + 1 segments
+  // (a sequence with segments has more than kWaveMaxWindows windows: at most this many of them)
+  const uint32_t max_long = (uint32_t)std::min<uint64_t>(n_reads, n_bases / kWaveMaxWindows + 1);
+  const uint64_t max_slots = n_bases / seg_windows + max_long;  // every such sequence adds at most W/seg + 1 segments
   const uint64_t nb = scan_blocks(n_reads);
   const uint32_t max_seg = div_up(max_windows, seg_windows);
-  const uint32_t n_groups = div_up(n_reads, kTileG);
+  const uint32_t max_groups = div_up(max_long, kTileG);
+  const bool tile_segs = tiles && seg_windows == kTileS;
   const uint64_t bytes_nseg = ((uint64_t)n_reads * 4 + 63) & ~63ull, bytes_off = ((uint64_t)(n_reads + 1) * 8 + 63) & ~63ull,
                  bytes_sums = ((nb + 1) * 8 + 63) & ~63ull, bytes_cnt = (max_slots * 4 + 63) & ~63ull,
-                 bytes_part = (max_slots * tw->n_dims * 8 + 63) & ~63ull, bytes_done = tiles ? (((uint64_t)n_groups * max_seg + 63) & ~63ull) : 0,
-                 bytes_long = ((uint64_t)n_reads * 4 + 64 + 63) & ~63ull;
+                 bytes_part = (max_slots * tw->n_dims * 8 + 63) & ~63ull, bytes_done = tile_segs ? ((max_slots * 4 + 63) & ~63ull) : 0,
+                 bytes_long = ((uint64_t)n_reads * 4 + 64 + 63) & ~63ull,
+                 bytes_olong = tile_segs ? (((uint64_t)max_long * 4 + 63) & ~63ull) : 0, bytes_gmax = tile_segs ? (((uint64_t)max_groups * 4 + 63) & ~63ull) : 0,
+                 bytes_res = tile_segs ? max_slots * kTileS * 4 : 0, bytes_todo = tile_segs ? ((max_slots * 8 + 64 + 63) & ~63ull) : 0;
   void *ws = nullptr;
-  KPOP_TRY(ctx().ws_for(st).ensure(bytes_nseg + bytes_off + bytes_sums + bytes_cnt + bytes_part + bytes_done + bytes_long, &ws));
+  KPOP_TRY(ctx().ws_for(st).ensure(bytes_nseg + bytes_off + 2 * bytes_sums + bytes_cnt + bytes_part + bytes_done + bytes_long + bytes_olong + bytes_gmax + bytes_res + bytes_todo, &ws));
   char *wp = reinterpret_cast<char *>(ws);
-  uint32_t *nseg = reinterpret_cast<uint32_t *>(wp);
-  uint64_t *seg_off = reinterpret_cast<uint64_t *>(wp + bytes_nseg);
-  uint64_t *sums = reinterpret_cast<uint64_t *>(wp + bytes_nseg + bytes_off);
-  uint32_t *pcnt = reinterpret_cast<uint32_t *>(wp + bytes_nseg + bytes_off + bytes_sums);
-  double *part = reinterpret_cast<double *>(wp + bytes_nseg + bytes_off + bytes_sums + bytes_cnt);
-  uint8_t *tile_done = tiles ? reinterpret_cast<uint8_t *>(wp + bytes_nseg + bytes_off + bytes_sums + bytes_cnt + bytes_part) : nullptr;
-  uint32_t *n_long = reinterpret_cast<uint32_t *>(wp + bytes_nseg + bytes_off + bytes_sums + bytes_cnt + bytes_part + bytes_done);
+  auto carve = [&](uint64_t bytes) {
+    char *p = wp;
+    wp += bytes;
+    return p;
+  };
+  uint32_t *nseg = reinterpret_cast<uint32_t *>(carve(bytes_nseg));
+  uint64_t *seg_off = reinterpret_cast<uint64_t *>(carve(bytes_off));
+  uint64_t *sums = reinterpret_cast<uint64_t *>(carve(bytes_sums));
+  uint64_t *sums2 = reinterpret_cast<uint64_t *>(carve(bytes_sums));
+  uint32_t *pcnt = reinterpret_cast<uint32_t *>(carve(bytes_cnt));
+  double *part = reinterpret_cast<double *>(carve(bytes_part));
+  uint32_t *slot_done = tile_segs ? reinterpret_cast<uint32_t *>(carve(bytes_done)) : nullptr;
+  uint32_t *n_long = reinterpret_cast<uint32_t *>(carve(bytes_long));
   uint32_t *long_ids = n_long + 16;
+  uint32_t *olong = reinterpret_cast<uint32_t *>(carve(bytes_olong));
+  uint32_t *gmax = reinterpret_cast<uint32_t *>(carve(bytes_gmax));
+  uint32_t *res_rows = reinterpret_cast<uint32_t *>(carve(bytes_res));
+  uint32_t *n_todo = reinterpret_cast<uint32_t *>(carve(bytes_todo));
+  uint2 *todo = tile_segs ? reinterpret_cast<uint2 *>(n_todo + 16) : nullptr;
   KPOP_HIP(hipMemsetAsync(n_long, 0, 64, st));
   segment_count_kernel<<<dim3(div_up(n_reads, 256)), dim3(256), 0, st>>>(d_offsets, n_reads, tv.hk, seg_windows, nseg, long_ids, n_long);
   KPOP_LAUNCH_CHECK();
-  // (a sequence with segments has more than kWaveMaxWindows windows: at most this many of them)
-  const uint32_t max_long = (uint32_t)std::min<uint64_t>(n_reads, n_bases / kWaveMaxWindows + 1);
   KPOP_TRY(exclusive_scan(LoadU32{nseg}, StoreU64{seg_off}, n_reads, sums, st));
-  if (tiles) {
-    KPOP_HIP(hipMemsetAsync(tile_done, 0, bytes_done, st));
-    const size_t lds = (size_t)kTileH * 4 + kTileH * 2 + kTileU * 4 + (size_t)kTileG * kTileXS * 2;
+  if (tile_segs) {
+    KPOP_HIP(hipMemsetAsync(slot_done, 0, bytes_done, st));
+    KPOP_TRY(exclusive_scan(LoadLong{nseg}, StoreLong{olong}, n_reads, sums2, st));
+    tile_group_max_kernel<<<dim3(div_up(max_groups, 4)), dim3(256), 0, st>>>(nseg, olong, sums2 + nb, gmax);
+    KPOP_LAUNCH_CHECK();
+    const size_t lds = (size_t)kTileH * 8 + kTileU * 4 + (size_t)kTileG * kTileXS * 2;
     static PerSlotOnce once;
     if (!once()) {
       KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&count_twist_tile_kernel<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       once() = true;
     }
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)n_groups * max_seg, (uint64_t)cx.n_cus);
-    count_twist_tile_kernel<uint32_t><<<dim3(blocks), dim3(1024), lds, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, n_reads,
-                                                                           max_seg, tile_done, ctx().tune_dbg >> 24);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)max_groups * max_seg, (uint64_t)cx.n_cus);
+    count_twist_tile_kernel<uint32_t><<<dim3(blocks), dim3(1024), lds, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, olong, sums2 + nb,
+                                                                           gmax, max_seg, slot_done, res_rows, ctx().tune_dbg >> 24);
+    KPOP_LAUNCH_CHECK();
+    const dim3 rgrid(capped_grid((max_slots + 3) / 4));
+    if (nt)
+      tile_residual_kernel<true><<<rgrid, dim3(256), 0, st>>>(tv, slot_done, res_rows, part, sums + nb);
+    else
+      tile_residual_kernel<false><<<rgrid, dim3(256), 0, st>>>(tv, slot_done, res_rows, part, sums + nb);
+    KPOP_LAUNCH_CHECK();
+    KPOP_HIP(hipMemsetAsync(n_todo, 0, 64, st));
+    tile_todo_kernel<<<dim3(std::min<uint32_t>(div_up(max_long, 4), 4096u)), dim3(256), 0, st>>>(nseg, seg_off, olong, sums2 + nb, slot_done, todo, n_todo);
     KPOP_LAUNCH_CHECK();
   }
-  dim3 grid(capped_grid((uint64_t)max_long * max_seg));
+  // (with a to-do list the pairs all have work, and how many is on the device: a grid that fills the chip, striding)
+  dim3 grid(tile_segs ? (uint32_t)std::min<uint64_t>(max_slots, (uint64_t)cx.n_cus * 16) : capped_grid((uint64_t)max_long * max_seg));
   // The dimensions go in passes of up to 256 (four blocks of 64 a lane), 128 or 64 -- one LAUNCH per pass, so that a pass never
   // loads blocks it has no dimensions for (300 dimensions: 256 + 44; a run-time guard on the loads brought the per-window
   // branches back: 2.4 -> 5.2 ms at 64 dimensions).  Every launch hashes the windows again: once per 256 dimensions, not per 64.
-#define KPOP_STREAM_B(H, NT, B, D0, D1) count_twist_stream_kernel<H, NT, B><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, long_ids, n_long, max_seg, seg_windows, tile_done, n_groups, D0, D1)
+#define KPOP_STREAM_B(H, NT, B, D0, D1) count_twist_stream_kernel<H, NT, B><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, long_ids, tile_segs ? n_todo : n_long, max_seg, seg_windows, todo, D0, D1)
 #define KPOP_STREAM(H, NT)                                                        \
   do {                                                                            \
     for (uint32_t pos = 0; pos < tw->n_dims;) {                                    \

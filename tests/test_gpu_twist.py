@@ -509,25 +509,29 @@ def test_count_twist_through_the_dense_image(kpop, oracle, k, d, content):
         api.dev_count_twist_dense(big, db.data_ptr(), do.data_ptr(), n, work.data_ptr(), out.data_ptr())
 
 
-@pytest.mark.parametrize("k,d", [(12, 64), (10, 40), (13, 130)])
-def test_assemblies_of_one_organism_through_the_tile_kernel(kpop, oracle, k, d):
-    """kpop_tune("dense", 2): stretches of 64 near-identical assemblies go through count_twist_tile_kernel (distinct rows in an
-    LDS set, counts in an LDS matrix, the matrix cores), divergent stretches and unrelated sequences are left to the
-    streaming kernel, short reads to the wave kernel -- against the oracle and the default kernels, normalised or not"""
+@pytest.mark.parametrize("k,d,rate", [(12, 64, 0.002), (10, 40, 0.001), (13, 130, 0.003), (12, 64, 0.01), (12, 64, 0.03), (11, 16, 0.1)])
+def test_assemblies_of_one_organism_through_the_tile_kernel(kpop, oracle, k, d, rate):
+    """The DEFAULT path for sequences of more than 512 windows: stretches of 64 assemblies go through count_twist_tile_kernel
+    (the rows of four seed sequences in an LDS set = the consensus, counted into an LDS matrix and multiplied on the matrix
+    cores; the rows private to a sequence listed and gathered by tile_residual_kernel), stretches that share little with
+    their seeds and unrelated sequences are left to the streaming kernel, short reads to the wave kernel -- against the
+    oracle and against kpop_tune("dense", 0), normalised or not, at divergences from 0.1 % to 10 % (lib/Twister.ml:146-188)"""
     from kpop_amd import api
     rng = np.random.RandomState(k + d)
     ref = rng.choice(list("ACGT"), size=7000)
     seqs = []
     for i in range(150):  # mutants: substitutions, a few Ns, some with a deletion (the windows shift), ragged ends
         m = ref.copy()
-        hit = rng.rand(len(m)) < 0.002
+        hit = rng.rand(len(m)) < rate
         m[hit] = rng.choice(list("ACGTN"), size=int(hit.sum()), p=[.24, .24, .24, .24, .04])
         if i % 7 == 0:
             cut = int(rng.randint(100, 6000))
             m = np.concatenate([m[:cut], m[cut + 5:]])
+        if i % 31 == 5:
+            m[1000:1700] = "N"  # a masked stretch (an amplicon that dropped out)
         seqs.append("".join(m[: len(m) - int(rng.randint(0, 900))]))
-    seqs += ["".join(rng.choice(list("ACGT"), size=int(rng.randint(3000, 9000)))) for _ in range(70)]  # unrelated: the set overflows
-    seqs += ["ACGTTGCA" * 10, "", "ACG"] + ["".join(rng.choice(list("ACGT"), size=150)) for _ in range(20)]
+    seqs += ["".join(rng.choice(list("ACGT"), size=int(rng.randint(3000, 9000)))) for _ in range(70)]  # unrelated: nothing in common with the seeds
+    seqs += ["ACGTTGCA" * 10, "", "ACG", "A" * 2000] + ["".join(rng.choice(list("ACGT"), size=150)) for _ in range(20)]
     order = rng.permutation(len(seqs))
     seqs = [seqs[i] for i in order[:40]] + seqs[:150] + [seqs[i] for i in order[40:] if i >= 150]  # a run of mutants in the middle
     bases, offs = concat(seqs)
@@ -541,16 +545,44 @@ def test_assemblies_of_one_organism_through_the_tile_kernel(kpop, oracle, k, d):
     tw = kpop.Twister.load(T, cols, k)
     for normalize in (True, False):
         want = oracle.twist(T, cols, h, c.astype(np.float64), o, normalize=normalize)
-        ref_rows = tw.count_twist(bases, offs, normalize=normalize)
-        api.tune("dense", 2)
+        got = tw.count_twist(bases, offs, normalize=normalize)
+        again = tw.count_twist(bases, offs, normalize=normalize)
+        api.tune("dense", 0)
         try:
-            got = tw.count_twist(bases, offs, normalize=normalize)
+            ref_rows = tw.count_twist(bases, offs, normalize=normalize)
         finally:
-            api.tune("dense", 0)
+            api.tune("dense", 2)
         scale = max(np.max(np.abs(want)), 1.0)
         assert np.max(np.abs(ref_rows - want)) <= 1e-12 * scale
         assert np.max(np.abs(got - want)) <= 1e-12 * scale, np.max(np.abs(got - want))
+        assert np.array_equal(got, again)  # (no order of additions depends on the run)
         assert not np.array_equal(got, ref_rows)  # (another order of additions: the tile kernel did run)
+
+
+def test_few_assemblies_among_many_reads_and_tiny_batches(kpop, oracle):
+    """the tile route's groups are cut from the sequences that HAVE segments: three assemblies of one organism among 3,000 reads
+    (fewer than the route bothers with), then forty of them scattered among the reads (one group), against the oracle"""
+    rng = np.random.RandomState(77)
+    k, d = 11, 24
+    ref = rng.choice(list("ACGT"), size=5000)
+    def mutant():
+        m = ref.copy()
+        hit = rng.rand(len(m)) < 0.004
+        m[hit] = rng.choice(list("ACGT"), size=int(hit.sum()))
+        return "".join(m)
+    reads = ["".join(rng.choice(list("ACGT"), size=150)) for _ in range(3000)]
+    cols = oracle.enumerate_kmers(k)
+    T = oracle.synth_twister(9, d, cols)
+    tw = kpop.Twister.load(T, cols, k)
+    for n_asm in (3, 40):
+        seqs = list(reads)
+        for i in range(n_asm):
+            seqs.insert(int(rng.randint(0, len(seqs))), mutant())
+        bases, offs = concat(seqs)
+        h, c, o = oracle.count_reads(bases, offs, k)
+        want = oracle.twist(T, cols, h, c.astype(np.float64), o)
+        got = tw.count_twist(bases, offs)
+        assert np.max(np.abs(got - want)) <= 1e-12 * max(np.max(np.abs(want)), 1.0)
 
 
 def test_understated_max_len_yields_nan_rows_not_stale_memory(kpop, oracle):
