@@ -578,15 +578,21 @@ constexpr uint64_t kStreamingRowBytes = 2ull << 30;
 // nseg[r] = the segments of sequence r (0: the one-wavefront-per-read kernel's), and the list of the sequences that have
 // any (wave-aggregated append: the order of the list is not the batch's, and nothing depends on it).  The streaming kernel
 // and the combine walk the LIST: one genome among 100,000 reads cost 0.66 ms of looking at pairs that had no segment.
+// (lpos, grel, segw: with the tile route on, a sequence of a group of ONE organism -- tile_group_probe_kernel -- is cut into the
+// tile kernel's stretches of 512 windows, any other into seg_windows as ever; segw[r] = which)
 __global__ void segment_count_kernel(const uint64_t *__restrict__ offsets, uint32_t n, int k, uint32_t seg_windows,
-                                     uint32_t *__restrict__ nseg, uint32_t *__restrict__ long_ids, uint32_t *__restrict__ n_long) {
+                                     uint32_t *__restrict__ nseg, uint32_t *__restrict__ long_ids, uint32_t *__restrict__ n_long,
+                                     const uint32_t *__restrict__ lpos, const uint32_t *__restrict__ grel, uint32_t *__restrict__ segw) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t ns = 0;
   if (r < n) {
     const uint64_t len = offsets[r + 1] - offsets[r];
     const uint64_t w = (len >= (uint64_t)k) ? len - k + 1 : 0;
-    ns = (w > kWaveMaxWindows) ? (uint32_t)((w + seg_windows - 1) / seg_windows) : 0u;
+    uint32_t sw = seg_windows;
+    if (lpos && w > kWaveMaxWindows && grel[lpos[r] / 64u]) sw = 512u;
+    ns = (w > kWaveMaxWindows) ? (uint32_t)((w + sw - 1) / sw) : 0u;
     nseg[r] = ns;
+    if (segw) segw[r] = sw;
   }
   const uint64_t m = __ballot(ns != 0);
   if (m) {
@@ -610,9 +616,10 @@ __global__ __launch_bounds__(256) void count_twist_stream_kernel(
     TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int content,
     const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ seg_off, double *__restrict__ partial,
     uint32_t *__restrict__ partial_cnt, const uint32_t *__restrict__ long_ids, const uint32_t *__restrict__ n_long_ptr, uint32_t max_seg,
-    uint32_t seg_windows, const uint2 *__restrict__ todo, uint32_t d_begin, uint32_t d_end) {
+    uint32_t seg_windows_all, const uint2 *__restrict__ todo, const uint32_t *__restrict__ segw, uint32_t *__restrict__ next_pair,
+    uint32_t d_begin, uint32_t d_end) {
   __shared__ double s_part[4][64 * NDB];
-  __shared__ uint32_t s_cnt[4];
+  __shared__ uint32_t s_cnt[4], s_pair;
   // todo: the (sequence, segment) pairs count_twist_tile_kernel left (tile_todo_kernel's list; n_long_ptr then counts those)
   const uint32_t n_reads = *n_long_ptr;  // the sequences that have segments (long_ids), not the batch
   if (n_reads == 0) return;
@@ -622,11 +629,19 @@ __global__ __launch_bounds__(256) void count_twist_stream_kernel(
   // from HBM once per XCD and are L2 hits for every other sequence.  Unrelated sequences lose nothing by this order.
   // A ragged batch (one genome among a million reads) has far more pairs than HIP allows blocks, and almost all of them
   // are empty, hence the grid-stride loop.
+  // With a to-do list every pair has work and the blocks are as many as the chip holds at once: each takes the next pair
+  // off a counter when it is done with one (dealt round-robin, 50,000 pairs over 2,048 blocks are 25 for some and 24 for
+  // others: the launch took 25 pairs' time, 12.99 against 12.60 ms).
   const uint64_t n_pairs = todo ? (uint64_t)n_reads : (uint64_t)n_reads * max_seg;
   for (uint64_t pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
   uint32_t seg, r;
   if (todo) {
-    const uint2 t = todo[pair];
+    if (threadIdx.x == 0) s_pair = atomicAdd(next_pair, 1u);
+    __syncthreads();
+    const uint32_t mine = s_pair;
+    if (mine >= n_pairs) break;  // (uniform)
+    pair = blockIdx.x;           // (the loop's own counter plays no part)
+    const uint2 t = todo[mine];
     r = t.x;
     seg = t.y;
   } else {
@@ -639,6 +654,7 @@ __global__ __launch_bounds__(256) void count_twist_stream_kernel(
   const uint64_t len = offsets[r + 1] - off;
   const int k = tv.hk;
   const uint64_t n_win = len - k + 1;  // nseg > 0 implies len >= k
+  const uint32_t seg_windows = segw ? segw[r] : seg_windows_all;
   const uint64_t w0 = (uint64_t)seg * seg_windows;
   const uint64_t w1 = min(n_win, w0 + seg_windows);
   const uint8_t *seq = bases + off;
@@ -739,24 +755,127 @@ constexpr uint32_t kTileSeedEvery = 16;  // sequences 0, 16, 32, 48 of a group a
 constexpr uint32_t kTileStageW = 136;    // dwords of a sequence's staged stretch: 3 + 512 + 14 bytes and the thirteenth dword of the last thread
 constexpr uint32_t kTileMinSeqs = 16;    // sequences with segments in a batch below which the tile kernel does not try
 
-// the sequences that have segments, in batch order (an exclusive scan's compaction), and the longest of every group of 64 of them
-struct LoadLong {
-  const uint32_t *nseg;
-  __device__ uint32_t operator()(uint64_t i) const { return nseg[i] != 0u; }
-};
-struct StoreLong {
-  uint32_t *olong;
-  __device__ void operator()(uint64_t i, uint64_t prefix, uint32_t v) const {
-    if (v) olong[prefix] = (uint32_t)i;
+// the sequences of more than kWaveMaxWindows windows, in batch order (an exclusive scan's compaction), each one's place in that list
+struct LoadLongW {
+  const uint64_t *offsets;
+  int k;
+  __device__ uint32_t operator()(uint64_t i) const {
+    const uint64_t len = offsets[i + 1] - offsets[i];
+    return (len >= (uint64_t)k && len - k + 1 > kWaveMaxWindows) ? 1u : 0u;
   }
 };
-__global__ __launch_bounds__(256) void tile_group_max_kernel(const uint32_t *__restrict__ nseg, const uint32_t *__restrict__ olong,
-                                                             const uint64_t *__restrict__ n_long_ptr, uint32_t *__restrict__ gmax) {
-  const uint32_t n_long = (uint32_t)*n_long_ptr, g = blockIdx.x * 4 + (threadIdx.x >> 6), li = g * kTileG + (threadIdx.x & 63);
-  uint32_t m = li < n_long ? nseg[olong[li]] : 0u;
+struct StoreLong {
+  uint32_t *olong, *lpos;
+  __device__ void operator()(uint64_t i, uint64_t prefix, uint32_t v) const {
+    if (v) {
+      olong[prefix] = (uint32_t)i;
+      lpos[i] = (uint32_t)prefix;
+    }
+  }
+};
+
+// Is a group of 64 of them ONE organism?  Asked before anything is laid out, at three stretches (a quarter, a half, three
+// quarters of the way along the group's longest sequence): the k-mers of the four seeds' 512 windows go into an LDS set (hashes:
+// no twister needed), eight windows of each of the 64 sequences are looked up, and half of them or more found at any of the three
+// stretches says yes.  A group that says no is never touched by the tile kernel and keeps the streaming kernel's own (longer)
+// segments: a batch of unrelated genomes pays this probe and nothing else (it paid 8-10 % for the tile kernel's attempts and for
+// segments of 512 windows before).  One block per group; also the group's longest sequence in stretches of 512 windows (gmax).
+__global__ __launch_bounds__(256) void tile_group_probe_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int k, int content,
+                                                               const uint32_t *__restrict__ olong, const uint64_t *__restrict__ n_long_ptr,
+                                                               uint32_t *__restrict__ gmax, uint32_t *__restrict__ grel) {
+  constexpr uint32_t kTab = 4096;
+  __shared__ uint32_t tab[kTab];
+  __shared__ uint32_t s_maxw, s_stat;
+  const uint32_t n_long = (uint32_t)*n_long_ptr, g = blockIdx.x;
+  if ((uint64_t)g * kTileG >= n_long) return;
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) {
+    const uint32_t li = g * kTileG + threadIdx.x;
+    uint32_t w = 0;
+    if (li < n_long) {
+      const uint32_t r = olong[li];
+      const uint64_t len = offsets[r + 1] - offsets[r];
+      w = (uint32_t)min<uint64_t>(len - k + 1, 0xFFFFFFFFull);  // (of the list: more than 512 windows)
+    }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-  if ((threadIdx.x & 63) == 0 && (uint64_t)g * kTileG < n_long) gmax[g] = m;
+    for (int o = 32; o > 0; o >>= 1) w = max(w, (uint32_t)__shfl_xor((int)w, o, 64));
+    if (lane == 0) s_maxw = w;
+  }
+  __syncthreads();
+  const uint32_t ns = (s_maxw + kTileS - 1) / kTileS;
+  const int shift = 2 * (k - 1);
+  const uint32_t mask = (uint32_t)bits_mask(2 * k);
+  // eight consecutive windows of sequence `li` of the list from window w on: their hashes, kNoCol where there is none
+  auto hashes = [&](uint32_t li, uint64_t w, uint32_t (&h)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = kNoCol;
+    if (li >= n_long) return;
+    const uint32_t r = olong[li];
+    const uint64_t off = offsets[r], len = offsets[r + 1] - off;
+    const uint64_t n_win = len - k + 1;
+    if (w >= n_win) return;
+    const uint8_t *seq = bases + off + w;
+    const uint32_t nb = (uint32_t)min<uint64_t>(n_win - w, 8) + (uint32_t)k - 1;  // bases to read
+    uint32_t fwd = 0, rc = 0;
+    int run = 0;
+    for (uint32_t j = 0; j < nb; ++j) {
+      const uint32_t c = base_code(seq[j]);
+      fwd = ((fwd << 2) | (c & 3u)) & mask;
+      rc = (rc >> 2) | ((3u - (c & 3u)) << shift);
+      run = c < 4u ? run + 1 : 0;
+      if (j + 1 >= (uint32_t)k && run >= k) {
+        const uint32_t v = (content == KPOP_DNA_DS && rc < fwd) ? rc : fwd;
+        const uint32_t i = j + 1 - (uint32_t)k;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if ((uint32_t)q == i) h[q] = v;
+      }
+    }
+  };
+  uint32_t rel = 0;
+  for (uint32_t sample = 1; sample <= 3 && !rel; ++sample) {  // (rel is uniform)
+    const uint64_t s_beg = (uint64_t)(ns * sample / 4) * kTileS;
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < kTab; q += 256) tab[q] = kNoCol;
+    if (threadIdx.x == 0) s_stat = 0;
+    __syncthreads();
+    uint32_t h[8];
+    hashes(g * kTileG + (threadIdx.x >> 6) * kTileSeedEvery, s_beg + (uint64_t)(threadIdx.x & 63) * 8, h);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (h[i] != kNoCol) {
+        uint32_t slot = (h[i] * 2654435761u) >> 20;  // 12 bits
+        for (uint32_t t = 0; t < kTab; ++t) {        // (at most 2,048 of 4,096 slots are ever taken)
+          const uint32_t prev = atomicCAS(&tab[slot], kNoCol, h[i]);
+          if (prev == kNoCol || prev == h[i]) break;
+          slot = (slot + 1) & (kTab - 1);
+        }
+      }
+    __syncthreads();
+    hashes(g * kTileG + (threadIdx.x >> 2), s_beg + (uint64_t)(threadIdx.x & 3) * 128, h);
+    uint32_t st = 0;  // windows | hits << 16
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (h[i] != kNoCol) {
+        uint32_t slot = (h[i] * 2654435761u) >> 20;
+        uint32_t key = tab[slot];
+        for (uint32_t t = 0; t < kTab && key != h[i] && key != kNoCol; ++t) {
+          slot = (slot + 1) & (kTab - 1);
+          key = tab[slot];
+        }
+        st += 1u + (key == h[i] ? 65536u : 0u);
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) st += (uint32_t)__shfl_xor((int)st, o, 64);
+    if (lane == 0 && st) atomicAdd(&s_stat, st);
+    __syncthreads();
+    const uint32_t tot = s_stat;
+    rel = ((tot & 0xFFFFu) > 0 && (tot >> 16) * 2u >= (tot & 0xFFFFu)) ? 1u : 0u;
+  }
+  if (threadIdx.x == 0) {
+    gmax[g] = ns;
+    grel[g] = rel;
+  }
 }
 
 // phase clocks of count_twist_tile_kernel (kpop_tune("dbg", 16 << 24) only: s_memtime ticks of every block's thread 0, summed
@@ -768,7 +887,8 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
     TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int content,
     const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ seg_off, double *__restrict__ partial,
     uint32_t *__restrict__ partial_cnt, const uint32_t *__restrict__ olong, const uint64_t *__restrict__ n_long_ptr,
-    const uint32_t *__restrict__ gmax, uint32_t max_seg, uint32_t *__restrict__ slot_done, uint32_t *__restrict__ res_rows, int dbg) {
+    const uint32_t *__restrict__ gmax, const uint32_t *__restrict__ grel, uint32_t max_seg, uint32_t *__restrict__ slot_done,
+    uint32_t *__restrict__ res_rows, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_lds[];
   uint2 *ht = reinterpret_cast<uint2 *>(tile_lds);                  // [kTileH] {twister row (kNoCol = empty), its number in the set}
   uint32_t *ucol = reinterpret_cast<uint32_t *>(ht + kTileH);       // [kTileU] row of number u
@@ -841,7 +961,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
   for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     // chunks are dealt with the groups fastest: blocks running together work on one stretch of all sequences
     const uint32_t seg = (uint32_t)(chunk / n_groups), grp = (uint32_t)(chunk % n_groups);
-    if (seg >= gmax[grp]) continue;  // (none of the group's sequences is this long)
+    if (!grel[grp] || seg >= gmax[grp]) continue;  // (not one organism: tile_group_probe_kernel; none of the group's sequences is this long)
     if (skip) {  // (uniform over the block)
       --skip;
       continue;
@@ -1226,22 +1346,39 @@ __global__ __launch_bounds__(256) void tile_residual_kernel(TwisterView tv, cons
 __global__ __launch_bounds__(256) void tile_todo_kernel(const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ seg_off,
                                                         const uint32_t *__restrict__ olong, const uint64_t *__restrict__ n_long_ptr,
                                                         const uint32_t *__restrict__ slot_done, uint2 *__restrict__ todo, uint32_t *__restrict__ n_todo) {
+  // a thread per sequence counts its slots left, the block takes room for all of them with ONE atomic (a wavefront per sequence
+  // and an atomic each: 5,000 atomics on one word, 59 us), then every sequence's pairs are written by its thread
+  __shared__ uint32_t s_wsum[4], s_base;
   const uint32_t n_long = (uint32_t)*n_long_ptr;
-  const int lane = threadIdx.x & 63;
-  for (uint32_t li = blockIdx.x * 4 + (threadIdx.x >> 6); li < n_long; li += gridDim.x * 4) {
-    const uint32_t r = olong[li], ns = nseg[r];
-    const uint64_t s0 = seg_off[r];
-    for (uint32_t sb = 0; sb < ns; sb += 64) {
-      const uint32_t seg = sb + lane;
-      const bool left = seg < ns && slot_done[s0 + seg] == 0u;
-      const uint64_t m = __ballot(left);
-      if (!m) continue;
-      uint32_t base = 0;
-      const int leader = __ffsll((long long)m) - 1;
-      if (lane == leader) base = atomicAdd(n_todo, (uint32_t)__popcll(m));
-      base = (uint32_t)__shfl((int)base, leader, 64);
-      if (left) todo[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(r, seg);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (uint32_t l0 = blockIdx.x * 256u; l0 < n_long; l0 += gridDim.x * 256u) {  // (uniform)
+    const uint32_t li = l0 + threadIdx.x;
+    uint32_t r = 0, ns = 0, left = 0;
+    uint64_t s0 = 0;
+    if (li < n_long) {
+      r = olong[li];
+      ns = nseg[r];
+      s0 = seg_off[r];
+      for (uint32_t seg = 0; seg < ns; ++seg) left += slot_done[s0 + seg] == 0u;
     }
+    uint32_t incl = left;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    __syncthreads();
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+      s_base = tot ? atomicAdd(n_todo, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t pos = s_base + incl - left;
+    for (int w = 0; w < wv; ++w) pos += s_wsum[w];
+    for (uint32_t seg = 0; seg < ns && left; ++seg)
+      if (slot_done[s0 + seg] == 0u) todo[pos++] = make_uint2(r, seg);
   }
 }
 
@@ -1264,7 +1401,15 @@ __global__ __launch_bounds__(256) void combine_partials_kernel(const uint32_t *_
     const bool norm = normalize && acc != 0.0;
     for (uint32_t d = threadIdx.x; d < n_dims; d += blockDim.x) {
       double t = 0.0;
-      for (uint32_t s = 0; s < ns; ++s) t = __dadd_rn(t, partial[(s0 + s) * n_dims + d]);
+      uint32_t s = 0;
+      for (; s + 8 <= ns; s += 8) {  // (eight loads in flight, added in segment order: 59 segments of 512 windows were 59 round trips)
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(s0 + s + u) * n_dims + d];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t = __dadd_rn(t, v[u]);
+      }
+      for (; s < ns; ++s) t = __dadd_rn(t, partial[(s0 + s) * n_dims + d]);
       out[(uint64_t)r * n_dims + d] = norm ? t / acc : t;
     }
   }
@@ -1450,24 +1595,25 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   // once and multiplied on the matrix cores, the private rows listed for tile_residual_kernel); what it leaves -- stretches
   // that share little with their seeds, found from a sample -- is the streaming kernel's as before.  kpop_tune("dense", 0)
   // opts out (the streaming kernel alone: the reference's order of additions within a segment).
-  const bool tiles = cx.tune_dense != 0 && tv.rsel && n_reads >= kTileMinSeqs && tv.hk <= 15;
-  if (tiles && !cx.tune_seg) seg_windows = kTileS;
+  const bool tiles = cx.tune_dense != 0 && tv.rsel && n_reads >= kTileMinSeqs && tv.hk <= 15 && !cx.tune_seg;
   const bool nt = cx.tune_nt == 1;
   // (a sequence with segments has more than kWaveMaxWindows windows: at most this many of them)
   const uint32_t max_long = (uint32_t)std::min<uint64_t>(n_reads, n_bases / kWaveMaxWindows + 1);
-  const uint64_t max_slots = n_bases / seg_windows + max_long;  // every such sequence adds at most W/seg + 1 segments
+  const uint32_t seg_least = tiles ? std::min(seg_windows, kTileS) : seg_windows;  // (the shortest segment any sequence is cut into)
+  const uint64_t max_slots = n_bases / seg_least + max_long;  // every such sequence adds at most W/seg + 1 segments
   const uint64_t nb = scan_blocks(n_reads);
-  const uint32_t max_seg = div_up(max_windows, seg_windows);
+  const uint32_t max_seg = div_up(max_windows, seg_least);
   const uint32_t max_groups = div_up(max_long, kTileG);
-  const bool tile_segs = tiles && seg_windows == kTileS;
   const uint64_t bytes_nseg = ((uint64_t)n_reads * 4 + 63) & ~63ull, bytes_off = ((uint64_t)(n_reads + 1) * 8 + 63) & ~63ull,
                  bytes_sums = ((nb + 1) * 8 + 63) & ~63ull, bytes_cnt = (max_slots * 4 + 63) & ~63ull,
-                 bytes_part = (max_slots * tw->n_dims * 8 + 63) & ~63ull, bytes_done = tile_segs ? ((max_slots * 4 + 63) & ~63ull) : 0,
+                 bytes_part = (max_slots * tw->n_dims * 8 + 63) & ~63ull, bytes_done = tiles ? ((max_slots * 4 + 63) & ~63ull) : 0,
                  bytes_long = ((uint64_t)n_reads * 4 + 64 + 63) & ~63ull,
-                 bytes_olong = tile_segs ? (((uint64_t)max_long * 4 + 63) & ~63ull) : 0, bytes_gmax = tile_segs ? (((uint64_t)max_groups * 4 + 63) & ~63ull) : 0,
-                 bytes_res = tile_segs ? max_slots * kTileS * 4 : 0, bytes_todo = tile_segs ? ((max_slots * 8 + 64 + 63) & ~63ull) : 0;
+                 bytes_olong = tiles ? (((uint64_t)max_long * 4 + 63) & ~63ull) : 0, bytes_gmax = tiles ? (((uint64_t)max_groups * 4 + 63) & ~63ull) : 0,
+                 bytes_res = tiles ? max_slots * kTileS * 4 : 0, bytes_todo = tiles ? ((max_slots * 8 + 1024 + 63) & ~63ull) : 0,
+                 bytes_perread = tiles ? bytes_nseg : 0;
   void *ws = nullptr;
-  KPOP_TRY(ctx().ws_for(st).ensure(bytes_nseg + bytes_off + 2 * bytes_sums + bytes_cnt + bytes_part + bytes_done + bytes_long + bytes_olong + bytes_gmax + bytes_res + bytes_todo, &ws));
+  KPOP_TRY(ctx().ws_for(st).ensure(bytes_nseg + bytes_off + 2 * bytes_sums + bytes_cnt + bytes_part + bytes_done + bytes_long + bytes_olong + 2 * bytes_gmax +
+                                       bytes_res + bytes_todo + 2 * bytes_perread, &ws));
   char *wp = reinterpret_cast<char *>(ws);
   auto carve = [&](uint64_t bytes) {
     char *p = wp;
@@ -1480,23 +1626,29 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   uint64_t *sums2 = reinterpret_cast<uint64_t *>(carve(bytes_sums));
   uint32_t *pcnt = reinterpret_cast<uint32_t *>(carve(bytes_cnt));
   double *part = reinterpret_cast<double *>(carve(bytes_part));
-  uint32_t *slot_done = tile_segs ? reinterpret_cast<uint32_t *>(carve(bytes_done)) : nullptr;
+  uint32_t *slot_done = tiles ? reinterpret_cast<uint32_t *>(carve(bytes_done)) : nullptr;
   uint32_t *n_long = reinterpret_cast<uint32_t *>(carve(bytes_long));
   uint32_t *long_ids = n_long + 16;
   uint32_t *olong = reinterpret_cast<uint32_t *>(carve(bytes_olong));
   uint32_t *gmax = reinterpret_cast<uint32_t *>(carve(bytes_gmax));
+  uint32_t *grel = reinterpret_cast<uint32_t *>(carve(bytes_gmax));
   uint32_t *res_rows = reinterpret_cast<uint32_t *>(carve(bytes_res));
   uint32_t *n_todo = reinterpret_cast<uint32_t *>(carve(bytes_todo));
-  uint2 *todo = tile_segs ? reinterpret_cast<uint2 *>(n_todo + 16) : nullptr;
+  uint2 *todo = tiles ? reinterpret_cast<uint2 *>(n_todo + 256) : nullptr;  // ([0] the list's length, [1..255] a take-the-next counter per streaming launch)
+  uint32_t *lpos = tiles ? reinterpret_cast<uint32_t *>(carve(bytes_perread)) : nullptr;
+  uint32_t *segw = tiles ? reinterpret_cast<uint32_t *>(carve(bytes_perread)) : nullptr;
   KPOP_HIP(hipMemsetAsync(n_long, 0, 64, st));
-  segment_count_kernel<<<dim3(div_up(n_reads, 256)), dim3(256), 0, st>>>(d_offsets, n_reads, tv.hk, seg_windows, nseg, long_ids, n_long);
+  if (tiles) {
+    // the long sequences in batch order, groups of 64 of them probed for being one organism -- before the segments are laid out
+    KPOP_TRY(exclusive_scan(LoadLongW{d_offsets, tv.hk}, StoreLong{olong, lpos}, n_reads, sums2, st));
+    tile_group_probe_kernel<<<dim3(max_groups), dim3(256), 0, st>>>(d_bases, d_offsets, tv.hk, content, olong, sums2 + nb, gmax, grel);
+    KPOP_LAUNCH_CHECK();
+  }
+  segment_count_kernel<<<dim3(div_up(n_reads, 256)), dim3(256), 0, st>>>(d_offsets, n_reads, tv.hk, seg_windows, nseg, long_ids, n_long, lpos, grel, segw);
   KPOP_LAUNCH_CHECK();
   KPOP_TRY(exclusive_scan(LoadU32{nseg}, StoreU64{seg_off}, n_reads, sums, st));
-  if (tile_segs) {
+  if (tiles) {
     KPOP_HIP(hipMemsetAsync(slot_done, 0, bytes_done, st));
-    KPOP_TRY(exclusive_scan(LoadLong{nseg}, StoreLong{olong}, n_reads, sums2, st));
-    tile_group_max_kernel<<<dim3(div_up(max_groups, 4)), dim3(256), 0, st>>>(nseg, olong, sums2 + nb, gmax);
-    KPOP_LAUNCH_CHECK();
     const size_t lds = (size_t)kTileH * 8 + kTileU * 4 + (size_t)kTileG * kTileXS * 2;
     static PerSlotOnce once;
     if (!once()) {
@@ -1505,7 +1657,7 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
     }
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)max_groups * max_seg, (uint64_t)cx.n_cus);
     count_twist_tile_kernel<uint32_t><<<dim3(blocks), dim3(1024), lds, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, olong, sums2 + nb,
-                                                                           gmax, max_seg, slot_done, res_rows, ctx().tune_dbg >> 24);
+                                                                           gmax, grel, max_seg, slot_done, res_rows, ctx().tune_dbg >> 24);
     KPOP_LAUNCH_CHECK();
     const dim3 rgrid(capped_grid((max_slots + 3) / 4));
     if (nt)
@@ -1513,16 +1665,18 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
     else
       tile_residual_kernel<false><<<rgrid, dim3(256), 0, st>>>(tv, slot_done, res_rows, part, sums + nb);
     KPOP_LAUNCH_CHECK();
-    KPOP_HIP(hipMemsetAsync(n_todo, 0, 64, st));
-    tile_todo_kernel<<<dim3(std::min<uint32_t>(div_up(max_long, 4), 4096u)), dim3(256), 0, st>>>(nseg, seg_off, olong, sums2 + nb, slot_done, todo, n_todo);
+    KPOP_HIP(hipMemsetAsync(n_todo, 0, 1024, st));
+    tile_todo_kernel<<<dim3(std::min<uint32_t>(div_up(max_long, 256), 4096u)), dim3(256), 0, st>>>(nseg, seg_off, olong, sums2 + nb, slot_done, todo, n_todo);
     KPOP_LAUNCH_CHECK();
   }
   // (with a to-do list the pairs all have work, and how many is on the device: a grid that fills the chip, striding)
-  dim3 grid(tile_segs ? (uint32_t)std::min<uint64_t>(max_slots, (uint64_t)cx.n_cus * 16) : capped_grid((uint64_t)max_long * max_seg));
+  dim3 grid(tiles ? (uint32_t)std::min<uint64_t>(max_slots, (uint64_t)cx.n_cus * 8) : capped_grid((uint64_t)max_long * max_seg));  // (eight blocks of 256 are resident per CU)
   // The dimensions go in passes of up to 256 (four blocks of 64 a lane), 128 or 64 -- one LAUNCH per pass, so that a pass never
   // loads blocks it has no dimensions for (300 dimensions: 256 + 44; a run-time guard on the loads brought the per-window
   // branches back: 2.4 -> 5.2 ms at 64 dimensions).  Every launch hashes the windows again: once per 256 dimensions, not per 64.
-#define KPOP_STREAM_B(H, NT, B, D0, D1) count_twist_stream_kernel<H, NT, B><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, long_ids, tile_segs ? n_todo : n_long, max_seg, seg_windows, todo, D0, D1)
+#define KPOP_STREAM_B(H, NT, B, D0, D1) count_twist_stream_kernel<H, NT, B><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, long_ids, tiles ? n_todo : n_long, max_seg, seg_windows, todo, segw, tiles ? n_todo + 1 + launch_no++ : nullptr, D0, D1)
+  int launch_no = 0;  // (a take-the-next counter per launch)
+  if (tiles && tw->n_dims > 255u * 256u) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_count_twist: %u dimensions (at most 65,280 with the tile route on; kpop_tune(\"dense\", 0) lifts that)", tw->n_dims);
 #define KPOP_STREAM(H, NT)                                                        \
   do {                                                                            \
     for (uint32_t pos = 0; pos < tw->n_dims;) {                                    \

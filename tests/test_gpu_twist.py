@@ -556,7 +556,9 @@ def test_assemblies_of_one_organism_through_the_tile_kernel(kpop, oracle, k, d, 
         assert np.max(np.abs(ref_rows - want)) <= 1e-12 * scale
         assert np.max(np.abs(got - want)) <= 1e-12 * scale, np.max(np.abs(got - want))
         assert np.array_equal(got, again)  # (no order of additions depends on the run)
-        assert not np.array_equal(got, ref_rows)  # (another order of additions: the tile kernel did run)
+        if rate <= 0.03:
+            assert not np.array_equal(got, ref_rows)  # (another order of additions: the tile kernel did run)
+        # (at 10 % fewer than a third of the windows survive: tile_group_probe_kernel leaves the groups to the streaming kernel)
 
 
 def test_few_assemblies_among_many_reads_and_tiny_batches(kpop, oracle):
