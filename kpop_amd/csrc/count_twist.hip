@@ -888,7 +888,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
     const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ seg_off, double *__restrict__ partial,
     uint32_t *__restrict__ partial_cnt, const uint32_t *__restrict__ olong, const uint64_t *__restrict__ n_long_ptr,
     const uint32_t *__restrict__ gmax, const uint32_t *__restrict__ grel, uint32_t max_seg, uint32_t *__restrict__ slot_done,
-    uint32_t *__restrict__ res_rows, int dbg) {
+    uint32_t *__restrict__ res_rows, uint32_t *__restrict__ wave_lists, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_lds[];
   uint2 *ht = reinterpret_cast<uint2 *>(tile_lds);                  // [kTileH] {twister row (kNoCol = empty), its number in the set}
   uint32_t *ucol = reinterpret_cast<uint32_t *>(ht + kTileH);       // [kTileU] row of number u
@@ -922,12 +922,12 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
       backoff = min(backoff * 2u, 1u << 20);
     }
   };
-  unsigned long long t_last = 0, t_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = 0;
   const bool stamps = (dbg & 16) && threadIdx.x == 0;
   auto stamp = [&](int phase) {
     if (stamps) {
       const unsigned long long now = __builtin_amdgcn_s_memtime();
-      t_acc[phase] += now - t_last;
+      atomicAdd(&g_tile_stamps[phase], now - t_last);
       t_last = now;
     }
   };
@@ -1169,6 +1169,8 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
     misses = 0;
     backoff = 8;
     // ---- 4. X[sequence][number of the row] += 1, or the row onto the sequence's residual list
+    const bool fused = tv.n_dims <= 64;  // (uniform)
+    uint32_t wcnt = 0;                   // residual rows of this wavefront's four sequences
     {
       uint32_t found = 0, resm = 0;
 #pragma unroll
@@ -1194,17 +1196,36 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
       const uint32_t rtot = (uint32_t)__shfl((int)incl, 15, 16);
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) found += (uint32_t)__shfl_xor((int)found, o, 16);
-      if (mine) {
-        const uint64_t slot = s_slot[tg];
-        uint32_t *list = res_rows + slot * kTileS + (incl - rcnt);
+      if (fused) {
+        // up to 64 dimensions the wavefront gathers its four sequences' residual rows itself, under the MFMAs below: ONE list
+        // per wavefront (its sequence in an entry's top two bits -- a row of k <= 15 needs 30 --, sequences in order, windows in
+        // order), in a scratch of the block's own that it reads back past the L1 (the previous chunk's list may still sit there)
+        uint32_t incl64 = rcnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t up = (uint32_t)__shfl_up((int)incl64, o, 64);
+          if (lane >= o) incl64 += up;
+        }
+        wcnt = (uint32_t)__builtin_amdgcn_readlane((int)incl64, 63);
+        uint32_t *wl = wave_lists + ((uint64_t)blockIdx.x * 16 + wv) * (4 * kTileS) + (incl64 - rcnt);
         uint32_t pos = 0;
         if (!(dbg & 4)) {
+#pragma unroll
+          for (uint32_t i = 0; i < kPer; ++i)
+            if ((resm >> i) & 1u) wl[pos++] = cols[i] | ((uint32_t)(lane >> 4) << 30);
+        }
+      }
+      if (mine) {
+        const uint64_t slot = s_slot[tg];
+        if (!fused && !(dbg & 4)) {
+          uint32_t *list = res_rows + slot * kTileS + (incl - rcnt);
+          uint32_t pos = 0;
 #pragma unroll
           for (uint32_t i = 0; i < kPer; ++i)
             if ((resm >> i) & 1u) list[pos++] = cols[i];
         }
         if (tq == 0) {
-          slot_done[slot] = 1u + rtot;
+          slot_done[slot] = fused ? 1u : 1u + rtot;  // (> 1: rows listed for tile_residual_kernel)
           partial_cnt[slot] = found;
         }
       }
@@ -1212,7 +1233,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
     // (the columns are padded with row 0 of the twister against zero counts: the loops below have no branches, so that the
     // loads of the steps ahead stay in flight under the MFMAs)
     const uint32_t U = s_n;
-    const bool ksplit = tv.n_dims <= 64;  // (uniform)
+    const bool ksplit = fused;
     const uint32_t UP = ksplit ? ((U + 63) & ~63u) : ((U + 31) & ~31u);
     for (uint32_t u = U + threadIdx.x; u < UP; u += 1024) ucol[u] = 0;
     __syncthreads();
@@ -1236,7 +1257,50 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
         for (int q = 0; q < PF; ++q) bb[q] = trow[(uint64_t)ucol[c0 + 4 * q + (lane >> 4)] * tv.d_pad];
       }
       const uint16_t *xrow = X16 + (lane & 15) * kTileXS + c0 + (lane >> 4);
+      // the residual gather, lane = dimension: 16 rows loaded before an iteration's 16 MFMAs (an iteration is ~4,000 cycles of a
+      // matrix pipe four wavefronts share: the rows' latency), added after them, in list order -- sequence by sequence
+      const uint32_t *wl = wave_lists + ((uint64_t)blockIdx.x * 16 + wv) * (4 * kTileS);
+      const double *grow = tv.rows + min((uint32_t)lane, tv.n_dims - 1);
+      constexpr int GR = 8;
+      double rsum[4] = {0.0, 0.0, 0.0, 0.0}, cur = 0.0;
+      uint32_t cur_j = 0, gpos = 0;
+      uint32_t colv = lane < (int)wcnt ? __hip_atomic_load(wl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kNoCol;
+      double gv[GR];
+      uint32_t gj[GR];  // (scalars)
+      auto stash = [&]() {
+        rsum[0] = cur_j == 0 ? cur : rsum[0];
+        rsum[1] = cur_j == 1 ? cur : rsum[1];
+        rsum[2] = cur_j == 2 ? cur : rsum[2];
+        rsum[3] = cur_j == 3 ? cur : rsum[3];
+      };
+      auto gather_issue = [&]() {  // the next GR rows of the list (gpos is a multiple of GR, GR divides 64)
+#pragma unroll
+        for (int u = 0; u < GR; ++u) {
+          const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)colv, (int)(gpos & 63u) + u);  // (scalar; kNoCol past the end)
+          gj[u] = cj;
+          gv[u] = grow[(uint64_t)(cj != kNoCol ? (cj & 0x3FFFFFFFu) : 0u) * tv.d_pad];
+        }
+      };
+      auto gather_add = [&]() {
+#pragma unroll
+        for (int u = 0; u < GR; ++u) {
+          if (gj[u] != kNoCol) {  // (scalar: uniform branches)
+            const uint32_t j = gj[u] >> 30;
+            if (j != cur_j) {  // (the list goes sequence by sequence: at most three changes)
+              stash();
+              cur = 0.0;
+              cur_j = j;
+            }
+            cur = __dadd_rn(cur, gv[u]);
+          }
+        }
+        gpos += GR;
+        if ((gpos & 63u) == 0 && gpos < wcnt)
+          colv = gpos + lane < wcnt ? __hip_atomic_load(wl + gpos + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kNoCol;
+      };
       for (uint32_t q0 = 0; q0 < Uq / 4; q0 += PF) {
+        const bool g = gpos < wcnt;  // (uniform)
+        if (g) gather_issue();
 #pragma unroll
         for (int qq = 0; qq < PF; ++qq) {
           const uint32_t q = q0 + qq;
@@ -1246,6 +1310,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
           for (int mi = 0; mi < 4; ++mi)
             acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xrow[mi * 16 * kTileXS + 4 * q], b, acc[mi], 0, 0, 0);
         }
+        if (g) gather_add();
       }
       __syncthreads();  // every wave is done with X: its room takes the quarters' sums, [quarter][sequence][dim]
       stamp(6);  // the matrix cores
@@ -1256,11 +1321,19 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
         for (int rr = 0; rr < 4; ++rr)  // lane l holds rows (l >> 4) + 4 r of an M tile, column l & 15 of the wave's 16 dims
           P[((uint32_t)kh * 64 + 16 * mi + (lane >> 4) + 4 * rr) * 64 + dc] = acc[mi][rr];
       __syncthreads();
-      for (uint32_t e = threadIdx.x; e < 64 * 64; e += 1024) {
-        const uint32_t g = e >> 6, d = e & 63u;
+      // what is left of the wavefront's list (a divergent stretch: more rows than the MFMAs hid), then its four sequences' sums:
+      // the quarters in order, then the residual rows' sum
+      while (gpos < wcnt) {
+        gather_issue();
+        gather_add();
+      }
+      stash();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t g = 4u * wv + j, e = g * 64u + lane;
         const uint64_t sl = s_slot[g];
-        const double v = __dadd_rn(__dadd_rn(__dadd_rn(P[e], P[4096 + e]), P[8192 + e]), P[12288 + e]);
-        if (sl != ~0ull && d < tv.n_dims) partial[sl * tv.n_dims + d] = v;
+        const double v = __dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(P[e], P[4096 + e]), P[8192 + e]), P[12288 + e]), rsum[j]);
+        if (sl != ~0ull && (uint32_t)lane < tv.n_dims) partial[sl * tv.n_dims + lane] = v;
       }
     }
     // ---- 3b. the same for D > 64: wave wv owns M tile wv & 3 (16 sequences) and the 16 dims of slice wv >> 2 of every 64
@@ -1295,8 +1368,6 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
     }
     stamp(7);  // the sums written
   }
-  if (stamps)
-    for (int i = 0; i < 9; ++i) atomicAdd(&g_tile_stamps[i], t_acc[i]);
 }
 
 // The residual rows of the (sequence, segment) slots count_twist_tile_kernel took: one wavefront per slot, lane = dimension,
@@ -1609,11 +1680,11 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
                  bytes_part = (max_slots * tw->n_dims * 8 + 63) & ~63ull, bytes_done = tiles ? ((max_slots * 4 + 63) & ~63ull) : 0,
                  bytes_long = ((uint64_t)n_reads * 4 + 64 + 63) & ~63ull,
                  bytes_olong = tiles ? (((uint64_t)max_long * 4 + 63) & ~63ull) : 0, bytes_gmax = tiles ? (((uint64_t)max_groups * 4 + 63) & ~63ull) : 0,
-                 bytes_res = tiles ? max_slots * kTileS * 4 : 0, bytes_todo = tiles ? ((max_slots * 8 + 1024 + 63) & ~63ull) : 0,
-                 bytes_perread = tiles ? bytes_nseg : 0;
+                 bytes_res = tiles && tw->n_dims > 64 ? max_slots * kTileS * 4 : 0, bytes_todo = tiles ? ((max_slots * 8 + 1024 + 63) & ~63ull) : 0,
+                 bytes_perread = tiles ? bytes_nseg : 0, bytes_wlists = tiles ? (uint64_t)cx.n_cus * 16 * 4 * kTileS * 4 : 0;
   void *ws = nullptr;
   KPOP_TRY(ctx().ws_for(st).ensure(bytes_nseg + bytes_off + 2 * bytes_sums + bytes_cnt + bytes_part + bytes_done + bytes_long + bytes_olong + 2 * bytes_gmax +
-                                       bytes_res + bytes_todo + 2 * bytes_perread, &ws));
+                                       bytes_res + bytes_todo + 2 * bytes_perread + bytes_wlists, &ws));
   char *wp = reinterpret_cast<char *>(ws);
   auto carve = [&](uint64_t bytes) {
     char *p = wp;
@@ -1637,6 +1708,7 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   uint2 *todo = tiles ? reinterpret_cast<uint2 *>(n_todo + 256) : nullptr;  // ([0] the list's length, [1..255] a take-the-next counter per streaming launch)
   uint32_t *lpos = tiles ? reinterpret_cast<uint32_t *>(carve(bytes_perread)) : nullptr;
   uint32_t *segw = tiles ? reinterpret_cast<uint32_t *>(carve(bytes_perread)) : nullptr;
+  uint32_t *wave_lists = reinterpret_cast<uint32_t *>(carve(bytes_wlists));
   KPOP_HIP(hipMemsetAsync(n_long, 0, 64, st));
   if (tiles) {
     // the long sequences in batch order, groups of 64 of them probed for being one organism -- before the segments are laid out
@@ -1657,14 +1729,16 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
     }
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)max_groups * max_seg, (uint64_t)cx.n_cus);
     count_twist_tile_kernel<uint32_t><<<dim3(blocks), dim3(1024), lds, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, olong, sums2 + nb,
-                                                                           gmax, grel, max_seg, slot_done, res_rows, ctx().tune_dbg >> 24);
+                                                                           gmax, grel, max_seg, slot_done, res_rows, wave_lists, ctx().tune_dbg >> 24);
     KPOP_LAUNCH_CHECK();
-    const dim3 rgrid(capped_grid((max_slots + 3) / 4));
-    if (nt)
-      tile_residual_kernel<true><<<rgrid, dim3(256), 0, st>>>(tv, slot_done, res_rows, part, sums + nb);
-    else
-      tile_residual_kernel<false><<<rgrid, dim3(256), 0, st>>>(tv, slot_done, res_rows, part, sums + nb);
-    KPOP_LAUNCH_CHECK();
+    if (tw->n_dims > 64) {  // (up to 64 dimensions the tile kernel has gathered the residual rows itself)
+      const dim3 rgrid(capped_grid((max_slots + 3) / 4));
+      if (nt)
+        tile_residual_kernel<true><<<rgrid, dim3(256), 0, st>>>(tv, slot_done, res_rows, part, sums + nb);
+      else
+        tile_residual_kernel<false><<<rgrid, dim3(256), 0, st>>>(tv, slot_done, res_rows, part, sums + nb);
+      KPOP_LAUNCH_CHECK();
+    }
     KPOP_HIP(hipMemsetAsync(n_todo, 0, 1024, st));
     tile_todo_kernel<<<dim3(std::min<uint32_t>(div_up(max_long, 256), 4096u)), dim3(256), 0, st>>>(nseg, seg_off, olong, sums2 + nb, slot_done, todo, n_todo);
     KPOP_LAUNCH_CHECK();
