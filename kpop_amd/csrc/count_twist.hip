@@ -749,9 +749,9 @@ __global__ __launch_bounds__(256) void count_twist_stream_kernel(
 // "dense" routes.  lib/Twister.ml:146-188.
 // ---------------------------------------------------------------------------
 using f64x4 = __attribute__((ext_vector_type(4))) double;
-constexpr uint32_t kTileG = 64, kTileS = 512, kTileU = 1024, kTileH = 2048, kTileXS = kTileU + 2;  // (X rows padded: 16 rows on 16 banks)
+constexpr uint32_t kTileProbeG = 64, kTileS = 512, kTileH = 2048;  // sequences of a probed group; windows of a stretch; slots of the set's table
+constexpr uint32_t tile_set_rows(int g) { return g == 64 ? 1024u : 896u; }  // rows the numbering has room for (X rows are padded by 2: 16 rows on 16 banks)
 constexpr uint32_t kTileSetCap = 768;    // rows in the set beyond which the seeds after the first add no more
-constexpr uint32_t kTileSeedEvery = 16;  // sequences 0, 16, 32, 48 of a group are its seeds
 constexpr uint32_t kTileStageW = 136;    // dwords of a sequence's staged stretch: 3 + 512 + 14 bytes and the thirteenth dword of the last thread
 constexpr uint32_t kTileMinSeqs = 16;    // sequences with segments in a batch below which the tile kernel does not try
 
@@ -787,10 +787,10 @@ __global__ __launch_bounds__(256) void tile_group_probe_kernel(const uint8_t *__
   __shared__ uint32_t tab[kTab];
   __shared__ uint32_t s_maxw, s_stat;
   const uint32_t n_long = (uint32_t)*n_long_ptr, g = blockIdx.x;
-  if ((uint64_t)g * kTileG >= n_long) return;
+  if ((uint64_t)g * kTileProbeG >= n_long) return;
   const int lane = threadIdx.x & 63;
   if (threadIdx.x < 64) {
-    const uint32_t li = g * kTileG + threadIdx.x;
+    const uint32_t li = g * kTileProbeG + threadIdx.x;
     uint32_t w = 0;
     if (li < n_long) {
       const uint32_t r = olong[li];
@@ -840,7 +840,7 @@ __global__ __launch_bounds__(256) void tile_group_probe_kernel(const uint8_t *__
     if (threadIdx.x == 0) s_stat = 0;
     __syncthreads();
     uint32_t h[8];
-    hashes(g * kTileG + (threadIdx.x >> 6) * kTileSeedEvery, s_beg + (uint64_t)(threadIdx.x & 63) * 8, h);
+    hashes(g * kTileProbeG + (threadIdx.x >> 6) * 16u, s_beg + (uint64_t)(threadIdx.x & 63) * 8, h);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       if (h[i] != kNoCol) {
@@ -852,7 +852,7 @@ __global__ __launch_bounds__(256) void tile_group_probe_kernel(const uint8_t *__
         }
       }
     __syncthreads();
-    hashes(g * kTileG + (threadIdx.x >> 2), s_beg + (uint64_t)(threadIdx.x & 3) * 128, h);
+    hashes(g * kTileProbeG + (threadIdx.x >> 2), s_beg + (uint64_t)(threadIdx.x & 3) * 128, h);
     uint32_t st = 0;  // windows | hits << 16
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -882,27 +882,30 @@ __global__ __launch_bounds__(256) void tile_group_probe_kernel(const uint8_t *__
 // over blocks and chunks; read and cleared by kpop_debug_counters)
 __device__ unsigned long long g_tile_stamps[16];
 
-template <typename H>
-__global__ __launch_bounds__(1024) void count_twist_tile_kernel(
+// G sequences a chunk: 64 (one block of 1,024 threads a CU, 152 KB of LDS) or 32 (512 threads, 78 KB: TWO blocks a CU, one in
+// its matrix phase while the other waits for bases and index words)
+template <typename H, int G>
+__global__ __launch_bounds__(16 * G) void count_twist_tile_kernel(
     TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int content,
     const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ seg_off, double *__restrict__ partial,
     uint32_t *__restrict__ partial_cnt, const uint32_t *__restrict__ olong, const uint64_t *__restrict__ n_long_ptr,
     const uint32_t *__restrict__ gmax, const uint32_t *__restrict__ grel, uint32_t max_seg, uint32_t *__restrict__ slot_done,
     uint32_t *__restrict__ res_rows, uint32_t *__restrict__ wave_lists, int dbg) {
+  constexpr uint32_t THREADS = 16 * G, WAVES = G / 4, TU = tile_set_rows(G), XS = TU + 2, SEEDEVERY = G / 4, MT = G / 16, KQ = WAVES / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_lds[];
   uint2 *ht = reinterpret_cast<uint2 *>(tile_lds);                  // [kTileH] {twister row (kNoCol = empty), its number in the set}
-  uint32_t *ucol = reinterpret_cast<uint32_t *>(ht + kTileH);       // [kTileU] row of number u
-  uint32_t *Xw = ucol + kTileU;                                     // [kTileG][kTileXS / 2] pairs of u16 counts
-  uint32_t *stage = Xw;                                             // before X is needed: [kTileG][kTileStageW] the stretch's bases,
-  uint32_t *seedcols = Xw + kTileG * kTileStageW;                   //   and [4][kTileS] the seeds' rows
-  __shared__ uint32_t s_n, s_new, s_samp, s_add[kTileG / kTileSeedEvery], s_wbase[16];
-  __shared__ uint64_t s_slot[kTileG];  // the group's (sequence, segment) slots, ~0: the sequence has no such segment
+  uint32_t *ucol = reinterpret_cast<uint32_t *>(ht + kTileH);       // [TU] row of number u
+  uint32_t *Xw = ucol + TU;                                     // [G][XS / 2] pairs of u16 counts
+  uint32_t *stage = Xw;                                             // before X is needed: [G][kTileStageW] the stretch's bases,
+  uint32_t *seedcols = Xw + G * kTileStageW;                   //   and [4][kTileS] the seeds' rows
+  __shared__ uint32_t s_n, s_new, s_samp, s_add[G / SEEDEVERY], s_wbase[WAVES];
+  __shared__ uint64_t s_slot[G];  // the group's (sequence, segment) slots, ~0: the sequence has no such segment
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // groups of 64 are cut from the sequences that HAVE segments, in batch order (olong: the scan's list, the same every run): a
   // few assemblies among a million reads make a few groups, not sixteen thousand empty ones
   const uint32_t n_long = (uint32_t)*n_long_ptr;
   if (n_long < kTileMinSeqs) return;  // (too few sequences to share anything: the streaming kernel's)
-  const uint32_t n_groups = (n_long + kTileG - 1) / kTileG;
+  const uint32_t n_groups = (n_long + G - 1) / G;
   const uint64_t n_chunks = (uint64_t)n_groups * max_seg;
   const int k = tv.hk;
   const int shift = 2 * (k - 1);
@@ -910,7 +913,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
   // thread t works on sequence t / 16 of the group and a sixteenth of the segment's windows (32), rolling the hash along
   constexpr uint32_t kPer = kTileS / 16;
   const uint32_t tg = threadIdx.x >> 4, tq = threadIdx.x & 15u;
-  const bool seed = (tg % kTileSeedEvery) == 0;
+  const bool seed = (tg % SEEDEVERY) == 0;
   // chunks in a row that shared too little with their seeds: after four the block skips the next `backoff` of its chunks
   // (they are the streaming kernel's), twice as many every time until a chunk is taken again
   int misses = 0;
@@ -961,12 +964,13 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
   for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     // chunks are dealt with the groups fastest: blocks running together work on one stretch of all sequences
     const uint32_t seg = (uint32_t)(chunk / n_groups), grp = (uint32_t)(chunk % n_groups);
-    if (!grel[grp] || seg >= gmax[grp]) continue;  // (not one organism: tile_group_probe_kernel; none of the group's sequences is this long)
+    const uint32_t pg = (uint32_t)(((uint64_t)grp * G) / kTileProbeG);  // (the probe's groups are of 64)
+    if (!grel[pg] || seg >= gmax[pg]) continue;  // (not one organism: tile_group_probe_kernel; none of the group's sequences is this long)
     if (skip) {  // (uniform over the block)
       --skip;
       continue;
     }
-    const uint32_t li = grp * kTileG + tg;
+    const uint32_t li = grp * G + tg;
     uint32_t r = 0;
     uint64_t off = 0, len = 0;
     bool mine = false;
@@ -1006,13 +1010,13 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
       }
     }
     if (tq == 0) s_slot[tg] = mine ? seg_off[r] + seg : ~0ull;
-    for (uint32_t q = threadIdx.x; q < kTileH; q += 1024) ht[q] = make_uint2(kNoCol, 0u);
+    for (uint32_t q = threadIdx.x; q < kTileH; q += THREADS) ht[q] = make_uint2(kNoCol, 0u);
     if (threadIdx.x == 0) {
       s_n = 0;
       s_new = 0;
       s_samp = 0;
     }
-    if (threadIdx.x < kTileG / kTileSeedEvery) s_add[threadIdx.x] = 0;
+    if (threadIdx.x < G / SEEDEVERY) s_add[threadIdx.x] = 0;
     __syncthreads();
     stamp(0);  // the bases staged, the set cleared
     // ---- 1. the thread's 32 windows: hashes rolled out of LDS, then their twister rows, eight look-ups in flight at a time
@@ -1062,7 +1066,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
     }
     if (seed) {
 #pragma unroll
-      for (uint32_t i = 0; i < kPer; ++i) seedcols[(tg / kTileSeedEvery) * kTileS + tq * kPer + i] = cols[i];
+      for (uint32_t i = 0; i < kPer; ++i) seedcols[(tg / SEEDEVERY) * kTileS + tq * kPer + i] = cols[i];
     }
     __syncthreads();
     stamp(1);  // everybody's rows found
@@ -1079,10 +1083,11 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
     __syncthreads();
     // the other seeds are admitted in order while the set stays within kTileSetCap rows, by what each would add at most (its
     // rows not of seed 0): a rule that does not depend on who runs when
-    uint32_t ecol[2];
+    constexpr uint32_t EJ = (3u * kTileS + THREADS - 1) / THREADS;
+    uint32_t ecol[EJ];
 #pragma unroll
-    for (uint32_t j = 0; j < 2; ++j) {
-      const uint32_t e = threadIdx.x + 1024u * j;  // (a wavefront's 64 entries are one seed's: 512 is a multiple of 64)
+    for (uint32_t j = 0; j < EJ; ++j) {
+      const uint32_t e = threadIdx.x + THREADS * j;  // (a wavefront's 64 entries are one seed's: 512 is a multiple of 64)
       ecol[j] = kNoCol;
       if (e < 3u * kTileS) {
         const uint32_t col = seedcols[kTileS + e];
@@ -1095,13 +1100,13 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
     {
       uint32_t total = s_new, in = 1u;  // bit q: seed q is in
 #pragma unroll
-      for (uint32_t q = 1; q < kTileG / kTileSeedEvery; ++q) {
+      for (uint32_t q = 1; q < G / SEEDEVERY; ++q) {
         total += s_add[q];
         in |= (((in >> (q - 1)) & 1u) && total <= kTileSetCap) ? (1u << q) : 0u;
       }
 #pragma unroll
-      for (uint32_t j = 0; j < 2; ++j) {
-        const uint32_t e = threadIdx.x + 1024u * j;
+      for (uint32_t j = 0; j < EJ; ++j) {
+        const uint32_t e = threadIdx.x + THREADS * j;
         if (e < 3u * kTileS && ecol[j] != kNoCol && ((in >> (1u + e / kTileS)) & 1u)) (void)insert(ecol[j]);
       }
     }
@@ -1111,10 +1116,15 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
       // X cleared (the bases and the seeds' rows have been used); the occupied slots numbered in table order (2 slots a
       // thread, a block-wide scan)
       uint4 *X4 = reinterpret_cast<uint4 *>(Xw);
-      for (uint32_t q = threadIdx.x; q < kTileG * kTileXS / 8; q += 1024) X4[q] = make_uint4(0u, 0u, 0u, 0u);
-      const uint32_t q0 = threadIdx.x * 2;
-      const uint32_t k0 = ht[q0].x, k1 = ht[q0 + 1].x;
-      const uint32_t o0 = k0 != kNoCol, o1 = k1 != kNoCol, occ = o0 + o1;
+      for (uint32_t q = threadIdx.x; q < G * XS / 8; q += THREADS) X4[q] = make_uint4(0u, 0u, 0u, 0u);
+      constexpr uint32_t SL = kTileH / THREADS;  // slots a thread
+      const uint32_t q0 = threadIdx.x * SL;
+      uint32_t kk[SL], occ = 0;
+#pragma unroll
+      for (uint32_t i = 0; i < SL; ++i) {
+        kk[i] = ht[q0 + i].x;
+        occ += kk[i] != kNoCol;
+      }
       uint32_t incl = occ;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
@@ -1125,16 +1135,14 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
       __syncthreads();
       uint32_t before = incl - occ;
       for (int w = 0; w < wv; ++w) before += s_wbase[w];
-      if (threadIdx.x == 1023) s_n = before + occ;  // (<= kTileSetCap < kTileU)
-      if (o0) {
-        ht[q0].y = before;
-        ucol[before] = k0;
-        ++before;
-      }
-      if (o1) {
-        ht[q0 + 1].y = before;
-        ucol[before] = k1;
-      }
+      if (threadIdx.x == THREADS - 1) s_n = before + occ;  // (<= kTileSetCap < TU)
+#pragma unroll
+      for (uint32_t i = 0; i < SL; ++i)
+        if (kk[i] != kNoCol) {
+          ht[q0 + i].y = before;
+          ucol[before] = kk[i];
+          ++before;
+        }
       __syncthreads();
     }
     stamp(3);  // X cleared, the set numbered
@@ -1180,7 +1188,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
           ++found;
           if (c & 0x80000000u) {
             const uint32_t u = c & 0x7FFFFFFFu;
-            if (!(dbg & 2)) atomicAdd(&Xw[tg * (kTileXS / 2) + (u >> 1)], 1u << (16 * (u & 1u)));
+            if (!(dbg & 2)) atomicAdd(&Xw[tg * (XS / 2) + (u >> 1)], 1u << (16 * (u & 1u)));
           } else
             resm |= 1u << i;
         }
@@ -1207,7 +1215,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
           if (lane >= o) incl64 += up;
         }
         wcnt = (uint32_t)__builtin_amdgcn_readlane((int)incl64, 63);
-        uint32_t *wl = wave_lists + ((uint64_t)blockIdx.x * 16 + wv) * (4 * kTileS) + (incl64 - rcnt);
+        uint32_t *wl = wave_lists + ((uint64_t)blockIdx.x * WAVES + wv) * (4 * kTileS) + (incl64 - rcnt);
         uint32_t pos = 0;
         if (!(dbg & 4)) {
 #pragma unroll
@@ -1234,32 +1242,32 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
     // loads of the steps ahead stay in flight under the MFMAs)
     const uint32_t U = s_n;
     const bool ksplit = fused;
-    const uint32_t UP = ksplit ? ((U + 63) & ~63u) : ((U + 31) & ~31u);
-    for (uint32_t u = U + threadIdx.x; u < UP; u += 1024) ucol[u] = 0;
+    const uint32_t UP = ksplit ? ((U + 16 * KQ - 1) & ~(16 * KQ - 1)) : ((U + 31) & ~31u);
+    for (uint32_t u = U + threadIdx.x; u < UP; u += THREADS) ucol[u] = 0;
     __syncthreads();
     stamp(5);  // the windows counted into X or listed
     const uint16_t *X16 = reinterpret_cast<const uint16_t *>(Xw);
     if (ksplit && !(dbg & 1)) {
-      // ---- 3a. partial[64 x D] = X[64 x U] * T_U for D <= 64: wave wv owns the 16 dims of slice wv & 3 and a QUARTER of the
-      // columns, for all 64 sequences (four accumulator tiles) -- every row of T is loaded once per block, not once per M tile
+      // ---- 3a. partial[64 x D] = X[64 x U] * T_U for D <= 64: wave wv owns the 16 dims of slice wv & 3 and a share (a quarter, or a half when G = 32) of the
+      // columns, for all G sequences (G / 16 accumulator tiles) -- every row of T is loaded once per block, not once per M tile
       // (the rows' latency, not the MFMAs, was this phase: 0.86 of the kernel's 2.04 ms).  The quarters are added in order.
       const int ni = wv & 3, kh = wv >> 2;
       const uint32_t dc = 16u * ni + (lane & 15);
       const double *trow = tv.rows + min(dc, tv.d_pad - 1);  // (columns past the twister's are not written below)
-      const uint32_t Uq = UP / 4, c0 = (uint32_t)kh * Uq;   // Uq a multiple of 16: a multiple of four steps
-      f64x4 acc[4];
+      const uint32_t Uq = UP / KQ, c0 = (uint32_t)kh * Uq;   // Uq a multiple of 16: a multiple of four steps
+      f64x4 acc[MT];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) acc[mi] = f64x4{0.0, 0.0, 0.0, 0.0};
+      for (uint32_t mi = 0; mi < MT; ++mi) acc[mi] = f64x4{0.0, 0.0, 0.0, 0.0};
       constexpr int PF = 4;  // (eight, with the columns padded to 128: no faster -- the phase is the MFMA pipe's now)
       double bb[PF];
       if (Uq) {
 #pragma unroll
         for (int q = 0; q < PF; ++q) bb[q] = trow[(uint64_t)ucol[c0 + 4 * q + (lane >> 4)] * tv.d_pad];
       }
-      const uint16_t *xrow = X16 + (lane & 15) * kTileXS + c0 + (lane >> 4);
+      const uint16_t *xrow = X16 + (lane & 15) * XS + c0 + (lane >> 4);
       // the residual gather, lane = dimension: 16 rows loaded before an iteration's 16 MFMAs (an iteration is ~4,000 cycles of a
       // matrix pipe four wavefronts share: the rows' latency), added after them, in list order -- sequence by sequence
-      const uint32_t *wl = wave_lists + ((uint64_t)blockIdx.x * 16 + wv) * (4 * kTileS);
+      const uint32_t *wl = wave_lists + ((uint64_t)blockIdx.x * WAVES + wv) * (4 * kTileS);
       const double *grow = tv.rows + min((uint32_t)lane, tv.n_dims - 1);
       constexpr int GR = 8;
       double rsum[4] = {0.0, 0.0, 0.0, 0.0}, cur = 0.0;
@@ -1307,8 +1315,8 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
           const double b = bb[qq];
           bb[qq] = trow[(uint64_t)ucol[c0 + min(4 * (q + PF) + (lane >> 4), Uq - 1)] * tv.d_pad];
 #pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-            acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xrow[mi * 16 * kTileXS + 4 * q], b, acc[mi], 0, 0, 0);
+          for (uint32_t mi = 0; mi < MT; ++mi)
+            acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xrow[mi * 16 * XS + 4 * q], b, acc[mi], 0, 0, 0);
         }
         if (g) gather_add();
       }
@@ -1316,10 +1324,10 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
       stamp(6);  // the matrix cores
       double *P = reinterpret_cast<double *>(Xw);
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (uint32_t mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)  // lane l holds rows (l >> 4) + 4 r of an M tile, column l & 15 of the wave's 16 dims
-          P[((uint32_t)kh * 64 + 16 * mi + (lane >> 4) + 4 * rr) * 64 + dc] = acc[mi][rr];
+          P[((uint32_t)kh * G + 16 * mi + (lane >> 4) + 4 * rr) * 64 + dc] = acc[mi][rr];
       __syncthreads();
       // what is left of the wavefront's list (a divergent stretch: more rows than the MFMAs hid), then its four sequences' sums:
       // the quarters in order, then the residual rows' sum
@@ -1332,12 +1340,15 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
       for (int j = 0; j < 4; ++j) {
         const uint32_t g = 4u * wv + j, e = g * 64u + lane;
         const uint64_t sl = s_slot[g];
-        const double v = __dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(P[e], P[4096 + e]), P[8192 + e]), P[12288 + e]), rsum[j]);
+        double v = P[e];
+#pragma unroll
+        for (uint32_t kq = 1; kq < KQ; ++kq) v = __dadd_rn(v, P[kq * G * 64 + e]);
+        v = __dadd_rn(v, rsum[j]);
         if (sl != ~0ull && (uint32_t)lane < tv.n_dims) partial[sl * tv.n_dims + lane] = v;
       }
     }
     // ---- 3b. the same for D > 64: wave wv owns M tile wv & 3 (16 sequences) and the 16 dims of slice wv >> 2 of every 64
-    const int mi = wv & 3, ni = wv >> 2;
+    const int mi = wv % (int)MT, ni = wv / (int)MT;
     for (uint32_t d0 = 0; d0 < tv.n_dims && !ksplit && !(dbg & 1); d0 += 64) {
       const uint32_t U32 = UP;
       const uint32_t dc = d0 + 16u * ni + (lane & 15);
@@ -1349,7 +1360,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_kernel(
 #pragma unroll
         for (int q = 0; q < PF; ++q) bb[q] = trow[(uint64_t)ucol[4 * q + (lane >> 4)] * tv.d_pad];
       }
-      const uint16_t *xrow = X16 + (16 * mi + (lane & 15)) * kTileXS + (lane >> 4);
+      const uint16_t *xrow = X16 + (16 * mi + (lane & 15)) * XS + (lane >> 4);
       for (uint32_t q0 = 0; q0 < U32 / 4; q0 += PF) {
 #pragma unroll
         for (int qq = 0; qq < PF; ++qq) {
@@ -1674,7 +1685,8 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   const uint64_t max_slots = n_bases / seg_least + max_long;  // every such sequence adds at most W/seg + 1 segments
   const uint64_t nb = scan_blocks(n_reads);
   const uint32_t max_seg = div_up(max_windows, seg_least);
-  const uint32_t max_groups = div_up(max_long, kTileG);
+  const uint32_t max_groups = div_up(max_long, kTileProbeG);
+  const int tile_g = cx.tune_tileg == 64 ? 64 : 32;  // sequences a chunk of the tile kernel (kpop_tune("tileg"))
   const uint64_t bytes_nseg = ((uint64_t)n_reads * 4 + 63) & ~63ull, bytes_off = ((uint64_t)(n_reads + 1) * 8 + 63) & ~63ull,
                  bytes_sums = ((nb + 1) * 8 + 63) & ~63ull, bytes_cnt = (max_slots * 4 + 63) & ~63ull,
                  bytes_part = (max_slots * tw->n_dims * 8 + 63) & ~63ull, bytes_done = tiles ? ((max_slots * 4 + 63) & ~63ull) : 0,
@@ -1721,15 +1733,22 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   KPOP_TRY(exclusive_scan(LoadU32{nseg}, StoreU64{seg_off}, n_reads, sums, st));
   if (tiles) {
     KPOP_HIP(hipMemsetAsync(slot_done, 0, bytes_done, st));
-    const size_t lds = (size_t)kTileH * 8 + kTileU * 4 + (size_t)kTileG * kTileXS * 2;
+    const size_t lds = (size_t)kTileH * 8 + tile_set_rows(tile_g) * 4 + (size_t)tile_g * (tile_set_rows(tile_g) + 2) * 2;
     static PerSlotOnce once;
     if (!once()) {
-      KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&count_twist_tile_kernel<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&count_twist_tile_kernel<uint32_t, 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)((size_t)kTileH * 8 + tile_set_rows(64) * 4 + (size_t)64 * (tile_set_rows(64) + 2) * 2)));
+      KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&count_twist_tile_kernel<uint32_t, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)((size_t)kTileH * 8 + tile_set_rows(32) * 4 + (size_t)32 * (tile_set_rows(32) + 2) * 2)));
       once() = true;
     }
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)max_groups * max_seg, (uint64_t)cx.n_cus);
-    count_twist_tile_kernel<uint32_t><<<dim3(blocks), dim3(1024), lds, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, olong, sums2 + nb,
-                                                                           gmax, grel, max_seg, slot_done, res_rows, wave_lists, ctx().tune_dbg >> 24);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)div_up(max_long, tile_g) * max_seg, (uint64_t)cx.n_cus * (tile_g == 32 ? 2 : 1));
+    if (tile_g == 64)
+      count_twist_tile_kernel<uint32_t, 64><<<dim3(blocks), dim3(1024), lds, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, olong, sums2 + nb,
+                                                                                  gmax, grel, max_seg, slot_done, res_rows, wave_lists, ctx().tune_dbg >> 24);
+    else
+      count_twist_tile_kernel<uint32_t, 32><<<dim3(blocks), dim3(512), lds, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, olong, sums2 + nb,
+                                                                                 gmax, grel, max_seg, slot_done, res_rows, wave_lists, ctx().tune_dbg >> 24);
     KPOP_LAUNCH_CHECK();
     if (tw->n_dims > 64) {  // (up to 64 dimensions the tile kernel has gathered the residual rows itself)
       const dim3 rgrid(capped_grid((max_slots + 3) / 4));

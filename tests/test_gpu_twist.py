@@ -494,15 +494,15 @@ def test_count_twist_through_the_dense_image(kpop, oracle, k, d, content):
         want = oracle.twist(T, cols, h, c.astype(np.float64), o, normalize=normalize)
         assert np.max(np.abs(got - want)) <= 1e-12 * max(np.max(np.abs(want)), 1.0), np.max(np.abs(got - want))
         assert np.all(got[0] == 0.0) and np.all(got[2] == 0.0)
-    if k == 8:  # the host entry point picks the dense image for batches of assemblies under kpop_tune("dense", 2)
+    if k == 8:  # the host entry point picks the dense image for batches of assemblies (the default; kpop_tune("dense", 0) opts out)
         long_ = [s_ for s_ in seqs if len(s_) > 7000] * 8
         lb, lo = concat(long_)
-        ref = tw.count_twist(lb, lo)
-        api.tune("dense", 2)
+        got = tw.count_twist(lb, lo)
+        api.tune("dense", 0)
         try:
-            got = tw.count_twist(lb, lo)
+            ref = tw.count_twist(lb, lo)
         finally:
-            api.tune("dense", 0)
+            api.tune("dense", 2)
         assert len(long_) >= 64 and np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref)) and not np.array_equal(got, ref)
     big = kpop.Twister.synth(1, 9, 8)
     with pytest.raises(kpop.KPopError):  # 131,072 k-mers: no dense image

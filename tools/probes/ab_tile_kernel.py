@@ -23,6 +23,8 @@ def main():
     st = torch.cuda.current_stream()
     k, d, n = 12, 64, int(os.environ.get("AB_GENOMES", "5000"))
     tw = kpop_amd.Twister.synth(0x5EED, k, d)
+    if os.environ.get("AB_TILEG"):
+        api.tune("tileg", int(os.environ["AB_TILEG"]))
 
     def timed(fn):
         fn()
