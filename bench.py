@@ -39,6 +39,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 READ_SEED, TWISTER_SEED, CLASS_SEED = 0x4B506F70, 0x5EED, 0xC1A55
+MFMA_F64_PEAK_TFLOPS = 78.6  # MI355X f64 matrix peak (256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz)
+L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md: aggregate L2 bandwidth, 34.5 TB/s
 XGMI_DIRECT_ESTIMATE_MS = 0.42  # 64 MB per shard over 7 links x 153 GB/s, one shard per link
 
 
@@ -340,18 +342,22 @@ class Rank:
             res["gather_checksum_ok"] = bool(int(tot.item()) == int(got.item()))
         # the gathered matrix in use: a few rows of every rank against all n_total twisted vectors
         q_rank = max(1, a.queries // self.world)
-        t.cuda.synchronize()
-        self.barrier()
-        t0 = time.perf_counter()
-        qid, stats, nn, idx, dd, z = job.all_vs_all_summary(q_rank, keep_at_most=2, max_neighbours=8)
-        t.cuda.synchronize()
-        ava = self.max_over_ranks(time.perf_counter() - t0)
+        ava_all = []
+        for _ in range(4):  # the first call grows the library's workspace (an allocation, reported on its own); then three warm ones
+            t.cuda.synchronize()
+            self.barrier()
+            t0 = time.perf_counter()
+            qid, stats, nn, idx, dd, z = job.all_vs_all_summary(q_rank, keep_at_most=2, max_neighbours=8)
+            t.cuda.synchronize()
+            ava_all.append(self.max_over_ranks(time.perf_counter() - t0))
+        ava = sorted(ava_all[1:])[1]
         idx_h, dd_h, nn_h = idx.cpu().numpy(), dd.cpu().numpy(), nn.cpu().numpy()
         # every read is its own nearest neighbour at distance 0 (identical reads would tie and also be listed)
         own = all((dd_h[j, 0] == 0.0) and (int(qid[j]) in idx_h[j, :min(int(nn_h[j]), idx_h.shape[1])].tolist())
                   for j in range(len(qid)))
         own_all = self.max_over_ranks(0.0 if own else 1.0) == 0.0
         res["all_vs_all"] = {"queries_total": q_rank * self.world, "against": n_total, "seconds": ava,
+                             "seconds_is": "median of three warm calls", "first_call_seconds": ava_all[0],
                              "pairs_per_second": q_rank * self.world * n_total / ava if ava > 0 else None,
                              "every_query_finds_itself_at_distance_0": own_all,
                              "note": "after the timed region; kpop_dev_distance_summary on the gathered matrix, N x N never formed"}
@@ -365,6 +371,185 @@ class Rank:
         if self.use_dist:
             self.dist.destroy_process_group()
         os.close(self.real_stdout)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE configs 2, 3 and 5 on this GPU (the N = 1 line's extras; every one a device-resident timing like `value`)
+# ---------------------------------------------------------------------------------------------------------
+def _event_ms(R, fn, reps, warm=1):
+    """median and all of `reps` HIP-event timings (ms) of fn() on the rank's stream, after `warm` untimed calls"""
+    t = R.torch
+    for _ in range(warm):
+        fn()
+    t.cuda.synchronize()
+    ms = []
+    for _ in range(reps):
+        e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+        e0.record(R.stream)
+        fn()
+        e1.record(R.stream)
+        t.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    return float(sorted(ms)[len(ms) // 2]), ms
+
+
+def config2_leg(R):
+    """BASELINE config 2: 10,000 x 150 bp, k = 10, D = 64 -- count -L (one CSR spectrum per read) and the fused count->twist"""
+    t, api, kp = R.torch, R.api, R.kpop
+    k, d, n, L = 10, 64, 10000, 150
+    tw = kp.Twister.synth(TWISTER_SEED, k, d)
+    try:
+        bases = t.empty(n * L, dtype=t.uint8, device=R.dev)
+        offs = t.empty(n + 1, dtype=t.int64, device=R.dev)
+        api.dev_synth_reads(READ_SEED, n, L, bases.data_ptr(), offs.data_ptr(), stream=R.sp)
+        w = L - k + 1
+        scratch = t.empty(api.dev_count_reads_scratch_bytes(n, L, k), dtype=t.uint8, device=R.dev)
+        oh = t.empty(n * w, dtype=t.int64, device=R.dev)
+        oc = t.empty(n * w, dtype=t.int32, device=R.dev)
+        oo = t.empty(n + 1, dtype=t.int64, device=R.dev)
+        out = t.zeros(n, d, dtype=t.float64, device=R.dev)
+        ms_c, _ = _event_ms(R, lambda: api.dev_count_reads(bases.data_ptr(), offs.data_ptr(), n, L, k, scratch.data_ptr(), oh.data_ptr(),
+                                                           oc.data_ptr(), oo.data_ptr(), stream=R.sp), 20, 3)
+        ms_t, _ = _event_ms(R, lambda: api.dev_count_twist(tw, bases.data_ptr(), offs.data_ptr(), n, n * L, L, out.data_ptr(), stream=R.sp), 20, 3)
+        alg_c = n * (L + w * 8)            # SURVEY 8d: read L B, write (L - k + 1) x (u32 hash + u32 count)
+        alg_t = n * (L + w * d * 8 + d * 8)  # read L B, gather nnz x D x 8 B, write D x 8 B
+        table = tw.info()["device_bytes"]
+        return {
+            "workload": "%d reads x %d bp, k=%d DNA-ds, D=%d (twister %.2f GB: inside the 256 MB Infinity Cache + L2 after the first launch)" % (n, L, k, d, table / 1e9),
+            "value": n / ((ms_c + ms_t) * 1e-3), "unit": "sequences/sec", "value_is": "count -L then the fused count->twist, both device-resident",
+            "ms_per_step": ms_c + ms_t, "kernels_ms": {"count_reads (-L, CSR out)": ms_c, "count_twist (fused)": ms_t},
+            "roofline": {"kernel": "count_twist_wave_kernel", "bound": "l2", "achieved": alg_t / (ms_t * 1e-3) / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg_t / (ms_t * 1e-3) / 1e9 / L2_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_t, "avg_launch_ms": ms_t,
+                         "note": "10,000 wavefronts are 1.2 rounds of the chip: the launch is a start, one gather chain per wavefront and a tail, not a "
+                                 "stream; the rows come from the caches (a 0.27 GB table), so the HBM figure would exceed 1 on a longer run of this shape"},
+            "roofline_count": {"kernel": "count_wave_kernel", "bound": "valu", "achieved_GBps_on_algorithmic_bytes": alg_c / (ms_c * 1e-3) / 1e9,
+                               "algorithmic_bytes_per_launch": alg_c, "avg_launch_ms": ms_c,
+                               "note": "instruction-bound (a bitonic network per read): profiles/r04_sq_counters.txt has the VALU issue fraction at 100k reads"},
+        }
+    finally:
+        tw.free()
+
+
+def _mutants_on_device(R, n, L, rate, seed):
+    """n copies of one synthetic L-base genome with point substitutions at `rate`, made on the device in slices"""
+    t, api = R.torch, R.api
+    ref = t.empty(L, dtype=t.uint8, device=R.dev)
+    ro = t.empty(2, dtype=t.int64, device=R.dev)
+    api.dev_synth_reads(seed, 1, L, ref.data_ptr(), ro.data_ptr(), stream=R.sp)
+    t.cuda.synchronize()
+    bases = ref.repeat(n)
+    acgt = t.tensor(list(b"ACGT"), dtype=t.uint8, device=R.dev)
+    g = t.Generator(device=R.dev)
+    g.manual_seed(seed)
+    step = 1 << 27
+    for lo in range(0, n * L, step):
+        hi = min(n * L, lo + step)
+        hit = t.rand(hi - lo, device=R.dev, generator=g) < rate
+        sub = acgt[t.randint(0, 4, (hi - lo,), device=R.dev, generator=g)]
+        bases[lo:hi] = t.where(hit, sub, bases[lo:hi])
+    offs = t.arange(n + 1, dtype=t.int64, device=R.dev) * L
+    return bases, offs
+
+
+def config3_leg(R):
+    """BASELINE config 3: 50,000 x 30 kb, k = 12, D = 64, the default dispatch -- once on unrelated genomes (the streaming
+    kernel: the HBM gather), once on assemblies of one organism (0.3 % divergence: the tile kernel, consensus on the matrix cores)"""
+    t, api = R.torch, R.api
+    k, d, n, L = R.args.k, R.args.dims, 50000, 30000
+    free, _ = t.cuda.mem_get_info(R.dev)
+    if free < 24e9:
+        return {"skipped": "needs 24 GB of free HBM, %.1f GB free" % (free / 1e9)}
+    out = t.zeros(n, d, dtype=t.float64, device=R.dev)
+    windows = n * (L - k + 1)
+    res = {"workload": "%d sequences x %d bp, k=%d DNA-ds, D=%d, default dispatch (kpop_tune untouched)" % (n, L, k, d)}
+    # unrelated genomes
+    bases = t.empty(n * L, dtype=t.uint8, device=R.dev)
+    offs = t.empty(n + 1, dtype=t.int64, device=R.dev)
+    api.dev_synth_reads(0xC1A55, n, L, bases.data_ptr(), offs.data_ptr(), stream=R.sp)
+    call = lambda: api.dev_count_twist(R.tw, bases.data_ptr(), offs.data_ptr(), n, n * L, L, out.data_ptr(), stream=R.sp)
+    ms, all_ms = _event_ms(R, call, 3, 1)
+    alg = n * L + windows * d * 8 + n * d * 8
+    res["unrelated_genomes"] = {
+        "value": n / (ms * 1e-3), "unit": "sequences/sec", "ms_per_step": ms, "ms_all": all_ms,
+        "roofline": {"kernel": "count_twist_stream_kernel", "bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms,
+                     "note": "the whole call (probe, scans, streaming kernel, combine) timed as one launch: the streaming kernel is > 99 % of it "
+                             "(profiles/r04_tile_kernel_ab.txt); every window's row is a random 512 B row of a 4.3 GB table"}}
+    del bases
+    # assemblies of one organism
+    bases, offs = _mutants_on_device(R, n, L, 0.003, 0x0123)
+    call = lambda: api.dev_count_twist(R.tw, bases.data_ptr(), offs.data_ptr(), n, n * L, L, out.data_ptr(), stream=R.sp)
+    ms, all_ms = _event_ms(R, call, 3, 1)
+    api.debug_counters(16)
+    api.tune("dbg", 32 << 24)
+    call()
+    cnt = api.debug_counters(16)
+    api.tune("dbg", 0)
+    flops = 2.0 * 64 * d * cnt[15]
+    res["one_organism_0.3pct"] = {
+        "value": n / (ms * 1e-3), "unit": "sequences/sec", "ms_per_step": ms, "ms_all": all_ms,
+        "roofline": {"kernel": "count_twist_tile_kernel", "bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": flops / (ms * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS, "traffic": None, "algorithmic_flops_per_launch": flops, "avg_launch_ms": ms,
+                     "chunks_taken": cnt[14], "set_rows_multiplied": cnt[15],
+                     "note": "flops = 2 x 64 sequences x D x the rows of every chunk's consensus set as multiplied (counted by the kernel in an extra, "
+                             "untimed call), over the WHOLE call's time: the matrix phase is a third of the kernel, the rest finds rows and builds "
+                             "the set (phase clocks and the MFMA-pipe counter: profiles/r04_tile_kernel_ab.txt, r04_tile_pmc.txt); the same batch through "
+                             "the streaming kernel alone (kpop_tune(\"dense\", 0)) is L2-latency-bound at ~100 SIMD-cycles a window"}}
+    api.tune("dense", 0)
+    try:
+        ms0, _ = _event_ms(R, call, 2, 1)
+    finally:
+        api.tune("dense", 2)
+    res["one_organism_0.3pct"]["streaming_kernel_alone_ms"] = ms0
+    res["one_organism_0.3pct"]["speedup_over_streaming_kernel"] = ms0 / ms
+    return res
+
+
+def config5_leg(R):
+    """BASELINE config 5: k = 15 (536,870,912 canonical 15-mers), D = 16, 10,000 reads x 150 bp: the whole 69 GB twister on this GPU"""
+    t, api, kp = R.torch, R.api, R.kpop
+    k, d, n, L = 15, 16, 10000, 150
+    free, _ = t.cuda.mem_get_info(R.dev)
+    if free < 150e9:
+        return {"skipped": "needs 150 GB of free HBM for the 69 GB twister and its synthesis, %.1f GB free" % (free / 1e9)}
+    t0 = time.perf_counter()
+    tw = kp.Twister.synth(TWISTER_SEED, k, d)
+    t.cuda.synchronize()
+    synth_s = time.perf_counter() - t0
+    try:
+        bases = t.empty(n * L, dtype=t.uint8, device=R.dev)
+        offs = t.empty(n + 1, dtype=t.int64, device=R.dev)
+        api.dev_synth_reads(READ_SEED, n, L, bases.data_ptr(), offs.data_ptr(), stream=R.sp)
+        out = t.zeros(n, d, dtype=t.float64, device=R.dev)
+        ms, all_ms = _event_ms(R, lambda: api.dev_count_twist(tw, bases.data_ptr(), offs.data_ptr(), n, n * L, L, out.data_ptr(), stream=R.sp), 20, 3)
+        w = L - k + 1
+        alg = n * (L + w * d * 8 + d * 8)
+        finite = bool(t.isfinite(out).all().item()) and bool((out.abs() < 1.0).all().item())
+        return {
+            "workload": "%d reads x %d bp, k=%d DNA-ds, D=%d; twister %d rows, %.1f GB resident (synthesised on the device in %.1f s, outside the timing)"
+                        % (n, L, k, d, tw.info()["n_cols"], tw.info()["device_bytes"] / 1e9, synth_s),
+            "value": n / (ms * 1e-3), "unit": "sequences/sec", "ms_per_step": ms,
+            "rows_finite_and_inside_the_coefficient_range": finite,
+            "roofline": {"kernel": "count_twist_wave_kernel", "bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms,
+                         "note": "128-byte rows (16 dims) gathered at random from 69 GB, every one an HBM miss behind an index-word miss (two dependent "
+                                 "round trips a window), 10,000 wavefronts = 1.2 rounds of the chip: latency, not bandwidth, sets this launch"}}
+    finally:
+        tw.free()
+
+
+def extra_configs(R):
+    legs = {}
+    for name, fn in (("config2_on_this_gpu", config2_leg), ("config3_on_this_gpu", config3_leg), ("config5_on_this_gpu", config5_leg)):
+        t0 = time.perf_counter()
+        try:
+            legs[name] = fn(R)
+        except Exception as e:  # a leg is a report, never a reason to lose the headline line
+            legs[name] = {"skipped": "leg failed: %r" % (e,)}
+        R.torch.cuda.synchronize()
+        R.torch.cuda.empty_cache()
+        legs[name]["leg_seconds"] = time.perf_counter() - t0
+    return legs
 
 
 def cpu_baseline(R, n_reads_gpu, gpu_twisted, gpu_dist, classes_host):
@@ -759,6 +944,7 @@ def main():
                 "note": "BASELINE config 4 (1M x %d bp in total) on one GPU: the N = 1 point of the strong-scaling curve "
                         "`bench.py --gpus N` reports for N > 1" % L}
             line["file_to_file"] = file_to_file(R)
+            line.update(extra_configs(R))
         R.finish(line)
         return
 

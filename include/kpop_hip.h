@@ -102,7 +102,9 @@ int kpop_synchronize(void *stream);
    extra LDS per block of the fused reads kernel (an occupancy probe); "dbg" development switches (also KPOP_TUNE_DBG)  */
 int kpop_tune(const char *key, int value);
 /* development: the phase clocks count_twist_tile_kernel adds up under kpop_tune("dbg", 16 << 24) (s_memtime ticks of thread 0 of
-   every block, nine phases; tools/probes/ab_tile_kernel.py prints them), read and cleared; synchronises the device */
+   every block, eight phases in out[0..7]; tools/probes/ab_tile_kernel.py prints them) and, under kpop_tune("dbg", 32 << 24), the
+   chunks it took (out[14]) and the rows of their consensus sets as multiplied on the matrix cores (out[15]: 2 x 64 x n_dims
+   flops each; bench.py's MFMA roofline); read and cleared; synchronises the device */
 int kpop_debug_counters(uint64_t *out, int n);
 
 /* plain device-memory helpers so a non-HIP host language can stage buffers */

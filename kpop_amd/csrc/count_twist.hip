@@ -1244,6 +1244,10 @@ __global__ __launch_bounds__(16 * G) void count_twist_tile_kernel(
     const bool ksplit = fused;
     const uint32_t UP = ksplit ? ((U + 16 * KQ - 1) & ~(16 * KQ - 1)) : ((U + 31) & ~31u);
     for (uint32_t u = U + threadIdx.x; u < UP; u += THREADS) ucol[u] = 0;
+    if ((dbg & 32) && threadIdx.x == 0) {  // (bench.py's count of the matrix cores' work: chunks taken, rows of their sets as multiplied)
+      atomicAdd(&g_tile_stamps[14], 1ull);
+      atomicAdd(&g_tile_stamps[15], (unsigned long long)UP);
+    }
     __syncthreads();
     stamp(5);  // the windows counted into X or listed
     const uint16_t *X16 = reinterpret_cast<const uint16_t *>(Xw);
