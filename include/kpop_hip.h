@@ -86,8 +86,10 @@ int kpop_synchronize(void *stream);
    "unroll" 8|16 row loads in flight per wave; "nt" row loads 0 plain | 1 non-temporal | 2 chosen by the size of the
    twister (default); "seg" windows per segment of the genome kernel, 0 = sized to an XCD's L2 (default); "hist" 1 (default) | 0: the
    merged spectrum of kpop_count_reads(per_read = 0) by atomic histogram where the hashes fit 26 bits, or always by sort;
-   "histlds" 1 (default) | 0 | 2: that histogram staged through LDS (private tables up to k = 7; sorted chunks of assemblies,
-   left off by a block that finds no repetition), direct global atomics as in round 2, or chunks always sorted;
+   "histlds" 1 (default) | 0 | 2 | 3: that histogram staged through LDS as the batch suggests (private tables up to k = 7;
+   (hash, count) tables over the same stretch of 64 assemblies of one organism; for what does not repeat -- a read set,
+   unrelated genomes -- the hashes partitioned by their top bits and every bucket counted in LDS, the table written without
+   a global atomic), direct global atomics as in round 2, chunks always combined, or always partitioned;
    "summary2" 1 (default) | 3 | 0 | 2: summaries against more than 4,096 rows by brackets from a sample and ONE pass over the
    distance rows, the same in two passes, round 2's one block per row, or (131,072 rows and more) with the distances
    computed and reduced in one kernel and no distance rows in memory -- same results, 1, 3 and 2 level;

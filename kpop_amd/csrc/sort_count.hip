@@ -400,6 +400,301 @@ __global__ __launch_bounds__(1024) void window_hist_combine_kernel(const uint8_t
   }
 }
 
+// ---------------------------------------------------------------------------
+// (c) INPUTS THAT DO NOT REPEAT (a read set, unrelated genomes): PARTITION, THEN COUNT IN LDS.  Every add of the forms above
+//     that reaches the global table is a scattered 4-byte memory-side atomic paying a 32-byte sector (0.03 of HBM on 100k
+//     random reads, traffic 3.7x the algorithmic bytes).  Instead:
+//       sizes      every window's hash -> its bucket (the top bits: a bucket = 2^LB consecutive bins, <= 32,768 = 128 KB of
+//                  u32 counters), counted per block in LDS, one global add per (block, bucket);
+//       offsets    exclusive scan of the (at most 2,048) bucket sizes: every bucket's stretch of the entry array, exactly;
+//       partition  the hashes again, a block collecting up to 32,768 of them in LDS before it reserves room in every bucket
+//                  with ONE atomic and writes each key's low LB bits (a u16) into its bucket's stretch;
+//       count      one block per bucket: its entries (u16, read in order) counted into an LDS table (ds_add_u32), the
+//                  bucket's range of the global table WRITTEN, dense -- no global atomic on the table, and no memset of it.
+//     The sequences are cut into items of at most 512 windows (host-built list); a wavefront takes an item at a time, a lane
+//     eight consecutive windows of it (rolling hash).  bin/KPopCount.ml:38,60.
+// ---------------------------------------------------------------------------
+struct HistItem {
+  uint32_t r, seg;
+};
+constexpr uint32_t kPartItem = 512;    // windows an item
+constexpr uint32_t kPartQuota = 2048;  // keys a wavefront collects per round (16 wavefronts: 32,768 keys, 128 KB)
+constexpr int kPartMaxLB = 15;
+
+static inline int part_bucket_bits(int hb) { return hb - 9 < kPartMaxLB ? (hb - 9 < 4 ? 4 : hb - 9) : kPartMaxLB; }  // LB: 512 buckets up to 24 hash bits, then buckets of 32,768 bins
+
+// the item's windows of this lane (eight consecutive ones): keys[i] valid where bit i of the return value is set.  The lane's
+// 8 + k - 1 symbols are loaded up front, every load in flight at once (k - 1 <= 12 here: hashes of up to 26 bits) -- as a loop of
+// dependent byte loads this was 19 round trips an item, and the partition's three passes took 0.33 ms on 100k reads
+template <int SB>
+__device__ __forceinline__ uint32_t part_item_keys(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, HistItem it, int k, int content,
+                                                   int lane, uint32_t (&keys)[8]) {
+  const uint64_t off = offsets[it.r], len = offsets[it.r + 1] - off;
+  const uint64_t n_win = len >= (uint64_t)k ? len - k + 1 : 0;
+  const uint64_t w0 = (uint64_t)it.seg * kPartItem + (uint64_t)lane * 8;
+#pragma unroll
+  for (uint32_t i = 0; i < 8; ++i) keys[i] = 0;
+  if (w0 >= n_win) return 0u;
+  const uint32_t nv = (uint32_t)min<uint64_t>(8, min<uint64_t>(n_win, (uint64_t)(it.seg + 1) * kPartItem) - w0);
+  const uint8_t *seq = bases + off + w0;
+  constexpr uint32_t kSym = (1u << SB) - 1u, kValid = SB == 2 ? 4u : 20u;
+  constexpr int kMaxSyms = 8 + 12;  // (k <= 13)
+  const uint32_t mask = (uint32_t)bits_mask(SB * k);
+  const int shift = SB * (k - 1);
+  const int ns = (int)nv + k - 1;  // symbols of this lane
+  uint32_t sym[kMaxSyms];
+#pragma unroll
+  for (int j = 0; j < kMaxSyms; ++j) sym[j] = j < ns ? (uint32_t)seq[j] : 0u;
+  uint32_t fwd = 0, rc = 0, ok = 0;
+  int run = 0;
+#pragma unroll
+  for (int j = 0; j < kMaxSyms; ++j) {
+    if (j < ns) {
+      const uint32_t c = SB == 2 ? base_code(sym[j]) : protein_code(sym[j]);
+      fwd = ((fwd << SB) | (c & kSym)) & mask;
+      if (SB == 2) rc = (rc >> 2) | ((3u - (c & 3u)) << shift);
+      run = c < kValid ? run + 1 : 0;
+      const int i = j - (k - 1);  // the window this symbol ends
+      if (i >= 0) {
+        const uint32_t key = (SB == 2 && content == KPOP_DNA_DS && rc < fwd) ? rc : fwd;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (q == i) keys[q] = key;
+        ok |= run >= k ? (1u << i) : 0u;
+      }
+    }
+  }
+  return ok;
+}
+
+// DNA items without any rolling: the wavefront packs the item's bases ONCE into LDS (two bits a base, first base in the most
+// significant bits: the hash's own convention, kmer.h; one more bit a base for "not ACGT"), then a window's hash is a 2k-bit
+// field of that stream, its reverse complement a bit reversal, its validity k zero bits -- ~16 vector instructions a window
+// with every lane busy, against ~29 per window on the 18 lanes a 150-base read keeps busy when each lane rolls eight windows.
+// Lane l gets windows l, 64 + l, ... of the item.  s_w: kPartStageWords words of the wavefront's own.
+constexpr uint32_t kPartCodeWords = 36, kPartInvWords = 20, kPartStageWords = kPartCodeWords + kPartInvWords;
+__device__ __forceinline__ uint32_t part_item_keys_dna(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, HistItem it, int k, int content,
+                                                       int lane, uint32_t (&keys)[8], uint32_t *s_w) {
+  const uint64_t off = offsets[it.r], len = offsets[it.r + 1] - off;
+  const uint64_t n_win = len >= (uint64_t)k ? len - k + 1 : 0, s_beg = (uint64_t)it.seg * kPartItem;
+  const uint32_t nw = s_beg < n_win ? (uint32_t)min<uint64_t>(kPartItem, n_win - s_beg) : 0u;  // windows of the item
+  const uint32_t nb = nw ? nw + (uint32_t)k - 1 : 0u;                                           // bases of the item
+  const uint8_t *seq = bases + off + s_beg;
+  uint8_t *s_code = reinterpret_cast<uint8_t *>(s_w);
+  uint8_t *s_inv = reinterpret_cast<uint8_t *>(s_w + kPartCodeWords);
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t b0 = (uint32_t)lane * 8u; b0 < kPartCodeWords * 16u; b0 += 512u) {  // (every byte of both streams is written: zeros and "invalid" past the end)
+    uint32_t raw[8];
+#pragma unroll
+    for (uint32_t i = 0; i < 8; ++i) raw[i] = b0 + i < nb ? (uint32_t)seq[b0 + i] : 0u;
+    uint32_t v = 0, inv = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 8; ++i) {
+      const uint32_t c = base_code(raw[i]);
+      v |= (c & 3u) << (14u - 2u * i);
+      inv |= (c > 3u ? 1u : 0u) << i;
+    }
+    s_code[b0 / 4] = (uint8_t)(v >> 8);
+    s_code[b0 / 4 + 1] = (uint8_t)v;
+    if (b0 / 8 < kPartInvWords * 4u) s_inv[b0 / 8] = (uint8_t)inv;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t mask = (uint32_t)bits_mask(2 * k), kmask = (1u << k) - 1u;
+  uint32_t ok = 0;
+#pragma unroll
+  for (uint32_t t = 0; t < 8; ++t) {
+    const uint32_t w = t * 64u + (uint32_t)lane;
+    const uint32_t B = w >> 2;  // byte of the code stream the window starts in
+    const uint64_t x = ((uint64_t)__builtin_bswap32(s_w[B >> 2]) << 32) | __builtin_bswap32(s_w[(B >> 2) + 1]);
+    const uint32_t fwd = (uint32_t)(x >> (64u - (8u * (B & 3u) + 2u * (w & 3u)) - 2u * (uint32_t)k)) & mask;
+    uint32_t r = __brev(fwd);
+    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+    const uint32_t rc = ((~r) >> (32u - 2u * (uint32_t)k)) & mask;
+    const uint64_t y = (uint64_t)s_w[kPartCodeWords + (w >> 5)] | ((uint64_t)s_w[kPartCodeWords + (w >> 5) + 1] << 32);
+    const bool good = w < nw && (((uint32_t)(y >> (w & 31u))) & kmask) == 0u;
+    keys[t] = (content == KPOP_DNA_DS && rc < fwd) ? rc : fwd;
+    ok |= good ? (1u << t) : 0u;
+  }
+  return ok;
+}
+
+template <int SB>
+__global__ __launch_bounds__(1024) void hist_part_sizes_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int k, int content,
+                                                               const HistItem *__restrict__ items, uint64_t n_items, int LB, uint32_t n_buckets,
+                                                               uint32_t *__restrict__ g_size) {
+  extern __shared__ uint32_t s_cnt[];
+  __shared__ uint32_t s_stage[16][kPartStageWords];
+  for (uint32_t b = threadIdx.x; b < n_buckets; b += 1024) s_cnt[b] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (uint64_t i = (uint64_t)blockIdx.x * 16 + wv; i < n_items; i += (uint64_t)gridDim.x * 16) {
+    uint32_t keys[8];
+    const uint32_t ok = SB == 2 ? part_item_keys_dna(bases, offsets, items[i], k, content, lane, keys, s_stage[wv])
+                                : part_item_keys<SB>(bases, offsets, items[i], k, content, lane, keys);
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j)
+      if ((ok >> j) & 1u) atomicAdd(&s_cnt[keys[j] >> LB], 1u);
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < n_buckets; b += 1024) {
+    const uint32_t c = s_cnt[b];
+    if (c) atomicAdd(&g_size[b], c);
+  }
+}
+
+// exclusive scan of at most 2,048 bucket sizes (one block): off[0..n], and the cursors the partition pass advances
+__global__ __launch_bounds__(1024) void hist_part_offsets_kernel(const uint32_t *__restrict__ g_size, uint32_t n_buckets, uint64_t *__restrict__ off,
+                                                                 unsigned long long *__restrict__ cursor) {
+  __shared__ uint64_t s_w[16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t b0 = threadIdx.x * 2;
+  const uint64_t a = b0 < n_buckets ? g_size[b0] : 0, b = b0 + 1 < n_buckets ? g_size[b0 + 1] : 0;
+  uint64_t incl = a + b;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint64_t up = (uint64_t)__shfl_up((unsigned long long)incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) s_w[wv] = incl;
+  __syncthreads();
+  uint64_t before = incl - a - b;
+  for (int w = 0; w < wv; ++w) before += s_w[w];
+  if (b0 < n_buckets) {
+    off[b0] = before;
+    cursor[b0] = before;
+  }
+  if (b0 + 1 < n_buckets) {
+    off[b0 + 1] = before + a;
+    cursor[b0 + 1] = before + a;
+  }
+  if (b0 + 2 >= n_buckets && b0 < n_buckets) off[n_buckets] = before + a + b;  // (the thread that holds the last bucket)
+}
+
+template <int SB>
+__global__ __launch_bounds__(1024) void hist_partition_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int k, int content,
+                                                              const HistItem *__restrict__ items, uint64_t n_items, int LB, uint32_t n_buckets,
+                                                              unsigned long long *__restrict__ cursor, uint16_t *__restrict__ entries) {
+  extern __shared__ uint32_t s_part[];
+  uint32_t *s_keys = s_part;                           // [16][kPartQuota]
+  uint32_t *s_cnt = s_part + 16 * kPartQuota;          // [n_buckets]
+  unsigned long long *s_base = reinterpret_cast<unsigned long long *>(s_cnt + n_buckets + (n_buckets & 1u));  // [n_buckets]
+  __shared__ unsigned long long s_next;
+  __shared__ uint32_t s_used[16];
+  __shared__ uint32_t s_stage[16][kPartStageWords];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // a block owns a contiguous run of items; its wavefronts take them one at a time
+  const uint64_t i0 = n_items * blockIdx.x / gridDim.x, i1 = n_items * (blockIdx.x + 1) / gridDim.x;
+  if (threadIdx.x == 0) s_next = i0;
+  const uint32_t low = (1u << LB) - 1u;
+  for (;;) {
+    for (uint32_t b = threadIdx.x; b < n_buckets; b += 1024) s_cnt[b] = 0;
+    __syncthreads();
+    uint32_t used = 0;
+    while (used + kPartItem <= kPartQuota) {
+      unsigned long long i = 0;
+      if (lane == 0) i = atomicAdd(&s_next, 1ull);
+      i = (unsigned long long)__shfl((long long)i, 0, 64);
+      if (i >= i1) break;
+      uint32_t keys[8];
+      const uint32_t ok = SB == 2 ? part_item_keys_dna(bases, offsets, items[i], k, content, lane, keys, s_stage[wv])
+                                  : part_item_keys<SB>(bases, offsets, items[i], k, content, lane, keys);
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j) {
+        const bool v = (ok >> j) & 1u;
+        const uint64_t m = __ballot(v);
+        if (v) {
+          s_keys[wv * kPartQuota + used + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = keys[j];
+          atomicAdd(&s_cnt[keys[j] >> LB], 1u);
+        }
+        used += (uint32_t)__popcll(m);
+      }
+    }
+    if (lane == 0) s_used[wv] = used;
+    __syncthreads();
+    const bool last = s_next >= i1;  // (uniform: every wavefront has stopped taking items before the barrier)
+    for (uint32_t b = threadIdx.x; b < n_buckets; b += 1024) {
+      const uint32_t c = s_cnt[b];
+      if (c) s_base[b] = atomicAdd(&cursor[b], (unsigned long long)c);
+      s_cnt[b] = 0;
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < used; i += 64) {
+      const uint32_t key = s_keys[wv * kPartQuota + i], b = key >> LB;
+      const uint32_t rank = atomicAdd(&s_cnt[b], 1u);
+      entries[s_base[b] + rank] = (uint16_t)(key & low);
+    }
+    __syncthreads();
+    if (last) break;
+  }
+}
+
+__global__ __launch_bounds__(1024) void hist_bucket_count_kernel(const uint16_t *__restrict__ entries, const uint64_t *__restrict__ off, int LB,
+                                                                 uint32_t *__restrict__ table) {
+  extern __shared__ uint32_t s_tab[];
+  const uint32_t n_bins = 1u << LB, b = blockIdx.x;
+  for (uint32_t j = threadIdx.x; j < n_bins; j += 1024) s_tab[j] = 0;
+  __syncthreads();
+  const uint64_t e0 = off[b], e1 = off[b + 1];
+  for (uint64_t i = e0 + threadIdx.x; i < e1; i += 1024) atomicAdd(&s_tab[entries[i]], 1u);
+  __syncthreads();
+  uint32_t *out = table + ((uint64_t)b << LB);
+  for (uint32_t j = threadIdx.x; j < n_bins; j += 1024) out[j] = s_tab[j];
+}
+
+// Are the batch's sequences ONE organism?  (The merged count of assemblies then goes through window_hist_combine_kernel's
+// LDS (hash, count) tables; a batch that is not, through the partition above.)  One block: the k-mers of sequence 0's first
+// 4,096 windows in an LDS set, sixteen windows of each of up to 63 other sequences looked up; yes when half of them are there.
+template <int SB>
+__global__ __launch_bounds__(1024) void hist_related_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, uint32_t n_reads, int k,
+                                                            int content, uint32_t *__restrict__ flag) {
+  constexpr uint32_t kTab = 8192, kEmpty = 0xFFFFFFFFu;
+  __shared__ uint32_t s_tab[kTab];
+  __shared__ uint32_t s_stat;
+  for (uint32_t q = threadIdx.x; q < kTab; q += 1024) s_tab[q] = kEmpty;
+  if (threadIdx.x == 0) s_stat = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  uint32_t keys[8];
+  {
+    const uint32_t i = threadIdx.x;  // items 0..7 of sequence 0, a wavefront each: 8 x 512 windows
+    const uint32_t ok = i < 512 ? part_item_keys<SB>(bases, offsets, HistItem{0u, i >> 6}, k, content, lane, keys) : 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j)
+      if ((ok >> j) & 1u) {
+        uint32_t slot = (keys[j] * 2654435761u) >> 19;
+        for (uint32_t t = 0; t < kTab; ++t) {
+          const uint32_t prev = atomicCAS(&s_tab[slot], kEmpty, keys[j]);
+          if (prev == kEmpty || prev == keys[j]) break;
+          slot = (slot + 1) & (kTab - 1);
+        }
+      }
+  }
+  __syncthreads();
+  {
+    // thread t: sequence 1 + t / 16 (if there is one), two lanes' worth of windows of one item spread over the first 4,096
+    const uint32_t r = 1 + threadIdx.x / 16, piece = threadIdx.x % 16;
+    uint32_t st = 0;
+    if (r < n_reads && r < 64) {
+      const uint32_t ok = part_item_keys<SB>(bases, offsets, HistItem{r, piece / 2}, k, content, (int)((piece % 2) * 32 + 5), keys);
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j)
+        if ((ok >> j) & 1u) {
+          uint32_t slot = (keys[j] * 2654435761u) >> 19, key = s_tab[slot];
+          for (uint32_t t = 0; t < kTab && key != keys[j] && key != kEmpty; ++t) {
+            slot = (slot + 1) & (kTab - 1);
+            key = s_tab[slot];
+          }
+          st += 1u + (key == keys[j] ? 65536u : 0u);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) st += (uint32_t)__shfl_xor((int)st, o, 64);
+    if (lane == 0 && st) atomicAdd(&s_stat, st);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *flag = ((s_stat & 0xFFFFu) > 0 && (s_stat >> 16) * 2u >= (s_stat & 0xFFFFu)) ? 1u : 0u;
+}
+
 struct NonZero {
   const uint32_t *t;
   __device__ uint32_t operator()(uint64_t i) const { return t[i] ? 1u : 0u; }
@@ -422,9 +717,12 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
   std::vector<uint64_t> rel(n_reads + 1);
   uint64_t max_win = 0;
   for (uint32_t r = 0; r <= n_reads; ++r) rel[r] = offsets[r] - base0;
+  uint64_t total_win = 0;
   for (uint32_t r = 0; r < n_reads; ++r) {
     const uint64_t len = rel[r + 1] - rel[r];
-    max_win = std::max(max_win, len >= (uint64_t)k ? len - k + 1 : 0);
+    const uint64_t w = len >= (uint64_t)k ? len - k + 1 : 0;
+    max_win = std::max(max_win, w);
+    total_win += w;
   }
   const int hb = hash_bits(k, content);
   const uint64_t n_bins = 1ull << hb;
@@ -437,11 +735,28 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
   KPOP_TRY(S.d_sums.alloc((scan_blocks(n_bins) + 1) * 8));
   KPOP_HIP(hipMemcpyAsync(S.d_bases.p, bases + base0, n_bases, hipMemcpyHostToDevice, st));
   KPOP_HIP(hipMemcpyAsync(S.d_off.p, rel.data(), (uint64_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
-  KPOP_HIP(hipMemsetAsync(S.d_ka.p, 0, n_bins * 4, st));
   uint32_t *table = S.d_ka.as<uint32_t>();
+  const int lds_mode = ctx().tune_histlds;  // 1 (default): LDS-staged where it applies; 0: round 2's direct atomics; 2: always combine chunks; 3: always partition
+  const bool protein = content == KPOP_PROTEIN;
+  // The partition path: hashes too wide for a private LDS table, enough windows to fill the chip twice over, fewer than 2^32
+  // of them -- and nothing to gain from combining: reads (no sequence above 4,096 windows), few assemblies, or assemblies
+  // that hist_related_kernel does not find to be one organism.
+  auto use_partition = [&]() -> bool {
+    if (!lds_mode || hb <= kHistLdsBits || hb - part_bucket_bits(hb) > 11 || total_win >= (1ull << 32) || k > 13) return false;
+    if (lds_mode == 3) return true;
+    if (lds_mode == 2 || total_win < (1u << 20)) return false;
+    if (max_win <= 4096 || n_reads < 16) return true;
+    DevBuf d_flag;
+    if (d_flag.alloc(4)) return false;
+    if (protein) hist_related_kernel<5><<<dim3(1), dim3(1024), 0, st>>>(S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), n_reads, k, content, d_flag.as<uint32_t>());
+    else hist_related_kernel<2><<<dim3(1), dim3(1024), 0, st>>>(S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), n_reads, k, content, d_flag.as<uint32_t>());
+    uint32_t related = 1;
+    if (hipMemcpyAsync(&related, d_flag.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return false;
+    return related == 0;
+  };
+  const bool partition = max_win > 0 && use_partition();
+  if (!partition) KPOP_HIP(hipMemsetAsync(S.d_ka.p, 0, n_bins * 4, st));
   if (max_win > 0) {
-    const int lds_mode = ctx().tune_histlds;  // 1 (default): LDS-staged where it applies; 0: round 2's direct atomics; 2: always sort chunks
-    const bool protein = content == KPOP_PROTEIN;
     if (lds_mode && hb <= kHistLdsBits) {
       // the whole table fits a block's LDS: private copies, one global atomic per non-zero counter and block
       const uint32_t max_seg = div_up(max_win, kKeySeg);
@@ -449,6 +764,46 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
       const size_t lds = (size_t)n_bins * 4;
       if (protein) window_hist_lds_kernel<5><<<dim3(blocks), dim3(1024), lds, st>>>(S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), k, content, hb, table, n_reads, max_seg);
       else window_hist_lds_kernel<2><<<dim3(blocks), dim3(1024), lds, st>>>(S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), k, content, hb, table, n_reads, max_seg);
+    } else if (partition) {
+      // nothing repeats (a read set, unrelated genomes): partition the hashes by their top bits, count every bucket in LDS
+      const int LB = part_bucket_bits(hb);
+      const uint32_t n_buckets = 1u << (hb - LB);
+      std::vector<HistItem> items;
+      items.reserve(total_win / kPartItem + n_reads);
+      for (uint32_t r = 0; r < n_reads; ++r) {
+        const uint64_t len = rel[r + 1] - rel[r], w = len >= (uint64_t)k ? len - k + 1 : 0;
+        for (uint64_t sgm = 0; sgm * kPartItem < w; ++sgm) items.push_back(HistItem{r, (uint32_t)sgm});
+      }
+      const uint64_t n_items = items.size();
+      DevBuf d_items, d_size, d_poff, d_cursor, d_entries;
+      KPOP_TRY(d_items.alloc(n_items * sizeof(HistItem)));
+      KPOP_TRY(d_size.alloc((uint64_t)n_buckets * 4));
+      KPOP_TRY(d_poff.alloc((uint64_t)(n_buckets + 1) * 8));
+      KPOP_TRY(d_cursor.alloc((uint64_t)n_buckets * 8));
+      KPOP_TRY(d_entries.alloc(total_win * 2 + 16));
+      KPOP_HIP(hipMemcpyAsync(d_items.p, items.data(), n_items * sizeof(HistItem), hipMemcpyHostToDevice, st));
+      KPOP_HIP(hipMemsetAsync(d_size.p, 0, (uint64_t)n_buckets * 4, st));
+      const uint32_t blocks1 = (uint32_t)std::min<uint64_t>(div_up(n_items, 16), (uint64_t)ctx().n_cus * 2);
+      const uint32_t blocks2 = (uint32_t)std::min<uint64_t>(div_up(n_items, 64), (uint64_t)ctx().n_cus);
+      const size_t lds_part = (size_t)16 * kPartQuota * 4 + (size_t)(n_buckets + (n_buckets & 1u)) * 4 + (size_t)n_buckets * 8;
+      static PerSlotOnce once;
+      if (!once()) {
+        KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_partition_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * kPartQuota * 4 + 2048 * 12)));
+        KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_partition_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * kPartQuota * 4 + 2048 * 12)));
+        KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_bucket_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        once() = true;
+      }
+#define KPOP_PART(SB)                                                                                                                        \
+  do {                                                                                                                                       \
+    hist_part_sizes_kernel<SB><<<dim3(blocks1), dim3(1024), (size_t)n_buckets * 4, st>>>(S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), k, content, \
+                                                                                        d_items.as<HistItem>(), n_items, LB, n_buckets, d_size.as<uint32_t>()); \
+    hist_part_offsets_kernel<<<dim3(1), dim3(1024), 0, st>>>(d_size.as<uint32_t>(), n_buckets, d_poff.as<uint64_t>(), d_cursor.as<unsigned long long>()); \
+    hist_partition_kernel<SB><<<dim3(blocks2), dim3(1024), lds_part, st>>>(S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), k, content, d_items.as<HistItem>(), \
+                                                                          n_items, LB, n_buckets, d_cursor.as<unsigned long long>(), d_entries.as<uint16_t>()); \
+  } while (0)
+      if (protein) KPOP_PART(5); else KPOP_PART(2);
+#undef KPOP_PART
+      hist_bucket_count_kernel<<<dim3(n_buckets), dim3(1024), (size_t)4 << LB, st>>>(d_entries.as<uint16_t>(), d_poff.as<uint64_t>(), LB, table);
     } else if (max_win <= 4096) {
       read_hist_kernel<uint32_t><<<dim3(std::min<uint32_t>(div_up(n_reads, 4), 1u << 16)), dim3(256), 0, st>>>(
           S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), k, content, table, n_reads);

@@ -86,11 +86,11 @@ def test_count_errors(kpop):
     assert len(h) == 0 and o.tolist() == [0]
 
 
-@pytest.fixture(params=[(1, 1), (1, 0), (1, 2), (0, 1)], ids=["histogram-lds", "histogram-direct", "histogram-sorted-chunks", "sort"])
+@pytest.fixture(params=[(1, 1), (1, 0), (1, 2), (1, 3), (0, 1)], ids=["histogram-lds", "histogram-direct", "histogram-combined-chunks", "histogram-partitioned", "sort"])
 def merged_path(request, kpop):
-    """-l by atomic histogram (hashes of up to 26 bits; the default there) -- staged through LDS (private tables up to
-    k = 7, sorted chunks of assemblies; the default), with direct global atomics, with every chunk sorted -- and by
-    device-wide sort (everything else)"""
+    """-l by histogram (hashes of up to 26 bits; the default there) -- staged through LDS as the batch suggests (private tables up
+    to k = 7, combined chunks of assemblies of one organism, partition-then-count for what does not repeat; the default), with
+    direct global atomics, with every chunk combined, always partitioned -- and by device-wide sort (everything else)"""
     from kpop_amd import api
     api.tune("hist", request.param[0])
     api.tune("histlds", request.param[1])
