@@ -332,9 +332,10 @@ int kpop_distance_rowwise(const double *m1, uint32_t r1, const double *m2, uint3
  * have a fixed stride max_neighbours per row; out_n[j] is the reference's
  * eff_len (may exceed max_neighbours: entries beyond the stride are dropped).
  * keep_at_most=0 means "all" (:723-726).  The r2 x r1 matrix is never formed.
- * Against a first operand of more than 4,096 rows at most 2,048 neighbours come back per row; a row whose list is
- * longer (keep_at_most = all, a tie group of thousands) makes the host entry points fail with KPOP_ERR_UNSUPPORTED
- * rather than return a list they cannot fill (the device entry points only report out_n). */
+ * Lists of any length: against a first operand of more than 4,096 rows the summary kernels themselves return at most
+ * 2,048 neighbours per row; a longer list (keep_at_most = all, :723-726; a tie group of thousands, :648-649) is completed
+ * by the host entry points -- the row's distances sorted by (distance, column) with the device-wide radix sort.  The
+ * device entry points (kpop_dev_*) report out_n and fill at most 2,048 entries of such a row. */
 int kpop_distance_summary(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
                           const double *metric, int kind, double p, int normalize, uint32_t keep_at_most,
                           uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,

@@ -17,7 +17,10 @@
 #include <algorithm>
 #include <vector>
 
+#include <string.h>
+
 #include "common.h"
+#include "radix_sort.h"
 #include "space_ops.h"
 #include "wave_sort.h"
 
@@ -1018,17 +1021,79 @@ static int embeddings_impl(const double *d_m, uint32_t rows, uint32_t n_dims, co
   return 0;
 }
 
-// Against more than kSummaryMaxR1 rows the summary returns at most kLargeNeighbours neighbours per row
-// (summary_large.hip).  A row whose list is longer (--summary-keep-at-most all, or a tie group of thousands) cannot be
-// written out from what came back: the host entry points say so instead of handing over rows of zeros.
+// Against more than kSummaryMaxR1 rows the summary kernels return at most kLargeNeighbours neighbours per row
+// (summary_large.hip); out_n is the reference's eff_len whatever its size.  A row whose list is longer
+// (--summary-keep-at-most all: req_len = r1, lib/Matrix.ml:723-726; or a tie group of thousands, :648-649) is completed
+// here, by the host entry points: the row's distances -- given, or computed by the kernel the summary itself uses -- are
+// sorted by (distance, column) with the device-wide radix sort (stable, the columns travelling as values: equal distances
+// keep column order, which is the multimap's, :641-650), and the first eff_len written over the row's stride with their
+// z-scores.  One row at a time: long lists are the rare request, and a row of a million distances is 24 small launches.
 constexpr uint32_t kLargeNeighbours = 2048;
-static int check_large_neighbour_lists(uint32_t r1, uint32_t r2, uint32_t max_neighbours, const uint32_t *out_n) {
+__global__ void long_list_keys_kernel(const double *__restrict__ d, uint32_t r1, uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < r1) {
+    const double x = d[i];
+    key[i] = x == 0.0 ? 0ull : (uint64_t)__double_as_longlong(x);  // (distances are not negative: their bit patterns sort as they do)
+    val[i] = i;
+  }
+}
+
+struct LongListSource {  // where a row's distances come from
+  const double *d_rows = nullptr;  // r2 x r1, given (kpop_summarize_distances) ...
+  const double *d1 = nullptr, *d2 = nullptr, *dm = nullptr;  // ... or the operands (kpop_distance_summary)
+  uint32_t n_dims = 0;
+  int kind = 0, normalize = 0;
+  double p = 2.0;
+};
+
+static int fill_long_lists(const LongListSource &src, uint32_t r1, uint32_t r2, uint32_t max_neighbours, const double *out_stats, const uint32_t *out_n,
+                           uint32_t *out_idx, double *out_dist, double *out_z, hipStream_t st) {
   if (r1 <= kSummaryMaxR1 || max_neighbours <= kLargeNeighbours) return KPOP_OK;
+  std::vector<uint32_t> todo;
   for (uint32_t j = 0; j < r2; ++j)
-    if (out_n[j] > kLargeNeighbours)
-      KPOP_FAIL(KPOP_ERR_UNSUPPORTED,
-                "summary: row %u lists %u neighbours; against a first operand of more than %u rows at most %u are returned per row "
-                "(keep_at_most = all, or a tie group that large, is not supported there)", j, out_n[j], kSummaryMaxR1, kLargeNeighbours);
+    if (out_n[j] > kLargeNeighbours) todo.push_back(j);
+  if (todo.empty()) return KPOP_OK;
+  if (!out_idx || !out_dist || !out_z) KPOP_FAIL(KPOP_ERR_INVALID, "summary: neighbour outputs are null");
+  DevBuf drow, dw, ka, kb, va, vb, scr;
+  if (!src.d_rows) {
+    KPOP_TRY(drow.alloc((uint64_t)r1 * 8));
+    KPOP_TRY(dw.alloc(kpop_dev_distance_workspace_bytes(r1, 1, src.n_dims)));
+  }
+  KPOP_TRY(ka.alloc((uint64_t)r1 * 8));
+  KPOP_TRY(kb.alloc((uint64_t)r1 * 8));
+  KPOP_TRY(va.alloc((uint64_t)r1 * 4));
+  KPOP_TRY(vb.alloc((uint64_t)r1 * 4));
+  KPOP_TRY(scr.alloc(radix_scratch_bytes(r1)));
+  std::vector<uint64_t> hk;
+  for (uint32_t j : todo) {
+    const double *row = src.d_rows ? src.d_rows + (uint64_t)j * r1 : drow.as<double>();
+    if (!src.d_rows)
+      KPOP_TRY(kpop_dev_distance_rowwise(src.d1, r1, src.d2 + (uint64_t)j * src.n_dims, 1, src.n_dims, src.dm, src.kind, src.p, src.normalize, dw.p,
+                                         drow.as<double>(), st));
+    long_list_keys_kernel<<<dim3(div_up(r1, 256)), dim3(256), 0, st>>>(row, r1, ka.as<uint64_t>(), va.as<uint32_t>());
+    KPOP_LAUNCH_CHECK();
+    uint64_t *sk = nullptr;
+    uint32_t *sv = nullptr;
+    KPOP_TRY(radix_sort_pairs_u64(ka.as<uint64_t>(), kb.as<uint64_t>(), va.as<uint32_t>(), vb.as<uint32_t>(), r1, 64, scr.p, st, &sk, &sv));
+    const uint32_t m = std::min(out_n[j], max_neighbours);
+    hk.resize(m);
+    KPOP_HIP(hipMemcpyAsync(hk.data(), sk, (uint64_t)m * 8, hipMemcpyDeviceToHost, st));
+    KPOP_HIP(hipMemcpyAsync(out_idx + (uint64_t)j * max_neighbours, sv, (uint64_t)m * 4, hipMemcpyDeviceToHost, st));
+    KPOP_HIP(hipStreamSynchronize(st));
+    const double mean = out_stats[(uint64_t)j * 4 + 0], sd = out_stats[(uint64_t)j * 4 + 1];
+    for (uint32_t q = 0; q < m; ++q) {
+      double dq;
+      memcpy(&dq, &hk[q], 8);
+      out_dist[(uint64_t)j * max_neighbours + q] = dq;
+      volatile double num = dq - mean;  // (two roundings, as the kernels': no contraction)
+      double zz = num / sd;
+      if (zz != zz) {  // the x86 invalid-operation NaN the reference's arithmetic gives (see the kernels)
+        const uint64_t nanbits = 0xFFF8000000000000ull;
+        memcpy(&zz, &nanbits, 8);
+      }
+      out_z[(uint64_t)j * max_neighbours + q] = zz;
+    }
+  }
   return KPOP_OK;
 }
 
@@ -1226,7 +1291,9 @@ extern "C" int kpop_summarize_distances(const double *dist, uint32_t r2, uint32_
     KPOP_HIP(hipMemcpyAsync(out_z, dz.p, nn * 8, hipMemcpyDeviceToHost, st));
   }
   KPOP_HIP(hipStreamSynchronize(st));
-  return check_large_neighbour_lists(r1, r2, max_neighbours, out_n);
+  LongListSource src;
+  src.d_rows = dd.as<double>();
+  return fill_long_lists(src, r1, r2, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st);
 }
 
 extern "C" int kpop_distance_rowwise(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
@@ -1291,5 +1358,13 @@ extern "C" int kpop_distance_summary(const double *m1, uint32_t r1, const double
     KPOP_HIP(hipMemcpyAsync(out_z, dz.p, nn * 8, hipMemcpyDeviceToHost, st));
   }
   KPOP_HIP(hipStreamSynchronize(st));
-  return check_large_neighbour_lists(r1, r2, max_neighbours, out_n);
+  LongListSource src;
+  src.d1 = d1.as<double>();
+  src.d2 = d2.as<double>();
+  src.dm = dm.as<double>();
+  src.n_dims = n_dims;
+  src.kind = kind;
+  src.normalize = normalize;
+  src.p = p;
+  return fill_long_lists(src, r1, r2, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st);
 }

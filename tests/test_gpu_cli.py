@@ -98,6 +98,32 @@ def twisted_text(dims, labels, rows):
     return s
 
 
+def test_summary_keep_at_most_all_against_a_large_reference_set(tmp_path, oracle):
+    """KPopTwistDB -I d .. --summary-keep-at-most all -S ..: 5,000 reference columns (more than the summary kernels list by
+    themselves), every one of them listed per row, in (distance, column) order -- lib/Matrix.ml:723-726,641-650"""
+    rng = np.random.RandomState(5)
+    r1, r2 = 5000, 3
+    dm = np.round(rng.rand(r2, r1) * 10, 2)  # two decimals: ties by the dozen
+    cols, rows = ["c%d" % i for i in range(r1)], ["q%d" % j for j in range(r2)]
+    text = '""' + "".join('\t"%s"' % c for c in cols) + "\n"
+    for j in range(r2):
+        text += '"%s"' % rows[j] + "".join("\t%.15g" % v for v in dm[j]) + "\n"
+    (tmp_path / "D.KPopDMatrix.txt").write_text(text)
+    r = run([TWISTDB, "-I", "d", str(tmp_path / "D"), "--summary-keep-at-most", "all", "-S", str(tmp_path / "All")])
+    assert r.returncode == 0, r.stderr
+    got = (tmp_path / "All.KPopSummary.txt").read_text().splitlines()
+    assert len(got) == r2
+    for j in range(r2):
+        st, idx, dist, z = oracle.summarize_row(dm[j], r1)
+        assert len(idx) == r1
+        g, w = got[j].split("\t"), oracle.format_summary_line(rows[j], st, cols, idx, dist, z).rstrip("\n").split("\t")
+        assert len(g) == len(w) == 5 + 3 * r1 and g[0] == w[0]
+        # (against more than 4,096 columns the statistics are summed in another order than the reference's: 1e-10, and the z-scores with them)
+        np.testing.assert_allclose([float(v) for v in g[1:5]], [float(v) for v in w[1:5]], rtol=1e-10)
+        assert g[5::3] == w[5::3] and g[6::3] == w[6::3]  # names and distances, to the character
+        np.testing.assert_allclose([float(v) for v in g[7::3]], [float(v) for v in w[7::3]], rtol=1e-8, atol=1e-9)
+
+
 def test_count_twist_distance_summary_pipeline(tmp_path, oracle, pyref):
     """KPopCount -L | KPopTwistDB -I T .. -k /dev/stdin -O t ..; then -d / -s / -S against the class vectors."""
     k, d = 5, 6

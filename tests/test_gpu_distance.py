@@ -317,20 +317,50 @@ def test_distance_summary_without_distance_rows(kpop, oracle, case):
                 np.testing.assert_allclose(z[j, :m], z_o[a:a + m], rtol=1e-8, atol=1e-9)
 
 
-def test_large_reference_set_refuses_lists_it_cannot_fill(kpop, oracle):
-    """against more than 4,096 rows at most 2,048 neighbours come back per row: a caller that asks for more room than
-    that (keep_at_most = all) gets an error, not rows of zeros (KPopTwistDB then exits 1 instead of printing them)"""
+def test_large_reference_set_long_neighbour_lists(kpop, oracle):
+    """against more than 4,096 rows the summary kernels return at most 2,048 neighbours per row; longer lists -- keep_at_most =
+    all (req_len = r1, lib/Matrix.ml:723-726), or a tie group of thousands (:648-649) -- are completed by the host entry
+    points (the row sorted by (distance, column) on the device): against the oracle, from the operands and from a given
+    distance matrix, with room for everything and with a stride that truncates"""
     rng = np.random.RandomState(1)
     m1, m2 = rng.normal(size=(5000, 8)), rng.normal(size=(3, 8))
+    m1[100:130] = m1[7]  # ties inside the list
     metric = oracle.metric_powers(oracle.synth_inertia(8))
-    with pytest.raises(kpop.KPopError) as e:
-        kpop.distance_summary(m1, m2, metric, keep_at_most=0, max_neighbours=5000)
-    assert "2048" in str(e.value)
+    for normalize in (True, False):
+        st, n, idx, dist, z = kpop.distance_summary(m1, m2, metric, normalize=normalize, keep_at_most=0, max_neighbours=5000)
+        so, offs, io, do, zo = oracle.distance_summary(m1, m2, metric, normalize=normalize, keep_at_most=0)
+        assert n.tolist() == [5000] * 3
+        np.testing.assert_allclose(st, so, rtol=1e-10)
+        for j in range(3):
+            a = int(offs[j])
+            assert idx[j].tolist() == io[a:a + 5000].tolist()
+            assert np.array_equal(dist[j], do[a:a + 5000])
+            np.testing.assert_allclose(z[j], zo[a:a + 5000], rtol=1e-8, atol=1e-9)
     dm = kpop.distance_rowwise(m1, m2, metric)
-    with pytest.raises(kpop.KPopError):
-        kpop.summarize_distances(dm, keep_at_most=0, max_neighbours=5000)
-    st, n, idx, dist, z = kpop.distance_summary(m1, m2, metric, keep_at_most=0, max_neighbours=2048)  # truncated by the caller's own stride
+    st, n, idx, dist, z = kpop.summarize_distances(dm, keep_at_most=0, max_neighbours=5000)
+    for j in range(3):
+        so, io, do, zo = oracle.summarize_row(dm[j], 5000)
+        assert n[j] == 5000 and idx[j].tolist() == io.tolist() and np.array_equal(dist[j], do)
+        np.testing.assert_allclose(z[j], zo, rtol=1e-8, atol=1e-9)
+    st, n, idx, dist, z = kpop.distance_summary(m1, m2, metric, keep_at_most=0, max_neighbours=3000)  # truncated by the caller's own stride
+    so, offs, io, do, zo = oracle.distance_summary(m1, m2, metric, keep_at_most=0)
     assert n.tolist() == [5000] * 3
+    for j in range(3):
+        a = int(offs[j])
+        assert idx[j].tolist() == io[a:a + 3000].tolist() and np.array_equal(dist[j], do[a:a + 3000])
+    # a tie group of 3,000 among 20,000 reference rows: keep_at_most = 5 lists the whole group
+    dm = rng.rand(4, 20000) + 1.0
+    for j in range(4):
+        tie = rng.choice(20000, size=3000, replace=False)
+        dm[j, tie] = 0.5
+        dm[j, rng.choice(np.setdiff1d(np.arange(20000), tie), size=2, replace=False)] = 0.25
+    st, n, idx, dist, z = kpop.summarize_distances(dm, keep_at_most=5, max_neighbours=4000)
+    for j in range(4):
+        so, io, do, zo = oracle.summarize_row(dm[j], 5)
+        assert n[j] == 3002 == len(io)
+        assert idx[j, :3002].tolist() == io.tolist() and np.array_equal(dist[j, :3002], do)
+        np.testing.assert_allclose(st[j], so, rtol=1e-10)
+        np.testing.assert_allclose(z[j, :3002], zo, rtol=1e-8, atol=1e-9)
 
 
 def test_summarize_distances_large_row_with_ties(kpop, oracle):
