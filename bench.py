@@ -819,11 +819,18 @@ def in_process(args):
     for _ in range(args.warmup):
         step()
     t0 = time.perf_counter()
-    tm = []
+    tm, ck = [], []
     for _ in range(args.steps):
         step()  # returns when every device is done and every copy of the matrix is complete
         tm.append([sh.timings(s) for s in range(N)])
+        ck.append([sh.chunk_timings(s) for s in range(N)])
     elapsed = time.perf_counter() - t0
+    # the same steps again with nothing between them (no timing calls): what the host side costs a step = wall - the slowest
+    # slot's own time from its rendezvous to its last push having landed
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    bare = (time.perf_counter() - t0) / args.steps * 1e3
     exposed = [float(np.mean([t[s]["ms_exposed_comm"] for t in tm])) for s in range(N)]
     compute = [float(np.mean([t[s]["ms_compute"] for t in tm])) for s in range(N)]
     # is every copy of the gathered matrix the union of the shards?  order-free checksum of the f64 bit patterns
@@ -847,6 +854,8 @@ def in_process(args):
     windows = max(L - k + 1, 0)
     per_read = L + windows * d * 8 + d * 8
     chunk_rows = -(-max(n_reads) // (chunks if gather else 1))
+    all_chunks = [x for c in ck for sl in c for x in sl if x > 0]
+    avg_chunk_ms = float(np.mean(all_chunks)) if all_chunks else None
     line = {
         "metric": "sequences/sec end-to-end count->twist->all-gather->distance, k=%d, %dk x %dbp in total" % (k, reads // 1000, L),
         "value": reads * args.steps / elapsed, "unit": "sequences/sec", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
@@ -862,10 +871,16 @@ def in_process(args):
                    "reads_per_gpu": max(n_reads),
                    "sharding": "reads in contiguous shards (kpop_shard_bounds); twister, classes and metric replicated; ONE exchange: "
                                "all-gather of twisted vectors by peer copies over xGMI"},
-        "roofline": {"kernel": "count_twist_wave_kernel", "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                     "traffic": None, "algorithmic_bytes_per_launch": chunk_rows * per_read,
-                     "note": "per-kernel events are taken in the torch.distributed mode and the 1-GPU line; this mode reports host wall time per device"},
-        "per_device_ms": {"compute_until_kernels_done": compute, "exposed_comm": exposed},
+        "roofline": {"kernel": "count_twist_wave_kernel", "bound": "hbm", "achieved": chunk_rows * per_read / (avg_chunk_ms * 1e-3) / 1e9 if avg_chunk_ms else None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": chunk_rows * per_read / (avg_chunk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_chunk_ms else None,
+                     "traffic": None, "algorithmic_bytes_per_launch": chunk_rows * per_read, "avg_launch_ms": avg_chunk_ms,
+                     "note": "one launch per chunk of %d reads; HIP events on every slot's compute stream around each launch "
+                             "(kpop_sharded_chunk_timings), averaged over slots, chunks and steps" % chunk_rows},
+        "per_device_ms": {"compute_until_kernels_done": compute, "exposed_comm": exposed,
+                          "count_twist_kernels_per_step": [float(np.mean([sum(c[s]) for c in ck])) for s in range(N)]},
+        "host_overhead_ms_per_step": bare - max(float(np.mean([t[s]["ms_compute"] + t[s]["ms_exposed_comm"] for t in tm])) for s in range(N)),
+        "host_overhead_is": "wall per step of %d back-to-back steps (%.3f ms) minus the slowest slot's own time from the step's rendezvous to its last "
+                            "push having landed: job hand-over to the persistent slot threads, buffer checks, the one rendezvous, the return" % (args.steps, bare),
         "startup_s": startup_s,
         "gather_checksum_ok": ok,
         "all_vs_all": {"queries_total": 0 if qid is None else int(len(qid)), "against": reads, "seconds": ava,

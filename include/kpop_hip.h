@@ -286,6 +286,9 @@ int kpop_sharded_resident_buffers(const kpop_sharded *sh, int slot, double **d_f
 /* of the last resident step on that slot: host time until its kernels were done, and the time it then still waited
    for its pushes to land (the exposed part of the exchange)                                                         */
 int kpop_sharded_timings(const kpop_sharded *sh, int slot, double *ms_compute, double *ms_exposed_comm);
+/* ... and its fused count->twist launches chunk by chunk (HIP events on the slot's compute stream; what a roofline of the
+   in-process path is computed from): ms[0 .. *n_chunks), at most max_chunks                                          */
+int kpop_sharded_chunk_timings(const kpop_sharded *sh, int slot, double *ms, int max_chunks, int *n_chunks);
 /* After a resident step with gather: slot s summarises the first min(queries_per_slot, n_s) rows of its shard (0 =
    all) against ALL n_total twisted vectors (Matrix.summarize_rowwise, lib/Matrix.ml:691-766; N x N is never formed).
    One output row per query, slots in order; out_query = the query's global read number; neighbour indices are global

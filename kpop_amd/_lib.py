@@ -57,6 +57,7 @@ SIGNATURES = {
     "kpop_sharded_resident_step": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), u32p, u64p, C.c_uint32, C.c_int, C.c_int]),
     "kpop_sharded_resident_buffers": (C.c_int, [vp, C.c_int, C.POINTER(vp), u64p, u64p, C.POINTER(vp)]),
     "kpop_sharded_timings": (C.c_int, [vp, C.c_int, f64p, f64p]),
+    "kpop_sharded_chunk_timings": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),
     "kpop_sharded_all_vs_all_summary": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, u64p, u64p, f64p, u32p,
                                                   u32p, f64p, f64p]),
     "kpop_sharded_destroy": (C.c_int, [vp]),

@@ -424,6 +424,13 @@ class Sharded:
         check(_lib.load().kpop_sharded_timings(self._h, int(slot), C.byref(a), C.byref(b)))
         return {"ms_compute": a.value, "ms_exposed_comm": b.value}
 
+    def chunk_timings(self, slot, max_chunks=64):
+        """ms of the fused count->twist launches of the last resident step on that slot, chunk by chunk (HIP events)"""
+        ms = (C.c_double * int(max_chunks))()
+        n = C.c_int()
+        check(_lib.load().kpop_sharded_chunk_timings(self._h, int(slot), ms, int(max_chunks), C.byref(n)))
+        return [float(ms[i]) for i in range(n.value)]
+
     def all_vs_all_summary(self, queries_per_slot=0, keep_at_most=2, max_neighbours=8, capacity=None):
         """after resident_step(gather=True) -> (query global ids, stats, n, idx, dist, z), one row per query"""
         cap = int(capacity if capacity is not None else max(1, queries_per_slot) * self.slots)

@@ -68,6 +68,7 @@ struct Arena {
 // per-device worker threads choose theirs when they start.
 struct Context {
   bool initialised = false;
+  uint32_t generation = 1;  // bumped when the slot is released (PerSlotOnce)
   int slot = 0;
   int device = -1;
   int n_cus = 256;
@@ -112,10 +113,22 @@ int current_slot();
 int n_slots();
 int use_slot(int slot);      // thread-local choice + hipSetDevice
 int require_init();
+void stop_slot_workers();  // multi.hip: the per-slot host threads end before their slots do
 // once-per-device-slot latch for hipFuncSetAttribute and the like (function attributes are per device)
+// (a slot that is released -- kpop_shutdown, kpop_init_devices with another GPU in it -- starts a new generation: the latches
+// of the old one no longer hold, the new device needs its attributes set again)
 struct PerSlotOnce {
   bool done[kMaxSlots] = {};
-  bool &operator()() { return done[current_slot()]; }
+  uint32_t gen[kMaxSlots] = {};
+  bool &operator()() {
+    const int s = current_slot();
+    const uint32_t g = ctx().generation;
+    if (gen[s] != g) {
+      gen[s] = g;
+      done[s] = false;
+    }
+    return done[s];
+  }
 };
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }

@@ -332,6 +332,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void twist_csr_kernel(
   const uint32_t spec = SEG ? s / n_seg : s;
   uint64_t lo = offsets[spec], hi = offsets[spec + 1];
   if (SEG) {
+    if (s % n_seg == n_seg - 1 && hi - lo > (uint64_t)n_seg * seg_lines) {
+      // the caller's max_lines understated this spectrum and its last stretches have no segment: a row of NaNs in the last
+      // segment's partial (the combine adds it in) says so -- never a silently shortened sum
+      for (uint32_t d = lane; d < tv.n_dims; d += 64) out[(uint64_t)s * tv.n_dims + d] = __longlong_as_double(0x7FF8000000000000ll);
+      return;
+    }
     lo = min(hi, lo + (uint64_t)(s % n_seg) * seg_lines);
     hi = min(hi, lo + seg_lines);
   }
@@ -2020,7 +2026,8 @@ extern "C" int kpop_spectra_twist(const kpop_twister *tw, const uint8_t *bases, 
       ArenaScope batch;
       SortedSpectra S;
       KPOP_TRY(sorted_count_device(bases, offsets + r0, nr, k, content, 1, ~0ull, S, st));
-      KPOP_TRY(launch_twist_csr<uint32_t>(tv, S.d_oh.as<uint64_t>(), S.d_oc.as<uint32_t>(), S.d_oo.as<uint64_t>(), nr, 0, normalize,
+      // (no spectrum has more lines than its sequence has windows: a few long genomes then take the segmented launch)
+      KPOP_TRY(launch_twist_csr<uint32_t>(tv, S.d_oh.as<uint64_t>(), S.d_oc.as<uint32_t>(), S.d_oo.as<uint64_t>(), nr, max_windows, normalize,
                                           d_out.as<double>() + r0 * tw->n_dims, st));
       KPOP_HIP(hipStreamSynchronize(st));  // the batch's scratch goes back to the arena at the end of this scope
     }

@@ -4,8 +4,11 @@
 // Parallel.process_stream_chunkwise (lib/Twister.ml:90-196, lib/Matrix.ml:212-266, 712-766).  An OCaml host cannot call
 // torch.distributed; it can call this.
 //
-// One host thread per device slot (kpop_init_devices), started per call: each chooses its slot (thread-local, like
-// hipSetDevice) and drives that device's streams.  Every sequence is independent through count and twist, so
+// One host thread per device slot (kpop_init_devices), PERSISTENT: started at the first call that needs them, each chooses
+// its slot once (thread-local, like hipSetDevice) and then takes job after job off a shared ticket until kpop_shutdown or
+// the next kpop_init_devices.  (Round 3 started and joined a thread per slot per call and met at two condition-variable
+// barriers per resident step: a visible share of a 2 ms step at eight GPUs.)  Every sequence is independent through count
+// and twist, so
 //
 //   kpop_sharded_run              reads cut into contiguous shards (kpop_shard_bounds), one streaming pipeline
 //                                 (pipeline.hip) per device, results written straight to the caller's rows: distances
@@ -22,7 +25,9 @@
 // Two slots may sit on the same physical GPU (that is how this file is tested on a one-GPU box): a twister replica is
 // then an alias and a "peer" copy is a device-local one; the order of operations is the same.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <functional>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -36,21 +41,21 @@ namespace {
 
 using namespace kpop;
 
-struct Barrier {  // C++17: no std::barrier
-  std::mutex mu;
-  std::condition_variable cv;
-  int n, waiting = 0;
-  uint64_t phase = 0;
-  explicit Barrier(int n_) : n(n_) {}
+// a rendezvous of the slot threads inside a job: they are all running (the job was handed to every one of them), the
+// wait is short, so it spins on an atomic (and yields now and then) instead of sleeping on a condition variable
+struct SpinBarrier {
+  std::atomic<int> waiting{0};
+  std::atomic<uint64_t> phase{0};
+  int n;
+  explicit SpinBarrier(int n_) : n(n_) {}
   void wait() {
-    std::unique_lock<std::mutex> lk(mu);
-    const uint64_t ph = phase;
-    if (++waiting == n) {
-      waiting = 0;
-      ++phase;
-      cv.notify_all();
+    const uint64_t ph = phase.load(std::memory_order_acquire);
+    if (waiting.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+      waiting.store(0, std::memory_order_relaxed);
+      phase.store(ph + 1, std::memory_order_release);
     } else {
-      cv.wait(lk, [&] { return phase != ph; });
+      for (uint32_t spins = 0; phase.load(std::memory_order_acquire) == ph; ++spins)
+        if ((spins & 1023u) == 1023u) std::this_thread::yield();
     }
   }
 };
@@ -89,32 +94,129 @@ struct SlotState {
   double *d_classes = nullptr, *d_metric = nullptr;
   hipStream_t s_compute = nullptr;
   std::vector<hipStream_t> s_comm;  // one per destination slot
-  std::vector<hipEvent_t> chunk_done;
+  std::vector<hipEvent_t> chunk_done, chunk_t0, chunk_t1;  // per chunk of a resident step: twisted (for the pushes); around its kernels (timing)
+  std::vector<float> chunk_ms;
+  int chunks_timed = 0;
   Block full, dmat, work, stats, nn, idx, ndist, z;
   double ms_compute = 0.0, ms_exposed_comm = 0.0;
 };
 
-// run fn(i) on one thread per slot, each on its device slot; the first failure (status + message) is the caller's
-template <class F>
-static int on_every_slot(int n, F fn) {
-  std::vector<int> rc(n, 0);
-  std::vector<std::string> msg(n);
+// The slot threads.  run(n, fn): fn(i) on slot i's thread for every i < n, at the same time; returns when all have returned;
+// the first failure (status + message) is the caller's.  A thread that could not choose its slot makes every job fail up
+// front -- no fn is entered anywhere, so nobody waits at a barrier for a partner that never came.
+class SlotWorkers {
+  std::mutex mu_call;  // one job at a time
+  std::mutex mu;
+  std::condition_variable cv_job, cv_done;
   std::vector<std::thread> th;
-  th.reserve(n);
-  for (int i = 0; i < n; ++i)
-    th.emplace_back([&, i] {
-      int r = use_slot(i);
-      if (r == 0) r = fn(i);
+  std::vector<int> rc, slot_rc;
+  std::vector<std::string> msg, slot_msg;
+  std::function<int(int)> job;
+  std::atomic<uint64_t> epoch{0};
+  std::atomic<int> remaining{0};
+  int n = 0;
+  bool stop = false;
+
+  void body(int i) {
+    slot_rc[i] = use_slot(i);
+    if (slot_rc[i] != 0) slot_msg[i] = get_error();
+    uint64_t seen = epoch.load(std::memory_order_acquire);  // (the tickets of the threads before these are not theirs to take)
+    {
+      std::lock_guard<std::mutex> lk(mu);  // (started: run() waits for this before the first job)
+      remaining.fetch_sub(1, std::memory_order_acq_rel);
+      cv_done.notify_all();
+    }
+    for (;;) {
+      // a job usually follows the last within microseconds (a step per call): spin a little, then sleep
+      for (uint32_t spins = 0; spins < 20000 && epoch.load(std::memory_order_acquire) == seen; ++spins) {}
+      if (epoch.load(std::memory_order_acquire) == seen) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_job.wait(lk, [&] { return stop || epoch.load(std::memory_order_acquire) != seen; });
+      }
+      if (stop) return;
+      seen = epoch.load(std::memory_order_acquire);
+      int r = job(i);
       rc[i] = r;
       if (r != 0) msg[i] = get_error();
-    });
-  for (auto &t : th) t.join();
-  for (int i = 0; i < n; ++i)
-    if (rc[i] != 0) {
-      set_error("device slot %d: %s", i, msg[i].c_str());
-      return rc[i];
+      if (remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+        std::lock_guard<std::mutex> lk(mu);
+        cv_done.notify_all();
+      }
     }
-  return 0;
+  }
+  void wait_done() {
+    for (uint32_t spins = 0; spins < 200000 && remaining.load(std::memory_order_acquire) != 0; ++spins) {}
+    if (remaining.load(std::memory_order_acquire) != 0) {
+      std::unique_lock<std::mutex> lk(mu);
+      cv_done.wait(lk, [&] { return remaining.load(std::memory_order_acquire) == 0; });
+    }
+  }
+
+ public:
+  ~SlotWorkers() { shutdown(); }
+  void shutdown() {
+    std::lock_guard<std::mutex> call(mu_call);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+      cv_job.notify_all();
+    }
+    for (auto &t : th)
+      if (t.joinable()) t.join();
+    th.clear();
+    n = 0;
+    stop = false;
+  }
+  template <class F>
+  int run(int want, F fn) {
+    std::lock_guard<std::mutex> call(mu_call);
+    if (want != n) {  // (first use, or another number of slots: kpop_init_devices stops the threads, so they never outlive their slots)
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        stop = true;
+        cv_job.notify_all();
+      }
+      for (auto &t : th)
+        if (t.joinable()) t.join();
+      th.clear();
+      stop = false;
+      n = want;
+      rc.assign(n, 0);
+      slot_rc.assign(n, 0);
+      msg.assign(n, std::string());
+      slot_msg.assign(n, std::string());
+      remaining.store(n, std::memory_order_release);
+      for (int i = 0; i < n; ++i) th.emplace_back([this, i] { body(i); });
+      wait_done();
+    }
+    for (int i = 0; i < n; ++i)
+      if (slot_rc[i] != 0) {
+        set_error("device slot %d: %s", i, slot_msg[i].c_str());
+        return slot_rc[i];
+      }
+    job = fn;
+    std::fill(rc.begin(), rc.end(), 0);
+    remaining.store(n, std::memory_order_release);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      epoch.fetch_add(1, std::memory_order_acq_rel);
+      cv_job.notify_all();
+    }
+    wait_done();
+    job = nullptr;
+    for (int i = 0; i < n; ++i)
+      if (rc[i] != 0) {
+        set_error("device slot %d: %s", i, msg[i].c_str());
+        return rc[i];
+      }
+    return 0;
+  }
+};
+static SlotWorkers g_workers;
+
+template <class F>
+static int on_every_slot(int n, F fn) {
+  return g_workers.run(n, fn);
 }
 
 static void bounds(uint64_t n_items, int rank, int world, uint64_t *lo, uint64_t *hi) {
@@ -124,6 +226,10 @@ static void bounds(uint64_t n_items, int rank, int world, uint64_t *lo, uint64_t
 }
 
 }  // namespace
+
+namespace kpop {
+void stop_slot_workers() { g_workers.shutdown(); }
+}  // namespace kpop
 
 struct kpop_sharded {
   int n = 0;
@@ -212,8 +318,9 @@ extern "C" int kpop_sharded_destroy(kpop_sharded *sh) {
     for (Block *b : all) b->release();
     if (st.d_classes) (void)hipFree(st.d_classes);
     if (st.d_metric) (void)hipFree(st.d_metric);
-    for (hipEvent_t e : st.chunk_done)
-      if (e) (void)hipEventDestroy(e);
+    for (auto *v : {&st.chunk_done, &st.chunk_t0, &st.chunk_t1})
+      for (hipEvent_t e : *v)
+        if (e) (void)hipEventDestroy(e);
     if (st.s_compute) {
       Context &c = ctx();
       std::lock_guard<std::mutex> lk(c.ws_mu);
@@ -351,7 +458,8 @@ extern "C" int kpop_sharded_resident_step(kpop_sharded *sh, const uint8_t *const
   if (chunks < 1) chunks = 1;
   for (int i = 0; i < n; ++i)  // (a slot that could not start its thread's work would leave the others at the barrier)
     if (!ctx_of(i).initialised) KPOP_FAIL(KPOP_ERR_NOT_INIT, "kpop_sharded_resident_step: device slot %d is gone (kpop_shutdown?)", i);
-  Barrier bar(n);
+  SpinBarrier bar(n);
+  std::atomic<int> failed{0};  // a slot whose buffers could not be had: nobody pushes anything anywhere (its `full` may be gone)
   return on_every_slot(n, [&](int i) -> int {
     SlotState &st = sh->s[i];
     int rc = 0;
@@ -369,9 +477,25 @@ extern "C" int kpop_sharded_resident_step(kpop_sharded *sh, const uint8_t *const
         }
         st.chunk_done.push_back(e);
       }
+      while (rc == 0 && (int)st.chunk_t0.size() < chunks) {
+        hipEvent_t e0, e1;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+          set_error("kpop_sharded_resident_step: hipEventCreate failed");
+          rc = KPOP_ERR_HIP;
+          break;
+        }
+        st.chunk_t0.push_back(e0);
+        st.chunk_t1.push_back(e1);
+      }
     } while (0);
-    bar.wait();  // every slot's `full` pointer is final before anybody pushes into it
-    // (a failed slot still takes part in every barrier, or the others would wait for ever)
+    if (rc != 0) failed.store(1, std::memory_order_release);
+    bar.wait();  // every slot's `full` pointer is final before anybody pushes into it -- the step's ONE rendezvous
+    // (a failed slot still takes part in it, or the others would wait for ever; and then nobody goes on)
+    if (rc == 0 && failed.load(std::memory_order_acquire)) {
+      set_error("kpop_sharded_resident_step: another device slot failed to allocate its buffers");
+      rc = KPOP_ERR_HIP;
+    }
+    st.chunks_timed = 0;
     const auto t0 = std::chrono::steady_clock::now();
     if (rc == 0) do {
         const uint32_t ni = n_reads[i];
@@ -380,9 +504,12 @@ extern "C" int kpop_sharded_resident_step(kpop_sharded *sh, const uint8_t *const
         for (int c = 0; c < chunks && rc == 0; ++c) {
           const uint32_t a = std::min<uint64_t>((uint64_t)c * per, ni), b = std::min<uint64_t>((uint64_t)a + per, ni);
           if (b == a) continue;
+          (void)hipEventRecord(st.chunk_t0[c], st.s_compute);
           if ((rc = kpop_dev_count_twist(st.tw, d_bases[i], d_offsets[i] + a, b - a, n_bases[i], max_len, sh->cfg.content,
                                          sh->cfg.normalize_counts, mine + (uint64_t)a * D, st.s_compute)))
             break;
+          (void)hipEventRecord(st.chunk_t1[c], st.s_compute);
+          st.chunks_timed = c + 1;
           if (!gather || n == 1) continue;
           if (hipEventRecord(st.chunk_done[c], st.s_compute) != hipSuccess) {
             set_error("hipEventRecord failed");
@@ -418,7 +545,11 @@ extern "C" int kpop_sharded_resident_step(kpop_sharded *sh, const uint8_t *const
       set_error("kpop_sharded_resident_step: %s", hipGetErrorString(e));
       rc = KPOP_ERR_HIP;
     }
-    bar.wait();  // every push has landed everywhere
+    st.chunk_ms.assign(st.chunks_timed, 0.f);
+    for (int c = 0; c < st.chunks_timed && rc == 0; ++c)
+      if (hipEventElapsedTime(&st.chunk_ms[c], st.chunk_t0[c], st.chunk_t1[c]) != hipSuccess) st.chunk_ms[c] = 0.f;  // (a chunk without reads)
+    // (no second rendezvous: this slot's pushes have landed -- its comm streams are drained -- and the call returns when every
+    // slot's thread has come this far, so every copy of the full matrix is complete when the caller sees it)
     return rc;
   });
 }
@@ -432,6 +563,17 @@ extern "C" int kpop_sharded_resident_buffers(const kpop_sharded *sh, int slot, d
   if (first_row) *first_row = sh->lo[slot];
   if (n_rows) *n_rows = sh->hi[slot] - sh->lo[slot];
   if (d_distances) *d_distances = sh->s[slot].dmat.as<double>();
+  return KPOP_OK;
+}
+
+// the fused count->twist launches of the last resident step on `slot`, chunk by chunk (HIP events on the slot's compute stream):
+// what a roofline of the in-process path is computed from.  *n_chunks = entries written (at most max_chunks).
+extern "C" int kpop_sharded_chunk_timings(const kpop_sharded *sh, int slot, double *ms, int max_chunks, int *n_chunks) {
+  if (!sh || slot < 0 || slot >= sh->n || !n_chunks || (max_chunks > 0 && !ms)) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_sharded_chunk_timings: bad argument");
+  const SlotState &st = sh->s[slot];
+  const int m = std::min<int>(max_chunks, (int)st.chunk_ms.size());
+  for (int c = 0; c < m; ++c) ms[c] = st.chunk_ms[c];
+  *n_chunks = m;
   return KPOP_OK;
 }
 

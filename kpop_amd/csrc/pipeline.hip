@@ -334,6 +334,9 @@ extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, con
     KPOP_HIP(hipEventRecord(pl->tl_events[at], st));
     return 0;
   };
+  // (the chunks, as a function of its own: a failure half way -- an allocation, a launch -- must not leave the earlier chunks
+  // copying into the caller's buffers behind a call that has reported an error and issued no ticket: see below)
+  auto run_chunks = [&]() -> int {
   for (uint32_t r0 = 0; r0 < n_reads;) {
     const uint32_t r1 = chunk_end(offsets, r0, n_reads, (r0 == 0 && first_chunk) ? first_chunk : chunk_reads, pl->cfg.chunk_bases);
     const uint32_t n = r1 - r0;
@@ -405,6 +408,18 @@ extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, con
     s.in_use = true;
     ++n_chunks;
     r0 = r1;
+  }
+  return KPOP_OK;
+  };
+  const int rc = run_chunks();
+  if (rc != KPOP_OK) {
+    // nothing of this batch is in flight when the error goes back: the caller may free or reuse its buffers
+    const std::string msg = get_error();
+    (void)hipStreamSynchronize(pl->s_h2d);
+    (void)hipStreamSynchronize(pl->s_compute);
+    (void)hipStreamSynchronize(pl->s_d2h);
+    set_error("%s", msg.c_str());
+    return rc;
   }
   pl->last_chunks = n_chunks;
   pl->tl_chunks = timeline ? std::min<uint32_t>(n_chunks, 256) : 0;

@@ -117,6 +117,7 @@ static void release_slot(Context &c) {
   }
   c.arena.release();
   c.initialised = false;
+  ++c.generation;
 }
 
 extern "C" int kpop_init_devices(const int *devices, int n) {
@@ -130,6 +131,7 @@ extern "C" int kpop_init_devices(const int *devices, int n) {
   for (int i = 0; i < n; ++i)
     if (devices[i] < 0 || devices[i] >= n_dev)
       KPOP_FAIL(KPOP_ERR_INVALID, "kpop_init: device %d out of range 0..%d", devices[i], n_dev - 1);
+  stop_slot_workers();
   for (int i = n; i < g_n_slots; ++i) release_slot(g_ctx[i]);
   for (int i = 0; i < n; ++i) {
     Context &c = g_ctx[i];
@@ -167,6 +169,7 @@ extern "C" int kpop_use_device(int slot) { return use_slot(slot); }
 extern "C" int kpop_device_slots(void) { return g_n_slots; }
 
 extern "C" int kpop_shutdown(void) {
+  stop_slot_workers();
   for (int i = 0; i < g_n_slots; ++i) release_slot(g_ctx[i]);
   g_n_slots = 0;
   tl_slot = 0;

@@ -160,6 +160,19 @@ def test_twist_few_very_long_spectra_in_segments(kpop, oracle, d, normalize):
     assert np.max(np.abs(got - want)) <= 1e-12 * scale and np.max(np.abs(plain - want)) <= 1e-12 * scale
     # both kernels form a spectrum's sums per stretch of 8,192 lines and add the stretches in order: the same bits
     assert np.array_equal(got, plain)
+    # kpop_dev_twist with the longest spectrum UNDERSTATED (20,000 where two spectra are longer): those two come back as rows of
+    # NaNs from the segmented launch too, never as silently shortened sums; the others are as before
+    import torch
+    dev = torch.device("cuda", 0)
+    dh, dv, do = (torch.from_numpy(a).to(dev) for a in (h.view(np.int64), v, o.view(np.int64)))
+    out = torch.zeros(len(lens), d, dtype=torch.float64, device=dev)
+    api.dev_twist(tw, dh.data_ptr(), dv.data_ptr(), do.data_ptr(), len(lens), 20000, out.data_ptr(), normalize=normalize)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    long_ = [i for i, n in enumerate(lens) if min(n, len(allk)) > 3 * 8192]
+    assert len(long_) == 3 and all(np.isnan(out[i]).all() for i in long_)
+    rest = [i for i in range(len(lens)) if i not in long_]
+    assert np.array_equal(out[rest], got[rest])
 
 
 def test_headline_shape_sample_vs_oracle(kpop, oracle):
