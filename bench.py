@@ -69,6 +69,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the PCIe-inclusive, file-to-file and config-4 legs of the 1-GPU line")
+    ap.add_argument("--no-children", action="store_true",
+                    help="skip the legs that start child processes (the rocprofv3 --pmc traffic passes, the file-to-file CLIs): for running the whole line under a profiler")
     ap.add_argument("--f2f-reads", type=int, default=1000000, help="reads of the file-to-file leg")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even at world size 1 (exercises the N>1 code path)")
     ap.add_argument("--spawn", action="store_true", help="start the ranks as a child launcher even for --gpus 1 (tests the relay)")
@@ -946,7 +948,7 @@ def main():
             # tools/probes/pcie_leg_repeat.py, the leg alone: 50.4-50.5, eight times out of eight)
             line["pcie_inclusive"] = pcie_inclusive(R, n_local)
             c4 = R.run_config4(1000000, max(3, min(args.steps, 10)), 2)
-            live = measure_traffic(R, n_local)
+            live = None if args.no_children else measure_traffic(R, n_local)
             if live:
                 line["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
                 line["roofline"]["traffic_source"] = live["source"]
@@ -958,7 +960,7 @@ def main():
                 "all_vs_all": c4["all_vs_all"],
                 "note": "BASELINE config 4 (1M x %d bp in total) on one GPU: the N = 1 point of the strong-scaling curve "
                         "`bench.py --gpus N` reports for N > 1" % L}
-            line["file_to_file"] = file_to_file(R)
+            line["file_to_file"] = {"value": None, "note": "--no-children"} if args.no_children else file_to_file(R)
             line.update(extra_configs(R))
         R.finish(line)
         return

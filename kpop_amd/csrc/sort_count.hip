@@ -17,6 +17,8 @@
 #include "scan.h"
 
 #include "lookback.h"
+#include <string.h>
+
 #include "sort_count.h"
 
 namespace kpop {
@@ -472,21 +474,30 @@ __device__ __forceinline__ uint32_t part_item_keys(const uint8_t *__restrict__ b
 // field of that stream, its reverse complement a bit reversal, its validity k zero bits -- ~16 vector instructions a window
 // with every lane busy, against ~29 per window on the 18 lanes a 150-base read keeps busy when each lane rolls eight windows.
 // Lane l gets windows l, 64 + l, ... of the item.  s_w: kPartStageWords words of the wavefront's own.
+// A DNA item is at most 496 windows -- 496 + k - 1 <= 508 bases: eight bytes a lane, ONE load instruction each -- and carries
+// its own address and size, so that its bytes are one dependent load behind the item list: a wavefront has FOUR items' bytes
+// in flight before it packs the first (an item at a time, the list -> offsets -> bases chain was ~4 us of latency per item
+// and all the kernels' time: 0.28 ms for the sizes of 5,000 genomes).
+struct HistItemD {
+  uint64_t off;  // the item's first base in `bases`
+  uint32_t nw;   // its windows
+  uint32_t pad;
+};
+constexpr uint32_t kPartItemD = 496;
 constexpr uint32_t kPartCodeWords = 36, kPartInvWords = 20, kPartStageWords = kPartCodeWords + kPartInvWords;
-__device__ __forceinline__ uint32_t part_item_keys_dna(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, HistItem it, int k, int content,
-                                                       int lane, uint32_t (&keys)[8], uint32_t *s_w) {
-  const uint64_t off = offsets[it.r], len = offsets[it.r + 1] - off;
-  const uint64_t n_win = len >= (uint64_t)k ? len - k + 1 : 0, s_beg = (uint64_t)it.seg * kPartItem;
-  const uint32_t nw = s_beg < n_win ? (uint32_t)min<uint64_t>(kPartItem, n_win - s_beg) : 0u;  // windows of the item
-  const uint32_t nb = nw ? nw + (uint32_t)k - 1 : 0u;                                           // bases of the item
-  const uint8_t *seq = bases + off + s_beg;
+__device__ __forceinline__ void part_issue(const uint8_t *__restrict__ bases, const HistItemD &it, int k, int lane, uint32_t (&raw)[8]) {
+  const uint32_t nb = it.nw ? it.nw + (uint32_t)k - 1 : 0u, b0 = (uint32_t)lane * 8u;
+  const uint8_t *seq = bases + it.off + b0;
+#pragma unroll
+  for (uint32_t i = 0; i < 8; ++i) raw[i] = b0 + i < nb ? (uint32_t)seq[i] : 0u;
+}
+__device__ __forceinline__ uint32_t part_finish(const uint32_t (&raw)[8], uint32_t nw, int k, int content, int lane, uint32_t (&keys)[8], uint32_t *s_w) {
   uint8_t *s_code = reinterpret_cast<uint8_t *>(s_w);
   uint8_t *s_inv = reinterpret_cast<uint8_t *>(s_w + kPartCodeWords);
   __builtin_amdgcn_wave_barrier();
-  for (uint32_t b0 = (uint32_t)lane * 8u; b0 < kPartCodeWords * 16u; b0 += 512u) {  // (every byte of both streams is written: zeros and "invalid" past the end)
-    uint32_t raw[8];
-#pragma unroll
-    for (uint32_t i = 0; i < 8; ++i) raw[i] = b0 + i < nb ? (uint32_t)seq[b0 + i] : 0u;
+  {
+    // (bytes past the item's bases are zeros here: "invalid"; what lies past the 512 staged bases in LDS is stale, and no window
+    // of this item reads it -- a window's 64-bit fields reach up to seven bytes further, and those bits are shifted or masked out)
     uint32_t v = 0, inv = 0;
 #pragma unroll
     for (uint32_t i = 0; i < 8; ++i) {
@@ -494,15 +505,18 @@ __device__ __forceinline__ uint32_t part_item_keys_dna(const uint8_t *__restrict
       v |= (c & 3u) << (14u - 2u * i);
       inv |= (c > 3u ? 1u : 0u) << i;
     }
-    s_code[b0 / 4] = (uint8_t)(v >> 8);
-    s_code[b0 / 4 + 1] = (uint8_t)v;
-    if (b0 / 8 < kPartInvWords * 4u) s_inv[b0 / 8] = (uint8_t)inv;
+    s_code[2 * lane] = (uint8_t)(v >> 8);
+    s_code[2 * lane + 1] = (uint8_t)v;
+    s_inv[lane] = (uint8_t)inv;
   }
   __builtin_amdgcn_wave_barrier();
   const uint32_t mask = (uint32_t)bits_mask(2 * k), kmask = (1u << k) - 1u;
   uint32_t ok = 0;
 #pragma unroll
+  for (uint32_t t = 0; t < 8; ++t) keys[t] = 0;
+#pragma unroll
   for (uint32_t t = 0; t < 8; ++t) {
+    if (t * 64u >= nw) break;  // (uniform: a 150-base read has three rounds of windows, not eight)
     const uint32_t w = t * 64u + (uint32_t)lane;
     const uint32_t B = w >> 2;  // byte of the code stream the window starts in
     const uint64_t x = ((uint64_t)__builtin_bswap32(s_w[B >> 2]) << 32) | __builtin_bswap32(s_w[(B >> 2) + 1]);
@@ -527,13 +541,32 @@ __global__ __launch_bounds__(1024) void hist_part_sizes_kernel(const uint8_t *__
   for (uint32_t b = threadIdx.x; b < n_buckets; b += 1024) s_cnt[b] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (uint64_t i = (uint64_t)blockIdx.x * 16 + wv; i < n_items; i += (uint64_t)gridDim.x * 16) {
-    uint32_t keys[8];
-    const uint32_t ok = SB == 2 ? part_item_keys_dna(bases, offsets, items[i], k, content, lane, keys, s_stage[wv])
-                                : part_item_keys<SB>(bases, offsets, items[i], k, content, lane, keys);
+  if (SB == 2) {
+    const HistItemD *itd = reinterpret_cast<const HistItemD *>(items);
+    for (uint64_t i = ((uint64_t)blockIdx.x * 16 + wv) * 4; i < n_items; i += (uint64_t)gridDim.x * 16 * 4) {
+      HistItemD h[4];
+      uint32_t raw[4][8];
 #pragma unroll
-    for (uint32_t j = 0; j < 8; ++j)
-      if ((ok >> j) & 1u) atomicAdd(&s_cnt[keys[j] >> LB], 1u);
+      for (int q = 0; q < 4; ++q) h[q] = i + q < n_items ? itd[i + q] : HistItemD{0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part_issue(bases, h[q], k, lane, raw[q]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint32_t keys[8];
+        const uint32_t ok = part_finish(raw[q], h[q].nw, k, content, lane, keys, s_stage[wv]);
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j)
+          if ((ok >> j) & 1u) atomicAdd(&s_cnt[keys[j] >> LB], 1u);
+      }
+    }
+  } else {
+    for (uint64_t i = (uint64_t)blockIdx.x * 16 + wv; i < n_items; i += (uint64_t)gridDim.x * 16) {
+      uint32_t keys[8];
+      const uint32_t ok = part_item_keys<SB>(bases, offsets, items[i], k, content, lane, keys);
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j)
+        if ((ok >> j) & 1u) atomicAdd(&s_cnt[keys[j] >> LB], 1u);
+    }
   }
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < n_buckets; b += 1024) {
@@ -573,53 +606,101 @@ __global__ __launch_bounds__(1024) void hist_part_offsets_kernel(const uint32_t 
 template <int SB>
 __global__ __launch_bounds__(1024) void hist_partition_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int k, int content,
                                                               const HistItem *__restrict__ items, uint64_t n_items, int LB, uint32_t n_buckets,
-                                                              unsigned long long *__restrict__ cursor, uint16_t *__restrict__ entries) {
+                                                              unsigned long long *__restrict__ cursor, uint16_t *__restrict__ entries, uint32_t quota) {
+  // quota: keys a wavefront collects per round -- 2,048 (one block a CU), or 1,024 where the buckets are few enough (<= 512:
+  // up to 24 hash bits) for TWO blocks a CU: the hashing is what the kernel spends its time on, and it wants the wavefronts
   extern __shared__ uint32_t s_part[];
-  uint32_t *s_keys = s_part;                           // [16][kPartQuota]
-  uint32_t *s_cnt = s_part + 16 * kPartQuota;          // [n_buckets]
+  uint32_t *s_keys = s_part;                           // [16][quota]
+  uint32_t *s_cnt = s_part + 16 * quota;               // [n_buckets]
   unsigned long long *s_base = reinterpret_cast<unsigned long long *>(s_cnt + n_buckets + (n_buckets & 1u));  // [n_buckets]
   __shared__ unsigned long long s_next;
   __shared__ uint32_t s_used[16];
   __shared__ uint32_t s_stage[16][kPartStageWords];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  // a block owns a contiguous run of items; its wavefronts take them one at a time
+  // a block owns a contiguous run of items, each of its wavefronts a sixteenth of that; a wavefront fills its quota of a round with
+  // whole items -- it knows an item's windows before it hashes them, so a round of 150-base reads is 14 reads a wavefront (1,946
+  // keys), not the 12 that "room for a full item" allowed: two rounds a block on 100k reads instead of three
   const uint64_t i0 = n_items * blockIdx.x / gridDim.x, i1 = n_items * (blockIdx.x + 1) / gridDim.x;
-  if (threadIdx.x == 0) s_next = i0;
+  const uint64_t per_wave = (i1 - i0 + 15) / 16;
+  uint64_t i = min(i1, i0 + (uint64_t)wv * per_wave);
+  const uint64_t i_end = min(i1, i + per_wave);
+  if (threadIdx.x == 0) s_next = 0;
   const uint32_t low = (1u << LB) - 1u;
   for (;;) {
     for (uint32_t b = threadIdx.x; b < n_buckets; b += 1024) s_cnt[b] = 0;
+    if (threadIdx.x == 0) s_next = 0;  // (wavefronts that still have items after this round)
     __syncthreads();
     uint32_t used = 0;
-    while (used + kPartItem <= kPartQuota) {
-      unsigned long long i = 0;
-      if (lane == 0) i = atomicAdd(&s_next, 1ull);
-      i = (unsigned long long)__shfl((long long)i, 0, 64);
-      if (i >= i1) break;
-      uint32_t keys[8];
-      const uint32_t ok = SB == 2 ? part_item_keys_dna(bases, offsets, items[i], k, content, lane, keys, s_stage[wv])
-                                  : part_item_keys<SB>(bases, offsets, items[i], k, content, lane, keys);
+    auto append = [&](uint32_t ok, const uint32_t (&keys)[8]) {
 #pragma unroll
       for (uint32_t j = 0; j < 8; ++j) {
         const bool v = (ok >> j) & 1u;
         const uint64_t m = __ballot(v);
         if (v) {
-          s_keys[wv * kPartQuota + used + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = keys[j];
+          s_keys[wv * quota + used + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = keys[j];
           atomicAdd(&s_cnt[keys[j] >> LB], 1u);
         }
         used += (uint32_t)__popcll(m);
       }
+    };
+    if (SB == 2) {
+      const HistItemD *itd = reinterpret_cast<const HistItemD *>(items);
+      bool full = false;
+      while (i < i_end && !full) {
+        HistItemD h[4];
+        uint32_t raw[4][8];
+        uint32_t nfit = 0, room = quota - used;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // (uniform) the items of this batch that still fit the round, in order
+          h[q] = i + q < i_end ? itd[i + q] : HistItemD{0, 0xFFFFFFFFu, 0};
+          if (nfit == (uint32_t)q && h[q].nw <= room) {
+            room -= h[q].nw;
+            ++nfit;
+          }
+        }
+        if (nfit < 4 && i + nfit < i_end) full = true;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if ((uint32_t)q < nfit) part_issue(bases, h[q], k, lane, raw[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if ((uint32_t)q < nfit) {
+            uint32_t keys[8];
+            const uint32_t ok = part_finish(raw[q], h[q].nw, k, content, lane, keys, s_stage[wv]);
+            append(ok, keys);
+          }
+        i += nfit;
+      }
+    } else {
+      while (i < i_end) {
+        {
+          const HistItem it = items[i];
+          const uint64_t len = offsets[it.r + 1] - offsets[it.r], n_win = len >= (uint64_t)k ? len - k + 1 : 0;
+          const uint64_t s_beg = (uint64_t)it.seg * kPartItem;
+          const uint32_t nw = s_beg < n_win ? (uint32_t)min<uint64_t>(kPartItem, n_win - s_beg) : 0u;
+          if (used + nw > quota) break;  // (uniform; an item never exceeds the quota by itself)
+        }
+        uint32_t keys[8];
+        const uint32_t ok = part_item_keys<SB>(bases, offsets, items[i], k, content, lane, keys);
+        ++i;
+        append(ok, keys);
+      }
     }
-    if (lane == 0) s_used[wv] = used;
+    if (lane == 0) {
+      s_used[wv] = used;
+      if (i < i_end) atomicAdd(&s_next, 1ull);
+    }
     __syncthreads();
-    const bool last = s_next >= i1;  // (uniform: every wavefront has stopped taking items before the barrier)
+    const bool last = s_next == 0;  // (uniform: no wavefront has items left)
     for (uint32_t b = threadIdx.x; b < n_buckets; b += 1024) {
       const uint32_t c = s_cnt[b];
       if (c) s_base[b] = atomicAdd(&cursor[b], (unsigned long long)c);
       s_cnt[b] = 0;
     }
     __syncthreads();
-    for (uint32_t i = lane; i < used; i += 64) {
-      const uint32_t key = s_keys[wv * kPartQuota + i], b = key >> LB;
+#pragma unroll 4
+    for (uint32_t q = lane; q < used; q += 64) {
+      const uint32_t key = s_keys[wv * quota + q], b = key >> LB;
       const uint32_t rank = atomicAdd(&s_cnt[b], 1u);
       entries[s_base[b] + rank] = (uint16_t)(key & low);
     }
@@ -768,24 +849,40 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
       // nothing repeats (a read set, unrelated genomes): partition the hashes by their top bits, count every bucket in LDS
       const int LB = part_bucket_bits(hb);
       const uint32_t n_buckets = 1u << (hb - LB);
-      std::vector<HistItem> items;
-      items.reserve(total_win / kPartItem + n_reads);
-      for (uint32_t r = 0; r < n_reads; ++r) {
-        const uint64_t len = rel[r + 1] - rel[r], w = len >= (uint64_t)k ? len - k + 1 : 0;
-        for (uint64_t sgm = 0; sgm * kPartItem < w; ++sgm) items.push_back(HistItem{r, (uint32_t)sgm});
+      static_assert(sizeof(HistItemD) == 16 && sizeof(HistItem) == 8, "two items of (read, segment) in the room of one with its address");
+      std::vector<HistItem> items;  // (DNA: pairs of entries hold one HistItemD)
+      if (protein) {
+        items.reserve(total_win / kPartItem + n_reads);
+        for (uint32_t r = 0; r < n_reads; ++r) {
+          const uint64_t len = rel[r + 1] - rel[r], w = len >= (uint64_t)k ? len - k + 1 : 0;
+          for (uint64_t sgm = 0; sgm * kPartItem < w; ++sgm) items.push_back(HistItem{r, (uint32_t)sgm});
+        }
+      } else {
+        items.reserve(2 * (total_win / kPartItemD + n_reads));
+        for (uint32_t r = 0; r < n_reads; ++r) {
+          const uint64_t len = rel[r + 1] - rel[r], w = len >= (uint64_t)k ? len - k + 1 : 0;
+          for (uint64_t w0 = 0; w0 < w; w0 += kPartItemD) {
+            const HistItemD it{rel[r] + w0, (uint32_t)std::min<uint64_t>(kPartItemD, w - w0), 0u};
+            HistItem two[2];
+            memcpy(two, &it, sizeof it);
+            items.push_back(two[0]);
+            items.push_back(two[1]);
+          }
+        }
       }
-      const uint64_t n_items = items.size();
+      const uint64_t n_items = protein ? items.size() : items.size() / 2;
       DevBuf d_items, d_size, d_poff, d_cursor, d_entries;
-      KPOP_TRY(d_items.alloc(n_items * sizeof(HistItem)));
+      KPOP_TRY(d_items.alloc(items.size() * sizeof(HistItem) + 16));
       KPOP_TRY(d_size.alloc((uint64_t)n_buckets * 4));
       KPOP_TRY(d_poff.alloc((uint64_t)(n_buckets + 1) * 8));
       KPOP_TRY(d_cursor.alloc((uint64_t)n_buckets * 8));
       KPOP_TRY(d_entries.alloc(total_win * 2 + 16));
-      KPOP_HIP(hipMemcpyAsync(d_items.p, items.data(), n_items * sizeof(HistItem), hipMemcpyHostToDevice, st));
+      KPOP_HIP(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(HistItem), hipMemcpyHostToDevice, st));
       KPOP_HIP(hipMemsetAsync(d_size.p, 0, (uint64_t)n_buckets * 4, st));
       const uint32_t blocks1 = (uint32_t)std::min<uint64_t>(div_up(n_items, 16), (uint64_t)ctx().n_cus * 2);
-      const uint32_t blocks2 = (uint32_t)std::min<uint64_t>(div_up(n_items, 64), (uint64_t)ctx().n_cus);
-      const size_t lds_part = (size_t)16 * kPartQuota * 4 + (size_t)(n_buckets + (n_buckets & 1u)) * 4 + (size_t)n_buckets * 8;
+      const uint32_t quota = n_buckets <= 512 ? kPartQuota / 2 : kPartQuota;
+      const uint32_t blocks2 = (uint32_t)std::min<uint64_t>(div_up(n_items, 64), (uint64_t)ctx().n_cus * (quota < kPartQuota ? 2 : 1));
+      const size_t lds_part = (size_t)16 * quota * 4 + (size_t)(n_buckets + (n_buckets & 1u)) * 4 + (size_t)n_buckets * 8;
       static PerSlotOnce once;
       if (!once()) {
         KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_partition_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * kPartQuota * 4 + 2048 * 12)));
@@ -799,7 +896,7 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
                                                                                         d_items.as<HistItem>(), n_items, LB, n_buckets, d_size.as<uint32_t>()); \
     hist_part_offsets_kernel<<<dim3(1), dim3(1024), 0, st>>>(d_size.as<uint32_t>(), n_buckets, d_poff.as<uint64_t>(), d_cursor.as<unsigned long long>()); \
     hist_partition_kernel<SB><<<dim3(blocks2), dim3(1024), lds_part, st>>>(S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), k, content, d_items.as<HistItem>(), \
-                                                                          n_items, LB, n_buckets, d_cursor.as<unsigned long long>(), d_entries.as<uint16_t>()); \
+                                                                          n_items, LB, n_buckets, d_cursor.as<unsigned long long>(), d_entries.as<uint16_t>(), quota); \
   } while (0)
       if (protein) KPOP_PART(5); else KPOP_PART(2);
 #undef KPOP_PART

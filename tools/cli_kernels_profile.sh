@@ -5,7 +5,7 @@
 set -u
 OUT="$(cd "$(dirname "$1")" && pwd)/$(basename "$1")"; shift
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
-SECTIONS=${*:-count_L twist_reads twist_genomes summary_65 summary_1M merged_hist merged_hist_mutants merged_hist_k7 merged_sort genomes_L fused_genomes}
+SECTIONS=${*:-count_L twist_reads twist_genomes summary_65 summary_1M merged_hist merged_hist_genomes merged_hist_mutants merged_hist_k7 merged_sort genomes_L fused_genomes fused_genomes_1pct fused_genomes_stream fused_genomes_unrelated}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for s in $SECTIONS; do

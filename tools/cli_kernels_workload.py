@@ -18,7 +18,11 @@ cli_kernels_report.py joins that with the profiler's per-kernel averages.
   merged_hist_k7       KPopCount -l, small k        window_hist_lds_kernel (private LDS tables)             5,000 wuhan mutants, k = 7
   merged_sort  KPopCount -l, k > 13 or hist off   window_keys + radix passes    the same inputs, kpop_tune("hist", 0)
   genomes_L    KPopCount -L, genomes        window_keys + radix passes        2,000 x 30 kb genomes, per-sequence spectra
-  fused_genomes KPopTwistDB on a reads stream of assemblies  count_twist_stream_kernel   5,000 wuhan mutants
+  merged_hist_genomes  KPopCount -l, unrelated genomes  hist_partition_kernel (+ sizes, bucket count)   5,000 x 30 kb random genomes
+  fused_genomes KPopTwistDB on a reads stream of assemblies  count_twist_tile_kernel (consensus on the matrix cores)   5,000 wuhan mutants (0.1 %)
+  fused_genomes_1pct   the same at 1 % divergence
+  fused_genomes_stream the same batch with kpop_tune("dense", 0)   count_twist_stream_kernel (rows from L2: latency-bound)
+  fused_genomes_unrelated   5,000 x 30 kb random genomes, default dispatch   count_twist_stream_kernel (the HBM gather)
 """
 import argparse
 import json
@@ -29,8 +33,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SECTIONS = ["count_L", "twist_reads", "twist_genomes", "summary_65", "summary_1M", "merged_hist", "merged_hist_mutants", "merged_hist_k7", "merged_sort", "genomes_L",
-            "fused_genomes"]
+SECTIONS = ["count_L", "twist_reads", "twist_genomes", "summary_65", "summary_1M", "merged_hist", "merged_hist_genomes", "merged_hist_mutants", "merged_hist_k7",
+            "merged_sort", "genomes_L", "fused_genomes", "fused_genomes_1pct", "fused_genomes_stream", "fused_genomes_unrelated"]
 
 
 def mutants(n, rate=0.001, seed=5):
@@ -90,9 +94,13 @@ def main():
                 api.dev_twist(tw, oh.data_ptr(), val.data_ptr(), oo.data_ptr(), n, w, out.data_ptr(), stream=sp)
             torch.cuda.synchronize()
             algo = {"twist_csr_kernel": {"bytes": nnz * 16 + nnz * d * 8 + n * d * 8, "note": "lines (hash, value) + one twister row per line + the twisted row"}}
-    elif sec in ("twist_genomes", "fused_genomes"):
+    elif sec in ("twist_genomes", "fused_genomes", "fused_genomes_1pct", "fused_genomes_stream", "fused_genomes_unrelated"):
         ng = 2000 if sec == "twist_genomes" else 5000
-        mb, mo = mutants(ng)
+        if sec == "fused_genomes_unrelated":
+            mb, mo = O.synth_reads(0xC1A55, ng, 30000)
+            mo = mo.astype(np.int64)
+        else:
+            mb, mo = mutants(ng, rate=0.01 if sec == "fused_genomes_1pct" else 0.001)
         tw = kpop_amd.Twister.synth(0x5EED, k, d)
         if sec == "twist_genomes":
             h, c, o = kpop_amd.count_reads(mb, mo.astype(np.uint64), k)
@@ -103,13 +111,30 @@ def main():
             torch.cuda.synchronize()
             algo["twist_csr_kernel"] = {"bytes": len(h) * 16 + len(h) * d * 8 + ng * d * 8, "note": "lines + one twister row per line + the twisted row"}
         else:
-            db, do = torch.from_numpy(mb).to(dev), torch.from_numpy(mo).to(dev)
+            db, do = torch.from_numpy(np.ascontiguousarray(mb)).to(dev), torch.from_numpy(np.asarray(mo, dtype=np.int64)).to(dev)
             out = torch.zeros(ng, d, dtype=torch.float64, device=dev)
+            if sec == "fused_genomes_stream":
+                api.tune("dense", 0)
             for _ in range(a.reps):
                 api.dev_count_twist(tw, db.data_ptr(), do.data_ptr(), ng, db.numel(), int(np.diff(mo).max()), out.data_ptr(), stream=sp)
             torch.cuda.synchronize()
             lens = np.diff(mo)
-            algo["count_twist_stream_kernel"] = {"bytes": int(lens.sum() + np.maximum(lens - k + 1, 0).sum() * d * 8), "note": "bases + one twister row per window (SURVEY 8d); near-identical genomes share rows, so HBM traffic can be far below this"}
+            gather = int(lens.sum() + np.maximum(lens - k + 1, 0).sum() * d * 8)
+            if sec == "fused_genomes_unrelated":
+                algo["count_twist_stream_kernel"] = {"bytes": gather, "bound": "hbm", "note": "bases + one twister row per window (SURVEY 8d): every row a random 512 B row of a 4.3 GB table"}
+            elif sec == "fused_genomes_stream":
+                algo["count_twist_stream_kernel"] = {"bytes": gather, "bound": "l2", "note": "kpop_tune(\"dense\", 0) on assemblies of one organism: the rows are shared between sequences and come from L2 "
+                                                                                        "(PMC traffic ~0.02 x these bytes); ~100 SIMD-cycles a window of hashing, look-up and a dependent row load: latency, not a bandwidth"}
+            else:
+                # the matrix cores' work, counted by the kernel itself in one more (profiled but separate) launch
+                api.debug_counters(16)
+                api.tune("dbg", 32 << 24)
+                api.dev_count_twist(tw, db.data_ptr(), do.data_ptr(), ng, db.numel(), int(np.diff(mo).max()), out.data_ptr(), stream=sp)
+                cnt = api.debug_counters(16)
+                api.tune("dbg", 0)
+                algo["count_twist_tile_kernel"] = {"flops": 2.0 * 64 * d * cnt[15], "bound": "mfma",
+                                                   "note": "2 x 64 sequences x D x the rows of every chunk's consensus set as multiplied (%d chunks, %d rows); the kernel also finds every "
+                                                           "window's row, builds the set and gathers the residual rows: its matrix phase is a third of it" % (cnt[14], cnt[15])}
     elif sec in ("summary_65", "summary_1M"):
         r1, r2, keep = (65, 100000, 2) if sec == "summary_65" else (1000000, 256, 300)
         g = torch.Generator(device=dev)
@@ -144,7 +169,7 @@ def main():
         wg = int(np.maximum(lens - kk + 1, 0).sum())
         name = "window_hist_combine_kernel" if kk == 12 else "window_hist_lds_kernel"
         algo[name] = {"bytes": int(lens.sum()) + wg * 8, "note": "SURVEY 8d: L B read + one 8-byte atomic read-modify-write per window (5,000 mutants of one 29.9 kb genome, k = %d)" % kk}
-    elif sec in ("merged_hist", "merged_sort", "genomes_L"):
+    elif sec in ("merged_hist", "merged_hist_genomes", "merged_sort", "genomes_L"):
         if sec == "genomes_L":
             gb, go = O.synth_reads(0xC1A55, 2000, 30000)
             for _ in range(3):
@@ -154,19 +179,24 @@ def main():
             algo["radix_scatter_kernel"] = {"bytes": win * 16, "note": "per pass: keys read and written once"}
             algo["radix_count_kernel"] = {"bytes": win * 8, "note": "per pass: keys read once"}
         else:
-            api.tune("hist", 1 if sec == "merged_hist" else 0)
+            api.tune("hist", 0 if sec == "merged_sort" else 1)
             rb, ro = O.synth_reads(0x4B506F70, n, L)
             gb, go = O.synth_reads(0xC1A55, 5000, 30000)
             cap = (4 ** k + 2 ** k) // 2 + 1
-            for _ in range(3):
-                kpop_amd.count_reads(rb, ro, k, per_read=False, capacity=cap)
-            for _ in range(3):
-                kpop_amd.count_reads(gb, go, k, per_read=False, capacity=cap)
+            if sec != "merged_hist_genomes":
+                for _ in range(3):
+                    kpop_amd.count_reads(rb, ro, k, per_read=False, capacity=cap)
+            if sec != "merged_hist":
+                for _ in range(3):
+                    kpop_amd.count_reads(gb, go, k, per_read=False, capacity=cap)
             wr, wg = n * (L - k + 1), 5000 * (30000 - k + 1)
-            if sec == "merged_hist":
-                algo["read_hist_kernel"] = {"bytes": n * L + wr * 8, "note": "SURVEY 8d: L B read + one 8-byte atomic read-modify-write per window"}
-                algo["window_hist_combine_kernel"] = {"bytes": 5000 * 30000 + wg * 8, "note": "the same for 5,000 UNRELATED genomes: nothing repeats inside a chunk, the blocks fall back to direct atomics"}
-                algo["scan_apply_kernel"] = {"bytes": 4 ** k * 4, "note": "compaction: the table read once (plus the spectrum written)"}
+            if sec in ("merged_hist", "merged_hist_genomes"):
+                nbases, w = (n * L, wr) if sec == "merged_hist" else (5000 * 30000, wg)
+                what = "100k x 150 bp random reads" if sec == "merged_hist" else "5,000 unrelated 30 kb genomes"
+                algo["hist_part_sizes_kernel"] = {"bytes": nbases, "bound": "valu", "note": what + ": the bases read, every window hashed, 512 LDS counters a block"}
+                algo["hist_partition_kernel"] = {"bytes": nbases + w * 2, "bound": "valu", "note": "the bases read again, one u16 entry written per window (scattered 2-byte stores, a run per bucket and round)"}
+                algo["hist_bucket_count_kernel"] = {"bytes": w * 2 + 4 ** k * 4, "bound": "hbm", "note": "the entries read once, the whole table written once (no memset, no global atomic)"}
+                algo["scan_apply_kernel"] = {"bytes": 4 ** k * 4, "bound": "hbm", "note": "compaction: the table read once (plus the spectrum written)"}
             else:
                 algo["window_keys_kernel"] = {"bytes": "mixed", "note": "two input sizes in one section: see per-dispatch rows"}
     if a.algo_json:
