@@ -1076,45 +1076,61 @@ __global__ __launch_bounds__(16 * G) void count_twist_tile_kernel(
     }
     __syncthreads();
     stamp(1);  // everybody's rows found
-    // ---- 2. the consensus set: seed 0's rows, a thread each
-    {
-      bool took = false;
-      if (threadIdx.x < kTileS) {
-        const uint32_t col = seedcols[threadIdx.x];
-        if (col != kNoCol) took = insert(col);
+    // ---- 2. the consensus set: a PRIMARY seed's rows whole, a thread each; then the other seeds, admitted in order while the set
+    // stays within kTileSetCap rows, by what each would add at most (its rows not of the primary): a rule that does not depend on
+    // who runs when.  The primary is seed 0 -- unless every other seed finds fewer than half of its rows there (sequence 0 of the
+    // group is the odd one out: a contaminant, another lineage): then the set is started again from seed 1.
+    constexpr uint32_t NS = G / SEEDEVERY;  // seeds (four)
+    constexpr uint32_t EJ = ((NS - 1) * kTileS + THREADS - 1) / THREADS;
+#pragma unroll 1
+    for (uint32_t primary = 0; primary < 2; ++primary) {
+      {
+        bool took = false;
+        if (threadIdx.x < kTileS) {
+          const uint32_t col = seedcols[primary * kTileS + threadIdx.x];
+          if (col != kNoCol) took = insert(col);
+        }
+        const uint32_t n = (uint32_t)__popcll(__ballot(took));
+        if (lane == 0 && n) atomicAdd(&s_new, n);
       }
-      const uint32_t n = (uint32_t)__popcll(__ballot(took));
-      if (lane == 0 && n) atomicAdd(&s_new, n);
-    }
-    __syncthreads();
-    // the other seeds are admitted in order while the set stays within kTileSetCap rows, by what each would add at most (its
-    // rows not of seed 0): a rule that does not depend on who runs when
-    constexpr uint32_t EJ = (3u * kTileS + THREADS - 1) / THREADS;
-    uint32_t ecol[EJ];
+      __syncthreads();
+      uint32_t ecol[EJ];
 #pragma unroll
-    for (uint32_t j = 0; j < EJ; ++j) {
-      const uint32_t e = threadIdx.x + THREADS * j;  // (a wavefront's 64 entries are one seed's: 512 is a multiple of 64)
-      ecol[j] = kNoCol;
-      if (e < 3u * kTileS) {
-        const uint32_t col = seedcols[kTileS + e];
-        if (col != kNoCol && find(col).x == kNoCol) ecol[j] = col;
-        const uint32_t n = (uint32_t)__popcll(__ballot(ecol[j] != kNoCol));
-        if (lane == 0 && n) atomicAdd(&s_add[1u + e / kTileS], n);
+      for (uint32_t j = 0; j < EJ; ++j) {
+        const uint32_t e = threadIdx.x + THREADS * j;  // (a wavefront's 64 entries are one seed's: 512 is a multiple of 64)
+        ecol[j] = kNoCol;
+        if (e < (NS - 1) * kTileS) {
+          const uint32_t pos = 1u + e / kTileS, q = (primary + pos) % NS;  // pos: the seed's place in the order of admission
+          const uint32_t col = seedcols[q * kTileS + e % kTileS];
+          if (col != kNoCol && find(col).x == kNoCol) ecol[j] = col;
+          const uint32_t n = (uint32_t)__popcll(__ballot(ecol[j] != kNoCol)), nv = (uint32_t)__popcll(__ballot(col != kNoCol));
+          if (lane == 0 && nv) atomicAdd(&s_add[pos], n | (nv << 16));  // rows it would add | rows it has
+        }
       }
-    }
-    __syncthreads();
-    {
-      uint32_t total = s_new, in = 1u;  // bit q: seed q is in
+      __syncthreads();
+      uint32_t total = s_new, in = 1u, strangers = 0, others = 0;  // in, bit pos: that seed is admitted
 #pragma unroll
-      for (uint32_t q = 1; q < G / SEEDEVERY; ++q) {
-        total += s_add[q];
-        in |= (((in >> (q - 1)) & 1u) && total <= kTileSetCap) ? (1u << q) : 0u;
+      for (uint32_t pos = 1; pos < NS; ++pos) {
+        const uint32_t add = s_add[pos] & 0xFFFFu, has = s_add[pos] >> 16;
+        total += add;
+        in |= (((in >> (pos - 1)) & 1u) && total <= kTileSetCap) ? (1u << pos) : 0u;
+        others += has ? 1u : 0u;
+        strangers += (has && add * 2u > has) ? 1u : 0u;
+      }
+      if (primary == 0 && others >= 2 && strangers == others) {  // (uniform) start again from seed 1
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < kTileH; q += THREADS) ht[q] = make_uint2(kNoCol, 0u);
+        if (threadIdx.x == 0) s_new = 0;
+        if (threadIdx.x < NS) s_add[threadIdx.x] = 0;
+        __syncthreads();
+        continue;
       }
 #pragma unroll
       for (uint32_t j = 0; j < EJ; ++j) {
         const uint32_t e = threadIdx.x + THREADS * j;
-        if (e < 3u * kTileS && ecol[j] != kNoCol && ((in >> (1u + e / kTileS)) & 1u)) (void)insert(ecol[j]);
+        if (e < (NS - 1) * kTileS && ecol[j] != kNoCol && ((in >> (1u + e / kTileS)) & 1u)) (void)insert(ecol[j]);
       }
+      break;
     }
     __syncthreads();
     stamp(2);  // the set built

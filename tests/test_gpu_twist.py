@@ -600,6 +600,37 @@ def test_few_assemblies_among_many_reads_and_tiny_batches(kpop, oracle):
         assert np.max(np.abs(got - want)) <= 1e-12 * max(np.max(np.abs(want)), 1.0)
 
 
+def test_first_sequence_of_a_group_is_the_odd_one_out(kpop, oracle):
+    """sequence 0 of a group seeds the consensus set; when it is a stranger (a contaminant among 80 assemblies of one organism)
+    the other seeds find fewer than half of their rows there and the set is started again from the next seed: the group still goes
+    through the tile kernel (another order of additions than kpop_tune("dense", 0)), and the stranger's own rows are right"""
+    from kpop_amd import api
+    rng = np.random.RandomState(21)
+    k, d = 12, 64
+    ref = rng.choice(list("ACGT"), size=6000)
+    def mutant():
+        m = ref.copy()
+        hit = rng.rand(len(m)) < 0.003
+        m[hit] = rng.choice(list("ACGT"), size=int(hit.sum()))
+        return "".join(m)
+    seqs = ["".join(rng.choice(list("ACGT"), size=6000))] + [mutant() for _ in range(80)]
+    bases, offs = concat(seqs)
+    h, c, o = oracle.count_reads(bases, offs, k)
+    cols = np.unique(h)
+    T = oracle.synth_twister(4, d, cols)
+    tw = kpop.Twister.load(T, cols, k)
+    want = oracle.twist(T, cols, h, c.astype(np.float64), o)
+    got = tw.count_twist(bases, offs)
+    api.tune("dense", 0)
+    try:
+        plain = tw.count_twist(bases, offs)
+    finally:
+        api.tune("dense", 2)
+    scale = max(np.max(np.abs(want)), 1.0)
+    assert np.max(np.abs(got - want)) <= 1e-12 * scale and np.max(np.abs(plain - want)) <= 1e-12 * scale
+    assert not np.array_equal(got[1:64], plain[1:64])  # (the mutants of group 0 went through the tile kernel)
+
+
 def test_understated_max_len_yields_nan_rows_not_stale_memory(kpop, oracle):
     """kpop_dev_count_twist trusts the caller's max_len to schedule the long-sequence pass; a read longer than it says
     must come back as NaNs, and kpop_dev_distance_rowwise refuses a null workspace for very long rows"""
