@@ -26,14 +26,18 @@ def main():
     kpop.init(0)
     rng = np.random.RandomState(int(os.environ.get("SEED", "1")))
     for it in range(int(os.environ.get("N", "30"))):
-        k = int(rng.randint(8, 15))
-        d = int(rng.choice([8, 33, 64, 100, 130]))
+        k = int(rng.randint(8, 16))
+        d = int(rng.choice([8, 9, 33, 64, 65, 100, 130, 257]))
         ref_len = int(rng.randint(2000, 12000))
         ref = rng.choice(list("ACGT"), size=ref_len)
-        rate = float(rng.choice([0.0005, 0.002, 0.01, 0.05]))
+        rate = float(rng.choice([0.0, 0.0005, 0.002, 0.01, 0.03, 0.05]))
+        content = int(rng.choice([0, 0, 1]))  # DNA-ds mostly, single strand now and then
         seqs = []
-        for i in range(int(rng.randint(70, 220))):
+        for i in range(int(rng.choice([3, 15, 16, 17, 63, 64, 65, 129, int(rng.randint(70, 220))]))):
             m = ref.copy()
+            if rng.rand() < 0.05:
+                a = int(rng.randint(0, ref_len - 700))
+                m[a:a + int(rng.randint(100, 700))] = "N"  # a masked stretch
             hit = rng.rand(len(m)) < rate
             m[hit] = rng.choice(list("ACGTN"), size=int(hit.sum()), p=[.24, .24, .24, .24, .04])
             if rng.rand() < 0.15:
@@ -46,10 +50,10 @@ def main():
             order = rng.permutation(len(seqs))
             seqs = [seqs[i] for i in order]
         bases, offs = concat(seqs)
-        h, c, o = O.count_reads(bases, offs, k)
+        h, c, o = O.count_reads(bases, offs, k, content)
         cols = np.unique(h)
         if k <= 10 and rng.rand() < 0.5:
-            cols = O.enumerate_kmers(k)
+            cols = O.enumerate_kmers(k, content)
         else:
             cols = cols[rng.rand(len(cols)) < 0.9]
         T = O.synth_twister(3 + it, d, cols)
@@ -57,12 +61,17 @@ def main():
         normalize = bool(rng.rand() < 0.5)
         want = O.twist(T, cols, h, c.astype(np.float64), o, normalize=normalize)
         scale = max(np.max(np.abs(want)), 1.0)
-        tag = "it=%d k=%d d=%d n=%d rate=%g normalize=%s" % (it, k, d, len(seqs), rate, normalize)
-        for mode in (0, 2):
+        tag = "it=%d k=%d d=%d n=%d rate=%g content=%d normalize=%s" % (it, k, d, len(seqs), rate, content, normalize)
+        for mode in (0, 2, 2):
             api.tune("dense", mode)
-            got = tw.count_twist(bases, offs, normalize=normalize)
+            api.tune("tileg", 64 if it % 3 else 32)
+            got = tw.count_twist(bases, offs, content=content, normalize=normalize)
             err = np.max(np.abs(got - want))
             assert err <= 1e-12 * scale, (tag, mode, err)
+            if mode == 2:
+                again = tw.count_twist(bases, offs, content=content, normalize=normalize)
+                assert np.array_equal(got, again), (tag, "not the same bits twice")
+        api.tune("tileg", 64)
         api.tune("dense", 0)
         got = tw.twist(h, c.astype(np.float64), o, normalize=normalize)  # the counted spectra through the CSR twist
         assert np.max(np.abs(got - want)) <= 1e-12 * scale, (tag, "csr", np.max(np.abs(got - want)))
@@ -70,6 +79,7 @@ def main():
         assert np.max(np.abs(got - want)) <= 1e-12 * scale, (tag, "csr u32")
         if it % 5 == 0:
             print("ok", tag, flush=True)
+    api.tune("dense", 2)
     print("all agree")
 
 
