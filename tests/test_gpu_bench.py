@@ -27,6 +27,22 @@ def test_self_launch_relays_one_json_line():
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["value"] > 0 and j["roofline"]["bound"] == "hbm"
 
 
+def test_default_line_carries_every_baseline_config():
+    """the one-GPU line the driver records: BASELINE configs 2, 3 and 5 as legs of their own (config 4's N = 1 point was there),
+    each with ms_per_step and a roofline against a bound that can hold it (no fraction above 1); all-vs-all timed warm"""
+    j = _bench(["--no-children", "--cpu-seconds", "2", "--steps", "5", "--warmup", "2"])
+    assert j["n_gpus"] == 1 and 0.0 < j["roofline"]["frac"] <= 1.0 and j["cpu_baseline"]["kind"] == "port"
+    c2, c3, c5 = j["config2_on_this_gpu"], j["config3_on_this_gpu"], j["config5_on_this_gpu"]
+    assert c2["ms_per_step"] > 0 and c2["roofline"]["bound"] == "l2" and 0.0 < c2["roofline"]["frac"] <= 1.0
+    for leg, bound in (("unrelated_genomes", "hbm"), ("one_organism_0.3pct", "mfma")):
+        r = c3[leg]["roofline"]
+        assert c3[leg]["ms_per_step"] > 0 and r["bound"] == bound and 0.0 < r["frac"] <= 1.0, (leg, r)
+    assert c3["one_organism_0.3pct"]["speedup_over_streaming_kernel"] > 1.5  # (the tile route is the default)
+    assert "skipped" in c5 or (c5["rows_finite_and_inside_the_coefficient_range"] and 0.0 < c5["roofline"]["frac"] <= 1.0)
+    ava = j["config4_on_this_gpu"]["all_vs_all"]
+    assert ava["every_query_finds_itself_at_distance_0"] and ava["first_call_seconds"] > 0 and ava["seconds"] > 0
+
+
 def test_config4_two_ranks_on_one_gpu():
     j = _bench(["--gpus", "2", "--reads", "40001", "--steps", "2", "--warmup", "1", "--queries", "64", "--ag-chunks", "3"],
                env={"KPOP_BENCH_SHARE_GPU": "1"})
