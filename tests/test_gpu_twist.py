@@ -422,6 +422,66 @@ def test_config3_50k_genomes_full_size(kpop, oracle):
     assert np.max(np.abs(total - merged)) <= 1e-9 * np.max(np.abs(merged)), np.max(np.abs(total - merged))
 
 
+def test_config3_50k_assemblies_of_one_organism_full_size(kpop, oracle):
+    """BASELINE config 3 as it is labelled -- the matrix-core path -- at its full size: 50,000 assemblies of ONE organism (a 30 kb
+    genome with 0.3 % substitutions per copy, made on the device), k = 12, D = 64, the default dispatch: 46,000 chunks through
+    count_twist_tile_kernel.  A sample of genomes against the oracle (twister restricted to the sample's k-mers); EVERY row through
+    linearity (without normalisation the rows add up to the twist of the batch's merged spectrum, itself counted by the LDS
+    (hash, count) route); and the same bits from a second call"""
+    import torch
+    from kpop_amd import api
+    k, d, n, L = 12, 64, 50000, 30000
+    dev = torch.device("cuda", 0)
+    sp = torch.cuda.current_stream().cuda_stream
+    tw = kpop.Twister.synth(0x7457, k, d)
+    ref = torch.empty(L, dtype=torch.uint8, device=dev)
+    ro = torch.empty(2, dtype=torch.int64, device=dev)
+    api.dev_synth_reads(0xBEEF, 1, L, ref.data_ptr(), ro.data_ptr(), stream=sp)
+    torch.cuda.synchronize()
+    bases = ref.repeat(n)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    step = 1 << 27
+    for lo in range(0, n * L, step):
+        hi = min(n * L, lo + step)
+        hit = torch.rand(hi - lo, device=dev, generator=g) < 0.003
+        sub = acgt[torch.randint(0, 4, (hi - lo,), device=dev, generator=g)]
+        bases[lo:hi] = torch.where(hit, sub, bases[lo:hi])
+    offs = torch.arange(n + 1, dtype=torch.int64, device=dev) * L
+    out = torch.zeros(n, d, dtype=torch.float64, device=dev)
+    api.dev_count_twist(tw, bases.data_ptr(), offs.data_ptr(), n, n * L, L, out.data_ptr(), stream=sp)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    out.zero_()
+    api.dev_count_twist(tw, bases.data_ptr(), offs.data_ptr(), n, n * L, L, out.data_ptr(), stream=sp)
+    torch.cuda.synchronize()
+    assert np.array_equal(got, out.cpu().numpy())
+    assert np.all(np.isfinite(got)) and np.all(np.abs(got) < 1.0)
+    pick = sorted(set([0, 1, 63, 64, 777, 24999, 49998, 49999] + list(range(3, n, 401))))
+    sb = np.concatenate([bases[r * L:(r + 1) * L].cpu().numpy() for r in pick])
+    so = np.arange(len(pick) + 1, dtype=np.uint64) * L
+    h, c, o = oracle.count_reads(sb, so, k)
+    cols = np.unique(h)
+    want = oracle.twist(oracle.synth_twister(0x7457, d, cols), cols, h, c.astype(np.float64), o)
+    np.testing.assert_allclose(got[pick], want, rtol=1e-12, atol=1e-15)
+    api.tune("dense", 0)
+    try:
+        api.dev_count_twist(tw, bases.data_ptr(), offs.data_ptr(), n, n * L, L, out.data_ptr(), stream=sp)
+        torch.cuda.synchronize()
+    finally:
+        api.tune("dense", 2)
+    plain = out.cpu().numpy()
+    assert not np.array_equal(plain, got) and np.max(np.abs(plain - got)) <= 1e-12 * np.max(np.abs(plain))  # (the tile route did run, and agrees)
+    api.dev_count_twist(tw, bases.data_ptr(), offs.data_ptr(), n, n * L, L, out.data_ptr(), normalize=False, stream=sp)
+    torch.cuda.synchronize()
+    total = out.sum(dim=0).cpu().numpy()
+    mh, mc, mo = kpop.count_reads(bases.cpu().numpy(), offs.cpu().numpy().astype(np.uint64), k, per_read=False, capacity=(4 ** k + 2 ** k) // 2 + 1)
+    assert int(mc.astype(np.int64).sum()) == n * (L - k + 1)
+    merged = tw.twist(mh, mc.astype(np.float64), mo, normalize=False)[0]
+    assert np.max(np.abs(total - merged)) <= 1e-9 * np.max(np.abs(merged)), np.max(np.abs(total - merged))
+
+
 @pytest.mark.parametrize("k,d,n", [(5, 64, 300), (7, 9, 129), (8, 100, 40), (9, 256, 70), (6, 200, 65)])
 def test_dense_twist_on_the_matrix_cores_equals_the_sparse_one(kpop, oracle, k, d, n):
     """kpop_dev_twist_dense (spectra as a dense matrix times the twister's rows, f64 MFMA) against kpop_dev_twist: the same
