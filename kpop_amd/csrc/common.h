@@ -133,6 +133,11 @@ struct PerSlotOnce {
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// scopes open on the calling THREAD: a DevBuf takes arena memory only inside one of its own thread's scopes (which hold the slot's
+// host_mu) -- a second host thread on the slot, in an entry point that opens none, gets a hipMalloc of its own instead of memory
+// that somebody else's scope is about to rewind
+int &arena_scopes_of_this_thread();
+
 struct ArenaScope {
   Context &c;
   size_t cur;
@@ -143,12 +148,14 @@ struct ArenaScope {
     cur = a.cur;
     off = a.off;
     ++a.depth;
+    ++arena_scopes_of_this_thread();
   }
   ~ArenaScope() {
     Arena &a = c.arena;
     a.cur = cur;
     a.off = off;
     --a.depth;
+    --arena_scopes_of_this_thread();
     c.host_mu.unlock();
   }
   ArenaScope(const ArenaScope &) = delete;
@@ -171,7 +178,7 @@ struct DevBuf {
     p = nullptr;
     bytes = n;
     if (n == 0) n = 8;
-    if (ctx().arena.depth > 0) {
+    if (arena_scopes_of_this_thread() > 0) {
       owned = false;
       return ctx().arena.take(n, &p);
     }

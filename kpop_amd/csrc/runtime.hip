@@ -23,6 +23,8 @@ const char *get_error() { return g_err; }
 static Context g_ctx[kMaxSlots];
 static int g_n_slots = 0;
 static thread_local int tl_slot = 0;
+static thread_local int tl_arena_scopes = 0;
+int &arena_scopes_of_this_thread() { return tl_arena_scopes; }
 
 Context &ctx() { return g_ctx[tl_slot]; }
 Context &ctx_of(int slot) { return g_ctx[slot]; }
