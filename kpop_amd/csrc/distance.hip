@@ -640,6 +640,373 @@ static int launch_summary_wave_r(const double *a, uint32_t r1, const double *b, 
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// The same summary with JB second-operand rows of a wavefront in hand at once (round 4).  What a row's summary shares with its
+// neighbours' is worth more than it looks:
+//  * the distances: a lane reads its column of the first operand from LDS ONCE per dimension for JB rows (the one-row kernel read
+//    512 B per row and dimension -- with four SIMDs on a CU exactly the LDS's 128 B a clock, so it ran at the LDS's rate, not the
+//    vector pipe's); the rows' own values are broadcast reads of [dimension][JB] words;
+//  * everything that is ONE value per row -- the two sequential chains (mean: lib/Matrix.ml:640-655; squared deviations:
+//    :657-670), the divisions and square roots behind mean and standard deviation, the z-scores -- is done by lane r for row r,
+//    JB rows in the time of one (a wave64 instruction costs the same for one lane as for 64);
+//  * the MAD (:659-678) needs no network: over the sorted distances, |d - median| is two sorted runs (falling before the
+//    median's position, rising from it), and the element of rank r1 / 2 of their union is found by testing all splits at once
+//    (one lane a split, one ballot), reading the runs where they lie in LDS;
+//  * the sort's exchanges run in the vector pipe (wave_sort.h).
+// Same operations in the same order on every value: the same bits as distance_summary_wave_kernel and distance_summary_kernel.
+// Batches go to wavefronts block-cyclically (batch = it * W + wave * blocks + block), so the blocks of a launch differ by at most
+// one batch whatever r2 is.
+// ---------------------------------------------------------------------------
+template <int KIND, bool PRE, int R, bool TAIL, int JB>
+__global__ __launch_bounds__(64 * kSummaryWaves) void distance_summary_batch_kernel(
+    const double *__restrict__ a, uint32_t r1, const double *__restrict__ b, uint32_t r2, uint32_t n_dims,
+    const double *__restrict__ metric, double p, uint32_t req_len, uint32_t max_neighbours, uint32_t stride, uint32_t per_wave,
+    double *__restrict__ out_stats, uint32_t *__restrict__ out_n, uint32_t *__restrict__ out_idx,
+    double *__restrict__ out_dist, double *__restrict__ out_z, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int RS = R + (TAIL ? 1 : 0);  // stripes of 64 sorted positions
+  constexpr int TW = 64 / JB;             // lanes a row has in the passes that take one lane per (row, item)
+  static_assert(!TAIL || kWaveTail <= TW, "a row's tail columns fit its lanes");
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t n_waves = blockDim.x >> 6, n_threads = blockDim.x;
+  // per wave: kd[JB][stride] (sorted distances), chain[JB][cs] (terms of the sequential sums; before that the batch's
+  // second-operand rows, [dimension][JB]), ki[JB][stride] (sorted columns), one word per row of mean, sd, median, MAD, eff_len
+  const uint32_t cs = PRE ? stride : max(stride, n_dims);
+  unsigned char *mine = smem + (size_t)wv * per_wave;
+  double *kd = reinterpret_cast<double *>(mine);
+  double *chain = kd + (size_t)JB * stride;
+  uint32_t *ki = reinterpret_cast<uint32_t *>(chain + (size_t)JB * cs);
+  double *s_mean = reinterpret_cast<double *>(ki + (size_t)JB * stride);
+  double *s_sd = s_mean + JB, *s_med = s_sd + JB, *s_mad = s_med + JB;
+  uint32_t *s_eff = reinterpret_cast<uint32_t *>(s_mad + JB);
+  double *s_bT = chain;
+  double *As = reinterpret_cast<double *>(smem + (size_t)n_waves * per_wave);  // [n_dims][r1] + metric[n_dims]
+  double *s_metric = As + (size_t)n_dims * r1;
+  if (!PRE) {
+    for (uint32_t e = threadIdx.x; e < r1 * n_dims; e += n_threads) {
+      const uint32_t i = e / n_dims, c = e % n_dims;  // coalesced read of row-major m1
+      As[(size_t)c * r1 + i] = a[e];
+    }
+    for (uint32_t c = threadIdx.x; c < n_dims; c += n_threads) s_metric[c] = metric[c];
+  }
+  __syncthreads();
+  const double inf = __longlong_as_double(0x7FF0000000000000ll);
+  const uint32_t n_tail = TAIL ? r1 - 64u * R : 0u;  // 1..kWaveTail
+  const uint32_t n_batches = (r2 + JB - 1) / JB, W = gridDim.x * n_waves;
+  const uint32_t m = r1 / 2;  // the upper median's position (:645-647)
+  for (uint32_t bt = (uint32_t)wv * gridDim.x + blockIdx.x; bt < n_batches; bt += W) {
+    const uint32_t j0 = bt * JB, nv = min((uint32_t)JB, r2 - j0);  // (rows beyond nv repeat the last one and are not written)
+    double dv[JB][R];  // distance of row r to column lane + 64 q (lib/Matrix.ml:744-749)
+    double dt[JB];     // TAIL: lane t < n_tail holds row r's distance to column 64 R + t
+#pragma unroll
+    for (int r = 0; r < JB; ++r) dt[r] = inf;
+    if (PRE) {
+#pragma unroll
+      for (int r = 0; r < JB; ++r) {
+        const double *arow = a + (uint64_t)(j0 + min((uint32_t)r, nv - 1)) * r1;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          const uint32_t i = (uint32_t)lane + 64u * q;
+          dv[r][q] = i < r1 ? arow[i] : inf;
+        }
+        if (TAIL && (uint32_t)lane < n_tail) dt[r] = arow[64u * R + lane];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < JB; ++r) {
+        const double *brow = b + (uint64_t)(j0 + min((uint32_t)r, nv - 1)) * n_dims;
+        for (uint32_t c = lane; c < n_dims; c += 64) s_bT[(size_t)c * JB + r] = brow[c];
+      }
+      __builtin_amdgcn_wave_barrier();
+      double acc[JB][R];
+#pragma unroll
+      for (int r = 0; r < JB; ++r)
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[r][q] = 0.0;
+      uint32_t col[R];
+#pragma unroll
+      for (int q = 0; q < R; ++q) col[q] = min((uint32_t)lane + 64u * q, r1 - 1);  // (lanes beyond r1 work on a copy of the last column)
+      // TAIL: the columns beyond 64 R ride along, lane (r, t) = (lane / TW, lane % TW) working out row r's distance to column 64 R + t
+      const uint32_t tr = (uint32_t)lane / TW, tt = (uint32_t)lane % TW;
+      const double *acol = As + 64u * R + (TAIL ? min(tt, n_tail - 1) : 0u);
+      double tacc = 0.0;
+      // the operands of dimension c + 1 are asked for before dimension c's arithmetic starts: an LDS read is ~100 cycles, a
+      // dimension's arithmetic 64 x JB / 4, and the compiler on its own waits for every read right after issuing it
+      struct Dim {
+        double mc, bv[JB], av[R], ta, tb;
+      };
+      auto fetch = [&](uint32_t c) {
+        Dim d;
+        d.mc = s_metric[c];
+#pragma unroll
+        for (int r = 0; r < JB; ++r) d.bv[r] = s_bT[(size_t)c * JB + r];
+#pragma unroll
+        for (int q = 0; q < R; ++q) d.av[q] = As[(size_t)c * r1 + col[q]];
+        d.ta = TAIL ? acol[(size_t)c * r1] : 0.0;
+        d.tb = TAIL ? s_bT[(size_t)c * JB + tr] : 0.0;
+        return d;
+      };
+      auto work = [&](const Dim &d) {
+#pragma unroll
+        for (int r = 0; r < JB; ++r)
+#pragma unroll
+          for (int q = 0; q < R; ++q) {
+            const double diff = __dsub_rn(d.av[q], d.bv[r]);
+            acc[r][q] = __dadd_rn(acc[r][q], component<KIND>(diff, d.mc, p));
+          }
+        if (TAIL) {
+          const double diff = __dsub_rn(d.ta, d.tb);
+          tacc = __dadd_rn(tacc, component<KIND>(diff, d.mc, p));
+        }
+      };
+      const uint32_t n_d = (dbg & 8) ? 0u : n_dims;
+      if (n_d) {
+        Dim cur = fetch(0);
+        for (uint32_t c = 0; c + 1 < n_d; ++c) {
+          const Dim nxt = fetch(c + 1);
+          work(cur);
+          cur = nxt;
+        }
+        work(cur);
+      }
+#pragma unroll
+      for (int r = 0; r < JB; ++r)
+#pragma unroll
+        for (int q = 0; q < R; ++q) dv[r][q] = ((uint32_t)lane + 64u * q) < r1 ? scale_distance<KIND>(acc[r][q], p) : inf;
+      if (TAIL) {
+        const double td = scale_distance<KIND>(tacc, p);
+#pragma unroll
+        for (int r = 0; r < JB; ++r) {
+          const double mine_t = __shfl(td, r * TW + (lane & (TW - 1)), 64);
+          dt[r] = (uint32_t)lane < n_tail ? mine_t : inf;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // the rows' values are done with: their words become the chains'
+    }
+    // ---- a row at a time: sort, the multimap's terms, eff_len, median, MAD
+#pragma unroll
+    for (int r = 0; r < JB; ++r) {
+      double *kd_r = kd + (size_t)r * stride, *chain_r = chain + (size_t)r * cs;
+      uint32_t *ki_r = ki + (size_t)r * stride;
+      uint64_t key[R];
+      uint32_t val[R];
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        const uint32_t i = (uint32_t)lane + 64u * q;
+        key[q] = i < r1 ? dist_key(dv[r][q]) : ~0ull;  // padding sorts last
+        val[q] = i < r1 ? i : 0xFFFFFFFFu;
+      }
+      if (!(dbg & 1)) wave_bitonic_sort_pairs<R, uint64_t>(key, val, lane);
+      if (!TAIL) {
+#pragma unroll
+        for (int q = 0; q < R; ++q) {  // sorted position of (lane, q) is lane * R + q; padding lies beyond r1
+          const uint32_t pos = (uint32_t)lane * R + q;
+          if (pos < r1) {
+            kd_r[pos] = key_dist(key[q]);
+            ki_r[pos] = val[q];
+          }
+        }
+      } else {
+        // (as in distance_summary_wave_kernel) a tail element goes behind the sorted elements <= it and the tail elements before it
+        // in (distance, column) order; a sorted element moves up by the tail elements < it
+        const uint64_t tkey = (uint32_t)lane < n_tail ? dist_key(dt[r]) : ~0ull;
+        uint32_t shift[R], my_pos = 0;
+#pragma unroll
+        for (int q = 0; q < R; ++q) shift[q] = 0;
+        for (uint32_t t = 0; t < n_tail; ++t) {
+          const uint64_t tk = wave_readlane_u64(tkey, (int)t);
+          uint32_t pos = 0;
+#pragma unroll
+          for (int q = 0; q < R; ++q) {
+            const bool before = key[q] <= tk;
+            pos += (uint32_t)__popcll(__ballot(before));
+            shift[q] += before ? 0u : 1u;
+          }
+          pos += (uint32_t)__popcll(__ballot((uint32_t)lane < n_tail && (tkey < tk || (tkey == tk && (uint32_t)lane < t))));
+          if ((uint32_t)lane == t) my_pos = pos;
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          kd_r[lane * R + q + shift[q]] = key_dist(key[q]);
+          ki_r[lane * R + q + shift[q]] = val[q];
+        }
+        if ((uint32_t)lane < n_tail) {
+          kd_r[my_pos] = dt[r];
+          ki_r[my_pos] = 64u * R + lane;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      // the terms of the multimap's walk (:640-655): a position that starts a group of equal distances holds set_len *. dist
+      double sv[RS];
+      uint64_t hm[RS];
+#pragma unroll
+      for (int q = 0; q < RS; ++q) {
+        const uint32_t pos = (uint32_t)q * 64u + lane;
+        sv[q] = pos < r1 ? kd_r[pos] : inf;
+        const double prev = pos > 0 && pos < r1 ? kd_r[pos - 1] : 0.0;
+        hm[q] = __ballot(pos < r1 && (pos == 0 || prev != sv[q]));
+      }
+#pragma unroll
+      for (int q = 0; q < RS; ++q) {
+        uint32_t next = r1;
+        const uint64_t above = lane == 63 ? 0ull : (hm[q] >> (lane + 1));
+        if (above) next = (uint32_t)q * 64u + lane + 1u + (uint32_t)__ffsll((long long)above) - 1u;
+        else {
+#pragma unroll
+          for (int q2 = RS - 1; q2 > q; --q2)
+            if (hm[q2]) next = (uint32_t)q2 * 64u + (uint32_t)__ffsll((long long)hm[q2]) - 1u;
+        }
+        const uint32_t pos = (uint32_t)q * 64u + lane;
+        const bool head = (hm[q] >> lane) & 1ull;
+        if (pos < r1) chain_r[pos] = head ? __dmul_rn((double)(next - pos), sv[q]) : 0.0;  // set_len *. dist (:643)
+      }
+      // groups are added while eff_len < req_len (:648-649): the first group boundary at or beyond req_len
+      uint32_t eff = r1;
+      if (req_len < r1) {
+#pragma unroll
+        for (int q = RS - 1; q >= 0; --q) {
+          const uint32_t lo = req_len > (uint32_t)q * 64u ? req_len - (uint32_t)q * 64u : 0u;
+          const uint64_t mm = lo >= 64u ? 0ull : (hm[q] >> lo) << lo;
+          if (mm) eff = (uint32_t)q * 64u + (uint32_t)__ffsll((long long)mm) - 1u;
+        }
+      }
+      const double median = kd_r[m];
+      // MAD = the element of rank m of |d - median| (:659-678).  Before the median's position the values fall, from it they
+      // rise: u_i = |kd[m - 1 - i] - median| (i < m) and w_i = |kd[m + i] - median| (i < r1 - m) are both ascending.  Taking i
+      // from u and m + 1 - i from w gives the m + 1 smallest when u_{i-1} <= w_{m+1-i} (true up to some i, false after); the
+      // largest such i is the count of lanes that say yes, less one, and the element of rank m is max(u_{i-1}, w_{m-i}).
+      uint32_t yes = 0;
+      for (uint32_t i0 = 0; i0 <= m && !(dbg & 4); i0 += 64) {
+        const uint32_t i = i0 + lane;
+        bool ok = false;
+        if (i <= m) {
+          ok = i == 0 || 2 * m + 1 - i >= r1;  // nothing taken from u yet / w has run out: w_{m+1-i} counts as +inf
+          if (!ok) ok = fabs(__dsub_rn(kd_r[m - i], median)) <= fabs(__dsub_rn(kd_r[2 * m + 1 - i], median));
+        }
+        yes += (uint32_t)__popcll(__ballot(ok));
+      }
+      const uint32_t is = yes ? yes - 1 : 0;
+      double mad = fabs(__dsub_rn(kd_r[min(2 * m - is, r1 - 1)], median));  // w_{m-is} (there whenever is is the largest yes)
+      if (is >= 1) mad = fmax(mad, fabs(__dsub_rn(kd_r[m - is], median)));
+      if (lane == r) {
+        s_med[r] = median;
+        s_mad[r] = mad;
+        s_eff[r] = eff;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- lane r for row r: the walk's sum in the multimap's order (:640-655)
+    const int rr = min(lane, JB - 1);
+    const uint32_t chain_len = (dbg & 2) ? min(r1, 1u) : r1;
+    {
+      const double *my = chain + (size_t)rr * cs;
+      double acc = 0.0;
+#pragma unroll 8
+      for (uint32_t i = 0; i < chain_len; ++i) acc = __dadd_rn(acc, my[i]);  // a position that starts no group adds +0.0: exact
+      if (lane < JB) s_mean[lane] = acc / (double)r1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // squared deviations in column order (:657-670)
+#pragma unroll
+    for (int r = 0; r < JB; ++r) {
+      const double mean = s_mean[r];
+      double *chain_r = chain + (size_t)r * cs;
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        const uint32_t i = (uint32_t)lane + 64u * q;
+        const double d0 = __dsub_rn(dv[r][q], mean);
+        if (i < r1) chain_r[i] = __dmul_rn(d0, d0);
+      }
+      if (TAIL && (uint32_t)lane < n_tail) {
+        const double d0 = __dsub_rn(dt[r], mean);
+        chain_r[64 * R + lane] = __dmul_rn(d0, d0);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+      const double *my = chain + (size_t)rr * cs;
+      double acc = 0.0;
+#pragma unroll 8
+      for (uint32_t i = 0; i < chain_len; ++i) acc = __dadd_rn(acc, my[i]);
+      const double sd = (r1 > 1) ? sqrt(acc / ((double)r1 - 1.0)) : 0.0;  // :679-683
+      if (lane < JB) s_sd[lane] = sd;
+      if ((uint32_t)lane < nv) {
+        double *st = out_stats + (uint64_t)(j0 + lane) * 4;
+        st[0] = s_mean[lane];
+        st[1] = sd;
+        st[2] = s_med[lane];
+        st[3] = s_mad[lane];
+        out_n[j0 + lane] = s_eff[lane];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // neighbours: the first eff_len entries of the multimap (:685-689), one lane per (row, entry) while the lists are short
+    uint32_t longest = 0;
+#pragma unroll
+    for (int r = 0; r < JB; ++r) longest = max(longest, (uint32_t)r < nv ? min(s_eff[r], max_neighbours) : 0u);
+    auto put = [&](uint32_t r, uint32_t q) {
+      const uint64_t o = (uint64_t)(j0 + r) * max_neighbours + q;
+      const double d = kd[(size_t)r * stride + q];
+      out_idx[o] = ki[(size_t)r * stride + q];
+      out_dist[o] = d;
+      double zz = __dsub_rn(d, s_mean[r]) / s_sd[r];
+      if (zz != zz) zz = __longlong_as_double((long long)0xFFF8000000000000ull);  // see distance_summary_kernel
+      out_z[o] = zz;
+    };
+    if (longest <= (uint32_t)TW) {
+      const uint32_t r = (uint32_t)lane / TW, q = (uint32_t)lane % TW;
+      if (r < nv && q < min(s_eff[r], max_neighbours)) put(r, q);
+    } else {
+      for (uint32_t r = 0; r < nv; ++r) {
+        const uint32_t n_out = min(s_eff[r], max_neighbours);
+        for (uint32_t q = lane; q < n_out; q += 64) put(r, q);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int R, bool TAIL>
+constexpr int summary_batch_rows() {  // JB: rows in hand at once, by the registers and LDS a row takes
+  return R + (TAIL ? 1 : 0) <= 2 ? 4 : 2;
+}
+static inline uint32_t summary_batch_stride(uint32_t r1) { return (r1 + 1) & ~1u; }
+static inline size_t summary_batch_per_wave(uint32_t r1, uint32_t n_dims, bool pre, int jb) {
+  const size_t stride = summary_batch_stride(r1), cs = pre ? stride : std::max<size_t>(stride, n_dims);
+  return ((size_t)jb * (stride * 12 + cs * 8 + 36) + 15) & ~(size_t)15;
+}
+static inline bool summary_fits_batch(uint32_t r1, uint32_t n_dims, bool pre, int jb) {  // eight wavefronts beside the first operand
+  const size_t shared = pre ? 0 : ((size_t)n_dims * r1 + n_dims) * 8;  // (fewer: the one-row kernel's smaller buffers keep more of them on the CU -- 200 classes x 64 dimensions 1.17 against 1.48 ms)
+  return shared + 8 * summary_batch_per_wave(r1, n_dims, pre, jb) <= kWaveSummaryWhole;
+}
+
+template <int KIND, bool PRE, int R, bool TAIL>
+static int launch_summary_batch_r(const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims, const double *metric,
+                                  double p, uint32_t req_len, uint32_t max_neighbours, double *out_stats, uint32_t *out_n,
+                                  uint32_t *out_idx, double *out_dist, double *out_z, hipStream_t st) {
+  constexpr int JB = summary_batch_rows<R, TAIL>();
+  const size_t per_wave = summary_batch_per_wave(r1, n_dims, PRE, JB);
+  const size_t shared = PRE ? 0 : ((size_t)n_dims * r1 + n_dims) * 8;
+  // a multiple of four wavefronts a block (a SIMD each), two blocks a CU when both fit its LDS
+  const bool two = 2 * (shared + kSummaryWaves * per_wave) <= kWaveSummaryWhole;
+  uint32_t waves = (uint32_t)std::min<size_t>(kSummaryWaves, (kWaveSummaryWhole - shared) / per_wave);
+  waves = std::max(4u, waves & ~3u);
+  const size_t smem = (size_t)waves * per_wave + shared;
+  static PerSlotOnce attr_once;
+  bool &attr_set = attr_once();
+  if (!attr_set) {
+    KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&distance_summary_batch_kernel<KIND, PRE, R, TAIL, JB>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    attr_set = true;
+  }
+  const uint32_t blocks = std::min<uint32_t>(div_up(div_up(r2, JB), waves), (uint32_t)ctx().n_cus * (two ? 2 : 1));
+  distance_summary_batch_kernel<KIND, PRE, R, TAIL, JB><<<dim3(blocks), dim3(64 * waves), smem, st>>>(
+      a, r1, b, r2, n_dims, metric, p, req_len, max_neighbours, summary_batch_stride(r1), (uint32_t)per_wave, out_stats, out_n, out_idx,
+      out_dist, out_z, (ctx().tune_dbg >> 16) & 15);
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
+
 // the stripes of 64 sorted positions a row of r1 distances takes in the wave kernel (R, + 1 with a tail)
 static inline uint32_t wave_summary_stripes(uint32_t r1, bool tails) {
   for (uint32_t r = 1; r <= 4; r <<= 1) {
@@ -662,6 +1029,19 @@ static int launch_summary_wave(const double *a, uint32_t r1, const double *b, ui
 #define KPOP_WAVE(RR, TT) \
   return launch_summary_wave_r<KIND, PRE, RR, TT>(a, r1, b, r2, n_dims, metric, p, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st)
   const bool tails = !(ctx().tune_dbg & 32768);  // (32768: the doubled network for a few columns beyond 64 R, for A/B)
+#define KPOP_BATCH(RR, TT)                                                                                                  \
+  do {                                                                                                                      \
+    if (summary_fits_batch(r1, n_dims, PRE, summary_batch_rows<RR, TT>()))                                                  \
+      return launch_summary_batch_r<KIND, PRE, RR, TT>(a, r1, b, r2, n_dims, metric, p, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st); \
+  } while (0)
+  if (!(ctx().tune_dbg & (1 << 30))) {  // (1 << 30: round 3's kernel, a row of a wavefront at a time, for A/B)
+    if (r1 <= 64) KPOP_BATCH(1, false);
+    else if (r1 <= 64 + kWaveTail && tails) KPOP_BATCH(1, true);
+    else if (r1 <= 128) KPOP_BATCH(2, false);
+    else if (r1 <= 128 + kWaveTail && tails) KPOP_BATCH(2, true);
+    else if (r1 <= 256) KPOP_BATCH(4, false);
+  }
+#undef KPOP_BATCH
   if (r1 <= 64) KPOP_WAVE(1, false);
   if (r1 <= 64 + kWaveTail && tails) KPOP_WAVE(1, true);
   if (r1 <= 128) KPOP_WAVE(2, false);

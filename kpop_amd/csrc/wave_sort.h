@@ -15,9 +15,34 @@ __device__ __forceinline__ K key_min(K a, K b) { return a < b ? a : b; }
 template <typename K>
 __device__ __forceinline__ K key_max(K a, K b) { return a < b ? b : a; }
 
-__device__ __forceinline__ uint32_t wave_shfl_xor(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
+// lane ^ m for the strides of the networks below.  ds_bpermute (what __shfl_xor is) goes through the LDS pipe and comes back ~100
+// cycles later, and every stage of a network waits for the one before: 21 stages of a 64-key sort were mostly that wait.  gfx950
+// can do each of the six strides in the vector pipe: 1 and 2 are quad permutations, 8 a rotation of the row of 16 (DPP modifiers of
+// v_mov), 4 a half-row mirror followed by a quad reversal, 16 and 32 the row / half-wave swaps (v_permlane16_swap, v_permlane32_swap:
+// with both operands the same value, one result holds the lower partner's word in both halves and the other the upper's).
+template <int CTRL>
+__device__ __forceinline__ uint32_t wave_dpp_mov(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t wave_shfl_xor(uint32_t v, int m) {  // m: a constant once the networks are unrolled
+  switch (m) {
+    case 1: return wave_dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    case 2: return wave_dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    case 4: return wave_dpp_mov<0x1B>(wave_dpp_mov<0x141>(v));  // row_half_mirror, then quad_perm [3,2,1,0]
+    case 8: return wave_dpp_mov<0x128>(v);  // row_ror:8
+    case 16: {
+      const auto s = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+      return (__lane_id() & 16) ? s[0] : s[1];
+    }
+    case 32: {
+      const auto s = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+      return (__lane_id() & 32) ? s[0] : s[1];
+    }
+    default: return (uint32_t)__shfl_xor((int)v, m, 64);
+  }
+}
 __device__ __forceinline__ uint64_t wave_shfl_xor(uint64_t v, int m) {
-  return (uint64_t)__shfl_xor((unsigned long long)v, m, 64);
+  return ((uint64_t)wave_shfl_xor((uint32_t)(v >> 32), m) << 32) | wave_shfl_xor((uint32_t)v, m);
 }
 __device__ __forceinline__ uint32_t wave_shfl_up1(uint32_t v) { return (uint32_t)__shfl_up((int)v, 1, 64); }
 __device__ __forceinline__ uint64_t wave_shfl_up1(uint64_t v) {
