@@ -60,7 +60,7 @@ template <int R>
 constexpr int reads_per_wave() { return R <= 2 ? 8 : (R == 4 ? 8 : 2); }
 
 template <int R, typename H, int SB = 2>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void count_wave_kernel(
+__global__ __launch_bounds__(64 * kWavesPerBlock, sizeof(H) == 4 ? 4 : 1) void count_wave_kernel(
     const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, uint32_t n, int k, int content,
     uint32_t *__restrict__ ticket_counter, uint64_t *__restrict__ state, uint64_t *__restrict__ gstate, uint32_t *__restrict__ garr,
     uint64_t *__restrict__ out_hash, uint32_t *__restrict__ out_count, uint64_t *__restrict__ out_offsets, int dbg = 0) {

@@ -49,36 +49,82 @@ __device__ __forceinline__ uint64_t wave_shfl_up1(uint64_t v) {
   return (uint64_t)__shfl_up((unsigned long long)v, 1, 64);
 }
 
+template <int CTRL>  // row_shl:n (0x100 + n: lane i reads lane i + n of its row of 16) / row_shr:n (0x110 + n: lane i - n); lanes that would read outside the row get 0
+__device__ __forceinline__ uint32_t wave_row_shift(uint32_t v) { return wave_dpp_mov<CTRL>(v); }
+template <int CTRL>
+__device__ __forceinline__ uint64_t wave_row_shift(uint64_t v) {
+  return ((uint64_t)wave_dpp_mov<CTRL>((uint32_t)(v >> 32)) << 32) | wave_dpp_mov<CTRL>((uint32_t)v);
+}
+// lane ^ (G - 1): the lanes of every group of G in reverse order (the first stage of a merge below)
+__device__ __forceinline__ uint32_t wave_mirror(uint32_t v, int G) {  // G: a constant once the network is unrolled
+  switch (G) {
+    case 2: return wave_dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    case 4: return wave_dpp_mov<0x1B>(v);    // quad_perm [3,2,1,0]
+    case 8: return wave_dpp_mov<0x141>(v);   // row_half_mirror
+    case 16: return wave_dpp_mov<0x140>(v);  // row_mirror
+    case 32: return wave_shfl_xor(wave_dpp_mov<0x140>(v), 16);
+    default: return (uint32_t)__shfl((int)v, 63 - (int)__lane_id(), 64);
+  }
+}
+__device__ __forceinline__ uint64_t wave_mirror(uint64_t v, int G) {
+  return ((uint64_t)wave_mirror((uint32_t)(v >> 32), G) << 32) | wave_mirror((uint32_t)v, G);
+}
+
+// The bitonic network in its one-direction form: a merge of two ascending runs of s / 2 starts by comparing element e with
+// e ^ (s - 1) -- the second run read backwards -- and goes on with the strides s / 4 ... 1; the smaller key always goes to the
+// lower index.  Round 3's form sorted every other run downwards instead, so which of (min, max) a slot keeps depended on its
+// lane in every stage, in-lane ones included: two selects per in-lane exchange that this form does not have (count_wave_kernel:
+// ~150 of ~800 vector instructions a read).
 template <int R, typename K>
 __device__ __forceinline__ void wave_bitonic_sort(K (&key)[R], int lane) {
   constexpr int N = 64 * R;
 #pragma unroll
   for (int s = 2; s <= N; s <<= 1) {
+    if (s <= R) {  // the mirror stage inside a lane
 #pragma unroll
-    for (int t = s >> 1; t > 0; t >>= 1) {
+      for (int r = 0; r < R; ++r)
+        if ((r & (s >> 1)) == 0) {
+          const K a = key[r], b = key[r ^ (s - 1)];
+          key[r] = key_min(a, b);
+          key[r ^ (s - 1)] = key_max(a, b);
+        }
+    } else {  // ... across the lanes of a group of G = s / R: (lane, r) against (lane ^ (G - 1), R - 1 - r)
+      const int G = s / R;
+      const bool lower = (lane & (G >> 1)) == 0;
+      K other[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) other[r] = wave_mirror(key[R - 1 - r], G);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const K mn = key_min(key[r], other[r]), mx = key_max(key[r], other[r]);
+        key[r] = lower ? mn : mx;
+      }
+    }
+#pragma unroll
+    for (int t = s >> 2; t > 0; t >>= 1) {
       if (t >= R) {
         const int lt = t / R;
-        // e & s == (lane & (s/R)) * R for s >= R; the last merge (s == N) is ascending everywhere
-        const bool asc = (s == N) ? true : ((lane & (s / R)) == 0);
         const bool lower = (lane & lt) == 0;
-        const bool keep_min = (lower == asc);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          K other = wave_shfl_xor(key[r], lt);
-          K mn = key_min(key[r], other), mx = key_max(key[r], other);
-          key[r] = keep_min ? mn : mx;
+          K mn, mx;
+          if (lt == 4) {  // a lower lane's partner is four lanes up its row, an upper lane's four down: a shift each, no xor of two moves
+            mn = key_min(key[r], wave_row_shift<0x104>(key[r]));
+            mx = key_max(key[r], wave_row_shift<0x114>(key[r]));
+          } else {
+            const K other = wave_shfl_xor(key[r], lt);
+            mn = key_min(key[r], other), mx = key_max(key[r], other);
+          }
+          key[r] = lower ? mn : mx;
         }
       } else {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
+        for (int r = 0; r < R; ++r)
           if ((r & t) == 0) {
-            const bool asc = (s >= N) ? true : (s < R ? ((r & s) == 0) : ((lane & (s / R)) == 0));
-            K a = key[r], b = key[r ^ t];
-            K mn = key_min(a, b), mx = key_max(a, b);
-            key[r] = asc ? mn : mx;
-            key[r ^ t] = asc ? mx : mn;
+            const K a = key[r], b = key[r ^ t];
+            key[r] = key_min(a, b);
+            key[r ^ t] = key_max(a, b);
           }
-        }
       }
     }
   }

@@ -19,7 +19,24 @@ def short(name):
     return n.split("(")[0]
 
 
-def main(d):
+def valu_busy(sq_root):
+    """kernel -> share of the launch during which a SIMD's vector pipe was issuing (tools/sq_counters.sh output, if given)"""
+    out = {}
+    if not sq_root:
+        return out
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(sq_root, "*_set*", "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for kn, c in acc.items():
+        if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
+            mean = lambda v: sum(v) / len(v)
+            out[kn] = mean(c["SQ_ACTIVE_INST_VALU"]) * 4 / (1024 * mean(c["GRBM_GUI_ACTIVE"]) / 8)
+    return out
+
+
+def main(d, sq_root=None):
+    busy = valu_busy(sq_root)
     rows = []
     for aj in sorted(glob.glob(os.path.join(d, "*_algo.json"))):
         sec = json.load(open(aj))
@@ -46,7 +63,7 @@ def main(d):
             rows.append((name, kn, calls, avg / 1e6, mn / 1e6, algo, traffic))
     # the bound a kernel is measured against is the workload's statement (hbm unless it says otherwise): a fraction is only
     # printed against a bound that can hold it -- "l2" against the 34.5 TB/s of the eight L2s, "mfma" against the 78.6 TFLOP/s
-    # of the f64 matrix cores (flops recorded by the workload), "valu" none here (the SQ counter report has the pipe's share)
+    # of the f64 matrix cores (flops recorded by the workload), "valu" against the vector pipe's issue rate (ACTIVE_INST_VALU x 4 / (1,024 SIMDs x GUI / 8), from the SQ counter directory given as the second argument)
     print("| section | kernel | launches | avg ms | min ms | algorithmic bytes (or flops) / launch | achieved | bound | fraction of the bound's peak | HBM traffic / launch (PMC) | traffic / algorithmic bytes | note |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|")
     for name, kn, calls, avg, mn, algo, traffic in rows:
@@ -65,7 +82,7 @@ def main(d):
             elif bound == "l2":
                 frac = "%.3f of 34.5 TB/s" % (gbs / 34500)
             elif bound == "valu":
-                frac = "(instruction-bound: SQ counters)"
+                frac = "%.2f of the VALU issue rate" % busy[kn] if kn in busy else "(instruction-bound: SQ counters)"
             if algo and algo.get("flops"):
                 note += "; %.1f Tops/s f64 of the 39.3 non-FMA peak" % (algo["flops"] / (avg * 1e-3) / 1e12)
         print("| %s | `%s` | %d | %.4f | %.4f | %s | %s | %s | %s | %s | %s | %s |" % (
@@ -74,4 +91,4 @@ def main(d):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)

@@ -11,7 +11,7 @@ cli_kernels_report.py joins that with the profiler's per-kernel averages.
   count_L      KPopCount -L, reads          count_wave_kernel                 100k x 150 bp, k = 12
   twist_reads  KPopTwistDB -k, read spectra twist_csr_kernel<double>          100k spectra of <= 139 lines, D = 64
   twist_genomes KPopTwistDB -k, genomes     twist_csr_kernel<double>          2,000 spectra of ~29.7k lines (wuhan mutants)
-  summary_65   KPopTwistDB -s vs classes    distance_summary_kernel           r1 = 65, r2 = 100k, D = 64
+  summary_65   KPopTwistDB -s vs classes    distance_summary_batch_kernel         r1 = 65, r2 = 100k, D = 64
   summary_1M   relatedness engine           summary1_pass_kernel (+ sample, finish, rowwise)  r1 = 1M, r2 = 256, keep 300
   merged_hist  KPopCount -l                 read_hist / window_hist + compaction   100k reads; 5,000 x 30 kb genomes
   merged_hist_mutants  KPopCount -l, one organism   window_hist_combine_kernel (LDS (hash, count) tables)   5,000 wuhan mutants, k = 12
@@ -85,7 +85,8 @@ def main():
             api.dev_count_reads(b.data_ptr(), o.data_ptr(), n, L, k, scratch.data_ptr(), oh.data_ptr(), oc.data_ptr(), oo.data_ptr(), stream=sp)
         torch.cuda.synchronize()
         nnz = int(oo[-1].item())
-        algo["count_wave_kernel"] = {"bytes": n * L + nnz * 12 + (n + 1) * 8, "note": "read L B per read, write (hash u64, count u32) per distinct k-mer + offsets"}
+        algo["count_wave_kernel"] = {"bytes": n * L + nnz * 12 + (n + 1) * 8, "bound": "valu",
+                                     "note": "read L B per read, write (hash u64, count u32) per distinct k-mer + offsets; instruction-bound: ~700 vector instructions a read, half of them the 256-slot sort network"}
         if sec == "twist_reads":
             tw = kpop_amd.Twister.synth(0x5EED, k, d)
             val = oc[:nnz].to(torch.float64)
@@ -154,8 +155,8 @@ def main():
                                      idx.data_ptr(), dd.data_ptr(), zz.data_ptr(), keep_at_most=keep, max_neighbours=mx, stream=sp)
         torch.cuda.synchronize()
         if sec == "summary_65":
-            algo["distance_summary"] = {"bytes": (r1 + r2) * d * 8 + r2 * (32 + 4 + keep * 20), "flops": 4.0 * r1 * r2 * d,
-                                               "note": "both operands once + one summary row; f64 VALU-bound: 4 unfusable ops per pair and dimension"}
+            algo["distance_summary"] = {"bytes": (r1 + r2) * d * 8 + r2 * (32 + 4 + keep * 20), "flops": 4.0 * r1 * r2 * d, "bound": "valu",
+                                               "note": "both operands once + one summary row; instruction-bound: 4 unfusable f64 ops per pair and dimension, then a sort of the row's (distance, column) pairs"}
         else:
             algo["summary1_pass_kernel"] = {"bytes": r2 * r1 * 8, "note": "one pass over the r1 distances of each query row is the algorithmic minimum: this kernel is that pass; fused_sample_kernel (a 6 % sample, several selections over it) and fused_finish_kernel (the ~13 % candidates, five passes) add theirs; summary_large_kernel is the fallback, idle here"}
             algo["distance_rowwise_kernel"] = {"bytes": (r1 + r2) * d * 8 + r1 * r2 * 8, "flops": 4.0 * r1 * r2 * d, "note": "chunk rows written for the summary kernel"}

@@ -14,6 +14,13 @@ bash tools/probes/r04_tile_pmc.sh gpurun_out/r04_tile_pmc1 0.01 > $O/tile_pmc_1p
 bash tools/cli_kernels_profile.sh gpurun_out/r04_cli > $O/cli_profile.log 2>&1
 # 3. SQ counters of the -L count kernel, the -s summary kernel, the partition histogram
 bash tools/sq_counters.sh gpurun_out/r04_sq count_L summary_65 merged_hist > $O/sq.log 2>&1
+# 3b. the classifier's summary kernel (four rows of a wavefront at a time) against round 3's, its phase ablation, kernel times, SQ counters;
+#     the -L count kernel after the networks' exchanges moved to the vector pipe
+for c in 65 64 10 100 130 200; do AB_CLASSES=$c AB_DBG=1 python tools/probes/ab_summary_wave.py; done > $O/summary_ab_new.txt 2>&1
+KPOP_TUNE_DBG=$((1<<30)) AB_CLASSES=65,64,10,100,130,200 python tools/probes/ab_summary_wave.py > $O/summary_ab_round3_kernel.txt 2>&1
+CLASSES="65 64 100 130" bash tools/probes/r04_summary.sh > $O/summary_kernels.txt 2>&1
+bash tools/probes/r04_summary_pmc.sh > $O/summary_pmc.txt 2>&1
+python tools/probes/probe_count.py > $O/count_wave_probe.txt 2>&1
 # 4. the bench line, plain; then the whole line (config legs included) under the kernel trace
 python bench.py > $O/bench.json 2> $O/bench.err
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_trace -o bench -- python3 $R/bench.py --no-children --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err)
