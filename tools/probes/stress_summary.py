@@ -54,6 +54,15 @@ def main():
         metric = O.metric_powers(O.synth_inertia(d))
         tag = "small it=%d r1=%d d=%d r2=%d kind=%d p=%g keep=%d grid=%s" % (it, r1, d, r2, kind, p, keep, grid)
         check(kpop, O, m1, m2, metric, kind, p, keep, min(r1, 64), tag)
+        if kind != 2 and r1 <= 600:  # the same rows as a ready distance matrix (summarize_distances: the kernels' PRE variants)
+            dm = kpop.distance_rowwise(m1, m2, metric, kind, p, True)
+            st, n, idx, dist, z = kpop.distance_summary(m1, m2, metric, kind, p, True, keep, max_neighbours=min(r1, 64))
+            st2, n2, idx2, dist2, z2 = kpop.summarize_distances(dm, keep_at_most=keep, max_neighbours=min(r1, 64))
+            for x, y in ((st, st2), (n, n2)):
+                assert np.array_equal(x, y, equal_nan=True), (tag, "summarize_distances")
+            for j in range(r2):
+                mm = min(int(n[j]), min(r1, 64))
+                assert np.array_equal(idx[j, :mm], idx2[j, :mm]) and np.array_equal(dist[j, :mm], dist2[j, :mm]) and np.array_equal(z[j, :mm], z2[j, :mm], equal_nan=True), (tag, j)
         if it % 25 == 0:
             print("ok", tag, flush=True)
     for it in range(n_large):
