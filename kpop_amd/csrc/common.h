@@ -98,6 +98,7 @@ struct Context {
   //   (>> 20) & 7      fused dense twist ablation                             (>> 24) & 15         count_twist_tile_kernel ablation: MFMA, X, set, lookups
   //   1 << 28          CSR twist: one wavefront per spectrum even for a few very long spectra (same bits as the segmented launch)
   //   1 << 29          ca: stay on the Cholesky factor however many pivots were at the rounding floor
+  //   1 << 30          summaries against <= 256 rows: round 3's kernel, one row of a wavefront at a time
   int tune_dbg = 0;
   int tune_dense = 2;    // the matrix-core routes of the twist: 2 (default) chosen by the batch -- assemblies through count_twist_tile_kernel (consensus on the matrix cores + residual gather), small-k assemblies through the dense image, dense spectra through the contraction --, 1 kpop_twist always dense, 0 never (the sparse mat-vec in the reference's order of additions everywhere)
   int tune_tileg = 64;   // sequences a chunk of count_twist_tile_kernel: 64 (one block of 1,024 threads a CU) or 32 (two of 512: measured slower, 1.96 against 1.64 ms on 5,000 mutants at 0.1 % -- every per-chunk step is paid twice as often)
