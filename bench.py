@@ -40,6 +40,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 READ_SEED, TWISTER_SEED, CLASS_SEED = 0x4B506F70, 0x5EED, 0xC1A55
 MFMA_F64_PEAK_TFLOPS = 78.6  # MI355X f64 matrix peak (256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz)
+MALL_GATHER_PEAK_GBS = 8600.0  # random whole rows of a table that sits in the 256 MiB Infinity Cache (MI355X_MICROARCH.md, 'Indexed rows')
 L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md: aggregate L2 bandwidth, 34.5 TB/s
 XGMI_DIRECT_ESTIMATE_MS = 0.42  # 64 MB per shard over 7 links x 153 GB/s, one shard per link
 
@@ -420,10 +421,12 @@ def config2_leg(R):
             "workload": "%d reads x %d bp, k=%d DNA-ds, D=%d (twister %.2f GB: inside the 256 MB Infinity Cache + L2 after the first launch)" % (n, L, k, d, table / 1e9),
             "value": n / ((ms_c + ms_t) * 1e-3), "unit": "sequences/sec", "value_is": "count -L then the fused count->twist, both device-resident",
             "ms_per_step": ms_c + ms_t, "kernels_ms": {"count_reads (-L, CSR out)": ms_c, "count_twist (fused)": ms_t},
-            "roofline": {"kernel": "count_twist_wave_kernel", "bound": "l2", "achieved": alg_t / (ms_t * 1e-3) / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg_t / (ms_t * 1e-3) / 1e9 / L2_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_t, "avg_launch_ms": ms_t,
-                         "note": "10,000 wavefronts are 1.2 rounds of the chip: the launch is a start, one gather chain per wavefront and a tail, not a "
-                                 "stream; the rows come from the caches (a 0.27 GB table), so the HBM figure would exceed 1 on a longer run of this shape"},
+            "roofline": {"kernel": "count_twist_wave_kernel", "bound": "infinity_cache", "achieved": alg_t / (ms_t * 1e-3) / 1e9, "peak": MALL_GATHER_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg_t / (ms_t * 1e-3) / 1e9 / MALL_GATHER_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_t, "avg_launch_ms": ms_t,
+                         "note": "the 0.27 GB table is past the L2s (4 MiB each) and inside the 256 MiB Infinity Cache: every row is a random 512-B read of it. "
+                                 "peak = what MI355X_MICROARCH.md measures for uniformly random rows of an Infinity-Cache-resident table (8.6 TB/s chip-wide at 38 MB, "
+                                 "7.4-7.9 at 151 MB). The launch scales with the reads from 2,000 to 100,000 of them (0.027 / 0.107 / 0.295 / 0.94 ms: "
+                                 "tools/probes/ab_small_batch_unroll.py) and does not change with the row loads in flight: bandwidth, not a latency chain"},
             "roofline_count": {"kernel": "count_wave_kernel", "bound": "valu", "achieved_GBps_on_algorithmic_bytes": alg_c / (ms_c * 1e-3) / 1e9,
                                "algorithmic_bytes_per_launch": alg_c, "avg_launch_ms": ms_c,
                                "note": "instruction-bound (a bitonic network per read): profiles/r04_sq_counters.txt has the VALU issue fraction at 100k reads"},
@@ -534,8 +537,11 @@ def config5_leg(R):
             "rows_finite_and_inside_the_coefficient_range": finite,
             "roofline": {"kernel": "count_twist_wave_kernel", "bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms,
-                         "note": "128-byte rows (16 dims) gathered at random from 69 GB, every one an HBM miss behind an index-word miss (two dependent "
-                                 "round trips a window), 10,000 wavefronts = 1.2 rounds of the chip: latency, not bandwidth, sets this launch"}}
+                         "note": "128-byte rows (16 dims) gathered at random from 69 GB, every one an HBM miss behind a miss on the 268 MB name -> row index "
+                                 "(a 64-byte sector of it per window, not in the algorithmic bytes: with it the launch moves ~1.5 x them). The launch scales "
+                                 "with the reads -- 2,000 / 10,000 / 30,000 / 100,000 reads 0.017 / 0.067 / 0.163 / 0.499 ms (tools/probes/ab_small_batch_unroll.py), "
+                                 "3.5 TB/s of rows at 100,000 -- so it is the memory system's rate for 128-byte random reads, with 10,000 wavefronts = 1.2 rounds "
+                                 "of the chip on top; 16 row loads in flight instead of 8 give 8 % at 10,000 reads and nothing at 100,000"}}
     finally:
         tw.free()
 
