@@ -20,6 +20,8 @@ def main():
     st = torch.cuda.current_stream()
     sp = st.cuda_stream
     cases = [(15, 16)] if os.environ.get("AB_K15") else [(10, 64), (12, 64)]
+    if os.environ.get("AB_CASES"):  # "k:d,k:d"
+        cases = [tuple(int(x) for x in c.split(":")) for c in os.environ["AB_CASES"].split(",")]
     for k, d in cases:
         tw = kpop_amd.Twister.synth(0x5EED, k, d)
         for n in (2000, 10000, 30000, 100000):
