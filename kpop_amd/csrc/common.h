@@ -96,6 +96,7 @@ struct Context {
   //   256              counter: the median kernel's staging alone            4096, 8192, 16384    distance_rowwise: tile choices
   //   32768            wave summary: the doubled network instead of the tail   (>> 16) & 15       wave summary ablation: sort, chains, MAD, distances
   //   (>> 20) & 7      fused dense twist ablation                             (>> 24) & 15         count_twist_tile_kernel ablation: MFMA, X, set, lookups
+  //   1024             distance_rowwise: the 256-row staging (two wavefronts a SIMD) where 128 rows would do
   //   1 << 28          CSR twist: one wavefront per spectrum even for a few very long spectra (same bits as the segmented launch)
   //   1 << 29          ca: stay on the Cholesky factor however many pivots were at the rounding floor
   //   1 << 30          summaries against <= 256 rows: round 3's kernel, one row of a wavefront at a time

@@ -92,8 +92,10 @@ constexpr int kDC = 16, kMaxW = 128, kMaxTJ = 256;
 // SLAB (spectral distances, n_dims in the millions and few rows): blockIdx.z owns dimensions [z*slab, (z+1)*slab) and
 // writes its raw partial sums to slab z of `out` ([gridDim.z][r2][r1]); reduce_slabs_kernel adds the slabs in order and
 // applies the scale.  SLAB = false is the hot path: one block walks all the dimensions, the sum is the reference's.
-template <int KIND, bool SLAB = false, int TY = 4>
-__global__ __launch_bounds__(256) void distance_rowwise_kernel(const double *__restrict__ a, uint32_t w, uint32_t r1,
+// MAXTJ: the most second-operand rows a block stages (TJ <= MAXTJ).  With 128 (one column tile of 61..127 columns: distances to a
+// set of classes) and the rows' norms in LDS instead of 48 registers the kernel fits 168 VGPRs: three wavefronts a SIMD, not two.
+template <int KIND, bool SLAB = false, int TY = 4, int MAXTJ = 256>
+__global__ __launch_bounds__(256, MAXTJ == 128 ? 3 : 1) void distance_rowwise_kernel(const double *__restrict__ a, uint32_t w, uint32_t r1,
                                                                const double *__restrict__ b, uint32_t r2,
                                                                uint32_t n_dims, const double *__restrict__ metric,
                                                                double p, double *__restrict__ out, uint32_t n_cg,
@@ -101,8 +103,9 @@ __global__ __launch_bounds__(256) void distance_rowwise_kernel(const double *__r
                                                                const double *__restrict__ nb = nullptr, const uint32_t *__restrict__ gate = nullptr) {
   if (gate && *gate == 0) return;  // (a fallback that is launched whatever happens and runs only when something failed: summary_large_impl)
   __shared__ __attribute__((aligned(16))) double As[kDC][kMaxW + 2];
-  __shared__ __attribute__((aligned(16))) double Bs[kDC][kMaxTJ + 2];
+  __shared__ __attribute__((aligned(16))) double Bs[kDC][MAXTJ + 2];
   __shared__ double s_metric[kDC];
+  __shared__ double s_na[kMaxW], s_nb[MAXTJ];  // the rows' norms (read as the rows are staged)
   const uint32_t TJ = TY * n_rg;
   const uint32_t i0 = blockIdx.x * w, j0 = blockIdx.y * TJ;
   const uint32_t i1 = min(r1, i0 + w);
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void distance_rowwise_kernel(const double *__r
     for (int x = 0; x < 4; ++x) acc[y][x] = 0.0;
   // Staging is software-pipelined through registers: the global loads of chunk c+1 are issued before
   // the arithmetic of chunk c and land in LDS after it, so HBM/L2 latency hides behind the f64 work.
-  constexpr int NA = kMaxW * kDC / 256, NB = kMaxTJ * kDC / 256;
+  constexpr int NA = kMaxW * kDC / 256, NB = MAXTJ * kDC / 256;
   double ra[NA], rb[NB];
   const uint32_t sc = threadIdx.x % kDC, rbase = threadIdx.x / kDC;  // 16 rows per sweep of the block
   const uint32_t d_begin = SLAB ? blockIdx.z * slab : 0u;
@@ -124,12 +127,11 @@ __global__ __launch_bounds__(256) void distance_rowwise_kernel(const double *__r
   // na / nb: the norms of the rows (lib/Matrix.ml:247-249 divides every element by its row's norm before the difference).
   // The quotients are taken here, as the rows are staged, instead of being written out as a second copy of both operands
   // and read back: the same IEEE division of the same operands.
-  double nav[NA], nbv[NB];
-#pragma unroll
-  for (int q = 0; q < NA; ++q) nav[q] = na ? na[min(i0 + rbase + q * 16, r1 - 1)] : 1.0;
-#pragma unroll
-  for (int q = 0; q < NB; ++q) nbv[q] = nb ? nb[min(j0 + rbase + q * 16, r2 - 1)] : 1.0;
   const bool divide = na != nullptr;
+  if (divide) {
+    for (uint32_t i = threadIdx.x; i < kMaxW; i += 256) s_na[i] = na[min(i0 + i, r1 - 1)];
+    for (uint32_t j = threadIdx.x; j < (uint32_t)MAXTJ; j += 256) s_nb[j] = nb ? nb[min(j0 + j, r2 - 1)] : 1.0;
+  }
   auto prefetch = [&](uint32_t c0) {
     const bool cok = c0 + sc < d_end;
 #pragma unroll
@@ -148,9 +150,9 @@ __global__ __launch_bounds__(256) void distance_rowwise_kernel(const double *__r
     __syncthreads();  // the previous chunk's readers are done
     if (divide) {
 #pragma unroll
-      for (int q = 0; q < NA; ++q) As[sc][rbase + q * 16] = __ddiv_rn(ra[q], nav[q]);
+      for (int q = 0; q < NA; ++q) As[sc][rbase + q * 16] = __ddiv_rn(ra[q], s_na[rbase + q * 16]);
 #pragma unroll
-      for (int q = 0; q < NB; ++q) Bs[sc][rbase + q * 16] = __ddiv_rn(rb[q], nbv[q]);
+      for (int q = 0; q < NB; ++q) Bs[sc][rbase + q * 16] = __ddiv_rn(rb[q], s_nb[rbase + q * 16]);
     } else {
 #pragma unroll
       for (int q = 0; q < NA; ++q) As[sc][rbase + q * 16] = ra[q];
@@ -1178,7 +1180,10 @@ static int rowwise_block(const double *a, uint32_t r1, const double *b, uint32_t
   const uint32_t rows_per_launch = 65535u * TJ;  // m2 rows ride on grid.y
   for (uint32_t j0 = 0; j0 < r2; j0 += rows_per_launch) {
     const uint32_t nr = std::min(rows_per_launch, r2 - j0);
-    if (tall)
+    if (tall && TJ <= 128 && !(ctx().tune_dbg & 1024))  // (1024: the 256-row staging with two wavefronts a SIMD, for A/B)
+      distance_rowwise_kernel<KIND, false, 8, 128><<<dim3(div_up(r1, w), div_up(nr, TJ)), dim3(256), 0, st>>>(
+          a, w, r1, b + (uint64_t)j0 * n_dims, nr, n_dims, metric, p, out + (uint64_t)j0 * r1, n_cg, n_rg, 0, na, nb ? nb + j0 : nullptr, gate);
+    else if (tall)
       distance_rowwise_kernel<KIND, false, 8><<<dim3(div_up(r1, w), div_up(nr, TJ)), dim3(256), 0, st>>>(
           a, w, r1, b + (uint64_t)j0 * n_dims, nr, n_dims, metric, p, out + (uint64_t)j0 * r1, n_cg, n_rg, 0, na, nb ? nb + j0 : nullptr, gate);
     else
