@@ -33,7 +33,7 @@ def test_default_line_carries_every_baseline_config():
     j = _bench(["--no-children", "--cpu-seconds", "2", "--steps", "5", "--warmup", "2"])
     assert j["n_gpus"] == 1 and 0.0 < j["roofline"]["frac"] <= 1.0 and j["cpu_baseline"]["kind"] == "port"
     c2, c3, c5 = j["config2_on_this_gpu"], j["config3_on_this_gpu"], j["config5_on_this_gpu"]
-    assert c2["ms_per_step"] > 0 and c2["roofline"]["bound"] == "l2" and 0.0 < c2["roofline"]["frac"] <= 1.0
+    assert c2["ms_per_step"] > 0 and c2["roofline"]["bound"] == "infinity_cache" and 0.0 < c2["roofline"]["frac"] <= 1.0
     for leg, bound in (("unrelated_genomes", "hbm"), ("one_organism_0.3pct", "mfma")):
         r = c3[leg]["roofline"]
         assert c3[leg]["ms_per_step"] > 0 and r["bound"] == bound and 0.0 < r["frac"] <= 1.0, (leg, r)
