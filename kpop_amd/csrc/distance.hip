@@ -664,7 +664,9 @@ __global__ __launch_bounds__(64 * kSummaryWaves) void distance_summary_batch_ker
     const double *__restrict__ a, uint32_t r1, const double *__restrict__ b, uint32_t r2, uint32_t n_dims,
     const double *__restrict__ metric, double p, uint32_t req_len, uint32_t max_neighbours, uint32_t stride, uint32_t per_wave,
     double *__restrict__ out_stats, uint32_t *__restrict__ out_n, uint32_t *__restrict__ out_idx,
-    double *__restrict__ out_dist, double *__restrict__ out_z, int dbg) {
+    double *__restrict__ out_dist, double *__restrict__ out_z, int dbg, const double *__restrict__ nb) {
+  // nb (not PRE): the norms of the second operand's rows, which then come as they are and are divided as they are staged
+  // (lib/Matrix.ml:247-249: the same quotients a divided copy holds -- one pass over the rows less to write and to read)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int RS = R + (TAIL ? 1 : 0);  // stripes of 64 sorted positions
   constexpr int TW = 64 / JB;             // lanes a row has in the passes that take one lane per (row, item)
@@ -716,8 +718,14 @@ __global__ __launch_bounds__(64 * kSummaryWaves) void distance_summary_batch_ker
     } else {
 #pragma unroll
       for (int r = 0; r < JB; ++r) {
-        const double *brow = b + (uint64_t)(j0 + min((uint32_t)r, nv - 1)) * n_dims;
-        for (uint32_t c = lane; c < n_dims; c += 64) s_bT[(size_t)c * JB + r] = brow[c];
+        const uint32_t jr = j0 + min((uint32_t)r, nv - 1);
+        const double *brow = b + (uint64_t)jr * n_dims;
+        if (nb) {
+          const double nrm = nb[jr];
+          for (uint32_t c = lane; c < n_dims; c += 64) s_bT[(size_t)c * JB + r] = __ddiv_rn(brow[c], nrm);
+        } else {
+          for (uint32_t c = lane; c < n_dims; c += 64) s_bT[(size_t)c * JB + r] = brow[c];
+        }
       }
       __builtin_amdgcn_wave_barrier();
       double acc[JB][R];
@@ -985,7 +993,7 @@ static inline bool summary_fits_batch(uint32_t r1, uint32_t n_dims, bool pre, in
 template <int KIND, bool PRE, int R, bool TAIL>
 static int launch_summary_batch_r(const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims, const double *metric,
                                   double p, uint32_t req_len, uint32_t max_neighbours, double *out_stats, uint32_t *out_n,
-                                  uint32_t *out_idx, double *out_dist, double *out_z, hipStream_t st) {
+                                  uint32_t *out_idx, double *out_dist, double *out_z, hipStream_t st, const double *nb) {
   constexpr int JB = summary_batch_rows<R, TAIL>();
   const size_t per_wave = summary_batch_per_wave(r1, n_dims, PRE, JB);
   const size_t shared = PRE ? 0 : ((size_t)n_dims * r1 + n_dims) * 8;
@@ -1004,7 +1012,7 @@ static int launch_summary_batch_r(const double *a, uint32_t r1, const double *b,
   const uint32_t blocks = std::min<uint32_t>(div_up(div_up(r2, JB), waves), (uint32_t)ctx().n_cus * (two ? 2 : 1));
   distance_summary_batch_kernel<KIND, PRE, R, TAIL, JB><<<dim3(blocks), dim3(64 * waves), smem, st>>>(
       a, r1, b, r2, n_dims, metric, p, req_len, max_neighbours, summary_batch_stride(r1), (uint32_t)per_wave, out_stats, out_n, out_idx,
-      out_dist, out_z, (ctx().tune_dbg >> 16) & 15);
+      out_dist, out_z, (ctx().tune_dbg >> 16) & 15, PRE ? nullptr : nb);
   KPOP_LAUNCH_CHECK();
   return 0;
 }
@@ -1024,24 +1032,38 @@ static inline bool summary_fits_wave(uint32_t r1, uint32_t n_dims, bool pre) {
   return ((size_t)n_dims * r1 + n_dims) * 8 + 4 * per_wave <= kWaveSummaryWhole;  // the first operand and at least four waves' buffers
 }
 
+// which instance of distance_summary_batch_kernel takes a first operand of r1 rows: 1 (R 1), 2 (R 1 + tail), 3 (R 2), 4 (R 2 + tail),
+// 5 (R 4); 0: none (round 3's kernel, one row of a wavefront at a time)
+static int summary_batch_case(uint32_t r1, uint32_t n_dims, bool pre) {
+  if (ctx().tune_dbg & (1 << 30)) return 0;  // (round 3's kernel, for A/B)
+  const bool tails = !(ctx().tune_dbg & 32768);
+  int c = 0;
+  if (r1 <= 64) c = 1;
+  else if (r1 <= 64 + kWaveTail && tails) c = 2;
+  else if (r1 <= 128) c = 3;
+  else if (r1 <= 128 + kWaveTail && tails) c = 4;
+  else if (r1 <= 256) c = 5;
+  if (!c) return 0;
+  const int jb = c <= 3 ? 4 : 2;  // (summary_batch_rows)
+  return summary_fits_batch(r1, n_dims, pre, jb) ? c : 0;
+}
+
 template <int KIND, bool PRE>
 static int launch_summary_wave(const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims, const double *metric,
                                double p, uint32_t req_len, uint32_t max_neighbours, double *out_stats, uint32_t *out_n,
-                               uint32_t *out_idx, double *out_dist, double *out_z, hipStream_t st) {
+                               uint32_t *out_idx, double *out_dist, double *out_z, hipStream_t st, const double *nb = nullptr) {
 #define KPOP_WAVE(RR, TT) \
   return launch_summary_wave_r<KIND, PRE, RR, TT>(a, r1, b, r2, n_dims, metric, p, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st)
   const bool tails = !(ctx().tune_dbg & 32768);  // (32768: the doubled network for a few columns beyond 64 R, for A/B)
-#define KPOP_BATCH(RR, TT)                                                                                                  \
-  do {                                                                                                                      \
-    if (summary_fits_batch(r1, n_dims, PRE, summary_batch_rows<RR, TT>()))                                                  \
-      return launch_summary_batch_r<KIND, PRE, RR, TT>(a, r1, b, r2, n_dims, metric, p, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st); \
-  } while (0)
-  if (!(ctx().tune_dbg & (1 << 30))) {  // (1 << 30: round 3's kernel, a row of a wavefront at a time, for A/B)
-    if (r1 <= 64) KPOP_BATCH(1, false);
-    else if (r1 <= 64 + kWaveTail && tails) KPOP_BATCH(1, true);
-    else if (r1 <= 128) KPOP_BATCH(2, false);
-    else if (r1 <= 128 + kWaveTail && tails) KPOP_BATCH(2, true);
-    else if (r1 <= 256) KPOP_BATCH(4, false);
+#define KPOP_BATCH(RR, TT) \
+  return launch_summary_batch_r<KIND, PRE, RR, TT>(a, r1, b, r2, n_dims, metric, p, req_len, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st, nb)
+  switch (summary_batch_case(r1, n_dims, PRE)) {
+    case 1: KPOP_BATCH(1, false);
+    case 2: KPOP_BATCH(1, true);
+    case 3: KPOP_BATCH(2, false);
+    case 4: KPOP_BATCH(2, true);
+    case 5: KPOP_BATCH(4, false);
+    default: break;
   }
 #undef KPOP_BATCH
   if (r1 <= 64) KPOP_WAVE(1, false);
@@ -1332,10 +1354,10 @@ template <int KIND, bool PRE>
 static int launch_summary(const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims,
                           const double *metric, double p, uint32_t keep_at_most, uint32_t max_neighbours,
                           double *out_stats, uint32_t *out_n, uint32_t *out_idx, double *out_dist, double *out_z,
-                          hipStream_t st) {
+                          hipStream_t st, const double *nb = nullptr) {  // nb: see summary_divides_in_flight
   if (summary_fits_wave(r1, n_dims, PRE) && ctx().tune_dbg != 4)
     return launch_summary_wave<KIND, PRE>(a, r1, b, r2, n_dims, metric, p, keep_at_most ? keep_at_most : r1, max_neighbours, out_stats,
-                                          out_n, out_idx, out_dist, out_z, st);
+                                          out_n, out_idx, out_dist, out_z, st, nb);
   uint32_t NP = 64;
   while (NP < r1) NP <<= 1;
   const size_t smem = (size_t)NP * (8 + 8 + 4);
@@ -1363,6 +1385,17 @@ static int summary_impl(const double *m1, uint32_t r1, const double *m2, uint32_
                         void *work, double *out_stats, uint32_t *out_n, uint32_t *out_idx, double *out_dist,
                         double *out_z, hipStream_t st) {
   const double *a, *b;
+  if (normalize && r2 && summary_fits_wave(r1, n_dims, false) && ctx().tune_dbg != 4 && summary_batch_case(r1, n_dims, false)) {
+    // The kernel that takes four rows of a wavefront at a time stages the second operand's rows itself: they go in as they are,
+    // with their norms, and are divided on the way (the same quotients); only the few rows of the first operand get a divided copy.
+    DistWork w = carve(work, r1, r2, n_dims);
+    row_norms_kernel<KIND><<<dim3(div_up(r1, kNormRows)), dim3(256), 0, st>>>(m1, r1, n_dims, metric, p, w.n1, w.a);
+    KPOP_LAUNCH_CHECK();
+    row_norms_kernel<KIND><<<dim3(div_up(r2, kNormRows)), dim3(256), 0, st>>>(m2, r2, n_dims, metric, p, w.n2, nullptr);
+    KPOP_LAUNCH_CHECK();
+    return launch_summary<KIND, false>(w.a, r1, m2, r2, n_dims, metric, p, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist,
+                                       out_z, st, w.n2);
+  }
   KPOP_TRY(prepare_operands<KIND>(m1, r1, m2, r2, n_dims, metric, p, normalize, work, &a, &b, st));
   if (r1 >= 1 && r1 <= kSummaryMaxR1 && !summary_fits_wave(r1, n_dims, false) && ctx().tune_dbg != 4) {
     // A first operand that does not fit LDS (100 x 200 dimensions, 500 x 64, anything of 513..4,096 rows): the distances of
