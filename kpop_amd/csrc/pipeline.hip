@@ -304,7 +304,7 @@ extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, con
   // ... and a SHORT FIRST chunk (a quarter of the others) when the size is the library's to choose: nothing comes down
   // before the first chunk has gone up and been twisted, and a download-bound batch ends that much later (0.50 ms of a
   // 2.46 ms batch with four equal chunks; profiles/r03_p_pipeline_timeline.txt)
-  uint32_t first_chunk = 0;
+  uint32_t first_chunk = 0, sched[4] = {0, 0, 0, 0}, n_sched = 0;
   if (chunk_reads == 0) {
     // ... unless the batch before this one is still in flight: then the batches overlap each other (this one goes up while
     // that one is twisted and comes down), and cutting this one up only costs -- every launch over a quarter of a batch
@@ -315,6 +315,18 @@ extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, con
     else {
       chunk_reads = std::min<uint32_t>(131072u, std::max<uint32_t>(16384u, (div_up(n_reads, 4) + 1023u) & ~1023u));
       if (n_reads > chunk_reads) first_chunk = std::max<uint32_t>(4096u, (chunk_reads / 4) & ~1023u);
+      // A lone batch of 64k-400k reads is download-bound, and what it loses is the time before the downloads start and the gaps
+      // in which they wait for a chunk's kernels: chunks that GROW (11, 14, 18, 22, 35 % of the batch) keep every chunk's kernels
+      // inside the download of the one before.  With kernels of 0.055 ms + 11.9 us per 1,000 reads and downloads of 0.02 ms +
+      // 18.8 us per 1,000 (profiles/r03_q_pipeline_timeline.txt) the best five-chunk schedule ends at 2.25 ms for 100,000 reads;
+      // a quarter-size chunk followed by four equal ones ends at 2.41 (measured: 2.44).
+      if (n_reads >= 65536 && n_reads <= 400000) {
+        static const uint32_t kPermille[5] = {110, 140, 180, 220, 350};
+        for (int c = 0; c < 4; ++c) sched[c] = std::max<uint32_t>(4096u, (uint32_t)(((uint64_t)n_reads * kPermille[c] / 1000 + 1023u) & ~1023ull));
+        n_sched = 4;  // (the fifth chunk is what is left)
+        chunk_reads = 131072u;
+        first_chunk = 0;
+      }
     }
   }
   const bool pin_tw = is_pinned(o->twisted), pin_di = is_pinned(o->distances), pin_st = is_pinned(o->stats),
@@ -336,9 +348,22 @@ extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, con
   };
   // (the chunks, as a function of its own: a failure half way -- an allocation, a launch -- must not leave the earlier chunks
   // copying into the caller's buffers behind a call that has reported an error and issued no ticket: see below)
+  // the chunks' ends first: every slot is sized for the batch's LARGEST chunk, so that chunks of different sizes going round the ring
+  // grow a slot once, not every time a larger chunk reaches it (growing synchronises)
+  std::vector<uint32_t> ends;
+  uint32_t cap_n = 0;
+  uint64_t cap_nb = 0;
+  for (uint32_t r0 = 0, c = 0; r0 < n_reads; ++c) {
+    const uint32_t want = c < n_sched ? sched[c] : ((r0 == 0 && first_chunk) ? first_chunk : chunk_reads);
+    const uint32_t r1 = chunk_end(offsets, r0, n_reads, want, pl->cfg.chunk_bases);
+    ends.push_back(r1);
+    cap_n = std::max(cap_n, r1 - r0);
+    cap_nb = std::max(cap_nb, offsets[r1] - offsets[r0]);
+    r0 = r1;
+  }
   auto run_chunks = [&]() -> int {
   for (uint32_t r0 = 0; r0 < n_reads;) {
-    const uint32_t r1 = chunk_end(offsets, r0, n_reads, (r0 == 0 && first_chunk) ? first_chunk : chunk_reads, pl->cfg.chunk_bases);
+    const uint32_t r1 = ends[n_chunks];
     const uint32_t n = r1 - r0;
     const uint64_t b0 = offsets[r0], nb = offsets[r1] - b0;
     uint64_t max_len = 0;
@@ -347,17 +372,17 @@ extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, con
     ++pl->next_chunk;
     // the slot's previous chunk must have left the device before its buffers are grown (ensure synchronises then
     // anyway) or overwritten (the stream waits below do that without stalling the host)
-    KPOP_TRY(s.bases.ensure(nb));
-    KPOP_TRY(s.offsets.ensure((uint64_t)(n + 1) * 8));
-    KPOP_TRY(s.twisted.ensure((uint64_t)n * D * 8));
-    if (outs & KPOP_OUT_DISTANCES) KPOP_TRY(s.dist.ensure((uint64_t)n * C * 8));
-    if (outs & (KPOP_OUT_DISTANCES | KPOP_OUT_SUMMARY)) KPOP_TRY(s.work.ensure(kpop_dev_distance_workspace_bytes(C, n, D)));
+    KPOP_TRY(s.bases.ensure(cap_nb));
+    KPOP_TRY(s.offsets.ensure((uint64_t)(cap_n + 1) * 8));
+    KPOP_TRY(s.twisted.ensure((uint64_t)cap_n * D * 8));
+    if (outs & KPOP_OUT_DISTANCES) KPOP_TRY(s.dist.ensure((uint64_t)cap_n * C * 8));
+    if (outs & (KPOP_OUT_DISTANCES | KPOP_OUT_SUMMARY)) KPOP_TRY(s.work.ensure(kpop_dev_distance_workspace_bytes(C, cap_n, D)));
     if (outs & KPOP_OUT_SUMMARY) {
-      KPOP_TRY(s.stats.ensure((uint64_t)n * 4 * 8));
-      KPOP_TRY(s.nn.ensure((uint64_t)n * 4));
-      KPOP_TRY(s.idx.ensure((uint64_t)n * mn * 4));
-      KPOP_TRY(s.ndist.ensure((uint64_t)n * mn * 8));
-      KPOP_TRY(s.z.ensure((uint64_t)n * mn * 8));
+      KPOP_TRY(s.stats.ensure((uint64_t)cap_n * 4 * 8));
+      KPOP_TRY(s.nn.ensure((uint64_t)cap_n * 4));
+      KPOP_TRY(s.idx.ensure((uint64_t)cap_n * mn * 4));
+      KPOP_TRY(s.ndist.ensure((uint64_t)cap_n * mn * 8));
+      KPOP_TRY(s.z.ensure((uint64_t)cap_n * mn * 8));
     }
     // up
     // The slot's previous chunk must have come down before the slot is overwritten.  The HOST waits for that, not the
