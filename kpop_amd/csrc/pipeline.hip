@@ -59,7 +59,7 @@ struct DevMem {  // grow-only device block
 
 struct RingSlot {
   DevMem bases, offsets, twisted, dist, work, stats, nn, idx, ndist, z;
-  hipEvent_t h2d_done = nullptr, compute_done = nullptr, d2h_done = nullptr;
+  hipEvent_t h2d_done = nullptr, twist_done = nullptr, compute_done = nullptr, d2h_done = nullptr;
   bool in_use = false;  // d2h_done has been recorded at least once
 };
 
@@ -149,6 +149,7 @@ static void destroy(kpop_pipeline *pl) {
     DevMem *all[] = {&s.bases, &s.offsets, &s.twisted, &s.dist, &s.work, &s.stats, &s.nn, &s.idx, &s.ndist, &s.z};
     for (DevMem *m : all) m->release();
     if (s.h2d_done) (void)hipEventDestroy(s.h2d_done);
+    if (s.twist_done) (void)hipEventDestroy(s.twist_done);
     if (s.compute_done) (void)hipEventDestroy(s.compute_done);
     if (s.d2h_done) (void)hipEventDestroy(s.d2h_done);
   }
@@ -234,6 +235,7 @@ extern "C" int kpop_pipeline_create(const kpop_twister *tw, const double *classe
     bool ok = true;
     for (RingSlot &s : pl->ring) {
       ok = ok && hipEventCreateWithFlags(&s.h2d_done, hipEventDisableTiming) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&s.twist_done, hipEventDisableTiming) == hipSuccess;
       ok = ok && hipEventCreateWithFlags(&s.compute_done, hipEventDisableTiming) == hipSuccess;
       ok = ok && hipEventCreateWithFlags(&s.d2h_done, hipEventDisableTiming) == hipSuccess;
     }
@@ -402,6 +404,10 @@ extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, con
     const uint8_t *d_bases = s.bases.as<uint8_t>() - b0;
     KPOP_TRY(kpop_dev_count_twist(pl->tw, d_bases, s.offsets.as<uint64_t>(), n, nb, (uint32_t)max_len, pl->cfg.content,
                                   pl->cfg.normalize_counts, s.twisted.as<double>(), pl->s_compute));
+    // the twisted rows can go down while the distances are still being worked out: half of a chunk's bytes, and for the first
+    // chunk of a lone batch that much less time before the downloads start
+    const bool early = (outs & KPOP_OUT_TWISTED) && (outs & (KPOP_OUT_DISTANCES | KPOP_OUT_SUMMARY));
+    if (early) KPOP_HIP(hipEventRecord(s.twist_done, pl->s_compute));
     if (outs & KPOP_OUT_DISTANCES)
       KPOP_TRY(kpop_dev_distance_rowwise_norms(pl->d_classes, C, pl->d_class_norms, s.twisted.as<double>(), n, D, pl->d_metric, pl->cfg.kind,
                                                pl->cfg.p, pl->cfg.normalize_distances, s.work.p, s.dist.as<double>(), pl->s_compute));
@@ -413,9 +419,14 @@ extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, con
     KPOP_TRY(mark(n_chunks, 3, pl->s_compute));
     KPOP_HIP(hipEventRecord(s.compute_done, pl->s_compute));
     // down
+    if (early) {
+      KPOP_HIP(hipStreamWaitEvent(pl->s_d2h, s.twist_done, 0));
+      KPOP_TRY(mark(n_chunks, 4, pl->s_d2h));
+      KPOP_TRY(copy_down(o->twisted + (uint64_t)r0 * D, s.twisted.p, n, (uint64_t)D * 8, pin_tw, pl->s_d2h));
+    }
     KPOP_HIP(hipStreamWaitEvent(pl->s_d2h, s.compute_done, 0));
-    KPOP_TRY(mark(n_chunks, 4, pl->s_d2h));
-    if (outs & KPOP_OUT_TWISTED)
+    if (!early) KPOP_TRY(mark(n_chunks, 4, pl->s_d2h));
+    if ((outs & KPOP_OUT_TWISTED) && !early)
       KPOP_TRY(copy_down(o->twisted + (uint64_t)r0 * D, s.twisted.p, n, (uint64_t)D * 8, pin_tw, pl->s_d2h));
     if (outs & KPOP_OUT_DISTANCES)
       KPOP_TRY(copy_down(o->distances + (uint64_t)r0 * C, s.dist.p, n, (uint64_t)C * 8, pin_di, pl->s_d2h));
