@@ -75,13 +75,68 @@ def parse_args(argv=None):
     ap.add_argument("--f2f-reads", type=int, default=1000000, help="reads of the file-to-file leg")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even at world size 1 (exercises the N>1 code path)")
     ap.add_argument("--spawn", action="store_true", help="start the ranks as a child launcher even for --gpus 1 (tests the relay)")
+    ap.add_argument("--timeout", type=float, default=900.0,
+                    help="the launcher's watchdog: seconds after which it ends the ranks' process group, prints every rank's last lines and exits non-zero")
+    ap.add_argument("--no-fallback", action="store_true",
+                    help="the launcher does not retry a failed RCCL run through --in-process (also KPOP_BENCH_NO_FALLBACK=1)")
     return ap.parse_args(argv)
 
 
 # ---------------------------------------------------------------------------------------------------------
 # the launcher: no torch, no GPU call in this process
 # ---------------------------------------------------------------------------------------------------------
+def _tail(path, n=40):
+    try:
+        with open(path, "rb") as f:
+            return b"\n".join(f.read().splitlines()[-n:]).decode("utf-8", "replace")
+    except OSError:
+        return "(no log)"
+
+
+def _run_child(cmd, env, timeout_s):
+    """start `cmd` in its own process group, relay its stdout looking for the JSON line, and end the whole group if it has not
+    finished after timeout_s -> (rc or None when it timed out, the JSON line or None, seconds)"""
+    import signal
+    import threading
+    t0 = time.time()
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)
+    found = []
+
+    def relay():
+        for raw in proc.stdout:
+            text = raw.decode("utf-8", "replace")
+            at = text.find('{"metric"')  # (a launcher that tees the ranks' output puts a prefix in front)
+            if at >= 0:
+                found.append(text[at:])
+            else:
+                sys.stderr.write(text)
+
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    try:
+        rc = proc.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        rc = None
+        for sig, grace in ((signal.SIGTERM, 5.0), (signal.SIGKILL, 5.0)):
+            try:
+                os.killpg(proc.pid, sig)  # (this process never touches a GPU: it may end its children as it likes)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+    th.join(timeout=5.0)
+    return rc, (found[-1] if found else None), time.time() - t0
+
+
 def self_launch(args):
+    """`bench.py --gpus N` from a plain shell: this process starts the ranks (torch.distributed.run, RCCL), watches them, and -- the
+    first N > 1 run will be somebody else's, on hardware this code has never seen -- leaves something to debug from when they fail:
+    a watchdog (--timeout), every rank's stderr kept in a file of its own and its tail printed, NCCL_DEBUG=WARN, and a second
+    attempt through the one-process C-ABI form (--in-process: peer copies, no RCCL) whose line says that it is a fallback."""
+    import tempfile
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -92,22 +147,54 @@ def self_launch(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL cannot share buffers across ranks without it
     env.setdefault("OMP_NUM_THREADS", "8")
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
-    line = None
-    for raw in proc.stdout:
-        text = raw.decode("utf-8", "replace")
-        if text.startswith('{"metric"'):
-            line = text
-        else:
-            sys.stderr.write(text)
-    rc = proc.wait()
-    if line is not None:
+    env.setdefault("NCCL_DEBUG", "WARN")
+    logdir = tempfile.mkdtemp(prefix="kpop_bench_ranks_")
+    env["KPOP_BENCH_LOGDIR"] = logdir
+    rc, line, took = _run_child(cmd, env, args.timeout)
+    logs = sorted(f for f in os.listdir(logdir) if f.endswith(".stderr"))
+    ok = rc == 0 and line is not None
+    for f in logs:  # the ranks' stderr: all of it (bounded) after a good run, the tail after a bad one
+        text = _tail(os.path.join(logdir, f), 200 if ok else 40)
+        if text.strip():
+            sys.stderr.write("---- %s%s\n%s\n" % (f, "" if ok else " (last 40 lines)", text))
+    if ok:
         sys.stdout.write(line)
         sys.stdout.flush()
-    elif rc == 0:
-        sys.stderr.write("bench.py: the ranks exited 0 but printed no JSON line\n")
-        rc = 1
-    sys.exit(rc)
+        sys.exit(0)
+    reason = ("no rank finished within --timeout %.0f s (the ranks' process group was ended)" % args.timeout if rc is None
+              else "the ranks exited %d" % rc if rc != 0 else "the ranks exited 0 but printed no JSON line")
+    sys.stderr.write("bench.py: %s after %.0f s; %d rank log(s) under %s\n" % (reason, took, len(logs), logdir))
+    if args.no_fallback or os.environ.get("KPOP_BENCH_NO_FALLBACK") == "1":
+        sys.exit(124 if rc is None else (rc or 1))
+    # a FRESH child through the C ABI alone: one process, one host thread per GPU, hipMemcpyPeerAsync instead of RCCL
+    sys.stderr.write("bench.py: trying the same job --in-process (kpop_init_devices + kpop_sharded_*: peer copies, no RCCL)\n")
+    env2 = dict(os.environ)
+    env2.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env2["KPOP_BENCH_FALLBACK_REASON"] = reason
+    rc2, line2, _ = _run_child([sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--in-process"] + ["--in-process"],
+                               env2, args.timeout)
+    if rc2 == 0 and line2 is not None:
+        sys.stdout.write(line2)
+        sys.stdout.flush()
+        sys.exit(0)
+    sys.stderr.write("bench.py: the --in-process attempt %s\n" % ("timed out" if rc2 is None else "exited %d" % rc2))
+    sys.exit(124 if rc is None else (rc or 1))
+
+
+def rank_preamble():
+    """first thing in a rank started by self_launch: its stderr into a file of its own (the launcher prints the tails), and the
+    test switch KPOP_BENCH_FAKE_HANG=<rank>|all -- a rank that never reaches the rendezvous -- before anything touches a GPU"""
+    logdir, rank = os.environ.get("KPOP_BENCH_LOGDIR"), os.environ.get("RANK", "0")
+    if logdir and os.path.isdir(logdir):
+        fd = os.open(os.path.join(logdir, "rank%s.stderr" % rank), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        os.dup2(fd, 2)
+        os.close(fd)
+    hang = os.environ.get("KPOP_BENCH_FAKE_HANG")
+    if hang is not None and hang in (rank, "all"):
+        sys.stderr.write("rank %s: KPOP_BENCH_FAKE_HANG: sleeping instead of joining the rendezvous\n" % rank)
+        sys.stderr.flush()
+        while True:
+            time.sleep(3600)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -313,6 +400,12 @@ class Rank:
         ex = [p[0].elapsed_time(p[1]) for ev in per_step_events for p in ev.get("exposed", [])]
         mine = float(np.sum(ex) / max(len(per_step_events), 1)) if ex else 0.0
         res["ms_exposed_comm_per_rank"] = self.gather_floats(mine)
+        res["ms_compute_per_rank"] = self.gather_floats(res["ms_twist_step"] or 0.0)
+        # how many ranks the COLLECTIVE saw (a sum of ones through it: not the launcher's word for it)
+        ones = t.ones(1, dtype=t.float64, device="cpu" if self.shared_gpu else self.dev)
+        if self.use_dist:
+            self.dist.all_reduce(ones)
+        res["n_ranks_seen"] = int(ones.item())
         res["startup_s_per_rank"] = self.gather_floats(self.startup_s)
         if job.full is not None:
             # the exchange alone, nothing else running: all chunks back to back on the comm stream
@@ -896,6 +989,9 @@ def in_process(args):
     }
     if shared:
         line["config"]["rig"] = "KPOP_BENCH_SHARE_GPU=1: every device slot is GPU 0; not a scaling number"
+    line["n_ranks_seen"] = int(sum(1 for n in n_reads if n > 0))  # (device slots that twisted a shard and pushed it to the others)
+    if os.environ.get("KPOP_BENCH_FALLBACK_REASON"):
+        line["fallback"] = "in-process after RCCL failure: " + os.environ["KPOP_BENCH_FALLBACK_REASON"]
     sh.close()
     print(json.dumps(line))
 
@@ -909,6 +1005,8 @@ def main():
         return
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
         self_launch(args)  # never returns
+    if "WORLD_SIZE" in os.environ:
+        rank_preamble()
     workload = args.workload if args.workload != "auto" else ("headline" if args.gpus == 1 else "config4")
     scaling = args.scaling if args.scaling != "auto" else ("weak" if workload == "headline" else "strong")
     reads = args.reads or (100000 if workload == "headline" else 1000000)
@@ -993,6 +1091,8 @@ def main():
                                    "one launch per chunk of %d reads, overlapped with the exchange of the previous chunk" % res["chunk_rows"]),
             "kernels_ms": {"count_twist_per_step": res["ms_twist_step"], "distance_rowwise(+norms)": res["ms_dist"],
                            "allgather_on_its_stream_per_step": res.get("ms_allgather_step_on_its_stream")},
+            "n_ranks_seen": res.get("n_ranks_seen"),
+            "ms_compute_per_rank": res.get("ms_compute_per_rank"),
             "exposed_comm_ms_per_rank": res.get("ms_exposed_comm_per_rank"),
             "startup_s_per_rank": res.get("startup_s_per_rank"),
             "collective": res.get("allgather"),

@@ -103,6 +103,7 @@ struct Context {
   int tune_dbg = 0;
   int tune_dense = 2;    // the matrix-core routes of the twist: 2 (default) chosen by the batch -- assemblies through count_twist_tile_kernel (consensus on the matrix cores + residual gather), small-k assemblies through the dense image, dense spectra through the contraction --, 1 kpop_twist always dense, 0 never (the sparse mat-vec in the reference's order of additions everywhere)
   int tune_tileg = 64;   // sequences a chunk of count_twist_tile_kernel: 64 (one block of 1,024 threads a CU) or 32 (two of 512: measured slower, 1.96 against 1.64 ms on 5,000 mutants at 0.1 % -- every per-chunk step is paid twice as often)
+  int tune_tilepipe = 1; // assemblies of one organism, up to 64 dimensions: count_twist_tile_pipe_kernel (producer and consumer wavefronts, tile_pipe.h); 0: round 4's count_twist_tile_kernel
   int tune_blocksort = 1;  // -L on sequences of up to 32,768 windows: one block per sequence, sorted in LDS (0: device-wide sort)
   int tune_hist = 1;     // merged (-l) spectrum by atomic histogram when the hashes fit 26 bits (0: always sort)
   int tune_summary2 = 1; // summaries against > 4,096 rows: 1 brackets and bands from a sample + ONE pass over distance rows, 3 the same in two passes (median, then MAD), 0 round 2's one block per row (8-10 passes), 2 the distances computed and reduced in one kernel, no distance rows (131,072 rows and more); 1, 2 and 3 are level at 256 x 1M

@@ -888,6 +888,10 @@ __global__ __launch_bounds__(256) void tile_group_probe_kernel(const uint8_t *__
 // over blocks and chunks; read and cleared by kpop_debug_counters)
 __device__ unsigned long long g_tile_stamps[16];
 
+}  // namespace kpop
+#include "tile_pipe.h"  // count_twist_tile_pipe_kernel: the same scheme as a producer / consumer pipeline (up to 64 dimensions)
+namespace kpop {
+
 // G sequences a chunk: 64 (one block of 1,024 threads a CU, 152 KB of LDS) or 32 (512 threads, 78 KB: TWO blocks a CU, one in
 // its matrix phase while the other waits for bases and index words)
 template <typename H, int G>
@@ -1719,7 +1723,10 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
                  bytes_long = ((uint64_t)n_reads * 4 + 64 + 63) & ~63ull,
                  bytes_olong = tiles ? (((uint64_t)max_long * 4 + 63) & ~63ull) : 0, bytes_gmax = tiles ? (((uint64_t)max_groups * 4 + 63) & ~63ull) : 0,
                  bytes_res = tiles && tw->n_dims > 64 ? max_slots * kTileS * 4 : 0, bytes_todo = tiles ? ((max_slots * 8 + 1024 + 63) & ~63ull) : 0,
-                 bytes_perread = tiles ? bytes_nseg : 0, bytes_wlists = tiles ? (uint64_t)cx.n_cus * 16 * 4 * kTileS * 4 : 0;
+                 bytes_perread = tiles ? bytes_nseg : 0;
+  // up to 64 dimensions: the pipelined kernel (tile_pipe.h; kpop_tune("tilepipe", 0): round 4's kernel, phases one after the other)
+  const bool pipe = tiles && tw->n_dims <= 64 && cx.tune_tilepipe != 0;
+  const uint64_t bytes_wlists = !tiles ? 0 : pipe ? (uint64_t)cx.n_cus * 2 * 8 * kPipeListCap * 4 : (uint64_t)cx.n_cus * 16 * 4 * kTileS * 4;
   void *ws = nullptr;
   KPOP_TRY(ctx().ws_for(st).ensure(bytes_nseg + bytes_off + 2 * bytes_sums + bytes_cnt + bytes_part + bytes_done + bytes_long + bytes_olong + 2 * bytes_gmax +
                                        bytes_res + bytes_todo + 2 * bytes_perread + bytes_wlists, &ws));
@@ -1769,7 +1776,16 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
       once() = true;
     }
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)div_up(max_long, tile_g) * max_seg, (uint64_t)cx.n_cus * (tile_g == 32 ? 2 : 1));
-    if (tile_g == 64)
+    if (pipe) {
+      static PerSlotOnce once_pipe;
+      if (!once_pipe()) {
+        KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&count_twist_tile_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPipeLdsBytes));
+        once_pipe() = true;
+      }
+      const uint32_t pblocks = (uint32_t)std::min<uint64_t>((uint64_t)div_up(max_long, kPipeG) * max_seg, (uint64_t)cx.n_cus);
+      count_twist_tile_pipe_kernel<<<dim3(pblocks), dim3(1024), kPipeLdsBytes, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, olong, sums2 + nb,
+                                                                                     gmax, grel, max_seg, slot_done, wave_lists, ctx().tune_dbg >> 24);
+    } else if (tile_g == 64)
       count_twist_tile_kernel<uint32_t, 64><<<dim3(blocks), dim3(1024), lds, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, olong, sums2 + nb,
                                                                                   gmax, grel, max_seg, slot_done, res_rows, wave_lists, ctx().tune_dbg >> 24);
     else

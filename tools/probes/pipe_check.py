@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""count_twist_tile_pipe_kernel (tile_pipe.h) against the streaming kernel and round 4's tile kernel on small batches of wuhan
+mutants: max relative difference, bit-stability over repeated runs, then (PIPE_TIME=1) ms per call on 5,000 of them.
+Run under `timeout`: a protocol error between the kernel's halves would spin for ever."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import kpop_amd
+    from kpop_amd import api
+    from oracle import oracle as O
+    from tools.cli_kernels_workload import mutants
+    kpop_amd.init(0)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream()
+    k, d = 12, int(os.environ.get("PIPE_D", "64"))
+    tw = kpop_amd.Twister.synth(0x5EED, k, d)
+
+    def run(db, do, n, L, mode, pipe):
+        api.tune("dense", mode)
+        api.tune("tilepipe", pipe)
+        out = torch.zeros(n, d, dtype=torch.float64, device=dev)
+        api.dev_count_twist(tw, db.data_ptr(), do.data_ptr(), n, db.numel(), L, out.data_ptr(), stream=st.cuda_stream)
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    cases = [(int(n), float(r)) for n, r in (c.split(":") for c in os.environ.get("PIPE_CASES", "64:0.001,100:0.01,333:0.003,1000:0.03").split(","))]
+    for n, rate in cases:
+        b, o = mutants(n, rate=rate)
+        if os.environ.get("PIPE_NS"):  # a few Ns and lowercase stretches
+            rng = np.random.RandomState(7)
+            b = b.copy()
+            b[rng.randint(0, b.size, size=b.size // 5000)] = ord("N")
+        db, do = torch.from_numpy(np.ascontiguousarray(b)).to(dev), torch.from_numpy(o.astype(np.int64)).to(dev)
+        L = int(np.diff(o.astype(np.int64)).max())
+        ref = run(db, do, n, L, 0, 0)
+        old = run(db, do, n, L, 2, 0)
+        new = [run(db, do, n, L, 2, 1) for _ in range(3)]
+        sc = np.max(np.abs(ref))
+        print("%5d mutants at %.1f %%: old tile vs streaming %.1e   pipe vs streaming %.1e   pipe run to run identical: %s"
+              % (n, 100 * rate, np.max(np.abs(old - ref)) / sc, np.max(np.abs(new[0] - ref)) / sc,
+                 all(np.array_equal(new[0], x) for x in new[1:])), flush=True)
+    if os.environ.get("PIPE_TIME"):
+        n = int(os.environ.get("PIPE_TIME_N", "5000"))
+        for rate in [float(x) for x in os.environ.get("PIPE_RATES", "0.001,0.01").split(",")]:
+            b, o = mutants(n, rate=rate)
+            db, do = torch.from_numpy(np.ascontiguousarray(b)).to(dev), torch.from_numpy(o.astype(np.int64)).to(dev)
+            L = int(np.diff(o.astype(np.int64)).max())
+            out = torch.zeros(n, d, dtype=torch.float64, device=dev)
+            res = {}
+            for name, mode, pipe in (("streaming", 0, 0), ("tile r4", 2, 0), ("pipe", 2, 1)):
+                api.tune("dense", mode)
+                api.tune("tilepipe", pipe)
+                ms = []
+                for it in range(6):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(st)
+                    api.dev_count_twist(tw, db.data_ptr(), do.data_ptr(), n, db.numel(), L, out.data_ptr(), stream=st.cuda_stream)
+                    e1.record(st)
+                    torch.cuda.synchronize()
+                    ms.append(e0.elapsed_time(e1))
+                res[name] = float(np.median(ms[1:]))
+            print("%d mutants at %.1f %%: " % (n, 100 * rate) + "   ".join("%s %.3f ms" % kv for kv in res.items()), flush=True)
+        if os.environ.get("PIPE_STAMPS"):
+            api.tune("dense", 2)
+            api.tune("tilepipe", 1)
+            api.tune("dbg", 16 << 24)
+            api.debug_counters(16)
+            api.dev_count_twist(tw, db.data_ptr(), do.data_ptr(), n, db.numel(), L, out.data_ptr(), stream=st.cuda_stream)
+            torch.cuda.synchronize()
+            c = api.debug_counters(16)
+            api.tune("dbg", 0)
+            pn = {0: "stage+clear", 1: "seeds+set", 2: "rows+number+X clear", 3: "windows", 4: "misses listed", 5: "their rows+publish", 6: "IN BARRIERS", 7: "WAIT FOR EMPTY"}
+            cn = {8: "WAIT FOR A CHUNK", 9: "mfma loop", 10: "sums out", 11: "IN BARRIERS", 12: "gather tail"}
+            ptot = float(sum(c[i] for i in pn)) or 1.0
+            ctot = float(sum(c[i] for i in cn)) or 1.0
+            print("producer wavefront 8 (%.0f ticks): " % ptot + "   ".join("%s %.3f" % (pn[i], c[i] / ptot) for i in sorted(pn)))
+            print("consumer wavefront 0 (%.0f ticks): " % ctot + "   ".join("%s %.3f" % (cn[i], c[i] / ctot) for i in sorted(cn)))
+    api.tune("dense", 2)
+    api.tune("tilepipe", 1)
+
+
+if __name__ == "__main__":
+    main()
