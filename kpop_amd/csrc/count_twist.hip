@@ -880,7 +880,9 @@ __global__ __launch_bounds__(256) void tile_group_probe_kernel(const uint8_t *__
   }
   if (threadIdx.x == 0) {
     gmax[g] = ns;
-    grel[g] = rel;
+    // (fewer than kTileMinSeqs long sequences: the tile kernels do not try, and segment_count_kernel must not cut them into
+    // stretches of 512 windows for nothing -- 10 related genomes among 100k reads kept the streaming kernel's own segments)
+    grel[g] = n_long < kTileMinSeqs ? 0u : rel;
   }
 }
 

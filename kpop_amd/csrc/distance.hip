@@ -1463,7 +1463,7 @@ __global__ void long_list_keys_kernel(const double *__restrict__ d, uint32_t r1,
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < r1) {
     const double x = d[i];
-    key[i] = x == 0.0 ? 0ull : (uint64_t)__double_as_longlong(x);  // (distances are not negative: their bit patterns sort as they do)
+    key[i] = dist_key(x == 0.0 ? 0.0 : x);  // the kernels' own order (-0 as +0): a caller's matrix may hold negative entries or NaNs
     val[i] = i;
   }
 }
@@ -1512,8 +1512,9 @@ static int fill_long_lists(const LongListSource &src, uint32_t r1, uint32_t r2, 
     KPOP_HIP(hipStreamSynchronize(st));
     const double mean = out_stats[(uint64_t)j * 4 + 0], sd = out_stats[(uint64_t)j * 4 + 1];
     for (uint32_t q = 0; q < m; ++q) {
+      const uint64_t kq = hk[q], bq = (kq >> 63) ? (kq & 0x7FFFFFFFFFFFFFFFull) : ~kq;  // key_dist on the host
       double dq;
-      memcpy(&dq, &hk[q], 8);
+      memcpy(&dq, &bq, 8);
       out_dist[(uint64_t)j * max_neighbours + q] = dq;
       volatile double num = dq - mean;  // (two roundings, as the kernels': no contraction)
       double zz = num / sd;

@@ -22,20 +22,39 @@
 namespace kpop {
 
 constexpr uint32_t kPipeG = 64;                  // sequences a chunk
-constexpr uint32_t kPipeXW = 193;                // dwords of a row of X: 768 one-byte counts + 4 (odd: 16 rows on 16 banks)
+constexpr uint32_t kPipeXW = 194;                // dwords of a row of X: 768 one-byte counts + 8 (2 mod 32: a half-wavefront's 16 rows x 2 columns of a ds_read_b32 on 32 banks)
 constexpr uint32_t kPipeAbsent = 0xFFFFFFFFu;    // a member's number when the twister has no row for it
 constexpr uint32_t kPipeListCap = 8 * kTileS;    // entries of a producer wavefront's residual list: 8 sequences x 512 windows
-constexpr size_t kPipeLdsBytes = (size_t)2 * kPipeG * kPipeXW * 4 + (size_t)kTileH * 8 + (size_t)2 * kTileSetCap * 4 + (size_t)kPipeG * kTileStageW * 4;
+// A sequence's stretch is staged as 2-BIT CODES, in 16-base units (33 of them: 512 windows + up to 14 bases more):
+//   F[33]  the codes first base most significant (a window's forward hash is a funnel shift of two of these dwords),
+//   R[33]  the COMPLEMENTS' codes first base least significant (its reverse complement's hash likewise),
+//   V[17]  one bit a base, set where the byte was not one of ACGT acgt (or lies past the sequence's end): a window is a k-mer
+//          when the k bits from its first base on are clear.
+// Bytes were decoded window by window before (twelve instructions a base, in every window pass); now once per base, four
+// bytes at a time, when the stretch is staged -- and a window's hash no longer rolls out of its predecessor's, so the windows that
+// miss the set are hashed again one by one, not all 64 of a thread.
+constexpr uint32_t kPipeUnits = 33, kPipeRowW = 85;  // dwords of a row: F at 0, R at 33, V at 66; 85 = 21 mod 32: four rows x eight threads' dwords on 32 banks
+constexpr size_t kPipeLdsBytes = (size_t)2 * kPipeG * kPipeXW * 4 + (size_t)kTileH * 8 + (size_t)2 * kTileSetCap * 4 + (size_t)kPipeG * kPipeRowW * 4;
+typedef uint32_t pipe_u32x4_any __attribute__((ext_vector_type(4), aligned(1)));  // sixteen bytes from any address: one global_load_dwordx4
 
 __device__ __forceinline__ uint32_t pipe_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// What the halves share is in LDS, and a wavefront's LDS operations complete in order: "everything I wrote is there" is
+// s_waitcnt lgkmcnt(0).  The compiler's workgroup fences also wait for every GLOBAL load and store in flight (vmcnt(0)) -- here
+// that is the look-ahead's loads of the next chunk's bases and the consumers' rows of T -- so they are used only where global
+// memory carries data between wavefronts (the residual lists, at the hand-over).
+__device__ __forceinline__ void pipe_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // spin until the LDS counter has reached `target`
 __device__ __forceinline__ void pipe_wait(const uint32_t *p, uint32_t target) {
   while ((int32_t)(pipe_ld(p) - target) < 0) __builtin_amdgcn_s_sleep(1);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  pipe_lds_fence();
 }
 // a barrier among the eight wavefronts of a half: everybody adds one, everybody waits for eight more than last time
+template <bool GLOBAL = false>
 __device__ __forceinline__ void pipe_half_barrier(uint32_t *ctr, uint32_t &target, int lane) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (GLOBAL)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  else
+    pipe_lds_fence();
   target += 8u;
   if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   pipe_wait(ctr, target);
@@ -52,16 +71,17 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
   uint32_t *Xw = reinterpret_cast<uint32_t *>(pipe_lds);          // [2][G][XW] four one-byte counts a word
   uint2 *ht = reinterpret_cast<uint2 *>(Xw + 2 * G * XW);         // [kTileH] {k-mer hash (kNoCol = empty), its number in the set}
   uint32_t *ucol = reinterpret_cast<uint32_t *>(ht + kTileH);     // [2][kTileSetCap] twister row of member u
-  uint32_t *stage = ucol + 2 * kTileSetCap;                       // [G][kTileStageW] the stretch's bases
+  uint32_t *stage = ucol + 2 * kTileSetCap;                       // [G][kPipeRowW] the stretch's bases as 2-bit codes: F, R, V
   __shared__ uint64_t s_slot[2][G];   // the group's (sequence, segment) slots, ~0: the sequence has no such segment
   __shared__ uint32_t s_rtot[2][8];   // entries of every producer wavefront's residual list (row | sequence of its eight << 29)
   __shared__ uint32_t s_U[2];         // members as multiplied (padded to 64)
-  __shared__ uint32_t s_align[G];     // the stretch's address modulo 4, per sequence
   __shared__ uint32_t s_pbar, s_cbar, s_full, s_empty, s_done;
   __shared__ uint32_t s_new, s_samp, s_over, s_add[4], s_wbase[8];
+  __shared__ unsigned long long s_stamp[16];  // the phase clocks of this block (kpop_tune("dbg", 16 << 24)), added to g_tile_stamps at the end
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t n_long = (uint32_t)*n_long_ptr;
   if (n_long < kTileMinSeqs) return;  // (too few sequences to share anything: the streaming kernel's)
+  if (threadIdx.x < 16) s_stamp[threadIdx.x] = 0;
   if (threadIdx.x == 0) {
     s_pbar = 0;
     s_cbar = 0;
@@ -76,7 +96,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
   auto stamp = [&](int phase) {
     if (stamps) {
       const unsigned long long now = __builtin_amdgcn_s_memtime();
-      atomicAdd(&g_tile_stamps[phase], now - t_last);
+      atomicAdd(&s_stamp[phase], now - t_last);  // (in LDS: a global atomic per phase was waited for at the next barrier's fence)
       t_last = now;
     }
   };
@@ -87,8 +107,8 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
     const uint32_t myseed = pt >> 7;            // and the seed it hashes four windows of (sequences 0, 16, 32, 48)
     const uint32_t n_groups = (n_long + G - 1) / G;
     const uint64_t n_chunks = (uint64_t)n_groups * max_seg;
-    const int shift = 2 * (k - 1);
-    const uint32_t mask = (uint32_t)bits_mask(2 * k);
+    const uint32_t mask = (uint32_t)bits_mask(2 * k), kmask = (1u << k) - 1u;
+    const uint32_t ssmask = content == KPOP_DNA_DS ? 0u : ~0u;  // (single-stranded: the forward hash whatever the other strand's)
     uint32_t pbar_t = 0, n_pub = 0;
     int misses = 0;
     uint32_t skip = 0, backoff = 8;
@@ -97,7 +117,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
       pipe_half_barrier(&s_pbar, pbar_t, lane);
       if (stamps) {
         const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
-        atomicAdd(&g_tile_stamps[6], dt);
+        atomicAdd(&s_stamp[6], dt);
         t_last += dt;
       }
     };
@@ -131,49 +151,131 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
       const uint32_t b = h & 63u;
       return ((bits >> b) & 1ull) ? q.z + (uint32_t)__popcll(bits & ((1ull << b) - 1ull)) : kNoCol;
     };
-    for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-      // chunks are dealt with the groups fastest: blocks running together work on one stretch of all sequences
-      const uint32_t seg = (uint32_t)(chunk / n_groups), grp = (uint32_t)(chunk % n_groups);
-      const uint32_t pg = (uint32_t)(((uint64_t)grp * G) / kTileProbeG);
-      if (!grel[pg] || seg >= gmax[pg]) continue;  // (not one organism: tile_group_probe_kernel; none of the group's sequences is this long)
-      if (skip) {
+    // The next chunk's (sequence, offset, length, slot) and then its bases are loaded a chunk AHEAD, into registers: three dependent
+    // trips to memory (list of long sequences -> offsets -> bases) that used to open every chunk.
+    // chunks are dealt with the groups fastest: blocks running together work on one stretch of all sequences
+    auto next_chunk = [&](uint64_t from) -> uint64_t {  // the first chunk at or after `from` (a stride of the grid) that is this route's
+      for (; from < n_chunks; from += gridDim.x) {
+        const uint32_t sg = (uint32_t)(from / n_groups), gp = (uint32_t)(from % n_groups);
+        const uint32_t pg = (uint32_t)(((uint64_t)gp * G) / kTileProbeG);
+        if (grel[pg] && sg < gmax[pg]) break;  // (one organism: tile_group_probe_kernel; and some sequence of the group is this long)
+      }
+      return from;
+    };
+    struct Meta {
+      uint32_t r;
+      uint64_t off, len, slot0;
+      uint32_t ns;
+    };
+    auto load_meta = [&](uint64_t c) -> Meta {
+      Meta m{0u, 0ull, 0ull, 0ull, 0u};
+      if (c < n_chunks) {
+        const uint32_t li = (uint32_t)(c % n_groups) * G + sq;
+        if (li < n_long) {
+          m.r = olong[li];
+          m.off = offsets[m.r];
+          m.len = offsets[m.r + 1] - m.off;
+          m.ns = nseg[m.r];
+          m.slot0 = seg_off[m.r];
+        }
+      }
+      return m;
+    };
+    // the thread's five 16-byte units of a stretch (units tq, tq + 8, ...: eight threads, one sequence), ALL asked for before any
+    // is looked at.  A unit that the sequence ends in is loaded as the sequence's LAST sixteen bytes and shifted down when it is
+    // stored; one past the end is not loaded (the stretch's first bytes stand in: nothing reads past the caller's buffer).
+    auto load_units = [&](const Meta &m, uint64_t c, uint4 (&v)[5], int &avail) {
+      const uint32_t sg = (uint32_t)(c / n_groups);
+      const bool mine = c < n_chunks && sg < m.ns;
+      const uint64_t s_beg = (uint64_t)sg * kTileS;
+      const uint8_t *ga = bases + (mine ? m.off + s_beg : 0ull);
+      avail = mine ? (int)min<uint64_t>(m.len - s_beg, (uint64_t)(kTileS + k - 1)) : 0;  // (a stretch of this route has >= 16 bases: its sequence has more than 512 windows)
+#pragma unroll
+      for (uint32_t r = 0; r < 5; ++r) {
+        const int b0 = 16 * (int)(tq + 8u * r);
+        const int at = b0 + 16 <= avail ? b0 : (b0 < avail ? avail - 16 : 0);
+        const pipe_u32x4_any w = *reinterpret_cast<const pipe_u32x4_any *>(ga + at);
+        v[r] = make_uint4(w.x, w.y, w.z, w.w);
+      }
+    };
+    // four ASCII bytes -> their 2-bit codes one a byte (A0 C1 G2 T3, either case), and bit 7 of every byte that is none of them
+    auto decode4 = [](uint32_t w, uint32_t &code, uint32_t &bad) {
+      const uint32_t u = w & 0xDFDFDFDFu;                       // fold case
+      const uint32_t x = (u >> 1) & 0x03030303u;                // A0 C1 T2 G3
+      code = x ^ ((x >> 1) & 0x01010101u);                      // A0 C1 G2 T3
+      const uint32_t back = __builtin_amdgcn_perm(0u, 0x54474341u, code);  // the letter every code stands for: "ACGT"[code]
+      const uint32_t d = back ^ u;                              // a byte that is not zero: not that letter, i.e. none of the four
+      bad = (((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u;
+    };
+    // ... and into LDS, a chunk later, as codes
+    auto store_units = [&](const uint4 (&v)[5], int avail) {
+      uint32_t *row = stage + sq * kPipeRowW;
+#pragma unroll
+      for (uint32_t r = 0; r < 5; ++r) {
+        const uint32_t u = tq + 8u * r;
+        if (u < kPipeUnits) {
+          const int b0 = 16 * (int)u;
+          uint32_t w[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+          if (b0 + 16 > avail) {  // (the unit the sequence ends in, or one past it: rare)
+            if (b0 >= avail) {
+              w[0] = w[1] = w[2] = w[3] = 0u;
+            } else {  // loaded as bytes [avail - 16, avail): down by sh = b0 + 16 - avail bytes, zeros behind
+              const uint32_t sh = (uint32_t)(b0 + 16 - avail), ds = sh >> 2, bs = sh & 3u;
+              uint32_t t[5];
+#pragma unroll
+              for (uint32_t j = 0; j < 5; ++j) {
+                t[j] = 0u;
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) t[j] = (j + ds == q) ? w[q] : t[j];
+              }
+#pragma unroll
+              for (uint32_t j = 0; j < 4; ++j) w[j] = __builtin_amdgcn_alignbyte(t[j + 1], t[j], bs);
+            }
+          }
+          uint32_t L = 0, V = 0;  // codes first base least significant; a bit a base that is no base
+#pragma unroll
+          for (uint32_t j = 0; j < 4; ++j) {
+            uint32_t c, bad;
+            decode4(w[j], c, bad);
+            c |= c >> 6;                        // bytes 0,1 -> bits 0..3; bytes 2,3 -> bits 16..19
+            c = (c | (c >> 12)) & 0xFFu;        // four codes, first base lowest
+            L |= c << (8u * j);
+            const uint32_t t = bad >> 7;        // bits 0, 8, 16, 24
+            const uint32_t g = ((t | (t >> 7)) | ((t >> 14) | (t >> 21))) & 0xFu;
+            V |= g << (4u * j);
+          }
+          uint32_t F = __builtin_bitreverse32(L);                           // first base highest, every code's two bits swapped ...
+          F = ((F >> 1) & 0x55555555u) | ((F & 0x55555555u) << 1);          // ... and back
+          row[u] = F;
+          row[kPipeUnits + u] = ~L;
+          reinterpret_cast<uint16_t *>(row + 2 * kPipeUnits)[u] = (uint16_t)V;
+        }
+      }
+      if (tq == 0) reinterpret_cast<uint16_t *>(row + 2 * kPipeUnits)[kPipeUnits] = 0xFFFFu;  // (bases 528..543: none)
+    };
+    uint64_t chunk = next_chunk(blockIdx.x);
+    Meta cm = load_meta(chunk);
+    uint4 cv[5];
+    int cavail;
+    load_units(cm, chunk, cv, cavail);
+    while (chunk < n_chunks) {
+      if (skip) {  // (a block that met four chunks in a row that shared too little skips ahead: the look-ahead starts again)
         --skip;
+        chunk = next_chunk(chunk + gridDim.x);
+        cm = load_meta(chunk);
+        load_units(cm, chunk, cv, cavail);
         continue;
       }
+      const uint32_t seg = (uint32_t)(chunk / n_groups);
       const uint32_t buf = n_pub & 1u;
-      const uint32_t li = grp * G + sq;
-      uint32_t r = 0;
-      uint64_t off = 0, len = 0;
-      bool mine = false;
-      if (li < n_long) {
-        r = olong[li];
-        off = offsets[r];
-        len = offsets[r + 1] - off;
-        mine = seg < nseg[r];
-      }
-      const uint64_t s_beg = (uint64_t)seg * kTileS;  // the stretch's first base (and window) in the sequence
-      // ---- 0. the stretch's bases into LDS as aligned dwords (bytes past either end of the sequence are zeros: no window there),
-      // the set cleared.  The barrier first: everybody is done with the last chunk's stage and set.
+      const bool mine = seg < cm.ns;
+      const uint64_t my_slot = mine ? cm.slot0 + seg : ~0ull;
+      // ---- 0. the stretch's bases into LDS, the set cleared.  The barrier first: everybody is done with the last chunk's stage and set.
       pbar();
-      {
-        const uint8_t *ga = bases + off + s_beg;
-        const uint32_t a = mine ? (uint32_t)(reinterpret_cast<uintptr_t>(ga) & 3u) : 0u;
-        const int avail = mine ? (int)min<uint64_t>(len - s_beg, (uint64_t)(kTileS + k - 1)) : 0;
-        uint32_t v[17];
-#pragma unroll
-        for (uint32_t j = 0; j < 17; ++j) {
-          const int b0 = 4 * (int)(tq + 8u * j) - (int)a;
-          v[j] = 0;
-          if (b0 >= 0 && b0 + 4 <= avail)
-            v[j] = *reinterpret_cast<const uint32_t *>(ga + b0);
-          else
-            for (int q = 0; q < 4; ++q)
-              if (b0 + q >= 0 && b0 + q < avail) v[j] |= (uint32_t)ga[b0 + q] << (8 * q);
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < 17; ++j) stage[sq * kTileStageW + tq + 8u * j] = v[j];
-        if (tq == 0) s_align[sq] = a;
-      }
+      store_units(cv, cavail);
+      // the chunk after this one: its sequences now, its bases once those are known (after the seeds' turn)
+      const uint64_t nchunk = next_chunk(chunk + gridDim.x);
+      const Meta nm = load_meta(nchunk);
 #pragma unroll
       for (uint32_t q = 0; q < kTileH / 512; ++q) ht[pt + 512u * q] = make_uint2(kNoCol, kPipeAbsent);
       if (pt == 0) {
@@ -184,32 +286,24 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
       if (pt < 4) s_add[pt] = 0;
       pbar();
       stamp(0);  // the bases staged, the set cleared
-      // ---- 1. the seeds: four windows a thread, hashed out of LDS
-      uint32_t sh4[4] = {kNoCol, kNoCol, kNoCol, kNoCol};
+      // ---- 1. the seeds: four windows a thread (4 w .. 4 w + 3 of its seed: one unit's dwords and the next's)
+      uint32_t sh4[4];
       {
-        const uint32_t sseq = 16u * myseed, p0 = s_align[sseq] + 4u * (pt & 127u);
-        const uint32_t *rowp = stage + sseq * kTileStageW + (p0 >> 2);
-        uint32_t d[6], by[5];
+        const uint32_t *row = stage + 16u * myseed * kPipeRowW;
+        const uint32_t w0 = 4u * (pt & 127u), j = w0 >> 4, o = w0 & 15u;
+        const uint32_t Fa = row[j], Fb = row[j + 1], Ra = row[kPipeUnits + j], Rb = row[kPipeUnits + j + 1];
+        const uint32_t jv = w0 >> 5;
+        const uint64_t VV = (((uint64_t)row[2 * kPipeUnits + jv + 1] << 32) | row[2 * kPipeUnits + jv]) >> (w0 & 31u);
+        const uint64_t T = ((uint64_t)Fa << 32) | Fb, U = ((uint64_t)Rb << 32) | Ra;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) d[i] = rowp[i];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) by[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], p0 & 3u);
-        uint32_t fwd = 0, rc = 0;
-        int run = 0;
-#pragma unroll
-        for (int j = 0; j < 18; ++j)
-          if (j < k + 3) {  // (uniform)
-            const uint32_t c = base_code((by[j >> 2] >> (8 * (j & 3))) & 0xFFu);
-            fwd = ((fwd << 2) | (c & 3u)) & mask;
-            rc = (rc >> 2) | ((3u - (c & 3u)) << shift);
-            run = c < 4u ? run + 1 : 0;
-            const uint32_t hv = (run >= k) ? ((content == KPOP_DNA_DS && rc < fwd) ? rc : fwd) : kNoCol;
-            const int i = j - (k - 1);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (i == q) sh4[q] = hv;
-          }
+        for (uint32_t i = 0; i < 4; ++i) {
+          const uint32_t fwd = (uint32_t)(T >> (64u - 2u * (o + i) - 2u * (uint32_t)k)) & mask;
+          const uint32_t rc = (uint32_t)(U >> (2u * (o + i))) & mask;
+          const bool good = (((uint32_t)VV >> i) & kmask) == 0u;
+          sh4[i] = good ? min(fwd, rc | ssmask) : kNoCol;
+        }
       }
+      stamp(13);  // the seeds hashed
       // ---- 2. the consensus set: a PRIMARY seed's k-mers whole; then the other seeds, admitted in order while the set stays
       // within kTileSetCap members, by what each would add at most.  The primary is seed 0 -- unless every other seed finds fewer
       // than half of its k-mers there (sequence 0 of the group is the odd one out): then the set is started again from seed 1.
@@ -264,8 +358,10 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
         }
         break;
       }
-      pbar();
       stamp(1);  // the set built
+      load_units(nm, nchunk, cv, cavail);  // (in flight under everything below)
+      stamp(14);  // the next chunk's bases asked for (its sequences' offsets waited for)
+      pbar();
       // ---- 3. the members' rows (four slots of the table a thread: the only look-ups in the twister's index besides the misses),
       // the members that HAVE a row numbered in table order; then this chunk's X cleared (once the consumers are done with it)
       uint32_t UP;
@@ -293,7 +389,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
           pipe_wait(&s_empty, 8u * (n_pub - 1u));
           if (stamps) {
             const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
-            atomicAdd(&g_tile_stamps[7], dt);
+            atomicAdd(&s_stamp[7], dt);
             t_last += dt;
           }
         }
@@ -310,7 +406,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           if (rows[i] != kNoCol) {
-            ht[4u * pt + i].y = before;
+            ht[4u * pt + i].y = (before >> 2) | ((before & 3u) << 30);  // (the member's count: dword of the row | byte of it, as << 27 gives the shift)
             uc[before] = rows[i];
             ++before;
           }
@@ -324,81 +420,78 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
       // ---- 4. every window against the set, eight at a time: a hit counts into X, a miss is remembered (a bit a window)
       uint64_t missm = 0;
       uint32_t found = 0;
-      const uint32_t a = s_align[sq];
-      const uint32_t *sg = stage + sq * kTileStageW + tq * 16u;
-      const uint32_t sh = a + (uint32_t)(k - 1);
-      const uint32_t *sm = sg + (sh >> 2);
-      auto warm = [&](uint32_t &fwd, uint32_t &rc, int &run) {  // the k - 1 bases before the first window's last base
-        uint32_t pw4[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pw4[i] = __builtin_amdgcn_alignbyte(sg[i + 1], sg[i], a);
-        fwd = 0;
-        rc = 0;
-        run = 0;
-#pragma unroll
-        for (int j = 0; j < 14; ++j)
-          if (j < k - 1) {  // (uniform)
-            const uint32_t c = base_code((pw4[j >> 2] >> (8 * (j & 3))) & 0xFFu);
-            fwd = ((fwd << 2) | (c & 3u)) & mask;
-            rc = (rc >> 2) | ((3u - (c & 3u)) << shift);
-            run = c < 4u ? run + 1 : 0;
-          }
-      };
-      // the hashes of windows 8 b .. 8 b + 7 of the thread (rolled on from the state), and which of them are k-mers
-      auto batch = [&](uint32_t b, uint32_t &fwd, uint32_t &rc, int &run, uint32_t (&h)[8]) -> uint32_t {
-        const uint32_t m0 = __builtin_amdgcn_alignbyte(sm[2 * b + 1], sm[2 * b], sh & 3u), m1 = __builtin_amdgcn_alignbyte(sm[2 * b + 2], sm[2 * b + 1], sh & 3u);
-        uint32_t vm = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < 8; ++i) {
-          const uint32_t c = base_code(((i < 4 ? m0 : m1) >> (8u * (i & 3u))) & 0xFFu);
-          fwd = ((fwd << 2) | (c & 3u)) & mask;
-          rc = (rc >> 2) | ((3u - (c & 3u)) << shift);
-          run = c < 4u ? run + 1 : 0;
-          h[i] = (content == KPOP_DNA_DS && rc < fwd) ? rc : fwd;
-          vm |= run >= k ? (1u << i) : 0u;
-        }
-        return vm;
+      const uint32_t *row = stage + sq * kPipeRowW;
+      // the hash of window w of the stretch (any w: the dwords come from LDS), kNoCol where there is no k-mer
+      auto hash_at = [&](uint32_t w) -> uint32_t {
+        const uint32_t j = w >> 4, o = w & 15u, jv = w >> 5;
+        const uint64_t T = ((uint64_t)row[j] << 32) | row[j + 1], U = ((uint64_t)row[kPipeUnits + j + 1] << 32) | row[kPipeUnits + j];
+        const uint64_t VV = (((uint64_t)row[2 * kPipeUnits + jv + 1] << 32) | row[2 * kPipeUnits + jv]) >> (w & 31u);
+        const uint32_t fwd = (uint32_t)(T >> (64u - 2u * o - 2u * (uint32_t)k)) & mask, rc = (uint32_t)(U >> (2u * o)) & mask;
+        return ((uint32_t)VV & kmask) == 0u ? min(fwd, rc | ssmask) : kNoCol;
       };
       {
-        uint32_t fwd, rc, valid = 0, hits = 0, over = 0;
-        int run;
-        warm(fwd, rc, run);
+        // (X counts in single bytes and the additions do not report back: a returning LDS atomic per window, its result looked at at
+        // once, was a trip to the LDS and back per window, 64 in a row.  A count can pass 255 only if one of the sequence's eight
+        // threads adds 32 or more of ITS 64 windows to one member; 32 occurrences among 64 consecutive windows leave at least 15
+        // of them one or two windows after the one before -- c12 below, which ordinary sequence keeps at zero and a homopolymer or
+        // dinucleotide run does not.)
+        uint32_t valid = 0, absent = 0, c12 = 0, hp1 = kNoCol, hp2 = kNoCol;
         uint32_t *Xs = Xw + buf * G * XW + sq * XW;
+        const uint32_t fsh = 32u - 2u * (uint32_t)k;
 #pragma unroll 1
-        for (uint32_t b = 0; b < 8; ++b) {
-          uint32_t h[8];
-          const uint32_t vm = batch(b, fwd, rc, run, h);
-          uint2 e[8];
+        for (uint32_t q = 0; q < 4; ++q) {  // sixteen windows a turn: one unit's dwords and the next's
+          const uint32_t j = 4u * tq + q;
+          const uint32_t Fa = row[j], Fb = row[j + 1], Ra = row[kPipeUnits + j], Rb = row[kPipeUnits + j + 1];
+          const uint32_t VV = reinterpret_cast<const uint16_t *>(row + 2 * kPipeUnits)[j] |
+                              ((uint32_t)reinterpret_cast<const uint16_t *>(row + 2 * kPipeUnits)[j + 1] << 16);  // bases 16 j .. 16 j + 31
 #pragma unroll
-          for (uint32_t i = 0; i < 8; ++i) e[i] = ht[set_slot(h[i])];
+          for (uint32_t half = 0; half < 2; ++half) {
+            uint32_t h[8], vm = 0;
 #pragma unroll
-          for (uint32_t i = 0; i < 8; ++i)
-            if ((vm >> i) & 1u) {
-              uint2 ee = e[i];
-              if (ee.x != h[i] && ee.x != kNoCol) {  // (a first probe that met another k-mer: walk on)
-                uint32_t slot = set_slot(h[i]);
-#pragma unroll 1
-                for (uint32_t t = 0; t < kTileH && ee.x != h[i] && ee.x != kNoCol; ++t) {
-                  slot = (slot + 1) & (kTileH - 1);
-                  ee = ht[slot];
-                }
-              }
-              ++valid;
-              if (ee.x == h[i]) {
-                ++hits;
-                if (ee.y != kPipeAbsent) {
-                  const uint32_t sft = 8u * (ee.y & 3u);
-                  const uint32_t old = atomicAdd(&Xs[ee.y >> 2], 1u << sft);
-                  over |= ((old >> sft) & 0xFFu) == 0xFFu ? 1u : 0u;
-                  ++found;
-                }
-              } else
-                missm |= 1ull << (8u * b + i);
+            for (uint32_t i = 0; i < 8; ++i) {
+              const uint32_t o = 8u * half + i;
+              const uint32_t fwd = (o ? __builtin_amdgcn_alignbit(Fa, Fb, 32u - 2u * o) : Fa) >> fsh;
+              const uint32_t rc = (o ? __builtin_amdgcn_alignbit(Rb, Ra, 2u * o) : Ra) & mask;
+              h[i] = min(fwd, rc | ssmask);
+              vm |= ((VV >> o) & kmask) == 0u ? (1u << i) : 0u;
             }
+            uint2 e[8];
+#pragma unroll
+            for (uint32_t i = 0; i < 8; ++i) e[i] = (dbg & 8) ? make_uint2(h[i], i) : ht[set_slot(h[i])];
+#pragma unroll
+            for (uint32_t i = 0; i < 8; ++i) {
+              c12 += (((vm >> i) & 1u) && (h[i] == hp1 || h[i] == hp2)) ? 1u : 0u;
+              hp2 = hp1;
+              hp1 = h[i];
+            }
+            valid += (uint32_t)__popc(vm);
+#pragma unroll
+            for (uint32_t i = 0; i < 8; ++i)
+              if ((vm >> i) & 1u) {
+                uint2 ee = e[i];
+                if (ee.x != h[i] && ee.x != kNoCol) {  // (a first probe that met another k-mer: walk on)
+                  uint32_t slot = set_slot(h[i]);
+#pragma unroll 1
+                  for (uint32_t t = 0; t < kTileH && ee.x != h[i] && ee.x != kNoCol; ++t) {
+                    slot = (slot + 1) & (kTileH - 1);
+                    ee = ht[slot];
+                  }
+                }
+                if (ee.x == h[i]) {
+                  if (ee.y != kPipeAbsent && !(dbg & 2))  // .y: the member's byte of X -- the dword's offset in the row | which byte << 30
+                    (void)__hip_atomic_fetch_add(Xs + (ee.y & 0xFFFFu), 1u << (ee.y >> 27), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  else
+                    ++absent;
+                } else
+                  missm |= 1ull << (16u * q + 8u * half + i);
+              }
+          }
         }
+        const uint32_t nmiss = (uint32_t)__popcll(missm), hits = valid - nmiss;
+        found = hits - absent;
         const uint32_t vh = valid | (hits << 16);
         if (vh) atomicAdd(&s_samp, vh);
-        if (over) s_over = 1u;
+        if (c12 >= 15u) s_over = 1u;
       }
       pbar();
       stamp(3);  // the windows counted
@@ -412,6 +505,8 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
             skip = backoff;
             backoff = min(backoff * 2u, 1u << 20);
           }
+          chunk = nchunk;
+          cm = nm;
           continue;
         }
       }
@@ -433,18 +528,12 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
         uint32_t wout = 0;  // entries that HAVE a row: the list as the consumers read it
         if (wtot) {  // (uniform)
           {
-            uint32_t fwd, rc;
-            int run;
-            warm(fwd, rc, run);
             uint32_t pos = incl - rcnt;
-#pragma unroll 1
-            for (uint32_t b = 0; b < 8; ++b) {
-              uint32_t h[8];
-              (void)batch(b, fwd, rc, run, h);
-              const uint32_t mb = (uint32_t)(missm >> (8u * b)) & 0xFFu;
-#pragma unroll
-              for (uint32_t i = 0; i < 8; ++i)
-                if ((mb >> i) & 1u) wl[pos++] = h[i];
+            uint64_t mm = missm;
+            while (mm) {  // (the thread's misses, in window order: each one hashed again by itself)
+              const uint32_t i = (uint32_t)__ffsll((long long)mm) - 1u;
+              mm &= mm - 1ull;
+              wl[pos++] = hash_at(64u * tq + i);
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -477,11 +566,10 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
           found += present;
         }
         if (tq == 0) {
-          const uint64_t slot = mine ? seg_off[r] + seg : ~0ull;
-          s_slot[buf][sq] = slot;
+          s_slot[buf][sq] = my_slot;
           if (mine) {
-            slot_done[slot] = 1u;
-            partial_cnt[slot] = found;
+            slot_done[my_slot] = 1u;
+            partial_cnt[my_slot] = found;
           }
         }
         if (lane == 0) s_rtot[buf][pw] = wout;
@@ -490,14 +578,22 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
         atomicAdd(&g_tile_stamps[14], 1ull);
         atomicAdd(&g_tile_stamps[15], (unsigned long long)UP);
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      pbar();
+      pipe_half_barrier<true>(&s_pbar, pbar_t, lane);  // (the lists are in global memory: this barrier waits for the stores too)
       ++n_pub;
-      if (pt == 0) __hip_atomic_store(&s_full, n_pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (pt == 0) __hip_atomic_store(&s_full, n_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (after the barrier: everybody's LDS and global writes are done)
       stamp(5);  // the misses' rows found, the chunk handed over
+      chunk = nchunk;
+      cm = nm;
     }
     pbar();
-    if (pt == 0) __hip_atomic_store(&s_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (pt == 0) __hip_atomic_store(&s_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (stamps) {
+      for (int i = 0; i < 8; ++i) atomicAdd(&g_tile_stamps[i], s_stamp[i]);
+      if (!(dbg & 32)) {
+        atomicAdd(&g_tile_stamps[13], s_stamp[13]);
+        atomicAdd(&g_tile_stamps[14], s_stamp[14]);
+      }
+    }
     return;
   }
   // ===================================================================== CONSUMER
@@ -512,15 +608,16 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
     pipe_half_barrier(&s_cbar, cbar_t, lane);
     if (stamps) {
       const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
-      atomicAdd(&g_tile_stamps[11], dt);
+      atomicAdd(&s_stamp[11], dt);
       t_last += dt;
     }
   };
   for (;;) {
     bool got = false;
     for (;;) {
-      const uint32_t dn = __hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const uint32_t fl = __hip_atomic_load(&s_full, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t dn = pipe_ld(&s_done);  // (read before s_full: done is set after the last chunk's hand-over)
+      pipe_lds_fence();
+      const uint32_t fl = pipe_ld(&s_full);
       if ((int32_t)(fl - n_con) > 0) {
         got = true;
         break;
@@ -529,7 +626,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
       __builtin_amdgcn_s_sleep(2);
     }
     if (!got) break;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    pipe_lds_fence();
     stamp(8);  // waited for a chunk
     const uint32_t buf = n_con & 1u;
     const uint32_t UP = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_U[buf]), nb = UP / 16u;
@@ -610,20 +707,20 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
 #pragma unroll
       for (uint32_t s = 0; s < 4; ++s) {
         const uint32_t b = b0 + s;
-        if (s == 0) gather_issue(gv, gj, entA);
-        if (s == 2) gather_issue(gv, gj, entB);
+        if (s == 0 && !(dbg & 4)) gather_issue(gv, gj, entA);
+        if (s == 2 && !(dbg & 4)) gather_issue(gv, gj, entB);
         load_rows(bs[(s + 3u) & 3u], uqn);  // block b + 3's rows of T
         uqn = *reinterpret_cast<const uint4 *>(uc + 16u * min(b + 4u, nb - 1u));
         const uint32_t bx = min(b + 1u, nb - 1u);
         const uint32_t an0 = xa[4u * bx], an1 = xa[16u * XW + 4u * bx];
 #pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {
+        for (uint32_t j = 0; j < 4 && !(dbg & 1); ++j) {
           acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)((a0 >> (8u * j)) & 0xFFu), bs[s][j], acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)((a1 >> (8u * j)) & 0xFFu), bs[s][j], acc1, 0, 0, 0);
         }
         a0 = an0;
         a1 = an1;
-        if ((s & 1u) == 1) gather_add(gv, gj);
+        if ((s & 1u) == 1 && !(dbg & 4)) gather_add(gv, gj);
       }
     }
     stamp(9);  // the matrix cores
@@ -636,7 +733,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
     }
     // the wavefront's list (all of it after the MFMAs' share), then its eight sequences' sums
     // (two batches in flight: sixteen rows a wavefront)
-    if (gpos < wcnt) {
+    if (gpos < wcnt && !(dbg & 4)) {
       gather_issue(gv, gj, entA);
       while (gpos < wcnt) {
         gather_issue(gv2, gj2, entB);
@@ -655,11 +752,13 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
       const double v = __dadd_rn(R[sqn * 64u + (uint32_t)lane], rsum[j]);
       if (sl != ~0ull && (uint32_t)lane < tv.n_dims) partial[sl * tv.n_dims + lane] = v;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) __hip_atomic_fetch_add(&s_empty, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    pipe_lds_fence();  // (done reading this buffer's X, rows and slots)
+    if (lane == 0) __hip_atomic_fetch_add(&s_empty, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     ++n_con;
     stamp(10);  // the sums written
   }
+  if (stamps)
+    for (int i = 8; i < 13; ++i) atomicAdd(&g_tile_stamps[i], s_stamp[i]);  // (the consumers' entries)
 }
 
 }  // namespace kpop

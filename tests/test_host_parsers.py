@@ -9,12 +9,15 @@ import pytest
 
 from conftest import ROOT
 
+# KPOP_TEST_SANITIZE=1 (tools/sanitize_host.sh): the harnesses are built with AddressSanitizer + UBSan like kpop_amd/bin_asan
+SAN = ["-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if os.environ.get("KPOP_TEST_SANITIZE") == "1" else []
+
 
 @pytest.fixture(scope="module")
 def harness(tmp_path_factory):
     out = tmp_path_factory.mktemp("parser_diff") / "parser_diff"
     src = os.path.join(ROOT, "tests", "host", "parser_diff.cpp")
-    subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", "-o", str(out), src, os.path.join(ROOT, "kpop_amd", "host", "kpop_text.cpp")],
+    subprocess.run(["g++", "-O1", "-std=c++17", "-pthread"] + SAN + ["-o", str(out), src, os.path.join(ROOT, "kpop_amd", "host", "kpop_text.cpp")],
                    check=True)
     return str(out)
 
@@ -47,7 +50,7 @@ def test_threaded_parser_agrees_with_sequential_one(harness, tmp_path):
 def seq_harness(tmp_path_factory):
     out = tmp_path_factory.mktemp("seq_diff") / "seq_diff"
     host = os.path.join(ROOT, "kpop_amd", "host")
-    subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", "-o", str(out), os.path.join(ROOT, "tests", "host", "seq_diff.cpp"),
+    subprocess.run(["g++", "-O1", "-std=c++17", "-pthread"] + SAN + ["-o", str(out), os.path.join(ROOT, "tests", "host", "seq_diff.cpp"),
                     os.path.join(host, "kpop_text.cpp"), os.path.join(host, "fast_seq.cpp")], check=True)
     return str(out)
 

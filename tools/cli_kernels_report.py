@@ -78,8 +78,12 @@ def main(d, sq_root=None):
             gbs = ab / (avg * 1e-3) / 1e9
             work, ach = "%.4g" % ab, "%.0f GB/s" % gbs
             if bound == "hbm":
+                # a fraction above 1 means the bytes did not come from HBM: the workload named the wrong bound (an L2- or
+                # Infinity-Cache-resident case) -- refuse to print it rather than publish it
+                assert gbs / 8000 <= 1.0, "%s / %s: %.0f GB/s of algorithmic bytes cannot be HBM-bound (traffic %s): fix the section's bound in cli_kernels_workload.py" % (name, kn, gbs, traffic)
                 frac = "%.3f of 8 TB/s" % (gbs / 8000)
             elif bound == "l2":
+                assert gbs / 34500 <= 1.0, "%s / %s: %.0f GB/s exceeds the L2s' 34.5 TB/s" % (name, kn, gbs)
                 frac = "%.3f of 34.5 TB/s" % (gbs / 34500)
             elif bound == "valu":
                 frac = "%.2f of the VALU issue rate" % busy[kn] if kn in busy else "(instruction-bound: SQ counters)"

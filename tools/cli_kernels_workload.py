@@ -110,7 +110,8 @@ def main():
             for _ in range(a.reps):
                 api.dev_twist(tw, dh.data_ptr(), dv.data_ptr(), do.data_ptr(), ng, int(np.diff(o.astype(np.int64)).max()), out.data_ptr(), stream=sp)
             torch.cuda.synchronize()
-            algo["twist_csr_kernel"] = {"bytes": len(h) * 16 + len(h) * d * 8 + ng * d * 8, "note": "lines + one twister row per line + the twisted row"}
+            algo["twist_csr_kernel"] = {"bytes": len(h) * 16 + len(h) * d * 8 + ng * d * 8, "bound": "l2",
+                                        "note": "lines + one twister row per line + the twisted row; mutants of one genome: the same ~30k rows (15 MB) for every spectrum, served by the L2s and the Infinity Cache -- HBM traffic is a tenth of these bytes"}
         else:
             db, do = torch.from_numpy(np.ascontiguousarray(mb)).to(dev), torch.from_numpy(np.asarray(mo, dtype=np.int64)).to(dev)
             out = torch.zeros(ng, d, dtype=torch.float64, device=dev)

@@ -55,7 +55,10 @@ def main():
             L = int(np.diff(o.astype(np.int64)).max())
             out = torch.zeros(n, d, dtype=torch.float64, device=dev)
             res = {}
+            only = os.environ.get("PIPE_ONLY")
             for name, mode, pipe in (("streaming", 0, 0), ("tile r4", 2, 0), ("pipe", 2, 1)):
+                if only and name != only:
+                    continue
                 api.tune("dense", mode)
                 api.tune("tilepipe", pipe)
                 ms = []
@@ -68,6 +71,21 @@ def main():
                     ms.append(e0.elapsed_time(e1))
                 res[name] = float(np.median(ms[1:]))
             print("%d mutants at %.1f %%: " % (n, 100 * rate) + "   ".join("%s %.3f ms" % kv for kv in res.items()), flush=True)
+        if os.environ.get("PIPE_ABLATE"):  # results are wrong: timing only
+            api.tune("dense", 2)
+            api.tune("tilepipe", 1)
+            for bits in [int(x) for x in os.environ["PIPE_ABLATE"].split(",")]:
+                api.tune("dbg", bits << 24)
+                ms = []
+                for it in range(5):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(st)
+                    api.dev_count_twist(tw, db.data_ptr(), do.data_ptr(), n, db.numel(), L, out.data_ptr(), stream=st.cuda_stream)
+                    e1.record(st)
+                    torch.cuda.synchronize()
+                    ms.append(e0.elapsed_time(e1))
+                print("   ablation bits %2d (1 no MFMA, 2 no X adds, 4 no gather, 8 no set look-ups): %.3f ms" % (bits, float(np.median(ms[1:]))), flush=True)
+            api.tune("dbg", 0)
         if os.environ.get("PIPE_STAMPS"):
             api.tune("dense", 2)
             api.tune("tilepipe", 1)
@@ -77,7 +95,7 @@ def main():
             torch.cuda.synchronize()
             c = api.debug_counters(16)
             api.tune("dbg", 0)
-            pn = {0: "stage+clear", 1: "seeds+set", 2: "rows+number+X clear", 3: "windows", 4: "misses listed", 5: "their rows+publish", 6: "IN BARRIERS", 7: "WAIT FOR EMPTY"}
+            pn = {0: "stage+clear", 1: "seeds+set", 2: "rows+number+X clear", 3: "windows", 4: "misses listed", 5: "their rows+publish", 6: "IN BARRIERS", 7: "WAIT FOR EMPTY", 13: "seeds hashed", 14: "next chunk's bases asked for"}
             cn = {8: "WAIT FOR A CHUNK", 9: "mfma loop", 10: "sums out", 11: "IN BARRIERS", 12: "gather tail"}
             ptot = float(sum(c[i] for i in pn)) or 1.0
             ctot = float(sum(c[i] for i in cn)) or 1.0
