@@ -586,12 +586,12 @@ def config3_leg(R):
     flops = 2.0 * 64 * d * cnt[15]
     res["one_organism_0.3pct"] = {
         "value": n / (ms * 1e-3), "unit": "sequences/sec", "ms_per_step": ms, "ms_all": all_ms,
-        "roofline": {"kernel": "count_twist_tile_kernel", "bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "roofline": {"kernel": "count_twist_tile_pipe_kernel", "bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": flops / (ms * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS, "traffic": None, "algorithmic_flops_per_launch": flops, "avg_launch_ms": ms,
                      "chunks_taken": cnt[14], "set_rows_multiplied": cnt[15],
                      "note": "flops = 2 x 64 sequences x D x the rows of every chunk's consensus set as multiplied (counted by the kernel in an extra, "
-                             "untimed call), over the WHOLE call's time: the matrix phase is a third of the kernel, the rest finds rows and builds "
-                             "the set (phase clocks and the MFMA-pipe counter: profiles/r04_tile_kernel_ab.txt, r04_tile_pmc.txt); the same batch through "
+                             "untimed call), over the WHOLE call's time: half the block's wavefronts multiply a chunk while the other half prepare the "
+                             "next (tile_pipe.h; phase clocks and the MFMA-pipe counter: profiles/r05_tile_pipe_ab.txt, r05_tile_pipe_pmc.txt); the same batch through "
                              "the streaming kernel alone (kpop_tune(\"dense\", 0)) is L2-latency-bound at ~100 SIMD-cycles a window"}}
     api.tune("dense", 0)
     try:
@@ -1066,6 +1066,21 @@ def main():
                         "`bench.py --gpus N` reports for N > 1" % L}
             line["file_to_file"] = {"value": None, "note": "--no-children"} if args.no_children else file_to_file(R)
             line.update(extra_configs(R))
+            # the legs' headline figures as flat scalars as well (a record that keeps only the names of nested objects still has these)
+            def _get(d, *path):
+                for key in path:
+                    d = d.get(key) if isinstance(d, dict) else None
+                return d
+            flat = {"config2_ms": _get(line, "config2_on_this_gpu", "ms_per_step"), "config2_frac": _get(line, "config2_on_this_gpu", "roofline", "frac"),
+                    "config3_unrelated_ms": _get(line, "config3_on_this_gpu", "unrelated_genomes", "ms_per_step"),
+                    "config3_unrelated_frac": _get(line, "config3_on_this_gpu", "unrelated_genomes", "roofline", "frac"),
+                    "config3_one_organism_ms": _get(line, "config3_on_this_gpu", "one_organism_0.3pct", "ms_per_step"),
+                    "config3_one_organism_frac": _get(line, "config3_on_this_gpu", "one_organism_0.3pct", "roofline", "frac"),
+                    "config4_n1_ms": _get(line, "config4_on_this_gpu", "ms_per_step"),
+                    "config4_all_vs_all_s": _get(line, "config4_on_this_gpu", "all_vs_all", "seconds"),
+                    "config5_ms": _get(line, "config5_on_this_gpu", "ms_per_step"), "config5_frac": _get(line, "config5_on_this_gpu", "roofline", "frac")}
+            head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")
+            line = dict([(key, line[key]) for key in head if key in line] + list(flat.items()) + [(key, v) for key, v in line.items() if key not in head])
         R.finish(line)
         return
 

@@ -1727,7 +1727,7 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
                  bytes_res = tiles && tw->n_dims > 64 ? max_slots * kTileS * 4 : 0, bytes_todo = tiles ? ((max_slots * 8 + 1024 + 63) & ~63ull) : 0,
                  bytes_perread = tiles ? bytes_nseg : 0;
   // up to 64 dimensions: the pipelined kernel (tile_pipe.h; kpop_tune("tilepipe", 0): round 4's kernel, phases one after the other)
-  const bool pipe = tiles && tw->n_dims <= 64 && cx.tune_tilepipe != 0;
+  const bool pipe = tiles && tw->n_dims <= 64 && cx.tune_tilepipe != 0 && tw->n_rows <= (1ull << 29);  // (a row's number shares a word with three bits of tag in the residual lists)
   const uint64_t bytes_wlists = !tiles ? 0 : pipe ? (uint64_t)cx.n_cus * 2 * 8 * kPipeListCap * 4 : (uint64_t)cx.n_cus * 16 * 4 * kTileS * 4;
   void *ws = nullptr;
   KPOP_TRY(ctx().ws_for(st).ensure(bytes_nseg + bytes_off + 2 * bytes_sums + bytes_cnt + bytes_part + bytes_done + bytes_long + bytes_olong + 2 * bytes_gmax +
@@ -1781,12 +1781,18 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
     if (pipe) {
       static PerSlotOnce once_pipe;
       if (!once_pipe()) {
-        KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&count_twist_tile_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPipeLdsBytes));
+        KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&count_twist_tile_pipe_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPipeLdsBytes));
+        KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&count_twist_tile_pipe_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPipeLdsBytes));
         once_pipe() = true;
       }
       const uint32_t pblocks = (uint32_t)std::min<uint64_t>((uint64_t)div_up(max_long, kPipeG) * max_seg, (uint64_t)cx.n_cus);
-      count_twist_tile_pipe_kernel<<<dim3(pblocks), dim3(1024), kPipeLdsBytes, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, olong, sums2 + nb,
-                                                                                     gmax, grel, max_seg, slot_done, wave_lists, ctx().tune_dbg >> 24);
+      const int tdbg = ctx().tune_dbg >> 24;
+      if (tdbg & 15)  // (the ablation switches: a build of the kernel of their own, so that the product's loops carry no test of them)
+        count_twist_tile_pipe_kernel<true><<<dim3(pblocks), dim3(1024), kPipeLdsBytes, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, olong, sums2 + nb,
+                                                                                             gmax, grel, max_seg, slot_done, wave_lists, tdbg);
+      else
+        count_twist_tile_pipe_kernel<false><<<dim3(pblocks), dim3(1024), kPipeLdsBytes, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, olong, sums2 + nb,
+                                                                                              gmax, grel, max_seg, slot_done, wave_lists, tdbg);
     } else if (tile_g == 64)
       count_twist_tile_kernel<uint32_t, 64><<<dim3(blocks), dim3(1024), lds, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, olong, sums2 + nb,
                                                                                   gmax, grel, max_seg, slot_done, res_rows, wave_lists, ctx().tune_dbg >> 24);

@@ -709,17 +709,67 @@ __global__ __launch_bounds__(1024) void hist_partition_kernel(const uint8_t *__r
   }
 }
 
+// CSR = false: the bucket's bins into the dense table (a caller that wants the table).  CSR = true: the (hash, count) pairs of the
+// bucket's non-zero bins straight into the spectrum -- the block counts them, takes its place by the decoupled look-back of
+// lookback.h (buckets are dealt by a ticket so that a block's predecessors are always running) and writes them in bin order:
+// the 4^k-counter table is never written, read twice more by two scans and compacted (73 us of a 100k-read call, 24 %).
+template <bool CSR>
 __global__ __launch_bounds__(1024) void hist_bucket_count_kernel(const uint16_t *__restrict__ entries, const uint64_t *__restrict__ off, int LB,
-                                                                 uint32_t *__restrict__ table) {
+                                                                 uint32_t *__restrict__ table, uint32_t n_buckets, uint32_t *__restrict__ ticket,
+                                                                 uint64_t *__restrict__ state, uint64_t *__restrict__ out_hash, uint32_t *__restrict__ out_count,
+                                                                 uint64_t cap, uint64_t *__restrict__ total_out) {
   extern __shared__ uint32_t s_tab[];
-  const uint32_t n_bins = 1u << LB, b = blockIdx.x;
+  __shared__ uint32_t s_b, s_wsum[16];
+  __shared__ uint64_t s_base;
+  const uint32_t n_bins = 1u << LB;
+  uint32_t b = blockIdx.x;
+  if (CSR) {
+    if (threadIdx.x == 0) s_b = atomicAdd(ticket, 1u);
+    __syncthreads();
+    b = s_b;
+  }
   for (uint32_t j = threadIdx.x; j < n_bins; j += 1024) s_tab[j] = 0;
   __syncthreads();
   const uint64_t e0 = off[b], e1 = off[b + 1];
   for (uint64_t i = e0 + threadIdx.x; i < e1; i += 1024) atomicAdd(&s_tab[entries[i]], 1u);
   __syncthreads();
-  uint32_t *out = table + ((uint64_t)b << LB);
-  for (uint32_t j = threadIdx.x; j < n_bins; j += 1024) out[j] = s_tab[j];
+  if (!CSR) {
+    uint32_t *out = table + ((uint64_t)b << LB);
+    for (uint32_t j = threadIdx.x; j < n_bins; j += 1024) out[j] = s_tab[j];
+    return;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t per = n_bins / 16, w0 = (uint32_t)wv * per;  // (at least 16 bins a bucket: a wavefront's run of them)
+  uint32_t cnt = 0;
+  for (uint32_t i = 0; i < per; i += 64) cnt += (uint32_t)__popcll(__ballot(i + lane < per && s_tab[w0 + i + lane] != 0u));
+  if (lane == 0) s_wsum[wv] = cnt;
+  __syncthreads();
+  if (wv == 0) {
+    uint32_t total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) total += s_wsum[w];
+    const uint64_t base = lookback_exclusive(state, b, (uint64_t)total, lane, 1);
+    if (lane == 0) {
+      s_base = base;
+      if (b == n_buckets - 1) *total_out = base + total;
+    }
+  }
+  __syncthreads();
+  uint64_t pos = s_base;
+  for (int w = 0; w < wv; ++w) pos += s_wsum[w];
+  for (uint32_t i = 0; i < per; i += 64) {
+    const uint32_t bin = w0 + i + (uint32_t)lane;
+    const uint32_t v = i + lane < per ? s_tab[bin] : 0u;
+    const uint64_t m = __ballot(v != 0u);
+    if (v) {
+      const uint64_t at = pos + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (at < cap) {  // (a spectrum beyond the caller's capacity is reported from the total, not written past it)
+        out_hash[at] = ((uint64_t)b << LB) | bin;
+        out_count[at] = v;
+      }
+    }
+    pos += (uint64_t)__popcll(m);
+  }
 }
 
 // Are the batch's sequences ONE organism?  (The merged count of assemblies then goes through window_hist_combine_kernel's
@@ -824,7 +874,7 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
   // that hist_related_kernel does not find to be one organism.
   auto use_partition = [&]() -> bool {
     if (!lds_mode || hb <= kHistLdsBits || hb - part_bucket_bits(hb) > 11 || total_win >= (1ull << 32) || k > 13) return false;
-    if (lds_mode == 3) return true;
+    if (lds_mode == 3 || lds_mode == 4) return true;
     if (lds_mode == 2 || total_win < (1u << 20)) return false;
     if (max_win <= 4096 || n_reads < 16) return true;
     DevBuf d_flag;
@@ -837,6 +887,9 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
   };
   const bool partition = max_win > 0 && use_partition();
   if (!partition) KPOP_HIP(hipMemsetAsync(S.d_ka.p, 0, n_bins * 4, st));
+  bool fused_csr = false;  // the partition path wrote the spectrum itself
+  uint64_t fused_bound = 0;
+  DevBuf d_state;
   if (max_win > 0) {
     if (lds_mode && hb <= kHistLdsBits) {
       // the whole table fits a block's LDS: private copies, one global atomic per non-zero counter and block
@@ -887,7 +940,8 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
       if (!once()) {
         KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_partition_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * kPartQuota * 4 + 2048 * 12)));
         KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_partition_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * kPartQuota * 4 + 2048 * 12)));
-        KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_bucket_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_bucket_count_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_bucket_count_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         once() = true;
       }
 #define KPOP_PART(SB)                                                                                                                        \
@@ -900,7 +954,22 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
   } while (0)
       if (protein) KPOP_PART(5); else KPOP_PART(2);
 #undef KPOP_PART
-      hist_bucket_count_kernel<<<dim3(n_buckets), dim3(1024), (size_t)4 << LB, st>>>(d_entries.as<uint16_t>(), d_poff.as<uint64_t>(), LB, table);
+      // the spectrum straight out of the buckets' LDS tables (kpop_tune("histlds", 4): always partitioned, with the dense table + compaction of round 4, for A/B)
+      fused_csr = lds_mode != 4;
+      if (fused_csr) {
+        const uint64_t bound = std::min<uint64_t>(std::min<uint64_t>(total_win, n_bins), cap);
+        KPOP_TRY(S.d_oh.alloc(std::max<uint64_t>(bound, 1) * 8));
+        KPOP_TRY(S.d_oc.alloc(std::max<uint64_t>(bound, 1) * 4));
+        KPOP_TRY(d_state.alloc((uint64_t)n_buckets * 8 + 64));
+        KPOP_HIP(hipMemsetAsync(d_state.p, 0, (uint64_t)n_buckets * 8 + 64, st));
+        uint64_t *state = d_state.as<uint64_t>() + 8;  // ([0] the ticket, [1] the total, then a word a bucket)
+        hist_bucket_count_kernel<true><<<dim3(n_buckets), dim3(1024), (size_t)4 << LB, st>>>(
+            d_entries.as<uint16_t>(), d_poff.as<uint64_t>(), LB, nullptr, n_buckets, reinterpret_cast<uint32_t *>(d_state.p), state, S.d_oh.as<uint64_t>(),
+            S.d_oc.as<uint32_t>(), bound, d_state.as<uint64_t>() + 1);
+        fused_bound = bound;
+      } else
+        hist_bucket_count_kernel<false><<<dim3(n_buckets), dim3(1024), (size_t)4 << LB, st>>>(d_entries.as<uint16_t>(), d_poff.as<uint64_t>(), LB, table, n_buckets,
+                                                                                             nullptr, nullptr, nullptr, nullptr, 0, nullptr);
     } else if (max_win <= 4096) {
       read_hist_kernel<uint32_t><<<dim3(std::min<uint32_t>(div_up(n_reads, 4), 1u << 16)), dim3(256), 0, st>>>(
           S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), k, content, table, n_reads);
@@ -917,6 +986,18 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
           S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), k, content, table, n_reads, max_seg);
     }
     KPOP_LAUNCH_CHECK();
+  }
+  if (fused_csr) {
+    uint64_t nu = 0;
+    KPOP_HIP(hipMemcpyAsync(&nu, d_state.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, st));
+    KPOP_HIP(hipStreamSynchronize(st));
+    if (nu > cap || nu > fused_bound)
+      KPOP_FAIL(KPOP_ERR_CAPACITY, "kpop_count_reads: %llu distinct k-mers, capacity %llu", (unsigned long long)nu, (unsigned long long)cap);
+    S.nu = nu;
+    const uint64_t two[2] = {0, nu};
+    KPOP_HIP(hipMemcpyAsync(S.d_oo.p, two, 16, hipMemcpyHostToDevice, st));
+    KPOP_HIP(hipStreamSynchronize(st));
+    return 0;
   }
   // count the non-zero bins, then write them out in index order
   uint64_t *sums = S.d_sums.as<uint64_t>();

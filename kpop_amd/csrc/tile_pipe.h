@@ -34,7 +34,9 @@ constexpr uint32_t kPipeListCap = 8 * kTileS;    // entries of a producer wavefr
 // bytes at a time, when the stretch is staged -- and a window's hash no longer rolls out of its predecessor's, so the windows that
 // miss the set are hashed again one by one, not all 64 of a thread.
 constexpr uint32_t kPipeUnits = 33, kPipeRowW = 85;  // dwords of a row: F at 0, R at 33, V at 66; 85 = 21 mod 32: four rows x eight threads' dwords on 32 banks
-constexpr size_t kPipeLdsBytes = (size_t)2 * kPipeG * kPipeXW * 4 + (size_t)kTileH * 8 + (size_t)2 * kTileSetCap * 4 + (size_t)kPipeG * kPipeRowW * 4;
+constexpr uint32_t kPipeMissLds = 192;  // entries of a producer wavefront's list of missed hashes that stay in LDS until their rows are found (beyond: global)
+constexpr size_t kPipeLdsBytes = (size_t)2 * kPipeG * kPipeXW * 4 + (size_t)kTileH * 8 + (size_t)2 * kTileSetCap * 4 + (size_t)kPipeG * kPipeRowW * 4 +
+                                 (size_t)8 * kPipeMissLds * 4;
 typedef uint32_t pipe_u32x4_any __attribute__((ext_vector_type(4), aligned(1)));  // sixteen bytes from any address: one global_load_dwordx4
 
 __device__ __forceinline__ uint32_t pipe_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -60,23 +62,31 @@ __device__ __forceinline__ void pipe_half_barrier(uint32_t *ctr, uint32_t &targe
   pipe_wait(ctr, target);
 }
 
+template <bool ABLATE>  // (true: the timing switches of kpop_tune("dbg", (1 | 2 | 4 | 8) << 24) are compiled in -- results are wrong under them)
 __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
     TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int content,
     const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ seg_off, double *__restrict__ partial,
     uint32_t *__restrict__ partial_cnt, const uint32_t *__restrict__ olong, const uint64_t *__restrict__ n_long_ptr,
     const uint32_t *__restrict__ gmax, const uint32_t *__restrict__ grel, uint32_t max_seg, uint32_t *__restrict__ slot_done,
-    uint32_t *__restrict__ lists, int dbg) {
+    uint32_t *__restrict__ lists, int dbg_in) {
   constexpr uint32_t G = kPipeG, XW = kPipeXW;
+  const int dbg = ABLATE ? dbg_in : (dbg_in & ~15);
   extern __shared__ __attribute__((aligned(16))) unsigned char pipe_lds[];
   uint32_t *Xw = reinterpret_cast<uint32_t *>(pipe_lds);          // [2][G][XW] four one-byte counts a word
   uint2 *ht = reinterpret_cast<uint2 *>(Xw + 2 * G * XW);         // [kTileH] {k-mer hash (kNoCol = empty), its number in the set}
   uint32_t *ucol = reinterpret_cast<uint32_t *>(ht + kTileH);     // [2][kTileSetCap] twister row of member u
   uint32_t *stage = ucol + 2 * kTileSetCap;                       // [G][kPipeRowW] the stretch's bases as 2-bit codes: F, R, V
+  uint32_t *mlist = stage + G * kPipeRowW;                        // [8][kPipeMissLds] a producer wavefront's missed hashes, before their rows
   __shared__ uint64_t s_slot[2][G];   // the group's (sequence, segment) slots, ~0: the sequence has no such segment
   __shared__ uint32_t s_rtot[2][8];   // entries of every producer wavefront's residual list (row | sequence of its eight << 29)
   __shared__ uint32_t s_U[2];         // members as multiplied (padded to 64)
   __shared__ uint32_t s_pbar, s_cbar, s_full, s_empty, s_done;
   __shared__ uint32_t s_new, s_samp, s_over, s_add[4], s_wbase[8];
+  __shared__ uint32_t s_ref[kPipeRowW];    // the set's REFERENCE: the staged stretch of the primary seed it was built from ...
+  __shared__ __attribute__((aligned(16))) uint16_t s_refnum[kTileS];    // ... the member every window of it is (0xFFFF none, 0xFFFE a member without a row),
+  __shared__ __attribute__((aligned(16))) uint32_t s_xref[kPipeXW];     // ... its own row of X (what a sequence IDENTICAL to it counts: every row of X starts as a copy),
+  __shared__ uint32_t s_refok[kTileS / 32], s_refabs[kTileS / 32];      // ... and a bit a window: its member has a row / is a member without one
+  __shared__ uint32_t s_refbad;                                          // ... 1: a count of that row passed 255 (the set is of no use: its chunks are the streaming kernel's)
   __shared__ unsigned long long s_stamp[16];  // the phase clocks of this block (kpop_tune("dbg", 16 << 24)), added to g_tile_stamps at the end
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t n_long = (uint32_t)*n_long_ptr;
@@ -104,10 +114,10 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
     // =================================================================== PRODUCER
     const uint32_t pw = (uint32_t)wv - 8u, pt = pw * 64u + (uint32_t)lane;
     const uint32_t sq = pt >> 3, tq = pt & 7u;  // the thread's sequence of the group and eighth of the stretch (64 windows)
-    const uint32_t myseed = pt >> 7;            // and the seed it hashes four windows of (sequences 0, 16, 32, 48)
     const uint32_t n_groups = (n_long + G - 1) / G;
     const uint64_t n_chunks = (uint64_t)n_groups * max_seg;
     const uint32_t mask = (uint32_t)bits_mask(2 * k), kmask = (1u << k) - 1u;
+    const uint32_t rowq = tv.d_pad >> 4;  // a row of the twister in 128-byte units (d_pad is a multiple of 16 doubles)
     const uint32_t ssmask = content == KPOP_DNA_DS ? 0u : ~0u;  // (single-stranded: the forward hash whatever the other strand's)
     uint32_t pbar_t = 0, n_pub = 0;
     int misses = 0;
@@ -154,13 +164,22 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
     // The next chunk's (sequence, offset, length, slot) and then its bases are loaded a chunk AHEAD, into registers: three dependent
     // trips to memory (list of long sequences -> offsets -> bases) that used to open every chunk.
     // chunks are dealt with the groups fastest: blocks running together work on one stretch of all sequences
-    auto next_chunk = [&](uint64_t from) -> uint64_t {  // the first chunk at or after `from` (a stride of the grid) that is this route's
-      for (; from < n_chunks; from += gridDim.x) {
+    // A block takes a CONTIGUOUS range of the chunks (groups fastest within a stretch): its chunks in a row are the same stretch of
+    // group after group of ONE organism -- the same consensus.  The set built for the first is kept for the following ones
+    // (phases 1 to 3 below only when the stretch changes, or a chunk found less than three quarters of its windows in it): the
+    // seeds hashed, the set built, its members numbered and their rows looked up were a third of a chunk's preparation.
+    // (blocks go to the eight XCDs in turn: the ranges are dealt so that the blocks of ONE XCD hold neighbouring ranges -- a few
+    // stretches' worth of twister rows per L2, not every stretch's)
+    const uint32_t vblock = gridDim.x % 8u == 0 ? (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u : blockIdx.x;
+    const uint64_t per_block = (n_chunks + gridDim.x - 1) / gridDim.x;
+    const uint64_t c_end = min(n_chunks, ((uint64_t)vblock + 1) * per_block);
+    auto next_chunk = [&](uint64_t from) -> uint64_t {  // the first chunk of the block's range at or after `from` that is this route's
+      for (; from < c_end; ++from) {
         const uint32_t sg = (uint32_t)(from / n_groups), gp = (uint32_t)(from % n_groups);
         const uint32_t pg = (uint32_t)(((uint64_t)gp * G) / kTileProbeG);
         if (grel[pg] && sg < gmax[pg]) break;  // (one organism: tile_group_probe_kernel; and some sequence of the group is this long)
       }
-      return from;
+      return from < c_end ? from : n_chunks;
     };
     struct Meta {
       uint32_t r;
@@ -253,7 +272,9 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
       }
       if (tq == 0) reinterpret_cast<uint16_t *>(row + 2 * kPipeUnits)[kPipeUnits] = 0xFFFFu;  // (bases 528..543: none)
     };
-    uint64_t chunk = next_chunk(blockIdx.x);
+    uint64_t chunk = next_chunk((uint64_t)vblock * per_block);
+    uint32_t set_seg = ~0u, set_UP = 0, prim_seed = 0;  // the stretch the set in LDS was built for, its members as multiplied
+    bool set_stale = true, rows_in[2] = {false, false};  // (rows_in: that buffer's copy of the members' rows is the set's)
     Meta cm = load_meta(chunk);
     uint4 cv[5];
     int cavail;
@@ -261,7 +282,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
     while (chunk < n_chunks) {
       if (skip) {  // (a block that met four chunks in a row that shared too little skips ahead: the look-ahead starts again)
         --skip;
-        chunk = next_chunk(chunk + gridDim.x);
+        chunk = next_chunk(chunk + 1);
         cm = load_meta(chunk);
         load_units(cm, chunk, cv, cavail);
         continue;
@@ -274,10 +295,15 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
       pbar();
       store_units(cv, cavail);
       // the chunk after this one: its sequences now, its bases once those are known (after the seeds' turn)
-      const uint64_t nchunk = next_chunk(chunk + gridDim.x);
+      const uint64_t nchunk = next_chunk(chunk + 1);
       const Meta nm = load_meta(nchunk);
+      const bool rebuild = set_stale || seg != set_seg;  // (uniform)
+      if (rebuild) {
 #pragma unroll
-      for (uint32_t q = 0; q < kTileH / 512; ++q) ht[pt + 512u * q] = make_uint2(kNoCol, kPipeAbsent);
+        for (uint32_t q = 0; q < kTileH / 512; ++q) ht[pt + 512u * q] = make_uint2(kNoCol, kPipeAbsent);
+        if (pt < kPipeXW) s_xref[pt] = 0u;
+        if (pt == 0) s_refbad = 0u;
+      }
       if (pt == 0) {
         s_new = 0;
         s_samp = 0;
@@ -286,21 +312,20 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
       if (pt < 4) s_add[pt] = 0;
       pbar();
       stamp(0);  // the bases staged, the set cleared
-      // ---- 1. the seeds: four windows a thread (4 w .. 4 w + 3 of its seed: one unit's dwords and the next's)
+      uint32_t UP = set_UP;
+      if (rebuild) {
+      // ---- 1. the seeds: window pt of each of the four, a thread (every step of the set's building is all 512 threads' then:
+      // a seed a quarter of the threads left six wavefronts waiting at the barriers while two inserted)
       uint32_t sh4[4];
       {
-        const uint32_t *row = stage + 16u * myseed * kPipeRowW;
-        const uint32_t w0 = 4u * (pt & 127u), j = w0 >> 4, o = w0 & 15u;
-        const uint32_t Fa = row[j], Fb = row[j + 1], Ra = row[kPipeUnits + j], Rb = row[kPipeUnits + j + 1];
-        const uint32_t jv = w0 >> 5;
-        const uint64_t VV = (((uint64_t)row[2 * kPipeUnits + jv + 1] << 32) | row[2 * kPipeUnits + jv]) >> (w0 & 31u);
-        const uint64_t T = ((uint64_t)Fa << 32) | Fb, U = ((uint64_t)Rb << 32) | Ra;
+        const uint32_t w = pt, j = w >> 4, o = w & 15u, jv = w >> 5;
 #pragma unroll
-        for (uint32_t i = 0; i < 4; ++i) {
-          const uint32_t fwd = (uint32_t)(T >> (64u - 2u * (o + i) - 2u * (uint32_t)k)) & mask;
-          const uint32_t rc = (uint32_t)(U >> (2u * (o + i))) & mask;
-          const bool good = (((uint32_t)VV >> i) & kmask) == 0u;
-          sh4[i] = good ? min(fwd, rc | ssmask) : kNoCol;
+        for (uint32_t sd = 0; sd < 4; ++sd) {
+          const uint32_t *srow = stage + 16u * sd * kPipeRowW;
+          const uint64_t T = ((uint64_t)srow[j] << 32) | srow[j + 1], U = ((uint64_t)srow[kPipeUnits + j + 1] << 32) | srow[kPipeUnits + j];
+          const uint64_t VV = (((uint64_t)srow[2 * kPipeUnits + jv + 1] << 32) | srow[2 * kPipeUnits + jv]) >> (w & 31u);
+          const uint32_t fwd = (uint32_t)(T >> (64u - 2u * o - 2u * (uint32_t)k)) & mask, rc = (uint32_t)(U >> (2u * o)) & mask;
+          sh4[sd] = ((uint32_t)VV & kmask) == 0u ? min(fwd, rc | ssmask) : kNoCol;
         }
       }
       stamp(13);  // the seeds hashed
@@ -309,28 +334,33 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
       // than half of its k-mers there (sequence 0 of the group is the odd one out): then the set is started again from seed 1.
 #pragma unroll 1
       for (uint32_t primary = 0; primary < 2; ++primary) {
-        if (myseed == primary) {
-          uint32_t took = 0;
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (sh4[i] != kNoCol) took += insert(sh4[i]) ? 1u : 0u;
-          if (took) atomicAdd(&s_new, took);
+        {
+          const uint32_t hp = primary ? sh4[1] : sh4[0];
+          const bool took = hp != kNoCol && insert(hp);
+          const uint32_t n = (uint32_t)__popcll(__ballot(took));
+          if (lane == 0 && n) atomicAdd(&s_new, n);
         }
         pbar();
-        const uint32_t pos = (myseed + 4u - primary) & 3u;  // the seed's place in the order of admission (0: the primary)
-        uint32_t em = 0;                                    // my k-mers the primary's set lacks
-        if (pos) {
-          uint32_t nadd = 0, nhas = 0;
+        // the others, in their order of admission (1, 2, 3 after seed 0; 2, 3, 0 after seed 1): which of my three the set lacks
+        uint32_t oh[3], em = 0;
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (sh4[i] != kNoCol) {
-              ++nhas;
-              if (find(sh4[i]).x == kNoCol) {
-                em |= 1u << i;
-                ++nadd;
-              }
+        for (uint32_t q = 0; q < 3; ++q) oh[q] = primary ? (q == 0 ? sh4[2] : q == 1 ? sh4[3] : sh4[0]) : sh4[q + 1];
+        {
+          uint2 e[3];
+#pragma unroll
+          for (uint32_t q = 0; q < 3; ++q) e[q] = ht[set_slot(oh[q] != kNoCol ? oh[q] : 0u)];
+#pragma unroll
+          for (uint32_t q = 0; q < 3; ++q) {
+            bool lacks = false;
+            if (oh[q] != kNoCol) {
+              uint2 ee = e[q];
+              if (ee.x != oh[q] && ee.x != kNoCol) ee = find(oh[q]);  // (a first probe that met another k-mer: walk on)
+              lacks = ee.x == kNoCol;
             }
-          if (nhas) atomicAdd(&s_add[pos], nadd | (nhas << 16));  // k-mers it would add | k-mers it has
+            em |= lacks ? (1u << q) : 0u;
+            const uint32_t nadd = (uint32_t)__popcll(__ballot(lacks)), nhas = (uint32_t)__popcll(__ballot(oh[q] != kNoCol));
+            if (lane == 0 && nhas) atomicAdd(&s_add[q + 1], nadd | (nhas << 16));  // k-mers it would add | k-mers it has
+          }
         }
         pbar();
         uint32_t total = s_new, in = 1u, strangers = 0, others = 0;  // in, bit pos: that seed is admitted
@@ -351,27 +381,36 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
           pbar();
           continue;
         }
-        if (pos && ((in >> pos) & 1u)) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if ((em >> i) & 1u) (void)insert(sh4[i]);
-        }
+        for (uint32_t q = 0; q < 3; ++q)
+          if (((em >> q) & 1u) && ((in >> (q + 1)) & 1u)) (void)insert(oh[q]);
+        prim_seed = primary;
         break;
       }
       stamp(1);  // the set built
+      }
       load_units(nm, nchunk, cv, cavail);  // (in flight under everything below)
       stamp(14);  // the next chunk's bases asked for (its sequences' offsets waited for)
-      pbar();
+      if (rebuild) pbar();
       // ---- 3. the members' rows (four slots of the table a thread: the only look-ups in the twister's index besides the misses),
       // the members that HAVE a row numbered in table order; then this chunk's X cleared (once the consumers are done with it)
-      uint32_t UP;
-      {
+      if (rebuild) {
         uint32_t kk[4], rows[4], occ = 0;
         uint4 q[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) kk[i] = ht[4u * pt + i].x;
 #pragma unroll
         for (int i = 0; i < 4; ++i) q[i] = *reinterpret_cast<const uint4 *>(tv.rsel + ((kk[i] != kNoCol ? kk[i] : 0u) >> 6));
+        // (under the index words' trip to memory: the wait for this buffer)
+        if (n_pub >= 2) {  // the consumers are done with this buffer's last chunk
+          const unsigned long long t0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+          pipe_wait(&s_empty, 8u * (n_pub - 1u));
+          if (stamps) {
+            const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
+            atomicAdd(&s_stamp[7], dt);
+            t_last += dt;
+          }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           rows[i] = kk[i] != kNoCol ? row_of(q[i], kk[i]) : kNoCol;
@@ -384,15 +423,6 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
           if (lane >= o) incl += up;
         }
         if (lane == 63) s_wbase[pw] = incl;
-        if (n_pub >= 2) {  // the consumers are done with this buffer's last chunk
-          const unsigned long long t0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-          pipe_wait(&s_empty, 8u * (n_pub - 1u));
-          if (stamps) {
-            const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
-            atomicAdd(&s_stamp[7], dt);
-            t_last += dt;
-          }
-        }
         pbar();
         uint32_t before = incl - occ, U = 0;
 #pragma unroll
@@ -407,16 +437,79 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
         for (int i = 0; i < 4; ++i)
           if (rows[i] != kNoCol) {
             ht[4u * pt + i].y = (before >> 2) | ((before & 3u) << 30);  // (the member's count: dword of the row | byte of it, as << 27 gives the shift)
-            uc[before] = rows[i];
+            uc[before] = rows[i] * rowq;  // (the row's offset in the twister, in 128-byte units: the consumers add it as it is)
             ++before;
           }
         if (pt < UP - U) uc[U + pt] = 0;  // (padded with row 0 of the twister against zero counts)
         if (pt == 0) s_U[buf] = UP;
-        uint4 *X4 = reinterpret_cast<uint4 *>(Xw + buf * G * XW);
-        for (uint32_t qq = pt; qq < G * XW / 4; qq += 512) X4[qq] = make_uint4(0u, 0u, 0u, 0u);
+        set_seg = seg;
+        set_UP = UP;
+        set_stale = false;
+        rows_in[buf] = true;
+        rows_in[buf ^ 1u] = false;
+        // the reference the window pass compares every sequence with: the primary seed's stretch, and its windows' members
+        pbar();  // (the members' numbers are all written)
+        {
+          const uint32_t *prow = stage + 16u * prim_seed * kPipeRowW;
+          if (pt < kPipeRowW) s_ref[pt] = prow[pt];
+          const uint32_t w = pt, j = w >> 4, o = w & 15u, jv = w >> 5;
+          const uint64_t T = ((uint64_t)prow[j] << 32) | prow[j + 1], U2 = ((uint64_t)prow[kPipeUnits + j + 1] << 32) | prow[kPipeUnits + j];
+          const uint64_t VV = (((uint64_t)prow[2 * kPipeUnits + jv + 1] << 32) | prow[2 * kPipeUnits + jv]) >> (w & 31u);
+          const uint32_t fwd = (uint32_t)(T >> (64u - 2u * o - 2u * (uint32_t)k)) & mask, rc = (uint32_t)(U2 >> (2u * o)) & mask;
+          uint32_t num = 0xFFFFu;
+          if (((uint32_t)VV & kmask) == 0u) {
+            const uint2 e = find(min(fwd, rc | ssmask));
+            if (e.x != kNoCol) num = e.y == kPipeAbsent ? 0xFFFEu : (((e.y & 0xFFFFu) << 2) | (e.y >> 30));
+          }
+          s_refnum[pt] = (uint16_t)num;
+          if (num < 0xFFFEu) atomicAdd(&s_xref[num >> 2], 1u << (8u * (num & 3u)));
+          const uint64_t okm = __ballot(num < 0xFFFEu), abm = __ballot(num == 0xFFFEu);
+          if (lane == 0) {
+            s_refok[2u * pw] = (uint32_t)okm;
+            s_refok[2u * pw + 1u] = (uint32_t)(okm >> 32);
+            s_refabs[2u * pw] = (uint32_t)abm;
+            s_refabs[2u * pw + 1u] = (uint32_t)(abm >> 32);
+          }
+        }
+        pbar();
+        if (pw == 0) {  // a count of the reference's own row past 255: its bytes add up to less than the windows counted (see below)
+          uint32_t sum = 0, cnt = 0;
+          for (uint32_t i = (uint32_t)lane; i < 192u; i += 64u) sum = __builtin_amdgcn_sad_u8(s_xref[i], 0u, sum);
+          if (lane < (int)(kTileS / 32)) cnt = (uint32_t)__popc(s_refok[lane]);
+          int diff = (int)sum - (int)cnt;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) diff += __shfl_xor(diff, o, 64);
+          if (lane == 0 && diff != 0) s_refbad = 1u;
+        }
+      } else {
+        // the set stands: this buffer's X cleared (once the consumers are done with it), the members' rows copied over if it has
+        // not had them yet (the other buffer has: its consumers only read it)
+        if (n_pub >= 2) {
+          const unsigned long long t0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+          pipe_wait(&s_empty, 8u * (n_pub - 1u));
+          if (stamps) {
+            const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
+            atomicAdd(&s_stamp[7], dt);
+            t_last += dt;
+          }
+        }
+        if (!rows_in[buf]) {
+          const uint32_t *from = ucol + (buf ^ 1u) * kTileSetCap;
+          uint32_t *to = ucol + buf * kTileSetCap;
+          for (uint32_t u = pt; u < UP; u += 512) to[u] = from[u];
+          rows_in[buf] = true;
+        }
+        if (pt == 0) s_U[buf] = UP;
+      }
+      // every sequence's row of X starts as the REFERENCE's: what a sequence identical to it counts.  The window pass then only
+      // touches the windows that differ (a count taken back where the reference's k-mer is not there, the sequence's own added).
+      {
+        uint32_t *Xs = Xw + buf * G * XW + sq * XW + 24u * tq;
+#pragma unroll
+        for (uint32_t i = 0; i < 12; ++i) *reinterpret_cast<uint2 *>(Xs + 2u * i) = *reinterpret_cast<const uint2 *>(s_xref + 24u * tq + 2u * i);
       }
       pbar();
-      stamp(2);  // the members' rows found and numbered, X cleared
+      stamp(2);  // the members' rows found and numbered, X set
       // ---- 4. every window against the set, eight at a time: a hit counts into X, a miss is remembered (a bit a window)
       uint64_t missm = 0;
       uint32_t found = 0;
@@ -430,68 +523,93 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
         return ((uint32_t)VV & kmask) == 0u ? min(fwd, rc | ssmask) : kNoCol;
       };
       {
-        // (X counts in single bytes and the additions do not report back: a returning LDS atomic per window, its result looked at at
-        // once, was a trip to the LDS and back per window, 64 in a row.  A count can pass 255 only if one of the sequence's eight
-        // threads adds 32 or more of ITS 64 windows to one member; 32 occurrences among 64 consecutive windows leave at least 15
-        // of them one or two windows after the one before -- c12 below, which ordinary sequence keeps at zero and a homopolymer or
-        // dinucleotide run does not.)
-        uint32_t valid = 0, absent = 0, c12 = 0, hp1 = kNoCol, hp2 = kNoCol;
+        // Pass A, a few bit operations per 16 windows: which windows hold exactly the REFERENCE's k bases (the primary seed of the
+        // set: assemblies of one organism are it almost everywhere)?  Those are already counted -- the row of X started as the
+        // reference's.  A window that differs (around a substitution; everything after an insertion or deletion) takes the
+        // reference's count back and goes the slow way: hashed, looked up in the set, counted or listed as a miss.
+        // (X counts in single bytes; a count that passed 255 shows in the row's sum: below.)
+        uint32_t valid = 0, absent = 0, sameok = 0;
+        uint64_t slowm = 0, decm = 0;
         uint32_t *Xs = Xw + buf * G * XW + sq * XW;
-        const uint32_t fsh = 32u - 2u * (uint32_t)k;
-#pragma unroll 1
-        for (uint32_t q = 0; q < 4; ++q) {  // sixteen windows a turn: one unit's dwords and the next's
+        // a bit a base that differs from the reference's, 16 bases a dword of codes: the even bits of (x | x >> 1), pushed together
+        auto differ16 = [](uint32_t x) -> uint32_t {
+          x = (x | (x >> 1)) & 0x55555555u;
+          x = (x | (x >> 1)) & 0x33333333u;
+          x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+          x = (x | (x >> 4)) & 0x00FF00FFu;
+          return (x | (x >> 8)) & 0xFFFFu;
+        };
+        // bit o of the result: any of bits o .. o + k - 1 of b set (o < 16, k <= 16)
+        auto any_of_k = [&](uint32_t b) -> uint32_t {
+          const uint32_t r2 = b | (b >> 1), r4 = r2 | (r2 >> 2), r8 = r4 | (r4 >> 4);  // any of 2, 4, 8 bits from o on
+          return k >= 8 ? (r8 | (r8 >> (k - 8))) : k >= 4 ? (r4 | (r4 >> (k - 4))) : k >= 2 ? (r2 | (r2 >> (k - 2))) : b;  // (uniform; two runs that overlap)
+        };
+        uint32_t dif[5], vv[3], vr[3];
+#pragma unroll
+        for (uint32_t q = 0; q < 5; ++q) dif[q] = differ16(row[kPipeUnits + 4u * tq + q] ^ s_ref[kPipeUnits + 4u * tq + q]);
+#pragma unroll
+        for (uint32_t q = 0; q < 3; ++q) {
+          vv[q] = row[2 * kPipeUnits + 2u * tq + q];
+          vr[q] = s_ref[2 * kPipeUnits + 2u * tq + q];
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {  // sixteen windows a turn: bases 16 j .. 16 j + 31
+          const uint32_t VV = (q & 1u) ? __builtin_amdgcn_alignbit(vv[(q >> 1) + 1], vv[q >> 1], 16) : vv[q >> 1];
+          const uint32_t VR = (q & 1u) ? __builtin_amdgcn_alignbit(vr[(q >> 1) + 1], vr[q >> 1], 16) : vr[q >> 1];
+          uint32_t ns = any_of_k(dif[q] | (dif[q + 1] << 16) | VV | VR) & 0xFFFFu;  // not the reference's k bases
+          const uint32_t iv = any_of_k(VV) & 0xFFFFu;                                      // no k-mer of the sequence's at all
+          if (dbg & 8) ns = 0xFFFFu;  // (a check of the shortcut: every window the slow way -- the results must not change)
           const uint32_t j = 4u * tq + q;
-          const uint32_t Fa = row[j], Fb = row[j + 1], Ra = row[kPipeUnits + j], Rb = row[kPipeUnits + j + 1];
-          const uint32_t VV = reinterpret_cast<const uint16_t *>(row + 2 * kPipeUnits)[j] |
-                              ((uint32_t)reinterpret_cast<const uint16_t *>(row + 2 * kPipeUnits)[j + 1] << 16);  // bases 16 j .. 16 j + 31
-#pragma unroll
-          for (uint32_t half = 0; half < 2; ++half) {
-            uint32_t h[8], vm = 0;
-#pragma unroll
-            for (uint32_t i = 0; i < 8; ++i) {
-              const uint32_t o = 8u * half + i;
-              const uint32_t fwd = (o ? __builtin_amdgcn_alignbit(Fa, Fb, 32u - 2u * o) : Fa) >> fsh;
-              const uint32_t rc = (o ? __builtin_amdgcn_alignbit(Rb, Ra, 2u * o) : Ra) & mask;
-              h[i] = min(fwd, rc | ssmask);
-              vm |= ((VV >> o) & kmask) == 0u ? (1u << i) : 0u;
-            }
-            uint2 e[8];
-#pragma unroll
-            for (uint32_t i = 0; i < 8; ++i) e[i] = (dbg & 8) ? make_uint2(h[i], i) : ht[set_slot(h[i])];
-#pragma unroll
-            for (uint32_t i = 0; i < 8; ++i) {
-              c12 += (((vm >> i) & 1u) && (h[i] == hp1 || h[i] == hp2)) ? 1u : 0u;
-              hp2 = hp1;
-              hp1 = h[i];
-            }
-            valid += (uint32_t)__popc(vm);
-#pragma unroll
-            for (uint32_t i = 0; i < 8; ++i)
-              if ((vm >> i) & 1u) {
-                uint2 ee = e[i];
-                if (ee.x != h[i] && ee.x != kNoCol) {  // (a first probe that met another k-mer: walk on)
-                  uint32_t slot = set_slot(h[i]);
-#pragma unroll 1
-                  for (uint32_t t = 0; t < kTileH && ee.x != h[i] && ee.x != kNoCol; ++t) {
-                    slot = (slot + 1) & (kTileH - 1);
-                    ee = ht[slot];
-                  }
-                }
-                if (ee.x == h[i]) {
-                  if (ee.y != kPipeAbsent && !(dbg & 2))  // .y: the member's byte of X -- the dword's offset in the row | which byte << 30
-                    (void)__hip_atomic_fetch_add(Xs + (ee.y & 0xFFFFu), 1u << (ee.y >> 27), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                  else
-                    ++absent;
-                } else
-                  missm |= 1ull << (16u * q + 8u * half + i);
-              }
-          }
+          const uint32_t ok16 = (s_refok[j >> 1] >> (16u * (j & 1u))) & 0xFFFFu, ab16 = (s_refabs[j >> 1] >> (16u * (j & 1u))) & 0xFFFFu;
+          valid += (uint32_t)__popc(~iv & 0xFFFFu);
+          sameok += (uint32_t)__popc(~ns & ok16);
+          absent += (uint32_t)__popc(~ns & ab16);
+          decm |= (uint64_t)(ns & ok16) << (16u * q);
+          slowm |= (uint64_t)(ns & ~iv & 0xFFFFu) << (16u * q);
+        }
+        while (decm) {  // the reference's k-mer is not this sequence's here: its count taken back (it was copied in: never below zero)
+          const uint32_t i = (uint32_t)__ffsll((long long)decm) - 1u;
+          decm &= decm - 1ull;
+          const uint32_t num = s_refnum[64u * tq + i];
+          if (!(dbg & 2)) (void)__hip_atomic_fetch_sub(Xs + (num >> 2), 1u << (8u * (num & 3u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (!(dbg & 32)) stamp(15);  // pass A
+        // Pass B: the slow windows, one by one (a thread that holds a substitution has about k of them)
+        while (slowm) {
+          const uint32_t i = (uint32_t)__ffsll((long long)slowm) - 1u;
+          slowm &= slowm - 1ull;
+          const uint32_t h = hash_at(64u * tq + i);
+          const uint2 ee = find(h);
+          if (ee.x == h) {
+            if (ee.y != kPipeAbsent) {  // .y: the member's byte of X -- the dword's offset in the row | which byte << 30
+              if (!(dbg & 2)) (void)__hip_atomic_fetch_add(Xs + (ee.y & 0xFFFFu), 1u << (ee.y >> 27), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else
+              ++absent;
+          } else
+            missm |= 1ull << i;
         }
         const uint32_t nmiss = (uint32_t)__popcll(missm), hits = valid - nmiss;
-        found = hits - absent;
+        found = hits - absent;  // (= the reference's windows with a row that are this sequence's too + the slow windows that found one)
+        (void)sameok;
         const uint32_t vh = valid | (hits << 16);
         if (vh) atomicAdd(&s_samp, vh);
-        if (c12 >= 15u) s_over = 1u;
+      }
+      pbar();
+      {
+        // a count that passed 255 carried into its neighbour (or out of its dword): the row's bytes then add up to 255 or 256 less
+        // than the windows counted into it, per carry -- never more, so carries cannot cancel
+        const uint32_t *Xs = Xw + buf * G * XW + sq * XW;
+        uint32_t sum = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 12; ++i) {  // 192 dwords of counts a row, eight threads: 24 each (a row starts on 8 bytes, not 16)
+          const uint2 x = *reinterpret_cast<const uint2 *>(Xs + 24u * tq + 2u * i);
+          sum = __builtin_amdgcn_sad_u8(x.x, 0u, sum);
+          sum = __builtin_amdgcn_sad_u8(x.y, 0u, sum);
+        }
+        int diff = (int)sum - (int)found;  // (found: the windows this thread counted into X)
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) diff += __shfl_xor(diff, o, 8);
+        if (diff != 0 && !(dbg & 2)) s_over = 1u;
       }
       pbar();
       stamp(3);  // the windows counted
@@ -499,12 +617,20 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
         // sequences that share little with the seeds (fewer than half the windows are of the consensus), or a k-mer 256 times
         // in one sequence's stretch: the chunk is left to the streaming kernel
         const uint32_t fh = s_samp;
-        if (s_over || (fh >> 16) * 2u < (fh & 0xFFFFu)) {
+        if ((dbg & 32) && pt == 0) {  // (development counts: chunks seen, with a count past 255, with an unusable reference, sharing too little, rebuilt)
+          atomicAdd(&g_tile_stamps[8], 1ull);
+          if (s_over) atomicAdd(&g_tile_stamps[9], 1ull);
+          if (s_refbad) atomicAdd(&g_tile_stamps[10], 1ull);
+          if ((fh >> 16) * 2u < (fh & 0xFFFFu)) atomicAdd(&g_tile_stamps[11], 1ull);
+          if (rebuild) atomicAdd(&g_tile_stamps[12], 1ull);
+        }
+        if (s_over || s_refbad || (fh >> 16) * 2u < (fh & 0xFFFFu)) {
           if (++misses >= 4) {
             misses = 0;
             skip = backoff;
             backoff = min(backoff * 2u, 1u << 20);
           }
+          set_stale = true;
           chunk = nchunk;
           cm = nm;
           continue;
@@ -512,6 +638,10 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
       }
       misses = 0;
       backoff = 8;
+      {
+        const uint32_t fh = s_samp;  // (fewer than three quarters of the windows in the set: the next chunk builds its own)
+        if ((fh >> 16) * 4u < (fh & 0xFFFFu) * 3u) set_stale = true;
+      }
       // ---- 5. the residual list of the wavefront's eight sequences: hashes in (sequence, window) order, then their rows
       {
         const uint32_t rcnt = (uint32_t)__popcll(missm);
@@ -527,16 +657,21 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
         for (int o = 4; o > 0; o >>= 1) found += (uint32_t)__shfl_xor((int)found, o, 8);
         uint32_t wout = 0;  // entries that HAVE a row: the list as the consumers read it
         if (wtot) {  // (uniform)
+          // (the hashes wait in LDS for their rows -- through global memory, written, fenced and read back, they cost two trips there;
+          // a list longer than the LDS has room for goes on in global memory, as before)
+          uint32_t *ml = mlist + pw * kPipeMissLds;
           {
             uint32_t pos = incl - rcnt;
             uint64_t mm = missm;
             while (mm) {  // (the thread's misses, in window order: each one hashed again by itself)
               const uint32_t i = (uint32_t)__ffsll((long long)mm) - 1u;
               mm &= mm - 1ull;
-              wl[pos++] = hash_at(64u * tq + i);
+              const uint32_t h = hash_at(64u * tq + i);
+              if (pos < kPipeMissLds) ml[pos] = h; else wl[pos] = h;
+              ++pos;
             }
           }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (wtot > kPipeMissLds) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); else pipe_lds_fence();  // (uniform)
           stamp(4);  // the misses' hashes listed
           // the entries' rows, 64 at a time: the ones the twister has stay (compacted in place: a batch is read before anything is
           // written at or after it), tagged with their sequence of the eight (bits 29..31: a row of this route is below 2^29) and
@@ -547,7 +682,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
           uint32_t present = 0;  // of MY sequence (lanes of a sequence all count it)
           for (uint32_t p0 = 0; p0 < wtot; p0 += 64) {
             const uint32_t e = p0 + (uint32_t)lane;
-            const uint32_t h = e < wtot ? __hip_atomic_load(wl + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+            const uint32_t h = e >= wtot ? 0u : e < kPipeMissLds ? ml[e] : __hip_atomic_load(wl + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const uint4 q = *reinterpret_cast<const uint4 *>(tv.rsel + (h >> 6));
             const uint32_t row = e < wtot ? row_of(q, h) : kNoCol;
             uint32_t tag = 0;
@@ -592,6 +727,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
       if (!(dbg & 32)) {
         atomicAdd(&g_tile_stamps[13], s_stamp[13]);
         atomicAdd(&g_tile_stamps[14], s_stamp[14]);
+        atomicAdd(&g_tile_stamps[15], s_stamp[15]);
       }
     }
     return;
@@ -686,11 +822,17 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
     double bs[4][4];
     uint32_t a0 = 0, a1 = 0;
     uint4 uqn = make_uint4(0u, 0u, 0u, 0u);
+    // byte j of w as a double: 2^52 + n has n in its low mantissa bits, and the subtraction is exact (one full-rate f64 add where
+    // v_cvt_f64_u32 is a quarter-rate instruction, eight times per block of 16 members)
+    auto byte_f64 = [](uint32_t w, uint32_t j) -> double {
+      const uint64_t bits = 0x4330000000000000ull | (uint64_t)((w >> (8u * j)) & 0xFFu);
+      return __longlong_as_double((long long)bits) - 4503599627370496.0;
+    };
     auto load_rows = [&](double (&dst)[4], const uint4 u) {
-      dst[0] = trow[(uint64_t)u.x * tv.d_pad];
-      dst[1] = trow[(uint64_t)u.y * tv.d_pad];
-      dst[2] = trow[(uint64_t)u.z * tv.d_pad];
-      dst[3] = trow[(uint64_t)u.w * tv.d_pad];
+      dst[0] = trow[(uint64_t)u.x << 4];  // (ucol holds the rows' offsets in 128-byte units: no 64-bit multiply per load)
+      dst[1] = trow[(uint64_t)u.y << 4];
+      dst[2] = trow[(uint64_t)u.z << 4];
+      dst[3] = trow[(uint64_t)u.w << 4];
     };
     if (nb) {
 #pragma unroll
@@ -715,8 +857,8 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
         const uint32_t an0 = xa[4u * bx], an1 = xa[16u * XW + 4u * bx];
 #pragma unroll
         for (uint32_t j = 0; j < 4 && !(dbg & 1); ++j) {
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)((a0 >> (8u * j)) & 0xFFu), bs[s][j], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)((a1 >> (8u * j)) & 0xFFu), bs[s][j], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(byte_f64(a0, j), bs[s][j], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(byte_f64(a1, j), bs[s][j], acc1, 0, 0, 0);
         }
         a0 = an0;
         a1 = an1;

@@ -634,6 +634,47 @@ def test_assemblies_of_one_organism_through_the_tile_kernel(kpop, oracle, k, d, 
         # (at 10 % fewer than a third of the windows survive: tile_group_probe_kernel leaves the groups to the streaming kernel)
 
 
+def test_assemblies_with_low_complexity_runs_and_shifted_copies(kpop, oracle):
+    """what the pipelined tile kernel (tile_pipe.h, up to 64 dimensions) leaves to the streaming kernel or takes the slow way:
+    stretches in which one k-mer occurs more than 255 times (a poly-A of 400, an (AT)n of 500, in every mutant: the one-byte
+    counts of X would overflow -- the row-sum check must send those chunks away, not return garbage), and assemblies that carry
+    an insertion early on (every window after it differs from the set's reference at its coordinate: hashed one by one) --
+    against the oracle, and the same bits twice"""
+    from kpop_amd import api
+    rng = np.random.RandomState(5)
+    k, d = 12, 64
+    ref = rng.choice(list("ACGT"), size=9000)
+    ref[1500:1900] = "A"
+    ref[4000:4500] = list("AT" * 250)
+    ref[6100:6400] = list("ACG" * 100)  # (period three: 100 of a k-mer per strand at most, no overflow)
+    seqs = []
+    for i in range(200):
+        m = ref.copy()
+        hit = rng.rand(len(m)) < 0.002
+        m[hit] = rng.choice(list("ACGT"), size=int(hit.sum()))
+        if i % 5 == 1:
+            at = int(rng.randint(50, 400))
+            m = np.concatenate([m[:at], rng.choice(list("ACGT"), size=int(rng.randint(1, 9))), m[at:]])  # an insertion: shifted from there on
+        seqs.append("".join(m))
+    bases, offs = concat(seqs)
+    h, c, o = oracle.count_reads(bases, offs, k)
+    cols = np.unique(h)
+    cols = cols[rng.rand(len(cols)) < 0.97]  # (some k-mers have no row: members without one, misses without one)
+    T = oracle.synth_twister(8, d, cols)
+    tw = kpop.Twister.load(T, cols, k)
+    want = oracle.twist(T, cols, h, c.astype(np.float64), o)
+    got, again = tw.count_twist(bases, offs), tw.count_twist(bases, offs)
+    api.tune("tilepipe", 0)
+    try:
+        r4 = tw.count_twist(bases, offs)  # round 4's kernel, phases one after the other
+    finally:
+        api.tune("tilepipe", 1)
+    scale = max(np.max(np.abs(want)), 1.0)
+    assert np.max(np.abs(got - want)) <= 1e-12 * scale, np.max(np.abs(got - want))
+    assert np.max(np.abs(r4 - want)) <= 1e-12 * scale
+    assert np.array_equal(got, again)
+
+
 def test_few_assemblies_among_many_reads_and_tiny_batches(kpop, oracle):
     """the tile route's groups are cut from the sequences that HAVE segments: three assemblies of one organism among 3,000 reads
     (fewer than the route bothers with), then forty of them scattered among the reads (one group), against the oracle"""

@@ -27,7 +27,8 @@ def main():
         api.tune("dense", mode)
         api.tune("tilepipe", pipe)
         out = torch.zeros(n, d, dtype=torch.float64, device=dev)
-        api.dev_count_twist(tw, db.data_ptr(), do.data_ptr(), n, db.numel(), L, out.data_ptr(), stream=st.cuda_stream)
+        api.dev_count_twist(tw, db.data_ptr(), do.data_ptr(), n, db.numel(), L, out.data_ptr(), stream=st.cuda_stream,
+                            normalize=not os.environ.get("PIPE_RAW"))
         torch.cuda.synchronize()
         return out.cpu().numpy()
 
@@ -42,8 +43,25 @@ def main():
         L = int(np.diff(o.astype(np.int64)).max())
         ref = run(db, do, n, L, 0, 0)
         old = run(db, do, n, L, 2, 0)
+        if os.environ.get("PIPE_DBG"):
+            api.tune("dbg", int(os.environ["PIPE_DBG"]) << 24)
+        if os.environ.get("PIPE_COUNTS"):
+            api.tune("dbg", (32 | int(os.environ.get("PIPE_COUNTS_DBG", "0"))) << 24)
+            api.debug_counters(16)
+            run(db, do, n, L, 2, 1)
+            c = api.debug_counters(16)
+            print("   chunks seen %d, count past 255 %d, reference unusable %d, share too little %d, rebuilt %d; taken %d, members multiplied %d"
+                  % (c[8], c[9], c[10], c[11], c[12], c[14], c[15]))
         new = [run(db, do, n, L, 2, 1) for _ in range(3)]
+        api.tune("dbg", 0)
         sc = np.max(np.abs(ref))
+        if os.environ.get("PIPE_ROWS"):
+            err = np.max(np.abs(new[0] - ref), axis=1) / sc
+            print("   per-row error (first 72 rows): " + " ".join("%.0e" % e for e in err[:72]))
+            r = int(np.argmax(err))
+            print("   worst row %d: pipe %s" % (r, np.array2string(new[0][r, :6], precision=4)))
+            print("   worst row %d: ref  %s" % (r, np.array2string(ref[r, :6], precision=4)))
+            print("   row 0: pipe %s  ref %s" % (np.array2string(new[0][0, :4], precision=5), np.array2string(ref[0, :4], precision=5)))
         print("%5d mutants at %.1f %%: old tile vs streaming %.1e   pipe vs streaming %.1e   pipe run to run identical: %s"
               % (n, 100 * rate, np.max(np.abs(old - ref)) / sc, np.max(np.abs(new[0] - ref)) / sc,
                  all(np.array_equal(new[0], x) for x in new[1:])), flush=True)
@@ -84,7 +102,7 @@ def main():
                     e1.record(st)
                     torch.cuda.synchronize()
                     ms.append(e0.elapsed_time(e1))
-                print("   ablation bits %2d (1 no MFMA, 2 no X adds, 4 no gather, 8 no set look-ups): %.3f ms" % (bits, float(np.median(ms[1:]))), flush=True)
+                print("   ablation bits %2d (1 no MFMA, 2 no X adds, 4 no gather, 8 no pass B): %.3f ms" % (bits, float(np.median(ms[1:]))), flush=True)
             api.tune("dbg", 0)
         if os.environ.get("PIPE_STAMPS"):
             api.tune("dense", 2)
@@ -95,7 +113,7 @@ def main():
             torch.cuda.synchronize()
             c = api.debug_counters(16)
             api.tune("dbg", 0)
-            pn = {0: "stage+clear", 1: "seeds+set", 2: "rows+number+X clear", 3: "windows", 4: "misses listed", 5: "their rows+publish", 6: "IN BARRIERS", 7: "WAIT FOR EMPTY", 13: "seeds hashed", 14: "next chunk's bases asked for"}
+            pn = {0: "stage+clear", 1: "seeds+set", 2: "rows+number+X clear", 3: "windows", 4: "misses listed", 5: "their rows+publish", 6: "IN BARRIERS", 7: "WAIT FOR EMPTY", 13: "seeds hashed", 14: "next chunk's bases asked for", 15: "windows: pass A (of windows)"}
             cn = {8: "WAIT FOR A CHUNK", 9: "mfma loop", 10: "sums out", 11: "IN BARRIERS", 12: "gather tail"}
             ptot = float(sum(c[i] for i in pn)) or 1.0
             ctot = float(sum(c[i] for i in cn)) or 1.0
