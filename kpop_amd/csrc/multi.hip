@@ -267,6 +267,7 @@ extern "C" int kpop_twister_replicate(const kpop_twister *src, int slot, kpop_tw
   tw->alias = false;
   tw->d_rows = nullptr;
   tw->d_rsel = nullptr;
+  tw->d_rblk = nullptr;
   tw->d_sorted_hash = nullptr;
   const int prev = current_slot();
   int rc = use_slot(slot);
@@ -287,6 +288,11 @@ extern "C" int kpop_twister_replicate(const kpop_twister *src, int slot, kpop_tw
         const uint64_t b = (((1ull << (2 * src->k)) + 63) / 64) * sizeof(RankWord);
         RP(hipMalloc(&tw->d_rsel, b));
         RP(hipMemcpyPeer(tw->d_rsel, dst_dev, src->d_rsel, src_dev, b));
+      }
+      if (src->d_rblk) {
+        const uint64_t b = rank_blocks(src->k) * 64;
+        RP(hipMalloc(&tw->d_rblk, b));
+        RP(hipMemcpyPeer(tw->d_rblk, dst_dev, src->d_rblk, src_dev, b));
       }
       if (src->d_sorted_hash) {
         RP(hipMalloc((void **)&tw->d_sorted_hash, src->n_rows * 8 + 8));

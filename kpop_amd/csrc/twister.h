@@ -13,6 +13,12 @@
 //   rsel : k <= 16: RankWord[4^k/64], rank-select form of the name -> row map: 64 presence bits + the number
 //          of present k-mers before the word; row = prefix + popcount(bits below).  4 MB at k=12 (a u32 LUT
 //          would be 67 MB and gets evicted by the row stream: +24 % HBM traffic, measured in round 1).
+//   rblk : k = 15, 16: the same map in BLOCKS of one 64-byte sector -- 480 presence bits (fifteen dwords) + the number of
+//          present k-mers before the block: 143 MB at k = 15 where the 16-byte words above are 268 MB, more than the whole
+//          256 MB Infinity Cache.  Behind every window's look-up comes a random 128-byte row from a table of tens of GB (an HBM
+//          miss by construction); with the index inside the cache the look-up in front of it no longer is one (BASELINE config 5).
+//          row = prefix + popcount(the block's bits below the k-mer's).  (The tile route for assemblies reads rank WORDS: it is
+//          off at these k.)
 //   sorted_hash : k > 16: the ascending hashes themselves, searched by bisection; the hit's index is the row.
 #pragma once
 #include <stdint.h>
@@ -28,6 +34,7 @@ struct kpop_twister {
   uint64_t n_rows = 0;  // distinct k-mers = device rows
   double *d_rows = nullptr;
   void *d_rsel = nullptr;
+  void *d_rblk = nullptr;  // k >= kRankBlockMinK: 64-byte blocks instead of d_rsel (which is then freed once the rows are placed)
   uint64_t *d_sorted_hash = nullptr;
   uint64_t device_bytes = 0;
   int slot = 0;        // device slot (common.h) whose memory holds the arrays
@@ -37,6 +44,9 @@ struct kpop_twister {
 namespace kpop {
 
 constexpr int kRankMaxK = 16;  // 4^16 / 64 words * 16 B = 1 GiB
+constexpr int kRankBlockMinK = 15;         // from this k on the index is kept as 64-byte blocks
+constexpr uint32_t kRankBlockBits = 480;   // presence bits of a block: dwords 0..14; dword 15: the rank of its first bit
+static inline uint64_t rank_blocks(int k) { return ((1ull << (2 * k)) + kRankBlockBits - 1) / kRankBlockBits; }
 constexpr uint32_t kNoCol = 0xFFFFFFFFu;
 
 struct RankWord {
@@ -48,6 +58,7 @@ struct RankWord {
 struct TwisterView {
   const double *rows;
   const RankWord *rsel;
+  const uint4 *rblk;  // [rank_blocks(k)][4]
   const uint64_t *sorted_hash;
   uint64_t n_rows;
   uint32_t n_dims;
@@ -57,7 +68,7 @@ struct TwisterView {
 };
 
 static inline TwisterView view_of(const kpop_twister *tw) {
-  return TwisterView{tw->d_rows, reinterpret_cast<const RankWord *>(tw->d_rsel), tw->d_sorted_hash, tw->n_rows,
+  return TwisterView{tw->d_rows, reinterpret_cast<const RankWord *>(tw->d_rsel), reinterpret_cast<const uint4 *>(tw->d_rblk), tw->d_sorted_hash, tw->n_rows,
                      tw->n_dims, tw->d_pad,                                     tw->k, tw->hk ? tw->hk : tw->k};
 }
 
@@ -65,6 +76,19 @@ static inline TwisterView view_of(const kpop_twister *tw) {
 // hash -> twister row, kNoCol when absent (lib/Twister.ml:151 Hashtbl.find_opt)
 __device__ __forceinline__ uint32_t lookup_col(const TwisterView &tv, uint64_t h) {
   if (h >> (2 * tv.k)) return kNoCol;  // not a k-mer of this twister's k (caller-supplied spectra)
+  if (tv.rblk) {  // one 64-byte sector: four 16-byte loads of consecutive addresses
+    const uint32_t hh = (uint32_t)h, blk = hh / kRankBlockBits, r = hh - blk * kRankBlockBits, w = r >> 5, bit = r & 31u;
+    const uint4 *p = tv.rblk + (uint64_t)blk * 4;
+    const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    const uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+    uint32_t below = 0, word = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 15; ++i) {
+      below += i < w ? (uint32_t)__popc(d[i]) : 0u;
+      word = i == w ? d[i] : word;
+    }
+    return ((word >> bit) & 1u) ? d[15] + below + (uint32_t)__popc(word & ((1u << bit) - 1u)) : kNoCol;
+  }
   if (tv.rsel) {
     const uint4 q = *reinterpret_cast<const uint4 *>(tv.rsel + (h >> 6));  // one 16-byte load
     const uint64_t bits = ((uint64_t)q.y << 32) | q.x;

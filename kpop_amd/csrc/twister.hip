@@ -120,6 +120,47 @@ static int finish_rank_select(kpop_twister *tw, uint64_t n_words, uint64_t *tota
   return 0;
 }
 
+// rank words -> 64-byte blocks (k >= kRankBlockMinK): block b holds the presence bits of hashes [480 b, 480 b + 480) and the rank
+// of the first of them; a thread a block (it reads nine words)
+__global__ __launch_bounds__(256) void rank_blocks_kernel(const RankWord *__restrict__ rsel, uint64_t n_words, uint64_t n_blocks, uint4 *__restrict__ rblk) {
+  const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= n_blocks) return;
+  const uint64_t h0 = b * kRankBlockBits;
+  const uint64_t w0 = h0 >> 6;
+  const uint32_t sh = (uint32_t)(h0 & 63);
+  auto bits_of = [&](uint64_t w) -> uint64_t { return w < n_words ? rsel[w].bits : 0ull; };
+  uint32_t d[16];
+#pragma unroll
+  for (uint32_t i = 0; i < 8; ++i) {  // eight 64-bit pieces from h0 on (the last one half used)
+    const uint64_t lo = bits_of(w0 + i), hi = bits_of(w0 + i + 1);
+    const uint64_t x = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+    d[2 * i] = (uint32_t)x;
+    d[2 * i + 1] = (uint32_t)(x >> 32);
+  }
+  const RankWord first = rsel[w0 < n_words ? w0 : n_words - 1];
+  d[15] = first.prefix + (uint32_t)__popcll(first.bits & ((1ull << sh) - 1ull));  // (dword 15 of the pieces is not the block's: bits 480..511)
+  rblk[b * 4 + 0] = make_uint4(d[0], d[1], d[2], d[3]);
+  rblk[b * 4 + 1] = make_uint4(d[4], d[5], d[6], d[7]);
+  rblk[b * 4 + 2] = make_uint4(d[8], d[9], d[10], d[11]);
+  rblk[b * 4 + 3] = make_uint4(d[12], d[13], d[14], d[15]);
+}
+
+// from kRankBlockMinK on: the index as blocks, the words freed (after everything that reads them: the rows' placement)
+static int compact_rank_index(kpop_twister *tw, hipStream_t st) {
+  if (tw->k < kRankBlockMinK || !tw->d_rsel) return 0;
+  const uint64_t n_words = ((1ull << (2 * tw->k)) + 63) / 64, n_blocks = rank_blocks(tw->k);
+  KPOP_HIP(hipMalloc(&tw->d_rblk, n_blocks * 64));
+  rank_blocks_kernel<<<dim3(div_up(n_blocks, 256)), dim3(256), 0, st>>>(reinterpret_cast<const RankWord *>(tw->d_rsel), n_words, n_blocks,
+                                                                       reinterpret_cast<uint4 *>(tw->d_rblk));
+  KPOP_LAUNCH_CHECK();
+  KPOP_HIP(hipStreamSynchronize(st));
+  KPOP_HIP(hipFree(tw->d_rsel));
+  tw->d_rsel = nullptr;
+  tw->device_bytes += n_blocks * 64;
+  tw->device_bytes -= n_words * sizeof(RankWord);
+  return 0;
+}
+
 }  // namespace kpop
 
 using namespace kpop;
@@ -132,6 +173,7 @@ extern "C" int kpop_twister_free(kpop_twister *tw) {
   }
   if (tw->d_rows) (void)hipFree(tw->d_rows);
   if (tw->d_rsel) (void)hipFree(tw->d_rsel);
+  if (tw->d_rblk) (void)hipFree(tw->d_rblk);
   if (tw->d_sorted_hash) (void)hipFree(tw->d_sorted_hash);
   delete tw;
   return KPOP_OK;
@@ -249,6 +291,7 @@ extern "C" int kpop_twister_load(const double *T_dims_major, uint64_t n_cols, ui
     KPOP_TRY(finish_rank_select(tw, n_words, &total, st));
     if (total != tw->n_rows) KPOP_FAIL(KPOP_ERR_HIP, "kpop_twister_load: rank index holds %llu k-mers, expected %llu",
                                        (unsigned long long)total, (unsigned long long)tw->n_rows);
+    KPOP_TRY(compact_rank_index(tw, st));
   } else {
     tw->d_sorted_hash = d_hash.as<uint64_t>();
     d_hash.p = nullptr;  // ownership moves to the twister
@@ -309,6 +352,7 @@ extern "C" int kpop_twister_synth_slice(uint64_t seed, int k, int content, uint3
       seed, reinterpret_cast<const RankWord *>(tw->d_rsel), n_hashes, n_dims, tw->n_dims, tw->d_pad, tw->d_rows);
   KPOP_LAUNCH_CHECK();
   KPOP_HIP(hipStreamSynchronize(st));
+  KPOP_TRY(compact_rank_index(tw, st));
   guard.tw = nullptr;
   *out = tw;
   return KPOP_OK;

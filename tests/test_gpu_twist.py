@@ -115,6 +115,32 @@ def test_count_twist_k_above_lut_limit(kpop, oracle):
     assert_close(tw.twist(h, c.astype(np.float64), o), want)
 
 
+@pytest.mark.parametrize("k", [15, 16])
+def test_count_twist_k15_k16_through_the_block_index(kpop, oracle, k):
+    """k = 15, 16: name -> row through rank-select BLOCKS of one 64-byte sector (480 presence bits + a prefix; twister.h) instead
+    of 16-byte words -- a twister that knows some of the k-mers that occur and some that do not, reads and a few assemblies (the
+    streaming kernel: the tile route reads rank words and is off at these k), against the oracle; hashes at both ends of the range
+    and next to block boundaries among the columns"""
+    d = 24
+    rng = np.random.RandomState(k)
+    bases, offs = oracle.synth_reads(8 + k, 300, 150)
+    genomes = ["".join(rng.choice(list("ACGT"), size=int(n))) for n in (3000, 700, 5200)]
+    gb, go = concat(genomes)
+    bases = np.concatenate([bases, gb])
+    offs = np.concatenate([offs, offs[-1] + go[1:]])
+    h, c, o = oracle.count_reads(bases, offs, k)
+    present = np.unique(h)
+    extra = np.array([0, 1, 479, 480, 481, 959, 960, (1 << (2 * k)) - 1, (1 << (2 * k)) - 480, 12345678], dtype=np.uint64)
+    # (names that are not canonical k-mers are never looked up: they only take their bits of the index, next to the block edges)
+    cols = np.unique(np.concatenate([present[rng.rand(len(present)) < 0.6], extra]).astype(np.uint64))
+    cols = cols[rng.permutation(len(cols))]
+    T = oracle.synth_twister(5, d, cols)
+    tw = kpop.Twister.load(T, cols, k)
+    want = oracle.twist(T, cols, h, c.astype(np.float64), o)
+    assert_close(tw.count_twist(bases, offs), want)
+    assert_close(tw.twist(h, c.astype(np.float64), o), want)
+
+
 def test_twist_long_spectrum(kpop, oracle):
     """A 30 kb genome's spectrum (config 3 shape) through the CSR twist."""
     from conftest import GOLDEN
