@@ -1304,6 +1304,17 @@ int launch_summary_fused(int kind, const double *a, uint32_t r1, const double *b
                          const double *srow, uint32_t s, uint32_t row0, uint32_t keep_at_most, uint32_t max_neighbours, double *out_stats,
                          uint32_t *out_n, uint32_t *out_idx, double *out_dist, double *out_z, double *seg, void *scratch, hipStream_t st,
                          const uint32_t **gate);
+// distance_mfma.hip: the large-reference summary's distances on the matrix cores, and what makes its results exact again
+bool summary_mfma_applies(int kind, uint32_t r1, uint32_t n_dims, uint32_t keep_at_most, uint32_t max_neighbours);
+uint64_t summary_mfma_scratch_bytes(uint32_t q, uint32_t r1, uint32_t n_dims);
+int launch_mfma_reference_norms(const double *a, uint32_t r1, uint32_t n_dims, const double *metric, void *scratch, uint32_t q_room, hipStream_t st);
+int launch_distance_rows_mfma(int kind, const double *a, uint32_t r1, const double *b, uint32_t q, uint32_t n_dims, const double *metric, double *rows,
+                              void *scratch, uint32_t q_room, hipStream_t st);
+int launch_summary_refine(int kind, const double *rows, const double *a, uint32_t r1, const double *b, uint32_t q, uint32_t n_dims, const double *metric,
+                          double p, uint32_t row0, uint32_t keep_at_most, uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
+                          double *out_dist, double *out_z, void *scratch, uint32_t q_room, hipStream_t st, const uint32_t **gate, const void **row_counts);
+int launch_summary_flagged_rows(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most, uint32_t max_neighbours,
+                                double *out_stats, uint32_t *out_n, uint32_t *out_idx, double *out_dist, double *out_z, const void *flags, hipStream_t st);
 int launch_summary_failed_rows(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most, uint32_t max_neighbours,
                                double *out_stats, uint32_t *out_n, uint32_t *out_idx, double *out_dist, double *out_z, void *scratch,
                                hipStream_t st);
@@ -1317,6 +1328,33 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
   const double *a, *b;
   KPOP_TRY(prepare_operands<KIND>(m1, r1, m2, r2, n_dims, metric, p, normalize, work, &a, &b, st));
   const uint64_t budget = 4096ull << 20;
+  if (summary_mfma_applies(KIND, r1, n_dims, keep_at_most, max_neighbours)) {
+    // the distances on the matrix cores, approximately, to LOCATE what the summary reports; what is reported is recomputed with the
+    // reference's chain (distance_mfma.hip).  Rows the refinement cannot vouch for: exact distance rows and the one-block-per-row
+    // kernel over them, both launched whatever happened and both returning at once when nothing was flagged.
+    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(r2, 2 * budget / ((uint64_t)r1 * 8)));  // (1,024 rows against a million)
+    if (chunk > 128) chunk = chunk / 128 * 128;
+    void *ws = nullptr;
+    const uint64_t row_bytes = ((uint64_t)chunk * r1 * 8 + 255) & ~255ull;
+    const uint64_t sum_bytes = (summary_large_scratch_bytes(chunk, r1) + 511) & ~255ull;
+    KPOP_TRY(ctx().ws_for(st).ensure(row_bytes + sum_bytes + summary_mfma_scratch_bytes(chunk, r1, n_dims) + 512, &ws));
+    double *rows = reinterpret_cast<double *>(ws);
+    void *scratch = reinterpret_cast<char *>(ws) + row_bytes, *mscratch = reinterpret_cast<char *>(ws) + row_bytes + sum_bytes;
+    KPOP_TRY(launch_mfma_reference_norms(a, r1, n_dims, metric, mscratch, chunk, st));
+    for (uint32_t q0 = 0; q0 < r2; q0 += chunk) {
+      const uint32_t q = std::min(chunk, r2 - q0);
+      const double *bq = b + (uint64_t)q0 * n_dims;
+      KPOP_TRY(launch_distance_rows_mfma(KIND, a, r1, bq, q, n_dims, metric, rows, mscratch, chunk, st));
+      KPOP_TRY(launch_summary_large(rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st, scratch));
+      const uint32_t *gate = nullptr;
+      const void *flags = nullptr;
+      KPOP_TRY(launch_summary_refine(KIND, rows, a, r1, bq, q, n_dims, metric, p, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist,
+                                     out_z, mscratch, chunk, st, &gate, &flags));
+      KPOP_TRY(rowwise_block<KIND>(a, r1, bq, q, n_dims, metric, p, rows, st, nullptr, nullptr, gate));
+      KPOP_TRY(launch_summary_flagged_rows(rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, flags, st));
+    }
+    return 0;
+  }
   if (summary_fused_applies(r1, keep_at_most)) {
     // 131,072 reference rows and more: no distance rows at all (summary_large.hip, "second step").  The workspace holds, per
     // chunk of query rows, the candidates' segments (the same room distance rows would take, mostly untouched), the sample of

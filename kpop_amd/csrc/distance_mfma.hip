@@ -1,0 +1,532 @@
+// distance_mfma.hip -- the distance step of the large-reference summary on the f64 MATRIX cores, with an exact refinement.
+//
+// kpop_dev_distance_summary of a few hundred query rows against 10^5 .. 10^6 reference rows (the relatedness engine,
+// /root/reference README.md:1101; lib/Matrix.ml:691-766) spent three quarters of its time computing the q x r1 distances in
+// the vector pipe, four unfusable f64 operations per pair and dimension (lib/Space.ml:182-205), while the matrix pipe idled.
+// Here:
+//   1. distance_rows_mfma_kernel: d2 = |a|^2_m + |b|^2_m - 2 a . (b m) with the dot products as f64 MFMAs (v_mfma_f64_16x16x4:
+//      a wavefront keeps 64 query rows as A fragments in registers and streams the reference rows through LDS 16 at a time).
+//      The values differ from the reference's chain in the last bits -- cancellation: |d2~ - d2| <= G2 = gamma (|a|^2 + |b|^2) --
+//      so they are used to LOCATE, never to report: the summary's selection machinery (summary_large.hip) runs on them as it
+//      would on exact rows,
+//   2. summary_refine_kernel (one block a query row) then makes everything that is reported exact again.  With u = d^2
+//      (u = the value itself for the cosine form) every approximate value is within G2 of the exact one, hence
+//        - every row NOT within 2 G2 of the approximate req_len-th smallest is certainly not a neighbour: the rows that are
+//          (a handful) are recomputed with the reference's sequential chain, sorted by (distance, column) and cut with their ties;
+//        - every value more than 2 G2 below (above) the approximate median is certainly below (above) the exact one: the exact
+//          median is the exact (n/2 - #below)-th smallest of the few in between; the MAD likewise around both of its edges;
+//      mean and standard deviation stay sums of the approximate values (1e-13 relative: the tests allow 1e-10 for rows this long).
+//      A row whose bands overflow or whose ranks do not fall inside them is FLAGGED and redone from exact distance rows by the
+//      kernels that were there before (the same fall-back the bracket path uses).
+// Euclidean and cosine forms (Minkowski's |x|^p is no contraction), up to 128 dimensions, req_len <= max_neighbours <= 2,048.
+#include <algorithm>
+
+#include "common.h"
+#include "space_ops.h"
+
+namespace kpop {
+
+using f64x4m = __attribute__((ext_vector_type(4))) double;
+
+// out[row] = sum_c m_c x_c^2; scaled (optional) = x m; *smax (optional) = the largest sum (one atomic a block)
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const double *__restrict__ x, uint32_t rows, uint32_t n_dims, const double *__restrict__ metric,
+                                                        double *__restrict__ out, double *__restrict__ scaled, unsigned long long *__restrict__ smax) {
+  __shared__ unsigned long long s_max;
+  if (threadIdx.x == 0) s_max = 0;
+  __syncthreads();
+  const uint32_t l = threadIdx.x & 15u;
+  // (a few thousand blocks at most: every block ends with an atomic on the ONE word of the maximum, and 62,500 of those took 0.7 ms)
+  for (uint32_t row = blockIdx.x * 16 + (threadIdx.x >> 4); row < ((rows + 15u) & ~15u); row += gridDim.x * 16) {
+  double acc = 0.0;
+  if (row < rows) {
+    for (uint32_t c0 = 0; c0 < n_dims; c0 += 128) {  // (eight loads in flight a lane: 128 dimensions a sweep)
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t c = c0 + l + 16u * k;
+        v[k] = c < n_dims ? x[(uint64_t)row * n_dims + c] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t c = c0 + l + 16u * k;
+        if (c < n_dims) {
+          const double m = metric[c];
+          acc += v[k] * v[k] * m;
+          if (scaled) scaled[(uint64_t)row * n_dims + c] = v[k] * m;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 16);
+  if (row < rows && l == 0) {
+    out[row] = acc;
+    if (smax) atomicMax(&s_max, (unsigned long long)__double_as_longlong(acc));  // (sums of squares: not negative, their bit patterns order as they do)
+  }
+  }
+  __syncthreads();
+  if (smax && threadIdx.x == 0) atomicMax(smax, s_max);
+}
+
+// sqrt(u), u >= 0, to an ulp or two in ten operations (the f64 vector operations of the epilogue and the f64 MFMAs share the
+// same units: what the epilogue spends the matrix pipe waits for).  rsq's 23 bits, one Newton step, one correction with the
+// residual; 0 -> 0; values below 1e-290 (their rsq overflows) -> 0: they ARE zero at the accuracy of these rows
+__device__ __forceinline__ double sqrt_fast(double u) {
+  const double y = __builtin_amdgcn_rsq(fmax(u, 1e-290));
+  double g = u * y;
+  const double h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  const double r2 = __builtin_fma(-g, g, u);
+  return __builtin_fma(r2, h, g);
+}
+
+// rows~[j][i] for 64 MI query rows a block (16 MI a wavefront, their A fragments in registers for the whole kernel) and a run of
+// 16-row tiles of the reference set (the B fragments, through LDS, double-buffered; the next tile's loads fly under the MFMAs).
+// MI = 2 for up to 64 dimensions, 132 registers: three wavefronts a SIMD, one's square roots and stores under another's MFMAs.
+template <int KIND, int KS, int MI>  // KS steps of 4 dimensions: n_dims <= 4 KS
+__global__ __launch_bounds__(256) void distance_rows_mfma_kernel(const double *__restrict__ a, uint32_t r1, const double *__restrict__ bm, uint32_t q, uint32_t n_dims,
+                                                                 const double *__restrict__ sa, const double *__restrict__ sb, double *__restrict__ out,
+                                                                 uint32_t tiles_per_block) {
+  constexpr int TS = 4 * KS + 2;  // a staged row's doubles: + 2 spreads a half-wavefront's 16 rows over the banks
+  __shared__ double s_tile[2][16][TS];
+  __shared__ double s_sa[2][16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t l15 = (uint32_t)lane & 15u, l4 = (uint32_t)lane >> 4;
+  const uint32_t j0 = blockIdx.y * (64u * MI) + (uint32_t)wv * (16u * MI);
+  double af[MI][KS];  // A fragments: lane = (query row l15 of the M tile, dimension 4 ks + l4)
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const uint32_t row = j0 + 16u * mi + l15, c = 4u * ks + l4;
+      af[mi][ks] = (row < q && c < n_dims) ? bm[(uint64_t)row * n_dims + c] : 0.0;
+    }
+  double sbv[MI][4];  // the norms of the rows a lane's accumulators belong to: row 16 mi + l4 + 4 rr
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const uint32_t row = j0 + 16u * mi + l4 + 4u * rr;
+      sbv[mi][rr] = row < q ? sb[row] : 0.0;
+    }
+  const uint32_t n_tiles = (r1 + 15u) / 16u;
+  const uint32_t t0 = blockIdx.x * tiles_per_block, t1 = min(n_tiles, t0 + tiles_per_block);
+  if (t0 >= t1) return;
+  const bool rows_full = j0 + 16u * MI <= q;  // (wavefront-uniform)
+  constexpr uint32_t PER = (16u * 4u * KS + 255u) / 256u;  // doubles of a tile a thread moves
+  double pre[PER], pre_sa = 0.0;
+  auto fetch = [&](uint32_t t) {
+#pragma unroll
+    for (uint32_t e = 0; e < PER; ++e) {
+      const uint32_t idx = threadIdx.x + 256u * e, r = idx / (4u * KS), c = idx % (4u * KS);
+      const uint32_t i = min(16u * t + r, r1 - 1u);  // (rows past the end: the last row again, never stored)
+      pre[e] = c < n_dims ? a[(uint64_t)i * n_dims + c] : 0.0;
+    }
+    if (threadIdx.x < 16) pre_sa = sa[min(16u * t + threadIdx.x, r1 - 1u)];
+  };
+  auto put = [&](int buf) {
+#pragma unroll
+    for (uint32_t e = 0; e < PER; ++e) {
+      const uint32_t idx = threadIdx.x + 256u * e, r = idx / (4u * KS), c = idx % (4u * KS);
+      s_tile[buf][r][c] = pre[e];
+    }
+    if (threadIdx.x < 16) s_sa[buf][threadIdx.x] = pre_sa;
+  };
+  static_assert((16u * 4u * KS) % 256u == 0, "a tile is a whole number of sweeps of the block");
+  fetch(t0);
+  put(0);
+  __syncthreads();
+  for (uint32_t t = t0; t < t1; ++t) {
+    const int buf = (int)((t - t0) & 1u);
+    fetch(min(t + 1, t1 - 1));  // (in flight under this tile's MFMAs; the last tile is fetched twice rather than branched around)
+    f64x4m acc[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) acc[mi] = f64x4m{0.0, 0.0, 0.0, 0.0};
+    if constexpr (KS <= 16) {  // the tile's B fragments first, then the MFMAs back to back
+      double bf[KS];  // B fragment: lane = (dimension 4 ks + l4, reference row l15)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) bf[ks] = s_tile[buf][l15][4 * ks + (int)l4];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi][ks], bf[ks], acc[mi], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const double bf = s_tile[buf][l15][4 * ks + (int)l4];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi][ks], bf, acc[mi], 0, 0, 0);
+      }
+    }
+    const double sai = s_sa[buf][l15];
+    put(buf ^ 1);  // (its readers passed the barrier that ended the previous tile)
+    const uint32_t i = 16u * t + l15;
+    if (rows_full && 16u * t + 16u <= r1) {  // (uniform) straight-line stores
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {  // lane holds query rows l4 + 4 rr of the M tile, reference row l15
+          const uint32_t row = j0 + 16u * mi + l4 + 4u * rr;
+          double u = sai + sbv[mi][rr] - 2.0 * acc[mi][rr];
+          u = u > 0.0 ? u : 0.0;
+          out[(uint64_t)row * r1 + i] = KIND == KPOP_EUCLIDEAN ? sqrt_fast(u) : u * 0.5;
+        }
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const uint32_t row = j0 + 16u * mi + l4 + 4u * rr;
+          double u = sai + sbv[mi][rr] - 2.0 * acc[mi][rr];
+          u = u > 0.0 ? u : 0.0;
+          if (row < q && i < r1) out[(uint64_t)row * r1 + i] = KIND == KPOP_EUCLIDEAN ? sqrt_fast(u) : u * 0.5;
+        }
+    }
+    __syncthreads();
+  }
+}
+
+// the RowCounts of summary_large.hip as this file sees them: 48 bytes a row, `fail` the tenth word
+constexpr uint32_t kRowCountsWords = 12, kRowCountsFail = 9;
+constexpr uint32_t kRefNb = 3072, kRefMed = 1024, kRefMad = 2048;  // room of the three bands (rows of the reference set)
+
+template <int KIND>
+__device__ __forceinline__ double exact_pair(const double *__restrict__ arow, const double *__restrict__ brow, const double *__restrict__ metric, uint32_t n_dims, double p) {
+  double acc = 0.0;
+  for (uint32_t c = 0; c < n_dims; ++c) {  // the reference's chain, dimension by dimension (lib/Space.ml:182-205; distance.hip)
+    const double diff = __dsub_rn(arow[c], brow[c]);
+    acc = __dadd_rn(acc, component<KIND>(diff, metric[c], p));
+  }
+  return scale_distance<KIND>(acc, p);
+}
+
+__device__ __forceinline__ bool pair_less(double da, uint32_t ia, double db, uint32_t ib) { return da < db || (da == db && ia < ib); }
+
+// One block a query row: see the head of the file.  rows: the approximate distances [q][r1]; stats etc.: what the summary made of
+// them (overwritten where exactness matters: median, MAD, the neighbours); rc: RowCounts (its `fail` set for a row left to the fall-back)
+template <int KIND>
+__global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__restrict__ rows, const double *__restrict__ a, uint32_t r1, const double *__restrict__ b,
+                                                              uint32_t n_dims, const double *__restrict__ metric, double p, const double *__restrict__ sb,
+                                                              const unsigned long long *__restrict__ smax_bits, uint32_t row0, uint32_t req_len,
+                                                              uint32_t max_neighbours, double gamma, double *__restrict__ out_stats, uint32_t *__restrict__ out_n,
+                                                              uint32_t *__restrict__ out_idx, double *__restrict__ out_dist, double *__restrict__ out_z,
+                                                              uint32_t *__restrict__ rc, uint32_t *__restrict__ n_failed) {
+  __shared__ uint32_t s_nb_i[kRefNb], s_med_i[kRefMed], s_mad_i[kRefMad];
+  __shared__ double s_nb_d[kRefNb], s_med_d[kRefMed], s_mad_d[kRefMad];
+  __shared__ double s_b[128], s_m[128];
+  __shared__ uint32_t s_cnt[8];  // [0] neighbours' band, [1] median's band, [2] below it, [3] MAD's band, [4] inside it, [5] failed
+  __shared__ double s_val[2];    // the exact median, the exact MAD
+  __shared__ double s_corr[16][2];
+  const uint32_t jl = blockIdx.x, j = row0 + jl;
+  if (rc[(uint64_t)jl * kRowCountsWords + kRowCountsFail]) return;  // (already the fall-back's)
+  const double *row = rows + (uint64_t)jl * r1;
+  const double *brow = b + (uint64_t)jl * n_dims;
+  for (uint32_t c = threadIdx.x; c < n_dims; c += 1024) {
+    s_b[c] = brow[c];
+    s_m[c] = metric[c];
+  }
+  if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const double mean_a = out_stats[(uint64_t)j * 4 + 0], sd_a = out_stats[(uint64_t)j * 4 + 1], med_a = out_stats[(uint64_t)j * 4 + 2], mad_a = out_stats[(uint64_t)j * 4 + 3];
+  const uint32_t eff_a = out_n[j];
+  const double S = sb[jl] + __longlong_as_double((long long)*smax_bits);
+  // |u~ - u| <= G for every pair of this row, u = d^2 for the euclidean form and the value itself for the cosine form (d^2 / 2)
+  const double G = (KIND == KPOP_EUCLIDEAN ? 1.0 : 0.5) * gamma * S;
+  auto sq = [](double x) -> double { return KIND == KPOP_EUCLIDEAN ? x * x : x; };
+  // how far an approximate value near x can be from its exact value, in the value's own units (to size the MAD's bands: the
+  // certificates below do not depend on it being right)
+  auto err_at = [&](double x) -> double {
+    if (KIND != KPOP_EUCLIDEAN) return G;
+    return x * x >= 4.0 * G ? 1.25 * G / x : 2.0 * sqrt(G);
+  };
+  bool ok = eff_a >= 1 && eff_a <= max_neighbours && req_len <= max_neighbours && req_len >= 1 && r1 >= 2;
+  // the approximate req_len-th smallest (the list the summary wrote is ascending)
+  const double t_a = ok ? out_dist[(uint64_t)j * max_neighbours + (min(req_len, eff_a) - 1u)] : 0.0;
+  // a neighbour (or a tie of the last) has u~ <= sq(t_a) + 2.5 G.  The band also takes everything so near the query that the
+  // cancellation shows in the VALUE (u~ <= 1e5 G: a copy of the query comes out at 1e-7 instead of 0): their exact values
+  // replace the approximate ones in the sums of the mean and the standard deviation as well
+  const double u_nb = fmax(sq(t_a) + 2.5 * G, 1e5 * G);
+  const double u_med_lo = sq(med_a) - 2.5 * G, u_med_hi = sq(med_a) + 2.5 * G;  // below / above: certainly below / above the exact median
+  // the MAD: |d - median| < MAD inside (E1, E2) = median -+ MAD.  Brackets for the two edges, W either side:
+  const double E2 = med_a + mad_a, E1 = med_a - mad_a;
+  const double W = 3.0 * (err_at(med_a) + fmax(err_at(E2), E1 > 0.0 ? err_at(E1) : 0.0)) + 1e-15 * E2;
+  const double e2lo = fmax(E2 - W, 0.0), e2hi = E2 + W, e1lo = E1 - W, e1hi = E1 + W;
+  const double u_e2lo = sq(e2lo) - 1.25 * G, u_e2hi = sq(e2hi) + 1.25 * G;  // u~ below / above these: certainly below / above the upper edge
+  const bool low_edge = e1hi > 0.0;                                        // (no lower edge: the MAD is at least the median)
+  const double u_e1hi = low_edge ? sq(e1hi) + 1.25 * G : -1.0, u_e1lo = e1lo > 0.0 ? sq(e1lo) - 1.25 * G : -1.0;
+  uint32_t n_below = 0, n_inside = 0;
+  constexpr int U = 8;  // loads in flight a thread
+  for (uint32_t base = 0; base < r1; base += 1024 * U) {
+    double xs[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const uint32_t i = base + k * 1024 + threadIdx.x;
+      xs[k] = row[min(i, r1 - 1u)];
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+    const uint32_t i = base + k * 1024 + threadIdx.x;
+    if (i >= r1) continue;
+    const double x = xs[k], u = sq(x);
+    if (u <= u_nb) {
+      const uint32_t at = atomicAdd(&s_cnt[0], 1u);
+      if (at < kRefNb) s_nb_i[at] = i;
+    }
+    if (u < u_med_lo) ++n_below;
+    else if (u <= u_med_hi) {
+      const uint32_t at = atomicAdd(&s_cnt[1], 1u);
+      if (at < kRefMed) s_med_i[at] = i;
+    }
+    const bool in_sure = u < u_e2lo && (!low_edge || u > u_e1hi);
+    const bool out_sure = u > u_e2hi || (e1lo > 0.0 && u < u_e1lo);
+    if (in_sure) ++n_inside;
+    else if (!out_sure) {
+      const uint32_t at = atomicAdd(&s_cnt[3], 1u);
+      if (at < kRefMad) s_mad_i[at] = i;
+    }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    n_below += (uint32_t)__shfl_xor((int)n_below, o, 64);
+    n_inside += (uint32_t)__shfl_xor((int)n_inside, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&s_cnt[2], n_below);
+    atomicAdd(&s_cnt[4], n_inside);
+  }
+  __syncthreads();
+  const uint32_t n_nb = s_cnt[0], n_med = s_cnt[1], n_lt = s_cnt[2], n_mad = s_cnt[3], n_in = s_cnt[4];
+  const uint32_t r_med = r1 / 2;  // element n / 2 of the sorted row: the upper median (lib/Matrix.ml:664-670)
+  ok = ok && n_nb <= kRefNb && n_med <= kRefMed && n_mad <= kRefMad && n_nb >= req_len && r_med >= n_lt && r_med - n_lt < n_med && r_med >= n_in && r_med - n_in < n_mad;
+  auto give_up = [&]() {  // the fall-back's
+    if (threadIdx.x == 0) {
+      rc[(uint64_t)jl * kRowCountsWords + kRowCountsFail] = 1u;
+      atomicAdd(n_failed, 1u);
+    }
+  };
+  if (!ok) {  // (uniform)
+    give_up();
+    return;
+  }
+  // the exact distances of the neighbours' and the median's bands
+  double c1 = 0.0, c2 = 0.0;  // what the band's exact values change in sum d and in sum (d - mean)^2
+  for (uint32_t e = threadIdx.x; e < n_nb; e += 1024) {
+    const double dx = exact_pair<KIND>(a + (uint64_t)s_nb_i[e] * n_dims, s_b, s_m, n_dims, p), x = row[s_nb_i[e]];
+    s_nb_d[e] = dx;
+    c1 += dx - x;
+    c2 += (dx - mean_a) * (dx - mean_a) - (x - mean_a) * (x - mean_a);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    c1 += __shfl_xor(c1, o, 64);
+    c2 += __shfl_xor(c2, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_corr[threadIdx.x >> 6][0] = c1;
+    s_corr[threadIdx.x >> 6][1] = c2;
+  }
+  for (uint32_t e = threadIdx.x; e < n_med; e += 1024) s_med_d[e] = exact_pair<KIND>(a + (uint64_t)s_med_i[e] * n_dims, s_b, s_m, n_dims, p);
+  __syncthreads();
+  // the median: the band's element of rank r_med - n_lt (ranks by counting: the bands are small)
+  for (uint32_t e = threadIdx.x; e < n_med; e += 1024) {
+    const double de = s_med_d[e];
+    const uint32_t ie = s_med_i[e];
+    uint32_t rank = 0;
+    for (uint32_t f = 0; f < n_med; ++f) rank += pair_less(s_med_d[f], s_med_i[f], de, ie) ? 1u : 0u;
+    if (rank == r_med - n_lt) s_val[0] = de;
+  }
+  __syncthreads();
+  const double median = s_val[0];
+  double mean = mean_a, sd = sd_a;
+  if (r1 > 1) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int w = 0; w < 16; ++w) {
+      t1 += s_corr[w][0];
+      t2 += s_corr[w][1];
+    }
+    const double n = (double)r1;
+    mean = mean_a + t1 / n;
+    const double ss = fmax(0.0, sd_a * sd_a * (n - 1.0) + t2 - n * (mean - mean_a) * (mean - mean_a));
+    sd = sqrt(ss / (n - 1.0));
+  }
+  // (the certificate: the values counted as below / above ARE below / above it -- they are G or more away in u)
+  if (!(sq(median) >= u_med_lo + G && sq(median) <= u_med_hi - G)) {  // (uniform)
+    give_up();
+    return;
+  }
+  // the MAD: exact deviations of its band from the exact median, the element of rank r_med - n_in
+  for (uint32_t e = threadIdx.x; e < n_mad; e += 1024)
+    s_mad_d[e] = fabs(__dsub_rn(exact_pair<KIND>(a + (uint64_t)s_mad_i[e] * n_dims, s_b, s_m, n_dims, p), median));
+  __syncthreads();
+  for (uint32_t e = threadIdx.x; e < n_mad; e += 1024) {
+    const double de = s_mad_d[e];
+    const uint32_t ie = s_mad_i[e];
+    uint32_t rank = 0;
+    for (uint32_t f = 0; f < n_mad; ++f) rank += pair_less(s_mad_d[f], s_mad_i[f], de, ie) ? 1u : 0u;
+    if (rank == r_med - n_in) s_val[1] = de;
+  }
+  // the neighbours: the band sorted by (distance, column) -- every element to its rank --, cut after the req_len-th with its ties
+  // (lib/Matrix.ml:641-650: the smallest groups of equal distances until req_len entries are reached)
+  __syncthreads();
+  const double mad = s_val[1];
+  {
+    // the certificate: both exact edges lie inside their brackets, so what was counted inside (outside) is
+    const double x2 = median + mad, x1 = median - mad;
+    const bool good = x2 >= e2lo && x2 <= e2hi && (low_edge ? (x1 <= e1hi && (e1lo <= 0.0 || x1 >= e1lo)) : x1 <= 0.0 || x1 <= e1hi);
+    if (!good) {  // (uniform)
+      give_up();
+      return;
+    }
+  }
+  uint32_t my_rank[(kRefNb + 1023) / 1024];
+#pragma unroll
+  for (uint32_t s = 0; s < (kRefNb + 1023) / 1024; ++s) {
+    const uint32_t e = threadIdx.x + 1024u * s;
+    my_rank[s] = 0xFFFFFFFFu;
+    if (e < n_nb) {
+      const double de = s_nb_d[e];
+      const uint32_t ie = s_nb_i[e];
+      uint32_t rank = 0;
+      for (uint32_t f = 0; f < n_nb; ++f) rank += pair_less(s_nb_d[f], s_nb_i[f], de, ie) ? 1u : 0u;
+      my_rank[s] = rank;
+      if (rank == req_len - 1u) s_val[0] = de;  // (the median has been read: its room takes the cut)
+    }
+  }
+  __syncthreads();
+  const double cut = s_val[0];
+  if (!(sq(cut) <= u_nb - G)) {  // (the certificate: no row outside the band is as near as the cut or ties with it)
+    give_up();
+    return;
+  }
+  uint32_t n_eff = 0;
+  for (uint32_t e = threadIdx.x; e < n_nb; e += 1024) n_eff += s_nb_d[e] <= cut ? 1u : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n_eff += (uint32_t)__shfl_xor((int)n_eff, o, 64);
+  if ((threadIdx.x & 63) == 0 && n_eff) atomicAdd(&s_cnt[6], n_eff);
+  __syncthreads();
+  const uint32_t eff = s_cnt[6];
+  if (eff > max_neighbours) {  // (a tie group longer than the caller's lists: the fall-back's, and after it the host's long lists)
+    if (threadIdx.x == 0) {
+      rc[(uint64_t)jl * kRowCountsWords + kRowCountsFail] = 1u;
+      atomicAdd(n_failed, 1u);
+    }
+    return;
+  }
+#pragma unroll
+  for (uint32_t s = 0; s < (kRefNb + 1023) / 1024; ++s) {
+    const uint32_t e = threadIdx.x + 1024u * s;
+    if (e < n_nb && my_rank[s] < eff) {
+      const double dq = s_nb_d[e];
+      out_idx[(uint64_t)j * max_neighbours + my_rank[s]] = s_nb_i[e];
+      out_dist[(uint64_t)j * max_neighbours + my_rank[s]] = dq;
+      double zz = __dsub_rn(dq, mean) / sd;
+      if (zz != zz) zz = __longlong_as_double((long long)0xFFF8000000000000ull);  // x86 invalid-operation NaN, see distance.hip
+      out_z[(uint64_t)j * max_neighbours + my_rank[s]] = zz;
+    }
+  }
+  if (threadIdx.x == 0) {
+    out_stats[(uint64_t)j * 4 + 0] = mean;
+    out_stats[(uint64_t)j * 4 + 1] = sd;
+    out_stats[(uint64_t)j * 4 + 2] = median;
+    out_stats[(uint64_t)j * 4 + 3] = mad;
+    out_n[j] = eff;
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------
+bool summary_mfma_applies(int kind, uint32_t r1, uint32_t n_dims, uint32_t keep_at_most, uint32_t max_neighbours) {
+  const uint32_t req_len = keep_at_most ? keep_at_most : r1;
+  return ctx().tune_summary_mfma != 0 && (kind == KPOP_EUCLIDEAN || kind == KPOP_COSINE) && n_dims >= 4 && n_dims <= 128 && r1 >= 65536 &&
+         req_len <= max_neighbours && max_neighbours <= 2048;
+}
+// room for: the query rows times the metric, the two sets of norms, the largest of them, the fall-back's flags and its count
+uint64_t summary_mfma_scratch_bytes(uint32_t q, uint32_t r1, uint32_t n_dims) {
+  return (((uint64_t)q * n_dims * 8 + 255) & ~255ull) + (((uint64_t)r1 * 8 + 255) & ~255ull) + (((uint64_t)q * 8 + 255) & ~255ull) + 256 +
+         (((uint64_t)q * kRowCountsWords * 4 + 255) & ~255ull) + 256;
+}
+struct MfmaScratch {
+  double *bm, *sa, *sb;
+  unsigned long long *smax;
+  uint32_t *rc, *n_failed;
+};
+static MfmaScratch carve_mfma(void *scratch, uint32_t q, uint32_t r1, uint32_t n_dims) {
+  char *p = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(scratch) + 255) & ~(uintptr_t)255);
+  MfmaScratch M;
+  M.bm = reinterpret_cast<double *>(p);
+  p += ((uint64_t)q * n_dims * 8 + 255) & ~255ull;
+  M.sa = reinterpret_cast<double *>(p);
+  p += ((uint64_t)r1 * 8 + 255) & ~255ull;
+  M.sb = reinterpret_cast<double *>(p);
+  p += ((uint64_t)q * 8 + 255) & ~255ull;
+  M.smax = reinterpret_cast<unsigned long long *>(p);
+  p += 256;
+  M.rc = reinterpret_cast<uint32_t *>(p);
+  p += ((uint64_t)q * kRowCountsWords * 4 + 255) & ~255ull;
+  M.n_failed = reinterpret_cast<uint32_t *>(p);
+  return M;
+}
+
+// the reference set's norms (once per call: they do not depend on the chunk of query rows)
+int launch_mfma_reference_norms(const double *a, uint32_t r1, uint32_t n_dims, const double *metric, void *scratch, uint32_t q_room, hipStream_t st) {
+  const MfmaScratch M = carve_mfma(scratch, q_room, r1, n_dims);
+  KPOP_HIP(hipMemsetAsync(M.smax, 0, 256, st));
+  row_sumsq_kernel<<<dim3(std::min(div_up(r1, 16), 4096u)), dim3(256), 0, st>>>(a, r1, n_dims, metric, M.sa, nullptr, M.smax);
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int KIND>
+static int launch_rows_mfma(const double *a, uint32_t r1, const double *b, uint32_t q, uint32_t n_dims, const double *metric, double *rows, const MfmaScratch &M,
+                            hipStream_t st) {
+  row_sumsq_kernel<<<dim3(std::min(div_up(q, 16), 4096u)), dim3(256), 0, st>>>(b, q, n_dims, metric, M.sb, M.bm, nullptr);
+  KPOP_LAUNCH_CHECK();
+  // every block resident at once (three a CU for up to 64 dimensions, two beyond), each an equal run of tiles
+  const uint32_t n_tiles = div_up(r1, 16);
+  const bool small = n_dims <= 64;
+  const uint32_t rows_per_block = small ? 128u : 256u, ny = div_up(q, rows_per_block);
+  const uint32_t resident = (uint32_t)ctx().n_cus * (small ? 3u : 2u);
+  const uint32_t gx = std::max(1u, std::min(n_tiles, std::max(1u, resident / ny)));
+  const uint32_t tpb = div_up(n_tiles, gx);
+  const dim3 grid(div_up(n_tiles, tpb), ny);
+  if (small)
+    distance_rows_mfma_kernel<KIND, 16, 2><<<grid, dim3(256), 0, st>>>(a, r1, M.bm, q, n_dims, M.sa, M.sb, rows, tpb);
+  else
+    distance_rows_mfma_kernel<KIND, 32, 4><<<grid, dim3(256), 0, st>>>(a, r1, M.bm, q, n_dims, M.sa, M.sb, rows, tpb);
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
+
+// the chunk's approximate distance rows (into `rows`), and the flags of its fall-back cleared
+int launch_distance_rows_mfma(int kind, const double *a, uint32_t r1, const double *b, uint32_t q, uint32_t n_dims, const double *metric, double *rows,
+                              void *scratch, uint32_t q_room, hipStream_t st) {
+  const MfmaScratch M = carve_mfma(scratch, q_room, r1, n_dims);
+  KPOP_HIP(hipMemsetAsync(M.rc, 0, (uint64_t)q * kRowCountsWords * 4, st));
+  KPOP_HIP(hipMemsetAsync(M.n_failed, 0, 256, st));
+  return kind == KPOP_EUCLIDEAN ? launch_rows_mfma<KPOP_EUCLIDEAN>(a, r1, b, q, n_dims, metric, rows, M, st)
+                                : launch_rows_mfma<KPOP_COSINE>(a, r1, b, q, n_dims, metric, rows, M, st);
+}
+
+// the refinement; *gate = the device word that counts the rows left to the fall-back, *row_counts = their flags (RowCounts)
+int launch_summary_refine(int kind, const double *rows, const double *a, uint32_t r1, const double *b, uint32_t q, uint32_t n_dims, const double *metric,
+                          double p, uint32_t row0, uint32_t keep_at_most, uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
+                          double *out_dist, double *out_z, void *scratch, uint32_t q_room, hipStream_t st, const uint32_t **gate, const void **row_counts) {
+  const MfmaScratch M = carve_mfma(scratch, q_room, r1, n_dims);
+  const uint32_t req_len = keep_at_most ? keep_at_most : r1;
+  // |u~ - u| <= gamma (|a|^2 + |b|^2): n_dims products and additions of the contraction and of the two norms at 2^-53 each, the
+  // chain's own roundings, and a factor of ten on top
+  const double gamma = 4e-15 * (double)std::max(n_dims, 16u);
+  if (kind == KPOP_EUCLIDEAN)
+    summary_refine_kernel<KPOP_EUCLIDEAN><<<dim3(q), dim3(1024), 0, st>>>(rows, a, r1, b, n_dims, metric, p, M.sb, M.smax, row0, req_len, max_neighbours, gamma, out_stats,
+                                                                          out_n, out_idx, out_dist, out_z, M.rc, M.n_failed);
+  else
+    summary_refine_kernel<KPOP_COSINE><<<dim3(q), dim3(1024), 0, st>>>(rows, a, r1, b, n_dims, metric, p, M.sb, M.smax, row0, req_len, max_neighbours, gamma, out_stats,
+                                                                       out_n, out_idx, out_dist, out_z, M.rc, M.n_failed);
+  KPOP_LAUNCH_CHECK();
+  *gate = M.n_failed;
+  *row_counts = M.rc;
+  return 0;
+}
+
+}  // namespace kpop

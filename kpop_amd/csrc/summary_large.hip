@@ -1530,6 +1530,16 @@ int launch_summary_failed_rows(const double *rows, uint32_t n_rows, uint32_t r1,
   return 0;
 }
 
+// the same over rows another path flagged (distance_mfma.hip: `flags` = its RowCounts, one a row of the chunk)
+int launch_summary_flagged_rows(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most, uint32_t max_neighbours,
+                                double *out_stats, uint32_t *out_n, uint32_t *out_idx, double *out_dist, double *out_z, const void *flags, hipStream_t st) {
+  summary_large_kernel<<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, keep_at_most ? keep_at_most : r1, max_neighbours, out_stats, out_n, out_idx,
+                                                           out_dist, out_z, reinterpret_cast<const RowCounts *>(flags));
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
+static_assert(sizeof(RowCounts) == 48 && offsetof(RowCounts, fail) == 36, "distance_mfma.hip writes RowCounts::fail by its word index");
+
 static inline uint32_t rows_cand_cap(uint32_t r1) { return std::max(cand_cap_for(r1), fused_cand_cap(r1)); }
 
 uint64_t summary_large_scratch_bytes(uint32_t n_rows, uint32_t r1) {

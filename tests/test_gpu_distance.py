@@ -603,3 +603,57 @@ def test_splits_gaps_golden_and_random(kpop, pyref):
         for s, (wg, wm) in enumerate(want):
             assert gap[s].hex() == wg.hex(), s
             assert sorted(perm[dim[s], :idx[s] + 1].tolist()) == wm, s
+
+
+@pytest.mark.parametrize("case", ["random", "classes", "near_duplicates", "grid", "offset", "constant"])
+@pytest.mark.parametrize("kind,d", [(0, 64), (1, 64), (0, 12), (0, 100)])
+def test_distance_summary_on_the_matrix_cores(kpop, oracle, case, kind, d):
+    """65,536 reference rows and more, euclidean / cosine: the distances are f64 MFMAs that LOCATE (|a|^2 + |b|^2 - 2 a.b: last
+    bits differ from the reference's chain), what is reported -- neighbours, median, MAD -- is recomputed with the chain
+    (distance_mfma.hip).  Exact against the oracle and bit for bit against the vector-pipe path (kpop_tune("summary_mfma", 0)),
+    where cancellation bites included: reference rows equal to a query and 1e-12 .. 1e-6 away from it (near_duplicates),
+    every row far from the origin (offset: the bands hold too much, the rows go to the fall-back), ties by the thousand
+    (grid, constant)"""
+    from kpop_amd import api
+    rng = np.random.RandomState(len(case) * 131 + kind * 7 + d)
+    r1, r2 = 70001, 9
+    if case == "classes":
+        centres = rng.normal(size=(5, d)) * 3
+        m1 = np.repeat(centres, [r1 // 5] * 4 + [r1 - 4 * (r1 // 5)], axis=0) + rng.normal(size=(r1, d)) * 0.3
+    elif case == "constant":
+        m1 = np.tile(rng.normal(size=(1, d)), (r1, 1))
+    elif case == "grid":
+        m1 = np.round(rng.normal(size=(r1, d)), 0)
+    else:
+        m1 = rng.normal(size=(r1, d))
+    m2 = rng.normal(size=(r2, d)) if case != "grid" else np.round(rng.normal(size=(r2, d)), 0)
+    if case == "offset":
+        m1 += 1000.0
+        m2 += 1000.0
+    m2[1] = m1[5]  # a zero distance
+    m1[77] = m1[5]  # ... twice
+    if case == "near_duplicates":
+        for t, eps in enumerate((0.0, 1e-12, 1e-9, 1e-6, 1e-3)):
+            rows = np.arange(1000 + 40 * t, 1000 + 40 * t + 40)
+            m1[rows] = m2[2] * (1.0 + eps * rng.normal(size=(40, d)))
+            m1[rows + 30000] = m2[3] + eps * rng.normal(size=(40, d))
+    metric = oracle.metric_powers(oracle.synth_inertia(d))
+    for normalize in (False, True) if case in ("random", "near_duplicates") else (True,):
+        for keep in (1, 300):
+            st_o, offs, idx_o, dist_o, z_o = oracle.distance_summary(m1, m2, metric, kind, 2.0, normalize, keep)
+            res = {}
+            for mode in (1, 0):
+                api.tune("summary_mfma", mode)
+                res[mode] = kpop.distance_summary(m1, m2, metric, kind, 2.0, normalize, keep, max_neighbours=512)
+            api.tune("summary_mfma", 1)
+            st, n, idx, dist, z = res[1]
+            np.testing.assert_allclose(st[:, :2], st_o[:, :2], rtol=1e-10, atol=1e-13)
+            assert np.array_equal(st[:, 2:], st_o[:, 2:]), (case, keep, st, st_o)  # median and MAD: order statistics, exact
+            assert np.array_equal(st[:, 2:], res[0][0][:, 2:])
+            for j in range(r2):
+                a, b = int(offs[j]), int(offs[j + 1])
+                assert n[j] == b - a == res[0][1][j], (case, keep, j, n[j], b - a)
+                m = min(n[j], 512)
+                assert idx[j, :m].tolist() == idx_o[a:a + m].tolist() and np.array_equal(dist[j, :m], dist_o[a:a + m]), (case, keep, j)
+                if case != "constant":
+                    np.testing.assert_allclose(z[j, :m], z_o[a:a + m], rtol=1e-8, atol=1e-9)
