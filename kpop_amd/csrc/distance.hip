@@ -20,6 +20,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "summary_types.h"
 #include "radix_sort.h"
 #include "space_ops.h"
 #include "wave_sort.h"
@@ -1294,7 +1295,7 @@ static int rowwise_impl(const double *m1, uint32_t r1, const double *m2, uint32_
 // summary_large.hip
 int launch_summary_large(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most,
                          uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
-                         double *out_dist, double *out_z, hipStream_t st, void *scratch);
+                         double *out_dist, double *out_z, hipStream_t st, void *scratch, SummaryLists *lists = nullptr);
 uint64_t summary_large_scratch_bytes(uint32_t n_rows, uint32_t r1);
 bool summary_fused_applies(uint32_t r1, uint32_t keep_at_most);
 uint32_t summary_fused_sample_rows(uint32_t r1);
@@ -1312,7 +1313,8 @@ int launch_distance_rows_mfma(int kind, const double *a, uint32_t r1, const doub
                               void *scratch, uint32_t q_room, hipStream_t st);
 int launch_summary_refine(int kind, const double *rows, const double *a, uint32_t r1, const double *b, uint32_t q, uint32_t n_dims, const double *metric,
                           double p, uint32_t row0, uint32_t keep_at_most, uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
-                          double *out_dist, double *out_z, void *scratch, uint32_t q_room, hipStream_t st, const uint32_t **gate, const void **row_counts);
+                          double *out_dist, double *out_z, void *scratch, uint32_t q_room, hipStream_t st, const SummaryLists &lists, const uint32_t **gate,
+                          const void **row_counts);
 int launch_summary_flagged_rows(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most, uint32_t max_neighbours,
                                 double *out_stats, uint32_t *out_n, uint32_t *out_idx, double *out_dist, double *out_z, const void *flags, hipStream_t st);
 int launch_summary_failed_rows(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most, uint32_t max_neighbours,
@@ -1345,11 +1347,12 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
       const uint32_t q = std::min(chunk, r2 - q0);
       const double *bq = b + (uint64_t)q0 * n_dims;
       KPOP_TRY(launch_distance_rows_mfma(KIND, a, r1, bq, q, n_dims, metric, rows, mscratch, chunk, st));
-      KPOP_TRY(launch_summary_large(rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st, scratch));
+      SummaryLists lists;
+      KPOP_TRY(launch_summary_large(rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st, scratch, &lists));
       const uint32_t *gate = nullptr;
       const void *flags = nullptr;
       KPOP_TRY(launch_summary_refine(KIND, rows, a, r1, bq, q, n_dims, metric, p, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist,
-                                     out_z, mscratch, chunk, st, &gate, &flags));
+                                     out_z, mscratch, chunk, st, lists, &gate, &flags));
       KPOP_TRY(rowwise_block<KIND>(a, r1, bq, q, n_dims, metric, p, rows, st, nullptr, nullptr, gate));
       KPOP_TRY(launch_summary_flagged_rows(rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, flags, st));
     }

@@ -22,6 +22,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "summary_types.h"
 #include "space_ops.h"
 
 namespace kpop {
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
                                                               const unsigned long long *__restrict__ smax_bits, uint32_t row0, uint32_t req_len,
                                                               uint32_t max_neighbours, double gamma, double *__restrict__ out_stats, uint32_t *__restrict__ out_n,
                                                               uint32_t *__restrict__ out_idx, double *__restrict__ out_dist, double *__restrict__ out_z,
-                                                              uint32_t *__restrict__ rc, uint32_t *__restrict__ n_failed) {
+                                                              uint32_t *__restrict__ rc, uint32_t *__restrict__ n_failed, SummaryLists L) {
   __shared__ uint32_t s_nb_i[kRefNb], s_med_i[kRefMed], s_mad_i[kRefMad];
   __shared__ double s_nb_d[kRefNb], s_med_d[kRefMed], s_mad_d[kRefMad];
   __shared__ double s_b[128], s_m[128];
@@ -256,36 +257,82 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
   const bool low_edge = e1hi > 0.0;                                        // (no lower edge: the MAD is at least the median)
   const double u_e1hi = low_edge ? sq(e1hi) + 1.25 * G : -1.0, u_e1lo = e1lo > 0.0 ? sq(e1lo) - 1.25 * G : -1.0;
   uint32_t n_below = 0, n_inside = 0;
-  constexpr int U = 8;  // loads in flight a thread
-  for (uint32_t base = 0; base < r1; base += 1024 * U) {
-    double xs[U];
-#pragma unroll
-    for (int k = 0; k < U; ++k) {
-      const uint32_t i = base + k * 1024 + threadIdx.x;
-      xs[k] = row[min(i, r1 - 1u)];
-    }
-#pragma unroll
-    for (int k = 0; k < U; ++k) {
-    const uint32_t i = base + k * 1024 + threadIdx.x;
-    if (i >= r1) continue;
-    const double x = xs[k], u = sq(x);
-    if (u <= u_nb) {
+  auto classify = [&](uint32_t i, double x, bool for_nb, bool for_med, bool for_mad) {
+    const double u = sq(x);
+    if (for_nb && u <= u_nb) {
       const uint32_t at = atomicAdd(&s_cnt[0], 1u);
       if (at < kRefNb) s_nb_i[at] = i;
     }
-    if (u < u_med_lo) ++n_below;
-    else if (u <= u_med_hi) {
-      const uint32_t at = atomicAdd(&s_cnt[1], 1u);
-      if (at < kRefMed) s_med_i[at] = i;
+    if (for_med) {
+      if (u < u_med_lo) ++n_below;
+      else if (u <= u_med_hi) {
+        const uint32_t at = atomicAdd(&s_cnt[1], 1u);
+        if (at < kRefMed) s_med_i[at] = i;
+      }
     }
-    const bool in_sure = u < u_e2lo && (!low_edge || u > u_e1hi);
-    const bool out_sure = u > u_e2hi || (e1lo > 0.0 && u < u_e1lo);
-    if (in_sure) ++n_inside;
-    else if (!out_sure) {
-      const uint32_t at = atomicAdd(&s_cnt[3], 1u);
-      if (at < kRefMad) s_mad_i[at] = i;
+    if (for_mad) {
+      const bool in_sure = u < u_e2lo && (!low_edge || u > u_e1hi);
+      const bool out_sure = u > u_e2hi || (e1lo > 0.0 && u < u_e1lo);
+      if (in_sure) ++n_inside;
+      else if (!out_sure) {
+        const uint32_t at = atomicAdd(&s_cnt[3], 1u);
+        if (at < kRefMad) s_mad_i[at] = i;
+      }
     }
+  };
+  // The summary's one pass left lists behind (summary_large.hip: the row's values inside the median's bracket or in the MAD's
+  // bands with their columns, those at or below the neighbours' threshold, and counts of everything else).  Where this row's
+  // narrow bands lie inside those wide ones, everything here is read off the lists -- a few per cent of the row -- and the row
+  // itself is not read again; otherwise it is scanned.
+  bool from_lists = false;
+  uint32_t base_below = 0, base_inside = 0;
+  if (L.info != nullptr) {
+    const RowCounts C = L.cnt[jl];
+    const FusedThr T = L.thr[jl];
+    from_lists = ok && !C.fail && C.n_cand <= L.cap && C.n_nb <= kNbCap;
+    // neighbours: every value with u~ <= u_nb is at or below the threshold (values are not negative: sq is monotone)
+    from_lists = from_lists && u_nb <= sq(T.cut);
+    // the median: its band strictly inside the bracket; below the band = below or at the bracket's lower end + listed ones
+    from_lists = from_lists && T.lo >= 0.0 && sq(T.lo) < u_med_lo && u_med_hi < sq(T.hi);
+    base_below = C.lt_lo + C.eq_lo;
+    // the MAD: the inner region certainly inside, beyond the bands certainly outside
+    const bool has_inner = T.Uin > T.Lin;
+    if (has_inner) from_lists = from_lists && sq(T.Uin) <= u_e2lo && (!low_edge || (T.Lin >= 0.0 && sq(T.Lin) >= u_e1hi));
+    from_lists = from_lists && sq(T.Uhi) >= u_e2hi && (T.Llo <= 0.0 || (e1lo > 0.0 && sq(T.Llo) <= u_e1lo));
+    base_inside = C.m_eqlo;
+    if (from_lists) {
+      const double *cv = L.cand + (uint64_t)jl * L.cap;
+      const uint32_t *ci = L.cand_i + (uint64_t)jl * L.cap;
+      for (uint32_t e = threadIdx.x; e < C.n_cand; e += 1024) {
+        const double x = cv[e];
+        const bool medc = x > T.lo && x < T.hi, in = x > T.Lin && x < T.Uin;
+        classify(ci[e], x, false, medc, !in);  // (listed and in the inner region: counted there already)
+      }
+      const double *nv = L.nb_d + (uint64_t)jl * kNbCap;
+      const uint32_t *ni = L.nb_idx + (uint64_t)jl * kNbCap;
+      for (uint32_t e = threadIdx.x; e < C.n_nb; e += 1024) classify(ni[e], nv[e], true, false, false);
     }
+  }
+  if (!from_lists) {
+    base_below = base_inside = 0;
+    constexpr int U = 8;  // loads in flight a thread
+    for (uint32_t base = 0; base < r1; base += 1024 * U) {
+      double xs[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const uint32_t i = base + k * 1024 + threadIdx.x;
+        xs[k] = row[min(i, r1 - 1u)];
+      }
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const uint32_t i = base + k * 1024 + threadIdx.x;
+        if (i < r1) classify(i, xs[k], true, true, true);
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(&s_cnt[2], base_below);
+    atomicAdd(&s_cnt[4], base_inside);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -511,18 +558,21 @@ int launch_distance_rows_mfma(int kind, const double *a, uint32_t r1, const doub
 // the refinement; *gate = the device word that counts the rows left to the fall-back, *row_counts = their flags (RowCounts)
 int launch_summary_refine(int kind, const double *rows, const double *a, uint32_t r1, const double *b, uint32_t q, uint32_t n_dims, const double *metric,
                           double p, uint32_t row0, uint32_t keep_at_most, uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
-                          double *out_dist, double *out_z, void *scratch, uint32_t q_room, hipStream_t st, const uint32_t **gate, const void **row_counts) {
+                          double *out_dist, double *out_z, void *scratch, uint32_t q_room, hipStream_t st, const SummaryLists &lists, const uint32_t **gate,
+                          const void **row_counts) {
   const MfmaScratch M = carve_mfma(scratch, q_room, r1, n_dims);
   const uint32_t req_len = keep_at_most ? keep_at_most : r1;
   // |u~ - u| <= gamma (|a|^2 + |b|^2): n_dims products and additions of the contraction and of the two norms at 2^-53 each, the
   // chain's own roundings, and a factor of ten on top
   const double gamma = 4e-15 * (double)std::max(n_dims, 16u);
+  SummaryLists L = lists;
+  if (!ctx().tune_summary_mfma_lists || !L.cand_i) L = SummaryLists{};
   if (kind == KPOP_EUCLIDEAN)
     summary_refine_kernel<KPOP_EUCLIDEAN><<<dim3(q), dim3(1024), 0, st>>>(rows, a, r1, b, n_dims, metric, p, M.sb, M.smax, row0, req_len, max_neighbours, gamma, out_stats,
-                                                                          out_n, out_idx, out_dist, out_z, M.rc, M.n_failed);
+                                                                          out_n, out_idx, out_dist, out_z, M.rc, M.n_failed, L);
   else
     summary_refine_kernel<KPOP_COSINE><<<dim3(q), dim3(1024), 0, st>>>(rows, a, r1, b, n_dims, metric, p, M.sb, M.smax, row0, req_len, max_neighbours, gamma, out_stats,
-                                                                       out_n, out_idx, out_dist, out_z, M.rc, M.n_failed);
+                                                                       out_n, out_idx, out_dist, out_z, M.rc, M.n_failed, L);
   KPOP_LAUNCH_CHECK();
   *gate = M.n_failed;
   *row_counts = M.rc;

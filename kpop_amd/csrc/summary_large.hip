@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "summary_types.h"
 #include "space_ops.h"
 
 namespace kpop {
@@ -262,7 +263,6 @@ __device__ void block_select_ranks(const Row row, uint32_t n, double centre, Sel
   }
 }
 
-struct RowCounts;
 __device__ bool row_failed(const RowCounts *cnt, uint32_t row);
 
 __global__ __launch_bounds__(kLT) void summary_large_kernel(const double *__restrict__ rows, uint32_t r1, uint32_t row0,
@@ -432,21 +432,11 @@ __global__ __launch_bounds__(kLT) void summary_large_kernel(const double *__rest
 // at the median or the cut) or whose keep_at_most exceeds what the lists hold is flagged and redone by the kernel above.
 // HBM traffic: the rows once written, twice read.
 // ===========================================================================
-constexpr uint32_t kSample = 65536, kSlice = 32768, kNbCap = 16384, kNbSort = 4096;
+constexpr uint32_t kSample = 65536, kSlice = 32768, kNbSort = 4096;  // (kNbCap: summary_types.h)
 // the brackets hold ~2.3 % of a row (six sigmas of a 65,536-element sample's quantile, both sides): room for 6 %, at least 65,536
 static inline uint32_t cand_cap_for(uint32_t r1) { return std::max<uint32_t>(65536u, ((r1 / 16 + 4095u) & ~4095u)); }
 
-struct RowInfo {   // written by the sample / finish kernels, read by the passes
-  double m_hat, median, mean, sd;
-  uint64_t klo, khi, kcut;   // brackets of the median (keys of d), neighbour threshold
-  uint64_t mlo, mhi;         // bracket of the MAD (keys of |d - median|)
-  uint32_t sample_n, sample_stride;
-};
-struct RowCounts {
-  uint32_t lt_lo, eq_lo, n_cand, eq_hi, n_nb;       // pass 1
-  uint32_t m_lt, m_eqlo, m_cand, m_eqhi;            // pass 2
-  uint32_t fail, pad0, pad1;
-};
+// (RowInfo, RowCounts: summary_types.h)
 
 __device__ __forceinline__ uint32_t sample_count(uint32_t n, uint32_t *stride) {
   if (n <= kSample) {
@@ -862,11 +852,7 @@ __device__ bool row_failed(const RowCounts *cnt, uint32_t row) { return cnt[row]
 // ===========================================================================
 constexpr uint32_t kStripe = 2048, kFW = 32, kFQ = 256, kFDC = 16, kMaxStripes = 8192;
 
-struct FusedThr {  // one query row's thresholds, as distances (64 bytes)
-  double lo, hi;            // the median's bracket (-inf / +inf: none)
-  double Llo, Lin, Uin, Uhi;  // lower band [Llo, Lin], inner region (Lin, Uin), upper band [Uin, Uhi]
-  double cut, mhat;
-};
+// (FusedThr: summary_types.h)
 struct StripeRec {
   uint32_t lt_eqlo, eqhi_nmed, inner, c_cnt;  // (16 bits each where paired: a stripe has 2,048 elements)
 };
@@ -1123,12 +1109,14 @@ __global__ __launch_bounds__(256, 2) void summary_fused_pass_kernel(
 // bands as doubles, here and in the finish kernel alike.)
 __global__ __launch_bounds__(256) void summary1_pass_kernel(const double *__restrict__ rows, uint32_t r1, const RowInfo *__restrict__ info,
                                                             const FusedThr *__restrict__ thr, RowCounts *__restrict__ cnt,
-                                                            double *__restrict__ cand, uint32_t *__restrict__ nb_idx, double *__restrict__ nb_d,
-                                                            double *__restrict__ part, uint32_t n_slices, uint32_t kCandCap) {
+                                                            double *__restrict__ cand, uint32_t *__restrict__ cand_i, uint32_t *__restrict__ nb_idx,
+                                                            double *__restrict__ nb_d, double *__restrict__ part, uint32_t n_slices, uint32_t kCandCap) {
   __shared__ uint32_t s_c[8];
   __shared__ double s_p[2][4];
   constexpr uint32_t kStage = 4096;
-  __shared__ double s_stage[kStage];
+  // (staged: the candidates' columns, 16 KB; their values are read again on the way out -- out of L2, the block has just had
+  // them -- rather than staged beside them: 48 KB of LDS a block left three blocks a CU and cost this kernel a third)
+  __shared__ uint32_t s_stage_i[kStage];
   __shared__ uint32_t s_n, s_base;
   const uint32_t j = blockIdx.y, sl = blockIdx.x;
   const double *row = rows + (uint64_t)j * r1;
@@ -1138,6 +1126,7 @@ __global__ __launch_bounds__(256) void summary1_pass_kernel(const double *__rest
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t i0 = sl * kSlice, i1 = min(r1, i0 + kSlice);
   double *my_cand = cand + (uint64_t)j * kCandCap;
+  uint32_t *my_cand_i = cand_i ? cand_i + (uint64_t)j * kCandCap : nullptr;
   uint32_t c_lt = 0, c_eqlo = 0, c_eqhi = 0, c_med = 0, c_in = 0;
   double sum = 0.0, sq = 0.0;
   constexpr int U = 8;  // loads in flight per thread
@@ -1148,8 +1137,23 @@ __global__ __launch_bounds__(256) void summary1_pass_kernel(const double *__rest
     if (threadIdx.x == 0) s_base = atomicAdd(&C->n_cand, cnt_);
     __syncthreads();
     const uint32_t b0 = s_base;
-    for (uint32_t q = threadIdx.x; q < cnt_; q += 256)
-      if (b0 + q < kCandCap) my_cand[b0 + q] = s_stage[q];
+    for (uint32_t q0 = threadIdx.x; q0 < cnt_; q0 += 256 * 8) {  // (eight of the gather's loads in flight a thread)
+      uint32_t ii[8];
+      double vv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        ii[u] = q0 + 256u * u < cnt_ ? s_stage_i[q0 + 256u * u] : i0;  // (past the end: a column of the slice, not stored)
+        vv[u] = row[ii[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t q = q0 + 256u * u;
+        if (q < cnt_ && b0 + q < kCandCap) {
+          my_cand[b0 + q] = vv[u];
+          if (my_cand_i) my_cand_i[b0 + q] = ii[u];  // (kept for the matrix-core path's refinement, distance_mfma.hip)
+        }
+      }
+    }
     __syncthreads();
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
@@ -1183,7 +1187,7 @@ __global__ __launch_bounds__(256) void summary1_pass_kernel(const double *__rest
       const bool is_cand = ok && (medc || (!in && d >= T.Llo && d <= T.Uhi));
       if (__ballot(is_cand)) {
         const uint32_t at = wave_append(is_cand, &s_n, lane);
-        if (is_cand) s_stage[at] = d;
+        if (is_cand) s_stage_i[at] = i;
       }
       const bool is_nb = ok && k <= I.kcut;
       if (__ballot(is_nb)) {
@@ -1544,7 +1548,7 @@ static inline uint32_t rows_cand_cap(uint32_t r1) { return std::max(cand_cap_for
 
 uint64_t summary_large_scratch_bytes(uint32_t n_rows, uint32_t r1) {
   const uint64_t n_slices = (r1 + kSlice - 1) / kSlice;
-  return (uint64_t)n_rows * (sizeof(RowInfo) + sizeof(RowCounts) + sizeof(FusedThr) + (uint64_t)rows_cand_cap(r1) * 8 + (uint64_t)kNbCap * 12 + n_slices * 16) +
+  return (uint64_t)n_rows * (sizeof(RowInfo) + sizeof(RowCounts) + sizeof(FusedThr) + (uint64_t)rows_cand_cap(r1) * 12 + (uint64_t)kNbCap * 12 + n_slices * 16) +
          8192;
 }
 
@@ -1552,7 +1556,8 @@ uint64_t summary_large_scratch_bytes(uint32_t n_rows, uint32_t r1) {
 // rows (brackets and bands from a sample, certificate for the MAD); 3: two passes (the first version of round 3).
 int launch_summary_large(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most,
                          uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
-                         double *out_dist, double *out_z, hipStream_t st, void *scratch) {
+                         double *out_dist, double *out_z, hipStream_t st, void *scratch, SummaryLists *lists) {
+  if (lists) *lists = SummaryLists{};
   const uint32_t req_len = keep_at_most ? keep_at_most : r1;
   const bool by_brackets = scratch && ctx().tune_summary2 && req_len <= kLargeMaxNb && r1 >= 2 * kSlice;
   if (!by_brackets) {
@@ -1579,11 +1584,14 @@ int launch_summary_large(const double *rows, uint32_t n_rows, uint32_t r1, uint3
   uint32_t *nb_idx = reinterpret_cast<uint32_t *>(p);
   p += (uint64_t)n_rows * kNbCap * 4;
   double *part = reinterpret_cast<double *>(p);
+  p += ((uint64_t)n_rows * n_slices * 16 + 255) & ~255ull;
+  uint32_t *cand_i = lists ? reinterpret_cast<uint32_t *>(p) : nullptr;
   if (ctx().tune_summary2 != 3) {
+    if (lists) *lists = SummaryLists{info, thr, cnt, cand, cand_i, cap, nb_idx, nb_d};
     KPOP_HIP(hipMemsetAsync(n_failed, 0, 256, st));
     fused_sample_kernel<true><<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, 0, r1, req_len, info, cnt, thr);
     KPOP_LAUNCH_CHECK();
-    summary1_pass_kernel<<<dim3(n_slices, n_rows), dim3(256), 0, st>>>(rows, r1, info, thr, cnt, cand, nb_idx, nb_d, part, n_slices, cap);
+    summary1_pass_kernel<<<dim3(n_slices, n_rows), dim3(256), 0, st>>>(rows, r1, info, thr, cnt, cand, cand_i, nb_idx, nb_d, part, n_slices, cap);
     KPOP_LAUNCH_CHECK();
     fused_finish_kernel<false><<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, req_len, max_neighbours, info, thr, cnt, nullptr, part, n_slices, nullptr, cand,
                                                                    cap, nb_idx, nb_d, n_failed, out_stats, out_n, out_idx, out_dist, out_z);

@@ -642,10 +642,13 @@ def test_distance_summary_on_the_matrix_cores(kpop, oracle, case, kind, d):
         for keep in (1, 300):
             st_o, offs, idx_o, dist_o, z_o = oracle.distance_summary(m1, m2, metric, kind, 2.0, normalize, keep)
             res = {}
-            for mode in (1, 0):
-                api.tune("summary_mfma", mode)
+            for mode in (1, 2, 0):  # 2: the refinement scans the distance rows instead of reading the summary's candidate lists
+                api.tune("summary_mfma", min(mode, 1))
+                api.tune("summary_mfma_lists", 0 if mode == 2 else 1)
                 res[mode] = kpop.distance_summary(m1, m2, metric, kind, 2.0, normalize, keep, max_neighbours=512)
             api.tune("summary_mfma", 1)
+            for a_, b_ in zip(res[1], res[2]):
+                assert np.array_equal(a_, b_, equal_nan=True)
             st, n, idx, dist, z = res[1]
             np.testing.assert_allclose(st[:, :2], st_o[:, :2], rtol=1e-10, atol=1e-13)
             assert np.array_equal(st[:, 2:], st_o[:, 2:]), (case, keep, st, st_o)  # median and MAD: order statistics, exact
