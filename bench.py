@@ -609,7 +609,7 @@ def config5_leg(R):
     k, d, n, L = 15, 16, 10000, 150
     free, _ = t.cuda.mem_get_info(R.dev)
     if free < 150e9:
-        return {"skipped": "needs 150 GB of free HBM for the 69 GB twister and its synthesis, %.1f GB free" % (free / 1e9)}
+        return {"skipped": "needs 150 GB of free HBM for the 69 GB twister and its synthesis (and 137 GB more for its rows at their hashes, built when they fit), %.1f GB free" % (free / 1e9)}
     t0 = time.perf_counter()
     tw = kp.Twister.synth(TWISTER_SEED, k, d)
     t.cuda.synchronize()
@@ -624,19 +624,41 @@ def config5_leg(R):
         alg = n * (L + w * d * 8 + d * 8)
         finite = bool(t.isfinite(out).all().item()) and bool((out.abs() < 1.0).all().item())
         return {
-            "workload": "%d reads x %d bp, k=%d DNA-ds, D=%d; twister %d rows, %.1f GB resident (synthesised on the device in %.1f s, outside the timing)"
-                        % (n, L, k, d, tw.info()["n_cols"], tw.info()["device_bytes"] / 1e9, synth_s),
+            "workload": "%d reads x %d bp, k=%d DNA-ds, D=%d; twister %d rows, %.1f GB resident%s (synthesised on the device in %.1f s, outside the timing)"
+                        % (n, L, k, d, tw.info()["n_cols"], tw.info()["device_bytes"] / 1e9,
+                           (" -- %.1f GB of it the rows once more at their hashes: no name -> row look-up" % (tw.info()["direct_bytes"] / 1e9)) if tw.info()["direct_bytes"] else "",
+                           synth_s),
+            "rows_at_their_hashes": bool(tw.info()["direct_bytes"]),
             "value": n / (ms * 1e-3), "unit": "sequences/sec", "ms_per_step": ms,
             "rows_finite_and_inside_the_coefficient_range": finite,
             "roofline": {"kernel": "count_twist_wave_kernel", "bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms,
-                         "note": "128-byte rows (16 dims) gathered at random from 69 GB, every one an HBM miss behind a miss on the 268 MB name -> row index "
-                                 "(a 64-byte sector of it per window, not in the algorithmic bytes: with it the launch moves ~1.5 x them). The launch scales "
-                                 "with the reads -- 2,000 / 10,000 / 30,000 / 100,000 reads 0.017 / 0.067 / 0.163 / 0.499 ms (tools/probes/ab_small_batch_unroll.py), "
-                                 "3.5 TB/s of rows at 100,000 -- so it is the memory system's rate for 128-byte random reads, with 10,000 wavefronts = 1.2 rounds "
-                                 "of the chip on top; 16 row loads in flight instead of 8 give 8 % at 10,000 reads and nothing at 100,000"}}
+                         "note": "128-byte rows (16 dims) gathered at random, every one an HBM miss. A complete twister of this shape keeps its rows a second "
+                                 "time at the address the hash names (137 GB beside the 69 GB in rank order; twister.h `direct`), so a window costs ONE miss and one "
+                                 "cache line: through the name -> row index (143 MB of 64-byte blocks) every window also moved a 128-byte line of index -- 1.96 x the "
+                                 "algorithmic bytes, measured -- and waited for two dependent misses. 2,000 / 10,000 / 30,000 / 100,000 reads: 0.015 / 0.042 / 0.107 / "
+                                 "0.321 ms with the rows at their hashes (5.4 TB/s of rows at 100,000), 0.017 / 0.059 / 0.157 / 0.500 ms through the index "
+                                 "(tools/probes/r05_direct_rows.py, profiles/r05_direct_rows.txt); 10,000 wavefronts are 1.2 rounds of the chip"}}
     finally:
         tw.free()
+
+
+def leg_traffic(R, roofline, **kw):
+    """a leg's HBM bytes per launch, measured NOW (measure_traffic: two --pmc child passes on the leg's shape), into its roofline"""
+    if R.args.no_children:
+        roofline["traffic_source"] = "not measured: --no-children"
+        return
+    R.torch.cuda.empty_cache()  # (the child needs the HBM this process has cached)
+    live = measure_traffic(R, **kw)
+    if not live:
+        roofline["traffic_source"] = "not measured: a rocprofv3 --pmc child pass failed or timed out"
+        return
+    roofline["traffic"] = live["hbm_bytes_per_launch"]
+    roofline["traffic_source"] = live["source"]
+    roofline["traffic_counters"] = {"FETCH_SIZE_KiB": live["FETCH_SIZE_KiB"], "WRITE_SIZE_KiB": live["WRITE_SIZE_KiB"]}
+    alg = roofline.get("algorithmic_bytes_per_launch")
+    if alg:
+        roofline["traffic_over_algorithmic"] = live["hbm_bytes_per_launch"] / alg
 
 
 def extra_configs(R):
@@ -650,6 +672,22 @@ def extra_configs(R):
         R.torch.cuda.synchronize()
         R.torch.cuda.empty_cache()
         legs[name]["leg_seconds"] = time.perf_counter() - t0
+    # the legs' HBM traffic, measured now (counter passes of child processes, after every timed leg: see the headline's)
+    t0 = time.perf_counter()
+    want = (("config2_on_this_gpu", None, dict(n_reads=10000, k=10, dims=64, read_len=150)),
+            ("config3_on_this_gpu", "unrelated_genomes", dict(n_reads=50000, k=R.args.k, dims=R.args.dims, read_len=30000, kernel="count_twist_stream_kernel", launches=2, timeout=400)),
+            ("config3_on_this_gpu", "one_organism_0.3pct", dict(n_reads=50000, k=R.args.k, dims=R.args.dims, read_len=30000, kernel="count_twist_tile_pipe_kernel", launches=2,
+                                                                mutants=0.003, timeout=400)),
+            ("config5_on_this_gpu", None, dict(n_reads=10000, k=15, dims=16, read_len=150)))
+    for name, sub, kw in want:
+        leg = legs.get(name, {})
+        leg = leg.get(sub, {}) if sub else leg
+        if isinstance(leg.get("roofline"), dict):
+            try:
+                leg_traffic(R, leg["roofline"], **kw)
+            except Exception as e:
+                leg["roofline"]["traffic_source"] = "not measured: %r" % (e,)
+    legs["traffic_passes_seconds"] = time.perf_counter() - t0
     return legs
 
 
@@ -798,7 +836,7 @@ def pcie_inclusive(R, n, reps=5, stream_batches=10):
     return out
 
 
-def measure_traffic(R, n_reads):
+def measure_traffic(R, n_reads, k=None, dims=None, read_len=None, kernel="count_twist_wave_kernel", launches=3, mutants=0.0, timeout=240):
     """HBM bytes per launch of the fused kernel, measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters
     never share a run with a trace summary) of a child process that launches the same kernel on the same shape
     (tools/pmc_workload.py), corrected as MI355X_MICROARCH.md's HBM section prescribes (unit KiB; FETCH_SIZE reads one
@@ -818,9 +856,11 @@ def measure_traffic(R, n_reads):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = tempfile.mkdtemp(prefix="kpop_pmc_", dir="/tmp")
             cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
-                   sys.executable, os.path.join(ROOT, "tools", "pmc_workload.py"), "--reads", str(n_reads), "--read-len", str(a.read_len),
-                   "-k", str(a.k), "--dims", str(a.dims), "--launches", "3", "--calib-rows", str(calib_rows)]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+                   sys.executable, os.path.join(ROOT, "tools", "pmc_workload.py"), "--reads", str(n_reads), "--read-len", str(read_len or a.read_len),
+                   "-k", str(k or a.k), "--dims", str(dims or a.dims), "--launches", str(launches), "--calib-rows", str(calib_rows)]
+            if mutants > 0.0:
+                cmd += ["--mutants", repr(mutants)]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
             if r.returncode != 0:
                 return None
             vals, cal = [], []
@@ -828,7 +868,7 @@ def measure_traffic(R, n_reads):
                 for row in csv.DictReader(open(f)):
                     if row["Counter_Name"] != counter:
                         continue
-                    if "count_twist_wave_kernel" in row["Kernel_Name"]:
+                    if kernel in row["Kernel_Name"]:
                         vals.append(float(row["Counter_Value"]))
                     elif "row_norms_kernel" in row["Kernel_Name"]:
                         cal.append(float(row["Counter_Value"]))

@@ -86,13 +86,22 @@ int kpop_synchronize(void *stream);
    "unroll" 8|16 row loads in flight per wave; "nt" row loads 0 plain | 1 non-temporal | 2 chosen by the size of the
    twister (default); "seg" windows per segment of the genome kernel, 0 = sized to an XCD's L2 (default); "hist" 1 (default) | 0: the
    merged spectrum of kpop_count_reads(per_read = 0) by atomic histogram where the hashes fit 26 bits, or always by sort;
-   "histlds" 1 (default) | 0 | 2 | 3: that histogram staged through LDS as the batch suggests (private tables up to k = 7;
+   "histlds" 1 (default) | 0 | 2 | 3 | 4: that histogram staged through LDS as the batch suggests (private tables up to k = 7;
    (hash, count) tables over the same stretch of 64 assemblies of one organism; for what does not repeat -- a read set,
    unrelated genomes -- the hashes partitioned by their top bits and every bucket counted in LDS, the table written without
-   a global atomic), direct global atomics as in round 2, chunks always combined, or always partitioned;
+   a global atomic, and -- round 5 -- the (hash, count) pairs of every bucket written straight into the spectrum at an offset taken
+   by a decoupled look-back: the 4^k-counter table is never written), direct global atomics as in round 2, chunks always
+   combined, always partitioned, or (4) partitioned with the dense table and its compaction as in round 4;
    "summary2" 1 (default) | 3 | 0 | 2: summaries against more than 4,096 rows by brackets from a sample and ONE pass over the
    distance rows, the same in two passes, round 2's one block per row, or (131,072 rows and more) with the distances
    computed and reduced in one kernel and no distance rows in memory -- same results, 1, 3 and 2 level;
+   "summary_mfma" 1 (default) | 0: summaries against 65,536 rows and more, euclidean / cosine, 4 to 128 dimensions: the distances
+   as f64 MFMAs (|a|^2 + |b|^2 - 2 a.b) that only LOCATE the neighbours, the median and the MAD's edges; everything reported is
+   recomputed with the reference's chain, rows the refinement cannot vouch for are redone from exact distance rows
+   (distance_mfma.hip).  Same medians, MADs and neighbour lists bit for bit; mean and standard deviation are sums of the
+   approximate values (1e-13 relative; values cancellation would show in are replaced by exact ones).  0: the chain for every pair.
+   "summary_mfma_lists" 1 (default) | 0: that refinement reads the candidate lists the summary's one pass left, or scans the rows;
+   "tilepipe" 1 (default) | 0: the tile route's kernel with producer and consumer wavefronts (tile_pipe.h), or round 4's;
    "dense" 2 (default) | 1 | 0: the matrix-core routes of the twist.  2: chosen by the batch -- sequences of more than 512
    windows (assemblies, k <= 15) go through count_twist_tile_kernel: the CONSENSUS rows of a stretch of 64 sequences x 512
    windows (the rows of four seed sequences, an LDS set) are multiplied on the f64 matrix cores, the rows private to one
@@ -165,6 +174,12 @@ int kpop_twister_set_count_k(kpop_twister *tw, int k);
 int kpop_twister_free(kpop_twister *tw);
 int kpop_twister_info(const kpop_twister *tw, uint64_t *n_cols, uint32_t *n_dims, int *k,
                       uint64_t *device_bytes);
+/* Bytes (part of device_bytes) of the twister's second copy of its rows AT THEIR HASHES, 0 when it keeps none.  A nearly
+   complete twister of k = 13..15 and up to 32 dimensions keeps one when it fits the free memory with room to spare
+   (k = 15, 16 dimensions: 137 GB beside 69 GB): the fused count -> twist of reads then needs no name -> row look-up, which
+   for such a twister is a cache line of index for every cache line of row (lib/Twister.ml:151 is a Hashtbl.find_opt per
+   k-mer).  kpop_tune("direct", 0 | 1 | 2) before loading: never | whenever it fits | by that rule (default).  Same results. */
+int kpop_twister_direct_bytes(const kpop_twister *tw, uint64_t *bytes);
 
 /* ------------------------------------------------------------------ twist
  * Replaces the worker closure of Twister.add_twisted_from_files,
@@ -338,7 +353,11 @@ int kpop_distance_rowwise(const double *m1, uint32_t r1, const double *m2, uint3
  * Lists of any length: against a first operand of more than 4,096 rows the summary kernels themselves return at most
  * 2,048 neighbours per row; a longer list (keep_at_most = all, :723-726; a tie group of thousands, :648-649) is completed
  * by the host entry points -- the row's distances sorted by (distance, column) with the device-wide radix sort.  The
- * device entry points (kpop_dev_*) report out_n and fill at most 2,048 entries of such a row. */
+ * device entry points (kpop_dev_*) report out_n and fill at most 2,048 entries of such a row.
+ * Cost of a long row: its distances recomputed, an 8-pass radix sort of r1 keys, two copies and a stream synchronisation --
+ * about 30 launches and ~0.3 ms a row (r1 = 100,000), one row after the other under the slot's lock.  keep_at_most = 0 against
+ * more than 4,096 rows makes EVERY query row long: meant for the reference's use (a few rows inspected in full), not for
+ * 100,000 queries (tens of seconds). */
 int kpop_distance_summary(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
                           const double *metric, int kind, double p, int normalize, uint32_t keep_at_most,
                           uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,

@@ -86,6 +86,7 @@ SIGNATURES = {
     "kpop_twister_set_count_k": (C.c_int, [vp, C.c_int]),
     "kpop_twister_free": (C.c_int, [vp]),
     "kpop_twister_info": (C.c_int, [vp, u64p, u32p, C.POINTER(C.c_int), u64p]),
+    "kpop_twister_direct_bytes": (C.c_int, [vp, u64p]),
     "kpop_twist": (C.c_int, [vp, u64p, f64p, u64p, C.c_uint32, C.c_int, f64p]),
     "kpop_count_twist": (C.c_int, [vp, u8p, u64p, C.c_uint32, C.c_int, C.c_int, f64p]),
     "kpop_spectra_twist": (C.c_int, [vp, u8p, u64p, C.c_uint32, C.c_int, C.c_int, C.c_int, f64p]),

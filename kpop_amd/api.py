@@ -160,7 +160,9 @@ class Twister:
         n_cols, n_dims, k, nbytes = C.c_uint64(), C.c_uint32(), C.c_int(), C.c_uint64()
         check(_lib.load().kpop_twister_info(self._h, C.byref(n_cols), C.byref(n_dims), C.byref(k),
                                             C.byref(nbytes)))
-        return {"n_cols": n_cols.value, "n_dims": n_dims.value, "k": k.value, "device_bytes": nbytes.value}
+        direct = C.c_uint64()
+        check(_lib.load().kpop_twister_direct_bytes(self._h, C.byref(direct)))
+        return {"n_cols": n_cols.value, "n_dims": n_dims.value, "k": k.value, "device_bytes": nbytes.value, "direct_bytes": direct.value}
 
     def twist(self, hash_, value, offsets, normalize=True):
         """Spectra (CSR of hash,value lines) -> twisted rows; lib/Twister.ml:146-188."""

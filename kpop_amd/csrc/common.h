@@ -106,6 +106,7 @@ struct Context {
   int tune_tilepipe = 1; // assemblies of one organism, up to 64 dimensions: count_twist_tile_pipe_kernel (producer and consumer wavefronts, tile_pipe.h); 0: round 4's count_twist_tile_kernel
   int tune_blocksort = 1;  // -L on sequences of up to 32,768 windows: one block per sequence, sorted in LDS (0: device-wide sort)
   int tune_hist = 1;     // merged (-l) spectrum by atomic histogram when the hashes fit 26 bits (0: always sort)
+  int tune_direct = 2; // a nearly complete twister of k 13..15 and <= 32 dimensions also keeps its rows at their hashes (twister.h): 2 by that rule, 1 whenever the table fits (any k <= 15), 0 never.  Read when a twister is loaded or synthesised
   int tune_summary_mfma_lists = 1; // the refinement reads the summary's candidate lists where its bands lie inside them; 0: it scans every distance row again
   int tune_summary_mfma = 1; // summaries against >= 65,536 rows, euclidean / cosine, up to 128 dimensions: the distances as f64 MFMAs + exact refinement (distance_mfma.hip); 0: the vector-pipe chain for every pair
   int tune_summary2 = 1; // summaries against > 4,096 rows: 1 brackets and bands from a sample + ONE pass over distance rows, 3 the same in two passes (median, then MAD), 0 round 2's one block per row (8-10 passes), 2 the distances computed and reduced in one kernel, no distance rows (131,072 rows and more); 1, 2 and 3 are level at 256 x 1M

@@ -242,6 +242,51 @@ __device__ __forceinline__ void wave_gather_rows_packed(const TwisterView &tv, c
   if (active && g == 0) out_row[d] = acc;
 }
 
+// The same gather from a twister that keeps its rows at their hashes (twister.h, `direct`): s_col holds the k-mers' HASHES, in
+// ascending order as the ranks would be, and a row that does not exist says so in its first double -- it then adds nothing, and
+// the windows that counted it are reported back (the caller takes them out of the normaliser and, if there were any, comes again).
+// With every k-mer present (the twisters this layout is built for) the loads, the products and the order of the additions are
+// those of wave_gather_rows_packed: the same bits.
+template <int U, bool NT>
+__device__ __forceinline__ uint32_t wave_gather_rows_direct(const TwisterView &tv, const uint32_t *s_hash, const double *s_x, const uint32_t *s_start,
+                                                            uint32_t nu, int lane, double *__restrict__ out_row) {
+  const uint32_t P = (tv.n_dims <= 8) ? 8u : (tv.n_dims <= 16 ? 16u : 32u);
+  const uint32_t G = 64u / P, g = (uint32_t)lane / P, d = (uint32_t)lane % P;
+  const bool active = d < tv.n_dims;
+  const double *base = tv.direct + d;
+  double acc = 0.0;
+  uint32_t gone = 0;  // windows of k-mers without a row (kept by the first lane of a group)
+  for (uint32_t u0 = 0; u0 < nu; u0 += G * U) {
+    double v[U], x[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const uint32_t u = u0 + (uint32_t)j * G + g;
+      const uint32_t uu = min(u, nu);  // [nu] is zero padding
+      const uint32_t h = s_hash[uu];
+      x[j] = s_x[uu];
+      const double *p = base + (uint64_t)h * tv.d_pad;
+      v[j] = (active && u < nu) ? (NT ? __builtin_nontemporal_load(p) : *p) : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const uint64_t none = __ballot(d == 0 && (uint64_t)__double_as_longlong(v[j]) == kDirectAbsent);
+      if (none) {  // (uniform; never taken for a complete twister)
+        if ((none >> (g * P)) & 1ull) {
+          v[j] = 0.0;
+          const uint32_t u = u0 + (uint32_t)j * G + g;
+          if (d == 0) gone += s_start[u + 1] - s_start[u];
+        }
+      }
+      acc = __dadd_rn(acc, __dmul_rn(v[j], x[j]));
+    }
+  }
+  for (uint32_t off = P; off < 64; off <<= 1) acc = __dadd_rn(acc, __shfl_xor(acc, (int)off, 64));
+  if (active && g == 0) out_row[d] = acc;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) gone += (uint32_t)__shfl_xor((int)gone, o, 64);
+  return gone;
+}
+
 // x_u = count_u / acc when normalising and acc <> 0 (lib/Twister.ml:177-178)
 template <int R>
 __device__ __forceinline__ void wave_fill_x(WaveLds<R, uint32_t> &L, uint32_t nu, double acc, int normalize, int lane) {
@@ -287,15 +332,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void count_twist_wave_kernel(
   wave_hash_windows<R, H>(L.codes, tv.hk, content, lane, hkey);
   // name -> column (lib/Twister.ml:151); k-mers the twister does not know are
   // dropped here, hence also from the normaliser (:158,:167-169)
+  const bool direct = tv.direct != nullptr && tv.n_dims <= 32;  // rows at their hashes: no look-up (twister.h)
   uint32_t key[R];
 #pragma unroll
-  for (int i = 0; i < R; ++i) key[i] = (hkey[i] != (H)~(H)0) ? lookup_col(tv, (uint64_t)hkey[i]) : kNoCol;
+  for (int i = 0; i < R; ++i) key[i] = (hkey[i] != (H)~(H)0) ? (direct ? (uint32_t)hkey[i] : lookup_col(tv, (uint64_t)hkey[i])) : kNoCol;
   wave_bitonic_sort<R, uint32_t>(key, lane);
   uint32_t n_valid;
   const uint32_t nu = wave_unique<R, uint32_t>(key, kNoCol, lane, L.key, L.start, n_valid);
   // counts are integers, so acc (:158) is exact whatever the order of the adds
   wave_fill_x<R>(L, nu, (double)n_valid, normalize, lane);
-  if (tv.n_dims <= 32)
+  if (direct) {
+    const uint32_t gone = wave_gather_rows_direct<U, NT>(tv, L.key, L.x, L.start, nu, lane, out + (uint64_t)r * tv.n_dims);
+    if (gone && normalize) {  // k-mers the twister does not know are not part of the normaliser (:158,:167-169): once more without them
+      __builtin_amdgcn_wave_barrier();
+      wave_fill_x<R>(L, nu, (double)(n_valid - gone), normalize, lane);
+      (void)wave_gather_rows_direct<U, NT>(tv, L.key, L.x, L.start, nu, lane, out + (uint64_t)r * tv.n_dims);
+    }
+  } else if (tv.n_dims <= 32)
     wave_gather_rows_packed<U, NT>(tv, L.key, L.x, nu, lane, out + (uint64_t)r * tv.n_dims);
   else
     wave_gather_rows<U, NT>(tv, L.key, L.x, nu, lane, out + (uint64_t)r * tv.n_dims);
@@ -1709,10 +1762,19 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   // once and multiplied on the matrix cores, the private rows listed for tile_residual_kernel); what it leaves -- stretches
   // that share little with their seeds, found from a sample -- is the streaming kernel's as before.  kpop_tune("dense", 0)
   // opts out (the streaming kernel alone: the reference's order of additions within a segment).
-  const bool tiles = cx.tune_dense != 0 && tv.rsel && n_reads >= kTileMinSeqs && tv.hk <= 15 && !cx.tune_seg;
+  bool tiles_wanted = cx.tune_dense != 0 && tv.rsel && n_reads >= kTileMinSeqs && tv.hk <= 15 && !cx.tune_seg;
   const bool nt = cx.tune_nt == 1;
   // (a sequence with segments has more than kWaveMaxWindows windows: at most this many of them)
   const uint32_t max_long = (uint32_t)std::min<uint64_t>(n_reads, n_bases / kWaveMaxWindows + 1);
+  // The tile route cuts sequences into 512-window segments, so its per-slot tables are sized for n_bases / 512 slots whatever the
+  // probe later finds (BASELINE config 3, D = 64: 1.5 GB of partial rows against 0.28 GB; beyond 64 dimensions 2 KB of residual
+  // list a slot on top).  Where that would pass 4 GiB of workspace -- per stream -- the batch keeps the streaming kernel.
+  if (tiles_wanted) {
+    const uint64_t slots = n_bases / std::min(seg_windows, kTileS) + max_long;
+    const uint64_t per_slot = (uint64_t)tw->n_dims * 8 + 4 + 4 + 8 + (tw->n_dims > 64 ? (uint64_t)kTileS * 4 : 0);
+    if (slots * per_slot > (4ull << 30)) tiles_wanted = false;
+  }
+  const bool tiles = tiles_wanted;
   const uint32_t seg_least = tiles ? std::min(seg_windows, kTileS) : seg_windows;  // (the shortest segment any sequence is cut into)
   const uint64_t max_slots = n_bases / seg_least + max_long;  // every such sequence adds at most W/seg + 1 segments
   const uint64_t nb = scan_blocks(n_reads);

@@ -269,6 +269,8 @@ extern "C" int kpop_twister_replicate(const kpop_twister *src, int slot, kpop_tw
   tw->d_rsel = nullptr;
   tw->d_rblk = nullptr;
   tw->d_sorted_hash = nullptr;
+  tw->d_direct = nullptr;  // (the copy keeps the rows in rank order only: device_bytes below)
+  if (src->d_direct) tw->device_bytes -= (1ull << (2 * src->k)) * src->d_pad * 8;
   const int prev = current_slot();
   int rc = use_slot(slot);
   if (rc == 0) do {

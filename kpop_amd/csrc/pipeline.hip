@@ -325,8 +325,8 @@ extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, con
       if (n_reads >= 65536 && n_reads <= 400000) {
         static const uint32_t kPermille[5] = {110, 140, 180, 220, 350};
         for (int c = 0; c < 4; ++c) sched[c] = std::max<uint32_t>(4096u, (uint32_t)(((uint64_t)n_reads * kPermille[c] / 1000 + 1023u) & ~1023ull));
-        n_sched = 4;  // (the fifth chunk is what is left)
-        chunk_reads = 131072u;
+        n_sched = 4;  // (the fifth chunk is what is left -- all of it: 35 % of 400,000 reads is more than 131,072, and a sixth chunk of a
+        chunk_reads = n_reads;  // few thousand reads would neither fill the chip nor shorten the drain)
         first_chunk = 0;
       }
     }

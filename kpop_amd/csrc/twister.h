@@ -19,6 +19,13 @@
 //          miss by construction); with the index inside the cache the look-up in front of it no longer is one (BASELINE config 5).
 //          row = prefix + popcount(the block's bits below the k-mer's).  (The tile route for assemblies reads rank WORDS: it is
 //          off at these k.)
+//   direct : (round 5) a NEARLY COMPLETE twister of large k and few dimensions also keeps its rows at the address the hash itself
+//          names -- [4^k][d_pad], a row that does not exist marked by kDirectAbsent in its first double.  The fused kernel for
+//          reads then has no name -> row look-up at all: BASELINE config 5 (k = 15, D = 16, every canonical 15-mer) moved a
+//          128-byte line of index for every 128-byte row (1.96 x the algorithmic bytes, measured; two dependent misses a
+//          window).  137 GB at k = 15 beside the 69 GB of rows in rank order (which every other kernel keeps using): what 288 GB
+//          of HBM are for.  Built when at least 0.45 of the hashes have a row (every canonical k-mer of a double-stranded
+//          twister is 0.5), d_pad <= 32, and the table fits what is free with room to spare; kpop_tune("direct", 0) opts out.
 //   sorted_hash : k > 16: the ascending hashes themselves, searched by bisection; the hit's index is the row.
 #pragma once
 #include <stdint.h>
@@ -36,6 +43,7 @@ struct kpop_twister {
   void *d_rsel = nullptr;
   void *d_rblk = nullptr;  // k >= kRankBlockMinK: 64-byte blocks instead of d_rsel (which is then freed once the rows are placed)
   uint64_t *d_sorted_hash = nullptr;
+  double *d_direct = nullptr;  // [4^k][d_pad]: the rows at their hashes (see above), or nullptr
   uint64_t device_bytes = 0;
   int slot = 0;        // device slot (common.h) whose memory holds the arrays
   bool alias = false;  // a second handle on another twister's arrays (kpop_twister_replicate onto the same GPU): frees nothing
@@ -48,6 +56,8 @@ constexpr int kRankBlockMinK = 15;         // from this k on the index is kept a
 constexpr uint32_t kRankBlockBits = 480;   // presence bits of a block: dwords 0..14; dword 15: the rank of its first bit
 static inline uint64_t rank_blocks(int k) { return ((1ull << (2 * k)) + kRankBlockBits - 1) / kRankBlockBits; }
 constexpr uint32_t kNoCol = 0xFFFFFFFFu;
+constexpr int kDirectMinK = 13;                                 // below: the index is a few MB and sits in L2
+constexpr uint64_t kDirectAbsent = 0x7FF4D1EC7AB5E27Eull;      // first double of a row of the direct table that does not exist (a NaN no twister file spells)
 
 struct RankWord {
   uint64_t bits;
@@ -65,11 +75,12 @@ struct TwisterView {
   uint32_t d_pad;
   int k;
   int hk;
+  const double *direct;  // rows at their hashes, or nullptr
 };
 
 static inline TwisterView view_of(const kpop_twister *tw) {
   return TwisterView{tw->d_rows, reinterpret_cast<const RankWord *>(tw->d_rsel), reinterpret_cast<const uint4 *>(tw->d_rblk), tw->d_sorted_hash, tw->n_rows,
-                     tw->n_dims, tw->d_pad,                                     tw->k, tw->hk ? tw->hk : tw->k};
+                     tw->n_dims, tw->d_pad,                                     tw->k, tw->hk ? tw->hk : tw->k, (tw->hk == 0 || tw->hk == tw->k) ? tw->d_direct : nullptr};
 }
 
 #if defined(__HIPCC__)

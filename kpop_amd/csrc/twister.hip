@@ -161,6 +161,39 @@ static int compact_rank_index(kpop_twister *tw, hipStream_t st) {
   return 0;
 }
 
+// direct[h] = the row of hash h, or the mark of a row that does not exist: a thread an element
+__global__ __launch_bounds__(256) void direct_rows_kernel(TwisterView tv, uint64_t n_hashes, double *__restrict__ direct) {
+  for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < n_hashes * tv.d_pad; idx += (uint64_t)gridDim.x * 256) {
+    const uint64_t h = idx / tv.d_pad;
+    const uint32_t e = (uint32_t)(idx % tv.d_pad);
+    const uint32_t col = lookup_col(tv, h);
+    if (col != kNoCol) direct[idx] = tv.rows[(uint64_t)col * tv.d_pad + e];
+    else if (e == 0) direct[idx] = __longlong_as_double((long long)kDirectAbsent);
+  }
+}
+
+// the rows once more, at their hashes (twister.h): where that pays and fits
+static int build_direct_rows(kpop_twister *tw, hipStream_t st) {
+  const int mode = ctx().tune_direct;  // 2: by the rule below; 1: whenever it fits; 0: never
+  if (!mode || tw->k < (mode == 1 ? 1 : kDirectMinK) || tw->k > 15 || tw->d_pad > 32 || !tw->n_rows || (!tw->d_rsel && !tw->d_rblk)) return 0;
+  const uint64_t n_hashes = 1ull << (2 * tw->k), bytes = n_hashes * tw->d_pad * 8;
+  if (mode == 2 && (double)tw->n_rows < 0.45 * (double)n_hashes) return 0;
+  size_t free_b = 0, total_b = 0;
+  KPOP_HIP(hipMemGetInfo(&free_b, &total_b));
+  if ((double)bytes > 0.8 * (double)free_b) return 0;  // (an optimisation: never the reason a twister does not load)
+  if (hipMalloc((void **)&tw->d_direct, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    tw->d_direct = nullptr;
+    return 0;
+  }
+  TwisterView tv = view_of(tw);
+  direct_rows_kernel<<<dim3((uint32_t)std::min<uint64_t>(div_up(n_hashes * tw->d_pad, 256), 1u << 20)), dim3(256), 0, st>>>(tv, n_hashes, tw->d_direct);
+  KPOP_LAUNCH_CHECK();
+  KPOP_HIP(hipStreamSynchronize(st));
+  tw->device_bytes += bytes;
+  return 0;
+}
+
 }  // namespace kpop
 
 using namespace kpop;
@@ -175,6 +208,7 @@ extern "C" int kpop_twister_free(kpop_twister *tw) {
   if (tw->d_rsel) (void)hipFree(tw->d_rsel);
   if (tw->d_rblk) (void)hipFree(tw->d_rblk);
   if (tw->d_sorted_hash) (void)hipFree(tw->d_sorted_hash);
+  if (tw->d_direct) (void)hipFree(tw->d_direct);
   delete tw;
   return KPOP_OK;
 }
@@ -186,6 +220,12 @@ extern "C" int kpop_twister_info(const kpop_twister *tw, uint64_t *n_cols, uint3
   if (n_dims) *n_dims = tw->n_dims;
   if (k) *k = tw->k;
   if (device_bytes) *device_bytes = tw->device_bytes;
+  return KPOP_OK;
+}
+
+extern "C" int kpop_twister_direct_bytes(const kpop_twister *tw, uint64_t *bytes) {
+  if (!tw || !bytes) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_twister_direct_bytes: null argument");
+  *bytes = tw->d_direct ? (1ull << (2 * tw->k)) * tw->d_pad * 8 : 0;
   return KPOP_OK;
 }
 
@@ -292,6 +332,7 @@ extern "C" int kpop_twister_load(const double *T_dims_major, uint64_t n_cols, ui
     if (total != tw->n_rows) KPOP_FAIL(KPOP_ERR_HIP, "kpop_twister_load: rank index holds %llu k-mers, expected %llu",
                                        (unsigned long long)total, (unsigned long long)tw->n_rows);
     KPOP_TRY(compact_rank_index(tw, st));
+    KPOP_TRY(build_direct_rows(tw, st));
   } else {
     tw->d_sorted_hash = d_hash.as<uint64_t>();
     d_hash.p = nullptr;  // ownership moves to the twister
@@ -353,6 +394,7 @@ extern "C" int kpop_twister_synth_slice(uint64_t seed, int k, int content, uint3
   KPOP_LAUNCH_CHECK();
   KPOP_HIP(hipStreamSynchronize(st));
   KPOP_TRY(compact_rank_index(tw, st));
+  if (!acc_dim) KPOP_TRY(build_direct_rows(tw, st));
   guard.tw = nullptr;
   *out = tw;
   return KPOP_OK;

@@ -782,3 +782,60 @@ def test_understated_max_len_yields_nan_rows_not_stale_memory(kpop, oracle):
     res = torch.zeros(2, 2, dtype=torch.float64, device=dev)
     with pytest.raises(kpop.KPopError):
         api.dev_distance_rowwise(m.data_ptr(), 2, m.data_ptr(), 2, 40000, metric.data_ptr(), None, res.data_ptr(), normalize=False)
+
+
+@pytest.mark.parametrize("d", [16, 24, 5])
+def test_count_twist_with_the_rows_at_their_hashes(kpop, oracle, d):
+    """A nearly complete twister of large k and few dimensions also keeps its rows at the address the hash names (twister.h,
+    `direct`): the fused kernel for reads then looks nothing up.  k = 13: (a) every canonical 13-mer (the layout is built by its
+    own rule) -- the same bits as without it (kpop_tune("direct", 0)); (b) a twister that knows SOME of the k-mers that occur
+    (forced: kpop_tune("direct", 1)) -- rows that do not exist must drop out of the sum AND of the normaliser; reads with Ns,
+    reads that hold nothing the twister knows, and assemblies (the streaming kernel keeps the index) in the batch; against the
+    oracle, normalised and not."""
+    from kpop_amd import api
+    k = 13
+    rng = np.random.RandomState(d)
+    bases, offs = oracle.synth_reads(77 + d, 400, 150)
+    bases = bases.copy()
+    bases[offs[3] + 40] = ord("N")
+    bases[offs[5]:offs[6]] = ord("N")  # a read of Ns: no window at all
+    genomes = ["".join(rng.choice(list("ACGT"), size=int(n))) for n in (2500, 900)]
+    gb, go = concat(genomes)
+    allb = np.concatenate([bases, gb])
+    allo = np.concatenate([offs, offs[-1] + go[1:]])
+    h, c, o = oracle.count_reads(allb, allo, k)
+    try:
+        # (a) complete
+        res = {}
+        for mode in (2, 0):
+            api.tune("direct", mode)
+            tw = kpop.Twister.synth(0x5EED, k, d)
+            assert (tw.info()["direct_bytes"] > 0) == (mode == 2)
+            res[mode] = tw.count_twist(allb, allo)
+            tw.free()
+        assert np.array_equal(res[2], res[0])
+        cols = np.unique(h)
+        want = oracle.twist(oracle.synth_twister(0x5EED, d, cols), cols, h, c.astype(np.float64), o)
+        assert_close(res[2], want)
+        # (b) partial, forced
+        present = np.unique(h)
+        keep = present[rng.rand(len(present)) < 0.6]
+        gone_read = np.unique(h[o[7]:o[8]])  # read 7 holds nothing the twister knows
+        keep = np.setdiff1d(keep, gone_read)
+        cols = np.unique(np.concatenate([keep, np.array([0, (1 << (2 * k)) - 1], dtype=np.uint64)]).astype(np.uint64))
+        cols = cols[rng.permutation(len(cols))]
+        T = oracle.synth_twister(5, d, cols)
+        for normalize in (True, False):
+            want = oracle.twist(T, cols, h, c.astype(np.float64), o, normalize=normalize)
+            got = {}
+            for mode in (1, 0):
+                api.tune("direct", mode)
+                tw = kpop.Twister.load(T, cols, k)
+                assert (tw.info()["direct_bytes"] > 0) == (mode == 1)
+                got[mode] = tw.count_twist(allb, allo, normalize=normalize)
+                tw.free()
+            assert_close(got[1], want)
+            assert_close(got[0], want)
+            assert np.all(got[1][7] == 0.0) and np.all(got[1][5] == 0.0)
+    finally:
+        api.tune("direct", 2)

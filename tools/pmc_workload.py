@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--dims", type=int, default=64)
     ap.add_argument("--launches", type=int, default=5)
     ap.add_argument("--calib-rows", type=int, default=2 * 1024 * 1024)
+    ap.add_argument("--mutants", type=float, default=0.0, help="the sequences are copies of ONE synthetic genome with point substitutions at this rate (assemblies of one organism)")
     a = ap.parse_args()
     import torch
 
@@ -45,9 +46,26 @@ def main():
     # 2. the fused kernel
     tw = kpop_amd.Twister.synth(0x5EED, a.k, a.dims)
     n, L = a.reads, a.read_len
-    bases = torch.empty(n * L, dtype=torch.uint8, device=dev)
-    offs = torch.empty(n + 1, dtype=torch.int64, device=dev)
-    api.dev_synth_reads(0x4B506F70, n, L, bases.data_ptr(), offs.data_ptr(), stream=sp)
+    if a.mutants > 0.0:  # as bench.py's _mutants_on_device
+        ref = torch.empty(L, dtype=torch.uint8, device=dev)
+        ro = torch.empty(2, dtype=torch.int64, device=dev)
+        api.dev_synth_reads(0x0123, 1, L, ref.data_ptr(), ro.data_ptr(), stream=sp)
+        torch.cuda.synchronize()
+        bases = ref.repeat(n)
+        acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+        g = torch.Generator(device=dev)
+        g.manual_seed(0x0123)
+        step = 1 << 27
+        for lo in range(0, n * L, step):
+            hi = min(n * L, lo + step)
+            hit = torch.rand(hi - lo, device=dev, generator=g) < a.mutants
+            sub = acgt[torch.randint(0, 4, (hi - lo,), device=dev, generator=g)]
+            bases[lo:hi] = torch.where(hit, sub, bases[lo:hi])
+        offs = torch.arange(n + 1, dtype=torch.int64, device=dev) * L
+    else:
+        bases = torch.empty(n * L, dtype=torch.uint8, device=dev)
+        offs = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        api.dev_synth_reads(0x4B506F70 if L <= 1000 else 0xC1A55, n, L, bases.data_ptr(), offs.data_ptr(), stream=sp)
     tout = torch.zeros(n, a.dims, dtype=torch.float64, device=dev)
     for _ in range(a.launches):
         api.dev_count_twist(tw, bases.data_ptr(), offs.data_ptr(), n, n * L, L, tout.data_ptr(), stream=sp)
