@@ -955,7 +955,13 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
       if (protein) KPOP_PART(5); else KPOP_PART(2);
 #undef KPOP_PART
       // the spectrum straight out of the buckets' LDS tables (kpop_tune("histlds", 4): always partitioned, with the dense table + compaction of round 4, for A/B)
-      fused_csr = lds_mode != 4;
+      // the pairs straight from the bucket count where the table is sparsely hit (a read set: 13.9 M windows into 16.8 M bins,
+      // 0.31 -> 0.27 ms); where every bin is hit many times over (5,000 genomes: 148 M windows) the blocks all reach the look-back
+      // at once and the dense table + scans are ahead (bucket count 0.38 against 0.26 + 0.08 ms): kept there.
+      // (Tried and dropped, round 5: the round's keys sorted by bucket inside LDS and every bucket's run written by one wavefront
+      // with consecutive lanes -- two more barriers and two more passes over LDS a round: the partition 139 -> 148 us on reads,
+      // 890 -> 950 on genomes.  The scattered two-byte stores are not what the kernel waits for; its hashing is.)
+      fused_csr = lds_mode != 4 && (lds_mode == 3 || total_win <= 2ull * (1ull << hb));
       if (fused_csr) {
         const uint64_t bound = std::min<uint64_t>(std::min<uint64_t>(total_win, n_bins), cap);
         KPOP_TRY(S.d_oh.alloc(std::max<uint64_t>(bound, 1) * 8));
