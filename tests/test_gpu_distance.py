@@ -660,3 +660,36 @@ def test_distance_summary_on_the_matrix_cores(kpop, oracle, case, kind, d):
                 assert idx[j, :m].tolist() == idx_o[a:a + m].tolist() and np.array_equal(dist[j, :m], dist_o[a:a + m]), (case, keep, j)
                 if case != "constant":
                     np.testing.assert_allclose(z[j, :m], z_o[a:a + m], rtol=1e-8, atol=1e-9)
+
+
+def test_distance_summary_on_the_matrix_cores_in_several_chunks(kpop, oracle):
+    """more query rows than one chunk of distance rows holds (8 GiB of them: 15,232 rows against 70,001), a last chunk that is
+    short, a number of reference rows that is no multiple of 16 and of dimensions that is none of 4: every row against the
+    vector-pipe path bit for bit (medians, MADs, neighbours), a handful against the oracle"""
+    from kpop_amd import api
+    rng = np.random.RandomState(11)
+    d, r1, r2 = 7, 70001, 16000
+    m1 = rng.normal(size=(r1, d))
+    m2 = rng.normal(size=(r2, d))
+    m2[15999] = m1[70000]
+    m2[15232] = m1[3]
+    metric = oracle.metric_powers(oracle.synth_inertia(d))
+    res = {}
+    for mode in (1, 0):
+        api.tune("summary_mfma", mode)
+        res[mode] = kpop.distance_summary(m1, m2, metric, 0, 2.0, True, 3, max_neighbours=16)
+    api.tune("summary_mfma", 1)
+    a, b = res[1], res[0]
+    assert np.array_equal(a[0][:, 2:], b[0][:, 2:])
+    np.testing.assert_allclose(a[0][:, :2], b[0][:, :2], rtol=1e-11)
+    assert np.array_equal(a[1], b[1])
+    keep = np.arange(16)[None, :] < np.minimum(a[1], 16)[:, None]
+    assert np.array_equal(a[2][keep], b[2][keep]) and np.array_equal(a[3][keep], b[3][keep])
+    pick = [0, 1, 15231, 15232, 15233, 15999]
+    st_o, offs, idx_o, dist_o, z_o = oracle.distance_summary(m1, m2[pick], metric, 0, 2.0, True, 3)
+    for t, j in enumerate(pick):
+        lo, hi = int(offs[t]), int(offs[t + 1])
+        assert a[1][j] == hi - lo
+        assert a[2][j, :hi - lo].tolist() == idx_o[lo:hi].tolist() and np.array_equal(a[3][j, :hi - lo], dist_o[lo:hi])
+        assert a[0][j, 2] == st_o[t, 2] and a[0][j, 3] == st_o[t, 3]
+    assert a[3][15999, 0] == 0.0 and a[2][15999, 0] == 70000
