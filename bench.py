@@ -452,7 +452,15 @@ class Rank:
         own = all((dd_h[j, 0] == 0.0) and (int(qid[j]) in idx_h[j, :min(int(nn_h[j]), idx_h.shape[1])].tolist())
                   for j in range(len(qid)))
         own_all = self.max_over_ranks(0.0 if own else 1.0) == 0.0
+        mfma_flops = 2.0 * q_rank * self.world * n_total * a.dims  # the contraction a . b of every pair: what the matrix cores do of the call
         res["all_vs_all"] = {"queries_total": q_rank * self.world, "against": n_total, "seconds": ava,
+                             "roofline": {"kernel": "distance_rows_mfma_kernel (+ the summary's sample / pass / finish / refine kernels: the WHOLE call is the time)", "bound": "mfma",
+                                          "achieved": mfma_flops / ava / 1e12 if ava > 0 else None, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": mfma_flops / ava / 1e12 / MFMA_F64_PEAK_TFLOPS if ava > 0 else None, "traffic": None,
+                                          "algorithmic_flops_per_launch": mfma_flops, "avg_launch_ms": ava * 1e3,
+                                          "note": "since round 5 the summary's distances are f64 MFMAs that locate; what is reported is recomputed with the reference's chain "
+                                                  "(csrc/distance_mfma.hip). The MFMA kernel is ~0.3 of the call and keeps the matrix pipes 0.62 busy (counter-measured: "
+                                                  "profiles/r05_mfma_distance.txt); the fraction here is the contraction's flops over the whole call"},
                              "seconds_is": "median of three warm calls", "first_call_seconds": ava_all[0],
                              "pairs_per_second": q_rank * self.world * n_total / ava if ava > 0 else None,
                              "every_query_finds_itself_at_distance_0": own_all,
