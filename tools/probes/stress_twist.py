@@ -27,7 +27,7 @@ def main():
     rng = np.random.RandomState(int(os.environ.get("SEED", "1")))
     for it in range(int(os.environ.get("N", "30"))):
         k = int(rng.randint(8, 16))
-        d = int(rng.choice([8, 9, 33, 64, 65, 100, 130, 257]))
+        d = int(rng.choice([8, 9, 16, 24, 33, 64, 65, 100, 130, 257]))
         ref_len = int(rng.randint(2000, 12000))
         ref = rng.choice(list("ACGT"), size=ref_len)
         rate = float(rng.choice([0.0, 0.0005, 0.002, 0.01, 0.03, 0.05]))
@@ -57,11 +57,16 @@ def main():
         else:
             cols = cols[rng.rand(len(cols)) < 0.9]
         T = O.synth_twister(3 + it, d, cols)
+        # (up to 32 dimensions and k <= 13: every other time with the rows also kept at their hashes -- twister.h `direct`, forced)
+        direct = d <= 32 and k <= 13 and it % 2 == 0
+        api.tune("direct", 1 if direct else 2)
         tw = kpop.Twister.load(T, cols, k)
+        api.tune("direct", 2)
+        assert (tw.info()["direct_bytes"] > 0) == direct
         normalize = bool(rng.rand() < 0.5)
         want = O.twist(T, cols, h, c.astype(np.float64), o, normalize=normalize)
         scale = max(np.max(np.abs(want)), 1.0)
-        tag = "it=%d k=%d d=%d n=%d rate=%g content=%d normalize=%s" % (it, k, d, len(seqs), rate, content, normalize)
+        tag = "it=%d k=%d d=%d n=%d rate=%g content=%d normalize=%s direct=%s" % (it, k, d, len(seqs), rate, content, normalize, direct)
         for mode in (0, 2, 2):
             api.tune("dense", mode)
             api.tune("tileg", 64 if it % 3 else 32)
