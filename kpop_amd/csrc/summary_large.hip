@@ -913,13 +913,54 @@ __global__ __launch_bounds__(kLT) void fused_sample_kernel(const double *__restr
   }
   uint32_t a, b;
   bracket_ranks(r1 / 2, r1, s, &a, &b);
-  Sel sel[kSel] = {Sel{a, kmin, kmax, 0, 0, 0, 0, 0}, Sel{b, kmin, kmax, 0, 0, 0, 0, 0}};
+  // A selection narrows [lo, hi] by bins that are linear in KEY space -- logarithmic in the value.  One sample far below the rest
+  // (the query's distance to ITSELF when its own column is among the sampled ones, a handful of near-duplicates: 0 or 1e-8 beside
+  // values around 1.4) stretches the first range over hundreds of binades, the whole sample lands in one or two bins and every
+  // selection goes a round or more longer: 0.9 -> 2.7 ms per 1,024 rows of BASELINE config 4's all-vs-all step.  So: where the
+  // smallest sample is below a sixteenth of the mean, the samples below that mark are counted (`below` of the selections that
+  // start above them) and the range starts at the smallest sample above it.
+  uint64_t klow = kmin;
+  uint32_t n_out = 0;
+  if (s > 64 && m_hat > 0.0 && key_f64(kmin) < m_hat * 0.0625) {  // (uniform)
+    const uint64_t kmark = f64_key(m_hat * 0.0625);
+    uint64_t k2 = ~0ull;
+    uint32_t c = 0;
+    for (uint32_t i = threadIdx.x; i < s; i += kLT) {
+      const uint64_t k = f64_key(sr[i]);
+      if (k < kmark) ++c;
+      else k2 = k2 < k ? k2 : k;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t o2 = (uint64_t)__shfl_xor((unsigned long long)k2, o, 64);
+      k2 = k2 < o2 ? k2 : o2;
+      c += (uint32_t)__shfl_xor((int)c, o, 64);
+    }
+    __syncthreads();
+    if (lane == 0) {
+      s_mm[wv] = k2;
+      s_mm[kLT / 64 + wv] = c;
+    }
+    __syncthreads();
+    klow = ~0ull;
+    for (int w = 0; w < kLT / 64; ++w) {
+      klow = klow < s_mm[w] ? klow : s_mm[w];
+      n_out += (uint32_t)s_mm[kLT / 64 + w];
+    }
+    __syncthreads();
+    if (klow == ~0ull || klow > kmax) {  // (nothing above the mark: as before)
+      klow = kmin;
+      n_out = 0;
+    }
+  }
+  auto from_low = [&](uint32_t rank, int done) { return rank >= n_out ? Sel{rank, klow, kmax, n_out, 0, 0, 0, done} : Sel{rank, kmin, kmax, 0, 0, 0, 0, done}; };
+  Sel sel[kSel] = {from_low(a, 0), from_low(b, 0)};
   block_select_ranks<0, false, Row>(sr, s, 0.0, sel, 2, s_hist, s_cand, s_misc);
   // the sample's own median, and -- same passes -- the neighbour threshold
   uint64_t kcut = ~0ull;
   const double want = 3.0 * (double)req_len * (double)s / (double)r1 + 16.0;
   const bool cut = want < (double)(s - 1);
-  Sel sm[kSel] = {Sel{s / 2, kmin, kmax, 0, 0, 0, 0, 0}, Sel{cut ? (uint32_t)want : 0u, kmin, kmax, 0, 0, 0, 0, cut ? 0 : 1}};
+  Sel sm[kSel] = {from_low(s / 2, 0), from_low(cut ? (uint32_t)want : 0u, cut ? 0 : 1)};
   block_select_ranks<0, false, Row>(sr, s, 0.0, sm, 2, s_hist, s_cand, s_misc);
   if (cut) kcut = sm[1].value;
   const double ms = key_f64(sm[0].value);
