@@ -92,6 +92,8 @@ int kpop_synchronize(void *stream);
    a global atomic, and -- round 5 -- the (hash, count) pairs of every bucket written straight into the spectrum at an offset taken
    by a decoupled look-back: the 4^k-counter table is never written), direct global atomics as in round 2, chunks always
    combined, always partitioned, or (4) partitioned with the dense table and its compaction as in round 4;
+   "histguess" 1 (default) | 0: that partition sizes its buckets from a sample of the batch (one piece in 32; a bucket that
+   overflows its room sends the call back to the exact count) or always counts every window first;
    "summary2" 1 (default) | 3 | 0 | 2: summaries against more than 4,096 rows by brackets from a sample and ONE pass over the
    distance rows, the same in two passes, round 2's one block per row, or (131,072 rows and more) with the distances
    computed and reduced in one kernel and no distance rows in memory -- same results, 1, 3 and 2 level;

@@ -106,6 +106,7 @@ struct Context {
   int tune_tilepipe = 1; // assemblies of one organism, up to 64 dimensions: count_twist_tile_pipe_kernel (producer and consumer wavefronts, tile_pipe.h); 0: round 4's count_twist_tile_kernel
   int tune_blocksort = 1;  // -L on sequences of up to 32,768 windows: one block per sequence, sorted in LDS (0: device-wide sort)
   int tune_hist = 1;     // merged (-l) spectrum by atomic histogram when the hashes fit 26 bits (0: always sort)
+  int tune_histguess = 1; // the merged count's partition path sizes its buckets from a sample of the items (one in 32) instead of a counting pass over all of them; a bucket that overflows sends the call back to the exact count.  0: always the exact count
   int tune_direct = 2; // a nearly complete twister of k 13..15 and <= 32 dimensions also keeps its rows at their hashes (twister.h): 2 by that rule, 1 whenever the table fits (any k <= 15), 0 never.  Read when a twister is loaded or synthesised
   int tune_summary_mfma_lists = 1; // the refinement reads the summary's candidate lists where its bands lie inside them; 0: it scans every distance row again
   int tune_summary_mfma = 1; // summaries against >= 65,536 rows, euclidean / cosine, up to 128 dimensions: the distances as f64 MFMAs + exact refinement (distance_mfma.hip); 0: the vector-pipe chain for every pair

@@ -192,6 +192,7 @@ extern "C" int kpop_tune(const char *key, int value) {
     else if (!strcmp(key, "ldspad") && value >= 0 && value <= 65536) c.tune_ldspad = value;
     else if (!strcmp(key, "hist") && (value == 0 || value == 1)) c.tune_hist = value;
     else if (!strcmp(key, "histlds") && value >= 0 && value <= 4) c.tune_histlds = value;
+    else if (!strcmp(key, "histguess") && (value == 0 || value == 1)) c.tune_histguess = value;
     else if (!strcmp(key, "direct") && value >= 0 && value <= 2) c.tune_direct = value;
     else if (!strcmp(key, "summary_mfma_lists") && (value == 0 || value == 1)) c.tune_summary_mfma_lists = value;
     else if (!strcmp(key, "summary_mfma") && (value == 0 || value == 1)) c.tune_summary_mfma = value;

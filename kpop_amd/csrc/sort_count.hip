@@ -576,12 +576,14 @@ __global__ __launch_bounds__(1024) void hist_part_sizes_kernel(const uint8_t *__
 }
 
 // exclusive scan of at most 2,048 bucket sizes (one block): off[0..n], and the cursors the partition pass advances
+// scale > 0: g_size counts a SAMPLE of the items (one in `scale`); a bucket gets room for scale x 5/4 times that + margin
 __global__ __launch_bounds__(1024) void hist_part_offsets_kernel(const uint32_t *__restrict__ g_size, uint32_t n_buckets, uint64_t *__restrict__ off,
-                                                                 unsigned long long *__restrict__ cursor) {
+                                                                 unsigned long long *__restrict__ cursor, uint32_t scale = 0, uint32_t margin = 0) {
   __shared__ uint64_t s_w[16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t b0 = threadIdx.x * 2;
-  const uint64_t a = b0 < n_buckets ? g_size[b0] : 0, b = b0 + 1 < n_buckets ? g_size[b0 + 1] : 0;
+  auto room = [&](uint32_t c) -> uint64_t { return scale ? ((uint64_t)c * scale * 5u) / 4u + margin : (uint64_t)c; };
+  const uint64_t a = b0 < n_buckets ? room(g_size[b0]) : 0, b = b0 + 1 < n_buckets ? room(g_size[b0 + 1]) : 0;
   uint64_t incl = a + b;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -606,7 +608,12 @@ __global__ __launch_bounds__(1024) void hist_part_offsets_kernel(const uint32_t 
 template <int SB>
 __global__ __launch_bounds__(1024) void hist_partition_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int k, int content,
                                                               const HistItem *__restrict__ items, uint64_t n_items, int LB, uint32_t n_buckets,
-                                                              unsigned long long *__restrict__ cursor, uint16_t *__restrict__ entries, uint32_t quota) {
+                                                              unsigned long long *__restrict__ cursor, uint16_t *__restrict__ entries, uint32_t quota,
+                                                              const uint64_t *__restrict__ room_end = nullptr, uint32_t *__restrict__ overflow = nullptr,
+                                                              uint64_t trash = 0) {
+  // room_end (= the offsets, from bucket 1 on): the buckets' rooms were GUESSED from a sample of the items (no counting pass over
+  // all of them); a bucket whose room is exceeded raises *overflow -- the caller then counts and partitions again, exactly --
+  // and its keys of this round go to the block's own stretch of a trash area behind the entries (ranks stay below the round's keys)
   // quota: keys a wavefront collects per round -- 2,048 (one block a CU), or 1,024 where the buckets are few enough (<= 512:
   // up to 24 hash bits) for TWO blocks a CU: the hashing is what the kernel spends its time on, and it wants the wavefronts
   extern __shared__ uint32_t s_part[];
@@ -694,7 +701,14 @@ __global__ __launch_bounds__(1024) void hist_partition_kernel(const uint8_t *__r
     const bool last = s_next == 0;  // (uniform: no wavefront has items left)
     for (uint32_t b = threadIdx.x; b < n_buckets; b += 1024) {
       const uint32_t c = s_cnt[b];
-      if (c) s_base[b] = atomicAdd(&cursor[b], (unsigned long long)c);
+      if (c) {
+        unsigned long long at = atomicAdd(&cursor[b], (unsigned long long)c);
+        if (room_end && at + c > room_end[b]) {
+          *overflow = 1u;
+          at = trash + (unsigned long long)blockIdx.x * 16ull * quota;
+        }
+        s_base[b] = at;
+      }
       s_cnt[b] = 0;
     }
     __syncthreads();
@@ -717,7 +731,8 @@ template <bool CSR>
 __global__ __launch_bounds__(1024) void hist_bucket_count_kernel(const uint16_t *__restrict__ entries, const uint64_t *__restrict__ off, int LB,
                                                                  uint32_t *__restrict__ table, uint32_t n_buckets, uint32_t *__restrict__ ticket,
                                                                  uint64_t *__restrict__ state, uint64_t *__restrict__ out_hash, uint32_t *__restrict__ out_count,
-                                                                 uint64_t cap, uint64_t *__restrict__ total_out) {
+                                                                 uint64_t cap, uint64_t *__restrict__ total_out,
+                                                                 const unsigned long long *__restrict__ ends = nullptr) {
   extern __shared__ uint32_t s_tab[];
   __shared__ uint32_t s_b, s_wsum[16];
   __shared__ uint64_t s_base;
@@ -730,7 +745,7 @@ __global__ __launch_bounds__(1024) void hist_bucket_count_kernel(const uint16_t 
   }
   for (uint32_t j = threadIdx.x; j < n_bins; j += 1024) s_tab[j] = 0;
   __syncthreads();
-  const uint64_t e0 = off[b], e1 = off[b + 1];
+  const uint64_t e0 = off[b], e1 = ends ? min((uint64_t)ends[b], off[b + 1]) : off[b + 1];  // (ends: rooms guessed from a sample, filled up to the cursors)
   for (uint64_t i = e0 + threadIdx.x; i < e1; i += 1024) atomicAdd(&s_tab[entries[i]], 1u);
   __syncthreads();
   if (!CSR) {
@@ -924,17 +939,43 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
         }
       }
       const uint64_t n_items = protein ? items.size() : items.size() / 2;
-      DevBuf d_items, d_size, d_poff, d_cursor, d_entries;
+      const uint32_t quota = n_buckets <= 512 ? kPartQuota / 2 : kPartQuota;
+      const uint32_t blocks2 = (uint32_t)std::min<uint64_t>(div_up(n_items, 64), (uint64_t)ctx().n_cus * (quota < kPartQuota ? 2 : 1));
+      // The exact sizes of the buckets cost a pass that hashes every window (a quarter of the call).  DNA, enough items: the sizes of
+      // one item in kPartSample instead, every bucket given 5/4 of what that predicts + a margin (the sample is a few hundred to a few
+      // thousand windows a bucket: 4 % standard deviation at worst), a bucket that overflows all the same caught by the partition
+      // pass -- which then runs again behind the exact count (kpop_tune("histguess", 0): always the exact count).
+      constexpr uint32_t kPartSample = 32, kPartMargin = 2048;
+      bool guess = !protein && ctx().tune_histguess && n_items >= 64 * kPartSample;
+      std::vector<HistItem> sample;
+      uint64_t sample_win = 0;
+      if (guess) {
+        sample.reserve(items.size() / kPartSample + 2);
+        for (uint64_t i = 0; i < n_items; i += kPartSample) {
+          sample.push_back(items[2 * i]);
+          sample.push_back(items[2 * i + 1]);
+          HistItemD it;
+          memcpy(&it, &items[2 * i], sizeof it);
+          sample_win += it.nw;
+        }
+      }
+      const uint64_t n_sample = sample.size() / 2;
+      const uint64_t room_total = guess ? (sample_win * kPartSample * 5) / 4 + (uint64_t)n_buckets * kPartMargin : total_win;
+      const uint64_t trash_at = room_total + 8, trash_len = guess ? (uint64_t)blocks2 * 16 * quota : 0;
+      DevBuf d_items, d_sample, d_size, d_poff, d_cursor, d_entries, d_over;
       KPOP_TRY(d_items.alloc(items.size() * sizeof(HistItem) + 16));
+      KPOP_TRY(d_sample.alloc(sample.size() * sizeof(HistItem) + 16));
       KPOP_TRY(d_size.alloc((uint64_t)n_buckets * 4));
       KPOP_TRY(d_poff.alloc((uint64_t)(n_buckets + 1) * 8));
       KPOP_TRY(d_cursor.alloc((uint64_t)n_buckets * 8));
-      KPOP_TRY(d_entries.alloc(total_win * 2 + 16));
+      KPOP_TRY(d_over.alloc(64));
+      KPOP_TRY(d_entries.alloc(std::max(room_total + 8 + trash_len, total_win) * 2 + 16));
       KPOP_HIP(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(HistItem), hipMemcpyHostToDevice, st));
+      if (guess) KPOP_HIP(hipMemcpyAsync(d_sample.p, sample.data(), sample.size() * sizeof(HistItem), hipMemcpyHostToDevice, st));
       KPOP_HIP(hipMemsetAsync(d_size.p, 0, (uint64_t)n_buckets * 4, st));
+      KPOP_HIP(hipMemsetAsync(d_over.p, 0, 64, st));
       const uint32_t blocks1 = (uint32_t)std::min<uint64_t>(div_up(n_items, 16), (uint64_t)ctx().n_cus * 2);
-      const uint32_t quota = n_buckets <= 512 ? kPartQuota / 2 : kPartQuota;
-      const uint32_t blocks2 = (uint32_t)std::min<uint64_t>(div_up(n_items, 64), (uint64_t)ctx().n_cus * (quota < kPartQuota ? 2 : 1));
+      const uint32_t blocks1s = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(div_up(n_sample, 16), 1), (uint64_t)ctx().n_cus * 2);
       const size_t lds_part = (size_t)16 * quota * 4 + (size_t)(n_buckets + (n_buckets & 1u)) * 4 + (size_t)n_buckets * 8;
       static PerSlotOnce once;
       if (!once()) {
@@ -952,8 +993,28 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
     hist_partition_kernel<SB><<<dim3(blocks2), dim3(1024), lds_part, st>>>(S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), k, content, d_items.as<HistItem>(), \
                                                                           n_items, LB, n_buckets, d_cursor.as<unsigned long long>(), d_entries.as<uint16_t>(), quota); \
   } while (0)
-      if (protein) KPOP_PART(5); else KPOP_PART(2);
+      if (guess) {
+        hist_part_sizes_kernel<2><<<dim3(blocks1s), dim3(1024), (size_t)n_buckets * 4, st>>>(S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), k, content,
+                                                                                            d_sample.as<HistItem>(), n_sample, LB, n_buckets, d_size.as<uint32_t>());
+        hist_part_offsets_kernel<<<dim3(1), dim3(1024), 0, st>>>(d_size.as<uint32_t>(), n_buckets, d_poff.as<uint64_t>(), d_cursor.as<unsigned long long>(), kPartSample,
+                                                                 kPartMargin);
+        hist_partition_kernel<2><<<dim3(blocks2), dim3(1024), lds_part, st>>>(S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), k, content, d_items.as<HistItem>(), n_items, LB,
+                                                                             n_buckets, d_cursor.as<unsigned long long>(), d_entries.as<uint16_t>(), quota,
+                                                                             d_poff.as<uint64_t>() + 1, d_over.as<uint32_t>(), trash_at);
+        KPOP_LAUNCH_CHECK();
+        uint32_t over = 0;
+        KPOP_HIP(hipMemcpyAsync(&over, d_over.p, 4, hipMemcpyDeviceToHost, st));
+        KPOP_HIP(hipStreamSynchronize(st));
+        if (over) {  // (a sample that did not speak for the batch: the exact count after all)
+          guess = false;
+          KPOP_HIP(hipMemsetAsync(d_size.p, 0, (uint64_t)n_buckets * 4, st));
+        }
+      }
+      if (!guess) {
+        if (protein) KPOP_PART(5); else KPOP_PART(2);
+      }
 #undef KPOP_PART
+      const unsigned long long *ends = guess ? d_cursor.as<unsigned long long>() : nullptr;
       // the spectrum straight out of the buckets' LDS tables (kpop_tune("histlds", 4): always partitioned, with the dense table + compaction of round 4, for A/B)
       // the pairs straight from the bucket count where the table is sparsely hit (a read set: 13.9 M windows into 16.8 M bins,
       // 0.31 -> 0.27 ms); where every bin is hit many times over (5,000 genomes: 148 M windows) the blocks all reach the look-back
@@ -971,11 +1032,11 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
         uint64_t *state = d_state.as<uint64_t>() + 8;  // ([0] the ticket, [1] the total, then a word a bucket)
         hist_bucket_count_kernel<true><<<dim3(n_buckets), dim3(1024), (size_t)4 << LB, st>>>(
             d_entries.as<uint16_t>(), d_poff.as<uint64_t>(), LB, nullptr, n_buckets, reinterpret_cast<uint32_t *>(d_state.p), state, S.d_oh.as<uint64_t>(),
-            S.d_oc.as<uint32_t>(), bound, d_state.as<uint64_t>() + 1);
+            S.d_oc.as<uint32_t>(), bound, d_state.as<uint64_t>() + 1, ends);
         fused_bound = bound;
       } else
         hist_bucket_count_kernel<false><<<dim3(n_buckets), dim3(1024), (size_t)4 << LB, st>>>(d_entries.as<uint16_t>(), d_poff.as<uint64_t>(), LB, table, n_buckets,
-                                                                                             nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+                                                                                             nullptr, nullptr, nullptr, nullptr, 0, nullptr, ends);
     } else if (max_win <= 4096) {
       read_hist_kernel<uint32_t><<<dim3(std::min<uint32_t>(div_up(n_reads, 4), 1u << 16)), dim3(256), 0, st>>>(
           S.d_bases.as<uint8_t>(), S.d_off.as<uint64_t>(), k, content, table, n_reads);

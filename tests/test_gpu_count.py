@@ -223,3 +223,28 @@ def test_count_assemblies_block_sort_equals_device_sort_and_oracle(kpop, oracle,
         prot = ["".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWYX"), size=n)) for n in (600, 3000, 20000)]
         pb, po = concat(prot)
         spectra_equal(kpop.count_reads(pb, po, k, kpop.PROTEIN), oracle.count_reads(pb, po, k, oracle.PROTEIN))
+
+
+@pytest.mark.parametrize("guess", [1, 0])
+def test_count_merged_when_the_sample_does_not_speak_for_the_batch(kpop, oracle, guess):
+    """-l on reads that do not repeat, partition path: the buckets' rooms come from ONE item in 32 (kpop_tune("histguess", 1), the
+    default).  Here every 32nd read -- the sampled ones -- is random and the 31 between them are copies of a few low-complexity
+    reads: the buckets those fall into overflow their guessed rooms, the partition pass says so and the call goes back to the
+    exact count.  The same spectrum either way, and as the oracle's; then an ordinary read set, where the guess holds."""
+    from kpop_amd import api
+    rng = np.random.RandomState(5)
+    n = 40000
+    rnd = ["".join(rng.choice(list("ACGT"), size=150)) for _ in range(n // 32 + 1)]
+    few = ["ACGTTGCA" * 19, "A" * 150, ("AC" * 75), "".join(rng.choice(list("ACGT"), size=150))]
+    seqs = [rnd[i // 32] if i % 32 == 0 else few[i % 4] for i in range(n)]
+    bases, offs = concat(seqs)
+    api.tune("histlds", 3)  # (always the partition path: repeats would otherwise send the batch elsewhere)
+    api.tune("histguess", guess)
+    try:
+        for k in (12, 13):
+            spectra_equal(kpop.count_reads(bases, offs, k, per_read=False), oracle.count_reads(bases, offs, k, per_read=False))
+        b2, o2 = oracle.synth_reads(0x77, 60000, 150)
+        spectra_equal(kpop.count_reads(b2, o2, 12, per_read=False), oracle.count_reads(b2, o2, 12, per_read=False))
+    finally:
+        api.tune("histlds", 1)
+        api.tune("histguess", 1)
