@@ -858,7 +858,7 @@ struct StoreBins {
 };
 
 static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, int k, int content, uint64_t cap,
-                             SortedSpectra &S, hipStream_t st) {
+                             SortedSpectra &S, hipStream_t st, bool exact_sizes = false) {
   const uint64_t base0 = offsets[0], n_bases = offsets[n_reads] - base0;
   std::vector<uint64_t> rel(n_reads + 1);
   uint64_t max_win = 0;
@@ -904,7 +904,8 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
   if (!partition) KPOP_HIP(hipMemsetAsync(S.d_ka.p, 0, n_bins * 4, st));
   bool fused_csr = false;  // the partition path wrote the spectrum itself
   uint64_t fused_bound = 0;
-  DevBuf d_state;
+  DevBuf d_state, d_over;
+  bool over_pending = false;  // the partition's rooms were guessed and nobody has looked at its overflow flag yet
   if (max_win > 0) {
     if (lds_mode && hb <= kHistLdsBits) {
       // the whole table fits a block's LDS: private copies, one global atomic per non-zero counter and block
@@ -946,7 +947,9 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
       // thousand windows a bucket: 4 % standard deviation at worst), a bucket that overflows all the same caught by the partition
       // pass -- which then runs again behind the exact count (kpop_tune("histguess", 0): always the exact count).
       constexpr uint32_t kPartSample = 32, kPartMargin = 2048;
-      bool guess = !protein && ctx().tune_histguess && n_items >= 64 * kPartSample;
+      bool guess = !protein && ctx().tune_histguess && !exact_sizes && n_items >= 64 * kPartSample;
+      // (the spectrum straight from the bucket count ends in a copy of its length anyway: the flag is looked at there, not here)
+      const bool fused_next = lds_mode != 4 && (lds_mode == 3 || total_win <= 2ull * (1ull << hb));
       std::vector<HistItem> sample;
       uint64_t sample_win = 0;
       if (guess) {
@@ -962,7 +965,7 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
       const uint64_t n_sample = sample.size() / 2;
       const uint64_t room_total = guess ? (sample_win * kPartSample * 5) / 4 + (uint64_t)n_buckets * kPartMargin : total_win;
       const uint64_t trash_at = room_total + 8, trash_len = guess ? (uint64_t)blocks2 * 16 * quota : 0;
-      DevBuf d_items, d_sample, d_size, d_poff, d_cursor, d_entries, d_over;
+      DevBuf d_items, d_sample, d_size, d_poff, d_cursor, d_entries;
       KPOP_TRY(d_items.alloc(items.size() * sizeof(HistItem) + 16));
       KPOP_TRY(d_sample.alloc(sample.size() * sizeof(HistItem) + 16));
       KPOP_TRY(d_size.alloc((uint64_t)n_buckets * 4));
@@ -1002,12 +1005,15 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
                                                                              n_buckets, d_cursor.as<unsigned long long>(), d_entries.as<uint16_t>(), quota,
                                                                              d_poff.as<uint64_t>() + 1, d_over.as<uint32_t>(), trash_at);
         KPOP_LAUNCH_CHECK();
-        uint32_t over = 0;
-        KPOP_HIP(hipMemcpyAsync(&over, d_over.p, 4, hipMemcpyDeviceToHost, st));
-        KPOP_HIP(hipStreamSynchronize(st));
-        if (over) {  // (a sample that did not speak for the batch: the exact count after all)
-          guess = false;
-          KPOP_HIP(hipMemsetAsync(d_size.p, 0, (uint64_t)n_buckets * 4, st));
+        if (fused_next) over_pending = true;
+        else {
+          uint32_t over = 0;
+          KPOP_HIP(hipMemcpyAsync(&over, d_over.p, 4, hipMemcpyDeviceToHost, st));
+          KPOP_HIP(hipStreamSynchronize(st));
+          if (over) {  // (a sample that did not speak for the batch: the exact count after all)
+            guess = false;
+            KPOP_HIP(hipMemsetAsync(d_size.p, 0, (uint64_t)n_buckets * 4, st));
+          }
         }
       }
       if (!guess) {
@@ -1022,7 +1028,7 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
       // (Tried and dropped, round 5: the round's keys sorted by bucket inside LDS and every bucket's run written by one wavefront
       // with consecutive lanes -- two more barriers and two more passes over LDS a round: the partition 139 -> 148 us on reads,
       // 890 -> 950 on genomes.  The scattered two-byte stores are not what the kernel waits for; its hashing is.)
-      fused_csr = lds_mode != 4 && (lds_mode == 3 || total_win <= 2ull * (1ull << hb));
+      fused_csr = fused_next;
       if (fused_csr) {
         const uint64_t bound = std::min<uint64_t>(std::min<uint64_t>(total_win, n_bins), cap);
         KPOP_TRY(S.d_oh.alloc(std::max<uint64_t>(bound, 1) * 8));
@@ -1056,8 +1062,11 @@ static int hist_count_device(const uint8_t *bases, const uint64_t *offsets, uint
   }
   if (fused_csr) {
     uint64_t nu = 0;
+    uint32_t over = 0;
     KPOP_HIP(hipMemcpyAsync(&nu, d_state.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, st));
+    if (over_pending) KPOP_HIP(hipMemcpyAsync(&over, d_over.p, 4, hipMemcpyDeviceToHost, st));
     KPOP_HIP(hipStreamSynchronize(st));
+    if (over) return hist_count_device(bases, offsets, n_reads, k, content, cap, S, st, true);  // (a sample that did not speak for the batch: once more, counted)
     if (nu > cap || nu > fused_bound)
       KPOP_FAIL(KPOP_ERR_CAPACITY, "kpop_count_reads: %llu distinct k-mers, capacity %llu", (unsigned long long)nu, (unsigned long long)cap);
     S.nu = nu;
