@@ -746,7 +746,25 @@ __global__ __launch_bounds__(1024) void hist_bucket_count_kernel(const uint16_t 
   for (uint32_t j = threadIdx.x; j < n_bins; j += 1024) s_tab[j] = 0;
   __syncthreads();
   const uint64_t e0 = off[b], e1 = ends ? min((uint64_t)ends[b], off[b + 1]) : off[b + 1];  // (ends: rooms guessed from a sample, filled up to the cursors)
-  for (uint64_t i = e0 + threadIdx.x; i < e1; i += 1024) atomicAdd(&s_tab[entries[i]], 1u);
+  {
+    // eight entries a load (the run's body from its first 16-byte boundary on; the few entries before it and after the last whole
+    // group one by one): a two-byte load a lane was 128 bytes a wavefront instruction
+    const uint64_t a0 = min(e1, (e0 + 7u) & ~7ull), a1 = a0 + ((e1 - a0) & ~7ull);
+    for (uint64_t i = e0 + threadIdx.x; i < a0; i += 1024) atomicAdd(&s_tab[entries[i]], 1u);
+    const uint4 *v8 = reinterpret_cast<const uint4 *>(entries + a0);
+    for (uint64_t g = threadIdx.x; g < (a1 - a0) / 8; g += 1024) {
+      const uint4 v = v8[g];
+      atomicAdd(&s_tab[v.x & 0xFFFFu], 1u);
+      atomicAdd(&s_tab[v.x >> 16], 1u);
+      atomicAdd(&s_tab[v.y & 0xFFFFu], 1u);
+      atomicAdd(&s_tab[v.y >> 16], 1u);
+      atomicAdd(&s_tab[v.z & 0xFFFFu], 1u);
+      atomicAdd(&s_tab[v.z >> 16], 1u);
+      atomicAdd(&s_tab[v.w & 0xFFFFu], 1u);
+      atomicAdd(&s_tab[v.w >> 16], 1u);
+    }
+    for (uint64_t i = a1 + threadIdx.x; i < e1; i += 1024) atomicAdd(&s_tab[entries[i]], 1u);
+  }
   __syncthreads();
   if (!CSR) {
     uint32_t *out = table + ((uint64_t)b << LB);
