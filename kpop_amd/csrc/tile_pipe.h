@@ -35,6 +35,7 @@ constexpr uint32_t kPipeListCap = 8 * kTileS;    // entries of a producer wavefr
 // miss the set are hashed again one by one, not all 64 of a thread.
 constexpr uint32_t kPipeUnits = 33, kPipeRowW = 85;  // dwords of a row: F at 0, R at 33, V at 66; 85 = 21 mod 32: four rows x eight threads' dwords on 32 banks
 constexpr uint32_t kPipeMissLds = 192;  // entries of a producer wavefront's list of missed hashes that stay in LDS until their rows are found (beyond: global)
+constexpr uint32_t kPipePrioList = 300;  // a consumer wavefront with more residual rows than this to gather goes ahead of the producers (s_setprio)
 constexpr size_t kPipeLdsBytes = (size_t)2 * kPipeG * kPipeXW * 4 + (size_t)kTileH * 8 + (size_t)2 * kTileSetCap * 4 + (size_t)kPipeG * kPipeRowW * 4 +
                                  (size_t)8 * kPipeMissLds * 4;
 typedef uint32_t pipe_u32x4_any __attribute__((ext_vector_type(4), aligned(1)));  // sixteen bytes from any address: one global_load_dwordx4
@@ -112,6 +113,13 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
   };
   if (wv >= 8) {
     // =================================================================== PRODUCER
+    // Issue priority.  An f64 MFMA holds its SIMD for 64 cycles, and with two consumers queueing MFMAs on every SIMD the producers'
+    // chain -- the launch, at low divergence -- waited its turn behind them: producers go ahead of consumers that only multiply
+    // (5,000 mutants at 0.1 / 0.3 %: 1.17 -> 1.02, 1.44 -> 1.20 ms).  A consumer whose chunk carries a long residual list is the
+    // launch instead (1 %, 3 %: producers first cost 3-4 % there) and raises itself above them for that chunk: below
+    // (more than kPipePrioList entries for its eight sequences; 150 and 700 measured worse than 300 at 0.3 % and at 1 %).
+    // kpop_tune("dbg", 64 << 24): everybody at the same priority, as before.
+    if (!(dbg_in & 64)) __builtin_amdgcn_s_setprio(2);
     const uint32_t pw = (uint32_t)wv - 8u, pt = pw * 64u + (uint32_t)lane;
     const uint32_t sq = pt >> 3, tq = pt & 7u;  // the thread's sequence of the group and eighth of the stretch (64 windows)
     const uint32_t n_groups = (n_long + G - 1) / G;
@@ -771,6 +779,9 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
     // ---- the residual gather, lane = dimension: eight rows loaded before two blocks' MFMAs, added after them, in list order
     const uint32_t *wl = lists + (((uint64_t)blockIdx.x * 2 + buf) * 8 + cw) * kPipeListCap;
     const uint32_t wcnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rtot[buf][cw]);
+    if (!(dbg_in & 64)) {
+      if (wcnt > kPipePrioList) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);  // (see the producers' s_setprio)
+    }
     constexpr int GR = 8;
     double rsum[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, cur = 0.0;
     uint32_t cur_j = 0, gpos = 0, ipos = 0;  // the next batch to add, the next batch to issue
