@@ -161,6 +161,7 @@ __global__ __launch_bounds__(256) void distance_rows_mfma_kernel(const double *_
       }
     }
     const double sai = s_sa[buf][l15];
+    __builtin_amdgcn_s_setprio(2);  // (the square roots and stores of this tile ahead of the other wavefronts' MFMAs: they end the tile, the MFMAs only fill the pipe)
     put(buf ^ 1);  // (its readers passed the barrier that ended the previous tile)
     const uint32_t i = 16u * t + l15;
     if (rows_full && 16u * t + 16u <= r1) {  // (uniform) straight-line stores
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(256) void distance_rows_mfma_kernel(const double *_
           if (row < q && i < r1) out[(uint64_t)row * r1 + i] = KIND == KPOP_EUCLIDEAN ? sqrt_fast(u) : u * 0.5;
         }
     }
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
   }
 }
