@@ -52,13 +52,13 @@ __device__ __forceinline__ void pipe_wait(const uint32_t *p, uint32_t target) {
   pipe_lds_fence();
 }
 // a barrier among the eight wavefronts of a half: everybody adds one, everybody waits for eight more than last time
-template <bool GLOBAL = false>
+template <bool GLOBAL = false, uint32_t N = 8>
 __device__ __forceinline__ void pipe_half_barrier(uint32_t *ctr, uint32_t &target, int lane) {
   if (GLOBAL)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   else
     pipe_lds_fence();
-  target += 8u;
+  target += N;
   if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   pipe_wait(ctr, target);
 }
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
   __shared__ uint64_t s_slot[2][G];   // the group's (sequence, segment) slots, ~0: the sequence has no such segment
   __shared__ uint32_t s_rtot[2][8];   // entries of every producer wavefront's residual list (row | sequence of its eight << 29)
   __shared__ uint32_t s_U[2];         // members as multiplied (padded to 64)
-  __shared__ uint32_t s_pbar, s_cbar, s_full, s_empty, s_done;
+  __shared__ uint32_t s_pbar, s_cbar4[2], s_full, s_empty, s_done;
   __shared__ uint32_t s_new, s_samp, s_over, s_add[4], s_wbase[8];
   __shared__ uint32_t s_ref[kPipeRowW];    // the set's REFERENCE: the staged stretch of the primary seed it was built from ...
   __shared__ __attribute__((aligned(16))) uint16_t s_refnum[kTileS];    // ... the member every window of it is (0xFFFF none, 0xFFFE a member without a row),
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
   if (threadIdx.x < 16) s_stamp[threadIdx.x] = 0;
   if (threadIdx.x == 0) {
     s_pbar = 0;
-    s_cbar = 0;
+    s_cbar4[0] = s_cbar4[1] = 0;
     s_full = 0;
     s_empty = 0;
     s_done = 0;
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
   uint32_t n_con = 0, cbar_t = 0;
   auto cbar = [&]() {
     const unsigned long long t0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    pipe_half_barrier(&s_cbar, cbar_t, lane);
+    pipe_half_barrier<false, 4>(&s_cbar4[mh], cbar_t, lane);  // (the four wavefronts of one half of the sequences: see the sums below)
     if (stamps) {
       const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
       atomicAdd(&s_stamp[11], dt);
@@ -877,12 +877,16 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
       }
     }
     stamp(9);  // the matrix cores
-    cbar();    // every consumer is done with X: its room takes the sums, [sequence][dimension]
-    double *R = reinterpret_cast<double *>(Xw + buf * G * XW);
+    // The sums leave through X's room, [sequence][dimension].  A wavefront multiplies 32 sequences (its half mh) by 16 dimensions and
+    // gathers for eight sequences of the SAME half: the four wavefronts of a half exchange among themselves only, in the rows of X
+    // that are their half's (32 x 776 bytes for 32 x 512 of sums) -- a barrier of four, not of all eight consumers
+    cbar();    // the half's wavefronts are done with its rows of X
+    double *R = reinterpret_cast<double *>(Xw + buf * G * XW + 32u * (uint32_t)mh * XW);
+    static_assert((32u * kPipeXW * 4u) % 8u == 0 && 32u * 64u * 8u <= 32u * kPipeXW * 4u, "a half's sums fit its own rows of X");
 #pragma unroll
     for (uint32_t rr = 0; rr < 4; ++rr) {  // lane l holds rows (l >> 4) + 4 r of an M tile, column l & 15 of the wavefront's 16 dimensions
-      R[(32u * (uint32_t)mh + g4 + 4u * rr) * 64u + 16u * (uint32_t)ni + c16] = acc0[rr];
-      R[(32u * (uint32_t)mh + 16u + g4 + 4u * rr) * 64u + 16u * (uint32_t)ni + c16] = acc1[rr];
+      R[(g4 + 4u * rr) * 64u + 16u * (uint32_t)ni + c16] = acc0[rr];
+      R[(16u + g4 + 4u * rr) * 64u + 16u * (uint32_t)ni + c16] = acc1[rr];
     }
     // the wavefront's list (all of it after the MFMAs' share), then its eight sequences' sums
     // (two batches in flight: sixteen rows a wavefront)
@@ -902,7 +906,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
     for (uint32_t j = 0; j < 8; ++j) {
       const uint32_t sqn = 8u * cw + j;
       const uint64_t sl = s_slot[buf][sqn];
-      const double v = __dadd_rn(R[sqn * 64u + (uint32_t)lane], rsum[j]);
+      const double v = __dadd_rn(R[(8u * (uint32_t)ni + j) * 64u + (uint32_t)lane], rsum[j]);
       if (sl != ~0ull && (uint32_t)lane < tv.n_dims) partial[sl * tv.n_dims + lane] = v;
     }
     pipe_lds_fence();  // (done reading this buffer's X, rows and slots)
