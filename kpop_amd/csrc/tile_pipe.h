@@ -18,6 +18,7 @@
 // residual rows in window order -- the same every run, equal to the streaming kernel's up to rounding.  Up to 64 dimensions
 // (beyond: count_twist_tile_kernel).  lib/Twister.ml:146-188.
 #pragma once
+#include <type_traits>
 
 namespace kpop {
 
@@ -856,12 +857,16 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
     // (no branch inside the four blocks: the compiler counts the loads in flight exactly and waits for a block's rows of T only --
     // with the gather or a block behind a condition it assumed the shorter path and waited for the rows issued one block ago.
     // Past the end of the list a batch loads row 0 and adds nothing.)
-    for (uint32_t b0 = 0; b0 < nb; b0 += 4) {  // (nb is a multiple of four)
+    // Two copies of the loop: with the gather's batches while the list lasts, without them after it (at 0.1 % divergence a wavefront's
+    // list is three batches and its set thirty blocks: the batches past the end -- row 0 loaded, nothing added -- were a tenth of the
+    // loop's instructions).  A batch is issued and added inside one turn of four blocks, so the change-over leaves nothing in flight.
+    auto four_blocks = [&](uint32_t b0, auto with_gather) {
+      constexpr bool WG = decltype(with_gather)::value;
 #pragma unroll
       for (uint32_t s = 0; s < 4; ++s) {
         const uint32_t b = b0 + s;
-        if (s == 0 && !(dbg & 4)) gather_issue(gv, gj, entA);
-        if (s == 2 && !(dbg & 4)) gather_issue(gv, gj, entB);
+        if (WG && s == 0 && !(dbg & 4)) gather_issue(gv, gj, entA);
+        if (WG && s == 2 && !(dbg & 4)) gather_issue(gv, gj, entB);
         load_rows(bs[(s + 3u) & 3u], uqn);  // block b + 3's rows of T
         uqn = *reinterpret_cast<const uint4 *>(uc + 16u * min(b + 4u, nb - 1u));
         const uint32_t bx = min(b + 1u, nb - 1u);
@@ -873,9 +878,12 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
         }
         a0 = an0;
         a1 = an1;
-        if ((s & 1u) == 1 && !(dbg & 4)) gather_add(gv, gj);
+        if (WG && (s & 1u) == 1 && !(dbg & 4)) gather_add(gv, gj);
       }
-    }
+    };
+    uint32_t b0 = 0;
+    for (; b0 < nb && ipos < wcnt; b0 += 4) four_blocks(b0, std::true_type{});  // (nb is a multiple of four)
+    for (; b0 < nb; b0 += 4) four_blocks(b0, std::false_type{});
     stamp(9);  // the matrix cores
     // The sums leave through X's room, [sequence][dimension].  A wavefront multiplies 32 sequences (its half mh) by 16 dimensions and
     // gathers for eight sequences of the SAME half: the four wavefronts of a half exchange among themselves only, in the rows of X
