@@ -82,7 +82,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
   __shared__ uint64_t s_slot[2][G];   // the group's (sequence, segment) slots, ~0: the sequence has no such segment
   __shared__ uint32_t s_rtot[2][8];   // entries of every producer wavefront's residual list (row | sequence of its eight << 29)
   __shared__ uint32_t s_U[2];         // members as multiplied (padded to 64)
-  __shared__ uint32_t s_pbar, s_cbar4[2], s_full, s_empty, s_done;
+  __shared__ uint32_t s_pbar, s_cbar4[2], s_full, s_empty2[2], s_done;  // (s_empty2: chunks released, counted per HALF of the consumers -- the halves are not in step any more, and one counter let a half that was two chunks ahead stand in for the other)
   __shared__ uint32_t s_new, s_samp, s_over, s_add[4], s_wbase[8];
   __shared__ uint32_t s_ref[kPipeRowW];    // the set's REFERENCE: the staged stretch of the primary seed it was built from ...
   __shared__ __attribute__((aligned(16))) uint16_t s_refnum[kTileS];    // ... the member every window of it is (0xFFFF none, 0xFFFE a member without a row),
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
     s_pbar = 0;
     s_cbar4[0] = s_cbar4[1] = 0;
     s_full = 0;
-    s_empty = 0;
+    s_empty2[0] = s_empty2[1] = 0;
     s_done = 0;
   }
   __syncthreads();  // the one hardware barrier: from here on the halves go their own ways
@@ -413,7 +413,8 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
         // (under the index words' trip to memory: the wait for this buffer)
         if (n_pub >= 2) {  // the consumers are done with this buffer's last chunk
           const unsigned long long t0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-          pipe_wait(&s_empty, 8u * (n_pub - 1u));
+          pipe_wait(&s_empty2[0], 4u * (n_pub - 1u));
+          pipe_wait(&s_empty2[1], 4u * (n_pub - 1u));
           if (stamps) {
             const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
             atomicAdd(&s_stamp[7], dt);
@@ -495,7 +496,8 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
         // not had them yet (the other buffer has: its consumers only read it)
         if (n_pub >= 2) {
           const unsigned long long t0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-          pipe_wait(&s_empty, 8u * (n_pub - 1u));
+          pipe_wait(&s_empty2[0], 4u * (n_pub - 1u));
+          pipe_wait(&s_empty2[1], 4u * (n_pub - 1u));
           if (stamps) {
             const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
             atomicAdd(&s_stamp[7], dt);
@@ -918,7 +920,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
       if (sl != ~0ull && (uint32_t)lane < tv.n_dims) partial[sl * tv.n_dims + lane] = v;
     }
     pipe_lds_fence();  // (done reading this buffer's X, rows and slots)
-    if (lane == 0) __hip_atomic_fetch_add(&s_empty, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) __hip_atomic_fetch_add(&s_empty2[mh], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     ++n_con;
     stamp(10);  // the sums written
   }
