@@ -839,3 +839,46 @@ def test_count_twist_with_the_rows_at_their_hashes(kpop, oracle, d):
             assert np.all(got[1][7] == 0.0) and np.all(got[1][5] == 0.0)
     finally:
         api.tune("direct", 2)
+
+
+@pytest.mark.parametrize("rate", [0.003, 0.01])
+def test_many_chunks_a_block_give_the_same_bits_every_call(kpop, oracle, rate):
+    """8,000 assemblies of one 30 kb organism through the pipelined tile kernel, five calls: every block works through some thirty
+    chunks with its producers two chunks ahead of its consumers and the consumers' halves out of step -- where a hand-over that
+    is wrong shows (one was: the release counter of round 5's first barriers by half) -- and the bits must be the same every
+    time; a sample of rows against the oracle."""
+    import torch
+    from kpop_amd import api
+    k, d, n, L = 12, 64, 8000, 30000
+    dev = torch.device("cuda", 0)
+    sp = torch.cuda.current_stream().cuda_stream
+    tw = kpop.Twister.synth(0x7457, k, d)
+    ref = torch.empty(L, dtype=torch.uint8, device=dev)
+    ro = torch.empty(2, dtype=torch.int64, device=dev)
+    api.dev_synth_reads(0xF00D, 1, L, ref.data_ptr(), ro.data_ptr(), stream=sp)
+    torch.cuda.synchronize()
+    bases = ref.repeat(n)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    hit = torch.rand(n * L, device=dev, generator=g) < rate
+    bases = torch.where(hit, acgt[torch.randint(0, 4, (n * L,), device=dev, generator=g)], bases)
+    offs = torch.arange(n + 1, dtype=torch.int64, device=dev) * L
+    out = torch.zeros(n, d, dtype=torch.float64, device=dev)
+    first = None
+    for _ in range(5):
+        out.zero_()
+        api.dev_count_twist(tw, bases.data_ptr(), offs.data_ptr(), n, n * L, L, out.data_ptr(), stream=sp)
+        torch.cuda.synchronize()
+        if first is None:
+            first = out.clone()
+        else:
+            assert torch.equal(first, out)
+    pick = [0, 1, 63, 64, 3999, 7998, 7999]
+    sb = np.concatenate([bases[r * L:(r + 1) * L].cpu().numpy() for r in pick])
+    so = np.arange(len(pick) + 1, dtype=np.uint64) * L
+    h, c, o = oracle.count_reads(sb, so, k)
+    cols = np.unique(h)
+    want = oracle.twist(oracle.synth_twister(0x7457, d, cols), cols, h, c.astype(np.float64), o)
+    np.testing.assert_allclose(first.cpu().numpy()[pick], want, rtol=1e-12, atol=1e-15)
+    tw.free()
