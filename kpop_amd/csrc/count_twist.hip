@@ -1697,6 +1697,23 @@ static int launch_count_twist_wave(int R, TwisterView tv, const uint8_t *bases, 
 }
 
 
+// the pipelined tile kernel (tile_pipe.h) takes this twister: a rank-select index of words (k <= 14), a row's number in 29 bits (it
+// shares a word with three bits of tag in the residual lists) and a row's offset in 128-byte units in 32 (beyond 64 dimensions)
+static bool tile_route_pipe(const kpop_twister *tw) {
+  return tw->d_rsel && (tw->hk ? tw->hk : tw->k) <= 15 && ctx().tune_tilepipe != 0 && tw->n_rows <= (1ull << 29) && (uint64_t)tw->n_rows * (tw->d_pad / 16) < 0xFFFFFFFFull;
+}
+// ... slab by slab: more than 64 dimensions (kpop_tune("tilewide", 1): at any number of them -- up to 64 the same bits as the other)
+static bool tile_route_wide(const kpop_twister *tw) { return tile_route_pipe(tw) && (tw->n_dims > 64 || ctx().tune_tilewide == 1); }
+// bytes of per-slot tables a call of the wide route may take: 4 GiB a slab of 64 columns, a quarter of the device's memory at most (the
+// same for every call: how a batch is cut into sub-batches must not depend on what happens to be free)
+static uint64_t tile_workspace_cap(uint32_t d_pad) {
+  if (ctx().tune_tilecap_mb > 0) return (uint64_t)ctx().tune_tilecap_mb << 20;
+  uint64_t cap = (4ull << 30) * div_up(d_pad, 64u);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) cap = std::min<uint64_t>(cap, std::max<uint64_t>(4ull << 30, (uint64_t)total_b / 4));
+  return cap;
+}
+
 static int check_offsets(const uint64_t *offsets, uint32_t n, uint64_t *max_len) {
   uint64_t m = 0;
   for (uint32_t r = 0; r < n; ++r) {
@@ -1746,6 +1763,23 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   hipStream_t st = as_stream(stream);
   const TwisterView tv = view_of(tw);
   const uint32_t max_windows = (max_len >= (uint32_t)tv.hk) ? max_len - tv.hk + 1 : 0;
+  // Assemblies through more than 64 dimensions whose partial rows pass the tile route's bound (below) go through in SUB-BATCHES of
+  // sequences, m of them at most m x max_len bases, each a call of its own.
+  if (max_windows > kWaveMaxWindows && tile_route_wide(tw) && ctx().tune_dense != 0 && !ctx().tune_seg && n_reads >= kTileMinSeqs) {
+    const uint64_t max_long0 = std::min<uint64_t>(n_reads, n_bases / kWaveMaxWindows + 1);
+    const uint64_t per_slot = (uint64_t)tw->n_dims * 8 + 4 + 4 + 8, cap = tile_workspace_cap(tw->d_pad);
+    if ((n_bases / kTileS + max_long0) * per_slot > cap) {
+      const uint64_t m = cap / (((uint64_t)max_len / kTileS + 2) * per_slot);
+      if (m >= 4096 && m < n_reads) {
+        for (uint64_t r0 = 0; r0 < n_reads; r0 += m) {
+          const uint32_t n = (uint32_t)std::min<uint64_t>(m, n_reads - r0);
+          KPOP_TRY(kpop_dev_count_twist(tw, d_bases, d_offsets + r0, n, std::min<uint64_t>(n_bases, (uint64_t)n * max_len), max_len, content, normalize,
+                                        d_out + r0 * tw->n_dims, stream));
+        }
+        return KPOP_OK;
+      }
+    }
+  }
   // reads of up to 512 windows: one wavefront per read (the kernel skips longer reads)
   const int R = pick_R(std::min(max_windows, kWaveMaxWindows));
   const int flags = (normalize ? 1 : 0) | (max_windows > kWaveMaxWindows ? 2 : 0);  // bit 1: the streaming pass below takes the long ones
@@ -1769,10 +1803,16 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   // The tile route cuts sequences into 512-window segments, so its per-slot tables are sized for n_bases / 512 slots whatever the
   // probe later finds (BASELINE config 3, D = 64: 1.5 GB of partial rows against 0.28 GB; beyond 64 dimensions 2 KB of residual
   // list a slot on top).  Where that would pass 4 GiB of workspace -- per stream -- the batch keeps the streaming kernel.
+  // Beyond 64 dimensions the pipelined kernel takes the columns in slabs of 64 (tile_pipe.h, WIDE); its bound is 4 GiB per slab of
+  // columns (BASELINE config 3 at 256 dimensions: 6.1 GB of partial rows; at the reference's 1,635, README.md:1029, 39 GB -- what 288 GB
+  // are for), and a batch beyond THAT goes through in sub-batches of sequences, each sized from max_len (below).
+  const bool pipe_able = tile_route_pipe(tw);
+  const bool wide = tile_route_wide(tw);
   if (tiles_wanted) {
     const uint64_t slots = n_bases / std::min(seg_windows, kTileS) + max_long;
-    const uint64_t per_slot = (uint64_t)tw->n_dims * 8 + 4 + 4 + 8 + (tw->n_dims > 64 ? (uint64_t)kTileS * 4 : 0);
-    if (slots * per_slot > (4ull << 30)) tiles_wanted = false;
+    const uint64_t per_slot = (uint64_t)tw->n_dims * 8 + 4 + 4 + 8 + (tw->n_dims > 64 && !wide ? (uint64_t)kTileS * 4 : 0);
+    const uint64_t cap = wide ? tile_workspace_cap(tw->d_pad) : (4ull << 30);
+    if (slots * per_slot > cap) tiles_wanted = false;  // (a batch that could go through in sub-batches has, above)
   }
   const bool tiles = tiles_wanted;
   const uint32_t seg_least = tiles ? std::min(seg_windows, kTileS) : seg_windows;  // (the shortest segment any sequence is cut into)
@@ -1786,11 +1826,12 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
                  bytes_part = (max_slots * tw->n_dims * 8 + 63) & ~63ull, bytes_done = tiles ? ((max_slots * 4 + 63) & ~63ull) : 0,
                  bytes_long = ((uint64_t)n_reads * 4 + 64 + 63) & ~63ull,
                  bytes_olong = tiles ? (((uint64_t)max_long * 4 + 63) & ~63ull) : 0, bytes_gmax = tiles ? (((uint64_t)max_groups * 4 + 63) & ~63ull) : 0,
-                 bytes_res = tiles && tw->n_dims > 64 ? max_slots * kTileS * 4 : 0, bytes_todo = tiles ? ((max_slots * 8 + 1024 + 63) & ~63ull) : 0,
+                 bytes_res = tiles && tw->n_dims > 64 && !wide ? max_slots * kTileS * 4 : 0, bytes_todo = tiles ? ((max_slots * 8 + 1024 + 63) & ~63ull) : 0,
                  bytes_perread = tiles ? bytes_nseg : 0;
   // up to 64 dimensions: the pipelined kernel (tile_pipe.h; kpop_tune("tilepipe", 0): round 4's kernel, phases one after the other)
-  const bool pipe = tiles && tw->n_dims <= 64 && cx.tune_tilepipe != 0 && tw->n_rows <= (1ull << 29);  // (a row's number shares a word with three bits of tag in the residual lists)
-  const uint64_t bytes_wlists = !tiles ? 0 : pipe ? (uint64_t)cx.n_cus * 2 * 8 * kPipeListCap * 4 : (uint64_t)cx.n_cus * 16 * 4 * kTileS * 4;
+  // (kpop_tune("tilepipe", 0): round 4's kernel, phases one after the other, the residual rows in a launch of their own beyond 64 dimensions)
+  const bool pipe = tiles && pipe_able;  // (a row's number shares a word with three bits of tag in the residual lists; beyond 64 dimensions a row's offset in 128-byte units is a word)
+  const uint64_t bytes_wlists = !tiles ? 0 : pipe ? (uint64_t)cx.n_cus * 2 * 8 * kPipeListCap * 4 * (wide ? 2 : 1) : (uint64_t)cx.n_cus * 16 * 4 * kTileS * 4;
   void *ws = nullptr;
   KPOP_TRY(ctx().ws_for(st).ensure(bytes_nseg + bytes_off + 2 * bytes_sums + bytes_cnt + bytes_part + bytes_done + bytes_long + bytes_olong + 2 * bytes_gmax +
                                        bytes_res + bytes_todo + 2 * bytes_perread + bytes_wlists, &ws));
@@ -1843,18 +1884,24 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
     if (pipe) {
       static PerSlotOnce once_pipe;
       if (!once_pipe()) {
-        KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&count_twist_tile_pipe_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPipeLdsBytes));
-        KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&count_twist_tile_pipe_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPipeLdsBytes));
+        KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&count_twist_tile_pipe_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPipeLdsBytes));
+        KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&count_twist_tile_pipe_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPipeLdsBytes));
+        KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&count_twist_tile_pipe_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPipeLdsBytes));
+        KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&count_twist_tile_pipe_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPipeLdsBytes));
         once_pipe() = true;
       }
       const uint32_t pblocks = (uint32_t)std::min<uint64_t>((uint64_t)div_up(max_long, kPipeG) * max_seg, (uint64_t)cx.n_cus);
-      const int tdbg = ctx().tune_dbg >> 24;
-      if (tdbg & 15)  // (the ablation switches: a build of the kernel of their own, so that the product's loops carry no test of them)
-        count_twist_tile_pipe_kernel<true><<<dim3(pblocks), dim3(1024), kPipeLdsBytes, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, olong, sums2 + nb,
-                                                                                             gmax, grel, max_seg, slot_done, wave_lists, tdbg);
-      else
-        count_twist_tile_pipe_kernel<false><<<dim3(pblocks), dim3(1024), kPipeLdsBytes, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, olong, sums2 + nb,
-                                                                                              gmax, grel, max_seg, slot_done, wave_lists, tdbg);
+      const int tdbg = ((ctx().tune_dbg >> 24) & 255) | (ctx().tune_pipeprio << 8);
+#define KPOP_PIPE(A, W) count_twist_tile_pipe_kernel<A, W><<<dim3(pblocks), dim3(1024), kPipeLdsBytes, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, olong, sums2 + nb, gmax, grel, max_seg, slot_done, wave_lists, tdbg)
+      // (the ablation switches: a build of the kernel of their own, so that the product's loops carry no test of them;
+      //  kpop_tune("tilewide", 1): the slab-by-slab kernel at any number of dimensions -- at up to 64 the same bits as the other)
+      const bool wide_k = wide;
+      if (tdbg & 15) {
+        if (wide_k) KPOP_PIPE(true, true); else KPOP_PIPE(true, false);
+      } else {
+        if (wide_k) KPOP_PIPE(false, true); else KPOP_PIPE(false, false);
+      }
+#undef KPOP_PIPE
     } else if (tile_g == 64)
       count_twist_tile_kernel<uint32_t, 64><<<dim3(blocks), dim3(1024), lds, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, olong, sums2 + nb,
                                                                                   gmax, grel, max_seg, slot_done, res_rows, wave_lists, ctx().tune_dbg >> 24);
@@ -1862,7 +1909,7 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
       count_twist_tile_kernel<uint32_t, 32><<<dim3(blocks), dim3(512), lds, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, olong, sums2 + nb,
                                                                                  gmax, grel, max_seg, slot_done, res_rows, wave_lists, ctx().tune_dbg >> 24);
     KPOP_LAUNCH_CHECK();
-    if (tw->n_dims > 64) {  // (up to 64 dimensions the tile kernel has gathered the residual rows itself)
+    if (tw->n_dims > 64 && !pipe) {  // (the pipelined kernel -- and round 4's up to 64 dimensions -- has gathered the residual rows itself)
       const dim3 rgrid(capped_grid((max_slots + 3) / 4));
       if (nt)
         tile_residual_kernel<true><<<rgrid, dim3(256), 0, st>>>(tv, slot_done, res_rows, part, sums + nb);

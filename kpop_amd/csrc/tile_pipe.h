@@ -36,6 +36,7 @@ constexpr uint32_t kPipeListCap = 8 * kTileS;    // entries of a producer wavefr
 // miss the set are hashed again one by one, not all 64 of a thread.
 constexpr uint32_t kPipeUnits = 33, kPipeRowW = 85;  // dwords of a row: F at 0, R at 33, V at 66; 85 = 21 mod 32: four rows x eight threads' dwords on 32 banks
 constexpr uint32_t kPipeMissLds = 192;  // entries of a producer wavefront's list of missed hashes that stay in LDS until their rows are found (beyond: global)
+constexpr uint32_t kPipeGRW = 4;        // WIDE: residual rows of a lane group in flight a batch (one 16-byte load of entries)
 constexpr uint32_t kPipePrioList = 300;  // a consumer wavefront with more residual rows than this to gather goes ahead of the producers (s_setprio)
 constexpr size_t kPipeLdsBytes = (size_t)2 * kPipeG * kPipeXW * 4 + (size_t)kTileH * 8 + (size_t)2 * kTileSetCap * 4 + (size_t)kPipeG * kPipeRowW * 4 +
                                  (size_t)8 * kPipeMissLds * 4;
@@ -64,7 +65,15 @@ __device__ __forceinline__ void pipe_half_barrier(uint32_t *ctr, uint32_t &targe
   pipe_wait(ctr, target);
 }
 
-template <bool ABLATE>  // (true: the timing switches of kpop_tune("dbg", (1 | 2 | 4 | 8) << 24) are compiled in -- results are wrong under them)
+// WIDE (more than 64 dimensions): the consumers take the twister's columns in SLABS of 64 -- the same X against slab after slab of the
+// members' rows, the chunk's buffer released after the last -- and every consumer wavefront is on its own: it gathers the residual rows
+// of the 32 sequences it multiplies, for its own 16 columns (a lane group of 16 takes the sequences whose rows of the accumulator tile it
+// holds: sequence g + 4 r + 16 t of the half, 128 bytes of a residual row a load), so its sums leave straight from its registers
+// to `partial` -- no exchange through X's room (X is still needed), no barrier among the consumers.  The producers then file the
+// residual rows by (sequence of the wavefront's eight) in fixed rooms of the list, padded to whole batches with kNoCol, as offsets in
+// 128-byte units like the members' (see step 5), and the chunks are dealt so that the blocks of one XCD work on the SAME stretch at a
+// time: at 256 dimensions a stretch's members are 1.5 MB of rows (10 MB at 1,635) -- one stretch an L2, not eight.
+template <bool ABLATE, bool WIDE = false>  // (ABLATE: the timing switches of kpop_tune("dbg", (1 | 2 | 4 | 8) << 24) are compiled in -- results are wrong under them)
 __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
     TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int content,
     const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ seg_off, double *__restrict__ partial,
@@ -82,6 +91,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
   __shared__ uint64_t s_slot[2][G];   // the group's (sequence, segment) slots, ~0: the sequence has no such segment
   __shared__ uint32_t s_rtot[2][8];   // entries of every producer wavefront's residual list (row | sequence of its eight << 29)
   __shared__ uint32_t s_U[2];         // members as multiplied (padded to 64)
+  __shared__ uint32_t s_rmax[2][8][2];  // WIDE: entries (a multiple of kPipeGRW, padding included) of the longest of the four lists in either room of a producer wavefront's
   __shared__ uint32_t s_pbar, s_cbar4[2], s_full, s_empty2[2], s_done;  // (s_empty2: chunks released, counted per HALF of the consumers -- the halves are not in step any more, and one counter let a half that was two chunks ahead stand in for the other)
   __shared__ uint32_t s_new, s_samp, s_over, s_add[4], s_wbase[8];
   __shared__ uint32_t s_ref[kPipeRowW];    // the set's REFERENCE: the staged stretch of the primary seed it was built from ...
@@ -179,11 +189,17 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
     // seeds hashed, the set built, its members numbered and their rows looked up were a third of a chunk's preparation.
     // (blocks go to the eight XCDs in turn: the ranges are dealt so that the blocks of ONE XCD hold neighbouring ranges -- a few
     // stretches' worth of twister rows per L2, not every stretch's)
+    // WIDE: an XCD's blocks take the chunks of the XCD's range IN TURN (block j of it: chunks j, j + 32, ...): they multiply the same
+    // stretch's members at the same time, slab after slab, out of one L2 -- and a block's chunks in a row are still one stretch's.
     const uint32_t vblock = gridDim.x % 8u == 0 ? (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u : blockIdx.x;
     const uint64_t per_block = (n_chunks + gridDim.x - 1) / gridDim.x;
-    const uint64_t c_end = min(n_chunks, ((uint64_t)vblock + 1) * per_block);
+    const bool by_xcd = WIDE && gridDim.x % 8u == 0;
+    const uint64_t per_xcd = (n_chunks + 7) / 8;
+    const uint32_t cstep = !WIDE ? 1u : by_xcd ? gridDim.x / 8u : gridDim.x;
+    const uint64_t c_first = !WIDE ? (uint64_t)vblock * per_block : by_xcd ? (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u : (uint64_t)blockIdx.x;
+    const uint64_t c_end = !WIDE ? min(n_chunks, ((uint64_t)vblock + 1) * per_block) : by_xcd ? min(n_chunks, (blockIdx.x % 8u + 1) * per_xcd) : n_chunks;
     auto next_chunk = [&](uint64_t from) -> uint64_t {  // the first chunk of the block's range at or after `from` that is this route's
-      for (; from < c_end; ++from) {
+      for (; from < c_end; from += cstep) {
         const uint32_t sg = (uint32_t)(from / n_groups), gp = (uint32_t)(from % n_groups);
         const uint32_t pg = (uint32_t)(((uint64_t)gp * G) / kTileProbeG);
         if (grel[pg] && sg < gmax[pg]) break;  // (one organism: tile_group_probe_kernel; and some sequence of the group is this long)
@@ -281,7 +297,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
       }
       if (tq == 0) reinterpret_cast<uint16_t *>(row + 2 * kPipeUnits)[kPipeUnits] = 0xFFFFu;  // (bases 528..543: none)
     };
-    uint64_t chunk = next_chunk((uint64_t)vblock * per_block);
+    uint64_t chunk = next_chunk(c_first);
     uint32_t set_seg = ~0u, set_UP = 0, prim_seed = 0;  // the stretch the set in LDS was built for, its members as multiplied
     bool set_stale = true, rows_in[2] = {false, false};  // (rows_in: that buffer's copy of the members' rows is the set's)
     Meta cm = load_meta(chunk);
@@ -291,7 +307,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
     while (chunk < n_chunks) {
       if (skip) {  // (a block that met four chunks in a row that shared too little skips ahead: the look-ahead starts again)
         --skip;
-        chunk = next_chunk(chunk + 1);
+        chunk = next_chunk(chunk + cstep);
         cm = load_meta(chunk);
         load_units(cm, chunk, cv, cavail);
         continue;
@@ -304,7 +320,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
       pbar();
       store_units(cv, cavail);
       // the chunk after this one: its sequences now, its bases once those are known (after the seeds' turn)
-      const uint64_t nchunk = next_chunk(chunk + 1);
+      const uint64_t nchunk = next_chunk(chunk + cstep);
       const Meta nm = load_meta(nchunk);
       const bool rebuild = set_stale || seg != set_seg;  // (uniform)
       if (rebuild) {
@@ -663,7 +679,10 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
           if (lane >= o) incl += up;
         }
         const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        uint32_t *wl = lists + (((uint64_t)blockIdx.x * 2 + buf) * 8 + pw) * kPipeListCap;
+        // (WIDE: the list's own room, then as much again for the hashes that do not fit the LDS -- the rows are not written in place there)
+        uint32_t *wl = lists + (((uint64_t)blockIdx.x * 2 + buf) * 8 + pw) * (WIDE ? 2 * kPipeListCap : kPipeListCap);
+        uint32_t *wh = WIDE ? wl + kPipeListCap : wl;
+        uint32_t present = 0;  // entries that have a row, of MY sequence (lanes of a sequence all count it)
 #pragma unroll
         for (int o = 4; o > 0; o >>= 1) found += (uint32_t)__shfl_xor((int)found, o, 8);
         uint32_t wout = 0;  // entries that HAVE a row: the list as the consumers read it
@@ -678,7 +697,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
               const uint32_t i = (uint32_t)__ffsll((long long)mm) - 1u;
               mm &= mm - 1ull;
               const uint32_t h = hash_at(64u * tq + i);
-              if (pos < kPipeMissLds) ml[pos] = h; else wl[pos] = h;
+              if (pos < kPipeMissLds) ml[pos] = h; else wh[pos] = h;
               ++pos;
             }
           }
@@ -690,10 +709,13 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
           uint32_t sbeg[8];  // where every sequence's entries begin (scalars)
 #pragma unroll
           for (int j = 0; j < 8; ++j) sbeg[j] = (uint32_t)__builtin_amdgcn_readlane((int)(incl - rcnt), 8 * j);
-          uint32_t present = 0;  // of MY sequence (lanes of a sequence all count it)
+          // WIDE: sequence j of the wavefront's eight is lane group j & 3's of the consumers (the rows g + 4 r of an accumulator tile are
+          // sequences g + 4 r + 16 t of a half), in room j >> 2: its entries go to [room][lane group][place among the sequence's own], the row's
+          // offset in the twister in 128-byte units.  A consumer's lane group reads its four entries of a batch with one 16-byte load.
+          uint32_t cb[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // entries with a row so far, a sequence (scalars)
           for (uint32_t p0 = 0; p0 < wtot; p0 += 64) {
             const uint32_t e = p0 + (uint32_t)lane;
-            const uint32_t h = e >= wtot ? 0u : e < kPipeMissLds ? ml[e] : __hip_atomic_load(wl + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t h = e >= wtot ? 0u : e < kPipeMissLds ? ml[e] : __hip_atomic_load(wh + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const uint4 q = *reinterpret_cast<const uint4 *>(tv.rsel + (h >> 6));
             const uint32_t row = e < wtot ? row_of(q, h) : kNoCol;
             uint32_t tag = 0;
@@ -701,15 +723,37 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
             for (int j = 1; j < 8; ++j) tag += e >= sbeg[j] ? 1u : 0u;
             const bool has = row != kNoCol;
             const uint64_t pm = __ballot(has);
-            if (has) wl[wout + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = row | (tag << 29);
+            if (!WIDE && has) wl[wout + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = row | (tag << 29);
             wout += (uint32_t)__popcll(pm);
+            uint32_t place = 0;
 #pragma unroll
             for (uint32_t j = 0; j < 8; ++j) {
-              const uint32_t n = (uint32_t)__popcll(__ballot(has && tag == j));
+              const uint64_t bj = __ballot(has && tag == j);
+              const uint32_t n = (uint32_t)__popcll(bj);
               present += ((uint32_t)lane >> 3) == j ? n : 0u;
+              if (WIDE) {
+                place = tag == j ? cb[j] + (uint32_t)__popcll(bj & ((1ull << lane) - 1ull)) : place;
+                cb[j] += n;
+              }
             }
+            if (WIDE && has) wl[(tag >> 2) * (kPipeListCap / 2) + (tag & 3u) * kTileS + place] = row * rowq;
           }
           found += present;
+        }
+        if (WIDE) {
+          // every list of a room padded with kNoCol to the room's longest, that rounded up to whole batches
+          uint32_t mx[2] = {0u, 0u};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) mx[j >> 2] = max(mx[j >> 2], (uint32_t)__builtin_amdgcn_readlane((int)present, 8 * j));
+          mx[0] = (mx[0] + kPipeGRW - 1u) & ~(kPipeGRW - 1u);
+          mx[1] = (mx[1] + kPipeGRW - 1u) & ~(kPipeGRW - 1u);
+          const uint32_t j = (uint32_t)lane >> 3;
+          uint32_t *room = wl + (j >> 2) * (kPipeListCap / 2) + (j & 3u) * kTileS;
+          for (uint32_t e = present + tq; e < mx[j >> 2]; e += 8u) room[e] = kNoCol;
+          if (lane == 0) {
+            s_rmax[buf][pw][0] = mx[0];
+            s_rmax[buf][pw][1] = mx[1];
+          }
         }
         if (tq == 0) {
           s_slot[buf][sq] = my_slot;
@@ -747,6 +791,186 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
   const uint32_t cw = (uint32_t)wv;
   const int ni = (int)(cw & 3u), mh = (int)(cw >> 2);  // 16 dimensions, 32 sequences (wavefronts cw and cw + 4 share a SIMD and their rows of T)
   const uint32_t g4 = (uint32_t)lane >> 4, c16 = (uint32_t)lane & 15u;
+  if constexpr (WIDE) {
+    // ------------------------------------------------------------------- the consumers of more than 64 dimensions
+    const uint32_t nslab = (tv.d_pad + 63u) >> 6;
+    uint32_t n_conw = 0;
+    // byte j of w as a double (see below)
+    auto byte_f64w = [](uint32_t w, uint32_t j) -> double {
+      const uint64_t bits = 0x4330000000000000ull | (uint64_t)((w >> (8u * j)) & 0xFFu);
+      return __longlong_as_double((long long)bits) - 4503599627370496.0;
+    };
+    for (;;) {
+      bool got = false;
+      for (;;) {
+        const uint32_t dn = pipe_ld(&s_done);
+        pipe_lds_fence();
+        const uint32_t fl = pipe_ld(&s_full);
+        if ((int32_t)(fl - n_conw) > 0) {
+          got = true;
+          break;
+        }
+        if (dn) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (!got) break;
+      pipe_lds_fence();
+      stamp(8);  // waited for a chunk
+      const uint32_t buf = n_conw & 1u;
+      const uint32_t UP = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_U[buf]), nb = UP / 16u;
+      const uint32_t *uc = ucol + buf * kTileSetCap + 4u * g4;
+      const uint32_t *xa = Xw + buf * G * XW + (32u * (uint32_t)mh + c16) * XW + g4;
+      // The residual rows of my half's 32 sequences: eight RANGES (producer wavefront 4 mh + (r >> 1), room r & 1), each as long as the
+      // longest of its four lists; lane group g4 walks list g4 of every range -- sequence 8 (r >> 1) + g4 + 4 (r & 1) of the half, which is
+      // row g4 + 4 (r & 3) of accumulator tile r >> 2: range r's sum belongs to acc[r >> 2][r & 3].  Batches of kPipeGRW entries, numbered
+      // through the ranges (cum[r]: the batches before range r).
+      uint32_t cum[9];
+      cum[0] = 0;
+#pragma unroll
+      for (uint32_t r = 0; r < 8; ++r)
+        cum[r + 1] = cum[r] + (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rmax[buf][4u * (uint32_t)mh + (r >> 1)][r & 1u]) / kPipeGRW;
+      const uint32_t nbat = cum[8];
+      const uint32_t *lbase = lists + (((uint64_t)blockIdx.x * 2 + buf) * 8 + 4u * (uint32_t)mh) * (2 * kPipeListCap) + g4 * kTileS;
+      // batch gi: its range, its four entries of my lane group (all kNoCol past the last batch)
+      auto range_of = [&](uint32_t gi) -> uint32_t {
+        uint32_t r = 0;
+#pragma unroll
+        for (uint32_t q = 1; q < 8; ++q) r += gi >= cum[q] ? 1u : 0u;
+        return r;
+      };
+      auto entries_of = [&](uint32_t gi, uint32_t r) -> uint4 {
+        uint32_t before = 0;
+#pragma unroll
+        for (uint32_t q = 1; q < 8; ++q) before = r == q ? cum[q] : before;
+        const uint32_t gc = gi < nbat ? gi - before : 0u;
+        const uint4 e = *reinterpret_cast<const uint4 *>(lbase + (uint64_t)(r >> 1) * (2 * kPipeListCap) + (r & 1u) * (kPipeListCap / 2) + kPipeGRW * gc);
+        return gi < nbat ? e : make_uint4(kNoCol, kNoCol, kNoCol, kNoCol);
+      };
+      if (!(dbg_in & 64)) {  // (kpop_tune("pipeprio"); the producers: 2)
+        switch ((dbg_in >> 8) & 3) {
+          case 0: __builtin_amdgcn_s_setprio(0); break;
+          case 1: __builtin_amdgcn_s_setprio(1); break;
+          case 2: __builtin_amdgcn_s_setprio(2); break;
+          default: __builtin_amdgcn_s_setprio(3); break;
+        }
+      }
+      if ((dbg & 32) && threadIdx.x == 0) atomicAdd(&g_tile_stamps[13], (unsigned long long)nbat);
+#pragma unroll 1
+      for (uint32_t slab = 0; slab < nslab; ++slab) {
+        const uint32_t col = 64u * slab + 16u * (uint32_t)ni + c16;
+        const double *trow = tv.rows + min(col, tv.d_pad - 1u);
+        f64x4 acc0 = f64x4{0.0, 0.0, 0.0, 0.0}, acc1 = f64x4{0.0, 0.0, 0.0, 0.0};
+        double rs[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, cur = 0.0;
+        uint32_t cur_r = 0, gi = 0;  // the range `cur` is the sum of; the next batch to issue
+        uint32_t rA = range_of(0), rB = range_of(1);
+        uint4 entA = entries_of(0, rA), entB = entries_of(1, rB);
+        double gv[kPipeGRW], gv2[kPipeGRW];
+        auto stash = [&]() {
+#pragma unroll
+          for (uint32_t q = 0; q < 8; ++q) rs[q] = cur_r == q ? cur : rs[q];
+        };
+        auto gather_issue = [&](double (&v)[kPipeGRW], const uint4 &ent) {
+          const uint32_t e[4] = {ent.x, ent.y, ent.z, ent.w};
+#pragma unroll
+          for (int u = 0; u < (int)kPipeGRW; ++u) v[u] = trow[(uint64_t)(e[u] != kNoCol ? e[u] : 0u) << 4];
+        };
+        auto gather_add = [&](const double (&v)[kPipeGRW], const uint4 &ent, uint32_t r) {
+          if (r != cur_r) {  // (uniform: at most seven changes a slab)
+            stash();
+            cur = 0.0;
+            cur_r = r;
+          }
+          const uint32_t e[4] = {ent.x, ent.y, ent.z, ent.w};
+#pragma unroll
+          for (int u = 0; u < (int)kPipeGRW; ++u) cur = __dadd_rn(cur, e[u] != kNoCol ? v[u] : 0.0);
+        };
+        double bs[4][4];
+        uint32_t a0 = 0, a1 = 0;
+        uint4 uqn = make_uint4(0u, 0u, 0u, 0u);
+        auto load_rows = [&](double (&dst)[4], const uint4 u) {
+          dst[0] = trow[(uint64_t)u.x << 4];
+          dst[1] = trow[(uint64_t)u.y << 4];
+          dst[2] = trow[(uint64_t)u.z << 4];
+          dst[3] = trow[(uint64_t)u.w << 4];
+        };
+        if (nb) {
+#pragma unroll
+          for (uint32_t s = 0; s < 3; ++s) load_rows(bs[s], *reinterpret_cast<const uint4 *>(uc + 16u * min(s, nb - 1u)));
+          uqn = *reinterpret_cast<const uint4 *>(uc + 16u * min(3u, nb - 1u));
+          a0 = xa[0];
+          a1 = xa[16u * XW];
+        }
+        asm volatile("; the list's first entries are here" ::"v"(entA.x), "v"(entB.x));
+        auto four_blocks = [&](uint32_t b0, auto with_gather) {
+          constexpr bool WG = decltype(with_gather)::value;
+#pragma unroll
+          for (uint32_t s = 0; s < 4; ++s) {
+            const uint32_t b = b0 + s;
+            if (WG && s == 0 && !(dbg & 4)) gather_issue(gv, entA);
+            if (WG && s == 2 && !(dbg & 4)) gather_issue(gv, entB);
+            load_rows(bs[(s + 3u) & 3u], uqn);  // block b + 3's rows of T
+            uqn = *reinterpret_cast<const uint4 *>(uc + 16u * min(b + 4u, nb - 1u));
+            const uint32_t bx = min(b + 1u, nb - 1u);
+            const uint32_t an0 = xa[4u * bx], an1 = xa[16u * XW + 4u * bx];
+#pragma unroll
+            for (uint32_t j = 0; j < 4 && !(dbg & 1); ++j) {
+              acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(byte_f64w(a0, j), bs[s][j], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(byte_f64w(a1, j), bs[s][j], acc1, 0, 0, 0);
+            }
+            a0 = an0;
+            a1 = an1;
+            if (WG && s == 1 && !(dbg & 4)) {
+              gather_add(gv, entA, rA);
+              rA = range_of(gi + 2);
+              entA = entries_of(gi + 2, rA);
+            }
+            if (WG && s == 3 && !(dbg & 4)) {
+              gather_add(gv, entB, rB);
+              rB = range_of(gi + 3);
+              entB = entries_of(gi + 3, rB);
+              gi += 2;
+            }
+          }
+        };
+        uint32_t b0 = 0;
+        for (; b0 < nb && gi < nbat; b0 += 4) four_blocks(b0, std::true_type{});  // (nb is a multiple of four)
+        for (; b0 < nb; b0 += 4) four_blocks(b0, std::false_type{});
+        // what is left of the lists after the MFMAs' share: two batches in flight
+        if (!(dbg & 4))
+          while (gi < nbat) {
+            gather_issue(gv, entA);
+            gather_issue(gv2, entB);
+            const uint32_t rA2 = range_of(gi + 2), rB2 = range_of(gi + 3);
+            const uint4 nA = entries_of(gi + 2, rA2), nB = entries_of(gi + 3, rB2);
+            gather_add(gv, entA, rA);
+            gather_add(gv2, entB, rB);
+            entA = nA;
+            entB = nB;
+            rA = rA2;
+            rB = rB2;
+            gi += 2;
+          }
+        stash();
+        // the sums: (the set's rows on the matrix cores) + (the residual rows), straight from the registers -- rows g4 + 4 rr of tile t
+        if (col < tv.n_dims) {
+#pragma unroll
+          for (uint32_t rr = 0; rr < 4; ++rr) {
+            const uint64_t sl0 = s_slot[buf][32u * (uint32_t)mh + g4 + 4u * rr], sl1 = s_slot[buf][32u * (uint32_t)mh + 16u + g4 + 4u * rr];
+            if (sl0 != ~0ull) partial[sl0 * tv.n_dims + col] = __dadd_rn(acc0[rr], rs[rr]);
+            if (sl1 != ~0ull) partial[sl1 * tv.n_dims + col] = __dadd_rn(acc1[rr], rs[4u + rr]);
+          }
+        }
+      }
+      stamp(9);  // the matrix cores and the gather, every slab
+      pipe_lds_fence();  // (done reading this buffer's X, rows and slots)
+      if (lane == 0) __hip_atomic_fetch_add(&s_empty2[mh], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      ++n_conw;
+      stamp(10);
+    }
+    if (stamps)
+      for (int i = 8; i < 13; ++i) atomicAdd(&g_tile_stamps[i], s_stamp[i]);
+    return;
+  }
   const double *trow = tv.rows + min(16u * (uint32_t)ni + c16, tv.d_pad - 1);  // (columns past the twister's are not written below)
   const double *grow = tv.rows + min((uint32_t)lane, tv.n_dims - 1);
   uint32_t n_con = 0, cbar_t = 0;

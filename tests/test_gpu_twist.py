@@ -660,6 +660,148 @@ def test_assemblies_of_one_organism_through_the_tile_kernel(kpop, oracle, k, d, 
         # (at 10 % fewer than a third of the windows survive: tile_group_probe_kernel leaves the groups to the streaming kernel)
 
 
+def _one_organism(rng, n, L, rate, unrelated=8, indel_every=7):
+    """n mutants of one random L-base sequence (substitutions at `rate`, a few Ns, deletions, ragged ends) + a few strangers and short reads"""
+    ref = rng.choice(list("ACGT"), size=L)
+    seqs = []
+    for i in range(n):
+        m = ref.copy()
+        hit = rng.rand(len(m)) < rate
+        m[hit] = rng.choice(list("ACGTN"), size=int(hit.sum()), p=[.24, .24, .24, .24, .04])
+        if indel_every and i % indel_every == 0:
+            cut = int(rng.randint(100, L - 1000))
+            m = np.concatenate([m[:cut], m[cut + 5:]])
+        if i % 31 == 5:
+            m[1000:1700] = "N"
+        seqs.append("".join(m[: len(m) - int(rng.randint(0, 900))]))
+    seqs += ["".join(rng.choice(list("ACGT"), size=int(rng.randint(3000, 5000)))) for _ in range(unrelated)]
+    seqs += ["ACGTTGCA" * 10, "", "ACG", "A" * 2000] + ["".join(rng.choice(list("ACGT"), size=150)) for _ in range(20)]
+    order = rng.permutation(len(seqs))
+    return [seqs[i] for i in order[:20]] + seqs[:n] + [seqs[i] for i in order[20:] if i >= n]
+
+
+@pytest.mark.parametrize("k,d,rate", [(12, 256, 0.003), (10, 1635, 0.002), (11, 100, 0.01), (12, 72, 0.03), (13, 130, 0.001), (9, 65, 0.003)])
+def test_assemblies_through_more_than_64_dimensions(kpop, oracle, k, d, rate):
+    """beyond 64 dimensions the pipelined tile kernel takes the twister's columns in slabs of 64 (tile_pipe.h, WIDE): the same X of a
+    chunk against slab after slab of the members' rows, every consumer wavefront gathering the residual rows of the sequences it
+    multiplies for its own 16 columns -- at the reference's own 1,635 dimensions (README.md:1029), at 256, at widths that end inside
+    a slab (100, 72, 130) and one column past a slab (65): against the oracle, against the streaming kernel, the same bits twice,
+    and against round 4's kernel (phases one after the other, the residual rows in a launch of their own).  lib/Twister.ml:146-188"""
+    from kpop_amd import api
+    rng = np.random.RandomState(1000 * k + d)
+    seqs = _one_organism(rng, 150, 7000, rate)
+    bases, offs = concat(seqs)
+    h, c, o = oracle.count_reads(bases, offs, k)
+    cols = np.unique(h)
+    cols = cols[rng.rand(len(cols)) < 0.95]
+    T = oracle.synth_twister(3, d, cols)
+    tw = kpop.Twister.load(T, cols, k)
+    for normalize in (True, False):
+        want = oracle.twist(T, cols, h, c.astype(np.float64), o, normalize=normalize)
+        got = tw.count_twist(bases, offs, normalize=normalize)
+        again = tw.count_twist(bases, offs, normalize=normalize)
+        api.tune("dense", 0)
+        try:
+            ref_rows = tw.count_twist(bases, offs, normalize=normalize)
+        finally:
+            api.tune("dense", 2)
+        scale = max(np.max(np.abs(want)), 1.0)
+        assert np.max(np.abs(ref_rows - want)) <= 1e-12 * scale
+        assert np.max(np.abs(got - want)) <= 1e-12 * scale, np.max(np.abs(got - want))
+        assert np.array_equal(got, again)
+        assert not np.array_equal(got, ref_rows)  # (another order of additions: the tile kernel did run)
+    api.tune("tilepipe", 0)
+    try:
+        r4 = tw.count_twist(bases, offs, normalize=False)
+    finally:
+        api.tune("tilepipe", 1)
+    assert np.max(np.abs(r4 - got)) <= 1e-12 * scale
+    tw.free()
+
+
+@pytest.mark.parametrize("k,d,rate", [(12, 64, 0.002), (10, 40, 0.01), (12, 64, 0.03)])
+def test_the_slab_by_slab_kernel_at_up_to_64_dimensions_gives_the_other_kernels_bits(kpop, oracle, k, d, rate):
+    """kpop_tune("tilewide", 1) sends a twister of up to 64 dimensions through the slab-by-slab consumers (one slab): the members'
+    rows are multiplied in the same order and a sequence's residual rows added in the same (window) order, so the rows must equal
+    the exchanging kernel's bit for bit -- the lists filed by lane group, the padding, the ranges and the sums leaving from the
+    accumulators' registers all have to be right for that."""
+    from kpop_amd import api
+    rng = np.random.RandomState(k * d)
+    seqs = _one_organism(rng, 200, 9000, rate)
+    bases, offs = concat(seqs)
+    h, c, o = oracle.count_reads(bases, offs, k)
+    cols = np.unique(h)
+    cols = cols[rng.rand(len(cols)) < 0.95]
+    T = oracle.synth_twister(5, d, cols)
+    tw = kpop.Twister.load(T, cols, k)
+    narrow = tw.count_twist(bases, offs)
+    api.tune("tilewide", 1)
+    try:
+        wide = tw.count_twist(bases, offs)
+    finally:
+        api.tune("tilewide", 0)
+    want = oracle.twist(T, cols, h, c.astype(np.float64), o)
+    assert np.max(np.abs(narrow - want)) <= 1e-12 * max(np.max(np.abs(want)), 1.0)
+    assert np.array_equal(narrow, wide)
+    tw.free()
+
+
+def test_a_batch_past_the_tile_routes_bound_goes_through_in_sub_batches(kpop, oracle):
+    """9,000 assemblies of 6 kb through 72 dimensions with the bound on the route's per-slot tables lowered to 40 MiB
+    (kpop_tune("tilecap_mb")): two sub-batches of sequences, each a call of its own -- rows against the streaming kernel's, a
+    sample against the oracle, the same bits twice"""
+    import torch
+    from kpop_amd import api
+    k, d, n, L = 11, 72, 9000, 6000
+    dev = torch.device("cuda", 0)
+    sp = torch.cuda.current_stream().cuda_stream
+    tw = kpop.Twister.synth(0x51AB, k, d)
+    ref = torch.empty(L, dtype=torch.uint8, device=dev)
+    ro = torch.empty(2, dtype=torch.int64, device=dev)
+    api.dev_synth_reads(0xBEEF, 1, L, ref.data_ptr(), ro.data_ptr(), stream=sp)
+    torch.cuda.synchronize()
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    hit = torch.rand(n * L, device=dev, generator=g) < 0.004
+    bases = torch.where(hit, acgt[torch.randint(0, 4, (n * L,), device=dev, generator=g)], ref.repeat(n))
+    offs = torch.arange(n + 1, dtype=torch.int64, device=dev) * L
+    out = torch.zeros(n, d, dtype=torch.float64, device=dev)
+
+    def run():
+        out.fill_(float("nan"))
+        api.dev_count_twist(tw, bases.data_ptr(), offs.data_ptr(), n, n * L, L, out.data_ptr(), stream=sp)
+        torch.cuda.synchronize()
+        return out.clone()
+
+    whole = run()
+    api.tune("tilecap_mb", 40)
+    try:
+        split, split2 = run(), run()
+    finally:
+        api.tune("tilecap_mb", 0)
+    api.tune("dense", 0)
+    try:
+        stream_rows = run()
+    finally:
+        api.tune("dense", 2)
+    assert torch.equal(split, split2)
+    assert not torch.equal(whole, stream_rows)
+    scale = float(stream_rows.abs().max())
+    assert float((whole - stream_rows).abs().max()) <= 1e-12 * scale
+    assert float((split - stream_rows).abs().max()) <= 1e-12 * scale
+    m = (40 << 20) // ((L // 512 + 2) * (d * 8 + 16))  # sequences a sub-batch (count_twist.hip)
+    assert 4096 <= m < n and not torch.equal(split, whole)  # (other groups share a consensus set: another order of additions)
+    pick = [0, 1, m - 1, m, m + 1, n - 1]
+    sb = np.concatenate([bases[r * L:(r + 1) * L].cpu().numpy() for r in pick])
+    so = np.arange(len(pick) + 1, dtype=np.uint64) * L
+    h, c, o = oracle.count_reads(sb, so, k)
+    cols = np.unique(h)
+    want = oracle.twist(oracle.synth_twister(0x51AB, d, cols), cols, h, c.astype(np.float64), o)
+    np.testing.assert_allclose(split.cpu().numpy()[pick], want, rtol=1e-12, atol=1e-15)
+    tw.free()
+
+
 def test_assemblies_with_low_complexity_runs_and_shifted_copies(kpop, oracle):
     """what the pipelined tile kernel (tile_pipe.h, up to 64 dimensions) leaves to the streaming kernel or takes the slow way:
     stretches in which one k-mer occurs more than 255 times (a poly-A of 400, an (AT)n of 500, in every mutant: the one-byte
@@ -841,15 +983,15 @@ def test_count_twist_with_the_rows_at_their_hashes(kpop, oracle, d):
         api.tune("direct", 2)
 
 
-@pytest.mark.parametrize("rate", [0.003, 0.01])
-def test_many_chunks_a_block_give_the_same_bits_every_call(kpop, oracle, rate):
+@pytest.mark.parametrize("rate,d", [(0.003, 64), (0.01, 64), (0.003, 256)])
+def test_many_chunks_a_block_give_the_same_bits_every_call(kpop, oracle, rate, d):
     """8,000 assemblies of one 30 kb organism through the pipelined tile kernel, five calls: every block works through some thirty
     chunks with its producers two chunks ahead of its consumers and the consumers' halves out of step -- where a hand-over that
     is wrong shows (one was: the release counter of round 5's first barriers by half) -- and the bits must be the same every
     time; a sample of rows against the oracle."""
     import torch
     from kpop_amd import api
-    k, d, n, L = 12, 64, 8000, 30000
+    k, n, L = 12, 8000, 30000
     dev = torch.device("cuda", 0)
     sp = torch.cuda.current_stream().cuda_stream
     tw = kpop.Twister.synth(0x7457, k, d)
