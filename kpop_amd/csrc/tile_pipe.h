@@ -36,7 +36,7 @@ constexpr uint32_t kPipeListCap = 8 * kTileS;    // entries of a producer wavefr
 // miss the set are hashed again one by one, not all 64 of a thread.
 constexpr uint32_t kPipeUnits = 33, kPipeRowW = 85;  // dwords of a row: F at 0, R at 33, V at 66; 85 = 21 mod 32: four rows x eight threads' dwords on 32 banks
 constexpr uint32_t kPipeMissLds = 192;  // entries of a producer wavefront's list of missed hashes that stay in LDS until their rows are found (beyond: global)
-constexpr uint32_t kPipeGRW = 4;        // WIDE: residual rows of a lane group in flight a batch (one 16-byte load of entries)
+constexpr int kPipeGRW = 16;            // WIDE: residual rows a producer wavefront has in flight (16 bytes a lane each: 16 KB a wavefront)
 constexpr uint32_t kPipePrioList = 300;  // a consumer wavefront with more residual rows than this to gather goes ahead of the producers (s_setprio)
 constexpr size_t kPipeLdsBytes = (size_t)2 * kPipeG * kPipeXW * 4 + (size_t)kTileH * 8 + (size_t)2 * kTileSetCap * 4 + (size_t)kPipeG * kPipeRowW * 4 +
                                  (size_t)8 * kPipeMissLds * 4;
@@ -66,13 +66,16 @@ __device__ __forceinline__ void pipe_half_barrier(uint32_t *ctr, uint32_t &targe
 }
 
 // WIDE (more than 64 dimensions): the consumers take the twister's columns in SLABS of 64 -- the same X against slab after slab of the
-// members' rows, the chunk's buffer released after the last -- and every consumer wavefront is on its own: it gathers the residual rows
-// of the 32 sequences it multiplies, for its own 16 columns (a lane group of 16 takes the sequences whose rows of the accumulator tile it
-// holds: sequence g + 4 r + 16 t of the half, 128 bytes of a residual row a load), so its sums leave straight from its registers
-// to `partial` -- no exchange through X's room (X is still needed), no barrier among the consumers.  The producers then file the
-// residual rows by (sequence of the wavefront's eight) in fixed rooms of the list, padded to whole batches with kNoCol, as offsets in
-// 128-byte units like the members' (see step 5), and the chunks are dealt so that the blocks of one XCD work on the SAME stretch at a
-// time: at 256 dimensions a stretch's members are 1.5 MB of rows (10 MB at 1,635) -- one stretch an L2, not eight.
+// members' rows, the chunk's buffer released after the last -- and the work changes hands: a chunk's MFMAs are D / 64 times the 64-dimension
+// kernel's while its preparation is what it was, so the PRODUCERS wait most of the time (0.8 of it at 256 dimensions, 0.97 at 1,635) and the
+// residual rows -- 2.3 MB a chunk from HBM at 256 dimensions and 0.3 % divergence, every load a DRAM round trip -- are theirs to gather:
+// sixteen 16-byte row loads in flight a producer wavefront (its own eight sequences, lane = two columns, 128 columns a pass), the sums
+// written to the sequences' slots of `partial` BEFORE the chunk is handed over.  A consumer wavefront then only multiplies; its sums leave
+// straight from the accumulators' registers, added to what the producers left in `partial` (read back through L2 at the slab's start).
+// (First form, measured: the consumers gathered for their own 16 columns under their MFMAs -- the loads' counter is one and in order, so
+// every four blocks of MFMAs waited for an HBM round trip: 0.22 of the matrix peak at 256 and at 1,635 dimensions.)
+// The chunks are dealt so that the blocks of one XCD work on the SAME stretch at a time: at 256 dimensions a stretch's members are
+// 1.5 MB of rows (10 MB at 1,635) -- one stretch an L2, not eight.
 template <bool ABLATE, bool WIDE = false>  // (ABLATE: the timing switches of kpop_tune("dbg", (1 | 2 | 4 | 8) << 24) are compiled in -- results are wrong under them)
 __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
     TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int content,
@@ -91,7 +94,6 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
   __shared__ uint64_t s_slot[2][G];   // the group's (sequence, segment) slots, ~0: the sequence has no such segment
   __shared__ uint32_t s_rtot[2][8];   // entries of every producer wavefront's residual list (row | sequence of its eight << 29)
   __shared__ uint32_t s_U[2];         // members as multiplied (padded to 64)
-  __shared__ uint32_t s_rmax[2][8][2];  // WIDE: entries (a multiple of kPipeGRW, padding included) of the longest of the four lists in either room of a producer wavefront's
   __shared__ uint32_t s_pbar, s_cbar4[2], s_full, s_empty2[2], s_done;  // (s_empty2: chunks released, counted per HALF of the consumers -- the halves are not in step any more, and one counter let a half that was two chunks ahead stand in for the other)
   __shared__ uint32_t s_new, s_samp, s_over, s_add[4], s_wbase[8];
   __shared__ uint32_t s_ref[kPipeRowW];    // the set's REFERENCE: the staged stretch of the primary seed it was built from ...
@@ -679,9 +681,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
           if (lane >= o) incl += up;
         }
         const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        // (WIDE: the list's own room, then as much again for the hashes that do not fit the LDS -- the rows are not written in place there)
-        uint32_t *wl = lists + (((uint64_t)blockIdx.x * 2 + buf) * 8 + pw) * (WIDE ? 2 * kPipeListCap : kPipeListCap);
-        uint32_t *wh = WIDE ? wl + kPipeListCap : wl;
+        uint32_t *wl = lists + (((uint64_t)blockIdx.x * 2 + buf) * 8 + pw) * kPipeListCap;
         uint32_t present = 0;  // entries that have a row, of MY sequence (lanes of a sequence all count it)
 #pragma unroll
         for (int o = 4; o > 0; o >>= 1) found += (uint32_t)__shfl_xor((int)found, o, 8);
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
               const uint32_t i = (uint32_t)__ffsll((long long)mm) - 1u;
               mm &= mm - 1ull;
               const uint32_t h = hash_at(64u * tq + i);
-              if (pos < kPipeMissLds) ml[pos] = h; else wh[pos] = h;
+              if (pos < kPipeMissLds) ml[pos] = h; else wl[pos] = h;
               ++pos;
             }
           }
@@ -709,13 +709,9 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
           uint32_t sbeg[8];  // where every sequence's entries begin (scalars)
 #pragma unroll
           for (int j = 0; j < 8; ++j) sbeg[j] = (uint32_t)__builtin_amdgcn_readlane((int)(incl - rcnt), 8 * j);
-          // WIDE: sequence j of the wavefront's eight is lane group j & 3's of the consumers (the rows g + 4 r of an accumulator tile are
-          // sequences g + 4 r + 16 t of a half), in room j >> 2: its entries go to [room][lane group][place among the sequence's own], the row's
-          // offset in the twister in 128-byte units.  A consumer's lane group reads its four entries of a batch with one 16-byte load.
-          uint32_t cb[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // entries with a row so far, a sequence (scalars)
           for (uint32_t p0 = 0; p0 < wtot; p0 += 64) {
             const uint32_t e = p0 + (uint32_t)lane;
-            const uint32_t h = e >= wtot ? 0u : e < kPipeMissLds ? ml[e] : __hip_atomic_load(wh + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t h = e >= wtot ? 0u : e < kPipeMissLds ? ml[e] : __hip_atomic_load(wl + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const uint4 q = *reinterpret_cast<const uint4 *>(tv.rsel + (h >> 6));
             const uint32_t row = e < wtot ? row_of(q, h) : kNoCol;
             uint32_t tag = 0;
@@ -723,37 +719,61 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
             for (int j = 1; j < 8; ++j) tag += e >= sbeg[j] ? 1u : 0u;
             const bool has = row != kNoCol;
             const uint64_t pm = __ballot(has);
-            if (!WIDE && has) wl[wout + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = row | (tag << 29);
+            if (has) wl[wout + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = row | (tag << 29);
             wout += (uint32_t)__popcll(pm);
-            uint32_t place = 0;
 #pragma unroll
             for (uint32_t j = 0; j < 8; ++j) {
-              const uint64_t bj = __ballot(has && tag == j);
-              const uint32_t n = (uint32_t)__popcll(bj);
+              const uint32_t n = (uint32_t)__popcll(__ballot(has && tag == j));
               present += ((uint32_t)lane >> 3) == j ? n : 0u;
-              if (WIDE) {
-                place = tag == j ? cb[j] + (uint32_t)__popcll(bj & ((1ull << lane) - 1ull)) : place;
-                cb[j] += n;
-              }
             }
-            if (WIDE && has) wl[(tag >> 2) * (kPipeListCap / 2) + (tag & 3u) * kTileS + place] = row * rowq;
           }
           found += present;
         }
-        if (WIDE) {
-          // every list of a room padded with kNoCol to the room's longest, that rounded up to whole batches
-          uint32_t mx[2] = {0u, 0u};
+        if constexpr (WIDE) {
+          // The residual rows of the wavefront's eight sequences, gathered HERE: every sequence's rows added in list (= window) order, lane =
+          // two columns of a pass of 128, sixteen rows in flight; the sums -- zeros for a sequence without entries -- go to the sequence's
+          // slot of `partial`, where the consumers add theirs.  (Up to 64 dimensions the consumers gather: there the producers are the launch.)
+          if (wout) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the list is read back by other lanes than wrote it)
+          stamp(5);  // the misses' rows found
+          const uint32_t npass = (tv.d_pad + 127u) >> 7;
+          uint32_t beg = 0;
+#pragma unroll 1
+          for (int j = 0; j < 8; ++j) {
+            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)present, 8 * j);
+            const uint64_t slj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_slot >> 32), 8 * j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_slot, 8 * j);
+            if (slj != ~0ull) {  // (uniform)
+#pragma unroll 1
+              for (uint32_t p = 0; p < npass; ++p) {
+                const uint32_t col = 128u * p + 2u * (uint32_t)lane;
+                const double *gcol = tv.rows + min(col, tv.d_pad - 2u);  // (d_pad is a multiple of 16: a pair of columns is inside or outside)
+                double c0 = 0.0, c1 = 0.0;
+#pragma unroll 1
+                for (uint32_t e0 = 0; e0 < cnt; e0 += (uint32_t)kPipeGRW) {
+                  const uint32_t nu = min((uint32_t)kPipeGRW, cnt - e0);
+                  const uint32_t ent = __hip_atomic_load(wl + min(beg + e0 + ((uint32_t)lane & (uint32_t)(kPipeGRW - 1)), kPipeListCap - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  double2 v[kPipeGRW];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) mx[j >> 2] = max(mx[j >> 2], (uint32_t)__builtin_amdgcn_readlane((int)present, 8 * j));
-          mx[0] = (mx[0] + kPipeGRW - 1u) & ~(kPipeGRW - 1u);
-          mx[1] = (mx[1] + kPipeGRW - 1u) & ~(kPipeGRW - 1u);
-          const uint32_t j = (uint32_t)lane >> 3;
-          uint32_t *room = wl + (j >> 2) * (kPipeListCap / 2) + (j & 3u) * kTileS;
-          for (uint32_t e = present + tq; e < mx[j >> 2]; e += 8u) room[e] = kNoCol;
-          if (lane == 0) {
-            s_rmax[buf][pw][0] = mx[0];
-            s_rmax[buf][pw][1] = mx[1];
+                  for (int u = 0; u < kPipeGRW; ++u) {
+                    const uint32_t rw = (uint32_t)__builtin_amdgcn_readlane((int)ent, u) & 0x1FFFFFFFu;
+                    v[u] = *reinterpret_cast<const double2 *>(gcol + (uint64_t)((uint32_t)u < nu ? rw : 0u) * tv.d_pad);
+                  }
+#pragma unroll
+                  for (int u = 0; u < kPipeGRW; ++u) {
+                    const bool ok = (uint32_t)u < nu;  // (uniform)
+                    c0 = __dadd_rn(c0, ok ? v[u].x : 0.0);
+                    c1 = __dadd_rn(c1, ok ? v[u].y : 0.0);
+                  }
+                }
+                if (!(dbg & 4)) {
+                  double *dst = partial + slj * tv.n_dims + col;
+                  if (col < tv.n_dims) dst[0] = c0;
+                  if (col + 1u < tv.n_dims) dst[1] = c1;
+                }
+              }
+            }
+            beg += cnt;
           }
+          stamp(12);  // the residual rows gathered (WIDE)
         }
         if (tq == 0) {
           s_slot[buf][sq] = my_slot;
@@ -792,7 +812,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
   const int ni = (int)(cw & 3u), mh = (int)(cw >> 2);  // 16 dimensions, 32 sequences (wavefronts cw and cw + 4 share a SIMD and their rows of T)
   const uint32_t g4 = (uint32_t)lane >> 4, c16 = (uint32_t)lane & 15u;
   if constexpr (WIDE) {
-    // ------------------------------------------------------------------- the consumers of more than 64 dimensions
+    // ------------------------------------------------------------------- the consumers of more than 64 dimensions: they only multiply
     const uint32_t nslab = (tv.d_pad + 63u) >> 6;
     uint32_t n_conw = 0;
     // byte j of w as a double (see below)
@@ -800,6 +820,14 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
       const uint64_t bits = 0x4330000000000000ull | (uint64_t)((w >> (8u * j)) & 0xFFu);
       return __longlong_as_double((long long)bits) - 4503599627370496.0;
     };
+    if (!(dbg_in & 64)) {  // (kpop_tune("pipeprio"); the producers: 2)
+      switch ((dbg_in >> 8) & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+      }
+    }
     for (;;) {
       bool got = false;
       for (;;) {
@@ -820,70 +848,20 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
       const uint32_t UP = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_U[buf]), nb = UP / 16u;
       const uint32_t *uc = ucol + buf * kTileSetCap + 4u * g4;
       const uint32_t *xa = Xw + buf * G * XW + (32u * (uint32_t)mh + c16) * XW + g4;
-      // The residual rows of my half's 32 sequences: eight RANGES (producer wavefront 4 mh + (r >> 1), room r & 1), each as long as the
-      // longest of its four lists; lane group g4 walks list g4 of every range -- sequence 8 (r >> 1) + g4 + 4 (r & 1) of the half, which is
-      // row g4 + 4 (r & 3) of accumulator tile r >> 2: range r's sum belongs to acc[r >> 2][r & 3].  Batches of kPipeGRW entries, numbered
-      // through the ranges (cum[r]: the batches before range r).
-      uint32_t cum[9];
-      cum[0] = 0;
+      // the slots of the eight sequences whose sums this lane holds: rows g4 + 4 rr of accumulator tile t = sequence 16 t + g4 + 4 rr of the half
+      uint64_t sl[8];
 #pragma unroll
-      for (uint32_t r = 0; r < 8; ++r)
-        cum[r + 1] = cum[r] + (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rmax[buf][4u * (uint32_t)mh + (r >> 1)][r & 1u]) / kPipeGRW;
-      const uint32_t nbat = cum[8];
-      const uint32_t *lbase = lists + (((uint64_t)blockIdx.x * 2 + buf) * 8 + 4u * (uint32_t)mh) * (2 * kPipeListCap) + g4 * kTileS;
-      // batch gi: its range, its four entries of my lane group (all kNoCol past the last batch)
-      auto range_of = [&](uint32_t gi) -> uint32_t {
-        uint32_t r = 0;
-#pragma unroll
-        for (uint32_t q = 1; q < 8; ++q) r += gi >= cum[q] ? 1u : 0u;
-        return r;
-      };
-      auto entries_of = [&](uint32_t gi, uint32_t r) -> uint4 {
-        uint32_t before = 0;
-#pragma unroll
-        for (uint32_t q = 1; q < 8; ++q) before = r == q ? cum[q] : before;
-        const uint32_t gc = gi < nbat ? gi - before : 0u;
-        const uint4 e = *reinterpret_cast<const uint4 *>(lbase + (uint64_t)(r >> 1) * (2 * kPipeListCap) + (r & 1u) * (kPipeListCap / 2) + kPipeGRW * gc);
-        return gi < nbat ? e : make_uint4(kNoCol, kNoCol, kNoCol, kNoCol);
-      };
-      if (!(dbg_in & 64)) {  // (kpop_tune("pipeprio"); the producers: 2)
-        switch ((dbg_in >> 8) & 3) {
-          case 0: __builtin_amdgcn_s_setprio(0); break;
-          case 1: __builtin_amdgcn_s_setprio(1); break;
-          case 2: __builtin_amdgcn_s_setprio(2); break;
-          default: __builtin_amdgcn_s_setprio(3); break;
-        }
-      }
-      if ((dbg & 32) && threadIdx.x == 0) atomicAdd(&g_tile_stamps[13], (unsigned long long)nbat);
+      for (uint32_t q = 0; q < 8; ++q) sl[q] = s_slot[buf][32u * (uint32_t)mh + 16u * (q >> 2) + g4 + 4u * (q & 3u)];
 #pragma unroll 1
       for (uint32_t slab = 0; slab < nslab; ++slab) {
         const uint32_t col = 64u * slab + 16u * (uint32_t)ni + c16;
+        const bool colok = col < tv.n_dims;
         const double *trow = tv.rows + min(col, tv.d_pad - 1u);
         f64x4 acc0 = f64x4{0.0, 0.0, 0.0, 0.0}, acc1 = f64x4{0.0, 0.0, 0.0, 0.0};
-        double rs[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, cur = 0.0;
-        uint32_t cur_r = 0, gi = 0;  // the range `cur` is the sum of; the next batch to issue
-        uint32_t rA = range_of(0), rB = range_of(1);
-        uint4 entA = entries_of(0, rA), entB = entries_of(1, rB);
-        double gv[kPipeGRW], gv2[kPipeGRW];
-        auto stash = [&]() {
+        // what the producers left in the slots: the sequences' residual rows, summed (asked for now, added after the slab's MFMAs)
+        double rs[8];
 #pragma unroll
-          for (uint32_t q = 0; q < 8; ++q) rs[q] = cur_r == q ? cur : rs[q];
-        };
-        auto gather_issue = [&](double (&v)[kPipeGRW], const uint4 &ent) {
-          const uint32_t e[4] = {ent.x, ent.y, ent.z, ent.w};
-#pragma unroll
-          for (int u = 0; u < (int)kPipeGRW; ++u) v[u] = trow[(uint64_t)(e[u] != kNoCol ? e[u] : 0u) << 4];
-        };
-        auto gather_add = [&](const double (&v)[kPipeGRW], const uint4 &ent, uint32_t r) {
-          if (r != cur_r) {  // (uniform: at most seven changes a slab)
-            stash();
-            cur = 0.0;
-            cur_r = r;
-          }
-          const uint32_t e[4] = {ent.x, ent.y, ent.z, ent.w};
-#pragma unroll
-          for (int u = 0; u < (int)kPipeGRW; ++u) cur = __dadd_rn(cur, e[u] != kNoCol ? v[u] : 0.0);
-        };
+        for (uint32_t q = 0; q < 8; ++q) rs[q] = (colok && sl[q] != ~0ull) ? partial[sl[q] * tv.n_dims + col] : 0.0;
         double bs[4][4];
         uint32_t a0 = 0, a1 = 0;
         uint4 uqn = make_uint4(0u, 0u, 0u, 0u);
@@ -900,14 +878,11 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
           a0 = xa[0];
           a1 = xa[16u * XW];
         }
-        asm volatile("; the list's first entries are here" ::"v"(entA.x), "v"(entB.x));
-        auto four_blocks = [&](uint32_t b0, auto with_gather) {
-          constexpr bool WG = decltype(with_gather)::value;
+#pragma unroll 1
+        for (uint32_t b0 = 0; b0 < nb; b0 += 4) {  // (nb is a multiple of four; no branch inside the four blocks: see below)
 #pragma unroll
           for (uint32_t s = 0; s < 4; ++s) {
             const uint32_t b = b0 + s;
-            if (WG && s == 0 && !(dbg & 4)) gather_issue(gv, entA);
-            if (WG && s == 2 && !(dbg & 4)) gather_issue(gv, entB);
             load_rows(bs[(s + 3u) & 3u], uqn);  // block b + 3's rows of T
             uqn = *reinterpret_cast<const uint4 *>(uc + 16u * min(b + 4u, nb - 1u));
             const uint32_t bx = min(b + 1u, nb - 1u);
@@ -919,49 +894,18 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
             }
             a0 = an0;
             a1 = an1;
-            if (WG && s == 1 && !(dbg & 4)) {
-              gather_add(gv, entA, rA);
-              rA = range_of(gi + 2);
-              entA = entries_of(gi + 2, rA);
-            }
-            if (WG && s == 3 && !(dbg & 4)) {
-              gather_add(gv, entB, rB);
-              rB = range_of(gi + 3);
-              entB = entries_of(gi + 3, rB);
-              gi += 2;
-            }
           }
-        };
-        uint32_t b0 = 0;
-        for (; b0 < nb && gi < nbat; b0 += 4) four_blocks(b0, std::true_type{});  // (nb is a multiple of four)
-        for (; b0 < nb; b0 += 4) four_blocks(b0, std::false_type{});
-        // what is left of the lists after the MFMAs' share: two batches in flight
-        if (!(dbg & 4))
-          while (gi < nbat) {
-            gather_issue(gv, entA);
-            gather_issue(gv2, entB);
-            const uint32_t rA2 = range_of(gi + 2), rB2 = range_of(gi + 3);
-            const uint4 nA = entries_of(gi + 2, rA2), nB = entries_of(gi + 3, rB2);
-            gather_add(gv, entA, rA);
-            gather_add(gv2, entB, rB);
-            entA = nA;
-            entB = nB;
-            rA = rA2;
-            rB = rB2;
-            gi += 2;
-          }
-        stash();
-        // the sums: (the set's rows on the matrix cores) + (the residual rows), straight from the registers -- rows g4 + 4 rr of tile t
-        if (col < tv.n_dims) {
+        }
+        // the sums: (the set's rows on the matrix cores) + (the residual rows), straight from the registers
+        if (colok) {
 #pragma unroll
           for (uint32_t rr = 0; rr < 4; ++rr) {
-            const uint64_t sl0 = s_slot[buf][32u * (uint32_t)mh + g4 + 4u * rr], sl1 = s_slot[buf][32u * (uint32_t)mh + 16u + g4 + 4u * rr];
-            if (sl0 != ~0ull) partial[sl0 * tv.n_dims + col] = __dadd_rn(acc0[rr], rs[rr]);
-            if (sl1 != ~0ull) partial[sl1 * tv.n_dims + col] = __dadd_rn(acc1[rr], rs[4u + rr]);
+            if (sl[rr] != ~0ull) partial[sl[rr] * tv.n_dims + col] = __dadd_rn(acc0[rr], rs[rr]);
+            if (sl[4u + rr] != ~0ull) partial[sl[4u + rr] * tv.n_dims + col] = __dadd_rn(acc1[rr], rs[4u + rr]);
           }
         }
       }
-      stamp(9);  // the matrix cores and the gather, every slab
+      stamp(9);  // the matrix cores, every slab
       pipe_lds_fence();  // (done reading this buffer's X, rows and slots)
       if (lane == 0) __hip_atomic_fetch_add(&s_empty2[mh], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       ++n_conw;
