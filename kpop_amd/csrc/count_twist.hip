@@ -1891,7 +1891,7 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
         once_pipe() = true;
       }
       const uint32_t pblocks = (uint32_t)std::min<uint64_t>((uint64_t)div_up(max_long, kPipeG) * max_seg, (uint64_t)cx.n_cus);
-      const int tdbg = ((ctx().tune_dbg >> 24) & 255) | (ctx().tune_pipeprio << 8);
+      const int tdbg = ((ctx().tune_dbg >> 24) & 127) | ((ctx().tune_pipeprio & 3) << 8) | ((ctx().tune_pipeprio & 4) ? 128 : 0);  // (bit 7: the producers' gather with plain loads)
 #define KPOP_PIPE(A, W) count_twist_tile_pipe_kernel<A, W><<<dim3(pblocks), dim3(1024), kPipeLdsBytes, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, olong, sums2 + nb, gmax, grel, max_seg, slot_done, wave_lists, tdbg)
       // (the ablation switches: a build of the kernel of their own, so that the product's loops carry no test of them;
       //  kpop_tune("tilewide", 1): the slab-by-slab kernel at any number of dimensions -- at up to 64 the same bits as the other)

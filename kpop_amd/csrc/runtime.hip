@@ -190,7 +190,7 @@ extern "C" int kpop_tune(const char *key, int value) {
     else if (!strcmp(key, "tilepipe") && (value == 0 || value == 1)) c.tune_tilepipe = value;
     else if (!strcmp(key, "tilewide") && (value == 0 || value == 1)) c.tune_tilewide = value;
     else if (!strcmp(key, "tilecap_mb") && value >= 0) c.tune_tilecap_mb = value;
-    else if (!strcmp(key, "pipeprio") && value >= 0 && value <= 3) c.tune_pipeprio = value;
+    else if (!strcmp(key, "pipeprio") && value >= 0 && value <= 7) c.tune_pipeprio = value;
     else if (!strcmp(key, "blocksort") && (value == 0 || value == 1)) c.tune_blocksort = value;
     else if (!strcmp(key, "ldspad") && value >= 0 && value <= 65536) c.tune_ldspad = value;
     else if (!strcmp(key, "hist") && (value == 0 || value == 1)) c.tune_hist = value;

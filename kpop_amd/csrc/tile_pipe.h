@@ -36,7 +36,6 @@ constexpr uint32_t kPipeListCap = 8 * kTileS;    // entries of a producer wavefr
 // miss the set are hashed again one by one, not all 64 of a thread.
 constexpr uint32_t kPipeUnits = 33, kPipeRowW = 85;  // dwords of a row: F at 0, R at 33, V at 66; 85 = 21 mod 32: four rows x eight threads' dwords on 32 banks
 constexpr uint32_t kPipeMissLds = 192;  // entries of a producer wavefront's list of missed hashes that stay in LDS until their rows are found (beyond: global)
-constexpr int kPipeGRW = 16;            // WIDE: residual rows a producer wavefront has in flight (16 bytes a lane each: 16 KB a wavefront)
 constexpr uint32_t kPipePrioList = 300;  // a consumer wavefront with more residual rows than this to gather goes ahead of the producers (s_setprio)
 constexpr size_t kPipeLdsBytes = (size_t)2 * kPipeG * kPipeXW * 4 + (size_t)kTileH * 8 + (size_t)2 * kTileSetCap * 4 + (size_t)kPipeG * kPipeRowW * 4 +
                                  (size_t)8 * kPipeMissLds * 4;
@@ -731,48 +730,130 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
         }
         if constexpr (WIDE) {
           // The residual rows of the wavefront's eight sequences, gathered HERE: every sequence's rows added in list (= window) order, lane =
-          // two columns of a pass of 128, sixteen rows in flight; the sums -- zeros for a sequence without entries -- go to the sequence's
-          // slot of `partial`, where the consumers add theirs.  (Up to 64 dimensions the consumers gather: there the producers are the launch.)
+          // two columns of a pass of 128; the sums -- zeros for a sequence without entries -- go to the sequence's slot of `partial`, where
+          // the consumers add theirs.  (Up to 64 dimensions the consumers gather: there the producers are the launch.)
+          // SIXTEEN 16-byte loads are in flight a wavefront THE WHOLE TIME (16 KB; 128 KB a CU): a ring of sixteen registers, slot u of
+          // revolution r + 1 asked for as soon as slot u of revolution r is added.  A revolution is 16 / W entries of one sequence x W
+          // passes (W = up to four passes of 128 columns: one row number serves W consecutive kilobytes of its row), the sequences'
+          // pass-groups one after the other; a sequence's 64 entries around the issuing revolution sit in a register (lane = entry), the
+          // next sequence's are asked for a sequence ahead.
           if (wout) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the list is read back by other lanes than wrote it)
           stamp(5);  // the misses' rows found
           const uint32_t npass = (tv.d_pad + 127u) >> 7;
-          uint32_t beg = 0;
-#pragma unroll 1
-          for (int j = 0; j < 8; ++j) {
-            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)present, 8 * j);
-            const uint64_t slj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_slot >> 32), 8 * j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_slot, 8 * j);
-            if (slj != ~0ull) {  // (uniform)
-#pragma unroll 1
-              for (uint32_t p = 0; p < npass; ++p) {
-                const uint32_t col = 128u * p + 2u * (uint32_t)lane;
-                const double *gcol = tv.rows + min(col, tv.d_pad - 2u);  // (d_pad is a multiple of 16: a pair of columns is inside or outside)
-                double c0 = 0.0, c1 = 0.0;
-#pragma unroll 1
-                for (uint32_t e0 = 0; e0 < cnt; e0 += (uint32_t)kPipeGRW) {
-                  const uint32_t nu = min((uint32_t)kPipeGRW, cnt - e0);
-                  const uint32_t ent = __hip_atomic_load(wl + min(beg + e0 + ((uint32_t)lane & (uint32_t)(kPipeGRW - 1)), kPipeListCap - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                  double2 v[kPipeGRW];
+          const uint32_t cntv = (dbg & 4) ? 0u : present;  // entries of my sequence (lanes 8 j .. 8 j + 7: sequence j)
+          uint32_t begv = 0;  // where they begin in the list
+          {
+            uint32_t pre = 0;
 #pragma unroll
-                  for (int u = 0; u < kPipeGRW; ++u) {
-                    const uint32_t rw = (uint32_t)__builtin_amdgcn_readlane((int)ent, u) & 0x1FFFFFFFu;
-                    v[u] = *reinterpret_cast<const double2 *>(gcol + (uint64_t)((uint32_t)u < nu ? rw : 0u) * tv.d_pad);
-                  }
+            for (uint32_t j = 0; j < 8; ++j) {
+              begv = ((uint32_t)lane >> 3) == j ? pre : begv;
+              pre += (uint32_t)__builtin_amdgcn_readlane((int)present, 8 * (int)j);
+            }
+          }
+          const uint32_t slo = (uint32_t)my_slot, shi = (uint32_t)(my_slot >> 32);
+          auto cnt_of = [&](uint32_t j) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)cntv, (int)(8u * j)); };
+          auto slot_of = [&](uint32_t j) -> uint64_t {
+            return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)shi, (int)(8u * j)) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)slo, (int)(8u * j));
+          };
+          auto next_seq = [&](uint32_t j) -> uint32_t {  // the first sequence at or after j that has a slot and entries
+            while (j < 8u && (cnt_of(j) == 0u || slot_of(j) == ~0ull)) ++j;
+            return j;
+          };
+          auto load_ev = [&](uint32_t j, uint32_t blk) -> uint32_t {  // entries 64 blk .. 64 blk + 63 of sequence j, lane = entry
+            const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)begv, (int)(8u * j));
+            return __hip_atomic_load(wl + min(b + 64u * blk + (uint32_t)lane, kPipeListCap - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          };
+          // sequences with a slot and no entries: zeros
+#pragma unroll 1
+          for (uint32_t j = 0; j < 8; ++j) {
+            const uint64_t slj = slot_of(j);
+            if (slj != ~0ull && cnt_of(j) == 0u)
+              for (uint32_t col = 2u * (uint32_t)lane; col < tv.n_dims; col += 128u) {
+                double *dst = partial + slj * tv.n_dims + col;
+                dst[0] = 0.0;
+                if (col + 1u < tv.n_dims) dst[1] = 0.0;
+              }
+          }
+          auto gather = [&](auto Wc) {
+            constexpr uint32_t W = decltype(Wc)::value, E = 16u / W;
+            const uint32_t ngrp = (npass + W - 1u) / W;
+            uint32_t ij = next_seq(0);  // the ISSUING revolution: sequence, pass-group, first entry
+            if (ij >= 8u) return;
+            uint32_t ig = 0, ie0 = 0, icnt = cnt_of(ij);
+            uint32_t ev = load_ev(ij, 0), evj = ij, evb = 0;  // the entries in the register: of sequence evj, block evb
+            uint32_t pj = next_seq(ij + 1u);
+            uint32_t evp = pj < 8u ? load_ev(pj, 0) : 0u;  // ... and of the next sequence, asked for a sequence ahead
+            uint32_t cg = 0, ce0 = 0, ccnt = 0;  // the revolution IN FLIGHT (added next)
+            uint64_t cslot = 0;
+            bool cvalid = false;
+            double2 v[16], acc[W];
 #pragma unroll
-                  for (int u = 0; u < kPipeGRW; ++u) {
-                    const bool ok = (uint32_t)u < nu;  // (uniform)
-                    c0 = __dadd_rn(c0, ok ? v[u].x : 0.0);
-                    c1 = __dadd_rn(c1, ok ? v[u].y : 0.0);
-                  }
+            for (int u = 0; u < 16; ++u) v[u] = make_double2(0.0, 0.0);
+#pragma unroll
+            for (uint32_t w = 0; w < W; ++w) acc[w] = make_double2(0.0, 0.0);
+#pragma unroll 1
+            for (;;) {
+              const bool ivalid = ij < 8u;
+              if (!ivalid && !cvalid) break;
+              if (ivalid && (evj != ij || evb != (ie0 >> 6))) {  // (uniform) another sequence's entries, or a sequence's next 64
+                if (ie0 == 0u && ij == pj) {
+                  ev = evp;
+                  pj = next_seq(ij + 1u);
+                  evp = pj < 8u ? load_ev(pj, 0) : 0u;
+                } else
+                  ev = load_ev(ij, ie0 >> 6);
+                evj = ij;
+                evb = ie0 >> 6;
+              }
+              const double *gcol[W];
+#pragma unroll
+              for (uint32_t w = 0; w < W; ++w) gcol[w] = tv.rows + min(128u * (W * ig + w) + 2u * (uint32_t)lane, tv.d_pad - 2u);  // (d_pad is a multiple of 16: a pair of columns is inside or outside)
+#pragma unroll
+              for (uint32_t u = 0; u < 16; ++u) {
+                const uint32_t eo = u / W, w = u % W;
+                const bool cok = cvalid && ce0 + eo < ccnt;  // (uniform)
+                acc[w].x = __dadd_rn(acc[w].x, cok ? v[u].x : 0.0);
+                acc[w].y = __dadd_rn(acc[w].y, cok ? v[u].y : 0.0);
+                const bool iok = ivalid && ie0 + eo < icnt;  // (uniform)
+                const uint32_t rw = (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)((ie0 + eo) & 63u)) & 0x1FFFFFFFu;
+                {  // (non-temporal -- kpop_tune("pipeprio", 4 | p): plain --: rows read once must not push the members' rows, read by every block of the XCD, out of its L2)
+                  typedef double pipe_f64x2 __attribute__((ext_vector_type(2)));
+                  const pipe_f64x2 *src = reinterpret_cast<const pipe_f64x2 *>(gcol[w] + (uint64_t)(iok ? rw : 0u) * tv.d_pad);
+                  const pipe_f64x2 t2 = (dbg_in & 128) ? *src : __builtin_nontemporal_load(src);
+                  v[u] = make_double2(t2.x, t2.y);
                 }
-                if (!(dbg & 4)) {
-                  double *dst = partial + slj * tv.n_dims + col;
-                  if (col < tv.n_dims) dst[0] = c0;
-                  if (col + 1u < tv.n_dims) dst[1] = c1;
+              }
+              if (cvalid && ce0 + E >= ccnt) {  // (uniform) the sequence's last entries of this pass-group: its sums
+#pragma unroll
+                for (uint32_t w = 0; w < W; ++w) {
+                  const uint32_t col = 128u * (W * cg + w) + 2u * (uint32_t)lane;
+                  double *dst = partial + cslot * tv.n_dims + col;
+                  if (col < tv.n_dims) dst[0] = acc[w].x;
+                  if (col + 1u < tv.n_dims) dst[1] = acc[w].y;
+                  acc[w] = make_double2(0.0, 0.0);
+                }
+              }
+              cvalid = ivalid;
+              cg = ig;
+              ce0 = ie0;
+              ccnt = icnt;
+              if (ivalid) {
+                cslot = slot_of(ij);
+                ie0 += E;
+                if (ie0 >= icnt) {
+                  ie0 = 0;
+                  if (++ig == ngrp) {
+                    ig = 0;
+                    ij = next_seq(ij + 1u);
+                    if (ij < 8u) icnt = cnt_of(ij);
+                  }
                 }
               }
             }
-            beg += cnt;
-          }
+          };
+          if (npass >= 3u) gather(std::integral_constant<uint32_t, 4>{});
+          else if (npass == 2u) gather(std::integral_constant<uint32_t, 2>{});
+          else gather(std::integral_constant<uint32_t, 1>{});
           stamp(12);  // the residual rows gathered (WIDE)
         }
         if (tq == 0) {
@@ -813,10 +894,13 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
   const uint32_t g4 = (uint32_t)lane >> 4, c16 = (uint32_t)lane & 15u;
   if constexpr (WIDE) {
     // ------------------------------------------------------------------- the consumers of more than 64 dimensions: they only multiply
-    const uint32_t nslab = (tv.d_pad + 63u) >> 6;
+    // A wavefront takes ALL 64 sequences (four accumulator tiles) x 16 columns, the eight of them a slab of 128 columns: a piece of a
+    // member's row is loaded ONCE a block (with 32 sequences a wavefront, as up to 64 dimensions, two wavefronts loaded every piece:
+    // 32 B a clock and CU at the matrix peak -- more than an XCD's L2 gives a CU; without MFMAs and gather the row stream alone took
+    // 11.4 of the launch's 20 ms at 1,635 dimensions).
+    const uint32_t nslab = (tv.d_pad + 127u) >> 7;
     uint32_t n_conw = 0;
-    // byte j of w as a double (see below)
-    auto byte_f64w = [](uint32_t w, uint32_t j) -> double {
+    auto byte_f64w = [](uint32_t w, uint32_t j) -> double {  // byte j of w as a double (see below)
       const uint64_t bits = 0x4330000000000000ull | (uint64_t)((w >> (8u * j)) & 0xFFu);
       return __longlong_as_double((long long)bits) - 4503599627370496.0;
     };
@@ -847,23 +931,18 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
       const uint32_t buf = n_conw & 1u;
       const uint32_t UP = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_U[buf]), nb = UP / 16u;
       const uint32_t *uc = ucol + buf * kTileSetCap + 4u * g4;
-      const uint32_t *xa = Xw + buf * G * XW + (32u * (uint32_t)mh + c16) * XW + g4;
-      // the slots of the eight sequences whose sums this lane holds: rows g4 + 4 rr of accumulator tile t = sequence 16 t + g4 + 4 rr of the half
-      uint64_t sl[8];
-#pragma unroll
-      for (uint32_t q = 0; q < 8; ++q) sl[q] = s_slot[buf][32u * (uint32_t)mh + 16u * (q >> 2) + g4 + 4u * (q & 3u)];
+      const uint32_t *xa = Xw + buf * G * XW + c16 * XW + g4;  // tile t: 16 t rows on
 #pragma unroll 1
       for (uint32_t slab = 0; slab < nslab; ++slab) {
-        const uint32_t col = 64u * slab + 16u * (uint32_t)ni + c16;
+        if (128u * slab + 16u * cw >= tv.d_pad) continue;  // (uniform: the last slab's wavefronts past the twister's columns)
+        const uint32_t col = 128u * slab + 16u * cw + c16;
         const bool colok = col < tv.n_dims;
         const double *trow = tv.rows + min(col, tv.d_pad - 1u);
-        f64x4 acc0 = f64x4{0.0, 0.0, 0.0, 0.0}, acc1 = f64x4{0.0, 0.0, 0.0, 0.0};
-        // what the producers left in the slots: the sequences' residual rows, summed (asked for now, added after the slab's MFMAs)
-        double rs[8];
+        f64x4 acc[4];
 #pragma unroll
-        for (uint32_t q = 0; q < 8; ++q) rs[q] = (colok && sl[q] != ~0ull) ? partial[sl[q] * tv.n_dims + col] : 0.0;
+        for (uint32_t t = 0; t < 4; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
         double bs[4][4];
-        uint32_t a0 = 0, a1 = 0;
+        uint32_t a[4] = {0u, 0u, 0u, 0u};
         uint4 uqn = make_uint4(0u, 0u, 0u, 0u);
         auto load_rows = [&](double (&dst)[4], const uint4 u) {
           dst[0] = trow[(uint64_t)u.x << 4];
@@ -875,34 +954,45 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
 #pragma unroll
           for (uint32_t s = 0; s < 3; ++s) load_rows(bs[s], *reinterpret_cast<const uint4 *>(uc + 16u * min(s, nb - 1u)));
           uqn = *reinterpret_cast<const uint4 *>(uc + 16u * min(3u, nb - 1u));
-          a0 = xa[0];
-          a1 = xa[16u * XW];
+#pragma unroll
+          for (uint32_t t = 0; t < 4; ++t) a[t] = xa[16u * t * XW];
         }
-#pragma unroll 1
-        for (uint32_t b0 = 0; b0 < nb; b0 += 4) {  // (nb is a multiple of four; no branch inside the four blocks: see below)
+        auto four_blocks = [&](uint32_t b0) {  // (no branch inside the four blocks: see the other consumers)
 #pragma unroll
           for (uint32_t s = 0; s < 4; ++s) {
             const uint32_t b = b0 + s;
             load_rows(bs[(s + 3u) & 3u], uqn);  // block b + 3's rows of T
             uqn = *reinterpret_cast<const uint4 *>(uc + 16u * min(b + 4u, nb - 1u));
             const uint32_t bx = min(b + 1u, nb - 1u);
-            const uint32_t an0 = xa[4u * bx], an1 = xa[16u * XW + 4u * bx];
+            uint32_t an[4];
+#pragma unroll
+            for (uint32_t t = 0; t < 4; ++t) an[t] = xa[16u * t * XW + 4u * bx];
 #pragma unroll
             for (uint32_t j = 0; j < 4 && !(dbg & 1); ++j) {
-              acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(byte_f64w(a0, j), bs[s][j], acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(byte_f64w(a1, j), bs[s][j], acc1, 0, 0, 0);
+#pragma unroll
+              for (uint32_t t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(byte_f64w(a[t], j), bs[s][j], acc[t], 0, 0, 0);
             }
-            a0 = an0;
-            a1 = an1;
+#pragma unroll
+            for (uint32_t t = 0; t < 4; ++t) a[t] = an[t];
           }
-        }
+        };
+        uint32_t b0 = 0;
+#pragma unroll 1
+        for (; b0 + 4u < nb; b0 += 4) four_blocks(b0);  // (nb is a multiple of four)
+        // what the producers left in the slots -- the sequences' residual rows, summed -- asked for under the last four blocks
+        // (rows g4 + 4 rr of accumulator tile t = sequence 16 t + g4 + 4 rr)
+        double rs[16];
+        uint64_t sl[16];
+#pragma unroll
+        for (uint32_t q = 0; q < 16; ++q) sl[q] = s_slot[buf][16u * (q >> 2) + g4 + 4u * (q & 3u)];
+#pragma unroll
+        for (uint32_t q = 0; q < 16; ++q) rs[q] = (colok && sl[q] != ~0ull) ? partial[sl[q] * tv.n_dims + col] : 0.0;
+        if (nb) four_blocks(b0);
         // the sums: (the set's rows on the matrix cores) + (the residual rows), straight from the registers
         if (colok) {
 #pragma unroll
-          for (uint32_t rr = 0; rr < 4; ++rr) {
-            if (sl[rr] != ~0ull) partial[sl[rr] * tv.n_dims + col] = __dadd_rn(acc0[rr], rs[rr]);
-            if (sl[4u + rr] != ~0ull) partial[sl[4u + rr] * tv.n_dims + col] = __dadd_rn(acc1[rr], rs[4u + rr]);
-          }
+          for (uint32_t q = 0; q < 16; ++q)
+            if (sl[q] != ~0ull) partial[sl[q] * tv.n_dims + col] = __dadd_rn(acc[q >> 2][q & 3u], rs[q]);
         }
       }
       stamp(9);  // the matrix cores, every slab

@@ -66,6 +66,10 @@ def main():
         call = lambda: api.dev_count_twist(tw, bases.data_ptr(), offs.data_ptr(), n, n * L, L, out.data_ptr(), stream=st.cuda_stream)
         ms = timed(call, reps)
         got = out.clone()
+        for bits in [int(x) for x in os.environ.get("R06_DBG", "").split(",") if x]:  # ablations (results are wrong under them): 1 no MFMAs, 4 no residual gather, 64 one issue priority
+            api.tune("dbg", bits << 24)
+            print("      dbg %2d: %9.3f ms" % (bits, timed(call, 3)), flush=True)
+            api.tune("dbg", 0)
         api.debug_counters(16)
         api.tune("dbg", 32 << 24)
         call()
