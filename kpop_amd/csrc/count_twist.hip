@@ -1831,7 +1831,7 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   // up to 64 dimensions: the pipelined kernel (tile_pipe.h; kpop_tune("tilepipe", 0): round 4's kernel, phases one after the other)
   // (kpop_tune("tilepipe", 0): round 4's kernel, phases one after the other, the residual rows in a launch of their own beyond 64 dimensions)
   const bool pipe = tiles && pipe_able;  // (a row's number shares a word with three bits of tag in the residual lists; beyond 64 dimensions a row's offset in 128-byte units is a word)
-  const uint64_t bytes_wlists = !tiles ? 0 : pipe ? (uint64_t)cx.n_cus * 2 * 8 * kPipeListCap * 4 : (uint64_t)cx.n_cus * 16 * 4 * kTileS * 4;
+  const uint64_t bytes_wlists = !tiles ? 0 : pipe ? (uint64_t)cx.n_cus * (wide ? 3 : 2) * 8 * kPipeListCap * 4 : (uint64_t)cx.n_cus * 16 * 4 * kTileS * 4;
   void *ws = nullptr;
   KPOP_TRY(ctx().ws_for(st).ensure(bytes_nseg + bytes_off + 2 * bytes_sums + bytes_cnt + bytes_part + bytes_done + bytes_long + bytes_olong + 2 * bytes_gmax +
                                        bytes_res + bytes_todo + 2 * bytes_perread + bytes_wlists, &ws));

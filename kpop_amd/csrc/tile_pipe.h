@@ -64,15 +64,17 @@ __device__ __forceinline__ void pipe_half_barrier(uint32_t *ctr, uint32_t &targe
   pipe_wait(ctr, target);
 }
 
-// WIDE (more than 64 dimensions): the consumers take the twister's columns in SLABS of 64 -- the same X against slab after slab of the
-// members' rows, the chunk's buffer released after the last -- and the work changes hands: a chunk's MFMAs are D / 64 times the 64-dimension
-// kernel's while its preparation is what it was, so the PRODUCERS wait most of the time (0.8 of it at 256 dimensions, 0.97 at 1,635) and the
-// residual rows -- 2.3 MB a chunk from HBM at 256 dimensions and 0.3 % divergence, every load a DRAM round trip -- are theirs to gather:
-// sixteen 16-byte row loads in flight a producer wavefront (its own eight sequences, lane = two columns, 128 columns a pass), the sums
-// written to the sequences' slots of `partial` BEFORE the chunk is handed over.  A consumer wavefront then only multiplies; its sums leave
-// straight from the accumulators' registers, added to what the producers left in `partial` (read back through L2 at the slab's start).
-// (First form, measured: the consumers gathered for their own 16 columns under their MFMAs -- the loads' counter is one and in order, so
-// every four blocks of MFMAs waited for an HBM round trip: 0.22 of the matrix peak at 256 and at 1,635 dimensions.)
+// WIDE (more than 64 dimensions): the work changes hands.  A chunk's MFMAs are D / 64 times the 64-dimension kernel's while its
+// preparation is what it was, and its residual rows -- 2.3 MB a chunk from HBM at 256 dimensions and 0.3 % divergence, every load a DRAM
+// round trip -- are as much time again at HBM's rate: THREE stages run at once in a block,
+//   wavefronts 8..15  PRODUCERS: chunk c + 1's preparation, as up to 64 dimensions;
+//   wavefronts 0..3   MFMA wavefronts, one a SIMD: chunk c, all 64 sequences x 16 columns a unit, the units of the twister's columns
+//                     in turn against the same X; the sums go straight from the accumulators' registers to the sequences' slots;
+//   wavefronts 4..7   GATHER wavefronts, one a SIMD: chunk c - 1's residual rows, sixteen 16-byte loads in flight each the whole time,
+//                     their sums added to the slots once the chunk's MFMAs are done (lists and slots are kept three chunks deep).
+// (Measured on the way: consumers gathering for their own columns under their MFMAs -- one in-order counter of loads, every four blocks of
+// MFMAs waited for a DRAM round trip: 0.22 of the matrix peak; producers gathering before they hand a chunk over -- preparation and
+// gather one after the other: 0.35-0.37, the gather alone 2.64, the MFMAs alone 2.57, both 3.28 ms on 5,000 mutants at 256 dimensions.)
 // The chunks are dealt so that the blocks of one XCD work on the SAME stretch at a time: at 256 dimensions a stretch's members are
 // 1.5 MB of rows (10 MB at 1,635) -- one stretch an L2, not eight.
 template <bool ABLATE, bool WIDE = false>  // (ABLATE: the timing switches of kpop_tune("dbg", (1 | 2 | 4 | 8) << 24) are compiled in -- results are wrong under them)
@@ -90,7 +92,12 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
   uint32_t *ucol = reinterpret_cast<uint32_t *>(ht + kTileH);     // [2][kTileSetCap] twister row of member u
   uint32_t *stage = ucol + 2 * kTileSetCap;                       // [G][kPipeRowW] the stretch's bases as 2-bit codes: F, R, V
   uint32_t *mlist = stage + G * kPipeRowW;                        // [8][kPipeMissLds] a producer wavefront's missed hashes, before their rows
-  __shared__ uint64_t s_slot[2][G];   // the group's (sequence, segment) slots, ~0: the sequence has no such segment
+  __shared__ uint64_t s_slot[3][G];   // the group's (sequence, segment) slots, ~0: the sequence has no such segment ([3]: WIDE keeps three chunks' worth)
+  __shared__ uint32_t s_gcnt[3][G], s_gbeg[3][G];  // WIDE: a sequence's entries in its producer wavefront's residual list, and where they begin
+  // WIDE: chunks every MFMA wavefront has multiplied / every gather wavefront has added the residual rows of -- ONE COUNTER A WAVEFRONT:
+  // nothing keeps the four in step (wavefront 0 has a unit more than the others at 72 dimensions), and with one counter for all, three
+  // of them two chunks ahead stood in for the fourth (the sub-batch test's 9,000 assemblies: columns 64..71 differed from call to call)
+  __shared__ uint32_t s_mdone[4], s_gdone[4];
   __shared__ uint32_t s_rtot[2][8];   // entries of every producer wavefront's residual list (row | sequence of its eight << 29)
   __shared__ uint32_t s_U[2];         // members as multiplied (padded to 64)
   __shared__ uint32_t s_pbar, s_cbar4[2], s_full, s_empty2[2], s_done;  // (s_empty2: chunks released, counted per HALF of the consumers -- the halves are not in step any more, and one counter let a half that was two chunks ahead stand in for the other)
@@ -112,6 +119,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
     s_empty2[0] = s_empty2[1] = 0;
     s_done = 0;
   }
+  if (threadIdx.x < 4) s_mdone[threadIdx.x] = s_gdone[threadIdx.x] = 0;
   __syncthreads();  // the one hardware barrier: from here on the halves go their own ways
   const int k = tv.hk;
   const bool stamps = (dbg & 16) && lane == 0 && (wv == 0 || wv == 8);
@@ -430,8 +438,13 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
         // (under the index words' trip to memory: the wait for this buffer)
         if (n_pub >= 2) {  // the consumers are done with this buffer's last chunk
           const unsigned long long t0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-          pipe_wait(&s_empty2[0], 4u * (n_pub - 1u));
-          pipe_wait(&s_empty2[1], 4u * (n_pub - 1u));
+          if constexpr (WIDE) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) pipe_wait(&s_mdone[w], n_pub - 1u);
+          } else {
+            pipe_wait(&s_empty2[0], 4u * (n_pub - 1u));
+            pipe_wait(&s_empty2[1], 4u * (n_pub - 1u));
+          }
           if (stamps) {
             const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
             atomicAdd(&s_stamp[7], dt);
@@ -513,8 +526,13 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
         // not had them yet (the other buffer has: its consumers only read it)
         if (n_pub >= 2) {
           const unsigned long long t0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-          pipe_wait(&s_empty2[0], 4u * (n_pub - 1u));
-          pipe_wait(&s_empty2[1], 4u * (n_pub - 1u));
+          if constexpr (WIDE) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) pipe_wait(&s_mdone[w], n_pub - 1u);
+          } else {
+            pipe_wait(&s_empty2[0], 4u * (n_pub - 1u));
+            pipe_wait(&s_empty2[1], 4u * (n_pub - 1u));
+          }
           if (stamps) {
             const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
             atomicAdd(&s_stamp[7], dt);
@@ -680,7 +698,13 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
           if (lane >= o) incl += up;
         }
         const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        uint32_t *wl = lists + (((uint64_t)blockIdx.x * 2 + buf) * 8 + pw) * kPipeListCap;
+        // (WIDE: the lists and what goes with them are kept THREE chunks deep -- the gather wavefronts read a chunk's after its MFMAs)
+        const uint32_t lb = WIDE ? n_pub % 3u : buf;
+        if (WIDE && n_pub >= 3u) {
+#pragma unroll
+          for (int w = 0; w < 4; ++w) pipe_wait(&s_gdone[w], n_pub - 2u);
+        }
+        uint32_t *wl = lists + (((uint64_t)blockIdx.x * (WIDE ? 3 : 2) + lb) * 8 + pw) * kPipeListCap;
         uint32_t present = 0;  // entries that have a row, of MY sequence (lanes of a sequence all count it)
 #pragma unroll
         for (int o = 4; o > 0; o >>= 1) found += (uint32_t)__shfl_xor((int)found, o, 8);
@@ -729,19 +753,8 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
           found += present;
         }
         if constexpr (WIDE) {
-          // The residual rows of the wavefront's eight sequences, gathered HERE: every sequence's rows added in list (= window) order, lane =
-          // two columns of a pass of 128; the sums -- zeros for a sequence without entries -- go to the sequence's slot of `partial`, where
-          // the consumers add theirs.  (Up to 64 dimensions the consumers gather: there the producers are the launch.)
-          // SIXTEEN 16-byte loads are in flight a wavefront THE WHOLE TIME (16 KB; 128 KB a CU): a ring of sixteen registers, slot u of
-          // revolution r + 1 asked for as soon as slot u of revolution r is added.  A revolution is 16 / W entries of one sequence x W
-          // passes (W = up to four passes of 128 columns: one row number serves W consecutive kilobytes of its row), the sequences'
-          // pass-groups one after the other; a sequence's 64 entries around the issuing revolution sit in a register (lane = entry), the
-          // next sequence's are asked for a sequence ahead.
-          if (wout) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the list is read back by other lanes than wrote it)
-          stamp(5);  // the misses' rows found
-          const uint32_t npass = (tv.d_pad + 127u) >> 7;
-          const uint32_t cntv = (dbg & 4) ? 0u : present;  // entries of my sequence (lanes 8 j .. 8 j + 7: sequence j)
-          uint32_t begv = 0;  // where they begin in the list
+          // (the residual rows are the GATHER wavefronts': what they need of this chunk -- every sequence's entries and where they begin)
+          uint32_t begv = 0;
           {
             uint32_t pre = 0;
 #pragma unroll
@@ -750,114 +763,13 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
               pre += (uint32_t)__builtin_amdgcn_readlane((int)present, 8 * (int)j);
             }
           }
-          const uint32_t slo = (uint32_t)my_slot, shi = (uint32_t)(my_slot >> 32);
-          auto cnt_of = [&](uint32_t j) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)cntv, (int)(8u * j)); };
-          auto slot_of = [&](uint32_t j) -> uint64_t {
-            return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)shi, (int)(8u * j)) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)slo, (int)(8u * j));
-          };
-          auto next_seq = [&](uint32_t j) -> uint32_t {  // the first sequence at or after j that has a slot and entries
-            while (j < 8u && (cnt_of(j) == 0u || slot_of(j) == ~0ull)) ++j;
-            return j;
-          };
-          auto load_ev = [&](uint32_t j, uint32_t blk) -> uint32_t {  // entries 64 blk .. 64 blk + 63 of sequence j, lane = entry
-            const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)begv, (int)(8u * j));
-            return __hip_atomic_load(wl + min(b + 64u * blk + (uint32_t)lane, kPipeListCap - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          };
-          // sequences with a slot and no entries: zeros
-#pragma unroll 1
-          for (uint32_t j = 0; j < 8; ++j) {
-            const uint64_t slj = slot_of(j);
-            if (slj != ~0ull && cnt_of(j) == 0u)
-              for (uint32_t col = 2u * (uint32_t)lane; col < tv.n_dims; col += 128u) {
-                double *dst = partial + slj * tv.n_dims + col;
-                dst[0] = 0.0;
-                if (col + 1u < tv.n_dims) dst[1] = 0.0;
-              }
+          if (tq == 0) {
+            s_gcnt[lb][sq] = (dbg & 4) ? 0u : present;
+            s_gbeg[lb][sq] = begv;
           }
-          auto gather = [&](auto Wc) {
-            constexpr uint32_t W = decltype(Wc)::value, E = 16u / W;
-            const uint32_t ngrp = (npass + W - 1u) / W;
-            uint32_t ij = next_seq(0);  // the ISSUING revolution: sequence, pass-group, first entry
-            if (ij >= 8u) return;
-            uint32_t ig = 0, ie0 = 0, icnt = cnt_of(ij);
-            uint32_t ev = load_ev(ij, 0), evj = ij, evb = 0;  // the entries in the register: of sequence evj, block evb
-            uint32_t pj = next_seq(ij + 1u);
-            uint32_t evp = pj < 8u ? load_ev(pj, 0) : 0u;  // ... and of the next sequence, asked for a sequence ahead
-            uint32_t cg = 0, ce0 = 0, ccnt = 0;  // the revolution IN FLIGHT (added next)
-            uint64_t cslot = 0;
-            bool cvalid = false;
-            double2 v[16], acc[W];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = make_double2(0.0, 0.0);
-#pragma unroll
-            for (uint32_t w = 0; w < W; ++w) acc[w] = make_double2(0.0, 0.0);
-#pragma unroll 1
-            for (;;) {
-              const bool ivalid = ij < 8u;
-              if (!ivalid && !cvalid) break;
-              if (ivalid && (evj != ij || evb != (ie0 >> 6))) {  // (uniform) another sequence's entries, or a sequence's next 64
-                if (ie0 == 0u && ij == pj) {
-                  ev = evp;
-                  pj = next_seq(ij + 1u);
-                  evp = pj < 8u ? load_ev(pj, 0) : 0u;
-                } else
-                  ev = load_ev(ij, ie0 >> 6);
-                evj = ij;
-                evb = ie0 >> 6;
-              }
-              const double *gcol[W];
-#pragma unroll
-              for (uint32_t w = 0; w < W; ++w) gcol[w] = tv.rows + min(128u * (W * ig + w) + 2u * (uint32_t)lane, tv.d_pad - 2u);  // (d_pad is a multiple of 16: a pair of columns is inside or outside)
-#pragma unroll
-              for (uint32_t u = 0; u < 16; ++u) {
-                const uint32_t eo = u / W, w = u % W;
-                const bool cok = cvalid && ce0 + eo < ccnt;  // (uniform)
-                acc[w].x = __dadd_rn(acc[w].x, cok ? v[u].x : 0.0);
-                acc[w].y = __dadd_rn(acc[w].y, cok ? v[u].y : 0.0);
-                const bool iok = ivalid && ie0 + eo < icnt;  // (uniform)
-                const uint32_t rw = (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)((ie0 + eo) & 63u)) & 0x1FFFFFFFu;
-                {  // (non-temporal -- kpop_tune("pipeprio", 4 | p): plain --: rows read once must not push the members' rows, read by every block of the XCD, out of its L2)
-                  typedef double pipe_f64x2 __attribute__((ext_vector_type(2)));
-                  const pipe_f64x2 *src = reinterpret_cast<const pipe_f64x2 *>(gcol[w] + (uint64_t)(iok ? rw : 0u) * tv.d_pad);
-                  const pipe_f64x2 t2 = (dbg_in & 128) ? *src : __builtin_nontemporal_load(src);
-                  v[u] = make_double2(t2.x, t2.y);
-                }
-              }
-              if (cvalid && ce0 + E >= ccnt) {  // (uniform) the sequence's last entries of this pass-group: its sums
-#pragma unroll
-                for (uint32_t w = 0; w < W; ++w) {
-                  const uint32_t col = 128u * (W * cg + w) + 2u * (uint32_t)lane;
-                  double *dst = partial + cslot * tv.n_dims + col;
-                  if (col < tv.n_dims) dst[0] = acc[w].x;
-                  if (col + 1u < tv.n_dims) dst[1] = acc[w].y;
-                  acc[w] = make_double2(0.0, 0.0);
-                }
-              }
-              cvalid = ivalid;
-              cg = ig;
-              ce0 = ie0;
-              ccnt = icnt;
-              if (ivalid) {
-                cslot = slot_of(ij);
-                ie0 += E;
-                if (ie0 >= icnt) {
-                  ie0 = 0;
-                  if (++ig == ngrp) {
-                    ig = 0;
-                    ij = next_seq(ij + 1u);
-                    if (ij < 8u) icnt = cnt_of(ij);
-                  }
-                }
-              }
-            }
-          };
-          if (npass >= 3u) gather(std::integral_constant<uint32_t, 4>{});
-          else if (npass == 2u) gather(std::integral_constant<uint32_t, 2>{});
-          else gather(std::integral_constant<uint32_t, 1>{});
-          stamp(12);  // the residual rows gathered (WIDE)
         }
         if (tq == 0) {
-          s_slot[buf][sq] = my_slot;
+          s_slot[lb][sq] = my_slot;
           if (mine) {
             slot_done[my_slot] = 1u;
             partial_cnt[my_slot] = found;
@@ -893,117 +805,249 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
   const int ni = (int)(cw & 3u), mh = (int)(cw >> 2);  // 16 dimensions, 32 sequences (wavefronts cw and cw + 4 share a SIMD and their rows of T)
   const uint32_t g4 = (uint32_t)lane >> 4, c16 = (uint32_t)lane & 15u;
   if constexpr (WIDE) {
-    // ------------------------------------------------------------------- the consumers of more than 64 dimensions: they only multiply
-    // A wavefront takes ALL 64 sequences (four accumulator tiles) x 16 columns, the eight of them a slab of 128 columns: a piece of a
-    // member's row is loaded ONCE a block (with 32 sequences a wavefront, as up to 64 dimensions, two wavefronts loaded every piece:
-    // 32 B a clock and CU at the matrix peak -- more than an XCD's L2 gives a CU; without MFMAs and gather the row stream alone took
-    // 11.4 of the launch's 20 ms at 1,635 dimensions).
-    const uint32_t nslab = (tv.d_pad + 127u) >> 7;
-    uint32_t n_conw = 0;
-    auto byte_f64w = [](uint32_t w, uint32_t j) -> double {  // byte j of w as a double (see below)
-      const uint64_t bits = 0x4330000000000000ull | (uint64_t)((w >> (8u * j)) & 0xFFu);
-      return __longlong_as_double((long long)bits) - 4503599627370496.0;
-    };
-    if (!(dbg_in & 64)) {  // (kpop_tune("pipeprio"); the producers: 2)
-      switch ((dbg_in >> 8) & 3) {
-        case 0: __builtin_amdgcn_s_setprio(0); break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        default: __builtin_amdgcn_s_setprio(3); break;
+    // ------------------------------------------------------------------- the consumers of more than 64 dimensions
+    const uint32_t nunits = tv.d_pad >> 4;  // the twister's columns in units of 16
+    if (cw < 4u) {
+      // ----------------------------------------------------------------- MFMA wavefronts: one a SIMD
+      // A wavefront takes ALL 64 sequences (four accumulator tiles) x 16 columns a UNIT, units cw, cw + 4, ... : a piece of a member's
+      // row is loaded once a block of the grid (with 32 sequences a wavefront, as up to 64 dimensions, two wavefronts loaded every piece),
+      // and ONE wavefront keeps its SIMD's matrix pipe busy: four independent accumulators, the rows of T three blocks (48 MFMAs) ahead.
+      uint32_t n_conw = 0;
+      auto byte_f64w = [](uint32_t w, uint32_t j) -> double {  // byte j of w as a double (see below)
+        const uint64_t bits = 0x4330000000000000ull | (uint64_t)((w >> (8u * j)) & 0xFFu);
+        return __longlong_as_double((long long)bits) - 4503599627370496.0;
+      };
+      if (!(dbg_in & 64)) {  // (kpop_tune("pipeprio"); the producers: 2)
+        switch ((dbg_in >> 8) & 3) {
+          case 0: __builtin_amdgcn_s_setprio(0); break;
+          case 1: __builtin_amdgcn_s_setprio(1); break;
+          case 2: __builtin_amdgcn_s_setprio(2); break;
+          default: __builtin_amdgcn_s_setprio(3); break;
+        }
       }
-    }
-    for (;;) {
-      bool got = false;
       for (;;) {
-        const uint32_t dn = pipe_ld(&s_done);
+        bool got = false;
+        for (;;) {
+          const uint32_t dn = pipe_ld(&s_done);
+          pipe_lds_fence();
+          const uint32_t fl = pipe_ld(&s_full);
+          if ((int32_t)(fl - n_conw) > 0) {
+            got = true;
+            break;
+          }
+          if (dn) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (!got) break;
         pipe_lds_fence();
-        const uint32_t fl = pipe_ld(&s_full);
-        if ((int32_t)(fl - n_conw) > 0) {
-          got = true;
-          break;
-        }
-        if (dn) break;
-        __builtin_amdgcn_s_sleep(2);
-      }
-      if (!got) break;
-      pipe_lds_fence();
-      stamp(8);  // waited for a chunk
-      const uint32_t buf = n_conw & 1u;
-      const uint32_t UP = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_U[buf]), nb = UP / 16u;
-      const uint32_t *uc = ucol + buf * kTileSetCap + 4u * g4;
-      const uint32_t *xa = Xw + buf * G * XW + c16 * XW + g4;  // tile t: 16 t rows on
+        stamp(8);  // waited for a chunk
+        const uint32_t buf = n_conw & 1u, lb = n_conw % 3u;
+        const uint32_t UP = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_U[buf]), nb = UP / 16u;
+        const uint32_t *uc = ucol + buf * kTileSetCap + 4u * g4;
+        const uint32_t *xa = Xw + buf * G * XW + c16 * XW + g4;  // tile t: 16 t rows on
 #pragma unroll 1
-      for (uint32_t slab = 0; slab < nslab; ++slab) {
-        if (128u * slab + 16u * cw >= tv.d_pad) continue;  // (uniform: the last slab's wavefronts past the twister's columns)
-        const uint32_t col = 128u * slab + 16u * cw + c16;
-        const bool colok = col < tv.n_dims;
-        const double *trow = tv.rows + min(col, tv.d_pad - 1u);
-        f64x4 acc[4];
+        for (uint32_t unit = cw; unit < nunits; unit += 4u) {
+          const uint32_t col = 16u * unit + c16;
+          const double *trow = tv.rows + col;
+          f64x4 acc[4];
 #pragma unroll
-        for (uint32_t t = 0; t < 4; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
-        double bs[4][4];
-        uint32_t a[4] = {0u, 0u, 0u, 0u};
-        uint4 uqn = make_uint4(0u, 0u, 0u, 0u);
-        auto load_rows = [&](double (&dst)[4], const uint4 u) {
-          dst[0] = trow[(uint64_t)u.x << 4];
-          dst[1] = trow[(uint64_t)u.y << 4];
-          dst[2] = trow[(uint64_t)u.z << 4];
-          dst[3] = trow[(uint64_t)u.w << 4];
-        };
-        if (nb) {
+          for (uint32_t t = 0; t < 4; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+          double bs[4][4];
+          uint32_t a[4] = {0u, 0u, 0u, 0u};
+          uint4 uqn = make_uint4(0u, 0u, 0u, 0u);
+          auto load_rows = [&](double (&dst)[4], const uint4 u) {
+            dst[0] = trow[(uint64_t)u.x << 4];
+            dst[1] = trow[(uint64_t)u.y << 4];
+            dst[2] = trow[(uint64_t)u.z << 4];
+            dst[3] = trow[(uint64_t)u.w << 4];
+          };
+          if (nb) {
 #pragma unroll
-          for (uint32_t s = 0; s < 3; ++s) load_rows(bs[s], *reinterpret_cast<const uint4 *>(uc + 16u * min(s, nb - 1u)));
-          uqn = *reinterpret_cast<const uint4 *>(uc + 16u * min(3u, nb - 1u));
+            for (uint32_t s = 0; s < 3; ++s) load_rows(bs[s], *reinterpret_cast<const uint4 *>(uc + 16u * min(s, nb - 1u)));
+            uqn = *reinterpret_cast<const uint4 *>(uc + 16u * min(3u, nb - 1u));
 #pragma unroll
-          for (uint32_t t = 0; t < 4; ++t) a[t] = xa[16u * t * XW];
-        }
-        auto four_blocks = [&](uint32_t b0) {  // (no branch inside the four blocks: see the other consumers)
+            for (uint32_t t = 0; t < 4; ++t) a[t] = xa[16u * t * XW];
+          }
+#pragma unroll 1
+          for (uint32_t b0 = 0; b0 < nb; b0 += 4) {  // (nb is a multiple of four; no branch inside the four blocks: see the other consumers)
 #pragma unroll
-          for (uint32_t s = 0; s < 4; ++s) {
-            const uint32_t b = b0 + s;
-            load_rows(bs[(s + 3u) & 3u], uqn);  // block b + 3's rows of T
-            uqn = *reinterpret_cast<const uint4 *>(uc + 16u * min(b + 4u, nb - 1u));
-            const uint32_t bx = min(b + 1u, nb - 1u);
-            uint32_t an[4];
+            for (uint32_t s = 0; s < 4; ++s) {
+              const uint32_t b = b0 + s;
+              load_rows(bs[(s + 3u) & 3u], uqn);  // block b + 3's rows of T
+              uqn = *reinterpret_cast<const uint4 *>(uc + 16u * min(b + 4u, nb - 1u));
+              const uint32_t bx = min(b + 1u, nb - 1u);
+              uint32_t an[4];
 #pragma unroll
-            for (uint32_t t = 0; t < 4; ++t) an[t] = xa[16u * t * XW + 4u * bx];
+              for (uint32_t t = 0; t < 4; ++t) an[t] = xa[16u * t * XW + 4u * bx];
 #pragma unroll
-            for (uint32_t j = 0; j < 4 && !(dbg & 1); ++j) {
+              for (uint32_t j = 0; j < 4 && !(dbg & 1); ++j) {
 #pragma unroll
-              for (uint32_t t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(byte_f64w(a[t], j), bs[s][j], acc[t], 0, 0, 0);
+                for (uint32_t t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(byte_f64w(a[t], j), bs[s][j], acc[t], 0, 0, 0);
+              }
+#pragma unroll
+              for (uint32_t t = 0; t < 4; ++t) a[t] = an[t];
             }
+          }
+          // the sums of the set's rows, straight from the registers (rows g4 + 4 rr of accumulator tile t = sequence 16 t + g4 + 4 rr);
+          // the gather wavefronts add the residual rows' to them
+          if (col < tv.n_dims) {
 #pragma unroll
-            for (uint32_t t = 0; t < 4; ++t) a[t] = an[t];
+            for (uint32_t q = 0; q < 16; ++q) {
+              const uint64_t sl = s_slot[lb][16u * (q >> 2) + g4 + 4u * (q & 3u)];
+              if (sl != ~0ull) partial[sl * tv.n_dims + col] = acc[q >> 2][q & 3u];
+            }
+          }
+        }
+        stamp(9);  // the matrix cores, every unit
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the sums are the gather wavefronts' to read)
+        pipe_lds_fence();  // (done reading this buffer's X, rows and slots)
+        ++n_conw;
+        if (lane == 0) __hip_atomic_store(&s_mdone[cw], n_conw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        stamp(10);
+      }
+      if (stamps)
+        for (int i = 8; i < 11; ++i) atomicAdd(&g_tile_stamps[i], s_stamp[i]);
+      return;
+    }
+    // ------------------------------------------------------------------- GATHER wavefronts: one a SIMD
+    // The residual rows -- 2.3 MB a chunk from HBM at 256 dimensions and 0.3 % divergence, every load a DRAM round trip -- of the 16
+    // sequences 16 gq .. 16 gq + 15 of a chunk, once its MFMAs are done: every sequence's rows added in list (= window) order, lane = two
+    // columns of a pass of 128, and the sums ADDED to what the MFMA wavefronts left in the sequence's slot.  SIXTEEN 16-byte loads are in
+    // flight a wavefront THE WHOLE TIME: a ring of sixteen registers, slot u of revolution r + 1 asked for as soon as slot u of revolution
+    // r is added.  A revolution is 16 / W entries of one sequence x W passes (W = up to four passes of 128 columns: one row number serves
+    // W consecutive kilobytes of its row), the sequences' pass-groups one after the other; a sequence's 64 entries around the issuing
+    // revolution sit in a register (lane = entry), the next sequence's are asked for a sequence ahead; the slot's sums are asked for
+    // with a pass-group's last revolution and added when it is.
+    {
+      const uint32_t gq = cw - 4u;
+      const uint32_t npass = (tv.d_pad + 127u) >> 7;
+      uint32_t n_g = 0;
+      if (!(dbg_in & 64)) __builtin_amdgcn_s_setprio(1);
+      for (;;) {
+        bool got = false;
+        for (;;) {
+          const uint32_t dn = pipe_ld(&s_done);
+          pipe_lds_fence();
+          const uint32_t fl = pipe_ld(&s_full);
+          if ((int32_t)(fl - n_g) > 0) {
+            got = true;
+            break;
+          }
+          if (dn) break;
+          __builtin_amdgcn_s_sleep(8);
+        }
+        if (!got) break;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) pipe_wait(&s_mdone[w], n_g + 1u);  // the chunk's MFMAs are done, their sums in the slots
+        const uint32_t lb = n_g % 3u;
+        const uint32_t sqi = 16u * gq + ((uint32_t)lane & 15u);
+        const uint32_t cntv = s_gcnt[lb][sqi], begv = s_gbeg[lb][sqi];  // lane j (< 16): sequence 16 gq + j
+        const uint64_t slotv = s_slot[lb][sqi];
+        const uint32_t slo = (uint32_t)slotv, shi = (uint32_t)(slotv >> 32);
+        const uint32_t *lbase = lists + (((uint64_t)blockIdx.x * 3 + lb) * 8 + 2u * gq) * kPipeListCap;
+        auto cnt_of = [&](uint32_t j) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)cntv, (int)j); };
+        auto slot_of = [&](uint32_t j) -> uint64_t {
+          return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)shi, (int)j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)slo, (int)j);
+        };
+        auto next_seq = [&](uint32_t j) -> uint32_t {  // the first sequence at or after j that has a slot and entries
+          while (j < 16u && (cnt_of(j) == 0u || slot_of(j) == ~0ull)) ++j;
+          return j;
+        };
+        auto load_ev = [&](uint32_t j, uint32_t blk) -> uint32_t {  // entries 64 blk .. 64 blk + 63 of sequence j, lane = entry
+          const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)begv, (int)j);
+          return __hip_atomic_load(lbase + (uint64_t)(j >> 3) * kPipeListCap + min(b + 64u * blk + (uint32_t)lane, kPipeListCap - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        auto gather = [&](auto Wc) {
+          constexpr uint32_t W = decltype(Wc)::value, E = 16u / W;
+          const uint32_t ngrp = (npass + W - 1u) / W;
+          uint32_t ij = next_seq(0);  // the ISSUING revolution: sequence, pass-group, first entry
+          if (ij >= 16u) return;
+          uint32_t ig = 0, ie0 = 0, icnt = cnt_of(ij);
+          uint32_t ev = load_ev(ij, 0), evj = ij, evb = 0;  // the entries in the register: of sequence evj, block evb
+          uint32_t pj = next_seq(ij + 1u);
+          uint32_t evp = pj < 16u ? load_ev(pj, 0) : 0u;  // ... and of the next sequence, asked for a sequence ahead
+          uint32_t cg = 0, ce0 = 0, ccnt = 0;  // the revolution IN FLIGHT (added next)
+          uint64_t cslot = 0;
+          bool cvalid = false;
+          double2 v[16], acc[W], pv[W];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = make_double2(0.0, 0.0);
+#pragma unroll
+          for (uint32_t w = 0; w < W; ++w) acc[w] = pv[w] = make_double2(0.0, 0.0);
+#pragma unroll 1
+          for (;;) {
+            const bool ivalid = ij < 16u;
+            if (!ivalid && !cvalid) break;
+            if (ivalid && (evj != ij || evb != (ie0 >> 6))) {  // (uniform) another sequence's entries, or a sequence's next 64
+              if (ie0 == 0u && ij == pj) {
+                ev = evp;
+                pj = next_seq(ij + 1u);
+                evp = pj < 16u ? load_ev(pj, 0) : 0u;
+              } else
+                ev = load_ev(ij, ie0 >> 6);
+              evj = ij;
+              evb = ie0 >> 6;
+            }
+            const double *gcol[W];
+#pragma unroll
+            for (uint32_t w = 0; w < W; ++w) gcol[w] = tv.rows + min(128u * (W * ig + w) + 2u * (uint32_t)lane, tv.d_pad - 2u);  // (d_pad is a multiple of 16: a pair of columns is inside or outside)
+#pragma unroll
+            for (uint32_t u = 0; u < 16; ++u) {
+              const uint32_t eo = u / W, w = u % W;
+              const bool cok = cvalid && ce0 + eo < ccnt;  // (uniform)
+              acc[w].x = __dadd_rn(acc[w].x, cok ? v[u].x : 0.0);
+              acc[w].y = __dadd_rn(acc[w].y, cok ? v[u].y : 0.0);
+              const bool iok = ivalid && ie0 + eo < icnt;  // (uniform)
+              const uint32_t rw = (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)((ie0 + eo) & 63u)) & 0x1FFFFFFFu;
+              v[u] = *reinterpret_cast<const double2 *>(gcol[w] + (uint64_t)(iok ? rw : 0u) * tv.d_pad);
+            }
+            if (cvalid && ce0 + E >= ccnt) {  // (uniform) the sequence's last entries of this pass-group: its sums, on top of the slot's
+#pragma unroll
+              for (uint32_t w = 0; w < W; ++w) {
+                const uint32_t col = 128u * (W * cg + w) + 2u * (uint32_t)lane;
+                double *dst = partial + cslot * tv.n_dims + col;
+                if (col < tv.n_dims) dst[0] = __dadd_rn(pv[w].x, acc[w].x);
+                if (col + 1u < tv.n_dims) dst[1] = __dadd_rn(pv[w].y, acc[w].y);
+                acc[w] = make_double2(0.0, 0.0);
+              }
+            }
+            if (ivalid && ie0 + E >= icnt) {  // (uniform) the slot's sums of the pass-group just asked for to its end
+              const uint64_t islot = slot_of(ij);
+#pragma unroll
+              for (uint32_t w = 0; w < W; ++w) {
+                const uint32_t col = 128u * (W * ig + w) + 2u * (uint32_t)lane;
+                const double *src = partial + islot * tv.n_dims + col;
+                pv[w].x = col < tv.n_dims ? src[0] : 0.0;
+                pv[w].y = col + 1u < tv.n_dims ? src[1] : 0.0;
+              }
+            }
+            cvalid = ivalid;
+            cg = ig;
+            ce0 = ie0;
+            ccnt = icnt;
+            if (ivalid) {
+              cslot = slot_of(ij);
+              ie0 += E;
+              if (ie0 >= icnt) {
+                ie0 = 0;
+                if (++ig == ngrp) {
+                  ig = 0;
+                  ij = next_seq(ij + 1u);
+                  if (ij < 16u) icnt = cnt_of(ij);
+                }
+              }
+            }
           }
         };
-        uint32_t b0 = 0;
-#pragma unroll 1
-        for (; b0 + 4u < nb; b0 += 4) four_blocks(b0);  // (nb is a multiple of four)
-        // what the producers left in the slots -- the sequences' residual rows, summed -- asked for under the last four blocks
-        // (rows g4 + 4 rr of accumulator tile t = sequence 16 t + g4 + 4 rr)
-        double rs[16];
-        uint64_t sl[16];
-#pragma unroll
-        for (uint32_t q = 0; q < 16; ++q) sl[q] = s_slot[buf][16u * (q >> 2) + g4 + 4u * (q & 3u)];
-#pragma unroll
-        for (uint32_t q = 0; q < 16; ++q) rs[q] = (colok && sl[q] != ~0ull) ? partial[sl[q] * tv.n_dims + col] : 0.0;
-        if (nb) four_blocks(b0);
-        // the sums: (the set's rows on the matrix cores) + (the residual rows), straight from the registers
-        if (colok) {
-#pragma unroll
-          for (uint32_t q = 0; q < 16; ++q)
-            if (sl[q] != ~0ull) partial[sl[q] * tv.n_dims + col] = __dadd_rn(acc[q >> 2][q & 3u], rs[q]);
-        }
+        if (npass >= 3u) gather(std::integral_constant<uint32_t, 4>{});
+        else if (npass == 2u) gather(std::integral_constant<uint32_t, 2>{});
+        else gather(std::integral_constant<uint32_t, 1>{});
+        pipe_lds_fence();  // (done with this chunk's lists and slots)
+        ++n_g;
+        if (lane == 0) __hip_atomic_store(&s_gdone[gq], n_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      stamp(9);  // the matrix cores, every slab
-      pipe_lds_fence();  // (done reading this buffer's X, rows and slots)
-      if (lane == 0) __hip_atomic_fetch_add(&s_empty2[mh], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      ++n_conw;
-      stamp(10);
+      return;
     }
-    if (stamps)
-      for (int i = 8; i < 13; ++i) atomicAdd(&g_tile_stamps[i], s_stamp[i]);
-    return;
   }
   const double *trow = tv.rows + min(16u * (uint32_t)ni + c16, tv.d_pad - 1);  // (columns past the twister's are not written below)
   const double *grow = tv.rows + min((uint32_t)lane, tv.n_dims - 1);

@@ -17,7 +17,7 @@ def main():
     kpop_amd.init(0)
     if os.environ.get("DBG"):
         api.tune("dbg", int(os.environ["DBG"]) << 24)
-    k, d, n, L = 12, 64, int(os.environ.get("N", "50000")), 30000
+    k, d, n, L = int(os.environ.get("K", "12")), int(os.environ.get("D", "64")), int(os.environ.get("N", "50000")), int(os.environ.get("L", "30000"))
     dev = torch.device("cuda", 0)
     sp = torch.cuda.current_stream().cuda_stream
     tw = kpop_amd.Twister.synth(0x7457, k, d)
@@ -46,6 +46,9 @@ def main():
             first = out.clone()
             continue
         bad = (first != out).any(dim=1).nonzero().flatten()
+        if len(bad) and os.environ.get("COLS"):
+            r0 = int(bad[0])
+            print("   row %d columns that differ: %s" % (r0, (first[r0] != out[r0]).nonzero().flatten()[:40].tolist()), flush=True)
         rel = float(((first - out).abs().max() / first.abs().max()).item())
         print("call %d: %d rows differ from the first call's (max relative difference %.2e)%s" % (rep, len(bad), rel, (": rows " + str(bad[:12].tolist())) if len(bad) else ""), flush=True)
 
