@@ -106,7 +106,7 @@ struct Context {
   int tune_tilepipe = 1; // assemblies of one organism, up to 64 dimensions: count_twist_tile_pipe_kernel (producer and consumer wavefronts, tile_pipe.h); 0: round 4's count_twist_tile_kernel
   int tune_tilewide = 0; // 1: the slab-by-slab form of that kernel (what more than 64 dimensions get) at any number of dimensions
   int tune_tilecap_mb = 0; // MiB of per-slot tables a call of the slab-by-slab route may take before the batch goes through in sub-batches (0: 4 GiB a slab of 64 columns, a quarter of the device's memory at most)
-  int tune_pipeprio = 0; // issue priority of the slab-by-slab kernel's consumers (producers: 2)
+  int tune_pipeprio = 1; // issue priority of the MFMA wavefronts of the tile kernel beyond 64 dimensions (producers: 2, gather wavefronts: 1); measured 0: 0.410 / 0.433, 1: 0.412 / 0.465, 2: 0.393 / 0.451, 3: 0.393 / 0.445 of the matrix peak at 256 / 1,635 dimensions; | 4: the gather with plain instead of non-temporal loads (no difference)
   int tune_blocksort = 1;  // -L on sequences of up to 32,768 windows: one block per sequence, sorted in LDS (0: device-wide sort)
   int tune_hist = 1;     // merged (-l) spectrum by atomic histogram when the hashes fit 26 bits (0: always sort)
   int tune_histguess = 1; // the merged count's partition path sizes its buckets from a sample of the items (one in 32) instead of a counting pass over all of them; a bucket that overflows sends the call back to the exact count.  0: always the exact count

@@ -36,6 +36,7 @@ constexpr uint32_t kPipeListCap = 8 * kTileS;    // entries of a producer wavefr
 // miss the set are hashed again one by one, not all 64 of a thread.
 constexpr uint32_t kPipeUnits = 33, kPipeRowW = 85;  // dwords of a row: F at 0, R at 33, V at 66; 85 = 21 mod 32: four rows x eight threads' dwords on 32 banks
 constexpr uint32_t kPipeMissLds = 192;  // entries of a producer wavefront's list of missed hashes that stay in LDS until their rows are found (beyond: global)
+constexpr uint32_t kPipePF = 3;         // WIDE: blocks of 16 members the MFMA wavefronts ask for the rows of T ahead (a ring of kPipePF + 1 slots of four rows)
 constexpr uint32_t kPipePrioList = 300;  // a consumer wavefront with more residual rows than this to gather goes ahead of the producers (s_setprio)
 constexpr size_t kPipeLdsBytes = (size_t)2 * kPipeG * kPipeXW * 4 + (size_t)kTileH * 8 + (size_t)2 * kTileSetCap * 4 + (size_t)kPipeG * kPipeRowW * 4 +
                                  (size_t)8 * kPipeMissLds * 4;
@@ -845,59 +846,93 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
         const uint32_t UP = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_U[buf]), nb = UP / 16u;
         const uint32_t *uc = ucol + buf * kTileSetCap + 4u * g4;
         const uint32_t *xa = Xw + buf * G * XW + c16 * XW + g4;  // tile t: 16 t rows on
-#pragma unroll 1
-        for (uint32_t unit = cw; unit < nunits; unit += 4u) {
-          const uint32_t col = 16u * unit + c16;
-          const double *trow = tv.rows + col;
-          f64x4 acc[4];
+        // The wavefront's units (cw, cw + 4, ...) x the set's blocks of 16 members are ONE run of blocks: the rows of T are asked for
+        // kPipePF blocks ahead ACROSS the units' ends (a load of a member's row from an XCD's L2 under everybody's traffic takes some
+        // 1.2 us -- three blocks of MFMAs, the distance up to 64 dimensions, covered half of it; and a prologue a unit was 6 % of a unit).
+        const uint32_t n_my = cw < nunits ? (nunits - cw + 3u) / 4u : 0u;
+        const uint32_t total = n_my * nb;
+        uint32_t col = 16u * cw + c16;                   // the unit being multiplied: its column of this lane
+        uint32_t bcur = 0;                               // ... the block of it
+        uint32_t pb = 0, punit = cw;                     // the block being asked for, its unit
+        const double *ptrow = tv.rows + min(col, tv.d_pad - 1u);
+        f64x4 acc[4];
 #pragma unroll
-          for (uint32_t t = 0; t < 4; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
-          double bs[4][4];
-          uint32_t a[4] = {0u, 0u, 0u, 0u};
-          uint4 uqn = make_uint4(0u, 0u, 0u, 0u);
-          auto load_rows = [&](double (&dst)[4], const uint4 u) {
-            dst[0] = trow[(uint64_t)u.x << 4];
-            dst[1] = trow[(uint64_t)u.y << 4];
-            dst[2] = trow[(uint64_t)u.z << 4];
-            dst[3] = trow[(uint64_t)u.w << 4];
-          };
-          if (nb) {
+        for (uint32_t t = 0; t < 4; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+        double bs[kPipePF + 1][4];
+        uint32_t a[4] = {0u, 0u, 0u, 0u};
+        uint4 uqn = make_uint4(0u, 0u, 0u, 0u);
+        auto ask = [&](double (&dst)[4]) {  // the rows of block pb of unit punit (uqn: its members), then on to the next block
+          dst[0] = ptrow[(uint64_t)uqn.x << 4];
+          dst[1] = ptrow[(uint64_t)uqn.y << 4];
+          dst[2] = ptrow[(uint64_t)uqn.z << 4];
+          dst[3] = ptrow[(uint64_t)uqn.w << 4];
+          ++pb;
+          const bool wrap = pb >= nb, more = punit + 4u < nunits;  // (uniform; past the last unit the last one's rows are asked for again)
+          pb = wrap ? 0u : pb;
+          ptrow += (wrap && more) ? 64 : 0;
+          punit += (wrap && more) ? 4u : 0u;
+          uqn = *reinterpret_cast<const uint4 *>(uc + 16u * pb);
+        };
+        if (total) {
+          uqn = *reinterpret_cast<const uint4 *>(uc);
 #pragma unroll
-            for (uint32_t s = 0; s < 3; ++s) load_rows(bs[s], *reinterpret_cast<const uint4 *>(uc + 16u * min(s, nb - 1u)));
-            uqn = *reinterpret_cast<const uint4 *>(uc + 16u * min(3u, nb - 1u));
+          for (uint32_t s = 0; s < kPipePF; ++s) ask(bs[s]);
 #pragma unroll
-            for (uint32_t t = 0; t < 4; ++t) a[t] = xa[16u * t * XW];
-          }
-#pragma unroll 1
-          for (uint32_t b0 = 0; b0 < nb; b0 += 4) {  // (nb is a multiple of four; no branch inside the four blocks: see the other consumers)
-#pragma unroll
-            for (uint32_t s = 0; s < 4; ++s) {
-              const uint32_t b = b0 + s;
-              load_rows(bs[(s + 3u) & 3u], uqn);  // block b + 3's rows of T
-              uqn = *reinterpret_cast<const uint4 *>(uc + 16u * min(b + 4u, nb - 1u));
-              const uint32_t bx = min(b + 1u, nb - 1u);
-              uint32_t an[4];
-#pragma unroll
-              for (uint32_t t = 0; t < 4; ++t) an[t] = xa[16u * t * XW + 4u * bx];
-#pragma unroll
-              for (uint32_t j = 0; j < 4 && !(dbg & 1); ++j) {
-#pragma unroll
-                for (uint32_t t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(byte_f64w(a[t], j), bs[s][j], acc[t], 0, 0, 0);
-              }
-#pragma unroll
-              for (uint32_t t = 0; t < 4; ++t) a[t] = an[t];
-            }
-          }
-          // the sums of the set's rows, straight from the registers (rows g4 + 4 rr of accumulator tile t = sequence 16 t + g4 + 4 rr);
-          // the gather wavefronts add the residual rows' to them
-          if (col < tv.n_dims) {
-#pragma unroll
-            for (uint32_t q = 0; q < 16; ++q) {
-              const uint64_t sl = s_slot[lb][16u * (q >> 2) + g4 + 4u * (q & 3u)];
-              if (sl != ~0ull) partial[sl * tv.n_dims + col] = acc[q >> 2][q & 3u];
-            }
-          }
+          for (uint32_t t = 0; t < 4; ++t) a[t] = xa[16u * t * XW];
         }
+        auto blocks4 = [&](auto phase) {  // four blocks, the ring's slots known at compile time (no branch inside: see the other consumers)
+          constexpr uint32_t P = decltype(phase)::value;
+#pragma unroll
+          for (uint32_t s = 0; s < 4; ++s) {
+            constexpr uint32_t R = kPipePF + 1u;
+            const uint32_t slot = (P + s) % R, pslot = (P + s + kPipePF) % R;
+            ask(bs[pslot]);
+            const uint32_t bx = bcur + 1u >= nb ? 0u : bcur + 1u;
+            uint32_t an[4];
+#pragma unroll
+            for (uint32_t t = 0; t < 4; ++t) an[t] = xa[16u * t * XW + 4u * bx];
+#pragma unroll
+            for (uint32_t j = 0; j < 4 && !(dbg & 1); ++j) {
+#pragma unroll
+              for (uint32_t t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(byte_f64w(a[t], j), bs[slot][j], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < 4; ++t) a[t] = an[t];
+            bcur = bx;
+          }
+          if (bcur == 0u) {  // (uniform) the unit's last block: its sums of the set's rows, straight from the registers (rows g4 + 4 rr of
+                             // accumulator tile t = sequence 16 t + g4 + 4 rr); the gather wavefronts add the residual rows' to them
+            if (col < tv.n_dims) {
+#pragma unroll
+              for (uint32_t q = 0; q < 16; ++q) {
+                const uint64_t sl = s_slot[lb][16u * (q >> 2) + g4 + 4u * (q & 3u)];
+                if (sl != ~0ull) partial[sl * tv.n_dims + col] = acc[q >> 2][q & 3u];
+              }
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < 4; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+            col += 64u;
+          }
+        };
+        static_assert((kPipePF + 1u) % 4u == 0u, "the ring of rows is whole groups of four blocks");
+        {
+          uint32_t L = 0;
+#pragma unroll 1
+          for (; L + (kPipePF + 1u) <= total; L += kPipePF + 1u) {
+            blocks4(std::integral_constant<uint32_t, 0>{});
+            if constexpr (kPipePF + 1u >= 8u) blocks4(std::integral_constant<uint32_t, 4>{});
+          }
+          if (L < total) blocks4(std::integral_constant<uint32_t, 0>{});  // (total is a multiple of four: nb is)
+        }
+        if (nb == 0u)  // (uniform) a set without a single row in the twister: the slots still start from zero
+          for (uint32_t unit = cw; unit < nunits; unit += 4u) {
+            const uint32_t c = 16u * unit + c16;
+            if (c < tv.n_dims)
+              for (uint32_t q = 0; q < 16; ++q) {
+                const uint64_t sl = s_slot[lb][16u * (q >> 2) + g4 + 4u * (q & 3u)];
+                if (sl != ~0ull) partial[sl * tv.n_dims + c] = 0.0;
+              }
+          }
         stamp(9);  // the matrix cores, every unit
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the sums are the gather wavefronts' to read)
         pipe_lds_fence();  // (done reading this buffer's X, rows and slots)
