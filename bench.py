@@ -608,6 +608,76 @@ def config3_leg(R):
         api.tune("dense", 2)
     res["one_organism_0.3pct"]["streaming_kernel_alone_ms"] = ms0
     res["one_organism_0.3pct"]["speedup_over_streaming_kernel"] = ms0 / ms
+    # ... and the same batch through twisters of more dimensions: beyond 64 the tile kernel takes the columns unit by unit in three stages
+    # a block (tile_pipe.h, WIDE) -- at 256 dimensions and at the 1,635 of the reference's own large run (README.md:1029; k = 10 as there)
+    dims = {str(d): {"k": k, "ms": ms, "roofline": dict(res["one_organism_0.3pct"]["roofline"]), "streaming_kernel_alone_ms": ms0, "speedup_over_streaming_kernel": ms0 / ms}}
+    del out
+    for kk, dd in ((12, 256), (10, 1635)):
+        free, _ = t.cuda.mem_get_info(R.dev)
+        need = ((4 ** kk) // 2) * dd * 8 * 1.05 + windows / 512.0 * dd * 8 * 1.1 + 6e9
+        if free < need:
+            dims[str(dd)] = {"k": kk, "skipped": "needs %.0f GB of free HBM, %.1f GB free" % (need / 1e9, free / 1e9)}
+            continue
+        tw = R.kpop.Twister.synth(TWISTER_SEED, kk, dd)
+        try:
+            outd = t.zeros(n, dd, dtype=t.float64, device=R.dev)
+            calld = lambda: api.dev_count_twist(tw, bases.data_ptr(), offs.data_ptr(), n, n * L, L, outd.data_ptr(), stream=R.sp)
+            msd, alld = _event_ms(R, calld, 3, 1)
+            api.debug_counters(16)
+            api.tune("dbg", 32 << 24)
+            calld()
+            cnt = api.debug_counters(16)
+            api.tune("dbg", 0)
+            fl = 2.0 * 64 * dd * cnt[15]
+            api.tune("dense", 0)
+            try:
+                ms0d, _ = _event_ms(R, calld, 1, 1)
+            finally:
+                api.tune("dense", 2)
+            dims[str(dd)] = {
+                "k": kk, "ms": msd, "ms_all": alld, "twister_GB": tw.info()["device_bytes"] / 1e9,
+                "roofline": {"kernel": "count_twist_tile_pipe_kernel", "bound": "mfma", "achieved": fl / (msd * 1e-3) / 1e12, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": fl / (msd * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS, "traffic": None, "algorithmic_flops_per_launch": fl, "avg_launch_ms": msd,
+                             "chunks_taken": cnt[14], "set_rows_multiplied": cnt[15],
+                             "residual_rows_GB": (windows * 0.036) * dd * 8 / 1e9,
+                             "note": "flops as for 64 dimensions (2 x 64 x D x set rows multiplied), over the whole call. At 0.3 % substitutions 3.6 % of the windows "
+                                     "are private to their sequence: their rows (residual_rows_GB, D x 8 bytes each) come from HBM whatever the scheme -- 0.095 B per "
+                                     "flop of the consensus where the machine has 0.064 (5 TB/s of gathered rows : 78.6 TFLOP/s): the HBM gather, not the matrix "
+                                     "pipe, bounds this route at 0.6-0.67 of the matrix peak"},
+                "streaming_kernel_alone_ms": ms0d, "speedup_over_streaming_kernel": ms0d / msd}
+            del outd
+        finally:
+            tw.free()
+        t.cuda.empty_cache()
+    res["one_organism_dims"] = dims
+    return res
+
+
+def dims_sweep(R):
+    """SURVEY 8(d)'s sweep of the headline reads kernel over D in {9, 64, 256, 1635}: 100,000 x 150 bp, the fused count->twist alone
+    (k = 12 up to 256 dimensions; k = 10 at 1,635, where a k = 12 twister would be 110 GB -- 6.9 GB is still 27 Infinity Caches)"""
+    t, api = R.torch, R.api
+    n, L = 100000, 150
+    bases = t.empty(n * L, dtype=t.uint8, device=R.dev)
+    offs = t.empty(n + 1, dtype=t.int64, device=R.dev)
+    api.dev_synth_reads(READ_SEED, n, L, bases.data_ptr(), offs.data_ptr(), stream=R.sp)
+    res = {"workload": "%d reads x %d bp, the fused count->twist kernel alone, by the twister's dimensions" % (n, L)}
+    for k, d in ((12, 9), (12, 64), (12, 256), (10, 1635)):
+        tw = R.kpop.Twister.synth(TWISTER_SEED, k, d)
+        try:
+            out = t.zeros(n, d, dtype=t.float64, device=R.dev)
+            ms, _ = _event_ms(R, lambda: api.dev_count_twist(tw, bases.data_ptr(), offs.data_ptr(), n, n * L, L, out.data_ptr(), stream=R.sp), 10, 2)
+            w = L - k + 1
+            alg = n * (L + w * d * 8 + d * 8)
+            line_b = max(128, ((d + 15) // 16) * 128)  # what a row costs the memory system: whole 128-byte lines of its d_pad x 8 bytes
+            res[str(d)] = {"k": k, "ms": ms, "twister_GB": tw.info()["device_bytes"] / 1e9,
+                           "roofline": {"kernel": "count_twist_wave_kernel", "bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms,
+                                        "line_bytes_per_launch": n * w * line_b}}
+            del out
+        finally:
+            tw.free()
+        t.cuda.empty_cache()
     return res
 
 
@@ -671,7 +741,7 @@ def leg_traffic(R, roofline, **kw):
 
 def extra_configs(R):
     legs = {}
-    for name, fn in (("config2_on_this_gpu", config2_leg), ("config3_on_this_gpu", config3_leg), ("config5_on_this_gpu", config5_leg)):
+    for name, fn in (("config2_on_this_gpu", config2_leg), ("config3_on_this_gpu", config3_leg), ("dims_sweep", dims_sweep), ("config5_on_this_gpu", config5_leg)):
         t0 = time.perf_counter()
         try:
             legs[name] = fn(R)
@@ -686,10 +756,18 @@ def extra_configs(R):
             ("config3_on_this_gpu", "unrelated_genomes", dict(n_reads=50000, k=R.args.k, dims=R.args.dims, read_len=30000, kernel="count_twist_stream_kernel", launches=2, timeout=400)),
             ("config3_on_this_gpu", "one_organism_0.3pct", dict(n_reads=50000, k=R.args.k, dims=R.args.dims, read_len=30000, kernel="count_twist_tile_pipe_kernel", launches=2,
                                                                 mutants=0.003, timeout=400)),
+            ("config3_on_this_gpu", ("one_organism_dims", "256"), dict(n_reads=50000, k=12, dims=256, read_len=30000, kernel="count_twist_tile_pipe_kernel", launches=2,
+                                                                        mutants=0.003, timeout=400)),
+            ("config3_on_this_gpu", ("one_organism_dims", "1635"), dict(n_reads=50000, k=10, dims=1635, read_len=30000, kernel="count_twist_tile_pipe_kernel", launches=2,
+                                                                         mutants=0.003, timeout=400)),
+            ("dims_sweep", "9", dict(n_reads=100000, k=12, dims=9, read_len=150)),
+            ("dims_sweep", "256", dict(n_reads=100000, k=12, dims=256, read_len=150)),
+            ("dims_sweep", "1635", dict(n_reads=100000, k=10, dims=1635, read_len=150)),
             ("config5_on_this_gpu", None, dict(n_reads=10000, k=15, dims=16, read_len=150)))
     for name, sub, kw in want:
         leg = legs.get(name, {})
-        leg = leg.get(sub, {}) if sub else leg
+        for key in ((sub,) if isinstance(sub, str) else (sub or ())):
+            leg = leg.get(key, {}) if isinstance(leg, dict) else {}
         if isinstance(leg.get("roofline"), dict):
             try:
                 leg_traffic(R, leg["roofline"], **kw)
@@ -1124,6 +1202,10 @@ def main():
                     "config3_unrelated_frac": _get(line, "config3_on_this_gpu", "unrelated_genomes", "roofline", "frac"),
                     "config3_one_organism_ms": _get(line, "config3_on_this_gpu", "one_organism_0.3pct", "ms_per_step"),
                     "config3_one_organism_frac": _get(line, "config3_on_this_gpu", "one_organism_0.3pct", "roofline", "frac"),
+                    "config3_d256_ms": _get(line, "config3_on_this_gpu", "one_organism_dims", "256", "ms"),
+                    "config3_d256_frac": _get(line, "config3_on_this_gpu", "one_organism_dims", "256", "roofline", "frac"),
+                    "config3_d1635_ms": _get(line, "config3_on_this_gpu", "one_organism_dims", "1635", "ms"),
+                    "config3_d1635_frac": _get(line, "config3_on_this_gpu", "one_organism_dims", "1635", "roofline", "frac"),
                     "config4_n1_ms": _get(line, "config4_on_this_gpu", "ms_per_step"),
                     "config4_all_vs_all_s": _get(line, "config4_on_this_gpu", "all_vs_all", "seconds"),
                     "config5_ms": _get(line, "config5_on_this_gpu", "ms_per_step"), "config5_frac": _get(line, "config5_on_this_gpu", "roofline", "frac")}
