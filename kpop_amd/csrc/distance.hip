@@ -1238,6 +1238,11 @@ static int rowwise_block(const double *a, uint32_t r1, const double *b, uint32_t
   return 0;
 }
 
+// distance_mfma.hip: every pair's distance as a tiled contraction on the f64 matrix cores
+bool distance_mfma_applies(int kind, uint32_t r1, uint32_t r2, uint32_t n_dims);
+int launch_distance_rowwise_mfma(int kind, const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims, const double *metric, double p, double *out,
+                                 hipStream_t st);
+
 template <int KIND>
 static int rowwise_impl(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
                         const double *metric, double p, int normalize, void *work, double *out, hipStream_t st,
@@ -1283,6 +1288,8 @@ static int rowwise_impl(const double *m1, uint32_t r1, const double *m2, uint32_
   if (!normalize || r1 >= 128 || (ctx().tune_dbg & 16384)) {
     const double *a, *b;
     KPOP_TRY(prepare_operands<KIND>(m1, r1, m2, r2, n_dims, metric, p, normalize, work, &a, &b, st));
+    // large jobs (the reference's own: 650 K samples x 1,636 classes x 1,635 dimensions, README.md:1054-1060) on the matrix cores
+    if (distance_mfma_applies(KIND, r1, r2, n_dims)) return launch_distance_rowwise_mfma(KIND, a, r1, b, r2, n_dims, metric, p, out, st);
     return rowwise_block<KIND>(a, r1, b, r2, n_dims, metric, p, out, st);
   }
   // norms only; the rowwise kernel divides as it stages the rows

@@ -190,6 +190,121 @@ __global__ __launch_bounds__(256) void distance_rows_mfma_kernel(const double *_
   }
 }
 
+// the reference's chain for one pair, dimension by dimension (lib/Space.ml:182-205; distance.hip)
+template <int KIND>
+__device__ __forceinline__ double exact_pair_rows(const double *__restrict__ arow, const double *__restrict__ brow, const double *__restrict__ metric, uint32_t n_dims, double p) {
+  double acc = 0.0;
+  for (uint32_t c = 0; c < n_dims; ++c) {
+    const double diff = __dsub_rn(arow[c], brow[c]);
+    acc = __dadd_rn(acc, component<KIND>(diff, metric[c], p));
+  }
+  return scale_distance<KIND>(acc, p);
+}
+
+// The same distances for ANY number of dimensions and any two sets of rows, as a tiled contraction: a block takes 128 query rows x 128
+// reference rows, both operands staged through LDS sixteen dimensions at a time (row-major rows, lanes along the dimensions: whole
+// 128-byte lines; the next chunk's loads fly under this chunk's 64 MFMAs a wavefront), a wavefront 64 x 64 = 4 x 4 accumulator tiles.
+// This is what the reference's own large runs are: 650 K samples x 1,636 classes x 1,635 dimensions (README.md:1054-1060), 300
+// neighbours in a database of 650 K x 1,635 (README.md:1101).
+// GUARD (kpop_dev_distance_rowwise: the values themselves are the result): d^2 = |a|^2 + |b|^2 - 2 a.b loses what the two rows have in
+// common to cancellation -- a pair whose d^2~ is below `tau` of |a|^2 + |b|^2 is recomputed with the reference's chain, dimension by
+// dimension (lib/Space.ml:182-205), the others are within (D + 3) 2^-53 / (4 tau) of it, relatively (1.8e-12 at 1,635 dimensions,
+// tau = 0.025; measured: a few 1e-14).  Without it (the summary's rows) the values only LOCATE: see the head of the file.
+constexpr int kDT = 128, kDK = 16, kDS = kDT + 17;  // tile edge, dimensions a chunk, LDS row stride in doubles (odd: the transposed staging's writes spread over the banks)
+
+template <int KIND, bool GUARD>
+__global__ __launch_bounds__(256, 2) void distance_gemm_mfma_kernel(const double *__restrict__ a, uint32_t r1, const double *__restrict__ bm, const double *__restrict__ b,
+                                                                 uint32_t q, uint32_t n_dims, const double *__restrict__ metric, double p,
+                                                                 const double *__restrict__ sa, const double *__restrict__ sb, double *__restrict__ out,
+                                                                 uint32_t tiles_m, uint32_t tiles_n, int m_fast, double tau) {
+  __shared__ double Qs[kDK][kDS];  // [dimension][query row of the tile]
+  __shared__ double Rs[kDK][kDS];  // [dimension][reference row of the tile]
+  // Workgroups are dealt to the eight XCDs in turn; the blocks of one XCD take a contiguous run of tiles, decoded with the short
+  // side fastest: the tiles that share a panel are neighbours in time on ONE L2.
+  uint32_t wgid = blockIdx.x;
+  {
+    const uint32_t nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
+    wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
+  }
+  const uint32_t bx = m_fast ? wgid % tiles_m : wgid / tiles_n;  // query tile
+  const uint32_t by = m_fast ? wgid / tiles_m : wgid % tiles_n;  // reference tile
+  const uint32_t m0 = bx * kDT, n0 = by * kDT;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
+  f64x4m acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f64x4m{0.0, 0.0, 0.0, 0.0};
+  constexpr int kQ = kDK / 2;  // loads a thread, panel and chunk
+  double rq[kQ], rr[kQ];
+  const uint32_t kk = threadIdx.x & (kDK - 1), rbase = threadIdx.x / kDK;  // the thread's dimension of a chunk, its first row of a panel
+  // (unconditional loads from addresses clamped into the operands, what lies outside zeroed afterwards: predicated loads each wait for themselves)
+  auto prefetch = [&](uint32_t k0) {
+#pragma unroll
+    for (int u = 0; u < kQ; ++u) {
+      const uint32_t row = rbase + (256 / kDK) * u, c = min(k0 + kk, n_dims - 1u);
+      rq[u] = bm[(uint64_t)min(m0 + row, q - 1u) * n_dims + c];
+      rr[u] = a[(uint64_t)min(n0 + row, r1 - 1u) * n_dims + c];
+    }
+#pragma unroll
+    for (int u = 0; u < kQ; ++u) {
+      const uint32_t row = rbase + (256 / kDK) * u;
+      const bool in = k0 + kk < n_dims;
+      rq[u] = (in && m0 + row < q) ? rq[u] : 0.0;
+      rr[u] = (in && n0 + row < r1) ? rr[u] : 0.0;
+    }
+  };
+  prefetch(0);
+  for (uint32_t k0 = 0; k0 < n_dims; k0 += kDK) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kQ; ++u) {
+      Qs[kk][rbase + (256 / kDK) * u] = rq[u];
+      Rs[kk][rbase + (256 / kDK) * u] = rr[u];
+    }
+    __syncthreads();
+    if (k0 + kDK < n_dims) prefetch(k0 + kDK);
+#pragma unroll
+    for (int ks = 0; ks < kDK; ks += 4) {
+      double fa[4], fb[4];
+      const int kr = ks + (lane >> 4), c = lane & 15;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fa[t] = Qs[kr][wm + t * 16 + c];
+        fb[t] = Rs[kr][wn + t * 16 + c];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // lane holds query rows (l >> 4) + 4 r of accumulator tile i, reference row l & 15 of tile j
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t col = n0 + wn + j * 16 + (lane & 15);
+    const double sai = sa[min(col, r1 - 1u)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t row = m0 + wm + i * 16 + (lane >> 4) + 4 * r;
+        if (row < q && col < r1) {
+          const double sbj = sb[row];
+          double u = sai + sbj - 2.0 * acc[i][j][r];
+          u = u > 0.0 ? u : 0.0;
+          double d;
+          if (GUARD && u < tau * (sai + sbj))
+            d = exact_pair_rows<KIND>(a + (uint64_t)col * n_dims, b + (uint64_t)row * n_dims, metric, n_dims, p);
+          else
+            d = KIND == KPOP_EUCLIDEAN ? (GUARD ? sqrt(u) : sqrt_fast(u)) : u * 0.5;
+          out[(uint64_t)row * r1 + col] = d;
+        }
+      }
+  }
+}
+
 // the RowCounts of summary_large.hip as this file sees them: 48 bytes a row, `fail` the tenth word
 constexpr uint32_t kRowCountsWords = 12, kRowCountsFail = 9;
 constexpr uint32_t kRefNb = 3072, kRefMed = 1024, kRefMad = 2048;  // room of the three bands (rows of the reference set)
@@ -225,10 +340,12 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
   if (rc[(uint64_t)jl * kRowCountsWords + kRowCountsFail]) return;  // (already the fall-back's)
   const double *row = rows + (uint64_t)jl * r1;
   const double *brow = b + (uint64_t)jl * n_dims;
-  for (uint32_t c = threadIdx.x; c < n_dims; c += 1024) {
+  const bool staged = n_dims <= 128;  // (beyond: the query row and the metric from memory -- L2 hits: every thread reads the same few KB)
+  for (uint32_t c = threadIdx.x; staged && c < n_dims; c += 1024) {
     s_b[c] = brow[c];
     s_m[c] = metric[c];
   }
+  const double *qb = staged ? s_b : brow, *qm = staged ? s_m : metric;
   if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   const double mean_a = out_stats[(uint64_t)j * 4 + 0], sd_a = out_stats[(uint64_t)j * 4 + 1], med_a = out_stats[(uint64_t)j * 4 + 2], mad_a = out_stats[(uint64_t)j * 4 + 3];
@@ -362,7 +479,7 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
   // the exact distances of the neighbours' and the median's bands
   double c1 = 0.0, c2 = 0.0;  // what the band's exact values change in sum d and in sum (d - mean)^2
   for (uint32_t e = threadIdx.x; e < n_nb; e += 1024) {
-    const double dx = exact_pair<KIND>(a + (uint64_t)s_nb_i[e] * n_dims, s_b, s_m, n_dims, p), x = row[s_nb_i[e]];
+    const double dx = exact_pair<KIND>(a + (uint64_t)s_nb_i[e] * n_dims, qb, qm, n_dims, p), x = row[s_nb_i[e]];
     s_nb_d[e] = dx;
     c1 += dx - x;
     c2 += (dx - mean_a) * (dx - mean_a) - (x - mean_a) * (x - mean_a);
@@ -376,7 +493,7 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
     s_corr[threadIdx.x >> 6][0] = c1;
     s_corr[threadIdx.x >> 6][1] = c2;
   }
-  for (uint32_t e = threadIdx.x; e < n_med; e += 1024) s_med_d[e] = exact_pair<KIND>(a + (uint64_t)s_med_i[e] * n_dims, s_b, s_m, n_dims, p);
+  for (uint32_t e = threadIdx.x; e < n_med; e += 1024) s_med_d[e] = exact_pair<KIND>(a + (uint64_t)s_med_i[e] * n_dims, qb, qm, n_dims, p);
   __syncthreads();
   // the median: the band's element of rank r_med - n_lt (ranks by counting: the bands are small)
   for (uint32_t e = threadIdx.x; e < n_med; e += 1024) {
@@ -407,7 +524,7 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
   }
   // the MAD: exact deviations of its band from the exact median, the element of rank r_med - n_in
   for (uint32_t e = threadIdx.x; e < n_mad; e += 1024)
-    s_mad_d[e] = fabs(__dsub_rn(exact_pair<KIND>(a + (uint64_t)s_mad_i[e] * n_dims, s_b, s_m, n_dims, p), median));
+    s_mad_d[e] = fabs(__dsub_rn(exact_pair<KIND>(a + (uint64_t)s_mad_i[e] * n_dims, qb, qm, n_dims, p), median));
   __syncthreads();
   for (uint32_t e = threadIdx.x; e < n_mad; e += 1024) {
     const double de = s_mad_d[e];
@@ -487,7 +604,7 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
 // ---- host side ------------------------------------------------------------------------------------------------------------
 bool summary_mfma_applies(int kind, uint32_t r1, uint32_t n_dims, uint32_t keep_at_most, uint32_t max_neighbours) {
   const uint32_t req_len = keep_at_most ? keep_at_most : r1;
-  return ctx().tune_summary_mfma != 0 && (kind == KPOP_EUCLIDEAN || kind == KPOP_COSINE) && n_dims >= 4 && n_dims <= 128 && r1 >= 65536 &&
+  return ctx().tune_summary_mfma != 0 && (kind == KPOP_EUCLIDEAN || kind == KPOP_COSINE) && n_dims >= 4 && n_dims < 32768 && r1 >= 65536 &&
          req_len <= max_neighbours && max_neighbours <= 2048;
 }
 // room for: the query rows times the metric, the two sets of norms, the largest of them, the fall-back's flags and its count
@@ -531,6 +648,13 @@ static int launch_rows_mfma(const double *a, uint32_t r1, const double *b, uint3
                             hipStream_t st) {
   row_sumsq_kernel<<<dim3(std::min(div_up(q, 16), 4096u)), dim3(256), 0, st>>>(b, q, n_dims, metric, M.sb, M.bm, nullptr);
   KPOP_LAUNCH_CHECK();
+  if (n_dims > 128) {  // the tiled contraction (any number of dimensions): 128 query rows x 128 reference rows a block
+    const uint32_t tiles_m = div_up(q, (uint32_t)kDT), tiles_n = div_up(r1, (uint32_t)kDT);
+    distance_gemm_mfma_kernel<KIND, false><<<dim3(tiles_m * tiles_n), dim3(256), 0, st>>>(a, r1, M.bm, b, q, n_dims, metric, 2.0, M.sa, M.sb, rows, tiles_m, tiles_n,
+                                                                                           tiles_m <= 16 ? 1 : 0, 0.0);
+    KPOP_LAUNCH_CHECK();
+    return 0;
+  }
   // every block resident at once (three a CU for up to 64 dimensions, two beyond), each an equal run of tiles
   const uint32_t n_tiles = div_up(r1, 16);
   const bool small = n_dims <= 64;
@@ -543,6 +667,34 @@ static int launch_rows_mfma(const double *a, uint32_t r1, const double *b, uint3
     distance_rows_mfma_kernel<KIND, 16, 2><<<grid, dim3(256), 0, st>>>(a, r1, M.bm, q, n_dims, M.sa, M.sb, rows, tpb);
   else
     distance_rows_mfma_kernel<KIND, 32, 4><<<grid, dim3(256), 0, st>>>(a, r1, M.bm, q, n_dims, M.sa, M.sb, rows, tpb);
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
+
+// kpop_dev_distance_rowwise on the matrix cores (euclidean / cosine, operands already divided by their norms where the caller asked):
+// out[j][i] for every pair, the pairs near enough for cancellation to show recomputed with the reference's chain (GUARD above)
+bool distance_mfma_applies(int kind, uint32_t r1, uint32_t r2, uint32_t n_dims) {
+  return ctx().tune_distance_mfma != 0 && (kind == KPOP_EUCLIDEAN || kind == KPOP_COSINE) && n_dims >= 16 && n_dims < 32768 && r1 >= 64 && r2 >= 64 &&
+         (uint64_t)r1 * r2 * n_dims >= (1ull << 32);
+}
+double distance_mfma_tau(uint32_t n_dims) { return std::min(0.5, std::max(1.0 / 16.0, (double)(n_dims + 3) * 1.11e-4)); }
+int launch_distance_rowwise_mfma(int kind, const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims, const double *metric, double p, double *out,
+                                 hipStream_t st) {
+  void *ws = nullptr;
+  KPOP_TRY(ctx().ws_for(st).ensure(summary_mfma_scratch_bytes(r2, r1, n_dims) + 512, &ws));
+  const MfmaScratch M = carve_mfma(ws, r2, r1, n_dims);
+  row_sumsq_kernel<<<dim3(std::min(div_up(r1, 16), 4096u)), dim3(256), 0, st>>>(a, r1, n_dims, metric, M.sa, nullptr, nullptr);
+  KPOP_LAUNCH_CHECK();
+  row_sumsq_kernel<<<dim3(std::min(div_up(r2, 16), 4096u)), dim3(256), 0, st>>>(b, r2, n_dims, metric, M.sb, M.bm, nullptr);
+  KPOP_LAUNCH_CHECK();
+  const uint32_t tiles_m = div_up(r2, (uint32_t)kDT), tiles_n = div_up(r1, (uint32_t)kDT);
+  if ((uint64_t)tiles_m * tiles_n >= (1ull << 31)) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "distance_rowwise: %u x %u tiles", tiles_m, tiles_n);
+  const double tau = distance_mfma_tau(n_dims);
+  const int m_fast = tiles_m <= tiles_n ? 1 : 0;  // (the shorter side fastest: its panel stays in the L2s)
+  if (kind == KPOP_EUCLIDEAN)
+    distance_gemm_mfma_kernel<KPOP_EUCLIDEAN, true><<<dim3(tiles_m * tiles_n), dim3(256), 0, st>>>(a, r1, M.bm, b, r2, n_dims, metric, p, M.sa, M.sb, out, tiles_m, tiles_n, m_fast, tau);
+  else
+    distance_gemm_mfma_kernel<KPOP_COSINE, true><<<dim3(tiles_m * tiles_n), dim3(256), 0, st>>>(a, r1, M.bm, b, r2, n_dims, metric, p, M.sa, M.sb, out, tiles_m, tiles_n, m_fast, tau);
   KPOP_LAUNCH_CHECK();
   return 0;
 }

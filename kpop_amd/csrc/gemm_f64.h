@@ -26,7 +26,7 @@ constexpr int kGS = kGT + 17;  // LDS row stride in doubles (odd: transposed sta
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
 template <bool TRANS_A>
-__global__ __launch_bounds__(256) void gemm_f64_mfma_kernel(const double *__restrict__ A, uint64_t lda,
+__global__ __launch_bounds__(256, 2) void gemm_f64_mfma_kernel(const double *__restrict__ A, uint64_t lda,
                                                             const double *__restrict__ B, uint64_t ldb,
                                                             double *__restrict__ C, uint64_t ldc, uint32_t M, uint32_t N,
                                                             uint64_t K, uint64_t k_per_split, int upper_only,

@@ -606,11 +606,12 @@ def test_splits_gaps_golden_and_random(kpop, pyref):
 
 
 @pytest.mark.parametrize("case", ["random", "classes", "near_duplicates", "grid", "offset", "constant"])
-@pytest.mark.parametrize("kind,d", [(0, 64), (1, 64), (0, 12), (0, 100)])
+@pytest.mark.parametrize("kind,d", [(0, 64), (1, 64), (0, 12), (0, 100), (0, 200), (1, 130)])
 def test_distance_summary_on_the_matrix_cores(kpop, oracle, case, kind, d):
     """65,536 reference rows and more, euclidean / cosine: the distances are f64 MFMAs that LOCATE (|a|^2 + |b|^2 - 2 a.b: last
     bits differ from the reference's chain), what is reported -- neighbours, median, MAD -- is recomputed with the chain
-    (distance_mfma.hip).  Exact against the oracle and bit for bit against the vector-pipe path (kpop_tune("summary_mfma", 0)),
+    (distance_mfma.hip; beyond 128 dimensions -- 200, 130 here -- the tiled contraction, 128 x 128 rows a block, any number of dimensions).
+    Exact against the oracle and bit for bit against the vector-pipe path (kpop_tune("summary_mfma", 0)),
     where cancellation bites included: reference rows equal to a query and 1e-12 .. 1e-6 away from it (near_duplicates),
     every row far from the origin (offset: the bands hold too much, the rows go to the fall-back), ties by the thousand
     (grid, constant)"""
@@ -660,6 +661,57 @@ def test_distance_summary_on_the_matrix_cores(kpop, oracle, case, kind, d):
                 assert idx[j, :m].tolist() == idx_o[a:a + m].tolist() and np.array_equal(dist[j, :m], dist_o[a:a + m]), (case, keep, j)
                 if case != "constant":
                     np.testing.assert_allclose(z[j, :m], z_o[a:a + m], rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize("case", ["random", "near_duplicates", "offset", "grid", "constant"])
+@pytest.mark.parametrize("kind,r1,r2,d", [(0, 1636, 2000, 1635), (1, 1636, 1700, 1635), (0, 3000, 8000, 200), (1, 300, 60000, 256)])
+def test_distance_rowwise_on_the_matrix_cores(kpop, oracle, case, kind, r1, r2, d):
+    """kpop_dev_distance_rowwise of 2^32 products and more (the reference's own job: 650 K samples x 1,636 classes x 1,635 dimensions,
+    README.md:1054-1060; lib/Matrix.ml:191-266) as a tiled contraction on the f64 matrix cores: every distance within 1e-12 of the
+    oracle's, relatively -- pairs whose d^2 is a small part of |a|^2 + |b|^2 (rows equal to each other, 1e-12 .. 1e-3 apart, everything
+    far from the origin) recomputed with the reference's chain, i.e. bit for bit; kpop_tune("distance_mfma", 0) gives the
+    vector pipe's bits for every pair"""
+    from kpop_amd import api
+    rng = np.random.RandomState(len(case) * 17 + kind + d)
+    if case == "constant":
+        m1 = np.tile(rng.normal(size=(1, d)), (r1, 1))
+    elif case == "grid":
+        m1 = np.round(rng.normal(size=(r1, d)), 0)
+    else:
+        m1 = rng.normal(size=(r1, d))
+    m2 = rng.normal(size=(r2, d)) if case != "grid" else np.round(rng.normal(size=(r2, d)), 0)
+    if case == "offset":
+        m1 += 1000.0
+        m2 += 1000.0
+    m2[1] = m1[5]
+    if case == "near_duplicates":
+        for t, eps in enumerate((0.0, 1e-12, 1e-9, 1e-6, 1e-3, 0.1, 0.3)):
+            m2[10 + t] = m1[7] * (1.0 + eps * rng.normal(size=d))
+            m2[30 + t] = m1[8 + t] + eps * rng.normal(size=d)
+    metric = oracle.metric_powers(oracle.synth_inertia(d))
+    sub = np.unique(np.concatenate([np.arange(min(r2, 64)), rng.randint(0, r2, size=200)]))  # (the oracle on a sample of the second operand's rows when it is long)
+    for normalize in (True, False) if case in ("random", "near_duplicates") else (True,):
+        got = kpop.distance_rowwise(m1, m2, metric, kind, 2.0, normalize)
+        want = oracle.distance_rowwise(m1, m2[sub], metric, kind, 2.0, normalize)
+        g = got[sub]
+        err = np.abs(g - want) / np.maximum(np.abs(want), 1e-300)
+        err[want == g] = 0.0
+        assert err.max() <= 1e-12, (case, normalize, err.max())
+        assert g[1, 5] == want[1, 5] == 0.0 or sub[1] != 1
+        if case == "offset":
+            assert np.array_equal(g, want)  # (every pair cancels: every pair went through the chain)
+        if case == "near_duplicates":
+            assert np.array_equal(sub[:64], np.arange(64))
+            assert np.array_equal(g[10:15, 7], want[10:15, 7]) and all(g[30 + t, 8 + t] == want[30 + t, 8 + t] for t in range(5))  # (the chain's bits for the pairs that cancel)
+        if r2 <= 8000:
+            api.tune("distance_mfma", 0)
+            try:
+                exact = kpop.distance_rowwise(m1, m2, metric, kind, 2.0, normalize)
+            finally:
+                api.tune("distance_mfma", 1)
+            assert np.array_equal(exact[sub], want)
+            if case == "random":
+                assert not np.array_equal(exact, got)  # (the matrix cores did run)
 
 
 def test_distance_summary_on_the_matrix_cores_in_several_chunks(kpop, oracle):
