@@ -50,8 +50,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["auto", "headline", "config4"], default="auto",
-                    help="auto = headline at 1 GPU, config4 (1M reads, all-gather) beyond")
+    ap.add_argument("--workload", choices=["auto", "headline", "config4", "config5"], default="auto",
+                    help="auto = headline at 1 GPU, config4 (1M reads, all-gather) beyond; config5 = k=15, D=16, 10,000 reads, the twister's k-mer rows "
+                         "sharded over the GPUs and ONE all-reduce of the partial rows (any --gpus; -k / --dims / --reads override)")
     ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto",
                     help="weak: --reads per GPU; strong: --reads in total (auto: weak for headline, strong for config4)")
     ap.add_argument("--reads", type=int, default=0, help="0 = 100,000 (headline) or 1,000,000 (config4)")
@@ -243,6 +244,11 @@ class Rank:
         kpop_amd.init(dev_index)
         self.stream = torch.cuda.current_stream()
         self.sp = self.stream.cuda_stream
+        if args.workload == "config5":  # (its twister is a slice of k-mer rows, built by run_config5; no class vectors)
+            self.tw = None
+            torch.cuda.synchronize()
+            self.startup_s = time.perf_counter() - t_start
+            return
         self.tw = kpop_amd.Twister.synth(TWISTER_SEED, args.k, args.dims)
         k, d, C = args.k, args.dims, args.classes
         cbases = torch.empty(C * args.class_len, dtype=torch.uint8, device=self.dev)
@@ -653,6 +659,73 @@ def config3_leg(R):
     return res
 
 
+def config3_distances_leg(R):
+    """the distance step at the reference's own size (README.md:1054-1060: 650 K samples x 1,636 classes x 1,635 dimensions; :1101: 300
+    neighbours in a database of 650 K x 1,635): kpop_dev_distance_rowwise of 100,000 x 1,636 x 1,635 and kpop_dev_distance_summary of
+    256 x 650,000 x 1,635 on the f64 matrix cores (distance_mfma.hip), beside the vector pipe (kpop_tune(..., 0))"""
+    t, api = R.torch, R.api
+    free, _ = t.cuda.mem_get_info(R.dev)
+    if free < 40e9:
+        return {"skipped": "needs 40 GB of free HBM, %.1f GB free" % (free / 1e9)}
+    g = t.Generator(device=R.dev)
+    g.manual_seed(1)
+    d, r1, r2 = 1635, 1636, 100000
+    res = {"workload": "synthetic rows (standard normal), D = %d, euclidean, distance-normalised, metric random" % d}
+    metric = t.rand(d, dtype=t.float64, device=R.dev, generator=g) + 0.1
+    metric /= metric.sum()
+    m1 = t.randn(r1, d, dtype=t.float64, device=R.dev, generator=g)
+    m2 = t.randn(r2, d, dtype=t.float64, device=R.dev, generator=g)
+    work = t.empty(api.dev_distance_workspace_bytes(r1, r2, d), dtype=t.uint8, device=R.dev)
+    out = t.empty(r2, r1, dtype=t.float64, device=R.dev)
+    call = lambda: api.dev_distance_rowwise(m1.data_ptr(), r1, m2.data_ptr(), r2, d, metric.data_ptr(), work.data_ptr(), out.data_ptr(), stream=R.sp)
+    ms, all_ms = _event_ms(R, call, 3, 1)
+    got = out.clone()
+    api.tune("distance_mfma", 0)
+    try:
+        ms0, _ = _event_ms(R, call, 1, 1)
+    finally:
+        api.tune("distance_mfma", 1)
+    rel = float(((got - out).abs() / out.abs().clamp_min(1e-300)).max())
+    fl = 2.0 * r1 * r2 * d
+    res["distance_rowwise_100k_x_1636"] = {
+        "ms": ms, "ms_all": all_ms, "value": r2 / (ms * 1e-3), "unit": "sequences/sec",
+        "roofline": {"kernel": "distance_gemm_mfma_kernel", "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": fl / (ms * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS, "traffic": None, "algorithmic_flops_per_launch": fl, "avg_launch_ms": ms,
+                     "note": "flops = 2 x rows x rows x D of the contraction a . (b m), over the whole call (both operands' norms and divisions, the contraction, "
+                             "square roots, the pairs that cancel recomputed with the reference's chain)"},
+        "vector_pipe_ms": ms0, "speedup_over_vector_pipe": ms0 / ms, "max_relative_difference_from_the_vector_pipe": rel}
+    del m2, out, got, work
+    t.cuda.empty_cache()
+    r1s, q = 650000, 256
+    db = t.randn(r1s, d, dtype=t.float64, device=R.dev, generator=g)
+    qs = db[t.randperm(r1s, device=R.dev, generator=g)[:q]].clone()
+    work = t.empty(api.dev_distance_workspace_bytes(r1s, q, d), dtype=t.uint8, device=R.dev)
+    K = 304
+    stats = t.zeros(q, 4, dtype=t.float64, device=R.dev)
+    nn = t.zeros(q, dtype=t.int32, device=R.dev)
+    idx = t.zeros(q, K, dtype=t.int32, device=R.dev)
+    dd = t.zeros(q, K, dtype=t.float64, device=R.dev)
+    zz = t.zeros_like(dd)
+    calls = lambda: api.dev_distance_summary(db.data_ptr(), r1s, qs.data_ptr(), q, d, metric.data_ptr(), work.data_ptr(), stats.data_ptr(), nn.data_ptr(),
+                                             idx.data_ptr(), dd.data_ptr(), zz.data_ptr(), keep_at_most=300, max_neighbours=K, stream=R.sp)
+    mss, alls = _event_ms(R, calls, 3, 1)
+    a = [x.clone() for x in (stats, nn, idx, dd)]
+    api.tune("summary_mfma", 0)
+    try:
+        mss0, _ = _event_ms(R, calls, 1, 1)
+    finally:
+        api.tune("summary_mfma", 1)
+    same = bool(t.equal(a[0][:, 2:], stats[:, 2:]) and t.equal(a[1], nn) and t.equal(a[2][:, :300], idx[:, :300]) and t.equal(a[3][:, :300], dd[:, :300]))
+    fls = 2.0 * r1s * q * d
+    res["distance_summary_256_x_650k"] = {
+        "ms": mss, "ms_all": alls, "value": q / (mss * 1e-3), "unit": "query rows/sec", "keep_at_most": 300,
+        "roofline": {"kernel": "distance_gemm_mfma_kernel", "bound": "mfma", "achieved": fls / (mss * 1e-3) / 1e12, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": fls / (mss * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS, "traffic": None, "algorithmic_flops_per_launch": fls, "avg_launch_ms": mss,
+                     "note": "the whole call (norms, contraction, the summary's selection on the approximate rows, the exact refinement) over the contraction's flops"},
+        "vector_pipe_ms": mss0, "speedup_over_vector_pipe": mss0 / mss, "medians_mads_neighbours_same_bits_as_the_vector_pipe": same}
+    return res
+
+
 def dims_sweep(R):
     """SURVEY 8(d)'s sweep of the headline reads kernel over D in {9, 64, 256, 1635}: 100,000 x 150 bp, the fused count->twist alone
     (k = 12 up to 256 dimensions; k = 10 at 1,635, where a k = 12 twister would be 110 GB -- 6.9 GB is still 27 Infinity Caches)"""
@@ -741,7 +814,7 @@ def leg_traffic(R, roofline, **kw):
 
 def extra_configs(R):
     legs = {}
-    for name, fn in (("config2_on_this_gpu", config2_leg), ("config3_on_this_gpu", config3_leg), ("dims_sweep", dims_sweep), ("config5_on_this_gpu", config5_leg)):
+    for name, fn in (("config2_on_this_gpu", config2_leg), ("config3_on_this_gpu", config3_leg), ("config3_distances", config3_distances_leg), ("dims_sweep", dims_sweep), ("config5_on_this_gpu", config5_leg)):
         t0 = time.perf_counter()
         try:
             legs[name] = fn(R)
@@ -1122,12 +1195,191 @@ def in_process(args):
     print(json.dumps(line))
 
 
+def _config5_shape(args):
+    """BASELINE config 5's shape unless the command line says otherwise (-k 12 / --dims 64 are the other workloads' defaults)"""
+    k = 15 if args.k == 12 else args.k
+    d = 16 if args.dims == 64 else args.dims
+    return k, d, args.reads or 10000, args.read_len
+
+
+def _config5_line(args, N, k, d, n, L, elapsed, launcher, sharding, extra):
+    line = {"metric": "sequences/sec count->twist, k=%d, D=%d, %d x %d bp, the twister's k-mer rows over %d GPU(s)" % (k, d, n, L, N),
+            "value": n * args.steps / elapsed, "unit": "sequences/sec", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "value_is": "device-resident; the all-reduce of the partial rows is inside the timed region",
+            "launcher": launcher,
+            "config": {"workload": "BASELINE config 5: %d reads x %d bp, k=%d DNA-ds (%d canonical k-mers), D=%d" % (n, L, k, ((4 ** k) + (2 ** k if k % 2 == 0 else 0)) // 2, d),
+                       "read_len": L, "k": k, "n_dims": d, "sharding": sharding}}
+    line.update(extra)
+    return line
+
+
+def run_config5(R):
+    """BASELINE config 5 for any number of ranks.  N = 1: the whole twister on the GPU (rows also at their hashes when they fit), the fused
+    count->twist.  N > 1: rank r keeps the k-mer rows of hash range r (equal cuts of the hash space, kpop_amd.shard.kmer_slice_bounds;
+    its rows ALSO at their hashes: a window that is another rank's costs nothing, one of its own ONE miss) with the all-ones column
+    that sums `acc`; every rank twists ALL reads against its rows, un-normalised; ONE all-reduce of [n x (D + 1)] f64 (RCCL; through
+    the host under KPOP_BENCH_SHARE_GPU=1), then the division by the reduced acc (lib/Twister.ml:158,177-183)."""
+    t, api, kp, args = R.torch, R.api, R.kpop, R.args
+    from kpop_amd.shard import kmer_slice_bounds
+    k, d, n, L = _config5_shape(args)
+    N = R.world
+    sharded = N > 1 or args.force_dist
+    if R.shared_gpu:
+        api.tune("direct", 0)  # (every rank's tables on ONE GPU: the rows at their hashes would not fit twice)
+    t0 = time.perf_counter()
+    tw = kp.Twister.synth(TWISTER_SEED, k, d, hash_range=kmer_slice_bounds(k, R.rank, N), acc_dim=True) if sharded else kp.Twister.synth(TWISTER_SEED, k, d)
+    t.cuda.synchronize()
+    synth_s = time.perf_counter() - t0
+    info = tw.info()
+    bases = t.empty(n * L, dtype=t.uint8, device=R.dev)
+    offs = t.empty(n + 1, dtype=t.int64, device=R.dev)
+    api.dev_synth_reads(READ_SEED, n, L, bases.data_ptr(), offs.data_ptr(), stream=R.sp)
+    cols = d + 1 if sharded else d
+    part = t.zeros(n, cols, dtype=t.float64, device=R.dev)
+    rows = t.zeros(n, d, dtype=t.float64, device=R.dev)
+    e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+    kms = []
+
+    def step(_i):
+        e0.record(R.stream)
+        api.dev_count_twist(tw, bases.data_ptr(), offs.data_ptr(), n, n * L, L, part.data_ptr(), normalize=not sharded, stream=R.sp)
+        e1.record(R.stream)
+        if not sharded:
+            return
+        if R.shared_gpu:  # gloo: through the host
+            h = part.cpu()
+            R.dist.all_reduce(h)
+            tot = h.to(R.dev)
+        else:
+            tot = part.clone()
+            R.dist.all_reduce(tot)  # RCCL
+        acc = tot[:, d:]
+        t.where(acc != 0, tot[:, :d] / t.where(acc != 0, acc, t.ones_like(acc)), tot[:, :d], out=rows)
+        t.cuda.synchronize()
+        kms.append(e0.elapsed_time(e1))
+    elapsed = R.timed(step, args.steps, args.warmup)
+    if not sharded:
+        t.cuda.synchronize()
+        rows.copy_(part)
+        ms_k, _ = _event_ms(R, lambda: api.dev_count_twist(tw, bases.data_ptr(), offs.data_ptr(), n, n * L, L, part.data_ptr(), stream=R.sp), 10, 1)
+        own_windows = float(n * (L - k + 1))
+    else:
+        ms_k = float(sorted(kms[-args.steps:])[len(kms[-args.steps:]) // 2]) if kms else None
+        own_windows = float(part[:, d].sum().item())  # the windows whose k-mer is one of this rank's rows (its share of acc)
+    row_b = info["n_dims"] * 8
+    alg = n * L + own_windows * row_b + n * cols * 8
+    ranks_windows = R.gather_floats(own_windows)
+    ranks_ms = R.gather_floats(ms_k or 0.0)
+    ranks_bytes = R.gather_floats(float(info["device_bytes"]))
+    ranks_direct = R.gather_floats(float(info.get("direct_bytes", 0)))
+    finite = bool(t.isfinite(rows).all().item()) and bool((rows.abs() < 1.0).all().item())
+    digest = {"sum": float(rows.sum().item()), "sum_of_squares": float((rows * rows).sum().item()), "row0": [float(x) for x in rows[0, :4].tolist()],
+              "row_last": [float(x) for x in rows[n - 1, :4].tolist()]}
+    line = None
+    if R.rank == 0:
+        line = _config5_line(args, N, k, d, n, L, elapsed,
+                             "torch.distributed, one rank per GPU (%s)" % ("gloo through the host: KPOP_BENCH_SHARE_GPU=1, every rank on GPU 0 -- not a scaling number" if R.shared_gpu else "RCCL") if R.use_dist else "one process, no collective",
+                             ("k-mer rows in %d equal cuts of the hash space, every rank twists ALL reads against its rows + the all-ones column; ONE exchange: all-reduce of "
+                              "[%d x %d] f64 partial rows (%.2f MB a rank)" % (N, n, cols, n * cols * 8 / 1e6)) if sharded else "none: the whole twister on one GPU",
+                             {"n_ranks_seen": int(sum(1 for w in ranks_windows if w > 0)) if sharded else 1,
+                              "roofline": {"kernel": "count_twist_wave_kernel", "bound": "hbm", "achieved": alg / (ms_k * 1e-3) / 1e9 if ms_k else None, "peak": HBM_PEAK_GBS,
+                                           "unit": "GB/s", "frac": alg / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_k else None, "traffic": None,
+                                           "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms_k,
+                                           "note": "rank 0's launch: the reads' bytes + one row (%d B) per window whose k-mer is one of the rank's + the partial rows written" % row_b},
+                              "per_rank": {"windows_of_own_kmers": ranks_windows, "count_twist_ms": ranks_ms, "twister_bytes": ranks_bytes, "rows_at_their_hashes_bytes": ranks_direct},
+                              "twister_synth_s": synth_s, "startup_s": R.startup_s,
+                              "rows_finite_and_inside_the_coefficient_range": finite, "rows_digest": digest})
+    tw.free()
+    return line
+
+
+def in_process_config5(args):
+    """`--gpus N --in-process --workload config5`: the same job from ONE process through the C ABI (kpop_init_devices, a slice of the
+    twister a device slot, kpop_dev_count_twist on every slot's stream), the partial rows added on the host in slot order -- the
+    launcher's fall-back when RCCL fails, and what a host without torch.distributed does.  No torch."""
+    import ctypes as C
+    import numpy as np
+    import kpop_amd
+    from kpop_amd import _lib
+    from kpop_amd.shard import kmer_slice_bounds
+    t_start = time.perf_counter()
+    lib = _lib.load()
+    shared = os.environ.get("KPOP_BENCH_SHARE_GPU") == "1"
+    N = args.gpus
+    kpop_amd.init_devices([0] * N if shared else list(range(N)))
+    if shared:
+        kpop_amd.api.tune("direct", 0)
+    k, d, n, L = _config5_shape(args)
+    sharded = N > 1 or args.force_dist
+    cols = d + 1 if sharded else d
+    vp = C.c_void_p
+
+    def dmalloc(nbytes):
+        h = vp()
+        kpop_amd.check(lib.kpop_dev_malloc(C.byref(h), int(max(nbytes, 8))))
+        return h
+    tws, bufs = [], []
+    for s_ in range(N):
+        kpop_amd.use_device(s_)
+        tws.append(kpop_amd.Twister.synth(TWISTER_SEED, k, d, hash_range=kmer_slice_bounds(k, s_, N), acc_dim=True) if sharded else kpop_amd.Twister.synth(TWISTER_SEED, k, d))
+        pb, po, pp = dmalloc(n * L), dmalloc((n + 1) * 8), dmalloc(n * cols * 8)
+        kpop_amd.check(lib.kpop_dev_synth_reads(READ_SEED, n, L, 0, pb, po, None))
+        kpop_amd.check(lib.kpop_synchronize(None))
+        bufs.append((pb, po, pp))
+    host = [np.zeros((n, cols)) for _ in range(N)]
+    rows = np.zeros((n, d))
+    startup_s = time.perf_counter() - t_start
+
+    def step():
+        for s_ in range(N):  # (launches return at once: the slots' kernels run side by side)
+            kpop_amd.use_device(s_)
+            pb, po, pp = bufs[s_]
+            kpop_amd.check(lib.kpop_dev_count_twist(tws[s_].handle, pb, po, n, n * L, L, 0, 0 if sharded else 1, pp, None))
+        for s_ in range(N):
+            kpop_amd.use_device(s_)
+            kpop_amd.check(lib.kpop_memcpy_d2h(host[s_].ctypes.data, bufs[s_][2], host[s_].nbytes))
+        tot = host[0].copy()
+        for s_ in range(1, N):
+            tot += host[s_]
+        if sharded:
+            acc = tot[:, d:]
+            np.divide(tot[:, :d], np.where(acc != 0, acc, 1.0), out=rows)
+        else:
+            rows[:] = tot
+    for _ in range(args.warmup):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    elapsed = time.perf_counter() - t0
+    own = [float(h[:, d].sum()) if sharded else float(n * (L - k + 1)) for h in host]
+    digest = {"sum": float(rows.sum()), "sum_of_squares": float((rows * rows).sum()), "row0": [float(x) for x in rows[0, :4]], "row_last": [float(x) for x in rows[n - 1, :4]]}
+    line = _config5_line(args, N, k, d, n, L, elapsed,
+                         "in-process: one process, kpop_init_devices + kpop_dev_count_twist on every slot, the partial rows added on the host in slot order; no torch.distributed, no RCCL",
+                         ("k-mer rows in %d equal cuts of the hash space; ONE exchange: the [%d x %d] f64 partial rows to the host and their sum" % (N, n, cols)) if sharded else "none",
+                         {"n_ranks_seen": int(sum(1 for w in own if w > 0)) if sharded else 1, "per_rank": {"windows_of_own_kmers": own},
+                          "roofline": {"kernel": "count_twist_wave_kernel", "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                                       "note": "the in-process form times whole steps only (launches on N devices + N downloads + the host's sum)"},
+                          "startup_s": startup_s, "rows_finite_and_inside_the_coefficient_range": bool(np.isfinite(rows).all() and (np.abs(rows) < 1.0).all()), "rows_digest": digest})
+    if shared:
+        line["config"]["rig"] = "KPOP_BENCH_SHARE_GPU=1: every device slot is GPU 0; not a scaling number"
+    if os.environ.get("KPOP_BENCH_FALLBACK_REASON"):
+        line["fallback"] = "in-process after RCCL failure: " + os.environ["KPOP_BENCH_FALLBACK_REASON"]
+    for tw in tws:
+        tw.free()
+    print(json.dumps(line))
+
+
 def main():
     args = parse_args()
     if args.gpus < 1:
         sys.exit("--gpus must be positive")
     if args.in_process:
-        in_process(args)
+        if args.workload == "config5":
+            in_process_config5(args)
+        else:
+            in_process(args)
         return
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
         self_launch(args)  # never returns
@@ -1137,6 +1389,9 @@ def main():
     scaling = args.scaling if args.scaling != "auto" else ("weak" if workload == "headline" else "strong")
     reads = args.reads or (100000 if workload == "headline" else 1000000)
     R = Rank(args)
+    if workload == "config5":
+        R.finish(run_config5(R))
+        return
     k, d, L, C = args.k, args.dims, args.read_len, args.classes
     common_cfg = {"read_len": L, "k": k, "n_dims": d, "n_classes": C, "class_len": args.class_len,
                   "twister": "%d canonical k-mers x %d dims, f64, synthetic, replicated on every GPU" % (R.tw.info()["n_cols"], d)}
@@ -1206,6 +1461,8 @@ def main():
                     "config3_d256_frac": _get(line, "config3_on_this_gpu", "one_organism_dims", "256", "roofline", "frac"),
                     "config3_d1635_ms": _get(line, "config3_on_this_gpu", "one_organism_dims", "1635", "ms"),
                     "config3_d1635_frac": _get(line, "config3_on_this_gpu", "one_organism_dims", "1635", "roofline", "frac"),
+                    "config3_distances_d1635_ms": _get(line, "config3_distances", "distance_rowwise_100k_x_1636", "ms"),
+                    "config3_distances_d1635_frac": _get(line, "config3_distances", "distance_rowwise_100k_x_1636", "roofline", "frac"),
                     "config4_n1_ms": _get(line, "config4_on_this_gpu", "ms_per_step"),
                     "config4_all_vs_all_s": _get(line, "config4_on_this_gpu", "all_vs_all", "seconds"),
                     "config5_ms": _get(line, "config5_on_this_gpu", "ms_per_step"), "config5_frac": _get(line, "config5_on_this_gpu", "roofline", "frac")}

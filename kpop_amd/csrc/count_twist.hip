@@ -264,8 +264,10 @@ __device__ __forceinline__ uint32_t wave_gather_rows_direct(const TwisterView &t
       const uint32_t uu = min(u, nu);  // [nu] is zero padding
       const uint32_t h = s_hash[uu];
       x[j] = s_x[uu];
-      const double *p = base + (uint64_t)h * tv.d_pad;
-      v[j] = (active && u < nu) ? (NT ? __builtin_nontemporal_load(p) : *p) : 0.0;
+      // (a twister that keeps a range of the k-mer rows: a hash outside it is not looked at -- marked as having no row)
+      const bool mine = h >= tv.direct_lo && h < tv.direct_hi;
+      const double *p = base + (uint64_t)(mine ? h - tv.direct_lo : 0u) * tv.d_pad;
+      v[j] = (active && u < nu) ? (mine ? (NT ? __builtin_nontemporal_load(p) : *p) : __longlong_as_double((long long)kDirectAbsent)) : 0.0;
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) {

@@ -30,6 +30,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 struct kpop_twister {
@@ -43,7 +45,8 @@ struct kpop_twister {
   void *d_rsel = nullptr;
   void *d_rblk = nullptr;  // k >= kRankBlockMinK: 64-byte blocks instead of d_rsel (which is then freed once the rows are placed)
   uint64_t *d_sorted_hash = nullptr;
-  double *d_direct = nullptr;  // [4^k][d_pad]: the rows at their hashes (see above), or nullptr
+  double *d_direct = nullptr;  // [direct_hi - direct_lo][d_pad]: the rows at their hashes (see above), or nullptr
+  uint64_t direct_lo = 0, direct_hi = 0;  // the hashes the table covers: all 4^k of them, or the slice of a twister that keeps a range of k-mer rows (kpop_twister_synth_slice)
   uint64_t device_bytes = 0;
   int slot = 0;        // device slot (common.h) whose memory holds the arrays
   bool alias = false;  // a second handle on another twister's arrays (kpop_twister_replicate onto the same GPU): frees nothing
@@ -76,11 +79,13 @@ struct TwisterView {
   int k;
   int hk;
   const double *direct;  // rows at their hashes, or nullptr
+  uint32_t direct_lo, direct_hi;  // ... of hashes direct_lo <= h < direct_hi (a hash outside has no row here)
 };
 
 static inline TwisterView view_of(const kpop_twister *tw) {
   return TwisterView{tw->d_rows, reinterpret_cast<const RankWord *>(tw->d_rsel), reinterpret_cast<const uint4 *>(tw->d_rblk), tw->d_sorted_hash, tw->n_rows,
-                     tw->n_dims, tw->d_pad,                                     tw->k, tw->hk ? tw->hk : tw->k, (tw->hk == 0 || tw->hk == tw->k) ? tw->d_direct : nullptr};
+                     tw->n_dims, tw->d_pad,                                     tw->k, tw->hk ? tw->hk : tw->k, (tw->hk == 0 || tw->hk == tw->k) ? tw->d_direct : nullptr,
+                     (uint32_t)tw->direct_lo, (uint32_t)std::min<uint64_t>(tw->direct_hi, 0xFFFFFFFFull)};
 }
 
 #if defined(__HIPCC__)

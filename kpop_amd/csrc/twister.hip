@@ -161,10 +161,10 @@ static int compact_rank_index(kpop_twister *tw, hipStream_t st) {
   return 0;
 }
 
-// direct[h] = the row of hash h, or the mark of a row that does not exist: a thread an element
-__global__ __launch_bounds__(256) void direct_rows_kernel(TwisterView tv, uint64_t n_hashes, double *__restrict__ direct) {
+// direct[h - lo] = the row of hash h, or the mark of a row that does not exist: a thread an element
+__global__ __launch_bounds__(256) void direct_rows_kernel(TwisterView tv, uint64_t lo, uint64_t n_hashes, double *__restrict__ direct) {
   for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < n_hashes * tv.d_pad; idx += (uint64_t)gridDim.x * 256) {
-    const uint64_t h = idx / tv.d_pad;
+    const uint64_t h = lo + idx / tv.d_pad;
     const uint32_t e = (uint32_t)(idx % tv.d_pad);
     const uint32_t col = lookup_col(tv, h);
     if (col != kNoCol) direct[idx] = tv.rows[(uint64_t)col * tv.d_pad + e];
@@ -172,12 +172,20 @@ __global__ __launch_bounds__(256) void direct_rows_kernel(TwisterView tv, uint64
   }
 }
 
-// the rows once more, at their hashes (twister.h): where that pays and fits
-static int build_direct_rows(kpop_twister *tw, hipStream_t st) {
+// the rows once more, at their hashes (twister.h): where that pays and fits.  [lo, hi): the hashes the twister keeps rows of -- all of
+// them, or the slice of a k-mer-row-sharded twister (a rank of BASELINE config 5's multi-GPU form: a window whose k-mer is another
+// rank's then costs this rank NOTHING, one of its own ONE miss; through the index either cost a line of index first)
+static int build_direct_rows(kpop_twister *tw, hipStream_t st, uint64_t lo = 0, uint64_t hi = ~0ull) {
   const int mode = ctx().tune_direct;  // 2: by the rule below; 1: whenever it fits; 0: never
   if (!mode || tw->k < (mode == 1 ? 1 : kDirectMinK) || tw->k > 15 || tw->d_pad > 32 || !tw->n_rows || (!tw->d_rsel && !tw->d_rblk)) return 0;
-  const uint64_t n_hashes = 1ull << (2 * tw->k), bytes = n_hashes * tw->d_pad * 8;
-  if (mode == 2 && (double)tw->n_rows < 0.45 * (double)n_hashes) return 0;
+  const uint64_t all = 1ull << (2 * tw->k);
+  hi = std::min(hi, all);
+  lo = std::min(lo, hi);
+  const bool slice = lo != 0 || hi != all;
+  const uint64_t n_hashes = hi - lo, bytes = n_hashes * tw->d_pad * 8;
+  if (!n_hashes) return 0;
+  // (a slice: whenever it fits -- the canonical k-mers thin out towards the high hashes, and a rank must not be the slow one for that)
+  if (mode == 2 && !slice && (double)tw->n_rows < 0.45 * (double)n_hashes) return 0;
   size_t free_b = 0, total_b = 0;
   KPOP_HIP(hipMemGetInfo(&free_b, &total_b));
   if ((double)bytes > 0.8 * (double)free_b) return 0;  // (an optimisation: never the reason a twister does not load)
@@ -186,8 +194,10 @@ static int build_direct_rows(kpop_twister *tw, hipStream_t st) {
     tw->d_direct = nullptr;
     return 0;
   }
+  tw->direct_lo = lo;
+  tw->direct_hi = hi;
   TwisterView tv = view_of(tw);
-  direct_rows_kernel<<<dim3((uint32_t)std::min<uint64_t>(div_up(n_hashes * tw->d_pad, 256), 1u << 20)), dim3(256), 0, st>>>(tv, n_hashes, tw->d_direct);
+  direct_rows_kernel<<<dim3((uint32_t)std::min<uint64_t>(div_up(n_hashes * tw->d_pad, 256), 1u << 20)), dim3(256), 0, st>>>(tv, lo, n_hashes, tw->d_direct);
   KPOP_LAUNCH_CHECK();
   KPOP_HIP(hipStreamSynchronize(st));
   tw->device_bytes += bytes;
@@ -225,7 +235,7 @@ extern "C" int kpop_twister_info(const kpop_twister *tw, uint64_t *n_cols, uint3
 
 extern "C" int kpop_twister_direct_bytes(const kpop_twister *tw, uint64_t *bytes) {
   if (!tw || !bytes) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_twister_direct_bytes: null argument");
-  *bytes = tw->d_direct ? (1ull << (2 * tw->k)) * tw->d_pad * 8 : 0;
+  *bytes = tw->d_direct ? (tw->direct_hi - tw->direct_lo) * tw->d_pad * 8 : 0;
   return KPOP_OK;
 }
 
@@ -394,7 +404,7 @@ extern "C" int kpop_twister_synth_slice(uint64_t seed, int k, int content, uint3
   KPOP_LAUNCH_CHECK();
   KPOP_HIP(hipStreamSynchronize(st));
   KPOP_TRY(compact_rank_index(tw, st));
-  if (!acc_dim) KPOP_TRY(build_direct_rows(tw, st));
+  KPOP_TRY(build_direct_rows(tw, st, hash_lo, hash_hi));
   guard.tw = nullptr;
   *out = tw;
   return KPOP_OK;

@@ -79,3 +79,24 @@ def test_config4_reports_exposed_comm_and_startup():
     j = _bench(["--gpus", "2", "--reads", "40000", "--steps", "2", "--warmup", "1", "--queries", "16"], env={"KPOP_BENCH_SHARE_GPU": "1"})
     assert len(j["exposed_comm_ms_per_rank"]) == 2 and len(j["startup_s_per_rank"]) == 2
     assert "4 chunks" in j["config"]["workload"]  # --ag-chunks 0 = max(4, GPUs)
+
+
+def test_config5_the_twisters_rows_over_two_ranks_and_over_two_slots():
+    """`--workload config5` (k-mer rows of the twister sharded, ONE all-reduce of the partial rows) at a k the box holds twice: one
+    GPU whole, two ranks sharing the GPU (gloo through the host), two device slots from one process (--in-process: the launcher's
+    fall-back) -- the same rows to 1e-12 whichever way, both ranks seen"""
+    common = ["--workload", "config5", "-k", "13", "--dims", "16", "--reads", "4000", "--steps", "2", "--warmup", "1"]
+    one = _bench(["--gpus", "1"] + common)
+    two = _bench(["--gpus", "2"] + common, env={"KPOP_BENCH_SHARE_GPU": "1"})
+    slots = _bench(["--gpus", "2", "--in-process"] + common, env={"KPOP_BENCH_SHARE_GPU": "1"})
+    assert one["n_gpus"] == 1 and one["n_ranks_seen"] == 1 and 0.0 < one["roofline"]["frac"] <= 1.0
+    assert two["n_gpus"] == 2 and two["n_ranks_seen"] == 2 and slots["n_ranks_seen"] == 2 and slots["launcher"].startswith("in-process")
+    assert len(two["per_rank"]["windows_of_own_kmers"]) == 2 and abs(sum(two["per_rank"]["windows_of_own_kmers"]) - 4000 * (150 - 13 + 1)) < 0.5
+    for j in (one, two, slots):
+        assert j["rows_finite_and_inside_the_coefficient_range"] is True and "config 5" in j["config"]["workload"]
+    a = one["rows_digest"]
+    for j in (two, slots):
+        b = j["rows_digest"]
+        assert abs(a["sum"] - b["sum"]) <= 1e-12 * max(1.0, abs(a["sum"])) * 100 and abs(a["sum_of_squares"] - b["sum_of_squares"]) <= 1e-12 * a["sum_of_squares"] * 100
+        for x, y in zip(a["row0"] + a["row_last"], b["row0"] + b["row_last"]):
+            assert abs(x - y) <= 1e-12 * max(abs(x), 1e-3)

@@ -328,6 +328,48 @@ def test_kmer_row_sharded_twister(kpop, oracle, k, d, world):
     np.testing.assert_allclose(full.count_twist(bases, offs), want, rtol=1e-12, atol=1e-15)
 
 
+@pytest.mark.parametrize("k,d,world", [(9, 16, 3), (10, 5, 2), (9, 31, 4)])
+def test_a_slice_of_the_twister_keeps_its_rows_at_their_hashes(kpop, oracle, k, d, world):
+    """a k-mer-row shard of up to 32 dimensions (a rank of BASELINE config 5's multi-GPU form) also keeps its rows at the address the
+    hash names, for its own range of hashes: a window whose k-mer is another rank's is not looked at, one of its own costs one
+    miss (kpop_tune("direct", 1) builds the table at any k).  Against the index slice by slice (1e-12: the additions are grouped
+    differently), the same windows counted; the slices' sum against the oracle."""
+    from kpop_amd import api
+    from kpop_amd.shard import kmer_slice_bounds
+    n, L = 400, 150
+    bases, offs = oracle.synth_reads(0x4B506F70, n, L)
+    bases = bases.copy()
+    bases[offs[7]:offs[8]] = ord("N")
+    cols = oracle.enumerate_kmers(k)
+    T = oracle.synth_twister(11, d, cols)
+    h, c, o = oracle.count_reads(bases, offs, k)
+    want = oracle.twist(T, cols, h, c.astype(np.float64), o)
+    total = np.zeros((n, d + 1))
+    for r in range(world):
+        rng_ = kmer_slice_bounds(k, r, world)
+        part = {}
+        for mode in (1, 0):
+            api.tune("direct", mode)
+            try:
+                tw = kpop.Twister.synth(11, k, d, hash_range=rng_, acc_dim=True)
+            finally:
+                api.tune("direct", 2)
+            assert (tw.info()["direct_bytes"] > 0) == (mode == 1)
+            if mode == 1:
+                assert tw.info()["direct_bytes"] == (rng_[1] - rng_[0]) * ((d + 1 + 15) // 16 * 16) * 8  # (its own hashes only, rows padded to 16 doubles)
+            part[mode] = tw.count_twist(bases, offs, normalize=False)
+            tw.free()
+        # (through the index the k-mers of other ranks drop out of the list before the rows are dealt to the lane groups, at their hashes
+        # they stay in it as rows that add nothing: another grouping of the same additions)
+        np.testing.assert_allclose(part[1], part[0], rtol=1e-12, atol=1e-14)
+        assert np.array_equal(part[0][:, -1], part[1][:, -1])  # (the windows counted: integers)
+        total += part[1]
+    acc = total[:, -1:]
+    got = np.where(acc != 0, total[:, :-1] / np.where(acc != 0, acc, 1.0), total[:, :-1])
+    assert np.all(got[7] == 0.0)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-15)
+
+
 def test_row_sharded_pipeline_with_rccl_world_size_1(kpop, oracle):
     """count_twist_row_sharded through torch.distributed's nccl (= RCCL) backend on one rank: the collective path is the
     one N > 1 ranks take; the result must be the plain twist."""
