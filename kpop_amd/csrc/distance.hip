@@ -1324,6 +1324,16 @@ int launch_summary_refine(int kind, const double *rows, const double *a, uint32_
                           const void **row_counts);
 int launch_summary_flagged_rows(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most, uint32_t max_neighbours,
                                 double *out_stats, uint32_t *out_n, uint32_t *out_idx, double *out_dist, double *out_z, const void *flags, hipStream_t st);
+// ... the same without distance rows: the summary's pass inside the contraction (summary_large.hip / distance_mfma.hip)
+bool summary_select_mfma_applies(uint32_t r1, uint32_t keep_at_most);
+int launch_mfma_query_prep(const double *b, uint32_t q, uint32_t r1, uint32_t n_dims, const double *metric, void *scratch, uint32_t q_room, hipStream_t st);
+int launch_rows_mfma_against(int kind, const double *as, const double *sas, uint32_t s, uint32_t q, uint32_t n_dims, double *rows, void *scratch, uint32_t q_room,
+                             uint32_t r1, hipStream_t st);
+int launch_row_sumsq(const double *x, uint32_t rows, uint32_t n_dims, const double *metric, double *out, hipStream_t st);
+int launch_summary_fused_mfma(int kind, const double *a, uint32_t r1, uint32_t n_rows, uint32_t n_dims, const double *srow, uint32_t s, uint32_t row0,
+                              uint32_t keep_at_most, uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx, double *out_dist,
+                              double *out_z, double *seg, uint32_t *seg_i, void *scratch, const void *mscratch, uint32_t q_room, hipStream_t st,
+                              SummaryLists *lists);
 int launch_summary_failed_rows(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most, uint32_t max_neighbours,
                                double *out_stats, uint32_t *out_n, uint32_t *out_idx, double *out_dist, double *out_z, void *scratch,
                                hipStream_t st);
@@ -1341,25 +1351,51 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
     // the distances on the matrix cores, approximately, to LOCATE what the summary reports; what is reported is recomputed with the
     // reference's chain (distance_mfma.hip).  Rows the refinement cannot vouch for: exact distance rows and the one-block-per-row
     // kernel over them, both launched whatever happened and both returning at once when nothing was flagged.
+    // Up to 128 dimensions (kpop_tune("summary_mfma", 2), the default) no approximate row is WRITTEN either: thresholds from the
+    // distances to a sample of the reference rows, then ONE kernel that classifies every distance in the accumulators' registers
+    // (summary_select_mfma_kernel); beyond, and under kpop_tune("summary_mfma", 1), round 5's path: rows, then the summary's pass over them.
+    const bool select = ctx().tune_summary_mfma == 2 && n_dims <= 128 && summary_select_mfma_applies(r1, keep_at_most);
     uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(r2, 2 * budget / ((uint64_t)r1 * 8)));  // (1,024 rows against a million)
     if (chunk > 128) chunk = chunk / 128 * 128;
     void *ws = nullptr;
-    const uint64_t row_bytes = ((uint64_t)chunk * r1 * 8 + 255) & ~255ull;
-    const uint64_t sum_bytes = (summary_large_scratch_bytes(chunk, r1) + 511) & ~255ull;
-    KPOP_TRY(ctx().ws_for(st).ensure(row_bytes + sum_bytes + summary_mfma_scratch_bytes(chunk, r1, n_dims) + 512, &ws));
-    double *rows = reinterpret_cast<double *>(ws);
-    void *scratch = reinterpret_cast<char *>(ws) + row_bytes, *mscratch = reinterpret_cast<char *>(ws) + row_bytes + sum_bytes;
+    const uint32_t s_rows = select ? summary_fused_sample_rows(r1) : 0;
+    const uint64_t row_bytes = ((uint64_t)chunk * r1 * 8 + 255) & ~255ull, segi_bytes = select ? (((uint64_t)chunk * r1 * 4 + 255) & ~255ull) : 0;
+    const uint64_t sum_bytes = (std::max(summary_large_scratch_bytes(chunk, r1), select ? summary_fused_scratch_bytes(chunk, r1) : 0) + 511) & ~255ull;
+    const uint64_t m_bytes = (summary_mfma_scratch_bytes(chunk, r1, n_dims) + 511) & ~255ull;
+    const uint64_t as_bytes = ((uint64_t)s_rows * n_dims * 8 + 255) & ~255ull, sas_bytes = ((uint64_t)s_rows * 8 + 255) & ~255ull,
+                   srow_bytes = ((uint64_t)chunk * s_rows * 8 + 255) & ~255ull;
+    KPOP_TRY(ctx().ws_for(st).ensure(row_bytes + segi_bytes + sum_bytes + m_bytes + as_bytes + sas_bytes + srow_bytes + 512, &ws));
+    char *wp = reinterpret_cast<char *>(ws);
+    double *rows = reinterpret_cast<double *>(wp);
+    uint32_t *seg_i = reinterpret_cast<uint32_t *>(wp + row_bytes);
+    void *scratch = wp + row_bytes + segi_bytes, *mscratch = wp + row_bytes + segi_bytes + sum_bytes;
+    double *a_s = reinterpret_cast<double *>(wp + row_bytes + segi_bytes + sum_bytes + m_bytes);
+    double *sa_s = reinterpret_cast<double *>(wp + row_bytes + segi_bytes + sum_bytes + m_bytes + as_bytes);
+    double *srow = reinterpret_cast<double *>(wp + row_bytes + segi_bytes + sum_bytes + m_bytes + as_bytes + sas_bytes);
     KPOP_TRY(launch_mfma_reference_norms(a, r1, n_dims, metric, mscratch, chunk, st));
+    if (select) {  // the sample of the reference rows and its norms: once a call
+      KPOP_TRY(launch_sample_gather(a, r1, n_dims, s_rows, a_s, st));
+      KPOP_TRY(launch_row_sumsq(a_s, s_rows, n_dims, metric, sa_s, st));
+    }
     for (uint32_t q0 = 0; q0 < r2; q0 += chunk) {
       const uint32_t q = std::min(chunk, r2 - q0);
       const double *bq = b + (uint64_t)q0 * n_dims;
-      KPOP_TRY(launch_distance_rows_mfma(KIND, a, r1, bq, q, n_dims, metric, rows, mscratch, chunk, st));
       SummaryLists lists;
-      KPOP_TRY(launch_summary_large(rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st, scratch, &lists));
       const uint32_t *gate = nullptr;
       const void *flags = nullptr;
-      KPOP_TRY(launch_summary_refine(KIND, rows, a, r1, bq, q, n_dims, metric, p, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist,
-                                     out_z, mscratch, chunk, st, lists, &gate, &flags));
+      if (select) {
+        KPOP_TRY(launch_mfma_query_prep(bq, q, r1, n_dims, metric, mscratch, chunk, st));
+        KPOP_TRY(launch_rows_mfma_against(KIND, a_s, sa_s, s_rows, q, n_dims, srow, mscratch, chunk, r1, st));
+        KPOP_TRY(launch_summary_fused_mfma(KIND, a, r1, q, n_dims, srow, s_rows, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, rows,
+                                           seg_i, scratch, mscratch, chunk, st, &lists));
+        KPOP_TRY(launch_summary_refine(KIND, nullptr, a, r1, bq, q, n_dims, metric, p, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist,
+                                       out_z, mscratch, chunk, st, lists, &gate, &flags));
+      } else {
+        KPOP_TRY(launch_distance_rows_mfma(KIND, a, r1, bq, q, n_dims, metric, rows, mscratch, chunk, st));
+        KPOP_TRY(launch_summary_large(rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st, scratch, &lists));
+        KPOP_TRY(launch_summary_refine(KIND, rows, a, r1, bq, q, n_dims, metric, p, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist,
+                                       out_z, mscratch, chunk, st, lists, &gate, &flags));
+      }
       KPOP_TRY(rowwise_block<KIND>(a, r1, bq, q, n_dims, metric, p, rows, st, nullptr, nullptr, gate));
       KPOP_TRY(launch_summary_flagged_rows(rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, flags, st));
     }

@@ -190,6 +190,185 @@ __global__ __launch_bounds__(256) void distance_rows_mfma_kernel(const double *_
   }
 }
 
+// The summary's ONE pass over the pairs, inside the contraction: the kernel above with the operands of the MFMA exchanged -- a lane then
+// holds ONE query row (l15 of its M tile) x four reference rows of the tile, so the query's thresholds (FusedThr: the median's bracket,
+// the MAD's bands, the neighbours' cut, from the distances to a sample) live in 16 registers a query -- and every distance classified
+// where it is made: counted, summed, a candidate of the median or the MAD filed in its (query, STRIPE of 2,048 reference rows) segment
+// with its column, a neighbour candidate in the row's list.  No distance row is written: round 5's path wrote 2 GB of them per 256
+// queries x 1M and read them back three times (1.4 of its 2.58 ms).  What comes out is what summary_fused_pass_kernel writes
+// (summary_large.hip): fused_finish_kernel<true> reads it, summary_refine_kernel makes what is reported exact.  lib/Matrix.ml:691-766.
+template <int KIND, int KS>
+__global__ __launch_bounds__(256) void summary_select_mfma_kernel(const double *__restrict__ a, uint32_t r1, const double *__restrict__ bm, uint32_t q, uint32_t n_dims,
+                                                                  const double *__restrict__ sa, const double *__restrict__ sb, const FusedThr *__restrict__ thr,
+                                                                  double *__restrict__ seg, uint32_t *__restrict__ seg_i, StripeRec *__restrict__ rec,
+                                                                  double *__restrict__ part, RowCounts *__restrict__ cnt, uint32_t *__restrict__ nb_idx,
+                                                                  double *__restrict__ nb_d, uint32_t n_stripes) {
+  constexpr int MI = 2, TS = 4 * KS + 2;
+  __shared__ double s_tile[2][16][TS];
+  __shared__ double s_sa[2][16];
+  __shared__ uint32_t s_ccnt[64 * MI];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t l15 = (uint32_t)lane & 15u, l4 = (uint32_t)lane >> 4;
+  const uint32_t stripe = blockIdx.x, j0 = blockIdx.y * (64u * MI) + (uint32_t)wv * (16u * MI);
+  if (threadIdx.x < 64 * MI) s_ccnt[threadIdx.x] = 0;
+  double qf[MI][KS];  // the query rows' fragments: lane = (query row l15 of the tile, dimension 4 ks + l4)
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const uint32_t row = j0 + 16u * mi + l15, c = 4u * ks + l4;
+      qf[mi][ks] = (row < q && c < n_dims) ? bm[(uint64_t)row * n_dims + c] : 0.0;
+    }
+  FusedThr T[MI];
+  double sbq[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const uint32_t row = min(j0 + 16u * mi + l15, q - 1u);
+    T[mi] = thr[row];
+    sbq[mi] = sb[row];
+  }
+  const uint32_t ref0 = stripe * kStripe, ref1 = min(r1, ref0 + kStripe);
+  const uint32_t t0 = ref0 / 16u, t1 = (ref1 + 15u) / 16u;
+  constexpr uint32_t PER = (16u * 4u * KS + 255u) / 256u;
+  double pre[PER], pre_sa = 0.0;
+  auto fetch = [&](uint32_t t) {
+#pragma unroll
+    for (uint32_t e = 0; e < PER; ++e) {
+      const uint32_t idx = threadIdx.x + 256u * e, r = idx / (4u * KS), c = idx % (4u * KS);
+      const uint32_t i = min(16u * t + r, r1 - 1u);
+      pre[e] = c < n_dims ? a[(uint64_t)i * n_dims + c] : 0.0;
+    }
+    if (threadIdx.x < 16) pre_sa = sa[min(16u * t + threadIdx.x, r1 - 1u)];
+  };
+  auto put = [&](int buf) {
+#pragma unroll
+    for (uint32_t e = 0; e < PER; ++e) {
+      const uint32_t idx = threadIdx.x + 256u * e, r = idx / (4u * KS), c = idx % (4u * KS);
+      s_tile[buf][r][c] = pre[e];
+    }
+    if (threadIdx.x < 16) s_sa[buf][threadIdx.x] = pre_sa;
+  };
+  double sum[MI], sq[MI];
+  uint32_t c01[MI], c23[MI], c4[MI];  // lt | eqlo << 16, eqhi | nmed << 16, inner: a lane sees 512 elements of a stripe a query
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    sum[mi] = sq[mi] = 0.0;
+    c01[mi] = c23[mi] = c4[mi] = 0u;
+  }
+  fetch(t0);
+  put(0);
+  __syncthreads();
+  for (uint32_t t = t0; t < t1; ++t) {
+    const int buf = (int)((t - t0) & 1u);
+    fetch(min(t + 1, t1 - 1));
+    f64x4m acc[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) acc[mi] = f64x4m{0.0, 0.0, 0.0, 0.0};
+    if constexpr (KS <= 16) {
+      double rf[KS];  // the reference tile's fragments: lane = (reference row l15, dimension 4 ks + l4)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) rf[ks] = s_tile[buf][l15][4 * ks + (int)l4];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(rf[ks], qf[mi][ks], acc[mi], 0, 0, 0);  // D[reference row][query row]
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const double rf = s_tile[buf][l15][4 * ks + (int)l4];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(rf, qf[mi][ks], acc[mi], 0, 0, 0);
+      }
+    }
+    double sai[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) sai[rr] = s_sa[buf][l4 + 4u * rr];
+    __builtin_amdgcn_s_setprio(2);
+    put(buf ^ 1);
+    const bool full = 16u * t + 16u <= ref1;  // (uniform)
+    // every distance of the tile counted and summed; the few that are candidates (of the median's bracket, of the MAD's bands: a few per
+    // cent) or neighbour candidates only MARKED here and filed after the tile's arithmetic, the lanes that have one together -- filed one
+    // element at a time, nine wavefront-instructions in ten found SOME lane with a candidate and took the slow way (1.37 ms the launch)
+    double dv[MI][4];
+    uint32_t cmask = 0, nmask = 0;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const uint32_t j = j0 + 16u * mi + l15;
+      const FusedThr &Tq = T[mi];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {  // lane holds reference rows l4 + 4 rr of the tile, query row l15 of the M tile
+        const uint32_t i = 16u * t + l4 + 4u * rr;
+        double u = sai[rr] + sbq[mi] - 2.0 * acc[mi][rr];
+        u = u > 0.0 ? u : 0.0;
+        const double d = KIND == KPOP_EUCLIDEAN ? sqrt_fast(u) : u * 0.5;
+        dv[mi][rr] = d;
+        const bool ok = j < q && (full || i < ref1);
+        const bool medc = d > Tq.lo && d < Tq.hi;
+        const bool in = d > Tq.Lin && d < Tq.Uin;
+        if (ok) {
+          c01[mi] += (d < Tq.lo ? 1u : 0u) + (d == Tq.lo ? 1u << 16 : 0u);
+          c23[mi] += ((d == Tq.hi && Tq.hi != Tq.lo) ? 1u : 0u) + (medc ? 1u << 16 : 0u);
+          c4[mi] += in ? 1u : 0u;
+          sum[mi] = __dadd_rn(sum[mi], d);
+          const double dvv = __dsub_rn(d, Tq.mhat);
+          sq[mi] = __dadd_rn(sq[mi], __dmul_rn(dvv, dvv));
+        }
+        cmask |= (ok && (medc || (!in && d >= Tq.Llo && d <= Tq.Uhi))) ? 1u << (4 * mi + rr) : 0u;
+        nmask |= (ok && d <= Tq.cut) ? 1u << (4 * mi + rr) : 0u;
+      }
+    }
+    auto pick = [&](uint32_t e) -> double {  // dv[e >> 2][e & 3] of a lane's own e
+      double x = dv[0][0];
+#pragma unroll
+      for (uint32_t f = 1; f < 4u * MI; ++f) x = e == f ? dv[f >> 2][f & 3u] : x;
+      return x;
+    };
+    while (__ballot(cmask != 0u)) {  // (as many turns as the lane with the most candidates has: one or two)
+      if (cmask) {
+        const uint32_t e = (uint32_t)__ffs((int)cmask) - 1u;
+        cmask &= cmask - 1u;
+        const uint32_t mi = e >> 2, j = j0 + 16u * mi + l15, i = 16u * t + l4 + 4u * (e & 3u);
+        const uint32_t slot = atomicAdd(&s_ccnt[(uint32_t)wv * (16u * MI) + 16u * mi + l15], 1u);
+        seg[(uint64_t)j * r1 + ref0 + slot] = pick(e);  // (at most as many as the stripe has columns)
+        seg_i[(uint64_t)j * r1 + ref0 + slot] = i;
+      }
+    }
+    while (__ballot(nmask != 0u)) {
+      if (nmask) {
+        const uint32_t e = (uint32_t)__ffs((int)nmask) - 1u;
+        nmask &= nmask - 1u;
+        const uint32_t mi = e >> 2, j = j0 + 16u * mi + l15, i = 16u * t + l4 + 4u * (e & 3u);
+        const uint32_t at = atomicAdd(&cnt[j].n_nb, 1u);
+        if (at < kNbCap) {
+          nb_idx[(uint64_t)j * kNbCap + at] = i;
+          nb_d[(uint64_t)j * kNbCap + at] = pick(e);
+        }
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
+  }
+  // a query's four lanes (l4 = 0..3: a quarter of the stripe's columns each), added up in a fixed order; the first writes
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+      sum[mi] = __dadd_rn(sum[mi], __shfl_xor(sum[mi], o, 64));
+      sq[mi] = __dadd_rn(sq[mi], __shfl_xor(sq[mi], o, 64));
+      c01[mi] += (uint32_t)__shfl_xor((int)c01[mi], o, 64);
+      c23[mi] += (uint32_t)__shfl_xor((int)c23[mi], o, 64);
+      c4[mi] += (uint32_t)__shfl_xor((int)c4[mi], o, 64);
+    }
+    const uint32_t j = j0 + 16u * mi + l15;
+    if (l4 == 0 && j < q) {
+      const uint64_t at = (uint64_t)j * n_stripes + stripe;
+      rec[at] = StripeRec{c01[mi], c23[mi], c4[mi], s_ccnt[(uint32_t)wv * (16u * MI) + 16u * mi + l15]};
+      part[at * 2 + 0] = sum[mi];
+      part[at * 2 + 1] = sq[mi];
+    }
+  }
+}
+
 // the reference's chain for one pair, dimension by dimension (lib/Space.ml:182-205; distance.hip)
 template <int KIND>
 __device__ __forceinline__ double exact_pair_rows(const double *__restrict__ arow, const double *__restrict__ brow, const double *__restrict__ metric, uint32_t n_dims, double p) {
@@ -333,6 +512,7 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
   __shared__ uint32_t s_nb_i[kRefNb], s_med_i[kRefMed], s_mad_i[kRefMad];
   __shared__ double s_nb_d[kRefNb], s_med_d[kRefMed], s_mad_d[kRefMad];
   __shared__ double s_b[128], s_m[128];
+  __shared__ double s_nb_x[kRefNb];  // the band's approximate values (what the sums of the mean and the standard deviation hold of them)
   __shared__ uint32_t s_cnt[8];  // [0] neighbours' band, [1] median's band, [2] below it, [3] MAD's band, [4] inside it, [5] failed
   __shared__ double s_val[2];    // the exact median, the exact MAD
   __shared__ double s_corr[16][2];
@@ -380,7 +560,10 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
     const double u = sq(x);
     if (for_nb && u <= u_nb) {
       const uint32_t at = atomicAdd(&s_cnt[0], 1u);
-      if (at < kRefNb) s_nb_i[at] = i;
+      if (at < kRefNb) {
+        s_nb_i[at] = i;
+        s_nb_x[at] = x;
+      }
     }
     if (for_med) {
       if (u < u_med_lo) ++n_below;
@@ -432,6 +615,13 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
       for (uint32_t e = threadIdx.x; e < C.n_nb; e += 1024) classify(ni[e], nv[e], true, false, false);
     }
   }
+  if (!from_lists && rows == nullptr) {  // (uniform) the one-kernel path wrote no distance rows to scan: the fall-back's
+    if (threadIdx.x == 0) {
+      rc[(uint64_t)jl * kRowCountsWords + kRowCountsFail] = 1u;
+      atomicAdd(n_failed, 1u);
+    }
+    return;
+  }
   if (!from_lists) {
     base_below = base_inside = 0;
     constexpr int U = 8;  // loads in flight a thread
@@ -479,7 +669,7 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
   // the exact distances of the neighbours' and the median's bands
   double c1 = 0.0, c2 = 0.0;  // what the band's exact values change in sum d and in sum (d - mean)^2
   for (uint32_t e = threadIdx.x; e < n_nb; e += 1024) {
-    const double dx = exact_pair<KIND>(a + (uint64_t)s_nb_i[e] * n_dims, qb, qm, n_dims, p), x = row[s_nb_i[e]];
+    const double dx = exact_pair<KIND>(a + (uint64_t)s_nb_i[e] * n_dims, qb, qm, n_dims, p), x = s_nb_x[e];
     s_nb_d[e] = dx;
     c1 += dx - x;
     c2 += (dx - mean_a) * (dx - mean_a) - (x - mean_a) * (x - mean_a);
@@ -695,6 +885,58 @@ int launch_distance_rowwise_mfma(int kind, const double *a, uint32_t r1, const d
     distance_gemm_mfma_kernel<KPOP_EUCLIDEAN, true><<<dim3(tiles_m * tiles_n), dim3(256), 0, st>>>(a, r1, M.bm, b, r2, n_dims, metric, p, M.sa, M.sb, out, tiles_m, tiles_n, m_fast, tau);
   else
     distance_gemm_mfma_kernel<KPOP_COSINE, true><<<dim3(tiles_m * tiles_n), dim3(256), 0, st>>>(a, r1, M.bm, b, r2, n_dims, metric, p, M.sa, M.sb, out, tiles_m, tiles_n, m_fast, tau);
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
+
+// the one-kernel path's pass (declared in summary_large.hip, which owns its scratch): q query rows (their fragments and norms in the
+// matrix-core scratch: launch_mfma_query_prep) against all r1 reference rows, a block a (stripe, 128 query rows)
+int launch_select_mfma(int kind, const double *a, uint32_t r1, uint32_t q, uint32_t n_dims, const void *mscratch, uint32_t q_room, const FusedThr *thr, double *seg,
+                       uint32_t *seg_i, StripeRec *rec, double *part, RowCounts *cnt, uint32_t *nb_idx, double *nb_d, uint32_t n_stripes, hipStream_t st) {
+  const MfmaScratch M = carve_mfma(const_cast<void *>(mscratch), q_room, r1, n_dims);
+  const dim3 grid(n_stripes, div_up(q, 128u));
+#define KPOP_SEL(K, KSV) summary_select_mfma_kernel<K, KSV><<<grid, dim3(256), 0, st>>>(a, r1, M.bm, q, n_dims, M.sa, M.sb, thr, seg, seg_i, rec, part, cnt, nb_idx, nb_d, n_stripes)
+  if (kind == KPOP_EUCLIDEAN) {
+    if (n_dims <= 64) KPOP_SEL(KPOP_EUCLIDEAN, 16); else KPOP_SEL(KPOP_EUCLIDEAN, 32);
+  } else {
+    if (n_dims <= 64) KPOP_SEL(KPOP_COSINE, 16); else KPOP_SEL(KPOP_COSINE, 32);
+  }
+#undef KPOP_SEL
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
+// the chunk's query rows times the metric and their norms into the scratch, the fall-back's flags cleared
+int launch_mfma_query_prep(const double *b, uint32_t q, uint32_t r1, uint32_t n_dims, const double *metric, void *scratch, uint32_t q_room, hipStream_t st) {
+  const MfmaScratch M = carve_mfma(scratch, q_room, r1, n_dims);
+  KPOP_HIP(hipMemsetAsync(M.rc, 0, (uint64_t)q * kRowCountsWords * 4, st));
+  KPOP_HIP(hipMemsetAsync(M.n_failed, 0, 256, st));
+  row_sumsq_kernel<<<dim3(std::min(div_up(q, 16), 4096u)), dim3(256), 0, st>>>(b, q, n_dims, metric, M.sb, M.bm, nullptr);
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
+// approximate distance rows of the prepared query rows against ANOTHER set of rows (the sample of the reference set: `as`, its norms `sas`)
+int launch_rows_mfma_against(int kind, const double *as, const double *sas, uint32_t s, uint32_t q, uint32_t n_dims, double *rows, void *scratch, uint32_t q_room,
+                             uint32_t r1, hipStream_t st) {
+  MfmaScratch M = carve_mfma(scratch, q_room, r1, n_dims);
+  const uint32_t n_tiles = div_up(s, 16);
+  const bool small = n_dims <= 64;
+  const uint32_t rows_per_block = small ? 128u : 256u, ny = div_up(q, rows_per_block);
+  const uint32_t resident = (uint32_t)ctx().n_cus * (small ? 3u : 2u);
+  const uint32_t gx = std::max(1u, std::min(n_tiles, std::max(1u, resident / ny)));
+  const uint32_t tpb = div_up(n_tiles, gx);
+  const dim3 grid(div_up(n_tiles, tpb), ny);
+#define KPOP_ROWS(K) \
+  do { \
+    if (small) distance_rows_mfma_kernel<K, 16, 2><<<grid, dim3(256), 0, st>>>(as, s, M.bm, q, n_dims, sas, M.sb, rows, tpb); \
+    else distance_rows_mfma_kernel<K, 32, 4><<<grid, dim3(256), 0, st>>>(as, s, M.bm, q, n_dims, sas, M.sb, rows, tpb); \
+  } while (0)
+  if (kind == KPOP_EUCLIDEAN) KPOP_ROWS(KPOP_EUCLIDEAN); else KPOP_ROWS(KPOP_COSINE);
+#undef KPOP_ROWS
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
+int launch_row_sumsq(const double *x, uint32_t rows, uint32_t n_dims, const double *metric, double *out, hipStream_t st) {
+  row_sumsq_kernel<<<dim3(std::min(div_up(rows, 16), 4096u)), dim3(256), 0, st>>>(x, rows, n_dims, metric, out, nullptr, nullptr);
   KPOP_LAUNCH_CHECK();
   return 0;
 }

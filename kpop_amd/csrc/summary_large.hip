@@ -850,12 +850,7 @@ __device__ bool row_failed(const RowCounts *cnt, uint32_t row) { return cnt[row]
 // hold -- a bracket that missed, a list that overflowed, the certificate -- flags the row, and flagged rows are redone from
 // distance rows computed then (the tiled kernel and summary_large_kernel, both launched always and gated on the flags).
 // ===========================================================================
-constexpr uint32_t kStripe = 2048, kFW = 32, kFQ = 256, kFDC = 16, kMaxStripes = 8192;
-
-// (FusedThr: summary_types.h)
-struct StripeRec {
-  uint32_t lt_eqlo, eqhi_nmed, inner, c_cnt;  // (16 bits each where paired: a stripe has 2,048 elements)
-};
+constexpr uint32_t kFW = 32, kFQ = 256, kFDC = 16;  // (kStripe, kMaxStripes, StripeRec, FusedThr: summary_types.h)
 
 static inline uint32_t fused_cand_cap(uint32_t r1) { return (r1 / 4 + 4095u) & ~4095u; }  // compacted candidates: room for a quarter of a row
 
@@ -1296,7 +1291,9 @@ __global__ __launch_bounds__(kLT) void fused_finish_kernel(const double *__restr
                                                            const uint32_t *__restrict__ nb_idx, const double *__restrict__ nb_d,
                                                            uint32_t *__restrict__ n_failed, double *__restrict__ out_stats,
                                                            uint32_t *__restrict__ out_n, uint32_t *__restrict__ out_idx,
-                                                           double *__restrict__ out_dist, double *__restrict__ out_z) {
+                                                           double *__restrict__ out_dist, double *__restrict__ out_z,
+                                                           const uint32_t *__restrict__ seg_i = nullptr, uint32_t *__restrict__ ccand_i = nullptr) {
+  // (seg_i / ccand_i: the candidates' columns beside their values, compacted the same way -- the matrix-core path's refinement reads them)
   __shared__ uint32_t s_hist[kSel * kBins];
   __shared__ uint64_t s_cand[kSel * kCand];
   __shared__ uint32_t s_misc[64];
@@ -1364,8 +1361,22 @@ __global__ __launch_bounds__(kLT) void fused_finish_kernel(const double *__restr
 #pragma unroll
           for (int u = 0; u < 8; ++u)
             if (e0 + u * 64 + lane < c) my_c[at + e0 + u * 64 + lane] = v[u];
+          if (seg_i) {
+            const uint32_t *srci = seg_i + (uint64_t)jl * r1 + (uint64_t)st * kStripe;
+            uint32_t *my_ci = ccand_i + (uint64_t)jl * cap;
+            uint32_t vi[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vi[u] = e0 + u * 64 + lane < c ? srci[e0 + u * 64 + lane] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (e0 + u * 64 + lane < c) my_ci[at + e0 + u * 64 + lane] = vi[u];
+          }
         }
       }
+    }
+    if (threadIdx.x == 0) {  // (the totals where the one-pass path keeps them: the matrix-core path's refinement reads them from there)
+      RowCounts *C = cnt + jl;
+      C->lt_lo = lt; C->eq_lo = eqlo; C->eq_hi = eqhi; C->m_lt = nmed; C->m_eqlo = n_inner; C->n_cand = n_c;
     }
     __syncthreads();
   } else {
@@ -1501,6 +1512,7 @@ struct FusedScratch {
   double *nb_d;
   uint32_t *nb_idx;
   double *ccand;
+  uint32_t *ccand_i;
   uint32_t *n_failed;
 };
 static uint64_t carve_fused(void *scratch, uint32_t n_rows, uint32_t r1, FusedScratch *F) {
@@ -1521,6 +1533,7 @@ static uint64_t carve_fused(void *scratch, uint32_t n_rows, uint32_t r1, FusedSc
   F->nb_d = reinterpret_cast<double *>(take((uint64_t)n_rows * kNbCap * 8));
   F->nb_idx = reinterpret_cast<uint32_t *>(take((uint64_t)n_rows * kNbCap * 4));
   F->ccand = reinterpret_cast<double *>(take((uint64_t)n_rows * fused_cand_cap(r1) * 8));
+  F->ccand_i = reinterpret_cast<uint32_t *>(take((uint64_t)n_rows * fused_cand_cap(r1) * 4));
   return (uint64_t)(p - p0) + 256;
 }
 uint64_t summary_fused_scratch_bytes(uint32_t n_rows, uint32_t r1) {
@@ -1561,6 +1574,36 @@ int launch_summary_fused(int kind, const double *a, uint32_t r1, const double *b
   KPOP_LAUNCH_CHECK();
   *gate = F.n_failed;
   return 0;
+}
+
+// The same with the pass on the f64 MATRIX cores (distance_mfma.hip: summary_select_mfma_kernel -- the approximate distances classified in the
+// accumulators' registers, no distance row written): thresholds from the distances to the sample (`srow`, [n_rows][s], approximate as
+// well), the pass, the finish over the stripes' segments (values in `seg`, columns in `seg_i`, both [n_rows][r1]).  What it reports is
+// approximate: `lists` is what the exact refinement (summary_refine_kernel) reads.
+int launch_select_mfma(int kind, const double *a, uint32_t r1, uint32_t q, uint32_t n_dims, const void *mscratch, uint32_t q_room, const FusedThr *thr, double *seg,
+                       uint32_t *seg_i, StripeRec *rec, double *part, RowCounts *cnt, uint32_t *nb_idx, double *nb_d, uint32_t n_stripes, hipStream_t st);
+int launch_summary_fused_mfma(int kind, const double *a, uint32_t r1, uint32_t n_rows, uint32_t n_dims, const double *srow, uint32_t s, uint32_t row0,
+                              uint32_t keep_at_most, uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx, double *out_dist,
+                              double *out_z, double *seg, uint32_t *seg_i, void *scratch, const void *mscratch, uint32_t q_room, hipStream_t st,
+                              SummaryLists *lists) {
+  const uint32_t req_len = keep_at_most ? keep_at_most : r1;
+  const uint32_t n_stripes = (r1 + kStripe - 1) / kStripe;
+  FusedScratch F;
+  carve_fused(scratch, n_rows, r1, &F);
+  KPOP_HIP(hipMemsetAsync(F.n_failed, 0, 256, st));
+  fused_sample_kernel<false><<<dim3(n_rows), dim3(kLT), 0, st>>>(srow, s, r1, req_len, F.info, F.cnt, F.thr);
+  KPOP_LAUNCH_CHECK();
+  KPOP_TRY(launch_select_mfma(kind, a, r1, n_rows, n_dims, mscratch, q_room, F.thr, seg, seg_i, F.rec, F.part, F.cnt, F.nb_idx, F.nb_d, n_stripes, st));
+  fused_finish_kernel<true><<<dim3(n_rows), dim3(kLT), 0, st>>>(seg, r1, row0, req_len, max_neighbours, F.info, F.thr, F.cnt, F.rec, F.part, n_stripes, F.pre,
+                                                          F.ccand, fused_cand_cap(r1), F.nb_idx, F.nb_d, F.n_failed, out_stats, out_n, out_idx, out_dist,
+                                                          out_z, seg_i, F.ccand_i);
+  KPOP_LAUNCH_CHECK();
+  *lists = SummaryLists{F.info, F.thr, F.cnt, F.ccand, F.ccand_i, fused_cand_cap(r1), F.nb_idx, F.nb_d};
+  return 0;
+}
+bool summary_select_mfma_applies(uint32_t r1, uint32_t keep_at_most) {
+  const uint32_t req_len = keep_at_most ? keep_at_most : r1;
+  return req_len <= kLargeMaxNb && r1 >= 4 * kSlice && (r1 + kStripe - 1) / kStripe <= kMaxStripes;
 }
 
 // the rows the fused path flagged, from distance rows computed meanwhile (gated the same way: nothing runs when none failed)

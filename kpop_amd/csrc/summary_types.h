@@ -24,6 +24,13 @@ struct FusedThr {  // one query row's thresholds, as distances (64 bytes)
   double cut, mhat;
 };
 
+// the one-kernel paths' bookkeeping per (query row, STRIPE of kStripe reference rows): the vector-pipe kernel of summary_large.hip and the
+// matrix-core kernel of distance_mfma.hip write it, fused_finish_kernel<true> reads it
+constexpr uint32_t kStripe = 2048, kMaxStripes = 8192;
+struct StripeRec {
+  uint32_t lt_eqlo, eqhi_nmed, inner, c_cnt;  // (16 bits each where paired: a stripe has 2,048 elements)
+};
+
 // the one-pass path's per-row lists, for a caller that wants to look things up in them (nullptr members: that path did not run)
 struct SummaryLists {
   const RowInfo *info = nullptr;
