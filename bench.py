@@ -714,7 +714,7 @@ def config3_distances_leg(R):
     try:
         mss0, _ = _event_ms(R, calls, 1, 1)
     finally:
-        api.tune("summary_mfma", 2)
+        api.tune("summary_mfma", 1)
     same = bool(t.equal(a[0][:, 2:], stats[:, 2:]) and t.equal(a[1], nn) and t.equal(a[2][:, :300], idx[:, :300]) and t.equal(a[3][:, :300], dd[:, :300]))
     fls = 2.0 * r1s * q * d
     res["distance_summary_256_x_650k"] = {

@@ -113,7 +113,7 @@ struct Context {
   int tune_direct = 2; // a nearly complete twister of k 13..15 and <= 32 dimensions also keeps its rows at their hashes (twister.h): 2 by that rule, 1 whenever the table fits (any k <= 15), 0 never.  Read when a twister is loaded or synthesised
   int tune_summary_mfma_lists = 1; // the refinement reads the summary's candidate lists where its bands lie inside them; 0: it scans every distance row again
   int tune_distance_mfma = 1; // kpop_dev_distance_rowwise of 2^32 products and more (rows x rows x dimensions), euclidean / cosine: the contraction on the f64 matrix cores, pairs that cancel recomputed with the reference's chain (<= 1e-12 relative, not bit for bit); 0: the vector-pipe chain for every pair (the reference's bits)
-  int tune_summary_mfma = 2; // (2: up to 128 dimensions the summary's pass runs INSIDE the contraction -- no approximate distance row is written; 1: round 5's path, rows then passes over them) summaries against >= 65,536 rows, euclidean / cosine: the distances as f64 MFMAs + exact refinement (distance_mfma.hip); 0: the vector-pipe chain for every pair
+  int tune_summary_mfma = 1; // (1, the default: approximate rows, then the summary's pass over them; 2: up to 128 dimensions the pass runs INSIDE the contraction and no approximate row is written -- same results, measured SLOWER: 256 x 1M x 64 2.9-3.2 against 2.7-2.8 ms, the classification's ~50 vector operations a pair serialise with the matrix pipe on a SIMD: profiles/r06_summary_select.txt) summaries against >= 65,536 rows, euclidean / cosine: the distances as f64 MFMAs + exact refinement (distance_mfma.hip); 0: the vector-pipe chain for every pair
   int tune_summary2 = 1; // summaries against > 4,096 rows: 1 brackets and bands from a sample + ONE pass over distance rows, 3 the same in two passes (median, then MAD), 0 round 2's one block per row (8-10 passes), 2 the distances computed and reduced in one kernel, no distance rows (131,072 rows and more); 1, 2 and 3 are level at 256 x 1M
   int tune_histlds = 1;  // ... staged through LDS: private tables (k <= 7), sorted chunks of assemblies (0: direct atomics; 2: always sort the chunks)
 };

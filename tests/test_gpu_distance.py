@@ -643,13 +643,13 @@ def test_distance_summary_on_the_matrix_cores(kpop, oracle, case, kind, d):
         for keep in (1, 300):
             st_o, offs, idx_o, dist_o, z_o = oracle.distance_summary(m1, m2, metric, kind, 2.0, normalize, keep)
             res = {}
-            # 3: the default -- the summary's pass inside the contraction, no distance row written (up to 128 dimensions; beyond: as 1);
-            # 1: round 5's path, approximate rows then the pass over them; 2: ... its refinement scanning the rows instead of reading the lists
+            # 3: the summary's pass inside the contraction, no distance row written (kpop_tune("summary_mfma", 2); up to 128 dimensions, beyond: as 1);
+            # 1: the default, approximate rows then the pass over them; 2: ... its refinement scanning the rows instead of reading the lists
             for mode in (3, 1, 2, 0):
                 api.tune("summary_mfma", {3: 2, 1: 1, 2: 1, 0: 0}[mode])
                 api.tune("summary_mfma_lists", 0 if mode == 2 else 1)
                 res[mode] = kpop.distance_summary(m1, m2, metric, kind, 2.0, normalize, keep, max_neighbours=512)
-            api.tune("summary_mfma", 2)
+            api.tune("summary_mfma", 1)
             api.tune("summary_mfma_lists", 1)
             for a_, b_ in zip(res[1], res[2]):
                 assert np.array_equal(a_, b_, equal_nan=True)
@@ -737,7 +737,7 @@ def test_distance_summary_on_the_matrix_cores_in_several_chunks(kpop, oracle):
     for mode in (2, 1, 0):
         api.tune("summary_mfma", mode)
         res[mode] = kpop.distance_summary(m1, m2, metric, 0, 2.0, True, 3, max_neighbours=16)
-    api.tune("summary_mfma", 2)
+    api.tune("summary_mfma", 1)
     assert np.array_equal(res[2][0][:, 2:], res[1][0][:, 2:]) and np.array_equal(res[2][1], res[1][1])
     a, b = res[2], res[0]
     assert np.array_equal(a[0][:, 2:], b[0][:, 2:])

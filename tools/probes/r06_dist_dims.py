@@ -75,13 +75,13 @@ def main():
         dd = torch.zeros(r2, K, dtype=torch.float64, device=dev)
         z = torch.zeros_like(dd)
         keep = {}
-        for mode in [int(x) for x in os.environ.get("R06_S_MODES", "2,0").split(",")]:  # 2: the summary's pass inside the contraction (default up to 128 dimensions), 1: rows then passes, 0: vector pipe
+        for mode in [int(x) for x in os.environ.get("R06_S_MODES", "1,0").split(",")]:  # 1: approximate rows then the summary's passes (default), 2: the pass inside the contraction (up to 128 dimensions), 0: vector pipe
             api.tune("summary_mfma", mode)
             ms = timed(lambda: api.dev_distance_summary(m1.data_ptr(), r1, m2.data_ptr(), r2, d, metric.data_ptr(), work.data_ptr(), stats.data_ptr(), n.data_ptr(),
                                                         idx.data_ptr(), dd.data_ptr(), z.data_ptr(), keep_at_most=300, max_neighbours=K, stream=st.cuda_stream), 3 if mode else 1)
             keep[mode] = (ms, [x.cpu().numpy().copy() for x in (stats, n, idx, dd)])
             print("      summary_mfma %d: %9.3f ms" % (mode, ms), flush=True)
-        api.tune("summary_mfma", 2)
+        api.tune("summary_mfma", 1)
         m_on = max(keep)
         keep[1] = keep[m_on]
         a, b = keep[1][1], keep[min(keep)][1]
