@@ -198,6 +198,20 @@ int kpop_twist(const kpop_twister *tw, const uint64_t *hash, const double *value
 int kpop_count_twist(const kpop_twister *tw, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
                      int content, int normalize, double *out);
 
+/* ------------------------------------------------------------ packed bases
+ * BASELINE north_star's "packed bases" at the boundary: 16 bases a 32-bit word of 2-bit codes (A 0, C 1, G 2, T 3, either case; base i
+ * of the batch in bits 2 (i % 16).. of word i / 16) and one bit a base that is none of ACGTacgt (32 bases a word; such a base starts
+ * no k-mer, as after Sequences.Lint.dnaize, bin/KPopCount.ml:242-245): 2.25 bits a base where every other entry point takes 8.  A host
+ * that keeps its sequences packed sends 3.56 x fewer bytes over the bus -- BASELINE config 3's 1.5 GB of bases cost 26 ms of bus
+ * against 9.6 ms of kernels.  kpop_pack_bases packs on the host (threads <= 0: the library chooses); on the device the words are
+ * spread back to one byte a base at HBM's rate and the kernels run as they are: the ASCII entry points' results bit for bit.
+ * offsets are in bases, from base 0 of the packed arrays.  Replaces the sequence side of bin/KPopCount.ml:36-50.                  */
+uint64_t kpop_packed_code_words(uint64_t n_bases);   /* (n_bases + 15) / 16 */
+uint64_t kpop_packed_mask_words(uint64_t n_bases);   /* (n_bases + 31) / 32 */
+int kpop_pack_bases(const uint8_t *bases, uint64_t n_bases, uint32_t *codes, uint32_t *invalid, int threads);
+int kpop_count_twist_packed(const kpop_twister *tw, const uint32_t *codes, const uint32_t *invalid, const uint64_t *offsets, uint32_t n_reads,
+                            int content, int normalize, double *out);
+
 /* The same pipeline with the count spelled out: the rows that kpop_count_reads(k, content, per_read = 1) followed
  * by kpop_twist would give, bit for bit, for sequences of any length, with the spectra never leaving the device.
  * k is the caller's (k <= the k the twister was loaded with: a twister file shows only the width of its k-mer names).
@@ -251,6 +265,8 @@ int kpop_pipeline_create(const kpop_twister *tw, const double *classes, uint32_t
    before collecting the previous and the bus never idles); with pageable ones it may wait for copies.            */
 int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
                          const kpop_pipeline_outputs *out, uint64_t *ticket);
+int kpop_pipeline_submit_packed(kpop_pipeline *pl, const uint32_t *codes, const uint32_t *invalid, const uint64_t *offsets, uint32_t n_reads,
+                                const kpop_pipeline_outputs *out, uint64_t *ticket);  /* the batch in 2.25 bits a base (see "packed bases") */
 int kpop_pipeline_collect(kpop_pipeline *pl, uint64_t ticket);  /* returns once that batch's outputs are in host memory */
 int kpop_pipeline_run(kpop_pipeline *pl, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
                       const kpop_pipeline_outputs *out);        /* submit + collect */
@@ -409,6 +425,12 @@ int kpop_dev_workspace_reserve_stream(uint64_t bytes, void *stream);
 int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bases, const uint64_t *d_offsets,
                          uint32_t n_reads, uint64_t n_bases, uint32_t max_len, int content, int normalize,
                          double *d_out, void *stream);
+/* ... from the packed form (see "packed bases"): d_codes / d_invalid as kpop_pack_bases writes them, resident on the device; the bases are
+   spread back to bytes into a second library-owned block of the stream (n_bases bytes), then kpop_dev_count_twist.  kpop_dev_unpack_bases
+   is that first step by itself (d_bases: n_bases bytes; A C G T, N for a base marked invalid).                                        */
+int kpop_dev_unpack_bases(const uint32_t *d_codes, const uint32_t *d_invalid, uint64_t n_bases, uint8_t *d_bases, void *stream);
+int kpop_dev_count_twist_packed(const kpop_twister *tw, const uint32_t *d_codes, const uint32_t *d_invalid, const uint64_t *d_offsets,
+                                uint32_t n_reads, uint64_t n_bases, uint32_t max_len, int content, int normalize, double *d_out, void *stream);
 /* max_lines = lines of the longest spectrum of the batch, or 0 when the caller does not know: up to 512 the kernel keeps
    the columns it finds while summing the counts (lib/Twister.ml:158) for the products (:183) instead of looking them up
    twice.  A spectrum longer than a non-zero max_lines says comes back as a row of NaNs.                              */

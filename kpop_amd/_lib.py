@@ -42,7 +42,14 @@ SIGNATURES = {
     "kpop_host_unregister": (C.c_int, [vp]),
     "kpop_pipeline_create": (C.c_int, [vp, f64p, C.c_uint32, f64p, C.POINTER(PipelineConfig), C.POINTER(vp)]),
     "kpop_pipeline_submit": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(PipelineOutputs), u64p]),
+    "kpop_pipeline_submit_packed": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.POINTER(PipelineOutputs), u64p]),
     "kpop_pipeline_collect": (C.c_int, [vp, C.c_uint64]),
+    "kpop_packed_code_words": (C.c_uint64, [C.c_uint64]),
+    "kpop_packed_mask_words": (C.c_uint64, [C.c_uint64]),
+    "kpop_pack_bases": (C.c_int, [vp, C.c_uint64, vp, vp, C.c_int]),
+    "kpop_count_twist_packed": (C.c_int, [vp, vp, vp, u64p, C.c_uint32, C.c_int, C.c_int, f64p]),
+    "kpop_dev_unpack_bases": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),
+    "kpop_dev_count_twist_packed": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.c_int, vp, vp]),
     "kpop_pipeline_run": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(PipelineOutputs)]),
     "kpop_pipeline_stats": (C.c_int, [vp, u32p, C.POINTER(C.c_int), u32p]),
     "kpop_pipeline_timeline": (C.c_int, [vp, C.c_uint32, f64p, u32p]),

@@ -56,6 +56,27 @@ def device_slots():
     return int(_lib.load().kpop_device_slots())
 
 
+def pack_bases(bases, threads=0):
+    """one byte a base -> (codes, invalid): 16 bases a uint32 of 2-bit codes (A0 C1 G2 T3, either case), one bit a base that is none of
+    ACGTacgt (32 a uint32) -- kpop_pack_bases; 2.25 bits a base for the *_packed entry points"""
+    bases = _c(bases, np.uint8)
+    n = bases.size
+    lib = _lib.load()
+    codes = np.zeros(max(int(lib.kpop_packed_code_words(n)), 1), dtype=np.uint32)
+    invalid = np.zeros(max(int(lib.kpop_packed_mask_words(n)), 1), dtype=np.uint32)
+    check(lib.kpop_pack_bases(_nz(bases, np.uint8).ctypes.data, n, codes.ctypes.data, invalid.ctypes.data, int(threads)))
+    return codes, invalid
+
+
+def dev_unpack_bases(d_codes, d_invalid, n_bases, d_bases, stream=0):
+    check(_lib.load().kpop_dev_unpack_bases(d_codes, d_invalid, int(n_bases), d_bases, stream))
+
+
+def dev_count_twist_packed(tw, d_codes, d_invalid, d_offsets, n_reads, n_bases, max_len, d_out, content=DNA_DS, normalize=True, stream=0):
+    check(_lib.load().kpop_dev_count_twist_packed(tw.handle, d_codes, d_invalid, d_offsets, int(n_reads), int(n_bases), int(max_len), int(content),
+                                                  1 if normalize else 0, d_out, stream))
+
+
 def tune(key, value):
     """Performance knobs for A/B runs (kpop_tune); results do not depend on them."""
     check(_lib.load().kpop_tune(key.encode(), int(value)))
@@ -187,6 +208,17 @@ class Twister:
                                            _p(_nz(out, np.float64), C.c_double)))
         return out
 
+    def count_twist_packed(self, codes, invalid, offsets, content=DNA_DS, normalize=True):
+        """The same from the packed form (pack_bases): 2.25 bits a base over the bus, the same rows bit for bit."""
+        codes = _c(codes, np.uint32)
+        invalid = _c(invalid, np.uint32)
+        offsets = _c(offsets, np.uint64)
+        n = len(offsets) - 1
+        out = np.zeros((n, self.info()["n_dims"]), dtype=np.float64)
+        check(_lib.load().kpop_count_twist_packed(self._h, _nz(codes, np.uint32).ctypes.data, _nz(invalid, np.uint32).ctypes.data, _p(offsets, C.c_uint64), n,
+                                                  int(content), 1 if normalize else 0, _p(_nz(out, np.float64), C.c_double)))
+        return out
+
     def spectra_twist(self, bases, offsets, k, content=DNA_DS, normalize=True):
         """Reads -> the rows count_reads(k) + twist would give, bit for bit, spectra kept on the device (any length)."""
         bases = _c(bases, np.uint8)
@@ -309,6 +341,24 @@ class Pipeline:
         tk = C.c_uint64()
         check(_lib.load().kpop_pipeline_submit(self._h, bases.ctypes.data, offsets.ctypes.data, n, C.byref(po), C.byref(tk)))
         self._pending[tk.value] = (bases, offsets, out)
+        return tk.value
+
+    def submit_packed(self, codes, invalid, offsets, out):
+        """submit() with the batch in the packed form (pack_bases): what goes up the bus is 2.25 bits a base"""
+        for a, dt in ((codes, np.uint32), (invalid, np.uint32), (offsets, np.uint64)):
+            if a.dtype != dt or not a.flags.c_contiguous:
+                raise ValueError("codes / invalid must be contiguous uint32 and offsets contiguous uint64")
+        n = len(offsets) - 1
+        po = _lib.PipelineOutputs()
+        for name in ("twisted", "distances", "stats", "n_neighbours", "nb_index", "nb_distance", "nb_z"):
+            a = out.get(name)
+            if a is not None:
+                if not a.flags.c_contiguous:
+                    raise ValueError("output %s is not contiguous" % name)
+                setattr(po, name, a.ctypes.data)
+        tk = C.c_uint64()
+        check(_lib.load().kpop_pipeline_submit_packed(self._h, codes.ctypes.data, invalid.ctypes.data, offsets.ctypes.data, n, C.byref(po), C.byref(tk)))
+        self._pending[tk.value] = (codes, invalid, offsets, out)
         return tk.value
 
     def collect(self, ticket):

@@ -82,6 +82,13 @@ struct Context {
     std::lock_guard<std::mutex> g(ws_mu);
     return ws_by_stream[st];
   }
+  // ... and a SECOND block a stream, for an entry point that prepares the input of another that takes the first (packed.hip: the
+  // bases spread back to bytes for kpop_dev_count_twist)
+  std::map<hipStream_t, Workspace> ws2_by_stream;
+  Workspace &ws2_for(hipStream_t st) {
+    std::lock_guard<std::mutex> g(ws_mu);
+    return ws2_by_stream[st];
+  }
   // host-buffer entry points (null stream + arena) of one slot run one at a time
   std::recursive_mutex host_mu;
   Arena arena;

@@ -59,6 +59,7 @@ struct DevMem {  // grow-only device block
 
 struct RingSlot {
   DevMem bases, offsets, twisted, dist, work, stats, nn, idx, ndist, z;
+  DevMem pcodes, pmask;  // a chunk's slice of a PACKED batch (kpop_pipeline_submit_packed), spread back into `bases` on the compute stream
   hipEvent_t h2d_done = nullptr, twist_done = nullptr, compute_done = nullptr, d2h_done = nullptr;
   bool in_use = false;  // d2h_done has been recorded at least once
 };
@@ -276,9 +277,14 @@ extern "C" int kpop_pipeline_destroy(kpop_pipeline *pl) {
   return KPOP_OK;
 }
 
-extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
-                                    const kpop_pipeline_outputs *o, uint64_t *ticket) {
+namespace kpop {
+int launch_unpack_bases(const uint32_t *d_codes, uint32_t cshift, const uint32_t *d_invalid, uint32_t mshift, uint64_t n_bases, uint8_t *d_out, hipStream_t st);  // packed.hip
+}
+// bases (one byte a base) or codes + invalid (packed.hip: 2.25 bits a base, from base 0 of the batch): the same chunks either way
+static int pipeline_submit_impl(kpop_pipeline *pl, const uint8_t *bases, const uint32_t *codes, const uint32_t *invalid, const uint64_t *offsets, uint32_t n_reads,
+                                const kpop_pipeline_outputs *o, uint64_t *ticket) {
   if (!pl || !o || (n_reads && !offsets)) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_submit: null argument");
+  const bool packed = codes != nullptr;
   SlotGuard guard(pl->slot);
   const int outs = pl->cfg.outputs;
   const uint32_t D = pl->n_dims, C = pl->n_classes, mn = pl->cfg.max_neighbours;
@@ -334,7 +340,7 @@ extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, con
   const bool pin_tw = is_pinned(o->twisted), pin_di = is_pinned(o->distances), pin_st = is_pinned(o->stats),
              pin_nn = is_pinned(o->n_neighbours), pin_ix = is_pinned(o->nb_index), pin_nd = is_pinned(o->nb_distance),
              pin_nz = is_pinned(o->nb_z);
-  pl->last_pinned = (is_pinned(bases) && is_pinned(offsets) && pin_tw && pin_di && pin_st && pin_nn && pin_ix && pin_nd && pin_nz) ? 1 : 0;
+  pl->last_pinned = ((packed ? is_pinned(codes) && is_pinned(invalid) : is_pinned(bases)) && is_pinned(offsets) && pin_tw && pin_di && pin_st && pin_nn && pin_ix && pin_nd && pin_nz) ? 1 : 0;
   uint32_t n_chunks = 0;
   const bool timeline = pl->cfg.record_timeline != 0;
   auto mark = [&](uint32_t chunk, int which, hipStream_t st) -> int {  // timing event `which` (0..5) of chunk
@@ -394,13 +400,24 @@ extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, con
     // waits for the oldest.
     if (s.in_use && hipEventQuery(s.d2h_done) != hipSuccess) KPOP_HIP(hipEventSynchronize(s.d2h_done));
     KPOP_TRY(mark(n_chunks, 0, pl->s_h2d));
-    if (nb) KPOP_HIP(hipMemcpyAsync(s.bases.p, bases + b0, nb, hipMemcpyHostToDevice, pl->s_h2d));
+    const uint64_t cw0 = b0 >> 4, mw0 = b0 >> 5;  // the chunk's first words of the packed batch
+    if (packed && nb) {
+      const uint64_t tot_c = (offsets[n_reads] + 15) >> 4, tot_m = (offsets[n_reads] + 31) >> 5;
+      const uint64_t ncw = std::min(tot_c - cw0, ((b0 + nb + 15) >> 4) - cw0 + 1), nmw = std::min(tot_m - mw0, ((b0 + nb + 31) >> 5) - mw0 + 1);
+      KPOP_TRY(s.pcodes.ensure(((cap_nb + 15) / 16 + 4) * 4));
+      KPOP_TRY(s.pmask.ensure(((cap_nb + 31) / 32 + 4) * 4));
+      KPOP_HIP(hipMemcpyAsync(s.pcodes.p, codes + cw0, ncw * 4, hipMemcpyHostToDevice, pl->s_h2d));
+      KPOP_HIP(hipMemcpyAsync(s.pmask.p, invalid + mw0, nmw * 4, hipMemcpyHostToDevice, pl->s_h2d));
+    } else if (nb)
+      KPOP_HIP(hipMemcpyAsync(s.bases.p, bases + b0, nb, hipMemcpyHostToDevice, pl->s_h2d));
     KPOP_HIP(hipMemcpyAsync(s.offsets.p, offsets + r0, (uint64_t)(n + 1) * 8, hipMemcpyHostToDevice, pl->s_h2d));
     KPOP_TRY(mark(n_chunks, 1, pl->s_h2d));
     KPOP_HIP(hipEventRecord(s.h2d_done, pl->s_h2d));
     // count -> twist -> distance: the kernels see the caller's absolute offsets, so the bases pointer is moved back by b0
     KPOP_HIP(hipStreamWaitEvent(pl->s_compute, s.h2d_done, 0));
     KPOP_TRY(mark(n_chunks, 2, pl->s_compute));
+    if (packed && nb)  // one byte a base again, at HBM's rate (the bus carried 2.25 bits of it)
+      KPOP_TRY(launch_unpack_bases(s.pcodes.as<uint32_t>(), (uint32_t)(b0 & 15u), s.pmask.as<uint32_t>(), (uint32_t)(b0 & 31u), nb, s.bases.as<uint8_t>(), pl->s_compute));
     const uint8_t *d_bases = s.bases.as<uint8_t>() - b0;
     KPOP_TRY(kpop_dev_count_twist(pl->tw, d_bases, s.offsets.as<uint64_t>(), n, nb, (uint32_t)max_len, pl->cfg.content,
                                   pl->cfg.normalize_counts, s.twisted.as<double>(), pl->s_compute));
@@ -464,6 +481,18 @@ extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, con
   ++pl->next_ticket;
   if (ticket) *ticket = tk;
   return KPOP_OK;
+}
+
+extern "C" int kpop_pipeline_submit(kpop_pipeline *pl, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                                    const kpop_pipeline_outputs *o, uint64_t *ticket) {
+  return pipeline_submit_impl(pl, bases, nullptr, nullptr, offsets, n_reads, o, ticket);
+}
+
+extern "C" int kpop_pipeline_submit_packed(kpop_pipeline *pl, const uint32_t *codes, const uint32_t *invalid, const uint64_t *offsets, uint32_t n_reads,
+                                           const kpop_pipeline_outputs *o, uint64_t *ticket) {
+  if (n_reads && offsets && offsets[n_reads] && (!codes || !invalid)) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_submit_packed: null argument");
+  static const uint32_t none = 0;
+  return pipeline_submit_impl(pl, nullptr, codes ? codes : &none, invalid ? invalid : &none, offsets, n_reads, o, ticket);
 }
 
 extern "C" int kpop_pipeline_collect(kpop_pipeline *pl, uint64_t ticket) {

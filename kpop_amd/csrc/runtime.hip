@@ -116,6 +116,8 @@ static void release_slot(Context &c) {
     std::lock_guard<std::mutex> g(c.ws_mu);
     for (auto &kv : c.ws_by_stream) kv.second.release();
     c.ws_by_stream.clear();
+    for (auto &kv : c.ws2_by_stream) kv.second.release();
+    c.ws2_by_stream.clear();
   }
   c.arena.release();
   c.initialised = false;

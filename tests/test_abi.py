@@ -72,3 +72,27 @@ def test_parse_distance():
     for bad in ("manhattan", "minkowski(x)", "minkowski(-1)"):
         with pytest.raises(ValueError):
             kpop_amd.parse_distance(bad)
+
+
+def test_pack_bases_on_the_host():
+    """kpop_pack_bases needs no GPU: 2-bit codes (A0 C1 G2 T3, either case; base i in bits 2 (i % 16).. of word i / 16) and a bit a base
+    that is none of ACGTacgt, whatever the number of threads and wherever the batch ends (bin/KPopCount.ml:242-245: Lint.dnaize)"""
+    import numpy as np
+    from kpop_amd import api
+    rng = np.random.RandomState(3)
+    lut = {ord(ch): i for i, ch in enumerate("ACGT")}
+    lut.update({ord(ch): i for i, ch in enumerate("acgt")})
+    for n in (0, 1, 15, 16, 17, 31, 32, 33, 4095, 4096, 4097, 100003):
+        b = np.frombuffer(bytes(rng.choice(list(b"ACGTacgtNnRYKM-*.x\x00\xff"), size=n).astype(np.uint8)), dtype=np.uint8) if n else np.zeros(0, np.uint8)
+        c, m = api.pack_bases(b, threads=1)
+        c3, m3 = api.pack_bases(b, threads=3)
+        assert np.array_equal(c, c3) and np.array_equal(m, m3)
+        assert len(c) == max((n + 15) // 16, 1) and len(m) == max((n + 31) // 32, 1)
+        for i in range(n):
+            code, inv = (int(c[i // 16]) >> (2 * (i % 16))) & 3, (int(m[i // 32]) >> (i % 32)) & 1
+            if int(b[i]) in lut:
+                assert inv == 0 and code == lut[int(b[i])], (n, i, chr(b[i]))
+            else:
+                assert inv == 1, (n, i, int(b[i]))
+        if n % 32:
+            assert (int(m[-1]) >> (n % 32)) == (1 << (32 - n % 32)) - 1  # (past the batch's end: no bases)

@@ -200,3 +200,51 @@ def test_pipeline_headline_shape(kpop, oracle):
     assert np.array_equal(out["twisted"], want_tw)
     assert np.max(np.abs(out["distances"] - want_di) / want_di) <= 1e-12
     pl.close()
+
+
+def test_packed_bases_give_the_ascii_paths_bits(kpop, oracle):
+    """2.25 bits a base at the boundary (kpop_pack_bases, kpop_count_twist_packed, kpop_dev_count_twist_packed,
+    kpop_pipeline_submit_packed; packed.hip): reads with Ns, lower case, IUPAC codes and dashes, empty and short ones, two
+    assemblies of one organism's size among them -- the rows of the one-byte-a-base entry points bit for bit, through the one
+    call, the device-resident call and the streaming pipeline (whose chunks start in the middle of a packed word), and against
+    the oracle (bin/KPopCount.ml:36-50, 242-245 -> lib/Twister.ml:146-188)"""
+    import torch
+    from kpop_amd import api
+    rng = np.random.RandomState(21)
+    k, d = 9, 40
+    alphabet, prob = list("ACGTacgtNRYKM-"), [.22] * 4 + [.02] * 4 + [.01] * 4 + [.0, .0]
+    prob[-2:] = [(1.0 - sum(prob[:-2])) / 2] * 2
+    seqs = ["", "ACG", "N" * 30, "acgtacgtacgtacgt"] + ["".join(rng.choice(alphabet, size=int(rng.randint(1, 400)), p=prob)) for _ in range(1500)]
+    seqs[700] = "".join(rng.choice(list("ACGT"), size=9000))
+    seqs[900] = "".join(rng.choice(list("ACGTN"), size=7013, p=[.2475] * 4 + [.01]))
+    bases, offs = concat(seqs)
+    cols = oracle.enumerate_kmers(k)
+    T = oracle.synth_twister(4, d, cols)
+    tw = kpop.Twister.load(T, cols, k)
+    codes, invalid = api.pack_bases(bases, threads=2)
+    want = tw.count_twist(bases, offs)
+    h, c, o = oracle.count_reads(bases, offs, k)
+    np.testing.assert_allclose(want, oracle.twist(T, cols, h, c.astype(np.float64), o), rtol=1e-12, atol=1e-15)
+    assert np.array_equal(tw.count_twist_packed(codes, invalid, offs), want)
+    # device-resident: unpack alone, then the packed twin
+    dev = torch.device("cuda", 0)
+    dc, dm = torch.from_numpy(codes.view(np.int32)).to(dev), torch.from_numpy(invalid.view(np.int32)).to(dev)
+    do = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    spread = torch.zeros(len(bases), dtype=torch.uint8, device=dev)
+    api.dev_unpack_bases(dc.data_ptr(), dm.data_ptr(), len(bases), spread.data_ptr())
+    torch.cuda.synchronize()
+    up = np.frombuffer(bytes(bases), dtype=np.uint8) & 0xDF
+    expect = np.where(np.isin(up, np.frombuffer(b"ACGT", dtype=np.uint8)), up, ord("N")).astype(np.uint8)
+    assert np.array_equal(spread.cpu().numpy(), expect)
+    out = torch.zeros(len(seqs), d, dtype=torch.float64, device=dev)
+    api.dev_count_twist_packed(tw, dc.data_ptr(), dm.data_ptr(), do.data_ptr(), len(seqs), len(bases), max(len(s_) for s_ in seqs), out.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    # the streaming pipeline, in chunks that start anywhere in a word
+    for chunk_reads in (0, 97, 400):
+        pl = kpop.Pipeline(tw, outputs=kpop.OUT_TWISTED, chunk_reads=chunk_reads, depth=3)
+        res = pl.alloc_outputs(len(seqs), pinned=False)
+        pl.collect(pl.submit_packed(codes, invalid, np.ascontiguousarray(offs, dtype=np.uint64), res))
+        assert np.array_equal(res["twisted"], want), chunk_reads
+        pl.close()
+    tw.free()
