@@ -995,6 +995,74 @@ def pcie_inclusive(R, n, reps=5, stream_batches=10):
     return out
 
 
+def pcie_inclusive_config3(R, n=5000, L=30000, reps=5):
+    """BASELINE config 3's kind of batch (assemblies of one organism, 0.3 % substitutions; 5,000 x 30 kb = 150 MB: a tenth of it) from
+    host memory to host memory through the streaming pipeline, one byte a base against the packed form (packed.hip: 2.25 bits a base):
+    a host caller of assemblies is bound by the BUS on ASCII -- the kernels take a third of the time the bytes take to arrive"""
+    import numpy as np
+    from kpop_amd import _lib
+    import kpop_amd
+    t, api = R.torch, R.api
+    lib = _lib.load()
+    bases_d, offs_d = _mutants_on_device(R, n, L, 0.003, 0x0123)
+    t.cuda.synchronize()
+    bases = kpop_amd.host_empty(n * L, np.uint8)
+    bases[:] = bases_d.cpu().numpy()
+    offs = kpop_amd.host_empty(n + 1, np.uint64)
+    offs[:] = offs_d.cpu().numpy().astype(np.uint64)
+    out_d = t.zeros(n, R.args.dims, dtype=t.float64, device=R.dev)
+    ms_kernel, _ = _event_ms(R, lambda: api.dev_count_twist(R.tw, bases_d.data_ptr(), offs_d.data_ptr(), n, n * L, L, out_d.data_ptr(), stream=R.sp), 5, 2)
+    # the packed form (a host that keeps its sequences packed does this once, not per call: timed, reported, not part of the step)
+    cw, mw = int(lib.kpop_packed_code_words(n * L)), int(lib.kpop_packed_mask_words(n * L))
+    codes, invalid = kpop_amd.host_empty(cw, np.uint32), kpop_amd.host_empty(mw, np.uint32)
+    pack_s = []
+    for th in (1, 0):
+        t0 = time.perf_counter()
+        kpop_amd.check(lib.kpop_pack_bases(bases.ctypes.data, n * L, codes.ctypes.data, invalid.ctypes.data, th))
+        pack_s.append(time.perf_counter() - t0)
+    dc, dm = t.from_numpy(np.array(codes).view(np.int32)).to(R.dev), t.from_numpy(np.array(invalid).view(np.int32)).to(R.dev)
+    spread = t.empty(n * L, dtype=t.uint8, device=R.dev)
+    ms_unpack, _ = _event_ms(R, lambda: api.dev_unpack_bases(dc.data_ptr(), dm.data_ptr(), n * L, spread.data_ptr(), stream=R.sp), 5, 2)
+    same_letters = bool(t.equal(spread, bases_d))
+    h2d, d2h = bus_rates(lib)
+    pl = kpop_amd.Pipeline(R.tw, outputs=kpop_amd.OUT_TWISTED)
+    res = {}
+    rows = {}
+    for name, submit, up in (("ascii", lambda o: pl.submit(bases, offs, o), int(bases.nbytes + offs.nbytes)),
+                             ("packed", lambda o: pl.submit_packed(codes, invalid, offs, o), int(codes.nbytes + invalid.nbytes + offs.nbytes))):
+        o = pl.alloc_outputs(n)
+        pl.collect(submit(o))
+        pl.collect(submit(o))
+        single = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            pl.collect(submit(o))
+            single.append(time.perf_counter() - t0)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            tickets = [submit(o) for _ in range(6)]
+            pl.collect(tickets[-1])
+            dt = (time.perf_counter() - t0) / 6
+            best = dt if best is None else min(best, dt)
+        down = int(o["twisted"].nbytes)
+        bus = max(up / (h2d * 1e9), down / (d2h * 1e9))
+        bound = max(bus, ms_kernel * 1e-3)
+        res[name] = {"value": n / best, "unit": "sequences/sec", "ms_per_batch": best * 1e3, "single_call_ms": min(single) * 1e3, "bytes_up": up, "bytes_down": down,
+                     "bus_bound_ms": bus * 1e3, "kernel_bound_ms": ms_kernel, "bound": "bus" if bus > ms_kernel * 1e-3 else "kernels",
+                     "fraction_of_the_larger_bound": bound / best, "chunks": pl.stats()["chunks"]}
+        rows[name] = np.array(o["twisted"])
+    pl.close()
+    res["workload"] = "%d assemblies x %d bp of one organism (0.3 %% substitutions), k=%d, D=%d, twisted rows back; six batches in flight, best of 3" % (n, L, R.args.k, R.args.dims)
+    res["speedup_packed_over_ascii"] = res["ascii"]["ms_per_batch"] / res["packed"]["ms_per_batch"]
+    res["same_rows_bit_for_bit"] = bool(np.array_equal(rows["ascii"], rows["packed"]))
+    res["unpack_on_device"] = {"ms": ms_unpack, "GBps_of_bytes_written": n * L / (ms_unpack * 1e-3) / 1e9, "letters_equal_the_ascii_batch": same_letters}
+    res["host_packing"] = {"one_thread_GBps": n * L / pack_s[0] / 1e9, "library_chosen_threads_GBps": n * L / pack_s[1] / 1e9,
+                           "note": "kpop_pack_bases on this host (input bytes per second); not part of the step: a caller of the packed entry points keeps its sequences packed"}
+    res["bus"] = {"h2d_GBps": h2d, "d2h_GBps": d2h}
+    return res
+
+
 def measure_traffic(R, n_reads, k=None, dims=None, read_len=None, kernel="count_twist_wave_kernel", launches=3, mutants=0.0, timeout=240):
     """HBM bytes per launch of the fused kernel, measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters
     never share a run with a trace summary) of a child process that launches the same kernel on the same shape
@@ -1432,6 +1500,10 @@ def main():
             # pipeline leg of the same process came out at 38 M sequences/s instead of 50, four runs out of five --
             # tools/probes/pcie_leg_repeat.py, the leg alone: 50.4-50.5, eight times out of eight)
             line["pcie_inclusive"] = pcie_inclusive(R, n_local)
+            try:
+                line["pcie_inclusive"]["config3"] = pcie_inclusive_config3(R)
+            except Exception as e:  # (a report, never a reason to lose the line)
+                line["pcie_inclusive"]["config3"] = {"skipped": "leg failed: %r" % (e,)}
             c4 = R.run_config4(1000000, max(3, min(args.steps, 10)), 2)
             live = None if args.no_children else measure_traffic(R, n_local)
             if live:
