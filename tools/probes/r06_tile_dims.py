@@ -92,7 +92,7 @@ def main():
             pn = ["staged", "set built", "rows+X set", "windows", "misses listed", "misses' rows", "p barriers", "wait empty"]
             ptot = float(sum(c[:8])) or 1.0
             print("   producers: " + "  ".join("%s %.3f" % (nm, x / ptot) for nm, x in zip(pn, c[:8])), flush=True)
-            cn = ["wait chunk", "matrix cores(+gather)", "sums out", "c barriers", "list tail (D<=64) | PRODUCERS gather (D>64)"]
+            cn = ["wait chunk", "matrix cores(+gather)", "sums out", "c barriers", "list tail (D<=64)"]
             ctot = float(sum(c[8:13])) or 1.0
             print("   consumers: " + "  ".join("%s %.3f" % (nm, x / ctot) for nm, x in zip(cn, c[8:13])), flush=True)
         tw.free()
