@@ -723,6 +723,25 @@ def config3_distances_leg(R):
                      "frac": fls / (mss * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS, "traffic": None, "algorithmic_flops_per_launch": fls, "avg_launch_ms": mss,
                      "note": "the whole call (norms, contraction, the summary's selection on the approximate rows, the exact refinement) over the contraction's flops"},
         "vector_pipe_ms": mss0, "speedup_over_vector_pipe": mss0 / mss, "medians_mads_neighbours_same_bits_as_the_vector_pipe": same}
+    # ... and with enough query rows for the call's fixed costs (the reference set divided by its norms: 17 GB moved) to be shared:
+    # what one call of the reference's own job (650 K query rows, README.md:1101) does chunk after chunk
+    try:
+        q2 = 4096
+        qs2 = db[t.randperm(r1s, device=R.dev, generator=g)[:q2]].clone()
+        work2 = t.empty(api.dev_distance_workspace_bytes(r1s, q2, d), dtype=t.uint8, device=R.dev)
+        st2, n2 = t.zeros(q2, 4, dtype=t.float64, device=R.dev), t.zeros(q2, dtype=t.int32, device=R.dev)
+        i2, d2, z2 = t.zeros(q2, K, dtype=t.int32, device=R.dev), t.zeros(q2, K, dtype=t.float64, device=R.dev), t.zeros(q2, K, dtype=t.float64, device=R.dev)
+        call2 = lambda: api.dev_distance_summary(db.data_ptr(), r1s, qs2.data_ptr(), q2, d, metric.data_ptr(), work2.data_ptr(), st2.data_ptr(), n2.data_ptr(),
+                                                 i2.data_ptr(), d2.data_ptr(), z2.data_ptr(), keep_at_most=300, max_neighbours=K, stream=R.sp)
+        ms2, all2 = _event_ms(R, call2, 2, 1)
+        fl2 = 2.0 * r1s * q2 * d
+        res["distance_summary_4096_x_650k"] = {"ms": ms2, "ms_all": all2, "value": q2 / (ms2 * 1e-3), "unit": "query rows/sec", "keep_at_most": 300,
+                                               "roofline": {"kernel": "distance_gemm_mfma_kernel", "bound": "mfma", "achieved": fl2 / (ms2 * 1e-3) / 1e12, "peak": MFMA_F64_PEAK_TFLOPS,
+                                                            "unit": "TFLOP/s", "frac": fl2 / (ms2 * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS, "traffic": None,
+                                                            "algorithmic_flops_per_launch": fl2, "avg_launch_ms": ms2},
+                                               "all_650k_query_rows_at_this_rate_s": 650000 / (q2 / (ms2 * 1e-3))}
+    except Exception as e:
+        res["distance_summary_4096_x_650k"] = {"skipped": "%r" % (e,)}
     return res
 
 
