@@ -111,8 +111,8 @@ struct Context {
   int tune_dense = 2;    // the matrix-core routes of the twist: 2 (default) chosen by the batch -- assemblies through count_twist_tile_kernel (consensus on the matrix cores + residual gather), small-k assemblies through the dense image, dense spectra through the contraction --, 1 kpop_twist always dense, 0 never (the sparse mat-vec in the reference's order of additions everywhere)
   int tune_tileg = 64;   // sequences a chunk of count_twist_tile_kernel: 64 (one block of 1,024 threads a CU) or 32 (two of 512: measured slower, 1.96 against 1.64 ms on 5,000 mutants at 0.1 % -- every per-chunk step is paid twice as often)
   int tune_tilepipe = 1; // assemblies of one organism, up to 64 dimensions: count_twist_tile_pipe_kernel (producer and consumer wavefronts, tile_pipe.h); 0: round 4's count_twist_tile_kernel
-  int tune_tilewide = 0; // 1: the slab-by-slab form of that kernel (what more than 64 dimensions get) at any number of dimensions
-  int tune_tilecap_mb = 0; // MiB of per-slot tables a call of the slab-by-slab route may take before the batch goes through in sub-batches (0: 4 GiB a slab of 64 columns, a quarter of the device's memory at most)
+  int tune_tilewide = 0; // 1: the three-stage form of that kernel (tile_pipe.h WIDE: what more than 64 dimensions get) at any number of dimensions
+  int tune_tilecap_mb = 0; // MiB of per-slot tables a call of that route beyond 64 dimensions may take before the batch goes through in sub-batches (0: 4 GiB per 64 columns, a quarter of the device's memory at most)
   int tune_pipeprio = 1; // issue priority of the MFMA wavefronts of the tile kernel beyond 64 dimensions (producers: 2, gather wavefronts: 1); measured 0: 0.410 / 0.433, 1: 0.412 / 0.465, 2: 0.393 / 0.451, 3: 0.393 / 0.445 of the matrix peak at 256 / 1,635 dimensions; | 4: the gather with plain instead of non-temporal loads (no difference)
   int tune_blocksort = 1;  // -L on sequences of up to 32,768 windows: one block per sequence, sorted in LDS (0: device-wide sort)
   int tune_hist = 1;     // merged (-l) spectrum by atomic histogram when the hashes fit 26 bits (0: always sort)

@@ -1704,9 +1704,9 @@ static int launch_count_twist_wave(int R, TwisterView tv, const uint8_t *bases, 
 static bool tile_route_pipe(const kpop_twister *tw) {
   return tw->d_rsel && (tw->hk ? tw->hk : tw->k) <= 15 && ctx().tune_tilepipe != 0 && tw->n_rows <= (1ull << 29) && (uint64_t)tw->n_rows * (tw->d_pad / 16) < 0xFFFFFFFFull;
 }
-// ... slab by slab: more than 64 dimensions (kpop_tune("tilewide", 1): at any number of them -- up to 64 the same bits as the other)
+// ... in its three-stage form (tile_pipe.h, WIDE: the columns unit by unit): more than 64 dimensions (kpop_tune("tilewide", 1): at any number of them -- up to 64 the same bits as the other)
 static bool tile_route_wide(const kpop_twister *tw) { return tile_route_pipe(tw) && (tw->n_dims > 64 || ctx().tune_tilewide == 1); }
-// bytes of per-slot tables a call of the wide route may take: 4 GiB a slab of 64 columns, a quarter of the device's memory at most (the
+// bytes of per-slot tables a call of the wide route may take: 4 GiB per 64 columns, a quarter of the device's memory at most (the
 // same for every call: how a batch is cut into sub-batches must not depend on what happens to be free)
 static uint64_t tile_workspace_cap(uint32_t d_pad) {
   if (ctx().tune_tilecap_mb > 0) return (uint64_t)ctx().tune_tilecap_mb << 20;
@@ -1805,7 +1805,7 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   // The tile route cuts sequences into 512-window segments, so its per-slot tables are sized for n_bases / 512 slots whatever the
   // probe later finds (BASELINE config 3, D = 64: 1.5 GB of partial rows against 0.28 GB; beyond 64 dimensions 2 KB of residual
   // list a slot on top).  Where that would pass 4 GiB of workspace -- per stream -- the batch keeps the streaming kernel.
-  // Beyond 64 dimensions the pipelined kernel takes the columns in slabs of 64 (tile_pipe.h, WIDE); its bound is 4 GiB per slab of
+  // Beyond 64 dimensions the pipelined kernel takes the columns unit by unit (tile_pipe.h, WIDE); its bound is 4 GiB per 64
   // columns (BASELINE config 3 at 256 dimensions: 6.1 GB of partial rows; at the reference's 1,635, README.md:1029, 39 GB -- what 288 GB
   // are for), and a batch beyond THAT goes through in sub-batches of sequences, each sized from max_len (below).
   const bool pipe_able = tile_route_pipe(tw);
@@ -1896,7 +1896,7 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
       const int tdbg = ((ctx().tune_dbg >> 24) & 127) | ((ctx().tune_pipeprio & 3) << 8) | ((ctx().tune_pipeprio & 4) ? 128 : 0);  // (bit 7: the producers' gather with plain loads)
 #define KPOP_PIPE(A, W) count_twist_tile_pipe_kernel<A, W><<<dim3(pblocks), dim3(1024), kPipeLdsBytes, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, olong, sums2 + nb, gmax, grel, max_seg, slot_done, wave_lists, tdbg)
       // (the ablation switches: a build of the kernel of their own, so that the product's loops carry no test of them;
-      //  kpop_tune("tilewide", 1): the slab-by-slab kernel at any number of dimensions -- at up to 64 the same bits as the other)
+      //  kpop_tune("tilewide", 1): the three-stage kernel at any number of dimensions -- at up to 64 the same bits as the other)
       const bool wide_k = wide;
       if (tdbg & 15) {
         if (wide_k) KPOP_PIPE(true, true); else KPOP_PIPE(true, false);

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(1024) void count_twist_tile_pipe_kernel(
     // (blocks go to the eight XCDs in turn: the ranges are dealt so that the blocks of ONE XCD hold neighbouring ranges -- a few
     // stretches' worth of twister rows per L2, not every stretch's)
     // WIDE: an XCD's blocks take the chunks of the XCD's range IN TURN (block j of it: chunks j, j + 32, ...): they multiply the same
-    // stretch's members at the same time, slab after slab, out of one L2 -- and a block's chunks in a row are still one stretch's.
+    // stretch's members at the same time, unit after unit, out of one L2 -- and a block's chunks in a row are still one stretch's.
     const uint32_t vblock = gridDim.x % 8u == 0 ? (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u : blockIdx.x;
     const uint64_t per_block = (n_chunks + gridDim.x - 1) / gridDim.x;
     const bool by_xcd = WIDE && gridDim.x % 8u == 0;

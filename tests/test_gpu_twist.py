@@ -724,9 +724,9 @@ def _one_organism(rng, n, L, rate, unrelated=8, indel_every=7):
 
 @pytest.mark.parametrize("k,d,rate", [(12, 256, 0.003), (10, 1635, 0.002), (11, 100, 0.01), (12, 72, 0.03), (13, 130, 0.001), (9, 65, 0.003)])
 def test_assemblies_through_more_than_64_dimensions(kpop, oracle, k, d, rate):
-    """beyond 64 dimensions the pipelined tile kernel takes the twister's columns in slabs of 64 (tile_pipe.h, WIDE): the same X of a
-    chunk against slab after slab of the members' rows, every consumer wavefront gathering the residual rows of the sequences it
-    multiplies for its own 16 columns -- at the reference's own 1,635 dimensions (README.md:1029), at 256, at widths that end inside
+    """beyond 64 dimensions the pipelined tile kernel runs three stages a block (tile_pipe.h, WIDE): producers prepare the next chunk, four
+    MFMA wavefronts multiply the current one's X against unit after unit of 16 columns of the members' rows, four gather wavefronts add
+    the chunk before's residual rows to its slots -- at the reference's own 1,635 dimensions (README.md:1029), at 256, at widths that end inside
     a slab (100, 72, 130) and one column past a slab (65): against the oracle, against the streaming kernel, the same bits twice,
     and against round 4's kernel (phases one after the other, the residual rows in a launch of their own).  lib/Twister.ml:146-188"""
     from kpop_amd import api
@@ -763,10 +763,10 @@ def test_assemblies_through_more_than_64_dimensions(kpop, oracle, k, d, rate):
 
 @pytest.mark.parametrize("k,d,rate", [(12, 64, 0.002), (10, 40, 0.01), (12, 64, 0.03)])
 def test_the_slab_by_slab_kernel_at_up_to_64_dimensions_gives_the_other_kernels_bits(kpop, oracle, k, d, rate):
-    """kpop_tune("tilewide", 1) sends a twister of up to 64 dimensions through the slab-by-slab consumers (one slab): the members'
-    rows are multiplied in the same order and a sequence's residual rows added in the same (window) order, so the rows must equal
-    the exchanging kernel's bit for bit -- the lists filed by lane group, the padding, the ranges and the sums leaving from the
-    accumulators' registers all have to be right for that."""
+    """kpop_tune("tilewide", 1) sends a twister of up to 64 dimensions through the three-stage kernel (MFMA wavefronts + gather
+    wavefronts): the members' rows are multiplied in the same order and a sequence's residual rows added in the same (window) order, so
+    the rows must equal the exchanging kernel's bit for bit -- the hand-overs between the three stages, the sums leaving from the
+    accumulators' registers and their meeting the gather's in the slots all have to be right for that."""
     from kpop_amd import api
     rng = np.random.RandomState(k * d)
     seqs = _one_organism(rng, 200, 9000, rate)
