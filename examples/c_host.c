@@ -137,6 +137,19 @@ int main(void) {
     CHECK(kpop_host_free(pnd));
     CHECK(kpop_host_free(pnz));
   }
+  {
+    /* the same three reads handed over PACKED (2 bits a base + a bit a base that is no base: include/kpop_hip.h, "packed bases"):
+       the host packs once, 2.25 bits a base cross the bus, the rows are the byte entry point's bit for bit */
+    const uint64_t n_bases = offsets[3];
+    uint32_t *codes = (uint32_t *)calloc(kpop_packed_code_words(n_bases) + 1, 4), *invalid = (uint32_t *)calloc(kpop_packed_mask_words(n_bases) + 1, 4);
+    double packed_rows[6];
+    CHECK(kpop_pack_bases(bases, n_bases, codes, invalid, 1));
+    CHECK(kpop_count_twist_packed(tw, codes, invalid, offsets, 3, KPOP_DNA_DS, 1, packed_rows));
+    printf("packed: %llu bases in %llu + %llu words, rows %s\n", (unsigned long long)n_bases, (unsigned long long)kpop_packed_code_words(n_bases),
+           (unsigned long long)kpop_packed_mask_words(n_bases), memcmp(packed_rows, fused, sizeof fused) == 0 ? "identical" : "DIFFERENT");
+    free(codes);
+    free(invalid);
+  }
   CHECK(kpop_twister_free(tw));
   free(T);
   CHECK(kpop_shutdown());

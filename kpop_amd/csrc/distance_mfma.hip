@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256, 2) void distance_gemm_mfma_kernel(const double
           if (GUARD && u < tau * (sai + sbj))
             d = exact_pair_rows<KIND>(a + (uint64_t)col * n_dims, b + (uint64_t)row * n_dims, metric, n_dims, p);
           else
-            d = KIND == KPOP_EUCLIDEAN ? (GUARD ? sqrt(u) : sqrt_fast(u)) : u * 0.5;
+            d = KIND == KPOP_EUCLIDEAN ? sqrt_fast(u) : u * 0.5;  // (an ulp or two: far inside what the contraction itself leaves)
           out[(uint64_t)row * r1 + col] = d;
         }
       }

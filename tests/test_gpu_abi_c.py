@@ -39,9 +39,11 @@ def test_c_host_program(tmp_path, oracle, pyref):
         fused = [float(x) for x in t.split("|")[1].split()[1:3]]
         assert np.allclose(fused, tw[i], rtol=1e-12, atol=0)
         assert lines[6 + i] == "distances %d: %.15g %.15g" % (i, dist[i, 0], dist[i, 1])
-    assert len(lines) == 16 and all(l.startswith("summary") for l in lines[9:12])
+    assert len(lines) == 17 and all(l.startswith("summary") for l in lines[9:12])
     # the streaming pipeline from C: two chunks, page-locked buffers, same neighbours, distances of the fused rows
     assert lines[12] == "pipeline: 2 chunks, pinned 1, neighbours identical"
     for i in range(3):
         got = [float(x) for x in lines[13 + i].split(":")[1].split()]
         assert np.allclose(got, dist[i], rtol=1e-12, atol=0)
+    # the packed entry points from C: 31 bases in 2 + 1 words, the byte entry point's rows
+    assert lines[16] == "packed: 31 bases in 2 + 1 words, rows identical"
