@@ -844,7 +844,8 @@ def test_a_batch_past_the_tile_routes_bound_goes_through_in_sub_batches(kpop, or
     tw.free()
 
 
-def test_assemblies_with_low_complexity_runs_and_shifted_copies(kpop, oracle):
+@pytest.mark.parametrize("d", [64, 136])
+def test_assemblies_with_low_complexity_runs_and_shifted_copies(kpop, oracle, d):
     """what the pipelined tile kernel (tile_pipe.h, up to 64 dimensions) leaves to the streaming kernel or takes the slow way:
     stretches in which one k-mer occurs more than 255 times (a poly-A of 400, an (AT)n of 500, in every mutant: the one-byte
     counts of X would overflow -- the row-sum check must send those chunks away, not return garbage), and assemblies that carry
@@ -852,7 +853,7 @@ def test_assemblies_with_low_complexity_runs_and_shifted_copies(kpop, oracle):
     against the oracle, and the same bits twice"""
     from kpop_amd import api
     rng = np.random.RandomState(5)
-    k, d = 12, 64
+    k = 12  # (d = 136: the three-stage kernel of more than 64 dimensions -- a chunk it turns away is never handed to its MFMA and gather wavefronts)
     ref = rng.choice(list("ACGT"), size=9000)
     ref[1500:1900] = "A"
     ref[4000:4500] = list("AT" * 250)
@@ -885,11 +886,12 @@ def test_assemblies_with_low_complexity_runs_and_shifted_copies(kpop, oracle):
     assert np.array_equal(got, again)
 
 
-def test_few_assemblies_among_many_reads_and_tiny_batches(kpop, oracle):
+@pytest.mark.parametrize("d", [24, 90])
+def test_few_assemblies_among_many_reads_and_tiny_batches(kpop, oracle, d):
     """the tile route's groups are cut from the sequences that HAVE segments: three assemblies of one organism among 3,000 reads
     (fewer than the route bothers with), then forty of them scattered among the reads (one group), against the oracle"""
     rng = np.random.RandomState(77)
-    k, d = 11, 24
+    k = 11
     ref = rng.choice(list("ACGT"), size=5000)
     def mutant():
         m = ref.copy()
@@ -911,13 +913,14 @@ def test_few_assemblies_among_many_reads_and_tiny_batches(kpop, oracle):
         assert np.max(np.abs(got - want)) <= 1e-12 * max(np.max(np.abs(want)), 1.0)
 
 
-def test_first_sequence_of_a_group_is_the_odd_one_out(kpop, oracle):
+@pytest.mark.parametrize("d", [64, 200])
+def test_first_sequence_of_a_group_is_the_odd_one_out(kpop, oracle, d):
     """sequence 0 of a group seeds the consensus set; when it is a stranger (a contaminant among 80 assemblies of one organism)
     the other seeds find fewer than half of their rows there and the set is started again from the next seed: the group still goes
     through the tile kernel (another order of additions than kpop_tune("dense", 0)), and the stranger's own rows are right"""
     from kpop_amd import api
     rng = np.random.RandomState(21)
-    k, d = 12, 64
+    k = 12
     ref = rng.choice(list("ACGT"), size=6000)
     def mutant():
         m = ref.copy()
