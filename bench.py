@@ -1079,6 +1079,23 @@ def pcie_inclusive_config3(R, n=5000, L=30000, reps=5):
     res["host_packing"] = {"one_thread_GBps": n * L / pack_s[0] / 1e9, "library_chosen_threads_GBps": n * L / pack_s[1] / 1e9,
                            "note": "kpop_pack_bases on this host (input bytes per second); not part of the step: a caller of the packed entry points keeps its sequences packed"}
     res["bus"] = {"h2d_GBps": h2d, "d2h_GBps": d2h}
+    # the headline batch from its packed words, device-resident: reads of up to 512 windows are twisted straight from them (no bytes made)
+    try:
+        nr, Lr = 100000, R.args.read_len
+        rb, ro = R.synth_reads(nr, 0)
+        t.cuda.synchronize()
+        hb = rb.cpu().numpy()
+        cw2, mw2 = int(lib.kpop_packed_code_words(nr * Lr)), int(lib.kpop_packed_mask_words(nr * Lr))
+        hc, hm = np.zeros(cw2, np.uint32), np.zeros(mw2, np.uint32)
+        kpop_amd.check(lib.kpop_pack_bases(hb.ctypes.data, nr * Lr, hc.ctypes.data, hm.ctypes.data, 0))
+        dcr, dmr = t.from_numpy(hc.view(np.int32)).to(R.dev), t.from_numpy(hm.view(np.int32)).to(R.dev)
+        o1, o2 = t.zeros(nr, R.args.dims, dtype=t.float64, device=R.dev), t.zeros(nr, R.args.dims, dtype=t.float64, device=R.dev)
+        ms_a, _ = _event_ms(R, lambda: api.dev_count_twist(R.tw, rb.data_ptr(), ro.data_ptr(), nr, nr * Lr, Lr, o1.data_ptr(), stream=R.sp), 10, 2)
+        ms_p, _ = _event_ms(R, lambda: api.dev_count_twist_packed(R.tw, dcr.data_ptr(), dmr.data_ptr(), ro.data_ptr(), nr, nr * Lr, Lr, o2.data_ptr(), stream=R.sp), 10, 2)
+        res["headline_reads_from_packed_words"] = {"ms_bytes": ms_a, "ms_packed": ms_p, "same_rows_bit_for_bit": bool(t.equal(o1, o2)),
+                                                   "note": "count_twist_wave_kernel<..., PACKED>: a read's codes staged from the batch's words (15 words a 150-base read instead of 150 bytes)"}
+    except Exception as e:
+        res["headline_reads_from_packed_words"] = {"skipped": "%r" % (e,)}
     return res
 
 

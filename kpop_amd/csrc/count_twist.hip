@@ -308,10 +308,12 @@ __device__ __forceinline__ void wave_fill_x(WaveLds<R, uint32_t> &L, uint32_t nu
 // ---------------------------------------------------------------------------
 // fused count -> twist: one wave per read
 // ---------------------------------------------------------------------------
-template <int R, typename H, int U, bool NT>
+// (PACKED: `bases` is the batch's words of 2-bit codes and `pinvalid` its marks of bases that are none -- kpop_dev_count_twist_packed)
+template <int R, typename H, int U, bool NT, bool PACKED = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void count_twist_wave_kernel(
     TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets,
-    const uint32_t *__restrict__ read_ids, uint32_t n, int content, int normalize, double *__restrict__ out) {
+    const uint32_t *__restrict__ read_ids, uint32_t n, int content, int normalize, double *__restrict__ out,
+    const uint32_t *__restrict__ pinvalid = nullptr) {
   __shared__ WaveLds<R, uint32_t> lds[kWavesPerBlock];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t w = blockIdx.x * kWavesPerBlock + wv;
@@ -329,7 +331,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void count_twist_wave_kernel(
   }
   normalize &= 1;
 
-  wave_stage_codes<R>(bases + off, len, lane, L.codes);
+  if constexpr (PACKED)
+    wave_stage_codes_packed<R>(reinterpret_cast<const uint32_t *>(bases), pinvalid, off, len, lane, L.codes);
+  else
+    wave_stage_codes<R>(bases + off, len, lane, L.codes);
   H hkey[R];
   wave_hash_windows<R, H>(L.codes, tv.hk, content, lane, hkey);
   // name -> column (lib/Twister.ml:151); k-mers the twister does not know are
@@ -1716,6 +1721,27 @@ static uint64_t tile_workspace_cap(uint32_t d_pad) {
   return cap;
 }
 
+// the same launch from the packed form of the batch (reads of up to 512 windows only: the caller has checked)
+template <typename H>
+static int launch_count_twist_wave_packed(int R, TwisterView tv, const uint32_t *codes, const uint32_t *invalid, const uint64_t *offsets, uint32_t n, int content,
+                                          int normalize, double *out, hipStream_t st) {
+  const Context &c = ctx();
+  const bool nt = c.tune_nt == 1 || (c.tune_nt == 2 && (uint64_t)tv.n_rows * tv.d_pad * 8 > kStreamingRowBytes);
+  dim3 grid(div_up(n, kWavesPerBlock)), block(64 * kWavesPerBlock);
+  const uint8_t *b = reinterpret_cast<const uint8_t *>(codes);
+#define KPOP_WP(RR, NTV) count_twist_wave_kernel<RR, H, 8, NTV, true><<<grid, block, (size_t)c.tune_ldspad, st>>>(tv, b, offsets, nullptr, n, content, normalize, out, invalid)
+  switch (R) {
+    case 1: if (nt) KPOP_WP(1, true); else KPOP_WP(1, false); break;
+    case 2: if (nt) KPOP_WP(2, true); else KPOP_WP(2, false); break;
+    case 4: if (nt) KPOP_WP(4, true); else KPOP_WP(4, false); break;
+    case 8: if (nt) KPOP_WP(8, true); else KPOP_WP(8, false); break;
+    default: KPOP_FAIL(KPOP_ERR_INVALID, "launch_count_twist_wave_packed: R=%d", R);
+  }
+#undef KPOP_WP
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
+
 static int check_offsets(const uint64_t *offsets, uint32_t n, uint64_t *max_len) {
   uint64_t m = 0;
   for (uint32_t r = 0; r < n; ++r) {
@@ -1958,6 +1984,23 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   KPOP_LAUNCH_CHECK();
   combine_partials_kernel<<<dim3(max_long), dim3(256), 0, st>>>(nseg, seg_off, part, pcnt, tw->n_dims, normalize, d_out, long_ids, n_long);
   KPOP_LAUNCH_CHECK();
+  return KPOP_OK;
+}
+
+// packed.hip's fast way: a batch whose reads ALL fit the one-wavefront-per-read kernel is twisted straight from its packed words (no
+// bytes are ever made); returns 1 when it did, 0 when the batch holds longer sequences (the caller spreads the bases and takes the usual way)
+int count_twist_wave_from_packed(const kpop_twister *tw, const uint32_t *d_codes, const uint32_t *d_invalid, const uint64_t *d_offsets, uint32_t n_reads,
+                                 uint32_t max_len, int content, int normalize, double *d_out, hipStream_t st, int *done) {
+  const TwisterView tv = view_of(tw);
+  const uint32_t max_windows = (max_len >= (uint32_t)tv.hk) ? max_len - tv.hk + 1 : 0;
+  *done = 0;
+  if (max_windows > kWaveMaxWindows || (content != KPOP_DNA_DS && content != KPOP_DNA_SS)) return KPOP_OK;
+  const int R = pick_R(max_windows);
+  if (tv.hk <= 15)
+    KPOP_TRY(launch_count_twist_wave_packed<uint32_t>(R, tv, d_codes, d_invalid, d_offsets, n_reads, content, normalize ? 1 : 0, d_out, st));
+  else
+    KPOP_TRY(launch_count_twist_wave_packed<uint64_t>(R, tv, d_codes, d_invalid, d_offsets, n_reads, content, normalize ? 1 : 0, d_out, st));
+  *done = 1;
   return KPOP_OK;
 }
 

@@ -9,8 +9,9 @@
 //             Lint.dnaize turns them all into bases that start no k-mer), 32 bases a word
 // -- 3.56 times fewer bytes over the bus.  On the device kpop_dev_unpack_bases spreads them back to one byte a base (ACGT, N for an
 // invalid one) at HBM's rate (1.5 GB in 0.3-0.4 ms: 1.28 bytes moved a base) and the kernels run as they are: what they hash is the
-// same letters, so every result is the ASCII path's bit for bit.  (The tile kernel re-codes its stretches as it stages them, the
-// wave kernel as it loads a read: a later round can hand them the words directly; the bus was the bound, not those.)
+// same letters, so every result is the ASCII path's bit for bit.  A batch of READS (all of up to 512 windows: the headline's kind) skips
+// even that: count_twist_wave_kernel<..., PACKED> stages a read's 2-bit codes straight from the words.  (The genome kernels still take
+// bytes: the tile kernel re-codes its stretches as it stages them; the bus was the bound, not that.)
 #include <algorithm>
 #include <cstring>
 #include <thread>
@@ -18,6 +19,10 @@
 
 #include "common.h"
 #include "twister.h"
+
+// count_twist.hip
+int count_twist_wave_from_packed(const kpop_twister *tw, const uint32_t *d_codes, const uint32_t *d_invalid, const uint64_t *d_offsets, uint32_t n_reads,
+                                 uint32_t max_len, int content, int normalize, double *d_out, hipStream_t st, int *done);
 
 namespace kpop {
 
@@ -135,6 +140,13 @@ extern "C" int kpop_dev_count_twist_packed(const kpop_twister *tw, const uint32_
   if (!tw || !d_offsets || !d_out || (n_bases && (!d_codes || !d_invalid))) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_count_twist_packed: null argument");
   if (n_reads == 0) return KPOP_OK;
   hipStream_t st = as_stream(stream);
+  // reads that all fit the one-wavefront-per-read kernel (the headline's kind of batch) are twisted straight from the words: a read of 150
+  // bases is fifteen words where it was 150 bytes, and no bytes are made at all
+  if (content != KPOP_DNA_DS && content != KPOP_DNA_SS)
+    KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_count_twist_packed: content %d (the packed form is DNA)", content);
+  int done = 0;
+  KPOP_TRY(count_twist_wave_from_packed(tw, d_codes, d_invalid, d_offsets, n_reads, max_len, content, normalize, d_out, st, &done));
+  if (done) return KPOP_OK;
   void *bytes = nullptr;
   KPOP_TRY(ctx().ws2_for(st).ensure(n_bases + 64, &bytes));  // (the library's SECOND block of the stream: kpop_dev_count_twist takes the first)
   KPOP_TRY(launch_unpack_bases(d_codes, 0, d_invalid, 0, n_bases, reinterpret_cast<uint8_t *>(bytes), st));

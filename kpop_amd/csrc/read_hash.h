@@ -41,6 +41,29 @@ __device__ __forceinline__ void wave_stage_codes(const uint8_t *__restrict__ seq
   __builtin_amdgcn_wave_barrier();
 }
 
+// The same from the PACKED form of a batch (packed.hip: 16 bases a word of 2-bit codes, first base least significant; one bit a base
+// that is none of ACGTacgt): base `off + p` of the batch to lane p -- a read of 150 bases is ten words of codes and five of marks
+// where it was 150 bytes (BASELINE north_star: "coalesced HBM loads of packed bases")
+template <int R>
+__device__ __forceinline__ void wave_stage_codes_packed(const uint32_t *__restrict__ codes, const uint32_t *__restrict__ invalid, uint64_t off, uint32_t len,
+                                                        int lane, uint8_t *s_codes) {
+  constexpr int NB = codes_bytes<R>();
+#pragma unroll
+  for (int i = 0; i < (NB + 63) / 64; ++i) {
+    int p = i * 64 + lane;
+    if (p < NB) {
+      uint32_t c = 4u;
+      if ((uint32_t)p < len) {
+        const uint64_t b = off + (uint64_t)p;
+        const uint32_t bad = (invalid[b >> 5] >> (uint32_t)(b & 31u)) & 1u;
+        c = bad ? 4u : (codes[b >> 4] >> (2u * (uint32_t)(b & 15u))) & 3u;
+      }
+      s_codes[p] = (uint8_t)c;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 // H = uint32_t for k <= 16, uint64_t above.  key[r] = canonical hash of window
 // lane*R+r, or the all-ones sentinel when the window is invalid.
 template <int R, typename H, int SB = 2>

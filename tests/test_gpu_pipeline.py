@@ -248,3 +248,40 @@ def test_packed_bases_give_the_ascii_paths_bits(kpop, oracle):
         assert np.array_equal(res["twisted"], want), chunk_reads
         pl.close()
     tw.free()
+
+
+@pytest.mark.parametrize("k,d,max_len", [(12, 64, 150), (9, 16, 60), (21, 33, 300), (5, 100, 516)])
+def test_reads_twisted_straight_from_the_packed_words(kpop, oracle, k, d, max_len):
+    """a batch whose reads all fit the one-wavefront-per-read kernel never becomes bytes on the device: count_twist_wave_kernel<...,
+    PACKED> stages a read's 2-bit codes from the words of the batch (BASELINE north_star: "coalesced HBM loads of packed bases") --
+    the byte kernel's rows bit for bit, Ns, lower case and IUPAC codes included, reads that start anywhere in a word"""
+    import torch
+    from kpop_amd import api
+    rng = np.random.RandomState(k * d)
+    alphabet, prob = list("ACGTacgtNRY-"), [.23] * 4 + [.015] * 4 + [.005] * 4
+    seqs = ["", "AC", "N" * 20] + ["".join(rng.choice(alphabet, size=int(rng.randint(1, max_len + 1)), p=prob)) for _ in range(3000)]
+    seqs[5] = "".join(rng.choice(list("ACGT"), size=max_len))
+    bases, offs = concat(seqs)
+    h, c, o = oracle.count_reads(bases, offs, k)
+    cols = np.unique(h)
+    T = oracle.synth_twister(9, d, cols)
+    tw = kpop.Twister.load(T, cols, k)
+    codes, invalid = api.pack_bases(bases)
+    dev = torch.device("cuda", 0)
+    dc, dm = torch.from_numpy(codes.view(np.int32)).to(dev), torch.from_numpy(invalid.view(np.int32)).to(dev)
+    do = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    db = torch.from_numpy(np.frombuffer(bytes(bases), dtype=np.uint8).copy()).to(dev)
+    longest = max(len(s_) for s_ in seqs)
+    for normalize in (True, False):
+        # (the byte kernel through the device-resident entry point: the host one sends batches that fill a small twister through the dense image)
+        ref = torch.full((len(seqs), d), float("nan"), dtype=torch.float64, device=dev)
+        api.dev_count_twist(tw, db.data_ptr(), do.data_ptr(), len(seqs), len(bases), longest, ref.data_ptr(), normalize=normalize)
+        out = torch.full((len(seqs), d), float("nan"), dtype=torch.float64, device=dev)
+        api.dev_count_twist_packed(tw, dc.data_ptr(), dm.data_ptr(), do.data_ptr(), len(seqs), len(bases), longest, out.data_ptr(), normalize=normalize)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+        if normalize:
+            want = ref.cpu().numpy()
+            np.testing.assert_allclose(want, oracle.twist(T, cols, h, c.astype(np.float64), o), rtol=1e-12, atol=1e-15)
+            assert np.array_equal(tw.count_twist_packed(codes, invalid, offs), want)
+    tw.free()
