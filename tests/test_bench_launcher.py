@@ -43,3 +43,26 @@ def test_failed_ranks_are_retried_in_process_and_the_retry_is_reported():
     assert rc != 0 and took < 90, (rc, took)
     assert "trying the same job --in-process" in err
     assert "the --in-process attempt" in err
+
+
+def test_config5_goes_through_the_same_launcher_and_fall_back():
+    # `--workload config5 --gpus 2`: the ranks hang (the test switch), the watchdog ends them, the in-process form of the SAME workload is
+    # tried from a fresh child (here it fails for want of a GPU: what is checked is that it was the config-5 job that was retried)
+    rc, out, err, took = _bench({"KPOP_BENCH_FAKE_HANG": "all"}, "--gpus", "2", "--workload", "config5", "-k", "13", "--timeout", "8")
+    assert rc != 0 and took < 90, (rc, took)
+    assert out == ""
+    assert "trying the same job --in-process" in err and "the --in-process attempt" in err
+
+
+def test_config5_shape_and_line_are_built_without_a_gpu():
+    """the workload's defaults (k = 15, D = 16, 10,000 reads unless the command line says otherwise) and the line's fixed fields"""
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args(["--workload", "config5", "--gpus", "4"])
+    assert bench._config5_shape(a) == (15, 16, 10000, 150)
+    a = bench.parse_args(["--workload", "config5", "-k", "13", "--dims", "8", "--reads", "500", "--steps", "2"])
+    assert bench._config5_shape(a) == (13, 8, 500, 150)
+    line = bench._config5_line(a, 2, 13, 8, 500, 150, 0.004, "launcher", "sharding", {"n_ranks_seen": 2})
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["dtype"] == "f64" and line["n_ranks_seen"] == 2
+    assert abs(line["value"] - 500 * 2 / 0.004) < 1e-6 and abs(line["ms_per_step"] - 2.0) < 1e-9
+    assert "config 5" in line["config"]["workload"] and "33554432 canonical" in line["config"]["workload"]
