@@ -97,13 +97,21 @@ int kpop_synchronize(void *stream);
    "summary2" 1 (default) | 3 | 0 | 2: summaries against more than 4,096 rows by brackets from a sample and ONE pass over the
    distance rows, the same in two passes, round 2's one block per row, or (131,072 rows and more) with the distances
    computed and reduced in one kernel and no distance rows in memory -- same results, 1, 3 and 2 level;
-   "summary_mfma" 1 (default) | 0: summaries against 65,536 rows and more, euclidean / cosine, 4 to 128 dimensions: the distances
+   "distance_mfma" 1 (default) | 0: kpop_dev_distance_rowwise of 2^32 products and more (rows x rows x dimensions), euclidean / cosine: the
+   pairs' dot products as f64 MFMAs (a tiled contraction, any number of dimensions), pairs whose d^2 is a small part of |a|^2 + |b|^2
+   recomputed with the reference's chain -- <= 1e-12 relative (3e-15 measured), not bit for bit; 0: the chain for every pair (the reference's bits);
+   "summary_mfma" 1 (default) | 2 | 0: summaries against 65,536 rows and more, euclidean / cosine, 4 dimensions and more (up to 128 the query rows
+   stay in registers, beyond a tiled contraction; 2: up to 128 dimensions the summary's pass runs inside the contraction and no approximate row
+   is written -- same results, measured slower): the distances
    as f64 MFMAs (|a|^2 + |b|^2 - 2 a.b) that only LOCATE the neighbours, the median and the MAD's edges; everything reported is
    recomputed with the reference's chain, rows the refinement cannot vouch for are redone from exact distance rows
    (distance_mfma.hip).  Same medians, MADs and neighbour lists bit for bit; mean and standard deviation are sums of the
    approximate values (1e-13 relative; values cancellation would show in are replaced by exact ones).  0: the chain for every pair.
    "summary_mfma_lists" 1 (default) | 0: that refinement reads the candidate lists the summary's one pass left, or scans the rows;
-   "tilepipe" 1 (default) | 0: the tile route's kernel with producer and consumer wavefronts (tile_pipe.h), or round 4's;
+   "tilepipe" 1 (default) | 0: the tile route's kernel with producer and consumer wavefronts (tile_pipe.h; beyond 64 dimensions its three-stage
+   form: producers / MFMA wavefronts / gather wavefronts), or round 4's; "tilewide" 0 (default) | 1: that three-stage form at any number of
+   dimensions (up to 64: the same bits); "tilecap_mb" 0 (default: 4 GiB per 64 columns, a quarter of the device at most) | MiB: the per-slot tables
+   a call of that route may take before the batch goes through in sub-batches of sequences; "pipeprio" 1 (default) | 0..3: issue priority of its MFMA wavefronts;
    "dense" 2 (default) | 1 | 0: the matrix-core routes of the twist.  2: chosen by the batch -- sequences of more than 512
    windows (assemblies, k <= 15) go through count_twist_tile_kernel: the CONSENSUS rows of a stretch of 64 sequences x 512
    windows (the rows of four seed sequences, an LDS set) are multiplied on the f64 matrix cores, the rows private to one
