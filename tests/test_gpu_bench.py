@@ -100,3 +100,18 @@ def test_config5_the_twisters_rows_over_two_ranks_and_over_two_slots():
         assert abs(a["sum"] - b["sum"]) <= 1e-12 * max(1.0, abs(a["sum"])) * 100 and abs(a["sum_of_squares"] - b["sum_of_squares"]) <= 1e-12 * a["sum_of_squares"] * 100
         for x, y in zip(a["row0"] + a["row_last"], b["row0"] + b["row_last"]):
             assert abs(x - y) <= 1e-12 * max(abs(x), 1e-3)
+
+
+def test_config5_through_rccl_world_size_1():
+    """the sharded form of config 5 with ONE rank (--force-dist): the slice is the whole hash space + the all-ones column, the partial rows go
+    through RCCL's all-reduce (world size 1: the collective path without a second GPU) and come back divided by the reduced acc -- the rows of
+    the plain one-GPU form to 1e-12"""
+    common = ["--workload", "config5", "-k", "13", "--dims", "16", "--reads", "4000", "--steps", "2", "--warmup", "1", "--gpus", "1"]
+    plain = _bench(common)
+    forced = _bench(common + ["--force-dist"])
+    assert forced["launcher"].startswith("torch.distributed") and "RCCL" in forced["launcher"] and forced["n_ranks_seen"] == 1
+    assert "all-reduce" in forced["config"]["sharding"] and forced["rows_finite_and_inside_the_coefficient_range"] is True
+    a, b = plain["rows_digest"], forced["rows_digest"]
+    assert abs(a["sum"] - b["sum"]) <= 1e-10 * max(1.0, abs(a["sum"])) and abs(a["sum_of_squares"] - b["sum_of_squares"]) <= 1e-10 * a["sum_of_squares"]
+    for x, y in zip(a["row0"] + a["row_last"], b["row0"] + b["row_last"]):
+        assert abs(x - y) <= 1e-12 * max(abs(x), 1e-3)
