@@ -389,15 +389,18 @@ __device__ __forceinline__ double exact_pair_rows(const double *__restrict__ aro
 // common to cancellation -- a pair whose d^2~ is below `tau` of |a|^2 + |b|^2 is recomputed with the reference's chain, dimension by
 // dimension (lib/Space.ml:182-205), the others are within (D + 3) 2^-53 / (4 tau) of it, relatively (1.8e-12 at 1,635 dimensions,
 // tau = 0.025; measured: a few 1e-14).  Without it (the summary's rows) the values only LOCATE: see the head of the file.
-constexpr int kDT = 128, kDK = 16, kDS = kDT + 17;  // tile edge, dimensions a chunk, LDS row stride in doubles (odd: the transposed staging's writes spread over the banks)
+constexpr int kDT = 128, kDK = 16, kDS = kDT + 17;
+constexpr size_t kDgLds = (size_t)4 * kDK * kDS * 8;  // two buffers x two panels  // tile edge, dimensions a chunk, LDS row stride in doubles (odd: the transposed staging's writes spread over the banks)
 
 template <int KIND, bool GUARD>
 __global__ __launch_bounds__(256, 2) void distance_gemm_mfma_kernel(const double *__restrict__ a, uint32_t r1, const double *__restrict__ bm, const double *__restrict__ b,
                                                                  uint32_t q, uint32_t n_dims, const double *__restrict__ metric, double p,
                                                                  const double *__restrict__ sa, const double *__restrict__ sb, double *__restrict__ out,
                                                                  uint32_t tiles_m, uint32_t tiles_n, int m_fast, double tau) {
-  __shared__ double Qs[kDK][kDS];  // [dimension][query row of the tile]
-  __shared__ double Rs[kDK][kDS];  // [dimension][reference row of the tile]
+  // two buffers a panel (74 KB a block in all, two blocks a CU): chunk c + 1 is written while chunk c is multiplied, ONE barrier a chunk
+  extern __shared__ __attribute__((aligned(16))) double dg_lds[];
+  double (*Qs)[kDK][kDS] = reinterpret_cast<double (*)[kDK][kDS]>(dg_lds);                       // [buffer][dimension][query row of the tile]
+  double (*Rs)[kDK][kDS] = reinterpret_cast<double (*)[kDK][kDS]>(dg_lds + 2 * kDK * kDS);       // [buffer][dimension][reference row of the tile]
   // Workgroups are dealt to the eight XCDs in turn; the blocks of one XCD take a contiguous run of tiles, decoded with the short
   // side fastest: the tiles that share a panel are neighbours in time on ONE L2.
   uint32_t wgid = blockIdx.x;
@@ -434,30 +437,36 @@ __global__ __launch_bounds__(256, 2) void distance_gemm_mfma_kernel(const double
       rr[u] = (in && n0 + row < r1) ? rr[u] : 0.0;
     }
   };
-  prefetch(0);
-  for (uint32_t k0 = 0; k0 < n_dims; k0 += kDK) {
-    __syncthreads();
+  auto put = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < kQ; ++u) {
-      Qs[kk][rbase + (256 / kDK) * u] = rq[u];
-      Rs[kk][rbase + (256 / kDK) * u] = rr[u];
+      Qs[buf][kk][rbase + (256 / kDK) * u] = rq[u];
+      Rs[buf][kk][rbase + (256 / kDK) * u] = rr[u];
     }
-    __syncthreads();
-    if (k0 + kDK < n_dims) prefetch(k0 + kDK);
+  };
+  prefetch(0);
+  put(0);
+  __syncthreads();
+  for (uint32_t k0 = 0, c = 0; k0 < n_dims; k0 += kDK, ++c) {
+    const int buf = (int)(c & 1u);
+    const bool more = k0 + kDK < n_dims;  // (uniform)
+    if (more) prefetch(k0 + kDK);
 #pragma unroll
     for (int ks = 0; ks < kDK; ks += 4) {
       double fa[4], fb[4];
-      const int kr = ks + (lane >> 4), c = lane & 15;
+      const int kr = ks + (lane >> 4), cc = lane & 15;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        fa[t] = Qs[kr][wm + t * 16 + c];
-        fb[t] = Rs[kr][wn + t * 16 + c];
+        fa[t] = Qs[buf][kr][wm + t * 16 + cc];
+        fb[t] = Rs[buf][kr][wn + t * 16 + cc];
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
+    if (more) put(buf ^ 1);  // (its readers passed the barrier that ended the chunk before)
+    __syncthreads();
   }
   // lane holds query rows (l >> 4) + 4 r of accumulator tile i, reference row l & 15 of tile j
 #pragma unroll
@@ -824,6 +833,19 @@ static MfmaScratch carve_mfma(void *scratch, uint32_t q, uint32_t r1, uint32_t n
   return M;
 }
 
+// the tiled contraction's 74 KB of dynamic LDS, allowed once a device slot
+static int distance_gemm_lds_attr() {
+  static PerSlotOnce once;
+  if (!once()) {
+    KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&distance_gemm_mfma_kernel<KPOP_EUCLIDEAN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDgLds));
+    KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&distance_gemm_mfma_kernel<KPOP_COSINE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDgLds));
+    KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&distance_gemm_mfma_kernel<KPOP_EUCLIDEAN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDgLds));
+    KPOP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&distance_gemm_mfma_kernel<KPOP_COSINE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDgLds));
+    once() = true;
+  }
+  return 0;
+}
+
 // the reference set's norms (once per call: they do not depend on the chunk of query rows)
 int launch_mfma_reference_norms(const double *a, uint32_t r1, uint32_t n_dims, const double *metric, void *scratch, uint32_t q_room, hipStream_t st) {
   const MfmaScratch M = carve_mfma(scratch, q_room, r1, n_dims);
@@ -840,8 +862,9 @@ static int launch_rows_mfma(const double *a, uint32_t r1, const double *b, uint3
   KPOP_LAUNCH_CHECK();
   if (n_dims > 128) {  // the tiled contraction (any number of dimensions): 128 query rows x 128 reference rows a block
     const uint32_t tiles_m = div_up(q, (uint32_t)kDT), tiles_n = div_up(r1, (uint32_t)kDT);
-    distance_gemm_mfma_kernel<KIND, false><<<dim3(tiles_m * tiles_n), dim3(256), 0, st>>>(a, r1, M.bm, b, q, n_dims, metric, 2.0, M.sa, M.sb, rows, tiles_m, tiles_n,
-                                                                                           tiles_m <= 16 ? 1 : 0, 0.0);
+    KPOP_TRY(distance_gemm_lds_attr());
+    distance_gemm_mfma_kernel<KIND, false><<<dim3(tiles_m * tiles_n), dim3(256), kDgLds, st>>>(a, r1, M.bm, b, q, n_dims, metric, 2.0, M.sa, M.sb, rows, tiles_m, tiles_n,
+                                                                                                tiles_m <= 16 ? 1 : 0, 0.0);
     KPOP_LAUNCH_CHECK();
     return 0;
   }
@@ -881,10 +904,11 @@ int launch_distance_rowwise_mfma(int kind, const double *a, uint32_t r1, const d
   if ((uint64_t)tiles_m * tiles_n >= (1ull << 31)) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "distance_rowwise: %u x %u tiles", tiles_m, tiles_n);
   const double tau = distance_mfma_tau(n_dims);
   const int m_fast = tiles_m <= tiles_n ? 1 : 0;  // (the shorter side fastest: its panel stays in the L2s)
+  KPOP_TRY(distance_gemm_lds_attr());
   if (kind == KPOP_EUCLIDEAN)
-    distance_gemm_mfma_kernel<KPOP_EUCLIDEAN, true><<<dim3(tiles_m * tiles_n), dim3(256), 0, st>>>(a, r1, M.bm, b, r2, n_dims, metric, p, M.sa, M.sb, out, tiles_m, tiles_n, m_fast, tau);
+    distance_gemm_mfma_kernel<KPOP_EUCLIDEAN, true><<<dim3(tiles_m * tiles_n), dim3(256), kDgLds, st>>>(a, r1, M.bm, b, r2, n_dims, metric, p, M.sa, M.sb, out, tiles_m, tiles_n, m_fast, tau);
   else
-    distance_gemm_mfma_kernel<KPOP_COSINE, true><<<dim3(tiles_m * tiles_n), dim3(256), 0, st>>>(a, r1, M.bm, b, r2, n_dims, metric, p, M.sa, M.sb, out, tiles_m, tiles_n, m_fast, tau);
+    distance_gemm_mfma_kernel<KPOP_COSINE, true><<<dim3(tiles_m * tiles_n), dim3(256), kDgLds, st>>>(a, r1, M.bm, b, r2, n_dims, metric, p, M.sa, M.sb, out, tiles_m, tiles_n, m_fast, tau);
   KPOP_LAUNCH_CHECK();
   return 0;
 }
