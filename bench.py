@@ -866,6 +866,13 @@ def extra_configs(R):
             except Exception as e:
                 leg["roofline"]["traffic_source"] = "not measured: %r" % (e,)
     legs["traffic_passes_seconds"] = time.perf_counter() - t0
+    try:  # (the 64-dimension entry of the sweep IS the one-organism leg: its traffic with it)
+        c3 = legs["config3_on_this_gpu"]
+        for key in ("traffic", "traffic_source", "traffic_counters"):
+            if key in c3["one_organism_0.3pct"]["roofline"]:
+                c3["one_organism_dims"]["64"]["roofline"][key] = c3["one_organism_0.3pct"]["roofline"][key]
+    except Exception:
+        pass
     return legs
 
 
