@@ -32,7 +32,9 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <string_view>
 #include <tuple>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/kpop_hip.h"
@@ -207,12 +209,29 @@ struct TwisterReg {
     twister = Table();
     inertia = Table();
     lazy_path.clear();
+    opaque = false;
+    columns.clear();
+    index.clear();
   }
   void need_matrix() {
     if (lazy_path.empty()) return;
     const std::string p = lazy_path;
     lazy_path.clear();
     read_binary_twister(p, &twister, &inertia);
+  }
+  // How k-mer names meet the twister's columns (lib/Twister.ml:71-76,151: a Hashtbl over the names, which are opaque strings there).
+  // Every column name the same number (<= 15) of lowercase hexadecimal digits -- what KPopCount writes -- and a k-mer's number is the
+  // value of its name: the reads stream and the fused kernels apply.  Anything else (names of a reduced alphabet, of a tool of the
+  // user's own) and a k-mer's number is its column's index through a dictionary over the names; only text spectra can meet such a twister.
+  bool opaque = false;
+  std::vector<uint64_t> columns;                            // hex: the columns' numbers, ascending
+  std::unordered_map<std::string_view, uint64_t> index;     // opaque: name -> column (views into twister.col_names)
+  KmerLookup lookup_;
+  const KmerLookup *lookup() {  // (pointers into this register: set at every use, the register may have been moved)
+    lookup_.opaque = opaque;
+    lookup_.columns = opaque ? nullptr : &columns;
+    lookup_.index = opaque ? &index : nullptr;
+    return &lookup_;
   }
   void upload() {
     if (dev) return;
@@ -223,24 +242,43 @@ struct TwisterReg {
     const size_t n = twister.cols();
     std::vector<uint64_t> col_hash(n);
     name_len = n ? twister.col_names[0].size() : 0;
-    std::atomic<size_t> bad{n};  // the first column whose name is not a hash (millions of names: the host threads convert them)
-    parallel_for(n, 65536, [&](size_t lo, size_t hi) {
-      for (size_t c = lo; c < hi; ++c) {
-        const std::string &nm = twister.col_names[c];
-        if (nm.size() != name_len || !hex_to_hash(nm, &col_hash[c])) {
-          size_t seen = bad.load();
-          while (c < seen && !bad.compare_exchange_weak(seen, c)) {
+    std::atomic<bool> all_hex{name_len >= 1 && name_len <= 15};  // (millions of names: the host threads convert them)
+    if (all_hex.load())
+      parallel_for(n, 65536, [&](size_t lo, size_t hi) {
+        for (size_t c = lo; c < hi && all_hex.load(std::memory_order_relaxed); ++c) {
+          const std::string &nm = twister.col_names[c];
+          bool ok = nm.size() == name_len;
+          uint64_t v = 0;
+          for (size_t i = 0; ok && i < name_len; ++i) {
+            const char ch = nm[i];
+            if (ch >= '0' && ch <= '9') v = (v << 4) | (uint64_t)(ch - '0');
+            else if (ch >= 'a' && ch <= 'f') v = (v << 4) | (uint64_t)(ch - 'a' + 10);
+            else ok = false;
           }
-          return;
+          if (!ok) {
+            all_hex.store(false);
+            return;
+          }
+          col_hash[c] = v;
         }
+      });
+    opaque = n > 0 && !all_hex.load();
+    int k;
+    if (opaque) {
+      if (n >= (1ull << 32) - 2) throw Error("more than 2^32-2 twister columns");
+      index.reserve(n * 2);
+      for (size_t c = 0; c < n; ++c) {
+        index[std::string_view(twister.col_names[c])] = c;  // (a later column of the same name shadows, Hashtbl.add)
+        col_hash[c] = c;
       }
-    });
-    if (bad.load() < n)
-      throw Error("twister column '" + twister.col_names[bad.load()] +
-                  "' is not a fixed-width hexadecimal k-mer hash (only DNA spectra produced by KPopCount are on the HIP path)");
-    const int k = (int)std::min<size_t>(2 * name_len, 30);  // names carry ceil(k/2) hex digits; the larger k covers both
-    if (name_len > 15) throw Error("k-mer names longer than 15 hex digits");
-    stage_mark("KPopTwistDB", "  column names to hashes");
+      name_len = 0;
+      k = 30;  // numbers below 2^32: the library finds rows by bisection over them, no k-mer arithmetic is involved
+    } else {
+      k = (int)std::min<size_t>(2 * name_len, 30);  // names carry ceil(k/2) hex digits; the larger k covers both
+      columns = col_hash;
+      if (!std::is_sorted(columns.begin(), columns.end())) std::sort(columns.begin(), columns.end());
+    }
+    stage_mark("KPopTwistDB", opaque ? "  column names into a dictionary" : "  column names to hashes");
     check(kpop_twister_load(twister.data.data(), n, (uint32_t)twister.rows(), col_hash.data(), std::max(k, 1), &dev));
     stage_mark("KPopTwistDB", "  twister on the device");
   }
@@ -319,7 +357,7 @@ void twist_read_stream(int fd, TwisterReg &T, bool normalize, std::vector<RowPie
   const size_t d = T.twister.rows();
   // the names KPopCount would have written carry name_digits(k) hex digits; if the twister's names are of another
   // width no k-mer of the stream can be a column of it (lib/Twister.ml:167-169): every row is the zero vector
-  const bool can_match = (size_t)name_digits(k, false) == T.name_len;
+  const bool can_match = !T.opaque && (size_t)name_digits(k, false) == T.name_len;
   // Blocks whose sequences all fit one wavefront (<= 512 windows) and more than 32 dimensions: the fused count->twist
   // kernel IS count + twist there (same ascending chain of unfused multiply-adds), and the block goes through the
   // library's streaming pipeline -- chunks of it going up, being twisted and coming down at the same time -- on every
@@ -391,6 +429,33 @@ void twist_read_stream(int fd, TwisterReg &T, bool normalize, std::vector<RowPie
         } else {
           check(kpop_sharded_spectra_twist(job.sh, bp, offsets.data(), (uint32_t)n, k, content, normalize ? 1 : 0, piece.rows.data()));
         }
+      } else if (T.opaque && n) {
+        // a twister over names of its own: the stream's k-mers meet it by the names KPopCount would have written for them
+        // (bin/KPopCount.ml:46) -- counted on the device, named and looked up here, twisted on the device
+        const uint64_t cap = offsets[n] + 1;
+        std::vector<uint64_t, DefaultInitAlloc<uint64_t>> h(cap);
+        std::vector<uint32_t, DefaultInitAlloc<uint32_t>> c(cap);
+        std::vector<uint64_t> so(n + 1);
+        static const uint8_t dummy = 0;
+        check(kpop_count_reads(b.bases.empty() ? &dummy : b.bases.data(), offsets.data(), (uint32_t)n, k, content, 1, h.data(), c.data(), so.data(), cap));
+        const uint64_t m = so[n];
+        DVec v(m);
+        const int digits = name_digits(k, false);
+        parallel_for(m, 65536, [&](size_t lo, size_t hi) {
+          static const char hx[] = "0123456789abcdef";
+          char name[16];
+          for (size_t i = lo; i < hi; ++i) {
+            uint64_t x = h[i];
+            for (int q = digits - 1; q >= 0; --q) {
+              name[q] = hx[x & 15];
+              x >>= 4;
+            }
+            const auto it = T.index.find(std::string_view(name, (size_t)digits));
+            h[i] = it == T.index.end() ? (~0ull >> 1) : it->second;
+            v[i] = (double)c[i];
+          }
+        });
+        check(kpop_twist(T.dev, h.data(), v.data(), so.data(), (uint32_t)n, normalize ? 1 : 0, piece.rows.data()));
       } else {
         std::fill(piece.rows.begin(), piece.rows.end(), 0.);
       }
@@ -490,7 +555,7 @@ void twist_text_spectra(int fd, const char *head, size_t head_len, TwisterReg &T
       while (blocks.pop(b)) {
         HashedSpectra sp;
         const auto t0 = now();
-        parse_spectra_block(b.data(), b.size(), T.name_len, absent, first, lines, sp, &n);
+        parse_spectra_block(b.data(), b.size(), T.name_len, absent, first, lines, sp, &n, 0, nullptr, T.lookup());
         t_parse += secs(t0, now());
         first = false;
         lines += n;

@@ -449,10 +449,11 @@ struct HexTable {
 };
 const HexTable kHex;
 
-void parse_chunk(const char *s, const char *e, size_t name_len, uint64_t absent, ChunkResult &r) {
+void parse_chunk(const char *s, const char *e, size_t name_len, uint64_t absent, ChunkResult &r, const KmerLookup *lk) {
   r.hash.reserve((size_t)(e - s) / 9 + 16);
   r.values.reserve((size_t)(e - s) / 9 + 16);
-  const bool fast_names = name_len >= 1 && name_len <= 16;
+  const bool fast_names = name_len >= 1 && name_len <= 16 && !(lk && lk->opaque);
+  const bool strict = lk != nullptr;  // names are strings: an uppercase digit makes another name than the columns' (all lowercase)
   while (s < e) {
     // The line KPopCount writes -- name_len hexadecimal digits, a tab, up to 15 decimal digits, a newline -- is taken in
     // one pass; anything else about a line (and a chunk's first line, which has bookkeeping of its own) goes the general way
@@ -467,7 +468,7 @@ void parse_chunk(const char *s, const char *e, size_t name_len, uint64_t absent,
         v = (v << 4) | (uint64_t)(d & 15);
       }
       if (upper) r.plain = false;
-      if (!(bad & 0x80)) {
+      if (!(bad & 0x80) && !(upper && strict)) {
         const char *p = s + name_len + 1;
         uint64_t iv = 0;
         int nd = 0;
@@ -527,7 +528,10 @@ void parse_chunk(const char *s, const char *e, size_t name_len, uint64_t absent,
       }
       if (!plain_line) r.plain = false;
       uint64_t h = absent;
-      if ((size_t)(tab - s) == name_len && name_len <= 16) {
+      if (lk && lk->opaque) {
+        const auto it = lk->index->find(std::string_view(s, (size_t)(tab - s)));
+        if (it != lk->index->end()) h = it->second;
+      } else if ((size_t)(tab - s) == name_len && name_len <= 16) {
         uint64_t v = 0;
         bool ok = name_len > 0;
         for (const char *p = s; p < tab; ++p) {
@@ -535,7 +539,7 @@ void parse_chunk(const char *s, const char *e, size_t name_len, uint64_t absent,
           int d;
           if (c >= '0' && c <= '9') d = c - '0';
           else if (c >= 'a' && c <= 'f') d = c - 'a' + 10;
-          else if (c >= 'A' && c <= 'F') d = c - 'A' + 10;
+          else if (c >= 'A' && c <= 'F' && !strict) d = c - 'A' + 10;
           else {
             ok = false;
             break;
@@ -543,6 +547,14 @@ void parse_chunk(const char *s, const char *e, size_t name_len, uint64_t absent,
           v = (v << 4) | (uint64_t)d;
         }
         if (ok) h = v;
+      }
+      // with the columns known, a line whose name is no column is dropped before its value is looked at (lib/Twister.ml:151-169)
+      const bool is_column = !lk || (h != absent && (lk->opaque || !lk->columns || std::binary_search(lk->columns->begin(), lk->columns->end(), h)));
+      if (!is_column) {
+        r.hash.push_back(absent);
+        r.values.push_back(0.);
+        s = next;
+        continue;
       }
       const char *vs = tab + 1;
       const size_t vl = (size_t)(le - vs);
@@ -570,7 +582,8 @@ void parse_chunk(const char *s, const char *e, size_t name_len, uint64_t absent,
 }  // namespace
 
 static void parse_spectra_buffer(const char *base, size_t size, size_t name_len, uint64_t absent, HashedSpectra &out, unsigned threads,
-                                 bool first_block = true, uint64_t lines_before = 0, uint64_t *n_lines = nullptr, bool *plain = nullptr);
+                                 bool first_block = true, uint64_t lines_before = 0, uint64_t *n_lines = nullptr, bool *plain = nullptr,
+                                 const KmerLookup *lk = nullptr);
 
 void read_spectra_hashed(const std::string &path, size_t name_len, uint64_t absent, HashedSpectra &out, unsigned threads) {
   const std::vector<char> buf = slurp(path);
@@ -601,7 +614,7 @@ void read_spectra_hashed_fd(int fd, const char *head, size_t head_len, size_t na
 }
 
 static void parse_spectra_buffer(const char *base, size_t size, size_t name_len, uint64_t absent, HashedSpectra &out, unsigned threads,
-                                 bool first_block, uint64_t lines_before_block, uint64_t *n_lines, bool *plain) {
+                                 bool first_block, uint64_t lines_before_block, uint64_t *n_lines, bool *plain, const KmerLookup *lk) {
   const unsigned T = pick_threads(threads, size, 2u << 20);
   std::vector<size_t> cut(T + 1, size);
   cut[0] = 0;
@@ -613,8 +626,8 @@ static void parse_spectra_buffer(const char *base, size_t size, size_t name_len,
   std::vector<ChunkResult> res(T);
   std::vector<std::thread> pool;
   for (unsigned t = 1; t < T; ++t)
-    pool.emplace_back([&, t] { parse_chunk(base + cut[t], base + cut[t + 1], name_len, absent, res[t]); });
-  parse_chunk(base + cut[0], base + cut[1], name_len, absent, res[0]);
+    pool.emplace_back([&, t] { parse_chunk(base + cut[t], base + cut[t + 1], name_len, absent, res[t], lk); });
+  parse_chunk(base + cut[0], base + cut[1], name_len, absent, res[0], lk);
   for (std::thread &th : pool) th.join();
   // errors in file order, with the sequential parser's precedence on line 1 (column count, then Header_expected)
   uint64_t lines_before = lines_before_block;
@@ -662,9 +675,9 @@ static void parse_spectra_buffer(const char *base, size_t size, size_t name_len,
 }
 
 void parse_spectra_block(const char *data, size_t size, size_t name_len, uint64_t absent, bool first_block, uint64_t lines_before,
-                         HashedSpectra &out, uint64_t *n_lines, unsigned threads, bool *plain) {
+                         HashedSpectra &out, uint64_t *n_lines, unsigned threads, bool *plain, const KmerLookup *lookup) {
   out = HashedSpectra();
-  parse_spectra_buffer(data, size, name_len, absent, out, threads, first_block, lines_before, n_lines, plain);
+  parse_spectra_buffer(data, size, name_len, absent, out, threads, first_block, lines_before, n_lines, plain, lookup);
 }
 
 SpectraTextStream::SpectraTextStream(int fd, const char *head, size_t head_len, size_t block_bytes)

@@ -10,6 +10,8 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <string_view>
+#include <unordered_map>
 #include <vector>
 
 namespace kpop_host {
@@ -129,6 +131,17 @@ struct HashedSpectra {
   std::vector<uint64_t, DefaultInitAlloc<uint64_t>> hash;  // (sized, then filled by threads: no zero-fill first -- it
   DVec values;                                             //  was half of the parsing time of a block)
 };
+// The twister's columns as the parser needs them (lib/Twister.ml:71-76, a Hashtbl from column name to column).  Given to the
+// parsers below it makes them say exactly what the reference says: a name is looked up as a STRING (so "0A" is not "0a"), and a
+// value that is not a float is an error only on a line whose name IS a column (float_of_string sits inside `Some idx`, :153-157).
+// Two forms.  hex: every column name is name_len lowercase hexadecimal digits (what KPopCount writes), a k-mer's number is the
+// value of its name and `columns` holds the columns' numbers in ascending order.  opaque: names are any strings, a k-mer's number
+// is its column's index through `index` (the last of several columns of one name, Hashtbl.add shadows).
+struct KmerLookup {
+  bool opaque = false;
+  const std::vector<uint64_t> *columns = nullptr;
+  const std::unordered_map<std::string_view, uint64_t> *index = nullptr;
+};
 void read_spectra_hashed(const std::string &path, size_t name_len, uint64_t absent, HashedSpectra &out, unsigned threads = 0);
 // the same on an open descriptor whose first head_len bytes the caller has already taken off (to look at them)
 void read_spectra_hashed_fd(int fd, const char *head, size_t head_len, size_t name_len, uint64_t absent, HashedSpectra &out,
@@ -153,7 +166,8 @@ class SpectraTextStream {
 // (Header_expected otherwise); lines_before: the lines of the blocks before this one, for the line numbers of
 // Wrong_number_of_columns; *n_lines receives this block's.  The same errors, in the same order, as the whole-file parser.
 void parse_spectra_block(const char *data, size_t size, size_t name_len, uint64_t absent, bool first_block, uint64_t lines_before,
-                         HashedSpectra &out, uint64_t *n_lines, unsigned threads = 0, bool *plain = nullptr);
+                         HashedSpectra &out, uint64_t *n_lines, unsigned threads = 0, bool *plain = nullptr,
+                         const KmerLookup *lookup = nullptr);
 // *plain: every data line of the block was name_len LOWERCASE hexadecimal digits, a tab, 1-15 decimal digits and a newline, and
 // no line carried a CR -- what KPopCount writes; KPopCountDB takes such blocks through this parser and the others line by line.
 

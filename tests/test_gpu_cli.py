@@ -595,7 +595,8 @@ def test_parallel_text_paths_are_chunking_invariant(tmp_path, oracle, pyref):
     outs = [subprocess.run([COUNT, "-k", str(k), "-L", "-f", str(tmp_path / "x.fa")], capture_output=True, text=True, env=e) for e in (tiny, one)]
     assert outs[0].returncode == 0 and outs[0].stdout == outs[1].stdout == expected_spectra(pyref, reads, k)
     (tmp_path / "x.KPopSpectra.txt").write_text(outs[0].stdout)
-    make_twister(tmp_path, oracle, k, d)
+    cols = make_twister(tmp_path, oracle, k, d)[0]
+    col = oracle.to_hex(int(cols[3]), k)  # a name that IS a column: its value is read (lib/Twister.ml:153-157)
     res = []
     for name, e in (("a", tiny), ("b", one)):
         r = subprocess.run([TWISTDB, "-I", "T", str(tmp_path / "Classes"), "-k", str(tmp_path / "x.KPopSpectra.txt"), "-O", "t", "/dev/stdout"],
@@ -604,12 +605,16 @@ def test_parallel_text_paths_are_chunking_invariant(tmp_path, oracle, pyref):
         res.append(r.stdout)
     assert res[0] == res[1] and res[0].count("\n") == len(reads) + 1
     lines = outs[0].stdout.splitlines(keepends=True)
-    for bad_at, bad, what in ((700, "aaa\t1\t2\n", "Wrong_number_of_columns(701, 3, 2)"), (1500, "aaa\tx1\n", "Float_expected(\"x1\")"),
+    for bad_at, bad, what in ((700, "aaa\t1\t2\n", "Wrong_number_of_columns(701, 3, 2)"), (1500, col + "\tx1\n", "Float_expected(\"x1\")"),
                               (0, "aaa\t3\n", "Header_expected(\"aaa\t3\")"), (900, "\tq\"uote\n", "Quotes_in_name")):
         (tmp_path / "bad.txt").write_text("".join(lines[:bad_at]) + bad + "".join(lines[bad_at:]))
         for e in (tiny, one):
             r = subprocess.run([TWISTDB, "-I", "T", str(tmp_path / "Classes"), "-k", str(tmp_path / "bad.txt")], capture_output=True, text=True, env=e)
             assert r.returncode == 1 and what in r.stderr, (what, r.stderr)
+    # "aaa" is no 5-mer: the line is dropped before its value is looked at (:167-169)
+    (tmp_path / "bad.txt").write_text("".join(lines[:1500]) + "aaa\tx1\n" + "".join(lines[1500:]))
+    r = subprocess.run([TWISTDB, "-I", "T", str(tmp_path / "Classes"), "-k", str(tmp_path / "bad.txt"), "-O", "t", "/dev/stdout"], capture_output=True, text=True, env=tiny)
+    assert r.returncode == 0 and r.stdout == res[0], r.stderr
 
 
 def test_protein_content_through_the_clis(tmp_path, oracle, pyref):
@@ -761,3 +766,89 @@ def test_kpoptwist_kmer_selection_device_path_equals_host_path(tmp_path):
         if tag != "plain":
             n_kmers = len(sh("KPopTwistDB -i T D_%s -O T /dev/stdout | head -1" % tag).stdout.split("\t")) - 1
             assert n_kmers < len(names), tag
+
+
+def _pyref_rows(pyref, T, names, text, normalize=True):
+    """lib/Twister.ml:91-188 in pure Python over the TEXT: parse, then one spectrum at a time by column NAME."""
+    sp = pyref.parse_spectra(text)
+    return [lab for lab, _ in sp], [pyref.twist(T.tolist(), names, lines, normalize) for _, lines in sp]
+
+
+def test_a_twister_over_names_of_its_own(tmp_path, oracle, pyref):
+    """lib/Twister.ml:71-76,151: spectra meet the twister's columns by NAME, and the names are any strings -- a reduced alphabet,
+    another tool's k-mers.  Such a twister's columns get numbers through a dictionary; text spectra are twisted as the reference
+    twists them (unknown names dropped before their value is read, :167-169; a repeated column name shadowed by its last, :73-76),
+    and KPopCount's own reads stream meets it through the names KPopCount would have written."""
+    d = 5
+    names = ["AAB", "x|y", "0a", "0A", "a b", "0a1", "q", "AAB", "ffff", "1b"]  # "AAB" twice: the second one is the column
+    rng = np.random.RandomState(21)
+    T = np.array([[float("%.15g" % x) for x in row] for row in rng.randn(d, len(names))])
+    dims = ["Dim%d" % (i + 1) for i in range(d)]
+    write_table(tmp_path / "O.KPopTwister.txt", names, dims, T)
+    write_table(tmp_path / "O.KPopInertia.txt", dims, ["inertia"], [oracle.synth_inertia(d)])
+    text = ('\ts1\nAAB\t3\nx|y\t2.5\n0a\t1\n0A\t4\nnot-a-column\tthree\nAAB\t1e0\n'
+            '\t"s2"\na b\t7\nq\t0\nzz\t9\n0a10\t4\n'
+            '\tempty\n'
+            '\tonly-unknown\nzz\t1\n'
+            '\ts5\nffff\t2\n1b\t3\n0a1\t5\n')
+    sp = tmp_path / "o.KPopSpectra.txt"
+    sp.write_text(text)
+    for extra in ([], ["--counts-normalize", "false"]):
+        r = run([TWISTDB, "-I", "T", str(tmp_path / "O")] + extra + ["-k", str(sp), "-O", "t", "/dev/stdout"])
+        assert r.returncode == 0, r.stderr
+        labels, rows = _pyref_rows(pyref, T, names, text, normalize=not extra)
+        want = twisted_text(dims, labels, rows)
+        assert r.stdout.splitlines()[0] == want.splitlines()[0]
+        for g, x in zip(r.stdout.splitlines()[1:], want.splitlines()[1:]):
+            gf, xf = g.split("\t"), x.split("\t")
+            assert gf[0] == xf[0]
+            np.testing.assert_allclose([float(v) for v in gf[1:]], [float(v) for v in xf[1:]], rtol=1e-13, atol=1e-300)
+    # many small blocks and threads: the same text
+    r2 = run([TWISTDB, "-I", "T", str(tmp_path / "O"), "-k", str(sp), "-O", "t", "/dev/stdout"],
+             env=dict(os.environ, KPOP_TEXT_BLOCK="16", KPOP_HOST_THREADS="5", KPOP_HOST_CHUNK="8"))
+    r1 = run([TWISTDB, "-I", "T", str(tmp_path / "O"), "-k", str(sp), "-O", "t", "/dev/stdout"])
+    assert r2.returncode == 0 and r2.stdout == r1.stdout
+    # a value that is not a float is an error on a column's line only (:153-157)
+    sp.write_text("\ta\nx|y\tthree\n")
+    r = run([TWISTDB, "-I", "T", str(tmp_path / "O"), "-k", str(sp)])
+    assert r.returncode == 1 and 'Float_expected("three")' in r.stderr
+    # KPopCount | KPopTwistDB: the reads stream's k-mers by the names KPopCount writes for k=3 and 4 ("0a", "1b": two hex digits)
+    write_fasta(tmp_path / "r.fa", READS)
+    penv = dict(os.environ, PATH=BIN + ":" + os.environ.get("PATH", ""))
+    for k in (4, 3, 7):
+        r = subprocess.run(["bash", "-c", "KPopCount -k %d -L -f r.fa | KPopTwistDB -I T O -k /dev/stdin -O t /dev/stdout" % k],
+                           cwd=str(tmp_path), capture_output=True, text=True, env=penv)
+        assert r.returncode == 0, r.stderr
+        labels, rows = _pyref_rows(pyref, T, names, expected_spectra(pyref, READS, k))
+        if k != 7:
+            assert any(any(v != 0 for v in row) for row in rows)
+        want = twisted_text(dims, labels, rows)
+        for g, x in zip(r.stdout.splitlines()[1:], want.splitlines()[1:]):
+            gf, xf = g.split("\t"), x.split("\t")
+            assert gf[0] == xf[0]
+            np.testing.assert_allclose([float(v) for v in gf[1:]], [float(v) for v in xf[1:]], rtol=1e-13, atol=1e-300)
+        assert len(r.stdout.splitlines()) == len(want.splitlines())
+
+
+def test_names_are_strings_for_a_twister_of_kmer_hashes_too(tmp_path, oracle, pyref):
+    """A twister KPopTwist wrote (lowercase hexadecimal names): an uppercase spelling is another name (Hashtbl over strings,
+    lib/Twister.ml:151), and a bad value on a line whose name is no column of the twister is never read (:153-157,167-169)."""
+    k, d = 4, 3
+    cols, T, dims, w = make_twister(tmp_path, oracle, k, d, keep=0.7)
+    names = [oracle.to_hex(h, k) for h in cols]
+    inside = [n for n in names if any(c in "abcdef" for c in n)][:3]
+    outside = [oracle.to_hex(h, k) for h in oracle.enumerate_kmers(k) if oracle.to_hex(h, k) not in set(names)][:2]
+    assert len(inside) == 3 and len(outside) == 2
+    text = ("\tu\n%s\t3\n%s\t5\n%s\t2\n%s\tthree\nzz\tfour\n%s\t1\n" % (inside[0], inside[1].upper(), inside[2], outside[0], outside[1]))
+    sp = tmp_path / "u.KPopSpectra.txt"
+    sp.write_text(text)
+    r = run([TWISTDB, "-I", "T", str(tmp_path / "Classes"), "-k", str(sp), "-O", "t", "/dev/stdout"])
+    assert r.returncode == 0, r.stderr
+    labels, rows = _pyref_rows(pyref, T, names, text)
+    want = twisted_text(dims, labels, rows)
+    gf, xf = r.stdout.splitlines()[1].split("\t"), want.splitlines()[1].split("\t")
+    assert gf[0] == xf[0] == '"u"'
+    np.testing.assert_allclose([float(v) for v in gf[1:]], [float(v) for v in xf[1:]], rtol=1e-13)
+    sp.write_text("\tu\n%s\tthree\n" % inside[0])
+    r = run([TWISTDB, "-I", "T", str(tmp_path / "Classes"), "-k", str(sp)])
+    assert r.returncode == 1 and 'Float_expected("three")' in r.stderr

@@ -134,3 +134,87 @@ def test_centroids_splits_match_the_python_restatement(tmp_path, pyref):
         assert r.returncode == 0, r.stderr
         want = pyref.splits_text(names, pyref.splits_centroids([list(map(float, row)) for row in emb]))
         assert r.stdout == want, (n, d)
+
+
+@pytest.fixture(scope="module")
+def lookup_harness(tmp_path_factory):
+    out = tmp_path_factory.mktemp("lookup_parse") / "lookup_parse"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-pthread"] + SAN + ["-o", str(out), os.path.join(ROOT, "tests", "host", "lookup_parse.cpp"),
+                    os.path.join(ROOT, "kpop_amd", "host", "kpop_text.cpp")], check=True)
+    return str(out)
+
+
+def _reference_lines(text, number_of):
+    """lib/Twister.ml:97-118 and :151-169 line by line: two tab-separated fields (:103-104), a header first (:106-107), names are
+    strings, a name that is no column is dropped before its value is read, a column's value must be a float (:153-157).  Of two
+    errors in one file the first in file order is the one reported here (in the reference which one surfaces depends on how far
+    the reader has run ahead of the workers)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import pyref
+    out = []
+    lines = text.split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    for n, line in enumerate(lines):
+        f = line.split("\t")
+        if len(f) != 2:
+            return "ERROR", "Wrong_number_of_columns(%d, %d, 2)" % (n + 1, len(f))
+        if n == 0 and f[0] != "":
+            return "ERROR", "Header_expected"
+        if f[0] == "":
+            try:
+                out.append("L " + pyref.strip_quotes(f[1]))
+            except ValueError:
+                return "ERROR", ""
+            continue
+        c = number_of(f[0])
+        if c is None:
+            out.append("-")
+            continue
+        try:
+            v = float(f[1]) if not f[1].lower().startswith(("0x", "-0x")) else float.fromhex(f[1])  # OCaml's float_of_string reads hexadecimal too
+        except ValueError:
+            return "ERROR", 'Float_expected("%s")' % f[1]
+        out.append("%d %.17g" % (c, v))
+    return "OK", out
+
+
+@pytest.mark.parametrize("mode", ["hex", "opaque"])
+def test_parser_that_knows_the_columns_says_what_the_reference_says(lookup_harness, tmp_path, mode):
+    rng = random.Random(3 if mode == "hex" else 4)
+    if mode == "hex":
+        names = sorted({"%03x" % rng.randrange(4096) for _ in range(900)})
+        table = {n: int(n, 16) for n in names}
+    else:
+        names = ["%03x" % rng.randrange(4096) for _ in range(300)] + ["AAB", "x|y", "0A", "a b", "k-%d" % 7, "q", "AAB", "0a1f", ""]
+        table = {n: i for i, n in enumerate(names)}  # the last of several columns of one name
+    (tmp_path / "names.txt").write_text("".join(n + "\n" for n in names if n != ""))
+    if mode == "opaque":
+        table.pop("", None)
+    pool = names[:50] + ["zz", "0A", "ABC", "abc", "fff", "000", "AAB", "x|y", "1234"]
+    base = "".join("\tr%d\n" % i + "".join("%s\t%s\n" % (rng.choice(pool), rng.choice(["1", "17", "2.5", "1e3", "0", "123456789012345", "1234567890123456", "three", "0x10", "nan", "-4"]))
+                                            for _ in range(rng.randrange(0, 9))) for i in range(40))
+    path = tmp_path / "in.txt"
+    n_err = n_ok = 0
+    for threads, chunk in (("6", "30"), ("1", "1")):
+        env = dict(os.environ, KPOP_HOST_THREADS=threads, KPOP_HOST_CHUNK=chunk)
+        for it in range(60):
+            s = list(base)
+            for _ in range(rng.randrange(0, 3)):
+                s[rng.randrange(len(s))] = rng.choice(["\n", "x", "0", "A", "a"])
+            data = "".join(s)
+            if it % 9 == 0:
+                data = data.replace("three", "3").replace("0x10", "16").replace("nan", "5")
+            path.write_text(data)
+            r = subprocess.run([lookup_harness, str(path), mode, str(tmp_path / "names.txt"), rng.choice(["1", "40", "300", "100000"])],
+                               capture_output=True, text=True, env=env)
+            assert r.returncode == 0, r.stderr
+            kind, want = _reference_lines(data, lambda nm: table.get(nm))
+            if kind == "ERROR":
+                n_err += 1
+                assert r.stdout.startswith("ERROR ") and want in r.stdout, (it, want, r.stdout[:200])
+            else:
+                n_ok += 1
+                assert r.stdout.splitlines() == want, (it, mode)
+    assert n_ok >= 5 and n_err >= 5
