@@ -58,7 +58,8 @@ typedef enum {
 /* bin/KPopCount.ml:66-82 (Content.t) */
 #define KPOP_DNA_DS 0
 #define KPOP_DNA_SS 1
-#define KPOP_PROTEIN 2 /* counting entry points only (kpop_count_reads, kpop_dev_count_reads), k <= 12 */
+#define KPOP_PROTEIN 2 /* k <= 12; counting, and since round 6 the fused count->twist calls too (kpop_count_twist, kpop_dev_count_twist,
+                          kpop_spectra_twist, the pipeline: five bits a residue, a twister loaded with 2 k_load >= 5 k bits); not the packed form */
 /* lib/Space.ml:140-143 (Distance.t) */
 #define KPOP_EUCLIDEAN 0
 #define KPOP_COSINE 1

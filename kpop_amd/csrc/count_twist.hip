@@ -309,7 +309,8 @@ __device__ __forceinline__ void wave_fill_x(WaveLds<R, uint32_t> &L, uint32_t nu
 // fused count -> twist: one wave per read
 // ---------------------------------------------------------------------------
 // (PACKED: `bases` is the batch's words of 2-bit codes and `pinvalid` its marks of bases that are none -- kpop_dev_count_twist_packed)
-template <int R, typename H, int U, bool NT, bool PACKED = false>
+// (SB: bits a symbol -- 2 DNA, 5 protein, as count_wave_kernel's)
+template <int R, typename H, int U, bool NT, bool PACKED = false, int SB = 2>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void count_twist_wave_kernel(
     TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets,
     const uint32_t *__restrict__ read_ids, uint32_t n, int content, int normalize, double *__restrict__ out,
@@ -334,9 +335,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void count_twist_wave_kernel(
   if constexpr (PACKED)
     wave_stage_codes_packed<R>(reinterpret_cast<const uint32_t *>(bases), pinvalid, off, len, lane, L.codes);
   else
-    wave_stage_codes<R>(bases + off, len, lane, L.codes);
+    wave_stage_codes<R, SB>(bases + off, len, lane, L.codes);
   H hkey[R];
-  wave_hash_windows<R, H>(L.codes, tv.hk, content, lane, hkey);
+  wave_hash_windows<R, H, SB>(L.codes, tv.hk, content, lane, hkey);
   // name -> column (lib/Twister.ml:151); k-mers the twister does not know are
   // dropped here, hence also from the normaliser (:158,:167-169)
   const bool direct = tv.direct != nullptr && tv.n_dims <= 32;  // rows at their hashes: no look-up (twister.h)
@@ -677,7 +678,7 @@ struct StoreU64 {
 
 // NDB: blocks of 64 dimensions a lane sums per pass over the windows (1, 2 or 4): with more than 64 dimensions the windows
 // are hashed and looked up ONCE per 64 NDB dimensions, not once per 64 (every dimension's sum is the same chain either way).
-template <typename H, bool NT, int NDB = 1>
+template <typename H, bool NT, int NDB = 1, int SB = 2>
 __global__ __launch_bounds__(256) void count_twist_stream_kernel(
     TwisterView tv, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, int content,
     const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ seg_off, double *__restrict__ partial,
@@ -724,7 +725,7 @@ __global__ __launch_bounds__(256) void count_twist_stream_kernel(
   const uint64_t w0 = (uint64_t)seg * seg_windows;
   const uint64_t w1 = min(n_win, w0 + seg_windows);
   const uint8_t *seq = bases + off;
-  const int shift = 2 * (k - 1);
+  const int shift = 2 * (k - 1);  // (DNA: where a base enters the reverse complement)
   const uint64_t slot = seg_off[r] + seg;
   for (uint32_t d0 = d_begin; d0 < d_end; d0 += 64 * NDB) {  // (the launch's share of the dimensions: see the host side)
     // (lanes past the last dimension load a column that exists and keep a sum nobody reads; a window without a row loads
@@ -746,13 +747,22 @@ __global__ __launch_bounds__(256) void count_twist_stream_kernel(
       if (win < w1) {
         H fwd = 0, rc = 0;
         bool good = true;
-        for (int j = 0; j < k; ++j) {
-          const uint32_t c = base_code(seq[win + j]);
-          good = good && (c < 4u);
-          fwd = (fwd << 2) | (H)(c & 3u);
-          rc = (rc >> 2) | ((H)(3u - (c & 3u)) << shift);
+        if constexpr (SB == 2) {
+          for (int j = 0; j < k; ++j) {
+            const uint32_t c = base_code(seq[win + j]);
+            good = good && (c < 4u);
+            fwd = (fwd << 2) | (H)(c & 3u);
+            rc = (rc >> 2) | ((H)(3u - (c & 3u)) << shift);
+          }
+        } else {
+          for (int j = 0; j < k; ++j) {
+            const uint32_t c = protein_code(seq[win + j]);
+            good = good && (c < 20u);
+            fwd = (fwd << 5) | (H)(c & 31u);
+          }
+          rc = fwd;
         }
-        if (good) col = lookup_col(tv, (uint64_t)((content == KPOP_DNA_DS && rc < fwd) ? rc : fwd));
+        if (good) col = lookup_col(tv, (uint64_t)((SB == 2 && content == KPOP_DNA_DS && rc < fwd) ? rc : fwd));
       }
       cnt += (uint32_t)__popcll(__ballot(col != kNoCol));
       constexpr int GU = kGatherUnroll / (NDB > 2 ? 2 : 1);  // rows in flight (x NDB loads each)
@@ -1690,10 +1700,31 @@ static int launch_count_twist_wave_v(int R, const TwisterView &tv, const uint8_t
   return 0;
 }
 
+// protein (bin/KPopCount.ml:246-248): five bits a residue, keys of 32 bits up to k = 6 and of 64 beyond
+template <typename H>
+static int launch_count_twist_wave_protein(int R, const TwisterView &tv, const uint8_t *bases, const uint64_t *offsets, const uint32_t *ids, uint32_t n,
+                                           int normalize, double *out, hipStream_t st) {
+  dim3 grid(div_up(n, kWavesPerBlock)), block(64 * kWavesPerBlock);
+#define KPOP_WPR(RR) count_twist_wave_kernel<RR, H, 8, false, false, 5><<<grid, block, (size_t)ctx().tune_ldspad, st>>>(tv, bases, offsets, ids, n, KPOP_PROTEIN, normalize, out)
+  switch (R) {
+    case 1: KPOP_WPR(1); break;
+    case 2: KPOP_WPR(2); break;
+    case 4: KPOP_WPR(4); break;
+    case 8: KPOP_WPR(8); break;
+    default: KPOP_FAIL(KPOP_ERR_INVALID, "launch_count_twist_wave: R=%d", R);
+  }
+#undef KPOP_WPR
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename H>
 static int launch_count_twist_wave(int R, TwisterView tv, const uint8_t *bases, const uint64_t *offsets,
                                    const uint32_t *ids, uint32_t n, int content, int normalize, double *out,
                                    hipStream_t st) {
+  if (content == KPOP_PROTEIN)  // (its own key width: H is the caller's choice for DNA)
+    return hash_bits(tv.hk, content) <= 30 ? launch_count_twist_wave_protein<uint32_t>(R, tv, bases, offsets, ids, n, normalize, out, st)
+                                           : launch_count_twist_wave_protein<uint64_t>(R, tv, bases, offsets, ids, n, normalize, out, st);
   const Context &c = ctx();
   const bool nt = c.tune_nt == 1 || (c.tune_nt == 2 && (uint64_t)tv.n_rows * tv.d_pad * 8 > kStreamingRowBytes);
   if (c.tune_unroll == 16)
@@ -1785,15 +1816,19 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
                                     double *d_out, void *stream) {
   KPOP_TRY(require_init());
   if (!tw || !d_offsets || !d_out) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_count_twist: null argument");
-  if (content != KPOP_DNA_DS && content != KPOP_DNA_SS)
-    KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_count_twist: content %d (the fused path is DNA only; protein spectra go through kpop_count_reads and kpop_twist)", content);
+  if (content != KPOP_DNA_DS && content != KPOP_DNA_SS && content != KPOP_PROTEIN)
+    KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_count_twist: Invalid_content(%d)", content);
+  const bool protein = content == KPOP_PROTEIN;  // five bits a residue (bin/KPopCount.ml:246-248): the wave and the streaming kernel, no tile route
   if (n_reads == 0) return KPOP_OK;
   hipStream_t st = as_stream(stream);
   const TwisterView tv = view_of(tw);
+  if (protein && (tv.hk > kMaxKProtein || hash_bits(tv.hk, content) > 2 * tw->k))
+    KPOP_FAIL(KPOP_ERR_INVALID, "kpop_dev_count_twist: protein k=%d (at most %d, and its %d-bit hashes must fit the %d bits the twister was loaded with)", tv.hk,
+              kMaxKProtein, hash_bits(tv.hk, content), 2 * tw->k);
   const uint32_t max_windows = (max_len >= (uint32_t)tv.hk) ? max_len - tv.hk + 1 : 0;
   // Assemblies through more than 64 dimensions whose partial rows pass the tile route's bound (below) go through in SUB-BATCHES of
   // sequences, m of them at most m x max_len bases, each a call of its own.
-  if (max_windows > kWaveMaxWindows && tile_route_wide(tw) && ctx().tune_dense != 0 && !ctx().tune_seg && n_reads >= kTileMinSeqs) {
+  if (!protein && max_windows > kWaveMaxWindows && tile_route_wide(tw) && ctx().tune_dense != 0 && !ctx().tune_seg && n_reads >= kTileMinSeqs) {
     const uint64_t max_long0 = std::min<uint64_t>(n_reads, n_bases / kWaveMaxWindows + 1);
     const uint64_t per_slot = (uint64_t)tw->n_dims * 8 + 4 + 4 + 8, cap = tile_workspace_cap(tw->d_pad);
     if ((n_bases / kTileS + max_long0) * per_slot > cap) {
@@ -1824,7 +1859,7 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   // once and multiplied on the matrix cores, the private rows listed for tile_residual_kernel); what it leaves -- stretches
   // that share little with their seeds, found from a sample -- is the streaming kernel's as before.  kpop_tune("dense", 0)
   // opts out (the streaming kernel alone: the reference's order of additions within a segment).
-  bool tiles_wanted = cx.tune_dense != 0 && tv.rsel && n_reads >= kTileMinSeqs && tv.hk <= 15 && !cx.tune_seg;
+  bool tiles_wanted = !protein && cx.tune_dense != 0 && tv.rsel && n_reads >= kTileMinSeqs && tv.hk <= 15 && !cx.tune_seg;
   const bool nt = cx.tune_nt == 1;
   // (a sequence with segments has more than kWaveMaxWindows windows: at most this many of them)
   const uint32_t max_long = (uint32_t)std::min<uint64_t>(n_reads, n_bases / kWaveMaxWindows + 1);
@@ -1954,7 +1989,7 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
   // The dimensions go in passes of up to 256 (four blocks of 64 a lane), 128 or 64 -- one LAUNCH per pass, so that a pass never
   // loads blocks it has no dimensions for (300 dimensions: 256 + 44; a run-time guard on the loads brought the per-window
   // branches back: 2.4 -> 5.2 ms at 64 dimensions).  Every launch hashes the windows again: once per 256 dimensions, not per 64.
-#define KPOP_STREAM_B(H, NT, B, D0, D1) count_twist_stream_kernel<H, NT, B><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, long_ids, tiles ? n_todo : n_long, max_seg, seg_windows, todo, segw, tiles ? n_todo + 1 + launch_no++ : nullptr, D0, D1)
+#define KPOP_STREAM_B(H, NT, B, D0, D1) count_twist_stream_kernel<H, NT, B, KPOP_STREAM_SB><<<grid, dim3(256), 0, st>>>(tv, d_bases, d_offsets, content, nseg, seg_off, part, pcnt, long_ids, tiles ? n_todo : n_long, max_seg, seg_windows, todo, segw, tiles ? n_todo + 1 + launch_no++ : nullptr, D0, D1)
   int launch_no = 0;  // (a take-the-next counter per launch)
   if (tiles && tw->n_dims > 255u * 256u) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_dev_count_twist: %u dimensions (at most 65,280 with the tile route on; kpop_tune(\"dense\", 0) lifts that)", tw->n_dims);
 #define KPOP_STREAM(H, NT)                                                        \
@@ -1974,11 +2009,19 @@ extern "C" int kpop_dev_count_twist(const kpop_twister *tw, const uint8_t *d_bas
       }                                                                           \
     }                                                                             \
   } while (0)
-  if (tv.hk <= 15) {
+#define KPOP_STREAM_SB 2
+  if (content == KPOP_PROTEIN) {
+#undef KPOP_STREAM_SB
+#define KPOP_STREAM_SB 5
+    if (hash_bits(tv.hk, content) <= 30) KPOP_STREAM(uint32_t, false); else KPOP_STREAM(uint64_t, false);
+#undef KPOP_STREAM_SB
+#define KPOP_STREAM_SB 2
+  } else if (tv.hk <= 15) {
     if (nt) KPOP_STREAM(uint32_t, true); else KPOP_STREAM(uint32_t, false);
   } else {
     if (nt) KPOP_STREAM(uint64_t, true); else KPOP_STREAM(uint64_t, false);
   }
+#undef KPOP_STREAM_SB
 #undef KPOP_STREAM
 #undef KPOP_STREAM_B
   KPOP_LAUNCH_CHECK();
@@ -2139,7 +2182,7 @@ extern "C" int kpop_count_twist(const kpop_twister *tw, const uint8_t *bases, co
   // kpop_tune("dense", 2): batches of assemblies at small k (every sequence holds a fifth or more of the twister's k-mers on
   // average, the twister small enough for the dense image) go through the u32 image and the f64 matrix cores; results
   // agree with the sparse kernels to rounding
-  const bool dense_image = ctx().tune_dense == 2 && tw->n_rows > 0 && tw->n_rows <= 36864 && tw->n_dims <= 256 && n_reads >= 64 &&
+  const bool dense_image = content != KPOP_PROTEIN && ctx().tune_dense == 2 && tw->n_rows > 0 && tw->n_rows <= 36864 && tw->n_dims <= 256 && n_reads >= 64 &&
                            (double)n_bases >= 0.2 * (double)tw->n_rows * (double)n_reads;
   if (dense_image) {
     DevBuf d_work;
@@ -2166,8 +2209,8 @@ extern "C" int kpop_spectra_twist(const kpop_twister *tw, const uint8_t *bases, 
   ArenaScope scratch;
   if (!tw || !offsets || (!out && n_reads)) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_spectra_twist: null argument");
   KPOP_TRY(check_count_args(k, content, "kpop_spectra_twist"));
-  if (content == KPOP_PROTEIN) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_spectra_twist: DNA only (protein spectra go through kpop_count_reads and kpop_twist)");
-  if (k > tw->k) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_spectra_twist: k=%d above the twister's k=%d", k, tw->k);
+  if (hash_bits(k, content) > 2 * tw->k)
+    KPOP_FAIL(KPOP_ERR_INVALID, "kpop_spectra_twist: k=%d (%d-bit hashes) above the twister's k=%d (%d bits)", k, hash_bits(k, content), tw->k, 2 * tw->k);
   if (n_reads == 0) return KPOP_OK;
   uint64_t max_len = 0;
   KPOP_TRY(check_offsets(offsets, n_reads, &max_len));

@@ -200,8 +200,8 @@ extern "C" int kpop_pipeline_create(const kpop_twister *tw, const double *classe
   const int outs = cfg->outputs;
   if (!outs || (outs & ~(KPOP_OUT_TWISTED | KPOP_OUT_DISTANCES | KPOP_OUT_SUMMARY)))
     KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_create: outputs=%d selects nothing or an unknown output", outs);
-  if (cfg->content != KPOP_DNA_DS && cfg->content != KPOP_DNA_SS)
-    KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "kpop_pipeline_create: content %d (the fused path is DNA only)", cfg->content);
+  if (cfg->content != KPOP_DNA_DS && cfg->content != KPOP_DNA_SS && cfg->content != KPOP_PROTEIN)
+    KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_create: Invalid_content(%d)", cfg->content);
   if (cfg->kind != KPOP_EUCLIDEAN && cfg->kind != KPOP_COSINE && cfg->kind != KPOP_MINKOWSKI)
     KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_create: unknown distance kind %d", cfg->kind);
   if (cfg->kind == KPOP_MINKOWSKI && !(cfg->p >= 0.0)) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_pipeline_create: negative Minkowski power");

@@ -142,7 +142,7 @@ struct Sink {  // where a batch of reads goes: the GPU and the text writer, or t
   void decide() {
     decided = true;
     const bool per_read = P.label.empty();
-    stream = per_read && P.output.empty() && P.content != KPOP_PROTEIN && stdout_reader_is_dropin_twistdb();
+    stream = per_read && P.output.empty() && stdout_reader_is_dropin_twistdb();
     if (stream) {
 #ifdef F_SETPIPE_SZ
       (void)fcntl(1, F_SETPIPE_SZ, 1 << 20);  // fewer, larger hand-overs to the reader (the default is 64 KB)

@@ -352,12 +352,13 @@ void twist_read_stream(int fd, TwisterReg &T, bool normalize, std::vector<RowPie
 #endif
   ReadStreamReader rs(fd);
   const int k = (int)rs.header.k, content = (int)rs.header.content;
-  if (k < 1 || k > 30 || (content != KPOP_DNA_DS && content != KPOP_DNA_SS)) throw Error("reads stream: unsupported k or content");
+  const bool protein = content == KPOP_PROTEIN;
+  if (k < 1 || k > (protein ? 12 : 30) || (content != KPOP_DNA_DS && content != KPOP_DNA_SS && !protein)) throw Error("reads stream: unsupported k or content");
   T.upload();
   const size_t d = T.twister.rows();
   // the names KPopCount would have written carry name_digits(k) hex digits; if the twister's names are of another
   // width no k-mer of the stream can be a column of it (lib/Twister.ml:167-169): every row is the zero vector
-  const bool can_match = !T.opaque && (size_t)name_digits(k, false) == T.name_len;
+  const bool can_match = !T.opaque && (size_t)name_digits(k, protein) == T.name_len;
   // Blocks whose sequences all fit one wavefront (<= 512 windows) and more than 32 dimensions: the fused count->twist
   // kernel IS count + twist there (same ascending chain of unfused multiply-adds), and the block goes through the
   // library's streaming pipeline -- chunks of it going up, being twisted and coming down at the same time -- on every
@@ -440,7 +441,7 @@ void twist_read_stream(int fd, TwisterReg &T, bool normalize, std::vector<RowPie
         check(kpop_count_reads(b.bases.empty() ? &dummy : b.bases.data(), offsets.data(), (uint32_t)n, k, content, 1, h.data(), c.data(), so.data(), cap));
         const uint64_t m = so[n];
         DVec v(m);
-        const int digits = name_digits(k, false);
+        const int digits = name_digits(k, protein);
         parallel_for(m, 65536, [&](size_t lo, size_t hi) {
           static const char hx[] = "0123456789abcdef";
           char name[16];

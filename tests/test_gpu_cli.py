@@ -659,6 +659,25 @@ def test_protein_content_through_the_clis(tmp_path, oracle, pyref):
     h, c, o = oracle.count_reads(pb, po, k, oracle.PROTEIN)
     rows = oracle.twist(T, cols, h, c.astype(np.float64), o)
     assert r.stdout == twisted_text(dims, [t for t, _ in prots], rows)
+    # more than 32 dimensions: the reads stream's blocks of short proteins take the fused kernel (five bits a residue), a block
+    # with a long one (more than 512 windows) the count + line-by-line twist; the same text either way
+    d2 = 40
+    T2 = np.array([[float("%.15g" % x) for x in row] for row in oracle.synth_twister(8, d2, cols)])
+    dims2 = ["Dim%d" % (i + 1) for i in range(d2)]
+    write_table(tmp_path / "Q.KPopTwister.txt", [pyref.to_hex_protein(int(h), k) for h in cols], dims2, T2)
+    write_table(tmp_path / "Q.KPopInertia.txt", dims2, ["inertia"], [oracle.synth_inertia(d2)])
+    for extra, name in (([], "p.fa"), ([("titin-like", "".join(aa[x] for x in rng.randint(0, 20, size=1400)))], "p2.fa")):
+        ps = prots + extra
+        with open(tmp_path / name, "w") as f:
+            for tag, s_ in ps:
+                f.write(">%s\n%s\n" % (tag, s_))
+        r = subprocess.run(["bash", "-c", "KPopCount -k %d -C protein -L -f %s | KPopTwistDB -I T Q -k /dev/stdin -O t /dev/stdout" % (k, name)],
+                           cwd=str(tmp_path), capture_output=True, text=True, env=penv)
+        assert r.returncode == 0, r.stderr
+        pb = np.frombuffer("".join(lint(s_) for _, s_ in ps).encode(), dtype=np.uint8)
+        po = np.concatenate([[0], np.cumsum([len(lint(s_)) for _, s_ in ps])]).astype(np.uint64)
+        h, c, o = oracle.count_reads(pb, po, k, oracle.PROTEIN)
+        assert r.stdout == twisted_text(dims2, [t for t, _ in ps], oracle.twist(T2, cols, h, c.astype(np.float64), o))
 
 
 def test_reference_wrapper_steps_match_one_process_kpoptwist(tmp_path, oracle, pyref):

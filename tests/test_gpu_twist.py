@@ -1069,3 +1069,47 @@ def test_many_chunks_a_block_give_the_same_bits_every_call(kpop, oracle, rate, d
     want = oracle.twist(oracle.synth_twister(0x7457, d, cols), cols, h, c.astype(np.float64), o)
     np.testing.assert_allclose(first.cpu().numpy()[pick], want, rtol=1e-12, atol=1e-15)
     tw.free()
+
+
+@pytest.mark.parametrize("k,d,tk", [(3, 64, 8), (3, 9, 30), (6, 40, 15), (7, 100, 30), (12, 65, 30), (2, 300, 5)])
+def test_protein_through_the_fused_kernels(kpop, oracle, k, d, tk):
+    """-C protein (bin/KPopCount.ml:246-248, five bits a residue) through the fused count->twist entry points: the one-wavefront
+    kernel for sequences of up to 512 windows, the streaming kernel for longer ones, kpop_spectra_twist (count, then the line-by-line
+    twist: bit for bit what the counting and the twisting calls give one after the other) and the pipeline.  The twister is loaded
+    with the k its names' width implies (tk: 2 tk bits hold the 5 k of a hash)."""
+    from kpop_amd import api
+    rng = np.random.RandomState(100 * k + d)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWYXBZ*", dtype=np.uint8)
+    p = np.array([1.0] * 20 + [0.06, 0.03, 0.03, 0.03])
+    p /= p.sum()
+    lens = [0, 1, k - 1, k, k + 1, 511 + k, 512 + k, 513 + k, 1500, 9000] + [int(x) for x in rng.randint(0, 600, size=200)]
+    prot = [bytes(aa[rng.choice(len(aa), size=max(n, 0), p=p)]).decode() for n in lens]
+    bases, offs = concat(prot)
+    h, c, o = oracle.count_reads(bases, offs, k, oracle.PROTEIN)
+    seen = np.unique(h)
+    cols = seen[rng.rand(len(seen)) < 0.7] if len(seen) > 50 else seen
+    cols = cols[rng.permutation(len(cols))]
+    T = oracle.synth_twister(9, d, cols)
+    tw = kpop.Twister.load(T, cols, tk)
+    tw.set_count_k(k)
+    short = np.array([i for i, n in enumerate(lens) if n - k + 1 <= 512])
+    sb, so = concat([prot[i] for i in short])
+    for normalize in (True, False):
+        want = oracle.twist(T, cols, h, c.astype(np.float64), o, normalize)
+        got = tw.count_twist(bases, offs, content=kpop.PROTEIN, normalize=normalize)
+        assert_close(got, want)
+        api.tune("dense", 0)  # (kpop_twist line by line, not its matrix-core route: what kpop_spectra_twist does on the device)
+        line_by_line = tw.twist(h, c.astype(np.float64), o, normalize=normalize)
+        api.tune("dense", 2)
+        assert np.array_equal(tw.spectra_twist(bases, offs, k, content=kpop.PROTEIN, normalize=normalize), line_by_line)
+        got_s = tw.count_twist(sb, so, content=kpop.PROTEIN, normalize=normalize)
+        assert_close(got_s, want[short])
+        assert np.array_equal(got_s, got[short])  # (the wave kernel's rows do not depend on what else the batch holds)
+    assert np.array_equal(got[:3], np.zeros((3, d)))
+    pl = kpop.Pipeline(tw, outputs=api.OUT_TWISTED, content=kpop.PROTEIN, normalize_counts=True)
+    res = pl.run(sb, so)
+    assert_close(res["twisted"], oracle.twist(T, cols, h, c.astype(np.float64), o, True)[short])
+    pl.close()
+    with pytest.raises(kpop.KPopError):
+        tw.set_count_k(k)
+        tw.count_twist_packed(*api.pack_bases(sb), so, content=kpop.PROTEIN)  # the packed form is DNA
