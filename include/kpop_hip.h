@@ -103,12 +103,14 @@ int kpop_synchronize(void *stream);
    recomputed with the reference's chain -- <= 1e-12 relative (3e-15 measured), not bit for bit; 0: the chain for every pair (the reference's bits);
    "summary_mfma" 1 (default) | 2 | 0: summaries against 65,536 rows and more, euclidean / cosine, 4 dimensions and more (up to 128 the query rows
    stay in registers, beyond a tiled contraction; 2: up to 128 dimensions the summary's pass runs inside the contraction and no approximate row
-   is written -- same results, measured slower): the distances
+   is written -- same results, measured level to slower: 2.77 against 2.71 ms for 256 x 1M x 64, 9.1 against 8.6 for 1,024): the distances
    as f64 MFMAs (|a|^2 + |b|^2 - 2 a.b) that only LOCATE the neighbours, the median and the MAD's edges; everything reported is
    recomputed with the reference's chain, rows the refinement cannot vouch for are redone from exact distance rows
    (distance_mfma.hip).  Same medians, MADs and neighbour lists bit for bit; mean and standard deviation are sums of the
    approximate values (1e-13 relative; values cancellation would show in are replaced by exact ones).  0: the chain for every pair.
    "summary_mfma_lists" 1 (default) | 0: that refinement reads the candidate lists the summary's one pass left, or scans the rows;
+   "summary_lanes" 1 (default) | 2: 512 query rows and more of such a summary in batches of 256 on two streams (measured level);
+   "summary_audit" 0 (default) | 1: count the rows left to the exact fall-back (kpop_debug_summary_fallbacks);
    "tilepipe" 1 (default) | 0: the tile route's kernel with producer and consumer wavefronts (tile_pipe.h; beyond 64 dimensions its three-stage
    form: producers / MFMA wavefronts / gather wavefronts), or round 4's; "tilewide" 0 (default) | 1: that three-stage form at any number of
    dimensions (up to 64: the same bits); "tilecap_mb" 0 (default: 4 GiB per 64 columns, a quarter of the device at most) | MiB: the per-slot tables
@@ -128,6 +130,10 @@ int kpop_tune(const char *key, int value);
    chunks it took (out[14]) and the rows of their consensus sets as multiplied on the matrix cores (out[15]: 2 x 64 x n_dims
    flops each; bench.py's MFMA roofline); read and cleared; synchronises the device */
 int kpop_debug_counters(uint64_t *out, int n);
+/* development: under kpop_tune("summary_audit", 1) the large-reference summaries (kpop_dev_distance_summary against 65,536 rows and
+   more) count the query rows they leave to their exact fall-back -- rows whose brackets missed or whose certificates failed; the
+   results are the same either way, the fall-back costs milliseconds.  Read and cleared.                                         */
+int kpop_debug_summary_fallbacks(uint64_t *rows);
 
 /* plain device-memory helpers so a non-HIP host language can stage buffers */
 int kpop_dev_malloc(void **ptr, uint64_t bytes);

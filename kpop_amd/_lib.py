@@ -79,6 +79,7 @@ SIGNATURES = {
     "kpop_synchronize": (C.c_int, [vp]),
     "kpop_tune": (C.c_int, [C.c_char_p, C.c_int]),
     "kpop_debug_counters": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
+    "kpop_debug_summary_fallbacks": (C.c_int, [C.POINTER(C.c_uint64)]),
     "kpop_dev_malloc": (C.c_int, [C.POINTER(vp), C.c_uint64]),
     "kpop_dev_free": (C.c_int, [vp]),
     "kpop_memcpy_h2d": (C.c_int, [vp, vp, C.c_uint64]),

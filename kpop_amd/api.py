@@ -89,6 +89,13 @@ def debug_counters(n=16):
     return [int(x) for x in out[:n]]
 
 
+def summary_fallbacks():
+    """query rows the large-reference summaries left to their exact fall-back since the last call (counted under tune("summary_audit", 1))"""
+    out = C.c_uint64(0)
+    check(_lib.load().kpop_debug_summary_fallbacks(C.byref(out)))
+    return int(out.value)
+
+
 def device_count():
     n = _lib.load().kpop_device_count()
     if n < 0:

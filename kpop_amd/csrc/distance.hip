@@ -1307,6 +1307,7 @@ uint64_t summary_large_scratch_bytes(uint32_t n_rows, uint32_t r1);
 bool summary_fused_applies(uint32_t r1, uint32_t keep_at_most);
 uint32_t summary_fused_sample_rows(uint32_t r1);
 uint64_t summary_fused_scratch_bytes(uint32_t n_rows, uint32_t r1);
+uint64_t summary_select_scratch_bytes(uint32_t n_rows, uint32_t r1);
 int launch_sample_gather(const double *a, uint32_t r1, uint32_t n_dims, uint32_t s, double *out, hipStream_t st);
 int launch_summary_fused(int kind, const double *a, uint32_t r1, const double *b, uint32_t n_rows, uint32_t n_dims, const double *metric, double p,
                          const double *srow, uint32_t s, uint32_t row0, uint32_t keep_at_most, uint32_t max_neighbours, double *out_stats,
@@ -1316,6 +1317,7 @@ int launch_summary_fused(int kind, const double *a, uint32_t r1, const double *b
 bool summary_mfma_applies(int kind, uint32_t r1, uint32_t n_dims, uint32_t keep_at_most, uint32_t max_neighbours);
 uint64_t summary_mfma_scratch_bytes(uint32_t q, uint32_t r1, uint32_t n_dims);
 int launch_mfma_reference_norms(const double *a, uint32_t r1, uint32_t n_dims, const double *metric, void *scratch, uint32_t q_room, hipStream_t st);
+int launch_mfma_copy_reference_norms(const void *from, void *to, uint32_t r1, uint32_t n_dims, uint32_t q_room, hipStream_t st);
 int launch_distance_rows_mfma(int kind, const double *a, uint32_t r1, const double *b, uint32_t q, uint32_t n_dims, const double *metric, double *rows,
                               void *scratch, uint32_t q_room, hipStream_t st);
 int launch_summary_refine(int kind, const double *rows, const double *a, uint32_t r1, const double *b, uint32_t q, uint32_t n_dims, const double *metric,
@@ -1338,6 +1340,24 @@ int launch_summary_failed_rows(const double *rows, uint32_t n_rows, uint32_t r1,
                                double *out_stats, uint32_t *out_n, uint32_t *out_idx, double *out_dist, double *out_z, void *scratch,
                                hipStream_t st);
 
+// kpop_tune("summary_audit", 1): the rows a chunk leaves to the exact fall-back are counted (a synchronisation and a 4-byte copy a chunk:
+// for tests and probes -- a fall-back that runs when it should not costs 4 ms a chunk and changes no result, so nothing else shows it)
+static int audit_fallback(const uint32_t *gate, hipStream_t st) {
+  if (!ctx().tune_summary_audit || !gate) return 0;
+  uint32_t g = 0;
+  KPOP_HIP(hipStreamSynchronize(st));
+  KPOP_HIP(hipMemcpy(&g, gate, 4, hipMemcpyDeviceToHost));
+  ctx().summary_fallback_rows += g;
+  return 0;
+}
+extern "C" int kpop_debug_summary_fallbacks(uint64_t *rows) {
+  KPOP_TRY(require_init());
+  if (!rows) KPOP_FAIL(KPOP_ERR_INVALID, "kpop_debug_summary_fallbacks: null argument");
+  *rows = ctx().summary_fallback_rows;
+  ctx().summary_fallback_rows = 0;
+  return KPOP_OK;
+}
+
 // r1 > kSummaryMaxR1: query rows in chunks, distance rows of a chunk in the library workspace
 template <int KIND>
 static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
@@ -1357,10 +1377,68 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
     const bool select = ctx().tune_summary_mfma == 2 && n_dims <= 128 && summary_select_mfma_applies(r1, keep_at_most);
     uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(r2, 2 * budget / ((uint64_t)r1 * 8)));  // (1,024 rows against a million)
     if (chunk > 128) chunk = chunk / 128 * 128;
+    // TWO LANES (kpop_tune("summary_lanes", 2); 512 query rows and more): batches of 256 rows alternately on the caller's stream and on one of
+    // the library's own, a lane's contraction waiting for the other lane's.  Meant to run a batch's sample / finish / refinement kernels (one
+    // block a row, a block a CU, chains of dependent steps) under the next batch's contraction and pass; measured level with one batch after
+    // the other (common.h), which stays the default.  Results do not depend on the lanes: every row is its own computation.
+    const bool two_lanes = !select && ctx().tune_summary_lanes == 2 && r2 >= 512 && chunk >= 512;
+    if (two_lanes) {
+      chunk = 256;
+      const uint64_t row_bytes = ((uint64_t)chunk * r1 * 8 + 255) & ~255ull;
+      const uint64_t sum_bytes = (summary_large_scratch_bytes(chunk, r1) + 511) & ~255ull, m_bytes = (summary_mfma_scratch_bytes(chunk, r1, n_dims) + 511) & ~255ull;
+      const uint64_t lane_bytes = row_bytes + sum_bytes + m_bytes + 256;
+      void *ws = nullptr;
+      KPOP_TRY(ctx().ws_for(st).ensure(2 * lane_bytes + 512, &ws));
+      Context::AuxLane *aux = nullptr;
+      KPOP_TRY(ctx().aux_for(st, &aux));
+      char *wp = reinterpret_cast<char *>(ws);
+      struct Lane {
+        hipStream_t s;
+        double *rows;
+        void *scratch, *mscratch;
+      } lane[2];
+      for (int l = 0; l < 2; ++l) {
+        char *base = wp + (uint64_t)l * lane_bytes;
+        lane[l] = Lane{l ? aux->stream : st, reinterpret_cast<double *>(base), base + row_bytes, base + row_bytes + sum_bytes};
+      }
+      KPOP_TRY(launch_mfma_reference_norms(a, r1, n_dims, metric, lane[0].mscratch, chunk, st));
+      KPOP_TRY(launch_mfma_copy_reference_norms(lane[0].mscratch, lane[1].mscratch, r1, n_dims, chunk, st));
+      KPOP_HIP(hipEventRecord(aux->fork, st));
+      KPOP_HIP(hipStreamWaitEvent(aux->stream, aux->fork, 0));
+      int rc = 0;
+      uint32_t bi = 0;
+      for (uint32_t q0 = 0; q0 < r2 && !rc; q0 += chunk, ++bi) {
+        const Lane &L = lane[bi & 1u];
+        const uint32_t q = std::min(chunk, r2 - q0);
+        const double *bq = b + (uint64_t)q0 * n_dims;
+        SummaryLists lists;
+        const uint32_t *gate = nullptr;
+        const void *flags = nullptr;
+        auto batch = [&]() -> int {
+          if (bi > 0) KPOP_HIP(hipStreamWaitEvent(L.s, aux->step[(bi - 1) & 1u], 0));  // this batch's contraction after the one before it
+          KPOP_TRY(launch_distance_rows_mfma(KIND, a, r1, bq, q, n_dims, metric, L.rows, L.mscratch, chunk, L.s));
+          KPOP_HIP(hipEventRecord(aux->step[bi & 1u], L.s));
+          KPOP_TRY(launch_summary_large(L.rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, L.s, L.scratch, &lists));
+          KPOP_TRY(launch_summary_refine(KIND, L.rows, a, r1, bq, q, n_dims, metric, p, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z,
+                                         L.mscratch, chunk, L.s, lists, &gate, &flags));
+          KPOP_TRY(audit_fallback(gate, L.s));
+          KPOP_TRY(rowwise_block<KIND>(a, r1, bq, q, n_dims, metric, p, L.rows, L.s, nullptr, nullptr, gate));
+          KPOP_TRY(launch_summary_flagged_rows(L.rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, flags, L.s));
+          return 0;
+        };
+        rc = batch();
+      }
+      // the join, whatever happened: the caller's stream goes on only when the library's own has drained
+      const hipError_t e1 = hipEventRecord(aux->join, aux->stream), e2 = hipStreamWaitEvent(st, aux->join, 0);
+      if (rc) return rc;
+      if (e1 != hipSuccess || e2 != hipSuccess) KPOP_FAIL(KPOP_ERR_HIP, "kpop_dev_distance_summary: joining the second lane: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+      return 0;
+    }
     void *ws = nullptr;
     const uint32_t s_rows = select ? summary_fused_sample_rows(r1) : 0;
-    const uint64_t row_bytes = ((uint64_t)chunk * r1 * 8 + 255) & ~255ull, segi_bytes = select ? (((uint64_t)chunk * r1 * 4 + 255) & ~255ull) : 0;
-    const uint64_t sum_bytes = (std::max(summary_large_scratch_bytes(chunk, r1), select ? summary_fused_scratch_bytes(chunk, r1) : 0) + 511) & ~255ull;
+    const uint64_t r1_seg = select ? (((uint64_t)r1 + 2047) & ~2047ull) : r1;  // (the select kernel's segments: a row rounded up to whole stripes of 2,048)
+    const uint64_t row_bytes = ((uint64_t)chunk * r1_seg * 8 + 255) & ~255ull, segi_bytes = select ? (((uint64_t)chunk * r1_seg * 4 + 255) & ~255ull) : 0;
+    const uint64_t sum_bytes = (std::max(summary_large_scratch_bytes(chunk, r1), select ? summary_select_scratch_bytes(chunk, r1) : 0) + 511) & ~255ull;
     const uint64_t m_bytes = (summary_mfma_scratch_bytes(chunk, r1, n_dims) + 511) & ~255ull;
     const uint64_t as_bytes = ((uint64_t)s_rows * n_dims * 8 + 255) & ~255ull, sas_bytes = ((uint64_t)s_rows * 8 + 255) & ~255ull,
                    srow_bytes = ((uint64_t)chunk * s_rows * 8 + 255) & ~255ull;
@@ -1390,11 +1468,13 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
                                            seg_i, scratch, mscratch, chunk, st, &lists));
         KPOP_TRY(launch_summary_refine(KIND, nullptr, a, r1, bq, q, n_dims, metric, p, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist,
                                        out_z, mscratch, chunk, st, lists, &gate, &flags));
+        KPOP_TRY(audit_fallback(gate, st));
       } else {
         KPOP_TRY(launch_distance_rows_mfma(KIND, a, r1, bq, q, n_dims, metric, rows, mscratch, chunk, st));
         KPOP_TRY(launch_summary_large(rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st, scratch, &lists));
         KPOP_TRY(launch_summary_refine(KIND, rows, a, r1, bq, q, n_dims, metric, p, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist,
                                        out_z, mscratch, chunk, st, lists, &gate, &flags));
+        KPOP_TRY(audit_fallback(gate, st));
       }
       KPOP_TRY(rowwise_block<KIND>(a, r1, bq, q, n_dims, metric, p, rows, st, nullptr, nullptr, gate));
       KPOP_TRY(launch_summary_flagged_rows(rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, flags, st));
@@ -1425,6 +1505,7 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
       const uint32_t *gate = nullptr;
       KPOP_TRY(launch_summary_fused(KIND, a, r1, bq, q, n_dims, metric, p, srow, s, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx,
                                     out_dist, out_z, seg, scratch, st, &gate));
+      KPOP_TRY(audit_fallback(gate, st));
       // the rows it flagged (a bracket that missed, a list that overflowed): their distance rows into the segments' room and the
       // one-block-per-row kernel over them -- both launched whatever happened, both return at once when nothing was flagged
       KPOP_TRY(rowwise_block<KIND>(a, r1, bq, q, n_dims, metric, p, seg, st, nullptr, nullptr, gate));

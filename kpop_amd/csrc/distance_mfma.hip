@@ -193,10 +193,18 @@ __global__ __launch_bounds__(256) void distance_rows_mfma_kernel(const double *_
 // The summary's ONE pass over the pairs, inside the contraction: the kernel above with the operands of the MFMA exchanged -- a lane then
 // holds ONE query row (l15 of its M tile) x four reference rows of the tile, so the query's thresholds (FusedThr: the median's bracket,
 // the MAD's bands, the neighbours' cut, from the distances to a sample) live in 16 registers a query -- and every distance classified
-// where it is made: counted, summed, a candidate of the median or the MAD filed in its (query, STRIPE of 2,048 reference rows) segment
-// with its column, a neighbour candidate in the row's list.  No distance row is written: round 5's path wrote 2 GB of them per 256
-// queries x 1M and read them back three times (1.4 of its 2.58 ms).  What comes out is what summary_fused_pass_kernel writes
-// (summary_large.hip): fused_finish_kernel<true> reads it, summary_refine_kernel makes what is reported exact.  lib/Matrix.ml:691-766.
+// where it is made.  No distance row is written (round 5's path wrote 2 GB of them per 256 queries x 1M and read them back).
+// What a lane sees of a query row in a stripe of 2,048 reference rows -- 512 distances -- is a SUB-STRIPE of its own: its counts and
+// sums in registers for the whole stripe, its candidates (of the median's bracket, of the MAD's bands: ~12 in 100) stored one after
+// the other in its own 512 slots of the row's segment with their columns, ONE record (StripeRec) at the end.  No shared counter, no
+// atomic, no exchange between lanes on the way (the first version of this kernel filed candidates through LDS counters, one atomic
+// round trip each, a lane at a time: 4,650 of its 6,700 cycles a tile went there and it lost to the path that writes the rows).
+// Seven comparisons classify a distance: the counts of d < lo, d <= lo, d < hi, d <= hi (what lies below, at and inside the median's
+// bracket are differences of these) and of the inner region; a candidate is inside the bracket or in a band.  Neighbour candidates
+// (one in a thousand) go to the row's list with an atomic.  fused_finish_kernel<true> reads the records (sub-stripes of 512),
+// summary_refine_kernel makes what is reported exact.  lib/Matrix.ml:691-766.
+constexpr uint32_t kSubStripe = kStripe / 4;
+constexpr uint32_t kNbStage = 1024;  // neighbour candidates a block keeps in LDS until its stripe is done (~260 expected: 128 queries x 2,048 rows at one in a thousand)
 template <int KIND, int KS>
 __global__ __launch_bounds__(256) void summary_select_mfma_kernel(const double *__restrict__ a, uint32_t r1, const double *__restrict__ bm, uint32_t q, uint32_t n_dims,
                                                                   const double *__restrict__ sa, const double *__restrict__ sb, const FusedThr *__restrict__ thr,
@@ -206,11 +214,15 @@ __global__ __launch_bounds__(256) void summary_select_mfma_kernel(const double *
   constexpr int MI = 2, TS = 4 * KS + 2;
   __shared__ double s_tile[2][16][TS];
   __shared__ double s_sa[2][16];
-  __shared__ uint32_t s_ccnt[64 * MI];
+  // neighbour candidates wait here for the end of the stripe: filed straight into the rows' lists they cost an atomic that RETURNS -- the
+  // wavefront then waits for everything it has in flight, the next tile's loads included, four tiles in ten
+  __shared__ double s_nbd[kNbStage];
+  __shared__ uint32_t s_nbj[kNbStage], s_nbi[kNbStage];
+  __shared__ uint32_t s_nbn;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t l15 = (uint32_t)lane & 15u, l4 = (uint32_t)lane >> 4;
   const uint32_t stripe = blockIdx.x, j0 = blockIdx.y * (64u * MI) + (uint32_t)wv * (16u * MI);
-  if (threadIdx.x < 64 * MI) s_ccnt[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_nbn = 0;
   double qf[MI][KS];  // the query rows' fragments: lane = (query row l15 of the tile, dimension 4 ks + l4)
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -221,13 +233,17 @@ __global__ __launch_bounds__(256) void summary_select_mfma_kernel(const double *
     }
   FusedThr T[MI];
   double sbq[MI];
+  const uint32_t ref0 = stripe * kStripe, ref1 = min(r1, ref0 + kStripe);
+  uint64_t woff[MI];  // where this lane's next candidate of query mi goes (seg / seg_i share the index)
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const uint32_t row = min(j0 + 16u * mi + l15, q - 1u);
     T[mi] = thr[row];
     sbq[mi] = sb[row];
+    // (a row's segments: n_stripes x kStripe slots -- the row length rounded up to whole stripes, so that the four sub-stripes of a
+    // last, partial stripe have their 512 slots each; rows past the last one file nothing: their distances are made NaNs)
+    woff[mi] = (uint64_t)row * ((uint64_t)n_stripes * kStripe) + ref0 + l4 * kSubStripe;
   }
-  const uint32_t ref0 = stripe * kStripe, ref1 = min(r1, ref0 + kStripe);
   const uint32_t t0 = ref0 / 16u, t1 = (ref1 + 15u) / 16u;
   constexpr uint32_t PER = (16u * 4u * KS + 255u) / 256u;
   double pre[PER], pre_sa = 0.0;
@@ -249,12 +265,50 @@ __global__ __launch_bounds__(256) void summary_select_mfma_kernel(const double *
     if (threadIdx.x < 16) s_sa[buf][threadIdx.x] = pre_sa;
   };
   double sum[MI], sq[MI];
-  uint32_t c01[MI], c23[MI], c4[MI];  // lt | eqlo << 16, eqhi | nmed << 16, inner: a lane sees 512 elements of a stripe a query
+  uint32_t c_lt[MI], c_le[MI], c_lth[MI], c_leh[MI], c_in[MI], c_k[MI];  // d < lo, d <= lo, d < hi, d <= hi, inner region, candidates filed
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     sum[mi] = sq[mi] = 0.0;
-    c01[mi] = c23[mi] = c4[mi] = 0u;
+    c_lt[mi] = c_le[mi] = c_lth[mi] = c_leh[mi] = c_in[mi] = c_k[mi] = 0u;
   }
+  const bool rows_full = j0 + 16u * MI <= q;  // (wavefront-uniform)
+  // one distance, where it is made: counted, summed, filed if it is a candidate.  (A NaN -- a pair that is not of the job: a row past
+  // the last one, a column past the stripe's end -- is below, at and inside nothing: counted nowhere, filed nowhere.)
+  auto take = [&](int mi, double d, bool valid, uint32_t i) {
+    const FusedThr &Tq = T[mi];
+    sum[mi] = __dadd_rn(sum[mi], valid ? d : 0.0);
+    const double dvv = valid ? __dsub_rn(d, Tq.mhat) : 0.0;
+    sq[mi] = __dadd_rn(sq[mi], __dmul_rn(dvv, dvv));
+    if (!valid) d = __longlong_as_double(0x7FF8000000000000ll);
+    const bool lt = d < Tq.lo, le = d <= Tq.lo, lth = d < Tq.hi, leh = d <= Tq.hi;
+    const bool in = d > Tq.Lin && d < Tq.Uin;
+    c_lt[mi] += lt ? 1u : 0u;
+    c_le[mi] += le ? 1u : 0u;
+    c_lth[mi] += lth ? 1u : 0u;
+    c_leh[mi] += leh ? 1u : 0u;
+    c_in[mi] += in ? 1u : 0u;
+    if ((!le && lth) || (!in && d >= Tq.Llo && d <= Tq.Uhi)) {
+      seg[woff[mi]] = d;
+      seg_i[woff[mi]] = i;
+      ++woff[mi];
+      ++c_k[mi];
+    }
+    if (d <= Tq.cut) {
+      const uint32_t j = j0 + 16u * (uint32_t)mi + l15;
+      const uint32_t at = atomicAdd(&s_nbn, 1u);
+      if (at < kNbStage) {
+        s_nbd[at] = d;
+        s_nbj[at] = j;
+        s_nbi[at] = i;
+      } else {  // (the stage is full: the long way)
+        const uint32_t g = atomicAdd(&cnt[j].n_nb, 1u);
+        if (g < kNbCap) {
+          nb_idx[(uint64_t)j * kNbCap + g] = i;
+          nb_d[(uint64_t)j * kNbCap + g] = d;
+        }
+      }
+    }
+  };
   fetch(t0);
   put(0);
   __syncthreads();
@@ -285,86 +339,52 @@ __global__ __launch_bounds__(256) void summary_select_mfma_kernel(const double *
     for (int rr = 0; rr < 4; ++rr) sai[rr] = s_sa[buf][l4 + 4u * rr];
     __builtin_amdgcn_s_setprio(2);
     put(buf ^ 1);
-    const bool full = 16u * t + 16u <= ref1;  // (uniform)
-    // every distance of the tile counted and summed; the few that are candidates (of the median's bracket, of the MAD's bands: a few per
-    // cent) or neighbour candidates only MARKED here and filed after the tile's arithmetic, the lanes that have one together -- filed one
-    // element at a time, nine wavefront-instructions in ten found SOME lane with a candidate and took the slow way (1.37 ms the launch)
-    double dv[MI][4];
-    uint32_t cmask = 0, nmask = 0;
+    if (rows_full && 16u * t + 16u <= ref1) {  // (uniform) every element of the tile is a pair of the job
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const uint32_t j = j0 + 16u * mi + l15;
-      const FusedThr &Tq = T[mi];
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {  // lane holds reference rows l4 + 4 rr of the tile, query row l15 of the M tile
-        const uint32_t i = 16u * t + l4 + 4u * rr;
-        double u = sai[rr] + sbq[mi] - 2.0 * acc[mi][rr];
-        u = u > 0.0 ? u : 0.0;
-        const double d = KIND == KPOP_EUCLIDEAN ? sqrt_fast(u) : u * 0.5;
-        dv[mi][rr] = d;
-        const bool ok = j < q && (full || i < ref1);
-        const bool medc = d > Tq.lo && d < Tq.hi;
-        const bool in = d > Tq.Lin && d < Tq.Uin;
-        if (ok) {
-          c01[mi] += (d < Tq.lo ? 1u : 0u) + (d == Tq.lo ? 1u << 16 : 0u);
-          c23[mi] += ((d == Tq.hi && Tq.hi != Tq.lo) ? 1u : 0u) + (medc ? 1u << 16 : 0u);
-          c4[mi] += in ? 1u : 0u;
-          sum[mi] = __dadd_rn(sum[mi], d);
-          const double dvv = __dsub_rn(d, Tq.mhat);
-          sq[mi] = __dadd_rn(sq[mi], __dmul_rn(dvv, dvv));
+        for (int rr = 0; rr < 4; ++rr) {  // lane holds reference rows l4 + 4 rr of the tile, query row l15 of the M tile
+          double u = sai[rr] + sbq[mi] - 2.0 * acc[mi][rr];
+          u = u > 0.0 ? u : 0.0;
+          const double d = KIND == KPOP_EUCLIDEAN ? sqrt_fast(u) : u * 0.5;
+          take(mi, d, true, 16u * t + l4 + 4u * (uint32_t)rr);
         }
-        cmask |= (ok && (medc || (!in && d >= Tq.Llo && d <= Tq.Uhi))) ? 1u << (4 * mi + rr) : 0u;
-        nmask |= (ok && d <= Tq.cut) ? 1u << (4 * mi + rr) : 0u;
-      }
-    }
-    auto pick = [&](uint32_t e) -> double {  // dv[e >> 2][e & 3] of a lane's own e
-      double x = dv[0][0];
+    } else {
 #pragma unroll
-      for (uint32_t f = 1; f < 4u * MI; ++f) x = e == f ? dv[f >> 2][f & 3u] : x;
-      return x;
-    };
-    while (__ballot(cmask != 0u)) {  // (as many turns as the lane with the most candidates has: one or two)
-      if (cmask) {
-        const uint32_t e = (uint32_t)__ffs((int)cmask) - 1u;
-        cmask &= cmask - 1u;
-        const uint32_t mi = e >> 2, j = j0 + 16u * mi + l15, i = 16u * t + l4 + 4u * (e & 3u);
-        const uint32_t slot = atomicAdd(&s_ccnt[(uint32_t)wv * (16u * MI) + 16u * mi + l15], 1u);
-        seg[(uint64_t)j * r1 + ref0 + slot] = pick(e);  // (at most as many as the stripe has columns)
-        seg_i[(uint64_t)j * r1 + ref0 + slot] = i;
-      }
-    }
-    while (__ballot(nmask != 0u)) {
-      if (nmask) {
-        const uint32_t e = (uint32_t)__ffs((int)nmask) - 1u;
-        nmask &= nmask - 1u;
-        const uint32_t mi = e >> 2, j = j0 + 16u * mi + l15, i = 16u * t + l4 + 4u * (e & 3u);
-        const uint32_t at = atomicAdd(&cnt[j].n_nb, 1u);
-        if (at < kNbCap) {
-          nb_idx[(uint64_t)j * kNbCap + at] = i;
-          nb_d[(uint64_t)j * kNbCap + at] = pick(e);
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const uint32_t i = 16u * t + l4 + 4u * (uint32_t)rr;
+          double u = sai[rr] + sbq[mi] - 2.0 * acc[mi][rr];
+          u = u > 0.0 ? u : 0.0;
+          const double d = KIND == KPOP_EUCLIDEAN ? sqrt_fast(u) : u * 0.5;
+          take(mi, d, j0 + 16u * (uint32_t)mi + l15 < q && i < ref1, i);
         }
-      }
     }
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();
   }
-  // a query's four lanes (l4 = 0..3: a quarter of the stripe's columns each), added up in a fixed order; the first writes
+  // a record a lane: sub-stripe 4 stripe + l4 of its query rows
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-    for (int o = 16; o < 64; o <<= 1) {
-      sum[mi] = __dadd_rn(sum[mi], __shfl_xor(sum[mi], o, 64));
-      sq[mi] = __dadd_rn(sq[mi], __shfl_xor(sq[mi], o, 64));
-      c01[mi] += (uint32_t)__shfl_xor((int)c01[mi], o, 64);
-      c23[mi] += (uint32_t)__shfl_xor((int)c23[mi], o, 64);
-      c4[mi] += (uint32_t)__shfl_xor((int)c4[mi], o, 64);
-    }
     const uint32_t j = j0 + 16u * mi + l15;
-    if (l4 == 0 && j < q) {
-      const uint64_t at = (uint64_t)j * n_stripes + stripe;
-      rec[at] = StripeRec{c01[mi], c23[mi], c4[mi], s_ccnt[(uint32_t)wv * (16u * MI) + 16u * mi + l15]};
+    if (j < q) {
+      const FusedThr &Tq = T[mi];
+      const uint32_t eqlo = c_le[mi] - c_lt[mi], nmed = Tq.lo < Tq.hi ? c_lth[mi] - c_le[mi] : 0u, eqhi = Tq.hi != Tq.lo ? c_leh[mi] - c_lth[mi] : 0u;
+      const uint64_t at = (uint64_t)j * (4u * n_stripes) + 4u * stripe + l4;
+      rec[at] = StripeRec{c_lt[mi] | (eqlo << 16), eqhi | (nmed << 16), c_in[mi], c_k[mi]};
       part[at * 2 + 0] = sum[mi];
       part[at * 2 + 1] = sq[mi];
+    }
+  }
+  // the stripe's neighbour candidates into their rows' lists
+  const uint32_t n_st = min(s_nbn, kNbStage);  // (the loop's last barrier stands between the last append and this read)
+  for (uint32_t e = threadIdx.x; e < n_st; e += 256) {
+    const uint32_t j = s_nbj[e];
+    const uint32_t g = atomicAdd(&cnt[j].n_nb, 1u);
+    if (g < kNbCap) {
+      nb_idx[(uint64_t)j * kNbCap + g] = s_nbi[e];
+      nb_d[(uint64_t)j * kNbCap + g] = s_nbd[e];
     }
   }
 }
@@ -625,6 +645,13 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
     }
   }
   if (!from_lists && rows == nullptr) {  // (uniform) the one-kernel path wrote no distance rows to scan: the fall-back's
+#ifdef KPOP_REFINE_WHY
+    if (threadIdx.x == 0 && L.info != nullptr) {
+      const FusedThr T = L.thr[jl];
+      printf("row %u not from lists: ok %d u_nb %g sq(cut) %g | lo %g hi %g u_med_lo %g u_med_hi %g | Lin %g Uin %g Llo %g Uhi %g u_e2lo %g u_e2hi %g u_e1lo %g u_e1hi %g low_edge %d med_a %g mad_a %g G %g\n", j, (int)ok, u_nb,
+             sq(T.cut), T.lo, T.hi, u_med_lo, u_med_hi, T.Lin, T.Uin, T.Llo, T.Uhi, u_e2lo, u_e2hi, u_e1lo, u_e1hi, (int)low_edge, med_a, mad_a, G);
+    }
+#endif
     if (threadIdx.x == 0) {
       rc[(uint64_t)jl * kRowCountsWords + kRowCountsFail] = 1u;
       atomicAdd(n_failed, 1u);
@@ -672,6 +699,9 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
     }
   };
   if (!ok) {  // (uniform)
+#ifdef KPOP_REFINE_WHY
+    if (threadIdx.x == 0) printf("row %u gives up: n_nb %u n_med %u n_lt %u n_mad %u n_in %u req_len %u r_med %u from_lists %d\n", j, n_nb, n_med, n_lt, n_mad, n_in, req_len, r_med, (int)from_lists);
+#endif
     give_up();
     return;
   }
@@ -741,6 +771,9 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
     const double x2 = median + mad, x1 = median - mad;
     const bool good = x2 >= e2lo && x2 <= e2hi && (low_edge ? (x1 <= e1hi && (e1lo <= 0.0 || x1 >= e1lo)) : x1 <= 0.0 || x1 <= e1hi);
     if (!good) {  // (uniform)
+#ifdef KPOP_REFINE_WHY
+      if (threadIdx.x == 0) printf("row %u: MAD certificate: median %.17g mad %.17g x1 %.17g x2 %.17g e1lo %g e1hi %g e2lo %g e2hi %g low_edge %d n_mad %u n_in %u med_a %.17g mad_a %.17g\n", j, median, mad, x1, x2, e1lo, e1hi, e2lo, e2hi, (int)low_edge, n_mad, n_in, med_a, mad_a);
+#endif
       give_up();
       return;
     }
@@ -762,6 +795,9 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
   __syncthreads();
   const double cut = s_val[0];
   if (!(sq(cut) <= u_nb - G)) {  // (the certificate: no row outside the band is as near as the cut or ties with it)
+#ifdef KPOP_REFINE_WHY
+    if (threadIdx.x == 0) printf("row %u: neighbours' certificate: cut %.17g u_nb %g G %g n_nb %u t_a %g eff_a %u\n", j, cut, u_nb, G, n_nb, t_a, eff_a);
+#endif
     give_up();
     return;
   }
@@ -773,6 +809,9 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
   __syncthreads();
   const uint32_t eff = s_cnt[6];
   if (eff > max_neighbours) {  // (a tie group longer than the caller's lists: the fall-back's, and after it the host's long lists)
+#ifdef KPOP_REFINE_WHY
+    if (threadIdx.x == 0) printf("row %u: eff %u > max_neighbours\n", j, eff);
+#endif
     if (threadIdx.x == 0) {
       rc[(uint64_t)jl * kRowCountsWords + kRowCountsFail] = 1u;
       atomicAdd(n_failed, 1u);
@@ -852,6 +891,14 @@ int launch_mfma_reference_norms(const double *a, uint32_t r1, uint32_t n_dims, c
   KPOP_HIP(hipMemsetAsync(M.smax, 0, 256, st));
   row_sumsq_kernel<<<dim3(std::min(div_up(r1, 16), 4096u)), dim3(256), 0, st>>>(a, r1, n_dims, metric, M.sa, nullptr, M.smax);
   KPOP_LAUNCH_CHECK();
+  return 0;
+}
+
+// ... into a second scratch of the same shape (a second chain of kernels of the same call: distance.hip, the two lanes of the summary)
+int launch_mfma_copy_reference_norms(const void *from, void *to, uint32_t r1, uint32_t n_dims, uint32_t q_room, hipStream_t st) {
+  const MfmaScratch A = carve_mfma(const_cast<void *>(from), q_room, r1, n_dims), B = carve_mfma(to, q_room, r1, n_dims);
+  KPOP_HIP(hipMemcpyAsync(B.sa, A.sa, (uint64_t)r1 * 8, hipMemcpyDeviceToDevice, st));
+  KPOP_HIP(hipMemcpyAsync(B.smax, A.smax, 256, hipMemcpyDeviceToDevice, st));
   return 0;
 }
 

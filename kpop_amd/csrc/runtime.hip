@@ -109,6 +109,17 @@ extern "C" int kpop_device_count(void) {
   return n;
 }
 
+int Context::aux_for(hipStream_t st, AuxLane **out) {
+  std::lock_guard<std::mutex> g(ws_mu);
+  AuxLane &a = aux_by_stream[st];
+  if (!a.stream) {
+    KPOP_HIP(hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking));
+    for (hipEvent_t *e : {&a.fork, &a.join, &a.step[0], &a.step[1]}) KPOP_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  }
+  *out = &a;
+  return 0;
+}
+
 static void release_slot(Context &c) {
   if (!c.initialised) return;
   (void)hipSetDevice(c.device);
@@ -118,6 +129,14 @@ static void release_slot(Context &c) {
     c.ws_by_stream.clear();
     for (auto &kv : c.ws2_by_stream) kv.second.release();
     c.ws2_by_stream.clear();
+    for (auto &kv : c.aux_by_stream) {
+      Context::AuxLane &a = kv.second;
+      if (a.stream) (void)hipStreamSynchronize(a.stream);
+      for (hipEvent_t e : {a.fork, a.join, a.step[0], a.step[1]})
+        if (e) (void)hipEventDestroy(e);
+      if (a.stream) (void)hipStreamDestroy(a.stream);
+    }
+    c.aux_by_stream.clear();
   }
   c.arena.release();
   c.initialised = false;
@@ -203,6 +222,8 @@ extern "C" int kpop_tune(const char *key, int value) {
     else if (!strcmp(key, "distance_mfma") && (value == 0 || value == 1)) c.tune_distance_mfma = value;
     else if (!strcmp(key, "summary_mfma") && value >= 0 && value <= 2) c.tune_summary_mfma = value;
     else if (!strcmp(key, "summary2") && value >= 0 && value <= 3) c.tune_summary2 = value;
+    else if (!strcmp(key, "summary_lanes") && (value == 1 || value == 2)) c.tune_summary_lanes = value;
+    else if (!strcmp(key, "summary_audit") && (value == 0 || value == 1)) c.tune_summary_audit = value;
     else if (!strcmp(key, "seg") && (value == 0 || (value >= 64 && value <= 16384 && value % 64 == 0))) c.tune_seg = value;
     else KPOP_FAIL(KPOP_ERR_INVALID, "kpop_tune: unknown knob or value %s=%d", key, value);
   }

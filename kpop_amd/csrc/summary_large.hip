@@ -93,6 +93,7 @@ __device__ __forceinline__ uint64_t elem_key(const Row &row, uint32_t i, double 
 // ---------------------------------------------------------------------------
 constexpr uint32_t kBins = 2048, kCand = 2048;
 constexpr int kSel = 2;
+constexpr int kSelLoads = 8;  // loads in flight a thread in the passes of a selection
 static_assert(kBins == 2 * kLT, "block_select_ranks: a thread owns two bins");
 
 struct Sel {          // one selection in progress / done
@@ -126,12 +127,12 @@ __device__ void block_select_ranks(const Row row, uint32_t n, double centre, Sel
     int shift[kSel];
     for (int t = 0; t < n_sel; ++t) shift[t] = range_shift(sel[t].lo, sel[t].hi);
     double sq = 0.0;
-    for (uint32_t i0 = threadIdx.x; i0 < n; i0 += kLT * 4) {  // four loads in flight a thread
-      double v[4];
+    for (uint32_t i0 = threadIdx.x; i0 < n; i0 += kLT * kSelLoads) {  // eight loads in flight a thread (a block a CU, a chain of round trips: four were 45k of a 65k-cycle pass over 120,000 candidates)
+      double v[kSelLoads];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = i0 + u * kLT < n ? row[i0 + u * kLT] : 0.0;
+      for (int u = 0; u < kSelLoads; ++u) v[u] = i0 + u * kLT < n ? row[i0 + u * kLT] : 0.0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < kSelLoads; ++u) {
         if (i0 + u * kLT >= n) continue;
         const uint64_t k = f64_key(TRANSFORM ? fabs(__dsub_rn(v[u], centre)) : v[u]);
         if (SUMSQ && round == 0) {
@@ -215,12 +216,12 @@ __device__ void block_select_ranks(const Row row, uint32_t n, double centre, Sel
       __syncthreads();
       if (threadIdx.x < (uint32_t)n_sel) s_misc[32 + threadIdx.x] = 0;
       __syncthreads();
-      for (uint32_t i0 = threadIdx.x; i0 < n; i0 += kLT * 4) {
-        double v[4];
+      for (uint32_t i0 = threadIdx.x; i0 < n; i0 += kLT * kSelLoads) {
+        double v[kSelLoads];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = i0 + u * kLT < n ? row[i0 + u * kLT] : 0.0;
+        for (int u = 0; u < kSelLoads; ++u) v[u] = i0 + u * kLT < n ? row[i0 + u * kLT] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kSelLoads; ++u) {
           if (i0 + u * kLT >= n) continue;
           const uint64_t k = f64_key(TRANSFORM ? fabs(__dsub_rn(v[u], centre)) : v[u]);
           for (int t = 0; t < n_sel; ++t)
@@ -432,6 +433,15 @@ __global__ __launch_bounds__(kLT) void summary_large_kernel(const double *__rest
 // at the median or the cut) or whose keep_at_most exceeds what the lists hold is flagged and redone by the kernel above.
 // HBM traffic: the rows once written, twice read.
 // ===========================================================================
+#ifdef KPOP_SUMMARY_STAMPS  // development only (tools/probes): phase clocks of block 0 of the one-block-a-row kernels
+__device__ unsigned long long g_sum_stamps[32];
+#define KPOP_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_sum_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#define KPOP_WHY(c) do { if (threadIdx.x == 0) { atomicAdd(&g_sum_stamps[24 + (c)], 1ull); g_sum_stamps[31] = blockIdx.x; } } while (0)  // why a row was left to the fall-back
+#else
+#define KPOP_STAMP(i) do { } while (0)
+#define KPOP_WHY(c) do { } while (0)
+#endif
+
 constexpr uint32_t kSample = 65536, kSlice = 32768, kNbSort = 4096;  // (kNbCap: summary_types.h)
 // the brackets hold ~2.3 % of a row (six sigmas of a 65,536-element sample's quantile, both sides): room for 6 %, at least 65,536
 static inline uint32_t cand_cap_for(uint32_t r1) { return std::max<uint32_t>(65536u, ((r1 / 16 + 4095u) & ~4095u)); }
@@ -679,6 +689,59 @@ __device__ bool neighbours_from_list(uint32_t n, uint32_t req_len, uint32_t max_
   uint32_t eff = n;
   bool ok = true;
   if (n_nb > kNbCap || (n_nb < n && req_len > n_nb) || (n_nb == n && n > kNbCap)) ok = false;
+  // The usual case first: the whole list fits the sort buffer (it holds ~3 req_len + 16 x the row's share of the sample) -- sorted
+  // whole by (distance, column), the effective length and the first M read off the sorted list.  The same answers as the selections
+  // below (which remain for longer lists), without their passes: 276k of this kernel's 790k cycles went into a list of 1,029.
+  if (ok && req_len < n && n_nb >= 1 && n_nb <= kNbSort) {
+    __syncthreads();
+    if (threadIdx.x == 0) (*s_take) = 0;
+    __syncthreads();
+    uint32_t NP = 1;
+    while (NP < n_nb) NP <<= 1;
+    for (uint32_t q = threadIdx.x; q < NP; q += kLT) {
+      const double d = q < n_nb ? my_d[q] : __longlong_as_double(0x7FF0000000000000ll);
+      s_cd[q] = d;
+      s_ci[q] = q < n_nb ? my_idx[q] : 0xFFFFFFFFu;
+      // (a NaN, or a -0.0 -- below +0.0 as a key, equal to it as a number --: the selections' way, which speaks in keys)
+      if (q < n_nb && (d != d || __double_as_longlong(d) == (long long)0x8000000000000000ull)) (*s_take) = 1;
+    }
+    __syncthreads();
+    const bool plain = (*s_take) == 0;
+    if (plain) {
+      for (uint32_t sz = 2; sz <= NP; sz <<= 1)
+        for (uint32_t t = sz >> 1; t > 0; t >>= 1) {
+          __syncthreads();
+          for (uint32_t q = threadIdx.x; q < NP / 2; q += kLT) {
+            const uint32_t a = 2 * q - (q & (t - 1)), b = a + t;
+            const bool asc = (a & sz) == 0;
+            const double da = s_cd[a], db = s_cd[b];
+            const uint32_t ia = s_ci[a], ib = s_ci[b];
+            const bool gt = (db < da) || (db == da && ib < ia);
+            if (gt == asc) {
+              s_cd[a] = db; s_cd[b] = da;
+              s_ci[a] = ib; s_ci[b] = ia;
+            }
+          }
+        }
+      __syncthreads();
+      const double v = s_cd[req_len - 1];  // (req_len <= n_nb: checked above)
+      for (uint32_t q = threadIdx.x; q < n_nb; q += kLT)
+        if (s_cd[q] <= v && (q + 1 == n_nb || s_cd[q + 1] > v)) (*s_take) = q + 1;  // the one place where the values at or below v end
+      __syncthreads();
+      eff = (*s_take);
+      const uint32_t M = min(min(eff, max_neighbours), kLargeMaxNb);
+      for (uint32_t q = threadIdx.x; q < M; q += kLT) {
+        out_idx[(uint64_t)j * max_neighbours + q] = s_ci[q];
+        out_dist[(uint64_t)j * max_neighbours + q] = s_cd[q];
+        double zz = __dsub_rn(s_cd[q], mean) / sd;
+        if (zz != zz) zz = __longlong_as_double((long long)0xFFF8000000000000ull);  // x86 invalid-operation NaN, see distance.hip
+        out_z[(uint64_t)j * max_neighbours + q] = zz;
+      }
+      __syncthreads();
+      *eff_out = eff;
+      return true;
+    }
+  }
   if (ok) {
     uint32_t M;
     uint64_t vkey = ~0ull;
@@ -882,14 +945,22 @@ __global__ __launch_bounds__(kLT) void fused_sample_kernel(const double *__restr
   if constexpr (SAMPLED) sr = SampledRow{src + (uint64_t)blockIdx.x * r1, stride};
   else sr = PlainRow{src + (uint64_t)blockIdx.x * s};
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  KPOP_STAMP(16);
   double part = 0.0;
   uint64_t kmin = ~0ull, kmax = 0;
-  for (uint32_t i = threadIdx.x; i < s; i += kLT) {
-    const double x = sr[i];
-    part = __dadd_rn(part, x);
-    const uint64_t k = f64_key(x);
-    kmin = kmin < k ? kmin : k;
-    kmax = kmax > k ? kmax : k;
+  for (uint32_t i0 = threadIdx.x; i0 < s; i0 += kLT * 8) {  // (eight loads in flight; the sum in the order one load a turn gave)
+    double x8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x8[u] = i0 + u * kLT < s ? sr[i0 + u * kLT] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (i0 + u * kLT >= s) continue;
+      const double x = x8[u];
+      part = __dadd_rn(part, x);
+      const uint64_t k = f64_key(x);
+      kmin = kmin < k ? kmin : k;
+      kmax = kmax > k ? kmax : k;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -906,6 +977,7 @@ __global__ __launch_bounds__(kLT) void fused_sample_kernel(const double *__restr
     kmin = kmin < s_mm[w] ? kmin : s_mm[w];
     kmax = kmax > s_mm[kLT / 64 + w] ? kmax : s_mm[kLT / 64 + w];
   }
+  KPOP_STAMP(17);
   uint32_t a, b;
   bracket_ranks(r1 / 2, r1, s, &a, &b);
   // A selection narrows [lo, hi] by bins that are linear in KEY space -- logarithmic in the value.  One sample far below the rest
@@ -920,10 +992,17 @@ __global__ __launch_bounds__(kLT) void fused_sample_kernel(const double *__restr
     const uint64_t kmark = f64_key(m_hat * 0.0625);
     uint64_t k2 = ~0ull;
     uint32_t c = 0;
-    for (uint32_t i = threadIdx.x; i < s; i += kLT) {
-      const uint64_t k = f64_key(sr[i]);
-      if (k < kmark) ++c;
-      else k2 = k2 < k ? k2 : k;
+    for (uint32_t i0 = threadIdx.x; i0 < s; i0 += kLT * 8) {
+      double x8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x8[u] = i0 + u * kLT < s ? sr[i0 + u * kLT] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (i0 + u * kLT >= s) continue;
+        const uint64_t k = f64_key(x8[u]);
+        if (k < kmark) ++c;
+        else k2 = k2 < k ? k2 : k;
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -948,20 +1027,24 @@ __global__ __launch_bounds__(kLT) void fused_sample_kernel(const double *__restr
       n_out = 0;
     }
   }
+  KPOP_STAMP(18);
   auto from_low = [&](uint32_t rank, int done) { return rank >= n_out ? Sel{rank, klow, kmax, n_out, 0, 0, 0, done} : Sel{rank, kmin, kmax, 0, 0, 0, 0, done}; };
   Sel sel[kSel] = {from_low(a, 0), from_low(b, 0)};
   block_select_ranks<0, false, Row>(sr, s, 0.0, sel, 2, s_hist, s_cand, s_misc);
+  KPOP_STAMP(19);
   // the sample's own median, and -- same passes -- the neighbour threshold
   uint64_t kcut = ~0ull;
   const double want = 3.0 * (double)req_len * (double)s / (double)r1 + 16.0;
   const bool cut = want < (double)(s - 1);
   Sel sm[kSel] = {from_low(s / 2, 0), from_low(cut ? (uint32_t)want : 0u, cut ? 0 : 1)};
   block_select_ranks<0, false, Row>(sr, s, 0.0, sm, 2, s_hist, s_cand, s_misc);
+  KPOP_STAMP(20);
   if (cut) kcut = sm[1].value;
   const double ms = key_f64(sm[0].value);
   const double far = fmax(fabs(__dsub_rn(key_f64(kmax), ms)), fabs(__dsub_rn(key_f64(kmin), ms)));
   Sel sa[kSel] = {Sel{a, f64_key(0.0), f64_key(far), 0, 0, 0, 0, 0}, Sel{b, f64_key(0.0), f64_key(far), 0, 0, 0, 0, 0}};
   block_select_ranks<1, false, Row>(sr, s, ms, sa, 2, s_hist, s_cand, s_misc);
+  KPOP_STAMP(21);
   if (threadIdx.x == 0) {
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
     const bool no_lo = a == 0, no_hi = b == s - 1;  // rank 0 / the last rank of the sample bound nothing
@@ -1292,8 +1375,11 @@ __global__ __launch_bounds__(kLT) void fused_finish_kernel(const double *__restr
                                                            uint32_t *__restrict__ n_failed, double *__restrict__ out_stats,
                                                            uint32_t *__restrict__ out_n, uint32_t *__restrict__ out_idx,
                                                            double *__restrict__ out_dist, double *__restrict__ out_z,
-                                                           const uint32_t *__restrict__ seg_i = nullptr, uint32_t *__restrict__ ccand_i = nullptr) {
-  // (seg_i / ccand_i: the candidates' columns beside their values, compacted the same way -- the matrix-core path's refinement reads them)
+                                                           const uint32_t *__restrict__ seg_i = nullptr, uint32_t *__restrict__ ccand_i = nullptr,
+                                                           uint32_t seg_stride = kStripe, uint64_t seg_ld = 0) {
+  // (seg_i / ccand_i: the candidates' columns beside their values, compacted the same way -- the matrix-core path's refinement reads them;
+  //  seg_stride: the elements between the starts of two records' segments -- kStripe, or the matrix-core kernel's sub-stripes of a quarter;
+  //  seg_ld: the elements between two rows' segments -- r1 (0), or the matrix-core kernel's whole stripes)
   __shared__ uint32_t s_hist[kSel * kBins];
   __shared__ uint64_t s_cand[kSel * kCand];
   __shared__ uint32_t s_misc[64];
@@ -1312,6 +1398,7 @@ __global__ __launch_bounds__(kLT) void fused_finish_kernel(const double *__restr
   double *my_c = ccand + (uint64_t)jl * cap;
   if (threadIdx.x < 8) s_tot[threadIdx.x] = 0;
   __syncthreads();
+  KPOP_STAMP(0);
   uint32_t lt, eqlo, eqhi, nmed, n_inner, n_c;
   bool ok;
   if constexpr (SEG) {
@@ -1349,27 +1436,29 @@ __global__ __launch_bounds__(kLT) void fused_finish_kernel(const double *__restr
     __syncthreads();
     lt = s_tot[0]; eqlo = s_tot[1]; eqhi = s_tot[2]; nmed = s_tot[3]; n_inner = s_tot[4]; n_c = running;
     ok = n_c <= cap;
-    // ---- the candidates, compacted (a wave per stripe)
+    // ---- the candidates, compacted: a wavefront per record, or -- records of up to 512 elements, ~60 of them filled -- sixteen lanes
     if (ok) {
-      for (uint32_t st = wv; st < n_stripes; st += kLT / 64) {
+      const uint32_t gl = seg_stride <= 512u ? 16u : 64u, gpw = 64u / gl;  // lanes a record, records a wavefront at a time
+      const uint32_t lg = (uint32_t)lane % gl, g = (uint32_t)lane / gl;
+      for (uint32_t st = (uint32_t)wv * gpw + g; st < n_stripes; st += (kLT / 64) * gpw) {
         const uint32_t c = my_rec[st].c_cnt, at = my_pre[st];
-        const double *src = seg + (uint64_t)jl * r1 + (uint64_t)st * kStripe;
-        for (uint32_t e0 = 0; e0 < c; e0 += 64 * 8) {  // eight loads in flight a lane (a loop of one was latency-bound: 0.24 ms)
+        const double *src = seg + (uint64_t)jl * (seg_ld ? seg_ld : (uint64_t)r1) + (uint64_t)st * seg_stride;
+        for (uint32_t e0 = 0; e0 < c; e0 += gl * 8) {  // eight loads in flight a lane (a loop of one was latency-bound: 0.24 ms)
           double v[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = e0 + u * 64 + lane < c ? src[e0 + u * 64 + lane] : 0.0;
+          for (int u = 0; u < 8; ++u) v[u] = e0 + u * gl + lg < c ? src[e0 + u * gl + lg] : 0.0;
 #pragma unroll
           for (int u = 0; u < 8; ++u)
-            if (e0 + u * 64 + lane < c) my_c[at + e0 + u * 64 + lane] = v[u];
+            if (e0 + u * gl + lg < c) my_c[at + e0 + u * gl + lg] = v[u];
           if (seg_i) {
-            const uint32_t *srci = seg_i + (uint64_t)jl * r1 + (uint64_t)st * kStripe;
+            const uint32_t *srci = seg_i + (uint64_t)jl * (seg_ld ? seg_ld : (uint64_t)r1) + (uint64_t)st * seg_stride;
             uint32_t *my_ci = ccand_i + (uint64_t)jl * cap;
             uint32_t vi[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) vi[u] = e0 + u * 64 + lane < c ? srci[e0 + u * 64 + lane] : 0u;
+            for (int u = 0; u < 8; ++u) vi[u] = e0 + u * gl + lg < c ? srci[e0 + u * gl + lg] : 0u;
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-              if (e0 + u * 64 + lane < c) my_ci[at + e0 + u * 64 + lane] = vi[u];
+              if (e0 + u * gl + lg < c) my_ci[at + e0 + u * gl + lg] = vi[u];
           }
         }
       }
@@ -1386,6 +1475,7 @@ __global__ __launch_bounds__(kLT) void fused_finish_kernel(const double *__restr
   }
   // ---- mean and sd: the stripes' sums in a fixed order -- runs of eight stripes by a thread each, then the runs' sums in
   // order by every thread out of LDS (one chain over 512 global loads was a quarter of this kernel)
+  KPOP_STAMP(1);
   double sum = 0.0, sqh = 0.0;
   {
     double *s_ps = s_cd;  // (the neighbours' sort buffer, not yet in use: 2 x 1,024 doubles)
@@ -1411,36 +1501,46 @@ __global__ __launch_bounds__(kLT) void fused_finish_kernel(const double *__restr
   const double ss = fmax(0.0, __dsub_rn(sqh, __dmul_rn((double)n, __dmul_rn(dm, dm))));
   const double sd = n > 1 ? sqrt(ss / ((double)n - 1.0)) : 0.0;
   // ---- the median: rank n / 2 among [lt below the bracket | eqlo at its lower end | nmed inside | eqhi at its upper end]
+  KPOP_STAMP(2);
   double median = 0.0;
   const uint32_t r = n / 2;
   if (ok) {
-    if (r < lt) ok = false;
+    if (r < lt) { ok = false; KPOP_WHY(1); }
     else if (r < lt + eqlo) median = key_f64(I.klo);
     else if (r < lt + eqlo + nmed) {
       Sel sm[1] = {Sel{r - lt - eqlo, I.klo + 1, I.khi - 1, 0, 0, 0, 0, 0}};  // keys strictly inside the bracket
       block_select_ranks<0>(PlainRow{my_c}, n_c, 0.0, sm, 1, s_hist, s_cand, s_misc);
       median = key_f64(sm[0].value);
     } else if (r < lt + eqlo + nmed + eqhi) median = key_f64(I.khi);
-    else ok = false;
+    else { ok = false; KPOP_WHY(2); }
   }
+  KPOP_STAMP(3);
   // ---- the neighbours
   uint32_t eff = n;
   if (ok)
     ok = neighbours_from_list(n, req_len, max_neighbours, cnt[jl].n_nb, nb_idx + (uint64_t)jl * kNbCap, nb_d + (uint64_t)jl * kNbCap, I.kcut, mean, sd,
                               j, out_idx, out_dist, out_z, s_hist, s_cand, s_misc, s_cd, s_ci, &s_take, &eff);
+  KPOP_STAMP(4);
+  if (!ok) KPOP_WHY(3);
   // ---- the MAD
   double mad = 0.0;
   if (ok) {
     const BandRow br{my_c, T.Llo, T.Lin, T.Uin, T.Uhi};
     uint64_t kmin = ~0ull, kmax = 0;
     uint32_t n_band = 0;
-    for (uint32_t i = threadIdx.x; i < n_c; i += kLT) {
-      const double d = br[i];
-      if (d == d) {
-        const uint64_t k = f64_key(fabs(__dsub_rn(d, median)));
-        kmin = kmin < k ? kmin : k;
-        kmax = kmax > k ? kmax : k;
-        ++n_band;
+    for (uint32_t i0 = threadIdx.x; i0 < n_c; i0 += kLT * 8) {  // (eight loads in flight a thread)
+      double d8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) d8[u] = i0 + u * kLT < n_c ? br[i0 + u * kLT] : __longlong_as_double(0x7FF8000000000000ll);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const double d = d8[u];
+        if (d == d) {
+          const uint64_t k = f64_key(fabs(__dsub_rn(d, median)));
+          kmin = kmin < k ? kmin : k;
+          kmax = kmax > k ? kmax : k;
+          ++n_band;
+        }
       }
     }
 #pragma unroll
@@ -1463,7 +1563,8 @@ __global__ __launch_bounds__(kLT) void fused_finish_kernel(const double *__restr
       kmax = kmax > s_mm[kLT / 64 + w] ? kmax : s_mm[kLT / 64 + w];
       n_band += s_wu[w];
     }
-    if (r < n_inner || r - n_inner >= n_band) ok = false;
+    KPOP_STAMP(5);
+    if (r < n_inner || r - n_inner >= n_band) { ok = false; KPOP_WHY(4); }
     else {
       Sel sa[1] = {Sel{r - n_inner, kmin, kmax, 0, 0, 0, 0, 0}};
       block_select_ranks<1, false, BandRow>(br, n_c, median, sa, 1, s_hist, s_cand, s_misc);
@@ -1473,13 +1574,21 @@ __global__ __launch_bounds__(kLT) void fused_finish_kernel(const double *__restr
       const uint32_t n_outer = n - n_inner - n_band;
       if (n_inner) {
         const double x_in = fmax(__dsub_rn(T.Uin, median), __dsub_rn(median, T.Lin));
-        if (!(mad >= x_in)) ok = false;
+        if (!(mad >= x_in)) { ok = false; KPOP_WHY(5); }
       }
       if (n_outer) {
         const double x_out = fmin(__dsub_rn(median, T.Llo), __dsub_rn(T.Uhi, median));
-        if (!(mad <= x_out)) ok = false;
+        if (!(mad <= x_out)) { ok = false; KPOP_WHY(6); }
       }
     }
+  }
+  KPOP_STAMP(6);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+#ifdef KPOP_SUMMARY_STAMPS
+    g_sum_stamps[8] = n_c;
+    g_sum_stamps[9] = cnt[jl].n_nb;
+    g_sum_stamps[10] = nmed;
+#endif
   }
   if (threadIdx.x == 0) {
     if (!ok) {
@@ -1515,8 +1624,9 @@ struct FusedScratch {
   uint32_t *ccand_i;
   uint32_t *n_failed;
 };
-static uint64_t carve_fused(void *scratch, uint32_t n_rows, uint32_t r1, FusedScratch *F) {
-  const uint64_t n_stripes = (r1 + kStripe - 1) / kStripe;
+static uint64_t carve_fused(void *scratch, uint32_t n_rows, uint32_t r1, FusedScratch *F, uint32_t stripe = kStripe) {
+  // records a row: one a stripe, or -- the matrix-core kernel, stripe = kStripe / 4 -- FOUR to every stripe of kStripe, the last one too
+  const uint64_t n_stripes = stripe == kStripe ? (r1 + kStripe - 1) / kStripe : (uint64_t)(kStripe / stripe) * ((r1 + kStripe - 1) / kStripe);
   char *p0 = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(scratch) + 255) & ~(uintptr_t)255), *p = p0;
   auto take = [&](uint64_t bytes) {
     char *at = p;
@@ -1539,6 +1649,10 @@ static uint64_t carve_fused(void *scratch, uint32_t n_rows, uint32_t r1, FusedSc
 uint64_t summary_fused_scratch_bytes(uint32_t n_rows, uint32_t r1) {
   FusedScratch F;
   return carve_fused(nullptr, n_rows, r1, &F);
+}
+uint64_t summary_select_scratch_bytes(uint32_t n_rows, uint32_t r1) {
+  FusedScratch F;
+  return carve_fused(nullptr, n_rows, r1, &F, kStripe / 4);
 }
 
 int launch_sample_gather(const double *a, uint32_t r1, uint32_t n_dims, uint32_t s, double *out, hipStream_t st) {
@@ -1587,23 +1701,25 @@ int launch_summary_fused_mfma(int kind, const double *a, uint32_t r1, uint32_t n
                               double *out_z, double *seg, uint32_t *seg_i, void *scratch, const void *mscratch, uint32_t q_room, hipStream_t st,
                               SummaryLists *lists) {
   const uint32_t req_len = keep_at_most ? keep_at_most : r1;
-  const uint32_t n_stripes = (r1 + kStripe - 1) / kStripe;
+  const uint32_t n_stripes = (r1 + kStripe - 1) / kStripe;  // blocks of the matrix-core kernel along the reference rows; it keeps FOUR records a stripe
   FusedScratch F;
-  carve_fused(scratch, n_rows, r1, &F);
+  carve_fused(scratch, n_rows, r1, &F, kStripe / 4);
   KPOP_HIP(hipMemsetAsync(F.n_failed, 0, 256, st));
+  // (a last stripe that is not whole leaves some of its four records unwritten -- a lane whose 512 slots lie past the end still writes
+  // its record, of zeros: every record of a row is written, see the kernel)
   fused_sample_kernel<false><<<dim3(n_rows), dim3(kLT), 0, st>>>(srow, s, r1, req_len, F.info, F.cnt, F.thr);
   KPOP_LAUNCH_CHECK();
   KPOP_TRY(launch_select_mfma(kind, a, r1, n_rows, n_dims, mscratch, q_room, F.thr, seg, seg_i, F.rec, F.part, F.cnt, F.nb_idx, F.nb_d, n_stripes, st));
-  fused_finish_kernel<true><<<dim3(n_rows), dim3(kLT), 0, st>>>(seg, r1, row0, req_len, max_neighbours, F.info, F.thr, F.cnt, F.rec, F.part, n_stripes, F.pre,
+  fused_finish_kernel<true><<<dim3(n_rows), dim3(kLT), 0, st>>>(seg, r1, row0, req_len, max_neighbours, F.info, F.thr, F.cnt, F.rec, F.part, 4 * n_stripes, F.pre,
                                                           F.ccand, fused_cand_cap(r1), F.nb_idx, F.nb_d, F.n_failed, out_stats, out_n, out_idx, out_dist,
-                                                          out_z, seg_i, F.ccand_i);
+                                                          out_z, seg_i, F.ccand_i, kStripe / 4, (uint64_t)n_stripes * kStripe);
   KPOP_LAUNCH_CHECK();
   *lists = SummaryLists{F.info, F.thr, F.cnt, F.ccand, F.ccand_i, fused_cand_cap(r1), F.nb_idx, F.nb_d};
   return 0;
 }
 bool summary_select_mfma_applies(uint32_t r1, uint32_t keep_at_most) {
   const uint32_t req_len = keep_at_most ? keep_at_most : r1;
-  return req_len <= kLargeMaxNb && r1 >= 4 * kSlice && (r1 + kStripe - 1) / kStripe <= kMaxStripes;
+  return req_len <= kLargeMaxNb && r1 >= 4 * kSlice && 4 * ((r1 + kStripe - 1) / kStripe) <= kMaxStripes;  // (four records a stripe)
 }
 
 // the rows the fused path flagged, from distance rows computed meanwhile (gated the same way: nothing runs when none failed)
@@ -1700,3 +1816,10 @@ int launch_summary_large(const double *rows, uint32_t n_rows, uint32_t r1, uint3
 }
 
 }  // namespace kpop
+
+#ifdef KPOP_SUMMARY_STAMPS
+extern "C" int kpop_debug_summary_stamps(unsigned long long *out) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(kpop::g_sum_stamps), 32 * 8) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -645,10 +645,18 @@ def test_distance_summary_on_the_matrix_cores(kpop, oracle, case, kind, d):
             res = {}
             # 3: the summary's pass inside the contraction, no distance row written (kpop_tune("summary_mfma", 2); up to 128 dimensions, beyond: as 1);
             # 1: the default, approximate rows then the pass over them; 2: ... its refinement scanning the rows instead of reading the lists
+            api.tune("summary_audit", 1)
+            api.summary_fallbacks()
             for mode in (3, 1, 2, 0):
                 api.tune("summary_mfma", {3: 2, 1: 1, 2: 1, 0: 0}[mode])
                 api.tune("summary_mfma_lists", 0 if mode == 2 else 1)
                 res[mode] = kpop.distance_summary(m1, m2, metric, kind, 2.0, normalize, keep, max_neighbours=512)
+                left = api.summary_fallbacks()
+                # rows left to the exact fall-back change no result and cost milliseconds: on plain data there must be none (a fall-back
+                # that ran hid a record-count mismatch of the in-contraction pass for a while: the results were right, the call three times slower)
+                if case in ("random", "classes") and mode != 0:
+                    assert left == 0, (case, mode, keep, left)
+            api.tune("summary_audit", 0)
             api.tune("summary_mfma", 1)
             api.tune("summary_mfma_lists", 1)
             for a_, b_ in zip(res[1], res[2]):
@@ -753,3 +761,48 @@ def test_distance_summary_on_the_matrix_cores_in_several_chunks(kpop, oracle):
         assert a[2][j, :hi - lo].tolist() == idx_o[lo:hi].tolist() and np.array_equal(a[3][j, :hi - lo], dist_o[lo:hi])
         assert a[0][j, 2] == st_o[t, 2] and a[0][j, 3] == st_o[t, 3]
     assert a[3][15999, 0] == 0.0 and a[2][15999, 0] == 70000
+
+
+@pytest.mark.parametrize("kind,d,r2", [(0, 24, 640), (1, 64, 515), (0, 200, 600)])
+def test_distance_summary_on_the_matrix_cores_many_query_rows(kpop, oracle, kind, d, r2):
+    """Hundreds of query rows against 70,001 (whole tiles of query rows in the matrix-core kernels; 512 and more: the two-stream form under
+    kpop_tune("summary_lanes", 2)): the default, the pass inside the contraction, two lanes and the vector pipe agree bit for bit on
+    medians, MADs and neighbours, no row goes to the fall-back, a handful of rows against the oracle"""
+    from kpop_amd import api
+    rng = np.random.RandomState(d + r2)
+    r1 = 70001
+    m1 = rng.normal(size=(r1, d))
+    m2 = rng.normal(size=(r2, d))
+    m2[::7] = m1[rng.randint(0, r1, size=len(m2[::7]))]  # (a copy of a reference row every seventh: a zero distance each)
+    metric = oracle.metric_powers(oracle.synth_inertia(d))
+    res = {}
+    api.tune("summary_audit", 1)
+    api.summary_fallbacks()
+    for name, mfma, lanes in (("default", 1, 1), ("select", 2, 1), ("lanes", 1, 2), ("vector", 0, 1)):
+        api.tune("summary_mfma", mfma)
+        api.tune("summary_lanes", lanes)
+        res[name] = kpop.distance_summary(m1, m2, metric, kind, 2.0, True, 20, max_neighbours=32)
+        left = api.summary_fallbacks()
+        assert left == 0, (name, left)
+    api.tune("summary_audit", 0)
+    api.tune("summary_mfma", 1)
+    api.tune("summary_lanes", 1)
+    ref = res["vector"]
+    for name in ("default", "select", "lanes"):
+        got = res[name]
+        assert np.array_equal(got[0][:, 2:], ref[0][:, 2:]), name
+        np.testing.assert_allclose(got[0][:, :2], ref[0][:, :2], rtol=1e-10)
+        assert np.array_equal(got[1], ref[1]), name
+        keep = np.arange(32)[None, :] < np.minimum(got[1], 32)[:, None]
+        assert np.array_equal(got[2][keep], ref[2][keep]) and np.array_equal(got[3][keep], ref[3][keep]), name
+    for a_, b_ in zip(res["lanes"], res["default"]):
+        assert np.array_equal(a_, b_, equal_nan=True)  # (the lanes change nothing at all)
+    pick = [0, 1, 7, 255, 256, r2 - 1]
+    st_o, offs, idx_o, dist_o, z_o = oracle.distance_summary(m1, m2[pick], metric, kind, 2.0, True, 20)
+    for t, j in enumerate(pick):
+        lo, hi = int(offs[t]), int(offs[t + 1])
+        got = res["default"]
+        assert got[1][j] == hi - lo
+        assert got[2][j, :hi - lo].tolist() == idx_o[lo:hi].tolist() and np.array_equal(got[3][j, :hi - lo], dist_o[lo:hi])
+        assert got[0][j, 2] == st_o[t, 2] and got[0][j, 3] == st_o[t, 3]
+

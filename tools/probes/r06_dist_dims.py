@@ -24,6 +24,10 @@ def main():
     g = torch.Generator(device=dev)
     g.manual_seed(1)
 
+    for kv in [x for x in os.environ.get("R06_TUNE", "").split(",") if x]:  # e.g. R06_TUNE=summary_lanes=1
+        key, val = kv.split("=")
+        api.tune(key, int(val))
+
     def timed(fn, reps=3):
         fn()
         torch.cuda.synchronize()
