@@ -1302,7 +1302,7 @@ static int rowwise_impl(const double *m1, uint32_t r1, const double *m2, uint32_
 // summary_large.hip
 int launch_summary_large(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most,
                          uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
-                         double *out_dist, double *out_z, hipStream_t st, void *scratch, SummaryLists *lists = nullptr);
+                         double *out_dist, double *out_z, hipStream_t st, void *scratch, SummaryLists *lists = nullptr, bool plain_rows = false);
 uint64_t summary_large_scratch_bytes(uint32_t n_rows, uint32_t r1);
 bool summary_fused_applies(uint32_t r1, uint32_t keep_at_most);
 uint32_t summary_fused_sample_rows(uint32_t r1);
@@ -1418,7 +1418,7 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
           if (bi > 0) KPOP_HIP(hipStreamWaitEvent(L.s, aux->step[(bi - 1) & 1u], 0));  // this batch's contraction after the one before it
           KPOP_TRY(launch_distance_rows_mfma(KIND, a, r1, bq, q, n_dims, metric, L.rows, L.mscratch, chunk, L.s));
           KPOP_HIP(hipEventRecord(aux->step[bi & 1u], L.s));
-          KPOP_TRY(launch_summary_large(L.rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, L.s, L.scratch, &lists));
+          KPOP_TRY(launch_summary_large(L.rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, L.s, L.scratch, &lists, true));
           KPOP_TRY(launch_summary_refine(KIND, L.rows, a, r1, bq, q, n_dims, metric, p, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z,
                                          L.mscratch, chunk, L.s, lists, &gate, &flags));
           KPOP_TRY(audit_fallback(gate, L.s));
@@ -1471,7 +1471,7 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
         KPOP_TRY(audit_fallback(gate, st));
       } else {
         KPOP_TRY(launch_distance_rows_mfma(KIND, a, r1, bq, q, n_dims, metric, rows, mscratch, chunk, st));
-        KPOP_TRY(launch_summary_large(rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st, scratch, &lists));
+        KPOP_TRY(launch_summary_large(rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st, scratch, &lists, true));
         KPOP_TRY(launch_summary_refine(KIND, rows, a, r1, bq, q, n_dims, metric, p, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist,
                                        out_z, mscratch, chunk, st, lists, &gate, &flags));
         KPOP_TRY(audit_fallback(gate, st));

@@ -1353,6 +1353,145 @@ __global__ __launch_bounds__(256) void summary1_pass_kernel(const double *__rest
   }
 }
 
+// The same pass for rows the library made itself (the matrix-core path's approximate rows: no negative zero, no key needed) -- every
+// distance through seven comparisons against the row's thresholds as DOUBLES (the counts of d < lo, d <= lo, d < hi, d <= hi and of the
+// inner region: what lies below, at and inside the median's bracket are differences of these), and the candidates of a whole turn
+// (eight elements a lane) appended to the block's stage with ONE LDS atomic a wavefront: twelve elements in a hundred are candidates,
+// so every wavefront appends at every element, and an atomic round trip each was most of what the pass above spends (2.7 ms per
+// 1,024 x 1M at 3.1 TB/s; this one is bound by the read).  Same counts, same candidate and neighbour sets as the pass above.
+__global__ __launch_bounds__(256) void summary1_pass_plain_kernel(const double *__restrict__ rows, uint32_t r1, const FusedThr *__restrict__ thr,
+                                                                  RowCounts *__restrict__ cnt, double *__restrict__ cand, uint32_t *__restrict__ cand_i,
+                                                                  uint32_t *__restrict__ nb_idx, double *__restrict__ nb_d, double *__restrict__ part,
+                                                                  uint32_t n_slices, uint32_t kCandCap) {
+  __shared__ uint32_t s_c[8];
+  __shared__ double s_p[2][4];
+  constexpr uint32_t kStage = 4096;
+  __shared__ uint32_t s_stage_i[kStage];
+  __shared__ uint32_t s_n, s_base;
+  const uint32_t j = blockIdx.y, sl = blockIdx.x;
+  const double *row = rows + (uint64_t)j * r1;
+  const FusedThr T = thr[j];
+  RowCounts *C = cnt + j;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t i0 = sl * kSlice, i1 = min(r1, i0 + kSlice);
+  double *my_cand = cand + (uint64_t)j * kCandCap;
+  uint32_t *my_cand_i = cand_i ? cand_i + (uint64_t)j * kCandCap : nullptr;
+  uint32_t c_lt = 0, c_le = 0, c_lth = 0, c_leh = 0, c_in = 0;
+  double sum = 0.0, sq = 0.0;
+  constexpr int U = 8;  // loads in flight per thread
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  auto flush = [&]() {  // all threads; s_n is stable (between barriers)
+    const uint32_t cnt_ = s_n;
+    if (threadIdx.x == 0) s_base = atomicAdd(&C->n_cand, cnt_);
+    __syncthreads();
+    const uint32_t b0 = s_base;
+    for (uint32_t q0 = threadIdx.x; q0 < cnt_; q0 += 256 * 8) {  // (eight of the gather's loads in flight a thread)
+      uint32_t ii[8];
+      double vv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        ii[u] = q0 + 256u * u < cnt_ ? s_stage_i[q0 + 256u * u] : i0;  // (past the end: a column of the slice, not stored)
+        vv[u] = row[ii[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t q = q0 + 256u * u;
+        if (q < cnt_ && b0 + q < kCandCap) {
+          my_cand[b0 + q] = vv[u];
+          if (my_cand_i) my_cand_i[b0 + q] = ii[u];
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+  };
+  const double nan = __longlong_as_double(0x7FF8000000000000ll);
+  for (uint32_t base = i0; base < i1; base += 256 * U) {
+    if (s_n > kStage - 256 * U) flush();  // (block-uniform: read between barriers) room for a whole turn of candidates
+    const bool whole = base + 256 * U <= i1;  // (uniform)
+    double dv8[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = base + u * 256 + threadIdx.x;
+      dv8[u] = (whole || i < i1) ? row[i] : nan;  // (a NaN is below, at and inside nothing)
+    }
+    uint64_t cmask[U];
+    uint32_t n_app = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double d = dv8[u];
+      const bool lt = d < T.lo, le = d <= T.lo, lth = d < T.hi, leh = d <= T.hi;
+      const bool in = d > T.Lin && d < T.Uin;
+      c_lt += lt ? 1u : 0u;
+      c_le += le ? 1u : 0u;
+      c_lth += lth ? 1u : 0u;
+      c_leh += leh ? 1u : 0u;
+      c_in += in ? 1u : 0u;
+      const bool valid = whole || d == d;
+      sum = __dadd_rn(sum, valid ? d : 0.0);
+      const double dvv = valid ? __dsub_rn(d, T.mhat) : 0.0;
+      sq = __dadd_rn(sq, __dmul_rn(dvv, dvv));
+      cmask[u] = __ballot((!le && lth) || (!in && d >= T.Llo && d <= T.Uhi));
+      n_app += (uint32_t)__popcll(cmask[u]);
+      if (__ballot(d <= T.cut)) {  // (one element in a thousand)
+        const bool is_nb = d <= T.cut;
+        const uint32_t at = wave_append(is_nb, &C->n_nb, lane);
+        if (is_nb && at < kNbCap) {
+          nb_idx[(uint64_t)j * kNbCap + at] = base + u * 256 + threadIdx.x;
+          nb_d[(uint64_t)j * kNbCap + at] = d;
+        }
+      }
+    }
+    if (n_app) {  // (wavefront-uniform) the turn's candidates: one atomic, then every lane's columns at its places
+      uint32_t at0 = 0;
+      if (lane == 0) at0 = atomicAdd(&s_n, n_app);
+      at0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at0);
+      const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if ((cmask[u] >> lane) & 1ull) s_stage_i[at0 + (uint32_t)__popcll(cmask[u] & below)] = base + u * 256 + threadIdx.x;
+        at0 += (uint32_t)__popcll(cmask[u]);
+      }
+    }
+    __syncthreads();  // s_n is read at the top of the next turn
+  }
+  if (s_n) flush();
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    c_lt += __shfl_xor((int)c_lt, o, 64);
+    c_le += __shfl_xor((int)c_le, o, 64);
+    c_lth += __shfl_xor((int)c_lth, o, 64);
+    c_leh += __shfl_xor((int)c_leh, o, 64);
+    c_in += __shfl_xor((int)c_in, o, 64);
+    sum = __dadd_rn(sum, __shfl_xor(sum, o, 64));
+    sq = __dadd_rn(sq, __shfl_xor(sq, o, 64));
+  }
+  if (threadIdx.x < 8) s_c[threadIdx.x] = 0;
+  __syncthreads();
+  if (lane == 0) {
+    const uint32_t eqlo = c_le - c_lt, nmed = T.lo < T.hi ? c_lth - c_le : 0u, eqhi = T.hi != T.lo ? c_leh - c_lth : 0u;
+    if (c_lt) atomicAdd(&s_c[0], c_lt);
+    if (eqlo) atomicAdd(&s_c[1], eqlo);
+    if (eqhi) atomicAdd(&s_c[2], eqhi);
+    if (nmed) atomicAdd(&s_c[3], nmed);
+    if (c_in) atomicAdd(&s_c[4], c_in);
+    s_p[0][wv] = sum;
+    s_p[1][wv] = sq;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_c[0]) atomicAdd(&C->lt_lo, s_c[0]);
+    if (s_c[1]) atomicAdd(&C->eq_lo, s_c[1]);
+    if (s_c[2]) atomicAdd(&C->eq_hi, s_c[2]);
+    if (s_c[3]) atomicAdd(&C->m_lt, s_c[3]);
+    if (s_c[4]) atomicAdd(&C->m_eqlo, s_c[4]);
+    part[((uint64_t)j * n_slices + sl) * 2 + 0] = __dadd_rn(__dadd_rn(__dadd_rn(s_p[0][0], s_p[0][1]), s_p[0][2]), s_p[0][3]);
+    part[((uint64_t)j * n_slices + sl) * 2 + 1] = __dadd_rn(__dadd_rn(__dadd_rn(s_p[1][0], s_p[1][1]), s_p[1][2]), s_p[1][3]);
+  }
+}
+
 struct BandRow {  // the candidates of the MAD among a row's compacted list: NaN for the others (its key is beyond every range)
   const double *p;
   double Llo, Lin, Uin, Uhi;
@@ -1756,7 +1895,7 @@ uint64_t summary_large_scratch_bytes(uint32_t n_rows, uint32_t r1) {
 // rows (brackets and bands from a sample, certificate for the MAD); 3: two passes (the first version of round 3).
 int launch_summary_large(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most,
                          uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
-                         double *out_dist, double *out_z, hipStream_t st, void *scratch, SummaryLists *lists) {
+                         double *out_dist, double *out_z, hipStream_t st, void *scratch, SummaryLists *lists, bool plain_rows) {
   if (lists) *lists = SummaryLists{};
   const uint32_t req_len = keep_at_most ? keep_at_most : r1;
   const bool by_brackets = scratch && ctx().tune_summary2 && req_len <= kLargeMaxNb && r1 >= 2 * kSlice;
@@ -1791,7 +1930,11 @@ int launch_summary_large(const double *rows, uint32_t n_rows, uint32_t r1, uint3
     KPOP_HIP(hipMemsetAsync(n_failed, 0, 256, st));
     fused_sample_kernel<true><<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, 0, r1, req_len, info, cnt, thr);
     KPOP_LAUNCH_CHECK();
-    summary1_pass_kernel<<<dim3(n_slices, n_rows), dim3(256), 0, st>>>(rows, r1, info, thr, cnt, cand, cand_i, nb_idx, nb_d, part, n_slices, cap);
+    // (plain_rows: the caller made the rows itself -- distances >= +0.0 -- and they need no keys; kpop_tune("summary_pass", 0): the general pass anyway)
+    if (plain_rows && ctx().tune_summary_pass)
+      summary1_pass_plain_kernel<<<dim3(n_slices, n_rows), dim3(256), 0, st>>>(rows, r1, thr, cnt, cand, cand_i, nb_idx, nb_d, part, n_slices, cap);
+    else
+      summary1_pass_kernel<<<dim3(n_slices, n_rows), dim3(256), 0, st>>>(rows, r1, info, thr, cnt, cand, cand_i, nb_idx, nb_d, part, n_slices, cap);
     KPOP_LAUNCH_CHECK();
     fused_finish_kernel<false><<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, r1, row0, req_len, max_neighbours, info, thr, cnt, nullptr, part, n_slices, nullptr, cand,
                                                                    cap, nb_idx, nb_d, n_failed, out_stats, out_n, out_idx, out_dist, out_z);
