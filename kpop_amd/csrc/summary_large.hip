@@ -92,7 +92,8 @@ __device__ __forceinline__ uint64_t elem_key(const Row &row, uint32_t i, double 
 // Up to kSel ranks are served by the same passes (they share the row, not the bin).
 // ---------------------------------------------------------------------------
 constexpr uint32_t kBins = 2048, kCand = 2048;
-constexpr int kSel = 2;
+constexpr int kSel = 2;     // (what most callers' LDS tables hold)
+constexpr int kSelMax = 4;  // ... and the most a call may ask for, with tables of its own to match (the sample kernel: four ranks of one scan)
 constexpr int kSelLoads = 8;  // loads in flight a thread in the passes of a selection
 static_assert(kBins == 2 * kLT, "block_select_ranks: a thread owns two bins");
 
@@ -124,7 +125,7 @@ __device__ void block_select_ranks(const Row row, uint32_t n, double centre, Sel
     __syncthreads();
     for (uint32_t q = threadIdx.x; q < (uint32_t)n_sel * kBins; q += kLT) s_hist[q] = 0;
     __syncthreads();
-    int shift[kSel];
+    int shift[kSelMax];
     for (int t = 0; t < n_sel; ++t) shift[t] = range_shift(sel[t].lo, sel[t].hi);
     double sq = 0.0;
     for (uint32_t i0 = threadIdx.x; i0 < n; i0 += kLT * kSelLoads) {  // eight loads in flight a thread (a block a CU, a chain of round trips: four were 45k of a 65k-cycle pass over 120,000 candidates)
@@ -184,7 +185,7 @@ __device__ void block_select_ranks(const Row row, uint32_t n, double centre, Sel
       }
     }
     __syncthreads();
-    bool collect[kSel];
+    bool collect[kSelMax];
     for (int t = 0; t < n_sel; ++t) {
       collect[t] = false;
       if (sel[t].done) continue;
@@ -934,8 +935,8 @@ template <bool SAMPLED>
 __global__ __launch_bounds__(kLT) void fused_sample_kernel(const double *__restrict__ src, uint32_t s_plain, uint32_t r1, uint32_t req_len,
                                                            RowInfo *__restrict__ info, RowCounts *__restrict__ cnt, FusedThr *__restrict__ thr) {
   __shared__ double s_w[kLT / 64];
-  __shared__ uint32_t s_hist[kSel * kBins];
-  __shared__ uint64_t s_cand[kSel * kCand];
+  __shared__ uint32_t s_hist[kSelMax * kBins];  // (four selections share the first scans: 96 KB of tables)
+  __shared__ uint64_t s_cand[kSelMax * kCand];
   __shared__ uint32_t s_misc[64];
   __shared__ uint64_t s_mm[2 * (kLT / 64)];
   uint32_t stride = 0;
@@ -1029,15 +1030,15 @@ __global__ __launch_bounds__(kLT) void fused_sample_kernel(const double *__restr
   }
   KPOP_STAMP(18);
   auto from_low = [&](uint32_t rank, int done) { return rank >= n_out ? Sel{rank, klow, kmax, n_out, 0, 0, 0, done} : Sel{rank, kmin, kmax, 0, 0, 0, 0, done}; };
-  Sel sel[kSel] = {from_low(a, 0), from_low(b, 0)};
-  block_select_ranks<0, false, Row>(sr, s, 0.0, sel, 2, s_hist, s_cand, s_misc);
-  KPOP_STAMP(19);
-  // the sample's own median, and -- same passes -- the neighbour threshold
+  // the bracket's two ranks, the sample's own median and the neighbour threshold: four ranks of the same keys, ONE set of passes over the
+  // sample (they were two sets of two: every pass streams the sample from HBM again, 134 MB for 256 rows)
   uint64_t kcut = ~0ull;
   const double want = 3.0 * (double)req_len * (double)s / (double)r1 + 16.0;
   const bool cut = want < (double)(s - 1);
-  Sel sm[kSel] = {from_low(s / 2, 0), from_low(cut ? (uint32_t)want : 0u, cut ? 0 : 1)};
-  block_select_ranks<0, false, Row>(sr, s, 0.0, sm, 2, s_hist, s_cand, s_misc);
+  Sel s4[kSelMax] = {from_low(a, 0), from_low(b, 0), from_low(s / 2, 0), from_low(cut ? (uint32_t)want : 0u, cut ? 0 : 1)};
+  block_select_ranks<0, false, Row>(sr, s, 0.0, s4, 4, s_hist, s_cand, s_misc);
+  const Sel sel[2] = {s4[0], s4[1]}, sm[2] = {s4[2], s4[3]};
+  KPOP_STAMP(19);
   KPOP_STAMP(20);
   if (cut) kcut = sm[1].value;
   const double ms = key_f64(sm[0].value);
