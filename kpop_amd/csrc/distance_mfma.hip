@@ -416,7 +416,9 @@ template <int KIND, bool GUARD>
 __global__ __launch_bounds__(256, 2) void distance_gemm_mfma_kernel(const double *__restrict__ a, uint32_t r1, const double *__restrict__ bm, const double *__restrict__ b,
                                                                  uint32_t q, uint32_t n_dims, const double *__restrict__ metric, double p,
                                                                  const double *__restrict__ sa, const double *__restrict__ sb, double *__restrict__ out,
-                                                                 uint32_t tiles_m, uint32_t tiles_n, int m_fast, double tau) {
+                                                                 uint32_t tiles_m, uint32_t tiles_n, int m_fast, double tau, const double *__restrict__ a_plain) {
+  // (a, bm: the two panels' sources, ONE of them times the metric -- the caller's choice, the smaller one; a_plain, b: the operands as they
+  // are, for the pairs the guard recomputes)
   // two buffers a panel (74 KB a block in all, two blocks a CU): chunk c + 1 is written while chunk c is multiplied, ONE barrier a chunk
   extern __shared__ __attribute__((aligned(16))) double dg_lds[];
   double (*Qs)[kDK][kDS] = reinterpret_cast<double (*)[kDK][kDS]>(dg_lds);                       // [buffer][dimension][query row of the tile]
@@ -441,23 +443,48 @@ __global__ __launch_bounds__(256, 2) void distance_gemm_mfma_kernel(const double
   constexpr int kQ = kDK / 2;  // loads a thread, panel and chunk
   double rq[kQ], rr[kQ];
   const uint32_t kk = threadIdx.x & (kDK - 1), rbase = threadIdx.x / kDK;  // the thread's dimension of a chunk, its first row of a panel
-  // (unconditional loads from addresses clamped into the operands, what lies outside zeroed afterwards: predicated loads each wait for themselves)
+  // Where the thread's loads of a chunk come from: ELEMENT OFFSETS from the tile's first row (rows past the operand's end clamped to its
+  // last row, zeroed when they are put), the same for every chunk -- the chunk moves the wavefront-uniform base, so a load costs no
+  // address arithmetic of its own.  What is loaded is not looked at before it is put into LDS, AFTER the chunk's MFMAs: masking the
+  // registers right after the loads (the first version) made every chunk wait for its successor's loads before its first MFMA --
+  // 2.2 of 12.0 ms on 100,000 x 1,636 x 1,635.
+  uint32_t oq[kQ], orr[kQ];
+#pragma unroll
+  for (int u = 0; u < kQ; ++u) {
+    const uint32_t row = rbase + (256 / kDK) * u;
+    oq[u] = (min(m0 + row, q - 1u) - m0) * n_dims + kk;
+    orr[u] = (min(n0 + row, r1 - 1u) - n0) * n_dims + kk;
+  }
+  const double *qt = bm + (uint64_t)m0 * n_dims, *rt = a + (uint64_t)n0 * n_dims;  // (uniform)
+  const bool interior = m0 + kDT <= q && n0 + kDT <= r1;                           // (uniform) every row of both panels exists
   auto prefetch = [&](uint32_t k0) {
+    if (k0 + kDK <= n_dims) {  // (uniform) a whole chunk
+      const double *qk = qt + k0, *rk = rt + k0;
 #pragma unroll
-    for (int u = 0; u < kQ; ++u) {
-      const uint32_t row = rbase + (256 / kDK) * u, c = min(k0 + kk, n_dims - 1u);
-      rq[u] = bm[(uint64_t)min(m0 + row, q - 1u) * n_dims + c];
-      rr[u] = a[(uint64_t)min(n0 + row, r1 - 1u) * n_dims + c];
-    }
+      for (int u = 0; u < kQ; ++u) {
+        rq[u] = qk[oq[u]];
+        rr[u] = rk[orr[u]];
+      }
+    } else {  // the last, partial chunk: dimensions past the end read the row's last one (zeroed when they are put)
+      const uint32_t back = k0 + kk < n_dims ? 0u : k0 + kk - (n_dims - 1u);
+      const double *qk = qt + k0, *rk = rt + k0;
 #pragma unroll
-    for (int u = 0; u < kQ; ++u) {
-      const uint32_t row = rbase + (256 / kDK) * u;
-      const bool in = k0 + kk < n_dims;
-      rq[u] = (in && m0 + row < q) ? rq[u] : 0.0;
-      rr[u] = (in && n0 + row < r1) ? rr[u] : 0.0;
+      for (int u = 0; u < kQ; ++u) {
+        rq[u] = qk[oq[u] - back];
+        rr[u] = rk[orr[u] - back];
+      }
     }
   };
-  auto put = [&](int buf) {
+  auto put = [&](int buf, uint32_t k0) {  // (k0: the chunk the registers hold)
+    if (!interior || k0 + kDK > n_dims) {  // (uniform) an edge: what lies outside the operands is zero
+      const bool in = k0 + kk < n_dims;
+#pragma unroll
+      for (int u = 0; u < kQ; ++u) {
+        const uint32_t row = rbase + (256 / kDK) * u;
+        rq[u] = (in && m0 + row < q) ? rq[u] : 0.0;
+        rr[u] = (in && n0 + row < r1) ? rr[u] : 0.0;
+      }
+    }
 #pragma unroll
     for (int u = 0; u < kQ; ++u) {
       Qs[buf][kk][rbase + (256 / kDK) * u] = rq[u];
@@ -465,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void distance_gemm_mfma_kernel(const double
     }
   };
   prefetch(0);
-  put(0);
+  put(0, 0);
   __syncthreads();
   for (uint32_t k0 = 0, c = 0; k0 < n_dims; k0 += kDK, ++c) {
     const int buf = (int)(c & 1u);
@@ -485,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void distance_gemm_mfma_kernel(const double
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (more) put(buf ^ 1);  // (its readers passed the barrier that ended the chunk before)
+    if (more) put(buf ^ 1, k0 + kDK);  // (its readers passed the barrier that ended the chunk before)
     __syncthreads();
   }
   // lane holds query rows (l >> 4) + 4 r of accumulator tile i, reference row l & 15 of tile j
@@ -504,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void distance_gemm_mfma_kernel(const double
           u = u > 0.0 ? u : 0.0;
           double d;
           if (GUARD && u < tau * (sai + sbj))
-            d = exact_pair_rows<KIND>(a + (uint64_t)col * n_dims, b + (uint64_t)row * n_dims, metric, n_dims, p);
+            d = exact_pair_rows<KIND>(a_plain + (uint64_t)col * n_dims, b + (uint64_t)row * n_dims, metric, n_dims, p);
           else
             d = KIND == KPOP_EUCLIDEAN ? sqrt_fast(u) : u * 0.5;  // (an ulp or two: far inside what the contraction itself leaves)
           out[(uint64_t)row * r1 + col] = d;
@@ -846,20 +873,21 @@ bool summary_mfma_applies(int kind, uint32_t r1, uint32_t n_dims, uint32_t keep_
          req_len <= max_neighbours && max_neighbours <= 2048;
 }
 // room for: the query rows times the metric, the two sets of norms, the largest of them, the fall-back's flags and its count
-uint64_t summary_mfma_scratch_bytes(uint32_t q, uint32_t r1, uint32_t n_dims) {
-  return (((uint64_t)q * n_dims * 8 + 255) & ~255ull) + (((uint64_t)r1 * 8 + 255) & ~255ull) + (((uint64_t)q * 8 + 255) & ~255ull) + 256 +
+static uint64_t mfma_scratch_bytes(uint32_t q, uint32_t r1, uint32_t n_dims, uint32_t bm_rows) {
+  return (((uint64_t)bm_rows * n_dims * 8 + 255) & ~255ull) + (((uint64_t)r1 * 8 + 255) & ~255ull) + (((uint64_t)q * 8 + 255) & ~255ull) + 256 +
          (((uint64_t)q * kRowCountsWords * 4 + 255) & ~255ull) + 256;
 }
+uint64_t summary_mfma_scratch_bytes(uint32_t q, uint32_t r1, uint32_t n_dims) { return mfma_scratch_bytes(q, r1, n_dims, q); }
 struct MfmaScratch {
   double *bm, *sa, *sb;
   unsigned long long *smax;
   uint32_t *rc, *n_failed;
 };
-static MfmaScratch carve_mfma(void *scratch, uint32_t q, uint32_t r1, uint32_t n_dims) {
+static MfmaScratch carve_mfma(void *scratch, uint32_t q, uint32_t r1, uint32_t n_dims, uint32_t bm_rows = 0) {  // (bm_rows: rows of the copy times the metric, q unless said)
   char *p = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(scratch) + 255) & ~(uintptr_t)255);
   MfmaScratch M;
   M.bm = reinterpret_cast<double *>(p);
-  p += ((uint64_t)q * n_dims * 8 + 255) & ~255ull;
+  p += ((uint64_t)(bm_rows ? bm_rows : q) * n_dims * 8 + 255) & ~255ull;
   M.sa = reinterpret_cast<double *>(p);
   p += ((uint64_t)r1 * 8 + 255) & ~255ull;
   M.sb = reinterpret_cast<double *>(p);
@@ -911,7 +939,7 @@ static int launch_rows_mfma(const double *a, uint32_t r1, const double *b, uint3
     const uint32_t tiles_m = div_up(q, (uint32_t)kDT), tiles_n = div_up(r1, (uint32_t)kDT);
     KPOP_TRY(distance_gemm_lds_attr());
     distance_gemm_mfma_kernel<KIND, false><<<dim3(tiles_m * tiles_n), dim3(256), kDgLds, st>>>(a, r1, M.bm, b, q, n_dims, metric, 2.0, M.sa, M.sb, rows, tiles_m, tiles_n,
-                                                                                                tiles_m <= 16 ? 1 : 0, 0.0);
+                                                                                                tiles_m <= 16 ? 1 : 0, 0.0, a);
     KPOP_LAUNCH_CHECK();
     return 0;
   }
@@ -941,21 +969,26 @@ double distance_mfma_tau(uint32_t n_dims) { return std::min(0.5, std::max(1.0 / 
 int launch_distance_rowwise_mfma(int kind, const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims, const double *metric, double p, double *out,
                                  hipStream_t st) {
   void *ws = nullptr;
-  KPOP_TRY(ctx().ws_for(st).ensure(summary_mfma_scratch_bytes(r2, r1, n_dims) + 512, &ws));
-  const MfmaScratch M = carve_mfma(ws, r2, r1, n_dims);
-  row_sumsq_kernel<<<dim3(std::min(div_up(r1, 16), 4096u)), dim3(256), 0, st>>>(a, r1, n_dims, metric, M.sa, nullptr, nullptr);
+  const uint32_t bm_rows = std::min(r1, r2);
+  KPOP_TRY(ctx().ws_for(st).ensure(mfma_scratch_bytes(r2, r1, n_dims, bm_rows) + 512, &ws));
+  const MfmaScratch M = carve_mfma(ws, r2, r1, n_dims, bm_rows);
+  // the metric goes onto the SMALLER operand (its copy times the metric is what the panels of that side are loaded from: 21 MB for 1,636
+  // classes where the copy of 100,000 samples was 1.3 GB written and read back -- half a millisecond of 11)
+  const bool scale_a = r1 <= r2;
+  row_sumsq_kernel<<<dim3(std::min(div_up(r1, 16), 4096u)), dim3(256), 0, st>>>(a, r1, n_dims, metric, M.sa, scale_a ? M.bm : nullptr, nullptr);
   KPOP_LAUNCH_CHECK();
-  row_sumsq_kernel<<<dim3(std::min(div_up(r2, 16), 4096u)), dim3(256), 0, st>>>(b, r2, n_dims, metric, M.sb, M.bm, nullptr);
+  row_sumsq_kernel<<<dim3(std::min(div_up(r2, 16), 4096u)), dim3(256), 0, st>>>(b, r2, n_dims, metric, M.sb, scale_a ? nullptr : M.bm, nullptr);
   KPOP_LAUNCH_CHECK();
+  const double *pa = scale_a ? M.bm : a, *pb = scale_a ? b : M.bm;  // the panels' sources
   const uint32_t tiles_m = div_up(r2, (uint32_t)kDT), tiles_n = div_up(r1, (uint32_t)kDT);
   if ((uint64_t)tiles_m * tiles_n >= (1ull << 31)) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "distance_rowwise: %u x %u tiles", tiles_m, tiles_n);
   const double tau = distance_mfma_tau(n_dims);
   const int m_fast = tiles_m <= tiles_n ? 1 : 0;  // (the shorter side fastest: its panel stays in the L2s)
   KPOP_TRY(distance_gemm_lds_attr());
   if (kind == KPOP_EUCLIDEAN)
-    distance_gemm_mfma_kernel<KPOP_EUCLIDEAN, true><<<dim3(tiles_m * tiles_n), dim3(256), kDgLds, st>>>(a, r1, M.bm, b, r2, n_dims, metric, p, M.sa, M.sb, out, tiles_m, tiles_n, m_fast, tau);
+    distance_gemm_mfma_kernel<KPOP_EUCLIDEAN, true><<<dim3(tiles_m * tiles_n), dim3(256), kDgLds, st>>>(pa, r1, pb, b, r2, n_dims, metric, p, M.sa, M.sb, out, tiles_m, tiles_n, m_fast, tau, a);
   else
-    distance_gemm_mfma_kernel<KPOP_COSINE, true><<<dim3(tiles_m * tiles_n), dim3(256), kDgLds, st>>>(a, r1, M.bm, b, r2, n_dims, metric, p, M.sa, M.sb, out, tiles_m, tiles_n, m_fast, tau);
+    distance_gemm_mfma_kernel<KPOP_COSINE, true><<<dim3(tiles_m * tiles_n), dim3(256), kDgLds, st>>>(pa, r1, pb, b, r2, n_dims, metric, p, M.sa, M.sb, out, tiles_m, tiles_n, m_fast, tau, a);
   KPOP_LAUNCH_CHECK();
   return 0;
 }
