@@ -79,7 +79,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_kernel(const double *__r
         rb[q] = B[min(k0 + kb, k_end - 1) * ldb + min(n0 + nn, N - 1)];
       }
     }
-    if (!TRANS_A) {
+  };
+  if (k_begin < k_end) prefetch(k_begin);
+  for (uint64_t k0 = k_begin; k0 < k_end; k0 += kGK) {
+    __syncthreads();
+    // (S W: what lies outside the operands is zeroed HERE, when the chunk is stored -- not right after its loads, which is before the
+    // MFMAs of the chunk in front of it in program order and made them wait for these loads: distance_mfma.hip, profiles/r06_gemm_loads.txt)
+    if (!TRANS_A && (k0 + kGK > k_end || m0 + kGT > M || n0 + kGT > N)) {  // (uniform) an edge
 #pragma unroll
       for (int q = 0; q < kQ; ++q) {
         const uint32_t kk = threadIdx.x & (kGK - 1), mm = threadIdx.x / kGK + (256 / kGK) * q;
@@ -88,10 +94,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_kernel(const double *__r
         rb[q] = (k0 + kb < k_end && n0 + nn < N) ? rb[q] : 0.0;
       }
     }
-  };
-  if (k_begin < k_end) prefetch(k_begin);
-  for (uint64_t k0 = k_begin; k0 < k_end; k0 += kGK) {
-    __syncthreads();
 #pragma unroll
     for (int q = 0; q < kQ; ++q) {
       if (TRANS_A) As[(threadIdx.x >> 7) + 2 * q][threadIdx.x & 127] = ra[q];
