@@ -409,8 +409,12 @@ __device__ __forceinline__ double exact_pair_rows(const double *__restrict__ aro
 // common to cancellation -- a pair whose d^2~ is below `tau` of |a|^2 + |b|^2 is recomputed with the reference's chain, dimension by
 // dimension (lib/Space.ml:182-205), the others are within (D + 3) 2^-53 / (4 tau) of it, relatively (1.8e-12 at 1,635 dimensions,
 // tau = 0.025; measured: a few 1e-14).  Without it (the summary's rows) the values only LOCATE: see the head of the file.
-constexpr int kDT = 128, kDK = 16, kDS = kDT + 17;
-constexpr size_t kDgLds = (size_t)4 * kDK * kDS * 8;  // two buffers x two panels  // tile edge, dimensions a chunk, LDS row stride in doubles (odd: the transposed staging's writes spread over the banks)
+// tile edge; dimensions a chunk; rows' stride in the LDS panels, in PAIRS of dimensions: a panel is [pair of dimensions][row][2] -- a thread
+// loads two neighbouring dimensions of a row at once (16 bytes) and stores them with one ds_write_b128; 130 = 2 mod 16 spreads the
+// sixteen lanes of a quarter-wavefront (8 pairs x 2 rows) over all the banks, and a fragment read (16 rows x 2 dimensions of a pair)
+// covers them exactly
+constexpr int kDT = 128, kDK = 16, kDS = kDT + 2;
+constexpr size_t kDgLds = (size_t)4 * (kDK / 2) * kDS * 16;  // two buffers x two panels
 
 template <int KIND, bool GUARD>
 __global__ __launch_bounds__(256, 2) void distance_gemm_mfma_kernel(const double *__restrict__ a, uint32_t r1, const double *__restrict__ bm, const double *__restrict__ b,
@@ -421,8 +425,9 @@ __global__ __launch_bounds__(256, 2) void distance_gemm_mfma_kernel(const double
   // are, for the pairs the guard recomputes)
   // two buffers a panel (74 KB a block in all, two blocks a CU): chunk c + 1 is written while chunk c is multiplied, ONE barrier a chunk
   extern __shared__ __attribute__((aligned(16))) double dg_lds[];
-  double (*Qs)[kDK][kDS] = reinterpret_cast<double (*)[kDK][kDS]>(dg_lds);                       // [buffer][dimension][query row of the tile]
-  double (*Rs)[kDK][kDS] = reinterpret_cast<double (*)[kDK][kDS]>(dg_lds + 2 * kDK * kDS);       // [buffer][dimension][reference row of the tile]
+  using Panel = double[kDK / 2][kDS][2];
+  Panel *Qs = reinterpret_cast<Panel *>(dg_lds);                              // [buffer][pair of dimensions][query row of the tile][2]
+  Panel *Rs = reinterpret_cast<Panel *>(dg_lds + 2 * (kDK / 2) * kDS * 2);   // [buffer][pair of dimensions][reference row of the tile][2]
   // Workgroups are dealt to the eight XCDs in turn; the blocks of one XCD take a contiguous run of tiles, decoded with the short
   // side fastest: the tiles that share a panel are neighbours in time on ONE L2.
   uint32_t wgid = blockIdx.x;
@@ -440,9 +445,13 @@ __global__ __launch_bounds__(256, 2) void distance_gemm_mfma_kernel(const double
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f64x4m{0.0, 0.0, 0.0, 0.0};
-  constexpr int kQ = kDK / 2;  // loads a thread, panel and chunk
-  double rq[kQ], rr[kQ];
-  const uint32_t kk = threadIdx.x & (kDK - 1), rbase = threadIdx.x / kDK;  // the thread's dimension of a chunk, its first row of a panel
+  constexpr int kQ = kDK / 4;  // 16-byte loads a thread, panel and chunk
+  struct __attribute__((aligned(8))) D2 {
+    double x, y;
+  };
+  D2 rq[kQ], rr[kQ];
+  const uint32_t kp = threadIdx.x & (kDK / 2 - 1), rbase = threadIdx.x / (kDK / 2);  // the thread's pair of dimensions of a chunk, its first row of a panel
+  constexpr uint32_t kRows = 256 / (kDK / 2);                                      // rows between two of its loads
   // Where the thread's loads of a chunk come from: ELEMENT OFFSETS from the tile's first row (rows past the operand's end clamped to its
   // last row, zeroed when they are put), the same for every chunk -- the chunk moves the wavefront-uniform base, so a load costs no
   // address arithmetic of its own.  What is loaded is not looked at before it is put into LDS, AFTER the chunk's MFMAs: masking the
@@ -451,44 +460,49 @@ __global__ __launch_bounds__(256, 2) void distance_gemm_mfma_kernel(const double
   uint32_t oq[kQ], orr[kQ];
 #pragma unroll
   for (int u = 0; u < kQ; ++u) {
-    const uint32_t row = rbase + (256 / kDK) * u;
-    oq[u] = (min(m0 + row, q - 1u) - m0) * n_dims + kk;
-    orr[u] = (min(n0 + row, r1 - 1u) - n0) * n_dims + kk;
+    const uint32_t row = rbase + kRows * u;
+    oq[u] = (min(m0 + row, q - 1u) - m0) * n_dims + 2u * kp;
+    orr[u] = (min(n0 + row, r1 - 1u) - n0) * n_dims + 2u * kp;
   }
   const double *qt = bm + (uint64_t)m0 * n_dims, *rt = a + (uint64_t)n0 * n_dims;  // (uniform)
   const bool interior = m0 + kDT <= q && n0 + kDT <= r1;                           // (uniform) every row of both panels exists
   auto prefetch = [&](uint32_t k0) {
-    if (k0 + kDK <= n_dims) {  // (uniform) a whole chunk
-      const double *qk = qt + k0, *rk = rt + k0;
+    const double *qk = qt + k0, *rk = rt + k0;
+    if (k0 + kDK <= n_dims) {  // (uniform) a whole chunk: 16 bytes a load (rows are 8-byte aligned: the hardware does not ask for more)
 #pragma unroll
       for (int u = 0; u < kQ; ++u) {
-        rq[u] = qk[oq[u]];
-        rr[u] = rk[orr[u]];
+        rq[u] = *reinterpret_cast<const D2 *>(qk + oq[u]);
+        rr[u] = *reinterpret_cast<const D2 *>(rk + orr[u]);
       }
     } else {  // the last, partial chunk: dimensions past the end read the row's last one (zeroed when they are put)
-      const uint32_t back = k0 + kk < n_dims ? 0u : k0 + kk - (n_dims - 1u);
-      const double *qk = qt + k0, *rk = rt + k0;
+      const uint32_t c0 = k0 + 2u * kp, b0 = c0 < n_dims ? 0u : c0 - (n_dims - 1u), b1 = c0 + 1u < n_dims ? 0u : c0 + 1u - (n_dims - 1u);
 #pragma unroll
       for (int u = 0; u < kQ; ++u) {
-        rq[u] = qk[oq[u] - back];
-        rr[u] = rk[orr[u] - back];
+        rq[u].x = qk[oq[u] - b0];
+        rq[u].y = qk[oq[u] + 1u - b1];
+        rr[u].x = rk[orr[u] - b0];
+        rr[u].y = rk[orr[u] + 1u - b1];
       }
     }
   };
   auto put = [&](int buf, uint32_t k0) {  // (k0: the chunk the registers hold)
     if (!interior || k0 + kDK > n_dims) {  // (uniform) an edge: what lies outside the operands is zero
-      const bool in = k0 + kk < n_dims;
+      const bool in0 = k0 + 2u * kp < n_dims, in1 = k0 + 2u * kp + 1u < n_dims;
 #pragma unroll
       for (int u = 0; u < kQ; ++u) {
-        const uint32_t row = rbase + (256 / kDK) * u;
-        rq[u] = (in && m0 + row < q) ? rq[u] : 0.0;
-        rr[u] = (in && n0 + row < r1) ? rr[u] : 0.0;
+        const uint32_t row = rbase + kRows * u;
+        const bool qin = m0 + row < q, rin = n0 + row < r1;
+        rq[u].x = (in0 && qin) ? rq[u].x : 0.0;
+        rq[u].y = (in1 && qin) ? rq[u].y : 0.0;
+        rr[u].x = (in0 && rin) ? rr[u].x : 0.0;
+        rr[u].y = (in1 && rin) ? rr[u].y : 0.0;
       }
     }
 #pragma unroll
     for (int u = 0; u < kQ; ++u) {
-      Qs[buf][kk][rbase + (256 / kDK) * u] = rq[u];
-      Rs[buf][kk][rbase + (256 / kDK) * u] = rr[u];
+      double *dq = Qs[buf][kp][rbase + kRows * u], *dr = Rs[buf][kp][rbase + kRows * u];
+      *reinterpret_cast<double2 *>(dq) = double2{rq[u].x, rq[u].y};
+      *reinterpret_cast<double2 *>(dr) = double2{rr[u].x, rr[u].y};
     }
   };
   prefetch(0);
@@ -504,8 +518,8 @@ __global__ __launch_bounds__(256, 2) void distance_gemm_mfma_kernel(const double
       const int kr = ks + (lane >> 4), cc = lane & 15;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        fa[t] = Qs[buf][kr][wm + t * 16 + cc];
-        fb[t] = Rs[buf][kr][wn + t * 16 + cc];
+        fa[t] = Qs[buf][kr >> 1][wm + t * 16 + cc][kr & 1];
+        fb[t] = Rs[buf][kr >> 1][wn + t * 16 + cc][kr & 1];
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
