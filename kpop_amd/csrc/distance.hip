@@ -1241,7 +1241,7 @@ static int rowwise_block(const double *a, uint32_t r1, const double *b, uint32_t
 // distance_mfma.hip: every pair's distance as a tiled contraction on the f64 matrix cores
 bool distance_mfma_applies(int kind, uint32_t r1, uint32_t r2, uint32_t n_dims);
 int launch_distance_rowwise_mfma(int kind, const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims, const double *metric, double p, double *out,
-                                 hipStream_t st);
+                                 hipStream_t st, const double *n1, const double *n2);
 
 template <int KIND>
 static int rowwise_impl(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
@@ -1286,10 +1286,16 @@ static int rowwise_impl(const double *m1, uint32_t r1, const double *m2, uint32_
   // 10 x 100,000 x 9.  With more column tiles every tile divides the second operand's rows again (4,096^2: 5 % slower), so
   // larger first operands keep the copies.  (16384: always the copies, for A/B.)
   if (!normalize || r1 >= 128 || (ctx().tune_dbg & 16384)) {
+    // large jobs (the reference's own: 650 K samples x 1,636 classes x 1,635 dimensions, README.md:1054-1060) on the matrix cores: the rows'
+    // norms only -- the contraction takes the operands as they are and scales a dot product where it comes out (distance_mfma.hip)
+    if (distance_mfma_applies(KIND, r1, r2, n_dims)) {
+      if (!normalize) return launch_distance_rowwise_mfma(KIND, m1, r1, m2, r2, n_dims, metric, p, out, st, nullptr, nullptr);
+      DistWork w = carve(work, r1, r2, n_dims);
+      KPOP_TRY(launch_row_norms_pair<KIND>((r1 && !norms1) ? m1 : nullptr, r1, w.n1, nullptr, m2, r2, w.n2, nullptr, n_dims, metric, p, st));
+      return launch_distance_rowwise_mfma(KIND, m1, r1, m2, r2, n_dims, metric, p, out, st, norms1 ? norms1 : w.n1, w.n2);
+    }
     const double *a, *b;
     KPOP_TRY(prepare_operands<KIND>(m1, r1, m2, r2, n_dims, metric, p, normalize, work, &a, &b, st));
-    // large jobs (the reference's own: 650 K samples x 1,636 classes x 1,635 dimensions, README.md:1054-1060) on the matrix cores
-    if (distance_mfma_applies(KIND, r1, r2, n_dims)) return launch_distance_rowwise_mfma(KIND, a, r1, b, r2, n_dims, metric, p, out, st);
     return rowwise_block<KIND>(a, r1, b, r2, n_dims, metric, p, out, st);
   }
   // norms only; the rowwise kernel divides as it stages the rows

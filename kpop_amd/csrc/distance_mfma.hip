@@ -400,6 +400,19 @@ __device__ __forceinline__ double exact_pair_rows(const double *__restrict__ aro
   return scale_distance<KIND>(acc, p);
 }
 
+// ... of two rows that are still to be divided by their norms (x /. norm, lib/Matrix.ml:201-202: the same division element by element
+// that the normalised copy holds, so the same bits)
+template <int KIND>
+__device__ __forceinline__ double exact_pair_rows_div(const double *__restrict__ arow, double na, const double *__restrict__ brow, double nb,
+                                                      const double *__restrict__ metric, uint32_t n_dims, double p) {
+  double acc = 0.0;
+  for (uint32_t c = 0; c < n_dims; ++c) {
+    const double diff = __dsub_rn(arow[c] / na, brow[c] / nb);
+    acc = __dadd_rn(acc, component<KIND>(diff, metric[c], p));
+  }
+  return scale_distance<KIND>(acc, p);
+}
+
 // The same distances for ANY number of dimensions and any two sets of rows, as a tiled contraction: a block takes 128 query rows x 128
 // reference rows, both operands staged through LDS sixteen dimensions at a time (row-major rows, lanes along the dimensions: whole
 // 128-byte lines; the next chunk's loads fly under this chunk's 64 MFMAs a wavefront), a wavefront 64 x 64 = 4 x 4 accumulator tiles.
@@ -420,7 +433,12 @@ template <int KIND, bool GUARD>
 __global__ __launch_bounds__(256, 2) void distance_gemm_mfma_kernel(const double *__restrict__ a, uint32_t r1, const double *__restrict__ bm, const double *__restrict__ b,
                                                                  uint32_t q, uint32_t n_dims, const double *__restrict__ metric, double p,
                                                                  const double *__restrict__ sa, const double *__restrict__ sb, double *__restrict__ out,
-                                                                 uint32_t tiles_m, uint32_t tiles_n, int m_fast, double tau, const double *__restrict__ a_plain) {
+                                                                 uint32_t tiles_m, uint32_t tiles_n, int m_fast, double tau, const double *__restrict__ a_plain,
+                                                                 const double *__restrict__ na = nullptr, const double *__restrict__ nb = nullptr,
+                                                                 const double *__restrict__ ia = nullptr, const double *__restrict__ ib = nullptr) {
+  // (na, nb, ia, ib -- all or none: the operands are still to be divided by their rows' norms na / nb; sa and sb are the sums of squares of
+  // the rows AS THEY WILL BE, ia / ib the norms' reciprocals: the contraction runs on the rows as they are and a dot product is scaled
+  // where it comes out -- no normalised copy of either operand is made: 0.83 ms of 10 for 100,000 x 1,636 x 1,635)
   // (a, bm: the two panels' sources, ONE of them times the metric -- the caller's choice, the smaller one; a_plain, b: the operands as they
   // are, for the pairs the guard recomputes)
   // two buffers a panel (74 KB a block in all, two blocks a CU): chunk c + 1 is written while chunk c is multiplied, ONE barrier a chunk
@@ -534,6 +552,7 @@ __global__ __launch_bounds__(256, 2) void distance_gemm_mfma_kernel(const double
   for (int j = 0; j < 4; ++j) {
     const uint32_t col = n0 + wn + j * 16 + (lane & 15);
     const double sai = sa[min(col, r1 - 1u)];
+    const double iai = ia ? ia[min(col, r1 - 1u)] : 1.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -541,11 +560,13 @@ __global__ __launch_bounds__(256, 2) void distance_gemm_mfma_kernel(const double
         const uint32_t row = m0 + wm + i * 16 + (lane >> 4) + 4 * r;
         if (row < q && col < r1) {
           const double sbj = sb[row];
-          double u = sai + sbj - 2.0 * acc[i][j][r];
+          const double dot = ib ? acc[i][j][r] * (iai * ib[row]) : acc[i][j][r];
+          double u = sai + sbj - 2.0 * dot;
           u = u > 0.0 ? u : 0.0;
           double d;
           if (GUARD && u < tau * (sai + sbj))
-            d = exact_pair_rows<KIND>(a_plain + (uint64_t)col * n_dims, b + (uint64_t)row * n_dims, metric, n_dims, p);
+            d = na ? exact_pair_rows_div<KIND>(a_plain + (uint64_t)col * n_dims, na[col], b + (uint64_t)row * n_dims, nb[row], metric, n_dims, p)
+                   : exact_pair_rows<KIND>(a_plain + (uint64_t)col * n_dims, b + (uint64_t)row * n_dims, metric, n_dims, p);
           else
             d = KIND == KPOP_EUCLIDEAN ? sqrt_fast(u) : u * 0.5;  // (an ulp or two: far inside what the contraction itself leaves)
           out[(uint64_t)row * r1 + col] = d;
@@ -980,12 +1001,25 @@ bool distance_mfma_applies(int kind, uint32_t r1, uint32_t r2, uint32_t n_dims) 
          (uint64_t)r1 * r2 * n_dims >= (1ull << 32);
 }
 double distance_mfma_tau(uint32_t n_dims) { return std::min(0.5, std::max(1.0 / 16.0, (double)(n_dims + 3) * 1.11e-4)); }
+// s[i] = s[i] / n[i]^2 (the sum of squares of the row divided by its norm), inv[i] = 1 / n[i]
+__global__ __launch_bounds__(256) void norm_scales_kernel(double *__restrict__ s, const double *__restrict__ n, uint32_t rows, double *__restrict__ inv) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < rows) {
+    const double r = 1.0 / n[i];
+    inv[i] = r;
+    s[i] = s[i] * r * r;
+  }
+}
+
+// a, b: the operands AS THEY ARE; n1, n2: their rows' norms when they are to be divided by them first (lib/Matrix.ml:201-202), nullptr otherwise
 int launch_distance_rowwise_mfma(int kind, const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims, const double *metric, double p, double *out,
-                                 hipStream_t st) {
+                                 hipStream_t st, const double *n1, const double *n2) {
   void *ws = nullptr;
   const uint32_t bm_rows = std::min(r1, r2);
-  KPOP_TRY(ctx().ws_for(st).ensure(mfma_scratch_bytes(r2, r1, n_dims, bm_rows) + 512, &ws));
+  const uint64_t m_bytes = (mfma_scratch_bytes(r2, r1, n_dims, bm_rows) + 511) & ~255ull, inv_bytes = (((uint64_t)r1 + r2) * 8 + 511) & ~255ull;
+  KPOP_TRY(ctx().ws_for(st).ensure(m_bytes + inv_bytes + 512, &ws));
   const MfmaScratch M = carve_mfma(ws, r2, r1, n_dims, bm_rows);
+  double *ia = reinterpret_cast<double *>(reinterpret_cast<char *>(ws) + m_bytes), *ib = ia + r1;
   // the metric goes onto the SMALLER operand (its copy times the metric is what the panels of that side are loaded from: 21 MB for 1,636
   // classes where the copy of 100,000 samples was 1.3 GB written and read back -- half a millisecond of 11)
   const bool scale_a = r1 <= r2;
@@ -993,6 +1027,14 @@ int launch_distance_rowwise_mfma(int kind, const double *a, uint32_t r1, const d
   KPOP_LAUNCH_CHECK();
   row_sumsq_kernel<<<dim3(std::min(div_up(r2, 16), 4096u)), dim3(256), 0, st>>>(b, r2, n_dims, metric, M.sb, scale_a ? nullptr : M.bm, nullptr);
   KPOP_LAUNCH_CHECK();
+  if (n1) {
+    norm_scales_kernel<<<dim3(div_up(r1, 256u)), dim3(256), 0, st>>>(M.sa, n1, r1, ia);
+    KPOP_LAUNCH_CHECK();
+    norm_scales_kernel<<<dim3(div_up(r2, 256u)), dim3(256), 0, st>>>(M.sb, n2, r2, ib);
+    KPOP_LAUNCH_CHECK();
+  } else {
+    ia = ib = nullptr;
+  }
   const double *pa = scale_a ? M.bm : a, *pb = scale_a ? b : M.bm;  // the panels' sources
   const uint32_t tiles_m = div_up(r2, (uint32_t)kDT), tiles_n = div_up(r1, (uint32_t)kDT);
   if ((uint64_t)tiles_m * tiles_n >= (1ull << 31)) KPOP_FAIL(KPOP_ERR_UNSUPPORTED, "distance_rowwise: %u x %u tiles", tiles_m, tiles_n);
@@ -1000,9 +1042,9 @@ int launch_distance_rowwise_mfma(int kind, const double *a, uint32_t r1, const d
   const int m_fast = tiles_m <= tiles_n ? 1 : 0;  // (the shorter side fastest: its panel stays in the L2s)
   KPOP_TRY(distance_gemm_lds_attr());
   if (kind == KPOP_EUCLIDEAN)
-    distance_gemm_mfma_kernel<KPOP_EUCLIDEAN, true><<<dim3(tiles_m * tiles_n), dim3(256), kDgLds, st>>>(pa, r1, pb, b, r2, n_dims, metric, p, M.sa, M.sb, out, tiles_m, tiles_n, m_fast, tau, a);
+    distance_gemm_mfma_kernel<KPOP_EUCLIDEAN, true><<<dim3(tiles_m * tiles_n), dim3(256), kDgLds, st>>>(pa, r1, pb, b, r2, n_dims, metric, p, M.sa, M.sb, out, tiles_m, tiles_n, m_fast, tau, a, n1, n2, ia, ib);
   else
-    distance_gemm_mfma_kernel<KPOP_COSINE, true><<<dim3(tiles_m * tiles_n), dim3(256), kDgLds, st>>>(pa, r1, pb, b, r2, n_dims, metric, p, M.sa, M.sb, out, tiles_m, tiles_n, m_fast, tau, a);
+    distance_gemm_mfma_kernel<KPOP_COSINE, true><<<dim3(tiles_m * tiles_n), dim3(256), kDgLds, st>>>(pa, r1, pb, b, r2, n_dims, metric, p, M.sa, M.sb, out, tiles_m, tiles_n, m_fast, tau, a, n1, n2, ia, ib);
   KPOP_LAUNCH_CHECK();
   return 0;
 }
