@@ -38,7 +38,9 @@ constexpr int kNormRows = 64, kNormDims = 32;
 template <int KIND>
 __device__ __forceinline__ void row_norms_block(const double *__restrict__ m, uint32_t rows, uint32_t n_dims,
                                                 const double *__restrict__ metric, double p,
-                                                double *__restrict__ norms, double *__restrict__ normalised, uint32_t block) {
+                                                double *__restrict__ norms, double *__restrict__ normalised, uint32_t block,
+                                                double *__restrict__ sumsq = nullptr) {
+  // (sumsq: the sum itself, before the scale -- sum_c m_c a_ic^2 for the euclidean and the cosine form: what the matrix-core path wants of a row)
   __shared__ double tile[kNormRows][kNormDims + 1];
   __shared__ double s_metric[kNormDims];
   __shared__ double s_norm[kNormRows];
@@ -65,7 +67,10 @@ __device__ __forceinline__ void row_norms_block(const double *__restrict__ m, ui
     double nv = scale_distance<KIND>(acc, p);
     nv = (nv == 0.0) ? 1.0 : nv;  // lib/Matrix.ml:67
     s_norm[threadIdx.x] = nv;
-    if (row0 + threadIdx.x < rows) norms[row0 + threadIdx.x] = nv;
+    if (row0 + threadIdx.x < rows) {
+      norms[row0 + threadIdx.x] = nv;
+      if (sumsq) sumsq[row0 + threadIdx.x] = acc;
+    }
   }
   if (!normalised) return;
   __syncthreads();
@@ -92,17 +97,19 @@ template <int KIND>
 __global__ __launch_bounds__(256) void row_norms_pair_kernel(const double *__restrict__ m1, uint32_t r1, double *__restrict__ n1,
                                                              double *__restrict__ a_div, const double *__restrict__ m2, uint32_t r2,
                                                              double *__restrict__ n2, double *__restrict__ b_div, uint32_t n_dims,
-                                                             const double *__restrict__ metric, double p, uint32_t blocks1) {
+                                                             const double *__restrict__ metric, double p, uint32_t blocks1,
+                                                             double *__restrict__ s1 = nullptr, double *__restrict__ s2 = nullptr) {
   const bool first = blockIdx.x < blocks1;  // (uniform)
-  row_norms_block<KIND>(first ? m1 : m2, first ? r1 : r2, n_dims, metric, p, first ? n1 : n2, first ? a_div : b_div, first ? blockIdx.x : blockIdx.x - blocks1);
+  row_norms_block<KIND>(first ? m1 : m2, first ? r1 : r2, n_dims, metric, p, first ? n1 : n2, first ? a_div : b_div, first ? blockIdx.x : blockIdx.x - blocks1,
+                        first ? s1 : s2);
 }
 
 template <int KIND>
 static int launch_row_norms_pair(const double *m1, uint32_t r1, double *n1, double *a_div, const double *m2, uint32_t r2, double *n2, double *b_div,
-                                 uint32_t n_dims, const double *metric, double p, hipStream_t st) {
+                                 uint32_t n_dims, const double *metric, double p, hipStream_t st, double *s1 = nullptr, double *s2 = nullptr) {
   const uint32_t blocks1 = m1 ? div_up(r1, kNormRows) : 0u, blocks2 = m2 ? div_up(r2, kNormRows) : 0u;
   if (blocks1 + blocks2 == 0) return 0;
-  row_norms_pair_kernel<KIND><<<dim3(blocks1 + blocks2), dim3(256), 0, st>>>(m1, r1, n1, a_div, m2, r2, n2, b_div, n_dims, metric, p, blocks1);
+  row_norms_pair_kernel<KIND><<<dim3(blocks1 + blocks2), dim3(256), 0, st>>>(m1, r1, n1, a_div, m2, r2, n2, b_div, n_dims, metric, p, blocks1, s1, s2);
   KPOP_LAUNCH_CHECK();
   return 0;
 }
@@ -1241,7 +1248,7 @@ static int rowwise_block(const double *a, uint32_t r1, const double *b, uint32_t
 // distance_mfma.hip: every pair's distance as a tiled contraction on the f64 matrix cores
 bool distance_mfma_applies(int kind, uint32_t r1, uint32_t r2, uint32_t n_dims);
 int launch_distance_rowwise_mfma(int kind, const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims, const double *metric, double p, double *out,
-                                 hipStream_t st, const double *n1, const double *n2);
+                                 hipStream_t st, const double *n1, const double *n2, const double *s1, const double *s2);
 
 template <int KIND>
 static int rowwise_impl(const double *m1, uint32_t r1, const double *m2, uint32_t r2, uint32_t n_dims,
@@ -1289,10 +1296,12 @@ static int rowwise_impl(const double *m1, uint32_t r1, const double *m2, uint32_
     // large jobs (the reference's own: 650 K samples x 1,636 classes x 1,635 dimensions, README.md:1054-1060) on the matrix cores: the rows'
     // norms only -- the contraction takes the operands as they are and scales a dot product where it comes out (distance_mfma.hip)
     if (distance_mfma_applies(KIND, r1, r2, n_dims)) {
-      if (!normalize) return launch_distance_rowwise_mfma(KIND, m1, r1, m2, r2, n_dims, metric, p, out, st, nullptr, nullptr);
+      if (!normalize) return launch_distance_rowwise_mfma(KIND, m1, r1, m2, r2, n_dims, metric, p, out, st, nullptr, nullptr, nullptr, nullptr);
+      // (the norms' pass hands over the rows' sums of squares as well -- the same sums before their scale: the larger operand is read ONCE
+      // before the contraction; they go where the normalised copies used to)
       DistWork w = carve(work, r1, r2, n_dims);
-      KPOP_TRY(launch_row_norms_pair<KIND>((r1 && !norms1) ? m1 : nullptr, r1, w.n1, nullptr, m2, r2, w.n2, nullptr, n_dims, metric, p, st));
-      return launch_distance_rowwise_mfma(KIND, m1, r1, m2, r2, n_dims, metric, p, out, st, norms1 ? norms1 : w.n1, w.n2);
+      KPOP_TRY(launch_row_norms_pair<KIND>(m1, r1, w.n1, nullptr, m2, r2, w.n2, nullptr, n_dims, metric, p, st, w.a, w.b));
+      return launch_distance_rowwise_mfma(KIND, m1, r1, m2, r2, n_dims, metric, p, out, st, norms1 ? norms1 : w.n1, w.n2, w.a, w.b);
     }
     const double *a, *b;
     KPOP_TRY(prepare_operands<KIND>(m1, r1, m2, r2, n_dims, metric, p, normalize, work, &a, &b, st));

@@ -1001,19 +1001,25 @@ bool distance_mfma_applies(int kind, uint32_t r1, uint32_t r2, uint32_t n_dims) 
          (uint64_t)r1 * r2 * n_dims >= (1ull << 32);
 }
 double distance_mfma_tau(uint32_t n_dims) { return std::min(0.5, std::max(1.0 / 16.0, (double)(n_dims + 3) * 1.11e-4)); }
-// s[i] = s[i] / n[i]^2 (the sum of squares of the row divided by its norm), inv[i] = 1 / n[i]
-__global__ __launch_bounds__(256) void norm_scales_kernel(double *__restrict__ s, const double *__restrict__ n, uint32_t rows, double *__restrict__ inv) {
+// s[i] = s_raw[i] / n[i]^2 (the sum of squares of the row divided by its norm), inv[i] = 1 / n[i]
+__global__ __launch_bounds__(256) void norm_scales_kernel(double *__restrict__ s, const double *__restrict__ s_raw, const double *__restrict__ n, uint32_t rows,
+                                                          double *__restrict__ inv) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i < rows) {
     const double r = 1.0 / n[i];
     inv[i] = r;
-    s[i] = s[i] * r * r;
+    s[i] = s_raw[i] * r * r;
   }
 }
+// scaled = x m, nothing else (the copy of the smaller operand the panels of its side are loaded from)
+__global__ __launch_bounds__(256) void scale_rows_kernel(const double *__restrict__ x, uint64_t n, uint32_t n_dims, const double *__restrict__ metric, double *__restrict__ scaled) {
+  for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (uint64_t)gridDim.x * 256) scaled[e] = x[e] * metric[e % n_dims];
+}
 
-// a, b: the operands AS THEY ARE; n1, n2: their rows' norms when they are to be divided by them first (lib/Matrix.ml:201-202), nullptr otherwise
+// a, b: the operands AS THEY ARE; n1, n2: their rows' norms when they are to be divided by them first (lib/Matrix.ml:201-202), nullptr otherwise;
+// s1, s2: with the norms, the rows' sums of squares (the norms' pass has them: no pass of its own over the operands)
 int launch_distance_rowwise_mfma(int kind, const double *a, uint32_t r1, const double *b, uint32_t r2, uint32_t n_dims, const double *metric, double p, double *out,
-                                 hipStream_t st, const double *n1, const double *n2) {
+                                 hipStream_t st, const double *n1, const double *n2, const double *s1, const double *s2) {
   void *ws = nullptr;
   const uint32_t bm_rows = std::min(r1, r2);
   const uint64_t m_bytes = (mfma_scratch_bytes(r2, r1, n_dims, bm_rows) + 511) & ~255ull, inv_bytes = (((uint64_t)r1 + r2) * 8 + 511) & ~255ull;
@@ -1023,17 +1029,27 @@ int launch_distance_rowwise_mfma(int kind, const double *a, uint32_t r1, const d
   // the metric goes onto the SMALLER operand (its copy times the metric is what the panels of that side are loaded from: 21 MB for 1,636
   // classes where the copy of 100,000 samples was 1.3 GB written and read back -- half a millisecond of 11)
   const bool scale_a = r1 <= r2;
-  row_sumsq_kernel<<<dim3(std::min(div_up(r1, 16), 4096u)), dim3(256), 0, st>>>(a, r1, n_dims, metric, M.sa, scale_a ? M.bm : nullptr, nullptr);
-  KPOP_LAUNCH_CHECK();
-  row_sumsq_kernel<<<dim3(std::min(div_up(r2, 16), 4096u)), dim3(256), 0, st>>>(b, r2, n_dims, metric, M.sb, scale_a ? nullptr : M.bm, nullptr);
-  KPOP_LAUNCH_CHECK();
-  if (n1) {
-    norm_scales_kernel<<<dim3(div_up(r1, 256u)), dim3(256), 0, st>>>(M.sa, n1, r1, ia);
+  if (n1 && s1 && s2) {
+    const uint64_t n_small = (uint64_t)(scale_a ? r1 : r2) * n_dims;
+    scale_rows_kernel<<<dim3((uint32_t)std::min<uint64_t>(div_up(n_small, (uint64_t)256), 8192)), dim3(256), 0, st>>>(scale_a ? a : b, n_small, n_dims, metric, M.bm);
     KPOP_LAUNCH_CHECK();
-    norm_scales_kernel<<<dim3(div_up(r2, 256u)), dim3(256), 0, st>>>(M.sb, n2, r2, ib);
+    norm_scales_kernel<<<dim3(div_up(r1, 256u)), dim3(256), 0, st>>>(M.sa, s1, n1, r1, ia);
+    KPOP_LAUNCH_CHECK();
+    norm_scales_kernel<<<dim3(div_up(r2, 256u)), dim3(256), 0, st>>>(M.sb, s2, n2, r2, ib);
     KPOP_LAUNCH_CHECK();
   } else {
-    ia = ib = nullptr;
+    row_sumsq_kernel<<<dim3(std::min(div_up(r1, 16), 4096u)), dim3(256), 0, st>>>(a, r1, n_dims, metric, M.sa, scale_a ? M.bm : nullptr, nullptr);
+    KPOP_LAUNCH_CHECK();
+    row_sumsq_kernel<<<dim3(std::min(div_up(r2, 16), 4096u)), dim3(256), 0, st>>>(b, r2, n_dims, metric, M.sb, scale_a ? nullptr : M.bm, nullptr);
+    KPOP_LAUNCH_CHECK();
+    if (n1) {
+      norm_scales_kernel<<<dim3(div_up(r1, 256u)), dim3(256), 0, st>>>(M.sa, M.sa, n1, r1, ia);
+      KPOP_LAUNCH_CHECK();
+      norm_scales_kernel<<<dim3(div_up(r2, 256u)), dim3(256), 0, st>>>(M.sb, M.sb, n2, r2, ib);
+      KPOP_LAUNCH_CHECK();
+    } else {
+      ia = ib = nullptr;
+    }
   }
   const double *pa = scale_a ? M.bm : a, *pb = scale_a ? b : M.bm;  // the panels' sources
   const uint32_t tiles_m = div_up(r2, (uint32_t)kDT), tiles_n = div_up(r1, (uint32_t)kDT);
