@@ -111,6 +111,8 @@ int kpop_synchronize(void *stream);
    "summary_mfma_lists" 1 (default) | 0: that refinement reads the candidate lists the summary's one pass left, or scans the rows;
    "summary_lanes" 1 (default) | 2: 512 query rows and more of such a summary in batches of 256 on two streams (measured level);
    "summary_audit" 0 (default) | 1: count the rows left to the exact fall-back (kpop_debug_summary_fallbacks);
+   "summary_rawref" 1 (default) | 0: such a summary takes its reference set as it is (no normalised copy of it is made: the norms' pass keeps the
+   rows' sums of squares, dot products are scaled where they come out, the exact chains divide as they go -- the same bits), or makes the copy;
    "summary_pass" 1 (default) | 0: the pass over such a summary's approximate rows written for rows the library made itself, or the general one;
    "tilepipe" 1 (default) | 0: the tile route's kernel with producer and consumer wavefronts (tile_pipe.h; beyond 64 dimensions its three-stage
    form: producers / MFMA wavefronts / gather wavefronts), or round 4's; "tilewide" 0 (default) | 1: that three-stage form at any number of

@@ -1331,14 +1331,15 @@ int launch_summary_fused(int kind, const double *a, uint32_t r1, const double *b
 // distance_mfma.hip: the large-reference summary's distances on the matrix cores, and what makes its results exact again
 bool summary_mfma_applies(int kind, uint32_t r1, uint32_t n_dims, uint32_t keep_at_most, uint32_t max_neighbours);
 uint64_t summary_mfma_scratch_bytes(uint32_t q, uint32_t r1, uint32_t n_dims);
-int launch_mfma_reference_norms(const double *a, uint32_t r1, uint32_t n_dims, const double *metric, void *scratch, uint32_t q_room, hipStream_t st);
+int launch_mfma_reference_norms(const double *a, uint32_t r1, uint32_t n_dims, const double *metric, void *scratch, uint32_t q_room, hipStream_t st,
+                                const double *na = nullptr, const double *s_raw = nullptr);
 int launch_mfma_copy_reference_norms(const void *from, void *to, uint32_t r1, uint32_t n_dims, uint32_t q_room, hipStream_t st);
 int launch_distance_rows_mfma(int kind, const double *a, uint32_t r1, const double *b, uint32_t q, uint32_t n_dims, const double *metric, double *rows,
-                              void *scratch, uint32_t q_room, hipStream_t st);
+                              void *scratch, uint32_t q_room, hipStream_t st, bool a_raw = false);
 int launch_summary_refine(int kind, const double *rows, const double *a, uint32_t r1, const double *b, uint32_t q, uint32_t n_dims, const double *metric,
                           double p, uint32_t row0, uint32_t keep_at_most, uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
                           double *out_dist, double *out_z, void *scratch, uint32_t q_room, hipStream_t st, const SummaryLists &lists, const uint32_t **gate,
-                          const void **row_counts);
+                          const void **row_counts, const double *na = nullptr);
 int launch_summary_flagged_rows(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most, uint32_t max_neighbours,
                                 double *out_stats, uint32_t *out_n, uint32_t *out_idx, double *out_dist, double *out_z, const void *flags, hipStream_t st);
 // ... the same without distance rows: the summary's pass inside the contraction (summary_large.hip / distance_mfma.hip)
@@ -1380,16 +1381,32 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
                               uint32_t max_neighbours, void *work, double *out_stats, uint32_t *out_n,
                               uint32_t *out_idx, double *out_dist, double *out_z, hipStream_t st) {
   const double *a, *b;
-  KPOP_TRY(prepare_operands<KIND>(m1, r1, m2, r2, n_dims, metric, p, normalize, work, &a, &b, st));
   const uint64_t budget = 4096ull << 20;
-  if (summary_mfma_applies(KIND, r1, n_dims, keep_at_most, max_neighbours)) {
+  const bool mfma = summary_mfma_applies(KIND, r1, n_dims, keep_at_most, max_neighbours);
+  const bool mfma_select = mfma && ctx().tune_summary_mfma == 2 && n_dims <= 128 && summary_select_mfma_applies(r1, keep_at_most);
+  // The matrix-core path (its default form) takes the REFERENCE set as it is: no normalised copy of it is made (8.5 GB read and written
+  // for 650,000 x 1,635, a quarter of a 256-row call) -- the norms' pass keeps the rows' sums of squares, a dot product is scaled by the
+  // norm's reciprocal where it comes out, the exact chains of the refinement and of the fall-back divide element by element as the copy
+  // did (the same bits).  The query rows, a few hundred, are divided as before.  kpop_tune("summary_rawref", 0): the copy, as before.
+  const double *na = nullptr, *s_raw = nullptr;  // the reference rows' norms and raw sums of squares when `a` is NOT divided
+  if (mfma && !mfma_select && normalize && ctx().tune_summary_rawref) {
+    DistWork w = carve(work, r1, r2, n_dims);
+    KPOP_TRY(launch_row_norms_pair<KIND>(m1, r1, w.n1, nullptr, m2, r2, w.n2, w.b, n_dims, metric, p, st, w.a, nullptr));
+    a = m1;
+    b = w.b;
+    na = w.n1;
+    s_raw = w.a;  // (r1 doubles at the head of the room the copy would have taken)
+  } else {
+    KPOP_TRY(prepare_operands<KIND>(m1, r1, m2, r2, n_dims, metric, p, normalize, work, &a, &b, st));
+  }
+  if (mfma) {
     // the distances on the matrix cores, approximately, to LOCATE what the summary reports; what is reported is recomputed with the
     // reference's chain (distance_mfma.hip).  Rows the refinement cannot vouch for: exact distance rows and the one-block-per-row
     // kernel over them, both launched whatever happened and both returning at once when nothing was flagged.
     // Up to 128 dimensions (kpop_tune("summary_mfma", 2), the default) no approximate row is WRITTEN either: thresholds from the
     // distances to a sample of the reference rows, then ONE kernel that classifies every distance in the accumulators' registers
     // (summary_select_mfma_kernel); beyond, and under kpop_tune("summary_mfma", 1), round 5's path: rows, then the summary's pass over them.
-    const bool select = ctx().tune_summary_mfma == 2 && n_dims <= 128 && summary_select_mfma_applies(r1, keep_at_most);
+    const bool select = mfma_select;
     uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(r2, 2 * budget / ((uint64_t)r1 * 8)));  // (1,024 rows against a million)
     if (chunk > 128) chunk = chunk / 128 * 128;
     // TWO LANES (kpop_tune("summary_lanes", 2); 512 query rows and more): batches of 256 rows alternately on the caller's stream and on one of
@@ -1416,7 +1433,7 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
         char *base = wp + (uint64_t)l * lane_bytes;
         lane[l] = Lane{l ? aux->stream : st, reinterpret_cast<double *>(base), base + row_bytes, base + row_bytes + sum_bytes};
       }
-      KPOP_TRY(launch_mfma_reference_norms(a, r1, n_dims, metric, lane[0].mscratch, chunk, st));
+      KPOP_TRY(launch_mfma_reference_norms(a, r1, n_dims, metric, lane[0].mscratch, chunk, st, na, s_raw));
       KPOP_TRY(launch_mfma_copy_reference_norms(lane[0].mscratch, lane[1].mscratch, r1, n_dims, chunk, st));
       KPOP_HIP(hipEventRecord(aux->fork, st));
       KPOP_HIP(hipStreamWaitEvent(aux->stream, aux->fork, 0));
@@ -1431,13 +1448,13 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
         const void *flags = nullptr;
         auto batch = [&]() -> int {
           if (bi > 0) KPOP_HIP(hipStreamWaitEvent(L.s, aux->step[(bi - 1) & 1u], 0));  // this batch's contraction after the one before it
-          KPOP_TRY(launch_distance_rows_mfma(KIND, a, r1, bq, q, n_dims, metric, L.rows, L.mscratch, chunk, L.s));
+          KPOP_TRY(launch_distance_rows_mfma(KIND, a, r1, bq, q, n_dims, metric, L.rows, L.mscratch, chunk, L.s, na != nullptr));
           KPOP_HIP(hipEventRecord(aux->step[bi & 1u], L.s));
           KPOP_TRY(launch_summary_large(L.rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, L.s, L.scratch, &lists, true));
           KPOP_TRY(launch_summary_refine(KIND, L.rows, a, r1, bq, q, n_dims, metric, p, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z,
-                                         L.mscratch, chunk, L.s, lists, &gate, &flags));
+                                         L.mscratch, chunk, L.s, lists, &gate, &flags, na));
           KPOP_TRY(audit_fallback(gate, L.s));
-          KPOP_TRY(rowwise_block<KIND>(a, r1, bq, q, n_dims, metric, p, L.rows, L.s, nullptr, nullptr, gate));
+          KPOP_TRY(rowwise_block<KIND>(a, r1, bq, q, n_dims, metric, p, L.rows, L.s, na, nullptr, gate));  // (na: the kernel divides the reference rows as it stages them)
           KPOP_TRY(launch_summary_flagged_rows(L.rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, flags, L.s));
           return 0;
         };
@@ -1465,7 +1482,7 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
     double *a_s = reinterpret_cast<double *>(wp + row_bytes + segi_bytes + sum_bytes + m_bytes);
     double *sa_s = reinterpret_cast<double *>(wp + row_bytes + segi_bytes + sum_bytes + m_bytes + as_bytes);
     double *srow = reinterpret_cast<double *>(wp + row_bytes + segi_bytes + sum_bytes + m_bytes + as_bytes + sas_bytes);
-    KPOP_TRY(launch_mfma_reference_norms(a, r1, n_dims, metric, mscratch, chunk, st));
+    KPOP_TRY(launch_mfma_reference_norms(a, r1, n_dims, metric, mscratch, chunk, st, na, s_raw));
     if (select) {  // the sample of the reference rows and its norms: once a call
       KPOP_TRY(launch_sample_gather(a, r1, n_dims, s_rows, a_s, st));
       KPOP_TRY(launch_row_sumsq(a_s, s_rows, n_dims, metric, sa_s, st));
@@ -1485,13 +1502,13 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
                                        out_z, mscratch, chunk, st, lists, &gate, &flags));
         KPOP_TRY(audit_fallback(gate, st));
       } else {
-        KPOP_TRY(launch_distance_rows_mfma(KIND, a, r1, bq, q, n_dims, metric, rows, mscratch, chunk, st));
+        KPOP_TRY(launch_distance_rows_mfma(KIND, a, r1, bq, q, n_dims, metric, rows, mscratch, chunk, st, na != nullptr));
         KPOP_TRY(launch_summary_large(rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st, scratch, &lists, true));
         KPOP_TRY(launch_summary_refine(KIND, rows, a, r1, bq, q, n_dims, metric, p, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist,
-                                       out_z, mscratch, chunk, st, lists, &gate, &flags));
+                                       out_z, mscratch, chunk, st, lists, &gate, &flags, na));
         KPOP_TRY(audit_fallback(gate, st));
       }
-      KPOP_TRY(rowwise_block<KIND>(a, r1, bq, q, n_dims, metric, p, rows, st, nullptr, nullptr, gate));
+      KPOP_TRY(rowwise_block<KIND>(a, r1, bq, q, n_dims, metric, p, rows, st, na, nullptr, gate));  // (na: the kernel divides the reference rows as it stages them)
       KPOP_TRY(launch_summary_flagged_rows(rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, flags, st));
     }
     return 0;

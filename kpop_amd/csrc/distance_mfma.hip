@@ -88,10 +88,12 @@ __device__ __forceinline__ double sqrt_fast(double u) {
 template <int KIND, int KS, int MI>  // KS steps of 4 dimensions: n_dims <= 4 KS
 __global__ __launch_bounds__(256) void distance_rows_mfma_kernel(const double *__restrict__ a, uint32_t r1, const double *__restrict__ bm, uint32_t q, uint32_t n_dims,
                                                                  const double *__restrict__ sa, const double *__restrict__ sb, double *__restrict__ out,
-                                                                 uint32_t tiles_per_block) {
+                                                                 uint32_t tiles_per_block, const double *__restrict__ ia = nullptr) {
+  // (ia: the reference rows come as they are, still to be divided by their norms -- sa is the sum of squares of the row AS IT WILL BE, ia
+  // the norm's reciprocal, a dot product is scaled where it comes out; nullptr: the rows are what they are)
   constexpr int TS = 4 * KS + 2;  // a staged row's doubles: + 2 spreads a half-wavefront's 16 rows over the banks
   __shared__ double s_tile[2][16][TS];
-  __shared__ double s_sa[2][16];
+  __shared__ double s_sa[2][16], s_ia[2][16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t l15 = (uint32_t)lane & 15u, l4 = (uint32_t)lane >> 4;
   const uint32_t j0 = blockIdx.y * (64u * MI) + (uint32_t)wv * (16u * MI);
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) void distance_rows_mfma_kernel(const double *_
   if (t0 >= t1) return;
   const bool rows_full = j0 + 16u * MI <= q;  // (wavefront-uniform)
   constexpr uint32_t PER = (16u * 4u * KS + 255u) / 256u;  // doubles of a tile a thread moves
-  double pre[PER], pre_sa = 0.0;
+  double pre[PER], pre_sa = 0.0, pre_ia = 1.0;
   auto fetch = [&](uint32_t t) {
 #pragma unroll
     for (uint32_t e = 0; e < PER; ++e) {
@@ -124,7 +126,10 @@ __global__ __launch_bounds__(256) void distance_rows_mfma_kernel(const double *_
       const uint32_t i = min(16u * t + r, r1 - 1u);  // (rows past the end: the last row again, never stored)
       pre[e] = c < n_dims ? a[(uint64_t)i * n_dims + c] : 0.0;
     }
-    if (threadIdx.x < 16) pre_sa = sa[min(16u * t + threadIdx.x, r1 - 1u)];
+    if (threadIdx.x < 16) {
+      pre_sa = sa[min(16u * t + threadIdx.x, r1 - 1u)];
+      if (ia) pre_ia = ia[min(16u * t + threadIdx.x, r1 - 1u)];
+    }
   };
   auto put = [&](int buf) {
 #pragma unroll
@@ -132,7 +137,10 @@ __global__ __launch_bounds__(256) void distance_rows_mfma_kernel(const double *_
       const uint32_t idx = threadIdx.x + 256u * e, r = idx / (4u * KS), c = idx % (4u * KS);
       s_tile[buf][r][c] = pre[e];
     }
-    if (threadIdx.x < 16) s_sa[buf][threadIdx.x] = pre_sa;
+    if (threadIdx.x < 16) {
+      s_sa[buf][threadIdx.x] = pre_sa;
+      s_ia[buf][threadIdx.x] = pre_ia;
+    }
   };
   static_assert((16u * 4u * KS) % 256u == 0, "a tile is a whole number of sweeps of the block");
   fetch(t0);
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(256) void distance_rows_mfma_kernel(const double *_
         for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi][ks], bf, acc[mi], 0, 0, 0);
       }
     }
-    const double sai = s_sa[buf][l15];
+    const double sai = s_sa[buf][l15], m2i = -2.0 * s_ia[buf][l15];  // (-2 times the scale of the tile's reference row: 1 unless ia)
     __builtin_amdgcn_s_setprio(2);  // (the square roots and stores of this tile ahead of the other wavefronts' MFMAs: they end the tile, the MFMAs only fill the pipe)
     put(buf ^ 1);  // (its readers passed the barrier that ended the previous tile)
     const uint32_t i = 16u * t + l15;
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(256) void distance_rows_mfma_kernel(const double *_
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {  // lane holds query rows l4 + 4 rr of the M tile, reference row l15
           const uint32_t row = j0 + 16u * mi + l4 + 4u * rr;
-          double u = sai + sbv[mi][rr] - 2.0 * acc[mi][rr];
+          double u = sai + sbv[mi][rr] + m2i * acc[mi][rr];
           u = u > 0.0 ? u : 0.0;
           out[(uint64_t)row * r1 + i] = KIND == KPOP_EUCLIDEAN ? sqrt_fast(u) : u * 0.5;
         }
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(256) void distance_rows_mfma_kernel(const double *_
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const uint32_t row = j0 + 16u * mi + l4 + 4u * rr;
-          double u = sai + sbv[mi][rr] - 2.0 * acc[mi][rr];
+          double u = sai + sbv[mi][rr] + m2i * acc[mi][rr];
           u = u > 0.0 ? u : 0.0;
           if (row < q && i < r1) out[(uint64_t)row * r1 + i] = KIND == KPOP_EUCLIDEAN ? sqrt_fast(u) : u * 0.5;
         }
@@ -560,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void distance_gemm_mfma_kernel(const double
         const uint32_t row = m0 + wm + i * 16 + (lane >> 4) + 4 * r;
         if (row < q && col < r1) {
           const double sbj = sb[row];
-          const double dot = ib ? acc[i][j][r] * (iai * ib[row]) : acc[i][j][r];
+          const double dot = (ia || ib) ? acc[i][j][r] * (ib ? iai * ib[row] : iai) : acc[i][j][r];
           double u = sai + sbj - 2.0 * dot;
           u = u > 0.0 ? u : 0.0;
           double d;
@@ -589,6 +597,18 @@ __device__ __forceinline__ double exact_pair(const double *__restrict__ arow, co
   return scale_distance<KIND>(acc, p);
 }
 
+// ... of a reference row that is still to be divided by its norm (x /. norm element by element: the bits the normalised copy would hold)
+template <int KIND>
+__device__ __forceinline__ double exact_pair_adiv(const double *__restrict__ arow, double na, const double *__restrict__ brow, const double *__restrict__ metric,
+                                                  uint32_t n_dims, double p) {
+  double acc = 0.0;
+  for (uint32_t c = 0; c < n_dims; ++c) {
+    const double diff = __dsub_rn(__ddiv_rn(arow[c], na), brow[c]);
+    acc = __dadd_rn(acc, component<KIND>(diff, metric[c], p));
+  }
+  return scale_distance<KIND>(acc, p);
+}
+
 __device__ __forceinline__ bool pair_less(double da, uint32_t ia, double db, uint32_t ib) { return da < db || (da == db && ia < ib); }
 
 // One block a query row: see the head of the file.  rows: the approximate distances [q][r1]; stats etc.: what the summary made of
@@ -599,7 +619,9 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
                                                               const unsigned long long *__restrict__ smax_bits, uint32_t row0, uint32_t req_len,
                                                               uint32_t max_neighbours, double gamma, double *__restrict__ out_stats, uint32_t *__restrict__ out_n,
                                                               uint32_t *__restrict__ out_idx, double *__restrict__ out_dist, double *__restrict__ out_z,
-                                                              uint32_t *__restrict__ rc, uint32_t *__restrict__ n_failed, SummaryLists L) {
+                                                              uint32_t *__restrict__ rc, uint32_t *__restrict__ n_failed, SummaryLists L,
+                                                              const double *__restrict__ na) {
+  // (na: the reference rows `a` come as they are, still to be divided by their norms na -- the exact chain divides as it goes; nullptr: they are what they are)
   __shared__ uint32_t s_nb_i[kRefNb], s_med_i[kRefMed], s_mad_i[kRefMad];
   __shared__ double s_nb_d[kRefNb], s_med_d[kRefMed], s_mad_d[kRefMad];
   __shared__ double s_b[128], s_m[128];
@@ -770,7 +792,9 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
   // the exact distances of the neighbours' and the median's bands
   double c1 = 0.0, c2 = 0.0;  // what the band's exact values change in sum d and in sum (d - mean)^2
   for (uint32_t e = threadIdx.x; e < n_nb; e += 1024) {
-    const double dx = exact_pair<KIND>(a + (uint64_t)s_nb_i[e] * n_dims, qb, qm, n_dims, p), x = s_nb_x[e];
+    const double dx = na ? exact_pair_adiv<KIND>(a + (uint64_t)s_nb_i[e] * n_dims, na[s_nb_i[e]], qb, qm, n_dims, p)
+                         : exact_pair<KIND>(a + (uint64_t)s_nb_i[e] * n_dims, qb, qm, n_dims, p);
+    const double x = s_nb_x[e];
     s_nb_d[e] = dx;
     c1 += dx - x;
     c2 += (dx - mean_a) * (dx - mean_a) - (x - mean_a) * (x - mean_a);
@@ -784,7 +808,9 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
     s_corr[threadIdx.x >> 6][0] = c1;
     s_corr[threadIdx.x >> 6][1] = c2;
   }
-  for (uint32_t e = threadIdx.x; e < n_med; e += 1024) s_med_d[e] = exact_pair<KIND>(a + (uint64_t)s_med_i[e] * n_dims, qb, qm, n_dims, p);
+  for (uint32_t e = threadIdx.x; e < n_med; e += 1024)
+    s_med_d[e] = na ? exact_pair_adiv<KIND>(a + (uint64_t)s_med_i[e] * n_dims, na[s_med_i[e]], qb, qm, n_dims, p)
+                    : exact_pair<KIND>(a + (uint64_t)s_med_i[e] * n_dims, qb, qm, n_dims, p);
   __syncthreads();
   // the median: the band's element of rank r_med - n_lt (ranks by counting: the bands are small)
   for (uint32_t e = threadIdx.x; e < n_med; e += 1024) {
@@ -815,7 +841,9 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
   }
   // the MAD: exact deviations of its band from the exact median, the element of rank r_med - n_in
   for (uint32_t e = threadIdx.x; e < n_mad; e += 1024)
-    s_mad_d[e] = fabs(__dsub_rn(exact_pair<KIND>(a + (uint64_t)s_mad_i[e] * n_dims, qb, qm, n_dims, p), median));
+    s_mad_d[e] = fabs(__dsub_rn(na ? exact_pair_adiv<KIND>(a + (uint64_t)s_mad_i[e] * n_dims, na[s_mad_i[e]], qb, qm, n_dims, p)
+                                   : exact_pair<KIND>(a + (uint64_t)s_mad_i[e] * n_dims, qb, qm, n_dims, p),
+                                median));
   __syncthreads();
   for (uint32_t e = threadIdx.x; e < n_mad; e += 1024) {
     const double de = s_mad_d[e];
@@ -909,12 +937,13 @@ bool summary_mfma_applies(int kind, uint32_t r1, uint32_t n_dims, uint32_t keep_
 }
 // room for: the query rows times the metric, the two sets of norms, the largest of them, the fall-back's flags and its count
 static uint64_t mfma_scratch_bytes(uint32_t q, uint32_t r1, uint32_t n_dims, uint32_t bm_rows) {
-  return (((uint64_t)bm_rows * n_dims * 8 + 255) & ~255ull) + (((uint64_t)r1 * 8 + 255) & ~255ull) + (((uint64_t)q * 8 + 255) & ~255ull) + 256 +
+  return (((uint64_t)r1 * 8 + 255) & ~255ull) + (((uint64_t)bm_rows * n_dims * 8 + 255) & ~255ull) + (((uint64_t)r1 * 8 + 255) & ~255ull) + (((uint64_t)q * 8 + 255) & ~255ull) + 256 +
          (((uint64_t)q * kRowCountsWords * 4 + 255) & ~255ull) + 256;
 }
 uint64_t summary_mfma_scratch_bytes(uint32_t q, uint32_t r1, uint32_t n_dims) { return mfma_scratch_bytes(q, r1, n_dims, q); }
 struct MfmaScratch {
   double *bm, *sa, *sb;
+  double *ia;  // the reciprocals of the reference rows' norms (the summary on reference rows that are still to be divided by them)
   unsigned long long *smax;
   uint32_t *rc, *n_failed;
 };
@@ -924,6 +953,8 @@ static MfmaScratch carve_mfma(void *scratch, uint32_t q, uint32_t r1, uint32_t n
   M.bm = reinterpret_cast<double *>(p);
   p += ((uint64_t)(bm_rows ? bm_rows : q) * n_dims * 8 + 255) & ~255ull;
   M.sa = reinterpret_cast<double *>(p);
+  p += ((uint64_t)r1 * 8 + 255) & ~255ull;
+  M.ia = reinterpret_cast<double *>(p);
   p += ((uint64_t)r1 * 8 + 255) & ~255ull;
   M.sb = reinterpret_cast<double *>(p);
   p += ((uint64_t)q * 8 + 255) & ~255ull;
@@ -949,10 +980,33 @@ static int distance_gemm_lds_attr() {
 }
 
 // the reference set's norms (once per call: they do not depend on the chunk of query rows)
-int launch_mfma_reference_norms(const double *a, uint32_t r1, uint32_t n_dims, const double *metric, void *scratch, uint32_t q_room, hipStream_t st) {
+// na, s_raw (both or neither): the reference rows come as they are, still to be divided by their norms na; s_raw their sums of squares as
+// they are (the norms' pass has them): sa = s_raw / na^2, ia = 1 / na -- no pass over the reference set here at all
+__global__ __launch_bounds__(256) void reference_scales_kernel(const double *__restrict__ s_raw, const double *__restrict__ n, uint32_t rows, double *__restrict__ sa,
+                                                               double *__restrict__ ia, unsigned long long *__restrict__ smax) {
+  __shared__ unsigned long long s_max;
+  if (threadIdx.x == 0) s_max = 0;
+  __syncthreads();
+  unsigned long long mine = 0;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < rows; i += gridDim.x * 256) {
+    const double r = 1.0 / n[i], v = s_raw[i] * r * r;
+    ia[i] = r;
+    sa[i] = v;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);  // (not negative: bit patterns order as the values do)
+    mine = mine > bits ? mine : bits;
+  }
+  atomicMax(&s_max, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(smax, s_max);
+}
+int launch_mfma_reference_norms(const double *a, uint32_t r1, uint32_t n_dims, const double *metric, void *scratch, uint32_t q_room, hipStream_t st,
+                                const double *na, const double *s_raw) {
   const MfmaScratch M = carve_mfma(scratch, q_room, r1, n_dims);
   KPOP_HIP(hipMemsetAsync(M.smax, 0, 256, st));
-  row_sumsq_kernel<<<dim3(std::min(div_up(r1, 16), 4096u)), dim3(256), 0, st>>>(a, r1, n_dims, metric, M.sa, nullptr, M.smax);
+  if (na && s_raw)
+    reference_scales_kernel<<<dim3(std::min(div_up(r1, 256u), 1024u)), dim3(256), 0, st>>>(s_raw, na, r1, M.sa, M.ia, M.smax);
+  else
+    row_sumsq_kernel<<<dim3(std::min(div_up(r1, 16), 4096u)), dim3(256), 0, st>>>(a, r1, n_dims, metric, M.sa, nullptr, M.smax);
   KPOP_LAUNCH_CHECK();
   return 0;
 }
@@ -961,20 +1015,22 @@ int launch_mfma_reference_norms(const double *a, uint32_t r1, uint32_t n_dims, c
 int launch_mfma_copy_reference_norms(const void *from, void *to, uint32_t r1, uint32_t n_dims, uint32_t q_room, hipStream_t st) {
   const MfmaScratch A = carve_mfma(const_cast<void *>(from), q_room, r1, n_dims), B = carve_mfma(to, q_room, r1, n_dims);
   KPOP_HIP(hipMemcpyAsync(B.sa, A.sa, (uint64_t)r1 * 8, hipMemcpyDeviceToDevice, st));
+  KPOP_HIP(hipMemcpyAsync(B.ia, A.ia, (uint64_t)r1 * 8, hipMemcpyDeviceToDevice, st));  // (filled or not: copied either way)
   KPOP_HIP(hipMemcpyAsync(B.smax, A.smax, 256, hipMemcpyDeviceToDevice, st));
   return 0;
 }
 
 template <int KIND>
 static int launch_rows_mfma(const double *a, uint32_t r1, const double *b, uint32_t q, uint32_t n_dims, const double *metric, double *rows, const MfmaScratch &M,
-                            hipStream_t st) {
+                            hipStream_t st, bool a_raw) {
+  const double *ia = a_raw ? M.ia : nullptr;  // (a_raw: the reference rows still to be divided by their norms, launch_mfma_reference_norms)
   row_sumsq_kernel<<<dim3(std::min(div_up(q, 16), 4096u)), dim3(256), 0, st>>>(b, q, n_dims, metric, M.sb, M.bm, nullptr);
   KPOP_LAUNCH_CHECK();
   if (n_dims > 128) {  // the tiled contraction (any number of dimensions): 128 query rows x 128 reference rows a block
     const uint32_t tiles_m = div_up(q, (uint32_t)kDT), tiles_n = div_up(r1, (uint32_t)kDT);
     KPOP_TRY(distance_gemm_lds_attr());
     distance_gemm_mfma_kernel<KIND, false><<<dim3(tiles_m * tiles_n), dim3(256), kDgLds, st>>>(a, r1, M.bm, b, q, n_dims, metric, 2.0, M.sa, M.sb, rows, tiles_m, tiles_n,
-                                                                                                tiles_m <= 16 ? 1 : 0, 0.0, a);
+                                                                                                tiles_m <= 16 ? 1 : 0, 0.0, a, nullptr, nullptr, ia, nullptr);
     KPOP_LAUNCH_CHECK();
     return 0;
   }
@@ -987,9 +1043,9 @@ static int launch_rows_mfma(const double *a, uint32_t r1, const double *b, uint3
   const uint32_t tpb = div_up(n_tiles, gx);
   const dim3 grid(div_up(n_tiles, tpb), ny);
   if (small)
-    distance_rows_mfma_kernel<KIND, 16, 2><<<grid, dim3(256), 0, st>>>(a, r1, M.bm, q, n_dims, M.sa, M.sb, rows, tpb);
+    distance_rows_mfma_kernel<KIND, 16, 2><<<grid, dim3(256), 0, st>>>(a, r1, M.bm, q, n_dims, M.sa, M.sb, rows, tpb, ia);
   else
-    distance_rows_mfma_kernel<KIND, 32, 4><<<grid, dim3(256), 0, st>>>(a, r1, M.bm, q, n_dims, M.sa, M.sb, rows, tpb);
+    distance_rows_mfma_kernel<KIND, 32, 4><<<grid, dim3(256), 0, st>>>(a, r1, M.bm, q, n_dims, M.sa, M.sb, rows, tpb, ia);
   KPOP_LAUNCH_CHECK();
   return 0;
 }
@@ -1119,19 +1175,19 @@ int launch_row_sumsq(const double *x, uint32_t rows, uint32_t n_dims, const doub
 
 // the chunk's approximate distance rows (into `rows`), and the flags of its fall-back cleared
 int launch_distance_rows_mfma(int kind, const double *a, uint32_t r1, const double *b, uint32_t q, uint32_t n_dims, const double *metric, double *rows,
-                              void *scratch, uint32_t q_room, hipStream_t st) {
+                              void *scratch, uint32_t q_room, hipStream_t st, bool a_raw) {
   const MfmaScratch M = carve_mfma(scratch, q_room, r1, n_dims);
   KPOP_HIP(hipMemsetAsync(M.rc, 0, (uint64_t)q * kRowCountsWords * 4, st));
   KPOP_HIP(hipMemsetAsync(M.n_failed, 0, 256, st));
-  return kind == KPOP_EUCLIDEAN ? launch_rows_mfma<KPOP_EUCLIDEAN>(a, r1, b, q, n_dims, metric, rows, M, st)
-                                : launch_rows_mfma<KPOP_COSINE>(a, r1, b, q, n_dims, metric, rows, M, st);
+  return kind == KPOP_EUCLIDEAN ? launch_rows_mfma<KPOP_EUCLIDEAN>(a, r1, b, q, n_dims, metric, rows, M, st, a_raw)
+                                : launch_rows_mfma<KPOP_COSINE>(a, r1, b, q, n_dims, metric, rows, M, st, a_raw);
 }
 
 // the refinement; *gate = the device word that counts the rows left to the fall-back, *row_counts = their flags (RowCounts)
 int launch_summary_refine(int kind, const double *rows, const double *a, uint32_t r1, const double *b, uint32_t q, uint32_t n_dims, const double *metric,
                           double p, uint32_t row0, uint32_t keep_at_most, uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
                           double *out_dist, double *out_z, void *scratch, uint32_t q_room, hipStream_t st, const SummaryLists &lists, const uint32_t **gate,
-                          const void **row_counts) {
+                          const void **row_counts, const double *na) {
   const MfmaScratch M = carve_mfma(scratch, q_room, r1, n_dims);
   const uint32_t req_len = keep_at_most ? keep_at_most : r1;
   // |u~ - u| <= gamma (|a|^2 + |b|^2): n_dims products and additions of the contraction and of the two norms at 2^-53 each, the
@@ -1141,10 +1197,10 @@ int launch_summary_refine(int kind, const double *rows, const double *a, uint32_
   if (!ctx().tune_summary_mfma_lists || !L.cand_i) L = SummaryLists{};
   if (kind == KPOP_EUCLIDEAN)
     summary_refine_kernel<KPOP_EUCLIDEAN><<<dim3(q), dim3(1024), 0, st>>>(rows, a, r1, b, n_dims, metric, p, M.sb, M.smax, row0, req_len, max_neighbours, gamma, out_stats,
-                                                                          out_n, out_idx, out_dist, out_z, M.rc, M.n_failed, L);
+                                                                          out_n, out_idx, out_dist, out_z, M.rc, M.n_failed, L, na);
   else
     summary_refine_kernel<KPOP_COSINE><<<dim3(q), dim3(1024), 0, st>>>(rows, a, r1, b, n_dims, metric, p, M.sb, M.smax, row0, req_len, max_neighbours, gamma, out_stats,
-                                                                       out_n, out_idx, out_dist, out_z, M.rc, M.n_failed, L);
+                                                                       out_n, out_idx, out_dist, out_z, M.rc, M.n_failed, L, na);
   KPOP_LAUNCH_CHECK();
   *gate = M.n_failed;
   *row_counts = M.rc;
