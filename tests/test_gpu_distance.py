@@ -778,17 +778,24 @@ def test_distance_summary_on_the_matrix_cores_many_query_rows(kpop, oracle, kind
     res = {}
     api.tune("summary_audit", 1)
     api.summary_fallbacks()
-    for name, mfma, lanes in (("default", 1, 1), ("select", 2, 1), ("lanes", 1, 2), ("vector", 0, 1)):
+    # (copy: the reference set divided by its norms into a copy first, as until late in round 6 -- the default takes it as it is; general_pass: the
+    # pass over the approximate rows written for any caller's rows)
+    for name, mfma, lanes, rawref, plain_pass in (("default", 1, 1, 1, 1), ("select", 2, 1, 1, 1), ("lanes", 1, 2, 1, 1), ("copy", 1, 1, 0, 1), ("general_pass", 1, 1, 1, 0),
+                                                  ("vector", 0, 1, 1, 1)):
         api.tune("summary_mfma", mfma)
         api.tune("summary_lanes", lanes)
+        api.tune("summary_rawref", rawref)
+        api.tune("summary_pass", plain_pass)
         res[name] = kpop.distance_summary(m1, m2, metric, kind, 2.0, True, 20, max_neighbours=32)
         left = api.summary_fallbacks()
         assert left == 0, (name, left)
     api.tune("summary_audit", 0)
     api.tune("summary_mfma", 1)
     api.tune("summary_lanes", 1)
+    api.tune("summary_rawref", 1)
+    api.tune("summary_pass", 1)
     ref = res["vector"]
-    for name in ("default", "select", "lanes"):
+    for name in ("default", "select", "lanes", "copy", "general_pass"):
         got = res[name]
         assert np.array_equal(got[0][:, 2:], ref[0][:, 2:]), name
         np.testing.assert_allclose(got[0][:, :2], ref[0][:, :2], rtol=1e-10)
