@@ -609,6 +609,60 @@ __device__ __forceinline__ double exact_pair_adiv(const double *__restrict__ aro
   return scale_distance<KIND>(acc, p);
 }
 
+// The same chain by a WAVEFRONT (rows of hundreds of dimensions: a thread a pair walks its own row, 8 bytes a step, every load a line of
+// its own -- 2.2 ms of a 14 ms summary of 256 x 650,000 x 1,635): 64 consecutive dimensions a sweep, a lane each -- one coalesced read of
+// both rows, the terms in parallel -- then the 64 terms added to the sum ONE AFTER THE OTHER in dimension order (every lane adds the
+// same values in the same order and ends with the same sum): the reference's order of additions, lib/Space.ml:182-205.
+// na = 0: the reference row is what it is; otherwise it is divided by na element by element as it goes.
+// The exact chain by a WAVEFRONT (rows of hundreds of dimensions: a thread a pair walks its own row, 8 bytes a step, every load a line of
+// its own -- 2.2 ms of a 14 ms summary of 256 x 650,000 x 1,635): 64 consecutive dimensions a sweep, a lane each -- one coalesced read of
+// the rows, the terms in parallel -- then the 64 terms added to the sum ONE AFTER THE OTHER in dimension order (every lane adds the same
+// values, read off the lanes with v_readlane, in the same order and ends with the same sum): the reference's order of additions,
+// lib/Space.ml:182-205.  na = 0: the reference row is what it is; otherwise it is divided by na element by element as it goes.
+// Two pairs at a time (two independent chains of additions; measured level with one: three instructions a term and pair are what it
+// costs, 1.0 ms for 256 rows x ~600 band rows x 1,635 against 2.2 ms a thread a pair)
+template <int KIND>
+__device__ __forceinline__ void exact_pair_wave2(const double *__restrict__ arow0, double na0, const double *__restrict__ arow1, double na1,
+                                                 const double *__restrict__ brow, const double *__restrict__ metric, uint32_t n_dims, double p, int lane, double *d0,
+                                                 double *d1) {
+  double acc0 = 0.0, acc1 = 0.0;
+  // (the next sweep's loads are in flight while this sweep's terms are added up)
+  uint32_t c = (uint32_t)lane;
+  double a0n = c < n_dims ? arow0[c] : 0.0, a1n = c < n_dims ? arow1[c] : 0.0, b_n = c < n_dims ? brow[c] : 0.0, m_n = c < n_dims ? metric[c] : 0.0;
+  for (uint32_t c0 = 0; c0 < n_dims; c0 += 64) {
+    const double a0c = a0n, a1c = a1n, b_c = b_n, m_c = m_n;
+    const uint32_t cn = c0 + 64u + (uint32_t)lane;
+    if (cn < n_dims) {
+      a0n = arow0[cn];
+      a1n = arow1[cn];
+      b_n = brow[cn];
+      m_n = metric[cn];
+    }
+    double t0 = 0.0, t1 = 0.0;
+    if (c0 + (uint32_t)lane < n_dims) {
+      const double av0 = na0 != 0.0 ? __ddiv_rn(a0c, na0) : a0c, av1 = na1 != 0.0 ? __ddiv_rn(a1c, na1) : a1c;
+      t0 = component<KIND>(__dsub_rn(av0, b_c), m_c, p);
+      t1 = component<KIND>(__dsub_rn(av1, b_c), m_c, p);
+    }
+    const uint32_t lim = min(64u, n_dims - c0);
+    const int t0lo = __double2loint(t0), t0hi = __double2hiint(t0), t1lo = __double2loint(t1), t1hi = __double2hiint(t1);
+    if (lim == 64u) {
+#pragma unroll
+      for (int l = 0; l < 64; ++l) {  // (v_readlane_b32: the terms of lane l as scalars, no trip through the LDS crossbar)
+        acc0 = __dadd_rn(acc0, __hiloint2double(__builtin_amdgcn_readlane(t0hi, l), __builtin_amdgcn_readlane(t0lo, l)));
+        acc1 = __dadd_rn(acc1, __hiloint2double(__builtin_amdgcn_readlane(t1hi, l), __builtin_amdgcn_readlane(t1lo, l)));
+      }
+    } else {
+      for (uint32_t l = 0; l < lim; ++l) {
+        acc0 = __dadd_rn(acc0, __shfl(t0, (int)l, 64));
+        acc1 = __dadd_rn(acc1, __shfl(t1, (int)l, 64));
+      }
+    }
+  }
+  *d0 = scale_distance<KIND>(acc0, p);
+  *d1 = scale_distance<KIND>(acc1, p);
+}
+
 __device__ __forceinline__ bool pair_less(double da, uint32_t ia, double db, uint32_t ib) { return da < db || (da == db && ia < ib); }
 
 // One block a query row: see the head of the file.  rows: the approximate distances [q][r1]; stats etc.: what the summary made of
@@ -791,13 +845,35 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
   }
   // the exact distances of the neighbours' and the median's bands
   double c1 = 0.0, c2 = 0.0;  // what the band's exact values change in sum d and in sum (d - mean)^2
-  for (uint32_t e = threadIdx.x; e < n_nb; e += 1024) {
-    const double dx = na ? exact_pair_adiv<KIND>(a + (uint64_t)s_nb_i[e] * n_dims, na[s_nb_i[e]], qb, qm, n_dims, p)
-                         : exact_pair<KIND>(a + (uint64_t)s_nb_i[e] * n_dims, qb, qm, n_dims, p);
-    const double x = s_nb_x[e];
-    s_nb_d[e] = dx;
-    c1 += dx - x;
-    c2 += (dx - mean_a) * (dx - mean_a) - (x - mean_a) * (x - mean_a);
+  const bool by_wave = !staged;  // (more than 128 dimensions: a wavefront two pairs, exact_pair_wave2)
+  const int lane_ = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+  auto exact_of = [&](uint32_t i) -> double {  // thread a pair
+    return na ? exact_pair_adiv<KIND>(a + (uint64_t)i * n_dims, na[i], qb, qm, n_dims, p) : exact_pair<KIND>(a + (uint64_t)i * n_dims, qb, qm, n_dims, p);
+  };
+  // a wavefront two pairs, e and e + 16 of a band's list (every lane gets both values; a second one past the list's end: the first again)
+  auto exact_wave2_of = [&](const uint32_t *idx, uint32_t e, uint32_t n, double *d0, double *d1) {
+    const uint32_t i0 = idx[e], i1 = idx[e + 16u < n ? e + 16u : e];
+    exact_pair_wave2<KIND>(a + (uint64_t)i0 * n_dims, na ? na[i0] : 0.0, a + (uint64_t)i1 * n_dims, na ? na[i1] : 0.0, qb, qm, n_dims, p, lane_, d0, d1);
+  };
+  if (by_wave) {
+    for (uint32_t e = (uint32_t)wv_; e < n_nb; e += 32) {
+      double dx[2];
+      exact_wave2_of(s_nb_i, e, n_nb, &dx[0], &dx[1]);
+      if (lane_ == 0)
+        for (uint32_t t = 0; t < 2u && e + 16u * t < n_nb; ++t) {
+          const double x = s_nb_x[e + 16u * t];
+          s_nb_d[e + 16u * t] = dx[t];
+          c1 += dx[t] - x;
+          c2 += (dx[t] - mean_a) * (dx[t] - mean_a) - (x - mean_a) * (x - mean_a);
+        }
+    }
+  } else {
+    for (uint32_t e = threadIdx.x; e < n_nb; e += 1024) {
+      const double dx = exact_of(s_nb_i[e]), x = s_nb_x[e];
+      s_nb_d[e] = dx;
+      c1 += dx - x;
+      c2 += (dx - mean_a) * (dx - mean_a) - (x - mean_a) * (x - mean_a);
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -808,9 +884,16 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
     s_corr[threadIdx.x >> 6][0] = c1;
     s_corr[threadIdx.x >> 6][1] = c2;
   }
-  for (uint32_t e = threadIdx.x; e < n_med; e += 1024)
-    s_med_d[e] = na ? exact_pair_adiv<KIND>(a + (uint64_t)s_med_i[e] * n_dims, na[s_med_i[e]], qb, qm, n_dims, p)
-                    : exact_pair<KIND>(a + (uint64_t)s_med_i[e] * n_dims, qb, qm, n_dims, p);
+  if (by_wave) {
+    for (uint32_t e = (uint32_t)wv_; e < n_med; e += 32) {
+      double dx[2];
+      exact_wave2_of(s_med_i, e, n_med, &dx[0], &dx[1]);
+      if (lane_ == 0)
+        for (uint32_t t = 0; t < 2u && e + 16u * t < n_med; ++t) s_med_d[e + 16u * t] = dx[t];
+    }
+  } else {
+    for (uint32_t e = threadIdx.x; e < n_med; e += 1024) s_med_d[e] = exact_of(s_med_i[e]);
+  }
   __syncthreads();
   // the median: the band's element of rank r_med - n_lt (ranks by counting: the bands are small)
   for (uint32_t e = threadIdx.x; e < n_med; e += 1024) {
@@ -840,10 +923,16 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
     return;
   }
   // the MAD: exact deviations of its band from the exact median, the element of rank r_med - n_in
-  for (uint32_t e = threadIdx.x; e < n_mad; e += 1024)
-    s_mad_d[e] = fabs(__dsub_rn(na ? exact_pair_adiv<KIND>(a + (uint64_t)s_mad_i[e] * n_dims, na[s_mad_i[e]], qb, qm, n_dims, p)
-                                   : exact_pair<KIND>(a + (uint64_t)s_mad_i[e] * n_dims, qb, qm, n_dims, p),
-                                median));
+  if (by_wave) {
+    for (uint32_t e = (uint32_t)wv_; e < n_mad; e += 32) {
+      double dx[2];
+      exact_wave2_of(s_mad_i, e, n_mad, &dx[0], &dx[1]);
+      if (lane_ == 0)
+        for (uint32_t t = 0; t < 2u && e + 16u * t < n_mad; ++t) s_mad_d[e + 16u * t] = fabs(__dsub_rn(dx[t], median));
+    }
+  } else {
+    for (uint32_t e = threadIdx.x; e < n_mad; e += 1024) s_mad_d[e] = fabs(__dsub_rn(exact_of(s_mad_i[e]), median));
+  }
   __syncthreads();
   for (uint32_t e = threadIdx.x; e < n_mad; e += 1024) {
     const double de = s_mad_d[e];
