@@ -679,7 +679,7 @@ def test_distance_summary_on_the_matrix_cores(kpop, oracle, case, kind, d):
 
 
 @pytest.mark.parametrize("case", ["random", "near_duplicates", "offset", "grid", "constant"])
-@pytest.mark.parametrize("kind,r1,r2,d", [(0, 1636, 2000, 1635), (1, 1636, 1700, 1635), (0, 3000, 8000, 200), (1, 300, 60000, 256)])
+@pytest.mark.parametrize("kind,r1,r2,d", [(0, 1636, 2000, 1635), (1, 1636, 1700, 1635), (0, 3000, 8000, 200), (1, 300, 60000, 256), (0, 6000, 4000, 200)])
 def test_distance_rowwise_on_the_matrix_cores(kpop, oracle, case, kind, r1, r2, d):
     """kpop_dev_distance_rowwise of 2^32 products and more (the reference's own job: 650 K samples x 1,636 classes x 1,635 dimensions,
     README.md:1054-1060; lib/Matrix.ml:191-266) as a tiled contraction on the f64 matrix cores: every distance within 1e-12 of the
