@@ -4,7 +4,7 @@
 set -u
 cd "$(dirname "$0")/.." || exit 1
 SECS=${1:-60}
-OUT=profiles/r05_host_sanitizers.txt
+OUT=${KPOP_SANITIZE_OUT:-profiles/r05_host_sanitizers.txt}
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 {
   echo "host boundary under g++ -fsanitize=address,undefined (make -C kpop_amd/host asan), $(date -u +%Y-%m-%dT%H:%MZ), $(g++ --version | head -1)"
