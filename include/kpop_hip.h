@@ -111,6 +111,9 @@ int kpop_synchronize(void *stream);
    "summary_mfma_lists" 1 (default) | 0: that refinement reads the candidate lists the summary's one pass left, or scans the rows;
    "summary_lanes" 1 (default) | 2: 512 query rows and more of such a summary in batches of 256 on two streams (measured level);
    "summary_audit" 0 (default) | 1: count the rows left to the exact fall-back (kpop_debug_summary_fallbacks);
+   "summary_sample" 1 (default) | 0: such a summary's brackets and bands from the query rows' distances to a sample of the REFERENCE ROWS at even
+   spacing (a small contraction of its own; whatever the layout of the database), or from 64 runs of 1,024 consecutive elements of the distance
+   rows (a database laid out lineage by lineage makes those runs speak for a few lineages: the brackets miss, the rows take the slow kernel);
    "summary_rawref" 1 (default) | 0: such a summary takes its reference set as it is (no normalised copy of it is made: the norms' pass keeps the
    rows' sums of squares, dot products are scaled where they come out, the exact chains divide as they go -- the same bits), or makes the copy;
    "summary_pass" 1 (default) | 0: the pass over such a summary's approximate rows written for rows the library made itself, or the general one;
@@ -134,7 +137,8 @@ int kpop_tune(const char *key, int value);
    flops each; bench.py's MFMA roofline); read and cleared; synchronises the device */
 int kpop_debug_counters(uint64_t *out, int n);
 /* development: under kpop_tune("summary_audit", 1) the large-reference summaries (kpop_dev_distance_summary against 65,536 rows and
-   more) count the query rows they leave to their exact fall-back -- rows whose brackets missed or whose certificates failed; the
+   more) count the query rows they leave to a fall-back -- rows whose sample-based brackets missed (the ten-pass kernel) or whose
+   certificates failed (exact distance rows); the
    results are the same either way, the fall-back costs milliseconds.  Read and cleared.                                         */
 int kpop_debug_summary_fallbacks(uint64_t *rows);
 

@@ -131,6 +131,7 @@ struct Context {
   int tune_distance_mfma = 1; // kpop_dev_distance_rowwise of 2^32 products and more (rows x rows x dimensions), euclidean / cosine: the contraction on the f64 matrix cores, pairs that cancel recomputed with the reference's chain (<= 1e-12 relative, not bit for bit); 0: the vector-pipe chain for every pair (the reference's bits)
   int tune_summary_mfma = 1; // (1, the default: approximate rows, then the summary's pass over them; 2: up to 128 dimensions the pass runs INSIDE the contraction and no approximate row is written -- same results, measured SLOWER: 256 x 1M x 64 2.9-3.2 against 2.7-2.8 ms, the classification's ~50 vector operations a pair serialise with the matrix pipe on a SIMD: profiles/r06_summary_select.txt) summaries against >= 65,536 rows, euclidean / cosine: the distances as f64 MFMAs + exact refinement (distance_mfma.hip); 0: the vector-pipe chain for every pair
   int tune_summary_lanes = 1; // 2: the matrix-core summary of 512 query rows and more in batches of 256 rows on TWO streams (the caller's and one of the library's), a batch's one-block-a-row kernels meant to run under the next batch's contraction and pass.  Measured level (1,024 x 1M x 64: 8.68 against 8.63 ms): a block of 1,024 threads and 100 KB of LDS does not get onto a CU while the other chain's grid holds it, the chains take turns anyway (profiles/r06_summary_lanes.txt).  Same results either way
+  int tune_summary_sample = 1;  // the matrix-core summary's brackets and bands: 1 from the query rows' distances to a sample of the REFERENCE ROWS at even spacing (a small contraction of its own: whatever the layout of the database), 0 from 64 runs of 1,024 consecutive elements of the distance rows (a database laid out lineage by lineage makes those runs speak for a few lineages only: the brackets miss)
   int tune_summary_rawref = 1;  // the matrix-core summary takes the reference set as it is (norms and sums of squares from one pass, a dot product scaled where it comes out, the exact chains dividing as they go): no normalised copy of it; 0: the copy, as before
   int tune_summary_pass = 1;  // the matrix-core summary's pass over its approximate rows: 1 the pass for rows the library made (doubles against thresholds, a turn's candidates appended with one atomic a wavefront), 0 the general pass (keys, an append an element)
   int tune_summary_audit = 0;  // 1: count the rows the large-reference summaries leave to their exact fall-back (kpop_debug_summary_fallbacks reads and clears)

@@ -1331,7 +1331,8 @@ static int rowwise_impl(const double *m1, uint32_t r1, const double *m2, uint32_
 // summary_large.hip
 int launch_summary_large(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most,
                          uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
-                         double *out_dist, double *out_z, hipStream_t st, void *scratch, SummaryLists *lists = nullptr, bool plain_rows = false);
+                         double *out_dist, double *out_z, hipStream_t st, void *scratch, SummaryLists *lists = nullptr, bool plain_rows = false,
+                         const double *srow = nullptr, uint32_t srow_n = 0);
 uint64_t summary_large_scratch_bytes(uint32_t n_rows, uint32_t r1);
 bool summary_fused_applies(uint32_t r1, uint32_t keep_at_most);
 uint32_t summary_fused_sample_rows(uint32_t r1);
@@ -1360,7 +1361,8 @@ int launch_summary_flagged_rows(const double *rows, uint32_t n_rows, uint32_t r1
 bool summary_select_mfma_applies(uint32_t r1, uint32_t keep_at_most);
 int launch_mfma_query_prep(const double *b, uint32_t q, uint32_t r1, uint32_t n_dims, const double *metric, void *scratch, uint32_t q_room, hipStream_t st);
 int launch_rows_mfma_against(int kind, const double *as, const double *sas, uint32_t s, uint32_t q, uint32_t n_dims, double *rows, void *scratch, uint32_t q_room,
-                             uint32_t r1, hipStream_t st);
+                             uint32_t r1, hipStream_t st, const double *ias = nullptr);
+int launch_mfma_sample_scalars(const void *scratch, uint32_t q_room, uint32_t r1, uint32_t n_dims, uint32_t s, double *sas, double *ias, hipStream_t st);
 int launch_row_sumsq(const double *x, uint32_t rows, uint32_t n_dims, const double *metric, double *out, hipStream_t st);
 int launch_summary_fused_mfma(int kind, const double *a, uint32_t r1, uint32_t n_rows, uint32_t n_dims, const double *srow, uint32_t s, uint32_t row0,
                               uint32_t keep_at_most, uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx, double *out_dist,
@@ -1432,9 +1434,13 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
       chunk = 256;
       const uint64_t row_bytes = ((uint64_t)chunk * r1 * 8 + 255) & ~255ull;
       const uint64_t sum_bytes = (summary_large_scratch_bytes(chunk, r1) + 511) & ~255ull, m_bytes = (summary_mfma_scratch_bytes(chunk, r1, n_dims) + 511) & ~255ull;
-      const uint64_t lane_bytes = row_bytes + sum_bytes + m_bytes + 256;
+      const bool row_sample2 = ctx().tune_summary_sample == 1;  // (the brackets from a sample of the reference rows: see the one-lane form below)
+      const uint32_t s_rows2 = row_sample2 ? (n_dims > 128 ? std::min(32768u, summary_fused_sample_rows(r1)) : summary_fused_sample_rows(r1)) : 0u;
+      const uint64_t srow2_bytes = ((uint64_t)chunk * s_rows2 * 8 + 255) & ~255ull, as2_bytes = ((uint64_t)s_rows2 * n_dims * 8 + 255) & ~255ull,
+                     sas2_bytes = ((uint64_t)s_rows2 * 8 + 255) & ~255ull;
+      const uint64_t lane_bytes = row_bytes + sum_bytes + m_bytes + srow2_bytes + 256;
       void *ws = nullptr;
-      KPOP_TRY(ctx().ws_for(st).ensure(2 * lane_bytes + 512, &ws));
+      KPOP_TRY(ctx().ws_for(st).ensure(2 * lane_bytes + as2_bytes + 2 * sas2_bytes + 512, &ws));
       Context::AuxLane *aux = nullptr;
       KPOP_TRY(ctx().aux_for(st, &aux));
       char *wp = reinterpret_cast<char *>(ws);
@@ -1442,13 +1448,21 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
         hipStream_t s;
         double *rows;
         void *scratch, *mscratch;
+        double *srow;
       } lane[2];
       for (int l = 0; l < 2; ++l) {
         char *base = wp + (uint64_t)l * lane_bytes;
-        lane[l] = Lane{l ? aux->stream : st, reinterpret_cast<double *>(base), base + row_bytes, base + row_bytes + sum_bytes};
+        lane[l] = Lane{l ? aux->stream : st, reinterpret_cast<double *>(base), base + row_bytes, base + row_bytes + sum_bytes,
+                       reinterpret_cast<double *>(base + row_bytes + sum_bytes + m_bytes)};
       }
+      double *a_s2 = reinterpret_cast<double *>(wp + 2 * lane_bytes), *sa_s2 = reinterpret_cast<double *>(wp + 2 * lane_bytes + as2_bytes),
+             *ia_s2 = na ? reinterpret_cast<double *>(wp + 2 * lane_bytes + as2_bytes + sas2_bytes) : nullptr;
       KPOP_TRY(launch_mfma_reference_norms(a, r1, n_dims, metric, lane[0].mscratch, chunk, st, na, s_raw));
       KPOP_TRY(launch_mfma_copy_reference_norms(lane[0].mscratch, lane[1].mscratch, r1, n_dims, chunk, st));
+      if (row_sample2) {
+        KPOP_TRY(launch_sample_gather(a, r1, n_dims, s_rows2, a_s2, st));
+        KPOP_TRY(launch_mfma_sample_scalars(lane[0].mscratch, chunk, r1, n_dims, s_rows2, sa_s2, ia_s2, st));
+      }
       KPOP_HIP(hipEventRecord(aux->fork, st));
       KPOP_HIP(hipStreamWaitEvent(aux->stream, aux->fork, 0));
       int rc = 0;
@@ -1464,10 +1478,13 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
           if (bi > 0) KPOP_HIP(hipStreamWaitEvent(L.s, aux->step[(bi - 1) & 1u], 0));  // this batch's contraction after the one before it
           KPOP_TRY(launch_distance_rows_mfma(KIND, a, r1, bq, q, n_dims, metric, L.rows, L.mscratch, chunk, L.s, na != nullptr));
           KPOP_HIP(hipEventRecord(aux->step[bi & 1u], L.s));
-          KPOP_TRY(launch_summary_large(L.rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, L.s, L.scratch, &lists, true));
+          if (row_sample2) KPOP_TRY(launch_rows_mfma_against(KIND, a_s2, sa_s2, s_rows2, q, n_dims, L.srow, L.mscratch, chunk, r1, L.s, ia_s2));
+          KPOP_TRY(launch_summary_large(L.rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, L.s, L.scratch, &lists, true,
+                                        row_sample2 ? L.srow : nullptr, s_rows2));
           KPOP_TRY(launch_summary_refine(KIND, L.rows, a, r1, bq, q, n_dims, metric, p, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z,
                                          L.mscratch, chunk, L.s, lists, &gate, &flags, na));
           KPOP_TRY(audit_fallback(gate, L.s));
+          KPOP_TRY(audit_fallback(lists.n_failed, L.s));
           KPOP_TRY(rowwise_block<KIND>(a, r1, bq, q, n_dims, metric, p, L.rows, L.s, na, nullptr, gate));  // (na: the kernel divides the reference rows as it stages them)
           KPOP_TRY(launch_summary_flagged_rows(L.rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, flags, L.s));
           return 0;
@@ -1481,12 +1498,17 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
       return 0;
     }
     void *ws = nullptr;
-    const uint32_t s_rows = select ? summary_fused_sample_rows(r1) : 0;
+    // the brackets and bands from the query rows' distances to a SAMPLE OF THE REFERENCE ROWS (even spacing), whatever the layout of the database
+    // (launch_summary_large); kpop_tune("summary_sample", 0): from runs of the distance rows, as until late in round 6
+    const bool row_sample = !select && ctx().tune_summary_sample == 1;
+    // (beyond 128 dimensions half the sample: its contraction is s / r1 of the main one -- a tenth for 650,000 rows -- while the candidates its
+    // wider brackets add, 12 -> 17 % of a row, cost little beside a contraction of 1,635 dimensions)
+    const uint32_t s_rows = select ? summary_fused_sample_rows(r1) : row_sample ? (n_dims > 128 ? std::min(32768u, summary_fused_sample_rows(r1)) : summary_fused_sample_rows(r1)) : 0;
     const uint64_t r1_seg = select ? (((uint64_t)r1 + 2047) & ~2047ull) : r1;  // (the select kernel's segments: a row rounded up to whole stripes of 2,048)
     const uint64_t row_bytes = ((uint64_t)chunk * r1_seg * 8 + 255) & ~255ull, segi_bytes = select ? (((uint64_t)chunk * r1_seg * 4 + 255) & ~255ull) : 0;
     const uint64_t sum_bytes = (std::max(summary_large_scratch_bytes(chunk, r1), select ? summary_select_scratch_bytes(chunk, r1) : 0) + 511) & ~255ull;
     const uint64_t m_bytes = (summary_mfma_scratch_bytes(chunk, r1, n_dims) + 511) & ~255ull;
-    const uint64_t as_bytes = ((uint64_t)s_rows * n_dims * 8 + 255) & ~255ull, sas_bytes = ((uint64_t)s_rows * 8 + 255) & ~255ull,
+    const uint64_t as_bytes = ((uint64_t)s_rows * n_dims * 8 + 255) & ~255ull, sas_bytes = 2 * (((uint64_t)s_rows * 8 + 255) & ~255ull),  // (sums of squares, reciprocals)
                    srow_bytes = ((uint64_t)chunk * s_rows * 8 + 255) & ~255ull;
     KPOP_TRY(ctx().ws_for(st).ensure(row_bytes + segi_bytes + sum_bytes + m_bytes + as_bytes + sas_bytes + srow_bytes + 512, &ws));
     char *wp = reinterpret_cast<char *>(ws);
@@ -1497,6 +1519,12 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
     double *sa_s = reinterpret_cast<double *>(wp + row_bytes + segi_bytes + sum_bytes + m_bytes + as_bytes);
     double *srow = reinterpret_cast<double *>(wp + row_bytes + segi_bytes + sum_bytes + m_bytes + as_bytes + sas_bytes);
     KPOP_TRY(launch_mfma_reference_norms(a, r1, n_dims, metric, mscratch, chunk, st, na, s_raw));
+    double *ia_s = nullptr;
+    if (row_sample) {  // the sample of the reference rows, its sums of squares and (the set taken as it is) its norms' reciprocals: once a call
+      KPOP_TRY(launch_sample_gather(a, r1, n_dims, s_rows, a_s, st));
+      if (na) ia_s = sa_s + (sas_bytes / 16);
+      KPOP_TRY(launch_mfma_sample_scalars(mscratch, chunk, r1, n_dims, s_rows, sa_s, ia_s, st));
+    }
     if (select) {  // the sample of the reference rows and its norms: once a call
       KPOP_TRY(launch_sample_gather(a, r1, n_dims, s_rows, a_s, st));
       KPOP_TRY(launch_row_sumsq(a_s, s_rows, n_dims, metric, sa_s, st));
@@ -1517,10 +1545,13 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
         KPOP_TRY(audit_fallback(gate, st));
       } else {
         KPOP_TRY(launch_distance_rows_mfma(KIND, a, r1, bq, q, n_dims, metric, rows, mscratch, chunk, st, na != nullptr));
-        KPOP_TRY(launch_summary_large(rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st, scratch, &lists, true));
+        if (row_sample) KPOP_TRY(launch_rows_mfma_against(KIND, a_s, sa_s, s_rows, q, n_dims, srow, mscratch, chunk, r1, st, ia_s));  // (the chunk's query rows are prepared: the call above)
+        KPOP_TRY(launch_summary_large(rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, st, scratch, &lists, true,
+                                      row_sample ? srow : nullptr, s_rows));
         KPOP_TRY(launch_summary_refine(KIND, rows, a, r1, bq, q, n_dims, metric, p, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist,
                                        out_z, mscratch, chunk, st, lists, &gate, &flags, na));
         KPOP_TRY(audit_fallback(gate, st));
+        KPOP_TRY(audit_fallback(lists.n_failed, st));  // (rows whose sample-based brackets missed: the ten-pass kernel's)
       }
       KPOP_TRY(rowwise_block<KIND>(a, r1, bq, q, n_dims, metric, p, rows, st, na, nullptr, gate));  // (na: the kernel divides the reference rows as it stages them)
       KPOP_TRY(launch_summary_flagged_rows(rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist, out_z, flags, st));

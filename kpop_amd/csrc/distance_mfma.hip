@@ -1237,8 +1237,22 @@ int launch_mfma_query_prep(const double *b, uint32_t q, uint32_t r1, uint32_t n_
 }
 // approximate distance rows of the prepared query rows against ANOTHER set of rows (the sample of the reference set: `as`, its norms `sas`)
 int launch_rows_mfma_against(int kind, const double *as, const double *sas, uint32_t s, uint32_t q, uint32_t n_dims, double *rows, void *scratch, uint32_t q_room,
-                             uint32_t r1, hipStream_t st) {
+                             uint32_t r1, hipStream_t st, const double *ias) {
+  // (ias: the sample's rows come as they are, still to be divided by their norms -- sas the sums of squares of the rows as they will be, ias the
+  // norms' reciprocals; nullptr: the rows are what they are)
   MfmaScratch M = carve_mfma(scratch, q_room, r1, n_dims);
+  if (n_dims > 128) {  // the tiled contraction
+    const uint32_t tiles_m = div_up(q, (uint32_t)kDT), tiles_n = div_up(s, (uint32_t)kDT);
+    KPOP_TRY(distance_gemm_lds_attr());
+    if (kind == KPOP_EUCLIDEAN)
+      distance_gemm_mfma_kernel<KPOP_EUCLIDEAN, false><<<dim3(tiles_m * tiles_n), dim3(256), kDgLds, st>>>(as, s, M.bm, nullptr, q, n_dims, nullptr, 2.0, sas, M.sb, rows, tiles_m, tiles_n,
+                                                                                                          tiles_m <= 16 ? 1 : 0, 0.0, nullptr, nullptr, nullptr, ias, nullptr);
+    else
+      distance_gemm_mfma_kernel<KPOP_COSINE, false><<<dim3(tiles_m * tiles_n), dim3(256), kDgLds, st>>>(as, s, M.bm, nullptr, q, n_dims, nullptr, 2.0, sas, M.sb, rows, tiles_m, tiles_n,
+                                                                                                       tiles_m <= 16 ? 1 : 0, 0.0, nullptr, nullptr, nullptr, ias, nullptr);
+    KPOP_LAUNCH_CHECK();
+    return 0;
+  }
   const uint32_t n_tiles = div_up(s, 16);
   const bool small = n_dims <= 64;
   const uint32_t rows_per_block = small ? 128u : 256u, ny = div_up(q, rows_per_block);
@@ -1248,11 +1262,27 @@ int launch_rows_mfma_against(int kind, const double *as, const double *sas, uint
   const dim3 grid(div_up(n_tiles, tpb), ny);
 #define KPOP_ROWS(K) \
   do { \
-    if (small) distance_rows_mfma_kernel<K, 16, 2><<<grid, dim3(256), 0, st>>>(as, s, M.bm, q, n_dims, sas, M.sb, rows, tpb); \
-    else distance_rows_mfma_kernel<K, 32, 4><<<grid, dim3(256), 0, st>>>(as, s, M.bm, q, n_dims, sas, M.sb, rows, tpb); \
+    if (small) distance_rows_mfma_kernel<K, 16, 2><<<grid, dim3(256), 0, st>>>(as, s, M.bm, q, n_dims, sas, M.sb, rows, tpb, ias); \
+    else distance_rows_mfma_kernel<K, 32, 4><<<grid, dim3(256), 0, st>>>(as, s, M.bm, q, n_dims, sas, M.sb, rows, tpb, ias); \
   } while (0)
   if (kind == KPOP_EUCLIDEAN) KPOP_ROWS(KPOP_EUCLIDEAN); else KPOP_ROWS(KPOP_COSINE);
 #undef KPOP_ROWS
+  KPOP_LAUNCH_CHECK();
+  return 0;
+}
+// the reference set's sums of squares (and, when it is taken as it is, its norms' reciprocals) of the SAMPLE of its rows -- rows
+// floor(i r1 / s), launch_sample_gather's -- out of the scratch launch_mfma_reference_norms filled
+__global__ __launch_bounds__(256) void gather_sample_scalars_kernel(const double *__restrict__ sa, const double *__restrict__ ia, uint32_t r1, uint32_t s,
+                                                                    double *__restrict__ sas, double *__restrict__ ias) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= s) return;
+  const uint64_t src = ((uint64_t)i * r1) / s;
+  sas[i] = sa[src];
+  if (ias) ias[i] = ia[src];
+}
+int launch_mfma_sample_scalars(const void *scratch, uint32_t q_room, uint32_t r1, uint32_t n_dims, uint32_t s, double *sas, double *ias, hipStream_t st) {
+  const MfmaScratch M = carve_mfma(const_cast<void *>(scratch), q_room, r1, n_dims);
+  gather_sample_scalars_kernel<<<dim3(div_up(s, 256u)), dim3(256), 0, st>>>(M.sa, M.ia, r1, s, sas, ias);
   KPOP_LAUNCH_CHECK();
   return 0;
 }

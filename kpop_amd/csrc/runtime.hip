@@ -226,6 +226,7 @@ extern "C" int kpop_tune(const char *key, int value) {
     else if (!strcmp(key, "summary_audit") && (value == 0 || value == 1)) c.tune_summary_audit = value;
     else if (!strcmp(key, "summary_pass") && (value == 0 || value == 1)) c.tune_summary_pass = value;
     else if (!strcmp(key, "summary_rawref") && (value == 0 || value == 1)) c.tune_summary_rawref = value;
+    else if (!strcmp(key, "summary_sample") && (value == 0 || value == 1)) c.tune_summary_sample = value;
     else if (!strcmp(key, "seg") && (value == 0 || (value >= 64 && value <= 16384 && value % 64 == 0))) c.tune_seg = value;
     else KPOP_FAIL(KPOP_ERR_INVALID, "kpop_tune: unknown knob or value %s=%d", key, value);
   }

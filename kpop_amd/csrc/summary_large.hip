@@ -1896,7 +1896,11 @@ uint64_t summary_large_scratch_bytes(uint32_t n_rows, uint32_t r1) {
 // rows (brackets and bands from a sample, certificate for the MAD); 3: two passes (the first version of round 3).
 int launch_summary_large(const double *rows, uint32_t n_rows, uint32_t r1, uint32_t row0, uint32_t keep_at_most,
                          uint32_t max_neighbours, double *out_stats, uint32_t *out_n, uint32_t *out_idx,
-                         double *out_dist, double *out_z, hipStream_t st, void *scratch, SummaryLists *lists, bool plain_rows) {
+                         double *out_dist, double *out_z, hipStream_t st, void *scratch, SummaryLists *lists, bool plain_rows, const double *srow, uint32_t srow_n) {
+  // (srow: [n_rows][srow_n] distances of the query rows to a SAMPLE OF THE REFERENCE ROWS at even spacing -- the brackets and bands come from
+  // them; nullptr: from runs of 1,024 consecutive elements of the distance rows themselves.  A database laid out lineage by lineage makes
+  // neighbouring elements of a distance row near-copies of each other: 64 runs then speak for 640 of 10,000 clusters, the brackets
+  // miss (126 + 176 of 512 rows on clusters of 100) and the rows go through the ten-pass kernel -- 8.1 ms where random rows take 2.3)
   if (lists) *lists = SummaryLists{};
   const uint32_t req_len = keep_at_most ? keep_at_most : r1;
   const bool by_brackets = scratch && ctx().tune_summary2 && req_len <= kLargeMaxNb && r1 >= 2 * kSlice;
@@ -1927,9 +1931,12 @@ int launch_summary_large(const double *rows, uint32_t n_rows, uint32_t r1, uint3
   p += ((uint64_t)n_rows * n_slices * 16 + 255) & ~255ull;
   uint32_t *cand_i = lists ? reinterpret_cast<uint32_t *>(p) : nullptr;
   if (ctx().tune_summary2 != 3) {
-    if (lists) *lists = SummaryLists{info, thr, cnt, cand, cand_i, cap, nb_idx, nb_d};
+    if (lists) *lists = SummaryLists{info, thr, cnt, cand, cand_i, cap, nb_idx, nb_d, n_failed};
     KPOP_HIP(hipMemsetAsync(n_failed, 0, 256, st));
-    fused_sample_kernel<true><<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, 0, r1, req_len, info, cnt, thr);
+    if (srow)
+      fused_sample_kernel<false><<<dim3(n_rows), dim3(kLT), 0, st>>>(srow, srow_n, r1, req_len, info, cnt, thr);
+    else
+      fused_sample_kernel<true><<<dim3(n_rows), dim3(kLT), 0, st>>>(rows, 0, r1, req_len, info, cnt, thr);
     KPOP_LAUNCH_CHECK();
     // (plain_rows: the caller made the rows itself -- distances >= +0.0 -- and they need no keys; kpop_tune("summary_pass", 0): the general pass anyway)
     if (plain_rows && ctx().tune_summary_pass)

@@ -41,6 +41,7 @@ struct SummaryLists {
   uint32_t cap = 0;
   const uint32_t *nb_idx = nullptr;  // [rows][kNbCap]: the columns and values at or below the neighbours' threshold
   const double *nb_d = nullptr;
+  const uint32_t *n_failed = nullptr;  // the device word that counts the rows whose brackets or bands missed (they went through the ten-pass kernel)
 };
 
 }  // namespace kpop

@@ -813,3 +813,46 @@ def test_distance_summary_on_the_matrix_cores_many_query_rows(kpop, oracle, kind
         assert got[2][j, :hi - lo].tolist() == idx_o[lo:hi].tolist() and np.array_equal(got[3][j, :hi - lo], dist_o[lo:hi])
         assert got[0][j, 2] == st_o[t, 2] and got[0][j, 3] == st_o[t, 3]
 
+
+
+@pytest.mark.parametrize("members,copies", [(100, 0.0), (500, 0.0)])
+def test_distance_summary_against_a_database_laid_out_lineage_by_lineage(kpop, oracle, members, copies):
+    """A reference set of clusters of near-identical rows, cluster after cluster (what a database of genomes sorted by lineage is): neighbouring
+    elements of a distance row are near-copies of each other.  The brackets come from the distances to a sample of the reference ROWS at
+    even spacing, so they hold whatever the layout: no row goes through a slow path (with runs of the distance rows as the sample,
+    kpop_tune("summary_sample", 0), most do -- asserted, so that the test keeps meaning something), and the results are those of the vector pipe"""
+    from kpop_amd import api
+    rng = np.random.RandomState(members)
+    d, r1, r2 = 32, 131072, 300
+    centres = rng.normal(size=((r1 + members - 1) // members, d))
+    m1 = np.repeat(centres, members, axis=0)[:r1] + 1e-3 * rng.normal(size=(r1, d))
+    m2 = m1[rng.randint(0, r1, size=r2)].copy() + 1e-4 * rng.normal(size=(r2, d))
+    metric = oracle.metric_powers(oracle.synth_inertia(d))
+    res, left = {}, {}
+    api.tune("summary_audit", 1)
+    api.summary_fallbacks()
+    for name, mfma, sample in (("rows", 1, 1), ("runs", 1, 0), ("vector", 0, 1)):
+        api.tune("summary_mfma", mfma)
+        api.tune("summary_sample", sample)
+        res[name] = kpop.distance_summary(m1, m2, metric, 0, 2.0, True, 20, max_neighbours=32)
+        left[name] = api.summary_fallbacks()
+    api.tune("summary_audit", 0)
+    api.tune("summary_mfma", 1)
+    api.tune("summary_sample", 1)
+    assert left["rows"] == 0, left
+    assert left["runs"] > r2 // 10, left  # (the failure this sample is there for)
+    for name in ("rows", "runs"):
+        got, ref = res[name], res["vector"]
+        assert np.array_equal(got[0][:, 2:], ref[0][:, 2:]), name
+        np.testing.assert_allclose(got[0][:, :2], ref[0][:, :2], rtol=1e-10)
+        assert np.array_equal(got[1], ref[1]), name
+        keep = np.arange(32)[None, :] < np.minimum(got[1], 32)[:, None]
+        assert np.array_equal(got[2][keep], ref[2][keep]) and np.array_equal(got[3][keep], ref[3][keep]), name
+    pick = [0, 1, 150, 299]
+    st_o, offs, idx_o, dist_o, z_o = oracle.distance_summary(m1, m2[pick], metric, 0, 2.0, True, 20)
+    for t, j in enumerate(pick):
+        lo, hi = int(offs[t]), int(offs[t + 1])
+        got = res["rows"]
+        assert got[1][j] == hi - lo
+        assert got[2][j, :hi - lo].tolist() == idx_o[lo:hi].tolist() and np.array_equal(got[3][j, :hi - lo], dist_o[lo:hi])
+        assert got[0][j, 2] == st_o[t, 2] and got[0][j, 3] == st_o[t, 3]

@@ -68,11 +68,19 @@ def main():
             continue
         r1, r2, d = (int(x) for x in case.split(":"))
         m1 = torch.randn(r1, d, dtype=torch.float64, device=dev, generator=g)
+        data = os.environ.get("R06_S_DATA", "random")
+        if data.startswith("clusters"):  # clusters:<members>:<noise>:<copies> -- a database of near-identical genomes (lineages), some of them exact copies
+            _, members, noise, copies = data.split(":")
+            members, noise, copies = int(members), float(noise), float(copies)
+            centres = torch.randn((r1 + members - 1) // members, d, dtype=torch.float64, device=dev, generator=g)
+            m1 = centres.repeat_interleave(members, dim=0)[:r1].clone()
+            keep = torch.rand(r1, device=dev, generator=g) < copies  # these stay exact copies of their centre
+            m1 += torch.where(keep[:, None], torch.zeros_like(m1), noise * torch.randn(r1, d, dtype=torch.float64, device=dev, generator=g))
         m2 = m1[torch.randperm(r1, device=dev)[:r2]].clone()
         metric = torch.rand(d, dtype=torch.float64, device=dev, generator=g) + 0.1
         metric /= metric.sum()
         work = torch.empty(api.dev_distance_workspace_bytes(r1, r2, d), dtype=torch.uint8, device=dev)
-        K = 304
+        K = int(os.environ.get("R06_S_K", "304"))
         stats = torch.zeros(r2, 4, dtype=torch.float64, device=dev)
         n = torch.zeros(r2, dtype=torch.int32, device=dev)
         idx = torch.zeros(r2, K, dtype=torch.int32, device=dev)
@@ -81,16 +89,22 @@ def main():
         keep = {}
         for mode in [int(x) for x in os.environ.get("R06_S_MODES", "1,0").split(",")]:  # 1: approximate rows then the summary's passes (default), 2: the pass inside the contraction (up to 128 dimensions), 0: vector pipe
             api.tune("summary_mfma", mode)
+            api.tune("summary_audit", 1)
+            api.summary_fallbacks()
             ms = timed(lambda: api.dev_distance_summary(m1.data_ptr(), r1, m2.data_ptr(), r2, d, metric.data_ptr(), work.data_ptr(), stats.data_ptr(), n.data_ptr(),
-                                                        idx.data_ptr(), dd.data_ptr(), z.data_ptr(), keep_at_most=300, max_neighbours=K, stream=st.cuda_stream), 3 if mode else 1)
+                                                        idx.data_ptr(), dd.data_ptr(), z.data_ptr(), keep_at_most=min(300, K - 4), max_neighbours=K, stream=st.cuda_stream), 3 if mode else 1)
+            left = api.summary_fallbacks()
+            api.tune("summary_audit", 0)
+            ms = timed(lambda: api.dev_distance_summary(m1.data_ptr(), r1, m2.data_ptr(), r2, d, metric.data_ptr(), work.data_ptr(), stats.data_ptr(), n.data_ptr(),
+                                                        idx.data_ptr(), dd.data_ptr(), z.data_ptr(), keep_at_most=min(300, K - 4), max_neighbours=K, stream=st.cuda_stream), 3 if mode else 1)
             keep[mode] = (ms, [x.cpu().numpy().copy() for x in (stats, n, idx, dd)])
-            print("      summary_mfma %d: %9.3f ms" % (mode, ms), flush=True)
+            print("      summary_mfma %d: %9.3f ms   (rows left to the exact fall-back, per call: %d of %d)" % (mode, ms, left // (4 if mode else 2), r2), flush=True)
         api.tune("summary_mfma", 1)
         m_on = max(keep)
         keep[1] = keep[m_on]
         a, b = keep[1][1], keep[min(keep)][1]
         fl = 2.0 * r1 * r2 * d
-        same = np.array_equal(a[0][:, 2:], b[0][:, 2:]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2][:, :300], b[2][:, :300]) and np.array_equal(a[3][:, :300], b[3][:, :300])
+        same = np.array_equal(a[0][:, 2:], b[0][:, 2:]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2][:, :min(300, K - 4)], b[2][:, :min(300, K - 4)]) and np.array_equal(a[3][:, :min(300, K - 4)], b[3][:, :min(300, K - 4)])
         print("-s  %d x %d x %d, 300 neighbours: matrix cores %9.3f ms = %.3f of %.1f TFLOP/s on the contraction's flops   vector pipe %9.3f ms (%.2fx)   medians, MADs, neighbours the same bits: %s"
               % (r2, r1, d, keep[1][0], fl / keep[1][0] / 1e9 / PEAK, PEAK, keep[min(keep)][0], keep[min(keep)][0] / keep[1][0], same), flush=True)
         del m1, m2, work

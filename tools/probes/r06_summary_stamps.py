@@ -8,6 +8,14 @@ dev = torch.device("cuda", 0); st = torch.cuda.current_stream()
 g = torch.Generator(device=dev); g.manual_seed(1)
 r1, r2, d = 1000000, 256, 64
 m1 = torch.randn(r1, d, dtype=torch.float64, device=dev, generator=g)
+data = os.environ.get("R06_S_DATA", "random")
+if data.startswith("clusters"):  # clusters:<members>:<noise>:<copies>, as tools/probes/r06_dist_dims.py
+    _, members, noise, copies = data.split(":")
+    members, noise, copies = int(members), float(noise), float(copies)
+    centres = torch.randn((r1 + members - 1) // members, d, dtype=torch.float64, device=dev, generator=g)
+    m1 = centres.repeat_interleave(members, dim=0)[:r1].clone()
+    keep = torch.rand(r1, device=dev, generator=g) < copies
+    m1 += torch.where(keep[:, None], torch.zeros_like(m1), noise * torch.randn(r1, d, dtype=torch.float64, device=dev, generator=g))
 m2 = m1[torch.randperm(r1, device=dev)[:r2]].clone()
 metric = torch.rand(d, dtype=torch.float64, device=dev, generator=g) + 0.1; metric /= metric.sum()
 work = torch.empty(api.dev_distance_workspace_bytes(r1, r2, d), dtype=torch.uint8, device=dev)
