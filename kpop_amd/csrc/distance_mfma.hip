@@ -838,7 +838,7 @@ __global__ __launch_bounds__(1024) void summary_refine_kernel(const double *__re
   };
   if (!ok) {  // (uniform)
 #ifdef KPOP_REFINE_WHY
-    if (threadIdx.x == 0) printf("row %u gives up: n_nb %u n_med %u n_lt %u n_mad %u n_in %u req_len %u r_med %u from_lists %d\n", j, n_nb, n_med, n_lt, n_mad, n_in, req_len, r_med, (int)from_lists);
+    if (threadIdx.x == 0) printf("row %u gives up: n_nb %u n_med %u n_lt %u n_mad %u n_in %u req_len %u r_med %u from_lists %d eff_a %u max_nb %u t_a %g med_a %g mad_a %g mean_a %g\n", j, n_nb, n_med, n_lt, n_mad, n_in, req_len, r_med, (int)from_lists, eff_a, max_neighbours, t_a, med_a, mad_a, mean_a);
 #endif
     give_up();
     return;
