@@ -1595,14 +1595,24 @@ static int summary_large_impl(const double *m1, uint32_t r1, const double *m2, u
   const uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(r2, budget / ((uint64_t)r1 * 8)));
   void *ws = nullptr;
   const uint64_t row_bytes = ((uint64_t)chunk * r1 * 8 + 255) & ~255ull;
-  KPOP_TRY(ctx().ws_for(st).ensure(row_bytes + summary_large_scratch_bytes(chunk, r1), &ws));
+  // (262,144 reference rows and more: the brackets and bands from the query rows' distances to a sample of the REFERENCE ROWS at even spacing,
+  // as in the matrix-core form above -- the same chain for every pair, a sixteenth of the distances again or less; runs of the distance rows
+  // speak for a few lineages of a database laid out lineage by lineage.  kpop_tune("summary_sample", 0): the runs)
+  const uint32_t s_rows = (ctx().tune_summary_sample == 1 && ctx().tune_summary2 == 1 && r1 >= 262144) ? summary_fused_sample_rows(r1) : 0;
+  const uint64_t as_bytes = ((uint64_t)s_rows * n_dims * 8 + 255) & ~255ull, srow_bytes = ((uint64_t)chunk * s_rows * 8 + 255) & ~255ull;
+  const uint64_t sum_bytes = (summary_large_scratch_bytes(chunk, r1) + 511) & ~255ull;
+  KPOP_TRY(ctx().ws_for(st).ensure(row_bytes + sum_bytes + as_bytes + srow_bytes + 256, &ws));
   double *rows = reinterpret_cast<double *>(ws);
   void *scratch = reinterpret_cast<char *>(ws) + row_bytes;
+  double *a_s = reinterpret_cast<double *>(reinterpret_cast<char *>(ws) + row_bytes + sum_bytes);
+  double *srow = reinterpret_cast<double *>(reinterpret_cast<char *>(ws) + row_bytes + sum_bytes + as_bytes);
+  if (s_rows) KPOP_TRY(launch_sample_gather(a, r1, n_dims, s_rows, a_s, st));
   for (uint32_t q0 = 0; q0 < r2; q0 += chunk) {
     const uint32_t q = std::min(chunk, r2 - q0);
     KPOP_TRY(rowwise_block<KIND>(a, r1, b + (uint64_t)q0 * n_dims, q, n_dims, metric, p, rows, st));
+    if (s_rows) KPOP_TRY(rowwise_block<KIND>(a_s, s_rows, b + (uint64_t)q0 * n_dims, q, n_dims, metric, p, srow, st));
     KPOP_TRY(launch_summary_large(rows, q, r1, q0, keep_at_most, max_neighbours, out_stats, out_n, out_idx, out_dist,
-                                  out_z, st, scratch));
+                                  out_z, st, scratch, nullptr, false, s_rows ? srow : nullptr, s_rows));
   }
   return 0;
 }
