@@ -815,15 +815,15 @@ def test_distance_summary_on_the_matrix_cores_many_query_rows(kpop, oracle, kind
 
 
 
-@pytest.mark.parametrize("members,copies", [(100, 0.0), (500, 0.0)])
-def test_distance_summary_against_a_database_laid_out_lineage_by_lineage(kpop, oracle, members, copies):
+@pytest.mark.parametrize("members,d", [(100, 32), (500, 32), (100, 136)])
+def test_distance_summary_against_a_database_laid_out_lineage_by_lineage(kpop, oracle, members, d):
     """A reference set of clusters of near-identical rows, cluster after cluster (what a database of genomes sorted by lineage is): neighbouring
     elements of a distance row are near-copies of each other.  The brackets come from the distances to a sample of the reference ROWS at
     even spacing, so they hold whatever the layout: no row goes through a slow path (with runs of the distance rows as the sample,
     kpop_tune("summary_sample", 0), most do -- asserted, so that the test keeps meaning something), and the results are those of the vector pipe"""
     from kpop_amd import api
-    rng = np.random.RandomState(members)
-    d, r1, r2 = 32, 131072, 300
+    rng = np.random.RandomState(members + d)
+    r1, r2 = 131072, 300
     centres = rng.normal(size=((r1 + members - 1) // members, d))
     m1 = np.repeat(centres, members, axis=0)[:r1] + 1e-3 * rng.normal(size=(r1, d))
     m2 = m1[rng.randint(0, r1, size=r2)].copy() + 1e-4 * rng.normal(size=(r2, d))
