@@ -465,8 +465,8 @@ class Rank:
                                           "frac": mfma_flops / ava / 1e12 / MFMA_F64_PEAK_TFLOPS if ava > 0 else None, "traffic": None,
                                           "algorithmic_flops_per_launch": mfma_flops, "avg_launch_ms": ava * 1e3,
                                           "note": "since round 5 the summary's distances are f64 MFMAs that locate; what is reported is recomputed with the reference's chain "
-                                                  "(csrc/distance_mfma.hip). The MFMA kernel is ~0.3 of the call and keeps the matrix pipes 0.62 busy (counter-measured: "
-                                                  "profiles/r05_mfma_distance.txt); the fraction here is the contraction's flops over the whole call"},
+                                                  "(csrc/distance_mfma.hip). The MFMA kernel is ~0.4 of the call (kernel by kernel: profiles/r06_summary_lanes.txt); "
+                                                  "the fraction here is the contraction's flops over the whole call"},
                              "seconds_is": "median of three warm calls", "first_call_seconds": ava_all[0],
                              "pairs_per_second": q_rank * self.world * n_total / ava if ava > 0 else None,
                              "every_query_finds_itself_at_distance_0": own_all,
@@ -742,6 +742,42 @@ def config3_distances_leg(R):
                                                "all_650k_query_rows_at_this_rate_s": 650000 / (q2 / (ms2 * 1e-3))}
     except Exception as e:
         res["distance_summary_4096_x_650k"] = {"skipped": "%r" % (e,)}
+    # ... and a database laid out lineage by lineage (what 650 K genomes sorted by lineage are: clusters of near-identical rows, cluster after
+    # cluster -- neighbouring entries of a distance row are near-copies of each other): the same call beside the same database shuffled.  The
+    # summary's brackets come from a sample of the reference ROWS, so the layout must not matter (it did until late in round 6: x 3.6)
+    try:
+        del db, work
+        t.cuda.empty_cache()
+        dl, r1l, ql, members = 64, 1000000, 256, 100
+        ml = t.rand(dl, dtype=t.float64, device=R.dev, generator=g) + 0.1
+        ml /= ml.sum()
+        centres = t.randn((r1l + members - 1) // members, dl, dtype=t.float64, device=R.dev, generator=g)
+        dbl = centres.repeat_interleave(members, dim=0)[:r1l].clone()
+        dbl += 1e-3 * t.randn(r1l, dl, dtype=t.float64, device=R.dev, generator=g)
+        perm = t.randperm(r1l, device=R.dev, generator=g)
+        ql_rows = dbl[perm[:ql]].clone()
+        dbs = dbl[perm].clone()  # the same rows, shuffled
+        workl = t.empty(api.dev_distance_workspace_bytes(r1l, ql, dl), dtype=t.uint8, device=R.dev)
+        stl, nl = t.zeros(ql, 4, dtype=t.float64, device=R.dev), t.zeros(ql, dtype=t.int32, device=R.dev)
+        il, dl_, zl = t.zeros(ql, K, dtype=t.int32, device=R.dev), t.zeros(ql, K, dtype=t.float64, device=R.dev), t.zeros(ql, K, dtype=t.float64, device=R.dev)
+        out_l = {}
+        for name, ref in (("sorted_by_lineage", dbl), ("shuffled", dbs)):
+            calll = lambda: api.dev_distance_summary(ref.data_ptr(), r1l, ql_rows.data_ptr(), ql, dl, ml.data_ptr(), workl.data_ptr(), stl.data_ptr(), nl.data_ptr(),
+                                                     il.data_ptr(), dl_.data_ptr(), zl.data_ptr(), keep_at_most=300, max_neighbours=K, stream=R.sp)
+            api.tune("summary_audit", 1)
+            api.summary_fallbacks()
+            msl, _ = _event_ms(R, calll, 3, 1)
+            left = api.summary_fallbacks() // 4
+            api.tune("summary_audit", 0)
+            msl, alll = _event_ms(R, calll, 3, 1)
+            out_l[name] = {"ms": msl, "ms_all": alll, "rows_through_a_slow_path_per_call": left, "medians": stl[:, 2].clone()}
+        same_medians = bool(t.equal(out_l["sorted_by_lineage"].pop("medians"), out_l["shuffled"].pop("medians")))
+        res["distance_summary_256_x_1M_lineages"] = {
+            "workload": "%d reference rows x %d dimensions in clusters of %d near-identical rows (noise 1e-3), %d query rows out of them, 300 neighbours" % (r1l, dl, members, ql),
+            "sorted_by_lineage": out_l["sorted_by_lineage"], "shuffled": out_l["shuffled"], "same_medians_either_layout": same_medians,
+            "note": "tests/test_gpu_distance.py::test_distance_summary_against_a_database_laid_out_lineage_by_lineage; profiles/r06_summary_lanes.txt 10."}
+    except Exception as e:
+        res["distance_summary_256_x_1M_lineages"] = {"skipped": "%r" % (e,)}
     return res
 
 
